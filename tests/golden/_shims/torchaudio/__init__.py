@@ -1,0 +1,2 @@
+"""Import-only stub so the reference module graph loads; never called on the ASR path."""
+from . import compliance  # noqa: F401,E402

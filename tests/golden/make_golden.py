@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/*.npz by running THE REFERENCE ITSELF
+(/root/reference, imported read-only through the no-op shims in tests/golden/_shims) on CPU/fp32.
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [case ...]
+
+What is pinned, per case (all produced by reference code paths, cited):
+  * feats      espnet2/asr/espnet_model.py:450-467 `_extract_feats` (Stft + LogMel)
+  * enc_out    espnet2/asr/espnet_model.py:380-448 `encode` (UtteranceMVN + ConformerEncoder)
+  * block outs ConformerEncoder.forward(return_all_hs=True) (conformer_encoder.py:377-384)
+  * ctc ids    espnet2/asr/ctc.py:207-215 `argmax`; G1 tokens = groupby + drop blank/sos/eos
+               (espnet2/bin/asr_inference.py:574-575)
+  * n-best     espnet2/bin/asr_inference.py:490-677 `Speech2Text.__call__` (BatchBeamSearch,
+               CTCPrefixScorer, TransformerDecoder, LengthBonus)
+
+Weights are the deterministic recipe of oracle/weights.py loaded into the reference model with
+`load_state_dict` (so fixtures carry only inputs' seeds and outputs); the key->shape table of the
+reference state_dict is stored too and the tests assert the replacement exposes the same table.
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+from itertools import groupby
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.dont_write_bytecode = True
+sys.path[:0] = [str(HERE / "_shims"), "/root/reference", str(REPO)]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+from oracle.weights import recipe_state_dict, synth_waveform, token_list  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+SMALL = dict(
+    encoder="conformer",
+    encoder_conf=dict(
+        output_size=256, attention_heads=4, linear_units=1024, num_blocks=12,
+        dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.1,
+        input_layer="conv2d", normalize_before=True, macaron_style=True,
+        rel_pos_type="latest", pos_enc_layer_type="rel_pos",
+        selfattention_layer_type="rel_selfattn", activation_type="swish",
+        use_cnn_module=True, cnn_module_kernel=31,
+    ),
+    decoder="transformer",
+    decoder_conf=dict(attention_heads=4, linear_units=2048, num_blocks=6, dropout_rate=0.1,
+                      positional_dropout_rate=0.1, self_attention_dropout_rate=0.1,
+                      src_attention_dropout_rate=0.1),
+    model_conf=dict(ctc_weight=0.3, lsm_weight=0.1, length_normalized_loss=False),
+    frontend_conf=dict(n_fft=512, win_length=400, hop_length=160),
+)
+LARGE = dict(
+    encoder="conformer",
+    encoder_conf=dict(
+        output_size=512, attention_heads=8, linear_units=2048, num_blocks=12,
+        dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.1,
+        input_layer="conv2d", normalize_before=True, macaron_style=True,
+        rel_pos_type="latest", pos_enc_layer_type="rel_pos",
+        selfattention_layer_type="rel_selfattn", activation_type="swish",
+        use_cnn_module=True, cnn_module_kernel=31,
+    ),
+    decoder="transformer",
+    decoder_conf=dict(attention_heads=8, linear_units=2048, num_blocks=6, dropout_rate=0.1,
+                      positional_dropout_rate=0.1, self_attention_dropout_rate=0.1,
+                      src_attention_dropout_rate=0.1),
+    model_conf=dict(ctc_weight=0.3, lsm_weight=0.1, length_normalized_loss=False),
+    frontend_conf=dict(n_fft=512, hop_length=160),
+)
+
+
+def tiny(d=64, heads=1, ff=128, blocks=2, dec_blocks=2, kernel=31):
+    c = json.loads(json.dumps(SMALL))
+    c["encoder_conf"].update(output_size=d, attention_heads=heads, linear_units=ff,
+                             num_blocks=blocks, cnn_module_kernel=kernel)
+    c["decoder_conf"].update(attention_heads=heads, linear_units=ff, num_blocks=dec_blocks)
+    return c
+
+
+def build_reference(conf, vocab, workdir, **s2t_kwargs):
+    from espnet2.bin.asr_inference import Speech2Text
+    from espnet2.tasks.asr import ASRTask
+
+    workdir = Path(workdir)
+    tok = workdir / "tokens.txt"
+    tok.write_text("\n".join(token_list(vocab)) + "\n")
+    cfg_in = workdir / "train.yaml"
+    cfg_in.write_text(yaml.safe_dump(conf))
+    ASRTask.main(cmd=["--dry_run", "true", "--output_dir", str(workdir / "asr"),
+                      "--token_list", str(tok), "--token_type", "word",
+                      "--config", str(cfg_in)])
+    cfg = workdir / "asr" / "config.yaml"
+    s2t = Speech2Text(asr_train_config=str(cfg), asr_model_file=None, device="cpu",
+                      dtype="float32", **s2t_kwargs)
+    return s2t, cfg.read_text()
+
+
+def load_recipe(model, seed):
+    sd = model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    new = recipe_state_dict(shapes, seed)
+    new["frontend.logmel.melmat"] = sd["frontend.logmel.melmat"].clone()
+    model.load_state_dict(new, strict=True)
+    model.eval()
+    return shapes
+
+
+def g1_tokens(ids, exclude):
+    return [int(x[0]) for x in groupby(ids) if int(x[0]) not in exclude]
+
+
+def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, with_blocks=False):
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as td:
+        s2t, cfg_text = build_reference(conf, vocab, td, beam_size=1, ctc_weight=1.0)
+    model = s2t.asr_model
+    shapes = load_recipe(model, wseed)
+    nmax = max(lengths)
+    speech = torch.zeros(len(utt_ids), nmax)
+    for i, (u, n) in enumerate(zip(utt_ids, lengths)):
+        speech[i, :n] = synth_waveform(u, n)
+    lens = torch.tensor(lengths, dtype=torch.long)
+    feats, flens = model._extract_feats(speech, lens)
+    feats_keep = feats.clone()
+    enc, olens = model.encode(speech, lens)
+    out = dict(
+        config_yaml=np.array(cfg_text), vocab=np.array(vocab), wseed=np.array(wseed),
+        utt_ids=np.array(utt_ids), lengths=np.array(lengths),
+        state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+        melmat=model.frontend.logmel.melmat.numpy(),
+        feats=feats_keep.numpy(), feats_lens=flens.numpy(),
+        enc_out=enc[:, ::keep_every].numpy().copy(), enc_keep_every=np.array(keep_every),
+        enc_olens=olens.numpy(),
+    )
+    if with_blocks:
+        nf, nl = model.normalize(feats_keep.clone(), flens)
+        from espnet2.legacy.nets.pytorch_backend.nets_utils import make_pad_mask
+        masks = (~make_pad_mask(nl)[:, None, :])
+        xs, masks2 = model.encoder.embed(nf, masks)
+        out["embed_x"] = xs[0].numpy().copy()
+        out["pos_emb"] = xs[1].numpy().copy()
+        blocks = []
+        for layer in model.encoder.encoders:
+            xs, masks2 = layer(xs, masks2)
+            blocks.append(xs[0].numpy().copy())
+        out["block_outs"] = np.stack(blocks)
+    logp = model.ctc.log_softmax(enc)
+    ids = model.ctc.argmax(enc)
+    out["ctc_ids"] = ids.numpy()
+    top2 = logp.topk(2, dim=-1).values
+    out["ctc_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    out["ctc_logp_head"] = logp[:, :4].numpy().copy()
+    excl = [model.blank_id, model.sos, model.eos]
+    toks = [g1_tokens(ids[b, : int(olens[b])].tolist(), excl) for b in range(len(utt_ids))]
+    out["g1_lens"] = np.array([len(t) for t in toks])
+    g1 = np.full((len(toks), max(1, max(len(t) for t in toks))), -1, dtype=np.int64)
+    for b, t in enumerate(toks):
+        g1[b, : len(t)] = t
+    out["g1_tokens"] = g1
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"[{name}] done in {time.time()-t0:.1f}s feats{tuple(feats.shape)} enc{tuple(enc.shape)} "
+          f"olens={olens.tolist()} g1_lens={out['g1_lens'].tolist()} "
+          f"min margin={out['ctc_margin'].min():.2e}")
+
+
+def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weight, nbest,
+                    keep_every=1):
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as td:
+        s2t, cfg_text = build_reference(conf, vocab, td, beam_size=beam, ctc_weight=ctc_weight,
+                                        nbest=nbest, penalty=0.0, lm_weight=0.0,
+                                        maxlenratio=0.0, minlenratio=0.0)
+    model = s2t.asr_model
+    shapes = load_recipe(model, wseed)
+    wav = synth_waveform(utt_id, n_samples)
+    enc, olens = model.encode(wav[None], torch.tensor([n_samples]))
+    t1 = time.time()
+    results = s2t(wav.numpy())
+    t_dec = time.time() - t1
+    L = max(len(h.yseq) for _, _, _, h in results)
+    yseq = np.full((len(results), L), -1, dtype=np.int64)
+    for i, (_, _, _, h) in enumerate(results):
+        yseq[i, : len(h.yseq)] = h.yseq.numpy()
+    keys = sorted(results[0][3].scores.keys())
+    out = dict(
+        config_yaml=np.array(cfg_text), vocab=np.array(vocab), wseed=np.array(wseed),
+        utt_id=np.array(utt_id), n_samples=np.array(n_samples), beam=np.array(beam),
+        ctc_weight=np.array(ctc_weight), nbest=np.array(nbest),
+        state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+        melmat=model.frontend.logmel.melmat.numpy(),
+        enc_out=enc[0, ::keep_every].numpy().copy(), enc_keep_every=np.array(keep_every),
+        yseq=yseq, yseq_lens=np.array([len(h.yseq) for _, _, _, h in results]),
+        score=np.array([float(h.score) for _, _, _, h in results]),
+        score_keys=np.array(json.dumps(keys)),
+        scores=np.array([[float(h.scores[k]) for k in keys] for _, _, _, h in results]),
+        token_int_best=np.array(results[0][2], dtype=np.int64),
+        ref_seconds=np.array(t_dec),
+    )
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"[{name}] done in {time.time()-t0:.1f}s (Speech2Text {t_dec:.1f}s) T={enc.shape[1]} "
+          f"best len={len(results[0][3].yseq)} score={float(results[0][3].score):.4f} keys={keys}")
+
+
+CASES = {
+    # config 0/1 of BASELINE.json: Conformer-small, one 10 s utterance
+    "small_10s": lambda: run_encode_case("small_10s", SMALL, 5000, 11, [0], [160000], keep_every=4),
+    # ragged batch (padding quirks: zero-padded STFT tail, MVN over valid frames, unmasked conv)
+    "small_ragged": lambda: run_encode_case("small_ragged", SMALL, 5000, 11, [1, 2, 3],
+                                            [48000, 37123, 16000]),
+    # tiny model with every block output pinned (oracle block-by-block check)
+    "tiny_blocks": lambda: run_encode_case("tiny_blocks", tiny(), 50, 7, [4, 5], [16000, 9000],
+                                           with_blocks=True),
+    # large model encoder, 10 s
+    "large_10s": lambda: run_encode_case("large_10s", LARGE, 5000, 13, [6], [160000], keep_every=8),
+    # G2: width-1 CTC prefix search (decode_ctc_bs1.yaml), short audio
+    "small_g2_3s": lambda: run_search_case("small_g2_3s", SMALL, 5000, 11, 7, 48000, 1, 1.0, 1,
+                                           keep_every=2),
+    # config 2/3: joint CTC/attention beam 10, ctc 0.3 (3 s and 10 s)
+    "large_beam10_3s": lambda: run_search_case("large_beam10_3s", LARGE, 5000, 13, 8, 48000, 10,
+                                               0.3, 10, keep_every=2),
+    "large_beam10_10s": lambda: run_search_case("large_beam10_10s", LARGE, 5000, 13, 9, 160000,
+                                                10, 0.3, 10, keep_every=8),
+    # tiny joint search (fast unit-level fixture for the search restatement)
+    "tiny_beam5": lambda: run_search_case("tiny_beam5", tiny(d=64, heads=2, ff=128), 50, 7, 10,
+                                          24000, 5, 0.3, 5),
+    "tiny_beam3_attn_only": lambda: run_search_case("tiny_beam3_attn_only",
+                                                    tiny(d=64, heads=2, ff=128), 50, 7, 11,
+                                                    16000, 3, 0.0, 3),
+}
+
+if __name__ == "__main__":
+    torch.set_num_threads(os.cpu_count() or 1)
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        CASES[n]()
