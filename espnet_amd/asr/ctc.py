@@ -1,0 +1,96 @@
+"""CTC head on the MI355X.  Mirrors espnet2/asr/ctc.py:9-215 for inference (`ctc_lo`,
+`softmax`/`log_softmax`/`argmax`); state-dict keys `ctc_lo.{weight,bias}`.  The loss is training
+only and out of scope."""
+import torch
+
+from espnet_amd import lib as L
+
+
+class CTC(torch.nn.Module):
+    def __init__(self, odim: int, encoder_output_size: int, dropout_rate: float = 0.0,
+                 ctc_type: str = "builtin", reduce: bool = True, ignore_nan_grad: bool = None,
+                 zero_infinity: bool = True, brctc_risk_strategy: str = "exp",
+                 brctc_group_strategy: str = "end", brctc_risk_factor: float = 0.0,
+                 compute_dtype: str = "bfloat16"):
+        super().__init__()
+        self.odim, self.eprojs = odim, encoder_output_size
+        self.dropout_rate = dropout_rate
+        self.ctc_lo = torch.nn.Linear(encoder_output_size, odim)  # parameter container
+        self.ctc_type = ctc_type
+        self.compute_dtype = compute_dtype
+        self._packed = None
+
+    @property
+    def em_dtype(self):
+        return L.DTYPES[self.compute_dtype]
+
+    @property
+    def act_dtype(self):
+        return torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32
+
+    def invalidate(self):
+        self._packed = None
+
+    def _pack(self, device):
+        p = self._packed
+        if p is None or p["device"] != device or p["dtype"] != self.em_dtype:
+            p = dict(w=self.ctc_lo.weight.detach().float().contiguous().to(self.act_dtype).to(device),
+                     b=self.ctc_lo.bias.detach().float().contiguous().to(device), device=device,
+                     dtype=self.em_dtype)
+            self._packed = p
+        return p
+
+    def _to_act(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        L.require_gpu(hs_pad, "hs_pad")
+        if hs_pad.dtype == self.act_dtype:
+            return hs_pad.contiguous()
+        src = hs_pad.to(torch.float32).contiguous()
+        dst = torch.empty(src.shape, dtype=self.act_dtype, device=src.device)
+        L.check(L.load().em_cast_f32(self.em_dtype, L.ptr(src), src.numel(), L.ptr(dst),
+                                     L.current_stream_ptr()), "em_cast_f32")
+        return dst
+
+    def logits_device(self, enc_act: torch.Tensor) -> torch.Tensor:
+        """enc_act (B,T,d) in the compute dtype -> logits (B,T,V) f32."""
+        p = self._pack(enc_act.device)
+        B, T, d = enc_act.shape
+        out = torch.empty(B, T, self.odim, dtype=torch.float32, device=enc_act.device)
+        a = L.EmGemmArgs(A=enc_act.data_ptr(), W=p["w"].data_ptr(), C=out.data_ptr(),
+                         bias=p["b"].data_ptr(), M=B * T, N=self.odim, K=d, lda=d, ldc=self.odim,
+                         scale=1.0)
+        L.check(L.load().em_gemm(self.em_dtype, L.EM_EPI_STORE_F32, L.EM_A_PLAIN, a,
+                                 L.current_stream_ptr()), "em_gemm(ctc_lo)")
+        return out
+
+    def log_softmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        """asr/ctc.py:197-205."""
+        logits = self.logits_device(self._to_act(hs_pad))
+        B, T, V = logits.shape
+        L.check(L.load().em_log_softmax_rows_f32(L.ptr(logits), B * T, V, L.current_stream_ptr()),
+                "em_log_softmax_rows_f32")
+        return logits
+
+    def argmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        """asr/ctc.py:207-215.  Returns (B, T) int64 like the reference."""
+        logits = self.logits_device(self._to_act(hs_pad))
+        B, T, V = logits.shape
+        ids = torch.empty(B, T, dtype=torch.int32, device=logits.device)
+        L.check(L.load().em_argmax_rows_f32(L.ptr(logits), B * T, V, L.ptr(ids),
+                                            L.current_stream_ptr()), "em_argmax_rows_f32")
+        return ids.to(torch.int64)
+
+    def greedy_device(self, enc_act: torch.Tensor, olens_dev: torch.Tensor, blank: int, sos_eos: int):
+        """Fused G1 path (bin/asr_inference.py:574-575): returns (ids (B,T) i32, tokens (B,T) i32
+        padded with -1, token_lens (B,) i32), all on the device, no host sync."""
+        p = self._pack(enc_act.device)
+        B, T, d = enc_act.shape
+        dev = enc_act.device
+        logits = torch.empty(B * T, self.odim, dtype=torch.float32, device=dev)
+        ids = torch.empty(B, T, dtype=torch.int32, device=dev)
+        tokens = torch.empty(B, T, dtype=torch.int32, device=dev)
+        tlens = torch.empty(B, dtype=torch.int32, device=dev)
+        L.check(L.load().em_ctc_greedy(self.em_dtype, L.ptr(enc_act), L.ptr(p["w"]), L.ptr(p["b"]),
+                                       B, T, d, self.odim, L.ptr(olens_dev), blank, sos_eos,
+                                       L.ptr(logits), L.ptr(ids), L.ptr(tokens), L.ptr(tlens),
+                                       L.current_stream_ptr()), "em_ctc_greedy")
+        return ids, tokens, tlens

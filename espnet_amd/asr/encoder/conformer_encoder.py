@@ -1,0 +1,300 @@
+"""ConformerEncoder on the MI355X: parameter tree + weight packing + one C-ABI call per batch.
+
+Mirrors espnet2/asr/encoder/conformer_encoder.py:53-429 (constructor keywords, `output_size()`,
+`forward(xs_pad, ilens, prev_states=None) -> (ys, olens, None)`) and exposes the SAME state-dict
+keys as the reference (`embed.conv.{0,2}`, `embed.out`, `encoders.N.{self_attn,feed_forward,
+feed_forward_macaron,conv_module,norm_*}`, `after_norm`), so reference checkpoints load unchanged.
+
+Only the BASELINE combination is accelerated (input_layer=conv2d, rel_pos / rel_selfattn with
+rel_pos_type=latest, macaron_style, use_cnn_module, normalize_before, swish, d_k = 64); any other
+combination raises NotImplementedError at construction (a maintainer integrating this class into
+the reference registry keeps the stock `conformer` entry for those).
+
+The torch.nn layers below are parameter CONTAINERS: their forward() is never called.  The
+arithmetic is csrc/{frontend,gemm,norm,attention,conv,encoder}.hip.
+"""
+import ctypes as C
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+from espnet_amd import lib as L
+from espnet_amd.nets_utils import conv2d_subsampled_lengths
+
+LN_EPS = 1e-12  # transformer/layer_norm.py:23
+
+
+class LayerNorm(torch.nn.LayerNorm):
+    def __init__(self, nout):
+        super().__init__(nout, eps=LN_EPS)
+
+
+class _Conv2dSubsampling(torch.nn.Module):
+    """Parameters of transformer/subsampling.py:386-409."""
+
+    def __init__(self, idim, odim):
+        super().__init__()
+        self.conv = torch.nn.Sequential(
+            torch.nn.Conv2d(1, odim, 3, 2), torch.nn.ReLU(),
+            torch.nn.Conv2d(odim, odim, 3, 2), torch.nn.ReLU())
+        self.out = torch.nn.Linear(odim * (((idim - 1) // 2 - 1) // 2), odim)
+
+
+class _RelPositionMultiHeadedAttention(torch.nn.Module):
+    """Parameters of transformer/attention.py:362-389 (+ MultiHeadedAttention :24-75)."""
+
+    def __init__(self, n_head, n_feat):
+        super().__init__()
+        self.d_k, self.h = n_feat // n_head, n_head
+        self.linear_q = torch.nn.Linear(n_feat, n_feat)
+        self.linear_k = torch.nn.Linear(n_feat, n_feat)
+        self.linear_v = torch.nn.Linear(n_feat, n_feat)
+        self.linear_out = torch.nn.Linear(n_feat, n_feat)
+        self.linear_pos = torch.nn.Linear(n_feat, n_feat, bias=False)
+        self.pos_bias_u = torch.nn.Parameter(torch.Tensor(self.h, self.d_k))
+        self.pos_bias_v = torch.nn.Parameter(torch.Tensor(self.h, self.d_k))
+        torch.nn.init.xavier_uniform_(self.pos_bias_u)
+        torch.nn.init.xavier_uniform_(self.pos_bias_v)
+
+
+class _PositionwiseFeedForward(torch.nn.Module):
+    def __init__(self, idim, hidden):
+        super().__init__()
+        self.w_1 = torch.nn.Linear(idim, hidden)
+        self.w_2 = torch.nn.Linear(hidden, idim)
+
+
+class _ConvolutionModule(torch.nn.Module):
+    """Parameters of conformer/convolution.py:22-54."""
+
+    def __init__(self, channels, kernel_size):
+        super().__init__()
+        assert (kernel_size - 1) % 2 == 0
+        self.pointwise_conv1 = torch.nn.Conv1d(channels, 2 * channels, 1)
+        self.depthwise_conv = torch.nn.Conv1d(channels, channels, kernel_size,
+                                              padding=(kernel_size - 1) // 2, groups=channels)
+        self.norm = torch.nn.BatchNorm1d(channels)
+        self.pointwise_conv2 = torch.nn.Conv1d(channels, channels, 1)
+
+
+class _EncoderLayer(torch.nn.Module):
+    """Parameters of conformer/encoder_layer.py:43-77."""
+
+    def __init__(self, size, heads, ff, kernel):
+        super().__init__()
+        self.self_attn = _RelPositionMultiHeadedAttention(heads, size)
+        self.feed_forward = _PositionwiseFeedForward(size, ff)
+        self.feed_forward_macaron = _PositionwiseFeedForward(size, ff)
+        self.conv_module = _ConvolutionModule(size, kernel)
+        self.norm_ff = LayerNorm(size)
+        self.norm_mha = LayerNorm(size)
+        self.norm_ff_macaron = LayerNorm(size)
+        self.norm_conv = LayerNorm(size)
+        self.norm_final = LayerNorm(size)
+
+
+def rel_pos_table(T: int, d: int) -> torch.Tensor:
+    """RelPositionalEncoding rows for a length-T input (embedding.py:286-332): row k is the
+    sinusoid of relative position T-1-k.  Built on the host with the same fp32 torch ops the
+    reference uses (`extend_pe`), once per distinct T."""
+    pe_positive = torch.zeros(T, d)
+    pe_negative = torch.zeros(T, d)
+    position = torch.arange(0, T, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe_positive[:, 0::2] = torch.sin(position * div_term)
+    pe_positive[:, 1::2] = torch.cos(position * div_term)
+    pe_negative[:, 0::2] = torch.sin(-1 * position * div_term)
+    pe_negative[:, 1::2] = torch.cos(-1 * position * div_term)
+    return torch.cat([torch.flip(pe_positive, [0]), pe_negative[1:]], dim=0)
+
+
+class ConformerEncoder(torch.nn.Module):
+    def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4,
+                 linear_units: int = 2048, num_blocks: int = 6, dropout_rate: float = 0.1,
+                 positional_dropout_rate: float = 0.1, attention_dropout_rate: float = 0.0,
+                 input_layer: Optional[str] = "conv2d", normalize_before: bool = True,
+                 concat_after: bool = False, positionwise_layer_type: str = "linear",
+                 positionwise_conv_kernel_size: int = 3, macaron_style: bool = False,
+                 rel_pos_type: str = "legacy", pos_enc_layer_type: str = "rel_pos",
+                 selfattention_layer_type: str = "rel_selfattn", activation_type: str = "swish",
+                 use_cnn_module: bool = True, zero_triu: bool = False, cnn_module_kernel: int = 31,
+                 padding_idx: int = -1, interctc_layer_idx: List[int] = [],
+                 interctc_use_conditioning: bool = False, ctc_trim: bool = False,
+                 stochastic_depth_rate=0.0, layer_drop_rate: float = 0.0,
+                 max_pos_emb_len: int = 5000, qk_norm: bool = False, use_flash_attn: bool = True,
+                 compute_dtype: str = "bfloat16"):
+        super().__init__()
+        bad = []
+        if input_layer != "conv2d": bad.append(f"input_layer={input_layer}")
+        if not normalize_before: bad.append("normalize_before=False")
+        if concat_after: bad.append("concat_after=True")
+        if positionwise_layer_type != "linear": bad.append(f"positionwise_layer_type={positionwise_layer_type}")
+        if not macaron_style: bad.append("macaron_style=False")
+        if rel_pos_type != "latest": bad.append(f"rel_pos_type={rel_pos_type}")
+        if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
+        if selfattention_layer_type != "rel_selfattn": bad.append(f"selfattention_layer_type={selfattention_layer_type}")
+        if activation_type != "swish": bad.append(f"activation_type={activation_type}")
+        if not use_cnn_module: bad.append("use_cnn_module=False")
+        if zero_triu: bad.append("zero_triu=True")
+        if len(interctc_layer_idx) > 0 or interctc_use_conditioning or ctc_trim: bad.append("interctc/ctc_trim")
+        if qk_norm: bad.append("qk_norm=True")
+        if output_size % 64 or output_size // attention_heads != 64: bad.append("d_k != 64")
+        if linear_units % 64: bad.append("linear_units % 64 != 0")
+        if cnn_module_kernel not in (3, 7, 15, 31): bad.append(f"cnn_module_kernel={cnn_module_kernel}")
+        if bad:
+            raise NotImplementedError("outside the MI355X Conformer fast path: " + ", ".join(bad))
+        self._output_size = output_size
+        self._input_size = input_size
+        self.heads, self.linear_units, self.num_blocks = attention_heads, linear_units, num_blocks
+        self.cnn_module_kernel = cnn_module_kernel
+        self.normalize_before = normalize_before
+        self.interctc_layer_idx = list(interctc_layer_idx)
+        self.interctc_use_conditioning = interctc_use_conditioning
+        self.compute_dtype = compute_dtype
+        self.embed = _Conv2dSubsampling(input_size, output_size)
+        self.encoders = torch.nn.ModuleList(
+            [_EncoderLayer(output_size, attention_heads, linear_units, cnn_module_kernel)
+             for _ in range(num_blocks)])
+        self.after_norm = LayerNorm(output_size)
+        self._packed = None
+        self._pos_cache = {}
+        self._ws = None
+
+    def output_size(self) -> int:
+        return self._output_size
+
+    # ------------------------------------------------------------------ packing (load time)
+    @property
+    def em_dtype(self) -> int:
+        return L.DTYPES[self.compute_dtype]
+
+    @property
+    def act_dtype(self) -> torch.dtype:
+        return torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32
+
+    def invalidate(self):
+        self._packed = None
+        self._pos_cache = {}
+
+    def pack(self, device):
+        """Repack the reference-layout parameters into the layouts the kernels consume (once)."""
+        dev = torch.device(device)
+        act = self.act_dtype
+        d, ff, Lb = self._output_size, self.linear_units, self.num_blocks
+        keep = []
+
+        def A(t):  # act-dtype matrix on the device
+            t = t.detach().to(torch.float32).contiguous().to(act).to(dev)
+            keep.append(t)
+            return t
+
+        def F(t):  # f32 vector/table on the device
+            t = t.detach().to(torch.float32).contiguous().to(dev)
+            keep.append(t)
+            return t
+
+        e = self.embed
+        F2 = e.out.in_features // d
+        w = L.EmConformerWeights()
+        w.d, w.heads, w.ff, w.num_blocks = d, self.heads, ff, Lb
+        w.kernel, w.n_mels = self.cnn_module_kernel, self._input_size
+        t = {}
+        t["conv1_w"] = F(e.conv[0].weight.reshape(d, 9))
+        t["conv1_b"] = F(e.conv[0].bias)
+        t["conv2_w"] = A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, 9 * d))
+        t["conv2_b"] = F(e.conv[2].bias)
+        t["embed_w"] = A(e.out.weight.reshape(d, d, F2).permute(0, 2, 1).reshape(d, F2 * d))
+        t["embed_b"] = F(e.out.bias)
+        t["wpos_all"] = A(torch.cat([l.self_attn.linear_pos.weight for l in self.encoders], dim=0))
+        t["after_norm_g"], t["after_norm_b"] = F(self.after_norm.weight), F(self.after_norm.bias)
+        for k, v in t.items():
+            setattr(w, k, v.data_ptr())
+        layers = (L.EmConformerLayer * Lb)()
+        glu_perm = torch.arange(2 * d).reshape(2, d // 16, 16).permute(1, 0, 2).reshape(-1)
+        for i, l in enumerate(self.encoders):
+            sa, cm = l.self_attn, l.conv_module
+            bn = cm.norm
+            scale = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
+            dw_w = cm.depthwise_conv.weight.double().reshape(d, -1) * scale[:, None]
+            dw_b = (cm.depthwise_conv.bias.double() - bn.running_mean.double()) * scale + bn.bias.double()
+            lt = dict(
+                norm_ff_mac_g=F(l.norm_ff_macaron.weight), norm_ff_mac_b=F(l.norm_ff_macaron.bias),
+                norm_mha_g=F(l.norm_mha.weight), norm_mha_b=F(l.norm_mha.bias),
+                norm_conv_g=F(l.norm_conv.weight), norm_conv_b=F(l.norm_conv.bias),
+                norm_ff_g=F(l.norm_ff.weight), norm_ff_b=F(l.norm_ff.bias),
+                norm_final_g=F(l.norm_final.weight), norm_final_b=F(l.norm_final.bias),
+                ffm_w1=A(l.feed_forward_macaron.w_1.weight), ffm_b1=F(l.feed_forward_macaron.w_1.bias),
+                ffm_w2=A(l.feed_forward_macaron.w_2.weight), ffm_b2=F(l.feed_forward_macaron.w_2.bias),
+                wqkv=A(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0)),
+                bqkv=F(torch.cat([sa.linear_q.bias, sa.linear_k.bias, sa.linear_v.bias], 0)),
+                pos_u=F(sa.pos_bias_u), pos_v=F(sa.pos_bias_v),
+                wout=A(sa.linear_out.weight), bout=F(sa.linear_out.bias),
+                pw1=A(cm.pointwise_conv1.weight.reshape(2 * d, d)[glu_perm]),
+                pw1_b=F(cm.pointwise_conv1.bias[glu_perm]),
+                dw_w=F(dw_w), dw_b=F(dw_b),
+                pw2=A(cm.pointwise_conv2.weight.reshape(d, d)), pw2_b=F(cm.pointwise_conv2.bias),
+                ff_w1=A(l.feed_forward.w_1.weight), ff_b1=F(l.feed_forward.w_1.bias),
+                ff_w2=A(l.feed_forward.w_2.weight), ff_b2=F(l.feed_forward.w_2.bias),
+            )
+            for k, v in lt.items():
+                setattr(layers[i], k, v.data_ptr())
+        w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))
+        self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype)
+        self._pos_cache = {}
+        return self._packed
+
+    def _ensure_packed(self, device):
+        p = self._packed
+        if p is None or p["device"] != device or p["dtype"] != self.em_dtype:
+            p = self.pack(device)
+        return p
+
+    def _pos_emb(self, T: int, device) -> torch.Tensor:
+        key = (T, str(device), self.em_dtype)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = rel_pos_table(T, self._output_size).to(self.act_dtype).to(device)
+        return self._pos_cache[key]
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def output_frames(T_f: int) -> int:
+        return ((T_f - 1) // 2 - 1) // 2
+
+    def forward_device(self, feats: torch.Tensor, flens: List[int], flens_dev: torch.Tensor,
+                       mvn_partial: Optional[torch.Tensor] = None):
+        """feats (B,T_f,D) f32 on the GPU.  Returns (enc_out f32 (B,T,d), enc_act (B,T,d) in the
+        compute dtype, olens list, olens_dev i32)."""
+        L.require_gpu(feats, "feats")
+        B, T_f, D = feats.shape
+        if T_f < 7:
+            # check_short_utt (subsampling.py:31-49) via conformer_encoder.py:360-369
+            raise L.TooShortUttError(
+                f"has {T_f} frames and is too short for subsampling "
+                f"(it needs more than 7 frames), return empty results", T_f, 7)
+        dev = feats.device
+        pk = self._ensure_packed(dev)
+        lib = L.load()
+        T = self.output_frames(T_f)
+        olens = conv2d_subsampled_lengths(flens, T_f)
+        olens_dev = torch.tensor(olens, dtype=torch.int32).to(dev, non_blocking=True)
+        need = lib.em_conformer_workspace_bytes(self.em_dtype, C.byref(pk["w"]), B, T_f)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        d = self._output_size
+        enc_out = torch.empty(B, T, d, dtype=torch.float32, device=dev)
+        enc_act = torch.empty(B, T, d, dtype=self.act_dtype, device=dev)
+        rc = lib.em_conformer_encode(
+            self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
+            L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(self._ws),
+            self._ws.numel(), L.ptr(enc_out), L.ptr(enc_act), L.current_stream_ptr())
+        L.check(rc, "em_conformer_encode")
+        return enc_out, enc_act, olens, olens_dev
+
+    def forward(self, xs_pad: torch.Tensor, ilens: torch.Tensor, prev_states: torch.Tensor = None
+                ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+        flens = [int(v) for v in ilens.tolist()]
+        flens_dev = torch.tensor(flens, dtype=torch.int32).to(xs_pad.device, non_blocking=True)
+        enc_out, _, olens, _ = self.forward_device(xs_pad.to(torch.float32).contiguous(), flens,
+                                                   flens_dev, None)
+        return enc_out, torch.tensor(olens, dtype=torch.long, device=xs_pad.device), None

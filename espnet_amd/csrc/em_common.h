@@ -1,0 +1,77 @@
+// espnet_amd — shared device helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Wave = 64 lanes everywhere; no other target is supported (no dual paths, no shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/espnet_amd.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define EM_WAVE 64
+
+// ---- MFMA traits: 16x16 output tile, C/D layout col = lane&15, row = (lane>>4)*4 + reg.
+// A operand: row = lane&15, k-slice (lane>>4); B operand: col = lane&15, k-slice (lane>>4).
+// Both operands use the same (lane-group, element) -> k convention, so the contraction is
+// correct for any hardware k numbering.
+template <typename T>
+struct Mma;
+
+template <>
+struct Mma<bf16> {
+  static constexpr int K = 32;   // contraction depth of one instruction
+  static constexpr int EPL = 8;  // elements per lane per operand
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ frag load(const bf16* p) { return *(const bf16x8*)p; }
+};
+
+template <>
+struct Mma<float> {
+  static constexpr int K = 4;
+  static constexpr int EPL = 1;
+  typedef float frag;
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ frag load(const float* p) { return *p; }
+};
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32, RNE
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define EM_CHECK_LAUNCH()                                  \
+  do {                                                     \
+    hipError_t e__ = hipGetLastError();                    \
+    if (e__ != hipSuccess) return EM_ERR_LAUNCH;           \
+  } while (0)
+
+static inline int em_cdiv(int a, int b) { return (a + b - 1) / b; }

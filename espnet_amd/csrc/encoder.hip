@@ -1,0 +1,169 @@
+// Host-side launch sequence of the Conformer encoder and the greedy CTC head (no device code
+// here): one C call enqueues every kernel of a forward pass on the caller's stream, so the Python
+// layer pays one FFI crossing per batch.
+//
+// Reference call graph being reproduced:
+//   ConformerEncoder.forward          espnet2/asr/encoder/conformer_encoder.py:327-429
+//   Conv2dSubsampling.forward         .../transformer/subsampling.py:432-447
+//   RelPositionalEncoding.forward     .../transformer/embedding.py:318-334  (x * sqrt(d))
+//   EncoderLayer.forward (x12)        .../conformer/encoder_layer.py:79-179
+//   CTC.argmax + G1 collapse          espnet2/asr/ctc.py:207-215, bin/asr_inference.py:574-575
+#include <math.h>
+
+#include "em_common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-12f;  // transformer/layer_norm.py:23
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Geo {
+  int T1, F1, T, F2;
+};
+inline Geo geo(int T_f, int n_mels) {
+  Geo g;
+  g.T1 = (T_f - 3) / 2 + 1;
+  g.F1 = (n_mels - 3) / 2 + 1;
+  g.T = (g.T1 - 3) / 2 + 1;
+  g.F2 = (g.F1 - 3) / 2 + 1;
+  return g;
+}
+
+struct Ws {
+  size_t c1, c2, x, xn, big, g, g2, ctx, pall, total;
+};
+inline Ws layout(int dtype, const EmConformerWeights* w, int B, int T_f) {
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  Geo g = geo(T_f, w->n_mels);
+  const size_t M = (size_t)B * g.T, d = w->d;
+  size_t wide = w->ff > 3 * w->d ? w->ff : 3 * w->d;
+  Ws s;
+  size_t o = 0;
+  s.c1 = o; o += align_up((size_t)B * g.T1 * g.F1 * d * es);
+  s.c2 = o; o += align_up(M * g.F2 * d * es);
+  s.x = o; o += align_up(M * d * 4);
+  s.xn = o; o += align_up(M * d * es);
+  s.big = o; o += align_up(M * wide * es);
+  s.g = o; o += align_up(M * d * es);
+  s.g2 = o; o += align_up(M * d * es);
+  s.ctx = o; o += align_up(M * d * es);
+  s.pall = o; o += align_up((size_t)(2 * g.T - 1) * w->num_blocks * d * es);
+  s.total = o;
+  return s;
+}
+
+inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
+                int N, int K, int lda, int ldc, float scale, void* stream) {
+  EmGemmArgs a;
+  a.A = A; a.W = W; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.scale = scale;
+  a.T1 = a.F1 = a.T2 = a.F2 = a.d = 0;
+  return em_gemm(dtype, epi, EM_A_PLAIN, &a, stream);
+}
+
+#define EM_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != EM_OK) return rc__; \
+  } while (0)
+
+}  // namespace
+
+extern "C" size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t B,
+                                               int32_t T_f) {
+  if (!w || B <= 0 || T_f < 7) return 0;
+  return layout(dtype, w, B, T_f).total;
+}
+
+extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* feats,
+                                   const float* mvn_partial, const int32_t* flens,
+                                   const int32_t* olens, int32_t B, int32_t T_f,
+                                   const void* pos_emb, void* workspace, size_t workspace_bytes,
+                                   float* enc_out, void* enc_act, void* stream) {
+  if (!w || !feats || !flens || !olens || !pos_emb || !workspace || !enc_out || !enc_act)
+    return EM_ERR_BAD_ARG;
+  if (dtype != EM_F32 && dtype != EM_BF16) return EM_ERR_BAD_ARG;
+  if (B <= 0) return EM_ERR_BAD_ARG;
+  if (T_f < 7) return EM_ERR_TOO_SHORT;  // check_short_utt, subsampling.py:31-49
+  const int d = w->d, h = w->heads, ff = w->ff, L = w->num_blocks;
+  if (d % 64 != 0 || h <= 0 || d / h != 64 || ff % 64 != 0) return EM_ERR_UNSUPPORTED;
+  const Ws s = layout(dtype, w, B, T_f);
+  if (workspace_bytes < s.total) return EM_ERR_WORKSPACE;
+  const Geo g = geo(T_f, w->n_mels);
+  const int T = g.T, M = B * T;
+  unsigned char* ws = (unsigned char*)workspace;
+  void* c1 = ws + s.c1;
+  void* c2 = ws + s.c2;
+  float* x = (float*)(ws + s.x);
+  void* xn = ws + s.xn;
+  void* big = ws + s.big;
+  void* gl = ws + s.g;
+  void* g2 = ws + s.g2;
+  void* ctx = ws + s.ctx;
+  void* pall = ws + s.pall;
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+
+  // ---- Conv2dSubsampling: conv1 (+MVN) -> conv2 implicit GEMM -> Linear, * sqrt(d)
+  EM_TRY(em_conv2d_sub1(dtype, feats, mvn_partial, flens, B, T_f, w->n_mels, w->conv1_w,
+                        w->conv1_b, d, c1, stream));
+  {
+    EmGemmArgs a;
+    a.A = c1; a.W = w->conv2_w; a.C = c2; a.bias = w->conv2_b;
+    a.M = M * g.F2; a.N = d; a.K = 9 * d; a.lda = 0; a.ldc = d; a.scale = 1.f;
+    a.T1 = g.T1; a.F1 = g.F1; a.T2 = T; a.F2 = g.F2; a.d = d;
+    EM_TRY(em_gemm(dtype, EM_EPI_RELU, EM_A_CONV2, &a, stream));
+  }
+  EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d, g.F2 * d, d,
+              sqrtf((float)d), stream));
+  // ---- linear_pos of every block in one GEMM: pall[2T-1][L*d]
+  EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, 2 * T - 1, L * d, d, d,
+              L * d, 1.f, stream));
+
+  const EmConformerLayer* ly = w->layers;
+  EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr,
+                      stream));
+  for (int l = 0; l < L; ++l) {
+    const EmConformerLayer& q = ly[l];
+    // macaron FFN: x += 0.5 * w2(swish(w1 LN(x)))
+    EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
+    // self-attention
+    EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
+    EM_TRY(em_relpos_attention(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
+                               q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
+    // convolution module
+    EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
+    EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, B, T, d, w->kernel, g2, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
+    // FFN
+    EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ff_w2, x, q.ff_b2, M, d, ff, ff, d, 0.5f, stream));
+    // norm_final, fused with the next consumer's LayerNorm
+    if (l + 1 < L) {
+      EM_TRY(em_layernorm2(dtype, x, q.norm_final_g, q.norm_final_b, ly[l + 1].norm_ff_mac_g,
+                           ly[l + 1].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr, stream));
+    } else {
+      EM_TRY(em_layernorm2(dtype, x, q.norm_final_g, q.norm_final_b, w->after_norm_g,
+                           w->after_norm_b, M, d, LN_EPS, enc_act, enc_out, stream));
+    }
+  }
+  return EM_OK;
+}
+
+extern "C" int em_ctc_greedy(int dtype, const void* enc_act, const void* w_ctc, const float* b_ctc,
+                             int32_t B, int32_t T, int32_t d, int32_t V, const int32_t* olens,
+                             int32_t blank, int32_t sos_eos, float* logits_ws, int32_t* ids,
+                             int32_t* tokens, int32_t* out_lens, void* stream) {
+  if (!enc_act || !w_ctc || !logits_ws || !ids || !tokens || !out_lens) return EM_ERR_BAD_ARG;
+  const int M = B * T;
+  EM_TRY(gemm(dtype, EM_EPI_STORE_F32, enc_act, w_ctc, logits_ws, b_ctc, M, V, d, d, V, 1.f,
+              stream));
+  EM_TRY(em_argmax_rows_f32(logits_ws, M, V, ids, stream));
+  EM_TRY(em_ctc_collapse(ids, olens, B, T, blank, sos_eos, tokens, out_lens, stream));
+  return EM_OK;
+}

@@ -1,0 +1,233 @@
+// Frontend kernels: framed STFT(512) -> power -> mel -> log, utterance-MVN partial sums, and the
+// first subsampling conv.  HBM-bound stage (960 320 algorithmic bytes / 10 s utt).
+//
+// Reference behaviour being reproduced (paths relative to espnet/espnet):
+//   espnet2/layers/stft.py:48-120      torch.stft(center=True, reflect pad, onesided, hann window)
+//   espnet2/asr/frontend/default.py:110 power = re^2 + im^2
+//   espnet2/layers/log_mel.py:57-84    matmul(melmat) -> clamp(1e-10) -> log -> zero the padding
+//   espnet2/layers/utterance_mvn.py:45-88
+//   espnet2/legacy/nets/pytorch_backend/transformer/subsampling.py:400-403 (first Conv2d + ReLU)
+#include "em_common.h"
+
+__device__ const float2 EM_TW512[384] = {
+#include "twiddle512.inc"
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// radix-4 DFT of u[0..3] (forward, e^{-2 pi i m q / 4})
+__device__ __forceinline__ void bfly4(float2 u[4]) {
+  float2 a = make_float2(u[0].x + u[2].x, u[0].y + u[2].y);
+  float2 b = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
+  float2 c = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
+  float2 d = make_float2(u[1].x - u[3].x, u[1].y - u[3].y);
+  u[0] = make_float2(a.x + c.x, a.y + c.y);
+  u[2] = make_float2(a.x - c.x, a.y - c.y);
+  // -i*d = (d.y, -d.x)
+  u[1] = make_float2(b.x + d.y, b.y - d.x);
+  u[3] = make_float2(b.x - d.y, b.y + d.x);
+}
+
+__device__ __forceinline__ int reflect_idx(int p, int N) {
+  if (p < 0) p = -p;
+  if (p >= N) p = 2 * (N - 1) - p;
+  // degenerate N < n_fft/2 inputs are rejected on the host (torch.stft raises as well)
+  return p;
+}
+
+// One wave per frame, four frames per 256-thread block.  Each lane owns 4 points of the packed
+// 256-point complex FFT (Stockham radix-4, 4 stages, ping-pong in LDS), then the real-FFT
+// untangling, |X|^2, and the banded mel contraction.
+__global__ __launch_bounds__(256) void frontend_logmel_kernel(
+    const float* __restrict__ wav, int N, int hop, const float* __restrict__ window,
+    const float* __restrict__ melw, const int* __restrict__ mel_lo, int mel_maxlen, int n_mels,
+    const int* __restrict__ flens, int T_f, float* __restrict__ feats) {
+  __shared__ float s_re[4][2][256];
+  __shared__ float s_im[4][2][256];
+  __shared__ float s_pow[4][264];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int t_raw = blockIdx.x * 4 + wave;
+  const int t = t_raw < T_f ? t_raw : T_f - 1;
+  const float* x = wav + (size_t)b * N;
+  float(*re)[256] = s_re[wave];
+  float(*im)[256] = s_im[wave];
+
+  // ---- load + window: z[n] = x[2n] + i x[2n+1], n = lane + 64 m
+  float2 u[4];
+  const int start = t * hop - 256;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    int n = lane + 64 * m;
+    int i0 = reflect_idx(start + 2 * n, N), i1 = reflect_idx(start + 2 * n + 1, N);
+    u[m] = make_float2(x[i0] * window[2 * n], x[i1] * window[2 * n + 1]);
+  }
+  // ---- stage p = 1 (no twiddles): out[4*lane + q]
+  bfly4(u);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    re[0][4 * lane + q] = u[q].x;
+    im[0][4 * lane + q] = u[q].y;
+  }
+  __syncthreads();
+  // ---- stages p = 4, 16, 64
+  int cur = 0;
+#pragma unroll
+  for (int s = 1; s < 4; ++s) {
+    const int p = 1 << (2 * s);
+    const int k = lane & (p - 1);
+    const int j = ((lane - k) << 2) + k;
+    const int twstep = 2 * k * (64 / p);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float2 v = make_float2(re[cur][lane + 64 * m], im[cur][lane + 64 * m]);
+      u[m] = (m == 0) ? v : cmul(v, EM_TW512[m * twstep]);
+    }
+    bfly4(u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      re[cur ^ 1][j + q * p] = u[q].x;
+      im[cur ^ 1][j + q * p] = u[q].y;
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  // ---- real-FFT untangle + power: k = lane + 64 m (m < 4) and k = 256 on lane 0
+  float* pw = s_pow[wave];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    int k = lane + 64 * m;
+    if (m == 4 && lane != 0) break;
+    int ka = k & 255, kb = (256 - k) & 255;
+    float2 zk = make_float2(re[cur][ka], im[cur][ka]);
+    float2 zc = make_float2(re[cur][kb], -im[cur][kb]);
+    float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+    // o = -i/2 (zk - zc)
+    float2 dlt = make_float2(zk.x - zc.x, zk.y - zc.y);
+    float2 o = make_float2(0.5f * dlt.y, -0.5f * dlt.x);
+    float2 w = (k < 384) ? EM_TW512[k] : make_float2(0.f, 0.f);
+    float2 xo = cmul(w, o);
+    float xr = e.x + xo.x, xi = e.y + xo.y;
+    pw[k] = xr * xr + xi * xi;
+  }
+  __syncthreads();
+  // ---- banded mel + log
+  const bool valid_frame = t < flens[b];
+  if (t_raw < T_f) {
+    float* out = feats + ((size_t)b * T_f + t) * n_mels;
+    for (int m = lane; m < n_mels; m += 64) {
+      float acc = 0.f;
+      int lo = mel_lo[m];
+      for (int s = 0; s < mel_maxlen; ++s) {
+        int k = lo + s;
+        k = k < 256 ? k : 256;
+        acc = fmaf(pw[k], melw[s * n_mels + m], acc);
+      }
+      acc = fmaxf(acc, 1e-10f);
+      out[m] = valid_frame ? logf(acc) : 0.f;
+    }
+  }
+}
+
+extern "C" int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, int32_t hop,
+                                      const float* window, const float* mel_packed,
+                                      const int32_t* mel_lo, int32_t mel_maxlen, int32_t n_mels,
+                                      const int32_t* flens, int32_t T_f, float* feats,
+                                      void* stream) {
+  if (B <= 0 || T_f <= 0) return EM_ERR_BAD_ARG;
+  if (N <= 256 || hop <= 0 || T_f != 1 + N / hop) return EM_ERR_BAD_ARG;
+  if (mel_maxlen < 1 || mel_maxlen > 257 || n_mels < 1) return EM_ERR_BAD_ARG;
+  dim3 grid(em_cdiv(T_f, 4), B);
+  hipLaunchKernelGGL(frontend_logmel_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, N, hop,
+                     window, mel_packed, mel_lo, mel_maxlen, n_mels, flens, T_f, feats);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+// ---- utterance MVN: 8 partial column sums per utterance over the valid frames --------------
+__global__ __launch_bounds__(128) void utt_mvn_partial_kernel(const float* __restrict__ feats,
+                                                              const int* __restrict__ flens,
+                                                              int T_f, int n_mels,
+                                                              float* __restrict__ partial) {
+  const int b = blockIdx.y, part = blockIdx.x;
+  const int len = flens[b] < T_f ? flens[b] : T_f;
+  const int chunk = (len + 7) / 8;
+  const int t0 = part * chunk;
+  const int t1 = (t0 + chunk) < len ? (t0 + chunk) : len;
+  for (int m = threadIdx.x; m < n_mels; m += blockDim.x) {
+    float acc = 0.f;
+    for (int t = t0; t < t1; ++t) acc += feats[((size_t)b * T_f + t) * n_mels + m];
+    partial[((size_t)b * 8 + part) * n_mels + m] = acc;
+  }
+}
+
+extern "C" int em_utt_mvn_partial_f32(const float* feats, const int32_t* flens, int32_t B,
+                                      int32_t T_f, int32_t n_mels, float* partial, void* stream) {
+  if (B <= 0 || T_f <= 0 || n_mels <= 0) return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(utt_mvn_partial_kernel, dim3(8, B), dim3(128), 0, (hipStream_t)stream, feats,
+                     flens, T_f, n_mels, partial);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+// ---- first subsampling conv: Conv2d(1, d, 3, stride 2) + ReLU, MVN subtraction fused ---------
+// grid (T1, B); the block stages the three (mean-subtracted) input rows in LDS and every thread
+// produces all F1 outputs of its channel(s); stores are coalesced over channels (channel-last).
+template <typename T>
+__global__ __launch_bounds__(256) void conv2d_sub1_kernel(
+    const float* __restrict__ feats, const float* __restrict__ partial,
+    const int* __restrict__ flens, int T_f, int n_mels, const float* __restrict__ w1,
+    const float* __restrict__ b1, int d, int T1, int F1, T* __restrict__ out) {
+  __shared__ float s_in[3][128];
+  const int t1 = blockIdx.x, b = blockIdx.y;
+  for (int i = threadIdx.x; i < 3 * n_mels; i += blockDim.x) {
+    int r = i / n_mels, f = i - r * n_mels;
+    float mean = 0.f;
+    if (partial) {
+      const float* pp = partial + (size_t)b * 8 * n_mels + f;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += pp[q * n_mels];
+      mean = s / (float)flens[b];
+    }
+    s_in[r][f] = feats[((size_t)b * T_f + 2 * t1 + r) * n_mels + f] - mean;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = w1[c * 9 + i];
+    const float bias = b1[c];
+    T* o = out + ((size_t)(b * T1 + t1) * F1) * d + c;
+    for (int f1 = 0; f1 < F1; ++f1) {
+      float acc = bias;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc = fmaf(w[i * 3 + j], s_in[i][2 * f1 + j], acc);
+      o[(size_t)f1 * d] = from_f32<T>(fmaxf(acc, 0.f));
+    }
+  }
+}
+
+extern "C" int em_conv2d_sub1(int dtype, const float* feats, const float* partial,
+                              const int32_t* flens, int32_t B, int32_t T_f, int32_t n_mels,
+                              const float* w1, const float* b1, int32_t d, void* out,
+                              void* stream) {
+  if (B <= 0 || n_mels < 3 || n_mels > 128 || d <= 0) return EM_ERR_BAD_ARG;
+  if (T_f < 7) return EM_ERR_TOO_SHORT;
+  const int T1 = (T_f - 3) / 2 + 1, F1 = (n_mels - 3) / 2 + 1;
+  dim3 grid(T1, B);
+  if (dtype == EM_F32)
+    hipLaunchKernelGGL(conv2d_sub1_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, feats,
+                       partial, flens, T_f, n_mels, w1, b1, d, T1, F1, (float*)out);
+  else if (dtype == EM_BF16)
+    hipLaunchKernelGGL(conv2d_sub1_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, feats,
+                       partial, flens, T_f, n_mels, w1, b1, d, T1, F1, (bf16*)out);
+  else
+    return EM_ERR_BAD_ARG;
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}

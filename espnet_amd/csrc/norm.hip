@@ -1,0 +1,107 @@
+// LayerNorm over the f32 residual stream, one wave per row (transformer/layer_norm.py:12-42,
+// eps 1e-12 passed by the caller).  Bandwidth-bound: each row is read once, kept in registers
+// (d/64 values per lane), reduced with wave shuffles, and written in the GEMM input dtype.
+#include "em_common.h"
+
+namespace {
+
+template <int NV>
+__device__ __forceinline__ void ln_row(float v[NV], const float* __restrict__ g,
+                                       const float* __restrict__ b, int lane, int d, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s += v[j];
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float c = v[j] - mean;
+    q += c * c;
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    int c = lane + 64 * j;
+    v[j] = (v[j] - mean) * rstd * g[c] + b[c];
+  }
+}
+
+// MODE 0: out = LN(x; g1,b1)  (optional f32 copy)
+// MODE 1: x <- LN(x; g1,b1) in place, out = LN(x; g2,b2)
+template <typename T, int NV, int MODE>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x,
+                                                        const float* __restrict__ g1,
+                                                        const float* __restrict__ b1,
+                                                        const float* __restrict__ g2,
+                                                        const float* __restrict__ b2, int M, int d,
+                                                        float eps, T* __restrict__ out,
+                                                        float* __restrict__ out_f32) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float* xr = x + (size_t)row * d;
+  float v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = xr[lane + 64 * j];
+  ln_row<NV>(v, g1, b1, lane, d, eps);
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) xr[lane + 64 * j] = v[j];
+    ln_row<NV>(v, g2, b2, lane, d, eps);
+  }
+  T* o = out + (size_t)row * d;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) o[lane + 64 * j] = from_f32<T>(v[j]);
+  if (out_f32) {
+    float* of = out_f32 + (size_t)row * d;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) of[lane + 64 * j] = v[j];
+  }
+}
+
+template <typename T, int MODE>
+int launch_ln(float* x, const float* g1, const float* b1, const float* g2, const float* b2, int M,
+              int d, float eps, T* out, float* out_f32, hipStream_t s) {
+  dim3 grid(em_cdiv(M, 4)), block(256);
+#define EM_LN_CASE(NV)                                                                          \
+  case NV:                                                                                      \
+    hipLaunchKernelGGL((layernorm_kernel<T, NV, MODE>), grid, block, 0, s, x, g1, b1, g2, b2, M, \
+                       d, eps, out, out_f32);                                                   \
+    break;
+  switch (d / 64) {
+    EM_LN_CASE(1) EM_LN_CASE(2) EM_LN_CASE(4) EM_LN_CASE(6) EM_LN_CASE(8) EM_LN_CASE(12)
+    EM_LN_CASE(16)
+    default: return EM_ERR_UNSUPPORTED;
+  }
+#undef EM_LN_CASE
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+}  // namespace
+
+extern "C" int em_layernorm(int dtype, const float* x, const float* g, const float* b, int32_t M,
+                            int32_t d, float eps, void* out, float* out_f32, void* stream) {
+  if (M <= 0 || d <= 0 || d % 64 != 0) return d % 64 ? EM_ERR_UNSUPPORTED : EM_ERR_BAD_ARG;
+  if (dtype == EM_F32)
+    return launch_ln<float, 0>((float*)x, g, b, nullptr, nullptr, M, d, eps, (float*)out, out_f32,
+                               (hipStream_t)stream);
+  if (dtype == EM_BF16)
+    return launch_ln<bf16, 0>((float*)x, g, b, nullptr, nullptr, M, d, eps, (bf16*)out, out_f32,
+                              (hipStream_t)stream);
+  return EM_ERR_BAD_ARG;
+}
+
+extern "C" int em_layernorm2(int dtype, float* x, const float* g1, const float* b1,
+                             const float* g2, const float* b2, int32_t M, int32_t d, float eps,
+                             void* out, float* out_f32, void* stream) {
+  if (M <= 0 || d <= 0 || d % 64 != 0) return d % 64 ? EM_ERR_UNSUPPORTED : EM_ERR_BAD_ARG;
+  if (dtype == EM_F32)
+    return launch_ln<float, 1>(x, g1, b1, g2, b2, M, d, eps, (float*)out, out_f32,
+                               (hipStream_t)stream);
+  if (dtype == EM_BF16)
+    return launch_ln<bf16, 1>(x, g1, b1, g2, b2, M, d, eps, (bf16*)out, out_f32,
+                              (hipStream_t)stream);
+  return EM_ERR_BAD_ARG;
+}

@@ -1,0 +1,146 @@
+"""ctypes binding of libespnet_amd.so (the C ABI declared in include/espnet_amd.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol is absent this
+module raises at first use, and every wrapper raises on a non-zero status.  Status codes are mapped
+to the exceptions the reference raises for the same condition (TooShortUttError for < 7 feature
+frames, espnet2/legacy/nets/pytorch_backend/transformer/subsampling.py:14-49).
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libespnet_amd.so"
+
+EM_OK = 0
+EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE = -1, -2, -3, -4, -5
+EM_F32, EM_BF16 = 0, 1
+(EM_EPI_STORE, EM_EPI_SWISH, EM_EPI_RELU, EM_EPI_RESID_F32, EM_EPI_SCALE_F32, EM_EPI_GLU,
+ EM_EPI_STORE_F32) = range(7)
+EM_A_PLAIN, EM_A_CONV2 = 0, 1
+
+DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
+
+
+class TooShortUttError(Exception):
+    """Same contract as the reference's TooShortUttError (subsampling.py:14-29)."""
+
+    def __init__(self, message, actual_size, limit):
+        super().__init__(message)
+        self.actual_size = actual_size
+        self.limit = limit
+
+
+class EspnetAmdError(RuntimeError):
+    pass
+
+
+class EmGemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldc", C.c_int32), ("scale", C.c_float),
+                ("T1", C.c_int32), ("F1", C.c_int32), ("T2", C.c_int32), ("F2", C.c_int32),
+                ("d", C.c_int32)]
+
+
+_LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b", "norm_conv_g",
+               "norm_conv_b", "norm_ff_g", "norm_ff_b", "norm_final_g", "norm_final_b",
+               "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "wqkv", "bqkv", "pos_u", "pos_v", "wout",
+               "bout", "pw1", "pw1_b", "dw_w", "dw_b", "pw2", "pw2_b", "ff_w1", "ff_b1", "ff_w2",
+               "ff_b2"]
+
+
+class EmConformerLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LAYER_PTRS]
+
+
+class EmConformerWeights(C.Structure):
+    _fields_ = [("d", C.c_int32), ("heads", C.c_int32), ("ff", C.c_int32),
+                ("num_blocks", C.c_int32), ("kernel", C.c_int32), ("n_mels", C.c_int32),
+                ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p),
+                ("conv2_b", C.c_void_p), ("embed_w", C.c_void_p), ("embed_b", C.c_void_p),
+                ("wpos_all", C.c_void_p), ("after_norm_g", C.c_void_p),
+                ("after_norm_b", C.c_void_p), ("layers", C.POINTER(EmConformerLayer))]
+
+
+_i32, _f32, _vp, _sz = C.c_int32, C.c_float, C.c_void_p, C.c_size_t
+_SIGNATURES = {
+    "em_version": (C.c_int, []),
+    "em_error_string": (C.c_char_p, [C.c_int]),
+    "em_frontend_logmel_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp,
+                                         _i32, _vp, _vp]),
+    "em_utt_mvn_partial_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "em_conv2d_sub1": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "em_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(EmGemmArgs), _vp]),
+    "em_layernorm": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "em_layernorm2": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "em_relpos_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32,
+                                      _i32, _vp, _vp]),
+    "em_dwconv_bn_swish": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "em_argmax_rows_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "em_log_softmax_rows_f32": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "em_ctc_collapse": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "em_conformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32]),
+    "em_conformer_encode": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _vp, _vp, _vp,
+                                      _i32, _i32, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "em_cast_f32": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
+    "em_ctc_greedy": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32,
+                                _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("ESPNET_AMD_LIB", str(_LIB_PATH)))
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """Load the shared library (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise EspnetAmdError(
+            f"{path} not found: the HIP extension is not built (run `python -m espnet_amd.build`). "
+            "espnet_amd has no CPU fallback.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc == EM_OK:
+        return
+    msg = load().em_error_string(rc).decode()
+    if rc == EM_ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    if rc == EM_ERR_BAD_ARG:
+        raise ValueError(f"{what}: {msg}")
+    raise EspnetAmdError(f"{what}: {msg} (code {rc})")
+
+
+def ptr(t):
+    """Raw device/host pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t, name="tensor"):
+    if not t.is_cuda:
+        raise EspnetAmdError(
+            f"{name} lives on {t.device}: espnet_amd runs only on an MI355X (HIP) device and has "
+            "no CPU fallback")

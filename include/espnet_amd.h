@@ -1,0 +1,200 @@
+/* espnet_amd.h — C ABI of libespnet_amd.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for ESPnet's ASR-inference hot path.  The reference has no FFI
+ * for this path — its boundary is the Python plugin API — so each entry point below names the
+ * reference Python interface it replaces (paths relative to espnet/espnet).  The Python host layer
+ * in espnet_amd/ mirrors those interfaces and binds this ABI with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer (PyTorch allocations, `tensor.data_ptr()`); the library
+ *     allocates nothing and keeps no mutable global state;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - return value: EM_OK or a negative EM_ERR_* code; nothing throws across the ABI;
+ *   - dtype: EM_F32 (exact-f32 MFMA, parity mode) or EM_BF16 (bf16 MFMA, f32 accumulate).
+ *     "act" buffers hold elements of that dtype; residual stream / features / logits are f32.
+ */
+#ifndef ESPNET_AMD_H_
+#define ESPNET_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EM_OK 0
+#define EM_ERR_UNSUPPORTED (-1) /* shape/config outside the fast path */
+#define EM_ERR_BAD_ARG (-2)
+#define EM_ERR_TOO_SHORT (-3) /* < 7 feature frames: TooShortUttError, subsampling.py:31-49 */
+#define EM_ERR_LAUNCH (-4)    /* hipGetLastError() != hipSuccess after a launch */
+#define EM_ERR_WORKSPACE (-5) /* workspace too small */
+
+#define EM_F32 0
+#define EM_BF16 1
+
+/* GEMM epilogues (C = A[M,K] * W[N,K]^T, f32 accumulate) */
+#define EM_EPI_STORE 0     /* C[act]  = acc + bias                                  */
+#define EM_EPI_SWISH 1     /* C[act]  = swish(acc + bias)       (FFN w_1, swish.py) */
+#define EM_EPI_RELU 2      /* C[act]  = relu(acc + bias)        (conv2d / decoder FFN) */
+#define EM_EPI_RESID_F32 3 /* C[f32] += scale * (acc + bias)    (residual stream)   */
+#define EM_EPI_SCALE_F32 4 /* C[f32]  = scale * (acc + bias)    (embed out * sqrt(d)) */
+#define EM_EPI_GLU 5       /* C[act][n/2] = (acc_v+b_v) * sigmoid(acc_g+b_g); W rows interleaved
+                              in 16-row granules [v0..15,g0..15,v16..31,...] (convolution.py:68-69) */
+#define EM_EPI_STORE_F32 6 /* C[f32]  = acc + bias              (CTC / decoder logits) */
+
+/* A-operand addressing */
+#define EM_A_PLAIN 0 /* row m at A + m*lda */
+#define EM_A_CONV2 1 /* implicit GEMM of Conv2d(d,d,3,stride 2) over a channel-last (B,T1,F1,d) map */
+
+typedef struct EmGemmArgs {
+  const void* A;     /* act dtype */
+  const void* W;     /* act dtype, [N][K] row-major (torch Linear layout) */
+  void* C;           /* act dtype or f32 depending on the epilogue */
+  const float* bias; /* [N] f32 or NULL */
+  int32_t M, N, K;   /* K % 64 == 0 */
+  int32_t lda, ldc;  /* in elements */
+  float scale;
+  int32_t T1, F1, T2, F2, d; /* EM_A_CONV2 only: M = B*T2*F2, K = 9*d */
+} EmGemmArgs;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int em_version(void);
+const char* em_error_string(int code);
+
+/* ---- A1+A2: Stft.forward (espnet2/layers/stft.py:48-120) + power (asr/frontend/default.py:110)
+ *      + LogMel.forward (espnet2/layers/log_mel.py:57-84), fused.  n_fft is fixed at 512.
+ *   wav        [B][N] f32 (zero padded to the batch maximum N, as espnet_model.py:454)
+ *   window     [512] f32: hann(win_length) zero padded/centred to n_fft (torch.stft semantics)
+ *   mel_packed [mel_maxlen][n_mels] f32: mel_packed[s][m] = melmat[mel_lo[m]+s][m] (0 past the band)
+ *   mel_lo     [n_mels] i32 first non-zero rFFT bin of each filter
+ *   flens      [B] i32 valid frames per utterance (stft.py:108-115); frames >= flens are zeroed
+ *   feats      [B][T_f][n_mels] f32 out, T_f = 1 + N/hop                                         */
+int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, int32_t hop, const float* window,
+                           const float* mel_packed, const int32_t* mel_lo, int32_t mel_maxlen,
+                           int32_t n_mels, const int32_t* flens, int32_t T_f, float* feats,
+                           void* stream);
+
+/* ---- A3: utterance_mvn (espnet2/layers/utterance_mvn.py:45-88), first half: per-utterance
+ *      partial column sums over the valid frames.  partial [B][8][n_mels] f32 out.  The mean
+ *      subtraction itself is fused into em_conv2d_sub1 (padded frames become -mean, :73).       */
+int em_utt_mvn_partial_f32(const float* feats, const int32_t* flens, int32_t B, int32_t T_f,
+                           int32_t n_mels, float* partial, void* stream);
+
+/* ---- A4 (first conv): Conv2dSubsampling.conv[0..1] = Conv2d(1,d,3,2)+ReLU
+ *      (transformer/subsampling.py:400-403), with the MVN mean subtraction fused on the input.
+ *   partial may be NULL (no mean subtraction).  w1 [d][9] f32, b1 [d] f32.
+ *   out [B][T1][F1][d] act dtype, channel-last.                                                 */
+int em_conv2d_sub1(int dtype, const float* feats, const float* partial, const int32_t* flens,
+                   int32_t B, int32_t T_f, int32_t n_mels, const float* w1, const float* b1,
+                   int32_t d, void* out, void* stream);
+
+/* ---- dense contraction (A4 conv2 / embed out, A7 projections, A8 pointwise convs, A9 FFN,
+ *      A11 ctc_lo, A14 decoder linears): torch.nn.Linear / Conv1d(k=1) / Conv2d semantics.     */
+int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* args, void* stream);
+
+/* ---- A10: LayerNorm (transformer/layer_norm.py:12-42, eps 1e-12) over the f32 residual stream.
+ *   em_layernorm : out[act] = LN(x; g, b)               (out_f32 optional f32 copy, may be NULL)
+ *   em_layernorm2: x <- LN(x; g1, b1) (in place, f32), out[act] = LN(x; g2, b2)
+ *                  (EncoderLayer.norm_final followed by the next block's first norm, or by
+ *                  after_norm; encoder_layer.py:170-171, conformer_encoder.py:423-424);
+ *                  out_f32 (optional) receives the second LN in f32                              */
+int em_layernorm(int dtype, const float* x, const float* g, const float* b, int32_t M, int32_t d,
+                 float eps, void* out, float* out_f32, void* stream);
+int em_layernorm2(int dtype, float* x, const float* g1, const float* b1, const float* g2,
+                  const float* b2, int32_t M, int32_t d, float eps, void* out, float* out_f32,
+                  void* stream);
+
+/* ---- A7: RelPositionMultiHeadedAttention core (transformer/attention.py:416-459 after the
+ *      projections): AC = (q+u)k^T, BD[i][j] = (q+v).p[T-1-i+j] (rel_shift :391-408 as index
+ *      arithmetic), softmax((AC+BD)/sqrt(dk)) over keys j < klens[b] (masked probs = 0), times V.
+ *   qkv  [B*T][3d] act (q | k | v per row);  p [2T-1][ldp] act (ldp = row stride, elements)
+ *   pos_u,pos_v [h][dk] f32;  ctx [B*T][d] act out.  dk must be 64.                              */
+int em_relpos_attention(int dtype, const void* qkv, const void* p, int32_t ldp, const float* pos_u,
+                        const float* pos_v, const int32_t* klens, int32_t B, int32_t T, int32_t h,
+                        int32_t dk, void* ctx, void* stream);
+
+/* ---- A8 (middle): depthwise Conv1d(k, pad (k-1)/2) + eval BatchNorm1d (folded into w,b by the
+ *      caller) + Swish (conformer/convolution.py:72-75).  x,y [B][T][d] act; w [d][k] f32.       */
+int em_dwconv_bn_swish(int dtype, const void* x, const float* w, const float* b, int32_t B,
+                       int32_t T, int32_t d, int32_t k, void* y, void* stream);
+
+/* ---- A11 / G1: CTC head.  argmax over vocab (asr/ctc.py:207-215), then groupby + drop
+ *      blank/sos/eos (bin/asr_inference.py:574-575).  logits [M][V] f32.                        */
+int em_argmax_rows_f32(const float* logits, int32_t M, int32_t V, int32_t* ids, void* stream);
+int em_log_softmax_rows_f32(float* logits, int32_t M, int32_t V, void* stream);
+int em_ctc_collapse(const int32_t* ids, const int32_t* olens, int32_t B, int32_t T, int32_t blank,
+                    int32_t sos_eos, int32_t* tokens, int32_t* out_lens, void* stream);
+
+/* ---- A4..A10 assembled: ConformerEncoder.forward (espnet2/asr/encoder/conformer_encoder.py:327-429)
+ *      for input_layer=conv2d, rel_pos / rel_selfattn (latest), macaron, cnn module,
+ *      normalize_before; EncoderLayer.forward (conformer/encoder_layer.py:79-179) per block.
+ *      Weights are packed once at load time by the host layer (espnet_amd/asr/encoder/
+ *      conformer_encoder.py) into caller-owned device buffers; this struct only carries pointers
+ *      ("act" = dtype of the call, everything else f32).  The struct itself lives in HOST memory. */
+typedef struct EmConformerLayer {
+  const float *norm_ff_mac_g, *norm_ff_mac_b, *norm_mha_g, *norm_mha_b, *norm_conv_g, *norm_conv_b,
+      *norm_ff_g, *norm_ff_b, *norm_final_g, *norm_final_b;
+  const void* ffm_w1; /* [ff][d] act */
+  const float* ffm_b1;
+  const void* ffm_w2; /* [d][ff] act */
+  const float* ffm_b2;
+  const void* wqkv; /* [3d][d] act: linear_q | linear_k | linear_v rows */
+  const float* bqkv;
+  const float *pos_u, *pos_v; /* [h][dk] */
+  const void* wout;           /* [d][d] act */
+  const float* bout;
+  const void* pw1; /* [2d][d] act, GLU-interleaved rows (EM_EPI_GLU) */
+  const float* pw1_b;
+  const float *dw_w, *dw_b; /* [d][k], [d] with eval BatchNorm folded in */
+  const void* pw2;          /* [d][d] act */
+  const float* pw2_b;
+  const void* ff_w1;
+  const float* ff_b1;
+  const void* ff_w2;
+  const float* ff_b2;
+} EmConformerLayer;
+
+typedef struct EmConformerWeights {
+  int32_t d, heads, ff, num_blocks, kernel, n_mels;
+  const float *conv1_w, *conv1_b; /* [d][9], [d] */
+  const void* conv2_w;            /* [d][9d] act, k = (kt*3+kf)*d + c_in */
+  const float* conv2_b;
+  const void* embed_w; /* [d][F2*d] act, columns permuted to f*d + c (channel-last) */
+  const float* embed_b;
+  const void* wpos_all; /* [num_blocks*d][d] act: linear_pos of every block stacked */
+  const float *after_norm_g, *after_norm_b;
+  const EmConformerLayer* layers; /* [num_blocks], host array */
+} EmConformerWeights;
+
+/* bytes of scratch em_conformer_encode needs for (B, T_f) */
+size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t B, int32_t T_f);
+
+/*   feats      [B][T_f][n_mels] f32 (log-mel, not yet mean-normalised)
+ *   mvn_partial[B][8][n_mels] f32 from em_utt_mvn_partial_f32, or NULL for no mean subtraction
+ *   flens      [B] i32 valid feature frames;  olens [B] i32 valid encoder frames (host computes
+ *              both from the lengths exactly as the reference's masks do)
+ *   pos_emb    [2T-1][d] act: RelPositionalEncoding table rows (embedding.py:286-332)
+ *   enc_out    [B][T][d] f32 out (after_norm applied); enc_act same in act dtype (input of the
+ *              CTC / decoder projections), T = ((T_f-1)/2-1)/2                                   */
+int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* feats,
+                        const float* mvn_partial, const int32_t* flens, const int32_t* olens,
+                        int32_t B, int32_t T_f, const void* pos_emb, void* workspace,
+                        size_t workspace_bytes, float* enc_out, void* enc_act, void* stream);
+
+/* ---- A11 + G1 assembled: ctc_lo GEMM -> argmax -> collapse.
+ *   enc_act [B*T][d] act; w_ctc [V][d] act; logits_ws [B*T][V] f32 scratch;
+ *   ids [B][T] i32 per-frame argmax; tokens [B][T] i32 (-1 padded); out_lens [B] i32            */
+int em_ctc_greedy(int dtype, const void* enc_act, const void* w_ctc, const float* b_ctc, int32_t B,
+                  int32_t T, int32_t d, int32_t V, const int32_t* olens, int32_t blank,
+                  int32_t sos_eos, float* logits_ws, int32_t* ids, int32_t* tokens,
+                  int32_t* out_lens, void* stream);
+
+/* f32 -> act dtype copy (lets reference-shaped f32 entry points feed the act-dtype GEMMs) */
+int em_cast_f32(int dtype, const float* src, size_t n, void* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESPNET_AMD_H_ */

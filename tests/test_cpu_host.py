@@ -1,0 +1,101 @@
+"""CPU-only tests of the host layer: the C ABI library loads and exports every declared symbol
+(no compute calls without a GPU), registry/config handling, state-dict compatibility, lengths."""
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+from espnet_amd import lib as L
+from tests.helpers import golden_state_dict, load_golden
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = (REPO / "include" / "espnet_amd.h").read_text()
+    declared = set(re.findall(r"\b(em_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    lib = L.load()  # raises if not built
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/espnet_amd.h but not exported"
+    assert declared == set(L.exported_symbols()), declared ^ set(L.exported_symbols())
+    assert lib.em_version() >= 1
+    assert b"short" in lib.em_error_string(L.EM_ERR_TOO_SHORT)
+
+
+def test_no_cpu_fallback():
+    from espnet_amd.tasks.asr import ASRTask
+
+    g = load_golden("tiny_blocks")
+    model = ASRTask.build_model(g["config"])
+    with pytest.raises(L.EspnetAmdError):
+        model.encode(torch.zeros(1, 16000), torch.tensor([16000]))
+
+
+@pytest.mark.parametrize("name", ["tiny_blocks", "small_10s", "large_10s", "tiny_beam5"])
+def test_state_dict_table_equals_reference(name):
+    from espnet_amd.tasks.asr import ASRTask
+
+    g = load_golden(name)
+    cfg = g["config"]
+    if cfg["encoder_conf"]["output_size"] // cfg["encoder_conf"]["attention_heads"] != 64:
+        with pytest.raises(NotImplementedError):
+            ASRTask.build_model(cfg)
+        return
+    model = ASRTask.build_model(cfg)
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == g["shapes"]
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    assert model.sos == model.eos == int(g["vocab"]) - 1 and model.blank_id == 0
+
+
+def test_unsupported_choices_raise():
+    from espnet_amd.tasks.asr import ASRTask
+
+    g = load_golden("tiny_blocks")
+    cfg = dict(g["config"])
+    cfg["encoder"] = "transformer"
+    with pytest.raises(NotImplementedError):
+        ASRTask.build_model(cfg)
+    cfg = dict(g["config"])
+    cfg["encoder_conf"] = dict(cfg["encoder_conf"], rel_pos_type="legacy")
+    with pytest.raises(NotImplementedError):
+        ASRTask.build_model(cfg)
+
+
+def test_lengths_match_oracle():
+    import random
+
+    from espnet_amd.nets_utils import conv2d_subsampled_lengths, stft_frame_lengths
+    from oracle.conformer import subsampled_lengths
+
+    assert stft_frame_lengths([30, 15], 4, 2) == [16, 8]  # test/espnet2/layers/test_stft.py:10-16
+    rng = random.Random(0)
+    for _ in range(300):
+        tmax = rng.randint(7, 400)
+        fl = [rng.randint(1, tmax) for _ in range(4)] + [tmax]
+        assert conv2d_subsampled_lengths(fl, tmax) == subsampled_lengths(torch.tensor(fl), tmax).tolist()
+
+
+def test_mel_band_packing_is_exact():
+    from espnet_amd.layers.log_mel import mel_filterbank, pack_banded
+
+    g = load_golden("small_10s")
+    m = mel_filterbank(16000, 512, 80, 0, 8000)
+    assert (m == g["melmat"]).all()
+    packed, lo, maxlen = pack_banded(torch.from_numpy(m))
+    dense = torch.zeros(257, 80)
+    for j in range(80):
+        for s in range(maxlen):
+            if lo[j] + s < 257:
+                dense[lo[j] + s, j] += packed[s, j]
+    assert torch.equal(dense, torch.from_numpy(m))
+
+
+def test_rel_pos_table_matches_oracle():
+    from espnet_amd.asr.encoder.conformer_encoder import rel_pos_table
+    from oracle.conformer import rel_pos_emb
+
+    for T, d in [(24, 64), (249, 256)]:
+        assert torch.equal(rel_pos_table(T, d), rel_pos_emb(T, d))

@@ -1,0 +1,286 @@
+"""GPU parity tests, kernel by kernel: every HIP kernel (called through the C ABI) against the
+oracle's CPU-fp32 restatement on the same seeded inputs.
+
+Tolerances (stated per SURVEY.md §8(c)):
+  * EM_F32 (exact-f32 MFMA): only the summation order differs from the CPU -> atol/rtol 1e-4 class.
+  * EM_BF16: operands rounded to bf16 (8 mantissa bits), f32 accumulate.  The reference value is
+    computed in f32 FROM THE SAME bf16-ROUNDED OPERANDS, so what is checked is the kernel, not
+    the rounding: 2e-2 relative to the output scale (output itself is rounded to bf16).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from espnet_amd import lib as L
+from oracle import conformer as oc
+
+pytestmark = pytest.mark.gpu
+DT = {"f32": (L.EM_F32, torch.float32), "bf16": (L.EM_BF16, torch.bfloat16)}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return L.load()
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def sptr():
+    return L.current_stream_ptr()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, tdt):
+    """Round to the activation dtype and come back to f32 (what the kernel actually sees)."""
+    return t.to(tdt).to(torch.float32)
+
+
+def assert_close(got, ref, tol, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def gemm(lib, dt, epi, A, W, C, bias, M, N, K, lda, ldc, scale=1.0, amode=L.EM_A_PLAIN, conv=None):
+    a = L.EmGemmArgs(A=A.data_ptr(), W=W.data_ptr(), C=C.data_ptr(),
+                     bias=0 if bias is None else bias.data_ptr(), M=M, N=N, K=K, lda=lda, ldc=ldc,
+                     scale=scale)
+    if conv:
+        a.T1, a.F1, a.T2, a.F2, a.d = conv
+    L.check(lib.em_gemm(dt, epi, amode, a, sptr()), "em_gemm")
+
+
+# --------------------------------------------------------------------------- MFMA layout
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_gemm_identity_asymmetric(lib, prec):
+    """A = I against an asymmetric W catches operand / output transposes (C must equal W^T)."""
+    dt, tdt = DT[prec]
+    n = 128
+    A = torch.eye(n)
+    W = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) / 16.0  # exact in bf16? keep small ints/16
+    W = q(W, tdt)
+    C = torch.zeros(n, n, dtype=torch.float32, device="cuda")
+    gemm(lib, dt, L.EM_EPI_STORE_F32, dev(A.to(tdt)), dev(W.to(tdt)), C, None, n, n, n, n, n)
+    torch.cuda.synchronize()
+    assert torch.equal(C.cpu(), W.t().contiguous())
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 256), (497, 768, 256), (1000, 5000, 256),
+                                   (77, 256, 1024)])
+def test_gemm_store_f32(lib, prec, M, N, K):
+    dt, tdt = DT[prec]
+    A, W, b = q(rnd(M, K, seed=1), tdt), q(rnd(N, K, seed=2, scale=K ** -0.5), tdt), rnd(N, seed=3)
+    C = torch.full((M, N), 7.0, dtype=torch.float32, device="cuda")
+    gemm(lib, dt, L.EM_EPI_STORE_F32, dev(A.to(tdt)), dev(W.to(tdt)), C, dev(b), M, N, K, K, N)
+    ref = A @ W.t() + b
+    assert_close(C, ref, 2e-5 if prec == "f32" else 2e-5, f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_gemm_epilogues(lib, prec):
+    dt, tdt = DT[prec]
+    M, N, K = 300, 256, 128
+    tol = 1e-5 if prec == "f32" else 1e-2
+    A, W, b = q(rnd(M, K, seed=4), tdt), q(rnd(N, K, seed=5, scale=K ** -0.5), tdt), rnd(N, seed=6)
+    Ad, Wd, bd = dev(A.to(tdt)), dev(W.to(tdt)), dev(b)
+    lin = A @ W.t() + b
+    for epi, fn in [(L.EM_EPI_STORE, lambda v: v), (L.EM_EPI_SWISH, oc.swish), (L.EM_EPI_RELU, F.relu)]:
+        C = torch.zeros(M, N, dtype=tdt, device="cuda")
+        gemm(lib, dt, epi, Ad, Wd, C, bd, M, N, K, K, N)
+        assert_close(C, fn(lin), tol, f"epi {epi}")
+    x0 = rnd(M, N, seed=7)
+    C = dev(x0.clone())
+    gemm(lib, dt, L.EM_EPI_RESID_F32, Ad, Wd, C, bd, M, N, K, K, N, scale=0.5)
+    assert_close(C, x0 + 0.5 * lin, 1e-5, "resid")
+    C = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    gemm(lib, dt, L.EM_EPI_SCALE_F32, Ad, Wd, C, bd, M, N, K, K, N, scale=16.0)
+    assert_close(C, 16.0 * lin, 1e-5, "scale")
+    # GLU: rows interleaved in 16-row granules [v | g]
+    d = N // 2
+    perm = torch.arange(N).reshape(2, d // 16, 16).permute(1, 0, 2).reshape(-1)
+    C = torch.zeros(M, d, dtype=tdt, device="cuda")
+    gemm(lib, dt, L.EM_EPI_GLU, Ad, dev(W[perm].to(tdt)), C, dev(b[perm]), M, N, K, K, d)
+    assert_close(C, F.glu(lin, dim=1), tol, "glu")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_conv2_implicit_gemm(lib, prec):
+    dt, tdt = DT[prec]
+    B, T1, F1, d = 2, 23, 39, 64
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    x = q(rnd(B, d, T1, F1, seed=8), tdt)           # NCHW for the reference
+    w = q(rnd(d, d, 3, 3, seed=9, scale=(9 * d) ** -0.5), tdt)
+    b = rnd(d, seed=10)
+    ref = F.relu(F.conv2d(x, w, b, stride=2))       # (B, d, T2, F2)
+    xcl = dev(x.permute(0, 2, 3, 1).to(tdt))        # (B, T1, F1, d) channel-last
+    wp = dev(w.permute(0, 2, 3, 1).reshape(d, 9 * d).to(tdt))
+    C = torch.zeros(B * T2 * F2, d, dtype=tdt, device="cuda")
+    gemm(lib, dt, L.EM_EPI_RELU, xcl, wp, C, dev(b), B * T2 * F2, d, 9 * d, 0, d, amode=L.EM_A_CONV2,
+         conv=(T1, F1, T2, F2, d))
+    got = C.float().cpu().reshape(B, T2, F2, d).permute(0, 3, 1, 2)
+    assert_close(got, ref, 2e-5 if prec == "f32" else 1e-2, "conv2")
+
+
+# --------------------------------------------------------------------------- frontend
+def _frontend(lib, speech, lens, melmat, win_length, hop):
+    from espnet_amd.asr.frontend.default import DefaultFrontend
+
+    fe = DefaultFrontend(n_fft=512, win_length=win_length, hop_length=hop)
+    fe.logmel.melmat.copy_(melmat)
+    fe.cuda()
+    return fe(dev(speech), lens)
+
+
+@pytest.mark.parametrize("win_length,hop", [(400, 160), (None, 160), (512, 128)])
+def test_frontend_logmel(lib, win_length, hop):
+    from oracle.mel import slaney_mel_filterbank
+    from oracle.weights import synth_waveform
+
+    melmat = torch.from_numpy(slaney_mel_filterbank(16000, 512, 80, 0, 8000).T.copy())
+    lens = torch.tensor([16000, 12345, 5000])
+    speech = torch.zeros(3, 16000)
+    for i, n in enumerate(lens.tolist()):
+        speech[i, :n] = synth_waveform(20 + i, n)
+    ref, rlens = oc.frontend_feats(speech, lens, melmat, 512, win_length, hop)
+    got, glens = _frontend(lib, speech, lens, melmat, win_length, hop)
+    assert glens.tolist() == rlens.tolist()
+    # log-mel of N(0, 0.1^2) noise: abs 1e-4; the log amplifies the relative f32
+    # FFT error of low-power bins, hence absolute tolerance on the log value.
+    err = (got.cpu() - ref).abs().max().item()
+    assert err < 2e-4, err
+
+
+def test_utt_mvn_and_conv1(lib):
+    B, T_f, D, d = 3, 61, 80, 64
+    feats = rnd(B, T_f, D, seed=11) * 2 - 8
+    flens = torch.tensor([61, 40, 7])
+    feats = feats.masked_fill(oc.make_pad_mask(flens, T_f)[:, :, None], 0.0)
+    fl = dev(flens.to(torch.int32))
+    partial = torch.empty(B, 8, D, device="cuda")
+    L.check(lib.em_utt_mvn_partial_f32(L.ptr(dev(feats)), L.ptr(fl), B, T_f, D, L.ptr(partial), sptr()))
+    mean = partial.sum(1).cpu() / flens[:, None].float()
+    ref_mean = feats.sum(1) / flens[:, None].float()
+    assert_close(mean, ref_mean, 1e-6, "mvn mean")
+    w1, b1 = rnd(d, 1, 3, 3, seed=12, scale=1 / 3), rnd(d, seed=13, scale=0.1)
+    normed = oc.utterance_mvn(feats, flens)
+    ref = F.relu(F.conv2d(normed.unsqueeze(1), w1, b1, stride=2)).permute(0, 2, 3, 1)  # (B,T1,F1,d)
+    T1, F1 = ref.shape[1], ref.shape[2]
+    for prec, tol in (("f32", 1e-5), ("bf16", 1e-2)):
+        dt, tdt = DT[prec]
+        out = torch.zeros(B, T1, F1, d, dtype=tdt, device="cuda")
+        L.check(lib.em_conv2d_sub1(dt, L.ptr(dev(feats)), L.ptr(partial), L.ptr(fl), B, T_f, D,
+                                   L.ptr(dev(w1.reshape(d, 9))), L.ptr(dev(b1)), d, L.ptr(out), sptr()))
+        assert_close(out, ref, tol, f"conv1 {prec}")
+
+
+# --------------------------------------------------------------------------- norm / conv / attention
+@pytest.mark.parametrize("d", [64, 256, 512])
+def test_layernorm(lib, d):
+    M = 77
+    x = rnd(M, d, seed=14) * 3 + 1
+    g1, b1, g2, b2 = 1 + 0.1 * rnd(d, seed=15), 0.1 * rnd(d, seed=16), 1 + 0.1 * rnd(d, seed=17), 0.1 * rnd(d, seed=18)
+    ref1 = F.layer_norm(x, (d,), g1, b1, 1e-12)
+    ref2 = F.layer_norm(ref1, (d,), g2, b2, 1e-12)
+    for prec, tol in (("f32", 2e-6), ("bf16", 1e-2)):
+        dt, tdt = DT[prec]
+        out = torch.zeros(M, d, dtype=tdt, device="cuda")
+        of = torch.zeros(M, d, device="cuda")
+        L.check(lib.em_layernorm(dt, L.ptr(dev(x)), L.ptr(dev(g1)), L.ptr(dev(b1)), M, d, 1e-12,
+                                 L.ptr(out), L.ptr(of), sptr()))
+        assert_close(out, ref1, tol, "ln")
+        assert_close(of, ref1, 2e-6, "ln f32 copy")
+        xd = dev(x.clone())
+        L.check(lib.em_layernorm2(dt, L.ptr(xd), L.ptr(dev(g1)), L.ptr(dev(b1)), L.ptr(dev(g2)),
+                                  L.ptr(dev(b2)), M, d, 1e-12, L.ptr(out), L.ptr(of), sptr()))
+        assert_close(xd, ref1, 2e-6, "ln2 in-place")
+        assert_close(out, ref2, tol, "ln2 out")
+        assert_close(of, ref2, 4e-6, "ln2 f32")
+
+
+@pytest.mark.parametrize("k", [31, 15])
+def test_dwconv_bn_swish(lib, k):
+    B, T, d = 2, 50, 128
+    x = rnd(B, T, d, seed=19)
+    w, b = rnd(d, 1, k, seed=20, scale=k ** -0.5), rnd(d, seed=21, scale=0.1)
+    gam, bet = 1 + 0.1 * rnd(d, seed=22), 0.1 * rnd(d, seed=23)
+    mean, var = 0.1 * rnd(d, seed=24), torch.rand(d, generator=torch.Generator().manual_seed(25)) + 0.5
+    scale = gam / torch.sqrt(var + 1e-5)
+    wf, bf = (w.reshape(d, k) * scale[:, None]), (b - mean) * scale + bet
+    for prec, tol in (("f32", 2e-6), ("bf16", 1e-2)):
+        dt, tdt = DT[prec]
+        xq = q(x, tdt)
+        y = F.conv1d(xq.transpose(1, 2), w, b, padding=(k - 1) // 2, groups=d)
+        y = F.batch_norm(y, mean, var, gam, bet, False, 0.0, 1e-5)
+        ref = oc.swish(y).transpose(1, 2)
+        out = torch.zeros(B, T, d, dtype=tdt, device="cuda")
+        L.check(lib.em_dwconv_bn_swish(dt, L.ptr(dev(xq.to(tdt))), L.ptr(dev(wf)), L.ptr(dev(bf)), B, T,
+                                       d, k, L.ptr(out), sptr()))
+        assert_close(out, ref, tol, f"dwconv {prec}")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("T,klens", [(74, [74, 59, 26]), (249, [249, 100]), (130, [130, 1])])
+def test_relpos_attention(lib, prec, T, klens):
+    dt, tdt = DT[prec]
+    B, h, dk = len(klens), 2, 64
+    d = h * dk
+    qkv = q(rnd(B, T, 3 * d, seed=26), tdt)
+    p = q(rnd(2 * T - 1, d, seed=27), tdt)
+    u, v = rnd(h, dk, seed=28, scale=0.3), rnd(h, dk, seed=29, scale=0.3)
+    qq = qkv[..., :d].reshape(B, T, h, dk)
+    kk = qkv[..., d:2 * d].reshape(B, T, h, dk).transpose(1, 2)
+    vv = qkv[..., 2 * d:].reshape(B, T, h, dk).transpose(1, 2)
+    pp = p.reshape(1, 2 * T - 1, h, dk).transpose(1, 2)
+    q_u = q(qq + u, tdt).transpose(1, 2)
+    q_v = q(qq + v, tdt).transpose(1, 2)
+    ac = q_u @ kk.transpose(-2, -1)
+    bd = oc.rel_shift(q_v @ pp.transpose(-2, -1))
+    scores = (ac + bd) / math.sqrt(dk)
+    valid = ~oc.make_pad_mask(torch.tensor(klens), T)
+    mask = ~valid[:, None, None, :]
+    attn = torch.softmax(scores.masked_fill(mask, torch.finfo(torch.float32).min), -1).masked_fill(mask, 0.0)
+    ref = (attn @ vv).transpose(1, 2).reshape(B, T, d)
+    ctx = torch.zeros(B, T, d, dtype=tdt, device="cuda")
+    L.check(lib.em_relpos_attention(dt, L.ptr(dev(qkv.to(tdt))), L.ptr(dev(p.to(tdt))), d, L.ptr(dev(u)),
+                                    L.ptr(dev(v)), L.ptr(dev(torch.tensor(klens, dtype=torch.int32))),
+                                    B, T, h, dk, L.ptr(ctx), sptr()))
+    assert_close(ctx, ref, 2e-5 if prec == "f32" else 2e-2, f"attention {prec} T={T}")
+
+
+# --------------------------------------------------------------------------- CTC head
+def test_argmax_logsoftmax_collapse(lib):
+    M, V = 333, 5000
+    x = rnd(M, V, seed=30)
+    x[5, 17] = x[5, 4000] = 9.0  # tie -> lowest index
+    xd = dev(x)
+    ids = torch.zeros(M, dtype=torch.int32, device="cuda")
+    L.check(lib.em_argmax_rows_f32(L.ptr(xd), M, V, L.ptr(ids), sptr()))
+    assert torch.equal(ids.cpu().long(), torch.argmax(x, dim=1))
+    assert ids[5].item() == 17
+    L.check(lib.em_log_softmax_rows_f32(L.ptr(xd), M, V, sptr()))
+    assert_close(xd, F.log_softmax(x, dim=1), 1e-6, "log_softmax")
+    B, T = 4, 150
+    g = torch.Generator().manual_seed(31)
+    idm = torch.randint(0, 4, (B, T), generator=g, dtype=torch.int32)
+    idm[idm == 3] = 49
+    olens = torch.tensor([150, 64, 65, 1], dtype=torch.int32)
+    tok = torch.zeros(B, T, dtype=torch.int32, device="cuda")
+    tl = torch.zeros(B, dtype=torch.int32, device="cuda")
+    L.check(lib.em_ctc_collapse(L.ptr(dev(idm)), L.ptr(dev(olens)), B, T, 0, 49, L.ptr(tok), L.ptr(tl), sptr()))
+    for b in range(B):
+        ref = oc.g1_collapse(idm[b, : olens[b]].tolist(), (0, 49))
+        assert tl[b].item() == len(ref)
+        assert tok[b, : len(ref)].cpu().tolist() == ref
+        assert (tok[b, len(ref):] == -1).all()
