@@ -27,8 +27,23 @@ def lib():
     return L.load()
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.contiguous().cuda()
+    """Copy to the GPU and keep the tensor alive until the test ends: `L.ptr(dev(x))` hands a raw
+    pointer to the C ABI, and a temporary would be freed (and its block re-used by the caching
+    allocator) before the kernel runs."""
+    t = t.contiguous().cuda()
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_kept_tensors():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def sptr():
