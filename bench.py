@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — audio-seconds/sec (RTF^-1) of the ASR-inference hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic utterances already resident in
+HBM: HIP STFT/log-mel frontend -> HIP Conformer encoder -> greedy CTC (G1) decode, all ranks'
+hypotheses collated with one RCCL all-gather per step (N > 1).  Workload = BASELINE.json
+configs[1]: Conformer-small (12 x 256d, 4 heads, ff 1024), batch 32 x 10 s @ 16 kHz per GPU
+(weak scaling: per-GPU batch fixed).  Random-init weights (torch.manual_seed(0)), synthetic
+N(0, 0.1^2) waveforms.
+
+One JSON line on rank 0 carries the throughput, the roofline of the dominant kernel family (the
+MFMA GEMM template, measured live with HIP events around every GEMM launch of extra steps run
+right after the timed region), and the CPU baseline (the oracle port on this box's host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+AUDIO_SEC = 10.0
+N_SAMPLES = 160000
+VOCAB = 5000
+MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    "small": dict(d=256, heads=4, ff=1024, win_length=400),
+    "large": dict(d=512, heads=8, ff=2048, win_length=None),
+}
+
+
+def model_config(name, dtype):
+    c = CONFIGS[name]
+    fconf = dict(n_fft=512, hop_length=160)
+    if c["win_length"]:
+        fconf["win_length"] = c["win_length"]
+    return dict(
+        token_list=["<blank>", "<unk>"] + [f"t{i}" for i in range(VOCAB - 3)] + ["<sos/eos>"],
+        frontend="default", frontend_conf=fconf, normalize="utterance_mvn", normalize_conf={},
+        encoder="conformer",
+        encoder_conf=dict(output_size=c["d"], attention_heads=c["heads"], linear_units=c["ff"],
+                          num_blocks=12, input_layer="conv2d", normalize_before=True,
+                          macaron_style=True, rel_pos_type="latest", pos_enc_layer_type="rel_pos",
+                          selfattention_layer_type="rel_selfattn", activation_type="swish",
+                          use_cnn_module=True, cnn_module_kernel=31),
+        decoder="transformer",
+        decoder_conf=dict(attention_heads=c["heads"], linear_units=2048, num_blocks=6),
+        model_conf=dict(ctc_weight=0.3), compute_dtype=dtype)
+
+
+def synth_batch(first_utt, batch):
+    wav = torch.empty(batch, N_SAMPLES)
+    for i in range(batch):
+        g = torch.Generator().manual_seed(1000 + first_utt + i)
+        wav[i] = torch.randn(N_SAMPLES, generator=g) * 0.1
+    return wav
+
+
+def cpu_baseline(model, budget_s=12.0):
+    """Oracle port (oracle/conformer.py = CPU-fp32 restatement of the reference path) timed on
+    the host cores, batch 1 (the reference's own inference batch, asr_inference.py:760-765)."""
+    from oracle import conformer as oc
+
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    enc = model.encoder
+    fe = model.frontend
+    # oversubscribing a many-core host makes torch-CPU slower, not faster: cap at 32 threads of
+    # the cores this process may run on, and report exactly the thread count used.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(32, avail))
+    torch.set_num_threads(cores)
+    wl = fe.win_length
+    times = []
+    t_start = time.perf_counter()
+    i = 0
+    with torch.no_grad():
+        while True:
+            wav = synth_batch(9000 + i, 1)
+            t0 = time.perf_counter()
+            e, ol = oc.encode(sd, wav, torch.tensor([N_SAMPLES]), enc.heads, enc.num_blocks, 512, wl, 160)
+            oc.greedy_ctc(sd, e, ol, blank=0, sos_eos=VOCAB - 1)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                times.append(dt)
+            i += 1
+            if (time.perf_counter() - t_start > budget_s and len(times) >= 3) or len(times) >= 200:
+                break
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(AUDIO_SEC / med, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"oracle CPU-fp32 port, {len(times)} utterances of 10 s, batch 1, median "
+                      f"{med*1e3:.1f} ms/utt (frontend + encoder + greedy CTC G1), 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--model", default="small", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from espnet_amd import lib as L
+    from espnet_amd.tasks.asr import ASRTask
+
+    torch.manual_seed(0)
+    model = ASRTask.build_model(model_config(args.model, args.dtype)).to(dev).eval()
+    B = args.batch
+    wav = synth_batch(rank * B, B).to(dev)
+    lens = [N_SAMPLES] * B
+    T = model.encoder.output_frames(1 + N_SAMPLES // 160)
+    gathered_tok = torch.empty(world * B, T, dtype=torch.int32, device=dev) if world > 1 else None
+    gathered_len = torch.empty(world * B, dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        st = model.encode_device(wav, lens)
+        _, tokens, tlens = model.greedy_ctc_device(st)
+        if world > 1:  # collate hypotheses: one RCCL all-gather of fixed-shape ids + lengths
+            dist.all_gather_into_tensor(gathered_tok, tokens)
+            dist.all_gather_into_tensor(gathered_len, tlens)
+        return tokens, tlens
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tokens, tlens = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    n_tok = int(tlens.sum().item())
+
+    out = None
+    if rank == 0:
+        value = world * B * AUDIO_SEC * args.steps / elapsed
+        out = {
+            "metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances",
+            "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: Conformer-{args.model} "
+                                   f"(12x{CONFIGS[args.model]['d']}d, {CONFIGS[args.model]['heads']} heads), "
+                                   f"HIP STFT/log-mel + HIP encoder + greedy CTC (G1), "
+                                   f"{B} x 10 s utterances per GPU per step, V={VOCAB}",
+                       "batch_per_gpu": B, "global_batch": world * B, "audio_seconds_per_utt": AUDIO_SEC,
+                       "parallelism": f"utterance-dp{world}", "greedy_tokens_last_step_rank0": n_tok},
+        }
+    # ---- roofline of the dominant kernel family (GEMM template): HIP events around every launch
+    if rank == 0 and not args.no_roofline:
+        lib = L.load()
+        cap = 4096
+        prof = lib.em_profile_create(cap)
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        cnt = C.c_int32(0)
+        tot_ms = tot_fl = 0.0
+        launches = 0
+        nprof = max(1, min(args.steps, 5))
+        with torch.no_grad():
+            for _ in range(nprof):
+                lib.em_profile_attach(prof)
+                model.greedy_ctc_device(model.encode_device(wav, lens))
+                lib.em_profile_attach(None)
+                L.check(lib.em_profile_read(prof, ms, fl, cap, C.byref(cnt)), "em_profile_read")
+                tot_ms += sum(ms[i] for i in range(cnt.value))
+                tot_fl += sum(fl[i] for i in range(cnt.value))
+                launches += cnt.value
+        lib.em_profile_destroy(prof)
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": "gemm_kernel<T,EPI,AMODE> (all instantiations)",
+            "launches_per_step": launches // nprof,
+            "avg_launch_us": round(tot_ms * 1e3 / launches, 2),
+            "algorithmic_gflop_per_step": round(tot_fl / nprof / 1e9, 2),
+            "gemm_ms_per_step": round(tot_ms / nprof, 3),
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

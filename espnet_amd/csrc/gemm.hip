@@ -5,134 +5,169 @@
 // Conv1d(k=1) (convolution.py:28-53) and Conv2d(d,d,3,2) as an implicit GEMM over a channel-last
 // feature map (subsampling.py:402-403).
 //
-// Tile: 128x128 per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA 16x16 tiles),
-// K-step = 128 bytes of K per row (64 bf16 / 32 f32), register-prefetched, LDS rows padded to
-// 144 B.  f32 accumulate in both modes; EM_F32 uses v_mfma_f32_16x16x4_f32 (exact f32 products),
-// EM_BF16 uses v_mfma_f32_16x16x32_bf16.
+// Structure (256 threads = 2x2 waves, BM x 128 output tile, BM in {128, 64}):
+//   * operands stream HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging), double
+//     buffered; loads of K-step t+1 stay in flight across the barriers of step t (counted
+//     s_waitcnt vmcnt + raw s_barrier, never a draining __syncthreads);
+//   * LDS rows are 128 B of K (64 bf16 / 32 f32), stored linearly as the DMA requires and
+//     XOR-swizzled on the SOURCE address (16-byte chunk c of row r lands at chunk c ^ (r & 7)),
+//     so ds_read_b128 fragment reads are bank-conflict free;
+//   * f32 accumulate in both modes: EM_BF16 -> v_mfma_f32_16x16x32_bf16, EM_F32 ->
+//     v_mfma_f32_16x16x4_f32 (exact f32 products; the parity mode);
+//   * epilogue: accumulators go through a per-wave LDS transpose so global stores are 8/16-byte
+//     per lane over 128-256 B contiguous row segments (bias / activation / residual fused).
 #include "em_common.h"
+
+struct EmProfile {
+  int capacity, count;
+  hipEvent_t *start, *stop;
+  double* flops;
+};
+static thread_local EmProfile* tl_profile = nullptr;
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int ROW_BYTES = 128;   // K bytes per row per K-step
-constexpr int LDS_STRIDE = 144;  // bytes (16 B pad against ds_read bank conflicts)
+constexpr int BN = 128;
+constexpr int ROWB = 128;  // bytes of K per LDS row per K-step
 
 struct ConvGeom {
   int T1, F1, T2, F2, d;
 };
 
-template <typename T, int EPI, int AMODE>
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+__device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int EPI, int AMODE, int BM>
 __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
                                                    const T* __restrict__ W, void* __restrict__ Cv,
                                                    const float* __restrict__ bias, int M, int N,
                                                    int K, int lda, int ldc, float scale,
                                                    ConvGeom g) {
-  constexpr int BK = ROW_BYTES / (int)sizeof(T);  // elements of K per step
-  constexpr int CH = 16 / (int)sizeof(T);         // elements per 16-byte chunk
-  constexpr int KSUB = BK / Mma<T>::K;            // MFMA k-steps per K-step
-  __shared__ __attribute__((aligned(16))) unsigned char s_a[BM * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) unsigned char s_b[BN * LDS_STRIDE];
+  using MM = Mma<T>;
+  constexpr int BK = ROWB / (int)sizeof(T);  // K elements per step
+  constexpr int KSUB = BK / MM::K;           // MFMA k-steps per K-step
+  constexpr int MI = BM / 32;                // 16-row fragments per wave along M (wave tile BM/2 x 64)
+  constexpr int A_LD = BM / 32;              // glds instructions per wave for the A tile (8 rows each)
+  constexpr int W_LD = BN / 32;
+  constexpr int NLOADS = A_LD + W_LD;
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, BUF = A_BYTES + W_BYTES;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lr = lane & 15, lg = lane >> 4;
 
-  // ---- staging assignment: chunk c = tid + 256 i  ->  row c/8, 16-byte piece c%8
-  const int piece = tid & 7;
-  size_t a_base[4], w_base[4];
+  // ---- per-lane global source addresses.  Load instruction i of this wave fills LDS rows
+  // (wave*LD + i)*8 .. +7; lane l supplies row (l >> 3) of those, LDS chunk (l & 7), i.e. global
+  // chunk (l & 7) ^ (row & 7) = (l & 7) ^ (l >> 3).
+  const int ld_row = lane >> 3;
+  const int ld_chunk = (lane & 7) ^ ld_row;
+  const unsigned char* a_src[A_LD];
+  const unsigned char* w_src[W_LD];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int row = (tid >> 3) + 32 * i;
-    int m = m0 + row;
+  for (int i = 0; i < A_LD; ++i) {
+    int m = m0 + (wave * A_LD + i) * 8 + ld_row;
     m = m < M ? m : M - 1;
+    size_t base;
     if (AMODE == EM_A_CONV2) {
       int per_b = g.T2 * g.F2;
       int bb = m / per_b, rem = m - bb * per_b;
       int t2 = rem / g.F2, f2 = rem - t2 * g.F2;
-      a_base[i] = ((size_t)(bb * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.d;
+      base = ((size_t)(bb * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.d;
     } else {
-      a_base[i] = (size_t)m * lda;
+      base = (size_t)m * lda;
     }
-    int n = n0 + row;
+    a_src[i] = (const unsigned char*)(A + base) + ld_chunk * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < W_LD; ++i) {
+    int n = n0 + (wave * W_LD + i) * 8 + ld_row;
     n = n < N ? n : N - 1;
-    w_base[i] = (size_t)n * K;
+    w_src[i] = (const unsigned char*)(W + (size_t)n * K) + ld_chunk * 16;
   }
 
-  uint4 ra[4], rb[4];
-  auto load_tile = [&](int k0) {
-    size_t koff = k0;
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    size_t koff = (size_t)k0;
     if (AMODE == EM_A_CONV2) {
       int q = k0 / g.d, c0 = k0 - q * g.d;
-      int kt = q / 3, kf = q - kt * 3;
-      koff = (size_t)(kt * g.F1 + kf) * g.d + c0;
+      int t3 = q / 3, f3 = q - t3 * 3;
+      koff = (size_t)(t3 * g.F1 + f3) * g.d + c0;
     }
+    unsigned char* sa = smem + buf * BUF;
+    unsigned char* sw = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *(const uint4*)(A + a_base[i] + koff + piece * CH);
-      rb[i] = *(const uint4*)(W + w_base[i] + k0 + piece * CH);
-    }
-  };
-  auto store_tile = [&]() {
+    for (int i = 0; i < A_LD; ++i)
+      glds16(a_src[i] + koff * sizeof(T), sa + (wave * A_LD + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int row = (tid >> 3) + 32 * i;
-      *(uint4*)(s_a + row * LDS_STRIDE + piece * 16) = ra[i];
-      *(uint4*)(s_b + row * LDS_STRIDE + piece * 16) = rb[i];
-    }
+    for (int i = 0; i < W_LD; ++i)
+      glds16(w_src[i] + (size_t)k0 * sizeof(T), sw + (wave * W_LD + i) * 1024);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int frag_row = lane & 15;
-  const int frag_koff = (lane >> 4) * Mma<T>::EPL * (int)sizeof(T);  // bytes
-  const unsigned char* pa = s_a + (wr * 64 + frag_row) * LDS_STRIDE + frag_koff;
-  const unsigned char* pb = s_b + (wc * 64 + frag_row) * LDS_STRIDE + frag_koff;
+  // fragment read offsets: row = tile_row + lr (tile_row % 16 == 0 -> row & 7 == lr & 7)
+  const int swz = lr & 7;
+  const int a_row_off = (wr * (BM / 2) + lr) * ROWB;
+  const int w_row_off = (wc * 64 + lr) * ROWB;
 
   const int nk = K / BK;
-  load_tile(0);
-  store_tile();
-  __syncthreads();
+  issue(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      issue(kt + 1, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // tile kt has landed for every wave
+    const unsigned char* sa = smem + cur * BUF;
+    const unsigned char* sw = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < KSUB; ++ks) {
-      typename Mma<T>::frag fa[4], fb[4];
+      int coff;  // byte offset inside the 128-byte row
+      if (sizeof(T) == 2) coff = (((ks * 4 + lg) ^ swz) << 4);
+      else coff = ((ks ^ swz) << 4) + lg * 4;
+      typename MM::frag fa[MI], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = Mma<T>::load((const T*)(pa + i * 16 * LDS_STRIDE + ks * Mma<T>::K * (int)sizeof(T)));
-        fb[i] = Mma<T>::load((const T*)(pb + i * 16 * LDS_STRIDE + ks * Mma<T>::K * (int)sizeof(T)));
-      }
+      for (int i = 0; i < MI; ++i) fa[i] = MM::load((const T*)(sa + a_row_off + i * 16 * ROWB + coff));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) fb[j] = MM::load((const T*)(sw + w_row_off + j * 16 * ROWB + coff));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      store_tile();
-      __syncthreads();
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done reading buf[cur]
   }
 
   // ---- epilogue.  C/D layout: col = lane & 15, row = (lane >> 4) * 4 + r.
-  const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+  const int wm0 = m0 + wr * (BM / 2), wn0 = n0 + wc * 64;
   if (EPI == EM_EPI_GLU) {
+    // value/gate column pairs sit in neighbouring fragments of the same lane: direct stores.
     T* C = (T*)Cv;
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
-      int ncol = n0 + wc * 64 + j * 16 + col_l;  // packed column of the value half
+      int ncol = wn0 + j * 16 + lr;  // packed column of the value half
       if (ncol >= N) continue;
       float bv = bias ? bias[ncol] : 0.f, bg = bias ? bias[ncol + 16] : 0.f;
-      int ocol = (n0 + wc * 64 + j * 16) / 2 + col_l;
+      int ocol = (wn0 + j * 16) / 2 + lr;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int m = m0 + wr * 64 + i * 16 + row_l + r;
+          int m = wm0 + i * 16 + lg * 4 + r;
           if (m < M) {
             float v = acc[i][j][r] + bv, gt = acc[i][j + 1][r] + bg;
             C[(size_t)m * ldc + ocol] = from_f32<T>(v * sigmoidf_(gt));
@@ -141,35 +176,106 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     }
     return;
   }
+  // per-wave LDS transpose of the whole wave tile: [BM/2 rows][64 cols] f32 (16 KiB per wave at
+  // BM = 128; exactly the 64 KiB of staging LDS), 16-column groups XOR-swizzled by (row >> 2) & 3.
+  // Three phases (all LDS writes -> all LDS reads -> math + global stores): hipcc orders every
+  // ds access after an LDS-DMA behind vmcnt(0), so no LDS access may follow the first store.
+  constexpr int WROWS = BM / 2;
+  float* ep = (float*)smem + wave * (WROWS * 64);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int n = n0 + wc * 64 + j * 16 + col_l;
-    if (n >= N) continue;
-    float bj = bias ? bias[n] : 0.f;
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int m = m0 + wr * 64 + i * 16 + row_l + r;
-        if (m >= M) continue;
-        float v = acc[i][j][r] + bj;
-        size_t o = (size_t)m * ldc + n;
-        if (EPI == EM_EPI_STORE) ((T*)Cv)[o] = from_f32<T>(v);
-        else if (EPI == EM_EPI_SWISH) ((T*)Cv)[o] = from_f32<T>(swishf_(v));
-        else if (EPI == EM_EPI_RELU) ((T*)Cv)[o] = from_f32<T>(fmaxf(v, 0.f));
-        else if (EPI == EM_EPI_RESID_F32) ((float*)Cv)[o] += scale * v;
-        else if (EPI == EM_EPI_SCALE_F32) ((float*)Cv)[o] = scale * v;
-        else if (EPI == EM_EPI_STORE_F32) ((float*)Cv)[o] = v;
+      for (int r = 0; r < 4; ++r)
+        ep[(i * 16 + lg * 4 + r) * 64 + ((j ^ lg) << 4) + lr] = acc[i][j][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int jg = (lane & 15) >> 2, cin = (lane & 3) * 4;
+  float4 vals[MI * 4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr)
+      vals[i * 4 + jr] = *(const float4*)(ep + (i * 16 + jr * 4 + lg) * 64 + ((jg ^ jr) << 4) + cin);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  const int c4 = (lane & 15) * 4;  // 4 consecutive output columns handled by this lane
+  const int ncol = wn0 + c4;
+  if (ncol >= N) return;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) {
+    b4.x = bias[ncol];
+    b4.y = ncol + 1 < N ? bias[ncol + 1] : 0.f;
+    b4.z = ncol + 2 < N ? bias[ncol + 2] : 0.f;
+    b4.w = ncol + 3 < N ? bias[ncol + 3] : 0.f;
+  }
+  const bool full4 = (ncol + 3 < N) && ((ldc & 3) == 0);
+#pragma unroll
+  for (int q = 0; q < MI * 4; ++q) {
+    const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
+    if (m >= M) continue;
+    float4 v = vals[q];
+    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+    if (EPI == EM_EPI_SWISH) {
+      v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w);
+    } else if (EPI == EM_EPI_RELU) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    const size_t o = (size_t)m * ldc + ncol;
+    if (EPI == EM_EPI_STORE || EPI == EM_EPI_SWISH || EPI == EM_EPI_RELU) {
+      T* C = (T*)Cv + o;
+      if (full4) {
+        if (sizeof(T) == 2) {
+          bf16x4 pk = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+          *(bf16x4*)C = pk;
+        } else {
+          *(float4*)C = v;
+        }
+      } else {
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < 4; ++e)
+          if (ncol + e < N) C[e] = from_f32<T>(vv[e]);
       }
+    } else {
+      float* C = (float*)Cv + o;
+      if (full4) {
+        if (EPI == EM_EPI_RESID_F32) {
+          float4 x = *(const float4*)C;
+          x.x += scale * v.x; x.y += scale * v.y; x.z += scale * v.z; x.w += scale * v.w;
+          *(float4*)C = x;
+        } else if (EPI == EM_EPI_SCALE_F32) {
+          *(float4*)C = make_float4(scale * v.x, scale * v.y, scale * v.z, scale * v.w);
+        } else {
+          *(float4*)C = v;
+        }
+      } else {
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < 4; ++e)
+          if (ncol + e < N) {
+            if (EPI == EM_EPI_RESID_F32) C[e] += scale * vv[e];
+            else if (EPI == EM_EPI_SCALE_F32) C[e] = scale * vv[e];
+            else C[e] = vv[e];
+          }
+      }
+    }
   }
 }
 
 template <typename T, int EPI, int AMODE>
 int launch(const EmGemmArgs* p, hipStream_t s) {
-  dim3 grid(em_cdiv(p->N, BN), em_cdiv(p->M, BM));
   ConvGeom g{p->T1, p->F1, p->T2, p->F2, p->d};
-  hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE>), grid, dim3(256), 0, s, (const T*)p->A,
-                     (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
+  const int nb = em_cdiv(p->N, BN);
+  // fewer than ~1.5 workgroups per CU at BM=128 -> halve the M tile to fill the 256 CUs
+  const bool small = (long)nb * em_cdiv(p->M, 128) < 384;
+  if (small) {
+    dim3 grid(nb, em_cdiv(p->M, 64));
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE, 64>), grid, dim3(256), 0, s, (const T*)p->A,
+                       (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
+  } else {
+    dim3 grid(nb, em_cdiv(p->M, 128));
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE, 128>), grid, dim3(256), 0, s, (const T*)p->A,
+                       (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
+  }
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
@@ -207,7 +313,61 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   } else if (p->lda % (dtype == EM_BF16 ? 8 : 4) != 0) {
     return EM_ERR_UNSUPPORTED;  // 16-byte aligned rows
   }
-  if (dtype == EM_F32) return dispatch<float>(epilogue, a_mode, p, (hipStream_t)stream);
-  if (dtype == EM_BF16) return dispatch<bf16>(epilogue, a_mode, p, (hipStream_t)stream);
-  return EM_ERR_BAD_ARG;
+  EmProfile* prof = tl_profile;
+  const bool rec = prof && prof->count < prof->capacity;
+  if (rec) hipEventRecord(prof->start[prof->count], (hipStream_t)stream);
+  int rc = EM_ERR_BAD_ARG;
+  if (dtype == EM_F32) rc = dispatch<float>(epilogue, a_mode, p, (hipStream_t)stream);
+  else if (dtype == EM_BF16) rc = dispatch<bf16>(epilogue, a_mode, p, (hipStream_t)stream);
+  if (rec) {
+    hipEventRecord(prof->stop[prof->count], (hipStream_t)stream);
+    prof->flops[prof->count] = 2.0 * (double)p->M * (double)p->N * (double)p->K;
+    prof->count++;
+  }
+  return rc;
+}
+
+// ---- optional per-launch timing of the GEMM family (bench.py's roofline leg) -----------------
+extern "C" EmProfile* em_profile_create(int32_t capacity) {
+  if (capacity <= 0) return nullptr;
+  EmProfile* pr = new EmProfile();
+  pr->capacity = capacity;
+  pr->count = 0;
+  pr->start = new hipEvent_t[capacity];
+  pr->stop = new hipEvent_t[capacity];
+  pr->flops = new double[capacity];
+  for (int i = 0; i < capacity; ++i) {
+    hipEventCreate(&pr->start[i]);
+    hipEventCreate(&pr->stop[i]);
+  }
+  return pr;
+}
+
+extern "C" void em_profile_destroy(EmProfile* pr) {
+  if (!pr) return;
+  if (tl_profile == pr) tl_profile = nullptr;
+  for (int i = 0; i < pr->capacity; ++i) {
+    hipEventDestroy(pr->start[i]);
+    hipEventDestroy(pr->stop[i]);
+  }
+  delete[] pr->start;
+  delete[] pr->stop;
+  delete[] pr->flops;
+  delete pr;
+}
+
+extern "C" void em_profile_attach(EmProfile* pr) { tl_profile = pr; }
+
+extern "C" int em_profile_read(EmProfile* pr, float* ms, double* flops, int32_t max_n,
+                               int32_t* count) {
+  if (!pr || !ms || !flops || !count) return EM_ERR_BAD_ARG;
+  int n = pr->count < max_n ? pr->count : max_n;
+  if (n > 0) hipEventSynchronize(pr->stop[n - 1]);
+  for (int i = 0; i < n; ++i) {
+    if (hipEventElapsedTime(&ms[i], pr->start[i], pr->stop[i]) != hipSuccess) return EM_ERR_LAUNCH;
+    flops[i] = pr->flops[i];
+  }
+  *count = n;
+  pr->count = 0;
+  return EM_OK;
 }

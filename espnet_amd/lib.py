@@ -82,6 +82,10 @@ _SIGNATURES = {
     "em_conformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32]),
     "em_conformer_encode": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _vp, _vp, _vp,
                                       _i32, _i32, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "em_profile_create": (_vp, [_i32]),
+    "em_profile_destroy": (None, [_vp]),
+    "em_profile_attach": (None, [_vp]),
+    "em_profile_read": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "em_cast_f32": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
     "em_ctc_greedy": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32,
                                 _vp, _vp, _vp, _vp, _vp]),

@@ -191,6 +191,17 @@ int em_ctc_greedy(int dtype, const void* enc_act, const void* w_ctc, const float
                   int32_t sos_eos, float* logits_ws, int32_t* ids, int32_t* tokens,
                   int32_t* out_lens, void* stream);
 
+/* ---- optional per-launch timing of the GEMM kernel family (measurement only; bench.py's
+ *      `roofline` leg).  While a profile is attached to the calling thread every em_gemm launch
+ *      (direct or from em_conformer_encode / em_ctc_greedy) is bracketed by hipEventRecord on its
+ *      stream.  em_profile_read waits for the last event, returns per-launch milliseconds and
+ *      2*M*N*K flops, and resets the profile.                                                    */
+typedef struct EmProfile EmProfile;
+EmProfile* em_profile_create(int32_t capacity);
+void em_profile_destroy(EmProfile* prof);
+void em_profile_attach(EmProfile* prof); /* NULL detaches */
+int em_profile_read(EmProfile* prof, float* ms, double* flops, int32_t max_n, int32_t* count);
+
 /* f32 -> act dtype copy (lets reference-shaped f32 entry points feed the act-dtype GEMMs) */
 int em_cast_f32(int dtype, const float* src, size_t n, void* dst, void* stream);
 
