@@ -102,11 +102,13 @@ def build_reference(conf, vocab, workdir, **s2t_kwargs):
     return s2t, cfg.read_text()
 
 
-def load_recipe(model, seed):
+def load_recipe(model, seed, tweaks=None):
     sd = model.state_dict()
     shapes = {k: tuple(v.shape) for k, v in sd.items()}
     new = recipe_state_dict(shapes, seed)
     new["frontend.logmel.melmat"] = sd["frontend.logmel.melmat"].clone()
+    for key, idx, delta in tweaks or []:  # e.g. bias the <eos> logit so hypotheses end early
+        new[key][idx] += delta
     model.load_state_dict(new, strict=True)
     model.eval()
     return shapes
@@ -171,14 +173,14 @@ def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, wi
 
 
 def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weight, nbest,
-                    keep_every=1):
+                    keep_every=1, penalty=0.0, maxlenratio=0.0, minlenratio=0.0, tweaks=None):
     t0 = time.time()
     with tempfile.TemporaryDirectory() as td:
         s2t, cfg_text = build_reference(conf, vocab, td, beam_size=beam, ctc_weight=ctc_weight,
-                                        nbest=nbest, penalty=0.0, lm_weight=0.0,
-                                        maxlenratio=0.0, minlenratio=0.0)
+                                        nbest=nbest, penalty=penalty, lm_weight=0.0,
+                                        maxlenratio=maxlenratio, minlenratio=minlenratio)
     model = s2t.asr_model
-    shapes = load_recipe(model, wseed)
+    shapes = load_recipe(model, wseed, tweaks)
     wav = synth_waveform(utt_id, n_samples)
     enc, olens = model.encode(wav[None], torch.tensor([n_samples]))
     t1 = time.time()
@@ -193,6 +195,9 @@ def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weigh
         config_yaml=np.array(cfg_text), vocab=np.array(vocab), wseed=np.array(wseed),
         utt_id=np.array(utt_id), n_samples=np.array(n_samples), beam=np.array(beam),
         ctc_weight=np.array(ctc_weight), nbest=np.array(nbest),
+        penalty=np.array(penalty), maxlenratio=np.array(maxlenratio),
+        minlenratio=np.array(minlenratio), tweaks=np.array(json.dumps(tweaks or [])),
+        n_ended=np.array(len(results)),
         state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
         melmat=model.frontend.logmel.melmat.numpy(),
         enc_out=enc[0, ::keep_every].numpy().copy(), enc_keep_every=np.array(keep_every),
@@ -233,6 +238,15 @@ CASES = {
     "tiny_beam3_attn_only": lambda: run_search_case("tiny_beam3_attn_only",
                                                     tiny(d=64, heads=2, ff=128), 50, 7, 11,
                                                     16000, 3, 0.0, 3),
+    # hypotheses that END EARLY (<eos> logit biased in decoder.output_layer): exercises the
+    # ended-list bookkeeping, end_detect (e2e_asr_common.py:14-44) and a shrinking running beam;
+    # plus length_bonus (penalty != 0) and a minlenratio bound
+    "tiny_beam4_early_eos": lambda: run_search_case(
+        "tiny_beam4_early_eos", tiny(d=64, heads=2, ff=128), 50, 7, 12, 32000, 4, 0.3, 4,
+        penalty=0.3, tweaks=[["decoder.output_layer.bias", 49, 3.5]]),
+    "tiny_beam4_minlen": lambda: run_search_case(
+        "tiny_beam4_minlen", tiny(d=64, heads=2, ff=128), 50, 7, 13, 32000, 4, 0.1, 8,
+        minlenratio=0.2, maxlenratio=0.6, tweaks=[["decoder.output_layer.bias", 49, 6.0]]),
 }
 
 if __name__ == "__main__":

@@ -91,3 +91,68 @@ def test_too_short():
     sd = golden_state_dict(g)
     with pytest.raises(oc.TooShortUttError):
         oc.conformer_encoder(sd, torch.zeros(1, 6, 80), torch.tensor([6]), 1, 2)
+
+
+# --------------------------------------------------------------------------- beam search (A12-A14)
+SEARCH_CASES = ["tiny_beam5", "tiny_beam3_attn_only", "tiny_beam4_early_eos", "tiny_beam4_minlen",
+                "small_g2_3s", "large_beam10_3s"]
+
+
+def run_oracle_search(g):
+    from oracle import beam_search as ob
+
+    sd = golden_state_dict(g)
+    hp = hparams(g)
+    speech, lens = golden_speech(g)
+    enc, _ = oc.encode(sd, speech, lens, hp["heads"], hp["num_blocks"], hp["n_fft"],
+                       hp["win_length"], hp["hop"])
+    V = int(g["vocab"])
+    dc = g["config"]["decoder_conf"]
+    kw = {k: float(g[k]) for k in ("penalty", "maxlenratio", "minlenratio") if k in g}
+    return ob.beam_search(sd, enc[0], dc["attention_heads"], dc["num_blocks"], int(g["beam"]),
+                          float(g["ctc_weight"]), sos=V - 1, eos=V - 1, **kw)
+
+
+@pytest.mark.parametrize("name", SEARCH_CASES)
+def test_beam_search_oracle_matches_reference_speech2text(name):
+    """The restated BatchBeamSearch + CTCPrefixScoreTH + K/V-cached decoder reproduces the
+    reference's Speech2Text n-best lists: identical yseq, scores within fp32 round-off."""
+    import json
+
+    g = load_golden(name)
+    res = run_oracle_search(g)
+    keys = json.loads(str(g["score_keys"]))
+    n = len(g["yseq_lens"])
+    assert len(res) >= n
+    for k in range(n):
+        ref = g["yseq"][k, : g["yseq_lens"][k]].tolist()
+        assert res[k]["yseq"] == ref, (name, k)
+        tol = 1e-5 * max(1.0, abs(float(g["score"][k]))) + 1e-4
+        assert abs(res[k]["score"] - float(g["score"][k])) < tol
+        for j, kk in enumerate(keys):
+            assert abs(res[k]["scores"][kk] - float(g["scores"][k, j])) < 1e-5 * abs(float(g["scores"][k, j])) + 1e-3
+
+
+def test_ctc_prefix_scorer_properties():
+    """Size-independent properties of the CTC prefix recurrence (no reference test pins
+    CTCPrefixScoreTH numerics): restricting the candidates does not change their scores, and for
+    the empty prefix psi(c) = log sum_t P(first non-blank label is c, emitted at t)."""
+    from oracle import beam_search as ob
+
+    torch.manual_seed(3)
+    T, V = 23, 11
+    logp = torch.log_softmax(torch.randn(T, V), -1)
+    sc = ob.CtcPrefixScorer(logp, eos=V - 1)
+    r0, s0 = sc.initial_state()
+    last = torch.tensor([V - 1])
+    full, r_full, psi_full = sc.score(0, last, r0, s0, None)
+    ids = torch.tensor([[3, 7, 1, 5]])
+    part, r_part, psi_part = sc.score(0, last, r0, s0, ids)
+    np.testing.assert_allclose(part[0, ids[0]].numpy(), full[0, ids[0]].numpy(), rtol=0, atol=1e-5)
+    # closed form for the empty prefix: psi(c) = logsumexp_t( sum_{u<t} logp[u,blank] + logp[t,c] )
+    cum = torch.cat([torch.zeros(1), torch.cumsum(logp[:, 0], 0)[:-1]])
+    want = torch.logsumexp(cum[:, None] + logp, 0)
+    np.testing.assert_allclose(psi_full[0, 1:V - 1].numpy(), want[1:V - 1].numpy(), rtol=0, atol=1e-4)
+    # eos entry = log P(prefix is complete) = total blank path; blank entry = logzero
+    assert abs(float(psi_full[0, V - 1]) - float(torch.cumsum(logp[:, 0], 0)[-1])) < 1e-4
+    assert float(psi_full[0, 0]) == ob.LOGZERO
