@@ -5,14 +5,31 @@ Mirrors espnet2/asr/decoder/transformer_decoder.py:393-468 (constructor) and :19
 (`embed.0`, `decoders.N.{self_attn,src_attn,feed_forward,norm1,norm2,norm3}`, `after_norm`,
 `output_layer`).  The torch.nn layers are parameter containers only.
 
-Round-1 status: parameter tree + checkpoint compatibility; the K/V-cached decoder-step kernels
- land with the beam-search row.
+The arithmetic is csrc/decoder.hip + csrc/gemm.hip + csrc/norm.hip, driven per search step by
+csrc/search.hip (`em_search_steps`); `pack()` repacks the reference-layout parameters once
+(q|k|v rows concatenated for self-attention, k|v for source attention, absolute sinusoid table).
+The scorer-interface methods (`batch_score`, `score`, `select_state`) of the reference are
+fulfilled inside the fused device search (espnet_amd/nets/batch_beam_search.py) rather than
+through per-step Python calls.
 """
+import ctypes as C
+import math
 from typing import List
 
 import torch
 
+from espnet_amd import lib as L
 from espnet_amd.asr.encoder.conformer_encoder import LayerNorm, _PositionwiseFeedForward
+
+
+def abs_pos_table(length: int, d: int) -> torch.Tensor:
+    """PositionalEncoding.extend_pe (transformer/embedding.py:56-79), same fp32 torch ops."""
+    pe = torch.zeros(length, d)
+    position = torch.arange(0, length, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
 
 
 class _MultiHeadedAttention(torch.nn.Module):
@@ -69,3 +86,62 @@ class TransformerDecoder(torch.nn.Module):
 
     def invalidate(self):
         self._packed = None
+
+    @property
+    def em_dtype(self) -> int:
+        return L.DTYPES[self.compute_dtype]
+
+    @property
+    def act_dtype(self) -> torch.dtype:
+        return torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32
+
+    def pack(self, device, pe_len: int = 1024):
+        dev = torch.device(device)
+        act = self.act_dtype
+        keep = []
+
+        def A(t):
+            t = t.detach().to(torch.float32).contiguous().to(act).to(dev)
+            keep.append(t)
+            return t
+
+        def F(t):
+            t = t.detach().to(torch.float32).contiguous().to(dev)
+            keep.append(t)
+            return t
+
+        w = L.EmDecoderWeights()
+        w.d, w.heads, w.ff, w.num_blocks = self.d, self.heads, self.linear_units, self.num_blocks
+        w.vocab, w.pe_len = self.vocab_size, pe_len
+        top = dict(embed=F(self.embed[0].weight), pe=F(abs_pos_table(pe_len, self.d)),
+                   after_norm_g=F(self.after_norm.weight), after_norm_b=F(self.after_norm.bias),
+                   out_w=A(self.output_layer.weight), out_b=F(self.output_layer.bias))
+        for k, v in top.items():
+            setattr(w, k, v.data_ptr())
+        layers = (L.EmDecoderLayer * self.num_blocks)()
+        for i, l in enumerate(self.decoders):
+            sa, ca, ff = l.self_attn, l.src_attn, l.feed_forward
+            lt = dict(
+                norm1_g=F(l.norm1.weight), norm1_b=F(l.norm1.bias),
+                norm2_g=F(l.norm2.weight), norm2_b=F(l.norm2.bias),
+                norm3_g=F(l.norm3.weight), norm3_b=F(l.norm3.bias),
+                self_wqkv=A(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0)),
+                self_bqkv=F(torch.cat([sa.linear_q.bias, sa.linear_k.bias, sa.linear_v.bias], 0)),
+                self_wout=A(sa.linear_out.weight), self_bout=F(sa.linear_out.bias),
+                src_wq=A(ca.linear_q.weight), src_bq=F(ca.linear_q.bias),
+                src_wkv=A(torch.cat([ca.linear_k.weight, ca.linear_v.weight], 0)),
+                src_bkv=F(torch.cat([ca.linear_k.bias, ca.linear_v.bias], 0)),
+                src_wout=A(ca.linear_out.weight), src_bout=F(ca.linear_out.bias),
+                w1=A(ff.w_1.weight), b1=F(ff.w_1.bias), w2=A(ff.w_2.weight), b2=F(ff.w_2.bias))
+            for k, v in lt.items():
+                setattr(layers[i], k, v.data_ptr())
+        w.layers = C.cast(layers, C.POINTER(L.EmDecoderLayer))
+        self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype,
+                            pe_len=pe_len)
+        return self._packed
+
+    def ensure_packed(self, device, pe_len: int):
+        p = self._packed
+        if p is None or p["device"] != device or p["dtype"] != self.em_dtype or p["pe_len"] < pe_len:
+            p = self.pack(device, max(1024, pe_len))
+        return p

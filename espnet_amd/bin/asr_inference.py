@@ -20,25 +20,11 @@ from typing import Any, Dict, List, NamedTuple, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
+from espnet_amd.nets.beam_search import Hypothesis
 from espnet_amd.tasks.asr import ASRTask
 from espnet_amd.text.token_id_converter import TokenIDConverter, build_tokenizer
 
 logger = logging.getLogger(__name__)
-
-
-class Hypothesis(NamedTuple):
-    """espnet2/legacy/nets/beam_search.py:15-31."""
-
-    yseq: torch.Tensor
-    score: Union[float, torch.Tensor] = 0
-    scores: Dict[str, Union[float, torch.Tensor]] = dict()
-    states: Dict[str, Any] = dict()
-    hs: List[torch.Tensor] = []
-
-    def asdict(self) -> dict:
-        return self._replace(
-            yseq=self.yseq.tolist(), score=float(self.score),
-            scores={k: float(v) for k, v in self.scores.items()})._asdict()
 
 
 class Speech2Text:
@@ -85,7 +71,8 @@ class Speech2Text:
 
             self.beam_search = build_beam_search(
                 asr_model, beam_size=beam_size, ctc_weight=ctc_weight, penalty=penalty,
-                lm_weight=0.0 if lm_file is None else lm_weight, token_list=token_list)
+                lm_weight=0.0 if lm_file is None else lm_weight, token_list=token_list,
+                normalize_length=normalize_length)
 
     # ------------------------------------------------------------------ single utterance (reference API)
     @torch.no_grad()
@@ -105,7 +92,8 @@ class Speech2Text:
         st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths])
         if self.ctc_greedy:
             return self._finish_greedy(*self.decode_greedy_device(st))
-        hyps = self.beam_search.search_batch(st, maxlenratio=self.maxlenratio, minlenratio=self.minlenratio)
+        hyps = self.beam_search.search_batch(st.enc_act, st.olens, maxlenratio=self.maxlenratio,
+                                             minlenratio=self.minlenratio)
         return [self._format(h[: self.nbest]) for h in hyps]
 
     def decode_greedy_device(self, st):

@@ -1,0 +1,310 @@
+// Attention-decoder step kernels for the label-synchronous beam search.
+//
+// Reference: TransformerDecoder.batch_score / forward_one_step
+// (espnet2/asr/decoder/transformer_decoder.py:191-311), DecoderLayer.forward with `cache`
+// (espnet2/legacy/nets/pytorch_backend/transformer/decoder_layer.py:73-179),
+// MultiHeadedAttention.forward (transformer/attention.py:121-151, 263-265),
+// PositionalEncoding.forward (transformer/embedding.py:84-95).
+//
+// The reference re-projects linear_k/linear_v of the whole prefix (self-attention) and of the whole
+// encoder memory (source attention) for every hypothesis, layer and step.  Here both are true
+// caches with identical values:
+//   * self-attention K/V of prefix position j depend only on y_0..y_j, so they are written once
+//     into kc/vc[layer][j][slot] when slot's hypothesis consumes position j; hypotheses are paths in
+//     a token tree and `anc[row][j]` names the slot holding position j of row's prefix.  A beam
+//     reorder therefore permutes only the small `anc` table, never the K/V cache;
+//   * source-attention K / V^T of the memory are computed once per utterance (em_search_init) and
+//     shared by the W hypotheses of that utterance (one workgroup per (utterance, head): MFMA
+//     QK^T and PV over a 16-row query tile).
+#include "em_common.h"
+
+namespace {
+
+// x[r] = embed[tok[r]] * sqrt(d) + pe[pos]      (embedding.py:93; f32 residual stream)
+__global__ __launch_bounds__(128) void dec_embed_kernel(const float* __restrict__ embed,
+                                                        const float* __restrict__ pe,
+                                                        const int* __restrict__ tok_row, int V,
+                                                        int d, int pos, float xscale,
+                                                        float* __restrict__ x) {
+  const int r = blockIdx.x;
+  int t = tok_row[r];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);  // rows of ended hypotheses hold stale ids
+  const float* e = embed + (size_t)t * d;
+  const float* p = pe + (size_t)pos * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) x[(size_t)r * d + c] = e[c] * xscale + p[c];
+}
+
+template <typename T>
+__device__ __forceinline__ float dot_row(const T* __restrict__ k, const float* q, int DK);
+
+template <>
+__device__ __forceinline__ float dot_row<bf16>(const bf16* __restrict__ k, const float* q, int DK) {
+  float acc = 0.f;
+  for (int c = 0; c < DK; c += 8) {
+    bf16x8 v = *(const bf16x8*)(k + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(q[c + e], (float)v[e], acc);
+  }
+  return acc;
+}
+template <>
+__device__ __forceinline__ float dot_row<float>(const float* __restrict__ k, const float* q, int DK) {
+  float acc = 0.f;
+  for (int c = 0; c < DK; c += 4) {
+    float4 v = *(const float4*)(k + c);
+    acc = fmaf(q[c], v.x, acc);
+    acc = fmaf(q[c + 1], v.y, acc);
+    acc = fmaf(q[c + 2], v.z, acc);
+    acc = fmaf(q[c + 3], v.w, acc);
+  }
+  return acc;
+}
+
+// One wave per (hypothesis row, head).  qkv [n][3d] (q | k | v of the token at position `pos`);
+// kc/vc [Lmax][n][d] (this layer); anc [n][Lmax].  ctx [n][d].
+constexpr int SA_MAXJ = 16;  // positions per lane: Lmax <= 1024
+template <typename T, int DK>
+__global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ qkv,
+                                                           T* __restrict__ kc, T* __restrict__ vc,
+                                                           const int* __restrict__ anc, int n,
+                                                           int d, int Lmax, int pos,
+                                                           T* __restrict__ ctx) {
+  __shared__ float p_s[SA_MAXJ * 64];
+  const int h = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+  const T* row = qkv + (size_t)r * 3 * d + h * DK;
+  float q[DK];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) q[c] = to_f32(row[c]);
+  // append this position's K/V to the cache (read back by later steps only)
+  if (lane < DK) {
+    const size_t o = ((size_t)pos * n + r) * d + h * DK + lane;
+    kc[o] = row[d + lane];
+    vc[o] = row[2 * d + lane];
+  }
+  const float scale = rsqrtf((float)DK);
+  const int* arow = anc + (size_t)r * Lmax;
+  float sc[SA_MAXJ];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jj = 0; jj < SA_MAXJ; ++jj) {
+    const int j = jj * 64 + lane;
+    sc[jj] = -INFINITY;
+    if (jj * 64 <= pos && j <= pos) {
+      const T* kr = (j == pos) ? row + d : kc + ((size_t)j * n + arow[j]) * d + h * DK;
+      sc[jj] = dot_row<T>(kr, q, DK) * scale;
+      mx = fmaxf(mx, sc[jj]);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < SA_MAXJ; ++jj) {
+    const int j = jj * 64 + lane;
+    if (jj * 64 <= pos) {
+      float p = (j <= pos) ? expf(sc[jj] - mx) : 0.f;
+      sum += p;
+      p_s[j] = p;
+    }
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  if (lane < DK) {
+    float acc = 0.f;
+    for (int j = 0; j < pos; ++j) {
+      const T* vr = vc + ((size_t)j * n + arow[j]) * d + h * DK;
+      acc = fmaf(p_s[j], to_f32(vr[lane]), acc);
+    }
+    acc = fmaf(p_s[pos], to_f32(row[2 * d + lane]), acc);
+    ctx[(size_t)r * d + h * DK + lane] = from_f32<T>(acc / sum);
+  }
+}
+
+// Source attention of the W hypotheses of one utterance over its encoder memory.
+// grid (heads, B, ceil(W/16)), 256 threads.  qs [n][d]; kmem rows at stride ldk (K part of the
+// per-layer [B*T][2d] projection); vT [B][d][Tpad] (V transposed, zero padded); klens [B].
+template <typename T, int DK>
+__global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__ qs,
+                                                           const T* __restrict__ kmem, int ldk,
+                                                           const T* __restrict__ vT,
+                                                           const int* __restrict__ klens, int W,
+                                                           int d, int Tn, int Tpad,
+                                                           T* __restrict__ ctx) {
+  using M = Mma<T>;
+  constexpr int KS = DK / M::K;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int LDS_S = Tpad + 4;                       // f32 score row stride
+  const int LDS_P = Tpad + 16 / (int)sizeof(T);     // probability row stride (elements)
+  float* S = (float*)smem_raw;                      // [16][LDS_S]
+  float* sums = S + 16 * LDS_S;                     // [16]
+  T* P = (T*)(sums + 16);                           // [16][LDS_P]
+
+  const int h = blockIdx.x, b = blockIdx.y, rg = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int row0 = b * W + rg * 16;
+  const int nrows = (W - rg * 16) < 16 ? (W - rg * 16) : 16;
+  const int klen = klens[b] < Tn ? klens[b] : Tn;
+  const float scale = rsqrtf((float)DK);
+
+  typename M::frag qf[KS];
+  {
+    const int rr = lr < nrows ? lr : nrows - 1;
+    const T* qrow = qs + (size_t)(row0 + rr) * d + h * DK;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = M::load(qrow + ks * M::K + lg * M::EPL);
+  }
+  const T* kb = kmem + (size_t)b * Tn * ldk + h * DK;
+  for (int nt = wave; nt < Tpad / 16; nt += 4) {
+    int key = nt * 16 + lr;
+    const int kc_ = key < Tn ? key : Tn - 1;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      acc = M::mma(qf[ks], M::load(kb + (size_t)kc_ * ldk + ks * M::K + lg * M::EPL), acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      S[(lg * 4 + r) * LDS_S + key] = key < klen ? acc[r] * scale : -INFINITY;
+  }
+  __syncthreads();
+  // softmax numerators per row (4 rows per wave); P holds exp(s - max) in the act dtype and
+  // sums[] the sum of the ROUNDED values, so the normalisation below is exact for what PV sees
+  for (int rr = wave * 4; rr < wave * 4 + 4; ++rr) {
+    float mx = -INFINITY;
+    for (int j = lane; j < Tpad; j += 64) mx = fmaxf(mx, S[rr * LDS_S + j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Tpad; j += 64) {
+      T pt = from_f32<T>(expf(S[rr * LDS_S + j] - mx));
+      P[rr * LDS_P + j] = pt;
+      sum += to_f32(pt);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) sums[rr] = sum;
+  }
+  __syncthreads();
+  if (wave < DK / 16) {
+    const T* vb = vT + ((size_t)b * d + h * DK + wave * 16 + lr) * Tpad;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < Tpad / M::K; ++kk) {
+      const int ko = kk * M::K + lg * M::EPL;
+      acc = M::mma(M::load(P + lr * LDS_P + ko), M::load(vb + ko), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = lg * 4 + r;
+      if (rr < nrows)
+        ctx[(size_t)(row0 + rr) * d + h * DK + wave * 16 + lr] = from_f32<T>(acc[r] / sums[rr]);
+    }
+  }
+}
+
+// vT[b][c][t] = kv[b*T + t][d + c]   (t < T; the padding t in [T, Tpad) stays zero)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ kv, int Tn, int d,
+                                                          int Tpad, T* __restrict__ vT) {
+  __shared__ T tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    int t = t0 + k, c = c0 + tx;
+    tile[k][tx] = (t < Tn && c < d) ? kv[((size_t)b * Tn + t) * 2 * d + d + c] : from_f32<T>(0.f);
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int c = c0 + k, t = t0 + tx;
+    if (c < d && t < Tn) vT[((size_t)b * d + c) * Tpad + t] = tile[tx][k];
+  }
+}
+
+template <typename T>
+int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, int n, int d, int heads,
+                     int Lmax, int pos, void* ctx, hipStream_t s) {
+  const int dk = d / heads;
+  dim3 grid(heads, n);
+  if (dk == 64)
+    hipLaunchKernelGGL((dec_self_attn_kernel<T, 64>), grid, dim3(64), 0, s, (const T*)qkv, (T*)kc,
+                       (T*)vc, anc, n, d, Lmax, pos, (T*)ctx);
+  else if (dk == 32)
+    hipLaunchKernelGGL((dec_self_attn_kernel<T, 32>), grid, dim3(64), 0, s, (const T*)qkv, (T*)kc,
+                       (T*)vc, anc, n, d, Lmax, pos, (T*)ctx);
+  else
+    return EM_ERR_UNSUPPORTED;
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+template <typename T>
+int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, const int* klens,
+                    int B, int W, int d, int heads, int Tn, int Tpad, void* ctx, hipStream_t s) {
+  const int dk = d / heads;
+  const size_t lds = (size_t)16 * (Tpad + 4) * 4 + 64 + (size_t)16 * (Tpad + 16 / sizeof(T)) * sizeof(T);
+  dim3 grid(heads, B, em_cdiv(W, 16));
+  if (dk == 64) {
+    if (hipFuncSetAttribute((const void*)dec_src_attn_kernel<T, 64>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return EM_ERR_LAUNCH;
+    hipLaunchKernelGGL((dec_src_attn_kernel<T, 64>), grid, dim3(256), lds, s, (const T*)qs,
+                       (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx);
+  } else if (dk == 32) {
+    if (hipFuncSetAttribute((const void*)dec_src_attn_kernel<T, 32>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return EM_ERR_LAUNCH;
+    hipLaunchKernelGGL((dec_src_attn_kernel<T, 32>), grid, dim3(256), lds, s, (const T*)qs,
+                       (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx);
+  } else {
+    return EM_ERR_UNSUPPORTED;
+  }
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+}  // namespace
+
+extern "C" int em_dec_embed_f32(const float* embed, const float* pe, const int32_t* tok_row,
+                                int32_t n, int32_t V, int32_t d, int32_t pos, float* x,
+                                void* stream) {
+  if (n <= 0 || d <= 0 || pos < 0) return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dec_embed_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, embed, pe,
+                     tok_row, V, d, pos, sqrtf((float)d), x);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc,
+                                     const int32_t* anc, int32_t n, int32_t d, int32_t heads,
+                                     int32_t Lmax, int32_t pos, void* ctx, void* stream) {
+  if (n <= 0 || heads <= 0 || pos < 0 || pos >= Lmax || Lmax > SA_MAXJ * 64) return EM_ERR_BAD_ARG;
+  if (dtype == EM_F32)
+    return self_attn_launch<float>(qkv, kc, vc, anc, n, d, heads, Lmax, pos, ctx, (hipStream_t)stream);
+  if (dtype == EM_BF16)
+    return self_attn_launch<bf16>(qkv, kc, vc, anc, n, d, heads, Lmax, pos, ctx, (hipStream_t)stream);
+  return EM_ERR_BAD_ARG;
+}
+
+extern "C" int em_dec_src_attention(int dtype, const void* qs, const void* kmem, int32_t ldk,
+                                    const void* vT, const int32_t* klens, int32_t B, int32_t W,
+                                    int32_t d, int32_t heads, int32_t T, int32_t Tpad, void* ctx,
+                                    void* stream) {
+  if (B <= 0 || W <= 0 || T <= 0 || Tpad < T || Tpad % 32 != 0) return EM_ERR_BAD_ARG;
+  if (dtype == EM_F32)
+    return src_attn_launch<float>(qs, kmem, ldk, vT, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream);
+  if (dtype == EM_BF16)
+    return src_attn_launch<bf16>(qs, kmem, ldk, vT, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream);
+  return EM_ERR_BAD_ARG;
+}
+
+extern "C" int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t T, int32_t d,
+                                  int32_t Tpad, void* vT, void* stream) {
+  if (B <= 0 || T <= 0 || d <= 0 || Tpad < T) return EM_ERR_BAD_ARG;
+  dim3 grid(em_cdiv(T, 32), em_cdiv(d, 32), B);
+  if (dtype == EM_F32)
+    hipLaunchKernelGGL(transpose_v_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)kv, T, d, Tpad, (float*)vT);
+  else if (dtype == EM_BF16)
+    hipLaunchKernelGGL(transpose_v_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)kv, T, d, Tpad, (bf16*)vT);
+  else
+    return EM_ERR_BAD_ARG;
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}

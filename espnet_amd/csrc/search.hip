@@ -1,0 +1,478 @@
+// Label-synchronous joint CTC/attention beam search, batched over utterances, device resident.
+//
+// Reference semantics being reproduced (paths relative to espnet/espnet):
+//   BeamSearch.__init__ / forward        espnet2/legacy/nets/beam_search.py:36-126, 385-498
+//   BatchBeamSearch.search / batch_beam / post_process
+//                                        espnet2/legacy/nets/batch_beam_search.py:98-122, 253-423
+//   CTCPrefixScoreTH.__call__            espnet2/legacy/nets/ctc_prefix_score.py:71-191
+//   CTCPrefixScorer.select_state         espnet2/legacy/nets/scorers/ctc.py:40-63
+//   LengthBonus.batch_score              espnet2/legacy/nets/scorers/length_bonus.py:39-58
+//   end_detect                           espnet2/legacy/nets/e2e_asr_common.py:14-44
+//
+// Layout.  B utterances x W beam slots = n rows (row = b*W + k).  Hypotheses are paths in a token
+// tree: tok[pos][row] / parent[pos][row]; `anc[row][pos]` lists the slot of every prefix position
+// (what the decoder's self-attention reads).  A row is alive or not; ended hypotheses are
+// appended to a per-utterance list (node position/slot + scores) and rebuilt on the host by
+// walking `parent`.  One step = pre-beam top-S on the full scorers -> CTC prefix scores of the
+// S candidates (+ <eos>) -> per-utterance top-W -> state update (tree, anc, scores, CTC forward
+// variables of the winners, ended list, end detection).  No host synchronisation inside a step.
+//
+// CTC prefix scoring: one thread per (row, candidate) runs the forward-variable recurrence over
+// the T frames sequentially in registers; the winners' forward variables (the next step's r_prev)
+// are re-derived by the same device function in the update kernel rather than storing all
+// S candidates' (T,2) tables (S = V when ctc_weight = 1).
+#include <math.h>
+
+#include "em_common.h"
+
+namespace {
+
+constexpr float LOGZERO = -10000000000.0f;  // ctc_prefix_score.py:34
+constexpr float D_END = -10.0f;             // log(1 * exp(-10)), e2e_asr_common.py:14
+
+__device__ __forceinline__ float logaddexp_(float a, float b) {
+  // torch.logsumexp over two elements: max + log(exp(a-max) + exp(b-max))
+  const float m = fmaxf(a, b);
+  return m + logf(expf(a - m) + expf(b - m));
+}
+
+// Forward-variable recurrence of one (prefix, candidate label c) pair; returns log psi.
+//   lp      log-probs of this utterance, [T][V]
+//   rprev   forward variables of the prefix, [T] x (r^n, r^b)
+//   i       prefix length without <sos> (= step index)
+// WRITE: also store the new forward variables rout[t] for every t < xlen.
+template <bool WRITE>
+__device__ __forceinline__ float ctc_prefix_scan(const float* __restrict__ lp, int V, int xlen,
+                                                 int c, int blank, int last, int i,
+                                                 const float2* __restrict__ rprev,
+                                                 float2* __restrict__ rout) {
+  const int start = i > 1 ? i : 1;
+  float rn = LOGZERO, rb = LOGZERO;
+  if (i == 0) rn = lp[c];  // r[0,0] = x[0] (:131-132)
+  if (WRITE) {
+    for (int t = 0; t < start - 1; ++t) rout[t] = make_float2(LOGZERO, LOGZERO);
+    rout[start - 1] = make_float2(rn, rb);
+  }
+  // log psi = logsumexp_t(log_phi[t-1] + x[t]) (+) r[start-1, 0]   (:166-181), online form
+  float m = rn, s = 1.0f;
+#pragma unroll 4
+  for (int t = start; t < xlen; ++t) {
+    const float2 rp = rprev[t - 1];
+    const float phi = (c == last) ? rp.y : logaddexp_(rp.x, rp.y);  // :135-144
+    const float xn = lp[(size_t)t * V + c], xb = lp[(size_t)t * V + blank];
+    const float nn = logaddexp_(rn, phi) + xn;  // :158-164
+    const float nb = logaddexp_(rn, rb) + xb;
+    const float term = phi + xn;
+    if (term > m) {
+      s = s * expf(m - term) + 1.0f;
+      m = term;
+    } else {
+      s += expf(term - m);
+    }
+    rn = nn;
+    rb = nb;
+    if (WRITE) rout[t] = make_float2(rn, rb);
+  }
+  return m + logf(s);
+}
+
+struct Ctx {
+  EmSearchParams p;
+  EmSearchBuffers b;
+};
+
+// ---- init ---------------------------------------------------------------------------------
+__global__ void search_init_rows_kernel(Ctx c) {
+  const int n = c.p.B * c.p.W;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const bool first = (r % c.p.W) == 0;
+  c.b.alive[r] = first ? 1 : 0;
+  c.b.run_score[r] = first ? 0.f : -INFINITY;
+  c.b.run_sdec[r] = 0.f;
+  c.b.run_sctc[r] = 0.f;
+  c.b.run_slen[r] = 0.f;
+  c.b.s_prev[r] = 0.f;
+  c.b.tok[r] = c.p.sos;
+  c.b.parent[r] = -1;
+  for (int j = 0; j < c.p.Lmax; ++j) {
+    c.b.anc_a[(size_t)r * c.p.Lmax + j] = r;
+    c.b.anc_b[(size_t)r * c.p.Lmax + j] = r;
+  }
+}
+
+// r_prev of the empty prefix: (logzero, cumsum_t logp[t][blank])  (ctc_prefix_score.py:89-96)
+__global__ void search_init_utt_kernel(Ctx c) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= c.p.B) return;
+  c.b.end_count[b] = 0;
+  c.b.done[b] = 0;
+  c.b.best_all[b] = -INFINITY;
+  for (int l = 0; l < c.p.Lmax + 2; ++l) c.b.best_by_len[(size_t)b * (c.p.Lmax + 2) + l] = -INFINITY;
+  if (c.p.w_ctc != 0.f) {
+    const float* lp = c.b.ctc_logp + (size_t)b * c.p.T * c.p.V;
+    float2* r0 = (float2*)c.b.r_a + (size_t)(b * c.p.W) * c.p.T;
+    float cum = 0.f;
+    for (int t = 0; t < c.p.T; ++t) {
+      cum += lp[(size_t)t * c.p.V + c.p.blank];
+      r0[t] = make_float2(LOGZERO, cum);
+    }
+  }
+}
+
+// ---- step 1: pre-beam.  One wave per row: top-S token ids of the weighted full scores --------
+// (batch_beam_search.py:289-302).  Row values staged in LDS; S rounds of wave arg-max
+// (ties -> lowest id).  cand_tok / cand_full[row][0..S).
+__global__ __launch_bounds__(64) void prebeam_kernel(Ctx c) {
+  extern __shared__ float vals[];
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int V = c.p.V, S = c.p.S, NC = c.p.NC;
+  if (!c.b.alive[r]) return;
+  const float* lp = c.b.dec_logp + (size_t)r * V;
+  for (int v = lane; v < V; v += 64) vals[v] = c.p.w_dec * lp[v] + c.p.w_len * 1.0f;
+  __syncthreads();
+  for (int k = 0; k < S; ++k) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = lane; v < V; v += 64) {
+      const float x = vals[v];
+      if (x > best) {
+        best = x;
+        bi = v;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      c.b.cand_tok[(size_t)r * NC + k] = bi;
+      c.b.cand_full[(size_t)r * NC + k] = best;
+      vals[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- step 2: candidate totals.  One thread per (row, candidate slot) ---------------------------
+//   pre-beam mode  : slots 0..S-1 = cand_tok, slot S = <eos> (always scored, :186-187)
+//   all-vocab mode : slot s = token s (S == V, NC == V)
+// total = (w_dec*dec + w_len) + w_ctc*(psi - s_prev) + running score   (batch_beam_search.py:289-314)
+__global__ __launch_bounds__(64) void candidate_kernel(Ctx c, int i) {
+  const int NC = c.p.NC, V = c.p.V, S = c.p.S;
+  const long idx = (long)blockIdx.x * 64 + threadIdx.x;
+  const long total_threads = (long)c.p.B * c.p.W * NC;
+  if (idx >= total_threads) return;
+  const int r = (int)(idx / NC), s = (int)(idx - (long)r * NC);
+  const int b = r / c.p.W;
+  float* out_total = c.b.cand_total + (size_t)r * NC + s;
+  if (!c.b.alive[r] || c.b.done[b]) {
+    *out_total = -INFINITY;
+    return;
+  }
+  const bool allv = (S >= V);
+  int tokc;
+  float full;
+  if (allv) {
+    tokc = s;
+    full = (c.p.w_dec != 0.f ? c.p.w_dec * c.b.dec_logp[(size_t)r * V + s] : 0.f) + c.p.w_len * 1.0f;
+    if (c.p.w_dec == 0.f && c.p.w_len == 0.f) full = 0.f;
+    c.b.cand_tok[(size_t)r * NC + s] = s;
+  } else if (s < S) {
+    tokc = c.b.cand_tok[(size_t)r * NC + s];
+    full = c.b.cand_full[(size_t)r * NC + s];
+  } else {  // the extra <eos> slot
+    tokc = c.p.eos;
+    full = c.p.w_dec * c.b.dec_logp[(size_t)r * V + tokc] + c.p.w_len * 1.0f;
+    c.b.cand_tok[(size_t)r * NC + s] = tokc;
+    // already among the pre-beam candidates: that slot carries it
+    for (int k = 0; k < S; ++k)
+      if (c.b.cand_tok[(size_t)r * NC + k] == tokc) {
+        *out_total = -INFINITY;
+        return;
+      }
+  }
+  float total = full;
+  if (c.p.w_ctc != 0.f) {
+    const int xlen = c.b.xlens[b];
+    const float2* rprev = (const float2*)(i & 1 ? c.b.r_b : c.b.r_a) + (size_t)r * c.p.T;
+    float psi;
+    if (tokc == c.p.blank && c.p.eos != c.p.blank) {
+      psi = LOGZERO;  // :188-190
+    } else if (tokc == c.p.eos) {
+      const float2 re = rprev[xlen - 1];
+      psi = logaddexp_(re.x, re.y);  // :184-186
+    } else {
+      const int last = c.b.tok[(size_t)i * c.p.B * c.p.W + r];
+      psi = ctc_prefix_scan<false>(c.b.ctc_logp + (size_t)b * c.p.T * V, V, xlen, tokc, c.p.blank,
+                                   last, i, rprev, nullptr);
+    }
+    c.b.cand_psi[(size_t)r * NC + s] = psi;
+    total = total + c.p.w_ctc * (psi - c.b.s_prev[r]);
+  }
+  *out_total = total + c.b.run_score[r];
+}
+
+// ---- step 3: per-utterance top-W over the W*NC candidate totals (batch_beam :98-122) -----------
+// one wave per utterance; W rounds of arg-max, ties -> lowest flat index (row-major slot order)
+__global__ __launch_bounds__(64) void select_kernel(Ctx c) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int W = c.p.W, NC = c.p.NC;
+  const int total = W * NC;
+  float* tot = c.b.cand_total + (size_t)b * total;
+  for (int k = 0; k < W; ++k) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = lane; v < total; v += 64) {
+      const float x = tot[v];
+      if (x > best) {
+        best = x;
+        bi = v;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      c.b.sel_idx[b * W + k] = (best > -INFINITY) ? bi : -1;
+      c.b.sel_total[b * W + k] = best;
+      if (best > -INFINITY) tot[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- step 4: build the new rows (batch_beam_search.py:317-357 + post_process :359-423) ---------
+// one workgroup (64 threads) per utterance
+__global__ __launch_bounds__(64) void update_kernel(Ctx c, int i) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int W = c.p.W, NC = c.p.NC, V = c.p.V, Lmax = c.p.Lmax, n = c.p.B * c.p.W;
+  __shared__ int s_prev_row[64], s_tok[64], s_valid[64], s_end[64];
+  const int* anc_old = (i & 1) ? c.b.anc_b : c.b.anc_a;
+  int* anc_new = (i & 1) ? c.b.anc_a : c.b.anc_b;
+  const float2* r_old = (const float2*)((i & 1) ? c.b.r_b : c.b.r_a);
+  float2* r_new = (float2*)((i & 1) ? c.b.r_a : c.b.r_b);
+  const bool was_done = c.b.done[b] != 0;
+  const int maxlen = c.b.maxlens[b], minlen = c.b.minlens[b];
+
+  float n_score = -INFINITY, n_sdec = 0.f, n_sctc = 0.f, n_slen = 0.f, n_sprev = 0.f;
+  if (lane < W) {
+    const int rnew = b * W + lane;
+    const int sel = was_done ? -1 : c.b.sel_idx[rnew];
+    int valid = sel >= 0, prow = b * W, tk = c.p.eos;
+    if (valid) {
+      const int pk = sel / NC, s = sel - pk * NC;
+      prow = b * W + pk;
+      tk = c.b.cand_tok[(size_t)prow * NC + s];
+      n_score = c.b.sel_total[rnew];
+      if (c.p.w_dec != 0.f) n_sdec = c.b.run_sdec[prow] + c.b.dec_logp[(size_t)prow * V + tk];
+      if (c.p.w_len != 0.f) n_slen = c.b.run_slen[prow] + 1.0f;
+      if (c.p.w_ctc != 0.f) {
+        const float psi = c.b.cand_psi[(size_t)prow * NC + s];
+        n_sctc = c.b.run_sctc[prow] + (psi - c.b.s_prev[prow]);
+        n_sprev = psi;  // select_state: s = log_psi[i, new_id] (scorers/ctc.py:56)
+      }
+    }
+    s_prev_row[lane] = prow;
+    s_tok[lane] = tk;
+    s_valid[lane] = valid;
+    // ended: the new token is <eos>, or <eos> is forced at the last position (:393-410)
+    s_end[lane] = valid && (tk == c.p.eos || i == maxlen - 1);
+  }
+  __syncthreads();
+  // (a) ancestor tables of the new rows
+  for (int k = 0; k < W; ++k) {
+    if (!s_valid[k]) continue;
+    const int rnew = b * W + k;
+    const int* src = anc_old + (size_t)s_prev_row[k] * Lmax;
+    int* dst = anc_new + (size_t)rnew * Lmax;
+    for (int j = lane; j <= i; j += 64) dst[j] = src[j];
+    if (lane == 0 && i + 1 < Lmax) dst[i + 1] = rnew;
+  }
+  // (b) CTC forward variables of the winners (scorers/ctc.py:54-62); ended rows need none
+  if (lane < W && s_valid[lane] && !s_end[lane] && c.p.w_ctc != 0.f) {
+    const int rnew = b * W + lane, prow = s_prev_row[lane];
+    const int last = c.b.tok[(size_t)i * n + prow];
+    ctc_prefix_scan<true>(c.b.ctc_logp + (size_t)b * c.p.T * V, V, c.b.xlens[b], s_tok[lane],
+                          c.p.blank, last, i, r_old + (size_t)prow * c.p.T,
+                          r_new + (size_t)rnew * c.p.T);
+  }
+  __syncthreads();  // every read of the old per-row state is done
+  if (lane < W) {
+    const int rnew = b * W + lane;
+    if (s_valid[lane]) {
+      c.b.tok[(size_t)(i + 1) * n + rnew] = s_tok[lane];
+      c.b.parent[(size_t)(i + 1) * n + rnew] = s_prev_row[lane];
+    }
+    const int alive = s_valid[lane] && !s_end[lane];
+    c.b.alive[rnew] = alive;
+    c.b.run_score[rnew] = alive ? n_score : -INFINITY;
+    c.b.run_sdec[rnew] = n_sdec;
+    c.b.run_sctc[rnew] = n_sctc;
+    c.b.run_slen[rnew] = n_slen;
+    c.b.s_prev[rnew] = n_sprev;
+    // stash for the serial ended-list pass
+    c.b.sel_total[rnew] = n_score;
+  }
+  __syncthreads();
+  if (lane == 0 && !was_done) {
+    // (c) ended list, in row order (the reference appends in batch order)
+    int cnt = c.b.end_count[b];
+    const int cap = c.p.end_cap;
+    int n_alive = 0;
+    for (int k = 0; k < W; ++k) {
+      const int rnew = b * W + k;
+      if (!s_valid[k]) continue;
+      if (!s_end[k]) {
+        ++n_alive;
+        continue;
+      }
+      if (i < minlen) continue;  // :417-418
+      const int forced = (i == maxlen - 1);
+      const int ylen = i + 2 + forced;  // <sos> + (i+1) tokens [+ forced <eos>]
+      const float sc = c.b.sel_total[rnew];
+      if (cnt < cap) {
+        const size_t e = (size_t)b * cap + cnt;
+        c.b.end_pos[e] = i + 1;
+        c.b.end_slot[e] = rnew;
+        c.b.end_forced[e] = forced;
+        c.b.end_score[e] = sc;
+        c.b.end_sdec[e] = c.b.run_sdec[rnew];
+        c.b.end_sctc[e] = c.b.run_sctc[rnew];
+        c.b.end_slen[e] = c.b.run_slen[rnew];
+        ++cnt;
+      }
+      if (sc > c.b.best_all[b]) c.b.best_all[b] = sc;
+      float* bl = c.b.best_by_len + (size_t)b * (Lmax + 2) + ylen;
+      if (sc > *bl) *bl = sc;
+    }
+    c.b.end_count[b] = cnt;
+    // (d) end detection (e2e_asr_common.py:14-44) and "no hypothesis" (beam_search.py:446-448)
+    int done = (n_alive == 0);
+    if (!done && c.p.use_end_detect && cnt > 0) {
+      int count = 0;
+      for (int m = 0; m < 3; ++m) {
+        const int len = i - m;
+        if (len < 0) continue;
+        const float v = c.b.best_by_len[(size_t)b * (Lmax + 2) + len];
+        if (v > -INFINITY && v - c.b.best_all[b] < D_END) ++count;
+      }
+      if (count == 3) done = 1;
+    }
+    if (done) c.b.done[b] = 1;
+  }
+}
+
+inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
+                int N, int K, int lda, int ldc, float scale, void* stream) {
+  EmGemmArgs a;
+  a.A = A; a.W = W; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.scale = scale;
+  a.T1 = a.F1 = a.T2 = a.F2 = a.d = 0;
+  return em_gemm(dtype, epi, EM_A_PLAIN, &a, stream);
+}
+
+#define EM_TRY(expr)                \
+  do {                              \
+    int rc__ = (expr);              \
+    if (rc__ != EM_OK) return rc__; \
+  } while (0)
+
+constexpr float LN_EPS = 1e-12f;
+
+int check(const EmSearchParams* p, const EmSearchBuffers* b) {
+  if (!p || !b) return EM_ERR_BAD_ARG;
+  if (p->B <= 0 || p->W <= 0 || p->W > 64 || p->V <= 1 || p->T <= 0 || p->Lmax < 2) return EM_ERR_BAD_ARG;
+  if (p->S <= 0 || p->NC <= 0 || p->end_cap <= 0) return EM_ERR_BAD_ARG;
+  if (p->S >= p->V ? p->NC != p->V : p->NC != p->S + 1) return EM_ERR_BAD_ARG;
+  if (p->w_dec == 0.f && p->w_ctc == 0.f) return EM_ERR_BAD_ARG;
+  if (p->w_dec == 0.f && p->S < p->V) return EM_ERR_BAD_ARG;  // no full scorer -> no pre-beam
+  return EM_OK;
+}
+
+}  // namespace
+
+extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
+                              const EmSearchBuffers* b, const void* enc_act, void* stream) {
+  EM_TRY(check(p, b));
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{*p, *b};
+  const int n = p->B * p->W;
+  if (p->w_dec != 0.f) {
+    if (!dw || !enc_act) return EM_ERR_BAD_ARG;
+    const int d = dw->d;
+    const size_t es = dtype == EM_BF16 ? 2 : 4;
+    // memory K | V of every decoder layer: one GEMM per layer over the whole batch, then V^T
+    for (int l = 0; l < dw->num_blocks; ++l) {
+      unsigned char* kv = (unsigned char*)b->mem_kv + (size_t)l * p->B * p->T * 2 * d * es;
+      unsigned char* vT = (unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
+      EM_TRY(gemm(dtype, EM_EPI_STORE, enc_act, dw->layers[l].src_wkv, kv, dw->layers[l].src_bkv,
+                  p->B * p->T, 2 * d, d, d, 2 * d, 1.f, stream));
+      EM_TRY(em_dec_transpose_v(dtype, kv, p->B, p->T, d, p->Tpad, vT, stream));
+    }
+  }
+  hipLaunchKernelGGL(search_init_rows_kernel, dim3(em_cdiv(n, 64)), dim3(64), 0, s, c);
+  hipLaunchKernelGGL(search_init_utt_kernel, dim3(em_cdiv(p->B, 64)), dim3(64), 0, s, c);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+// Steps i0 .. i1-1 (i = number of tokens after <sos> already in every running hypothesis).
+extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
+                               const EmSearchBuffers* b, int32_t i0, int32_t i1, void* stream) {
+  EM_TRY(check(p, b));
+  if (i0 < 0 || i1 > p->Lmax - 1) return EM_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{*p, *b};
+  const int n = p->B * p->W, V = p->V;
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  for (int i = i0; i < i1; ++i) {
+    if (p->w_dec != 0.f) {
+      const int d = dw->d, ff = dw->ff, h = dw->heads;
+      const int* anc = (i & 1) ? b->anc_b : b->anc_a;
+      EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok + (size_t)i * n, n, V, d, i, b->x, stream));
+      for (int l = 0; l < dw->num_blocks; ++l) {
+        const EmDecoderLayer& q = dw->layers[l];
+        unsigned char* kc = (unsigned char*)b->self_k + (size_t)l * p->Lmax * n * d * es;
+        unsigned char* vc = (unsigned char*)b->self_v + (size_t)l * p->Lmax * n * d * es;
+        const unsigned char* kv = (const unsigned char*)b->mem_kv + (size_t)l * p->B * p->T * 2 * d * es;
+        const unsigned char* vT = (const unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
+        EM_TRY(em_layernorm(dtype, b->x, q.norm1_g, q.norm1_b, n, d, LN_EPS, b->xn, nullptr, stream));
+        EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.self_wqkv, b->qkv, q.self_bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
+        EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, n, d, h, p->Lmax, i, b->ctx, stream));
+        EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.self_wout, b->x, q.self_bout, n, d, d, d, d, 1.f, stream));
+        EM_TRY(em_layernorm(dtype, b->x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->xn, nullptr, stream));
+        EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.src_wq, b->qs, q.src_bq, n, d, d, d, d, 1.f, stream));
+        EM_TRY(em_dec_src_attention(dtype, b->qs, kv, 2 * d, vT, b->xlens, p->B, p->W, d, h, p->T, p->Tpad, b->ctx, stream));
+        EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.src_wout, b->x, q.src_bout, n, d, d, d, d, 1.f, stream));
+        EM_TRY(em_layernorm(dtype, b->x, q.norm3_g, q.norm3_b, n, d, LN_EPS, b->xn, nullptr, stream));
+        EM_TRY(gemm(dtype, EM_EPI_RELU, b->xn, q.w1, b->hbuf, q.b1, n, ff, d, d, ff, 1.f, stream));
+        EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->hbuf, q.w2, b->x, q.b2, n, d, ff, ff, d, 1.f, stream));
+      }
+      EM_TRY(em_layernorm(dtype, b->x, dw->after_norm_g, dw->after_norm_b, n, d, LN_EPS, b->xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_STORE_F32, b->xn, dw->out_w, b->dec_logp, dw->out_b, n, V, d, d, V, 1.f, stream));
+      EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
+      if (p->S < V)
+        hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
+    }
+    {
+      const long threads = (long)n * p->NC;
+      hipLaunchKernelGGL(candidate_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, c, i);
+    }
+    hipLaunchKernelGGL(select_kernel, dim3(p->B), dim3(64), 0, s, c);
+    hipLaunchKernelGGL(update_kernel, dim3(p->B), dim3(64), 0, s, c, i);
+    EM_CHECK_LAUNCH();
+  }
+  return EM_OK;
+}

@@ -62,6 +62,41 @@ class EmConformerWeights(C.Structure):
                 ("after_norm_b", C.c_void_p), ("layers", C.POINTER(EmConformerLayer))]
 
 
+_DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",
+                   "self_bqkv", "self_wout", "self_bout", "src_wq", "src_bq", "src_wkv", "src_bkv",
+                   "src_wout", "src_bout", "w1", "b1", "w2", "b2"]
+
+
+class EmDecoderLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _DEC_LAYER_PTRS]
+
+
+class EmDecoderWeights(C.Structure):
+    _fields_ = [("d", C.c_int32), ("heads", C.c_int32), ("ff", C.c_int32),
+                ("num_blocks", C.c_int32), ("vocab", C.c_int32), ("pe_len", C.c_int32),
+                ("embed", C.c_void_p), ("pe", C.c_void_p), ("after_norm_g", C.c_void_p),
+                ("after_norm_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
+                ("layers", C.POINTER(EmDecoderLayer))]
+
+
+class EmSearchParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "W", "V", "T", "Tpad", "S", "NC", "Lmax", "end_cap",
+                                         "sos", "eos", "blank", "use_end_detect")] + \
+               [(n, C.c_float) for n in ("w_dec", "w_ctc", "w_len")]
+
+
+SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_logp", "tok", "parent", "anc_a", "anc_b",
+                  "alive", "run_score", "run_sdec", "run_sctc", "run_slen", "s_prev", "r_a", "r_b",
+                  "cand_tok", "cand_full", "cand_psi", "cand_total", "sel_idx", "sel_total",
+                  "end_count", "end_pos", "end_slot", "end_forced", "end_score", "end_sdec",
+                  "end_sctc", "end_slen", "best_all", "best_by_len", "done", "x", "xn", "qkv", "qs",
+                  "ctx", "hbuf", "dec_logp", "self_k", "self_v", "mem_kv", "mem_vT"]
+
+
+class EmSearchBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in SEARCH_BUFFERS]
+
+
 _i32, _f32, _vp, _sz = C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 _SIGNATURES = {
     "em_version": (C.c_int, []),
@@ -87,6 +122,16 @@ _SIGNATURES = {
     "em_profile_attach": (None, [_vp]),
     "em_profile_read": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "em_cast_f32": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
+    "em_dec_embed_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "em_dec_self_attention": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                        _vp, _vp]),
+    "em_dec_src_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
+                                       _i32, _i32, _vp, _vp]),
+    "em_dec_transpose_v": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "em_search_init": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),
+                                 C.POINTER(EmSearchBuffers), _vp, _vp]),
+    "em_search_steps": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),
+                                  C.POINTER(EmSearchBuffers), _i32, _i32, _vp]),
     "em_ctc_greedy": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32,
                                 _vp, _vp, _vp, _vp, _vp]),
 }

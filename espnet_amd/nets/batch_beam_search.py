@@ -1,0 +1,233 @@
+"""BatchBeamSearch on the MI355X: label-synchronous joint CTC/attention beam search, batched over
+utterances x beam, fully device resident (csrc/search.hip + csrc/decoder.hip).
+
+Mirrors espnet2/legacy/nets/beam_search.py:36-126 (constructor: scorers / weights / beam_size /
+vocab_size / sos / eos / pre_beam_ratio / pre_beam_score_key / normalize_length; zero-weight
+scorers are dropped) and :385-498 (`forward(x, maxlenratio, minlenratio) -> n-best Hypothesis
+list`), with BatchBeamSearch's step semantics (legacy/nets/batch_beam_search.py:253-423).
+`search_batch` is the utterance-batched entry the MI355X path adds; `forward` keeps the
+reference's single-utterance signature.
+
+Supported scorers: "decoder" (TransformerDecoder), "ctc" (CTCPrefixScorer), "length_bonus".
+An LM / n-gram scorer is SURVEY.md §8(f) "next".
+"""
+import ctypes as C
+import logging
+from typing import Dict, List, Optional
+
+import torch
+
+from espnet_amd import lib as L
+from espnet_amd.nets.beam_search import Hypothesis
+from espnet_amd.nets.scorers.ctc import CTCPrefixScorer
+from espnet_amd.nets.scorers.length_bonus import LengthBonus
+
+logger = logging.getLogger(__name__)
+
+_I32 = {"xlens", "maxlens", "minlens", "tok", "parent", "anc_a", "anc_b", "alive", "cand_tok",
+        "sel_idx", "end_count", "end_pos", "end_slot", "end_forced", "done"}
+_ACT = {"xn", "qkv", "qs", "ctx", "hbuf", "self_k", "self_v", "mem_kv", "mem_vT"}
+
+
+class BeamSearch:
+    def __init__(self, scorers: Dict[str, object], weights: Dict[str, float], beam_size: int,
+                 vocab_size: int, sos: int, eos: int, token_list: List[str] = None,
+                 pre_beam_ratio: float = 1.5, pre_beam_score_key: str = None,
+                 return_hs: bool = False, hyp_primer: List[int] = None,
+                 normalize_length: bool = False):
+        if return_hs or hyp_primer is not None:
+            raise NotImplementedError("return_hs / hyp_primer are outside the MI355X hot path")
+        self.weights = weights
+        self.scorers, self.full_scorers, self.part_scorers = {}, {}, {}
+        for k, v in scorers.items():  # beam_search.py:80-96
+            w = weights.get(k, 0)
+            if w == 0 or v is None:
+                continue
+            if k not in ("decoder", "ctc", "length_bonus"):
+                raise NotImplementedError(f"scorer {k!r}: SURVEY.md §8(f) 'next' (LM / n-gram)")
+            self.scorers[k] = v
+            (self.part_scorers if isinstance(v, CTCPrefixScorer) else self.full_scorers)[k] = v
+        self.sos, self.eos = sos, eos
+        self.token_list = token_list
+        self.pre_beam_size = int(pre_beam_ratio * beam_size)
+        self.beam_size = beam_size
+        self.n_vocab = vocab_size
+        if (pre_beam_score_key is not None and pre_beam_score_key != "full"
+                and pre_beam_score_key not in self.full_scorers):
+            raise KeyError(f"{pre_beam_score_key} is not found in {self.full_scorers}")
+        if pre_beam_score_key not in (None, "full"):
+            raise NotImplementedError("pre_beam_score_key other than 'full'")
+        self.pre_beam_score_key = pre_beam_score_key
+        self.do_pre_beam = (self.pre_beam_score_key is not None
+                            and self.pre_beam_size < self.n_vocab and len(self.part_scorers) > 0)
+        self.normalize_length = normalize_length
+        if "decoder" not in self.scorers and "ctc" not in self.scorers:
+            raise ValueError("beam search needs the decoder and/or the ctc scorer")
+        self._bufs = {}
+        self.step_chunk = 16  # steps enqueued between two polls of the `done` flags
+
+
+class BatchBeamSearch(BeamSearch):
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl):
+        key = (str(dev), act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl)
+        if key in self._bufs:
+            return self._bufs[key]
+        self._bufs.clear()  # one live shape at a time
+        n = B * W
+        use_dec, use_ctc = "decoder" in self.scorers, "ctc" in self.scorers
+        shapes = dict(
+            xlens=(B,), maxlens=(B,), minlens=(B,), tok=(Lmax, n), parent=(Lmax, n),
+            anc_a=(n, Lmax), anc_b=(n, Lmax), alive=(n,), run_score=(n,), run_sdec=(n,),
+            run_sctc=(n,), run_slen=(n,), s_prev=(n,),
+            r_a=(n, T, 2) if use_ctc else (1,), r_b=(n, T, 2) if use_ctc else (1,),
+            cand_tok=(n, NC), cand_full=(n, NC), cand_psi=(n, NC), cand_total=(n, NC),
+            sel_idx=(n,), sel_total=(n,), end_count=(B,), end_pos=(B, cap), end_slot=(B, cap),
+            end_forced=(B, cap), end_score=(B, cap), end_sdec=(B, cap), end_sctc=(B, cap),
+            end_slen=(B, cap), best_all=(B,), best_by_len=(B, Lmax + 2), done=(B,))
+        if use_dec:
+            shapes.update(x=(n, d), xn=(n, d), qkv=(n, 3 * d), qs=(n, d), ctx=(n, d), hbuf=(n, ff),
+                          dec_logp=(n, V), self_k=(nl, Lmax, n, d), self_v=(nl, Lmax, n, d),
+                          mem_kv=(nl, B * T, 2 * d), mem_vT=(nl, B, d, Tpad))
+        t = {}
+        for name, shp in shapes.items():
+            dt = torch.int32 if name in _I32 else (act if name in _ACT else torch.float32)
+            t[name] = (torch.zeros if name == "mem_vT" else torch.empty)(shp, dtype=dt, device=dev)
+        self._bufs[key] = t
+        return t
+
+    # ------------------------------------------------------------------ batched search
+    @torch.no_grad()
+    def search_batch(self, enc_act: torch.Tensor, olens: List[int], maxlenratio: float = 0.0,
+                     minlenratio: float = 0.0) -> List[List[Hypothesis]]:
+        """enc_act (B, T, d) encoder output in the compute dtype ON THE GPU; olens host ints.
+        Returns the ended hypotheses of every utterance, best first (beam_search.py:453-461)."""
+        L.require_gpu(enc_act, "enc_act")
+        lib = L.load()
+        dev = enc_act.device
+        B, T, d = enc_act.shape
+        W, V = self.beam_size, self.n_vocab
+        dec = self.scorers.get("decoder")
+        ctc_sc = self.scorers.get("ctc")
+        em_dtype = dec.em_dtype if dec is not None else ctc_sc.ctc.em_dtype
+        act = torch.bfloat16 if em_dtype == L.EM_BF16 else torch.float32
+        enc_act = enc_act.to(act).contiguous()
+        # length bounds per utterance (beam_search.py:414-429 with inp.shape[0] = olens[b])
+        maxlens, minlens = [], []
+        for tb in olens:
+            if maxlenratio == 0:
+                ml = tb
+            elif maxlenratio < 0:
+                ml = -1 * int(maxlenratio)
+            else:
+                ml = max(1, int(maxlenratio * tb))
+            maxlens.append(ml)
+            minlens.append(-1 * int(minlenratio) if minlenratio < 0 else int(minlenratio * tb))
+        Lmax = max(maxlens) + 2
+        S = self.pre_beam_size if self.do_pre_beam else V
+        NC = S + 1 if S < V else V
+        cap = W * (max(maxlens) + 1)
+        Tpad = (T + 31) // 32 * 32
+        nl = dec.num_blocks if dec is not None else 0
+        ff = dec.linear_units if dec is not None else 0
+        bufs = self._alloc(dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl)
+        bufs["xlens"].copy_(torch.tensor(olens, dtype=torch.int32))
+        bufs["maxlens"].copy_(torch.tensor(maxlens, dtype=torch.int32))
+        bufs["minlens"].copy_(torch.tensor(minlens, dtype=torch.int32))
+        ctc_logp = None
+        if ctc_sc is not None:
+            ctc_logp = ctc_sc.ctc.log_softmax(enc_act)  # (B,T,V) f32, scorers/ctc.py:96
+        p = L.EmSearchParams(B=B, W=W, V=V, T=T, Tpad=Tpad, S=S, NC=NC, Lmax=Lmax, end_cap=cap,
+                             sos=self.sos, eos=self.eos, blank=0,
+                             use_end_detect=1 if maxlenratio == 0.0 else 0,
+                             w_dec=float(self.weights.get("decoder", 0.0)) if dec is not None else 0.0,
+                             w_ctc=float(self.weights.get("ctc", 0.0)) if ctc_sc is not None else 0.0,
+                             w_len=float(self.weights.get("length_bonus", 0.0))
+                             if "length_bonus" in self.scorers else 0.0)
+        bs = L.EmSearchBuffers()
+        for name in L.SEARCH_BUFFERS:
+            if name == "ctc_logp":
+                bs.ctc_logp = ctc_logp.data_ptr() if ctc_logp is not None else None
+            else:
+                setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
+        dw = dec.ensure_packed(dev, Lmax)["w"] if dec is not None else None
+        dwp = C.byref(dw) if dw is not None else None
+        stream = L.current_stream_ptr()
+        L.check(lib.em_search_init(em_dtype, C.byref(p), dwp, C.byref(bs), L.ptr(enc_act), stream),
+                "em_search_init")
+        i, imax = 0, max(maxlens)
+        while i < imax:
+            j = min(imax, i + self.step_chunk)
+            L.check(lib.em_search_steps(em_dtype, C.byref(p), dwp, C.byref(bs), i, j, stream),
+                    "em_search_steps")
+            i = j
+            if i < imax and bool(bufs["done"].all().item()):  # the only host sync of the search
+                break
+        return self._collect(bufs, B, W, maxlens)
+
+    # ------------------------------------------------------------------ readout (host)
+    def _collect(self, bufs, B, W, maxlens) -> List[List[Hypothesis]]:
+        cpu = {k: bufs[k].cpu() for k in ("end_count", "end_pos", "end_slot", "end_forced",
+                                          "end_score", "end_sdec", "end_sctc", "end_slen", "tok",
+                                          "parent")}
+        tok, parent = cpu["tok"], cpu["parent"]
+        keys = [k for k in ("decoder", "ctc", "length_bonus") if k in self.scorers]
+        col = dict(decoder="end_sdec", ctc="end_sctc", length_bonus="end_slen")
+        out = []
+        for b in range(B):
+            hyps = []
+            for e in range(int(cpu["end_count"][b])):
+                pos, slot = int(cpu["end_pos"][b, e]), int(cpu["end_slot"][b, e])
+                ys = []
+                while pos >= 0:
+                    ys.append(int(tok[pos, slot]))
+                    slot = int(parent[pos, slot])
+                    pos -= 1
+                ys.reverse()
+                if int(cpu["end_forced"][b, e]):
+                    ys.append(self.eos)
+                hyps.append(Hypothesis(yseq=torch.tensor(ys, dtype=torch.long),
+                                       score=cpu["end_score"][b, e].clone(),
+                                       scores={k: cpu[col[k]][b, e].clone() for k in keys}))
+            if self.normalize_length:  # beam_search.py:453-459
+                hyps.sort(key=lambda h: float(h.score) / (len(h.yseq) - 1), reverse=True)
+            else:
+                hyps.sort(key=lambda h: float(h.score), reverse=True)
+            if len(hyps) == 0:
+                logger.warning("there is no N-best results, perform recognition again with smaller minlenratio.")
+            out.append(hyps)
+        return out
+
+    # ------------------------------------------------------------------ reference signature
+    def forward(self, x: torch.Tensor, maxlenratio: float = 0.0, minlenratio: float = 0.0,
+                pre_x: torch.Tensor = None) -> List[Hypothesis]:
+        """x (T, D) encoded speech of ONE utterance (beam_search.py:385-498)."""
+        if pre_x is not None:
+            raise NotImplementedError("sequential attention (pre_x)")
+        L.require_gpu(x, "x")
+        logger.info("decoder input length: " + str(x.shape[0]))
+        nbest = self.search_batch(x.unsqueeze(0), [int(x.shape[0])], maxlenratio, minlenratio)[0]
+        if len(nbest) == 0:
+            return [] if minlenratio < 0.1 else self.forward(x, maxlenratio, max(0.0, minlenratio - 0.1))
+        best = nbest[0]
+        for k, v in best.scores.items():
+            logger.info(f"{float(v):6.2f} * {self.weights[k]:3} = {float(v) * self.weights[k]:6.2f} for {k}")
+        logger.info(f"total log probability: {float(best.score):.2f}")
+        logger.info(f"normalized log probability: {float(best.score) / len(best.yseq):.2f}")
+        return nbest
+
+    __call__ = forward
+
+
+def build_beam_search(asr_model, beam_size: int, ctc_weight: float, penalty: float,
+                      lm_weight: float = 0.0, token_list=None, normalize_length: bool = False):
+    """Scorer / weight set-up of Speech2Text (espnet2/bin/asr_inference.py:168-176, 310-316,
+    353-381)."""
+    scorers = dict(decoder=asr_model.decoder,
+                   ctc=CTCPrefixScorer(ctc=asr_model.ctc, eos=asr_model.eos) if asr_model.ctc is not None else None,
+                   length_bonus=LengthBonus(len(token_list)))
+    weights = dict(decoder=1.0 - ctc_weight, ctc=ctc_weight, lm=lm_weight, length_bonus=penalty)
+    return BatchBeamSearch(beam_size=beam_size, weights=weights, scorers=scorers, sos=asr_model.sos,
+                           eos=asr_model.eos, vocab_size=len(token_list), token_list=token_list,
+                           pre_beam_score_key=None if ctc_weight == 1.0 else "full",
+                           normalize_length=normalize_length)

@@ -191,6 +191,108 @@ int em_ctc_greedy(int dtype, const void* enc_act, const void* w_ctc, const float
                   int32_t sos_eos, float* logits_ws, int32_t* ids, int32_t* tokens,
                   int32_t* out_lens, void* stream);
 
+/* ---- A14: attention-decoder step (TransformerDecoder.batch_score / forward_one_step,
+ *      espnet2/asr/decoder/transformer_decoder.py:191-311; DecoderLayer.forward with cache,
+ *      transformer/decoder_layer.py:73-179; MultiHeadedAttention, transformer/attention.py:77-265).
+ *      K/V are true caches (identical values to the reference's per-step re-projection):
+ *      self-attention K/V live in a token-tree cache indexed through `anc`, source-attention
+ *      K / V^T of the encoder memory are computed once per utterance by em_search_init.          */
+/*   x[r] = embed[tok_row[r]] * sqrt(d) + pe[pos]  (embedding.py:93);  embed [V][d], pe [>pos][d] f32 */
+int em_dec_embed_f32(const float* embed, const float* pe, const int32_t* tok_row, int32_t n,
+                     int32_t V, int32_t d, int32_t pos, float* x, void* stream);
+/*   qkv [n][3d] act (q|k|v of the token at position pos); kc,vc [Lmax][n][d] act (one layer);
+ *   anc [n][Lmax] i32 slot of every prefix position; ctx [n][d] act out.  d/heads in {32, 64}.    */
+int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc, const int32_t* anc,
+                          int32_t n, int32_t d, int32_t heads, int32_t Lmax, int32_t pos,
+                          void* ctx, void* stream);
+/*   qs [B*W][d] act; kmem: K rows of utterance b at kmem + (b*T + t)*ldk; vT [B][d][Tpad] act
+ *   (zero padded, Tpad % 32 == 0); klens [B] valid memory frames; ctx [B*W][d] act out.           */
+int em_dec_src_attention(int dtype, const void* qs, const void* kmem, int32_t ldk, const void* vT,
+                         const int32_t* klens, int32_t B, int32_t W, int32_t d, int32_t heads,
+                         int32_t T, int32_t Tpad, void* ctx, void* stream);
+/*   vT[b][c][t] = kv[(b*T + t)*2d + d + c]                                                       */
+int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t T, int32_t d, int32_t Tpad,
+                       void* vT, void* stream);
+
+typedef struct EmDecoderLayer {
+  const float *norm1_g, *norm1_b, *norm2_g, *norm2_b, *norm3_g, *norm3_b;
+  const void* self_wqkv; /* [3d][d] act: self_attn.linear_q | linear_k | linear_v */
+  const float* self_bqkv;
+  const void* self_wout; /* [d][d] act */
+  const float* self_bout;
+  const void* src_wq; /* [d][d] act */
+  const float* src_bq;
+  const void* src_wkv; /* [2d][d] act: src_attn.linear_k | linear_v (used once per utterance) */
+  const float* src_bkv;
+  const void* src_wout;
+  const float* src_bout;
+  const void* w1; /* [ff][d] act (ReLU FFN) */
+  const float* b1;
+  const void* w2; /* [d][ff] act */
+  const float* b2;
+} EmDecoderLayer;
+
+typedef struct EmDecoderWeights {
+  int32_t d, heads, ff, num_blocks, vocab, pe_len;
+  const float* embed; /* [V][d] f32: decoder.embed.0.weight */
+  const float* pe;    /* [pe_len][d] f32 absolute sinusoid table (embedding.py:56-79) */
+  const float *after_norm_g, *after_norm_b;
+  const void* out_w; /* [V][d] act: decoder.output_layer */
+  const float* out_b;
+  const EmDecoderLayer* layers; /* [num_blocks], host array */
+} EmDecoderWeights;
+
+/* ---- A12 + A13: label-synchronous joint CTC/attention beam search, batched over utterances
+ *      (BatchBeamSearch.search / post_process, espnet2/legacy/nets/batch_beam_search.py:253-423;
+ *      BeamSearch.forward, legacy/nets/beam_search.py:385-498; CTCPrefixScoreTH.__call__,
+ *      legacy/nets/ctc_prefix_score.py:71-191; end_detect, legacy/nets/e2e_asr_common.py:14-44).
+ *      n = B*W rows (row = b*W + k).  Every buffer is caller-owned device memory.               */
+typedef struct EmSearchParams {
+  int32_t B, W, V;
+  int32_t T, Tpad;     /* memory frames of the batch (max) and its multiple-of-32 padding */
+  int32_t S;           /* pre-beam size int(1.5*W), or V when there is no pre-beam (beam_search.py:105-119) */
+  int32_t NC;          /* candidate slots per row: S+1 (the extra slot is <eos>) or V */
+  int32_t Lmax;        /* token positions held per hypothesis (>= max maxlen + 2) */
+  int32_t end_cap;     /* capacity of the per-utterance ended list */
+  int32_t sos, eos, blank;
+  int32_t use_end_detect; /* maxlenratio == 0 (beam_search.py:443) */
+  float w_dec, w_ctc, w_len; /* scorer weights: decoder, ctc, length_bonus (asr_inference.py:310-316) */
+} EmSearchParams;
+
+typedef struct EmSearchBuffers {
+  const int32_t *xlens, *maxlens, *minlens; /* [B] valid memory frames, max / min output length */
+  const float* ctc_logp;                    /* [B][T][V] CTC.log_softmax(enc) (scorers/ctc.py:96) */
+  int32_t *tok, *parent;                    /* [Lmax][n] token tree */
+  int32_t *anc_a, *anc_b;                   /* [n][Lmax] ancestor slots, double buffered by step parity */
+  int32_t* alive;                           /* [n] */
+  float *run_score, *run_sdec, *run_sctc, *run_slen, *s_prev; /* [n] */
+  float *r_a, *r_b;                         /* [n][T][2] CTC forward variables (r^n, r^b) */
+  int32_t* cand_tok;                        /* [n][NC] */
+  float *cand_full, *cand_psi, *cand_total; /* [n][NC] */
+  int32_t* sel_idx;                         /* [n] */
+  float* sel_total;                         /* [n] */
+  int32_t *end_count;                       /* [B] */
+  int32_t *end_pos, *end_slot, *end_forced; /* [B][end_cap] tree node of the last token; forced <eos> flag */
+  float *end_score, *end_sdec, *end_sctc, *end_slen; /* [B][end_cap] */
+  float *best_all, *best_by_len;            /* [B], [B][Lmax+2] end-detection statistics */
+  int32_t* done;                            /* [B] */
+  float* x;                                 /* [n][d] f32 decoder residual stream */
+  void *xn, *qkv, *qs, *ctx, *hbuf;         /* act: [n][d], [n][3d], [n][d], [n][d], [n][ff] */
+  float* dec_logp;                          /* [n][V] */
+  void *self_k, *self_v;                    /* act [layers][Lmax][n][d] */
+  void *mem_kv;                             /* act [layers][B*T][2d] */
+  void *mem_vT;                             /* act [layers][B][d][Tpad], zero initialised by the caller */
+} EmSearchBuffers;
+
+/*   Projects the encoder memory (enc_act [B][T][d] act) to per-layer K | V and V^T, and writes the
+ *   initial search state (one alive <sos> hypothesis per utterance, CTC r_prev of the empty prefix). */
+int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
+                   const EmSearchBuffers* b, const void* enc_act, void* stream);
+/*   Enqueues search steps i0 .. i1-1 (decoder step, pre-beam, CTC prefix scores, top-W, update).
+ *   Utterances whose `done` flag is set are skipped; the host polls `done` between calls.        */
+int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
+                    const EmSearchBuffers* b, int32_t i0, int32_t i1, void* stream);
+
 /* ---- optional per-launch timing of the GEMM kernel family (measurement only; bench.py's
  *      `roofline` leg).  While a profile is attached to the calling thread every em_gemm launch
  *      (direct or from em_conformer_encode / em_ctc_greedy) is bracketed by hipEventRecord on its
