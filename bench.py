@@ -106,17 +106,62 @@ def cpu_baseline(model, budget_s=12.0):
                       f"{med*1e3:.1f} ms/utt (frontend + encoder + greedy CTC G1), 1 warm-up"}
 
 
+def cpu_baseline_beam(model, beam, ctc_weight, budget_s=25.0):
+    """Oracle port of the reference Speech2Text beam search (oracle/beam_search.py; K/V-cached,
+    i.e. FASTER than the reference's own CPU path, which measured 13.3 s/utt here) on host cores."""
+    from oracle import beam_search as ob
+    from oracle import conformer as oc
+
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    enc, dec, fe = model.encoder, model.decoder, model.frontend
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(32, avail))
+    torch.set_num_threads(cores)
+    times = []
+    t_start = time.perf_counter()
+    i = 0
+    with torch.no_grad():
+        while True:
+            wav = synth_batch(9000 + i, 1)
+            t0 = time.perf_counter()
+            e, ol = oc.encode(sd, wav, torch.tensor([N_SAMPLES]), enc.heads, enc.num_blocks, 512,
+                              fe.win_length, 160)
+            ob.beam_search(sd, e[0, : int(ol[0])], dec.heads, dec.num_blocks, beam, ctc_weight,
+                           sos=VOCAB - 1, eos=VOCAB - 1)
+            times.append(time.perf_counter() - t0)
+            i += 1
+            if time.perf_counter() - t_start > budget_s or len(times) >= 20:
+                break
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(AUDIO_SEC / med, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"oracle CPU-fp32 port (K/V-cached restatement of Speech2Text beam search), "
+                      f"{len(times)} utterances of 10 s, batch 1, median {med:.2f} s/utt "
+                      f"(frontend + encoder + beam {beam} search, 249 steps), no warm-up"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
-    ap.add_argument("--model", default="small", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step")
+    ap.add_argument("--model", default=None, choices=sorted(CONFIGS))
+    ap.add_argument("--workload", default="greedy", choices=["greedy", "beam"],
+                    help="greedy = BASELINE.json configs[1] (the bench line); beam = configs[2]: "
+                         "Conformer-large, joint CTC/attention beam 10, batch 16")
+    ap.add_argument("--beam", type=int, default=10)
+    ap.add_argument("--ctc-weight", type=float, default=0.3)
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.model is None:
+        args.model = "small" if args.workload == "greedy" else "large"
+    if args.batch is None:
+        args.batch = 32 if args.workload == "greedy" else 16
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,9 +188,27 @@ def main():
     gathered_tok = torch.empty(world * B, T, dtype=torch.int32, device=dev) if world > 1 else None
     gathered_len = torch.empty(world * B, dtype=torch.int32, device=dev) if world > 1 else None
 
+    beam_search = None
+    if args.workload == "beam":
+        from espnet_amd.nets.batch_beam_search import build_beam_search
+
+        beam_search = build_beam_search(model, beam_size=args.beam, ctc_weight=args.ctc_weight,
+                                        penalty=0.0, token_list=model.token_list)
+
     def step():
         st = model.encode_device(wav, lens)
-        _, tokens, tlens = model.greedy_ctc_device(st)
+        if beam_search is None:
+            _, tokens, tlens = model.greedy_ctc_device(st)
+        else:  # n-best lists are rebuilt on the host; the best one is padded back for collation
+            nbest = beam_search.search_batch(st.enc_act, st.olens)
+            tokens = torch.full((B, T), -1, dtype=torch.int32)
+            tl = []
+            for b, hyps in enumerate(nbest):
+                ids = [t for t in hyps[0].yseq[1:-1].tolist() if t != 0][:T] if hyps else []
+                tokens[b, : len(ids)] = torch.tensor(ids, dtype=torch.int32)
+                tl.append(len(ids))
+            tokens = tokens.to(dev)
+            tlens = torch.tensor(tl, dtype=torch.int32, device=dev)
         if world > 1:  # collate hypotheses: one RCCL all-gather of fixed-shape ids + lengths
             dist.all_gather_into_tensor(gathered_tok, tokens)
             dist.all_gather_into_tensor(gathered_len, tlens)
@@ -180,28 +243,33 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: Conformer-{args.model} "
-                                   f"(12x{CONFIGS[args.model]['d']}d, {CONFIGS[args.model]['heads']} heads), "
-                                   f"HIP STFT/log-mel + HIP encoder + greedy CTC (G1), "
-                                   f"{B} x 10 s utterances per GPU per step, V={VOCAB}",
+            "config": {"workload": (f"BASELINE.json configs[1]: Conformer-{args.model} "
+                                    f"(12x{CONFIGS[args.model]['d']}d, {CONFIGS[args.model]['heads']} heads), "
+                                    f"HIP STFT/log-mel + HIP encoder + greedy CTC (G1), "
+                                    f"{B} x 10 s utterances per GPU per step, V={VOCAB}")
+                       if beam_search is None else
+                       (f"BASELINE.json configs[2]: Conformer-{args.model} "
+                        f"(12x{CONFIGS[args.model]['d']}d, {CONFIGS[args.model]['heads']} heads) + 6-layer "
+                        f"attention decoder, joint CTC/attention beam search beam={args.beam} "
+                        f"ctc_weight={args.ctc_weight}, {B} x 10 s utterances per GPU per step, V={VOCAB}"),
                        "batch_per_gpu": B, "global_batch": world * B, "audio_seconds_per_utt": AUDIO_SEC,
                        "parallelism": f"utterance-dp{world}", "greedy_tokens_last_step_rank0": n_tok},
         }
     # ---- roofline of the dominant kernel family (GEMM template): HIP events around every launch
     if rank == 0 and not args.no_roofline:
         lib = L.load()
-        cap = 4096
+        cap = 32768
         prof = lib.em_profile_create(cap)
         ms = (C.c_float * cap)()
         fl = (C.c_double * cap)()
         cnt = C.c_int32(0)
         tot_ms = tot_fl = 0.0
         launches = 0
-        nprof = max(1, min(args.steps, 5))
+        nprof = max(1, min(args.steps, 5 if beam_search is None else 1))
         with torch.no_grad():
             for _ in range(nprof):
                 lib.em_profile_attach(prof)
-                model.greedy_ctc_device(model.encode_device(wav, lens))
+                step()
                 lib.em_profile_attach(None)
                 L.check(lib.em_profile_read(prof, ms, fl, cap, C.byref(cnt)), "em_profile_read")
                 tot_ms += sum(ms[i] for i in range(cnt.value))
@@ -220,7 +288,8 @@ def main():
             "gemm_ms_per_step": round(tot_ms / nprof, 3),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model)
+        out["cpu_baseline"] = (cpu_baseline(model) if beam_search is None
+                               else cpu_baseline_beam(model, args.beam, args.ctc_weight))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

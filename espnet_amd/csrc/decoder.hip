@@ -35,87 +35,136 @@ __global__ __launch_bounds__(128) void dec_embed_kernel(const float* __restrict_
 }
 
 template <typename T>
-__device__ __forceinline__ float dot_row(const T* __restrict__ k, const float* q, int DK);
-
+__device__ __forceinline__ void load8(const T* __restrict__ p, float o[8]);
 template <>
-__device__ __forceinline__ float dot_row<bf16>(const bf16* __restrict__ k, const float* q, int DK) {
-  float acc = 0.f;
-  for (int c = 0; c < DK; c += 8) {
-    bf16x8 v = *(const bf16x8*)(k + c);
+__device__ __forceinline__ void load8<bf16>(const bf16* __restrict__ p, float o[8]) {
+  const bf16x8 v = *(const bf16x8*)p;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc = fmaf(q[c + e], (float)v[e], acc);
-  }
-  return acc;
+  for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
 }
 template <>
-__device__ __forceinline__ float dot_row<float>(const float* __restrict__ k, const float* q, int DK) {
-  float acc = 0.f;
-  for (int c = 0; c < DK; c += 4) {
-    float4 v = *(const float4*)(k + c);
-    acc = fmaf(q[c], v.x, acc);
-    acc = fmaf(q[c + 1], v.y, acc);
-    acc = fmaf(q[c + 2], v.z, acc);
-    acc = fmaf(q[c + 3], v.w, acc);
-  }
-  return acc;
+__device__ __forceinline__ void load8<float>(const float* __restrict__ p, float o[8]) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+  o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* __restrict__ p, const float o[8]);
+template <>
+__device__ __forceinline__ void store8<bf16>(bf16* __restrict__ p, const float o[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16)o[e];
+  *(bf16x8*)p = v;
+}
+template <>
+__device__ __forceinline__ void store8<float>(float* __restrict__ p, const float o[8]) {
+  *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
+  *(float4*)(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
 }
 
 // One wave per (hypothesis row, head).  qkv [n][3d] (q | k | v of the token at position `pos`);
 // kc/vc [Lmax][n][d] (this layer); anc [n][Lmax].  ctx [n][d].
-constexpr int SA_MAXJ = 16;  // positions per lane: Lmax <= 1024
+// Lane = (position sub-index jsub, 8-channel chunk ch): one wave-wide load instruction covers
+// NJ = 64/(DK/8) prefix positions x the whole head (16-byte loads for bf16), so a 250-token prefix
+// is 32 iterations for QK^T and 32 for PV; partial dots are reduced across the chunk lanes,
+// partial contexts across the position lanes.
+constexpr int SA_MAXL = 1024;
 template <typename T, int DK>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ qkv,
                                                            T* __restrict__ kc, T* __restrict__ vc,
                                                            const int* __restrict__ anc, int n,
                                                            int d, int Lmax, int pos,
                                                            T* __restrict__ ctx) {
-  __shared__ float p_s[SA_MAXJ * 64];
+  constexpr int NCH = DK / 8;   // lanes per position
+  constexpr int NJ = 64 / NCH;  // positions per iteration
+  __shared__ float p_s[SA_MAXL];
+  __shared__ int a_s[SA_MAXL];
   const int h = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+  const int ch = lane % NCH, jsub = lane / NCH;
   const T* row = qkv + (size_t)r * 3 * d + h * DK;
-  float q[DK];
-#pragma unroll
-  for (int c = 0; c < DK; ++c) q[c] = to_f32(row[c]);
+  float q[8];
+  load8<T>(row + ch * 8, q);
   // append this position's K/V to the cache (read back by later steps only)
-  if (lane < DK) {
-    const size_t o = ((size_t)pos * n + r) * d + h * DK + lane;
-    kc[o] = row[d + lane];
-    vc[o] = row[2 * d + lane];
+  if (lane < NCH) {
+    const size_t o = ((size_t)pos * n + r) * d + h * DK + lane * 8;
+    float t8[8];
+    load8<T>(row + d + lane * 8, t8);
+    store8<T>(kc + o, t8);
+    load8<T>(row + 2 * d + lane * 8, t8);
+    store8<T>(vc + o, t8);
   }
   const float scale = rsqrtf((float)DK);
-  const int* arow = anc + (size_t)r * Lmax;
-  float sc[SA_MAXJ];
-  float mx = -INFINITY;
+  // ancestor slots of the prefix: one coalesced read into LDS, so the K/V row addresses of the
+  // loops below do not hang off a second dependent global load
+  for (int j = lane; j < pos; j += 64) a_s[j] = anc[(size_t)r * Lmax + j];
+  __syncthreads();
+  const int niter = (pos + NJ) / NJ;  // ceil((pos+1)/NJ)
+  for (int it0 = 0; it0 < niter; it0 += 4) {
+    float k8[4][8];
 #pragma unroll
-  for (int jj = 0; jj < SA_MAXJ; ++jj) {
-    const int j = jj * 64 + lane;
-    sc[jj] = -INFINITY;
-    if (jj * 64 <= pos && j <= pos) {
-      const T* kr = (j == pos) ? row + d : kc + ((size_t)j * n + arow[j]) * d + h * DK;
-      sc[jj] = dot_row<T>(kr, q, DK) * scale;
-      mx = fmaxf(mx, sc[jj]);
+    for (int u = 0; u < 4; ++u) {  // issue the (up to) four row loads first
+      const int j = (it0 + u) * NJ + jsub;
+      if (j <= pos) {
+        const T* kr = (j == pos) ? row + d : kc + ((size_t)j * n + a_s[j]) * d + h * DK;
+        load8<T>(kr + ch * 8, k8[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = (it0 + u) * NJ + jsub;
+      float dot = 0.f;
+      if (j <= pos) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dot = fmaf(q[e], k8[u][e], dot);
+      }
+#pragma unroll
+      for (int o = 1; o < NCH; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      if (ch == 0 && j <= pos) p_s[j] = dot * scale;
     }
   }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = lane; j <= pos; j += 64) mx = fmaxf(mx, p_s[j]);
   mx = wave_max(mx);
   float sum = 0.f;
-#pragma unroll
-  for (int jj = 0; jj < SA_MAXJ; ++jj) {
-    const int j = jj * 64 + lane;
-    if (jj * 64 <= pos) {
-      float p = (j <= pos) ? expf(sc[jj] - mx) : 0.f;
-      sum += p;
-      p_s[j] = p;
-    }
+  for (int j = lane; j <= pos; j += 64) {
+    const float p = expf(p_s[j] - mx);
+    p_s[j] = p;
+    sum += p;
   }
   sum = wave_sum(sum);
   __syncthreads();
-  if (lane < DK) {
-    float acc = 0.f;
-    for (int j = 0; j < pos; ++j) {
-      const T* vr = vc + ((size_t)j * n + arow[j]) * d + h * DK;
-      acc = fmaf(p_s[j], to_f32(vr[lane]), acc);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int it0 = 0; it0 < niter; it0 += 4) {
+    float v8[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = (it0 + u) * NJ + jsub;
+      if (j <= pos) {
+        const T* vr = (j == pos) ? row + 2 * d : vc + ((size_t)j * n + a_s[j]) * d + h * DK;
+        load8<T>(vr + ch * 8, v8[u]);
+      }
     }
-    acc = fmaf(p_s[pos], to_f32(row[2 * d + lane]), acc);
-    ctx[(size_t)r * d + h * DK + lane] = from_f32<T>(acc / sum);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = (it0 + u) * NJ + jsub;
+      if (j <= pos) {
+        const float p = p_s[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v8[u][e], acc[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = NCH; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  if (lane < NCH) {
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    store8<T>(ctx + (size_t)r * d + h * DK + lane * 8, acc);
   }
 }
 
@@ -273,7 +322,7 @@ extern "C" int em_dec_embed_f32(const float* embed, const float* pe, const int32
 extern "C" int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc,
                                      const int32_t* anc, int32_t n, int32_t d, int32_t heads,
                                      int32_t Lmax, int32_t pos, void* ctx, void* stream) {
-  if (n <= 0 || heads <= 0 || pos < 0 || pos >= Lmax || Lmax > SA_MAXJ * 64) return EM_ERR_BAD_ARG;
+  if (n <= 0 || heads <= 0 || pos < 0 || pos >= Lmax || Lmax > SA_MAXL) return EM_ERR_BAD_ARG;
   if (dtype == EM_F32)
     return self_attn_launch<float>(qkv, kc, vc, anc, n, d, heads, Lmax, pos, ctx, (hipStream_t)stream);
   if (dtype == EM_BF16)

@@ -17,10 +17,10 @@
 // S candidates (+ <eos>) -> per-utterance top-W -> state update (tree, anc, scores, CTC forward
 // variables of the winners, ended list, end detection).  No host synchronisation inside a step.
 //
-// CTC prefix scoring: one thread per (row, candidate) runs the forward-variable recurrence over
-// the T frames sequentially in registers; the winners' forward variables (the next step's r_prev)
-// are re-derived by the same device function in the update kernel rather than storing all
-// S candidates' (T,2) tables (S = V when ctc_weight = 1).
+// CTC prefix scoring: a candidate's log psi is a reduction over frames of terms built from the
+// PREFIX's forward variables, so it is computed by one wave per (row, candidate) with lanes over
+// frames; the forward-variable recurrence itself (sequential in t) runs only for the W winners
+// per utterance, in the update kernel.  CTC log-probs are kept transposed ([V][B*T]).
 #include <math.h>
 
 #include "em_common.h"
@@ -31,50 +31,22 @@ constexpr float LOGZERO = -10000000000.0f;  // ctc_prefix_score.py:34
 constexpr float D_END = -10.0f;             // log(1 * exp(-10)), e2e_asr_common.py:14
 
 __device__ __forceinline__ float logaddexp_(float a, float b) {
-  // torch.logsumexp over two elements: max + log(exp(a-max) + exp(b-max))
+  // torch.logsumexp over two elements: max + log(exp(a-max) + exp(b-max)); one of the two
+  // exponentials is exactly 1.  The forward variables reach magnitudes of 1e2..1e3, where an f32
+  // ulp (6e-5 at 1e3) dwarfs the error of the hardware exp/log approximations used here.
   const float m = fmaxf(a, b);
-  return m + logf(expf(a - m) + expf(b - m));
+  return m + __logf(1.0f + __expf(-fabsf(a - b)));
 }
 
-// Forward-variable recurrence of one (prefix, candidate label c) pair; returns log psi.
-//   lp      log-probs of this utterance, [T][V]
-//   rprev   forward variables of the prefix, [T] x (r^n, r^b)
-//   i       prefix length without <sos> (= step index)
-// WRITE: also store the new forward variables rout[t] for every t < xlen.
-template <bool WRITE>
-__device__ __forceinline__ float ctc_prefix_scan(const float* __restrict__ lp, int V, int xlen,
-                                                 int c, int blank, int last, int i,
-                                                 const float2* __restrict__ rprev,
-                                                 float2* __restrict__ rout) {
-  const int start = i > 1 ? i : 1;
-  float rn = LOGZERO, rb = LOGZERO;
-  if (i == 0) rn = lp[c];  // r[0,0] = x[0] (:131-132)
-  if (WRITE) {
-    for (int t = 0; t < start - 1; ++t) rout[t] = make_float2(LOGZERO, LOGZERO);
-    rout[start - 1] = make_float2(rn, rb);
-  }
-  // log psi = logsumexp_t(log_phi[t-1] + x[t]) (+) r[start-1, 0]   (:166-181), online form
-  float m = rn, s = 1.0f;
-#pragma unroll 4
-  for (int t = start; t < xlen; ++t) {
-    const float2 rp = rprev[t - 1];
-    const float phi = (c == last) ? rp.y : logaddexp_(rp.x, rp.y);  // :135-144
-    const float xn = lp[(size_t)t * V + c], xb = lp[(size_t)t * V + blank];
-    const float nn = logaddexp_(rn, phi) + xn;  // :158-164
-    const float nb = logaddexp_(rn, rb) + xb;
-    const float term = phi + xn;
-    if (term > m) {
-      s = s * expf(m - term) + 1.0f;
-      m = term;
-    } else {
-      s += expf(term - m);
-    }
-    rn = nn;
-    rb = nb;
-    if (WRITE) rout[t] = make_float2(rn, rb);
-  }
-  return m + logf(s);
-}
+// CTC log-probs are held TRANSPOSED, lpT[v][b*T + t] (em_search_init), so that the T frames of
+// one (utterance, label) pair are contiguous: a wave reads them with one coalesced load per lane
+// and a thread walking them sequentially stays inside a few cache lines / one page.
+//
+// log psi of a candidate needs NO recurrence: log_psi = logsumexp_t(log_phi[t-1] + x[t]) (+)
+// r[start-1, 0] where log_phi comes from the PREFIX's forward variables (ctc_prefix_score.py
+// :135-144, :166-181).  It is a pure reduction over t -> one wave per (row, candidate), lanes over
+// frames (`candidate_kernel`).  Only the W winners per utterance need the sequential recurrence
+// r[t] (:158-164), which yields the next step's r_prev (`ctc_state_scan`).
 
 struct Ctx {
   EmSearchParams p;
@@ -110,19 +82,130 @@ __global__ void search_init_utt_kernel(Ctx c) {
   c.b.best_all[b] = -INFINITY;
   for (int l = 0; l < c.p.Lmax + 2; ++l) c.b.best_by_len[(size_t)b * (c.p.Lmax + 2) + l] = -INFINITY;
   if (c.p.w_ctc != 0.f) {
-    const float* lp = c.b.ctc_logp + (size_t)b * c.p.T * c.p.V;
+    const float* xb = c.b.ctc_lpT + (size_t)c.p.blank * c.p.B * c.p.T + (size_t)b * c.p.T;
     float2* r0 = (float2*)c.b.r_a + (size_t)(b * c.p.W) * c.p.T;
     float cum = 0.f;
     for (int t = 0; t < c.p.T; ++t) {
-      cum += lp[(size_t)t * c.p.V + c.p.blank];
+      cum += xb[t];
       r0[t] = make_float2(LOGZERO, cum);
     }
   }
 }
 
-// ---- step 1: pre-beam.  One wave per row: top-S token ids of the weighted full scores --------
-// (batch_beam_search.py:289-302).  Row values staged in LDS; S rounds of wave arg-max
-// (ties -> lowest id).  cand_tok / cand_full[row][0..S).
+// ---- step 1: decoder log-softmax + pre-beam, one 256-thread workgroup per row ----------------
+// logits -> log-probs in place (transformer_decoder.py:233), then the top-S token ids of the
+// weighted full scores w_dec*logp + w_len (batch_beam_search.py:289-302), S rounds of block
+// arg-max over register-resident values (ties -> lowest id).  NV values per thread: V <= 256*NV.
+template <int NV>
+__global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = c.p.V, S = c.p.S, NC = c.p.NC;
+  if (!c.b.alive[r]) return;
+  float* lp = c.b.dec_logp + (size_t)r * V;
+  float w[NV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = tid + 256 * k;
+    w[k] = v < V ? lp[v] : -INFINITY;
+    mx = fmaxf(mx, w[k]);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) s_v[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) sum += (tid + 256 * k < V) ? expf(w[k] - mx) : 0.f;
+  sum = wave_sum(sum);
+  if (lane == 0) s_v[wave] = sum;
+  __syncthreads();
+  const float lse = mx + logf(s_v[0] + s_v[1] + s_v[2] + s_v[3]);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = tid + 256 * k;
+    if (v < V) {
+      const float l = w[k] - lse;
+      lp[v] = l;
+      w[k] = c.p.w_dec * l + c.p.w_len * 1.0f;
+    }
+  }
+  if (S >= V) return;
+  // each wave extracts the top-S of its own 64*NV values with wave-level ops only (no block
+  // barrier inside the rounds); the 4*S survivors are merged by wave 0
+  __shared__ float m_v[4 * 64];
+  __shared__ int m_i[4 * 64];
+  const int SS = S < 64 ? S : 64;
+  for (int k = 0; k < SS; ++k) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      if (w[q] > best) {  // ascending ids within a thread: strict > keeps the lowest
+        best = w[q];
+        bi = tid + 256 * q;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      m_v[wave * 64 + k] = best;
+      m_i[wave * 64 + k] = bi;
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      if (tid + 256 * q == bi) w[q] = -INFINITY;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float cv[4];
+    int ci[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cv[q] = lane < SS ? m_v[q * 64 + lane] : -INFINITY;
+      ci[q] = lane < SS ? m_i[q * 64 + lane] : 0x7fffffff;
+    }
+    for (int k = 0; k < SS; ++k) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (cv[q] > best || (cv[q] == best && ci[q] < bi)) {
+          best = cv[q];
+          bi = ci[q];
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      if (lane == 0) {
+        c.b.cand_tok[(size_t)r * NC + k] = bi;
+        c.b.cand_full[(size_t)r * NC + k] = best;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ci[q] == bi) cv[q] = -INFINITY;
+    }
+  }
+}
+
+// generic-vocabulary fallback of the pre-beam (after em_log_softmax_rows_f32): one wave per row,
+// row values staged in LDS.
 __global__ __launch_bounds__(64) void prebeam_kernel(Ctx c) {
   extern __shared__ float vals[];
   const int r = blockIdx.x, lane = threadIdx.x;
@@ -159,20 +242,20 @@ __global__ __launch_bounds__(64) void prebeam_kernel(Ctx c) {
   }
 }
 
-// ---- step 2: candidate totals.  One thread per (row, candidate slot) ---------------------------
+// ---- step 2: candidate totals.  One wave per (row, candidate slot), 4 waves per block ----------
 //   pre-beam mode  : slots 0..S-1 = cand_tok, slot S = <eos> (always scored, :186-187)
 //   all-vocab mode : slot s = token s (S == V, NC == V)
 // total = (w_dec*dec + w_len) + w_ctc*(psi - s_prev) + running score   (batch_beam_search.py:289-314)
-__global__ __launch_bounds__(64) void candidate_kernel(Ctx c, int i) {
+__global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i) {
   const int NC = c.p.NC, V = c.p.V, S = c.p.S;
-  const long idx = (long)blockIdx.x * 64 + threadIdx.x;
-  const long total_threads = (long)c.p.B * c.p.W * NC;
-  if (idx >= total_threads) return;
+  const int lane = threadIdx.x & 63;
+  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= (long)c.p.B * c.p.W * NC) return;
   const int r = (int)(idx / NC), s = (int)(idx - (long)r * NC);
   const int b = r / c.p.W;
   float* out_total = c.b.cand_total + (size_t)r * NC + s;
   if (!c.b.alive[r] || c.b.done[b]) {
-    *out_total = -INFINITY;
+    if (lane == 0) *out_total = -INFINITY;
     return;
   }
   const bool allv = (S >= V);
@@ -182,20 +265,21 @@ __global__ __launch_bounds__(64) void candidate_kernel(Ctx c, int i) {
     tokc = s;
     full = (c.p.w_dec != 0.f ? c.p.w_dec * c.b.dec_logp[(size_t)r * V + s] : 0.f) + c.p.w_len * 1.0f;
     if (c.p.w_dec == 0.f && c.p.w_len == 0.f) full = 0.f;
-    c.b.cand_tok[(size_t)r * NC + s] = s;
+    if (lane == 0) c.b.cand_tok[(size_t)r * NC + s] = s;
   } else if (s < S) {
     tokc = c.b.cand_tok[(size_t)r * NC + s];
     full = c.b.cand_full[(size_t)r * NC + s];
   } else {  // the extra <eos> slot
     tokc = c.p.eos;
     full = c.p.w_dec * c.b.dec_logp[(size_t)r * V + tokc] + c.p.w_len * 1.0f;
-    c.b.cand_tok[(size_t)r * NC + s] = tokc;
+    if (lane == 0) c.b.cand_tok[(size_t)r * NC + s] = tokc;
     // already among the pre-beam candidates: that slot carries it
-    for (int k = 0; k < S; ++k)
-      if (c.b.cand_tok[(size_t)r * NC + k] == tokc) {
-        *out_total = -INFINITY;
-        return;
-      }
+    bool dup = false;
+    for (int k = lane; k < S; k += 64) dup |= (c.b.cand_tok[(size_t)r * NC + k] == tokc);
+    if (__any(dup)) {
+      if (lane == 0) *out_total = -INFINITY;
+      return;
+    }
   }
   float total = full;
   if (c.p.w_ctc != 0.f) {
@@ -208,14 +292,32 @@ __global__ __launch_bounds__(64) void candidate_kernel(Ctx c, int i) {
       const float2 re = rprev[xlen - 1];
       psi = logaddexp_(re.x, re.y);  // :184-186
     } else {
-      const int last = c.b.tok[(size_t)i * c.p.B * c.p.W + r];
-      psi = ctc_prefix_scan<false>(c.b.ctc_logp + (size_t)b * c.p.T * V, V, xlen, tokc, c.p.blank,
-                                   last, i, rprev, nullptr);
+      const bool same = (tokc == c.b.tok[(size_t)i * c.p.B * c.p.W + r]);
+      const float* xc = c.b.ctc_lpT + (size_t)tokc * c.p.B * c.p.T + (size_t)b * c.p.T;
+      const int start = i > 1 ? i : 1;
+      // lane-local online logsumexp over its frames, then a wave combine
+      float m = -INFINITY, sm = 0.f;
+      if (lane == 0) {  // the r[start-1, 0] term (:176-178): x[0] for the empty prefix, else logzero
+        m = (i == 0) ? xc[0] : LOGZERO;
+        sm = 1.f;
+      }
+      for (int t = start + lane; t < xlen; t += 64) {
+        const float2 rp = rprev[t - 1];
+        const float phi = same ? rp.y : logaddexp_(rp.x, rp.y);  // :135-144
+        const float term = phi + xc[t];
+        const float mm = fmaxf(m, term);
+        sm = sm * expf(m - mm) + expf(term - mm);
+        m = mm;
+      }
+      const float M = wave_max(m);
+      sm = (m > -INFINITY) ? sm * expf(m - M) : 0.f;
+      sm = wave_sum(sm);
+      psi = M + logf(sm);
     }
-    c.b.cand_psi[(size_t)r * NC + s] = psi;
+    if (lane == 0) c.b.cand_psi[(size_t)r * NC + s] = psi;
     total = total + c.p.w_ctc * (psi - c.b.s_prev[r]);
   }
-  *out_total = total + c.b.run_score[r];
+  if (lane == 0) *out_total = total + c.b.run_score[r];
 }
 
 // ---- step 3: per-utterance top-W over the W*NC candidate totals (batch_beam :98-122) -----------
@@ -251,6 +353,58 @@ __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
     }
     __syncthreads();
   }
+}
+
+// ---- step 3b: CTC forward variables of the winners (scorers/ctc.py:54-62) ---------------------
+// One 64-thread workgroup per new row (prefix of row `prow` + label tk).  The recurrence
+// r[t] = logsumexp(..) (ctc_prefix_score.py:158-164) is sequential in t, so everything that is
+// not on the chain is taken off it: all lanes stage x[t][tk], x[t][blank] and the phi terms
+// (:135-144, computed in parallel from the prefix's r_prev) in LDS with coalesced reads, lane 0
+// walks the chain LDS -> LDS, all lanes write the result back coalesced.  Only t >= max(i,1)-1
+// is produced: a later step's recurrence starts at t = i+1 and reads r_prev[t-1].
+constexpr int CTC_TMAX = 2048;
+__global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i) {
+  __shared__ float s_xn[CTC_TMAX], s_xb[CTC_TMAX], s_phi[CTC_TMAX];
+  __shared__ float2 s_out[CTC_TMAX];
+  const int rnew = blockIdx.x, lane = threadIdx.x;
+  const int W = c.p.W, NC = c.p.NC, n = c.p.B * c.p.W;
+  const int b = rnew / W;
+  if (c.b.done[b]) return;
+  const int sel = c.b.sel_idx[rnew];
+  if (sel < 0) return;
+  const int pk = sel / NC, slot = sel - pk * NC;
+  const int prow = b * W + pk;
+  const int tk = c.b.cand_tok[(size_t)prow * NC + slot];
+  if (tk == c.p.eos || i == c.b.maxlens[b] - 1) return;  // ended: no state needed
+  const int xlen = c.b.xlens[b];
+  const size_t BT = (size_t)c.p.B * c.p.T;
+  const float* xc = c.b.ctc_lpT + (size_t)tk * BT + (size_t)b * c.p.T;
+  const float* xb = c.b.ctc_lpT + (size_t)c.p.blank * BT + (size_t)b * c.p.T;
+  const float2* rprev = (const float2*)((i & 1) ? c.b.r_b : c.b.r_a) + (size_t)prow * c.p.T;
+  float2* rout = (float2*)((i & 1) ? c.b.r_a : c.b.r_b) + (size_t)rnew * c.p.T;
+  const bool same = (tk == c.b.tok[(size_t)i * n + prow]);
+  const int start = i > 1 ? i : 1;
+  for (int t = start + lane; t < xlen; t += 64) {
+    s_xn[t] = xc[t];
+    s_xb[t] = xb[t];
+    const float2 rp = rprev[t - 1];
+    s_phi[t] = same ? rp.y : logaddexp_(rp.x, rp.y);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float rn = (i == 0) ? xc[0] : LOGZERO, rb = LOGZERO;  // r[0,0] = x[0] (:131-132)
+    s_out[start - 1] = make_float2(rn, rb);
+#pragma unroll 4
+    for (int t = start; t < xlen; ++t) {
+      const float nn = logaddexp_(rn, s_phi[t]) + s_xn[t];
+      const float nb = logaddexp_(rn, rb) + s_xb[t];
+      rn = nn;
+      rb = nb;
+      s_out[t] = make_float2(rn, rb);
+    }
+  }
+  __syncthreads();
+  for (int t = start - 1 + lane; t < xlen; t += 64) rout[t] = s_out[t];
 }
 
 // ---- step 4: build the new rows (batch_beam_search.py:317-357 + post_process :359-423) ---------
@@ -299,14 +453,6 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i) {
     int* dst = anc_new + (size_t)rnew * Lmax;
     for (int j = lane; j <= i; j += 64) dst[j] = src[j];
     if (lane == 0 && i + 1 < Lmax) dst[i + 1] = rnew;
-  }
-  // (b) CTC forward variables of the winners (scorers/ctc.py:54-62); ended rows need none
-  if (lane < W && s_valid[lane] && !s_end[lane] && c.p.w_ctc != 0.f) {
-    const int rnew = b * W + lane, prow = s_prev_row[lane];
-    const int last = c.b.tok[(size_t)i * n + prow];
-    ctc_prefix_scan<true>(c.b.ctc_logp + (size_t)b * c.p.T * V, V, c.b.xlens[b], s_tok[lane],
-                          c.p.blank, last, i, r_old + (size_t)prow * c.p.T,
-                          r_new + (size_t)rnew * c.p.T);
   }
   __syncthreads();  // every read of the old per-row state is done
   if (lane < W) {
@@ -374,6 +520,37 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i) {
   }
 }
 
+// x[v][col] <- log_softmax over v of (x[v][col] + bias[v]), columns = (utterance, frame) pairs.
+// 64 columns x 4 vocabulary slices per block; coalesced over columns.
+__global__ __launch_bounds__(256) void col_logsoftmax_kernel(float* __restrict__ x,
+                                                             const float* __restrict__ bias, int V,
+                                                             int ncol) {
+  __shared__ float s_m[4][64], s_s[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  float m = -INFINITY, sm = 0.f;
+  if (col < ncol)
+    for (int v = g; v < V; v += 4) {
+      const float val = x[(size_t)v * ncol + col] + (bias ? bias[v] : 0.f);
+      const float mm = fmaxf(m, val);
+      sm = sm * expf(m - mm) + expf(val - mm);
+      m = mm;
+    }
+  s_m[g][cl] = m;
+  s_s[g][cl] = sm;
+  __syncthreads();
+  float M = fmaxf(fmaxf(s_m[0][cl], s_m[1][cl]), fmaxf(s_m[2][cl], s_m[3][cl]));
+  float S = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) S += s_m[q][cl] > -INFINITY ? s_s[q][cl] * expf(s_m[q][cl] - M) : 0.f;
+  const float lse = M + logf(S);
+  if (col < ncol)
+    for (int v = g; v < V; v += 4) {
+      const size_t o = (size_t)v * ncol + col;
+      x[o] = x[o] + (bias ? bias[v] : 0.f) - lse;
+    }
+}
+
 inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
                 int N, int K, int lda, int ldc, float scale, void* stream) {
   EmGemmArgs a;
@@ -394,6 +571,7 @@ constexpr float LN_EPS = 1e-12f;
 int check(const EmSearchParams* p, const EmSearchBuffers* b) {
   if (!p || !b) return EM_ERR_BAD_ARG;
   if (p->B <= 0 || p->W <= 0 || p->W > 64 || p->V <= 1 || p->T <= 0 || p->Lmax < 2) return EM_ERR_BAD_ARG;
+  if (p->w_ctc != 0.f && p->T > CTC_TMAX) return EM_ERR_UNSUPPORTED;
   if (p->S <= 0 || p->NC <= 0 || p->end_cap <= 0) return EM_ERR_BAD_ARG;
   if (p->S >= p->V ? p->NC != p->V : p->NC != p->S + 1) return EM_ERR_BAD_ARG;
   if (p->w_dec == 0.f && p->w_ctc == 0.f) return EM_ERR_BAD_ARG;
@@ -404,7 +582,8 @@ int check(const EmSearchParams* p, const EmSearchBuffers* b) {
 }  // namespace
 
 extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
-                              const EmSearchBuffers* b, const void* enc_act, void* stream) {
+                              const EmSearchBuffers* b, const void* enc_act, int32_t d_model,
+                              const void* ctc_w, const float* ctc_b, void* stream) {
   EM_TRY(check(p, b));
   hipStream_t s = (hipStream_t)stream;
   Ctx c{*p, *b};
@@ -421,6 +600,16 @@ extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecode
                   p->B * p->T, 2 * d, d, d, 2 * d, 1.f, stream));
       EM_TRY(em_dec_transpose_v(dtype, kv, p->B, p->T, d, p->Tpad, vT, stream));
     }
+  }
+  if (p->w_ctc != 0.f) {
+    if (!ctc_w || !enc_act || !b->ctc_lpT) return EM_ERR_BAD_ARG;
+    const int BT = p->B * p->T;
+    // logits^T [V][B*T] = W_ctc [V][d] x enc^T: the transposed layout falls out of swapping the
+    // GEMM operands; bias + log-softmax over V (asr/ctc.py:197-205) run column-wise in place
+    EM_TRY(gemm(dtype, EM_EPI_STORE_F32, ctc_w, enc_act, b->ctc_lpT, nullptr, p->V, BT, d_model,
+                d_model, BT, 1.f, stream));
+    hipLaunchKernelGGL(col_logsoftmax_kernel, dim3(em_cdiv(BT, 64)), dim3(256), 0, s, b->ctc_lpT,
+                       ctc_b, p->V, BT);
   }
   hipLaunchKernelGGL(search_init_rows_kernel, dim3(em_cdiv(n, 64)), dim3(64), 0, s, c);
   hipLaunchKernelGGL(search_init_utt_kernel, dim3(em_cdiv(p->B, 64)), dim3(64), 0, s, c);
@@ -462,15 +651,27 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
       }
       EM_TRY(em_layernorm(dtype, b->x, dw->after_norm_g, dw->after_norm_b, n, d, LN_EPS, b->xn, nullptr, stream));
       EM_TRY(gemm(dtype, EM_EPI_STORE_F32, b->xn, dw->out_w, b->dec_logp, dw->out_b, n, V, d, d, V, 1.f, stream));
-      EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
-      if (p->S < V)
+      if (p->S > 64 && p->S < V) {
+        EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
         hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
+      } else if (V <= 256 * 8) {
+        hipLaunchKernelGGL(logsoftmax_prebeam_kernel<8>, dim3(n), dim3(256), 0, s, c);
+      } else if (V <= 256 * 20) {
+        hipLaunchKernelGGL(logsoftmax_prebeam_kernel<20>, dim3(n), dim3(256), 0, s, c);
+      } else if (V <= 256 * 40) {
+        hipLaunchKernelGGL(logsoftmax_prebeam_kernel<40>, dim3(n), dim3(256), 0, s, c);
+      } else {
+        EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
+        if (p->S < V)
+          hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
+      }
     }
     {
-      const long threads = (long)n * p->NC;
-      hipLaunchKernelGGL(candidate_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, c, i);
+      const long waves = (long)n * p->NC;
+      hipLaunchKernelGGL(candidate_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, c, i);
     }
     hipLaunchKernelGGL(select_kernel, dim3(p->B), dim3(64), 0, s, c);
+    if (p->w_ctc != 0.f) hipLaunchKernelGGL(ctc_state_kernel, dim3(n), dim3(64), 0, s, c, i);
     hipLaunchKernelGGL(update_kernel, dim3(p->B), dim3(64), 0, s, c, i);
     EM_CHECK_LAUNCH();
   }

@@ -85,7 +85,7 @@ class EmSearchParams(C.Structure):
                [(n, C.c_float) for n in ("w_dec", "w_ctc", "w_len")]
 
 
-SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_logp", "tok", "parent", "anc_a", "anc_b",
+SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "anc_a", "anc_b",
                   "alive", "run_score", "run_sdec", "run_sctc", "run_slen", "s_prev", "r_a", "r_b",
                   "cand_tok", "cand_full", "cand_psi", "cand_total", "sel_idx", "sel_total",
                   "end_count", "end_pos", "end_slot", "end_forced", "end_score", "end_sdec",
@@ -129,7 +129,7 @@ _SIGNATURES = {
                                        _i32, _i32, _vp, _vp]),
     "em_dec_transpose_v": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "em_search_init": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),
-                                 C.POINTER(EmSearchBuffers), _vp, _vp]),
+                                 C.POINTER(EmSearchBuffers), _vp, _i32, _vp, _vp, _vp]),
     "em_search_steps": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),
                                   C.POINTER(EmSearchBuffers), _i32, _i32, _vp]),
     "em_ctc_greedy": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32,

@@ -81,6 +81,7 @@ class BatchBeamSearch(BeamSearch):
             anc_a=(n, Lmax), anc_b=(n, Lmax), alive=(n,), run_score=(n,), run_sdec=(n,),
             run_sctc=(n,), run_slen=(n,), s_prev=(n,),
             r_a=(n, T, 2) if use_ctc else (1,), r_b=(n, T, 2) if use_ctc else (1,),
+            ctc_lpT=(V, B * T) if use_ctc else None,
             cand_tok=(n, NC), cand_full=(n, NC), cand_psi=(n, NC), cand_total=(n, NC),
             sel_idx=(n,), sel_total=(n,), end_count=(B,), end_pos=(B, cap), end_slot=(B, cap),
             end_forced=(B, cap), end_score=(B, cap), end_sdec=(B, cap), end_sctc=(B, cap),
@@ -91,6 +92,8 @@ class BatchBeamSearch(BeamSearch):
                           mem_kv=(nl, B * T, 2 * d), mem_vT=(nl, B, d, Tpad))
         t = {}
         for name, shp in shapes.items():
+            if shp is None:
+                continue
             dt = torch.int32 if name in _I32 else (act if name in _ACT else torch.float32)
             t[name] = (torch.zeros if name == "mem_vT" else torch.empty)(shp, dtype=dt, device=dev)
         self._bufs[key] = t
@@ -134,9 +137,7 @@ class BatchBeamSearch(BeamSearch):
         bufs["xlens"].copy_(torch.tensor(olens, dtype=torch.int32))
         bufs["maxlens"].copy_(torch.tensor(maxlens, dtype=torch.int32))
         bufs["minlens"].copy_(torch.tensor(minlens, dtype=torch.int32))
-        ctc_logp = None
-        if ctc_sc is not None:
-            ctc_logp = ctc_sc.ctc.log_softmax(enc_act)  # (B,T,V) f32, scorers/ctc.py:96
+        ctc_pk = ctc_sc.ctc._pack(dev) if ctc_sc is not None else None
         p = L.EmSearchParams(B=B, W=W, V=V, T=T, Tpad=Tpad, S=S, NC=NC, Lmax=Lmax, end_cap=cap,
                              sos=self.sos, eos=self.eos, blank=0,
                              use_end_detect=1 if maxlenratio == 0.0 else 0,
@@ -146,14 +147,13 @@ class BatchBeamSearch(BeamSearch):
                              if "length_bonus" in self.scorers else 0.0)
         bs = L.EmSearchBuffers()
         for name in L.SEARCH_BUFFERS:
-            if name == "ctc_logp":
-                bs.ctc_logp = ctc_logp.data_ptr() if ctc_logp is not None else None
-            else:
-                setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
+            setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
         dw = dec.ensure_packed(dev, Lmax)["w"] if dec is not None else None
         dwp = C.byref(dw) if dw is not None else None
         stream = L.current_stream_ptr()
-        L.check(lib.em_search_init(em_dtype, C.byref(p), dwp, C.byref(bs), L.ptr(enc_act), stream),
+        L.check(lib.em_search_init(em_dtype, C.byref(p), dwp, C.byref(bs), L.ptr(enc_act), d,
+                                   L.ptr(ctc_pk["w"]) if ctc_pk else None,
+                                   L.ptr(ctc_pk["b"]) if ctc_pk else None, stream),
                 "em_search_init")
         i, imax = 0, max(maxlens)
         while i < imax:

@@ -261,7 +261,9 @@ typedef struct EmSearchParams {
 
 typedef struct EmSearchBuffers {
   const int32_t *xlens, *maxlens, *minlens; /* [B] valid memory frames, max / min output length */
-  const float* ctc_logp;                    /* [B][T][V] CTC.log_softmax(enc) (scorers/ctc.py:96) */
+  float* ctc_lpT;                           /* [V][B*T] CTC.log_softmax(enc) (scorers/ctc.py:96), TRANSPOSED:
+                                               the T frames of one (utterance, label) are contiguous;
+                                               written by em_search_init */
   int32_t *tok, *parent;                    /* [Lmax][n] token tree */
   int32_t *anc_a, *anc_b;                   /* [n][Lmax] ancestor slots, double buffered by step parity */
   int32_t* alive;                           /* [n] */
@@ -284,10 +286,13 @@ typedef struct EmSearchBuffers {
   void *mem_vT;                             /* act [layers][B][d][Tpad], zero initialised by the caller */
 } EmSearchBuffers;
 
-/*   Projects the encoder memory (enc_act [B][T][d] act) to per-layer K | V and V^T, and writes the
- *   initial search state (one alive <sos> hypothesis per utterance, CTC r_prev of the empty prefix). */
+/*   Projects the encoder memory (enc_act [B][T][d_model] act) to per-layer K | V and V^T, computes
+ *   the transposed CTC log-probs (ctc_w [V][d_model] act, ctc_b [V] f32: ctc.ctc_lo; may be NULL
+ *   when w_ctc == 0) and writes the initial search state (one alive <sos> hypothesis per
+ *   utterance, CTC r_prev of the empty prefix).                                                  */
 int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
-                   const EmSearchBuffers* b, const void* enc_act, void* stream);
+                   const EmSearchBuffers* b, const void* enc_act, int32_t d_model,
+                   const void* ctc_w, const float* ctc_b, void* stream);
 /*   Enqueues search steps i0 .. i1-1 (decoder step, pre-beam, CTC prefix scores, top-W, update).
  *   Utterances whose `done` flag is set are skipped; the host polls `done` between calls.        */
 int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
