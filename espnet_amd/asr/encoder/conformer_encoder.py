@@ -232,7 +232,7 @@ class ConformerEncoder(torch.nn.Module):
                 wout=A(sa.linear_out.weight), bout=F(sa.linear_out.bias),
                 pw1=A(cm.pointwise_conv1.weight.reshape(2 * d, d)[glu_perm]),
                 pw1_b=F(cm.pointwise_conv1.bias[glu_perm]),
-                dw_w=F(dw_w), dw_b=F(dw_b),
+                dw_w=F(dw_w.t()), dw_b=F(dw_b),  # [k][d]: tap-major, coalesced over channels
                 pw2=A(cm.pointwise_conv2.weight.reshape(d, d)), pw2_b=F(cm.pointwise_conv2.bias),
                 ff_w1=A(l.feed_forward.w_1.weight), ff_b1=F(l.feed_forward.w_1.bias),
                 ff_w2=A(l.feed_forward.w_2.weight), ff_b2=F(l.feed_forward.w_2.bias),

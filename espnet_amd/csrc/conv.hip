@@ -7,43 +7,70 @@
 
 namespace {
 
-constexpr int TT = 16;   // outputs per thread along time
+constexpr int TT = 16;  // outputs per workgroup along time
 constexpr int KMAX = 31;
 
+// One workgroup = TT output frames x 256 channels of one utterance.  The (TT + KW - 1) x 256 input
+// tile is staged in LDS with 16-byte coalesced loads (zero rows outside [0, T)); thread c then
+// walks its channel's column once, feeding each value to the (up to KW) outputs it contributes to
+// -- every tap weight and every accumulator stays in registers, each input is read from LDS once.
 template <typename T, int KW>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias, int Tn, int d,
                                                      T* __restrict__ y) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= d) return;
-  const int t0 = blockIdx.y * TT, b = blockIdx.z;
   constexpr int HALF = (KW - 1) / 2;
+  constexpr int ROWS = TT + KW - 1;
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int CPR = 256 / EPC;            // chunks per 256-channel row
+  __shared__ __attribute__((aligned(16))) T tile[ROWS][256];
+  const int c0 = blockIdx.x * 256, t0 = blockIdx.y * TT, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const T* xb = x + (size_t)b * Tn * d;
+  constexpr int NLD = (ROWS * CPR + 255) / 256;
+  uint4 stage[NLD];
+#pragma unroll
+  for (int it = 0; it < NLD; ++it) {  // all global loads in flight before the first LDS store
+    const int q = tid + it * 256;
+    const int r = q / CPR, ch = q - r * CPR;
+    const int t = t0 - HALF + r;
+    stage[it] = make_uint4(0u, 0u, 0u, 0u);
+    if (q < ROWS * CPR && t >= 0 && t < Tn && c0 + ch * EPC < d)
+      stage[it] = *(const uint4*)(xb + (size_t)t * d + c0 + ch * EPC);
+  }
+#pragma unroll
+  for (int it = 0; it < NLD; ++it) {
+    const int q = tid + it * 256;
+    const int r = q / CPR, ch = q - r * CPR;
+    if (q < ROWS * CPR) *(uint4*)(&tile[r][ch * EPC]) = stage[it];
+  }
+  __syncthreads();
+  const int c = c0 + tid;
+  if (c >= d) return;
   float wk[KW];
 #pragma unroll
-  for (int k = 0; k < KW; ++k) wk[k] = w[c * KW + k];
-  float win[TT + KW - 1];
-  const T* xb = x + (size_t)b * Tn * d + c;
-#pragma unroll
-  for (int i = 0; i < TT + KW - 1; ++i) {
-    int t = t0 - HALF + i;
-    win[i] = (t >= 0 && t < Tn) ? to_f32(xb[(size_t)t * d]) : 0.f;
-  }
+  for (int k = 0; k < KW; ++k) wk[k] = w[(size_t)k * d + c];  // tap-major: coalesced
   const float bc = bias[c];
+  float acc[TT];
+#pragma unroll
+  for (int o = 0; o < TT; ++o) acc[o] = bc;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const float v = to_f32(tile[r][tid]);
+#pragma unroll
+    for (int o = 0; o < TT; ++o)
+      if (r - o >= 0 && r - o < KW) acc[o] = fmaf(wk[r - o], v, acc[o]);
+  }
   T* yb = y + (size_t)b * Tn * d + c;
 #pragma unroll
-  for (int o = 0; o < TT; ++o) {
-    if (t0 + o >= Tn) break;
-    float acc = bc;
-#pragma unroll
-    for (int k = 0; k < KW; ++k) acc = fmaf(wk[k], win[o + k], acc);
-    yb[(size_t)(t0 + o) * d] = from_f32<T>(swishf_(acc));
-  }
+  for (int o = 0; o < TT; ++o)
+    if (t0 + o < Tn) yb[(size_t)(t0 + o) * d] = from_f32<T>(swishf_(acc[o]));
 }
 
 template <typename T>
 int launch_dw(const void* x, const float* w, const float* b, int B, int Tn, int d, int k, void* y,
               hipStream_t s) {
+  if (d % (16 / (int)sizeof(T)) != 0) return EM_ERR_UNSUPPORTED;
   dim3 grid(em_cdiv(d, 256), em_cdiv(Tn, TT), B);
 #define EM_DW_CASE(KW)                                                                      \
   case KW:                                                                                  \

@@ -59,7 +59,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order.  Workgroup L runs on XCD L % 8 (each XCD has its own 4 MiB L2); tiles are
+  // numbered M-major (q = m_tile * n_tiles + n_tile) and XCD x takes the contiguous chunk
+  // [x * cpx, (x+1) * cpx), so the n_tiles workgroups that share an A row-panel run on the same
+  // XCD at about the same time (A is fetched into one L2 once instead of into all eight).
+  const int n_tiles = (N + BN - 1) / BN, m_tiles = (M + BM - 1) / BM;
+  const int cpx = (n_tiles * m_tiles + 7) >> 3;
+  const int q = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  if (q >= n_tiles * m_tiles) return;
+  const int m0 = (q / n_tiles) * BM, n0 = (q % n_tiles) * BN;
   const int lr = lane & 15, lg = lane >> 4;
 
   // ---- per-lane global source addresses.  Load instruction i of this wave fills LDS rows
@@ -268,11 +276,11 @@ int launch(const EmGemmArgs* p, hipStream_t s) {
   // fewer than ~1.5 workgroups per CU at BM=128 -> halve the M tile to fill the 256 CUs
   const bool small = (long)nb * em_cdiv(p->M, 128) < 384;
   if (small) {
-    dim3 grid(nb, em_cdiv(p->M, 64));
+    dim3 grid(8 * em_cdiv(nb * em_cdiv(p->M, 64), 8));
     hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE, 64>), grid, dim3(256), 0, s, (const T*)p->A,
                        (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
   } else {
-    dim3 grid(nb, em_cdiv(p->M, 128));
+    dim3 grid(8 * em_cdiv(nb * em_cdiv(p->M, 128), 8));
     hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE, 128>), grid, dim3(256), 0, s, (const T*)p->A,
                        (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
   }

@@ -1,0 +1,75 @@
+"""Utterance-parallel inference across the GPUs of one node: one process per GPU, utterances
+sharded in contiguous slabs, weights replicated, NO data-path collective; hypotheses are collated
+with one fixed-shape all-gather (RCCL over xGMI on the GPU box: backend "nccl"; "gloo" in the CPU
+tests).
+
+The reference scales inference the same way, with independent processes over split key files
+merged afterwards (egs2/TEMPLATE/asr1/asr.sh:1589-1619, 1636-1648; `ngpu > 1` is rejected inside
+one process, espnet2/bin/asr_inference.py:760-765).  SURVEY.md §8(e).
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slab [lo, hi) of rank `rank`; slab sizes differ by at most one (the first
+    n_items % world ranks get the extra item), like `split_scps` in asr.sh."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pack_hypotheses(token_ids: Sequence[Sequence[int]], scores: Sequence[float], max_len: int,
+                    slab: int, device) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Fixed-shape records for the collective: ids (slab, max_len) i32 padded with -1, lengths
+    (slab,) i32 (-1 marks an empty padding record), scores (slab,) f32."""
+    ids = torch.full((slab, max_len), -1, dtype=torch.int32)
+    lens = torch.full((slab,), -1, dtype=torch.int32)
+    sc = torch.zeros(slab, dtype=torch.float32)
+    for k, (t, s) in enumerate(zip(token_ids, scores)):
+        t = list(t)[:max_len]
+        ids[k, : len(t)] = torch.tensor(t, dtype=torch.int32)
+        lens[k] = len(t)
+        sc[k] = float(s)
+    return ids.to(device), lens.to(device), sc.to(device)
+
+
+def gather_hypotheses(ids: torch.Tensor, lens: torch.Tensor, scores: torch.Tensor, n_items: int,
+                      group=None) -> List[Tuple[List[int], float]]:
+    """One all-gather per tensor of the ranks' fixed-shape slabs; returns the n_items hypotheses in
+    global utterance order on EVERY rank (rank 0 is the one that writes results)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        g_ids, g_lens, g_sc = ids, lens, scores
+    else:
+        slab = ids.size(0)
+        g_ids = torch.empty((world * slab, ids.size(1)), dtype=ids.dtype, device=ids.device)
+        g_lens = torch.empty((world * slab,), dtype=lens.dtype, device=lens.device)
+        g_sc = torch.empty((world * slab,), dtype=scores.dtype, device=scores.device)
+        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
+        dist.all_gather_into_tensor(g_lens, lens.contiguous(), group=group)
+        dist.all_gather_into_tensor(g_sc, scores.contiguous(), group=group)
+    g_ids, g_lens, g_sc = g_ids.cpu(), g_lens.cpu(), g_sc.cpu()
+    slab = g_ids.size(0) // world
+    out = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_items, r, world)
+        for k in range(hi - lo):
+            n = int(g_lens[r * slab + k])
+            assert n >= 0, "padding record inside a rank's slab"
+            out.append((g_ids[r * slab + k, :n].tolist(), float(g_sc[r * slab + k])))
+    return out
+
+
+def decode_sharded(decode_fn, n_items: int, max_len: int, device, group=None):
+    """decode_fn(lo, hi) -> (list of token-id lists, list of scores) for utterances [lo, hi).
+    Every rank decodes its slab and the hypotheses are collated in utterance order."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi = shard_bounds(n_items, rank, world)
+    toks, scores = decode_fn(lo, hi) if hi > lo else ([], [])
+    slab = (n_items + world - 1) // world
+    ids, lens, sc = pack_hypotheses(toks, scores, max_len, slab, device)
+    return gather_hypotheses(ids, lens, sc, n_items, group)

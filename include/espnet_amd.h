@@ -116,7 +116,7 @@ int em_relpos_attention(int dtype, const void* qkv, const void* p, int32_t ldp, 
                         int32_t dk, void* ctx, void* stream);
 
 /* ---- A8 (middle): depthwise Conv1d(k, pad (k-1)/2) + eval BatchNorm1d (folded into w,b by the
- *      caller) + Swish (conformer/convolution.py:72-75).  x,y [B][T][d] act; w [d][k] f32.       */
+ *      caller) + Swish (conformer/convolution.py:72-75).  x,y [B][T][d] act; w [k][d] f32 (tap-major).       */
 int em_dwconv_bn_swish(int dtype, const void* x, const float* w, const float* b, int32_t B,
                        int32_t T, int32_t d, int32_t k, void* y, void* stream);
 
@@ -147,7 +147,7 @@ typedef struct EmConformerLayer {
   const float* bout;
   const void* pw1; /* [2d][d] act, GLU-interleaved rows (EM_EPI_GLU) */
   const float* pw1_b;
-  const float *dw_w, *dw_b; /* [d][k], [d] with eval BatchNorm folded in */
+  const float *dw_w, *dw_b; /* [k][d] (tap-major), [d] with eval BatchNorm folded in */
   const void* pw2;          /* [d][d] act */
   const float* pw2_b;
   const void* ff_w1;

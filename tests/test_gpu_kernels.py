@@ -240,7 +240,7 @@ def test_dwconv_bn_swish(lib, k):
         y = F.batch_norm(y, mean, var, gam, bet, False, 0.0, 1e-5)
         ref = oc.swish(y).transpose(1, 2)
         out = torch.zeros(B, T, d, dtype=tdt, device="cuda")
-        L.check(lib.em_dwconv_bn_swish(dt, L.ptr(dev(xq.to(tdt))), L.ptr(dev(wf)), L.ptr(dev(bf)), B, T,
+        L.check(lib.em_dwconv_bn_swish(dt, L.ptr(dev(xq.to(tdt))), L.ptr(dev(wf.t().contiguous())), L.ptr(dev(bf)), B, T,
                                        d, k, L.ptr(out), sptr()))
         assert_close(out, ref, tol, f"dwconv {prec}")
 
