@@ -55,10 +55,22 @@ inline Ws layout(int dtype, const EmConformerWeights* w, int B, int T_f) {
 
 inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
                 int N, int K, int lda, int ldc, float scale, void* stream) {
-  EmGemmArgs a;
+  EmGemmArgs a = {};
   a.A = A; a.W = W; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.scale = scale;
   a.T1 = a.F1 = a.T2 = a.F2 = a.d = 0;
+  return em_gemm(dtype, epi, EM_A_PLAIN, &a, stream);
+}
+
+// GEMM + residual/scale + fused LayerNorm(s) (EM_EPI_RESID_LN / EM_EPI_SCALE_LN, N == 256)
+inline int gemm_ln(int dtype, int epi, const void* A, const void* W, float* x, const float* bias,
+                   int M, int N, int K, float scale, const float* g1, const float* b1,
+                   const float* g2, const float* b2, void* out, float* out_f32, void* stream) {
+  EmGemmArgs a = {};
+  a.A = A; a.W = W; a.C = x; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N; a.scale = scale;
+  a.ln_g = g1; a.ln_b = b1; a.ln2_g = g2; a.ln2_b = b2; a.ln_out = out; a.ln_out_f32 = out_f32;
+  a.ln_eps = 1e-12f;
   return em_gemm(dtype, epi, EM_A_PLAIN, &a, stream);
 }
 
@@ -108,19 +120,56 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   EM_TRY(em_conv2d_sub1(dtype, feats, mvn_partial, flens, B, T_f, w->n_mels, w->conv1_w,
                         w->conv1_b, d, c1, stream));
   {
-    EmGemmArgs a;
+    EmGemmArgs a = {};
     a.A = c1; a.W = w->conv2_w; a.C = c2; a.bias = w->conv2_b;
     a.M = M * g.F2; a.N = d; a.K = 9 * d; a.lda = 0; a.ldc = d; a.scale = 1.f;
     a.T1 = g.T1; a.F1 = g.F1; a.T2 = T; a.F2 = g.F2; a.d = d;
     EM_TRY(em_gemm(dtype, EM_EPI_RELU, EM_A_CONV2, &a, stream));
   }
-  EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d, g.F2 * d, d,
-              sqrtf((float)d), stream));
+  const EmConformerLayer* ly = w->layers;
   // ---- linear_pos of every block in one GEMM: pall[2T-1][L*d]
   EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, 2 * T - 1, L * d, d, d,
               L * d, 1.f, stream));
+  // LayerNorm fused into the producing GEMM's epilogue (EM_EPI_*_LN, N == 256): correct and tested
+  // (tests/test_gpu_kernels.py::test_gemm_layernorm_epilogue) but measured SLOWER on MI355X than
+  // GEMM + stand-alone LN at B=32 (K=256: 16.4 vs 7.1+3.5 us, K=1024: 21.5 vs 12.2+3.5 us;
+  // 250 single-resident workgroups with a long serial epilogue), so it is off.  profiles/ r01f.
+  constexpr bool kFuseLayerNorm = false;
+  if (kFuseLayerNorm && d == 256) {
+    // every LayerNorm rides in the epilogue of the GEMM that produces its input row (one
+    // workgroup owns whole 256-wide rows): no stand-alone LN launches, x is not re-read
+    EM_TRY(gemm_ln(dtype, EM_EPI_SCALE_LN, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d,
+                   sqrtf((float)d), ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, nullptr, nullptr, xn,
+                   nullptr, stream));
+    for (int l = 0; l < L; ++l) {
+      const EmConformerLayer& q = ly[l];
+      EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
+      EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, 0.5f, q.norm_mha_g,
+                     q.norm_mha_b, nullptr, nullptr, xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
+      EM_TRY(em_relpos_attention(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
+                                 q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
+      EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, ctx, q.wout, x, q.bout, M, d, d, 1.f, q.norm_conv_g,
+                     q.norm_conv_b, nullptr, nullptr, xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
+      EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, B, T, d, w->kernel, g2, stream));
+      EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, g2, q.pw2, x, q.pw2_b, M, d, d, 1.f, q.norm_ff_g,
+                     q.norm_ff_b, nullptr, nullptr, xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
+      if (l + 1 < L)
+        EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, big, q.ff_w2, x, q.ff_b2, M, d, ff, 0.5f,
+                       q.norm_final_g, q.norm_final_b, ly[l + 1].norm_ff_mac_g,
+                       ly[l + 1].norm_ff_mac_b, xn, nullptr, stream));
+      else
+        EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, big, q.ff_w2, x, q.ff_b2, M, d, ff, 0.5f,
+                       q.norm_final_g, q.norm_final_b, w->after_norm_g, w->after_norm_b, enc_act,
+                       enc_out, stream));
+    }
+    return EM_OK;
+  }
+  EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d, g.F2 * d, d,
+              sqrtf((float)d), stream));
 
-  const EmConformerLayer* ly = w->layers;
   EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr,
                       stream));
   for (int l = 0; l < L; ++l) {

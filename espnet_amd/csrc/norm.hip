@@ -60,10 +60,86 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x,
   }
 }
 
+// Vectorised form for d % 256 == 0: lane l owns the float4 chunks l, l+64, ... of the row
+// (16-byte loads, 8/16-byte stores).
+template <int NV4>
+__device__ __forceinline__ void ln_row4(float4 v[NV4], const float* __restrict__ g,
+                                        const float* __restrict__ b, int lane, int d, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    const float a = v[j].x - mean, bq = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
+    q += (a * a + bq * bq) + (c * c + e * e);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    const float4 g4 = *(const float4*)(g + (j * 64 + lane) * 4);
+    const float4 b4 = *(const float4*)(b + (j * 64 + lane) * 4);
+    v[j].x = (v[j].x - mean) * rstd * g4.x + b4.x;
+    v[j].y = (v[j].y - mean) * rstd * g4.y + b4.y;
+    v[j].z = (v[j].z - mean) * rstd * g4.z + b4.z;
+    v[j].w = (v[j].w - mean) * rstd * g4.w + b4.w;
+  }
+}
+
+template <typename T, int NV4, int MODE>
+__global__ __launch_bounds__(256) void layernorm4_kernel(float* __restrict__ x,
+                                                         const float* __restrict__ g1,
+                                                         const float* __restrict__ b1,
+                                                         const float* __restrict__ g2,
+                                                         const float* __restrict__ b2, int M, int d,
+                                                         float eps, T* __restrict__ out,
+                                                         float* __restrict__ out_f32) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float4* xr = (float4*)(x + (size_t)row * d);
+  float4 v[NV4];
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) v[j] = xr[j * 64 + lane];
+  ln_row4<NV4>(v, g1, b1, lane, d, eps);
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) xr[j * 64 + lane] = v[j];
+    ln_row4<NV4>(v, g2, b2, lane, d, eps);
+  }
+  T* o = out + (size_t)row * d;
+#pragma unroll
+  for (int j = 0; j < NV4; ++j) {
+    if (sizeof(T) == 2) {
+      bf16x4 pk = {(bf16)v[j].x, (bf16)v[j].y, (bf16)v[j].z, (bf16)v[j].w};
+      *(bf16x4*)(o + (j * 64 + lane) * 4) = pk;
+    } else {
+      *(float4*)(o + (j * 64 + lane) * 4) = v[j];
+    }
+  }
+  if (out_f32) {
+    float4* of = (float4*)(out_f32 + (size_t)row * d);
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) of[j * 64 + lane] = v[j];
+  }
+}
+
 template <typename T, int MODE>
 int launch_ln(float* x, const float* g1, const float* b1, const float* g2, const float* b2, int M,
               int d, float eps, T* out, float* out_f32, hipStream_t s) {
   dim3 grid(em_cdiv(M, 4)), block(256);
+  if (d % 256 == 0 && d <= 1024) {
+#define EM_LN4_CASE(NV4)                                                                          \
+  case NV4:                                                                                       \
+    hipLaunchKernelGGL((layernorm4_kernel<T, NV4, MODE>), grid, block, 0, s, x, g1, b1, g2, b2, M, \
+                       d, eps, out, out_f32);                                                     \
+    break;
+    switch (d / 256) { EM_LN4_CASE(1) EM_LN4_CASE(2) EM_LN4_CASE(3) EM_LN4_CASE(4) }
+#undef EM_LN4_CASE
+    EM_CHECK_LAUNCH();
+    return EM_OK;
+  }
 #define EM_LN_CASE(NV)                                                                          \
   case NV:                                                                                      \
     hipLaunchKernelGGL((layernorm_kernel<T, NV, MODE>), grid, block, 0, s, x, g1, b1, g2, b2, M, \

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void col_logsoftmax_kernel(float* __restrict__
 
 inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
                 int N, int K, int lda, int ldc, float scale, void* stream) {
-  EmGemmArgs a;
+  EmGemmArgs a = {};
   a.A = A; a.W = W; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.scale = scale;
   a.T1 = a.F1 = a.T2 = a.F2 = a.d = 0;

@@ -15,7 +15,7 @@ EM_OK = 0
 EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE = -1, -2, -3, -4, -5
 EM_F32, EM_BF16 = 0, 1
 (EM_EPI_STORE, EM_EPI_SWISH, EM_EPI_RELU, EM_EPI_RESID_F32, EM_EPI_SCALE_F32, EM_EPI_GLU,
- EM_EPI_STORE_F32) = range(7)
+ EM_EPI_STORE_F32, EM_EPI_RESID_LN, EM_EPI_SCALE_LN) = range(9)
 EM_A_PLAIN, EM_A_CONV2 = 0, 1
 
 DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
@@ -39,7 +39,10 @@ class EmGemmArgs(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldc", C.c_int32), ("scale", C.c_float),
                 ("T1", C.c_int32), ("F1", C.c_int32), ("T2", C.c_int32), ("F2", C.c_int32),
-                ("d", C.c_int32)]
+                ("d", C.c_int32),
+                ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln2_g", C.c_void_p),
+                ("ln2_b", C.c_void_p), ("ln_out", C.c_void_p), ("ln_out_f32", C.c_void_p),
+                ("ln_eps", C.c_float)]
 
 
 _LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b", "norm_conv_g",

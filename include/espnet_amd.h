@@ -43,6 +43,13 @@ extern "C" {
 #define EM_EPI_GLU 5       /* C[act][n/2] = (acc_v+b_v) * sigmoid(acc_g+b_g); W rows interleaved
                               in 16-row granules [v0..15,g0..15,v16..31,...] (convolution.py:68-69) */
 #define EM_EPI_STORE_F32 6 /* C[f32]  = acc + bias              (CTC / decoder logits) */
+/* GEMM + LayerNorm fused (N == 256: one workgroup owns whole rows; transformer/layer_norm.py:12-42):
+ *   x = C[f32] (+)= scale * (acc + bias);  ln2_g == NULL: C <- x,          ln_out[act] = LN(x; ln_g, ln_b)
+ *                                          ln2_g != NULL: C <- LN(x; ln_g, ln_b) =: y, ln_out = LN(y; ln2_g, ln2_b)
+ *   (the second form is EncoderLayer.norm_final followed by the next block's first norm or by
+ *   after_norm, encoder_layer.py:170-171, conformer_encoder.py:423-424)                          */
+#define EM_EPI_RESID_LN 7  /* x = C + scale * (acc + bias) */
+#define EM_EPI_SCALE_LN 8  /* x = scale * (acc + bias)     */
 
 /* A-operand addressing */
 #define EM_A_PLAIN 0 /* row m at A + m*lda */
@@ -57,6 +64,11 @@ typedef struct EmGemmArgs {
   int32_t lda, ldc;  /* in elements */
   float scale;
   int32_t T1, F1, T2, F2, d; /* EM_A_CONV2 only: M = B*T2*F2, K = 9*d */
+  /* EM_EPI_*_LN only */
+  const float *ln_g, *ln_b, *ln2_g, *ln2_b; /* [N] f32 */
+  void* ln_out;                             /* [M][N] act */
+  float* ln_out_f32;                        /* optional f32 copy of ln_out, or NULL */
+  float ln_eps;
 } EmGemmArgs;
 
 /* ---- library ------------------------------------------------------------------------------- */
