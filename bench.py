@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--beam", type=int, default=10)
     ap.add_argument("--ctc-weight", type=float, default=0.3)
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the per-GPU batch over this many HIP streams (independent utterances)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -195,7 +197,31 @@ def main():
         beam_search = build_beam_search(model, beam_size=args.beam, ctc_weight=args.ctc_weight,
                                         penalty=0.0, token_list=model.token_list)
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
+
+    def step_multistream():
+        # utterances are independent: each slice of the batch runs the whole path on its own
+        # stream, so the small latency-bound kernels of different slices overlap on the chip
+        main = torch.cuda.current_stream()
+        outs = []
+        per = (B + len(streams) - 1) // len(streams)
+        for k, s in enumerate(streams):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                sl = slice(k * per, min(B, (k + 1) * per))
+                st = model.encode_device(wav[sl], lens[sl])
+                outs.append(model.greedy_ctc_device(st)[1:])
+        for s in streams:
+            main.wait_stream(s)
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+
     def step():
+        if streams and beam_search is None:
+            tokens, tlens = step_multistream()
+            if world > 1:
+                dist.all_gather_into_tensor(gathered_tok, tokens)
+                dist.all_gather_into_tensor(gathered_len, tlens)
+            return tokens, tlens
         st = model.encode_device(wav, lens)
         if beam_search is None:
             _, tokens, tlens = model.greedy_ctc_device(st)

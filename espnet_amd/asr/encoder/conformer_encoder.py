@@ -279,15 +279,22 @@ class ConformerEncoder(torch.nn.Module):
         olens = conv2d_subsampled_lengths(flens, T_f)
         olens_dev = torch.tensor(olens, dtype=torch.int32).to(dev, non_blocking=True)
         need = lib.em_conformer_workspace_bytes(self.em_dtype, C.byref(pk["w"]), B, T_f)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        # one workspace per stream: independent utterance batches may be encoded concurrently on
+        # different HIP streams
+        skey = torch.cuda.current_stream().cuda_stream
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(skey)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._ws[skey] = ws
         d = self._output_size
         enc_out = torch.empty(B, T, d, dtype=torch.float32, device=dev)
         enc_act = torch.empty(B, T, d, dtype=self.act_dtype, device=dev)
         rc = lib.em_conformer_encode(
             self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
-            L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(self._ws),
-            self._ws.numel(), L.ptr(enc_out), L.ptr(enc_act), L.current_stream_ptr())
+            L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(ws),
+            ws.numel(), L.ptr(enc_out), L.ptr(enc_act), L.current_stream_ptr())
         L.check(rc, "em_conformer_encode")
         return enc_out, enc_act, olens, olens_dev
 
