@@ -170,6 +170,38 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d, g.F2 * d, d,
               sqrtf((float)d), stream));
 
+  // Fused feed-forward blocks (csrc/ffn.hip: LN + w_1 + Swish + w_2 + residual in one kernel, the
+  // hidden activation never leaves the chip).  Correct and tested
+  // (tests/test_gpu_kernels.py::test_ffn_fused_bf16) but measured SLOWER on MI355X at B = 32:
+  // 45 us per FFN vs 29.6 us for LN + two GEMMs.  A row-block workgroup has to stream all of
+  // W1 + W2 (1 MiB) through one CU; the ablation (tools/ffn_bench.py, EM_FFN_DBG) shows 14 us of
+  // weight streaming (73 GB/s per CU), 11 us of MFMA, 5 us of Swish and 14 us of prologue /
+  // epilogue / barriers that do not overlap.  Off until the weights are split across workgroups.
+  constexpr bool kUseFusedFfn = false;
+  if (kUseFusedFfn && dtype == EM_BF16 && d == 256 && ff % 128 == 0 && ff <= 2048) {
+    for (int l = 0; l < L; ++l) {
+      const EmConformerLayer& q = ly[l];
+      EM_TRY(em_ffn_fused_bf16(x, q.norm_ff_mac_g, q.norm_ff_mac_b, LN_EPS, q.ffm_w1, q.ffm_b1,
+                               q.ffm_w2, q.ffm_b2, M, d, ff, 0.5f, stream));
+      EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
+      EM_TRY(em_relpos_attention(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
+                                 q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
+      EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
+      EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, B, T, d, w->kernel, g2, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
+      EM_TRY(em_ffn_fused_bf16(x, q.norm_ff_g, q.norm_ff_b, LN_EPS, q.ff_w1, q.ff_b1, q.ff_w2,
+                               q.ff_b2, M, d, ff, 0.5f, stream));
+      if (l + 1 < L)
+        EM_TRY(em_layernorm_inplace_f32(x, q.norm_final_g, q.norm_final_b, M, d, LN_EPS, stream));
+      else
+        EM_TRY(em_layernorm2(dtype, x, q.norm_final_g, q.norm_final_b, w->after_norm_g,
+                             w->after_norm_b, M, d, LN_EPS, enc_act, enc_out, stream));
+    }
+    return EM_OK;
+  }
   EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr,
                       stream));
   for (int l = 0; l < L; ++l) {

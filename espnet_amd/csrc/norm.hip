@@ -45,9 +45,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x,
 #pragma unroll
   for (int j = 0; j < NV; ++j) v[j] = xr[lane + 64 * j];
   ln_row<NV>(v, g1, b1, lane, d, eps);
-  if (MODE == 1) {
+  if (MODE >= 1) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) xr[lane + 64 * j] = v[j];
+    if (MODE == 2) return;  // in place only
     ln_row<NV>(v, g2, b2, lane, d, eps);
   }
   T* o = out + (size_t)row * d;
@@ -103,9 +104,10 @@ __global__ __launch_bounds__(256) void layernorm4_kernel(float* __restrict__ x,
 #pragma unroll
   for (int j = 0; j < NV4; ++j) v[j] = xr[j * 64 + lane];
   ln_row4<NV4>(v, g1, b1, lane, d, eps);
-  if (MODE == 1) {
+  if (MODE >= 1) {
 #pragma unroll
     for (int j = 0; j < NV4; ++j) xr[j * 64 + lane] = v[j];
+    if (MODE == 2) return;  // in place only
     ln_row4<NV4>(v, g2, b2, lane, d, eps);
   }
   T* o = out + (size_t)row * d;
@@ -180,4 +182,11 @@ extern "C" int em_layernorm2(int dtype, float* x, const float* g1, const float* 
     return launch_ln<bf16, 1>(x, g1, b1, g2, b2, M, d, eps, (bf16*)out, out_f32,
                               (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
+}
+
+extern "C" int em_layernorm_inplace_f32(float* x, const float* g, const float* b, int32_t M,
+                                        int32_t d, float eps, void* stream) {
+  if (M <= 0 || d <= 0 || d % 64 != 0) return d % 64 ? EM_ERR_UNSUPPORTED : EM_ERR_BAD_ARG;
+  return launch_ln<float, 2>(x, g, b, nullptr, nullptr, M, d, eps, (float*)nullptr, nullptr,
+                             (hipStream_t)stream);
 }

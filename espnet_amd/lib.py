@@ -111,6 +111,8 @@ _SIGNATURES = {
     "em_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(EmGemmArgs), _vp]),
     "em_layernorm": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
     "em_layernorm2": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "em_ffn_fused_bf16": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "em_layernorm_inplace_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "em_relpos_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _i32, _vp, _vp]),
     "em_dwconv_bn_swish": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

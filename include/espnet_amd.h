@@ -118,6 +118,18 @@ int em_layernorm2(int dtype, float* x, const float* g1, const float* b1, const f
                   const float* b2, int32_t M, int32_t d, float eps, void* out, float* out_f32,
                   void* stream);
 
+/* ---- A9 + A10 fused (bf16, d == 256, ff % 128 == 0, ff <= 2048): the macaron feed-forward of
+ *      EncoderLayer.forward (conformer/encoder_layer.py:108-121, 160-168):
+ *      x += scale * (w_2 . swish(w_1 . LayerNorm(x; ln_g, ln_b) + b1) + b2)
+ *      (positionwise_feed_forward.py:30-32, layer_norm.py:12-42).  x [M][d] f32 in/out;
+ *      w1 [ff][d], w2 [d][ff] bf16.  The hidden activation never leaves the chip.               */
+int em_ffn_fused_bf16(float* x, const float* ln_g, const float* ln_b, float eps, const void* w1,
+                      const float* b1, const void* w2, const float* b2, int32_t M, int32_t d,
+                      int32_t ff, float scale, void* stream);
+/*   x <- LayerNorm(x; g, b) in place (EncoderLayer.norm_final, encoder_layer.py:170-171)         */
+int em_layernorm_inplace_f32(float* x, const float* g, const float* b, int32_t M, int32_t d,
+                             float eps, void* stream);
+
 /* ---- A7: RelPositionMultiHeadedAttention core (transformer/attention.py:416-459 after the
  *      projections): AC = (q+u)k^T, BD[i][j] = (q+v).p[T-1-i+j] (rel_shift :391-408 as index
  *      arithmetic), softmax((AC+BD)/sqrt(dk)) over keys j < klens[b] (masked probs = 0), times V.

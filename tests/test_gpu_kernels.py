@@ -335,3 +335,33 @@ def test_gemm_layernorm_epilogue(lib, prec, M, K, double, resid):
     assert_close(xd, x, 2e-5 if prec == "f32" else 2e-3, "x after ln-gemm")
     assert_close(out32, ref, 2e-5 if prec == "f32" else 2e-3, "ln f32 out")
     assert_close(out, ref, tol, "ln act out")
+
+
+@pytest.mark.parametrize("M,ff", [(64, 128), (500, 1024), (7968, 1024), (333, 2048)])
+def test_ffn_fused_bf16(lib, M, ff):
+    """em_ffn_fused_bf16 == x + scale * w2(swish(w1(LN(x)))) with bf16 operands, f32 accumulate."""
+    d = 256
+    x0 = rnd(M, d, seed=50)
+    g, b = 1 + 0.1 * rnd(d, seed=51), 0.1 * rnd(d, seed=52)
+    w1 = q(rnd(ff, d, seed=53, scale=d ** -0.5), torch.bfloat16)
+    w2 = q(rnd(d, ff, seed=54, scale=ff ** -0.5), torch.bfloat16)
+    b1, b2 = rnd(ff, seed=55, scale=0.1), rnd(d, seed=56, scale=0.1)
+    xn = q(F.layer_norm(x0, (d,), g, b, 1e-12), torch.bfloat16)
+    hdn = q(oc.swish(xn @ w1.t() + b1), torch.bfloat16)
+    ref = x0 + 0.5 * (hdn @ w2.t() + b2)
+    xd = dev(x0.clone())
+    L.check(lib.em_ffn_fused_bf16(L.ptr(xd), L.ptr(dev(g)), L.ptr(dev(b)), 1e-12,
+                                  L.ptr(dev(w1.to(torch.bfloat16))), L.ptr(dev(b1)),
+                                  L.ptr(dev(w2.to(torch.bfloat16))), L.ptr(dev(b2)), M, d, ff, 0.5,
+                                  sptr()), "em_ffn_fused_bf16")
+    # differences: bf16 rounding of LN(x)/hidden at slightly different f32 values
+    assert_close(xd, ref, 4e-3, "fused ffn")
+
+
+def test_layernorm_inplace(lib):
+    M, d = 300, 256
+    x = rnd(M, d, seed=60)
+    g, b = 1 + 0.1 * rnd(d, seed=61), 0.1 * rnd(d, seed=62)
+    xd = dev(x.clone())
+    L.check(lib.em_layernorm_inplace_f32(L.ptr(xd), L.ptr(dev(g)), L.ptr(dev(b)), M, d, 1e-12, sptr()))
+    assert_close(xd, F.layer_norm(x, (d,), g, b, 1e-12), 2e-6, "ln inplace")
