@@ -34,6 +34,34 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   if (lane == 0) ids[row] = bi;
 }
 
+// Second half of the GEMM-fused arg-max: G (value, column) partials per row -> best column.
+__global__ __launch_bounds__(256) void argmax_partials_kernel(const float2* __restrict__ part, int M,
+                                                              int G, int* __restrict__ ids) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int g = lane; g < G; g += 64) {
+    const float2 p = part[(size_t)row * G + g];
+    const int c = __float_as_int(p.y);
+    if (p.x > best || (p.x == best && c < bi)) {
+      best = p.x;
+      bi = c;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (lane == 0) ids[row] = bi;
+}
+
 // In-place log-softmax, one wave per row (two passes over an L2-resident row).
 __global__ __launch_bounds__(256) void log_softmax_rows_kernel(float* __restrict__ x, int M,
                                                                int V) {
@@ -84,6 +112,15 @@ extern "C" int em_argmax_rows_f32(const float* logits, int32_t M, int32_t V, int
   if (M <= 0 || V <= 0) return EM_ERR_BAD_ARG;
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(em_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream,
                      logits, M, V, ids);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_argmax_partials(const float* part, int32_t M, int32_t G, int32_t* ids,
+                                  void* stream) {
+  if (M <= 0 || G <= 0) return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(argmax_partials_kernel, dim3(em_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)part, M, G, ids);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

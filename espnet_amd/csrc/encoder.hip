@@ -242,9 +242,11 @@ extern "C" int em_ctc_greedy(int dtype, const void* enc_act, const void* w_ctc, 
                              int32_t* tokens, int32_t* out_lens, void* stream) {
   if (!enc_act || !w_ctc || !logits_ws || !ids || !tokens || !out_lens) return EM_ERR_BAD_ARG;
   const int M = B * T;
-  EM_TRY(gemm(dtype, EM_EPI_STORE_F32, enc_act, w_ctc, logits_ws, b_ctc, M, V, d, d, V, 1.f,
-              stream));
-  EM_TRY(em_argmax_rows_f32(logits_ws, M, V, ids, stream));
+  // arg-max fused into the ctc_lo GEMM epilogue: the (M, V) f32 logits (160 MB at B = 32) are
+  // never written; only 2*ceil(V/128) (value, column) partials per frame are
+  const int G = 2 * em_cdiv(V, 128);
+  EM_TRY(gemm(dtype, EM_EPI_ARGMAX_PART, enc_act, w_ctc, logits_ws, b_ctc, M, V, d, d, G, 1.f, stream));
+  EM_TRY(em_argmax_partials(logits_ws, M, G, ids, stream));
   EM_TRY(em_ctc_collapse(ids, olens, B, T, blank, sos_eos, tokens, out_lens, stream));
   return EM_OK;
 }

@@ -197,6 +197,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     }
     return;
   }
+  if constexpr (EPI == EM_EPI_ARGMAX_PART) {
+    // per-row (max, argmax) over this wave's 64 columns, straight from the accumulators: the 4
+    // in-lane fragments first, then the 16 lanes of a row group by shuffles (ties -> lowest column,
+    // = torch.argmax).  Cv: [M][ldc] pairs (f32 value, i32 column); group = n0/64 + wc.
+    float2* part = (float2*)Cv;
+    const int grp = (wn0 >> 6);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = wn0 + j * 16 + lr;
+          const float v = col < N ? acc[i][j][r] + (bias ? bias[col] : 0.f) : -INFINITY;
+          if (v > best) {  // ascending columns: strict > keeps the lowest on ties
+            best = v;
+            bi = col;
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const float ov = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+          }
+        }
+        const int m = wm0 + i * 16 + lg * 4 + r;
+        if (lr == 0 && m < M) part[(size_t)m * ldc + grp] = make_float2(best, __int_as_float(bi));
+      }
+    return;
+  }
   // per-wave LDS transpose of the whole wave tile: [BM/2 rows][64 cols] f32 (16 KiB per wave at
   // BM = 128; exactly the 64 KiB of staging LDS), 16-column groups XOR-swizzled by (row >> 2) & 3.
   // Three phases (all LDS writes -> all LDS reads -> math + global stores): hipcc orders every
@@ -422,6 +457,7 @@ int dispatch(int epi, int amode, const EmGemmArgs* p, hipStream_t s) {
     case EM_EPI_SCALE_F32: return launch<T, EM_EPI_SCALE_F32, EM_A_PLAIN>(p, s);
     case EM_EPI_GLU: return launch<T, EM_EPI_GLU, EM_A_PLAIN>(p, s);
     case EM_EPI_STORE_F32: return launch<T, EM_EPI_STORE_F32, EM_A_PLAIN>(p, s);
+    case EM_EPI_ARGMAX_PART: return launch<T, EM_EPI_ARGMAX_PART, EM_A_PLAIN>(p, s);
     case EM_EPI_RESID_LN: return launch_ln<T, EM_EPI_RESID_LN>(p, s);
     case EM_EPI_SCALE_LN: return launch_ln<T, EM_EPI_SCALE_LN>(p, s);
   }

@@ -15,7 +15,7 @@ EM_OK = 0
 EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE = -1, -2, -3, -4, -5
 EM_F32, EM_BF16 = 0, 1
 (EM_EPI_STORE, EM_EPI_SWISH, EM_EPI_RELU, EM_EPI_RESID_F32, EM_EPI_SCALE_F32, EM_EPI_GLU,
- EM_EPI_STORE_F32, EM_EPI_RESID_LN, EM_EPI_SCALE_LN) = range(9)
+ EM_EPI_STORE_F32, EM_EPI_RESID_LN, EM_EPI_SCALE_LN, EM_EPI_ARGMAX_PART) = range(10)
 EM_A_PLAIN, EM_A_CONV2 = 0, 1
 
 DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
@@ -117,6 +117,7 @@ _SIGNATURES = {
                                       _i32, _vp, _vp]),
     "em_dwconv_bn_swish": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "em_argmax_rows_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "em_argmax_partials": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "em_log_softmax_rows_f32": (C.c_int, [_vp, _i32, _i32, _vp]),
     "em_ctc_collapse": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "em_conformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32]),

@@ -50,6 +50,10 @@ extern "C" {
  *   after_norm, encoder_layer.py:170-171, conformer_encoder.py:423-424)                          */
 #define EM_EPI_RESID_LN 7  /* x = C + scale * (acc + bias) */
 #define EM_EPI_SCALE_LN 8  /* x = scale * (acc + bias)     */
+/* GEMM + per-row partial arg-max (CTC.argmax without materialising the (M, V) logits, asr/ctc.py:207-215):
+ *   C[m][g] = (max, argmax) of (acc + bias) over the 64 columns [64 g, 64 g + 64) as an (f32, i32) pair;
+ *   ldc = number of 64-column groups = 2 * ceil(N / 128); finish with em_argmax_partials.        */
+#define EM_EPI_ARGMAX_PART 9
 
 /* A-operand addressing */
 #define EM_A_PLAIN 0 /* row m at A + m*lda */
@@ -147,6 +151,8 @@ int em_dwconv_bn_swish(int dtype, const void* x, const float* w, const float* b,
 /* ---- A11 / G1: CTC head.  argmax over vocab (asr/ctc.py:207-215), then groupby + drop
  *      blank/sos/eos (bin/asr_inference.py:574-575).  logits [M][V] f32.                        */
 int em_argmax_rows_f32(const float* logits, int32_t M, int32_t V, int32_t* ids, void* stream);
+/*   ids[m] = column of the best of the G (value, column) pairs of row m (ties -> lowest column) */
+int em_argmax_partials(const float* part, int32_t M, int32_t G, int32_t* ids, void* stream);
 int em_log_softmax_rows_f32(float* logits, int32_t M, int32_t V, void* stream);
 int em_ctc_collapse(const int32_t* ids, const int32_t* olens, int32_t B, int32_t T, int32_t blank,
                     int32_t sos_eos, int32_t* tokens, int32_t* out_lens, void* stream);
@@ -207,8 +213,8 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
                         int32_t B, int32_t T_f, const void* pos_emb, void* workspace,
                         size_t workspace_bytes, float* enc_out, void* enc_act, void* stream);
 
-/* ---- A11 + G1 assembled: ctc_lo GEMM -> argmax -> collapse.
- *   enc_act [B*T][d] act; w_ctc [V][d] act; logits_ws [B*T][V] f32 scratch;
+/* ---- A11 + G1 assembled: ctc_lo GEMM (+ arg-max fused in its epilogue) -> collapse.
+ *   enc_act [B*T][d] act; w_ctc [V][d] act; logits_ws >= B*T * 2*ceil(V/128) * 2 f32 scratch;
  *   ids [B][T] i32 per-frame argmax; tokens [B][T] i32 (-1 padded); out_lens [B] i32            */
 int em_ctc_greedy(int dtype, const void* enc_act, const void* w_ctc, const float* b_ctc, int32_t B,
                   int32_t T, int32_t d, int32_t V, const int32_t* olens, int32_t blank,
