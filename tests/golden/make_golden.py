@@ -213,6 +213,63 @@ def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weigh
           f"best len={len(results[0][3].yseq)} score={float(results[0][3].score):.4f} keys={keys}")
 
 
+def stream_feats(utt_id, n_samples):
+    """Deterministic encoder input for the streaming fixtures: log-mel of the synthetic waveform
+    (oracle frontend, itself pinned against the reference) minus its per-utterance mean."""
+    from oracle import conformer as oc
+    from oracle.mel import slaney_mel_filterbank
+
+    mel = torch.from_numpy(slaney_mel_filterbank(sr=16000, n_fft=512, n_mels=80, fmin=0, fmax=8000).T.copy())
+    wav = synth_waveform(utt_id, n_samples)
+    f, fl = oc.frontend_feats(wav[None], torch.tensor([n_samples]), mel, 512, 512, 128)
+    return oc.utterance_mvn(f, fl)[0]
+
+
+def run_streaming_case(name, enc_conf, wseed, utt_id, n_samples, chunk_frames, keep_every=1):
+    """ContextualBlockConformerEncoder.forward_infer fed chunk by chunk
+    (espnet2/asr/encoder/contextual_block_conformer_encoder.py:386-600), as
+    Speech2TextStreaming.__call__ drives it (espnet2/bin/asr_inference_streaming.py:316-322)."""
+    from espnet2.asr.encoder.contextual_block_conformer_encoder import ContextualBlockConformerEncoder
+
+    t0 = time.time()
+    enc = ContextualBlockConformerEncoder(input_size=80, **enc_conf)
+    sd = enc.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    enc.load_state_dict(recipe_state_dict(shapes, wseed, skip=()), strict=True)
+    enc.eval()
+    feats = stream_feats(utt_id, n_samples)
+    outs, lens, state = [], [], None
+    pos = 0
+    while pos < feats.size(0):
+        nxt = min(feats.size(0), pos + chunk_frames)
+        final = nxt == feats.size(0)
+        y, _, state = enc(feats[None, pos:nxt], torch.tensor([nxt - pos]), state, is_final=final,
+                          infer_mode=True)
+        outs.append(y[0] if y.dim() == 3 else y)
+        lens.append(int(outs[-1].size(0)))
+        pos = nxt
+    ys = torch.cat(outs, dim=0)
+    # one-shot (is_final on the whole utterance) for the block-parallel path
+    y1, _, _ = enc(feats[None], torch.tensor([feats.size(0)]), None, is_final=True, infer_mode=True)
+    y1 = y1[0] if y1.dim() == 3 else y1
+    out = dict(enc_conf=np.array(json.dumps(enc_conf)), wseed=np.array(wseed), utt_id=np.array(utt_id),
+               n_samples=np.array(n_samples), chunk_frames=np.array(chunk_frames),
+               state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+               n_feat_frames=np.array(feats.size(0)), out_lens=np.array(lens),
+               ys=ys[::keep_every].numpy().copy(), ys_oneshot=y1[::keep_every].numpy().copy(),
+               keep_every=np.array(keep_every), ys_total=np.array(ys.size(0)),
+               ys_oneshot_total=np.array(y1.size(0)))
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"[{name}] done in {time.time()-t0:.1f}s feats{tuple(feats.shape)} out lens {lens} "
+          f"total {ys.size(0)} oneshot {y1.size(0)}")
+
+
+STREAM_SMALL = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12,
+                    input_layer="conv2d", normalize_before=True, activation_type="swish",
+                    macaron_style=True, use_cnn_module=True, cnn_module_kernel=15, block_size=40,
+                    hop_size=16, look_ahead=16, init_average=True, ctx_pos_enc=True)
+STREAM_TINY = dict(STREAM_SMALL, output_size=64, attention_heads=1, linear_units=128, num_blocks=2)
+
 CASES = {
     # config 0/1 of BASELINE.json: Conformer-small, one 10 s utterance
     "small_10s": lambda: run_encode_case("small_10s", SMALL, 5000, 11, [0], [160000], keep_every=4),
@@ -247,6 +304,12 @@ CASES = {
     "tiny_beam4_minlen": lambda: run_search_case(
         "tiny_beam4_minlen", tiny(d=64, heads=2, ff=128), 50, 7, 13, 32000, 4, 0.1, 8,
         minlenratio=0.2, maxlenratio=0.6, tweaks=[["decoder.output_layer.bias", 49, 6.0]]),
+    # config 5: contextual-block streaming Conformer (aishell recipe shape), 640 ms chunks
+    "stream_small_6s": lambda: run_streaming_case("stream_small_6s", STREAM_SMALL, 17, 20, 96000, 80,
+                                                  keep_every=4),
+    # tiny: every frame kept; odd chunk size exercises both carry buffers; 0.3 s = short-utterance path
+    "stream_tiny_4s": lambda: run_streaming_case("stream_tiny_4s", STREAM_TINY, 18, 21, 64000, 37),
+    "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 
 if __name__ == "__main__":

@@ -49,3 +49,23 @@ def hparams(g):
         win_length=fc.get("win_length", None),
         hop=fc.get("hop_length", 128),
     )
+
+
+def stream_feats(utt_id, n_samples):
+    """Encoder input of the streaming fixtures (same recipe as tests/golden/make_golden.py)."""
+    from oracle import conformer as oc
+    from oracle.mel import slaney_mel_filterbank
+
+    mel = torch.from_numpy(slaney_mel_filterbank(sr=16000, n_fft=512, n_mels=80, fmin=0, fmax=8000).T.copy())
+    wav = synth_waveform(utt_id, n_samples)
+    f, fl = oc.frontend_feats(wav[None], torch.tensor([n_samples]), mel, 512, 512, 128)
+    return oc.utterance_mvn(f, fl)[0]
+
+
+def load_stream_golden(name):
+    z = np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
+    g = {k: z[k] for k in z.files}
+    g["conf"] = json.loads(str(g["enc_conf"]))
+    g["shapes"] = {k: tuple(v) for k, v in json.loads(str(g["state_shapes"])).items()}
+    g["sd"] = recipe_state_dict(g["shapes"], int(g["wseed"]), skip=())
+    return g

@@ -156,3 +156,34 @@ def test_ctc_prefix_scorer_properties():
     # eos entry = log P(prefix is complete) = total blank path; blank entry = logzero
     assert abs(float(psi_full[0, V - 1]) - float(torch.cumsum(logp[:, 0], 0)[-1])) < 1e-4
     assert float(psi_full[0, 0]) == ob.LOGZERO
+
+
+# --------------------------------------------------------------------------- streaming encoder (A16)
+@pytest.mark.parametrize("name", ["stream_tiny_4s", "stream_tiny_short", "stream_small_6s"])
+def test_streaming_encoder_oracle_matches_reference(name):
+    """oracle/streaming.py == ContextualBlockConformerEncoder.forward_infer fed chunk by chunk:
+    same number of emitted frames per call, outputs within fp32 round-off; the one-shot
+    (is_final) call agrees too."""
+    from oracle.streaming import CBEncoderOracle
+    from tests.helpers import load_stream_golden, stream_feats
+
+    g = load_stream_golden(name)
+    c = g["conf"]
+    feats = stream_feats(int(g["utt_id"]), int(g["n_samples"]))
+    assert feats.size(0) == int(g["n_feat_frames"])
+    orc = CBEncoderOracle(g["sd"], c["attention_heads"], c["num_blocks"], c["block_size"],
+                          c["hop_size"], c["look_ahead"])
+    cf = int(g["chunk_frames"])
+    outs, lens, state, pos = [], [], None, 0
+    while pos < feats.size(0):
+        nxt = min(feats.size(0), pos + cf)
+        y, state = orc.forward_infer(feats[pos:nxt], state, nxt == feats.size(0))
+        outs.append(y)
+        lens.append(y.size(0))
+        pos = nxt
+    assert lens == g["out_lens"].tolist()
+    ke = int(g["keep_every"])
+    ys = torch.cat(outs, 0)
+    np.testing.assert_allclose(ys[::ke].numpy(), g["ys"], atol=2e-4, rtol=0)
+    y1, _ = orc.forward_infer(feats, None, True)
+    np.testing.assert_allclose(y1[::ke].numpy(), g["ys_oneshot"], atol=2e-4, rtol=0)
