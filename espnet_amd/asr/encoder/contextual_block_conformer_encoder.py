@@ -1,0 +1,346 @@
+"""ContextualBlockConformerEncoder (streaming, BASELINE config 5) on the MI355X.
+
+Mirrors espnet2/asr/encoder/contextual_block_conformer_encoder.py:39-600 for streaming inference:
+the constructor keywords, `output_size()`, `forward(xs_pad, ilens, prev_states, is_final=...,
+infer_mode=True)` and `forward_infer(xs_pad, ilens, prev_states, is_final)` with the reference's
+state dictionary (`prev_addin`, `buffer_before_downsampling`, `ilens_buffer`,
+`buffer_after_downsampling`, `n_processed_blocks`, `past_encoder_ctx`), and the reference's
+state-dict keys (`embed.conv.{0,2}`, `embed.out`, `encoders.N.{self_attn,feed_forward,
+feed_forward_macaron,conv_module,norm1,norm2,norm_ff_macaron,norm_conv,norm_final}`, `after_norm`).
+
+Split of work:
+  * host (this file, integers + tensor slicing only): the buffering before / after the 4x
+    subsampling, block counting, output stitching — exactly the reference's control flow
+    (:386-600), because it decides WHICH frames a call processes;
+  * device (csrc/streaming.hip, gemm.hip, norm.hip, conv.hip, frontend.hip): every arithmetic op —
+    subsampling convs, block assembly with stream positional encoding and block means, all
+    encoder layers, context hand-over, after_norm.
+
+`step_graph(...)` captures one steady-state call (fixed chunk -> fixed block count) into a hipGraph
+(torch.cuda.CUDAGraph on ROCm) so a chunk costs one graph launch instead of ~200 kernel launches.
+The torch.nn layers are parameter containers only.
+"""
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from espnet_amd import lib as L
+from espnet_amd.asr.decoder.transformer_decoder import abs_pos_table
+from espnet_amd.asr.encoder.conformer_encoder import (LayerNorm, _ConvolutionModule,
+                                                      _PositionwiseFeedForward)
+
+LN_EPS = 1e-12
+
+
+class _Conv2dSubsamplingWOPosEnc(torch.nn.Module):
+    """Parameters of transformer/subsampling_without_posenc.py:11-42 (kernels [3,3], strides [2,2])."""
+
+    def __init__(self, idim, odim):
+        super().__init__()
+        self.conv = torch.nn.Sequential(torch.nn.Conv2d(1, odim, 3, 2), torch.nn.ReLU(),
+                                        torch.nn.Conv2d(odim, odim, 3, 2), torch.nn.ReLU())
+        self.out = torch.nn.Linear(odim * (((idim - 3) // 2 + 1 - 3) // 2 + 1), odim)
+
+
+class _MultiHeadedAttention(torch.nn.Module):
+    def __init__(self, n_head, n_feat):
+        super().__init__()
+        self.linear_q = torch.nn.Linear(n_feat, n_feat)
+        self.linear_k = torch.nn.Linear(n_feat, n_feat)
+        self.linear_v = torch.nn.Linear(n_feat, n_feat)
+        self.linear_out = torch.nn.Linear(n_feat, n_feat)
+
+
+class _ContextualBlockEncoderLayer(torch.nn.Module):
+    """Parameters of conformer/contextual_block_encoder_layer.py:46-77."""
+
+    def __init__(self, size, heads, ff, kernel):
+        super().__init__()
+        self.self_attn = _MultiHeadedAttention(heads, size)
+        self.feed_forward = _PositionwiseFeedForward(size, ff)
+        self.feed_forward_macaron = _PositionwiseFeedForward(size, ff)
+        self.conv_module = _ConvolutionModule(size, kernel)
+        self.norm1 = LayerNorm(size)
+        self.norm2 = LayerNorm(size)
+        self.norm_ff_macaron = LayerNorm(size)
+        self.norm_conv = LayerNorm(size)
+        self.norm_final = LayerNorm(size)
+
+
+class ContextualBlockConformerEncoder(torch.nn.Module):
+    def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4,
+                 linear_units: int = 2048, num_blocks: int = 6, dropout_rate: float = 0.1,
+                 positional_dropout_rate: float = 0.1, attention_dropout_rate: float = 0.0,
+                 input_layer: Optional[str] = "conv2d", normalize_before: bool = True,
+                 concat_after: bool = False, positionwise_layer_type: str = "linear",
+                 positionwise_conv_kernel_size: int = 3, macaron_style: bool = False,
+                 pos_enc_class=None, selfattention_layer_type: str = "rel_selfattn",
+                 activation_type: str = "swish", use_cnn_module: bool = True,
+                 cnn_module_kernel: int = 31, padding_idx: int = -1, block_size: int = 40,
+                 hop_size: int = 16, look_ahead: int = 16, init_average: bool = True,
+                 ctx_pos_enc: bool = True, compute_dtype: str = "bfloat16"):
+        super().__init__()
+        bad = []
+        if input_layer != "conv2d": bad.append(f"input_layer={input_layer}")
+        if not normalize_before: bad.append("normalize_before=False")
+        if concat_after: bad.append("concat_after=True")
+        if positionwise_layer_type != "linear": bad.append(f"positionwise_layer_type={positionwise_layer_type}")
+        if not macaron_style: bad.append("macaron_style=False")
+        if pos_enc_class is not None: bad.append("pos_enc_class")
+        if activation_type != "swish": bad.append(f"activation_type={activation_type}")
+        if not use_cnn_module: bad.append("use_cnn_module=False")
+        if not init_average: bad.append("init_average=False")
+        if not ctx_pos_enc: bad.append("ctx_pos_enc=False")
+        if output_size % 64 or output_size // attention_heads not in (32, 64): bad.append("d_k not in {32,64}")
+        if linear_units % 64: bad.append("linear_units % 64 != 0")
+        if cnn_module_kernel not in (3, 7, 15, 31): bad.append(f"cnn_module_kernel={cnn_module_kernel}")
+        if block_size <= 0 or block_size + 2 > 64: bad.append(f"block_size={block_size}")
+        if bad:
+            raise NotImplementedError("outside the MI355X streaming-Conformer fast path: " + ", ".join(bad))
+        self._output_size, self._input_size = output_size, input_size
+        self.heads, self.linear_units, self.num_blocks = attention_heads, linear_units, num_blocks
+        self.cnn_module_kernel = cnn_module_kernel
+        self.normalize_before = normalize_before
+        self.block_size, self.hop_size, self.look_ahead = block_size, hop_size, look_ahead
+        self.init_average, self.ctx_pos_enc = init_average, ctx_pos_enc
+        self.subsample = 4
+        self.compute_dtype = compute_dtype
+        self.embed = _Conv2dSubsamplingWOPosEnc(input_size, output_size)
+        self.encoders = torch.nn.ModuleList(
+            [_ContextualBlockEncoderLayer(output_size, attention_heads, linear_units, cnn_module_kernel)
+             for _ in range(num_blocks)])
+        self.after_norm = LayerNorm(output_size)
+        self._packed = None
+        self._ws = {}
+
+    def output_size(self) -> int:
+        return self._output_size
+
+    @property
+    def em_dtype(self) -> int:
+        return L.DTYPES[self.compute_dtype]
+
+    @property
+    def act_dtype(self) -> torch.dtype:
+        return torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32
+
+    def invalidate(self):
+        self._packed = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate()
+        return r
+
+    # ------------------------------------------------------------------ packing (load time)
+    def pack(self, device):
+        dev = torch.device(device)
+        act = self.act_dtype
+        d, ff, NL = self._output_size, self.linear_units, self.num_blocks
+        keep = []
+
+        def A(t):
+            t = t.detach().to(torch.float32).contiguous().to(act).to(dev)
+            keep.append(t)
+            return t
+
+        def F(t):
+            t = t.detach().to(torch.float32).contiguous().to(dev)
+            keep.append(t)
+            return t
+
+        e = self.embed
+        F2 = e.out.in_features // d
+        w = L.EmConformerWeights()
+        w.d, w.heads, w.ff, w.num_blocks = d, self.heads, ff, NL
+        w.kernel, w.n_mels = self.cnn_module_kernel, self._input_size
+        top = dict(conv1_w=F(e.conv[0].weight.reshape(d, 9)), conv1_b=F(e.conv[0].bias),
+                   conv2_w=A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, 9 * d)),
+                   conv2_b=F(e.conv[2].bias),
+                   embed_w=A(e.out.weight.reshape(d, d, F2).permute(0, 2, 1).reshape(d, F2 * d)),
+                   embed_b=F(e.out.bias), after_norm_g=F(self.after_norm.weight),
+                   after_norm_b=F(self.after_norm.bias))
+        for k, v in top.items():
+            setattr(w, k, v.data_ptr())
+        layers = (L.EmConformerLayer * NL)()
+        glu_perm = torch.arange(2 * d).reshape(2, d // 16, 16).permute(1, 0, 2).reshape(-1)
+        for i, l in enumerate(self.encoders):
+            sa, cm = l.self_attn, l.conv_module
+            bn = cm.norm
+            scale = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            dw_w = cm.depthwise_conv.weight.double().reshape(d, -1) * scale[:, None]
+            dw_b = (cm.depthwise_conv.bias.double() - bn.running_mean.double()) * scale + bn.bias.double()
+            lt = dict(
+                norm_ff_mac_g=F(l.norm_ff_macaron.weight), norm_ff_mac_b=F(l.norm_ff_macaron.bias),
+                norm_mha_g=F(l.norm1.weight), norm_mha_b=F(l.norm1.bias),
+                norm_conv_g=F(l.norm_conv.weight), norm_conv_b=F(l.norm_conv.bias),
+                norm_ff_g=F(l.norm2.weight), norm_ff_b=F(l.norm2.bias),
+                norm_final_g=F(l.norm_final.weight), norm_final_b=F(l.norm_final.bias),
+                ffm_w1=A(l.feed_forward_macaron.w_1.weight), ffm_b1=F(l.feed_forward_macaron.w_1.bias),
+                ffm_w2=A(l.feed_forward_macaron.w_2.weight), ffm_b2=F(l.feed_forward_macaron.w_2.bias),
+                wqkv=A(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0)),
+                bqkv=F(torch.cat([sa.linear_q.bias, sa.linear_k.bias, sa.linear_v.bias], 0)),
+                wout=A(sa.linear_out.weight), bout=F(sa.linear_out.bias),
+                pw1=A(cm.pointwise_conv1.weight.reshape(2 * d, d)[glu_perm]),
+                pw1_b=F(cm.pointwise_conv1.bias[glu_perm]),
+                dw_w=F(dw_w.t()), dw_b=F(dw_b),
+                pw2=A(cm.pointwise_conv2.weight.reshape(d, d)), pw2_b=F(cm.pointwise_conv2.bias),
+                ff_w1=A(l.feed_forward.w_1.weight), ff_b1=F(l.feed_forward.w_1.bias),
+                ff_w2=A(l.feed_forward.w_2.weight), ff_b2=F(l.feed_forward.w_2.bias))
+            for k, v in lt.items():
+                setattr(layers[i], k, v.data_ptr())
+        w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))
+        pe = abs_pos_table(5000, d).to(dev)  # StreamPositionalEncoding.extend_pe (embedding.py:357-374)
+        self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype, pe=pe, F2=F2)
+        return self._packed
+
+    def _ensure_packed(self, device):
+        p = self._packed
+        if p is None or p["device"] != device or p["dtype"] != self.em_dtype:
+            p = self.pack(device)
+        return p
+
+    # ------------------------------------------------------------------ device pieces
+    def _embed_device(self, xs: torch.Tensor) -> torch.Tensor:
+        """Conv2dSubsamplingWOPosEnc.forward (subsampling_without_posenc.py:44-62); xs (t, idim) f32
+        on the GPU -> (t', d) f32."""
+        pk = self._ensure_packed(xs.device)
+        lib, w = L.load(), pk["w"]
+        t, nm = xs.shape
+        d = self._output_size
+        T1, F1 = (t - 3) // 2 + 1, (nm - 3) // 2 + 1
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        dev, act, st = xs.device, self.act_dtype, L.current_stream_ptr()
+        flen = torch.full((1,), t, dtype=torch.int32, device=dev)
+        c1 = torch.empty(T1 * F1 * d, dtype=act, device=dev)
+        L.check(lib.em_conv2d_sub1(self.em_dtype, L.ptr(xs), None, L.ptr(flen), 1, t, nm, w.conv1_w,
+                                   w.conv1_b, d, L.ptr(c1), st), "em_conv2d_sub1")
+        c2 = torch.empty(T2 * F2 * d, dtype=act, device=dev)
+        a = L.EmGemmArgs(A=c1.data_ptr(), W=w.conv2_w, C=c2.data_ptr(), bias=w.conv2_b, M=T2 * F2, N=d,
+                         K=9 * d, lda=0, ldc=d, scale=1.0, T1=T1, F1=F1, T2=T2, F2=F2, d=d)
+        L.check(lib.em_gemm(self.em_dtype, L.EM_EPI_RELU, L.EM_A_CONV2, a, st), "em_gemm(conv2)")
+        out = torch.empty(T2, d, dtype=torch.float32, device=dev)
+        a = L.EmGemmArgs(A=c2.data_ptr(), W=w.embed_w, C=out.data_ptr(), bias=w.embed_b, M=T2, N=d,
+                         K=F2 * d, lda=F2 * d, ldc=d, scale=1.0)
+        L.check(lib.em_gemm(self.em_dtype, L.EM_EPI_SCALE_F32, L.EM_A_PLAIN, a, st), "em_gemm(embed.out)")
+        return out
+
+    def _workspace(self, dev, n_blk, Lb):
+        pk = self._ensure_packed(dev)
+        need = L.load().em_cb_workspace_bytes(self.em_dtype, C.byref(pk["w"]), n_blk, Lb)
+        key = (torch.cuda.current_stream().cuda_stream, n_blk, Lb)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    def _encode_blocks(self, x: torch.Tensor, mask_mode: int, past_ctx, next_ctx):
+        """x (n_blk, L, d) f32 in place."""
+        pk = self._ensure_packed(x.device)
+        n_blk, Lb, _ = x.shape
+        ws = self._workspace(x.device, n_blk, Lb)
+        L.check(L.load().em_cb_encode_blocks(self.em_dtype, C.byref(pk["w"]), L.ptr(x), n_blk, Lb,
+                                             mask_mode, L.ptr(past_ctx), L.ptr(next_ctx), L.ptr(ws),
+                                             ws.numel(), L.current_stream_ptr()), "em_cb_encode_blocks")
+
+    def _after_norm(self, ys: torch.Tensor) -> torch.Tensor:
+        pk = self._ensure_packed(ys.device)
+        w = pk["w"]
+        L.check(L.load().em_layernorm_inplace_f32(L.ptr(ys), w.after_norm_g, w.after_norm_b,
+                                                  ys.size(0), ys.size(1), LN_EPS,
+                                                  L.current_stream_ptr()), "after_norm")
+        return ys
+
+    # ------------------------------------------------------------------ reference entry points
+    def forward(self, xs_pad, ilens, prev_states=None, is_final=True, infer_mode=False):
+        if not infer_mode:
+            raise NotImplementedError("forward_train (full-utterance block processing used in "
+                                      "training) is outside the inference hot path")
+        return self.forward_infer(xs_pad, ilens, prev_states, is_final)
+
+    @torch.no_grad()
+    def forward_infer(self, xs_pad: torch.Tensor, ilens: torch.Tensor, prev_states=None,
+                      is_final: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Optional[dict]]:
+        """contextual_block_conformer_encoder.py:386-600.  xs_pad (1, t, idim) f32 ON THE GPU."""
+        L.require_gpu(xs_pad, "xs_pad")
+        assert xs_pad.size(0) == 1
+        dev = xs_pad.device
+        pk = self._ensure_packed(dev)
+        lib = L.load()
+        d, bs, hs, la, sub = self._output_size, self.block_size, self.hop_size, self.look_ahead, self.subsample
+        st = prev_states or dict(prev_addin=None, buffer_before_downsampling=None, ilens_buffer=None,
+                                 buffer_after_downsampling=None, n_processed_blocks=0,
+                                 past_encoder_ctx=None)
+        prev_addin, buf_after = st["prev_addin"], st["buffer_after_downsampling"]
+        n_proc, past_ctx = st["n_processed_blocks"], st["past_encoder_ctx"]
+        xs = xs_pad[0].to(torch.float32)
+        if st["buffer_before_downsampling"] is not None:
+            xs = torch.cat([st["buffer_before_downsampling"], xs], dim=0)
+        empty = (xs.new_zeros(1, 0, d), xs.new_zeros(1))
+        if is_final:
+            buf_before = None
+        else:
+            n_samples = xs.size(0) // sub - 1
+            if n_samples < 2:  # :424-438
+                return (*empty, dict(st, buffer_before_downsampling=xs,
+                                     ilens_buffer=torch.tensor([xs.size(0)])))
+            n_res = xs.size(0) % sub + sub * 2
+            buf_before = xs[xs.size(0) - n_res:].contiguous()
+            xs = xs[: n_samples * sub]
+        x = self._embed_device(xs.contiguous())
+        if buf_after is not None:
+            x = torch.cat([buf_after, x], dim=0)
+        total = x.size(0)
+        if is_final:
+            block_num = math.ceil(float(total - (bs - hs - la) - la) / float(hs))
+            buf_after = None
+        else:
+            if total <= bs:  # :474-487
+                return (*empty, dict(prev_addin=prev_addin, buffer_before_downsampling=buf_before,
+                                     ilens_buffer=torch.tensor([buf_before.size(0)]),
+                                     buffer_after_downsampling=x, n_processed_blocks=n_proc,
+                                     past_encoder_ctx=past_ctx))
+            overlap = bs - hs
+            block_num = max(0, total - overlap) // hs
+            res = total - hs * block_num
+            buf_after = x[total - res:].contiguous()
+            x = x[: block_num * hs + overlap]
+        x = x.contiguous()
+        stream = L.current_stream_ptr()
+        if n_proc == 0 and total <= bs and is_final:  # short utterance (:496-505)
+            xc = torch.empty(1, total, d, dtype=torch.float32, device=dev)
+            L.check(lib.em_stream_pos_enc_f32(L.ptr(x), L.ptr(pk["pe"]), 0, total, d, L.ptr(xc), stream),
+                    "em_stream_pos_enc_f32")
+            self._encode_blocks(xc, 0, None, None)
+            return self._after_norm(xc[0]).unsqueeze(0), xs.new_zeros(1), None
+        chunks = torch.empty(block_num, bs + 2, d, dtype=torch.float32, device=dev)
+        addin = torch.empty(d, dtype=torch.float32, device=dev)
+        L.check(lib.em_cb_build_blocks_f32(L.ptr(x), L.ptr(pk["pe"]), L.ptr(prev_addin), n_proc,
+                                           block_num, x.size(0), bs, hs, d, L.ptr(chunks), L.ptr(addin),
+                                           stream), "em_cb_build_blocks_f32")
+        next_ctx = torch.empty(self.num_blocks, d, dtype=torch.float32, device=dev)
+        self._encode_blocks(chunks, 1, past_ctx, next_ctx)
+        ys_chunk = chunks[:, 1 : bs + 1]
+        offset = bs - la - hs
+        if is_final:
+            y_len = x.size(0) if n_proc == 0 else x.size(0) - offset
+        else:
+            y_len = block_num * hs + (offset if n_proc == 0 else 0)
+        ys = torch.zeros(y_len, d, dtype=torch.float32, device=dev)
+        if n_proc == 0:
+            ys[:offset] = ys_chunk[0, :offset]
+        for i in range(block_num):  # :565-576 (slicing only)
+            cur = i * hs + (offset if n_proc == 0 else 0)
+            clen = min(bs - offset, y_len - cur) if (i == block_num - 1 and is_final) else hs
+            ys[cur : cur + clen] = ys_chunk[i, offset : offset + clen]
+        ys = self._after_norm(ys).unsqueeze(0)
+        olen = torch.tensor([y_len], dtype=torch.float32, device=dev)
+        if is_final:
+            return ys, olen, None
+        return ys, olen, dict(prev_addin=addin, buffer_before_downsampling=buf_before,
+                              ilens_buffer=torch.tensor([buf_before.size(0)]),
+                              buffer_after_downsampling=buf_after,
+                              n_processed_blocks=n_proc + block_num, past_encoder_ctx=next_ctx)

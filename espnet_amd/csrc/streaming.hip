@@ -1,0 +1,281 @@
+// Streaming (contextual block) Conformer encoder step — SURVEY.md §8(a) A16, BASELINE config 5.
+//
+// Reference: ContextualBlockConformerEncoder.forward_infer
+// (espnet2/asr/encoder/contextual_block_conformer_encoder.py:386-600) and
+// ContextualBlockEncoderLayer.forward_infer
+// (espnet2/legacy/nets/pytorch_backend/conformer/contextual_block_encoder_layer.py:197-310).
+//
+// The per-call unit of work is a tensor of n_blk blocks x L = block_size + 2 slots x d (slot 0 =
+// context inherited from the previous block, slots 1..block_size = frames, slot L-1 = this block's
+// context).  All shapes of a steady-state call are static, so the whole step (≈170 launches for 12
+// layers) is captured once into a hipGraph by the host layer and replayed per chunk.
+//
+// Kernels here: block assembly (StreamPositionalEncoding + block means, embedding.py:376-389,
+// encoder :512-536), plain multi-head attention inside a block with the contextual mask
+// (attention.py:121-151, encoder :539-544), context propagation between layers (layer :292-304).
+// The dense parts reuse gemm.hip / norm.hip / conv.hip.
+#include <math.h>
+
+#include "em_common.h"
+
+namespace {
+
+// One workgroup per block i.  xs [total][d] f32 (subsampled frames of this call incl. the carried
+// buffer), pe [>= ...][d] absolute sinusoid table, x out [n_blk][L][d] f32.
+//   slot L-1 = addin_i   = mean(frames of block i) * sqrt(d) + pe[i + n_proc]
+//   slot 0   = addin_{i-1} (i > 0), else prev_addin carried from the previous call, else addin_0
+//   slot 1+j = xs[cur + j] * sqrt(d) + pe[cur + hop * n_proc + j]; unused slots are zero
+__global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __restrict__ xs,
+                                                              const float* __restrict__ pe,
+                                                              const float* __restrict__ prev_addin,
+                                                              int n_proc, int total, int bs, int hs,
+                                                              int d, float xscale,
+                                                              float* __restrict__ x,
+                                                              float* __restrict__ addin_out) {
+  const int i = blockIdx.x, L = bs + 2;
+  float* xb = x + (size_t)i * L * d;
+  const int cur = i * hs;
+  const int clen = (total - cur) < bs ? (total - cur) : bs;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float sum = 0.f;
+    for (int j = 0; j < clen; ++j) {
+      const float v = xs[(size_t)(cur + j) * d + c];
+      sum += v;
+      xb[(size_t)(1 + j) * d + c] = v * xscale + pe[(size_t)(cur + hs * n_proc + j) * d + c];
+    }
+    for (int j = clen; j < bs; ++j) xb[(size_t)(1 + j) * d + c] = 0.f;
+    const float addin = (sum / (float)clen) * xscale + pe[(size_t)(i + n_proc) * d + c];
+    xb[(size_t)(L - 1) * d + c] = addin;
+    float first;
+    if (i > 0) {  // the previous block's context: recomputed here, no inter-workgroup dependency
+      const int pcur = (i - 1) * hs;
+      const int plen = (total - pcur) < bs ? (total - pcur) : bs;
+      float ps = 0.f;
+      for (int j = 0; j < plen; ++j) ps += xs[(size_t)(pcur + j) * d + c];
+      first = (ps / (float)plen) * xscale + pe[(size_t)(i - 1 + n_proc) * d + c];
+    } else {
+      first = prev_addin ? prev_addin[c] : addin;
+    }
+    xb[c] = first;
+    if (i == gridDim.x - 1) addin_out[c] = addin;
+  }
+}
+
+// Plain multi-head attention inside each block: one 64-thread workgroup per (head, block), thread r
+// = query slot r.  qkv [n_blk*L][3d] act (q | k | v).  mask_mode 1 = contextual mask
+// (encoder :539-544): query slot 0 attends to nothing (its output is 0), every other slot attends to
+// slots 0..L-2; mask_mode 0 = no mask (short-utterance path).
+template <typename T, int DK>
+__global__ __launch_bounds__(64) void block_mha_kernel(const T* __restrict__ qkv, int L, int d,
+                                                       int mask_mode, T* __restrict__ ctx) {
+  extern __shared__ float sm[];
+  float* Ks = sm;                   // [L][DK + 1]
+  float* Vs = Ks + L * (DK + 1);    // [L][DK + 1]
+  const int h = blockIdx.x, blk = blockIdx.y, r = threadIdx.x;
+  const T* base = qkv + (size_t)blk * L * 3 * d + h * DK;
+  for (int e = r; e < L * DK; e += 64) {
+    const int j = e / DK, c = e - j * DK;
+    Ks[j * (DK + 1) + c] = to_f32(base[(size_t)j * 3 * d + d + c]);
+    Vs[j * (DK + 1) + c] = to_f32(base[(size_t)j * 3 * d + 2 * d + c]);
+  }
+  __syncthreads();
+  if (r >= L) return;
+  T* out = ctx + ((size_t)blk * L + r) * d + h * DK;
+  const int nkeys = mask_mode ? L - 1 : L;
+  if (mask_mode && r == 0) {
+    for (int c = 0; c < DK; ++c) out[c] = from_f32<T>(0.f);
+    return;
+  }
+  float q[DK];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) q[c] = to_f32(base[(size_t)r * 3 * d + c]);
+  const float scale = rsqrtf((float)DK);
+  float mx = -INFINITY;
+  for (int j = 0; j < nkeys; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) s = fmaf(q[c], Ks[j * (DK + 1) + c], s);
+    mx = fmaxf(mx, s * scale);
+  }
+  float acc[DK];
+#pragma unroll
+  for (int c = 0; c < DK; ++c) acc[c] = 0.f;
+  float sum = 0.f;
+  for (int j = 0; j < nkeys; ++j) {  // scores recomputed: cheaper than an L x L LDS table here
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) s = fmaf(q[c], Ks[j * (DK + 1) + c], s);
+    const float p = expf(s * scale - mx);
+    sum += p;
+#pragma unroll
+    for (int c = 0; c < DK; ++c) acc[c] = fmaf(p, Vs[j * (DK + 1) + c], acc[c]);
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int c = 0; c < DK; ++c) out[c] = from_f32<T>(acc[c] * inv);
+}
+
+// Context hand-over after a layer (layer :292-304), in place on x [n_blk][L][d] f32:
+//   x[0][0] = past_ctx (or x[0][L-1] for the first block of an utterance); x[b][0] = x[b-1][L-1];
+//   next_ctx = x[n_blk-1][L-1].
+__global__ __launch_bounds__(256) void cb_propagate_ctx_kernel(float* __restrict__ x,
+                                                               const float* __restrict__ past_ctx,
+                                                               float* __restrict__ next_ctx,
+                                                               int n_blk, int L, int d) {
+  const int b = blockIdx.x;
+  float* xb = x + (size_t)b * L * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float v;
+    if (b == 0) v = past_ctx ? past_ctx[c] : xb[(size_t)(L - 1) * d + c];
+    else v = x[((size_t)(b - 1) * L + (L - 1)) * d + c];
+    xb[c] = v;
+    if (b == n_blk - 1 && next_ctx) next_ctx[c] = xb[(size_t)(L - 1) * d + c];
+  }
+}
+
+// out[j] = xs[j] * sqrt(d) + pe[start + j]   (StreamPositionalEncoding.forward, embedding.py:376-389)
+__global__ __launch_bounds__(256) void stream_pos_enc_kernel(const float* __restrict__ xs,
+                                                             const float* __restrict__ pe, int start,
+                                                             int d, float xscale,
+                                                             float* __restrict__ out) {
+  const int j = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    out[(size_t)j * d + c] = xs[(size_t)j * d + c] * xscale + pe[(size_t)(start + j) * d + c];
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct CbWs {
+  size_t xn, big, g, g2, ctx, total;
+};
+inline CbWs cb_layout(int dtype, const EmConformerWeights* w, int M) {
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  const size_t d = w->d;
+  const size_t wide = (size_t)w->ff > 3 * d ? w->ff : 3 * d;
+  CbWs s;
+  size_t o = 0;
+  s.xn = o; o += align_up((size_t)M * d * es);
+  s.big = o; o += align_up((size_t)M * wide * es);
+  s.g = o; o += align_up((size_t)M * d * es);
+  s.g2 = o; o += align_up((size_t)M * d * es);
+  s.ctx = o; o += align_up((size_t)M * d * es);
+  s.total = o;
+  return s;
+}
+
+inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
+                int N, int K, int lda, int ldc, float scale, void* stream) {
+  EmGemmArgs a = {};
+  a.A = A; a.W = W; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.scale = scale;
+  return em_gemm(dtype, epi, EM_A_PLAIN, &a, stream);
+}
+
+#define EM_TRY(expr)                \
+  do {                              \
+    int rc__ = (expr);              \
+    if (rc__ != EM_OK) return rc__; \
+  } while (0)
+
+constexpr float LN_EPS = 1e-12f;
+
+}  // namespace
+
+extern "C" int em_cb_build_blocks_f32(const float* xs, const float* pe, const float* prev_addin,
+                                      int32_t n_proc, int32_t n_blk, int32_t total, int32_t bs,
+                                      int32_t hs, int32_t d, float* x, float* addin_out,
+                                      void* stream) {
+  if (!xs || !pe || !x || !addin_out || n_blk <= 0 || total <= 0 || bs <= 0 || hs <= 0 || d <= 0)
+    return EM_ERR_BAD_ARG;
+  if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
+  hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk), dim3(256), 0, (hipStream_t)stream, xs, pe,
+                     prev_addin, n_proc, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_stream_pos_enc_f32(const float* xs, const float* pe, int32_t start, int32_t n,
+                                     int32_t d, float* out, void* stream) {
+  if (!xs || !pe || !out || n <= 0 || d <= 0 || start < 0) return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(stream_pos_enc_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, xs, pe, start,
+                     d, sqrtf((float)d), out);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_block_mha(int dtype, const void* qkv, int32_t n_blk, int32_t L, int32_t d,
+                            int32_t heads, int32_t mask_mode, void* ctx, void* stream) {
+  if (!qkv || !ctx || n_blk <= 0 || L <= 0 || L > 64 || heads <= 0) return EM_ERR_BAD_ARG;
+  const int dk = d / heads;
+  const size_t lds = (size_t)2 * L * (dk + 1) * sizeof(float);
+  dim3 grid(heads, n_blk);
+  hipStream_t s = (hipStream_t)stream;
+#define EM_MHA_CASE(TT, DKK)                                                                   \
+  hipLaunchKernelGGL((block_mha_kernel<TT, DKK>), grid, dim3(64), lds, s, (const TT*)qkv, L, d, \
+                     mask_mode, (TT*)ctx)
+  if (dtype == EM_F32 && dk == 64) EM_MHA_CASE(float, 64);
+  else if (dtype == EM_F32 && dk == 32) EM_MHA_CASE(float, 32);
+  else if (dtype == EM_BF16 && dk == 64) EM_MHA_CASE(bf16, 64);
+  else if (dtype == EM_BF16 && dk == 32) EM_MHA_CASE(bf16, 32);
+  else return EM_ERR_UNSUPPORTED;
+#undef EM_MHA_CASE
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_cb_propagate_ctx_f32(float* x, const float* past_ctx, float* next_ctx,
+                                       int32_t n_blk, int32_t L, int32_t d, void* stream) {
+  if (!x || n_blk <= 0 || L < 2 || d <= 0) return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cb_propagate_ctx_kernel, dim3(n_blk), dim3(256), 0, (hipStream_t)stream, x,
+                     past_ctx, next_ctx, n_blk, L, d);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" size_t em_cb_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t n_blk,
+                                        int32_t L) {
+  if (!w || n_blk <= 0 || L <= 0) return 0;
+  return cb_layout(dtype, w, n_blk * L).total;
+}
+
+// All layers of the block encoder on x [n_blk][L][d] f32 (in place).  past_ctx / next_ctx:
+// [num_blocks][d] f32 context vectors carried across calls (past_ctx NULL = first call of an
+// utterance; both NULL with mask_mode 0 = short-utterance path without context slots).
+// EmConformerLayer fields are reused: norm_mha = norm1, norm_ff = norm2, no pos_u / pos_v; the
+// feed-forward activation is ReLU (contextual_block_conformer_encoder.py:148-154).
+extern "C" int em_cb_encode_blocks(int dtype, const EmConformerWeights* w, float* x, int32_t n_blk,
+                                   int32_t L, int32_t mask_mode, const float* past_ctx,
+                                   float* next_ctx, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  if (!w || !x || !workspace || n_blk <= 0 || L <= 0) return EM_ERR_BAD_ARG;
+  if (dtype != EM_F32 && dtype != EM_BF16) return EM_ERR_BAD_ARG;
+  const int d = w->d, h = w->heads, ff = w->ff, NL = w->num_blocks, M = n_blk * L;
+  if (d % 64 != 0 || ff % 64 != 0 || (d / h != 64 && d / h != 32)) return EM_ERR_UNSUPPORTED;
+  const CbWs s = cb_layout(dtype, w, M);
+  if (workspace_bytes < s.total) return EM_ERR_WORKSPACE;
+  unsigned char* ws = (unsigned char*)workspace;
+  void *xn = ws + s.xn, *big = ws + s.big, *gl = ws + s.g, *g2 = ws + s.g2, *ctx = ws + s.ctx;
+  for (int l = 0; l < NL; ++l) {
+    const EmConformerLayer& q = w->layers[l];
+    EM_TRY(em_layernorm(dtype, x, q.norm_ff_mac_g, q.norm_ff_mac_b, M, d, LN_EPS, xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RELU, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
+    EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
+    EM_TRY(em_block_mha(dtype, big, n_blk, L, d, h, mask_mode, ctx, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
+    EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
+    EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, n_blk, L, d, w->kernel, g2, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
+    EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RELU, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ff_w2, x, q.ff_b2, M, d, ff, ff, d, 0.5f, stream));
+    EM_TRY(em_layernorm_inplace_f32(x, q.norm_final_g, q.norm_final_b, M, d, LN_EPS, stream));
+    if (mask_mode)
+      EM_TRY(em_cb_propagate_ctx_f32(x, past_ctx ? past_ctx + (size_t)l * d : nullptr,
+                                     next_ctx ? next_ctx + (size_t)l * d : nullptr, n_blk, L, d,
+                                     stream));
+  }
+  return EM_OK;
+}

@@ -123,6 +123,13 @@ _SIGNATURES = {
     "em_conformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32]),
     "em_conformer_encode": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _vp, _vp, _vp,
                                       _i32, _i32, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "em_stream_pos_enc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "em_cb_build_blocks_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "em_block_mha": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "em_cb_propagate_ctx_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "em_cb_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32]),
+    "em_cb_encode_blocks": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _i32, _i32, _i32,
+                                      _vp, _vp, _vp, _sz, _vp]),
     "em_profile_create": (_vp, [_i32]),
     "em_profile_destroy": (None, [_vp]),
     "em_profile_attach": (None, [_vp]),

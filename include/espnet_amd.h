@@ -328,6 +328,36 @@ int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* d
 int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
                     const EmSearchBuffers* b, int32_t i0, int32_t i1, void* stream);
 
+/* ---- A16: streaming (contextual block) Conformer encoder step
+ *      (ContextualBlockConformerEncoder.forward_infer, espnet2/asr/encoder/
+ *      contextual_block_conformer_encoder.py:386-600; ContextualBlockEncoderLayer.forward_infer,
+ *      legacy/nets/pytorch_backend/conformer/contextual_block_encoder_layer.py:197-310).
+ *      Buffering across calls is host logic (espnet_amd/asr/encoder/
+ *      contextual_block_conformer_encoder.py); these entry points do the arithmetic of one call on
+ *      static shapes, so the host can capture a steady-state call in a hipGraph.                 */
+/*   out[j] = xs[j]*sqrt(d) + pe[start+j]  (StreamPositionalEncoding.forward, embedding.py:376-389) */
+int em_stream_pos_enc_f32(const float* xs, const float* pe, int32_t start, int32_t n, int32_t d,
+                          float* out, void* stream);
+/*   Block assembly (:512-536): xs [total][d] f32 subsampled frames, pe [..][d] sinusoid table,
+ *   prev_addin [d] context carried from the previous call or NULL; x [n_blk][bs+2][d] f32 out,
+ *   addin_out [d] = context of the last block.                                                   */
+int em_cb_build_blocks_f32(const float* xs, const float* pe, const float* prev_addin, int32_t n_proc,
+                           int32_t n_blk, int32_t total, int32_t bs, int32_t hs, int32_t d, float* x,
+                           float* addin_out, void* stream);
+/*   MultiHeadedAttention inside each block (attention.py:121-151): qkv [n_blk*L][3d] act,
+ *   mask_mode 1 = contextual mask (:539-544), 0 = none; ctx [n_blk*L][d] act.  L <= 64.          */
+int em_block_mha(int dtype, const void* qkv, int32_t n_blk, int32_t L, int32_t d, int32_t heads,
+                 int32_t mask_mode, void* ctx, void* stream);
+/*   Context hand-over after a layer (layer :292-304), in place on x [n_blk][L][d] f32.           */
+int em_cb_propagate_ctx_f32(float* x, const float* past_ctx, float* next_ctx, int32_t n_blk,
+                            int32_t L, int32_t d, void* stream);
+size_t em_cb_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t n_blk, int32_t L);
+/*   All layers on x [n_blk][L][d] f32 in place.  EmConformerLayer is reused (norm_mha = norm1,
+ *   norm_ff = norm2, pos_u/pos_v unused; ReLU feed-forward).  past_ctx / next_ctx [num_blocks][d].  */
+int em_cb_encode_blocks(int dtype, const EmConformerWeights* w, float* x, int32_t n_blk, int32_t L,
+                        int32_t mask_mode, const float* past_ctx, float* next_ctx, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* ---- optional per-launch timing of the GEMM kernel family (measurement only; bench.py's
  *      `roofline` leg).  While a profile is attached to the calling thread every em_gemm launch
  *      (direct or from em_conformer_encode / em_ctc_greedy) is bracketed by hipEventRecord on its
