@@ -318,9 +318,11 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
             return self._after_norm(xc[0]).unsqueeze(0), xs.new_zeros(1), None
         chunks = torch.empty(block_num, bs + 2, d, dtype=torch.float32, device=dev)
         addin = torch.empty(d, dtype=torch.float32, device=dev)
+        n_proc_dev = st.get("n_processed_blocks_dev")  # set by StreamingStepGraph only
         L.check(lib.em_cb_build_blocks_f32(L.ptr(x), L.ptr(pk["pe"]), L.ptr(prev_addin), n_proc,
-                                           block_num, x.size(0), bs, hs, d, L.ptr(chunks), L.ptr(addin),
-                                           stream), "em_cb_build_blocks_f32")
+                                           L.ptr(n_proc_dev), block_num, x.size(0), bs, hs, d,
+                                           L.ptr(chunks), L.ptr(addin), stream),
+                "em_cb_build_blocks_f32")
         next_ctx = torch.empty(self.num_blocks, d, dtype=torch.float32, device=dev)
         self._encode_blocks(chunks, 1, past_ctx, next_ctx)
         ys_chunk = chunks[:, 1 : bs + 1]
@@ -337,10 +339,103 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
             clen = min(bs - offset, y_len - cur) if (i == block_num - 1 and is_final) else hs
             ys[cur : cur + clen] = ys_chunk[i, offset : offset + clen]
         ys = self._after_norm(ys).unsqueeze(0)
-        olen = torch.tensor([y_len], dtype=torch.float32, device=dev)
+        olen = xs.new_full((1,), float(y_len))  # device fill (capturable), as the reference returns it
         if is_final:
             return ys, olen, None
         return ys, olen, dict(prev_addin=addin, buffer_before_downsampling=buf_before,
                               ilens_buffer=torch.tensor([buf_before.size(0)]),
                               buffer_after_downsampling=buf_after,
                               n_processed_blocks=n_proc + block_num, past_encoder_ctx=next_ctx)
+
+
+class StreamingStepGraph:
+    """hipGraph replay of the steady-state streaming step (BASELINE config 5).
+
+    Feeding fixed-size chunks, `forward_infer` reaches a steady state after a few calls: the carried
+    buffers keep their shapes and every call processes the same number of blocks, so the ~200
+    kernel launches of a call are identical except for the positional-encoding offset (read from
+    device memory).  This wrapper runs the encoder eagerly until two consecutive calls have the same
+    signature, captures the next call into a hipGraph (torch.cuda.CUDAGraph = hipGraph on ROCm)
+    over static input / state buffers, and from then on replays it: one graph launch per chunk.
+    `is_final` calls and any call whose chunk size differs fall back to the eager path.
+    """
+
+    def __init__(self, encoder: ContextualBlockConformerEncoder, chunk_frames: int):
+        self.enc, self.chunk = encoder, chunk_frames
+        self.state, self.graph, self.graph_sig = None, None, None
+        self.in_graph_state = False
+        self.n_replays = 0
+
+    @staticmethod
+    def _signature(st):
+        return (tuple(st["buffer_before_downsampling"].shape), tuple(st["buffer_after_downsampling"].shape),
+                st["prev_addin"] is not None, st["past_encoder_ctx"] is not None)
+
+    def reset(self):
+        self.state = None  # the captured graph stays valid for the next utterance
+        self.in_graph_state = False
+
+    def _capture(self, feats):
+        st = self.state
+        dev = feats.device
+        self.s_in = feats.clone()
+        self.s_state = dict(
+            prev_addin=st["prev_addin"].clone(),
+            buffer_before_downsampling=st["buffer_before_downsampling"].clone(),
+            ilens_buffer=st["ilens_buffer"],
+            buffer_after_downsampling=st["buffer_after_downsampling"].clone(),
+            n_processed_blocks=1,  # > 0: steady state; the real count lives on the device
+            n_processed_blocks_dev=torch.tensor([st["n_processed_blocks"]], dtype=torch.int32, device=dev),
+            past_encoder_ctx=st["past_encoder_ctx"].clone())
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on the capture stream (allocator, workspaces)
+            self.enc.forward_infer(self.s_in[None], torch.tensor([self.chunk]), dict(self.s_state), False)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ys, _, nst = self.enc.forward_infer(self.s_in[None], torch.tensor([self.chunk]),
+                                                dict(self.s_state), False)
+            # carry the state forward inside the graph (static buffers, same shapes)
+            self.s_state["prev_addin"].copy_(nst["prev_addin"])
+            self.s_state["buffer_before_downsampling"].copy_(nst["buffer_before_downsampling"])
+            self.s_state["buffer_after_downsampling"].copy_(nst["buffer_after_downsampling"])
+            self.s_state["past_encoder_ctx"].copy_(nst["past_encoder_ctx"])
+            self.s_state["n_processed_blocks_dev"].add_(nst["n_processed_blocks"] - 1)
+        self.graph, self.s_out = g, ys
+        self.blocks_per_call = nst["n_processed_blocks"] - 1
+
+    def _load_static_state(self):
+        st = self.state
+        for k in ("prev_addin", "buffer_before_downsampling", "buffer_after_downsampling", "past_encoder_ctx"):
+            self.s_state[k].copy_(st[k])
+        self.s_state["n_processed_blocks_dev"].fill_(st["n_processed_blocks"])
+
+    @torch.no_grad()
+    def __call__(self, feats: torch.Tensor, is_final: bool = False):
+        """feats (t, idim) f32 on the GPU.  Returns ys (t_out, d) f32 (a view of a static buffer
+        when replayed: consume or clone it before the next call)."""
+        steady = (not is_final and feats.size(0) == self.chunk and self.state is not None
+                  and self.state["past_encoder_ctx"] is not None
+                  and self.state["buffer_after_downsampling"] is not None)
+        if steady and self.graph is not None and self._signature(self.state) == self.graph_sig:
+            if not self.in_graph_state:
+                self._load_static_state()
+                self.in_graph_state = True
+            self.s_in.copy_(feats)
+            self.graph.replay()
+            self.n_replays += 1
+            self.state["n_processed_blocks"] += self.blocks_per_call
+            return self.s_out[0]
+        if self.in_graph_state:  # leave graph mode: pull the state back out
+            for k in ("prev_addin", "buffer_before_downsampling", "buffer_after_downsampling", "past_encoder_ctx"):
+                self.state[k] = self.s_state[k].clone()
+            self.in_graph_state = False
+        prev_sig = self._signature(self.state) if steady else None
+        ys, _, nst = self.enc.forward_infer(feats[None], torch.tensor([feats.size(0)]), self.state, is_final)
+        self.state = nst
+        if (steady and self.graph is None and nst is not None and prev_sig == self._signature(nst)):
+            self.graph_sig = prev_sig
+            self._capture(feats)
+            self.in_graph_state = False
+        return ys[0]

@@ -28,11 +28,16 @@ namespace {
 __global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __restrict__ xs,
                                                               const float* __restrict__ pe,
                                                               const float* __restrict__ prev_addin,
-                                                              int n_proc, int total, int bs, int hs,
+                                                              int n_proc_host,
+                                                              const int* __restrict__ n_proc_dev,
+                                                              int total, int bs, int hs,
                                                               int d, float xscale,
                                                               float* __restrict__ x,
                                                               float* __restrict__ addin_out) {
   const int i = blockIdx.x, L = bs + 2;
+  // the number of blocks already processed feeds the positional-encoding offsets; a hipGraph-
+  // captured step reads it from device memory (kernel arguments are frozen at capture)
+  const int n_proc = n_proc_dev ? *n_proc_dev : n_proc_host;
   float* xb = x + (size_t)i * L * d;
   const int cur = i * hs;
   const int clen = (total - cur) < bs ? (total - cur) : bs;
@@ -182,14 +187,15 @@ constexpr float LN_EPS = 1e-12f;
 }  // namespace
 
 extern "C" int em_cb_build_blocks_f32(const float* xs, const float* pe, const float* prev_addin,
-                                      int32_t n_proc, int32_t n_blk, int32_t total, int32_t bs,
+                                      int32_t n_proc, const int32_t* n_proc_dev, int32_t n_blk,
+                                      int32_t total, int32_t bs,
                                       int32_t hs, int32_t d, float* x, float* addin_out,
                                       void* stream) {
   if (!xs || !pe || !x || !addin_out || n_blk <= 0 || total <= 0 || bs <= 0 || hs <= 0 || d <= 0)
     return EM_ERR_BAD_ARG;
   if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
   hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk), dim3(256), 0, (hipStream_t)stream, xs, pe,
-                     prev_addin, n_proc, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+                     prev_addin, n_proc, n_proc_dev, total, bs, hs, d, sqrtf((float)d), x, addin_out);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

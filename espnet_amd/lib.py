@@ -124,7 +124,8 @@ _SIGNATURES = {
     "em_conformer_encode": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _vp, _vp, _vp,
                                       _i32, _i32, _vp, _vp, _sz, _vp, _vp, _vp]),
     "em_stream_pos_enc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
-    "em_cb_build_blocks_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "em_cb_build_blocks_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
+                                         _vp]),
     "em_block_mha": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "em_cb_propagate_ctx_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "em_cb_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32]),

@@ -339,11 +339,13 @@ int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* 
 int em_stream_pos_enc_f32(const float* xs, const float* pe, int32_t start, int32_t n, int32_t d,
                           float* out, void* stream);
 /*   Block assembly (:512-536): xs [total][d] f32 subsampled frames, pe [..][d] sinusoid table,
- *   prev_addin [d] context carried from the previous call or NULL; x [n_blk][bs+2][d] f32 out,
- *   addin_out [d] = context of the last block.                                                   */
+ *   prev_addin [d] context carried from the previous call or NULL; n_proc = blocks processed by
+ *   earlier calls, read from n_proc_dev (device i32) when that is non-NULL -- a hipGraph-captured
+ *   step needs it in device memory; x [n_blk][bs+2][d] f32 out, addin_out [d] = context of the
+ *   last block.                                                                                  */
 int em_cb_build_blocks_f32(const float* xs, const float* pe, const float* prev_addin, int32_t n_proc,
-                           int32_t n_blk, int32_t total, int32_t bs, int32_t hs, int32_t d, float* x,
-                           float* addin_out, void* stream);
+                           const int32_t* n_proc_dev, int32_t n_blk, int32_t total, int32_t bs,
+                           int32_t hs, int32_t d, float* x, float* addin_out, void* stream);
 /*   MultiHeadedAttention inside each block (attention.py:121-151): qkv [n_blk*L][3d] act,
  *   mask_mode 1 = contextual mask (:539-544), 0 = none; ctx [n_blk*L][d] act.  L <= 64.          */
 int em_block_mha(int dtype, const void* qkv, int32_t n_blk, int32_t L, int32_t d, int32_t heads,

@@ -93,3 +93,33 @@ def test_block_mha_kernel():
                 ref = torch.softmax(sc, -1) @ v
             ref = ref.permute(0, 2, 1, 3).reshape(n_blk * Lb, d)
             assert (ctx.float().cpu() - ref).abs().max().item() < tol, (dt, mode)
+
+
+def test_streaming_step_hipgraph_replay_equals_eager():
+    """BASELINE config 5: the steady-state chunk step replayed from a hipGraph gives exactly the
+    eager results (same kernels, same data), including across the eager -> graph -> final hand-over."""
+    from espnet_amd.asr.encoder.contextual_block_conformer_encoder import StreamingStepGraph
+
+    g = load_stream_golden("stream_small_6s")
+    feats = stream_feats(int(g["utt_id"]), int(g["n_samples"])).cuda()
+    enc = build(g, "bfloat16")
+    cf = 64  # 640 ms of 10 ms frames -> 16 encoder frames = one block per call
+    eager, state, pos = [], None, 0
+    while pos < feats.size(0):
+        nxt = min(feats.size(0), pos + cf)
+        y, _, state = enc.forward_infer(feats[None, pos:nxt], torch.tensor([nxt - pos]), state,
+                                        nxt == feats.size(0))
+        eager.append(y[0].clone())
+        pos = nxt
+    runner = StreamingStepGraph(enc, cf)
+    for rep in range(2):  # second utterance reuses the captured graph
+        got, pos = [], 0
+        runner.reset()
+        while pos < feats.size(0):
+            nxt = min(feats.size(0), pos + cf)
+            got.append(runner(feats[pos:nxt], is_final=(nxt == feats.size(0))).clone())
+            pos = nxt
+        assert runner.n_replays > 0
+        assert [t.size(0) for t in got] == [t.size(0) for t in eager]
+        for a, b in zip(got, eager):
+            assert torch.equal(a, b)
