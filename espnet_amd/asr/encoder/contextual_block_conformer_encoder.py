@@ -360,8 +360,9 @@ class StreamingStepGraph:
     `is_final` calls and any call whose chunk size differs fall back to the eager path.
     """
 
-    def __init__(self, encoder: ContextualBlockConformerEncoder, chunk_frames: int):
-        self.enc, self.chunk = encoder, chunk_frames
+    def __init__(self, encoder: ContextualBlockConformerEncoder, chunk_frames: int = 0):
+        # chunk_frames is only a hint: the graph is captured for whatever chunk size repeats
+        self.enc, self.chunk, self.last_size = encoder, chunk_frames, -1
         self.state, self.graph, self.graph_sig = None, None, None
         self.in_graph_state = False
         self.n_replays = 0
@@ -415,6 +416,9 @@ class StreamingStepGraph:
     def __call__(self, feats: torch.Tensor, is_final: bool = False):
         """feats (t, idim) f32 on the GPU.  Returns ys (t_out, d) f32 (a view of a static buffer
         when replayed: consume or clone it before the next call)."""
+        if self.graph is None and feats.size(0) == self.last_size:
+            self.chunk = feats.size(0)  # a repeating chunk size: this is the one worth capturing
+        self.last_size = feats.size(0)
         steady = (not is_final and feats.size(0) == self.chunk and self.state is not None
                   and self.state["past_encoder_ctx"] is not None
                   and self.state["buffer_after_downsampling"] is not None)

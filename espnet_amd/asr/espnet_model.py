@@ -92,7 +92,10 @@ class ESPnetASRModel(torch.nn.Module):
         feats = self.frontend.forward_device(speech, flens_dev)
         partial = None
         if self.normalize is not None:
-            partial = self.normalize.partial_sums(feats, flens_dev)
+            if hasattr(self.normalize, "partial_sums"):  # UtteranceMVN: subtraction fused into conv1
+                partial = self.normalize.partial_sums(feats, flens_dev)
+            else:  # GlobalMVN: in place
+                feats = self.normalize.forward_device(feats, flens_dev)
         enc_out, enc_act, olens, olens_dev = self.encoder.forward_device(feats, flens, flens_dev, partial)
         return EncoderState(enc_out, enc_act, olens, olens_dev, feats, flens)
 

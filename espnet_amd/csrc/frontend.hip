@@ -231,3 +231,68 @@ extern "C" int em_conv2d_sub1(int dtype, const float* feats, const float* partia
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
+
+// ---- GlobalMVN.forward (espnet2/layers/global_mvn.py:71-100): x <- (x - mean) / std on the valid
+// frames, padded frames forced to zero; in place.  mean / stdv may be NULL (norm_means / norm_vars off).
+__global__ __launch_bounds__(256) void global_mvn_kernel(float* __restrict__ x,
+                                                         const int* __restrict__ flens,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ stdv, int T_f,
+                                                         int n_mels) {
+  const int b = blockIdx.y;
+  const size_t n = (size_t)T_f * n_mels;
+  float* xb = x + (size_t)b * n;
+  const int len = flens ? flens[b] : T_f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / n_mels), c = (int)(i - (size_t)t * n_mels);
+    float v = xb[i];
+    if (mean) v -= mean[c];
+    if (t >= len) v = 0.f;
+    if (stdv) v /= stdv[c];
+    xb[i] = v;
+  }
+}
+
+extern "C" int em_global_mvn_f32(float* feats, const int32_t* flens, const float* mean,
+                                 const float* stdv, int32_t B, int32_t T_f, int32_t n_mels,
+                                 void* stream) {
+  if (!feats || B <= 0 || T_f <= 0 || n_mels <= 0) return EM_ERR_BAD_ARG;
+  int gx = (int)(((size_t)T_f * n_mels + 255) / 256);
+  gx = gx > 256 ? 256 : gx;
+  hipLaunchKernelGGL(global_mvn_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, feats, flens,
+                     mean, stdv, T_f, n_mels);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+// ---- utterance_mvn applied stand-alone (espnet2/layers/utterance_mvn.py:45-88, norm_means only):
+// padded frames are zeroed first, then the mean over the valid frames is subtracted from EVERY
+// frame (so padded frames become -mean, :73), in place.  partial from em_utt_mvn_partial_f32.
+__global__ __launch_bounds__(256) void utt_mvn_apply_kernel(float* __restrict__ x,
+                                                            const float* __restrict__ partial,
+                                                            const int* __restrict__ flens, int T_f,
+                                                            int n_mels) {
+  const int b = blockIdx.y;
+  const size_t n = (size_t)T_f * n_mels;
+  float* xb = x + (size_t)b * n;
+  const int len = flens[b];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / n_mels), c = (int)(i - (size_t)t * n_mels);
+    const float* pp = partial + (size_t)b * 8 * n_mels + c;
+    float sm = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sm += pp[q * n_mels];
+    xb[i] = (t < len ? xb[i] : 0.f) - sm / (float)len;
+  }
+}
+
+extern "C" int em_utt_mvn_apply_f32(float* feats, const float* partial, const int32_t* flens,
+                                    int32_t B, int32_t T_f, int32_t n_mels, void* stream) {
+  if (!feats || !partial || !flens || B <= 0 || T_f <= 0 || n_mels <= 0) return EM_ERR_BAD_ARG;
+  int gx = (int)(((size_t)T_f * n_mels + 255) / 256);
+  gx = gx > 256 ? 256 : gx;
+  hipLaunchKernelGGL(utt_mvn_apply_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, feats,
+                     partial, flens, T_f, n_mels);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}

@@ -27,3 +27,18 @@ class UtteranceMVN(torch.nn.Module):
                                                 L.ptr(partial), L.current_stream_ptr()),
                 "em_utt_mvn_partial_f32")
         return partial
+
+    def forward_device(self, feats: torch.Tensor, flens_dev: torch.Tensor) -> torch.Tensor:
+        """Stand-alone normalisation (the streaming frontend needs the features themselves):
+        feats (B, T_f, D) f32 on the GPU, IN PLACE like the reference (`x -= mean`, :73)."""
+        partial = self.partial_sums(feats, flens_dev)
+        B, T_f, D = feats.shape
+        L.check(L.load().em_utt_mvn_apply_f32(L.ptr(feats), L.ptr(partial), L.ptr(flens_dev), B, T_f, D,
+                                              L.current_stream_ptr()), "em_utt_mvn_apply_f32")
+        return feats
+
+    def forward(self, x: torch.Tensor, ilens: torch.Tensor = None):
+        if ilens is None:
+            ilens = x.new_full([x.size(0)], x.size(1))
+        flens_dev = ilens.to(device=x.device, dtype=torch.int32)
+        return self.forward_device(x.to(torch.float32).contiguous(), flens_dev), ilens

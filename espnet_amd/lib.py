@@ -107,6 +107,8 @@ _SIGNATURES = {
     "em_frontend_logmel_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp,
                                          _i32, _vp, _vp]),
     "em_utt_mvn_partial_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "em_utt_mvn_apply_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "em_global_mvn_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "em_conv2d_sub1": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "em_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(EmGemmArgs), _vp]),
     "em_layernorm": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),

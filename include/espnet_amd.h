@@ -98,6 +98,17 @@ int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, int32_t hop, 
 int em_utt_mvn_partial_f32(const float* feats, const int32_t* flens, int32_t B, int32_t T_f,
                            int32_t n_mels, float* partial, void* stream);
 
+/*   utterance_mvn applied stand-alone (streaming frontend): feats <- (valid ? feats : 0) - mean,
+ *   in place; partial from em_utt_mvn_partial_f32.                                              */
+int em_utt_mvn_apply_f32(float* feats, const float* partial, const int32_t* flens, int32_t B,
+                         int32_t T_f, int32_t n_mels, void* stream);
+
+/* ---- A3 (alternative): GlobalMVN.forward (espnet2/layers/global_mvn.py:71-100), in place:
+ *      feats <- (feats - mean) / stdv on frames < flens[b], 0 on padded frames.  mean / stdv [n_mels]
+ *      f32 or NULL (norm_means / norm_vars off); flens NULL = all frames valid.                   */
+int em_global_mvn_f32(float* feats, const int32_t* flens, const float* mean, const float* stdv,
+                      int32_t B, int32_t T_f, int32_t n_mels, void* stream);
+
 /* ---- A4 (first conv): Conv2dSubsampling.conv[0..1] = Conv2d(1,d,3,2)+ReLU
  *      (transformer/subsampling.py:400-403), with the MVN mean subtraction fused on the input.
  *   partial may be NULL (no mean subtraction).  w1 [d][9] f32, b1 [d] f32.

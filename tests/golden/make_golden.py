@@ -264,6 +264,51 @@ def run_streaming_case(name, enc_conf, wseed, utt_id, n_samples, chunk_frames, k
           f"total {ys.size(0)} oneshot {y1.size(0)}")
 
 
+def run_stream_frontend_case(name, utt_id, n_samples, chunk_samples, use_global_mvn):
+    """Speech2TextStreaming.apply_frontend (espnet2/bin/asr_inference_streaming.py:205-293) called
+    as an unbound function on a stub carrying the attributes it reads, with the reference
+    ESPnetASRModel (DefaultFrontend + UtteranceMVN or GlobalMVN)."""
+    import types
+
+    from espnet2.bin.asr_inference_streaming import Speech2TextStreaming
+
+    t0 = time.time()
+    conf = json.loads(json.dumps(tiny()))
+    extra = {}
+    with tempfile.TemporaryDirectory() as td:
+        if use_global_mvn:
+            g = torch.Generator().manual_seed(99)
+            count = 1000.0
+            mean = torch.randn(80, generator=g) * 2.0 - 8.0
+            var = torch.rand(80, generator=g) * 4.0 + 1.0
+            np.savez(Path(td) / "stats.npz", count=np.array(count), sum=(mean * count).numpy(),
+                     sum_square=((var + mean * mean) * count).numpy())
+            conf["normalize"] = "global_mvn"
+            conf["normalize_conf"] = dict(stats_file=str(Path(td) / "stats.npz"))
+        s2t, cfg_text = build_reference(conf, 50, td, beam_size=1, ctc_weight=1.0)
+        model = s2t.asr_model
+        if use_global_mvn:
+            extra = dict(gmvn_mean=model.normalize.mean.numpy().copy(), gmvn_std=model.normalize.std.numpy().copy())
+    fc = conf["frontend_conf"]
+    stub = types.SimpleNamespace(asr_model=model, device="cpu", dtype="float32", n_fft=fc["n_fft"],
+                                 hop_length=fc["hop_length"], win_length=fc["win_length"])
+    wav = synth_waveform(utt_id, n_samples)
+    feats, lens, state, pos = [], [], None, 0
+    while pos < n_samples:
+        nxt = min(n_samples, pos + chunk_samples)
+        f, fl, state = Speech2TextStreaming.apply_frontend(stub, wav[pos:nxt], state, is_final=(nxt == n_samples))
+        lens.append(-1 if f is None else int(f.size(1)))
+        if f is not None:
+            feats.append(f[0])
+        pos = nxt
+    out = dict(utt_id=np.array(utt_id), n_samples=np.array(n_samples), chunk_samples=np.array(chunk_samples),
+               frontend_conf=np.array(json.dumps(fc)), use_global_mvn=np.array(use_global_mvn),
+               melmat=model.frontend.logmel.melmat.numpy(), feat_lens=np.array(lens),
+               feats=torch.cat(feats, 0).numpy(), **extra)
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"[{name}] done in {time.time()-t0:.1f}s lens {lens}")
+
+
 STREAM_SMALL = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12,
                     input_layer="conv2d", normalize_before=True, activation_type="swish",
                     macaron_style=True, use_cnn_module=True, cnn_module_kernel=15, block_size=40,
@@ -309,6 +354,9 @@ CASES = {
                                                   keep_every=4),
     # tiny: every frame kept; odd chunk size exercises both carry buffers; 0.3 s = short-utterance path
     "stream_tiny_4s": lambda: run_streaming_case("stream_tiny_4s", STREAM_TINY, 18, 21, 64000, 37),
+    # Speech2TextStreaming.apply_frontend: 640 ms chunks with GlobalMVN, odd chunk size with UtteranceMVN
+    "stream_frontend_gmvn": lambda: run_stream_frontend_case("stream_frontend_gmvn", 23, 48000, 10240, True),
+    "stream_frontend_umvn": lambda: run_stream_frontend_case("stream_frontend_umvn", 24, 30000, 7001, False),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 
