@@ -142,6 +142,109 @@ def cpu_baseline_beam(model, beam, ctc_weight, budget_s=25.0):
                       f"(frontend + encoder + beam {beam} search, 249 steps), no warm-up"}
 
 
+def main_stream(args):
+    """BASELINE.json configs[4]: streaming contextual-block Conformer (aishell recipe shape: 12 x
+    256d, 4 heads, ff 2048, conv k 15, block 40 / hop 16 / look-ahead 16), one audio stream fed in
+    640 ms chunks through Speech2TextStreaming (HIP frontend -> hipGraph-captured encoder step ->
+    incremental greedy CTC).  A step = one 10 s utterance = 16 chunks."""
+    import tempfile
+
+    import yaml
+
+    from espnet_amd.bin.asr_inference_streaming import Speech2TextStreaming
+
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload stream is single-stream"
+    torch.cuda.set_device(0)
+    enc_conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12,
+                    input_layer="conv2d", normalize_before=True, activation_type="swish",
+                    macaron_style=True, use_cnn_module=True, cnn_module_kernel=15, block_size=40,
+                    hop_size=16, look_ahead=16, init_average=True, ctx_pos_enc=True)
+    cfg = dict(token_list=["<blank>", "<unk>"] + [f"t{i}" for i in range(VOCAB - 3)] + ["<sos/eos>"],
+               frontend="default", frontend_conf=dict(n_fft=512, hop_length=160, win_length=400),
+               normalize="utterance_mvn", normalize_conf={}, encoder="contextual_block_conformer",
+               encoder_conf=enc_conf, decoder="transformer",
+               decoder_conf=dict(attention_heads=4, linear_units=2048, num_blocks=6),
+               model_conf=dict(ctc_weight=0.3))
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as td:
+        (Path(td) / "config.yaml").write_text(yaml.safe_dump(cfg))
+        s2t = Speech2TextStreaming(str(Path(td) / "config.yaml"), None, device="cuda", dtype=args.dtype)
+    chunk = 10240
+    wav = synth_batch(0, 1)[0]
+    chunks = [wav[p : p + chunk] for p in range(0, N_SAMPLES, chunk)]
+
+    def step():
+        lat = []
+        for k, c in enumerate(chunks):
+            t0 = time.perf_counter()
+            out = s2t(c, is_final=(k == len(chunks) - 1))  # ends with a host read of the new tokens
+            lat.append(time.perf_counter() - t0)
+        return out, lat
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lats = []
+    for _ in range(args.steps):
+        out, lat = step()
+        lats += lat[2:-1]  # steady-state chunks (the first two only buffer, the last is final)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lats.sort()
+    res = {"metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances", "value":
+           round(AUDIO_SEC * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[4]: streaming contextual_block_conformer (12x256d, "
+                                  "block 40 / hop 16 / look-ahead 16), ONE stream, 640 ms chunks, hipGraph-"
+                                  "captured encoder step, incremental greedy CTC",
+                      "chunk_ms": 640, "chunks_per_utt": len(chunks),
+                      "chunk_latency_ms_median": round(lats[len(lats) // 2] * 1e3, 3),
+                      "chunk_latency_ms_p95": round(lats[int(len(lats) * 0.95)] * 1e3, 3),
+                      "hipgraph_replays": s2t._runner.n_replays if s2t._runner else 0,
+                      "tokens_last_utt": len(out[0][2]) if out else 0}}
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_stream(s2t.asr_model, enc_conf)
+    print(json.dumps(res), flush=True)
+
+
+def cpu_baseline_stream(model, enc_conf, budget_s=15.0):
+    from oracle import conformer as oc
+    from oracle.streaming import CBEncoderOracle
+
+    sd = {k[len("encoder."):]: v.detach().float().cpu() for k, v in model.state_dict().items()
+          if k.startswith("encoder.")}
+    mel = model.frontend.logmel.melmat.detach().float().cpu()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(32, avail))
+    torch.set_num_threads(cores)
+    orc = CBEncoderOracle(sd, enc_conf["attention_heads"], enc_conf["num_blocks"], enc_conf["block_size"],
+                          enc_conf["hop_size"], enc_conf["look_ahead"])
+    times, t_start, i = [], time.perf_counter(), 0
+    with torch.no_grad():
+        while time.perf_counter() - t_start < budget_s or len(times) < 2:
+            wav = synth_batch(9000 + i, 1)
+            t0 = time.perf_counter()
+            f, fl = oc.frontend_feats(wav, torch.tensor([N_SAMPLES]), mel, 512, 400, 160)
+            f = oc.utterance_mvn(f, fl)[0]
+            state, pos = None, 0
+            while pos < f.size(0):
+                nxt = min(f.size(0), pos + 64)
+                _, state = orc.forward_infer(f[pos:nxt], state, nxt == f.size(0))
+                pos = nxt
+            times.append(time.perf_counter() - t0)
+            i += 1
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(AUDIO_SEC / med, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"oracle CPU-fp32 port of the streaming encoder (frontend + 64-frame chunks through "
+                      f"forward_infer, no decoding), {len(times)} utterances of 10 s, median {med:.2f} s/utt"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,7 +252,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step")
     ap.add_argument("--model", default=None, choices=sorted(CONFIGS))
-    ap.add_argument("--workload", default="greedy", choices=["greedy", "beam"],
+    ap.add_argument("--workload", default="greedy", choices=["greedy", "beam", "stream"],
                     help="greedy = BASELINE.json configs[1] (the bench line); beam = configs[2]: "
                          "Conformer-large, joint CTC/attention beam 10, batch 16")
     ap.add_argument("--beam", type=int, default=10)
@@ -160,6 +263,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "stream":
+        return main_stream(args)
     if args.model is None:
         args.model = "small" if args.workload == "greedy" else "large"
     if args.batch is None:
