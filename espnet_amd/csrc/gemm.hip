@@ -466,6 +466,8 @@ int dispatch(int epi, int amode, const EmGemmArgs* p, hipStream_t s) {
 
 }  // namespace
 
+int em_gemm_skinny(int dtype, int epilogue, const EmGemmArgs* p, void* stream);  // gemm_skinny.hip
+
 extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p, void* stream) {
   if (!p || !p->A || !p->W || !p->C) return EM_ERR_BAD_ARG;
   if (p->M <= 0 || p->N <= 0 || p->K <= 0) return EM_ERR_BAD_ARG;
@@ -482,9 +484,14 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   EmProfile* prof = tl_profile;
   const bool rec = prof && prof->count < prof->capacity;
   if (rec) hipEventRecord(prof->start[prof->count], (hipStream_t)stream);
-  int rc = EM_ERR_BAD_ARG;
-  if (dtype == EM_F32) rc = dispatch<float>(epilogue, a_mode, p, (hipStream_t)stream);
-  else if (dtype == EM_BF16) rc = dispatch<bf16>(epilogue, a_mode, p, (hipStream_t)stream);
+  int rc = EM_ERR_UNSUPPORTED;
+  // very few rows (streaming encoder step, single-utterance beam): latency-bound weight streaming
+  if (a_mode == EM_A_PLAIN && p->M <= 48) rc = em_gemm_skinny(dtype, epilogue, p, stream);
+  if (rc == EM_ERR_UNSUPPORTED) {
+    rc = EM_ERR_BAD_ARG;
+    if (dtype == EM_F32) rc = dispatch<float>(epilogue, a_mode, p, (hipStream_t)stream);
+    else if (dtype == EM_BF16) rc = dispatch<bf16>(epilogue, a_mode, p, (hipStream_t)stream);
+  }
   if (rec) {
     hipEventRecord(prof->stop[prof->count], (hipStream_t)stream);
     prof->flops[prof->count] = 2.0 * (double)p->M * (double)p->N * (double)p->K;

@@ -104,9 +104,10 @@ def test_gemm_store_f32(lib, prec, M, N, K):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-def test_gemm_epilogues(lib, prec):
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128),  # tiled kernel
+                                   (5, 64, 64), (42, 256, 2048), (48, 96, 256), (160, 1536, 512)])  # skinny (M <= 48) / tiled
+def test_gemm_epilogues(lib, prec, M, N, K):
     dt, tdt = DT[prec]
-    M, N, K = 300, 256, 128
     tol = 1e-5 if prec == "f32" else 1e-2
     A, W, b = q(rnd(M, K, seed=4), tdt), q(rnd(N, K, seed=5, scale=K ** -0.5), tdt), rnd(N, seed=6)
     Ad, Wd, bd = dev(A.to(tdt)), dev(W.to(tdt)), dev(b)
