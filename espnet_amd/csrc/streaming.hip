@@ -66,58 +66,62 @@ __global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __res
   }
 }
 
-// Plain multi-head attention inside each block: one 64-thread workgroup per (head, block), thread r
-// = query slot r.  qkv [n_blk*L][3d] act (q | k | v).  mask_mode 1 = contextual mask
-// (encoder :539-544): query slot 0 attends to nothing (its output is 0), every other slot attends to
-// slots 0..L-2; mask_mode 0 = no mask (short-utterance path).
+// Plain multi-head attention inside each block: one 256-thread workgroup per (head, block); four
+// threads share a query slot, each owning DK/4 channels (partial dot products are combined with two
+// shuffles, the context accumulates per channel slice).  qkv [n_blk*L][3d] act (q | k | v).
+// mask_mode 1 = contextual mask (encoder :539-544): query slot 0 attends to nothing (its output is
+// 0), every other slot attends to slots 0..L-2; mask_mode 0 = no mask (short-utterance path).
 template <typename T, int DK>
-__global__ __launch_bounds__(64) void block_mha_kernel(const T* __restrict__ qkv, int L, int d,
-                                                       int mask_mode, T* __restrict__ ctx) {
+__global__ __launch_bounds__(256) void block_mha_kernel(const T* __restrict__ qkv, int L, int d,
+                                                        int mask_mode, T* __restrict__ ctx) {
+  constexpr int DKP = DK / 4;
   extern __shared__ float sm[];
-  float* Ks = sm;                   // [L][DK + 1]
-  float* Vs = Ks + L * (DK + 1);    // [L][DK + 1]
-  const int h = blockIdx.x, blk = blockIdx.y, r = threadIdx.x;
+  float* Ks = sm;                 // [L][DK]
+  float* Vs = Ks + L * DK;        // [L][DK]
+  float* S = Vs + L * DK;         // [64][L + 1] scaled scores
+  const int h = blockIdx.x, blk = blockIdx.y, tid = threadIdx.x;
+  const int r = tid >> 2, part = tid & 3;
   const T* base = qkv + (size_t)blk * L * 3 * d + h * DK;
-  for (int e = r; e < L * DK; e += 64) {
+  for (int e = tid; e < L * DK; e += 256) {
     const int j = e / DK, c = e - j * DK;
-    Ks[j * (DK + 1) + c] = to_f32(base[(size_t)j * 3 * d + d + c]);
-    Vs[j * (DK + 1) + c] = to_f32(base[(size_t)j * 3 * d + 2 * d + c]);
+    Ks[e] = to_f32(base[(size_t)j * 3 * d + d + c]);
+    Vs[e] = to_f32(base[(size_t)j * 3 * d + 2 * d + c]);
   }
   __syncthreads();
-  if (r >= L) return;
-  T* out = ctx + ((size_t)blk * L + r) * d + h * DK;
   const int nkeys = mask_mode ? L - 1 : L;
-  if (mask_mode && r == 0) {
-    for (int c = 0; c < DK; ++c) out[c] = from_f32<T>(0.f);
-    return;
-  }
-  float q[DK];
+  const bool active = r < L;
+  const int rq = active ? r : L - 1;
+  float q[DKP];
 #pragma unroll
-  for (int c = 0; c < DK; ++c) q[c] = to_f32(base[(size_t)r * 3 * d + c]);
+  for (int c = 0; c < DKP; ++c) q[c] = to_f32(base[(size_t)rq * 3 * d + part * DKP + c]);
   const float scale = rsqrtf((float)DK);
   float mx = -INFINITY;
   for (int j = 0; j < nkeys; ++j) {
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < DK; ++c) s = fmaf(q[c], Ks[j * (DK + 1) + c], s);
-    mx = fmaxf(mx, s * scale);
+    for (int c = 0; c < DKP; ++c) s = fmaf(q[c], Ks[j * DK + part * DKP + c], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s *= scale;
+    mx = fmaxf(mx, s);
+    if (part == 0) S[r * (L + 1) + j] = s;
   }
-  float acc[DK];
+  __syncthreads();
+  float acc[DKP];
 #pragma unroll
-  for (int c = 0; c < DK; ++c) acc[c] = 0.f;
+  for (int c = 0; c < DKP; ++c) acc[c] = 0.f;
   float sum = 0.f;
-  for (int j = 0; j < nkeys; ++j) {  // scores recomputed: cheaper than an L x L LDS table here
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < DK; ++c) s = fmaf(q[c], Ks[j * (DK + 1) + c], s);
-    const float p = expf(s * scale - mx);
+  for (int j = 0; j < nkeys; ++j) {
+    const float p = expf(S[r * (L + 1) + j] - mx);
     sum += p;
 #pragma unroll
-    for (int c = 0; c < DK; ++c) acc[c] = fmaf(p, Vs[j * (DK + 1) + c], acc[c]);
+    for (int c = 0; c < DKP; ++c) acc[c] = fmaf(p, Vs[j * DK + part * DKP + c], acc[c]);
   }
-  const float inv = 1.0f / sum;
+  if (!active) return;
+  T* out = ctx + ((size_t)blk * L + r) * d + h * DK + part * DKP;
+  const float inv = (mask_mode && r == 0) ? 0.f : 1.0f / sum;
 #pragma unroll
-  for (int c = 0; c < DK; ++c) out[c] = from_f32<T>(acc[c] * inv);
+  for (int c = 0; c < DKP; ++c) out[c] = from_f32<T>(acc[c] * inv);
 }
 
 // Context hand-over after a layer (layer :292-304), in place on x [n_blk][L][d] f32:
@@ -213,11 +217,11 @@ extern "C" int em_block_mha(int dtype, const void* qkv, int32_t n_blk, int32_t L
                             int32_t heads, int32_t mask_mode, void* ctx, void* stream) {
   if (!qkv || !ctx || n_blk <= 0 || L <= 0 || L > 64 || heads <= 0) return EM_ERR_BAD_ARG;
   const int dk = d / heads;
-  const size_t lds = (size_t)2 * L * (dk + 1) * sizeof(float);
+  const size_t lds = ((size_t)2 * L * dk + (size_t)64 * (L + 1)) * sizeof(float);
   dim3 grid(heads, n_blk);
   hipStream_t s = (hipStream_t)stream;
 #define EM_MHA_CASE(TT, DKK)                                                                   \
-  hipLaunchKernelGGL((block_mha_kernel<TT, DKK>), grid, dim3(64), lds, s, (const TT*)qkv, L, d, \
+  hipLaunchKernelGGL((block_mha_kernel<TT, DKK>), grid, dim3(256), lds, s, (const TT*)qkv, L, d, \
                      mask_mode, (TT*)ctx)
   if (dtype == EM_F32 && dk == 64) EM_MHA_CASE(float, 64);
   else if (dtype == EM_F32 && dk == 32) EM_MHA_CASE(float, 32);
