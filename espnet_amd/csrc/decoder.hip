@@ -21,12 +21,20 @@
 namespace {
 
 // x[r] = embed[tok[r]] * sqrt(d) + pe[pos]      (embedding.py:93; f32 residual stream)
+// pos_dev != NULL (hipGraph-captured search step): the position comes from device memory and
+// tok_row is then the BASE of the [pos][n] token table.
 __global__ __launch_bounds__(128) void dec_embed_kernel(const float* __restrict__ embed,
                                                         const float* __restrict__ pe,
                                                         const int* __restrict__ tok_row, int V,
-                                                        int d, int pos, float xscale,
+                                                        int d, int pos, const int* __restrict__ pos_dev,
+                                                        int pe_len, float xscale,
                                                         float* __restrict__ x) {
   const int r = blockIdx.x;
+  if (pos_dev) {
+    pos = *pos_dev;
+    if (pos >= pe_len) return;  // a replayed graph may run past the last useful step
+    tok_row += (size_t)pos * gridDim.x;
+  }
   int t = tok_row[r];
   t = t < 0 ? 0 : (t >= V ? V - 1 : t);  // rows of ended hypotheses hold stale ids
   const float* e = embed + (size_t)t * d;
@@ -73,9 +81,18 @@ constexpr int SA_MAXL = 1024;
 template <typename T, int DK>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ qkv,
                                                            T* __restrict__ kc, T* __restrict__ vc,
-                                                           const int* __restrict__ anc, int n,
+                                                           const int* __restrict__ anc,
+                                                           const int* __restrict__ anc_odd, int n,
                                                            int d, int Lmax, int pos,
+                                                           const int* __restrict__ pos_dev,
                                                            T* __restrict__ ctx) {
+  // pos_dev != NULL (hipGraph-captured search step): position from device memory; the ancestor
+  // table is double-buffered by step parity (anc at even steps, anc_odd at odd steps)
+  if (pos_dev) {
+    pos = *pos_dev;
+    if (pos >= Lmax) return;
+    if (pos & 1) anc = anc_odd;
+  }
   constexpr int NCH = DK / 8;   // lanes per position
   constexpr int NJ = 64 / NCH;  // positions per iteration
   __shared__ float p_s[SA_MAXL];
@@ -266,16 +283,17 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ 
 }
 
 template <typename T>
-int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, int n, int d, int heads,
-                     int Lmax, int pos, void* ctx, hipStream_t s) {
+int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n,
+                     int d, int heads, int Lmax, int pos, const int* pos_dev, void* ctx,
+                     hipStream_t s) {
   const int dk = d / heads;
   dim3 grid(heads, n);
   if (dk == 64)
     hipLaunchKernelGGL((dec_self_attn_kernel<T, 64>), grid, dim3(64), 0, s, (const T*)qkv, (T*)kc,
-                       (T*)vc, anc, n, d, Lmax, pos, (T*)ctx);
+                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, (T*)ctx);
   else if (dk == 32)
     hipLaunchKernelGGL((dec_self_attn_kernel<T, 32>), grid, dim3(64), 0, s, (const T*)qkv, (T*)kc,
-                       (T*)vc, anc, n, d, Lmax, pos, (T*)ctx);
+                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, (T*)ctx);
   else
     return EM_ERR_UNSUPPORTED;
   EM_CHECK_LAUNCH();
@@ -288,16 +306,25 @@ int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, c
   const int dk = d / heads;
   const size_t lds = (size_t)16 * (Tpad + 4) * 4 + 64 + (size_t)16 * (Tpad + 16 / sizeof(T)) * sizeof(T);
   dim3 grid(heads, B, em_cdiv(W, 16));
+  // (the attribute is raised once per process and size: no runtime API call on later launches,
+  //  which also keeps the launch legal inside a stream capture)
+  static size_t attr64 = 0, attr32 = 0;
   if (dk == 64) {
-    if (hipFuncSetAttribute((const void*)dec_src_attn_kernel<T, 64>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return EM_ERR_LAUNCH;
+    if (lds > attr64) {
+      if (hipFuncSetAttribute((const void*)dec_src_attn_kernel<T, 64>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return EM_ERR_LAUNCH;
+      attr64 = lds;
+    }
     hipLaunchKernelGGL((dec_src_attn_kernel<T, 64>), grid, dim3(256), lds, s, (const T*)qs,
                        (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx);
   } else if (dk == 32) {
-    if (hipFuncSetAttribute((const void*)dec_src_attn_kernel<T, 32>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return EM_ERR_LAUNCH;
+    if (lds > attr32) {
+      if (hipFuncSetAttribute((const void*)dec_src_attn_kernel<T, 32>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return EM_ERR_LAUNCH;
+      attr32 = lds;
+    }
     hipLaunchKernelGGL((dec_src_attn_kernel<T, 32>), grid, dim3(256), lds, s, (const T*)qs,
                        (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx);
   } else {
@@ -310,23 +337,24 @@ int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, c
 }  // namespace
 
 extern "C" int em_dec_embed_f32(const float* embed, const float* pe, const int32_t* tok_row,
-                                int32_t n, int32_t V, int32_t d, int32_t pos, float* x,
-                                void* stream) {
+                                int32_t n, int32_t V, int32_t d, int32_t pos,
+                                const int32_t* pos_dev, int32_t pe_len, float* x, void* stream) {
   if (n <= 0 || d <= 0 || pos < 0) return EM_ERR_BAD_ARG;
   hipLaunchKernelGGL(dec_embed_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, embed, pe,
-                     tok_row, V, d, pos, sqrtf((float)d), x);
+                     tok_row, V, d, pos, pos_dev, pe_len, sqrtf((float)d), x);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
 
 extern "C" int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc,
-                                     const int32_t* anc, int32_t n, int32_t d, int32_t heads,
-                                     int32_t Lmax, int32_t pos, void* ctx, void* stream) {
+                                     const int32_t* anc, const int32_t* anc_odd, int32_t n,
+                                     int32_t d, int32_t heads, int32_t Lmax, int32_t pos,
+                                     const int32_t* pos_dev, void* ctx, void* stream) {
   if (n <= 0 || heads <= 0 || pos < 0 || pos >= Lmax || Lmax > SA_MAXL) return EM_ERR_BAD_ARG;
   if (dtype == EM_F32)
-    return self_attn_launch<float>(qkv, kc, vc, anc, n, d, heads, Lmax, pos, ctx, (hipStream_t)stream);
+    return self_attn_launch<float>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, ctx, (hipStream_t)stream);
   if (dtype == EM_BF16)
-    return self_attn_launch<bf16>(qkv, kc, vc, anc, n, d, heads, Lmax, pos, ctx, (hipStream_t)stream);
+    return self_attn_launch<bf16>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, ctx, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
 }
 

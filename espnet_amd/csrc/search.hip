@@ -246,7 +246,9 @@ __global__ __launch_bounds__(64) void prebeam_kernel(Ctx c) {
 //   pre-beam mode  : slots 0..S-1 = cand_tok, slot S = <eos> (always scored, :186-187)
 //   all-vocab mode : slot s = token s (S == V, NC == V)
 // total = (w_dec*dec + w_len) + w_ctc*(psi - s_prev) + running score   (batch_beam_search.py:289-314)
-__global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i) {
+__global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i_host) {
+  const int i = c.b.step ? *c.b.step : i_host;
+  if (i >= c.p.Lmax - 1) return;
   const int NC = c.p.NC, V = c.p.V, S = c.p.S;
   const int lane = threadIdx.x & 63;
   const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -363,7 +365,9 @@ __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
 // walks the chain LDS -> LDS, all lanes write the result back coalesced.  Only t >= max(i,1)-1
 // is produced: a later step's recurrence starts at t = i+1 and reads r_prev[t-1].
 constexpr int CTC_TMAX = 2048;
-__global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i) {
+__global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i_host) {
+  const int i = c.b.step ? *c.b.step : i_host;
+  if (i >= c.p.Lmax - 1) return;
   __shared__ float s_xn[CTC_TMAX], s_xb[CTC_TMAX], s_phi[CTC_TMAX];
   __shared__ float2 s_out[CTC_TMAX];
   const int rnew = blockIdx.x, lane = threadIdx.x;
@@ -409,7 +413,9 @@ __global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i) {
 
 // ---- step 4: build the new rows (batch_beam_search.py:317-357 + post_process :359-423) ---------
 // one workgroup (64 threads) per utterance
-__global__ __launch_bounds__(64) void update_kernel(Ctx c, int i) {
+__global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
+  const int i = c.b.step ? *c.b.step : i_host;
+  if (i >= c.p.Lmax - 1) return;
   const int b = blockIdx.x, lane = threadIdx.x;
   const int W = c.p.W, NC = c.p.NC, V = c.p.V, Lmax = c.p.Lmax, n = c.p.B * c.p.W;
   __shared__ int s_prev_row[64], s_tok[64], s_valid[64], s_end[64];
@@ -551,6 +557,8 @@ __global__ __launch_bounds__(256) void col_logsoftmax_kernel(float* __restrict__
     }
 }
 
+__global__ void step_advance_kernel(int* step) { *step += 1; }
+
 inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
                 int N, int K, int lda, int ldc, float scale, void* stream) {
   EmGemmArgs a = {};
@@ -613,6 +621,7 @@ extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecode
   }
   hipLaunchKernelGGL(search_init_rows_kernel, dim3(em_cdiv(n, 64)), dim3(64), 0, s, c);
   hipLaunchKernelGGL(search_init_utt_kernel, dim3(em_cdiv(p->B, 64)), dim3(64), 0, s, c);
+  if (b->step) hipMemsetAsync(b->step, 0, sizeof(int32_t), s);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
@@ -621,7 +630,7 @@ extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecode
 extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
                                const EmSearchBuffers* b, int32_t i0, int32_t i1, void* stream) {
   EM_TRY(check(p, b));
-  if (i0 < 0 || i1 > p->Lmax - 1) return EM_ERR_BAD_ARG;
+  if (i0 < 0 || (!b->step && i1 > p->Lmax - 1)) return EM_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   Ctx c{*p, *b};
   const int n = p->B * p->W, V = p->V;
@@ -630,7 +639,11 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
     if (p->w_dec != 0.f) {
       const int d = dw->d, ff = dw->ff, h = dw->heads;
       const int* anc = (i & 1) ? b->anc_b : b->anc_a;
-      EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok + (size_t)i * n, n, V, d, i, b->x, stream));
+      if (b->step)
+        EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok, n, V, d, 0, b->step, p->Lmax, b->x, stream));
+      else
+        EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok + (size_t)i * n, n, V, d, i, nullptr,
+                                dw->pe_len, b->x, stream));
       for (int l = 0; l < dw->num_blocks; ++l) {
         const EmDecoderLayer& q = dw->layers[l];
         unsigned char* kc = (unsigned char*)b->self_k + (size_t)l * p->Lmax * n * d * es;
@@ -639,7 +652,12 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
         const unsigned char* vT = (const unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
         EM_TRY(em_layernorm(dtype, b->x, q.norm1_g, q.norm1_b, n, d, LN_EPS, b->xn, nullptr, stream));
         EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.self_wqkv, b->qkv, q.self_bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
-        EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, n, d, h, p->Lmax, i, b->ctx, stream));
+        if (b->step)
+          EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, b->anc_a, b->anc_b, n, d, h, p->Lmax, 0,
+                                       b->step, b->ctx, stream));
+        else
+          EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, anc, n, d, h, p->Lmax, i, nullptr,
+                                       b->ctx, stream));
         EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.self_wout, b->x, q.self_bout, n, d, d, d, d, 1.f, stream));
         EM_TRY(em_layernorm(dtype, b->x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->xn, nullptr, stream));
         EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.src_wq, b->qs, q.src_bq, n, d, d, d, d, 1.f, stream));
@@ -673,6 +691,7 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
     hipLaunchKernelGGL(select_kernel, dim3(p->B), dim3(64), 0, s, c);
     if (p->w_ctc != 0.f) hipLaunchKernelGGL(ctc_state_kernel, dim3(n), dim3(64), 0, s, c, i);
     hipLaunchKernelGGL(update_kernel, dim3(p->B), dim3(64), 0, s, c, i);
+    if (b->step) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, b->step);
     EM_CHECK_LAUNCH();
   }
   return EM_OK;

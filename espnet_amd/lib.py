@@ -92,7 +92,7 @@ SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "an
                   "alive", "run_score", "run_sdec", "run_sctc", "run_slen", "s_prev", "r_a", "r_b",
                   "cand_tok", "cand_full", "cand_psi", "cand_total", "sel_idx", "sel_total",
                   "end_count", "end_pos", "end_slot", "end_forced", "end_score", "end_sdec",
-                  "end_sctc", "end_slen", "best_all", "best_by_len", "done", "x", "xn", "qkv", "qs",
+                  "end_sctc", "end_slen", "best_all", "best_by_len", "done", "step", "x", "xn", "qkv", "qs",
                   "ctx", "hbuf", "dec_logp", "self_k", "self_v", "mem_kv", "mem_vT"]
 
 
@@ -138,9 +138,9 @@ _SIGNATURES = {
     "em_profile_attach": (None, [_vp]),
     "em_profile_read": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "em_cast_f32": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
-    "em_dec_embed_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "em_dec_self_attention": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                        _vp, _vp]),
+    "em_dec_embed_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "em_dec_self_attention": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                        _i32, _vp, _vp, _vp]),
     "em_dec_src_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                                        _i32, _i32, _vp, _vp]),
     "em_dec_transpose_v": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -25,7 +25,7 @@ from espnet_amd.nets.scorers.length_bonus import LengthBonus
 logger = logging.getLogger(__name__)
 
 _I32 = {"xlens", "maxlens", "minlens", "tok", "parent", "anc_a", "anc_b", "alive", "cand_tok",
-        "sel_idx", "end_count", "end_pos", "end_slot", "end_forced", "done"}
+        "sel_idx", "end_count", "end_pos", "end_slot", "end_forced", "done", "step"}
 _ACT = {"xn", "qkv", "qs", "ctx", "hbuf", "self_k", "self_v", "mem_kv", "mem_vT"}
 
 
@@ -64,7 +64,9 @@ class BeamSearch:
         if "decoder" not in self.scorers and "ctc" not in self.scorers:
             raise ValueError("beam search needs the decoder and/or the ctc scorer")
         self._bufs = {}
+        self._graphs = {}
         self.step_chunk = 16  # steps enqueued between two polls of the `done` flags
+        self.use_hipgraph = True  # replay a captured hipGraph of `step_chunk` search steps
 
 
 class BatchBeamSearch(BeamSearch):
@@ -74,6 +76,7 @@ class BatchBeamSearch(BeamSearch):
         if key in self._bufs:
             return self._bufs[key]
         self._bufs.clear()  # one live shape at a time
+        self._graphs.clear()  # graphs captured over the old buffers die with them
         n = B * W
         use_dec, use_ctc = "decoder" in self.scorers, "ctc" in self.scorers
         shapes = dict(
@@ -83,7 +86,7 @@ class BatchBeamSearch(BeamSearch):
             r_a=(n, T, 2) if use_ctc else (1,), r_b=(n, T, 2) if use_ctc else (1,),
             ctc_lpT=(V, B * T) if use_ctc else None,
             cand_tok=(n, NC), cand_full=(n, NC), cand_psi=(n, NC), cand_total=(n, NC),
-            sel_idx=(n,), sel_total=(n,), end_count=(B,), end_pos=(B, cap), end_slot=(B, cap),
+            sel_idx=(n,), sel_total=(n,), step=(1,), end_count=(B,), end_pos=(B, cap), end_slot=(B, cap),
             end_forced=(B, cap), end_score=(B, cap), end_sdec=(B, cap), end_sctc=(B, cap),
             end_slen=(B, cap), best_all=(B,), best_by_len=(B, Lmax + 2), done=(B,))
         if use_dec:
@@ -148,18 +151,51 @@ class BatchBeamSearch(BeamSearch):
         bs = L.EmSearchBuffers()
         for name in L.SEARCH_BUFFERS:
             setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
+        if not self.use_hipgraph:
+            bs.step = None
         dw = dec.ensure_packed(dev, Lmax)["w"] if dec is not None else None
         dwp = C.byref(dw) if dw is not None else None
         stream = L.current_stream_ptr()
-        L.check(lib.em_search_init(em_dtype, C.byref(p), dwp, C.byref(bs), L.ptr(enc_act), d,
-                                   L.ptr(ctc_pk["w"]) if ctc_pk else None,
-                                   L.ptr(ctc_pk["b"]) if ctc_pk else None, stream),
-                "em_search_init")
-        i, imax = 0, max(maxlens)
+
+        def init():
+            L.check(lib.em_search_init(em_dtype, C.byref(p), dwp, C.byref(bs), L.ptr(enc_act), d,
+                                       L.ptr(ctc_pk["w"]) if ctc_pk else None,
+                                       L.ptr(ctc_pk["b"]) if ctc_pk else None,
+                                       L.current_stream_ptr()), "em_search_init")
+
+        def steps(i0, i1):
+            L.check(lib.em_search_steps(em_dtype, C.byref(p), dwp, C.byref(bs), i0, i1,
+                                        L.current_stream_ptr()), "em_search_steps")
+
+        init()
+        imax, K = max(maxlens), self.step_chunk
+        if self.use_hipgraph:
+            # One hipGraph = K search steps (~75 launches each).  Every step-dependent kernel reads the
+            # step index from device memory, so the same graph is replayed ceil(imax / K) times; steps
+            # past the end are no-ops.  The graph is tied to the buffer set and the parameter block.
+            gkey = (id(bufs), bytes(p), em_dtype, id(dec._packed) if dec is not None else 0)
+            g = self._graphs.get(gkey)
+            if g is None:
+                steps(0, 1)  # warm-up outside capture (one-time attribute calls, lazy module loads)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    steps(0, K)
+                self._graphs[gkey] = (g, p, bs)  # keep the argument blocks alive with the graph
+                init()  # the warm-up step advanced the search state: start over
+            else:
+                g = g[0]
+            i = 0
+            while i < imax:
+                g.replay()
+                i += K
+                if i < imax and bool(bufs["done"].all().item()):
+                    break
+            return self._collect(bufs, B, W, maxlens)
+        i = 0
         while i < imax:
-            j = min(imax, i + self.step_chunk)
-            L.check(lib.em_search_steps(em_dtype, C.byref(p), dwp, C.byref(bs), i, j, stream),
-                    "em_search_steps")
+            j = min(imax, i + K)
+            steps(i, j)
             i = j
             if i < imax and bool(bufs["done"].all().item()):  # the only host sync of the search
                 break
@@ -167,28 +203,40 @@ class BatchBeamSearch(BeamSearch):
 
     # ------------------------------------------------------------------ readout (host)
     def _collect(self, bufs, B, W, maxlens) -> List[List[Hypothesis]]:
-        cpu = {k: bufs[k].cpu() for k in ("end_count", "end_pos", "end_slot", "end_forced",
-                                          "end_score", "end_sdec", "end_sctc", "end_slen", "tok",
-                                          "parent")}
+        """One D2H copy of the ended lists + token tree, then a vectorised back-trace: all ended
+        hypotheses walk their `parent` pointers together, one numpy gather per token position."""
+        import numpy as np
+
+        cpu = {k: bufs[k].cpu().numpy() for k in ("end_count", "end_pos", "end_slot", "end_forced",
+                                                  "end_score", "end_sdec", "end_sctc", "end_slen",
+                                                  "tok", "parent")}
         tok, parent = cpu["tok"], cpu["parent"]
+        counts = cpu["end_count"]
+        bi = np.repeat(np.arange(B), counts)
+        ei = np.concatenate([np.arange(c) for c in counts]) if counts.sum() else np.zeros(0, dtype=np.int64)
+        pos = cpu["end_pos"][bi, ei].astype(np.int64)
+        cur = cpu["end_slot"][bi, ei].astype(np.int64)
+        E = len(pos)
+        ys = np.full((E, tok.shape[0] + 1), -1, dtype=np.int64)
+        for j in range(int(pos.max()) if E else -1, -1, -1):
+            m = pos >= j
+            c = cur[m]
+            ys[m, j] = tok[j, c]
+            cur[m] = parent[j, c]
+        forced = cpu["end_forced"][bi, ei].astype(bool)
+        ys[np.arange(E)[forced], pos[forced] + 1] = self.eos
+        lens = pos + 1 + forced
         keys = [k for k in ("decoder", "ctc", "length_bonus") if k in self.scorers]
         col = dict(decoder="end_sdec", ctc="end_sctc", length_bonus="end_slen")
-        out = []
+        out, off = [], 0
         for b in range(B):
             hyps = []
-            for e in range(int(cpu["end_count"][b])):
-                pos, slot = int(cpu["end_pos"][b, e]), int(cpu["end_slot"][b, e])
-                ys = []
-                while pos >= 0:
-                    ys.append(int(tok[pos, slot]))
-                    slot = int(parent[pos, slot])
-                    pos -= 1
-                ys.reverse()
-                if int(cpu["end_forced"][b, e]):
-                    ys.append(self.eos)
-                hyps.append(Hypothesis(yseq=torch.tensor(ys, dtype=torch.long),
-                                       score=cpu["end_score"][b, e].clone(),
-                                       scores={k: cpu[col[k]][b, e].clone() for k in keys}))
+            for e in range(int(counts[b])):
+                k = off + e
+                hyps.append(Hypothesis(yseq=torch.from_numpy(ys[k, : lens[k]].copy()),
+                                       score=torch.tensor(cpu["end_score"][b, e]),
+                                       scores={kk: torch.tensor(cpu[col[kk]][b, e]) for kk in keys}))
+            off += int(counts[b])
             if self.normalize_length:  # beam_search.py:453-459
                 hyps.sort(key=lambda h: float(h.score) / (len(h.yseq) - 1), reverse=True)
             else:

@@ -239,13 +239,18 @@ int em_ctc_greedy(int dtype, const void* enc_act, const void* w_ctc, const float
  *      self-attention K/V live in a token-tree cache indexed through `anc`, source-attention
  *      K / V^T of the encoder memory are computed once per utterance by em_search_init.          */
 /*   x[r] = embed[tok_row[r]] * sqrt(d) + pe[pos]  (embedding.py:93);  embed [V][d], pe [>pos][d] f32 */
+/*   pos_dev != NULL: the position is read from device memory (hipGraph-captured step) and
+ *   tok_row is then the base of a [pos][n] token table; pe_len bounds the position.              */
 int em_dec_embed_f32(const float* embed, const float* pe, const int32_t* tok_row, int32_t n,
-                     int32_t V, int32_t d, int32_t pos, float* x, void* stream);
+                     int32_t V, int32_t d, int32_t pos, const int32_t* pos_dev, int32_t pe_len,
+                     float* x, void* stream);
 /*   qkv [n][3d] act (q|k|v of the token at position pos); kc,vc [Lmax][n][d] act (one layer);
  *   anc [n][Lmax] i32 slot of every prefix position; ctx [n][d] act out.  d/heads in {32, 64}.    */
+/*   pos_dev != NULL: position from device memory; anc is then used at even and anc_odd at odd
+ *   positions (the search double-buffers the table by step parity).                              */
 int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc, const int32_t* anc,
-                          int32_t n, int32_t d, int32_t heads, int32_t Lmax, int32_t pos,
-                          void* ctx, void* stream);
+                          const int32_t* anc_odd, int32_t n, int32_t d, int32_t heads, int32_t Lmax,
+                          int32_t pos, const int32_t* pos_dev, void* ctx, void* stream);
 /*   qs [B*W][d] act; kmem: K rows of utterance b at kmem + (b*T + t)*ldk; vT [B][d][Tpad] act
  *   (zero padded, Tpad % 32 == 0); klens [B] valid memory frames; ctx [B*W][d] act out.           */
 int em_dec_src_attention(int dtype, const void* qs, const void* kmem, int32_t ldk, const void* vT,
@@ -319,6 +324,10 @@ typedef struct EmSearchBuffers {
   float *end_score, *end_sdec, *end_sctc, *end_slen; /* [B][end_cap] */
   float *best_all, *best_by_len;            /* [B], [B][Lmax+2] end-detection statistics */
   int32_t* done;                            /* [B] */
+  int32_t* step;                            /* device step counter, or NULL.  Non-NULL = graph mode: every
+                                               step kernel reads the step index from here (kernel
+                                               arguments are frozen in a captured hipGraph) and
+                                               em_search_steps advances it after each step */
   float* x;                                 /* [n][d] f32 decoder residual stream */
   void *xn, *qkv, *qs, *ctx, *hbuf;         /* act: [n][d], [n][3d], [n][d], [n][d], [n][ff] */
   float* dec_logp;                          /* [n][V] */
@@ -335,7 +344,9 @@ int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* d
                    const EmSearchBuffers* b, const void* enc_act, int32_t d_model,
                    const void* ctc_w, const float* ctc_b, void* stream);
 /*   Enqueues search steps i0 .. i1-1 (decoder step, pre-beam, CTC prefix scores, top-W, update).
- *   Utterances whose `done` flag is set are skipped; the host polls `done` between calls.        */
+ *   Utterances whose `done` flag is set are skipped; the host polls `done` between calls.
+ *   With b->step set, i1 - i0 steps are enqueued starting at the device counter's value, so the
+ *   call can be captured once into a hipGraph and replayed; steps past Lmax - 2 are no-ops.      */
 int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
                     const EmSearchBuffers* b, int32_t i0, int32_t i1, void* stream);
 
