@@ -409,9 +409,16 @@ def main():
         lib.em_profile_destroy(prof)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        # HBM traffic of the same kernel family from rocprofv3 PMC passes of this command
+        # (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 read correction applied; see
+        # profiles/r01_pmc_gemm_traffic.json).  Only quoted for the workload it was measured on.
+        traffic = None
+        tj = REPO / "profiles" / "r01_pmc_gemm_traffic.json"
+        if tj.exists() and beam_search is None and args.model == "small" and B == 32 and args.dtype == "bfloat16":
+            traffic = json.loads(tj.read_text())["gemm_family"]["hbm_bytes_per_launch"]
         out["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic,
             "kernel": "gemm_kernel<T,EPI,AMODE> (all instantiations)",
             "launches_per_step": launches // nprof,
             "avg_launch_us": round(tot_ms * 1e3 / launches, 2),
