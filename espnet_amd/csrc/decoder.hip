@@ -71,15 +71,34 @@ __device__ __forceinline__ void store8<float>(float* __restrict__ p, const float
   *(float4*)(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
 }
 
-// One wave per (hypothesis row, head).  qkv [n][3d] (q | k | v of the token at position `pos`);
-// kc/vc [Lmax][n][d] (this layer); anc [n][Lmax].  ctx [n][d].
+// 8 consecutive elements kept in their storage form (16 B for bf16, 32 B for f32) so that many
+// row loads can be in flight without spending 8 VGPRs each on converted floats.
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16* p) { v = *(const bf16x8*)p; }
+  __device__ __forceinline__ float at(int e) const { return (float)v[e]; }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+  __device__ __forceinline__ float at(int e) const {
+    return e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : e == 3 ? a.w : e == 4 ? b.x : e == 5 ? b.y : e == 6 ? b.z : b.w;
+  }
+};
+
+// One wave per (hypothesis row, head); the `group` rows of one utterance (its beam) share a
+// workgroup: hypotheses of a beam share almost all of their ancestors, so the same K/V cache rows
+// are requested by the waves of one CU (L1 / one L2) instead of by up to `group` CUs on 8 XCDs.
+// qkv [n][3d] (q | k | v of the token at position `pos`); kc/vc [Lmax][n][d] (this layer);
+// anc [n][Lmax].  ctx [n][d].
 // Lane = (position sub-index jsub, 8-channel chunk ch): one wave-wide load instruction covers
 // NJ = 64/(DK/8) prefix positions x the whole head (16-byte loads for bf16), so a 250-token prefix
 // is 32 iterations for QK^T and 32 for PV; partial dots are reduced across the chunk lanes,
 // partial contexts across the position lanes.
 constexpr int SA_MAXL = 1024;
 template <typename T, int DK>
-__global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ qkv,
+__global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict__ qkv,
                                                            T* __restrict__ kc, T* __restrict__ vc,
                                                            const int* __restrict__ anc,
                                                            const int* __restrict__ anc_odd, int n,
@@ -95,15 +114,20 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
   }
   constexpr int NCH = DK / 8;   // lanes per position
   constexpr int NJ = 64 / NCH;  // positions per iteration
-  __shared__ float p_s[SA_MAXL];
-  __shared__ int a_s[SA_MAXL];
-  const int h = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+  extern __shared__ float sa_lds[];  // per wave: Lmax scores + Lmax ancestor slots
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* p_s = sa_lds + (size_t)wave * 2 * Lmax;
+  int* a_s = (int*)(p_s + Lmax);
+  const int h = blockIdx.x;
+  int r = blockIdx.y * (blockDim.x >> 6) + wave;
+  const bool live = r < n;  // the last group may be partial; keep every wave in the barriers
+  r = live ? r : n - 1;
   const int ch = lane % NCH, jsub = lane / NCH;
   const T* row = qkv + (size_t)r * 3 * d + h * DK;
   float q[8];
   load8<T>(row + ch * 8, q);
   // append this position's K/V to the cache (read back by later steps only)
-  if (lane < NCH) {
+  if (lane < NCH && live) {
     const size_t o = ((size_t)pos * n + r) * d + h * DK + lane * 8;
     float t8[8];
     load8<T>(row + d + lane * 8, t8);
@@ -117,23 +141,26 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
   for (int j = lane; j < pos; j += 64) a_s[j] = anc[(size_t)r * Lmax + j];
   __syncthreads();
   const int niter = (pos + NJ) / NJ;  // ceil((pos+1)/NJ)
-  for (int it0 = 0; it0 < niter; it0 += 4) {
-    float k8[4][8];
+  // The gathers are latency-bound (one 128-byte row per position, scattered over the cache): keep
+  // UN row loads per lane in flight before the first use.
+  constexpr int UN = sizeof(T) == 2 ? 8 : 4;
+  for (int it0 = 0; it0 < niter; it0 += UN) {
+    Raw8<T> k8[UN];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {  // issue the (up to) four row loads first
+    for (int u = 0; u < UN; ++u) {
       const int j = (it0 + u) * NJ + jsub;
       if (j <= pos) {
         const T* kr = (j == pos) ? row + d : kc + ((size_t)j * n + a_s[j]) * d + h * DK;
-        load8<T>(kr + ch * 8, k8[u]);
+        k8[u].load(kr + ch * 8);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int j = (it0 + u) * NJ + jsub;
       float dot = 0.f;
       if (j <= pos) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dot = fmaf(q[e], k8[u][e], dot);
+        for (int e = 0; e < 8; ++e) dot = fmaf(q[e], k8[u].at(e), dot);
       }
 #pragma unroll
       for (int o = 1; o < NCH; o <<= 1) dot += __shfl_xor(dot, o, 64);
@@ -153,23 +180,23 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
   sum = wave_sum(sum);
   __syncthreads();
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int it0 = 0; it0 < niter; it0 += 4) {
-    float v8[4][8];
+  for (int it0 = 0; it0 < niter; it0 += UN) {
+    Raw8<T> v8[UN];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int j = (it0 + u) * NJ + jsub;
       if (j <= pos) {
         const T* vr = (j == pos) ? row + 2 * d : vc + ((size_t)j * n + a_s[j]) * d + h * DK;
-        load8<T>(vr + ch * 8, v8[u]);
+        v8[u].load(vr + ch * 8);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int j = (it0 + u) * NJ + jsub;
       if (j <= pos) {
         const float p = p_s[j];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v8[u][e], acc[e]);
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v8[u].at(e), acc[e]);
       }
     }
   }
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
   for (int o = NCH; o < 64; o <<= 1)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-  if (lane < NCH) {
+  if (lane < NCH && live) {
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] *= inv;
@@ -284,15 +311,18 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ 
 
 template <typename T>
 int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n,
-                     int d, int heads, int Lmax, int pos, const int* pos_dev, void* ctx,
+                     int d, int heads, int Lmax, int pos, const int* pos_dev, int group, void* ctx,
                      hipStream_t s) {
   const int dk = d / heads;
-  dim3 grid(heads, n);
+  group = group < 1 ? 1 : (group > 16 ? 16 : group);
+  while (group > 1 && (size_t)group * 2 * Lmax * sizeof(float) > 64 * 1024) --group;  // default LDS limit
+  dim3 grid(heads, em_cdiv(n, group)), block(64 * group);
+  const size_t lds = (size_t)group * 2 * Lmax * sizeof(float);
   if (dk == 64)
-    hipLaunchKernelGGL((dec_self_attn_kernel<T, 64>), grid, dim3(64), 0, s, (const T*)qkv, (T*)kc,
+    hipLaunchKernelGGL((dec_self_attn_kernel<T, 64>), grid, block, lds, s, (const T*)qkv, (T*)kc,
                        (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, (T*)ctx);
   else if (dk == 32)
-    hipLaunchKernelGGL((dec_self_attn_kernel<T, 32>), grid, dim3(64), 0, s, (const T*)qkv, (T*)kc,
+    hipLaunchKernelGGL((dec_self_attn_kernel<T, 32>), grid, block, lds, s, (const T*)qkv, (T*)kc,
                        (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, (T*)ctx);
   else
     return EM_ERR_UNSUPPORTED;
@@ -349,12 +379,13 @@ extern "C" int em_dec_embed_f32(const float* embed, const float* pe, const int32
 extern "C" int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc,
                                      const int32_t* anc, const int32_t* anc_odd, int32_t n,
                                      int32_t d, int32_t heads, int32_t Lmax, int32_t pos,
-                                     const int32_t* pos_dev, void* ctx, void* stream) {
+                                     const int32_t* pos_dev, int32_t group, void* ctx,
+                                     void* stream) {
   if (n <= 0 || heads <= 0 || pos < 0 || pos >= Lmax || Lmax > SA_MAXL) return EM_ERR_BAD_ARG;
   if (dtype == EM_F32)
-    return self_attn_launch<float>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, ctx, (hipStream_t)stream);
+    return self_attn_launch<float>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, group, ctx, (hipStream_t)stream);
   if (dtype == EM_BF16)
-    return self_attn_launch<bf16>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, ctx, (hipStream_t)stream);
+    return self_attn_launch<bf16>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, group, ctx, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
 }
 

@@ -654,10 +654,10 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
         EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.self_wqkv, b->qkv, q.self_bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
         if (b->step)
           EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, b->anc_a, b->anc_b, n, d, h, p->Lmax, 0,
-                                       b->step, b->ctx, stream));
+                                       b->step, (p->W + 1) / 2, b->ctx, stream));
         else
           EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, anc, n, d, h, p->Lmax, i, nullptr,
-                                       b->ctx, stream));
+                                       (p->W + 1) / 2, b->ctx, stream));
         EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.self_wout, b->x, q.self_bout, n, d, d, d, d, 1.f, stream));
         EM_TRY(em_layernorm(dtype, b->x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->xn, nullptr, stream));
         EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.src_wq, b->qs, q.src_bq, n, d, d, d, d, 1.f, stream));

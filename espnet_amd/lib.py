@@ -140,7 +140,7 @@ _SIGNATURES = {
     "em_cast_f32": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
     "em_dec_embed_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "em_dec_self_attention": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
-                                        _i32, _vp, _vp, _vp]),
+                                        _i32, _vp, _i32, _vp, _vp]),
     "em_dec_src_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                                        _i32, _i32, _vp, _vp]),
     "em_dec_transpose_v": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -247,10 +247,11 @@ int em_dec_embed_f32(const float* embed, const float* pe, const int32_t* tok_row
 /*   qkv [n][3d] act (q|k|v of the token at position pos); kc,vc [Lmax][n][d] act (one layer);
  *   anc [n][Lmax] i32 slot of every prefix position; ctx [n][d] act out.  d/heads in {32, 64}.    */
 /*   pos_dev != NULL: position from device memory; anc is then used at even and anc_odd at odd
- *   positions (the search double-buffers the table by step parity).                              */
+ *   positions (the search double-buffers the table by step parity).  group (1..16) consecutive rows
+ *   share a workgroup (the beam of one utterance: shared ancestors hit the same cache).          */
 int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc, const int32_t* anc,
                           const int32_t* anc_odd, int32_t n, int32_t d, int32_t heads, int32_t Lmax,
-                          int32_t pos, const int32_t* pos_dev, void* ctx, void* stream);
+                          int32_t pos, const int32_t* pos_dev, int32_t group, void* ctx, void* stream);
 /*   qs [B*W][d] act; kmem: K rows of utterance b at kmem + (b*T + t)*ldk; vT [B][d][Tpad] act
  *   (zero padded, Tpad % 32 == 0); klens [B] valid memory frames; ctx [B*W][d] act out.           */
 int em_dec_src_attention(int dtype, const void* qs, const void* kmem, int32_t ldk, const void* vT,

@@ -204,7 +204,7 @@ def test_dec_self_attention(lib, prec, heads, d):
     ctx = torch.empty(n, d, dtype=dt, device="cuda")
     kc0, vc0 = kc.clone(), vc.clone()
     L.check(lib.em_dec_self_attention(em, L.ptr(qkv), L.ptr(kc), L.ptr(vc), L.ptr(anc), L.ptr(anc), n,
-                                      d, heads, Lmax, pos, None, L.ptr(ctx), None), "self_attn")
+                                      d, heads, Lmax, pos, None, 3, L.ptr(ctx), None), "self_attn")
     torch.cuda.synchronize()
     q, k_new, v_new = qkv.float().split(d, dim=1)
     ref = torch.empty(n, d)
