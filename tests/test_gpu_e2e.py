@@ -15,7 +15,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import golden_speech, golden_state_dict, load_golden
+from oracle import conformer as oc
+from tests.helpers import golden_speech, golden_state_dict, hparams, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -104,3 +105,44 @@ def test_cpu_tensor_fails_loudly():
     model = build(g, "float32")
     with pytest.raises(EspnetAmdError):
         model.encode_device(torch.zeros(1, 16000), [16000])
+
+
+def test_long_and_ragged_utterances_f32():
+    """Sizes beyond the fixtures: a 30 s utterance (T = 749 encoder frames: several attention key
+    tiles, rel-pos window > 256) batched with a 12.3 s one; f32 encoder vs the oracle, and the
+    greedy tokens bit-exact wherever the oracle's own top-2 margin is not round-off."""
+    import yaml
+
+    from espnet_amd.tasks.asr import ASRTask
+    from oracle.weights import synth_waveform
+
+    g = load_golden("small_10s")
+    sd = golden_state_dict(g)
+    cfg = dict(g["config"])
+    cfg["compute_dtype"] = "float32"
+    model = ASRTask.build_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda().eval()
+    lens = [480000, 196800]
+    speech = torch.zeros(2, max(lens))
+    for i, n in enumerate(lens):
+        speech[i, :n] = synth_waveform(40 + i, n)
+    hp = hparams(g)
+    with torch.no_grad():
+        ref_enc, ref_olens = oc.encode(sd, speech, torch.tensor(lens), hp["heads"], hp["num_blocks"],
+                                       hp["n_fft"], hp["win_length"], hp["hop"])
+        ref_logp = oc.ctc_log_softmax(sd, ref_enc)
+    st = model.encode_device(speech.cuda(), lens)
+    assert st.olens == ref_olens.tolist() and st.olens[0] == 749
+    for b in range(2):
+        err = (st.enc_out[b, : st.olens[b]].cpu() - ref_enc[b, : st.olens[b]]).abs().max().item()
+        assert err < 2e-3, (b, err)
+    ids, tokens, tlens = model.greedy_ctc_device(st)
+    top2 = ref_logp.topk(2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1])
+    ref_ids = ref_logp.argmax(-1)
+    for b in range(2):
+        n = st.olens[b]
+        diff = ids[b, :n].cpu().long() != ref_ids[b, :n]
+        assert (margin[b, :n][diff] < 1e-4).all()
+        assert diff.float().mean().item() < 0.01
