@@ -292,8 +292,13 @@ def main():
     wav = synth_batch(rank * B, B).to(dev)
     lens = [N_SAMPLES] * B
     T = model.encoder.output_frames(1 + N_SAMPLES // 160)
-    gathered_tok = torch.empty(world * B, T, dtype=torch.int32, device=dev) if world > 1 else None
-    gathered_len = torch.empty(world * B, dtype=torch.int32, device=dev) if world > 1 else None
+    # hypotheses are collated with ONE fixed-shape all-gather per step: (B, T + 1) int32 records,
+    # token ids padded with -1 and the token count in the last column
+    gathered = torch.empty(world * B, T + 1, dtype=torch.int32, device=dev) if world > 1 else None
+
+    def collate(tokens, tlens):
+        rec = torch.cat([tokens, tlens.view(-1, 1)], dim=1).contiguous()
+        dist.all_gather_into_tensor(gathered, rec)
 
     beam_search = None
     if args.workload == "beam":
@@ -324,8 +329,7 @@ def main():
         if streams and beam_search is None:
             tokens, tlens = step_multistream()
             if world > 1:
-                dist.all_gather_into_tensor(gathered_tok, tokens)
-                dist.all_gather_into_tensor(gathered_len, tlens)
+                collate(tokens, tlens)
             return tokens, tlens
         st = model.encode_device(wav, lens)
         if beam_search is None:
@@ -341,8 +345,7 @@ def main():
             tokens = tokens.to(dev)
             tlens = torch.tensor(tl, dtype=torch.int32, device=dev)
         if world > 1:  # collate hypotheses: one RCCL all-gather of fixed-shape ids + lengths
-            dist.all_gather_into_tensor(gathered_tok, tokens)
-            dist.all_gather_into_tensor(gathered_len, tlens)
+            collate(tokens, tlens)
         return tokens, tlens
 
     def barrier():

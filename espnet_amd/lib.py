@@ -168,6 +168,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own libamdhip64; it must be the HIP runtime this library binds to (streams
+    # and device pointers come from torch).  Importing torch first makes the dynamic linker resolve
+    # our DT_NEEDED libamdhip64 to the copy torch already loaded instead of a second runtime.
+    import torch  # noqa: F401
+
     path = library_path()
     if not path.exists():
         raise EspnetAmdError(
