@@ -213,6 +213,64 @@ def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weigh
           f"best len={len(results[0][3].yseq)} score={float(results[0][3].score):.4f} keys={keys}")
 
 
+def run_lm_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weight, lm_weight, nbest,
+                       lm_conf):
+    """Speech2Text with a TransformerLM scorer (espnet2/bin/asr_inference.py:179-191, weight
+    `lm_weight`; espnet2/lm/transformer_lm.py batch_score).  The LM config comes from an
+    LMTask --dry_run (espnet2/tasks/lm.py), weights from the shared recipe (key prefix "lm.")."""
+    from espnet2.bin.asr_inference import Speech2Text
+    from espnet2.tasks.asr import ASRTask
+    from espnet2.tasks.lm import LMTask
+
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        tok = td / "tokens.txt"
+        tok.write_text("\n".join(token_list(vocab)) + "\n")
+        (td / "train.yaml").write_text(yaml.safe_dump(conf))
+        ASRTask.main(cmd=["--dry_run", "true", "--output_dir", str(td / "asr"), "--token_list", str(tok),
+                          "--token_type", "word", "--config", str(td / "train.yaml")])
+        (td / "lm.yaml").write_text(yaml.safe_dump(dict(lm="transformer", lm_conf=lm_conf)))
+        LMTask.main(cmd=["--dry_run", "true", "--output_dir", str(td / "lm"), "--token_list", str(tok),
+                         "--token_type", "word", "--config", str(td / "lm.yaml")])
+        s2t = Speech2Text(asr_train_config=str(td / "asr" / "config.yaml"), asr_model_file=None,
+                          lm_train_config=str(td / "lm" / "config.yaml"), lm_file=None, device="cpu",
+                          dtype="float32", beam_size=beam, ctc_weight=ctc_weight, lm_weight=lm_weight,
+                          nbest=nbest, penalty=0.0, maxlenratio=0.0, minlenratio=0.0)
+        cfg_text = (td / "asr" / "config.yaml").read_text()
+    model = s2t.asr_model
+    shapes = load_recipe(model, wseed)
+    lm = s2t.beam_search.scorers["lm"]
+    lm_shapes = {k: tuple(v.shape) for k, v in lm.state_dict().items()}
+    lm_sd = recipe_state_dict({"lm." + k: v for k, v in lm_shapes.items()}, wseed, skip=())
+    lm.load_state_dict({k[3:]: v for k, v in lm_sd.items()}, strict=True)
+    lm.eval()
+    wav = synth_waveform(utt_id, n_samples)
+    enc, olens = model.encode(wav[None], torch.tensor([n_samples]))
+    results = s2t(wav.numpy())
+    L = max(len(h.yseq) for _, _, _, h in results)
+    yseq = np.full((len(results), L), -1, dtype=np.int64)
+    for i, (_, _, _, h) in enumerate(results):
+        yseq[i, : len(h.yseq)] = h.yseq.numpy()
+    keys = sorted(results[0][3].scores.keys())
+    out = dict(config_yaml=np.array(cfg_text), vocab=np.array(vocab), wseed=np.array(wseed),
+               utt_id=np.array(utt_id), n_samples=np.array(n_samples), beam=np.array(beam),
+               ctc_weight=np.array(ctc_weight), lm_weight=np.array(lm_weight), nbest=np.array(nbest),
+               lm_conf=np.array(json.dumps(lm_conf)),
+               state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+               lm_state_shapes=np.array(json.dumps({k: list(v) for k, v in lm_shapes.items()})),
+               melmat=model.frontend.logmel.melmat.numpy(), enc_out=enc[0].numpy().copy(),
+               enc_keep_every=np.array(1), yseq=yseq,
+               yseq_lens=np.array([len(h.yseq) for _, _, _, h in results]),
+               score=np.array([float(h.score) for _, _, _, h in results]),
+               score_keys=np.array(json.dumps(keys)),
+               scores=np.array([[float(h.scores[k]) for k in keys] for _, _, _, h in results]),
+               token_int_best=np.array(results[0][2], dtype=np.int64))
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"[{name}] done in {time.time()-t0:.1f}s T={enc.shape[1]} best len={len(results[0][3].yseq)} "
+          f"score={float(results[0][3].score):.4f} keys={keys}")
+
+
 def stream_feats(utt_id, n_samples):
     """Deterministic encoder input for the streaming fixtures: log-mel of the synthetic waveform
     (oracle frontend, itself pinned against the reference) minus its per-utterance mean."""
@@ -357,6 +415,13 @@ CASES = {
     # Speech2TextStreaming.apply_frontend: 640 ms chunks with GlobalMVN, odd chunk size with UtteranceMVN
     "stream_frontend_gmvn": lambda: run_stream_frontend_case("stream_frontend_gmvn", 23, 48000, 10240, True),
     "stream_frontend_umvn": lambda: run_stream_frontend_case("stream_frontend_umvn", 24, 30000, 7001, False),
+    # LM scorer fusion: joint CTC/attention + TransformerLM, lm_weight 0.6
+    "tiny_beam5_lm": lambda: run_lm_search_case(
+        "tiny_beam5_lm", tiny(d=64, heads=2, ff=128), 50, 7, 14, 24000, 5, 0.3, 0.6, 5,
+        dict(pos_enc=None, embed_unit=32, att_unit=64, head=2, unit=128, layer=2)),
+    "tiny_beam4_lm_posenc": lambda: run_lm_search_case(
+        "tiny_beam4_lm_posenc", tiny(d=64, heads=2, ff=128), 50, 7, 15, 24000, 4, 0.5, 1.0, 4,
+        dict(pos_enc="sinusoidal", embed_unit=64, att_unit=128, head=2, unit=128, layer=1)),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

@@ -187,3 +187,31 @@ def test_streaming_encoder_oracle_matches_reference(name):
     np.testing.assert_allclose(ys[::ke].numpy(), g["ys"], atol=2e-4, rtol=0)
     y1, _ = orc.forward_infer(feats, None, True)
     np.testing.assert_allclose(y1[::ke].numpy(), g["ys_oneshot"], atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc"])
+def test_beam_search_with_lm_scorer_matches_reference(name):
+    """TransformerLM as a full scorer (lm_weight) — oracle vs reference n-best."""
+    import json
+
+    from oracle import beam_search as ob
+    from oracle.weights import recipe_state_dict
+
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    lm_shapes = {"lm." + k: tuple(v) for k, v in json.loads(str(g["lm_state_shapes"])).items()}
+    sd.update(recipe_state_dict(lm_shapes, int(g["wseed"]), skip=()))
+    hp = hparams(g)
+    speech, lens = golden_speech(g)
+    enc, _ = oc.encode(sd, speech, lens, hp["heads"], hp["num_blocks"], hp["n_fft"], hp["win_length"], hp["hop"])
+    V = int(g["vocab"])
+    dc = g["config"]["decoder_conf"]
+    res = ob.beam_search(sd, enc[0], dc["attention_heads"], dc["num_blocks"], int(g["beam"]),
+                         float(g["ctc_weight"]), sos=V - 1, eos=V - 1, lm_weight=float(g["lm_weight"]),
+                         lm_conf=json.loads(str(g["lm_conf"])))
+    keys = json.loads(str(g["score_keys"]))
+    for k in range(len(g["yseq_lens"])):
+        assert res[k]["yseq"] == g["yseq"][k, : g["yseq_lens"][k]].tolist()
+        assert abs(res[k]["score"] - float(g["score"][k])) < 1e-4 + 1e-5 * abs(float(g["score"][k]))
+        for j, kk in enumerate(keys):
+            assert abs(res[k]["scores"][kk] - float(g["scores"][k, j])) < 1e-3
