@@ -41,8 +41,9 @@ class Speech2Text:
         for k, v in unsupported.items():
             if v not in (None, False, {}, [], 0.99, 5, -1, ["Linear"], "qint8"):
                 raise NotImplementedError(f"Speech2Text({k}={v!r}) is outside the MI355X hot path")
-        if transducer_conf is not None or lm_file is not None or ngram_file is not None or streaming:
-            raise NotImplementedError("transducer / LM / n-gram / streaming scorers: SURVEY.md §8(f) 'next' rows")
+        if transducer_conf is not None or ngram_file is not None or streaming:
+            raise NotImplementedError("transducer / n-gram scorers and streaming=True (use Speech2TextStreaming): "
+                                      "SURVEY.md §8(f) 'next' rows")
         if not str(device).startswith("cuda"):
             raise RuntimeError("espnet_amd.Speech2Text runs on an MI355X only (device='cuda'); no CPU fallback")
         # the reference's `dtype` is the model dtype; here it selects the MFMA mode
@@ -69,10 +70,17 @@ class Speech2Text:
         if not ctc_greedy:
             from espnet_amd.nets.batch_beam_search import build_beam_search
 
+            lm = None
+            if lm_train_config is not None:  # asr_inference.py:179-191
+                from espnet_amd.tasks.lm import LMTask
+
+                lm_model, _ = LMTask.build_model_from_file(lm_train_config, lm_file, device, compute_dtype=dtype)
+                lm = lm_model.lm
+            self.lm = lm
             self.beam_search = build_beam_search(
                 asr_model, beam_size=beam_size, ctc_weight=ctc_weight, penalty=penalty,
-                lm_weight=0.0 if lm_file is None else lm_weight, token_list=token_list,
-                normalize_length=normalize_length)
+                lm_weight=lm_weight if lm is not None else 0.0, token_list=token_list,
+                normalize_length=normalize_length, lm=lm)
 
     # ------------------------------------------------------------------ single utterance (reference API)
     @torch.no_grad()

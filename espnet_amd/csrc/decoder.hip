@@ -104,7 +104,10 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
                                                            const int* __restrict__ anc_odd, int n,
                                                            int d, int Lmax, int pos,
                                                            const int* __restrict__ pos_dev,
+                                                           const int* __restrict__ tok_tab,
                                                            T* __restrict__ ctx) {
+  // tok_tab != NULL ([Lmax][n] token table): keys whose token id is 0 are masked
+  // (TransformerLM._target_mask, espnet2/lm/transformer_lm.py:54-57).
   // pos_dev != NULL (hipGraph-captured search step): position from device memory; the ancestor
   // table is double-buffered by step parity (anc at even steps, anc_odd at odd steps)
   if (pos_dev) {
@@ -164,7 +167,10 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
       }
 #pragma unroll
       for (int o = 1; o < NCH; o <<= 1) dot += __shfl_xor(dot, o, 64);
-      if (ch == 0 && j <= pos) p_s[j] = dot * scale;
+      if (ch == 0 && j <= pos) {
+        const bool masked = tok_tab && tok_tab[(size_t)j * n + (j == pos ? r : a_s[j])] == 0;
+        p_s[j] = masked ? -INFINITY : dot * scale;
+      }
     }
   }
   __syncthreads();
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
   mx = wave_max(mx);
   float sum = 0.f;
   for (int j = lane; j <= pos; j += 64) {
-    const float p = expf(p_s[j] - mx);
+    const float p = mx > -INFINITY ? expf(p_s[j] - mx) : 0.f;  // all keys masked -> zeros
     p_s[j] = p;
     sum += p;
   }
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   if (lane < NCH && live) {
-    const float inv = 1.0f / sum;
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] *= inv;
     store8<T>(ctx + (size_t)r * d + h * DK + lane * 8, acc);
@@ -309,10 +315,61 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const T* __restrict__ 
   }
 }
 
+// TransformerLM input: e[r] = embed[tok[r]] in the act dtype (the A operand of the input Linear).
+template <typename T>
+__global__ __launch_bounds__(128) void lm_embed_kernel(const float* __restrict__ embed,
+                                                       const int* __restrict__ tok_row, int V, int eu,
+                                                       const int* __restrict__ pos_dev, int Lmax,
+                                                       T* __restrict__ e) {
+  const int r = blockIdx.x;
+  if (pos_dev) {
+    const int pos = *pos_dev;
+    if (pos >= Lmax) return;
+    tok_row += (size_t)pos * gridDim.x;
+  }
+  int t = tok_row[r];
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+  for (int c = threadIdx.x; c < eu; c += blockDim.x) e[(size_t)r * eu + c] = from_f32<T>(embed[(size_t)t * eu + c]);
+}
+
+// TransformerLM input layer tail (legacy/nets/pytorch_backend/transformer/encoder.py:132-139) on
+// x [n][d] f32 in place: torch.nn.LayerNorm(eps 1e-5) -> ReLU -> optional PositionalEncoding
+// (x * sqrt(d) + pe[pos]).  One wave per row.
+__global__ __launch_bounds__(256) void lm_input_norm_kernel(float* __restrict__ x,
+                                                            const float* __restrict__ g,
+                                                            const float* __restrict__ b,
+                                                            const float* __restrict__ pe, int n, int d,
+                                                            int pos, const int* __restrict__ pos_dev,
+                                                            int Lmax) {
+  if (pos_dev) {
+    pos = *pos_dev;
+    if (pos >= Lmax) return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float* xr = x + (size_t)row * d;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float t = xr[c] - mean;
+    q += t * t;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+  const float xs = sqrtf((float)d);
+  for (int c = lane; c < d; c += 64) {
+    float v = fmaxf((xr[c] - mean) * rstd * g[c] + b[c], 0.f);
+    if (pe) v = v * xs + pe[(size_t)pos * d + c];
+    xr[c] = v;
+  }
+}
+
 template <typename T>
 int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n,
-                     int d, int heads, int Lmax, int pos, const int* pos_dev, int group, void* ctx,
-                     hipStream_t s) {
+                     int d, int heads, int Lmax, int pos, const int* pos_dev, int group,
+                     const int* tok_tab, void* ctx, hipStream_t s) {
   const int dk = d / heads;
   group = group < 1 ? 1 : (group > 16 ? 16 : group);
   while (group > 1 && (size_t)group * 2 * Lmax * sizeof(float) > 64 * 1024) --group;  // default LDS limit
@@ -320,10 +377,10 @@ int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const 
   const size_t lds = (size_t)group * 2 * Lmax * sizeof(float);
   if (dk == 64)
     hipLaunchKernelGGL((dec_self_attn_kernel<T, 64>), grid, block, lds, s, (const T*)qkv, (T*)kc,
-                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, (T*)ctx);
+                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, tok_tab, (T*)ctx);
   else if (dk == 32)
     hipLaunchKernelGGL((dec_self_attn_kernel<T, 32>), grid, block, lds, s, (const T*)qkv, (T*)kc,
-                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, (T*)ctx);
+                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, tok_tab, (T*)ctx);
   else
     return EM_ERR_UNSUPPORTED;
   EM_CHECK_LAUNCH();
@@ -379,13 +436,13 @@ extern "C" int em_dec_embed_f32(const float* embed, const float* pe, const int32
 extern "C" int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc,
                                      const int32_t* anc, const int32_t* anc_odd, int32_t n,
                                      int32_t d, int32_t heads, int32_t Lmax, int32_t pos,
-                                     const int32_t* pos_dev, int32_t group, void* ctx,
-                                     void* stream) {
+                                     const int32_t* pos_dev, int32_t group, const int32_t* tok_tab,
+                                     void* ctx, void* stream) {
   if (n <= 0 || heads <= 0 || pos < 0 || pos >= Lmax || Lmax > SA_MAXL) return EM_ERR_BAD_ARG;
   if (dtype == EM_F32)
-    return self_attn_launch<float>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, group, ctx, (hipStream_t)stream);
+    return self_attn_launch<float>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, group, tok_tab, ctx, (hipStream_t)stream);
   if (dtype == EM_BF16)
-    return self_attn_launch<bf16>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, group, ctx, (hipStream_t)stream);
+    return self_attn_launch<bf16>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, group, tok_tab, ctx, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
 }
 
@@ -413,6 +470,32 @@ extern "C" int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t 
                        (const bf16*)kv, T, d, Tpad, (bf16*)vT);
   else
     return EM_ERR_BAD_ARG;
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_lm_embed(int dtype, const float* embed, const int32_t* tok_row, int32_t n, int32_t V,
+                           int32_t embed_unit, const int32_t* pos_dev, int32_t Lmax, void* e,
+                           void* stream) {
+  if (!embed || !tok_row || !e || n <= 0 || embed_unit <= 0) return EM_ERR_BAD_ARG;
+  if (dtype == EM_F32)
+    hipLaunchKernelGGL(lm_embed_kernel<float>, dim3(n), dim3(128), 0, (hipStream_t)stream, embed, tok_row,
+                       V, embed_unit, pos_dev, Lmax, (float*)e);
+  else if (dtype == EM_BF16)
+    hipLaunchKernelGGL(lm_embed_kernel<bf16>, dim3(n), dim3(128), 0, (hipStream_t)stream, embed, tok_row,
+                       V, embed_unit, pos_dev, Lmax, (bf16*)e);
+  else
+    return EM_ERR_BAD_ARG;
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_lm_input_norm_f32(float* x, const float* g, const float* b, const float* pe,
+                                    int32_t n, int32_t d, int32_t pos, const int32_t* pos_dev,
+                                    int32_t Lmax, void* stream) {
+  if (!x || !g || !b || n <= 0 || d <= 0) return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(lm_input_norm_kernel, dim3(em_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, g,
+                     b, pe, n, d, pos, pos_dev, Lmax);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

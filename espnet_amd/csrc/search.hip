@@ -64,6 +64,7 @@ __global__ void search_init_rows_kernel(Ctx c) {
   c.b.run_sdec[r] = 0.f;
   c.b.run_sctc[r] = 0.f;
   c.b.run_slen[r] = 0.f;
+  if (c.b.run_slm) c.b.run_slm[r] = 0.f;
   c.b.s_prev[r] = 0.f;
   c.b.tok[r] = c.p.sos;
   c.b.parent[r] = -1;
@@ -103,36 +104,60 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = c.p.V, S = c.p.S, NC = c.p.NC;
   if (!c.b.alive[r]) return;
-  float* lp = c.b.dec_logp + (size_t)r * V;
-  float w[NV];
-  float mx = -INFINITY;
+  // log-softmax of one logits row in place (block-wide), returning this thread's NV log-probs
+  auto row_log_softmax = [&](float* lp, float (&out)[NV]) {
+    float mx = -INFINITY;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int v = tid + 256 * k;
-    w[k] = v < V ? lp[v] : -INFINITY;
-    mx = fmaxf(mx, w[k]);
-  }
-  mx = wave_max(mx);
-  if (lane == 0) s_v[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]));
-  __syncthreads();
-  float sum = 0.f;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) sum += (tid + 256 * k < V) ? expf(w[k] - mx) : 0.f;
-  sum = wave_sum(sum);
-  if (lane == 0) s_v[wave] = sum;
-  __syncthreads();
-  const float lse = mx + logf(s_v[0] + s_v[1] + s_v[2] + s_v[3]);
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int v = tid + 256 * k;
-    if (v < V) {
-      const float l = w[k] - lse;
-      lp[v] = l;
-      w[k] = c.p.w_dec * l + c.p.w_len * 1.0f;
+    for (int k = 0; k < NV; ++k) {
+      const int v = tid + 256 * k;
+      out[k] = v < V ? lp[v] : -INFINITY;
+      mx = fmaxf(mx, out[k]);
     }
+    mx = wave_max(mx);
+    if (lane == 0) s_v[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sum += (tid + 256 * k < V) ? expf(out[k] - mx) : 0.f;
+    sum = wave_sum(sum);
+    if (lane == 0) s_v[wave] = sum;
+    __syncthreads();
+    const float lse = mx + logf(s_v[0] + s_v[1] + s_v[2] + s_v[3]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = tid + 256 * k;
+      if (v < V) {
+        out[k] -= lse;
+        lp[v] = out[k];
+      }
+    }
+  };
+  // weighted full scores in the scorer order of the reference (decoder, length_bonus, lm;
+  // batch_beam_search.py:289-290)
+  float w[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) w[k] = (tid + 256 * k < V) ? 0.f : -INFINITY;
+  if (c.p.w_dec != 0.f) {
+    float l[NV];
+    row_log_softmax(c.b.dec_logp + (size_t)r * V, l);
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (tid + 256 * k < V) w[k] = c.p.w_dec * l[k];
+  }
+  if (c.p.w_len != 0.f) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (tid + 256 * k < V) w[k] += c.p.w_len * 1.0f;
+  }
+  if (c.p.w_lm != 0.f) {
+    float l[NV];
+    row_log_softmax(c.b.lm_logp + (size_t)r * V, l);
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (tid + 256 * k < V) w[k] += c.p.w_lm * l[k];
   }
   if (S >= V) return;
   // each wave extracts the top-S of its own 64*NV values with wave-level ops only (no block
@@ -263,17 +288,24 @@ __global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i_host) {
   const bool allv = (S >= V);
   int tokc;
   float full;
+  // weighted sum of the full scorers for token t, in the reference's scorer order
+  auto full_score = [&](int t) {
+    float f = 0.f;
+    if (c.p.w_dec != 0.f) f = c.p.w_dec * c.b.dec_logp[(size_t)r * V + t];
+    if (c.p.w_len != 0.f) f += c.p.w_len * 1.0f;
+    if (c.p.w_lm != 0.f) f += c.p.w_lm * c.b.lm_logp[(size_t)r * V + t];
+    return f;
+  };
   if (allv) {
     tokc = s;
-    full = (c.p.w_dec != 0.f ? c.p.w_dec * c.b.dec_logp[(size_t)r * V + s] : 0.f) + c.p.w_len * 1.0f;
-    if (c.p.w_dec == 0.f && c.p.w_len == 0.f) full = 0.f;
+    full = full_score(s);
     if (lane == 0) c.b.cand_tok[(size_t)r * NC + s] = s;
   } else if (s < S) {
     tokc = c.b.cand_tok[(size_t)r * NC + s];
     full = c.b.cand_full[(size_t)r * NC + s];
   } else {  // the extra <eos> slot
     tokc = c.p.eos;
-    full = c.p.w_dec * c.b.dec_logp[(size_t)r * V + tokc] + c.p.w_len * 1.0f;
+    full = full_score(tokc);
     if (lane == 0) c.b.cand_tok[(size_t)r * NC + s] = tokc;
     // already among the pre-beam candidates: that slot carries it
     bool dup = false;
@@ -426,7 +458,7 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
   const bool was_done = c.b.done[b] != 0;
   const int maxlen = c.b.maxlens[b], minlen = c.b.minlens[b];
 
-  float n_score = -INFINITY, n_sdec = 0.f, n_sctc = 0.f, n_slen = 0.f, n_sprev = 0.f;
+  float n_score = -INFINITY, n_sdec = 0.f, n_sctc = 0.f, n_slen = 0.f, n_sprev = 0.f, n_slm = 0.f;
   if (lane < W) {
     const int rnew = b * W + lane;
     const int sel = was_done ? -1 : c.b.sel_idx[rnew];
@@ -438,6 +470,7 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
       n_score = c.b.sel_total[rnew];
       if (c.p.w_dec != 0.f) n_sdec = c.b.run_sdec[prow] + c.b.dec_logp[(size_t)prow * V + tk];
       if (c.p.w_len != 0.f) n_slen = c.b.run_slen[prow] + 1.0f;
+      if (c.p.w_lm != 0.f) n_slm = c.b.run_slm[prow] + c.b.lm_logp[(size_t)prow * V + tk];
       if (c.p.w_ctc != 0.f) {
         const float psi = c.b.cand_psi[(size_t)prow * NC + s];
         n_sctc = c.b.run_sctc[prow] + (psi - c.b.s_prev[prow]);
@@ -473,6 +506,7 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
     c.b.run_sdec[rnew] = n_sdec;
     c.b.run_sctc[rnew] = n_sctc;
     c.b.run_slen[rnew] = n_slen;
+    if (c.b.run_slm) c.b.run_slm[rnew] = n_slm;
     c.b.s_prev[rnew] = n_sprev;
     // stash for the serial ended-list pass
     c.b.sel_total[rnew] = n_score;
@@ -503,6 +537,7 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
         c.b.end_sdec[e] = c.b.run_sdec[rnew];
         c.b.end_sctc[e] = c.b.run_sctc[rnew];
         c.b.end_slen[e] = c.b.run_slen[rnew];
+        if (c.b.end_slm) c.b.end_slm[e] = c.b.run_slm[rnew];
         ++cnt;
       }
       if (sc > c.b.best_all[b]) c.b.best_all[b] = sc;
@@ -582,8 +617,46 @@ int check(const EmSearchParams* p, const EmSearchBuffers* b) {
   if (p->w_ctc != 0.f && p->T > CTC_TMAX) return EM_ERR_UNSUPPORTED;
   if (p->S <= 0 || p->NC <= 0 || p->end_cap <= 0) return EM_ERR_BAD_ARG;
   if (p->S >= p->V ? p->NC != p->V : p->NC != p->S + 1) return EM_ERR_BAD_ARG;
-  if (p->w_dec == 0.f && p->w_ctc == 0.f) return EM_ERR_BAD_ARG;
-  if (p->w_dec == 0.f && p->S < p->V) return EM_ERR_BAD_ARG;  // no full scorer -> no pre-beam
+  if (p->w_dec == 0.f && p->w_ctc == 0.f && p->w_lm == 0.f) return EM_ERR_BAD_ARG;
+  if (p->w_dec == 0.f && p->w_lm == 0.f && p->w_len == 0.f && p->S < p->V)
+    return EM_ERR_BAD_ARG;  // no full scorer -> no pre-beam
+  if (p->w_lm != 0.f && (!b->lm_logp || !b->run_slm || !b->end_slm || !b->lm)) return EM_ERR_BAD_ARG;
+  return EM_OK;
+}
+
+// One TransformerLM step for the n rows (espnet2/lm/transformer_lm.py:103-137 batch_score ->
+// Encoder.forward_one_step): embedding -> input Linear + LayerNorm(1e-5) + ReLU (+ pos-enc) ->
+// pre-norm self-attention / ReLU feed-forward layers over the token-tree K/V cache -> after_norm ->
+// vocabulary projection (logits; the log-softmax is fused into the pre-beam kernel).
+int lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i, void* stream) {
+  const EmLmWeights* lm = b->lm;
+  const int n = p->B * p->W, V = p->V, d = lm->d, ff = lm->ff, eu = lm->embed_unit;
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  const int* anc = (i & 1) ? b->anc_b : b->anc_a;
+  const int32_t* step = b->step;
+  EM_TRY(em_lm_embed(dtype, lm->embed, step ? b->tok : b->tok + (size_t)i * n, n, V, eu, step, p->Lmax,
+                     b->lm_e, stream));
+  EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, b->lm_e, lm->in_w, b->lm_x, lm->in_b, n, d, eu, eu, d, 1.f, stream));
+  EM_TRY(em_lm_input_norm_f32(b->lm_x, lm->in_ln_g, lm->in_ln_b, lm->pe, n, d, i, step, p->Lmax, stream));
+  for (int l = 0; l < lm->num_blocks; ++l) {
+    const EmLmLayer& q = lm->layers[l];
+    unsigned char* kc = (unsigned char*)b->lm_k + (size_t)l * p->Lmax * n * d * es;
+    unsigned char* vc = (unsigned char*)b->lm_v + (size_t)l * p->Lmax * n * d * es;
+    EM_TRY(em_layernorm(dtype, b->lm_x, q.norm1_g, q.norm1_b, n, d, LN_EPS, b->lm_xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_STORE, b->lm_xn, q.wqkv, b->lm_qkv, q.bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
+    if (step)
+      EM_TRY(em_dec_self_attention(dtype, b->lm_qkv, kc, vc, b->anc_a, b->anc_b, n, d, lm->heads, p->Lmax,
+                                   0, step, (p->W + 1) / 2, b->tok, b->lm_ctx, stream));
+    else
+      EM_TRY(em_dec_self_attention(dtype, b->lm_qkv, kc, vc, anc, anc, n, d, lm->heads, p->Lmax, i,
+                                   nullptr, (p->W + 1) / 2, b->tok, b->lm_ctx, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->lm_ctx, q.wout, b->lm_x, q.bout, n, d, d, d, d, 1.f, stream));
+    EM_TRY(em_layernorm(dtype, b->lm_x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->lm_xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RELU, b->lm_xn, q.w1, b->lm_h, q.b1, n, ff, d, d, ff, 1.f, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->lm_h, q.w2, b->lm_x, q.b2, n, d, ff, ff, d, 1.f, stream));
+  }
+  EM_TRY(em_layernorm(dtype, b->lm_x, lm->after_norm_g, lm->after_norm_b, n, d, LN_EPS, b->lm_xn, nullptr, stream));
+  EM_TRY(gemm(dtype, EM_EPI_STORE_F32, b->lm_xn, lm->out_w, b->lm_logp, lm->out_b, n, V, d, d, V, 1.f, stream));
   return EM_OK;
 }
 
@@ -654,10 +727,10 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
         EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.self_wqkv, b->qkv, q.self_bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
         if (b->step)
           EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, b->anc_a, b->anc_b, n, d, h, p->Lmax, 0,
-                                       b->step, (p->W + 1) / 2, b->ctx, stream));
+                                       b->step, (p->W + 1) / 2, nullptr, b->ctx, stream));
         else
           EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, anc, n, d, h, p->Lmax, i, nullptr,
-                                       (p->W + 1) / 2, b->ctx, stream));
+                                       (p->W + 1) / 2, nullptr, b->ctx, stream));
         EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.self_wout, b->x, q.self_bout, n, d, d, d, d, 1.f, stream));
         EM_TRY(em_layernorm(dtype, b->x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->xn, nullptr, stream));
         EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.src_wq, b->qs, q.src_bq, n, d, d, d, d, 1.f, stream));
@@ -669,19 +742,20 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
       }
       EM_TRY(em_layernorm(dtype, b->x, dw->after_norm_g, dw->after_norm_b, n, d, LN_EPS, b->xn, nullptr, stream));
       EM_TRY(gemm(dtype, EM_EPI_STORE_F32, b->xn, dw->out_w, b->dec_logp, dw->out_b, n, V, d, d, V, 1.f, stream));
-      if (p->S > 64 && p->S < V) {
+    }
+    if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));
+    if (p->w_dec != 0.f || p->w_lm != 0.f || p->w_len != 0.f) {
+      if ((p->S > 64 && p->S < V) || V > 256 * 40) {
+        if (p->w_lm != 0.f || p->w_dec == 0.f) return EM_ERR_UNSUPPORTED;  // needs the fused row kernel
         EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
-        hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
+        if (p->S < V)
+          hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
       } else if (V <= 256 * 8) {
         hipLaunchKernelGGL(logsoftmax_prebeam_kernel<8>, dim3(n), dim3(256), 0, s, c);
       } else if (V <= 256 * 20) {
         hipLaunchKernelGGL(logsoftmax_prebeam_kernel<20>, dim3(n), dim3(256), 0, s, c);
-      } else if (V <= 256 * 40) {
-        hipLaunchKernelGGL(logsoftmax_prebeam_kernel<40>, dim3(n), dim3(256), 0, s, c);
       } else {
-        EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
-        if (p->S < V)
-          hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
+        hipLaunchKernelGGL(logsoftmax_prebeam_kernel<40>, dim3(n), dim3(256), 0, s, c);
       }
     }
     {

@@ -85,7 +85,22 @@ class EmDecoderWeights(C.Structure):
 class EmSearchParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "W", "V", "T", "Tpad", "S", "NC", "Lmax", "end_cap",
                                          "sos", "eos", "blank", "use_end_detect")] + \
-               [(n, C.c_float) for n in ("w_dec", "w_ctc", "w_len")]
+               [(n, C.c_float) for n in ("w_dec", "w_ctc", "w_len", "w_lm")]
+
+
+_LM_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "wqkv", "bqkv", "wout", "bout", "w1", "b1",
+                  "w2", "b2"]
+
+
+class EmLmLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LM_LAYER_PTRS]
+
+
+class EmLmWeights(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d", "heads", "ff", "num_blocks", "vocab", "embed_unit")] + \
+               [(n, C.c_void_p) for n in ("embed", "in_w", "in_b", "in_ln_g", "in_ln_b", "pe",
+                                          "after_norm_g", "after_norm_b", "out_w", "out_b")] + \
+               [("layers", C.POINTER(EmLmLayer))]
 
 
 SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "anc_a", "anc_b",
@@ -93,7 +108,9 @@ SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "an
                   "cand_tok", "cand_full", "cand_psi", "cand_total", "sel_idx", "sel_total",
                   "end_count", "end_pos", "end_slot", "end_forced", "end_score", "end_sdec",
                   "end_sctc", "end_slen", "best_all", "best_by_len", "done", "step", "x", "xn", "qkv", "qs",
-                  "ctx", "hbuf", "dec_logp", "self_k", "self_v", "mem_kv", "mem_vT"]
+                  "ctx", "hbuf", "dec_logp", "self_k", "self_v", "mem_kv", "mem_vT",
+                  "lm", "lm_e", "lm_xn", "lm_qkv", "lm_ctx", "lm_h", "lm_x", "lm_logp", "lm_k", "lm_v",
+                  "run_slm", "end_slm"]
 
 
 class EmSearchBuffers(C.Structure):
@@ -140,7 +157,9 @@ _SIGNATURES = {
     "em_cast_f32": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
     "em_dec_embed_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "em_dec_self_attention": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
-                                        _i32, _vp, _i32, _vp, _vp]),
+                                        _i32, _vp, _i32, _vp, _vp, _vp]),
+    "em_lm_embed": (C.c_int, [C.c_int, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "em_lm_input_norm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "em_dec_src_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                                        _i32, _i32, _vp, _vp]),
     "em_dec_transpose_v": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -8,8 +8,8 @@ list`), with BatchBeamSearch's step semantics (legacy/nets/batch_beam_search.py:
 `search_batch` is the utterance-batched entry the MI355X path adds; `forward` keeps the
 reference's single-utterance signature.
 
-Supported scorers: "decoder" (TransformerDecoder), "ctc" (CTCPrefixScorer), "length_bonus".
-An LM / n-gram scorer is SURVEY.md §8(f) "next".
+Supported scorers: "decoder" (TransformerDecoder), "ctc" (CTCPrefixScorer), "length_bonus" and
+"lm" (espnet_amd.lm.transformer_lm.TransformerLM).  An n-gram scorer is SURVEY.md §8(f) "next".
 """
 import ctypes as C
 import logging
@@ -26,7 +26,8 @@ logger = logging.getLogger(__name__)
 
 _I32 = {"xlens", "maxlens", "minlens", "tok", "parent", "anc_a", "anc_b", "alive", "cand_tok",
         "sel_idx", "end_count", "end_pos", "end_slot", "end_forced", "done", "step"}
-_ACT = {"xn", "qkv", "qs", "ctx", "hbuf", "self_k", "self_v", "mem_kv", "mem_vT"}
+_ACT = {"xn", "qkv", "qs", "ctx", "hbuf", "self_k", "self_v", "mem_kv", "mem_vT", "lm_e", "lm_xn",
+        "lm_qkv", "lm_ctx", "lm_h", "lm_k", "lm_v"}
 
 
 class BeamSearch:
@@ -43,8 +44,8 @@ class BeamSearch:
             w = weights.get(k, 0)
             if w == 0 or v is None:
                 continue
-            if k not in ("decoder", "ctc", "length_bonus"):
-                raise NotImplementedError(f"scorer {k!r}: SURVEY.md §8(f) 'next' (LM / n-gram)")
+            if k not in ("decoder", "ctc", "length_bonus", "lm"):
+                raise NotImplementedError(f"scorer {k!r}: SURVEY.md §8(f) 'next' (n-gram)")
             self.scorers[k] = v
             (self.part_scorers if isinstance(v, CTCPrefixScorer) else self.full_scorers)[k] = v
         self.sos, self.eos = sos, eos
@@ -61,8 +62,8 @@ class BeamSearch:
         self.do_pre_beam = (self.pre_beam_score_key is not None
                             and self.pre_beam_size < self.n_vocab and len(self.part_scorers) > 0)
         self.normalize_length = normalize_length
-        if "decoder" not in self.scorers and "ctc" not in self.scorers:
-            raise ValueError("beam search needs the decoder and/or the ctc scorer")
+        if not any(k in self.scorers for k in ("decoder", "ctc", "lm")):
+            raise ValueError("beam search needs the decoder, the ctc and/or the lm scorer")
         self._bufs = {}
         self._graphs = {}
         self.step_chunk = 16  # steps enqueued between two polls of the `done` flags
@@ -71,8 +72,9 @@ class BeamSearch:
 
 class BatchBeamSearch(BeamSearch):
     # ------------------------------------------------------------------ buffers
-    def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl):
-        key = (str(dev), act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl)
+    def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm=None):
+        key = (str(dev), act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl,
+               None if lm is None else (lm.att_unit, lm.unit, lm.layer, lm.embed_unit))
         if key in self._bufs:
             return self._bufs[key]
         self._bufs.clear()  # one live shape at a time
@@ -93,6 +95,11 @@ class BatchBeamSearch(BeamSearch):
             shapes.update(x=(n, d), xn=(n, d), qkv=(n, 3 * d), qs=(n, d), ctx=(n, d), hbuf=(n, ff),
                           dec_logp=(n, V), self_k=(nl, Lmax, n, d), self_v=(nl, Lmax, n, d),
                           mem_kv=(nl, B * T, 2 * d), mem_vT=(nl, B, d, Tpad))
+        if lm is not None:
+            dl = lm.att_unit
+            shapes.update(lm_e=(n, lm.embed_unit), lm_xn=(n, dl), lm_qkv=(n, 3 * dl), lm_ctx=(n, dl),
+                          lm_h=(n, lm.unit), lm_x=(n, dl), lm_logp=(n, V), lm_k=(lm.layer, Lmax, n, dl),
+                          lm_v=(lm.layer, Lmax, n, dl), run_slm=(n,), end_slm=(B, cap))
         t = {}
         for name, shp in shapes.items():
             if shp is None:
@@ -115,7 +122,11 @@ class BatchBeamSearch(BeamSearch):
         W, V = self.beam_size, self.n_vocab
         dec = self.scorers.get("decoder")
         ctc_sc = self.scorers.get("ctc")
-        em_dtype = dec.em_dtype if dec is not None else ctc_sc.ctc.em_dtype
+        lm = self.scorers.get("lm")
+        em_dtype = dec.em_dtype if dec is not None else (ctc_sc.ctc.em_dtype if ctc_sc is not None else lm.em_dtype)
+        if lm is not None and lm.em_dtype != em_dtype:
+            lm.compute_dtype = "bfloat16" if em_dtype == L.EM_BF16 else "float32"
+            lm.invalidate()
         act = torch.bfloat16 if em_dtype == L.EM_BF16 else torch.float32
         enc_act = enc_act.to(act).contiguous()
         # length bounds per utterance (beam_search.py:414-429 with inp.shape[0] = olens[b])
@@ -136,7 +147,7 @@ class BatchBeamSearch(BeamSearch):
         Tpad = (T + 31) // 32 * 32
         nl = dec.num_blocks if dec is not None else 0
         ff = dec.linear_units if dec is not None else 0
-        bufs = self._alloc(dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl)
+        bufs = self._alloc(dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm)
         bufs["xlens"].copy_(torch.tensor(olens, dtype=torch.int32))
         bufs["maxlens"].copy_(torch.tensor(maxlens, dtype=torch.int32))
         bufs["minlens"].copy_(torch.tensor(minlens, dtype=torch.int32))
@@ -147,12 +158,16 @@ class BatchBeamSearch(BeamSearch):
                              w_dec=float(self.weights.get("decoder", 0.0)) if dec is not None else 0.0,
                              w_ctc=float(self.weights.get("ctc", 0.0)) if ctc_sc is not None else 0.0,
                              w_len=float(self.weights.get("length_bonus", 0.0))
-                             if "length_bonus" in self.scorers else 0.0)
+                             if "length_bonus" in self.scorers else 0.0,
+                             w_lm=float(self.weights.get("lm", 0.0)) if lm is not None else 0.0)
         bs = L.EmSearchBuffers()
         for name in L.SEARCH_BUFFERS:
             setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
         if not self.use_hipgraph:
             bs.step = None
+        lmw = lm.ensure_packed(dev, Lmax)["w"] if lm is not None else None
+        if lmw is not None:
+            bs.lm = C.addressof(lmw)
         dw = dec.ensure_packed(dev, Lmax)["w"] if dec is not None else None
         dwp = C.byref(dw) if dw is not None else None
         stream = L.current_stream_ptr()
@@ -173,7 +188,8 @@ class BatchBeamSearch(BeamSearch):
             # One hipGraph = K search steps (~75 launches each).  Every step-dependent kernel reads the
             # step index from device memory, so the same graph is replayed ceil(imax / K) times; steps
             # past the end are no-ops.  The graph is tied to the buffer set and the parameter block.
-            gkey = (id(bufs), bytes(p), em_dtype, id(dec._packed) if dec is not None else 0)
+            gkey = (id(bufs), bytes(p), em_dtype, id(dec._packed) if dec is not None else 0,
+                    id(lm._packed) if lm is not None else 0)
             g = self._graphs.get(gkey)
             if g is None:
                 steps(0, 1)  # warm-up outside capture (one-time attribute calls, lazy module loads)
@@ -181,7 +197,7 @@ class BatchBeamSearch(BeamSearch):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     steps(0, K)
-                self._graphs[gkey] = (g, p, bs)  # keep the argument blocks alive with the graph
+                self._graphs[gkey] = (g, p, bs, lmw)  # keep the argument blocks alive with the graph
                 init()  # the warm-up step advanced the search state: start over
             else:
                 g = g[0]
@@ -209,7 +225,7 @@ class BatchBeamSearch(BeamSearch):
 
         cpu = {k: bufs[k].cpu().numpy() for k in ("end_count", "end_pos", "end_slot", "end_forced",
                                                   "end_score", "end_sdec", "end_sctc", "end_slen",
-                                                  "tok", "parent")}
+                                                  "end_slm", "tok", "parent") if k in bufs}
         tok, parent = cpu["tok"], cpu["parent"]
         counts = cpu["end_count"]
         bi = np.repeat(np.arange(B), counts)
@@ -226,8 +242,8 @@ class BatchBeamSearch(BeamSearch):
         forced = cpu["end_forced"][bi, ei].astype(bool)
         ys[np.arange(E)[forced], pos[forced] + 1] = self.eos
         lens = pos + 1 + forced
-        keys = [k for k in ("decoder", "ctc", "length_bonus") if k in self.scorers]
-        col = dict(decoder="end_sdec", ctc="end_sctc", length_bonus="end_slen")
+        keys = [k for k in ("decoder", "ctc", "length_bonus", "lm") if k in self.scorers]
+        col = dict(decoder="end_sdec", ctc="end_sctc", length_bonus="end_slen", lm="end_slm")
         out, off = [], 0
         for b in range(B):
             hyps = []
@@ -268,12 +284,14 @@ class BatchBeamSearch(BeamSearch):
 
 
 def build_beam_search(asr_model, beam_size: int, ctc_weight: float, penalty: float,
-                      lm_weight: float = 0.0, token_list=None, normalize_length: bool = False):
+                      lm_weight: float = 0.0, token_list=None, normalize_length: bool = False, lm=None):
     """Scorer / weight set-up of Speech2Text (espnet2/bin/asr_inference.py:168-176, 310-316,
     353-381)."""
     scorers = dict(decoder=asr_model.decoder,
                    ctc=CTCPrefixScorer(ctc=asr_model.ctc, eos=asr_model.eos) if asr_model.ctc is not None else None,
                    length_bonus=LengthBonus(len(token_list)))
+    if lm is not None:
+        scorers["lm"] = lm  # asr_inference.py:179-191 (scorers["lm"] = lm.lm)
     weights = dict(decoder=1.0 - ctc_weight, ctc=ctc_weight, lm=lm_weight, length_bonus=penalty)
     return BatchBeamSearch(beam_size=beam_size, weights=weights, scorers=scorers, sos=asr_model.sos,
                            eos=asr_model.eos, vocab_size=len(token_list), token_list=token_list,

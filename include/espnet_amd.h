@@ -248,10 +248,20 @@ int em_dec_embed_f32(const float* embed, const float* pe, const int32_t* tok_row
  *   anc [n][Lmax] i32 slot of every prefix position; ctx [n][d] act out.  d/heads in {32, 64}.    */
 /*   pos_dev != NULL: position from device memory; anc is then used at even and anc_odd at odd
  *   positions (the search double-buffers the table by step parity).  group (1..16) consecutive rows
- *   share a workgroup (the beam of one utterance: shared ancestors hit the same cache).          */
+ *   share a workgroup (the beam of one utterance: shared ancestors hit the same cache).
+ *   tok_tab != NULL ([Lmax][n] token table): keys whose token id is 0 are masked
+ *   (TransformerLM._target_mask, espnet2/lm/transformer_lm.py:54-57).                            */
 int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc, const int32_t* anc,
                           const int32_t* anc_odd, int32_t n, int32_t d, int32_t heads, int32_t Lmax,
-                          int32_t pos, const int32_t* pos_dev, int32_t group, void* ctx, void* stream);
+                          int32_t pos, const int32_t* pos_dev, int32_t group, const int32_t* tok_tab,
+                          void* ctx, void* stream);
+/*   TransformerLM input (espnet2/lm/transformer_lm.py:35, transformer/encoder.py:132-139):
+ *   e[r] = embed[tok_row[r]] in the act dtype;  then (after the input Linear) in place on x f32:
+ *   torch LayerNorm(eps 1e-5) -> ReLU -> optional x*sqrt(d) + pe[pos].  pos_dev as above.       */
+int em_lm_embed(int dtype, const float* embed, const int32_t* tok_row, int32_t n, int32_t V,
+                int32_t embed_unit, const int32_t* pos_dev, int32_t Lmax, void* e, void* stream);
+int em_lm_input_norm_f32(float* x, const float* g, const float* b, const float* pe, int32_t n,
+                         int32_t d, int32_t pos, const int32_t* pos_dev, int32_t Lmax, void* stream);
 /*   qs [B*W][d] act; kmem: K rows of utterance b at kmem + (b*T + t)*ldk; vT [B][d][Tpad] act
  *   (zero padded, Tpad % 32 == 0); klens [B] valid memory frames; ctx [B*W][d] act out.           */
 int em_dec_src_attention(int dtype, const void* qs, const void* kmem, int32_t ldk, const void* vT,
@@ -304,7 +314,34 @@ typedef struct EmSearchParams {
   int32_t sos, eos, blank;
   int32_t use_end_detect; /* maxlenratio == 0 (beam_search.py:443) */
   float w_dec, w_ctc, w_len; /* scorer weights: decoder, ctc, length_bonus (asr_inference.py:310-316) */
+  float w_lm;                /* language-model scorer weight (lm_weight), 0 = no LM */
 } EmSearchParams;
+
+/* TransformerLM used as a full scorer (espnet2/lm/transformer_lm.py:12-137):
+ * nn.Embedding -> Encoder(input_layer="linear") -> nn.Linear head.  "act" = dtype of the call.  */
+typedef struct EmLmLayer {
+  const float *norm1_g, *norm1_b, *norm2_g, *norm2_b;
+  const void* wqkv; /* [3d][d] act: self_attn.linear_q | linear_k | linear_v */
+  const float* bqkv;
+  const void* wout; /* [d][d] act */
+  const float* bout;
+  const void* w1; /* [ff][d] act (ReLU) */
+  const float* b1;
+  const void* w2; /* [d][ff] act */
+  const float* b2;
+} EmLmLayer;
+
+typedef struct EmLmWeights {
+  int32_t d, heads, ff, num_blocks, vocab, embed_unit;
+  const float* embed;               /* [V][embed_unit] f32: lm.embed.weight */
+  const void* in_w;                 /* [d][embed_unit] act: lm.encoder.embed.0 */
+  const float *in_b, *in_ln_g, *in_ln_b; /* encoder.embed.0 bias, encoder.embed.1 (torch LayerNorm, eps 1e-5) */
+  const float* pe;                  /* [>= Lmax][d] sinusoid table, or NULL (pos_enc=None) */
+  const float *after_norm_g, *after_norm_b;
+  const void* out_w;                /* [V][d] act: lm.decoder */
+  const float* out_b;
+  const EmLmLayer* layers;          /* [num_blocks], host array */
+} EmLmWeights;
 
 typedef struct EmSearchBuffers {
   const int32_t *xlens, *maxlens, *minlens; /* [B] valid memory frames, max / min output length */
@@ -335,6 +372,12 @@ typedef struct EmSearchBuffers {
   void *self_k, *self_v;                    /* act [layers][Lmax][n][d] */
   void *mem_kv;                             /* act [layers][B*T][2d] */
   void *mem_vT;                             /* act [layers][B][d][Tpad], zero initialised by the caller */
+  /* language-model scorer (all NULL when w_lm == 0) */
+  const EmLmWeights* lm;                    /* host struct */
+  void *lm_e, *lm_xn, *lm_qkv, *lm_ctx, *lm_h; /* act: [n][embed_unit], [n][d], [n][3d], [n][d], [n][ff] */
+  float *lm_x, *lm_logp;                    /* f32: [n][d], [n][V] */
+  void *lm_k, *lm_v;                        /* act [lm layers][Lmax][n][d] */
+  float *run_slm, *end_slm;                 /* [n], [B][end_cap] accumulated LM score */
 } EmSearchBuffers;
 
 /*   Projects the encoder memory (enc_act [B][T][d_model] act) to per-layer K | V and V^T, computes

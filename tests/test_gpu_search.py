@@ -30,7 +30,19 @@ def _sub(sd, prefix):
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
-def build_search(g, sd, dtype="float32", dev="cuda"):
+def build_lm(g, dtype="float32", dev="cuda"):
+    """TransformerLM of an LM golden case: recipe weights under the reference's own key names."""
+    from espnet_amd.lm.transformer_lm import TransformerLM
+    from oracle.weights import recipe_state_dict
+
+    shapes = {"lm." + k: tuple(v) for k, v in json.loads(str(g["lm_state_shapes"])).items()}
+    lsd = recipe_state_dict(shapes, int(g["wseed"]), skip=())
+    lm = TransformerLM(int(g["vocab"]), compute_dtype=dtype, **json.loads(str(g["lm_conf"])))
+    lm.load_state_dict(_sub(lsd, "lm."), strict=True)
+    return lm.to(dev)
+
+
+def build_search(g, sd, dtype="float32", dev="cuda", lm=None):
     """decoder + CTC head + BatchBeamSearch for a golden case (no encoder needed)."""
     from espnet_amd.asr.ctc import CTC
     from espnet_amd.asr.decoder.transformer_decoder import TransformerDecoder
@@ -51,7 +63,8 @@ def build_search(g, sd, dtype="float32", dev="cuda"):
                                   sos=V - 1, eos=V - 1)
     return build_beam_search(model, beam_size=int(g["beam"]), ctc_weight=cw,
                              penalty=float(g["penalty"]) if "penalty" in g else 0.0,
-                             token_list=token_list(V))
+                             lm_weight=float(g["lm_weight"]) if lm is not None else 0.0,
+                             token_list=token_list(V), lm=lm)
 
 
 def oracle_enc(g, sd):
@@ -101,6 +114,48 @@ def test_search_f32_matches_reference_nbest(name):
     # the ended list is sorted
     sc = [float(h.score) for h in hyps]
     assert sc == sorted(sc, reverse=True)
+
+
+@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_search_with_lm_scorer_f32_matches_reference_nbest(name, graph):
+    """SURVEY §8(f) rank 1: decoder + CTC prefix + TransformerLM scorers fused in the device search;
+    the reference's n-best (token sequences, total and per-scorer scores incl. "lm") must be in mine."""
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    bs = build_search(g, sd, "float32", lm=build_lm(g, "float32"))
+    bs.use_hipgraph = graph
+    assert "lm" in json.loads(str(g["score_keys"]))
+    for _ in range(2 if graph else 1):  # second call replays the captured graph
+        hyps = bs.search_batch(enc.cuda(), [int(olens[0])])[0]
+        check_against_golden(g, hyps, tol_abs=2e-3, tol_rel=2e-5)
+        assert hyps[0].yseq.tolist() == g["yseq"][0, : g["yseq_lens"][0]].tolist()
+
+
+def test_search_with_lm_scorer_bf16_and_batched():
+    """bf16 LM + decoder: score level vs the fp32 reference, additivity of the per-scorer scores, and
+    utterance batching stays transparent with the LM cache in play."""
+    g = load_golden("tiny_beam4_lm_posenc")
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    bs = build_search(g, sd, "bfloat16", lm=build_lm(g, "bfloat16"))
+    T = int(olens[0])
+    hyps = bs.search_batch(enc.cuda(), [T])[0]
+    assert abs(float(hyps[0].score) - float(g["score"][0])) < 0.03 * abs(float(g["score"][0]))
+    for h in hyps:
+        tot = sum(bs.weights[k] * float(v) for k, v in h.scores.items())
+        assert abs(tot - float(h.score)) < 1e-2 + 1e-4 * abs(tot)
+    bs32 = build_search(g, sd, "float32", lm=build_lm(g, "float32"))
+    e2 = torch.zeros(2, T, enc.shape[-1])
+    e2[0], e2[1, : T - 9] = enc[0], enc[0, 9:]
+    both = bs32.search_batch(e2.cuda(), [T, T - 9])
+    for b, (x, n) in enumerate([(enc[:, :T], T), (enc[:, 9:T], T - 9)]):
+        single = bs32.search_batch(x.contiguous().cuda(), [n])[0]
+        assert [h.yseq.tolist() for h in single] == [h.yseq.tolist() for h in both[b]]
+        for hs, hb in zip(single, both[b]):
+            assert abs(float(hs.score) - float(hb.score)) < 1e-3
+            assert abs(float(hs.scores["lm"]) - float(hb.scores["lm"])) < 1e-3
 
 
 def test_search_batched_equals_single():
@@ -204,7 +259,7 @@ def test_dec_self_attention(lib, prec, heads, d):
     ctx = torch.empty(n, d, dtype=dt, device="cuda")
     kc0, vc0 = kc.clone(), vc.clone()
     L.check(lib.em_dec_self_attention(em, L.ptr(qkv), L.ptr(kc), L.ptr(vc), L.ptr(anc), L.ptr(anc), n,
-                                      d, heads, Lmax, pos, None, 3, L.ptr(ctx), None), "self_attn")
+                                      d, heads, Lmax, pos, None, 3, None, L.ptr(ctx), None), "self_attn")
     torch.cuda.synchronize()
     q, k_new, v_new = qkv.float().split(d, dim=1)
     ref = torch.empty(n, d)
