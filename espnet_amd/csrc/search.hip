@@ -97,6 +97,8 @@ __global__ void search_init_utt_kernel(Ctx c) {
 // logits -> log-probs in place (transformer_decoder.py:233), then the top-S token ids of the
 // weighted full scores w_dec*logp + w_len (batch_beam_search.py:289-302), S rounds of block
 // arg-max over register-resident values (ties -> lowest id).  NV values per thread: V <= 256*NV.
+constexpr int PREBEAM_SMAX = 128;  // pre-beam width of the fused row kernel (beam_size <= 85)
+
 template <int NV>
 __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
   __shared__ float s_v[4];
@@ -162,9 +164,9 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
   if (S >= V) return;
   // each wave extracts the top-S of its own 64*NV values with wave-level ops only (no block
   // barrier inside the rounds); the 4*S survivors are merged by wave 0
-  __shared__ float m_v[4 * 64];
-  __shared__ int m_i[4 * 64];
-  const int SS = S < 64 ? S : 64;
+  __shared__ float m_v[4 * PREBEAM_SMAX];
+  __shared__ int m_i[4 * PREBEAM_SMAX];
+  const int SS = S < PREBEAM_SMAX ? S : PREBEAM_SMAX;
   for (int k = 0; k < SS; ++k) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
       }
     }
     if (lane == 0) {
-      m_v[wave * 64 + k] = best;
-      m_i[wave * 64 + k] = bi;
+      m_v[wave * SS + k] = best;
+      m_i[wave * SS + k] = bi;
     }
 #pragma unroll
     for (int q = 0; q < NV; ++q)
@@ -193,18 +195,20 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
   }
   __syncthreads();
   if (wave == 0) {
-    float cv[4];
-    int ci[4];
+    constexpr int NQ = 4 * PREBEAM_SMAX / 64;
+    float cv[NQ];
+    int ci[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      cv[q] = lane < SS ? m_v[q * 64 + lane] : -INFINITY;
-      ci[q] = lane < SS ? m_i[q * 64 + lane] : 0x7fffffff;
+    for (int q = 0; q < NQ; ++q) {
+      const int j = lane + 64 * q;
+      cv[q] = j < 4 * SS ? m_v[j] : -INFINITY;
+      ci[q] = j < 4 * SS ? m_i[j] : 0x7fffffff;
     }
     for (int k = 0; k < SS; ++k) {
       float best = -INFINITY;
       int bi = 0x7fffffff;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < NQ; ++q)
         if (cv[q] > best || (cv[q] == best && ci[q] < bi)) {
           best = cv[q];
           bi = ci[q];
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
         c.b.cand_full[(size_t)r * NC + k] = best;
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < NQ; ++q)
         if (ci[q] == bi) cv[q] = -INFINITY;
     }
   }
@@ -745,7 +749,7 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
     }
     if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));
     if (p->w_dec != 0.f || p->w_lm != 0.f || p->w_len != 0.f) {
-      if ((p->S > 64 && p->S < V) || V > 256 * 40) {
+      if ((p->S > PREBEAM_SMAX && p->S < V) || V > 256 * 40) {
         if (p->w_lm != 0.f || p->w_dec == 0.f) return EM_ERR_UNSUPPORTED;  // needs the fused row kernel
         EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
         if (p->S < V)

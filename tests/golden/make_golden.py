@@ -422,6 +422,15 @@ CASES = {
     "tiny_beam4_lm_posenc": lambda: run_lm_search_case(
         "tiny_beam4_lm_posenc", tiny(d=64, heads=2, ff=128), 50, 7, 15, 24000, 4, 0.5, 1.0, 4,
         dict(pos_enc="sinusoidal", embed_unit=64, att_unit=128, head=2, unit=128, layer=1)),
+    # the LibriSpeech decode shape (egs2/librispeech/asr1/conf/decode_asr.yaml: beam 60, ctc 0.3, lm 0.6)
+    # on a tiny model with a vocabulary wider than the pre-beam (int(1.5 * 60) = 90 < 300)
+    "tiny_beam60_lm_v300": lambda: run_lm_search_case(
+        "tiny_beam60_lm_v300", tiny(d=64, heads=2, ff=128), 300, 9, 16, 32000, 60, 0.3, 0.6, 20,
+        dict(pos_enc=None, embed_unit=64, att_unit=64, head=2, unit=128, layer=2)),
+    # end-to-end shape for the HIP encoder (d_k = 64): Speech2Text(lm_train_config, lm_file, lm_weight)
+    "e2e_beam5_lm": lambda: run_lm_search_case(
+        "e2e_beam5_lm", tiny(d=128, heads=2, ff=128), 50, 11, 17, 40000, 5, 0.3, 0.6, 5,
+        dict(pos_enc=None, embed_unit=64, att_unit=128, head=2, unit=128, layer=2)),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 
