@@ -262,21 +262,27 @@ class ConformerEncoder(torch.nn.Module):
         return ((T_f - 1) // 2 - 1) // 2
 
     def forward_device(self, feats: torch.Tensor, flens: List[int], flens_dev: torch.Tensor,
-                       mvn_partial: Optional[torch.Tensor] = None):
+                       mvn_partial: Optional[torch.Tensor] = None, isolate: bool = False):
         """feats (B,T_f,D) f32 on the GPU.  Returns (enc_out f32 (B,T,d), enc_act (B,T,d) in the
         compute dtype, olens list, olens_dev i32)."""
         L.require_gpu(feats, "feats")
         B, T_f, D = feats.shape
-        if T_f < 7:
-            # check_short_utt (subsampling.py:31-49) via conformer_encoder.py:360-369
+        # check_short_utt (subsampling.py:31-49) via conformer_encoder.py:360-369; the reference sees one
+        # utterance per call, so in a padded batch every row is held to the same limit
+        short = [b for b, n in enumerate(flens) if n < 7] if T_f >= 7 else list(range(B))
+        if short:
+            n0 = min(T_f, int(flens[short[0]]))
             raise L.TooShortUttError(
-                f"has {T_f} frames and is too short for subsampling "
-                f"(it needs more than 7 frames), return empty results", T_f, 7)
+                f"has {n0} frames and is too short for subsampling "
+                f"(it needs more than 7 frames), return empty results", n0, 7, indices=short)
         dev = feats.device
         pk = self._ensure_packed(dev)
         lib = L.load()
         T = self.output_frames(T_f)
-        olens = conv2d_subsampled_lengths(flens, T_f)
+        if isolate:  # every utterance as if it were the whole batch: tmax = its own length
+            olens = [conv2d_subsampled_lengths([n], int(n))[0] for n in flens]
+        else:  # the padded mask is sliced, so padded rows keep up to two frames more (subsampling.py:448)
+            olens = conv2d_subsampled_lengths(flens, T_f)
         olens_dev = torch.tensor(olens, dtype=torch.int32).to(dev, non_blocking=True)
         need = lib.em_conformer_workspace_bytes(self.em_dtype, C.byref(pk["w"]), B, T_f)
         # one workspace per stream: independent utterance batches may be encoded concurrently on
@@ -294,7 +300,8 @@ class ConformerEncoder(torch.nn.Module):
         rc = lib.em_conformer_encode(
             self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
             L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(ws),
-            ws.numel(), L.ptr(enc_out), L.ptr(enc_act), L.current_stream_ptr())
+            ws.numel(), L.ptr(enc_out), L.ptr(enc_act), L.EM_ENC_ISOLATE_UTTS if isolate else 0,
+            L.current_stream_ptr())
         L.check(rc, "em_conformer_encode")
         return enc_out, enc_act, olens, olens_dev
 

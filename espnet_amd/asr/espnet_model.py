@@ -81,22 +81,33 @@ class ESPnetASRModel(torch.nn.Module):
         return r
 
     # ------------------------------------------------------------------ encode
-    def encode_device(self, speech: torch.Tensor, speech_lengths: List[int]) -> EncoderState:
-        """speech (B, N) f32 ON THE GPU (zero padded), speech_lengths host ints.  No host sync."""
+    def encode_device(self, speech: torch.Tensor, speech_lengths: List[int],
+                      isolate: bool = False) -> EncoderState:
+        """speech (B, N) f32 ON THE GPU (zero padded), speech_lengths host ints.  No host sync.
+        isolate=False: the reference's padded-batch semantics (`encode`, espnet_model.py:380-448: STFT
+        reflect padding at the padded end, unmasked depthwise conv).  isolate=True: batching is
+        transparent — row b equals what `Speech2Text.__call__` computes for utterance b alone."""
         L.require_gpu(speech, "speech")
         nmax = max(int(n) for n in speech_lengths)
         speech = speech[:, :nmax].contiguous()  # espnet_model.py:454 (crop to the longest)
         dev = speech.device
         flens = self.frontend.feature_lengths(speech_lengths)
         flens_dev = torch.tensor(flens, dtype=torch.int32).to(dev, non_blocking=True)
-        feats = self.frontend.forward_device(speech, flens_dev)
+        wlens_dev = None
+        if isolate and len(set(int(n) for n in speech_lengths)) > 1:
+            if min(int(n) for n in speech_lengths) <= self.frontend.n_fft // 2:
+                raise ValueError(f"an input of {min(speech_lengths)} samples is too short for reflect padding "
+                                 f"of {self.frontend.n_fft // 2}")  # torch.stft raises for it as well
+            wlens_dev = torch.tensor([int(n) for n in speech_lengths], dtype=torch.int32).to(dev, non_blocking=True)
+        feats = self.frontend.forward_device(speech, flens_dev, wlens_dev)
         partial = None
         if self.normalize is not None:
             if hasattr(self.normalize, "partial_sums"):  # UtteranceMVN: subtraction fused into conv1
                 partial = self.normalize.partial_sums(feats, flens_dev)
             else:  # GlobalMVN: in place
                 feats = self.normalize.forward_device(feats, flens_dev)
-        enc_out, enc_act, olens, olens_dev = self.encoder.forward_device(feats, flens, flens_dev, partial)
+        enc_out, enc_act, olens, olens_dev = self.encoder.forward_device(feats, flens, flens_dev, partial,
+                                                                         isolate=isolate)
         return EncoderState(enc_out, enc_act, olens, olens_dev, feats, flens)
 
     def encode(self, speech: torch.Tensor, speech_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

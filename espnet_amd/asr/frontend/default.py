@@ -73,8 +73,11 @@ class DefaultFrontend(torch.nn.Module):
     def feature_lengths(self, input_lengths) -> list:
         return stft_frame_lengths([int(n) for n in input_lengths], self.n_fft, self.hop_length)
 
-    def forward_device(self, speech: torch.Tensor, flens_dev: torch.Tensor) -> torch.Tensor:
-        """speech (B, N) f32 on the GPU; flens_dev (B,) i32 on the GPU.  Returns feats (B,T_f,n_mels)."""
+    def forward_device(self, speech: torch.Tensor, flens_dev: torch.Tensor,
+                       wlens_dev: torch.Tensor = None) -> torch.Tensor:
+        """speech (B, N) f32 on the GPU; flens_dev (B,) i32 on the GPU.  Returns feats (B,T_f,n_mels).
+        wlens_dev (B,) i32 sample counts: reflect-pad every utterance at its own end (the utterance
+        decoded alone) instead of at the padded length N (torch.stft on the padded batch)."""
         L.require_gpu(speech, "speech")
         if self._packed is None or self._packed["device"] != speech.device:
             self.pack(speech.device)
@@ -86,8 +89,8 @@ class DefaultFrontend(torch.nn.Module):
         feats = torch.empty(B, T_f, self.n_mels, dtype=torch.float32, device=speech.device)
         L.check(L.load().em_frontend_logmel_f32(
             L.ptr(speech), B, N, self.hop_length, L.ptr(pk["window"]), L.ptr(pk["mel"]),
-            L.ptr(pk["lo"]), pk["maxlen"], self.n_mels, L.ptr(flens_dev), T_f, L.ptr(feats),
-            L.current_stream_ptr()), "em_frontend_logmel_f32")
+            L.ptr(pk["lo"]), pk["maxlen"], self.n_mels, L.ptr(flens_dev), L.ptr(wlens_dev), T_f,
+            L.ptr(feats), L.current_stream_ptr()), "em_frontend_logmel_f32")
         return feats
 
     def forward(self, input: torch.Tensor, input_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -20,6 +20,7 @@ from typing import Any, Dict, List, NamedTuple, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
+from espnet_amd.lib import TooShortUttError
 from espnet_amd.nets.beam_search import Hypothesis
 from espnet_amd.tasks.asr import ASRTask
 from espnet_amd.text.token_id_converter import TokenIDConverter, build_tokenizer
@@ -95,9 +96,10 @@ class Speech2Text:
     @torch.no_grad()
     def batch_decode(self, speech: torch.Tensor, speech_lengths: Sequence[int]):
         """speech (B, N) zero padded (host or device), lengths host ints.  Returns one reference-
-        shaped result list per utterance."""
+        shaped result list per utterance; row b is what `__call__` returns for utterance b alone
+        (isolated-utterance encoding: the reference decodes one utterance per call)."""
         speech = speech.to(self.device, torch.float32, non_blocking=True)
-        st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths])
+        st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths], isolate=True)
         if self.ctc_greedy:
             return self._finish_greedy(*self.decode_greedy_device(st))
         hyps = self.beam_search.search_batch(st.enc_act, st.olens, maxlenratio=self.maxlenratio,
@@ -137,3 +139,223 @@ class Speech2Text:
         if model_tag is not None:
             raise NotImplementedError("model zoo download needs network access (espnet_model_zoo)")
         return Speech2Text(**kwargs)
+
+
+# ---------------------------------------------------------------------- decode CLI (asr.sh stage 12)
+def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.0, batch_size: int = 1,
+              dtype: str = "bfloat16", beam_size: int = 20, ngpu: int = 1, seed: int = 0,
+              ctc_weight: float = 0.5, lm_weight: float = 1.0, ngram_weight: float = 0.9,
+              penalty: float = 0.0, nbest: int = 1, normalize_length: bool = False, num_workers: int = 1,
+              log_level: Union[int, str] = "INFO", data_path_and_name_and_type=None,
+              key_file: Optional[str] = None, asr_train_config: Optional[str] = None,
+              asr_model_file: Optional[str] = None, lm_train_config: Optional[str] = None,
+              lm_file: Optional[str] = None, word_lm_train_config: Optional[str] = None,
+              word_lm_file: Optional[str] = None, ngram_file: Optional[str] = None,
+              model_tag: Optional[str] = None, token_type: Optional[str] = None,
+              bpemodel: Optional[str] = None, allow_variable_data_keys: bool = False,
+              transducer_conf: Optional[dict] = None, streaming: bool = False, ctc_greedy: bool = False,
+              bucket_window: int = 8, **unsupported):
+    """The reference's `inference()` (espnet2/bin/asr_inference.py:716-906) for the MI355X path: same
+    keywords, same `output_dir/{n}best_recog/{token,token_int,score,text}` files in the key order of the
+    input, same per-utterance TooShortUttError fallback (:851-858) — but `batch_size > 1` decodes
+    length-bucketed utterance batches (`Speech2Text.batch_decode`) while reader threads load the next
+    window.  Returns the RTF summary it also logs (`utils/calculate_rtf.py` reads the log markers)."""
+    import time
+    from collections import deque
+
+    from espnet_amd.fileio.datadir_writer import DatadirWriter
+
+    if word_lm_train_config is not None:
+        raise NotImplementedError("Word LM is not implemented")
+    if ngpu > 1:
+        raise NotImplementedError("only single GPU decoding is supported per process: split the key file "
+                                  "like asr.sh does, or use espnet_amd.distributed.decode_sharded")
+    if ngpu < 1:
+        raise RuntimeError("espnet_amd decodes on an MI355X only: pass --ngpu 1 (no CPU fallback)")
+    logging.basicConfig(level=log_level,
+                        format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    speech2text = Speech2Text.from_pretrained(
+        model_tag=model_tag, asr_train_config=asr_train_config, asr_model_file=asr_model_file,
+        transducer_conf=transducer_conf, lm_train_config=lm_train_config, lm_file=lm_file,
+        ngram_file=ngram_file, token_type=token_type, bpemodel=bpemodel, device="cuda",
+        maxlenratio=maxlenratio, minlenratio=minlenratio, dtype=dtype, beam_size=beam_size,
+        ctc_weight=ctc_weight, lm_weight=lm_weight, ngram_weight=ngram_weight, penalty=penalty, nbest=nbest,
+        normalize_length=normalize_length, streaming=streaming, ctc_greedy=ctc_greedy, **unsupported)
+    loader = ASRTask.build_streaming_iterator(
+        data_path_and_name_and_type, dtype="float32", batch_size=batch_size, key_file=key_file,
+        num_workers=num_workers, preprocess_fn=ASRTask.build_preprocess_fn(speech2text.asr_train_args, False),
+        collate_fn=ASRTask.build_collate_fn(speech2text.asr_train_args, False),
+        allow_variable_data_keys=allow_variable_data_keys, inference=True, ngpu=ngpu,
+        bucket_window=bucket_window)
+    fs = 16000
+    fconf = getattr(speech2text.asr_train_args, "frontend_conf", None) or {}
+    if isinstance(fconf.get("fs", None), int):
+        fs = fconf["fs"]
+
+    def too_short():  # asr_inference.py:852-854
+        hyp = Hypothesis(score=0.0, scores={}, states={}, yseq=[])
+        return [(" ", ["<space>"], [2], hyp)] * nbest
+
+    def decode_batch(keys, batch):
+        speech, lens = batch["speech"], [int(n) for n in batch["speech_lengths"]]
+        for k, n in zip(keys, lens):
+            logger.info(f"speech length: {n}")  # one line per utterance, as :520
+        try:
+            return speech2text.batch_decode(speech, lens)
+        except TooShortUttError as e:
+            # a short utterance must not take the batch down: placeholder rows for the short ones
+            # (:851-858), the rest decoded as one smaller batch
+            bad = set(e.indices if e.indices is not None else range(len(keys)))
+            for i in sorted(bad):
+                logger.warning(f"Utterance {[keys[i]]} {e if len(bad) == 1 else 'is too short for subsampling'}")
+            good = [i for i in range(len(keys)) if i not in bad]
+            out = [too_short() for _ in keys]
+            if good:
+                sub = speech2text.batch_decode(speech[good, : max(lens[i] for i in good)], [lens[i] for i in good])
+                for i, r in zip(good, sub):
+                    out[i] = r
+            return out
+
+    pending, written, n_samples = {}, 0, 0
+    t0 = time.perf_counter()
+    with DatadirWriter(output_dir) as writer:
+        for keys, batch in loader:
+            assert all(isinstance(s, str) for s in keys), keys
+            assert len(keys) == batch["speech"].size(0)
+            n_samples += int(batch["speech_lengths"].sum())
+            for k, res in zip(keys, decode_batch(keys, batch)):
+                pending[k] = res
+            order = loader.key_order
+            while written < len(order) and order[written] in pending:  # emit in input order
+                key = order[written]
+                for n, (text, token, token_int, hyp) in zip(range(1, nbest + 1), pending.pop(key)):
+                    w = writer[f"{n}best_recog"]
+                    w["token"][key] = " ".join(token)
+                    w["token_int"][key] = " ".join(map(str, token_int))
+                    w["score"][key] = str(hyp.score)
+                    if text is not None:
+                        w["text"][key] = text
+                written += 1
+        assert not pending, sorted(pending)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    audio_s = n_samples / fs
+    summary = dict(utterances=written, audio_seconds=audio_s, wall_seconds=dt,
+                   rtf=dt / audio_s if audio_s else float("nan"))
+    logger.info("decoded %d utterances, %.1f audio-s in %.2f s: RTF %.5f (%.0f audio-s/s)", written, audio_s,
+                dt, summary["rtf"], audio_s / dt if dt else float("nan"))
+    return summary
+
+
+def _str2bool(v: str) -> bool:
+    if v.lower() in ("true", "1", "yes", "y", "t"):
+        return True
+    if v.lower() in ("false", "0", "no", "n", "f"):
+        return False
+    raise ValueError(f"not a boolean: {v!r}")
+
+
+def _str_or_none(v: str):
+    return None if v.strip().lower() in ("none", "null", "nil", "") else v
+
+
+def _str2triple_str(v: str):
+    """`path,name,type` (espnet2/utils/types.py str2triple_str)."""
+    parts = [p.strip().strip("()").strip("'\"") for p in v.split(",")]
+    if len(parts) != 3:
+        raise ValueError(f"expected 'path,name,type': {v!r}")
+    return tuple(parts)
+
+
+def get_parser():
+    """Option names, types and defaults of espnet2/bin/asr_inference.py:911-1137 for the options this
+    path implements; `--config` yaml files work like config_argparse; options of other tasks are
+    accepted at their reference default and rejected otherwise (Speech2Text checks)."""
+    import argparse
+
+    p = argparse.ArgumentParser(description="ASR Decoding (MI355X)",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--config", type=str, default=None, help="yaml file with option defaults")
+    p.add_argument("--log_level", type=lambda x: x.upper(), default="INFO",
+                   choices=("CRITICAL", "ERROR", "WARNING", "INFO", "DEBUG", "NOTSET"))
+    p.add_argument("--output_dir", type=str, required=True)
+    p.add_argument("--ngpu", type=int, default=1, help="must be 1: one MI355X per process")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"],
+                   help="MFMA mode of the encoder/decoder (float32 = exact-f32 MFMA)")
+    p.add_argument("--num_workers", type=int, default=1, help="audio reader threads")
+    g = p.add_argument_group("Input data related")
+    g.add_argument("--data_path_and_name_and_type", type=_str2triple_str, required=True, action="append")
+    g.add_argument("--key_file", type=_str_or_none)
+    g.add_argument("--allow_variable_data_keys", type=_str2bool, default=False)
+    g = p.add_argument_group("The model configuration related")
+    for name in ("asr_train_config", "asr_model_file", "lm_train_config", "lm_file", "word_lm_train_config",
+                 "word_lm_file", "ngram_file", "model_tag"):
+        g.add_argument(f"--{name}", type=str)
+    g = p.add_argument_group("Beam-search related")
+    g.add_argument("--batch_size", type=int, default=1, help="utterances per device batch")
+    g.add_argument("--bucket_window", type=int, default=8,
+                   help="read-ahead window, in batches, that is sorted by length before batching")
+    g.add_argument("--nbest", type=int, default=1)
+    g.add_argument("--beam_size", type=int, default=20)
+    g.add_argument("--penalty", type=float, default=0.0)
+    g.add_argument("--maxlenratio", type=float, default=0.0)
+    g.add_argument("--minlenratio", type=float, default=0.0)
+    g.add_argument("--ctc_weight", type=float, default=0.5)
+    g.add_argument("--lm_weight", type=float, default=1.0)
+    g.add_argument("--ngram_weight", type=float, default=0.9)
+    g.add_argument("--streaming", type=_str2bool, default=False)
+    g.add_argument("--normalize_length", type=_str2bool, default=False)
+    g.add_argument("--ctc_greedy", type=_str2bool, default=False,
+                   help="G1: arg-max + collapse on the device instead of the beam search")
+    g = p.add_argument_group("Text converter related")
+    g.add_argument("--token_type", type=_str_or_none, default=None, choices=["char", "bpe", "word", None])
+    g.add_argument("--bpemodel", type=_str_or_none, default=None)
+    g = p.add_argument_group("Options of other decoding modes (accepted at the reference default only)")
+    for name, typ, default in _OTHER_MODE_OPTIONS:
+        if typ == "list":
+            g.add_argument(f"--{name}", type=str, nargs="*", default=default)
+        else:
+            g.add_argument(f"--{name}", type=typ, default=default)
+    return p
+
+
+def _yaml_or_none(v: str):
+    import yaml
+
+    return None if v.strip().lower() in ("none", "null", "") else yaml.safe_load(v)
+
+
+# (name, type, reference default) of asr_inference.py:1010-1136 options that select other models
+_OTHER_MODE_OPTIONS = [
+    ("enh_s2t_task", _str2bool, False), ("multi_asr", _str2bool, False),
+    ("quantize_asr_model", _str2bool, False), ("quantize_lm", _str2bool, False),
+    ("quantize_modules", "list", ["Linear"]), ("quantize_dtype", str, "qint8"),
+    ("transducer_conf", _yaml_or_none, None), ("hugging_face_decoder", _str2bool, False),
+    ("hugging_face_decoder_conf", _yaml_or_none, {}), ("time_sync", _str2bool, False),
+    ("prompt_token_file", _str_or_none, None), ("lang_prompt_token", _str_or_none, None),
+    ("nlp_prompt_token", _str_or_none, None), ("partial_ar", _str2bool, False),
+    ("threshold_probability", float, 0.99), ("max_seq_len", int, 5), ("max_mask_parallel", int, -1),
+]
+
+
+def main(cmd=None):
+    import sys
+
+    import yaml
+
+    print(" ".join(sys.argv), file=sys.stderr)
+    parser = get_parser()
+    pre, _ = parser.parse_known_args(cmd)
+    if pre.config is not None:  # config_argparse: yaml values become defaults, flags still win
+        with open(pre.config, encoding="utf-8") as f:
+            parser.set_defaults(**(yaml.safe_load(f) or {}))
+    kwargs = vars(parser.parse_args(cmd))
+    kwargs.pop("config", None)
+    return inference(**kwargs)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,8 +1,10 @@
 // Depthwise Conv1d(k, zero pad (k-1)/2) + eval-mode BatchNorm1d + Swish of the Conformer
 // convolution module (espnet2/legacy/nets/pytorch_backend/conformer/convolution.py:72-75).
 // The BatchNorm affine (running stats) is folded into the depthwise weights/bias by the caller.
-// Bandwidth-bound; channel-last (B, T, d) so every access is coalesced over channels.  No padding
-// mask is applied (the reference lets padded frames leak into their neighbours; parity needs it).
+// Bandwidth-bound; channel-last (B, T, d) so every access is coalesced over channels.  Without
+// `tlens` no padding mask is applied (the reference lets the padded frames of a batch leak into
+// their neighbours; batched parity needs it); with `tlens` frames t >= tlens[b] read as zero, which
+// is what the utterance sees when it is decoded alone (asr_inference.py: one utterance per call).
 #include "em_common.h"
 
 namespace {
@@ -17,7 +19,8 @@ constexpr int KMAX = 31;
 template <typename T, int KW>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
                                                      const float* __restrict__ w,
-                                                     const float* __restrict__ bias, int Tn, int d,
+                                                     const float* __restrict__ bias,
+                                                     const int* __restrict__ tlens, int Tn, int d,
                                                      T* __restrict__ y) {
   constexpr int HALF = (KW - 1) / 2;
   constexpr int ROWS = TT + KW - 1;
@@ -27,6 +30,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
   const int c0 = blockIdx.x * 256, t0 = blockIdx.y * TT, b = blockIdx.z;
   const int tid = threadIdx.x;
   const T* xb = x + (size_t)b * Tn * d;
+  const int Tv = tlens ? (tlens[b] < Tn ? tlens[b] : Tn) : Tn;
   constexpr int NLD = (ROWS * CPR + 255) / 256;
   uint4 stage[NLD];
 #pragma unroll
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
     const int r = q / CPR, ch = q - r * CPR;
     const int t = t0 - HALF + r;
     stage[it] = make_uint4(0u, 0u, 0u, 0u);
-    if (q < ROWS * CPR && t >= 0 && t < Tn && c0 + ch * EPC < d)
+    if (q < ROWS * CPR && t >= 0 && t < Tv && c0 + ch * EPC < d)
       stage[it] = *(const uint4*)(xb + (size_t)t * d + c0 + ch * EPC);
   }
 #pragma unroll
@@ -68,14 +72,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
 }
 
 template <typename T>
-int launch_dw(const void* x, const float* w, const float* b, int B, int Tn, int d, int k, void* y,
-              hipStream_t s) {
+int launch_dw(const void* x, const float* w, const float* b, const int* tlens, int B, int Tn, int d,
+              int k, void* y, hipStream_t s) {
   if (d % (16 / (int)sizeof(T)) != 0) return EM_ERR_UNSUPPORTED;
   dim3 grid(em_cdiv(d, 256), em_cdiv(Tn, TT), B);
 #define EM_DW_CASE(KW)                                                                      \
   case KW:                                                                                  \
-    hipLaunchKernelGGL((dwconv_kernel<T, KW>), grid, dim3(256), 0, s, (const T*)x, w, b, Tn, \
-                       d, (T*)y);                                                           \
+    hipLaunchKernelGGL((dwconv_kernel<T, KW>), grid, dim3(256), 0, s, (const T*)x, w, b, tlens, \
+                       Tn, d, (T*)y);                                                       \
     break;
   switch (k) {
     EM_DW_CASE(3) EM_DW_CASE(7) EM_DW_CASE(15) EM_DW_CASE(31)
@@ -89,10 +93,10 @@ int launch_dw(const void* x, const float* w, const float* b, int B, int Tn, int 
 }  // namespace
 
 extern "C" int em_dwconv_bn_swish(int dtype, const void* x, const float* w, const float* b,
-                                  int32_t B, int32_t T, int32_t d, int32_t k, void* y,
-                                  void* stream) {
+                                  const int32_t* tlens, int32_t B, int32_t T, int32_t d, int32_t k,
+                                  void* y, void* stream) {
   if (B <= 0 || T <= 0 || d <= 0 || k > KMAX) return EM_ERR_BAD_ARG;
-  if (dtype == EM_F32) return launch_dw<float>(x, w, b, B, T, d, k, y, (hipStream_t)stream);
-  if (dtype == EM_BF16) return launch_dw<bf16>(x, w, b, B, T, d, k, y, (hipStream_t)stream);
+  if (dtype == EM_F32) return launch_dw<float>(x, w, b, tlens, B, T, d, k, y, (hipStream_t)stream);
+  if (dtype == EM_BF16) return launch_dw<bf16>(x, w, b, tlens, B, T, d, k, y, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
 }

@@ -92,7 +92,9 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
                                    const float* mvn_partial, const int32_t* flens,
                                    const int32_t* olens, int32_t B, int32_t T_f,
                                    const void* pos_emb, void* workspace, size_t workspace_bytes,
-                                   float* enc_out, void* enc_act, void* stream) {
+                                   float* enc_out, void* enc_act, int32_t flags, void* stream) {
+  // EM_ENC_ISOLATE_UTTS: the depthwise conv treats frames >= olens[b] as zero (see conv.hip)
+  const int32_t* conv_lens = (flags & EM_ENC_ISOLATE_UTTS) ? olens : nullptr;
   if (!w || !feats || !flens || !olens || !pos_emb || !workspace || !enc_out || !enc_act)
     return EM_ERR_BAD_ARG;
   if (dtype != EM_F32 && dtype != EM_BF16) return EM_ERR_BAD_ARG;
@@ -152,7 +154,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
       EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, ctx, q.wout, x, q.bout, M, d, d, 1.f, q.norm_conv_g,
                      q.norm_conv_b, nullptr, nullptr, xn, nullptr, stream));
       EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
-      EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, B, T, d, w->kernel, g2, stream));
+      EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, conv_lens, B, T, d, w->kernel, g2, stream));
       EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, g2, q.pw2, x, q.pw2_b, M, d, d, 1.f, q.norm_ff_g,
                      q.norm_ff_b, nullptr, nullptr, xn, nullptr, stream));
       EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
@@ -190,7 +192,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
       EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
       EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
-      EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, B, T, d, w->kernel, g2, stream));
+      EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, conv_lens, B, T, d, w->kernel, g2, stream));
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
       EM_TRY(em_ffn_fused_bf16(x, q.norm_ff_g, q.norm_ff_b, LN_EPS, q.ff_w1, q.ff_b1, q.ff_w2,
                                q.ff_b2, M, d, ff, 0.5f, stream));
@@ -218,7 +220,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     // convolution module
     EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
-    EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, B, T, d, w->kernel, g2, stream));
+    EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, conv_lens, B, T, d, w->kernel, g2, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
     // FFN
     EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));

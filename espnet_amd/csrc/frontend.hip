@@ -43,7 +43,8 @@ __device__ __forceinline__ int reflect_idx(int p, int N) {
 __global__ __launch_bounds__(256) void frontend_logmel_kernel(
     const float* __restrict__ wav, int N, int hop, const float* __restrict__ window,
     const float* __restrict__ melw, const int* __restrict__ mel_lo, int mel_maxlen, int n_mels,
-    const int* __restrict__ flens, int T_f, float* __restrict__ feats) {
+    const int* __restrict__ flens, const int* __restrict__ wlens, int T_f,
+    float* __restrict__ feats) {
   __shared__ float s_re[4][2][256];
   __shared__ float s_im[4][2][256];
   __shared__ float s_pow[4][264];
@@ -52,6 +53,9 @@ __global__ __launch_bounds__(256) void frontend_logmel_kernel(
   const int t_raw = blockIdx.x * 4 + wave;
   const int t = t_raw < T_f ? t_raw : T_f - 1;
   const float* x = wav + (size_t)b * N;
+  // reflect boundary: the padded batch length (what torch.stft sees for a padded batch) or, with
+  // wlens, this utterance's own length (what it sees when the utterance is decoded alone)
+  const int Nb = wlens ? (wlens[b] < N ? wlens[b] : N) : N;
   float(*re)[256] = s_re[wave];
   float(*im)[256] = s_im[wave];
 
@@ -61,7 +65,9 @@ __global__ __launch_bounds__(256) void frontend_logmel_kernel(
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     int n = lane + 64 * m;
-    int i0 = reflect_idx(start + 2 * n, N), i1 = reflect_idx(start + 2 * n + 1, N);
+    int i0 = reflect_idx(start + 2 * n, Nb), i1 = reflect_idx(start + 2 * n + 1, Nb);
+    i0 = i0 < 0 ? 0 : (i0 < N ? i0 : N - 1);  // frames past flens[b] are zeroed below: keep them in range
+    i1 = i1 < 0 ? 0 : (i1 < N ? i1 : N - 1);
     u[m] = make_float2(x[i0] * window[2 * n], x[i1] * window[2 * n + 1]);
   }
   // ---- stage p = 1 (no twiddles): out[4*lane + q]
@@ -134,14 +140,14 @@ __global__ __launch_bounds__(256) void frontend_logmel_kernel(
 extern "C" int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, int32_t hop,
                                       const float* window, const float* mel_packed,
                                       const int32_t* mel_lo, int32_t mel_maxlen, int32_t n_mels,
-                                      const int32_t* flens, int32_t T_f, float* feats,
-                                      void* stream) {
+                                      const int32_t* flens, const int32_t* wlens, int32_t T_f,
+                                      float* feats, void* stream) {
   if (B <= 0 || T_f <= 0) return EM_ERR_BAD_ARG;
   if (N <= 256 || hop <= 0 || T_f != 1 + N / hop) return EM_ERR_BAD_ARG;
   if (mel_maxlen < 1 || mel_maxlen > 257 || n_mels < 1) return EM_ERR_BAD_ARG;
   dim3 grid(em_cdiv(T_f, 4), B);
   hipLaunchKernelGGL(frontend_logmel_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, N, hop,
-                     window, mel_packed, mel_lo, mel_maxlen, n_mels, flens, T_f, feats);
+                     window, mel_packed, mel_lo, mel_maxlen, n_mels, flens, wlens, T_f, feats);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

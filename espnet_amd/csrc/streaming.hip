@@ -276,7 +276,7 @@ extern "C" int em_cb_encode_blocks(int dtype, const EmConformerWeights* w, float
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
     EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
-    EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, n_blk, L, d, w->kernel, g2, stream));
+    EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, nullptr, n_blk, L, d, w->kernel, g2, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
     EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(gemm(dtype, EM_EPI_RELU, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));

@@ -18,16 +18,18 @@ EM_F32, EM_BF16 = 0, 1
  EM_EPI_STORE_F32, EM_EPI_RESID_LN, EM_EPI_SCALE_LN, EM_EPI_ARGMAX_PART) = range(10)
 EM_A_PLAIN, EM_A_CONV2 = 0, 1
 
+EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flag (include/espnet_amd.h)
 DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
 
 
 class TooShortUttError(Exception):
     """Same contract as the reference's TooShortUttError (subsampling.py:14-29)."""
 
-    def __init__(self, message, actual_size, limit):
+    def __init__(self, message, actual_size, limit, indices=None):
         super().__init__(message)
         self.actual_size = actual_size
         self.limit = limit
+        self.indices = indices  # batch rows that are too short (utterance-batched entry only)
 
 
 class EspnetAmdError(RuntimeError):
@@ -121,7 +123,7 @@ _i32, _f32, _vp, _sz = C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 _SIGNATURES = {
     "em_version": (C.c_int, []),
     "em_error_string": (C.c_char_p, [C.c_int]),
-    "em_frontend_logmel_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp,
+    "em_frontend_logmel_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
                                          _i32, _vp, _vp]),
     "em_utt_mvn_partial_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "em_utt_mvn_apply_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -134,14 +136,14 @@ _SIGNATURES = {
     "em_layernorm_inplace_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "em_relpos_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _i32, _vp, _vp]),
-    "em_dwconv_bn_swish": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "em_dwconv_bn_swish": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "em_argmax_rows_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "em_argmax_partials": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "em_log_softmax_rows_f32": (C.c_int, [_vp, _i32, _i32, _vp]),
     "em_ctc_collapse": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "em_conformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32]),
     "em_conformer_encode": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _vp, _vp, _vp,
-                                      _i32, _i32, _vp, _vp, _sz, _vp, _vp, _vp]),
+                                      _i32, _i32, _vp, _vp, _sz, _vp, _vp, _i32, _vp]),
     "em_stream_pos_enc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "em_cb_build_blocks_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp,
                                          _vp]),

@@ -117,3 +117,71 @@ class ASRTask:
         model.to(device)
         model.eval()
         return model, args
+
+    # ------------------------------------------------------------------ decode-set iterator
+    @classmethod
+    def required_data_names(cls, train: bool = True, inference: bool = False):
+        """espnet2/tasks/asr.py:437-447."""
+        return ("speech",) if inference else ("speech", "text")
+
+    @classmethod
+    def build_preprocess_fn(cls, args, train: bool):
+        """Inference-time subset of `CommonPreprocessor` (espnet2/train/preprocessor.py:456-482 with
+        train=False: no RIR/noise; `speech_volume_normalize` and channel averaging still apply)."""
+        if train:
+            raise NotImplementedError("training-time preprocessing is outside the MI355X hot path")
+        if not _get(args, "use_preprocessor", True):
+            return None
+        pc = _get(args, "preprocessor_conf") or {}
+        vol = pc.get("speech_volume_normalize", _get(args, "speech_volume_normalize"))
+        single = bool(pc.get("force_single_channel", False))
+
+        def preprocess(uid, data):
+            import numpy as np
+
+            sp = data.get("speech")
+            if sp is not None:
+                if vol is not None:
+                    ma = np.max(np.abs(sp))
+                    if ma != 0:
+                        sp = sp * vol / ma
+                if single and sp.ndim == 2:
+                    sp = np.mean(sp, axis=1)
+                data["speech"] = sp
+            return data
+
+        return preprocess
+
+    @classmethod
+    def build_collate_fn(cls, args, train: bool):
+        """espnet2/tasks/asr.py:418-426: CommonCollateFn(float_pad_value=0.0, int_pad_value=-1)."""
+        from functools import partial
+
+        from espnet_amd.train.iterable_dataset import common_collate_fn
+
+        return partial(common_collate_fn, float_pad_value=0.0, int_pad_value=-1)
+
+    @classmethod
+    def build_streaming_iterator(cls, data_path_and_name_and_type, preprocess_fn=None, collate_fn=None,
+                                 key_file: Optional[str] = None, batch_size: int = 1, dtype="float32",
+                                 num_workers: int = 1, allow_variable_data_keys: bool = False, ngpu: int = 0,
+                                 inference: bool = False, bucket_window: int = 8):
+        """espnet2/tasks/abs_task.py:2403-2451, with utterance batches (batch_size > 1) cut from a
+        length-sorted read-ahead window; `.key_order` on the result gives the original order."""
+        from espnet_amd.train.iterable_dataset import (IterableESPnetDataset, StreamingBatchIterator,
+                                                       common_collate_fn)
+
+        if dtype in ("bfloat16", "float16"):
+            dtype = "float32"  # host-side sample dtype; the MFMA mode is Speech2Text's business
+        ds = IterableESPnetDataset(data_path_and_name_and_type, preprocess=preprocess_fn, float_dtype=dtype,
+                                   key_file=key_file)
+        for k in cls.required_data_names(False, inference):  # abs_task.py check_task_requirements
+            if not ds.has_name(k):
+                raise RuntimeError(f'"{k}" is required for {cls.__name__}. (--data_path_and_name_and_type)')
+        if not allow_variable_data_keys:
+            extra = set(ds.names()) - set(cls.required_data_names(False, inference)) - {"text"}
+            if extra:
+                raise RuntimeError(f"The data-name must be one of ('speech', 'text'): {sorted(extra)}")
+        return StreamingBatchIterator(ds, batch_size=batch_size, bucket_window=bucket_window,
+                                      num_workers=num_workers, collate_fn=collate_fn or common_collate_fn,
+                                      length_key="speech", pin_memory=ngpu > 0)

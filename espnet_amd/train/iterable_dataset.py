@@ -1,0 +1,185 @@
+"""Streaming decode-set iterator with length-bucketed utterance batches.
+
+Reference behaviour restated: `IterableESPnetDataset.__iter__` (espnet2/train/iterable_dataset.py:
+149-249: key order from `key_file` or the first scp, one line per file per key, keys must agree,
+optional preprocess, float arrays cast to `float_dtype`), `CommonCollateFn` (espnet2/train/
+collate_fn.py:17-95: pad to the longest with 0.0, add `<name>_lengths`) and
+`AbsTask.build_streaming_iterator` (espnet2/tasks/abs_task.py:2403-2451).
+
+MI355X-first difference: the reference decodes one utterance per step (`batch_size > 1` raises,
+asr_inference.py:760-761).  Here a window of `bucket_window * batch_size` utterances is read ahead by
+a pool of reader threads while the GPU decodes, sorted by length and cut into batches so padding
+waste stays small; `key_order` records the original order so the writer can emit results in it.
+"""
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from espnet_amd.fileio.sound_scp import load_entry
+
+
+class IterableESPnetDataset:
+    def __init__(self, path_name_type_list: Sequence[Tuple[str, str, str]],
+                 preprocess: Optional[Callable[[str, Dict[str, np.ndarray]], Dict[str, np.ndarray]]] = None,
+                 float_dtype: str = "float32", int_dtype: str = "long", key_file: Optional[str] = None):
+        if len(path_name_type_list) == 0:
+            raise ValueError('1 or more elements are required for "path_name_type_list"')
+        self.path_name_type_list = [tuple(x) for x in path_name_type_list]
+        names = [n for _, n, _ in self.path_name_type_list]
+        for n in names:
+            if names.count(n) > 1:
+                raise RuntimeError(f'"{n}" is duplicated for data-key')
+        self.preprocess, self.float_dtype, self.int_dtype, self.key_file = preprocess, float_dtype, int_dtype, key_file
+
+    def names(self) -> Tuple[str, ...]:
+        return tuple(n for _, n, _ in self.path_name_type_list)
+
+    def has_name(self, name) -> bool:
+        return name in self.names()
+
+    def entries(self) -> Iterator[Tuple[str, List[str]]]:
+        """(uid, [scp value per file]) in key order — text parsing only, no audio I/O."""
+        key_path = self.key_file if self.key_file is not None else self.path_name_type_list[0][0]
+        files = [open(p, encoding="utf-8") for p, _, _ in self.path_name_type_list]
+        count = 0
+        try:
+            with open(key_path, encoding="utf-8") as kf:
+                for line in kf:
+                    sp = line.rstrip().split(maxsplit=1)
+                    if not sp:
+                        continue
+                    uid = sp[0]
+                    count += 1
+                    while True:  # scp files may hold more keys than the key file: skip forward
+                        keys, values = [], []
+                        for f in files:
+                            try:
+                                ln = next(f)
+                            except StopIteration:
+                                raise RuntimeError(f"{uid} is not found in the files")
+                            s2 = ln.rstrip().split(maxsplit=1)
+                            if len(s2) != 2:
+                                raise RuntimeError(f"This line doesn't include a space: {f.name}: {ln!r}")
+                            keys.append(s2[0])
+                            values.append(s2[1])
+                        if any(k != keys[0] for k in keys):
+                            raise RuntimeError("Keys are mismatched. Text files are not sorted or not having same keys")
+                        if keys[0] == uid:
+                            break
+                    yield uid, values
+        finally:
+            for f in files:
+                f.close()
+        if count == 0:
+            raise RuntimeError("No iteration")
+
+    def load(self, uid: str, values: List[str]) -> Dict[str, np.ndarray]:
+        data = {name: load_entry(v, kind) for v, (_, name, kind) in zip(values, self.path_name_type_list)}
+        if self.preprocess is not None:
+            data = self.preprocess(uid, data)
+        for name, v in data.items():
+            if not isinstance(v, np.ndarray):
+                raise RuntimeError(f'All values must be converted to np.ndarray object by preprocessing, '
+                                   f'but "{name}" is still {type(v)}.')
+            if v.dtype.kind == "f":
+                data[name] = v.astype(self.float_dtype)
+            elif v.dtype.kind == "i":
+                data[name] = v.astype(self.int_dtype)
+            else:
+                raise NotImplementedError(f"Not supported dtype: {v.dtype}")
+        return data
+
+    def __iter__(self):
+        for uid, values in self.entries():
+            yield uid, self.load(uid, values)
+
+
+def common_collate_fn(data: List[Tuple[str, Dict[str, np.ndarray]]], float_pad_value: float = 0.0,
+                      int_pad_value: int = -32768):
+    """[(uid, {name: array})] -> (uids, {name: (B, Lmax, ...) tensor, name_lengths: (B,) long})."""
+    uids = [u for u, _ in data]
+    dicts = [d for _, d in data]
+    if not all(set(d) == set(dicts[0]) for d in dicts):
+        raise RuntimeError("dict-keys mismatching")
+    out = {}
+    for key in dicts[0]:
+        arrs = [d[key] for d in dicts]
+        pad = int_pad_value if arrs[0].dtype.kind == "i" else float_pad_value
+        lens = [a.shape[0] for a in arrs]
+        buf = np.full((len(arrs), max(lens)) + arrs[0].shape[1:], pad, dtype=arrs[0].dtype)
+        for i, a in enumerate(arrs):
+            buf[i, : lens[i]] = a
+        out[key] = torch.from_numpy(buf)
+        out[key + "_lengths"] = torch.tensor(lens, dtype=torch.long)
+    return uids, out
+
+
+class StreamingBatchIterator:
+    """Iterable of `(keys, batch)`; `key_order` grows with the original key order as windows are read."""
+
+    def __init__(self, dataset: IterableESPnetDataset, batch_size: int = 1, bucket_window: int = 8,
+                 num_workers: int = 1, collate_fn=common_collate_fn, length_key: Optional[str] = None,
+                 prefetch_batches: int = 4, pin_memory: bool = False):
+        if batch_size < 1 or bucket_window < 1:
+            raise ValueError("batch_size and bucket_window must be >= 1")
+        self.dataset, self.batch_size, self.window = dataset, batch_size, batch_size * bucket_window
+        self.num_workers, self.collate_fn = max(1, num_workers), collate_fn
+        self.length_key = length_key or dataset.names()[0]
+        self.prefetch, self.pin_memory = prefetch_batches, pin_memory
+        self.key_order: List[str] = []
+
+    def _windows(self):
+        buf = []
+        for e in self.dataset.entries():
+            buf.append(e)
+            if len(buf) == self.window:
+                yield buf
+                buf = []
+        if buf:
+            yield buf
+
+    def _produce(self, q: "queue.Queue", stop: threading.Event):
+        try:
+            with ThreadPoolExecutor(self.num_workers) as pool:
+                for win in self._windows():
+                    loaded = list(pool.map(lambda e: (e[0], self.dataset.load(*e)), win))
+                    self.key_order.extend(u for u, _ in loaded)
+                    # longest first, ties in file order (stable): batches of near-equal length
+                    order = sorted(range(len(loaded)), key=lambda i: -loaded[i][1][self.length_key].shape[0])
+                    for s in range(0, len(order), self.batch_size):
+                        keys, batch = self.collate_fn([loaded[i] for i in order[s : s + self.batch_size]])
+                        if self.pin_memory:
+                            batch = {k: v.pin_memory() for k, v in batch.items()}
+                        while not stop.is_set():
+                            try:
+                                q.put((keys, batch), timeout=0.1)
+                                break
+                            except queue.Full:
+                                continue
+                        if stop.is_set():
+                            return
+            q.put(None)
+        except BaseException as e:  # surface reader errors in the consumer
+            q.put(e)
+
+    def __iter__(self):
+        q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+        self.key_order = []
+        th = threading.Thread(target=self._produce, args=(q, stop), daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            th.join(timeout=5.0)

@@ -86,11 +86,16 @@ const char* em_error_string(int code);
  *   mel_packed [mel_maxlen][n_mels] f32: mel_packed[s][m] = melmat[mel_lo[m]+s][m] (0 past the band)
  *   mel_lo     [n_mels] i32 first non-zero rFFT bin of each filter
  *   flens      [B] i32 valid frames per utterance (stft.py:108-115); frames >= flens are zeroed
+ *   wlens      [B] i32 valid samples per utterance, or NULL.  NULL: the reflect padding of
+ *              center=True sits at the padded length N, which is what torch.stft does for a padded
+ *              batch.  Given: it sits at each utterance's own end, i.e. what the utterance gets when
+ *              Speech2Text decodes it alone (asr_inference.py:514, one utterance per call); every
+ *              wlens[b] must exceed n_fft/2 like torch.stft's own reflect-pad check
  *   feats      [B][T_f][n_mels] f32 out, T_f = 1 + N/hop                                         */
 int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, int32_t hop, const float* window,
                            const float* mel_packed, const int32_t* mel_lo, int32_t mel_maxlen,
-                           int32_t n_mels, const int32_t* flens, int32_t T_f, float* feats,
-                           void* stream);
+                           int32_t n_mels, const int32_t* flens, const int32_t* wlens, int32_t T_f,
+                           float* feats, void* stream);
 
 /* ---- A3: utterance_mvn (espnet2/layers/utterance_mvn.py:45-88), first half: per-utterance
  *      partial column sums over the valid frames.  partial [B][8][n_mels] f32 out.  The mean
@@ -155,9 +160,12 @@ int em_relpos_attention(int dtype, const void* qkv, const void* p, int32_t ldp, 
                         int32_t dk, void* ctx, void* stream);
 
 /* ---- A8 (middle): depthwise Conv1d(k, pad (k-1)/2) + eval BatchNorm1d (folded into w,b by the
- *      caller) + Swish (conformer/convolution.py:72-75).  x,y [B][T][d] act; w [k][d] f32 (tap-major).       */
-int em_dwconv_bn_swish(int dtype, const void* x, const float* w, const float* b, int32_t B,
-                       int32_t T, int32_t d, int32_t k, void* y, void* stream);
+ *      caller) + Swish (conformer/convolution.py:72-75).  x,y [B][T][d] act; w [k][d] f32 (tap-major).
+ *      tlens [B] i32 or NULL: with lengths, input frames t >= tlens[b] read as zero (the utterance
+ *      decoded alone); NULL reproduces the reference's unmasked conv over a padded batch.          */
+int em_dwconv_bn_swish(int dtype, const void* x, const float* w, const float* b,
+                       const int32_t* tlens, int32_t B, int32_t T, int32_t d, int32_t k, void* y,
+                       void* stream);
 
 /* ---- A11 / G1: CTC head.  argmax over vocab (asr/ctc.py:207-215), then groupby + drop
  *      blank/sos/eos (bin/asr_inference.py:574-575).  logits [M][V] f32.                        */
@@ -209,6 +217,9 @@ typedef struct EmConformerWeights {
   const EmConformerLayer* layers; /* [num_blocks], host array */
 } EmConformerWeights;
 
+/* em_conformer_encode flags */
+#define EM_ENC_ISOLATE_UTTS 1 /* every utterance of a ragged batch encodes as if it were alone */
+
 /* bytes of scratch em_conformer_encode needs for (B, T_f) */
 size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t B, int32_t T_f);
 
@@ -218,11 +229,15 @@ size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int3
  *              both from the lengths exactly as the reference's masks do)
  *   pos_emb    [2T-1][d] act: RelPositionalEncoding table rows (embedding.py:286-332)
  *   enc_out    [B][T][d] f32 out (after_norm applied); enc_act same in act dtype (input of the
- *              CTC / decoder projections), T = ((T_f-1)/2-1)/2                                   */
+ *              CTC / decoder projections), T = ((T_f-1)/2-1)/2
+ *   flags      0: padded-batch semantics of ConformerEncoder.forward (padded frames leak through the
+ *              unmasked depthwise conv, convolution.py:72);  EM_ENC_ISOLATE_UTTS: batching is
+ *              transparent, row b equals the encoding of utterance b alone                        */
 int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* feats,
                         const float* mvn_partial, const int32_t* flens, const int32_t* olens,
                         int32_t B, int32_t T_f, const void* pos_emb, void* workspace,
-                        size_t workspace_bytes, float* enc_out, void* enc_act, void* stream);
+                        size_t workspace_bytes, float* enc_out, void* enc_act, int32_t flags,
+                        void* stream);
 
 /* ---- A11 + G1 assembled: ctc_lo GEMM (+ arg-max fused in its epilogue) -> collapse.
  *   enc_act [B*T][d] act; w_ctc [V][d] act; logits_ws >= B*T * 2*ceil(V/128) * 2 f32 scratch;

@@ -213,6 +213,52 @@ def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weigh
           f"best len={len(results[0][3].yseq)} score={float(results[0][3].score):.4f} keys={keys}")
 
 
+def cli_wave(utt_id, n):
+    """int16-quantised synthetic waveform of the decode-CLI golden (so the wav file is the input)."""
+    return np.clip(np.rint(synth_waveform(utt_id, n).numpy().astype(np.float64) * 32768.0), -32768, 32767).astype("<i2")
+
+
+def run_cli_case(name, conf, vocab, wseed, utts, beam, ctc_weight, nbest):
+    """The reference's decode CLI end to end (espnet2/bin/asr_inference.py `main`): wav.scp of 16-bit
+    PCM files -> output_dir/{n}best_recog/{token,token_int,score,text}.  `utts` = [(key, utt_id, n)]
+    in wav.scp order; a too-short entry exercises the TooShortUttError fallback (:851-858)."""
+    import wave
+
+    from espnet2.bin.asr_inference import main as ref_main
+
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        s2t, cfg_text = build_reference(conf, vocab, td, beam_size=beam, ctc_weight=ctc_weight, nbest=nbest)
+        shapes = load_recipe(s2t.asr_model, wseed)
+        torch.save(s2t.asr_model.state_dict(), td / "model.pth")
+        lines = []
+        for key, u, n in utts:
+            with wave.open(str(td / f"{key}.wav"), "wb") as w:
+                w.setnchannels(1), w.setsampwidth(2), w.setframerate(16000)
+                w.writeframes(cli_wave(u, n).tobytes())
+            lines.append(f"{key} {td / (key + '.wav')}")
+        (td / "wav.scp").write_text("\n".join(lines) + "\n")
+        ref_main(cmd=["--output_dir", str(td / "out"), "--ngpu", "0", "--dtype", "float32",
+                      "--data_path_and_name_and_type", f"{td / 'wav.scp'},speech,sound",
+                      "--asr_train_config", str(td / "asr" / "config.yaml"),
+                      "--asr_model_file", str(td / "model.pth"), "--beam_size", str(beam),
+                      "--ctc_weight", str(ctc_weight), "--nbest", str(nbest), "--lm_weight", "0.0",
+                      "--batch_size", "1", "--num_workers", "0"])
+        files = {}
+        for f in sorted((td / "out").rglob("*")):
+            if f.is_file():
+                files[str(f.relative_to(td / "out"))] = f.read_text()
+    np.savez_compressed(HERE / f"{name}.npz", config_yaml=np.array(cfg_text), vocab=np.array(vocab),
+                        wseed=np.array(wseed), utts=np.array(json.dumps(utts)), beam=np.array(beam),
+                        ctc_weight=np.array(ctc_weight), nbest=np.array(nbest),
+                        state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+                        melmat=s2t.asr_model.frontend.logmel.melmat.numpy(),
+                        files=np.array(json.dumps(files)))
+    print(f"[{name}] done in {time.time()-t0:.1f}s files={sorted(files)}")
+    print(files.get("1best_recog/token_int", "")[:400])
+
+
 def run_lm_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weight, lm_weight, nbest,
                        lm_conf):
     """Speech2Text with a TransformerLM scorer (espnet2/bin/asr_inference.py:179-191, weight
@@ -431,6 +477,11 @@ CASES = {
     "e2e_beam5_lm": lambda: run_lm_search_case(
         "e2e_beam5_lm", tiny(d=128, heads=2, ff=128), 50, 11, 17, 40000, 5, 0.3, 0.6, 5,
         dict(pos_enc=None, embed_unit=64, att_unit=128, head=2, unit=128, layer=2)),
+    # decode CLI: ragged wav.scp incl. one utterance below the subsampling limit
+    "cli_decode": lambda: run_cli_case(
+        "cli_decode", tiny(d=128, heads=2, ff=128), 50, 13,
+        [["uttA", 31, 28000], ["uttB", 32, 9000], ["uttC", 33, 500], ["uttD", 34, 41000],
+         ["uttE", 35, 16000], ["uttF", 36, 23456], ["uttG", 37, 33000]], 3, 0.3, 2),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

@@ -1,0 +1,203 @@
+"""Host side of the decode CLI: file formats, the bucketed iterator and the
+parser — no GPU.  References: espnet2/fileio/datadir_writer.py, fileio/sound_scp.py,
+train/iterable_dataset.py, train/collate_fn.py, bin/asr_inference.py:911-1137."""
+import json
+import struct
+import wave
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from espnet_amd.fileio.datadir_writer import DatadirWriter
+from espnet_amd.fileio.read_text import read_2columns_text
+from espnet_amd.fileio.sound_scp import SoundScpReader, read_wav, write_wav_pcm16
+from espnet_amd.train.iterable_dataset import IterableESPnetDataset, StreamingBatchIterator, common_collate_fn
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def test_datadir_writer_layout_and_guards(tmp_path):
+    with DatadirWriter(tmp_path / "out") as w:
+        w["1best_recog"]["token"]["utt1"] = "a b c"
+        w["1best_recog"]["token"]["utt2"] = ""
+        w["1best_recog"]["score"]["utt1"] = "-1.5"
+        with pytest.raises(RuntimeError):
+            w["1best_recog"]["x"] = "y"  # a directory node takes no lines
+        with pytest.raises(RuntimeError):
+            w["1best_recog"]["token"]["sub"]  # a file node has no children
+        with pytest.warns(UserWarning, match="Duplicated"):
+            w["1best_recog"]["token"]["utt1"] = "again"
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            w.close()
+        assert any("mismatching" in str(r.message) for r in rec)  # token has utt2, score does not
+    assert (tmp_path / "out/1best_recog/token").read_text() == "utt1 a b c\nutt2 \nutt1 again\n"
+    assert (tmp_path / "out/1best_recog/score").read_text() == "utt1 -1.5\n"
+
+
+def test_read_2columns_text(tmp_path):
+    p = tmp_path / "wav.scp"
+    p.write_text("k1 /a b/c.wav\nk2\nk3   x\n")
+    assert read_2columns_text(p) == {"k1": "/a b/c.wav", "k2": "", "k3": "x"}
+    p.write_text("k1 a\nk1 b\n")
+    with pytest.raises(RuntimeError, match="duplicated"):
+        read_2columns_text(p)
+
+
+@pytest.mark.parametrize("width", [1, 2, 3, 4])
+def test_read_wav_pcm_matches_stdlib_wave(tmp_path, width):
+    """Integer PCM of every width: value / 2**(8w-1) (8-bit unsigned), mono and stereo."""
+    rng = np.random.default_rng(width)
+    for nch in (1, 2):
+        n = 777
+        if width == 1:
+            ints = rng.integers(0, 256, size=(n, nch))
+            raw = ints.astype(np.uint8).tobytes()
+            want = (ints - 128) / 128.0
+        else:
+            lim = 2 ** (8 * width - 1)
+            ints = rng.integers(-lim, lim, size=(n, nch))
+            raw = b"".join(int(v).to_bytes(width, "little", signed=True) for v in ints.reshape(-1))
+            want = ints / float(lim)
+        f = tmp_path / f"w{width}_{nch}.wav"
+        with wave.open(str(f), "wb") as w:
+            w.setnchannels(nch), w.setsampwidth(width), w.setframerate(8000)
+            w.writeframes(raw)
+        x, rate = read_wav(f)
+        assert rate == 8000 and x.dtype == np.float64
+        assert x.shape == ((n,) if nch == 1 else (n, nch))
+        np.testing.assert_array_equal(x.reshape(n, nch), want)
+
+
+def test_read_wav_float_extra_chunks_and_errors(tmp_path):
+    x = np.linspace(-1, 1, 101, dtype="<f4")
+    body = x.tobytes()
+    fmt = struct.pack("<HHIIHH", 3, 1, 16000, 16000 * 4, 4, 32)
+    junk = b"LIST" + struct.pack("<I", 3) + b"abc" + b"\x00"  # odd-sized chunk + pad byte
+    riff = b"WAVE" + junk + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(body)) + body
+    f = tmp_path / "f32.wav"
+    f.write_bytes(b"RIFF" + struct.pack("<I", len(riff)) + riff)
+    y, rate = read_wav(f, dtype="float32")
+    assert rate == 16000
+    np.testing.assert_array_equal(y, x)
+    (tmp_path / "a.flac").write_bytes(b"fLaC" + b"\0" * 40)
+    with pytest.raises(NotImplementedError):
+        read_wav(tmp_path / "a.flac")
+    with pytest.raises(NotImplementedError):
+        read_wav("sox a.wav -t wav - |")
+
+
+def test_write_wav_roundtrip_and_scp_reader(tmp_path):
+    rng = np.random.default_rng(0)
+    x = (rng.integers(-32768, 32768, size=1000) / 32768.0).astype(np.float32)
+    write_wav_pcm16(tmp_path / "a.wav", x, 16000)
+    with wave.open(str(tmp_path / "a.wav"), "rb") as w:  # a standard reader agrees on the container
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 16000, 1000)
+    (tmp_path / "wav.scp").write_text(f"u1 {tmp_path / 'a.wav'}\n")
+    r = SoundScpReader(tmp_path / "wav.scp")
+    rate, y = r["u1"]
+    assert rate == 16000 and list(r) == ["u1"] and len(r) == 1 and "u1" in r
+    np.testing.assert_array_equal(y, x.astype(np.float64))
+
+
+def _make_set(tmp_path, lens):
+    lines = []
+    for i, n in enumerate(lens):
+        np.save(tmp_path / f"u{i}.npy", np.full(n, i, dtype=np.float64))
+        lines.append(f"u{i} {tmp_path / f'u{i}.npy'}")
+    (tmp_path / "feats.scp").write_text("\n".join(lines) + "\n")
+    return str(tmp_path / "feats.scp")
+
+
+def test_iterable_dataset_order_keyfile_and_dtype(tmp_path):
+    scp = _make_set(tmp_path, [5, 3, 9, 4])
+    ds = IterableESPnetDataset([(scp, "speech", "npy")])
+    got = list(ds)
+    assert [u for u, _ in got] == ["u0", "u1", "u2", "u3"]
+    assert all(d["speech"].dtype == np.float32 for _, d in got)  # float_dtype cast (:240-243)
+    (tmp_path / "keys").write_text("u1\nu3\n")
+    ds = IterableESPnetDataset([(scp, "speech", "npy")], key_file=str(tmp_path / "keys"))
+    assert [u for u, _ in ds] == ["u1", "u3"]
+    (tmp_path / "keys").write_text("u1\nzz\n")
+    with pytest.raises(RuntimeError, match="not found"):
+        list(IterableESPnetDataset([(scp, "speech", "npy")], key_file=str(tmp_path / "keys")))
+    (tmp_path / "empty").write_text("")
+    with pytest.raises(RuntimeError, match="No iteration"):
+        list(IterableESPnetDataset([(scp, "speech", "npy")], key_file=str(tmp_path / "empty")))
+    with pytest.raises(NotImplementedError):
+        list(IterableESPnetDataset([(scp, "speech", "kaldi_ark")]))
+
+
+def test_collate_pads_and_reports_lengths():
+    data = [("a", {"speech": np.ones(3, np.float32)}), ("b", {"speech": np.ones(5, np.float32)})]
+    keys, batch = common_collate_fn(data)
+    assert keys == ["a", "b"] and batch["speech"].shape == (2, 5)
+    assert batch["speech"][0].tolist() == [1, 1, 1, 0, 0] and batch["speech_lengths"].tolist() == [3, 5]
+
+
+@pytest.mark.parametrize("batch_size,window,workers", [(1, 1, 1), (3, 2, 2), (4, 8, 3), (16, 1, 1)])
+def test_bucketed_iterator_covers_all_and_sorts_within_window(tmp_path, batch_size, window, workers):
+    lens = [7, 30, 12, 5, 22, 22, 9, 40, 3, 18, 27]
+    scp = _make_set(tmp_path, lens)
+    ds = IterableESPnetDataset([(scp, "speech", "npy")])
+    it = StreamingBatchIterator(ds, batch_size=batch_size, bucket_window=window, num_workers=workers,
+                                length_key="speech")
+    seen, batches = [], []
+    for keys, batch in it:
+        assert len(keys) <= batch_size and batch["speech"].shape[0] == len(keys)
+        bl = batch["speech_lengths"].tolist()
+        assert bl == sorted(bl, reverse=True)  # longest first inside a batch
+        for k, n, row in zip(keys, bl, batch["speech"]):
+            i = int(k[1:])
+            assert n == lens[i] and row[:n].eq(i).all() and row[n:].eq(0).all()
+        seen += keys
+        batches.append(bl)
+    assert sorted(seen) == sorted(f"u{i}" for i in range(len(lens)))
+    assert it.key_order == [f"u{i}" for i in range(len(lens))]
+    w = batch_size * window
+    for s in range(0, len(lens), w):  # a window's utterances come out before the next window's
+        assert set(seen[s : s + w]) == {f"u{i}" for i in range(s, min(s + w, len(lens)))}
+    if batch_size == 4 and window == 8:  # one window: globally sorted -> padding waste is minimal
+        flat = [n for b in batches for n in b]
+        assert flat == sorted(lens, reverse=True)
+
+
+def test_iterator_surfaces_reader_errors(tmp_path):
+    scp = _make_set(tmp_path, [4, 4])
+    (tmp_path / "u1.npy").unlink()
+    it = StreamingBatchIterator(IterableESPnetDataset([(scp, "speech", "npy")]), batch_size=2)
+    with pytest.raises(FileNotFoundError):
+        list(it)
+
+
+def test_parser_matches_reference_option_table():
+    """Every option of the reference CLI is accepted; defaults are the reference's except the three
+    documented ones (ngpu: no CPU path; dtype: MFMA mode names; token_type also lists "word")."""
+    from espnet_amd.bin.asr_inference import get_parser
+
+    ref = json.loads((GOLD / "asr_inference_cli_options.json").read_text())
+    mine = {a.dest: a for a in get_parser()._actions if a.dest != "help"}
+    assert set(ref) <= set(mine), sorted(set(ref) - set(mine))
+    assert set(mine) - set(ref) == {"bucket_window", "ctc_greedy"}
+    for name, r in ref.items():
+        a = mine[name]
+        assert a.required == r["required"], name
+        if name in ("ngpu", "dtype"):
+            continue
+        d = r["default"]
+        if name == "hugging_face_decoder_conf":
+            d = {}
+        assert a.default == d, (name, a.default, d)
+    assert mine["ngpu"].default == 1 and mine["dtype"].default == "bfloat16"
+
+
+def test_cli_refuses_cpu_and_multi_gpu(tmp_path):
+    from espnet_amd.bin.asr_inference import main
+
+    base = ["--output_dir", str(tmp_path / "o"), "--data_path_and_name_and_type", "x.scp,speech,sound"]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        main(base + ["--ngpu", "0"])
+    with pytest.raises(NotImplementedError, match="single GPU"):
+        main(base + ["--ngpu", "2"])

@@ -146,3 +146,44 @@ def test_long_and_ragged_utterances_f32():
         diff = ids[b, :n].cpu().long() != ref_ids[b, :n]
         assert (margin[b, :n][diff] < 1e-4).all()
         assert diff.float().mean().item() < 0.01
+
+
+def test_isolated_utterance_batching_is_transparent_f32():
+    """`encode_device(..., isolate=True)` (what Speech2Text.batch_decode and the decode CLI use): every
+    row of a ragged batch equals the ORACLE's encoding of that utterance decoded alone — reflect padding
+    at the utterance's own end, depthwise conv blind to the padded frames — including a 0.56 s
+    utterance (T = 13) next to a 2.6 s one.  The padded-batch mode (isolate=False) is the reference's
+    `ESPnetASRModel.encode` on the padded batch and must differ at the short rows' tail."""
+    from espnet_amd.tasks.asr import ASRTask
+    from oracle.weights import synth_waveform
+
+    g = load_golden("small_10s")
+    sd = golden_state_dict(g)
+    cfg = dict(g["config"])
+    cfg["compute_dtype"] = "float32"
+    model = ASRTask.build_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.cuda().eval()
+    lens = [41000, 9000, 23456, 41000, 1500]
+    speech = torch.zeros(len(lens), max(lens))
+    for i, n in enumerate(lens):
+        speech[i, :n] = synth_waveform(60 + i, n)
+    hp = hparams(g)
+    st = model.encode_device(speech.cuda(), lens, isolate=True)
+    st_pad = model.encode_device(speech.cuda(), lens, isolate=False)
+    worst_pad = 0.0
+    for b, n in enumerate(lens):
+        with torch.no_grad():
+            ref, ol = oc.encode(sd, speech[b : b + 1, :n], torch.tensor([n]), hp["heads"], hp["num_blocks"],
+                                hp["n_fft"], hp["win_length"], hp["hop"])
+        T = int(ol[0])
+        assert st.olens[b] == T
+        err = (st.enc_out[b, :T].cpu() - ref[0]).abs().max().item()
+        assert err < 2e-3, (b, err)
+        worst_pad = max(worst_pad, (st_pad.enc_out[b, :T].cpu() - ref[0]).abs().max().item())
+    assert worst_pad > 1e-2  # the two semantics are genuinely different on ragged input
+    # equal lengths: both modes are the same computation
+    eq = speech[[0, 3]].cuda()
+    a = model.encode_device(eq, [41000, 41000], isolate=True).enc_out
+    b = model.encode_device(eq, [41000, 41000], isolate=False).enc_out
+    assert torch.equal(a, b)

@@ -241,9 +241,22 @@ def test_dwconv_bn_swish(lib, k):
         y = F.batch_norm(y, mean, var, gam, bet, False, 0.0, 1e-5)
         ref = oc.swish(y).transpose(1, 2)
         out = torch.zeros(B, T, d, dtype=tdt, device="cuda")
-        L.check(lib.em_dwconv_bn_swish(dt, L.ptr(dev(xq.to(tdt))), L.ptr(dev(wf.t().contiguous())), L.ptr(dev(bf)), B, T,
+        L.check(lib.em_dwconv_bn_swish(dt, L.ptr(dev(xq.to(tdt))), L.ptr(dev(wf.t().contiguous())), L.ptr(dev(bf)), None, B, T,
                                        d, k, L.ptr(out), sptr()))
         assert_close(out, ref, tol, f"dwconv {prec}")
+        # with lengths: frames t >= tlens[b] read as zero (the utterance decoded alone)
+        tl = [T, max(1, T // 3)][:B] + [T] * max(0, B - 2)
+        xm = xq.clone()
+        for bi, n in enumerate(tl):
+            xm[bi, n:] = 0
+        ym = F.conv1d(xm.transpose(1, 2), w, b, padding=(k - 1) // 2, groups=d)
+        ym = oc.swish(F.batch_norm(ym, mean, var, gam, bet, False, 0.0, 1e-5)).transpose(1, 2)
+        out2 = torch.zeros(B, T, d, dtype=tdt, device="cuda")
+        L.check(lib.em_dwconv_bn_swish(dt, L.ptr(dev(xq.to(tdt))), L.ptr(dev(wf.t().contiguous())), L.ptr(dev(bf)),
+                                       L.ptr(torch.tensor(tl, dtype=torch.int32, device="cuda")), B, T, d, k,
+                                       L.ptr(out2), sptr()))
+        for bi, n in enumerate(tl):
+            assert_close(out2[bi, :n], ym[bi, :n], tol, f"dwconv masked {prec}")
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
