@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--streams", type=int, default=1,
                     help="split the per-GPU batch over this many HIP streams (independent utterances)")
+    ap.add_argument("--graph", action="store_true",
+                    help="greedy workload: capture the whole pass (all --streams branches) in one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -325,7 +327,14 @@ def main():
             main.wait_stream(s)
         return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
 
+    graph = {}
+
     def step():
+        if graph:
+            graph["g"].replay()
+            if world > 1:
+                collate(*graph["out"])
+            return graph["out"]
         if streams and beam_search is None:
             tokens, tlens = step_multistream()
             if world > 1:
@@ -356,6 +365,19 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
+        if args.graph and beam_search is None:
+            # the pass has no host-dependent control flow (lengths live on the device), so the whole
+            # frontend -> encoder -> greedy CTC chain, with its fork/join over --streams, is one graph
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                if streams:
+                    out_g = step_multistream()
+                else:
+                    out_g = model.greedy_ctc_device(model.encode_device(wav, lens))[1:]
+            graph.update(g=g, out=out_g)
+            for _ in range(2):
+                step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -400,6 +422,7 @@ def main():
         tot_ms = tot_fl = 0.0
         launches = 0
         nprof = max(1, min(args.steps, 5 if beam_search is None else 1))
+        graph.clear()  # event bracketing needs live launches
         with torch.no_grad():
             for _ in range(nprof):
                 lib.em_profile_attach(prof)

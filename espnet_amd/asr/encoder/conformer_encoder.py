@@ -160,6 +160,7 @@ class ConformerEncoder(torch.nn.Module):
         self._packed = None
         self._pos_cache = {}
         self._ws = None
+        self._olens_cache = {}
 
     def output_size(self) -> int:
         return self._output_size
@@ -283,7 +284,13 @@ class ConformerEncoder(torch.nn.Module):
             olens = [conv2d_subsampled_lengths([n], int(n))[0] for n in flens]
         else:  # the padded mask is sliced, so padded rows keep up to two frames more (subsampling.py:448)
             olens = conv2d_subsampled_lengths(flens, T_f)
-        olens_dev = torch.tensor(olens, dtype=torch.int32).to(dev, non_blocking=True)
+        okey = (tuple(olens), dev)
+        olens_dev = self._olens_cache.get(okey)
+        if olens_dev is None:  # kept on the device for repeating batch shapes (see encode_device)
+            olens_dev = torch.tensor(olens, dtype=torch.int32).to(dev, non_blocking=True)
+            if len(self._olens_cache) >= 8:
+                self._olens_cache.pop(next(iter(self._olens_cache)))
+            self._olens_cache[okey] = olens_dev
         need = lib.em_conformer_workspace_bytes(self.em_dtype, C.byref(pk["w"]), B, T_f)
         # one workspace per stream: independent utterance batches may be encoded concurrently on
         # different HIP streams

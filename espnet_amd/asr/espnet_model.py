@@ -59,6 +59,7 @@ class ESPnetASRModel(torch.nn.Module):
         self.postencoder = None
         self.encoder = encoder
         self.use_transducer_decoder = False
+        self._len_cache = {}
         # espnet_model.py:167-192
         self.decoder = decoder if ctc_weight < 1.0 else None
         self.ctc = None if ctc_weight == 0.0 else ctc
@@ -92,13 +93,23 @@ class ESPnetASRModel(torch.nn.Module):
         speech = speech[:, :nmax].contiguous()  # espnet_model.py:454 (crop to the longest)
         dev = speech.device
         flens = self.frontend.feature_lengths(speech_lengths)
-        flens_dev = torch.tensor(flens, dtype=torch.int32).to(dev, non_blocking=True)
-        wlens_dev = None
-        if isolate and len(set(int(n) for n in speech_lengths)) > 1:
-            if min(int(n) for n in speech_lengths) <= self.frontend.n_fft // 2:
-                raise ValueError(f"an input of {min(speech_lengths)} samples is too short for reflect padding "
-                                 f"of {self.frontend.n_fft // 2}")  # torch.stft raises for it as well
-            wlens_dev = torch.tensor([int(n) for n in speech_lengths], dtype=torch.int32).to(dev, non_blocking=True)
+        # length vectors live on the device; the last few distinct ones are kept so a repeating batch
+        # shape costs no H2D copy (and a captured hipGraph of the pass keeps valid pointers)
+        ckey = (tuple(int(n) for n in speech_lengths), bool(isolate), dev)
+        cached = self._len_cache.get(ckey)
+        if cached is None:
+            flens_dev = torch.tensor(flens, dtype=torch.int32).to(dev, non_blocking=True)
+            wlens_dev = None
+            if isolate and len(set(ckey[0])) > 1:
+                if min(ckey[0]) <= self.frontend.n_fft // 2:
+                    raise ValueError(f"an input of {min(ckey[0])} samples is too short for reflect padding "
+                                     f"of {self.frontend.n_fft // 2}")  # torch.stft raises for it as well
+                wlens_dev = torch.tensor(ckey[0], dtype=torch.int32).to(dev, non_blocking=True)
+            if len(self._len_cache) >= 8:
+                self._len_cache.pop(next(iter(self._len_cache)))
+            self._len_cache[ckey] = (flens_dev, wlens_dev)
+        else:
+            flens_dev, wlens_dev = cached
         feats = self.frontend.forward_device(speech, flens_dev, wlens_dev)
         partial = None
         if self.normalize is not None:

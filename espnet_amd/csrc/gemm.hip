@@ -141,6 +141,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
   const int a_row_off = (wr * WM + lr) * ROWB;
   const int w_row_off = (wc * 64 + lr) * ROWB;
 
+  // RESID epilogue: the f32 residual tile this lane will update is requested now, so its HBM/L2
+  // latency overlaps the K loop (loads retire in order: it has landed by the first tile wait).
+  // Loading it inside the store loop serialises MI*4 dependent round trips (each load may alias
+  // the previous store): -1.5 us per launch at M = 7968.
+  constexpr bool PREFETCH_C = (EPI == EM_EPI_RESID_F32);
+  float4 cpre[PREFETCH_C ? MI * 4 : 1];
+  if constexpr (PREFETCH_C) {
+    const int ncol_p = n0 + wc * 64 + (lane & 15) * 4;
+    if ((ncol_p + 3 < N) && ((ldc & 3) == 0)) {
+#pragma unroll
+      for (int q = 0; q < MI * 4; ++q) {
+        int m = m0 + wr * WM + (q >> 2) * 16 + (q & 3) * 4 + lg;
+        m = m < M ? m : M - 1;
+        cpre[q] = *(const float4*)((const float*)Cv + (size_t)m * ldc + ncol_p);
+      }
+    }
+  }
+
   const int nk = K / BK;
   issue(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -375,8 +393,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     } else {
       float* C = (float*)Cv + o;
       if (full4) {
-        if (EPI == EM_EPI_RESID_F32) {
-          float4 x = *(const float4*)C;
+        if constexpr (EPI == EM_EPI_RESID_F32) {
+          float4 x = cpre[q];
           x.x += scale * v.x; x.y += scale * v.y; x.z += scale * v.z; x.w += scale * v.w;
           *(float4*)C = x;
         } else if (EPI == EM_EPI_SCALE_F32) {
