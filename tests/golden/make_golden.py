@@ -368,6 +368,78 @@ def run_streaming_case(name, enc_conf, wseed, utt_id, n_samples, chunk_frames, k
           f"total {ys.size(0)} oneshot {y1.size(0)}")
 
 
+def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples, beam, ctc_weight, nbest,
+                           tweaks=None, disable_repetition_detection=False, penalty=0.0):
+    """Speech2TextStreaming end to end (espnet2/bin/asr_inference_streaming.py:293-336): waveform chunks
+    -> apply_frontend -> ContextualBlockConformerEncoder.forward_infer -> BatchBeamSearchOnline.forward
+    (espnet2/legacy/nets/batch_beam_search_online.py:155-534, block 40 / hop 16 / look-ahead 16).
+    Stored per call: the encoder frames handed to the search and the n-best it returned."""
+    import logging
+
+    from espnet2.bin.asr_inference_streaming import Speech2TextStreaming
+
+    t0 = time.time()
+    conf = tiny(d=64, heads=1, ff=128)
+    conf["encoder"] = "contextual_block_conformer"
+    conf["encoder_conf"] = dict(STREAM_TINY)
+    events = []
+
+    class Grab(logging.Handler):
+        def emit(self, rec):
+            m = rec.getMessage()
+            for key in ("Detected repetition", "reaching EOS in this block", "end detected at",
+                        "no hypothesis. Finish", "adding <eos> in the last position"):
+                if key in m:
+                    events.append(key)
+
+    with tempfile.TemporaryDirectory() as td:
+        _, cfg_text = build_reference(conf, vocab, td, beam_size=1, ctc_weight=1.0)
+        s2t = Speech2TextStreaming(asr_train_config=str(Path(td) / "asr" / "config.yaml"), asr_model_file=None,
+                                   device="cpu", dtype="float32", beam_size=beam, ctc_weight=ctc_weight,
+                                   lm_weight=0.0, penalty=penalty, nbest=nbest,
+                                   disable_repetition_detection=disable_repetition_detection)
+    model = s2t.asr_model
+    shapes = load_recipe(model, wseed, tweaks)
+    h = Grab()
+    logging.getLogger().addHandler(h)
+    logging.getLogger().setLevel(logging.INFO)
+    wav = synth_waveform(utt_id, n_samples)
+    calls, enc_chunks = [], []
+    orig_bs = s2t.beam_search.forward
+
+    def spy(x, maxlenratio=0.0, minlenratio=0.0, is_final=True):
+        enc_chunks.append(x.detach().clone())
+        return orig_bs(x=x, maxlenratio=maxlenratio, minlenratio=minlenratio, is_final=is_final)
+
+    s2t.beam_search.forward = spy
+    pos = 0
+    while pos < n_samples:
+        nxt = min(n_samples, pos + chunk_samples)
+        n_before = len(enc_chunks)
+        ev0 = len(events)
+        res = s2t(wav[pos:nxt].numpy(), is_final=(nxt == n_samples))
+        calls.append(dict(
+            searched=len(enc_chunks) > n_before, events=events[ev0:],
+            hyps=[dict(yseq=[int(v) for v in hy.yseq.tolist()], score=float(hy.score),
+                       scores={k: float(v) for k, v in hy.scores.items()}) for _, _, _, hy in res]))
+        pos = nxt
+    logging.getLogger().removeHandler(h)
+    enc_all = torch.cat(enc_chunks, 0) if enc_chunks else torch.zeros(0, 64)
+    np.savez_compressed(
+        HERE / f"{name}.npz", config_yaml=np.array(cfg_text), vocab=np.array(vocab), wseed=np.array(wseed),
+        utt_id=np.array(utt_id), n_samples=np.array(n_samples), chunk_samples=np.array(chunk_samples),
+        beam=np.array(beam), ctc_weight=np.array(ctc_weight), nbest=np.array(nbest), penalty=np.array(penalty),
+        tweaks=np.array(json.dumps(tweaks or [])),
+        disable_repetition_detection=np.array(disable_repetition_detection),
+        state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+        melmat=model.frontend.logmel.melmat.numpy(), enc_all=enc_all.numpy(),
+        enc_lens=np.array([int(c.size(0)) for c in enc_chunks]), calls=np.array(json.dumps(calls)))
+    print(f"[{name}] done in {time.time()-t0:.1f}s enc chunks {[int(c.size(0)) for c in enc_chunks]}")
+    for k, c in enumerate(calls):
+        print(f"   call {k}: searched={c['searched']} events={c['events']} n_hyps={len(c['hyps'])} "
+              + (f"best len={len(c['hyps'][0]['yseq'])} score={c['hyps'][0]['score']:.3f}" if c["hyps"] else ""))
+
+
 def run_stream_frontend_case(name, utt_id, n_samples, chunk_samples, use_global_mvn):
     """Speech2TextStreaming.apply_frontend (espnet2/bin/asr_inference_streaming.py:205-293) called
     as an unbound function on a stub carrying the attributes it reads, with the reference
@@ -482,6 +554,14 @@ CASES = {
         "cli_decode", tiny(d=128, heads=2, ff=128), 50, 13,
         [["uttA", 31, 28000], ["uttB", 32, 9000], ["uttC", 33, 500], ["uttD", 34, 41000],
          ["uttE", 35, 16000], ["uttF", 36, 23456], ["uttG", 37, 33000]], 3, 0.3, 2),
+    # streaming decode: Speech2TextStreaming + BatchBeamSearchOnline, 640 ms chunks
+    "stream_search_a": lambda: run_stream_search_case(
+        "stream_search_a", 50, 21, 41, 80000, 10240, 4, 0.3, 4, tweaks=[["decoder.output_layer.bias", 49, 2.5]]),
+    "stream_search_b": lambda: run_stream_search_case(
+        "stream_search_b", 50, 22, 42, 64000, 10240, 5, 0.5, 3, tweaks=[["decoder.output_layer.bias", 49, 1.0]],
+        disable_repetition_detection=True),
+    "stream_search_c": lambda: run_stream_search_case(
+        "stream_search_c", 50, 23, 43, 48000, 7000, 3, 0.3, 3, penalty=0.2),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

@@ -215,3 +215,41 @@ def test_beam_search_with_lm_scorer_matches_reference(name):
         assert abs(res[k]["score"] - float(g["score"][k])) < 1e-4 + 1e-5 * abs(float(g["score"][k]))
         for j, kk in enumerate(keys):
             assert abs(res[k]["scores"][kk] - float(g["scores"][k, j])) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["stream_search_a", "stream_search_b", "stream_search_c"])
+def test_online_beam_search_matches_reference_per_call(name):
+    """BatchBeamSearchOnline (block-synchronous search with CTC extend_prob /
+    extend_state, repetition / local-<eos> breaks, rewind, end detection) — the oracle replays the
+    encoder frames each `Speech2TextStreaming.__call__` handed to the search and must return the same
+    n-best per call (token sequences exactly, scores to fp32 round-off)."""
+    import json
+
+    from oracle.beam_search_online import OnlineBeamSearchOracle
+
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    V = int(g["vocab"])
+    dc = g["config"]["decoder_conf"]
+    orc = OnlineBeamSearchOracle(sd, dc["attention_heads"], dc["num_blocks"], int(g["beam"]), float(g["ctc_weight"]),
+                                 sos=V - 1, eos=V - 1, penalty=float(g["penalty"]),
+                                 disable_repetition_detection=bool(g["disable_repetition_detection"]))
+    enc_all = torch.from_numpy(g["enc_all"])
+    calls = json.loads(str(g["calls"]))
+    lens = g["enc_lens"].tolist()
+    assert len(calls) == len(lens)
+    pos, nbest = 0, int(g["nbest"])
+    seen_events = []
+    for k, (call, n) in enumerate(zip(calls, lens)):
+        orc.events = []
+        res = orc.forward(enc_all[pos : pos + n], is_final=(k == len(calls) - 1))[:nbest]
+        pos += n
+        seen_events += orc.events
+        assert [e for e in orc.events] == call["events"], (k, orc.events, call["events"])
+        assert len(res) == len(call["hyps"]), (k, len(res), len(call["hyps"]))
+        for mine, ref in zip(res, call["hyps"]):
+            assert mine["yseq"] == ref["yseq"], k
+            assert abs(mine["score"] - ref["score"]) < 1e-3 + 1e-5 * abs(ref["score"])
+            for kk, v in ref["scores"].items():
+                assert abs(mine["scores"][kk] - v) < 2e-3 + 1e-5 * abs(v)
+    assert seen_events, "golden exercises no break / end event"
