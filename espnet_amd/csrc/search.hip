@@ -53,6 +53,10 @@ struct Ctx {
   EmSearchBuffers b;
 };
 
+// frame stride of the CTC tables (ctc_lpT rows, r_a / r_b rows): the visible length T offline, the
+// fixed capacity ldT of a stream whose visible length grows block by block
+__host__ __device__ inline int ldt(const EmSearchParams& p) { return p.ldT > 0 ? p.ldT : p.T; }
+
 // ---- init ---------------------------------------------------------------------------------
 __global__ void search_init_rows_kernel(Ctx c) {
   const int n = c.p.B * c.p.W;
@@ -83,8 +87,9 @@ __global__ void search_init_utt_kernel(Ctx c) {
   c.b.best_all[b] = -INFINITY;
   for (int l = 0; l < c.p.Lmax + 2; ++l) c.b.best_by_len[(size_t)b * (c.p.Lmax + 2) + l] = -INFINITY;
   if (c.p.w_ctc != 0.f) {
-    const float* xb = c.b.ctc_lpT + (size_t)c.p.blank * c.p.B * c.p.T + (size_t)b * c.p.T;
-    float2* r0 = (float2*)c.b.r_a + (size_t)(b * c.p.W) * c.p.T;
+    const int LT = ldt(c.p);
+    const float* xb = c.b.ctc_lpT + (size_t)c.p.blank * c.p.B * LT + (size_t)b * LT;
+    float2* r0 = (float2*)c.b.r_a + (size_t)(b * c.p.W) * LT;
     float cum = 0.f;
     for (int t = 0; t < c.p.T; ++t) {
       cum += xb[t];
@@ -322,7 +327,8 @@ __global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i_host) {
   float total = full;
   if (c.p.w_ctc != 0.f) {
     const int xlen = c.b.xlens[b];
-    const float2* rprev = (const float2*)(i & 1 ? c.b.r_b : c.b.r_a) + (size_t)r * c.p.T;
+    const int LT = ldt(c.p);
+    const float2* rprev = (const float2*)(i & 1 ? c.b.r_b : c.b.r_a) + (size_t)r * LT;
     float psi;
     if (tokc == c.p.blank && c.p.eos != c.p.blank) {
       psi = LOGZERO;  // :188-190
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i_host) {
       psi = logaddexp_(re.x, re.y);  // :184-186
     } else {
       const bool same = (tokc == c.b.tok[(size_t)i * c.p.B * c.p.W + r]);
-      const float* xc = c.b.ctc_lpT + (size_t)tokc * c.p.B * c.p.T + (size_t)b * c.p.T;
+      const float* xc = c.b.ctc_lpT + (size_t)tokc * c.p.B * LT + (size_t)b * LT;
       const int start = i > 1 ? i : 1;
       // lane-local online logsumexp over its frames, then a wave combine
       float m = -INFINITY, sm = 0.f;
@@ -417,11 +423,12 @@ __global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i_host) {
   const int tk = c.b.cand_tok[(size_t)prow * NC + slot];
   if (tk == c.p.eos || i == c.b.maxlens[b] - 1) return;  // ended: no state needed
   const int xlen = c.b.xlens[b];
-  const size_t BT = (size_t)c.p.B * c.p.T;
-  const float* xc = c.b.ctc_lpT + (size_t)tk * BT + (size_t)b * c.p.T;
-  const float* xb = c.b.ctc_lpT + (size_t)c.p.blank * BT + (size_t)b * c.p.T;
-  const float2* rprev = (const float2*)((i & 1) ? c.b.r_b : c.b.r_a) + (size_t)prow * c.p.T;
-  float2* rout = (float2*)((i & 1) ? c.b.r_a : c.b.r_b) + (size_t)rnew * c.p.T;
+  const int LT = ldt(c.p);
+  const size_t BT = (size_t)c.p.B * LT;
+  const float* xc = c.b.ctc_lpT + (size_t)tk * BT + (size_t)b * LT;
+  const float* xb = c.b.ctc_lpT + (size_t)c.p.blank * BT + (size_t)b * LT;
+  const float2* rprev = (const float2*)((i & 1) ? c.b.r_b : c.b.r_a) + (size_t)prow * LT;
+  float2* rout = (float2*)((i & 1) ? c.b.r_a : c.b.r_b) + (size_t)rnew * LT;
   const bool same = (tk == c.b.tok[(size_t)i * n + prow]);
   const int start = i > 1 ? i : 1;
   for (int t = start + lane; t < xlen; t += 64) {
@@ -569,14 +576,14 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
 // 64 columns x 4 vocabulary slices per block; coalesced over columns.
 __global__ __launch_bounds__(256) void col_logsoftmax_kernel(float* __restrict__ x,
                                                              const float* __restrict__ bias, int V,
-                                                             int ncol) {
+                                                             int ncol, int ld) {
   __shared__ float s_m[4][64], s_s[4][64];
   const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   float m = -INFINITY, sm = 0.f;
   if (col < ncol)
     for (int v = g; v < V; v += 4) {
-      const float val = x[(size_t)v * ncol + col] + (bias ? bias[v] : 0.f);
+      const float val = x[(size_t)v * ld + col] + (bias ? bias[v] : 0.f);
       const float mm = fmaxf(m, val);
       sm = sm * expf(m - mm) + expf(val - mm);
       m = mm;
@@ -591,7 +598,7 @@ __global__ __launch_bounds__(256) void col_logsoftmax_kernel(float* __restrict__
   const float lse = M + logf(S);
   if (col < ncol)
     for (int v = g; v < V; v += 4) {
-      const size_t o = (size_t)v * ncol + col;
+      const size_t o = (size_t)v * ld + col;
       x[o] = x[o] + (bias ? bias[v] : 0.f) - lse;
     }
 }
@@ -664,6 +671,38 @@ int lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i,
   return EM_OK;
 }
 
+
+
+// Source-attention memory of every decoder layer for the p->T visible frames: K | V by one GEMM per
+// layer over the whole batch, then V^T (strides follow p->T / p->Tpad).
+int project_memory(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, const EmSearchBuffers* b,
+                   const void* enc_act, void* stream) {
+  const int d = dw->d;
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  for (int l = 0; l < dw->num_blocks; ++l) {
+    unsigned char* kv = (unsigned char*)b->mem_kv + (size_t)l * p->B * p->T * 2 * d * es;
+    unsigned char* vT = (unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
+    EM_TRY(gemm(dtype, EM_EPI_STORE, enc_act, dw->layers[l].src_wkv, kv, dw->layers[l].src_bkv,
+                p->B * p->T, 2 * d, d, d, 2 * d, 1.f, stream));
+    EM_TRY(em_dec_transpose_v(dtype, kv, p->B, p->T, d, p->Tpad, vT, stream));
+  }
+  return EM_OK;
+}
+
+// logits^T [V][B*ldT] = W_ctc [V][d] x enc^T: the transposed layout falls out of swapping the GEMM
+// operands; bias + log-softmax over V (asr/ctc.py:197-205) run column-wise in place
+int ctc_log_probs(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, const void* enc_act,
+                  int d_model, const void* ctc_w, const float* ctc_b, void* stream) {
+  if (!ctc_w || !enc_act || !b->ctc_lpT) return EM_ERR_BAD_ARG;
+  const int BT = p->B * p->T, ld = p->B * ldt(*p);
+  if (ld != BT && p->B != 1) return EM_ERR_BAD_ARG;  // a frame capacity only makes sense per stream
+  EM_TRY(gemm(dtype, EM_EPI_STORE_F32, ctc_w, enc_act, b->ctc_lpT, nullptr, p->V, BT, d_model, d_model,
+              ld, 1.f, stream));
+  hipLaunchKernelGGL(col_logsoftmax_kernel, dim3(em_cdiv(BT, 64)), dim3(256), 0, (hipStream_t)stream,
+                     b->ctc_lpT, ctc_b, p->V, BT, ld);
+  return EM_OK;
+}
+
 }  // namespace
 
 extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
@@ -675,33 +714,207 @@ extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecode
   const int n = p->B * p->W;
   if (p->w_dec != 0.f) {
     if (!dw || !enc_act) return EM_ERR_BAD_ARG;
-    const int d = dw->d;
-    const size_t es = dtype == EM_BF16 ? 2 : 4;
-    // memory K | V of every decoder layer: one GEMM per layer over the whole batch, then V^T
-    for (int l = 0; l < dw->num_blocks; ++l) {
-      unsigned char* kv = (unsigned char*)b->mem_kv + (size_t)l * p->B * p->T * 2 * d * es;
-      unsigned char* vT = (unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
-      EM_TRY(gemm(dtype, EM_EPI_STORE, enc_act, dw->layers[l].src_wkv, kv, dw->layers[l].src_bkv,
-                  p->B * p->T, 2 * d, d, d, 2 * d, 1.f, stream));
-      EM_TRY(em_dec_transpose_v(dtype, kv, p->B, p->T, d, p->Tpad, vT, stream));
-    }
+    EM_TRY(project_memory(dtype, p, dw, b, enc_act, stream));
   }
-  if (p->w_ctc != 0.f) {
-    if (!ctc_w || !enc_act || !b->ctc_lpT) return EM_ERR_BAD_ARG;
-    const int BT = p->B * p->T;
-    // logits^T [V][B*T] = W_ctc [V][d] x enc^T: the transposed layout falls out of swapping the
-    // GEMM operands; bias + log-softmax over V (asr/ctc.py:197-205) run column-wise in place
-    EM_TRY(gemm(dtype, EM_EPI_STORE_F32, ctc_w, enc_act, b->ctc_lpT, nullptr, p->V, BT, d_model,
-                d_model, BT, 1.f, stream));
-    hipLaunchKernelGGL(col_logsoftmax_kernel, dim3(em_cdiv(BT, 64)), dim3(256), 0, s, b->ctc_lpT,
-                       ctc_b, p->V, BT);
-  }
+  if (p->w_ctc != 0.f) EM_TRY(ctc_log_probs(dtype, p, b, enc_act, d_model, ctc_w, ctc_b, stream));
   hipLaunchKernelGGL(search_init_rows_kernel, dim3(em_cdiv(n, 64)), dim3(64), 0, s, c);
   hipLaunchKernelGGL(search_init_utt_kernel, dim3(em_cdiv(p->B, 64)), dim3(64), 0, s, c);
   if (b->step) hipMemsetAsync(b->step, 0, sizeof(int32_t), s);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
+
+namespace {
+
+// One label step up to the per-utterance top-W selection: decoder (+ LM) step for the n rows,
+// log-softmax + pre-beam, CTC prefix scores of the candidates, selection.  Nothing of the search
+// state (tree, ancestor tables, running scores, r) is modified; the decoder / LM K/V caches get
+// their position-i entries.
+int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, const EmSearchBuffers* b,
+                int i, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{*p, *b};
+  const int n = p->B * p->W, V = p->V;
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  if (p->w_dec != 0.f) {
+    const int d = dw->d, ff = dw->ff, h = dw->heads;
+    const int* anc = (i & 1) ? b->anc_b : b->anc_a;
+    if (b->step)
+      EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok, n, V, d, 0, b->step, p->Lmax, b->x, stream));
+    else
+      EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok + (size_t)i * n, n, V, d, i, nullptr,
+                              dw->pe_len, b->x, stream));
+    for (int l = 0; l < dw->num_blocks; ++l) {
+      const EmDecoderLayer& q = dw->layers[l];
+      unsigned char* kc = (unsigned char*)b->self_k + (size_t)l * p->Lmax * n * d * es;
+      unsigned char* vc = (unsigned char*)b->self_v + (size_t)l * p->Lmax * n * d * es;
+      const unsigned char* kv = (const unsigned char*)b->mem_kv + (size_t)l * p->B * p->T * 2 * d * es;
+      const unsigned char* vT = (const unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
+      EM_TRY(em_layernorm(dtype, b->x, q.norm1_g, q.norm1_b, n, d, LN_EPS, b->xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.self_wqkv, b->qkv, q.self_bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
+      if (b->step)
+        EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, b->anc_a, b->anc_b, n, d, h, p->Lmax, 0,
+                                     b->step, (p->W + 1) / 2, nullptr, b->ctx, stream));
+      else
+        EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, anc, n, d, h, p->Lmax, i, nullptr,
+                                     (p->W + 1) / 2, nullptr, b->ctx, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.self_wout, b->x, q.self_bout, n, d, d, d, d, 1.f, stream));
+      EM_TRY(em_layernorm(dtype, b->x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.src_wq, b->qs, q.src_bq, n, d, d, d, d, 1.f, stream));
+      EM_TRY(em_dec_src_attention(dtype, b->qs, kv, 2 * d, vT, b->xlens, p->B, p->W, d, h, p->T, p->Tpad, b->ctx, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.src_wout, b->x, q.src_bout, n, d, d, d, d, 1.f, stream));
+      EM_TRY(em_layernorm(dtype, b->x, q.norm3_g, q.norm3_b, n, d, LN_EPS, b->xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RELU, b->xn, q.w1, b->hbuf, q.b1, n, ff, d, d, ff, 1.f, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->hbuf, q.w2, b->x, q.b2, n, d, ff, ff, d, 1.f, stream));
+    }
+    EM_TRY(em_layernorm(dtype, b->x, dw->after_norm_g, dw->after_norm_b, n, d, LN_EPS, b->xn, nullptr, stream));
+    EM_TRY(gemm(dtype, EM_EPI_STORE_F32, b->xn, dw->out_w, b->dec_logp, dw->out_b, n, V, d, d, V, 1.f, stream));
+  }
+  if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));
+  if (p->w_dec != 0.f || p->w_lm != 0.f || p->w_len != 0.f) {
+    if ((p->S > PREBEAM_SMAX && p->S < V) || V > 256 * 40) {
+      if (p->w_lm != 0.f || p->w_dec == 0.f) return EM_ERR_UNSUPPORTED;  // needs the fused row kernel
+      EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
+      if (p->S < V)
+        hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
+    } else if (V <= 256 * 8) {
+      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<8>, dim3(n), dim3(256), 0, s, c);
+    } else if (V <= 256 * 20) {
+      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<20>, dim3(n), dim3(256), 0, s, c);
+    } else {
+      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<40>, dim3(n), dim3(256), 0, s, c);
+    }
+  }
+  {
+    const long waves = (long)n * p->NC;
+    hipLaunchKernelGGL(candidate_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, c, i);
+  }
+  hipLaunchKernelGGL(select_kernel, dim3(p->B), dim3(64), 0, s, c);
+  return EM_OK;
+}
+
+// ---- streaming (block-synchronous) search: device ops under the host's control flow -----------
+// Reference: BatchBeamSearchOnline (espnet2/legacy/nets/batch_beam_search_online.py:155-534).  The
+// host mirrors its loop (repetition / local-<eos> breaks, rewind, ended lists); the device keeps the
+// numeric state.  Row layout, token tree, ancestor tables and the r ping-pong are the offline ones;
+// the visible memory length (p->T, xlens[0]) grows block by block under a fixed frame stride ldT.
+
+// CTCPrefixScoreTH.extend_state (ctc_prefix_score.py:248-270, Eq. 14 of arXiv:2006.14941): over the
+// new frames [t_old, T) the prefix continues along the blank path only:
+// r[t] = (logzero, r[t-1][1] + logp[t][blank]).  One thread per alive row (a block brings ~16 frames).
+__global__ void online_extend_r_kernel(Ctx c, int i, int t_old) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= c.p.B * c.p.W || !c.b.alive[r]) return;
+  const int LT = ldt(c.p), b = r / c.p.W;
+  float2* rr = (float2*)((i & 1) ? c.b.r_b : c.b.r_a) + (size_t)r * LT;
+  const float* xb = c.b.ctc_lpT + (size_t)c.p.blank * c.p.B * LT + (size_t)b * LT;
+  const int start = t_old > 1 ? t_old : 1, T = c.b.xlens[b];
+  float cum = rr[start - 1].y;
+  for (int t = start; t < T; ++t) {
+    cum += xb[t];
+    rr[t] = make_float2(LOGZERO, cum);
+  }
+}
+
+// `best` of BatchBeamSearch.search (batch_beam_search.py:317-357) as one record per new row k:
+// [valid, parent slot, token, total, decoder, ctc, length_bonus, lm]; the new s_prev goes to online_psi.
+__global__ __launch_bounds__(64) void online_best_kernel(Ctx c) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  const int W = c.p.W, NC = c.p.NC, V = c.p.V;
+  if (k >= W) return;
+  const int rnew = b * W + k;
+  float* o = c.b.online_best + (size_t)rnew * 8;
+  const int sel = c.b.sel_idx[rnew];
+  if (sel < 0) {
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    c.b.online_psi[rnew] = 0.f;
+    return;
+  }
+  const int pk = sel / NC, sl = sel - pk * NC, prow = b * W + pk;
+  const int tk = c.b.cand_tok[(size_t)prow * NC + sl];
+  float sdec = 0.f, sctc = 0.f, slen = 0.f, slm = 0.f, psi = 0.f;
+  if (c.p.w_dec != 0.f) sdec = c.b.run_sdec[prow] + c.b.dec_logp[(size_t)prow * V + tk];
+  if (c.p.w_len != 0.f) slen = c.b.run_slen[prow] + 1.0f;
+  if (c.p.w_lm != 0.f) slm = c.b.run_slm[prow] + c.b.lm_logp[(size_t)prow * V + tk];
+  if (c.p.w_ctc != 0.f) {
+    psi = c.b.cand_psi[(size_t)prow * NC + sl];
+    sctc = c.b.run_sctc[prow] + (psi - c.b.s_prev[prow]);
+  }
+  o[0] = 1.f; o[1] = (float)pk; o[2] = (float)tk; o[3] = c.b.sel_total[rnew];
+  o[4] = sdec; o[5] = sctc; o[6] = slen; o[7] = slm;
+  c.b.online_psi[rnew] = psi;
+}
+
+// prev_hyps = running_hyps (:459): the per-row scalars are copied; r / anc of the state before step i
+// stay where they are (parity i & 1), the commit writes the other parity.
+__global__ void online_snapshot_kernel(Ctx c, int restore) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= c.p.B * c.p.W) return;
+  float* sn = c.b.online_snap + (size_t)r * 8;
+  if (!restore) {
+    sn[0] = (float)c.b.alive[r]; sn[1] = c.b.run_score[r]; sn[2] = c.b.run_sdec[r];
+    sn[3] = c.b.run_sctc[r]; sn[4] = c.b.run_slen[r]; sn[5] = c.b.run_slm ? c.b.run_slm[r] : 0.f;
+    sn[6] = c.b.s_prev[r];
+  } else {
+    c.b.alive[r] = (int)sn[0]; c.b.run_score[r] = sn[1]; c.b.run_sdec[r] = sn[2];
+    c.b.run_sctc[r] = sn[3]; c.b.run_slen[r] = sn[4];
+    if (c.b.run_slm) c.b.run_slm[r] = sn[5];
+    c.b.s_prev[r] = sn[6];
+  }
+}
+
+// running_hyps = post_process(best) (:460-462 with batch_beam_search.py:412-423): the rows of `best`
+// that did not end with <eos> become the running rows; tree, ancestor tables and scores as offline.
+__global__ __launch_bounds__(64) void online_commit_kernel(Ctx c, int i) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int W = c.p.W, Lmax = c.p.Lmax, n = c.p.B * c.p.W;
+  __shared__ int s_prow[64], s_tok[64], s_valid[64];
+  const int* anc_old = (i & 1) ? c.b.anc_b : c.b.anc_a;
+  int* anc_new = (i & 1) ? c.b.anc_a : c.b.anc_b;
+  float rec[8];
+  if (lane < W) {
+    const float* o = c.b.online_best + (size_t)(b * W + lane) * 8;
+    for (int j = 0; j < 8; ++j) rec[j] = o[j];
+    s_valid[lane] = rec[0] != 0.f;
+    s_prow[lane] = b * W + (int)rec[1];
+    s_tok[lane] = (int)rec[2];
+  }
+  __syncthreads();
+  for (int k = 0; k < W; ++k) {
+    if (!s_valid[k]) continue;
+    const int rnew = b * W + k;
+    const int* src = anc_old + (size_t)s_prow[k] * Lmax;
+    int* dst = anc_new + (size_t)rnew * Lmax;
+    for (int j = lane; j <= i; j += 64) dst[j] = src[j];
+    if (lane == 0 && i + 1 < Lmax) dst[i + 1] = rnew;
+  }
+  __syncthreads();
+  if (lane < W) {
+    const int rnew = b * W + lane;
+    if (s_valid[lane]) {
+      c.b.tok[(size_t)(i + 1) * n + rnew] = s_tok[lane];
+      c.b.parent[(size_t)(i + 1) * n + rnew] = s_prow[lane];
+    }
+    const int alive = s_valid[lane] && s_tok[lane] != c.p.eos;
+    c.b.alive[rnew] = alive;
+    c.b.run_score[rnew] = alive ? rec[3] : -INFINITY;
+    c.b.run_sdec[rnew] = rec[4];
+    c.b.run_sctc[rnew] = rec[5];
+    c.b.run_slen[rnew] = rec[6];
+    if (c.b.run_slm) c.b.run_slm[rnew] = rec[7];
+    c.b.s_prev[rnew] = c.b.online_psi[rnew];
+  }
+}
+
+int check_online(const EmSearchParams* p, const EmSearchBuffers* b) {
+  EM_TRY(check(p, b));
+  if (p->B != 1 || b->step) return EM_ERR_BAD_ARG;  // one stream; host-driven steps
+  if (!b->online_best || !b->online_psi || !b->online_snap) return EM_ERR_BAD_ARG;
+  if (p->ldT < p->T) return EM_ERR_BAD_ARG;
+  return EM_OK;
+}
+
+}  // namespace
 
 // Steps i0 .. i1-1 (i = number of tokens after <sos> already in every running hypothesis).
 extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
@@ -710,67 +923,76 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
   if (i0 < 0 || (!b->step && i1 > p->Lmax - 1)) return EM_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   Ctx c{*p, *b};
-  const int n = p->B * p->W, V = p->V;
-  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  const int n = p->B * p->W;
   for (int i = i0; i < i1; ++i) {
-    if (p->w_dec != 0.f) {
-      const int d = dw->d, ff = dw->ff, h = dw->heads;
-      const int* anc = (i & 1) ? b->anc_b : b->anc_a;
-      if (b->step)
-        EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok, n, V, d, 0, b->step, p->Lmax, b->x, stream));
-      else
-        EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok + (size_t)i * n, n, V, d, i, nullptr,
-                                dw->pe_len, b->x, stream));
-      for (int l = 0; l < dw->num_blocks; ++l) {
-        const EmDecoderLayer& q = dw->layers[l];
-        unsigned char* kc = (unsigned char*)b->self_k + (size_t)l * p->Lmax * n * d * es;
-        unsigned char* vc = (unsigned char*)b->self_v + (size_t)l * p->Lmax * n * d * es;
-        const unsigned char* kv = (const unsigned char*)b->mem_kv + (size_t)l * p->B * p->T * 2 * d * es;
-        const unsigned char* vT = (const unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
-        EM_TRY(em_layernorm(dtype, b->x, q.norm1_g, q.norm1_b, n, d, LN_EPS, b->xn, nullptr, stream));
-        EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.self_wqkv, b->qkv, q.self_bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
-        if (b->step)
-          EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, b->anc_a, b->anc_b, n, d, h, p->Lmax, 0,
-                                       b->step, (p->W + 1) / 2, nullptr, b->ctx, stream));
-        else
-          EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, anc, n, d, h, p->Lmax, i, nullptr,
-                                       (p->W + 1) / 2, nullptr, b->ctx, stream));
-        EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.self_wout, b->x, q.self_bout, n, d, d, d, d, 1.f, stream));
-        EM_TRY(em_layernorm(dtype, b->x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->xn, nullptr, stream));
-        EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.src_wq, b->qs, q.src_bq, n, d, d, d, d, 1.f, stream));
-        EM_TRY(em_dec_src_attention(dtype, b->qs, kv, 2 * d, vT, b->xlens, p->B, p->W, d, h, p->T, p->Tpad, b->ctx, stream));
-        EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.src_wout, b->x, q.src_bout, n, d, d, d, d, 1.f, stream));
-        EM_TRY(em_layernorm(dtype, b->x, q.norm3_g, q.norm3_b, n, d, LN_EPS, b->xn, nullptr, stream));
-        EM_TRY(gemm(dtype, EM_EPI_RELU, b->xn, q.w1, b->hbuf, q.b1, n, ff, d, d, ff, 1.f, stream));
-        EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->hbuf, q.w2, b->x, q.b2, n, d, ff, ff, d, 1.f, stream));
-      }
-      EM_TRY(em_layernorm(dtype, b->x, dw->after_norm_g, dw->after_norm_b, n, d, LN_EPS, b->xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_STORE_F32, b->xn, dw->out_w, b->dec_logp, dw->out_b, n, V, d, d, V, 1.f, stream));
-    }
-    if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));
-    if (p->w_dec != 0.f || p->w_lm != 0.f || p->w_len != 0.f) {
-      if ((p->S > PREBEAM_SMAX && p->S < V) || V > 256 * 40) {
-        if (p->w_lm != 0.f || p->w_dec == 0.f) return EM_ERR_UNSUPPORTED;  // needs the fused row kernel
-        EM_TRY(em_log_softmax_rows_f32(b->dec_logp, n, V, stream));
-        if (p->S < V)
-          hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
-      } else if (V <= 256 * 8) {
-        hipLaunchKernelGGL(logsoftmax_prebeam_kernel<8>, dim3(n), dim3(256), 0, s, c);
-      } else if (V <= 256 * 20) {
-        hipLaunchKernelGGL(logsoftmax_prebeam_kernel<20>, dim3(n), dim3(256), 0, s, c);
-      } else {
-        hipLaunchKernelGGL(logsoftmax_prebeam_kernel<40>, dim3(n), dim3(256), 0, s, c);
-      }
-    }
-    {
-      const long waves = (long)n * p->NC;
-      hipLaunchKernelGGL(candidate_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, c, i);
-    }
-    hipLaunchKernelGGL(select_kernel, dim3(p->B), dim3(64), 0, s, c);
+    EM_TRY(search_core(dtype, p, dw, b, i, stream));
     if (p->w_ctc != 0.f) hipLaunchKernelGGL(ctc_state_kernel, dim3(n), dim3(64), 0, s, c, i);
     hipLaunchKernelGGL(update_kernel, dim3(p->B), dim3(64), 0, s, c, i);
     if (b->step) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, b->step);
     EM_CHECK_LAUNCH();
   }
+  return EM_OK;
+}
+
+// extend (batch_beam_search_online.py:518-534) for the p->T frames now visible: decoder memory
+// re-projected (strides follow p->T), CTC log-probs of all visible frames (scorers/ctc.py:128-139;
+// frames already present keep their values: the encoder output of a frame never changes), and r of the
+// running rows (state before step i) continued from t_old.  xlens[0] must already hold p->T.
+extern "C" int em_search_online_extend(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
+                                       const EmSearchBuffers* b, const void* enc_act, int32_t d_model,
+                                       const void* ctc_w, const float* ctc_b, int32_t i, int32_t t_old,
+                                       void* stream) {
+  EM_TRY(check_online(p, b));
+  if (t_old < 1 || t_old > p->T || i < 0) return EM_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{*p, *b};
+  if (p->w_dec != 0.f) {
+    if (!dw || !enc_act) return EM_ERR_BAD_ARG;
+    EM_TRY(project_memory(dtype, p, dw, b, enc_act, stream));
+  }
+  if (p->w_ctc != 0.f) {
+    EM_TRY(ctc_log_probs(dtype, p, b, enc_act, d_model, ctc_w, ctc_b, stream));
+    hipLaunchKernelGGL(online_extend_r_kernel, dim3(1), dim3(64), 0, s, c, i, t_old);
+  }
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+// best = search(running_hyps, h) (:400): fills online_best [W][8] for the host to read.
+extern "C" int em_search_online_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
+                                     const EmSearchBuffers* b, int32_t i, void* stream) {
+  EM_TRY(check_online(p, b));
+  if (i < 0 || i >= p->Lmax - 1) return EM_ERR_BAD_ARG;
+  EM_TRY(search_core(dtype, p, dw, b, i, stream));
+  Ctx c{*p, *b};
+  hipLaunchKernelGGL(online_best_kernel, dim3(p->B), dim3(64), 0, (hipStream_t)stream, c);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+// prev_hyps = running_hyps; running_hyps = post_process(best) (:459-462) after em_search_online_core(i).
+extern "C" int em_search_online_commit(int dtype, const EmSearchParams* p, const EmSearchBuffers* b,
+                                       int32_t i, void* stream) {
+  (void)dtype;
+  EM_TRY(check_online(p, b));
+  if (i < 0 || i >= p->Lmax - 1) return EM_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{*p, *b};
+  const int n = p->B * p->W;
+  hipLaunchKernelGGL(online_snapshot_kernel, dim3(em_cdiv(n, 64)), dim3(64), 0, s, c, 0);
+  if (p->w_ctc != 0.f) hipLaunchKernelGGL(ctc_state_kernel, dim3(n), dim3(64), 0, s, c, i);
+  hipLaunchKernelGGL(online_commit_kernel, dim3(p->B), dim3(64), 0, s, c, i);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+// running_hyps = prev_hyps (:484-487): the scalars come back from the snapshot; the caller steps
+// its position back by one, which re-selects the r / anc parity of that state.
+extern "C" int em_search_online_rewind(const EmSearchParams* p, const EmSearchBuffers* b, void* stream) {
+  EM_TRY(check_online(p, b));
+  Ctx c{*p, *b};
+  hipLaunchKernelGGL(online_snapshot_kernel, dim3(em_cdiv(p->B * p->W, 64)), dim3(64), 0,
+                     (hipStream_t)stream, c, 1);
+  EM_CHECK_LAUNCH();
   return EM_OK;
 }

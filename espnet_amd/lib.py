@@ -87,7 +87,7 @@ class EmDecoderWeights(C.Structure):
 class EmSearchParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "W", "V", "T", "Tpad", "S", "NC", "Lmax", "end_cap",
                                          "sos", "eos", "blank", "use_end_detect")] + \
-               [(n, C.c_float) for n in ("w_dec", "w_ctc", "w_len", "w_lm")]
+               [(n, C.c_float) for n in ("w_dec", "w_ctc", "w_len", "w_lm")] + [("ldT", C.c_int32)]
 
 
 _LM_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "wqkv", "bqkv", "wout", "bout", "w1", "b1",
@@ -112,7 +112,7 @@ SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "an
                   "end_sctc", "end_slen", "best_all", "best_by_len", "done", "step", "x", "xn", "qkv", "qs",
                   "ctx", "hbuf", "dec_logp", "self_k", "self_v", "mem_kv", "mem_vT",
                   "lm", "lm_e", "lm_xn", "lm_qkv", "lm_ctx", "lm_h", "lm_x", "lm_logp", "lm_k", "lm_v",
-                  "run_slm", "end_slm"]
+                  "run_slm", "end_slm", "online_best", "online_psi", "online_snap"]
 
 
 class EmSearchBuffers(C.Structure):
@@ -169,6 +169,13 @@ _SIGNATURES = {
                                  C.POINTER(EmSearchBuffers), _vp, _i32, _vp, _vp, _vp]),
     "em_search_steps": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),
                                   C.POINTER(EmSearchBuffers), _i32, _i32, _vp]),
+    "em_search_online_extend": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),
+                                          C.POINTER(EmSearchBuffers), _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "em_search_online_core": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),
+                                        C.POINTER(EmSearchBuffers), _i32, _vp]),
+    "em_search_online_commit": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmSearchBuffers),
+                                          _i32, _vp]),
+    "em_search_online_rewind": (C.c_int, [C.POINTER(EmSearchParams), C.POINTER(EmSearchBuffers), _vp]),
     "em_ctc_greedy": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32,
                                 _vp, _vp, _vp, _vp, _vp]),
 }

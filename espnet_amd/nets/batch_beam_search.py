@@ -72,9 +72,9 @@ class BeamSearch:
 
 class BatchBeamSearch(BeamSearch):
     # ------------------------------------------------------------------ buffers
-    def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm=None):
+    def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm=None, online=False):
         key = (str(dev), act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl,
-               None if lm is None else (lm.att_unit, lm.unit, lm.layer, lm.embed_unit))
+               None if lm is None else (lm.att_unit, lm.unit, lm.layer, lm.embed_unit), online)
         if key in self._bufs:
             return self._bufs[key]
         self._bufs.clear()  # one live shape at a time
@@ -100,6 +100,8 @@ class BatchBeamSearch(BeamSearch):
             shapes.update(lm_e=(n, lm.embed_unit), lm_xn=(n, dl), lm_qkv=(n, 3 * dl), lm_ctx=(n, dl),
                           lm_h=(n, lm.unit), lm_x=(n, dl), lm_logp=(n, V), lm_k=(lm.layer, Lmax, n, dl),
                           lm_v=(lm.layer, Lmax, n, dl), run_slm=(n,), end_slm=(B, cap))
+        if online:  # em_search_online_* (batch_beam_search_online.py)
+            shapes.update(online_best=(n, 8), online_psi=(n,), online_snap=(n, 8))
         t = {}
         for name, shp in shapes.items():
             if shp is None:

@@ -330,6 +330,8 @@ typedef struct EmSearchParams {
   int32_t use_end_detect; /* maxlenratio == 0 (beam_search.py:443) */
   float w_dec, w_ctc, w_len; /* scorer weights: decoder, ctc, length_bonus (asr_inference.py:310-316) */
   float w_lm;                /* language-model scorer weight (lm_weight), 0 = no LM */
+  int32_t ldT;               /* frame stride of ctc_lpT / r_a / r_b; 0 = T.  A stream (B == 1) whose
+                                visible length T grows block by block keeps a fixed capacity here */
 } EmSearchParams;
 
 /* TransformerLM used as a full scorer (espnet2/lm/transformer_lm.py:12-137):
@@ -393,6 +395,10 @@ typedef struct EmSearchBuffers {
   float *lm_x, *lm_logp;                    /* f32: [n][d], [n][V] */
   void *lm_k, *lm_v;                        /* act [lm layers][Lmax][n][d] */
   float *run_slm, *end_slm;                 /* [n], [B][end_cap] accumulated LM score */
+  /* streaming search (em_search_online_*; NULL offline) */
+  float *online_best;                       /* [n][8] valid, parent slot, token, total, dec, ctc, len, lm */
+  float *online_psi;                        /* [n] log psi of the selected candidates (next s_prev) */
+  float *online_snap;                       /* [n][8] per-row scalars of prev_hyps */
 } EmSearchBuffers;
 
 /*   Projects the encoder memory (enc_act [B][T][d_model] act) to per-layer K | V and V^T, computes
@@ -408,6 +414,31 @@ int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* d
  *   call can be captured once into a hipGraph and replayed; steps past Lmax - 2 are no-ops.      */
 int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
                     const EmSearchBuffers* b, int32_t i0, int32_t i1, void* stream);
+
+/* ---- §8(f) rank 3: block-synchronous streaming search, BatchBeamSearchOnline
+ *      (espnet2/legacy/nets/batch_beam_search_online.py:155-534).  The host mirrors the reference's
+ *      control flow (block loop :296-376, process_one_block :394-493: repetition / local-<eos> breaks,
+ *      rewind, ended lists); these entry points are its device operations on ONE stream (B == 1,
+ *      b->step NULL).  State layout as em_search_init; p->T / p->Tpad = frames visible to the current
+ *      block, p->ldT = frame capacity; xlens[0] = p->T; maxlens[0] >= Lmax (no forced <eos> on the
+ *      device: the host owns the length logic).  em_search_init starts the stream on the first block. */
+/*   extend (:518-534): source-attention memory re-projected for the p->T visible frames, CTC
+ *   log-probs of all of them (extend_prob, legacy/nets/scorers/ctc.py:128-139), and the forward
+ *   variables of the running rows (state before step i) continued over [t_old, T) along the blank
+ *   path (extend_state, legacy/nets/ctc_prefix_score.py:248-270).  enc_act [T][d_model] act.        */
+int em_search_online_extend(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
+                            const EmSearchBuffers* b, const void* enc_act, int32_t d_model,
+                            const void* ctc_w, const float* ctc_b, int32_t i, int32_t t_old, void* stream);
+/*   best = search(running_hyps, h) (:400, BatchBeamSearch.search batch_beam_search.py:253-357) for
+ *   step i: scorers, pre-beam, CTC prefix scores, top-W -> online_best.  No search state is modified. */
+int em_search_online_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
+                          const EmSearchBuffers* b, int32_t i, void* stream);
+/*   prev_hyps = running_hyps; running_hyps = post_process(best) (:459-462): snapshot, forward
+ *   variables of the winners, tree / ancestor / score update; rows ending in <eos> leave the beam.    */
+int em_search_online_commit(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int32_t i,
+                            void* stream);
+/*   running_hyps = prev_hyps (:484-487); the caller decrements its position.                          */
+int em_search_online_rewind(const EmSearchParams* p, const EmSearchBuffers* b, void* stream);
 
 /* ---- A16: streaming (contextual block) Conformer encoder step
  *      (ContextualBlockConformerEncoder.forward_infer, espnet2/asr/encoder/
