@@ -5,12 +5,16 @@ is_final)` (waveform overlap buffer + edge-frame trimming, :205-293, reproduced 
 the features coming from the HIP frontend), `__call__(speech, is_final)` feeding
 `ContextualBlockConformerEncoder.forward_infer` chunk by chunk (:316-322), `reset()`.
 
-Decoding.  The reference decodes streaming audio with `BatchBeamSearchOnline` (block-synchronous
-beam search with CTC `extend_prob`, legacy/nets/batch_beam_search_online.py) — SURVEY.md §8(f)
-rank 3, not built yet.  Until then partial results are incremental greedy CTC (G1: per-frame
-argmax + collapse carried across chunk boundaries, bin/asr_inference.py:574-575) and, on
-`is_final`, either G1 over the whole utterance or the offline joint CTC/attention beam search over
-the accumulated encoder output (`beam_size > 1`).
+Decoding (`search=`):
+  * "online" (default when beam_size > 1; what the reference does, :122-136, :316-330): every chunk's
+    encoder frames go to `BatchBeamSearchOnline` — block-synchronous joint CTC/attention search with CTC
+    `extend_prob` / `extend_state` (espnet_amd/nets/batch_beam_search_online.py).  Like the reference, a
+    non-final call returns hypotheses only when some reached <eos> inside a block.
+  * "greedy" (default when beam_size == 1; BASELINE config 5's per-chunk step): incremental greedy CTC
+    (G1: per-frame argmax + collapse carried across chunk seams, bin/asr_inference.py:574-575), a
+    partial transcript after every chunk.
+  * "offline": greedy partials, and the offline joint CTC/attention beam search over the accumulated
+    encoder output at `is_final`.
 """
 import logging
 import math
@@ -38,9 +42,13 @@ class Speech2TextStreaming:
                  beam_size: int = 1, ctc_weight: float = 0.5, lm_weight: float = 0.0,
                  penalty: float = 0.0, nbest: int = 1, disable_repetition_detection: bool = False,
                  decoder_text_length_limit: int = 0, encoded_feat_length_limit: int = 0,
-                 use_hipgraph: bool = True):
-        if lm_file is not None or lm_train_config is not None:
-            raise NotImplementedError("LM scorer: SURVEY.md §8(f) 'next'")
+                 normalize_length: bool = False, use_hipgraph: bool = True, search: Optional[str] = None):
+        if search is None:
+            search = "online" if beam_size > 1 else "greedy"
+        if search not in ("online", "greedy", "offline"):
+            raise ValueError(f"search={search!r}")
+        if decoder_text_length_limit or encoded_feat_length_limit:
+            raise NotImplementedError("decoder_text_length_limit / encoded_feat_length_limit")
         if not str(device).startswith("cuda"):
             raise RuntimeError("espnet_amd runs on an MI355X only (device='cuda'); no CPU fallback")
         assert batch_size == 1
@@ -51,13 +59,40 @@ class Speech2TextStreaming:
         self.asr_model, self.asr_train_args = asr_model, args
         self.device, self.dtype = device, dtype
         self.maxlenratio, self.minlenratio, self.nbest = maxlenratio, minlenratio, nbest
-        self.beam_size = beam_size
+        self.beam_size, self.search = beam_size, search
         self.beam_search = None
-        if beam_size > 1:
+        lm = None
+        if lm_train_config is not None:  # :97-102
+            from espnet_amd.tasks.lm import LMTask
+
+            lm = LMTask.build_model_from_file(lm_train_config, lm_file, device, compute_dtype=dtype)[0].lm
+        if search == "offline":
             from espnet_amd.nets.batch_beam_search import build_beam_search
 
             self.beam_search = build_beam_search(asr_model, beam_size=beam_size, ctc_weight=ctc_weight,
-                                                 penalty=penalty, token_list=asr_model.token_list)
+                                                 penalty=penalty, token_list=asr_model.token_list,
+                                                 lm_weight=lm_weight if lm is not None else 0.0, lm=lm,
+                                                 normalize_length=normalize_length)
+        elif search == "online":
+            from espnet_amd.nets.batch_beam_search_online import BatchBeamSearchOnline
+            from espnet_amd.nets.scorers.ctc import CTCPrefixScorer
+            from espnet_amd.nets.scorers.length_bonus import LengthBonus
+
+            token_list = asr_model.token_list
+            # :88-136 (the search always runs with block 40 / hop 16 / look-ahead 16: the reference
+            # leaves its encoder_conf read-out commented and BatchBeamSearchOnline's defaults apply)
+            scorers = dict(decoder=asr_model.decoder,
+                           ctc=CTCPrefixScorer(ctc=asr_model.ctc, eos=asr_model.eos) if asr_model.ctc else None,
+                           length_bonus=LengthBonus(len(token_list)))
+            if lm is not None:
+                scorers["lm"] = lm
+            weights = dict(decoder=1.0 - ctc_weight, ctc=ctc_weight, lm=lm_weight if lm is not None else 0.0,
+                           length_bonus=penalty)
+            self.beam_search = BatchBeamSearchOnline(
+                beam_size=beam_size, weights=weights, scorers=scorers, sos=asr_model.sos, eos=asr_model.eos,
+                vocab_size=len(token_list), token_list=token_list,
+                pre_beam_score_key=None if ctc_weight == 1.0 else "full", normalize_length=normalize_length,
+                disable_repetition_detection=disable_repetition_detection)
         token_type = token_type if token_type is not None else getattr(args, "token_type", None)
         bpemodel = bpemodel if bpemodel is not None else getattr(args, "bpemodel", None)
         self.tokenizer = (None if token_type is None or (token_type == "bpe" and bpemodel is None)
@@ -79,6 +114,8 @@ class Speech2TextStreaming:
         self._partial_ids: List[int] = []
         if self._runner is not None:
             self._runner.reset()
+        if self.search == "online" and self.beam_search is not None:
+            self.beam_search.reset()
 
     # ------------------------------------------------------------------ frontend (:205-293)
     def apply_frontend(self, speech: torch.Tensor, prev_states=None, is_final: bool = False):
@@ -127,10 +164,15 @@ class Speech2TextStreaming:
         ret = []
         if feats is not None:
             enc = self._encode_chunk(feats[0].contiguous(), is_final)
-            if enc.size(0) > 0:
-                self._enc_chunks.append(enc.clone())
-                self._extend_partial(enc)
-            ret = self._results(is_final)
+            if self.search == "online":  # :323-330
+                nbest_hyps = self.beam_search(x=enc, maxlenratio=self.maxlenratio, minlenratio=self.minlenratio,
+                                              is_final=is_final)
+                ret = self.assemble_hyps(nbest_hyps)
+            else:
+                if enc.size(0) > 0:
+                    self._enc_chunks.append(enc.clone())
+                    self._extend_partial(enc)
+                ret = self._results(is_final)
         if is_final:
             self.reset()
         return ret

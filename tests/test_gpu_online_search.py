@@ -99,3 +99,47 @@ def test_online_search_restarts_cleanly_and_bf16_runs():
         tot = sum(float(v) * {"decoder": 1 - float(g["ctc_weight"]), "ctc": float(g["ctc_weight"]),
                               "length_bonus": float(g["penalty"])}[k] for k, v in h.scores.items())
         assert abs(tot - float(h.score)) < 2e-2 + 1e-4 * abs(tot)
+
+
+@pytest.mark.parametrize("name", ["stream_search_a", "stream_search_b"])
+def test_speech2text_streaming_online_end_to_end_f32(name, tmp_path):
+    """Waveform chunks -> HIP frontend -> HIP contextual-block encoder -> device online search, behind the
+    reference's Speech2TextStreaming API.  The encoder runs on the GPU here, so its ~1e-4 activation
+    differences may move scores by ~1e-2: per call the same events and hypothesis count, scores within
+    that band, and identical token sequences wherever the reference's own top-2 gap is clear."""
+    from espnet_amd.bin.asr_inference_streaming import Speech2TextStreaming
+    from oracle.weights import synth_waveform
+
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    (tmp_path / "config.yaml").write_text(str(g["config_yaml"]))
+    torch.save(sd, tmp_path / "model.pth")
+    s2t = Speech2TextStreaming(str(tmp_path / "config.yaml"), str(tmp_path / "model.pth"), device="cuda",
+                               dtype="float32", beam_size=int(g["beam"]), ctc_weight=float(g["ctc_weight"]),
+                               penalty=float(g["penalty"]), nbest=int(g["nbest"]),
+                               disable_repetition_detection=bool(g["disable_repetition_detection"]))
+    assert s2t.search == "online"
+    s2t.beam_search.max_frames = 256
+    n, chunk = int(g["n_samples"]), int(g["chunk_samples"])
+    wav = synth_waveform(int(g["utt_id"]), n)
+    calls = json.loads(str(g["calls"]))
+    pos, k, same_tokens = 0, 0, 0
+    while pos < n:
+        nxt = min(n, pos + chunk)
+        s2t.beam_search.events = []
+        res = s2t(wav[pos:nxt].numpy(), is_final=(nxt == n))
+        ref = calls[k]
+        if nxt < n:
+            assert s2t.beam_search.events == ref["events"], (k, s2t.beam_search.events, ref["events"])
+        assert len(res) == len(ref["hyps"]), (k, len(res), len(ref["hyps"]))
+        if ref["hyps"]:
+            text, token, token_int, hyp = res[0]
+            r0 = ref["hyps"][0]
+            assert abs(float(hyp.score) - r0["score"]) < 5e-2 + 1e-4 * abs(r0["score"]), (k, float(hyp.score), r0["score"])
+            lower = [h["score"] for h in ref["hyps"] if h["score"] < r0["score"] - 1e-6]  # duplicates aside
+            gap = r0["score"] - lower[0] if lower else 1.0
+            if gap > 0.1:
+                assert hyp.yseq.tolist() == r0["yseq"], k
+                same_tokens += 1
+        pos, k = nxt, k + 1
+    assert k == len(calls) and same_tokens >= 1
