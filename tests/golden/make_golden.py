@@ -491,6 +491,25 @@ STREAM_SMALL = dict(output_size=256, attention_heads=4, linear_units=2048, num_b
                     hop_size=16, look_ahead=16, init_average=True, ctx_pos_enc=True)
 STREAM_TINY = dict(STREAM_SMALL, output_size=64, attention_heads=1, linear_units=128, num_blocks=2)
 
+EBF_SMALL = dict(
+    encoder="e_branchformer",
+    encoder_conf=dict(output_size=256, attention_heads=4, attention_layer_type="rel_selfattn",
+                      pos_enc_layer_type="rel_pos", rel_pos_type="latest", cgmlp_linear_units=1024,
+                      cgmlp_conv_kernel=31, use_linear_after_conv=False, gate_activation="identity",
+                      num_blocks=12, dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.1,
+                      input_layer="conv2d", layer_drop_rate=0.0, linear_units=1024,
+                      positionwise_layer_type="linear", use_ffn=True, macaron_ffn=True, merge_conv_kernel=31),
+    decoder="transformer",
+    decoder_conf=dict(attention_heads=4, linear_units=2048, num_blocks=6, dropout_rate=0.1,
+                      positional_dropout_rate=0.1, self_attention_dropout_rate=0.1, src_attention_dropout_rate=0.1),
+    model_conf=dict(ctc_weight=0.3, lsm_weight=0.1, length_normalized_loss=False),
+    frontend_conf=dict(n_fft=512, win_length=400, hop_length=160),
+)
+EBF_TINY = json.loads(json.dumps(EBF_SMALL))
+EBF_TINY["encoder_conf"].update(output_size=64, attention_heads=1, cgmlp_linear_units=128, linear_units=128,
+                                num_blocks=2, cgmlp_conv_kernel=15, merge_conv_kernel=7)
+EBF_TINY["decoder_conf"].update(attention_heads=1, linear_units=128, num_blocks=1)
+
 CASES = {
     # config 0/1 of BASELINE.json: Conformer-small, one 10 s utterance
     "small_10s": lambda: run_encode_case("small_10s", SMALL, 5000, 11, [0], [160000], keep_every=4),
@@ -562,6 +581,11 @@ CASES = {
         disable_repetition_detection=True),
     "stream_search_c": lambda: run_stream_search_case(
         "stream_search_c", 50, 23, 43, 48000, 7000, 3, 0.3, 3, penalty=0.2),
+    # E-Branchformer: attention + cgMLP branches, depthwise-conv merge
+    "ebf_tiny_blocks": lambda: run_encode_case("ebf_tiny_blocks", EBF_TINY, 50, 31, [51, 52], [32000, 21000],
+                                               with_blocks=True),
+    "ebf_small_5s": lambda: run_encode_case("ebf_small_5s", EBF_SMALL, 5000, 32, [53, 54], [80000, 48000],
+                                            keep_every=4),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

@@ -253,3 +253,29 @@ def test_online_beam_search_matches_reference_per_call(name):
             for kk, v in ref["scores"].items():
                 assert abs(mine["scores"][kk] - v) < 2e-3 + 1e-5 * abs(v)
     assert seen_events, "golden exercises no break / end event"
+
+
+@pytest.mark.parametrize("name", ["ebf_tiny_blocks", "ebf_small_5s"])
+def test_ebranchformer_encoder_matches_reference(name):
+    """E-Branchformer (attention + cgMLP branches, depthwise-conv merge) — oracle vs
+    the reference's `ESPnetASRModel.encode` with encoder=e_branchformer, incl. per-block outputs."""
+    from oracle import ebranchformer as oe
+
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    hp = hparams(g)
+    speech, lens = golden_speech(g)
+    enc, olens = oe.encode(sd, speech, lens, hp["heads"], hp["num_blocks"], hp["n_fft"], hp["win_length"], hp["hop"])
+    assert olens.tolist() == g["enc_olens"].tolist()
+    ke = int(g["enc_keep_every"])
+    np.testing.assert_allclose(enc[:, ::ke].numpy(), g["enc_out"], atol=5e-4, rtol=0)
+    if "block_outs" in g:
+        feats, flens = oc.frontend_feats(speech, lens, sd["frontend.logmel.melmat"], hp["n_fft"], hp["win_length"],
+                                         hp["hop"])
+        feats = oc.utterance_mvn(feats, flens)
+        _, _, blocks = oe.ebranchformer_encoder(sd, feats, flens, hp["heads"], hp["num_blocks"], return_blocks=True)
+        for i, b in enumerate(blocks):
+            np.testing.assert_allclose(b.numpy(), g["block_outs"][i], atol=1e-4, rtol=0)
+    ids = oc.ctc_argmax(sd, enc).numpy()
+    diff = ids != g["ctc_ids"]
+    assert (g["ctc_margin"][diff] < 1e-4).all() and diff.mean() < 0.01
