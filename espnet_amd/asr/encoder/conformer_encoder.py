@@ -110,6 +110,8 @@ def rel_pos_table(T: int, d: int) -> torch.Tensor:
 
 
 class ConformerEncoder(torch.nn.Module):
+    _WS_FN, _ENC_FN = "em_conformer_workspace_bytes", "em_conformer_encode"  # C-ABI entry points of forward_device
+
     def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4,
                  linear_units: int = 2048, num_blocks: int = 6, dropout_rate: float = 0.1,
                  positional_dropout_rate: float = 0.1, attention_dropout_rate: float = 0.0,
@@ -291,7 +293,7 @@ class ConformerEncoder(torch.nn.Module):
             if len(self._olens_cache) >= 8:
                 self._olens_cache.pop(next(iter(self._olens_cache)))
             self._olens_cache[okey] = olens_dev
-        need = lib.em_conformer_workspace_bytes(self.em_dtype, C.byref(pk["w"]), B, T_f)
+        need = getattr(lib, self._WS_FN)(self.em_dtype, C.byref(pk["w"]), B, T_f)
         # one workspace per stream: independent utterance batches may be encoded concurrently on
         # different HIP streams
         skey = torch.cuda.current_stream().cuda_stream
@@ -304,12 +306,12 @@ class ConformerEncoder(torch.nn.Module):
         d = self._output_size
         enc_out = torch.empty(B, T, d, dtype=torch.float32, device=dev)
         enc_act = torch.empty(B, T, d, dtype=self.act_dtype, device=dev)
-        rc = lib.em_conformer_encode(
+        rc = getattr(lib, self._ENC_FN)(
             self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
             L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(ws),
             ws.numel(), L.ptr(enc_out), L.ptr(enc_act), L.EM_ENC_ISOLATE_UTTS if isolate else 0,
             L.current_stream_ptr())
-        L.check(rc, "em_conformer_encode")
+        L.check(rc, self._ENC_FN)
         return enc_out, enc_act, olens, olens_dev
 
     def forward(self, xs_pad: torch.Tensor, ilens: torch.Tensor, prev_states: torch.Tensor = None

@@ -16,12 +16,21 @@ constexpr int KMAX = 31;
 // tile is staged in LDS with 16-byte coalesced loads (zero rows outside [0, T)); thread c then
 // walks its channel's column once, feeding each value to the (up to KW) outputs it contributes to
 // -- every tap weight and every accumulator stays in registers, each input is read from LDS once.
-template <typename T, int KW>
-__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
+// MODE (EM_DW_*): what happens to conv(x) + bias before it is stored
+//   SWISH  y = swish(.)            Conformer conv module (BatchNorm folded into w, b)
+//   LINEAR y = .                   plain depthwise conv
+//   GATE   y = gate * (.)          cgMLP CSGU with identity gate activation (cgmlp.py:61-79): gate is
+//                                  the other half of the hidden activation, read with its own stride
+//   SELFRES y = x + (.)            E-Branchformer merge: x_concat + depthwise_conv_fusion(x_concat)
+//                                  (e_branchformer_encoder.py:166-170)
+// x, gate and y carry their own row strides so halves of wider matrices are used in place.
+template <typename T, int KW, int MODE>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, int ldx,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ bias,
                                                      const int* __restrict__ tlens, int Tn, int d,
-                                                     T* __restrict__ y) {
+                                                     const T* __restrict__ gate, int ldg,
+                                                     T* __restrict__ y, int ldy) {
   constexpr int HALF = (KW - 1) / 2;
   constexpr int ROWS = TT + KW - 1;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
@@ -29,7 +38,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
   __shared__ __attribute__((aligned(16))) T tile[ROWS][256];
   const int c0 = blockIdx.x * 256, t0 = blockIdx.y * TT, b = blockIdx.z;
   const int tid = threadIdx.x;
-  const T* xb = x + (size_t)b * Tn * d;
+  const T* xb = x + (size_t)b * Tn * ldx;
   const int Tv = tlens ? (tlens[b] < Tn ? tlens[b] : Tn) : Tn;
   constexpr int NLD = (ROWS * CPR + 255) / 256;
   uint4 stage[NLD];
@@ -40,7 +49,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
     const int t = t0 - HALF + r;
     stage[it] = make_uint4(0u, 0u, 0u, 0u);
     if (q < ROWS * CPR && t >= 0 && t < Tv && c0 + ch * EPC < d)
-      stage[it] = *(const uint4*)(xb + (size_t)t * d + c0 + ch * EPC);
+      stage[it] = *(const uint4*)(xb + (size_t)t * ldx + c0 + ch * EPC);
   }
 #pragma unroll
   for (int it = 0; it < NLD; ++it) {
@@ -65,21 +74,29 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x,
     for (int o = 0; o < TT; ++o)
       if (r - o >= 0 && r - o < KW) acc[o] = fmaf(wk[r - o], v, acc[o]);
   }
-  T* yb = y + (size_t)b * Tn * d + c;
+  T* yb = y + (size_t)b * Tn * ldy + c;
+  const T* gb = MODE == EM_DW_GATE ? gate + (size_t)b * Tn * ldg + c : nullptr;
 #pragma unroll
-  for (int o = 0; o < TT; ++o)
-    if (t0 + o < Tn) yb[(size_t)(t0 + o) * d] = from_f32<T>(swishf_(acc[o]));
+  for (int o = 0; o < TT; ++o) {
+    if (t0 + o >= Tn) continue;
+    float r = acc[o];
+    if (MODE == EM_DW_SWISH) r = swishf_(r);
+    if (MODE == EM_DW_GATE) r *= to_f32(gb[(size_t)(t0 + o) * ldg]);
+    if (MODE == EM_DW_SELFRES) r += to_f32(tile[o + HALF][tid]);
+    yb[(size_t)(t0 + o) * ldy] = from_f32<T>(r);
+  }
 }
 
-template <typename T>
-int launch_dw(const void* x, const float* w, const float* b, const int* tlens, int B, int Tn, int d,
-              int k, void* y, hipStream_t s) {
-  if (d % (16 / (int)sizeof(T)) != 0) return EM_ERR_UNSUPPORTED;
+template <typename T, int MODE>
+int launch_dw(const void* x, int ldx, const float* w, const float* b, const int* tlens, int B, int Tn, int d,
+              int k, const void* gate, int ldg, void* y, int ldy, hipStream_t s) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  if (d % EPC != 0 || ldx % EPC != 0) return EM_ERR_UNSUPPORTED;  // 16-byte staged loads
   dim3 grid(em_cdiv(d, 256), em_cdiv(Tn, TT), B);
-#define EM_DW_CASE(KW)                                                                      \
-  case KW:                                                                                  \
-    hipLaunchKernelGGL((dwconv_kernel<T, KW>), grid, dim3(256), 0, s, (const T*)x, w, b, tlens, \
-                       Tn, d, (T*)y);                                                       \
+#define EM_DW_CASE(KW)                                                                               \
+  case KW:                                                                                           \
+    hipLaunchKernelGGL((dwconv_kernel<T, KW, MODE>), grid, dim3(256), 0, s, (const T*)x, ldx, w, b,  \
+                       tlens, Tn, d, (const T*)gate, ldg, (T*)y, ldy);                               \
     break;
   switch (k) {
     EM_DW_CASE(3) EM_DW_CASE(7) EM_DW_CASE(15) EM_DW_CASE(31)
@@ -90,13 +107,35 @@ int launch_dw(const void* x, const float* w, const float* b, const int* tlens, i
   return EM_OK;
 }
 
+template <typename T>
+int dispatch_dw(int mode, const void* x, int ldx, const float* w, const float* b, const int* tlens, int B,
+                int Tn, int d, int k, const void* gate, int ldg, void* y, int ldy, hipStream_t s) {
+  switch (mode) {
+    case EM_DW_SWISH: return launch_dw<T, EM_DW_SWISH>(x, ldx, w, b, tlens, B, Tn, d, k, gate, ldg, y, ldy, s);
+    case EM_DW_LINEAR: return launch_dw<T, EM_DW_LINEAR>(x, ldx, w, b, tlens, B, Tn, d, k, gate, ldg, y, ldy, s);
+    case EM_DW_GATE:
+      if (!gate || ldg < d) return EM_ERR_BAD_ARG;
+      return launch_dw<T, EM_DW_GATE>(x, ldx, w, b, tlens, B, Tn, d, k, gate, ldg, y, ldy, s);
+    case EM_DW_SELFRES: return launch_dw<T, EM_DW_SELFRES>(x, ldx, w, b, tlens, B, Tn, d, k, gate, ldg, y, ldy, s);
+  }
+  return EM_ERR_BAD_ARG;
+}
+
 }  // namespace
+
+extern "C" int em_dwconv(int dtype, int mode, const void* x, int32_t ldx, const float* w, const float* b,
+                         const int32_t* tlens, int32_t B, int32_t T, int32_t d, int32_t k, const void* gate,
+                         int32_t ldg, void* y, int32_t ldy, void* stream) {
+  if (!x || !w || !b || !y || B <= 0 || T <= 0 || d <= 0 || k > KMAX || ldx < d || ldy < d) return EM_ERR_BAD_ARG;
+  if (dtype == EM_F32)
+    return dispatch_dw<float>(mode, x, ldx, w, b, tlens, B, T, d, k, gate, ldg, y, ldy, (hipStream_t)stream);
+  if (dtype == EM_BF16)
+    return dispatch_dw<bf16>(mode, x, ldx, w, b, tlens, B, T, d, k, gate, ldg, y, ldy, (hipStream_t)stream);
+  return EM_ERR_BAD_ARG;
+}
 
 extern "C" int em_dwconv_bn_swish(int dtype, const void* x, const float* w, const float* b,
                                   const int32_t* tlens, int32_t B, int32_t T, int32_t d, int32_t k,
                                   void* y, void* stream) {
-  if (B <= 0 || T <= 0 || d <= 0 || k > KMAX) return EM_ERR_BAD_ARG;
-  if (dtype == EM_F32) return launch_dw<float>(x, w, b, tlens, B, T, d, k, y, (hipStream_t)stream);
-  if (dtype == EM_BF16) return launch_dw<bf16>(x, w, b, tlens, B, T, d, k, y, (hipStream_t)stream);
-  return EM_ERR_BAD_ARG;
+  return em_dwconv(dtype, EM_DW_SWISH, x, d, w, b, tlens, B, T, d, k, nullptr, 0, y, d, stream);
 }

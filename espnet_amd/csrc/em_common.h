@@ -62,6 +62,8 @@ __device__ __forceinline__ float sigmoidf_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+// exact (erf) GELU = torch.nn.GELU() default (cgmlp.py:106-108)
+__device__ __forceinline__ float geluf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

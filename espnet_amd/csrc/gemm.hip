@@ -374,9 +374,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
       v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w);
     } else if (EPI == EM_EPI_RELU) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (EPI == EM_EPI_GELU) {
+      v.x = geluf_(v.x); v.y = geluf_(v.y); v.z = geluf_(v.z); v.w = geluf_(v.w);
     }
     const size_t o = (size_t)m * ldc + ncol;
-    if (EPI == EM_EPI_STORE || EPI == EM_EPI_SWISH || EPI == EM_EPI_RELU) {
+    if (EPI == EM_EPI_STORE || EPI == EM_EPI_SWISH || EPI == EM_EPI_RELU || EPI == EM_EPI_GELU) {
       T* C = (T*)Cv + o;
       if (full4) {
         if (sizeof(T) == 2) {
@@ -471,6 +473,7 @@ int dispatch(int epi, int amode, const EmGemmArgs* p, hipStream_t s) {
     case EM_EPI_STORE: return launch<T, EM_EPI_STORE, EM_A_PLAIN>(p, s);
     case EM_EPI_SWISH: return launch<T, EM_EPI_SWISH, EM_A_PLAIN>(p, s);
     case EM_EPI_RELU: return launch<T, EM_EPI_RELU, EM_A_PLAIN>(p, s);
+    case EM_EPI_GELU: return launch<T, EM_EPI_GELU, EM_A_PLAIN>(p, s);
     case EM_EPI_RESID_F32: return launch<T, EM_EPI_RESID_F32, EM_A_PLAIN>(p, s);
     case EM_EPI_SCALE_F32: return launch<T, EM_EPI_SCALE_F32, EM_A_PLAIN>(p, s);
     case EM_EPI_GLU: return launch<T, EM_EPI_GLU, EM_A_PLAIN>(p, s);

@@ -157,6 +157,44 @@ int launch_ln(float* x, const float* g1, const float* b1, const float* g2, const
   return EM_OK;
 }
 
+
+// LayerNorm of an act-dtype matrix with arbitrary row strides (the gate half of the cgMLP hidden
+// activation, cgmlp.py:63-64: channels [n, 2n) of a [M][2n] matrix).  One wave per row, values in
+// registers (n <= 64 * NVA), two-pass statistics like ln_row.
+constexpr int NVA = 48;
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_act_kernel(const T* __restrict__ x, int ldx,
+                                                            const float* __restrict__ g,
+                                                            const float* __restrict__ b, int M, int n,
+                                                            float eps, T* __restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* xr = x + (size_t)row * ldx;
+  float v[NVA];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NVA; ++j) {
+    const int c = lane + 64 * j;
+    v[j] = c < n ? to_f32(xr[c]) : 0.f;
+    s += v[j];
+  }
+  const float mean = wave_sum(s) / (float)n;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NVA; ++j) {
+    const float c = (lane + 64 * j < n) ? v[j] - mean : 0.f;
+    q += c * c;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + eps);
+  T* o = out + (size_t)row * ldo;
+#pragma unroll
+  for (int j = 0; j < NVA; ++j) {
+    const int c = lane + 64 * j;
+    if (c < n) o[c] = from_f32<T>((v[j] - mean) * rstd * g[c] + b[c]);
+  }
+}
+
 }  // namespace
 
 extern "C" int em_layernorm(int dtype, const float* x, const float* g, const float* b, int32_t M,
@@ -189,4 +227,21 @@ extern "C" int em_layernorm_inplace_f32(float* x, const float* g, const float* b
   if (M <= 0 || d <= 0 || d % 64 != 0) return d % 64 ? EM_ERR_UNSUPPORTED : EM_ERR_BAD_ARG;
   return launch_ln<float, 2>(x, g, b, nullptr, nullptr, M, d, eps, (float*)nullptr, nullptr,
                              (hipStream_t)stream);
+}
+
+extern "C" int em_layernorm_act(int dtype, const void* x, int32_t ldx, const float* g, const float* b,
+                                int32_t M, int32_t n, float eps, void* out, int32_t ldo, void* stream) {
+  if (!x || !g || !b || !out || M <= 0 || n <= 0 || ldx < n || ldo < n) return EM_ERR_BAD_ARG;
+  if (n > 64 * NVA) return EM_ERR_UNSUPPORTED;
+  dim3 grid(em_cdiv(M, 4));
+  if (dtype == EM_F32)
+    hipLaunchKernelGGL(layernorm_act_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       ldx, g, b, M, n, eps, (float*)out, ldo);
+  else if (dtype == EM_BF16)
+    hipLaunchKernelGGL(layernorm_act_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       g, b, M, n, eps, (bf16*)out, ldo);
+  else
+    return EM_ERR_BAD_ARG;
+  EM_CHECK_LAUNCH();
+  return EM_OK;
 }

@@ -15,9 +15,10 @@ EM_OK = 0
 EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE = -1, -2, -3, -4, -5
 EM_F32, EM_BF16 = 0, 1
 (EM_EPI_STORE, EM_EPI_SWISH, EM_EPI_RELU, EM_EPI_RESID_F32, EM_EPI_SCALE_F32, EM_EPI_GLU,
- EM_EPI_STORE_F32, EM_EPI_RESID_LN, EM_EPI_SCALE_LN, EM_EPI_ARGMAX_PART) = range(10)
+ EM_EPI_STORE_F32, EM_EPI_RESID_LN, EM_EPI_SCALE_LN, EM_EPI_ARGMAX_PART, EM_EPI_GELU) = range(11)
 EM_A_PLAIN, EM_A_CONV2 = 0, 1
 
+EM_DW_SWISH, EM_DW_LINEAR, EM_DW_GATE, EM_DW_SELFRES = range(4)
 EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flag (include/espnet_amd.h)
 DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
 
@@ -65,6 +66,26 @@ class EmConformerWeights(C.Structure):
                 ("conv2_b", C.c_void_p), ("embed_w", C.c_void_p), ("embed_b", C.c_void_p),
                 ("wpos_all", C.c_void_p), ("after_norm_g", C.c_void_p),
                 ("after_norm_b", C.c_void_p), ("layers", C.POINTER(EmConformerLayer))]
+
+
+# order of include/espnet_amd.h EmEBranchformerLayer
+_EBF_LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b", "norm_mlp_g", "norm_mlp_b",
+                   "norm_ff_g", "norm_ff_b", "norm_final_g", "norm_final_b", "ffm_w1", "ffm_w2", "ff_w1", "ff_w2",
+                   "ffm_b1", "ffm_b2", "ff_b1", "ff_b2", "wqkv", "bqkv", "pos_u", "pos_v", "wout", "bout",
+                   "proj1_w", "proj1_b", "csgu_norm_g", "csgu_norm_b", "csgu_conv_w", "csgu_conv_b", "proj2_w",
+                   "proj2_b", "merge_conv_w", "merge_conv_b", "merge_w", "merge_b"]
+
+
+class EmEBranchformerLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _EBF_LAYER_PTRS]
+
+
+class EmEBranchformerWeights(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d", "heads", "ff", "cg", "num_blocks", "cg_kernel", "merge_kernel",
+                                         "n_mels")] + \
+               [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "embed_w", "embed_b",
+                                          "wpos_all", "after_norm_g", "after_norm_b")] + \
+               [("layers", C.POINTER(EmEBranchformerLayer))]
 
 
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",
@@ -142,6 +163,12 @@ _SIGNATURES = {
     "em_log_softmax_rows_f32": (C.c_int, [_vp, _i32, _i32, _vp]),
     "em_ctc_collapse": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "em_conformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32]),
+    "em_ebranchformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmEBranchformerWeights), _i32, _i32]),
+    "em_ebranchformer_encode": (C.c_int, [C.c_int, C.POINTER(EmEBranchformerWeights), _vp, _vp, _vp, _vp,
+                                          _i32, _i32, _vp, _vp, _sz, _vp, _vp, _i32, _vp]),
+    "em_dwconv": (C.c_int, [C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp,
+                            _i32, _vp]),
+    "em_layernorm_act": (C.c_int, [C.c_int, _vp, _i32, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "em_conformer_encode": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _vp, _vp, _vp,
                                       _i32, _i32, _vp, _vp, _sz, _vp, _vp, _i32, _vp]),
     "em_stream_pos_enc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),

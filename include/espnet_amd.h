@@ -54,6 +54,7 @@ extern "C" {
  *   C[m][g] = (max, argmax) of (acc + bias) over the 64 columns [64 g, 64 g + 64) as an (f32, i32) pair;
  *   ldc = number of 64-column groups = 2 * ceil(N / 128); finish with em_argmax_partials.        */
 #define EM_EPI_ARGMAX_PART 9
+#define EM_EPI_GELU 10     /* C[act]  = gelu_erf(acc + bias)    (cgMLP channel_proj1, cgmlp.py:106) */
 
 /* A-operand addressing */
 #define EM_A_PLAIN 0 /* row m at A + m*lda */
@@ -167,6 +168,23 @@ int em_dwconv_bn_swish(int dtype, const void* x, const float* w, const float* b,
                        const int32_t* tlens, int32_t B, int32_t T, int32_t d, int32_t k, void* y,
                        void* stream);
 
+/*   The same kernel with the output stage selectable and per-operand row strides (E-Branchformer:
+ *   espnet2/asr/layers/cgmlp.py:61-79 and e_branchformer_encoder.py:166-170):
+ *     EM_DW_SWISH   y = swish(conv(x) + b)      EM_DW_LINEAR  y = conv(x) + b
+ *     EM_DW_GATE    y = gate * (conv(x) + b)    EM_DW_SELFRES y = x + conv(x) + b
+ *   x [B][T] rows of stride ldx, gate rows of stride ldg (EM_DW_GATE only), y rows of stride ldy.   */
+#define EM_DW_SWISH 0
+#define EM_DW_LINEAR 1
+#define EM_DW_GATE 2
+#define EM_DW_SELFRES 3
+int em_dwconv(int dtype, int mode, const void* x, int32_t ldx, const float* w, const float* b,
+              const int32_t* tlens, int32_t B, int32_t T, int32_t d, int32_t k, const void* gate,
+              int32_t ldg, void* y, int32_t ldy, void* stream);
+/*   LayerNorm (layer_norm.py:12-42) of an act-dtype matrix with row strides: the gate half of the cgMLP
+ *   hidden activation (cgmlp.py:63).  x rows of stride ldx, n channels, out rows of stride ldo.        */
+int em_layernorm_act(int dtype, const void* x, int32_t ldx, const float* g, const float* b, int32_t M,
+                     int32_t n, float eps, void* out, int32_t ldo, void* stream);
+
 /* ---- A11 / G1: CTC head.  argmax over vocab (asr/ctc.py:207-215), then groupby + drop
  *      blank/sos/eos (bin/asr_inference.py:574-575).  logits [M][V] f32.                        */
 int em_argmax_rows_f32(const float* logits, int32_t M, int32_t V, int32_t* ids, void* stream);
@@ -238,6 +256,52 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
                         int32_t B, int32_t T_f, const void* pos_emb, void* workspace,
                         size_t workspace_bytes, float* enc_out, void* enc_act, int32_t flags,
                         void* stream);
+
+/* ---- §8(f) rank 4: E-Branchformer encoder (espnet2/asr/encoder/e_branchformer_encoder.py:55-520) for
+ *      input_layer=conv2d, rel_pos / rel_selfattn (latest), use_ffn + macaron_ffn, swish FFN,
+ *      cgMLP with identity gate and no linear after the conv (espnet2/asr/layers/cgmlp.py).
+ *      Conv2dSubsampling, rel-pos attention, FFN and LayerNorm are the Conformer kernels.          */
+typedef struct EmEBranchformerLayer {
+  const float *norm_ff_mac_g, *norm_ff_mac_b, *norm_mha_g, *norm_mha_b, *norm_mlp_g, *norm_mlp_b;
+  const float *norm_ff_g, *norm_ff_b, *norm_final_g, *norm_final_b;
+  const void *ffm_w1, *ffm_w2, *ff_w1, *ff_w2; /* [ff][d], [d][ff] act */
+  const float *ffm_b1, *ffm_b2, *ff_b1, *ff_b2;
+  const void* wqkv;  /* [3d][d] act (q | k | v) */
+  const float* bqkv;
+  const float *pos_u, *pos_v; /* [h][dk] */
+  const void* wout;           /* [d][d] act */
+  const float* bout;
+  const void* proj1_w; /* cgmlp.channel_proj1.0 [cg][d] act */
+  const float* proj1_b;
+  const float *csgu_norm_g, *csgu_norm_b; /* [cg/2] */
+  const float *csgu_conv_w, *csgu_conv_b; /* [k][cg/2] tap-major, [cg/2] */
+  const void* proj2_w;                    /* cgmlp.channel_proj2 [d][cg/2] act */
+  const float* proj2_b;
+  const float *merge_conv_w, *merge_conv_b; /* depthwise_conv_fusion [km][2d] tap-major, [2d] */
+  const void* merge_w;                      /* merge_proj [d][2d] act */
+  const float* merge_b;
+} EmEBranchformerLayer;
+
+typedef struct EmEBranchformerWeights {
+  int32_t d, heads, ff, cg, num_blocks, cg_kernel, merge_kernel, n_mels;
+  const float *conv1_w, *conv1_b;
+  const void* conv2_w;
+  const float* conv2_b;
+  const void* embed_w;
+  const float* embed_b;
+  const void* wpos_all; /* [num_blocks*d][d] act */
+  const float *after_norm_g, *after_norm_b;
+  const EmEBranchformerLayer* layers;
+} EmEBranchformerWeights;
+
+size_t em_ebranchformer_workspace_bytes(int dtype, const EmEBranchformerWeights* w, int32_t B, int32_t T_f);
+/*   Arguments as em_conformer_encode.  flags: EM_ENC_ISOLATE_UTTS masks both depthwise convs (cgMLP and
+ *   merge) by olens; 0 reproduces the reference's unmasked convs over a padded batch.              */
+int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* w, const float* feats,
+                            const float* mvn_partial, const int32_t* flens, const int32_t* olens,
+                            int32_t B, int32_t T_f, const void* pos_emb, void* workspace,
+                            size_t workspace_bytes, float* enc_out, void* enc_act, int32_t flags,
+                            void* stream);
 
 /* ---- A11 + G1 assembled: ctc_lo GEMM (+ arg-max fused in its epilogue) -> collapse.
  *   enc_act [B*T][d] act; w_ctc [V][d] act; logits_ws >= B*T * 2*ceil(V/128) * 2 f32 scratch;

@@ -1,0 +1,148 @@
+"""GPU parity of the E-Branchformer encoder through the C-ABI
+(em_ebranchformer_encode; kernel-level: em_gemm GELU epilogue, em_layernorm_act, em_dwconv modes)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import conformer as oc  # noqa: E402
+from oracle import ebranchformer as oe  # noqa: E402
+from tests.helpers import golden_speech, golden_state_dict, hparams, load_golden  # noqa: E402
+
+
+def build(g, dtype):
+    from espnet_amd.tasks.asr import ASRTask
+
+    cfg = dict(g["config"])
+    cfg["compute_dtype"] = dtype
+    model = ASRTask.build_model(cfg)
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    return model.cuda().eval()
+
+
+def test_state_dict_keys_equal_reference():
+    g = load_golden("ebf_tiny_blocks")
+    model = build(g, "float32")
+    import json
+
+    ref = {k: tuple(v) for k, v in json.loads(str(g["state_shapes"])).items()}
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert {k: v for k, v in mine.items() if k.startswith("encoder.")} == \
+           {k: v for k, v in ref.items() if k.startswith("encoder.")}
+
+
+@pytest.mark.parametrize("name", ["ebf_small_5s"])
+def test_encode_float32_matches_reference(name):
+    g = load_golden(name)
+    model = build(g, "float32")
+    speech, lens = golden_speech(g)
+    enc, olens = model.encode(speech.cuda(), lens)
+    assert olens.tolist() == g["enc_olens"].tolist()
+    ke = int(g["enc_keep_every"])
+    ref = torch.from_numpy(g["enc_out"])
+    for b in range(enc.size(0)):  # padded rows beyond olens are not defined by the reference either
+        n = (int(olens[b]) + ke - 1) // ke
+        err = (enc[b, ::ke].cpu()[:n] - ref[b, :n]).abs().max().item()
+        assert err < 2e-3, (b, err)
+    _, tokens, tlens = model.greedy_ctc_device(model._last_state)
+    ids = model.ctc.argmax(enc).cpu().numpy()
+    diff = ids != g["ctc_ids"]
+    for b in range(ids.shape[0]):
+        n = int(olens[b])
+        assert (g["ctc_margin"][b, :n][diff[b, :n]] < 1e-4).all()
+        if not diff[b, :n].any():
+            assert tokens[b, : int(tlens[b])].tolist() == g["g1_tokens"][b, : g["g1_lens"][b]].tolist()
+
+
+def test_encode_bfloat16_within_tolerance_and_isolated_rows():
+    g = load_golden("ebf_small_5s")
+    sd = golden_state_dict(g)
+    hp = hparams(g)
+    speech, lens = golden_speech(g)
+    model = build(g, "bfloat16")
+    enc, olens = model.encode(speech.cuda(), lens)
+    ke = int(g["enc_keep_every"])
+    ref = torch.from_numpy(g["enc_out"])
+    for b in range(enc.size(0)):
+        n = (int(olens[b]) + ke - 1) // ke
+        rel = (enc[b, ::ke].cpu()[:n] - ref[b, :n]).norm() / ref[b, :n].norm()
+        assert rel < 3e-2, (b, float(rel))  # bf16 operands, f32 accumulation / residual stream
+    # isolated-utterance batching (decode CLI semantics): row b == the ORACLE on utterance b alone
+    m32 = build(g, "float32")
+    st = m32.encode_device(speech.cuda(), [int(v) for v in lens], isolate=True)
+    for b, n in enumerate(int(v) for v in lens):
+        with torch.no_grad():
+            r, ol = oe.encode(sd, speech[b : b + 1, :n], torch.tensor([n]), hp["heads"], hp["num_blocks"],
+                              hp["n_fft"], hp["win_length"], hp["hop"])
+        T = int(ol[0])
+        assert st.olens[b] == T
+        assert (st.enc_out[b, :T].cpu() - r[0]).abs().max().item() < 2e-3
+
+
+def _dev(t):
+    return t.cuda().contiguous()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_cgmlp_kernels_against_torch(prec):
+    """GELU epilogue, strided LayerNorm and the gated / self-residual depthwise conv, each against plain
+    torch fp32 on the same (rounded) inputs."""
+    from espnet_amd import lib as L
+
+    lib = L.load()
+    dt, tdt, tol = (L.EM_F32, torch.float32, 3e-5) if prec == "f32" else (L.EM_BF16, torch.bfloat16, 2e-2)
+    g = torch.Generator().manual_seed(3)
+    M, d, cg, B, T, k = 2 * 37, 128, 256, 2, 37, 15
+    ch = cg // 2
+    sp = L.current_stream_ptr()
+    # GEMM + exact GELU
+    a = (torch.randn(M, d, generator=g) * 0.5).to(tdt)
+    w = (torch.randn(cg, d, generator=g) * d ** -0.5).to(tdt)
+    bias = torch.randn(cg, generator=g) * 0.1
+    ref = F.gelu(F.linear(a.float(), w.float(), bias))
+    h = torch.empty(M, cg, dtype=tdt, device="cuda")
+    ad, wd, bd = _dev(a), _dev(w), _dev(bias)
+    args = L.EmGemmArgs(A=ad.data_ptr(), W=wd.data_ptr(), C=h.data_ptr(), bias=bd.data_ptr(), M=M, N=cg, K=d,
+                        lda=d, ldc=cg, scale=1.0)
+    L.check(lib.em_gemm(dt, L.EM_EPI_GELU, L.EM_A_PLAIN, args, sp), "gelu gemm")
+    assert (h.float().cpu() - ref).abs().max().item() < tol * 4
+    # LayerNorm of the gate half, in place in the wide matrix
+    hq = h.float().cpu()
+    gam, bet = 1 + 0.1 * torch.randn(ch, generator=g), 0.1 * torch.randn(ch, generator=g)
+    ref_gn = F.layer_norm(hq[:, ch:], (ch,), gam, bet, 1e-12)
+    gn = torch.empty(M, ch, dtype=tdt, device="cuda")
+    gd, bd2 = _dev(gam), _dev(bet)
+    L.check(lib.em_layernorm_act(dt, h.data_ptr() + ch * h.element_size(), cg, gd.data_ptr(), bd2.data_ptr(), M, ch,
+                                 1e-12, gn.data_ptr(), ch, sp), "ln act")
+    assert (gn.float().cpu() - ref_gn).abs().max().item() < tol * 8
+    # gated depthwise conv: r * (conv(gn) + b), with and without length masking
+    cw = torch.randn(ch, 1, k, generator=g) * k ** -0.5
+    cb = torch.randn(ch, generator=g) * 0.1
+    gq = gn.float().cpu().view(B, T, ch)
+    rq = hq[:, :ch].view(B, T, ch)
+    cwd, cbd = _dev(cw.reshape(ch, k).t()), _dev(cb)
+    for tl in (None, [T, T // 2]):
+        gm = gq.clone()
+        if tl is not None:
+            for bi, n in enumerate(tl):
+                gm[bi, n:] = 0
+        ref_gate = rq * F.conv1d(gm.transpose(1, 2), cw, cb, padding=(k - 1) // 2, groups=ch).transpose(1, 2)
+        out = torch.empty(B, T, ch, dtype=tdt, device="cuda")
+        tld = torch.tensor(tl, dtype=torch.int32, device="cuda") if tl is not None else None
+        L.check(lib.em_dwconv(dt, L.EM_DW_GATE, gn.data_ptr(), ch, cwd.data_ptr(), cbd.data_ptr(), L.ptr(tld), B, T, ch,
+                              k, h.data_ptr(), cg, out.data_ptr(), ch, sp), "dw gate")
+        for bi in range(B):
+            n = T if tl is None else tl[bi]
+            assert (out[bi, :n].float().cpu() - ref_gate[bi, :n]).abs().max().item() < tol * 8
+    # self-residual depthwise conv over a [.., 2d] matrix
+    cat = (torch.randn(B, T, 2 * d, generator=g) * 0.5).to(tdt)
+    mw = torch.randn(2 * d, 1, 7, generator=g) * 7 ** -0.5
+    mb = torch.randn(2 * d, generator=g) * 0.1
+    ref_m = cat.float() + F.conv1d(cat.float().transpose(1, 2), mw, mb, padding=3, groups=2 * d).transpose(1, 2)
+    outm = torch.empty(B, T, 2 * d, dtype=tdt, device="cuda")
+    catd, mwd, mbd = _dev(cat), _dev(mw.reshape(2 * d, 7).t()), _dev(mb)
+    L.check(lib.em_dwconv(dt, L.EM_DW_SELFRES, catd.data_ptr(), 2 * d, mwd.data_ptr(), mbd.data_ptr(), None, B, T,
+                          2 * d, 7, None, 0, outm.data_ptr(), 2 * d, sp), "dw selfres")
+    assert (outm.float().cpu() - ref_m).abs().max().item() < tol * 8
