@@ -38,6 +38,8 @@ MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3}  # /opt/skills/guides/
 CONFIGS = {
     "small": dict(d=256, heads=4, ff=1024, win_length=400),
     "large": dict(d=512, heads=8, ff=2048, win_length=None),
+    # E-Branchformer of egs2/librispeech/asr1/conf/tuning/train_asr_e_branchformer.yaml
+    "ebf": dict(d=512, heads=8, ff=1024, win_length=None, ebf=dict(cg=3072, blocks=17, merge=31)),
 }
 
 
@@ -46,6 +48,20 @@ def model_config(name, dtype):
     fconf = dict(n_fft=512, hop_length=160)
     if c["win_length"]:
         fconf["win_length"] = c["win_length"]
+    if "ebf" in c:
+        e = c["ebf"]
+        enc = dict(encoder="e_branchformer",
+                   encoder_conf=dict(output_size=c["d"], attention_heads=c["heads"], linear_units=c["ff"],
+                                     num_blocks=e["blocks"], input_layer="conv2d", rel_pos_type="latest",
+                                     pos_enc_layer_type="rel_pos", attention_layer_type="rel_selfattn",
+                                     cgmlp_linear_units=e["cg"], cgmlp_conv_kernel=31, use_linear_after_conv=False,
+                                     gate_activation="identity", use_ffn=True, macaron_ffn=True,
+                                     ffn_activation_type="swish", merge_conv_kernel=e["merge"]))
+        return dict(token_list=["<blank>", "<unk>"] + [f"t{i}" for i in range(VOCAB - 3)] + ["<sos/eos>"],
+                    frontend="default", frontend_conf=fconf, normalize="utterance_mvn", normalize_conf={},
+                    decoder="transformer",
+                    decoder_conf=dict(attention_heads=c["heads"], linear_units=2048, num_blocks=6),
+                    model_conf=dict(ctc_weight=0.3), compute_dtype=dtype, **enc)
     return dict(
         token_list=["<blank>", "<unk>"] + [f"t{i}" for i in range(VOCAB - 3)] + ["<sos/eos>"],
         frontend="default", frontend_conf=fconf, normalize="utterance_mvn", normalize_conf={},
@@ -85,6 +101,11 @@ def cpu_baseline(model, budget_s=12.0):
     cores = max(1, min(32, avail))
     torch.set_num_threads(cores)
     wl = fe.win_length
+    encode_fn = oc.encode
+    if type(enc).__name__ == "EBranchformerEncoder":
+        from oracle import ebranchformer as oe
+
+        encode_fn = oe.encode
     times = []
     t_start = time.perf_counter()
     i = 0
@@ -92,7 +113,7 @@ def cpu_baseline(model, budget_s=12.0):
         while True:
             wav = synth_batch(9000 + i, 1)
             t0 = time.perf_counter()
-            e, ol = oc.encode(sd, wav, torch.tensor([N_SAMPLES]), enc.heads, enc.num_blocks, 512, wl, 160)
+            e, ol = encode_fn(sd, wav, torch.tensor([N_SAMPLES]), enc.heads, enc.num_blocks, 512, wl, 160)
             oc.greedy_ctc(sd, e, ol, blank=0, sos_eos=VOCAB - 1)
             dt = time.perf_counter() - t0
             if i > 0:
@@ -399,8 +420,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[1]: Conformer-{args.model} "
-                                    f"(12x{CONFIGS[args.model]['d']}d, {CONFIGS[args.model]['heads']} heads), "
+            "config": {"workload": ((f"BASELINE.json configs[1]: Conformer-{args.model} "
+                                     f"(12x{CONFIGS[args.model]['d']}d, {CONFIGS[args.model]['heads']} heads), "
+                                     if "ebf" not in CONFIGS[args.model] else
+                                     "SURVEY 8(f) rank 4: E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31), ") +
                                     f"HIP STFT/log-mel + HIP encoder + greedy CTC (G1), "
                                     f"{B} x 10 s utterances per GPU per step, V={VOCAB}")
                        if beam_search is None else
