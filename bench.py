@@ -189,7 +189,8 @@ def main_stream(args):
     torch.manual_seed(0)
     with tempfile.TemporaryDirectory() as td:
         (Path(td) / "config.yaml").write_text(yaml.safe_dump(cfg))
-        s2t = Speech2TextStreaming(str(Path(td) / "config.yaml"), None, device="cuda", dtype=args.dtype)
+        s2t = Speech2TextStreaming(str(Path(td) / "config.yaml"), None, device="cuda", dtype=args.dtype,
+                                   beam_size=args.stream_beam, ctc_weight=0.3)
     chunk = 10240
     wav = synth_batch(0, 1)[0]
     chunks = [wav[p : p + chunk] for p in range(0, N_SAMPLES, chunk)]
@@ -220,11 +221,15 @@ def main_stream(args):
            "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[4]: streaming contextual_block_conformer (12x256d, "
                                   "block 40 / hop 16 / look-ahead 16), ONE stream, 640 ms chunks, hipGraph-"
-                                  "captured encoder step, incremental greedy CTC",
+                                  "captured encoder step, " + ("incremental greedy CTC" if args.stream_beam <= 1 else
+                                                               "block-synchronous online beam search"),
                       "chunk_ms": 640, "chunks_per_utt": len(chunks),
                       "chunk_latency_ms_median": round(lats[len(lats) // 2] * 1e3, 3),
                       "chunk_latency_ms_p95": round(lats[int(len(lats) * 0.95)] * 1e3, 3),
                       "hipgraph_replays": s2t._runner.n_replays if s2t._runner else 0,
+                      **({"search": f"BatchBeamSearchOnline beam {args.stream_beam}, ctc_weight 0.3",
+                          "search_steps_per_utt": s2t.beam_search.n_steps // (args.steps + args.warmup)}
+                         if args.stream_beam > 1 else {}),
                       "tokens_last_utt": len(out[0][2]) if out else 0}}
     if not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_stream(s2t.asr_model, enc_conf)
@@ -281,6 +286,12 @@ def main():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--streams", type=int, default=1,
                     help="split the per-GPU batch over this many HIP streams (independent utterances)")
+    ap.add_argument("--stream-beam", type=int, default=1,
+                    help="--workload stream: beam size; > 1 decodes with the block-synchronous online search "
+                         "(BatchBeamSearchOnline) instead of incremental greedy CTC")
+    ap.add_argument("--h2d", action="store_true",
+                    help="also copy the waveforms host->device inside every timed step (pinned host memory): the "
+                         "PCIe-inclusive rate quoted in DESIGN.md; never the headline `value`")
     ap.add_argument("--graph", action="store_true",
                     help="greedy workload: capture the whole pass (all --streams branches) in one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -312,6 +323,7 @@ def main():
     torch.manual_seed(0)
     model = ASRTask.build_model(model_config(args.model, args.dtype)).to(dev).eval()
     B = args.batch
+    wav_host = synth_batch(rank * B, B).pin_memory() if args.h2d else None
     wav = synth_batch(rank * B, B).to(dev)
     lens = [N_SAMPLES] * B
     T = model.encoder.output_frames(1 + N_SAMPLES // 160)
@@ -361,6 +373,8 @@ def main():
             if world > 1:
                 collate(tokens, tlens)
             return tokens, tlens
+        if wav_host is not None:
+            wav.copy_(wav_host, non_blocking=True)
         st = model.encode_device(wav, lens)
         if beam_search is None:
             _, tokens, tlens = model.greedy_ctc_device(st)
@@ -432,7 +446,8 @@ def main():
                         f"attention decoder, joint CTC/attention beam search beam={args.beam} "
                         f"ctc_weight={args.ctc_weight}, {B} x 10 s utterances per GPU per step, V={VOCAB}"),
                        "batch_per_gpu": B, "global_batch": world * B, "audio_seconds_per_utt": AUDIO_SEC,
-                       "parallelism": f"utterance-dp{world}", "greedy_tokens_last_step_rank0": n_tok},
+                       "parallelism": f"utterance-dp{world}", "greedy_tokens_last_step_rank0": n_tok,
+                       **({"inputs": "host (pinned) -> device copy inside the timed step"} if args.h2d else {})},
         }
     # ---- roofline of the dominant kernel family (GEMM template): HIP events around every launch
     if rank == 0 and not args.no_roofline:

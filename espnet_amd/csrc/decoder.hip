@@ -96,7 +96,7 @@ template <> struct Raw8<float> {
 // NJ = 64/(DK/8) prefix positions x the whole head (16-byte loads for bf16), so a 250-token prefix
 // is 32 iterations for QK^T and 32 for PV; partial dots are reduced across the chunk lanes,
 // partial contexts across the position lanes.
-constexpr int SA_MAXL = 1024;
+constexpr int SA_MAXL = 4096;  // Lmax scores + Lmax ancestor slots per wave must fit the 64 KiB default LDS
 template <typename T, int DK>
 __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict__ qkv,
                                                            T* __restrict__ kc, T* __restrict__ vc,

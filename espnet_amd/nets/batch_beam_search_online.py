@@ -62,6 +62,7 @@ class BatchBeamSearchOnline(BatchBeamSearch):
         self.max_frames = max_frames  # frame capacity of one stream (source attention keeps T scores in LDS)
         self.use_hipgraph = False
         self.events: List[str] = []  # log markers of the reference, kept for tests / diagnostics
+        self.n_steps = 0  # label steps computed on the device since construction (diagnostics)
         self.reset()
 
     def reset(self):
@@ -143,6 +144,7 @@ class BatchBeamSearchOnline(BatchBeamSearch):
     def _search(self) -> _Rows:
         """best = self.search(self.running_hyps, h) (:400)."""
         D, lib = self._dev, L.load()
+        self.n_steps += 1
         L.check(lib.em_search_online_core(D["em_dtype"], C.byref(self._p), D["dwp"], C.byref(D["bs"]),
                                           self.process_idx, L.current_stream_ptr()), "em_search_online_core")
         D["best_host"].copy_(D["bufs"]["online_best"], non_blocking=True)
