@@ -294,6 +294,9 @@ def main():
                          "PCIe-inclusive rate quoted in DESIGN.md; never the headline `value`")
     ap.add_argument("--graph", action="store_true",
                     help="greedy workload: capture the whole pass (all --streams branches) in one hipGraph")
+    ap.add_argument("--dist-debug-one-gpu", action="store_true",
+                    help="developer check of the multi-rank control flow on a ONE-GPU box: every rank uses "
+                         "cuda:0 and the collectives go through gloo on host copies (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -309,13 +312,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.dist_debug_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_debug_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from espnet_amd import lib as L
     from espnet_amd.tasks.asr import ASRTask
@@ -333,6 +341,11 @@ def main():
 
     def collate(tokens, tlens):
         rec = torch.cat([tokens, tlens.view(-1, 1)], dim=1).contiguous()
+        if args.dist_debug_one_gpu:
+            parts = [torch.empty(rec.shape, dtype=rec.dtype) for _ in range(world)]
+            dist.all_gather(parts, rec.cpu())
+            gathered.copy_(torch.cat(parts, 0))
+            return
         dist.all_gather_into_tensor(gathered, rec)
 
     beam_search = None
@@ -362,15 +375,17 @@ def main():
 
     graph = {}
 
-    def step():
+    def step(do_collate=True):
+        # do_collate=False: rank 0's event-instrumented passes after the timed region run alone, so
+        # they must not enter a collective the other ranks never join
         if graph:
             graph["g"].replay()
-            if world > 1:
+            if world > 1 and do_collate:
                 collate(*graph["out"])
             return graph["out"]
         if streams and beam_search is None:
             tokens, tlens = step_multistream()
-            if world > 1:
+            if world > 1 and do_collate:
                 collate(tokens, tlens)
             return tokens, tlens
         if wav_host is not None:
@@ -388,7 +403,7 @@ def main():
                 tl.append(len(ids))
             tokens = tokens.to(dev)
             tlens = torch.tensor(tl, dtype=torch.int32, device=dev)
-        if world > 1:  # collate hypotheses: one RCCL all-gather of fixed-shape ids + lengths
+        if world > 1 and do_collate:  # collate hypotheses: one RCCL all-gather of fixed-shape ids + lengths
             collate(tokens, tlens)
         return tokens, tlens
 
@@ -419,7 +434,7 @@ def main():
             tokens, tlens = step()
         barrier()
         elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.dist_debug_one_gpu else dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -464,7 +479,7 @@ def main():
         with torch.no_grad():
             for _ in range(nprof):
                 lib.em_profile_attach(prof)
-                step()
+                step(do_collate=False)
                 lib.em_profile_attach(None)
                 L.check(lib.em_profile_read(prof, ms, fl, cap, C.byref(cnt)), "em_profile_read")
                 tot_ms += sum(ms[i] for i in range(cnt.value))
