@@ -260,7 +260,7 @@ def run_cli_case(name, conf, vocab, wseed, utts, beam, ctc_weight, nbest):
 
 
 def run_lm_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weight, lm_weight, nbest,
-                       lm_conf):
+                       lm_conf, lm_name="transformer"):
     """Speech2Text with a TransformerLM scorer (espnet2/bin/asr_inference.py:179-191, weight
     `lm_weight`; espnet2/lm/transformer_lm.py batch_score).  The LM config comes from an
     LMTask --dry_run (espnet2/tasks/lm.py), weights from the shared recipe (key prefix "lm.")."""
@@ -276,7 +276,7 @@ def run_lm_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_we
         (td / "train.yaml").write_text(yaml.safe_dump(conf))
         ASRTask.main(cmd=["--dry_run", "true", "--output_dir", str(td / "asr"), "--token_list", str(tok),
                           "--token_type", "word", "--config", str(td / "train.yaml")])
-        (td / "lm.yaml").write_text(yaml.safe_dump(dict(lm="transformer", lm_conf=lm_conf)))
+        (td / "lm.yaml").write_text(yaml.safe_dump(dict(lm=lm_name, lm_conf=lm_conf)))
         LMTask.main(cmd=["--dry_run", "true", "--output_dir", str(td / "lm"), "--token_list", str(tok),
                          "--token_type", "word", "--config", str(td / "lm.yaml")])
         s2t = Speech2Text(asr_train_config=str(td / "asr" / "config.yaml"), asr_model_file=None,
@@ -302,7 +302,7 @@ def run_lm_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_we
     out = dict(config_yaml=np.array(cfg_text), vocab=np.array(vocab), wseed=np.array(wseed),
                utt_id=np.array(utt_id), n_samples=np.array(n_samples), beam=np.array(beam),
                ctc_weight=np.array(ctc_weight), lm_weight=np.array(lm_weight), nbest=np.array(nbest),
-               lm_conf=np.array(json.dumps(lm_conf)),
+               lm_conf=np.array(json.dumps(lm_conf)), lm_name=np.array(lm_name),
                state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
                lm_state_shapes=np.array(json.dumps({k: list(v) for k, v in lm_shapes.items()})),
                melmat=model.frontend.logmel.melmat.numpy(), enc_out=enc[0].numpy().copy(),
@@ -586,6 +586,13 @@ CASES = {
                                                with_blocks=True),
     "ebf_small_5s": lambda: run_encode_case("ebf_small_5s", EBF_SMALL, 5000, 32, [53, 54], [80000, 48000],
                                             keep_every=4),
+    # SequentialRNNLM (LSTM) as the LM scorer (espnet2/lm/seq_rnn_lm.py; the LMTask default `lm: seq_rnn`)
+    "tiny_beam5_rnnlm": lambda: run_lm_search_case(
+        "tiny_beam5_rnnlm", tiny(d=64, heads=2, ff=128), 50, 7, 18, 28000, 5, 0.3, 0.7, 5,
+        dict(unit=64, nlayers=2), lm_name="seq_rnn"),
+    "tiny_beam4_rnnlm_nhid": lambda: run_lm_search_case(
+        "tiny_beam4_rnnlm_nhid", tiny(d=64, heads=2, ff=128), 50, 7, 19, 24000, 4, 0.5, 1.0, 4,
+        dict(unit=64, nhid=128, nlayers=1), lm_name="seq_rnn"),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

@@ -189,7 +189,8 @@ def test_streaming_encoder_oracle_matches_reference(name):
     np.testing.assert_allclose(y1[::ke].numpy(), g["ys_oneshot"], atol=2e-4, rtol=0)
 
 
-@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam60_lm_v300", "e2e_beam5_lm"])
+@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam60_lm_v300", "e2e_beam5_lm",
+                                  "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid"])
 def test_beam_search_with_lm_scorer_matches_reference(name):
     """TransformerLM as a full scorer (lm_weight) — oracle vs reference n-best."""
     import json
