@@ -622,6 +622,46 @@ inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const
 
 constexpr float LN_EPS = 1e-12f;
 
+// ---- SequentialRNNLM (LSTM) step pieces (espnet2/lm/seq_rnn_lm.py:140-177 batch_score) -------
+// hin[l][r] = h of row r's PARENT after the previous step (zero state at step 0, :155-156)
+template <typename T>
+__global__ void rnn_gather_kernel(Ctx c, int i_host, int layers, int ld) {
+  const int i = c.b.step ? *c.b.step : i_host;
+  if (i >= c.p.Lmax - 1) return;
+  const int n = c.p.B * c.p.W;
+  const int r = blockIdx.x, l = blockIdx.y;
+  int p = i > 0 ? c.b.parent[(size_t)i * n + r] : r;
+  p = (p < 0 || p >= n) ? r : p;  // rows that never lived carry no parent
+  const T* src = (const T*)c.b.rnn_hs + (((size_t)((i + 1) & 1) * layers + l) * n + p) * ld;
+  T* dst = (T*)c.b.rnn_hin + ((size_t)l * n + r) * ld;
+  for (int ch = threadIdx.x; ch < ld; ch += blockDim.x) dst[ch] = i > 0 ? src[ch] : from_f32<T>(0.f);
+}
+
+// gates [n][4*nhid] (i | f | g | o, already W_ih x + W_hh h + b) -> c, h (torch.nn.LSTM cell)
+template <typename T>
+__global__ void lstm_cell_kernel(Ctx c, int i_host, int layers, int l, int nhid, int ld) {
+  const int i = c.b.step ? *c.b.step : i_host;
+  if (i >= c.p.Lmax - 1) return;
+  const int n = c.p.B * c.p.W;
+  const int r = blockIdx.x;
+  int p = i > 0 ? c.b.parent[(size_t)i * n + r] : r;
+  p = (p < 0 || p >= n) ? r : p;
+  const float* g = c.b.rnn_gates + (size_t)r * 4 * nhid;
+  const float* cprev = c.b.rnn_cs + (((size_t)((i + 1) & 1) * layers + l) * n + p) * ld;
+  float* cnew = c.b.rnn_cs + (((size_t)(i & 1) * layers + l) * n + r) * ld;
+  T* hnew = (T*)c.b.rnn_hs + (((size_t)(i & 1) * layers + l) * n + r) * ld;
+  T* hout = (T*)c.b.rnn_hin + ((size_t)l * n + r) * ld;  // A operand of the next GEMM (fixed address)
+  for (int ch = threadIdx.x; ch < nhid; ch += blockDim.x) {
+    const float gi = 1.f / (1.f + expf(-g[ch])), gf = 1.f / (1.f + expf(-g[nhid + ch]));
+    const float gg = tanhf(g[2 * nhid + ch]), go = 1.f / (1.f + expf(-g[3 * nhid + ch]));
+    const float cc = gf * (i > 0 ? cprev[ch] : 0.f) + gi * gg;
+    const float hh = go * tanhf(cc);
+    cnew[ch] = cc;
+    hnew[ch] = from_f32<T>(hh);
+    hout[ch] = from_f32<T>(hh);
+  }
+}
+
 int check(const EmSearchParams* p, const EmSearchBuffers* b) {
   if (!p || !b) return EM_ERR_BAD_ARG;
   if (p->B <= 0 || p->W <= 0 || p->W > 64 || p->V <= 1 || p->T <= 0 || p->Lmax < 2) return EM_ERR_BAD_ARG;
@@ -639,8 +679,42 @@ int check(const EmSearchParams* p, const EmSearchBuffers* b) {
 // Encoder.forward_one_step): embedding -> input Linear + LayerNorm(1e-5) + ReLU (+ pos-enc) ->
 // pre-norm self-attention / ReLU feed-forward layers over the token-tree K/V cache -> after_norm ->
 // vocabulary projection (logits; the log-softmax is fused into the pre-beam kernel).
+int lstm_lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i, void* stream) {
+  const EmLmWeights* lm = b->lm;
+  const int n = p->B * p->W, V = p->V, d = lm->d, nh = lm->nhid, eu = lm->embed_unit, Ln = lm->num_blocks;
+  if (!lm->rnn || !b->rnn_hs || !b->rnn_cs || !b->rnn_hin || !b->rnn_gates || !b->lm_e) return EM_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{*p, *b};
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  const int32_t* step = b->step;
+  // embedding of the last token (seq_rnn_lm.py:92) and the parents' hidden states
+  EM_TRY(em_lm_embed(dtype, lm->embed, step ? b->tok : b->tok + (size_t)i * n, n, V, eu, step, p->Lmax,
+                     b->lm_e, stream));
+  if (dtype == EM_BF16)
+    hipLaunchKernelGGL(rnn_gather_kernel<bf16>, dim3(n, Ln), dim3(128), 0, s, c, i, Ln, d);
+  else
+    hipLaunchKernelGGL(rnn_gather_kernel<float>, dim3(n, Ln), dim3(128), 0, s, c, i, Ln, d);
+  for (int l = 0; l < Ln; ++l) {
+    const EmRnnLayer& q = lm->rnn[l];
+    const void* x = l == 0 ? b->lm_e : (const void*)((const unsigned char*)b->rnn_hin + (size_t)(l - 1) * n * d * es);
+    const int kin = l == 0 ? eu : d;
+    const void* hin = (const unsigned char*)b->rnn_hin + (size_t)l * n * d * es;
+    EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, x, q.w_ih, b->rnn_gates, q.bias, n, 4 * nh, kin, kin, 4 * nh, 1.f, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, hin, q.w_hh, b->rnn_gates, nullptr, n, 4 * nh, d, d, 4 * nh, 1.f, stream));
+    if (dtype == EM_BF16)
+      hipLaunchKernelGGL(lstm_cell_kernel<bf16>, dim3(n), dim3(128), 0, s, c, i, Ln, l, nh, d);
+    else
+      hipLaunchKernelGGL(lstm_cell_kernel<float>, dim3(n), dim3(128), 0, s, c, i, Ln, l, nh, d);
+  }
+  const void* top = (const unsigned char*)b->rnn_hin + (size_t)(Ln - 1) * n * d * es;
+  EM_TRY(gemm(dtype, EM_EPI_STORE_F32, top, lm->out_w, b->lm_logp, lm->out_b, n, V, d, d, V, 1.f, stream));
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
 int lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i, void* stream) {
   const EmLmWeights* lm = b->lm;
+  if (lm->kind == EM_LM_LSTM) return lstm_lm_step(dtype, p, b, i, stream);
   const int n = p->B * p->W, V = p->V, d = lm->d, ff = lm->ff, eu = lm->embed_unit;
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   const int* anc = (i & 1) ? b->anc_b : b->anc_a;

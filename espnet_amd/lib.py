@@ -119,11 +119,19 @@ class EmLmLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _LM_LAYER_PTRS]
 
 
+class EmRnnLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_ih", "w_hh", "bias")]
+
+
+EM_LM_TRANSFORMER, EM_LM_LSTM = 0, 1
+
+
 class EmLmWeights(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d", "heads", "ff", "num_blocks", "vocab", "embed_unit")] + \
                [(n, C.c_void_p) for n in ("embed", "in_w", "in_b", "in_ln_g", "in_ln_b", "pe",
                                           "after_norm_g", "after_norm_b", "out_w", "out_b")] + \
-               [("layers", C.POINTER(EmLmLayer))]
+               [("layers", C.POINTER(EmLmLayer)), ("kind", C.c_int32), ("nhid", C.c_int32),
+                ("rnn", C.POINTER(EmRnnLayer))]
 
 
 SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "anc_a", "anc_b",
@@ -133,7 +141,8 @@ SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "an
                   "end_sctc", "end_slen", "best_all", "best_by_len", "done", "step", "x", "xn", "qkv", "qs",
                   "ctx", "hbuf", "dec_logp", "self_k", "self_v", "mem_kv", "mem_vT",
                   "lm", "lm_e", "lm_xn", "lm_qkv", "lm_ctx", "lm_h", "lm_x", "lm_logp", "lm_k", "lm_v",
-                  "run_slm", "end_slm", "online_best", "online_psi", "online_snap"]
+                  "run_slm", "end_slm", "rnn_hs", "rnn_cs", "rnn_hin", "rnn_gates",
+                  "online_best", "online_psi", "online_snap"]
 
 
 class EmSearchBuffers(C.Structure):

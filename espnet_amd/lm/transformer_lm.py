@@ -79,6 +79,16 @@ class TransformerLM(torch.nn.Module):
         self.invalidate()
         return r
 
+    def search_key(self):
+        return ("transformer", self.att_unit, self.unit, self.layer, self.embed_unit)
+
+    def search_buffers(self, n, V, Lmax, B, cap):
+        """name -> shape of the EmSearchBuffers entries this scorer needs (nets/batch_beam_search.py)."""
+        dl = self.att_unit
+        return dict(lm_e=(n, self.embed_unit), lm_xn=(n, dl), lm_qkv=(n, 3 * dl), lm_ctx=(n, dl), lm_h=(n, self.unit),
+                    lm_x=(n, dl), lm_logp=(n, V), lm_k=(self.layer, Lmax, n, dl), lm_v=(self.layer, Lmax, n, dl),
+                    run_slm=(n,), end_slm=(B, cap))
+
     def pack(self, device, pe_len: int = 1024):
         dev = torch.device(device)
         act = torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32

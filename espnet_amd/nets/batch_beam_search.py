@@ -27,7 +27,8 @@ logger = logging.getLogger(__name__)
 _I32 = {"xlens", "maxlens", "minlens", "tok", "parent", "anc_a", "anc_b", "alive", "cand_tok",
         "sel_idx", "end_count", "end_pos", "end_slot", "end_forced", "done", "step"}
 _ACT = {"xn", "qkv", "qs", "ctx", "hbuf", "self_k", "self_v", "mem_kv", "mem_vT", "lm_e", "lm_xn",
-        "lm_qkv", "lm_ctx", "lm_h", "lm_k", "lm_v"}
+        "lm_qkv", "lm_ctx", "lm_h", "lm_k", "lm_v", "rnn_hs", "rnn_hin"}
+_ZERO = {"mem_vT", "rnn_hs", "rnn_cs", "rnn_hin"}  # pad columns / tails that must read as zero
 
 
 class BeamSearch:
@@ -74,7 +75,7 @@ class BatchBeamSearch(BeamSearch):
     # ------------------------------------------------------------------ buffers
     def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm=None, online=False):
         key = (str(dev), act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl,
-               None if lm is None else (lm.att_unit, lm.unit, lm.layer, lm.embed_unit), online)
+               None if lm is None else lm.search_key(), online)
         if key in self._bufs:
             return self._bufs[key]
         self._bufs.clear()  # one live shape at a time
@@ -96,10 +97,7 @@ class BatchBeamSearch(BeamSearch):
                           dec_logp=(n, V), self_k=(nl, Lmax, n, d), self_v=(nl, Lmax, n, d),
                           mem_kv=(nl, B * T, 2 * d), mem_vT=(nl, B, d, Tpad))
         if lm is not None:
-            dl = lm.att_unit
-            shapes.update(lm_e=(n, lm.embed_unit), lm_xn=(n, dl), lm_qkv=(n, 3 * dl), lm_ctx=(n, dl),
-                          lm_h=(n, lm.unit), lm_x=(n, dl), lm_logp=(n, V), lm_k=(lm.layer, Lmax, n, dl),
-                          lm_v=(lm.layer, Lmax, n, dl), run_slm=(n,), end_slm=(B, cap))
+            shapes.update(lm.search_buffers(n, V, Lmax, B, cap))
         if online:  # em_search_online_* (batch_beam_search_online.py)
             shapes.update(online_best=(n, 8), online_psi=(n,), online_snap=(n, 8))
         t = {}
@@ -107,7 +105,7 @@ class BatchBeamSearch(BeamSearch):
             if shp is None:
                 continue
             dt = torch.int32 if name in _I32 else (act if name in _ACT else torch.float32)
-            t[name] = (torch.zeros if name == "mem_vT" else torch.empty)(shp, dtype=dt, device=dev)
+            t[name] = (torch.zeros if name in _ZERO else torch.empty)(shp, dtype=dt, device=dev)
         self._bufs[key] = t
         return t
 

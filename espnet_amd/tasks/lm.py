@@ -9,9 +9,10 @@ from typing import Optional, Union
 import torch
 import yaml
 
+from espnet_amd.lm.seq_rnn_lm import SequentialRNNLM
 from espnet_amd.lm.transformer_lm import ESPnetLanguageModel, TransformerLM
 
-lm_choices = {"transformer": TransformerLM}
+lm_choices = {"seq_rnn": SequentialRNNLM, "transformer": TransformerLM}  # espnet2/tasks/lm.py:36-44
 
 
 class LMTask:

@@ -422,7 +422,22 @@ typedef struct EmLmWeights {
   const void* out_w;                /* [V][d] act: lm.decoder */
   const float* out_b;
   const EmLmLayer* layers;          /* [num_blocks], host array */
+  /* kind == EM_LM_LSTM: SequentialRNNLM with an LSTM (espnet2/lm/seq_rnn_lm.py:14-177).  d = nhid padded
+   * to the GEMM K step (ld of every hidden-state row), embed_unit = unit padded likewise (embed is
+   * [V][embed_unit] with zero pad columns), num_blocks = nlayers, out_w [V][d] act, out_b; the
+   * transformer-only fields are NULL.                                                              */
+  int32_t kind;                     /* EM_LM_TRANSFORMER (0) | EM_LM_LSTM (1) */
+  int32_t nhid;                     /* true hidden size (<= d) */
+  const struct EmRnnLayer* rnn;     /* [num_blocks], host array */
 } EmLmWeights;
+
+#define EM_LM_TRANSFORMER 0
+#define EM_LM_LSTM 1
+typedef struct EmRnnLayer {
+  const void* w_ih;  /* [4*nhid][in_pad] act, PyTorch gate order i | f | g | o; in_pad = embed_unit (layer 0) or d */
+  const void* w_hh;  /* [4*nhid][d] act */
+  const float* bias; /* [4*nhid] = bias_ih + bias_hh */
+} EmRnnLayer;
 
 typedef struct EmSearchBuffers {
   const int32_t *xlens, *maxlens, *minlens; /* [B] valid memory frames, max / min output length */
@@ -459,6 +474,12 @@ typedef struct EmSearchBuffers {
   float *lm_x, *lm_logp;                    /* f32: [n][d], [n][V] */
   void *lm_k, *lm_v;                        /* act [lm layers][Lmax][n][d] */
   float *run_slm, *end_slm;                 /* [n], [B][end_cap] accumulated LM score */
+  /* LSTM language model (kind == EM_LM_LSTM; NULL otherwise).  States of the rows of step i live in
+   * parity i & 1; a row reads its parent's state (token-tree `parent`) of the other parity.          */
+  void* rnn_hs;                             /* act [2][layers][n][d] hidden states (pad columns zero) */
+  float* rnn_cs;                            /* f32 [2][layers][n][d] cell states */
+  void* rnn_hin;                            /* act [layers][n][d] parent-gathered h, then this step's h */
+  float* rnn_gates;                         /* f32 [n][4*nhid] */
   /* streaming search (em_search_online_*; NULL offline) */
   float *online_best;                       /* [n][8] valid, parent slot, token, total, dec, ctc, len, lm */
   float *online_psi;                        /* [n] log psi of the selected candidates (next s_prev) */

@@ -32,12 +32,13 @@ def _sub(sd, prefix):
 
 def build_lm(g, dtype="float32", dev="cuda"):
     """TransformerLM of an LM golden case: recipe weights under the reference's own key names."""
-    from espnet_amd.lm.transformer_lm import TransformerLM
+    from espnet_amd.tasks.lm import lm_choices
     from oracle.weights import recipe_state_dict
 
     shapes = {"lm." + k: tuple(v) for k, v in json.loads(str(g["lm_state_shapes"])).items()}
     lsd = recipe_state_dict(shapes, int(g["wseed"]), skip=())
-    lm = TransformerLM(int(g["vocab"]), compute_dtype=dtype, **json.loads(str(g["lm_conf"])))
+    cls = lm_choices[str(g["lm_name"]) if "lm_name" in g else "transformer"]
+    lm = cls(int(g["vocab"]), compute_dtype=dtype, **json.loads(str(g["lm_conf"])))
     lm.load_state_dict(_sub(lsd, "lm."), strict=True)
     return lm.to(dev)
 
@@ -116,7 +117,8 @@ def test_search_f32_matches_reference_nbest(name):
     assert sc == sorted(sc, reverse=True)
 
 
-@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam60_lm_v300"])
+@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam60_lm_v300",
+                                  "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_search_with_lm_scorer_f32_matches_reference_nbest(name, graph):
     """SURVEY §8(f) rank 1: decoder + CTC prefix + TransformerLM scorers fused in the device search;
@@ -134,10 +136,11 @@ def test_search_with_lm_scorer_f32_matches_reference_nbest(name, graph):
             assert hyps[0].yseq.tolist() == g["yseq"][0, : g["yseq_lens"][0]].tolist()
 
 
-def test_search_with_lm_scorer_bf16_and_batched():
+@pytest.mark.parametrize("gname", ["tiny_beam4_lm_posenc", "tiny_beam5_rnnlm"])
+def test_search_with_lm_scorer_bf16_and_batched(gname):
     """bf16 LM + decoder: score level vs the fp32 reference, additivity of the per-scorer scores, and
-    utterance batching stays transparent with the LM cache in play."""
-    g = load_golden("tiny_beam4_lm_posenc")
+    utterance batching stays transparent with the LM cache / LSTM state in play."""
+    g = load_golden(gname)
     sd = golden_state_dict(g)
     enc, olens = oracle_enc(g, sd)
     bs = build_search(g, sd, "bfloat16", lm=build_lm(g, "bfloat16"))
