@@ -1,6 +1,8 @@
 // LayerNorm over the f32 residual stream, one wave per row (transformer/layer_norm.py:12-42,
 // eps 1e-12 passed by the caller).  Bandwidth-bound: each row is read once, kept in registers
 // (d/64 values per lane), reduced with wave shuffles, and written in the GEMM input dtype.
+#include <stdint.h>
+
 #include "em_common.h"
 
 namespace {
@@ -159,39 +161,63 @@ int launch_ln(float* x, const float* g1, const float* b1, const float* g2, const
 
 
 // LayerNorm of an act-dtype matrix with arbitrary row strides (the gate half of the cgMLP hidden
-// activation, cgmlp.py:63-64: channels [n, 2n) of a [M][2n] matrix).  One wave per row, values in
-// registers (n <= 64 * NVA), two-pass statistics like ln_row.
-constexpr int NVA = 48;
+// activation, cgmlp.py:63-64: channels [n, 2n) of a [M][2n] matrix).  One wave per row, 16-byte
+// loads / stores (8 bf16 or 4 f32 per lane per access), values in registers, two-pass statistics.
+constexpr int NVA = 48;  // values per lane: n <= 64 * NVA
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_act_kernel(const T* __restrict__ x, int ldx,
                                                             const float* __restrict__ g,
                                                             const float* __restrict__ b, int M, int n,
                                                             float eps, T* __restrict__ out, int ldo) {
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int NJ = NVA / EPC;             // chunks per lane
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const T* xr = x + (size_t)row * ldx;
-  float v[NVA];
+  const int nchunk = n / EPC;
+  float v[NJ][EPC];
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < NVA; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int c = lane + 64 * j;
-    v[j] = c < n ? to_f32(xr[c]) : 0.f;
-    s += v[j];
+    if (c < nchunk) {
+      const uint4 raw = *(const uint4*)(xr + (size_t)c * EPC);
+      const T* e = (const T*)&raw;
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) {
+        v[j][k] = to_f32(e[k]);
+        s += v[j][k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) v[j][k] = 0.f;
+    }
   }
   const float mean = wave_sum(s) / (float)n;
   float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < NVA; ++j) {
-    const float c = (lane + 64 * j < n) ? v[j] - mean : 0.f;
-    q += c * c;
-  }
+  for (int j = 0; j < NJ; ++j)
+    if (lane + 64 * j < nchunk) {
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) {
+        const float c = v[j][k] - mean;
+        q += c * c;
+      }
+    }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + eps);
   T* o = out + (size_t)row * ldo;
 #pragma unroll
-  for (int j = 0; j < NVA; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int c = lane + 64 * j;
-    if (c < n) o[c] = from_f32<T>((v[j] - mean) * rstd * g[c] + b[c]);
+    if (c >= nchunk) continue;
+    __attribute__((aligned(16))) T r[EPC];
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) {
+      const int ch = c * EPC + k;
+      r[k] = from_f32<T>((v[j][k] - mean) * rstd * g[ch] + b[ch]);
+    }
+    *(uint4*)(o + (size_t)c * EPC) = *(const uint4*)r;
   }
 }
 
@@ -233,6 +259,8 @@ extern "C" int em_layernorm_act(int dtype, const void* x, int32_t ldx, const flo
                                 int32_t M, int32_t n, float eps, void* out, int32_t ldo, void* stream) {
   if (!x || !g || !b || !out || M <= 0 || n <= 0 || ldx < n || ldo < n) return EM_ERR_BAD_ARG;
   if (n > 64 * NVA) return EM_ERR_UNSUPPORTED;
+  const int epc = dtype == EM_BF16 ? 8 : 4;  // 16-byte accesses: channel counts, strides and bases aligned
+  if (n % epc || ldx % epc || ldo % epc || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return EM_ERR_UNSUPPORTED;
   dim3 grid(em_cdiv(M, 4));
   if (dtype == EM_F32)
     hipLaunchKernelGGL(layernorm_act_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x,
