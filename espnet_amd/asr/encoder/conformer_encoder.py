@@ -254,10 +254,20 @@ class ConformerEncoder(torch.nn.Module):
         return p
 
     def _pos_emb(self, T: int, device) -> torch.Tensor:
-        key = (T, str(device), self.em_dtype)
-        if key not in self._pos_cache:
-            self._pos_cache[key] = rel_pos_table(T, self._output_size).to(self.act_dtype).to(device)
-        return self._pos_cache[key]
+        """(2T-1, d) rows for a length-T input: a contiguous row slice of one table built for a maximum
+        length, exactly as the reference slices its `pe` buffer (embedding.py:329-332).  Row k of the
+        slice is the sinusoid of relative position T-1-k whatever the table length, so the values are
+        bit-identical to a table built for T; the table grows by doubling (built once per size)."""
+        key = (str(device), self.em_dtype)
+        tab = self._pos_cache.get(key)
+        if tab is None or tab[0] < T:
+            tmax = max(512, tab[0] * 2 if tab else 0)
+            while tmax < T:
+                tmax *= 2
+            tab = (tmax, rel_pos_table(tmax, self._output_size).to(self.act_dtype).to(device))
+            self._pos_cache[key] = tab
+        tmax, table = tab
+        return table[tmax - T : tmax + T - 1]
 
     # ------------------------------------------------------------------ forward
     @staticmethod

@@ -52,6 +52,10 @@ class Speech2Text:
             asr_train_config, asr_model_file, device, compute_dtype=dtype)
         self.asr_model = asr_model
         self.asr_train_args = asr_train_args
+        for m in (asr_model.frontend, asr_model.encoder):  # repack the weights for the kernels now, not
+            pk = getattr(m, "_ensure_packed", None)        # inside the first decode call
+            if pk is not None:
+                pk(torch.device(device if ":" in str(device) else f"{device}:{torch.cuda.current_device()}"))
         self.device, self.dtype = device, dtype
         self.beam_size, self.ctc_weight, self.penalty = beam_size, ctc_weight, penalty
         self.maxlenratio, self.minlenratio, self.nbest = maxlenratio, minlenratio, nbest
@@ -106,6 +110,26 @@ class Speech2Text:
                                              minlenratio=self.minlenratio)
         return [self._format(h[: self.nbest]) for h in hyps]
 
+    @torch.no_grad()
+    def batch_decode_async(self, speech: torch.Tensor, speech_lengths: Sequence[int]):
+        """Like `batch_decode`, but for greedy CTC the device work is only ENQUEUED: the returned
+        handle's `.result()` waits for this batch alone (an event after its D2H copy), so the caller can
+        enqueue the next batch first and format this one while the GPU runs.  The beam search polls the
+        device between step chunks and therefore completes inside this call."""
+        if not self.ctc_greedy:
+            res = self.batch_decode(speech, speech_lengths)
+            return _Done(res)
+        speech = speech.to(self.device, torch.float32, non_blocking=True)
+        st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths], isolate=True)
+        tokens, tlens = self.decode_greedy_device(st)
+        tok_h = torch.empty(tokens.shape, dtype=tokens.dtype).pin_memory()
+        len_h = torch.empty(tlens.shape, dtype=tlens.dtype).pin_memory()
+        tok_h.copy_(tokens, non_blocking=True)
+        len_h.copy_(tlens, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _PendingGreedy(self, tok_h, len_h, ev, (tokens, tlens, st))
+
     def decode_greedy_device(self, st):
         """Device-resident G1 result: (tokens (B,T) i32 padded with -1, token_lens (B,) i32)."""
         _, tokens, tlens = self.asr_model.greedy_ctc_device(st)
@@ -113,6 +137,9 @@ class Speech2Text:
 
     def _finish_greedy(self, tokens, tlens):
         tokens, tlens = tokens.cpu(), tlens.cpu()  # the one D2H copy of the batch
+        return self._finish_greedy_host(tokens, tlens)
+
+    def _finish_greedy_host(self, tokens, tlens):
         sos, eos = self.asr_model.sos, self.asr_model.eos
         out = []
         for b in range(tokens.size(0)):
@@ -130,7 +157,7 @@ class Speech2Text:
             token = self.converter.ids2tokens(token_int)
             text = self.tokenizer.tokens2text(token) if self.tokenizer is not None else None
             results.append((text, token, token_int, hyp))
-        if results:
+        if results and logger.isEnabledFor(logging.INFO):
             logger.info("best hypo: " + "".join(results[0][1]) + "\n")
         return results
 
@@ -139,6 +166,26 @@ class Speech2Text:
         if model_tag is not None:
             raise NotImplementedError("model zoo download needs network access (espnet_model_zoo)")
         return Speech2Text(**kwargs)
+
+
+class _Done:
+    def __init__(self, res):
+        self._res = res
+
+    def result(self):
+        return self._res
+
+
+class _PendingGreedy:
+    """Greedy batch whose kernels and D2H copy are enqueued; `keep` pins the device tensors until then."""
+
+    def __init__(self, s2t, tok_h, len_h, ev, keep):
+        self.s2t, self.tok_h, self.len_h, self.ev, self.keep = s2t, tok_h, len_h, ev, keep
+
+    def result(self):
+        self.ev.synchronize()
+        self.keep = None
+        return self.s2t._finish_greedy_host(self.tok_h, self.len_h)
 
 
 # ---------------------------------------------------------------------- decode CLI (asr.sh stage 12)
@@ -198,12 +245,13 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
         hyp = Hypothesis(score=0.0, scores={}, states={}, yseq=[])
         return [(" ", ["<space>"], [2], hyp)] * nbest
 
-    def decode_batch(keys, batch):
+    def submit(keys, batch):
+        """Enqueue one batch; returns a zero-argument callable giving its per-utterance results."""
         speech, lens = batch["speech"], [int(n) for n in batch["speech_lengths"]]
         for k, n in zip(keys, lens):
             logger.info(f"speech length: {n}")  # one line per utterance, as :520
         try:
-            return speech2text.batch_decode(speech, lens)
+            return speech2text.batch_decode_async(speech, lens).result
         except TooShortUttError as e:
             # a short utterance must not take the batch down: placeholder rows for the short ones
             # (:851-858), the rest decoded as one smaller batch
@@ -216,16 +264,14 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
                 sub = speech2text.batch_decode(speech[good, : max(lens[i] for i in good)], [lens[i] for i in good])
                 for i, r in zip(good, sub):
                     out[i] = r
-            return out
+            return lambda: out
 
     pending, written, n_samples = {}, 0, 0
     t0 = time.perf_counter()
     with DatadirWriter(output_dir) as writer:
-        for keys, batch in loader:
-            assert all(isinstance(s, str) for s in keys), keys
-            assert len(keys) == batch["speech"].size(0)
-            n_samples += int(batch["speech_lengths"].sum())
-            for k, res in zip(keys, decode_batch(keys, batch)):
+        def drain(keys, get):
+            nonlocal written
+            for k, res in zip(keys, get()):
                 pending[k] = res
             order = loader.key_order
             while written < len(order) and order[written] in pending:  # emit in input order
@@ -238,6 +284,18 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
                     if text is not None:
                         w["text"][key] = text
                 written += 1
+
+        inflight = None  # one batch stays enqueued on the GPU while the previous one is formatted and written
+        for keys, batch in loader:
+            assert all(isinstance(s, str) for s in keys), keys
+            assert len(keys) == batch["speech"].size(0)
+            n_samples += int(batch["speech_lengths"].sum())
+            nxt = (keys, submit(keys, batch))
+            if inflight is not None:
+                drain(*inflight)
+            inflight = nxt
+        if inflight is not None:
+            drain(*inflight)
         assert not pending, sorted(pending)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -53,18 +53,21 @@ def read_wav(path: Union[Path, str], dtype="float64", always_2d: bool = False) -
     tag, nch, rate, bits = fmt
     bps = bits // 8
     n = len(data) // (bps * nch) * nch
+    # integers of up to 24 bits times a power of two are exact in float32: when float32 is what the
+    # caller wants (the decode CLI), skip the float64 detour — same values, half the host traffic
+    ft = np.float32 if np.dtype(dtype) == np.float32 else np.float64
     if tag == _WAVE_FORMAT_IEEE_FLOAT:
         x = np.frombuffer(data, dtype="<f4" if bits == 32 else "<f8", count=n).astype(np.float64)
     elif tag == _WAVE_FORMAT_PCM:
         if bits == 8:
-            x = (np.frombuffer(data, dtype=np.uint8, count=n).astype(np.float64) - 128.0) / 128.0
+            x = (np.frombuffer(data, dtype=np.uint8, count=n).astype(ft) - ft(128.0)) / ft(128.0)
         elif bits == 16:
-            x = np.frombuffer(data, dtype="<i2", count=n).astype(np.float64) / 32768.0
+            x = np.frombuffer(data, dtype="<i2", count=n).astype(ft) * ft(1.0 / 32768.0)
         elif bits == 24:
             b = np.frombuffer(data, dtype=np.uint8, count=n * 3).reshape(-1, 3).astype(np.int32)
             v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
             v = np.where(v & 0x800000, v - 0x1000000, v)
-            x = v.astype(np.float64) / 8388608.0
+            x = v.astype(ft) * ft(1.0 / 8388608.0)
         elif bits == 32:
             x = np.frombuffer(data, dtype="<i4", count=n).astype(np.float64) / 2147483648.0
         else:
@@ -91,7 +94,7 @@ def write_wav_pcm16(path: Union[Path, str], samples: np.ndarray, rate: int) -> N
 def load_entry(value: str, kind: str) -> np.ndarray:
     """One scp value -> array, by data type name (iterable_dataset.py DATA_TYPES)."""
     if kind == "sound":
-        return read_wav(value)[0]
+        return read_wav(value, dtype="float32")[0]  # the dataset casts float arrays to float32 anyway
     if kind == "npy":
         return np.load(value)
     raise NotImplementedError(f"data type {kind!r}: the decode CLI reads 'sound' (wav) and 'npy' entries")
