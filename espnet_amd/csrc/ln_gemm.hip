@@ -1,0 +1,204 @@
+// LayerNorm fused into the GEMM that consumes it, for the small-M launches of the decoder / LM step:
+//     C[M][N] = epilogue( LN(x[M][K]; g, b, eps) * W[N][K]^T + bias )
+// x is the f32 residual stream; K is the model dimension, so one workgroup can normalise its rows
+// completely before the contraction.  In the beam-search step (M = B*W rows, ~75 launches of ~5 us,
+// each at the launch-latency floor) every pre-norm LayerNorm (decoder_layer.py:96-98,119-121,150-152;
+// transformer_decoder.py:226-227; encoder_layer.py of the LM) was its own launch; here it rides in the
+// prologue of the projection that follows it.
+//
+// Workgroup = 32 rows x 64 columns, 4 waves.  Prologue: wave w normalises rows 8w .. 8w+7 (one row at
+// a time, K/64 values per lane, two-pass statistics like norm.hip) and writes them in the operand
+// dtype to LDS.  Main loop: wave w owns 16 columns and both 16-row tiles; A fragments come from LDS,
+// W fragments straight from global memory (each W element is used by one wave only), 4 k-steps of
+// loads in flight.  Every workgroup of a column strip re-normalises the same rows: 64 KB of L2 reads
+// and ~2 us of ALU instead of a 5 us launch.
+#include <cstdlib>
+
+#include "em_common.h"
+
+namespace {
+
+constexpr int LG_BM = 32, LG_BN = 64;
+constexpr int LG_MAXV = 16;  // K <= 64 * LG_MAXV
+
+// NV = float4 chunks per lane per row (K <= 64 * NV).  All loads of a wave's 8 rows are in flight before
+// any reduction: loading row by row serialises the global round trips.
+template <typename T, int EPI, int NV>
+__global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ g,
+                                                      const float* __restrict__ be, float eps,
+                                                      const T* __restrict__ W,
+                                                      const float* __restrict__ bias,
+                                                      void* __restrict__ Cv, int M, int N, int K,
+                                                      int ldc, int dbg) {
+  using MM = Mma<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
+  T* sA = (T*)lg_smem;
+  const int LDA = K + 16 / (int)sizeof(T);  // padded row (elements): 16-byte aligned, conflict-free
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.x * LG_BN, m0 = blockIdx.y * LG_BM;
+  const int nv = K >> 6;
+
+  // ---- the first U k-steps of this wave's W rows are requested before anything else: they do not depend
+  // on the LayerNorm, so their latency overlaps the x loads and the statistics (one global round trip
+  // for the whole kernel when K <= U * MM::K, i.e. K <= 512 in bf16)
+  constexpr int U = 16;
+  const int nsteps = K / MM::K;
+  int n = n0 + wave * 16 + lr;
+  n = n < N ? n : N - 1;
+  const T* wrow = W + (size_t)n * K + lg * MM::EPL;
+  typename MM::frag fw[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) fw[u] = MM::load(wrow + (size_t)(u < nsteps ? u : nsteps - 1) * MM::K);
+  if (dbg & 1) {  // ablation: no W traffic
+#pragma unroll
+    for (int u = 0; u < U; ++u) fw[u] = MM::load((const T*)lg_smem);
+  }
+
+  // ---- prologue: LayerNorm of rows m0 .. m0+31 into LDS.  16 lanes per row (4 rows per wave at a time,
+  // 2 passes): float4 loads (256 contiguous bytes per row and instruction), statistics reduced over 16
+  // lanes only (xor 1, 2, 4, 8: DPP row operations, no LDS crossbar), 4 operand-dtype values per LDS
+  // store.  The first version used one row per wave with 64-lane reductions and cost 6.5 us of the
+  // kernel's 11.7 (ablation EM_LNG_DBG, tools/ln_gemm_bench.py).
+  if (!(dbg & 2)) {
+    const int grp = lane >> 4, li = lane & 15;
+    float4 v[2][NV];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      int m = m0 + wave * 8 + ps * 4 + grp;
+      m = m < M ? m : M - 1;
+      const float4* xr = (const float4*)(x + (size_t)m * K);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[ps][j] = j < nv ? xr[j * 16 + li] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 g4[NV], b4[NV];  // requested with the rows: not a second round trip after the statistics
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      g4[j] = j < nv ? *(const float4*)(g + (j * 16 + li) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      b4[j] = j < nv ? *(const float4*)(be + (j * 16 + li) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) s += (v[ps][j].x + v[ps][j].y) + (v[ps][j].z + v[ps][j].w);
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      const float mean = s / (float)K;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (j < nv) {
+          const float a = v[ps][j].x - mean, b2 = v[ps][j].y - mean, c = v[ps][j].z - mean, d2 = v[ps][j].w - mean;
+          q += (a * a + b2 * b2) + (c * c + d2 * d2);
+        }
+      q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+      const float rstd = 1.0f / sqrtf(q / (float)K + eps);
+      T* dst = sA + (size_t)(wave * 8 + ps * 4 + grp) * LDA;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (j < nv) {
+          const int c0 = (j * 16 + li) * 4;
+          __attribute__((aligned(16))) T o[4];
+          o[0] = from_f32<T>((v[ps][j].x - mean) * rstd * g4[j].x + b4[j].x);
+          o[1] = from_f32<T>((v[ps][j].y - mean) * rstd * g4[j].y + b4[j].y);
+          o[2] = from_f32<T>((v[ps][j].z - mean) * rstd * g4[j].z + b4[j].z);
+          o[3] = from_f32<T>((v[ps][j].w - mean) * rstd * g4[j].w + b4[j].w);
+          if (sizeof(T) == 2) *(uint2*)(dst + c0) = *(const uint2*)o;
+          else *(uint4*)(dst + c0) = *(const uint4*)o;
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- contraction: wave w -> columns n0 + 16w .. +15, row tiles 0 and 1
+  const T* a0 = sA + (size_t)lr * LDA + lg * MM::EPL;
+  const T* a1 = a0 + (size_t)16 * LDA;
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < ((dbg & 4) ? 0 : nsteps); s0 += U) {
+    if (s0 > 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) fw[u] = MM::load(wrow + (size_t)(s0 + u < nsteps ? s0 + u : nsteps - 1) * MM::K);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s0 + u < nsteps) {
+        acc0 = MM::mma(MM::load(a0 + (size_t)(s0 + u) * MM::K), fw[u], acc0);
+        acc1 = MM::mma(MM::load(a1 + (size_t)(s0 + u) * MM::K), fw[u], acc1);
+      }
+  }
+
+  // ---- epilogue.  C/D layout: col = lr, row = lg*4 + r
+  const int ncol = n0 + wave * 16 + lr;
+  if (ncol >= N) return;
+  const float bv = bias ? bias[ncol] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x4 a = i ? acc1 : acc0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + i * 16 + lg * 4 + r;
+      if (m >= M) continue;
+      float y = a[r] + bv;
+      if (EPI == EM_EPI_RELU) y = fmaxf(y, 0.f);
+      const size_t o = (size_t)m * ldc + ncol;
+      if (EPI == EM_EPI_STORE_F32) ((float*)Cv)[o] = y;
+      else ((T*)Cv)[o] = from_f32<T>(y);
+    }
+  }
+}
+
+template <typename T, int EPI, int NV>
+int launch_ln_gemm_nv(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
+                      void* C, int M, int N, int K, int ldc, hipStream_t s) {
+  const size_t lds = (size_t)LG_BM * (K + 16 / sizeof(T)) * sizeof(T);
+  static bool attr_done = false;  // per instantiation: raise the dynamic-LDS cap once (not per launch:
+  if (!attr_done) {               // launches may be inside a hipGraph capture)
+    if (hipFuncSetAttribute((const void*)ln_gemm_kernel<T, EPI, NV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 1024) != hipSuccess)
+      return EM_ERR_LAUNCH;
+    attr_done = true;
+  }
+  static const int dbg = getenv("EM_LNG_DBG") ? atoi(getenv("EM_LNG_DBG")) : 0;  // ablation bits (tools/)
+  dim3 grid(em_cdiv(N, LG_BN), em_cdiv(M, LG_BM));
+  hipLaunchKernelGGL((ln_gemm_kernel<T, EPI, NV>), grid, dim3(256), lds, s, x, g, b, eps, (const T*)W, bias, C,
+                     M, N, K, ldc, dbg);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+template <typename T, int EPI>
+int launch_ln_gemm(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
+                   void* C, int M, int N, int K, int ldc, hipStream_t s) {
+  const int nv = K / 64;
+  if (nv <= 1) return launch_ln_gemm_nv<T, EPI, 1>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  if (nv <= 4) return launch_ln_gemm_nv<T, EPI, 4>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  if (nv <= 8) return launch_ln_gemm_nv<T, EPI, 8>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  return launch_ln_gemm_nv<T, EPI, LG_MAXV>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+}
+
+template <typename T>
+int dispatch_ln_gemm(int epi, const float* x, const float* g, const float* b, float eps, const void* W,
+                     const float* bias, void* C, int M, int N, int K, int ldc, hipStream_t s) {
+  switch (epi) {
+    case EM_EPI_STORE: return launch_ln_gemm<T, EM_EPI_STORE>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+    case EM_EPI_RELU: return launch_ln_gemm<T, EM_EPI_RELU>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+    case EM_EPI_STORE_F32: return launch_ln_gemm<T, EM_EPI_STORE_F32>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  }
+  return EM_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int em_ln_gemm(int dtype, int epilogue, const float* x, const float* ln_g, const float* ln_b,
+                          float eps, const void* W, const float* bias, void* C, int32_t M, int32_t N,
+                          int32_t K, int32_t ldc, void* stream) {
+  if (!x || !ln_g || !ln_b || !W || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return EM_ERR_BAD_ARG;
+  if (K % 64 != 0 || K > 64 * LG_MAXV) return EM_ERR_UNSUPPORTED;
+  if (dtype == EM_F32)
+    return dispatch_ln_gemm<float>(epilogue, x, ln_g, ln_b, eps, W, bias, C, M, N, K, ldc, (hipStream_t)stream);
+  if (dtype == EM_BF16)
+    return dispatch_ln_gemm<bf16>(epilogue, x, ln_g, ln_b, eps, W, bias, C, M, N, K, ldc, (hipStream_t)stream);
+  return EM_ERR_BAD_ARG;
+}

@@ -622,6 +622,20 @@ inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const
 
 constexpr float LN_EPS = 1e-12f;
 
+// C = epi(LN(x) W^T + bias) for the n rows of a search step.  Measured at K = 512 (tools/ln_gemm_bench.py):
+// the fused kernel takes 8-9 us against 9.4-9.7 us for LayerNorm + tiled GEMM (two launches at the ~4.7 us
+// floor) while its grid stays within one wave of workgroups; for wide outputs (vocabulary) or many rows
+// the pair wins (10.0 vs 11.8 us at N = 5000), so those keep it.
+inline int ln_proj(int dtype, int epi, const float* x, const float* g, const float* be, const void* W,
+                   const float* bias, void* C, void* xn_scratch, int n, int N, int K, void* stream) {
+  const long wgs = (long)em_cdiv(N, 64) * em_cdiv(n, 32);
+  // n <= 48 (one stream): LayerNorm + the skinny GEMM is 6.6 us, the fused kernel 7.5
+  if (n > 48 && wgs <= 256 && K % 64 == 0 && K <= 1024)
+    return em_ln_gemm(dtype, epi, x, g, be, LN_EPS, W, bias, C, n, N, K, N, stream);
+  EM_TRY(em_layernorm(dtype, x, g, be, n, K, LN_EPS, xn_scratch, nullptr, stream));
+  return gemm(dtype, epi, xn_scratch, W, C, bias, n, N, K, K, N, 1.f, stream);
+}
+
 // ---- SequentialRNNLM (LSTM) step pieces (espnet2/lm/seq_rnn_lm.py:140-177 batch_score) -------
 // hin[l][r] = h of row r's PARENT after the previous step (zero state at step 0, :155-156)
 template <typename T>
@@ -727,8 +741,8 @@ int lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i,
     const EmLmLayer& q = lm->layers[l];
     unsigned char* kc = (unsigned char*)b->lm_k + (size_t)l * p->Lmax * n * d * es;
     unsigned char* vc = (unsigned char*)b->lm_v + (size_t)l * p->Lmax * n * d * es;
-    EM_TRY(em_layernorm(dtype, b->lm_x, q.norm1_g, q.norm1_b, n, d, LN_EPS, b->lm_xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_STORE, b->lm_xn, q.wqkv, b->lm_qkv, q.bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
+    EM_TRY(ln_proj(dtype, EM_EPI_STORE, b->lm_x, q.norm1_g, q.norm1_b, q.wqkv, q.bqkv, b->lm_qkv, b->lm_xn, n, 3 * d,
+                   d, stream));
     if (step)
       EM_TRY(em_dec_self_attention(dtype, b->lm_qkv, kc, vc, b->anc_a, b->anc_b, n, d, lm->heads, p->Lmax,
                                    0, step, (p->W + 1) / 2, b->tok, b->lm_ctx, stream));
@@ -736,12 +750,11 @@ int lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i,
       EM_TRY(em_dec_self_attention(dtype, b->lm_qkv, kc, vc, anc, anc, n, d, lm->heads, p->Lmax, i,
                                    nullptr, (p->W + 1) / 2, b->tok, b->lm_ctx, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->lm_ctx, q.wout, b->lm_x, q.bout, n, d, d, d, d, 1.f, stream));
-    EM_TRY(em_layernorm(dtype, b->lm_x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->lm_xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RELU, b->lm_xn, q.w1, b->lm_h, q.b1, n, ff, d, d, ff, 1.f, stream));
+    EM_TRY(ln_proj(dtype, EM_EPI_RELU, b->lm_x, q.norm2_g, q.norm2_b, q.w1, q.b1, b->lm_h, b->lm_xn, n, ff, d, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->lm_h, q.w2, b->lm_x, q.b2, n, d, ff, ff, d, 1.f, stream));
   }
-  EM_TRY(em_layernorm(dtype, b->lm_x, lm->after_norm_g, lm->after_norm_b, n, d, LN_EPS, b->lm_xn, nullptr, stream));
-  EM_TRY(gemm(dtype, EM_EPI_STORE_F32, b->lm_xn, lm->out_w, b->lm_logp, lm->out_b, n, V, d, d, V, 1.f, stream));
+  EM_TRY(ln_proj(dtype, EM_EPI_STORE_F32, b->lm_x, lm->after_norm_g, lm->after_norm_b, lm->out_w, lm->out_b,
+                 b->lm_logp, b->lm_xn, n, V, d, stream));
   return EM_OK;
 }
 
@@ -824,8 +837,9 @@ int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, 
       unsigned char* vc = (unsigned char*)b->self_v + (size_t)l * p->Lmax * n * d * es;
       const unsigned char* kv = (const unsigned char*)b->mem_kv + (size_t)l * p->B * p->T * 2 * d * es;
       const unsigned char* vT = (const unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
-      EM_TRY(em_layernorm(dtype, b->x, q.norm1_g, q.norm1_b, n, d, LN_EPS, b->xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.self_wqkv, b->qkv, q.self_bqkv, n, 3 * d, d, d, 3 * d, 1.f, stream));
+      // every pre-norm LayerNorm rides in the prologue of the projection that consumes it (ln_gemm.hip)
+      EM_TRY(ln_proj(dtype, EM_EPI_STORE, b->x, q.norm1_g, q.norm1_b, q.self_wqkv, q.self_bqkv, b->qkv, b->xn, n,
+                     3 * d, d, stream));
       if (b->step)
         EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, b->anc_a, b->anc_b, n, d, h, p->Lmax, 0,
                                      b->step, (p->W + 1) / 2, nullptr, b->ctx, stream));
@@ -833,16 +847,15 @@ int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, 
         EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, anc, n, d, h, p->Lmax, i, nullptr,
                                      (p->W + 1) / 2, nullptr, b->ctx, stream));
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.self_wout, b->x, q.self_bout, n, d, d, d, d, 1.f, stream));
-      EM_TRY(em_layernorm(dtype, b->x, q.norm2_g, q.norm2_b, n, d, LN_EPS, b->xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_STORE, b->xn, q.src_wq, b->qs, q.src_bq, n, d, d, d, d, 1.f, stream));
+      EM_TRY(ln_proj(dtype, EM_EPI_STORE, b->x, q.norm2_g, q.norm2_b, q.src_wq, q.src_bq, b->qs, b->xn, n, d, d,
+                     stream));
       EM_TRY(em_dec_src_attention(dtype, b->qs, kv, 2 * d, vT, b->xlens, p->B, p->W, d, h, p->T, p->Tpad, b->ctx, stream));
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.src_wout, b->x, q.src_bout, n, d, d, d, d, 1.f, stream));
-      EM_TRY(em_layernorm(dtype, b->x, q.norm3_g, q.norm3_b, n, d, LN_EPS, b->xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_RELU, b->xn, q.w1, b->hbuf, q.b1, n, ff, d, d, ff, 1.f, stream));
+      EM_TRY(ln_proj(dtype, EM_EPI_RELU, b->x, q.norm3_g, q.norm3_b, q.w1, q.b1, b->hbuf, b->xn, n, ff, d, stream));
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->hbuf, q.w2, b->x, q.b2, n, d, ff, ff, d, 1.f, stream));
     }
-    EM_TRY(em_layernorm(dtype, b->x, dw->after_norm_g, dw->after_norm_b, n, d, LN_EPS, b->xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_STORE_F32, b->xn, dw->out_w, b->dec_logp, dw->out_b, n, V, d, d, V, 1.f, stream));
+    EM_TRY(ln_proj(dtype, EM_EPI_STORE_F32, b->x, dw->after_norm_g, dw->after_norm_b, dw->out_w, dw->out_b,
+                   b->dec_logp, b->xn, n, V, d, stream));
   }
   if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));
   if (p->w_dec != 0.f || p->w_lm != 0.f || p->w_len != 0.f) {

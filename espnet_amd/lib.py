@@ -175,6 +175,7 @@ _SIGNATURES = {
     "em_ebranchformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmEBranchformerWeights), _i32, _i32]),
     "em_ebranchformer_encode": (C.c_int, [C.c_int, C.POINTER(EmEBranchformerWeights), _vp, _vp, _vp, _vp,
                                           _i32, _i32, _vp, _vp, _sz, _vp, _vp, _i32, _vp]),
+    "em_ln_gemm": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "em_dwconv": (C.c_int, [C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp,
                             _i32, _vp]),
     "em_layernorm_act": (C.c_int, [C.c_int, _vp, _i32, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),

@@ -151,6 +151,15 @@ int em_ffn_fused_bf16(float* x, const float* ln_g, const float* ln_b, float eps,
 int em_layernorm_inplace_f32(float* x, const float* g, const float* b, int32_t M, int32_t d,
                              float eps, void* stream);
 
+/*   LayerNorm fused into the projection that consumes it, for small-M launches (the decoder / LM step
+ *   of the beam search: every pre-norm LayerNorm of decoder_layer.py:96-152 and
+ *   transformer_decoder.py:226-227 rides in the prologue of the next Linear):
+ *     C[M][N] = epilogue( LN(x[M][K]; ln_g, ln_b, eps) W[N][K]^T + bias ),  x f32, W act,
+ *   epilogue in {EM_EPI_STORE, EM_EPI_RELU, EM_EPI_STORE_F32}; K % 64 == 0, K <= 1024.               */
+int em_ln_gemm(int dtype, int epilogue, const float* x, const float* ln_g, const float* ln_b, float eps,
+               const void* W, const float* bias, void* C, int32_t M, int32_t N, int32_t K, int32_t ldc,
+               void* stream);
+
 /* ---- A7: RelPositionMultiHeadedAttention core (transformer/attention.py:416-459 after the
  *      projections): AC = (q+u)k^T, BD[i][j] = (q+v).p[T-1-i+j] (rel_shift :391-408 as index
  *      arithmetic), softmax((AC+BD)/sqrt(dk)) over keys j < klens[b] (masked probs = 0), times V.

@@ -379,3 +379,25 @@ def test_layernorm_inplace(lib):
     xd = dev(x.clone())
     L.check(lib.em_layernorm_inplace_f32(L.ptr(xd), L.ptr(dev(g)), L.ptr(dev(b)), M, d, 1e-12, sptr()))
     assert_close(xd, F.layer_norm(x, (d,), g, b, 1e-12), 2e-6, "ln inplace")
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(37, 200, 64), (160, 1536, 512), (5, 5000, 256), (640, 96, 1024)])
+def test_ln_gemm_small_m(lib, prec, M, N, K):
+    """LayerNorm fused into the consuming projection (decoder / LM step): against torch fp32 on the
+    operand-dtype-rounded LayerNorm output, for the three epilogues the search uses."""
+    dt, tdt = DT[prec]
+    x = rnd(M, K, seed=31) * 2 + 0.3
+    g, be = 1 + 0.1 * rnd(K, seed=32), 0.1 * rnd(K, seed=33)
+    w = q(rnd(N, K, seed=34, scale=K ** -0.5), tdt)
+    bias = 0.1 * rnd(N, seed=35)
+    xn = q(F.layer_norm(x, (K,), g, be, 1e-12), tdt)
+    ref = F.linear(xn, w, bias)
+    tol = 3e-5 if prec == "f32" else 3e-2
+    xd, gd, bd, wd, biasd = dev(x), dev(g), dev(be), dev(w.to(tdt)), dev(bias)
+    for epi, r, odt in ((L.EM_EPI_STORE, ref, tdt), (L.EM_EPI_RELU, torch.relu(ref), tdt),
+                        (L.EM_EPI_STORE_F32, ref, torch.float32)):
+        out = torch.zeros(M, N, dtype=odt, device="cuda")
+        L.check(lib.em_ln_gemm(dt, epi, L.ptr(xd), L.ptr(gd), L.ptr(bd), 1e-12, L.ptr(wd), L.ptr(biasd), L.ptr(out),
+                               M, N, K, N, sptr()), "em_ln_gemm")
+        assert_close(out, r, tol, f"ln_gemm {prec} epi {epi}")
