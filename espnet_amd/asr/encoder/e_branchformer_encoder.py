@@ -46,21 +46,25 @@ class _CGMLP(torch.nn.Module):
 
 
 class _EBranchformerEncoderLayer(torch.nn.Module):
-    """Parameters of EBranchformerEncoderLayer (e_branchformer_encoder.py:68-108)."""
+    """Parameters of EBranchformerEncoderLayer (e_branchformer_encoder.py:68-108); with ff = None and
+    merge_kernel = None those of BranchformerEncoderLayer, merge_method="concat"
+    (branchformer_encoder.py:65-136)."""
 
     def __init__(self, size, heads, ff, cg, cg_kernel, merge_kernel):
         super().__init__()
         self.attn = _RelPositionMultiHeadedAttention(heads, size)
         self.cgmlp = _CGMLP(size, cg, cg_kernel)
-        self.feed_forward = _PositionwiseFeedForward(size, ff)
-        self.feed_forward_macaron = _PositionwiseFeedForward(size, ff)
-        self.norm_ff = LayerNorm(size)
-        self.norm_ff_macaron = LayerNorm(size)
+        if ff is not None:
+            self.feed_forward = _PositionwiseFeedForward(size, ff)
+            self.feed_forward_macaron = _PositionwiseFeedForward(size, ff)
+            self.norm_ff = LayerNorm(size)
+            self.norm_ff_macaron = LayerNorm(size)
         self.norm_mha = LayerNorm(size)
         self.norm_mlp = LayerNorm(size)
         self.norm_final = LayerNorm(size)
-        self.depthwise_conv_fusion = torch.nn.Conv1d(2 * size, 2 * size, merge_kernel, 1, (merge_kernel - 1) // 2,
-                                                     groups=2 * size, bias=True)
+        if merge_kernel is not None:
+            self.depthwise_conv_fusion = torch.nn.Conv1d(2 * size, 2 * size, merge_kernel, 1,
+                                                         (merge_kernel - 1) // 2, groups=2 * size, bias=True)
         self.merge_proj = torch.nn.Linear(2 * size, size)
 
 
@@ -134,8 +138,11 @@ class EBranchformerEncoder(ConformerEncoder):
         e = self.embed
         F2 = e.out.in_features // d
         w = L.EmEBranchformerWeights()
-        w.d, w.heads, w.ff, w.cg, w.num_blocks = d, self.heads, ff, cg, Lb
-        w.cg_kernel, w.merge_kernel, w.n_mels = self.cgmlp_conv_kernel, self.merge_conv_kernel, self._input_size
+        w.d, w.heads, w.cg, w.num_blocks = d, self.heads, cg, Lb
+        w.cg_kernel, w.merge_kernel, w.n_mels = self.cgmlp_conv_kernel, self.merge_conv_kernel or 0, self._input_size
+        has_ffn, has_mconv = ff is not None, self.merge_conv_kernel is not None
+        w.ff = ff or 0
+        w.use_ffn, w.merge_conv = int(has_ffn), int(has_mconv)
         t = dict(conv1_w=F(e.conv[0].weight.reshape(d, 9)), conv1_b=F(e.conv[0].bias),
                  conv2_w=A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, 9 * d)), conv2_b=F(e.conv[2].bias),
                  embed_w=A(e.out.weight.reshape(d, d, F2).permute(0, 2, 1).reshape(d, F2 * d)),
@@ -148,15 +155,9 @@ class EBranchformerEncoder(ConformerEncoder):
         for i, l in enumerate(self.encoders):
             sa, cm = l.attn, l.cgmlp
             lt = dict(
-                norm_ff_mac_g=F(l.norm_ff_macaron.weight), norm_ff_mac_b=F(l.norm_ff_macaron.bias),
                 norm_mha_g=F(l.norm_mha.weight), norm_mha_b=F(l.norm_mha.bias),
                 norm_mlp_g=F(l.norm_mlp.weight), norm_mlp_b=F(l.norm_mlp.bias),
-                norm_ff_g=F(l.norm_ff.weight), norm_ff_b=F(l.norm_ff.bias),
                 norm_final_g=F(l.norm_final.weight), norm_final_b=F(l.norm_final.bias),
-                ffm_w1=A(l.feed_forward_macaron.w_1.weight), ffm_b1=F(l.feed_forward_macaron.w_1.bias),
-                ffm_w2=A(l.feed_forward_macaron.w_2.weight), ffm_b2=F(l.feed_forward_macaron.w_2.bias),
-                ff_w1=A(l.feed_forward.w_1.weight), ff_b1=F(l.feed_forward.w_1.bias),
-                ff_w2=A(l.feed_forward.w_2.weight), ff_b2=F(l.feed_forward.w_2.bias),
                 wqkv=A(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0)),
                 bqkv=F(torch.cat([sa.linear_q.bias, sa.linear_k.bias, sa.linear_v.bias], 0)),
                 pos_u=F(sa.pos_bias_u), pos_v=F(sa.pos_bias_v),
@@ -166,12 +167,68 @@ class EBranchformerEncoder(ConformerEncoder):
                 csgu_conv_w=F(cm.csgu.conv.weight.reshape(cg // 2, -1).t()),  # [k][cg/2] tap-major
                 csgu_conv_b=F(cm.csgu.conv.bias),
                 proj2_w=A(cm.channel_proj2.weight), proj2_b=F(cm.channel_proj2.bias),
-                merge_conv_w=F(l.depthwise_conv_fusion.weight.reshape(2 * d, -1).t()),
-                merge_conv_b=F(l.depthwise_conv_fusion.bias),
                 merge_w=A(l.merge_proj.weight), merge_b=F(l.merge_proj.bias))
+            if has_ffn:
+                lt.update(
+                    norm_ff_mac_g=F(l.norm_ff_macaron.weight), norm_ff_mac_b=F(l.norm_ff_macaron.bias),
+                    norm_ff_g=F(l.norm_ff.weight), norm_ff_b=F(l.norm_ff.bias),
+                    ffm_w1=A(l.feed_forward_macaron.w_1.weight), ffm_b1=F(l.feed_forward_macaron.w_1.bias),
+                    ffm_w2=A(l.feed_forward_macaron.w_2.weight), ffm_b2=F(l.feed_forward_macaron.w_2.bias),
+                    ff_w1=A(l.feed_forward.w_1.weight), ff_b1=F(l.feed_forward.w_1.bias),
+                    ff_w2=A(l.feed_forward.w_2.weight), ff_b2=F(l.feed_forward.w_2.bias))
+            if has_mconv:
+                lt.update(merge_conv_w=F(l.depthwise_conv_fusion.weight.reshape(2 * d, -1).t()),
+                          merge_conv_b=F(l.depthwise_conv_fusion.bias))
             for k, v in lt.items():
                 setattr(layers[i], k, v.data_ptr())
         w.layers = C.cast(layers, C.POINTER(L.EmEBranchformerLayer))
         self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype)
         self._pos_cache = {}
         return self._packed
+
+
+class BranchformerEncoder(EBranchformerEncoder):
+    """BranchformerEncoder (espnet2/asr/encoder/branchformer_encoder.py:293-620) for merge_method="concat" with
+    both branches: the E-Branchformer layer without feed-forward modules and without the depthwise conv in
+    front of `merge_proj` (state-dict keys `encoders.N.{attn, cgmlp, norm_mha, norm_mlp, norm_final,
+    merge_proj}`); same kernels, `EmEBranchformerWeights.use_ffn = merge_conv = 0`."""
+
+    def __init__(self, input_size: int, output_size: int = 256, use_attn: bool = True, attention_heads: int = 4,
+                 attention_layer_type: str = "rel_selfattn", pos_enc_layer_type: str = "rel_pos",
+                 rel_pos_type: str = "latest", use_cgmlp: bool = True, cgmlp_linear_units: int = 2048,
+                 cgmlp_conv_kernel: int = 31, use_linear_after_conv: bool = False,
+                 gate_activation: str = "identity", merge_method: str = "concat", cgmlp_weight=0.5,
+                 attn_branch_drop_rate=0.0, num_blocks: int = 12, dropout_rate: float = 0.1,
+                 positional_dropout_rate: float = 0.1, attention_dropout_rate: float = 0.0,
+                 input_layer: Optional[str] = "conv2d", zero_triu: bool = False, padding_idx: int = -1,
+                 stochastic_depth_rate=0.0, qk_norm: bool = False, use_flash_attn: bool = True,
+                 compute_dtype: str = "bfloat16"):
+        torch.nn.Module.__init__(self)
+        bad = []
+        if not (use_attn and use_cgmlp): bad.append("use_attn and use_cgmlp must both be True")
+        if merge_method != "concat": bad.append(f"merge_method={merge_method}")
+        if input_layer != "conv2d": bad.append(f"input_layer={input_layer}")
+        if attention_layer_type != "rel_selfattn": bad.append(f"attention_layer_type={attention_layer_type}")
+        if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
+        if rel_pos_type != "latest": bad.append(f"rel_pos_type={rel_pos_type}")
+        if use_linear_after_conv: bad.append("use_linear_after_conv=True")
+        if gate_activation != "identity": bad.append(f"gate_activation={gate_activation}")
+        if zero_triu: bad.append("zero_triu=True")
+        if qk_norm: bad.append("qk_norm=True")
+        if output_size % 64 or output_size // attention_heads != 64: bad.append("d_k != 64")
+        if cgmlp_linear_units % 128: bad.append("cgmlp_linear_units % 128 != 0")
+        if cgmlp_conv_kernel not in (3, 7, 15, 31): bad.append(f"cgmlp_conv_kernel={cgmlp_conv_kernel}")
+        if bad:
+            raise NotImplementedError("outside the MI355X Branchformer fast path: " + ", ".join(bad))
+        self._output_size, self._input_size = output_size, input_size
+        self.heads, self.linear_units, self.num_blocks = attention_heads, None, num_blocks
+        self.cgmlp_linear_units, self.cgmlp_conv_kernel = cgmlp_linear_units, cgmlp_conv_kernel
+        self.merge_conv_kernel = None
+        self.interctc_layer_idx, self.interctc_use_conditioning = [], False
+        self.compute_dtype = compute_dtype
+        self.embed = _Conv2dSubsampling(input_size, output_size)
+        self.encoders = torch.nn.ModuleList(
+            [_EBranchformerEncoderLayer(output_size, attention_heads, None, cgmlp_linear_units, cgmlp_conv_kernel,
+                                        None) for _ in range(num_blocks)])
+        self.after_norm = LayerNorm(output_size)
+        self._packed, self._pos_cache, self._ws, self._olens_cache = None, {}, None, {}

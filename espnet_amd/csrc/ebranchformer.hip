@@ -95,7 +95,7 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   if (T_f < 7) return EM_ERR_TOO_SHORT;
   const int d = w->d, h = w->heads, ff = w->ff, cg = w->cg, L = w->num_blocks, ch = cg / 2;
   const int kalign = dtype == EM_BF16 ? 64 : 32;
-  if (d % 64 != 0 || h <= 0 || d / h != 64 || ff % 64 != 0 || cg % 128 != 0 || ch % kalign != 0)
+  if (d % 64 != 0 || h <= 0 || d / h != 64 || (w->use_ffn && ff % 64 != 0) || cg % 128 != 0 || ch % kalign != 0)
     return EM_ERR_UNSUPPORTED;
   const Ws s = layout(dtype, w, B, T_f);
   if (workspace_bytes < s.total) return EM_ERR_WORKSPACE;
@@ -131,12 +131,16 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d, g.F2 * d, d,
               sqrtf((float)d), stream));
   const EmEBranchformerLayer* ly = w->layers;
-  EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr, stream));
+  const bool ffn = w->use_ffn != 0;
+  if (ffn)
+    EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr, stream));
   for (int l = 0; l < L; ++l) {
     const EmEBranchformerLayer& q = ly[l];
-    // macaron FFN (:132-135): x += 0.5 * w2(swish(w1 LN(x)))
-    EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
+    if (ffn) {
+      // macaron FFN (:132-135): x += 0.5 * w2(swish(w1 LN(x)))
+      EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
+    }
     // the two branches read the same x (:138-139)
     EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(em_layernorm(dtype, x, q.norm_mlp_g, q.norm_mlp_b, M, d, LN_EPS, xn2, nullptr, stream));
@@ -154,21 +158,30 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
                      w->cg_kernel, big, cg, gated, ch, stream));
     EM_TRY(gemm(dtype, EM_EPI_STORE, gated, q.proj2_w, cat + (size_t)d * es, q.proj2_b, M, d, ch, ch, 2 * d,
                 1.f, stream));
-    // merge (:165-170): x += merge_proj(cat + dwconv(cat))
-    EM_TRY(em_dwconv(dtype, EM_DW_SELFRES, cat, 2 * d, q.merge_conv_w, q.merge_conv_b, conv_lens, B, T, 2 * d,
-                     w->merge_kernel, nullptr, 0, tmp, 2 * d, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, tmp, q.merge_w, x, q.merge_b, M, d, 2 * d, 2 * d, d, 1.f, stream));
-    // FFN (:172-176)
-    EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ff_w2, x, q.ff_b2, M, d, ff, ff, d, 0.5f, stream));
-    // norm_final (:178), fused with the next consumer's LayerNorm
-    if (l + 1 < L)
+    // merge: E-Branchformer (:165-170) x += merge_proj(cat + dwconv(cat)); Branchformer (concat,
+    // branchformer_encoder.py:207-211) x += merge_proj(cat)
+    const void* merged = cat;
+    if (w->merge_conv) {
+      EM_TRY(em_dwconv(dtype, EM_DW_SELFRES, cat, 2 * d, q.merge_conv_w, q.merge_conv_b, conv_lens, B, T, 2 * d,
+                       w->merge_kernel, nullptr, 0, tmp, 2 * d, stream));
+      merged = tmp;
+    }
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, merged, q.merge_w, x, q.merge_b, M, d, 2 * d, 2 * d, d, 1.f, stream));
+    if (ffn) {
+      // FFN (:172-176)
+      EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ff_w2, x, q.ff_b2, M, d, ff, ff, d, 0.5f, stream));
+    }
+    // norm_final (:178), fused with the next consumer's LayerNorm where there is exactly one
+    if (l + 1 == L)
+      EM_TRY(em_layernorm2(dtype, x, q.norm_final_g, q.norm_final_b, w->after_norm_g, w->after_norm_b, M, d,
+                           LN_EPS, enc_act, enc_out, stream));
+    else if (ffn)
       EM_TRY(em_layernorm2(dtype, x, q.norm_final_g, q.norm_final_b, ly[l + 1].norm_ff_mac_g,
                            ly[l + 1].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr, stream));
     else
-      EM_TRY(em_layernorm2(dtype, x, q.norm_final_g, q.norm_final_b, w->after_norm_g, w->after_norm_b, M, d,
-                           LN_EPS, enc_act, enc_out, stream));
+      EM_TRY(em_layernorm_inplace_f32(x, q.norm_final_g, q.norm_final_b, M, d, LN_EPS, stream));
   }
   return EM_OK;
 }

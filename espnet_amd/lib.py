@@ -85,7 +85,7 @@ class EmEBranchformerWeights(C.Structure):
                                          "n_mels")] + \
                [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "embed_w", "embed_b",
                                           "wpos_all", "after_norm_g", "after_norm_b")] + \
-               [("layers", C.POINTER(EmEBranchformerLayer))]
+               [("layers", C.POINTER(EmEBranchformerLayer)), ("use_ffn", C.c_int32), ("merge_conv", C.c_int32)]
 
 
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",

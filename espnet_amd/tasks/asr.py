@@ -19,7 +19,7 @@ from espnet_amd.asr.ctc import CTC
 from espnet_amd.asr.decoder.transformer_decoder import TransformerDecoder
 from espnet_amd.asr.encoder.conformer_encoder import ConformerEncoder
 from espnet_amd.asr.encoder.contextual_block_conformer_encoder import ContextualBlockConformerEncoder
-from espnet_amd.asr.encoder.e_branchformer_encoder import EBranchformerEncoder
+from espnet_amd.asr.encoder.e_branchformer_encoder import BranchformerEncoder, EBranchformerEncoder
 from espnet_amd.asr.espnet_model import ESPnetASRModel
 from espnet_amd.asr.frontend.default import DefaultFrontend
 from espnet_amd.layers.global_mvn import GlobalMVN
@@ -29,7 +29,7 @@ frontend_choices = {"default": DefaultFrontend}
 normalize_choices = {"utterance_mvn": UtteranceMVN, "global_mvn": GlobalMVN}
 encoder_choices = {"conformer": ConformerEncoder,
                    "contextual_block_conformer": ContextualBlockConformerEncoder,
-                   "e_branchformer": EBranchformerEncoder}
+                   "e_branchformer": EBranchformerEncoder, "branchformer": BranchformerEncoder}
 decoder_choices = {"transformer": TransformerDecoder}
 model_choices = {"espnet": ESPnetASRModel}
 

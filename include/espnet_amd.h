@@ -301,6 +301,10 @@ typedef struct EmEBranchformerWeights {
   const void* wpos_all; /* [num_blocks*d][d] act */
   const float *after_norm_g, *after_norm_b;
   const EmEBranchformerLayer* layers;
+  /* Branchformer (espnet2/asr/encoder/branchformer_encoder.py:49-290, merge_method="concat") is the same
+   * layer without the feed-forward modules and without the depthwise conv in front of merge_proj:   */
+  int32_t use_ffn;    /* 1: macaron + final FFN (E-Branchformer); 0: none (ffm_ / ff_ / norm_ff fields unused) */
+  int32_t merge_conv; /* 1: x += merge_proj(cat + dwconv(cat)); 0: x += merge_proj(cat) */
 } EmEBranchformerWeights;
 
 size_t em_ebranchformer_workspace_bytes(int dtype, const EmEBranchformerWeights* w, int32_t B, int32_t T_f);

@@ -510,6 +510,19 @@ EBF_TINY["encoder_conf"].update(output_size=64, attention_heads=1, cgmlp_linear_
                                 num_blocks=2, cgmlp_conv_kernel=15, merge_conv_kernel=7)
 EBF_TINY["decoder_conf"].update(attention_heads=1, linear_units=128, num_blocks=1)
 
+BF_SMALL = json.loads(json.dumps(EBF_SMALL))
+BF_SMALL["encoder"] = "branchformer"
+BF_SMALL["encoder_conf"] = dict(output_size=256, use_attn=True, attention_heads=4, attention_layer_type="rel_selfattn",
+                                pos_enc_layer_type="rel_pos", rel_pos_type="latest", use_cgmlp=True,
+                                cgmlp_linear_units=1024, cgmlp_conv_kernel=31, use_linear_after_conv=False,
+                                gate_activation="identity", merge_method="concat", num_blocks=6, dropout_rate=0.1,
+                                positional_dropout_rate=0.1, attention_dropout_rate=0.1, input_layer="conv2d",
+                                stochastic_depth_rate=0.0)
+BF_TINY = json.loads(json.dumps(BF_SMALL))
+BF_TINY["encoder_conf"].update(output_size=64, attention_heads=1, cgmlp_linear_units=128, num_blocks=2,
+                               cgmlp_conv_kernel=7)
+BF_TINY["decoder_conf"].update(attention_heads=1, linear_units=128, num_blocks=1)
+
 CASES = {
     # config 0/1 of BASELINE.json: Conformer-small, one 10 s utterance
     "small_10s": lambda: run_encode_case("small_10s", SMALL, 5000, 11, [0], [160000], keep_every=4),
@@ -593,6 +606,10 @@ CASES = {
     "tiny_beam4_rnnlm_nhid": lambda: run_lm_search_case(
         "tiny_beam4_rnnlm_nhid", tiny(d=64, heads=2, ff=128), 50, 7, 19, 24000, 4, 0.5, 1.0, 4,
         dict(unit=64, nhid=128, nlayers=1), lm_name="seq_rnn"),
+    # Branchformer (merge_method concat): the E-Branchformer layer without FFNs and merge conv
+    "bf_tiny_blocks": lambda: run_encode_case("bf_tiny_blocks", BF_TINY, 50, 33, [55, 56], [30000, 17000],
+                                              with_blocks=True),
+    "bf_small_4s": lambda: run_encode_case("bf_small_4s", BF_SMALL, 5000, 34, [57, 58], [64000, 40000], keep_every=4),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

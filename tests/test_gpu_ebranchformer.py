@@ -22,8 +22,9 @@ def build(g, dtype):
     return model.cuda().eval()
 
 
-def test_state_dict_keys_equal_reference():
-    g = load_golden("ebf_tiny_blocks")
+@pytest.mark.parametrize("gname", ["ebf_tiny_blocks", "bf_tiny_blocks"])
+def test_state_dict_keys_equal_reference(gname):
+    g = load_golden(gname)
     model = build(g, "float32")
     import json
 
@@ -33,7 +34,7 @@ def test_state_dict_keys_equal_reference():
            {k: v for k, v in ref.items() if k.startswith("encoder.")}
 
 
-@pytest.mark.parametrize("name", ["ebf_small_5s"])
+@pytest.mark.parametrize("name", ["ebf_small_5s", "bf_small_4s"])
 def test_encode_float32_matches_reference(name):
     g = load_golden(name)
     model = build(g, "float32")
@@ -56,8 +57,9 @@ def test_encode_float32_matches_reference(name):
             assert tokens[b, : int(tlens[b])].tolist() == g["g1_tokens"][b, : g["g1_lens"][b]].tolist()
 
 
-def test_encode_bfloat16_within_tolerance_and_isolated_rows():
-    g = load_golden("ebf_small_5s")
+@pytest.mark.parametrize("gname", ["ebf_small_5s", "bf_small_4s"])
+def test_encode_bfloat16_within_tolerance_and_isolated_rows(gname):
+    g = load_golden(gname)
     sd = golden_state_dict(g)
     hp = hparams(g)
     speech, lens = golden_speech(g)

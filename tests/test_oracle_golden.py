@@ -256,7 +256,7 @@ def test_online_beam_search_matches_reference_per_call(name):
     assert seen_events, "golden exercises no break / end event"
 
 
-@pytest.mark.parametrize("name", ["ebf_tiny_blocks", "ebf_small_5s"])
+@pytest.mark.parametrize("name", ["ebf_tiny_blocks", "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s"])
 def test_ebranchformer_encoder_matches_reference(name):
     """E-Branchformer (attention + cgMLP branches, depthwise-conv merge) — oracle vs
     the reference's `ESPnetASRModel.encode` with encoder=e_branchformer, incl. per-block outputs."""
