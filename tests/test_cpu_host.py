@@ -33,7 +33,8 @@ def test_no_cpu_fallback():
         model.encode(torch.zeros(1, 16000), torch.tensor([16000]))
 
 
-@pytest.mark.parametrize("name", ["tiny_blocks", "small_10s", "large_10s", "tiny_beam5"])
+@pytest.mark.parametrize("name", ["tiny_blocks", "small_10s", "large_10s", "tiny_beam5", "ebf_tiny_blocks",
+                                  "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s", "stream_search_a"])
 def test_state_dict_table_equals_reference(name):
     from espnet_amd.tasks.asr import ASRTask
 
@@ -48,6 +49,25 @@ def test_state_dict_table_equals_reference(name):
     assert mine == g["shapes"]
     model.load_state_dict(golden_state_dict(g), strict=True)
     assert model.sos == model.eos == int(g["vocab"]) - 1 and model.blank_id == 0
+
+
+@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid"])
+def test_lm_state_dict_table_equals_reference(name):
+    """LM scorers expose the reference's own state-dict keys/shapes (espnet2/lm/{transformer_lm,seq_rnn_lm}.py),
+    through LMTask's registry names (espnet2/tasks/lm.py:36-44)."""
+    import json
+
+    from espnet_amd.lm.transformer_lm import ESPnetLanguageModel
+    from espnet_amd.tasks.lm import LMTask
+    from oracle.weights import token_list
+
+    g = load_golden(name)
+    V = int(g["vocab"])
+    lm_name = str(g["lm_name"]) if "lm_name" in g else "transformer"
+    model = LMTask.build_model(dict(lm=lm_name, lm_conf=json.loads(str(g["lm_conf"])), token_list=token_list(V)))
+    assert isinstance(model, ESPnetLanguageModel)
+    ref = {"lm." + k: tuple(v) for k, v in json.loads(str(g["lm_state_shapes"])).items()}
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == ref
 
 
 def test_unsupported_choices_raise():
