@@ -20,7 +20,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from espnet_amd import lib as L
-from espnet_amd.nets_utils import conv2d_subsampled_lengths
+from espnet_amd.nets_utils import (SUBSAMPLING_CONVS, SUBSAMPLING_MIN_FRAMES, conv2d_subsampled_lengths,
+                                   conv_out_size)
 
 LN_EPS = 1e-12  # transformer/layer_norm.py:23
 
@@ -31,14 +32,17 @@ class LayerNorm(torch.nn.LayerNorm):
 
 
 class _Conv2dSubsampling(torch.nn.Module):
-    """Parameters of transformer/subsampling.py:386-409."""
+    """Parameters of Conv2dSubsampling / Conv2dSubsampling6 / Conv2dSubsampling8
+    (transformer/subsampling.py:386-409, 692-715, 785-808): `conv.{0,2[,4]}`, `out`."""
 
-    def __init__(self, idim, odim):
+    def __init__(self, idim, odim, input_layer: str = "conv2d"):
         super().__init__()
-        self.conv = torch.nn.Sequential(
-            torch.nn.Conv2d(1, odim, 3, 2), torch.nn.ReLU(),
-            torch.nn.Conv2d(odim, odim, 3, 2), torch.nn.ReLU())
-        self.out = torch.nn.Linear(odim * (((idim - 1) // 2 - 1) // 2), odim)
+        mods, cin = [], 1
+        for k, s in SUBSAMPLING_CONVS[input_layer]:
+            mods += [torch.nn.Conv2d(cin, odim, k, s), torch.nn.ReLU()]
+            cin = odim
+        self.conv = torch.nn.Sequential(*mods)
+        self.out = torch.nn.Linear(odim * conv_out_size(idim, input_layer), odim)
 
 
 class _RelPositionMultiHeadedAttention(torch.nn.Module):
@@ -128,7 +132,7 @@ class ConformerEncoder(torch.nn.Module):
                  compute_dtype: str = "bfloat16"):
         super().__init__()
         bad = []
-        if input_layer != "conv2d": bad.append(f"input_layer={input_layer}")
+        if input_layer not in SUBSAMPLING_CONVS: bad.append(f"input_layer={input_layer}")
         if not normalize_before: bad.append("normalize_before=False")
         if concat_after: bad.append("concat_after=True")
         if positionwise_layer_type != "linear": bad.append(f"positionwise_layer_type={positionwise_layer_type}")
@@ -154,7 +158,8 @@ class ConformerEncoder(torch.nn.Module):
         self.interctc_layer_idx = list(interctc_layer_idx)
         self.interctc_use_conditioning = interctc_use_conditioning
         self.compute_dtype = compute_dtype
-        self.embed = _Conv2dSubsampling(input_size, output_size)
+        self.input_layer = input_layer
+        self.embed = _Conv2dSubsampling(input_size, output_size, input_layer)
         self.encoders = torch.nn.ModuleList(
             [_EncoderLayer(output_size, attention_heads, linear_units, cnn_module_kernel)
              for _ in range(num_blocks)])
@@ -205,8 +210,7 @@ class ConformerEncoder(torch.nn.Module):
         t = {}
         t["conv1_w"] = F(e.conv[0].weight.reshape(d, 9))
         t["conv1_b"] = F(e.conv[0].bias)
-        t["conv2_w"] = A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, 9 * d))
-        t["conv2_b"] = F(e.conv[2].bias)
+        self._pack_subsampling(w, t, A, F)
         t["embed_w"] = A(e.out.weight.reshape(d, d, F2).permute(0, 2, 1).reshape(d, F2 * d))
         t["embed_b"] = F(e.out.bias)
         t["wpos_all"] = A(torch.cat([l.self_attn.linear_pos.weight for l in self.encoders], dim=0))
@@ -247,6 +251,18 @@ class ConformerEncoder(torch.nn.Module):
         self._pos_cache = {}
         return self._packed
 
+    def _pack_subsampling(self, w, t, A, F):
+        """conv.2 (and conv.4): [d][k*k*d] with column (kt*k + kf)*d + c_in, the implicit GEMM's K order."""
+        e, d = self.embed, self._output_size
+        layer = getattr(self, "input_layer", "conv2d")
+        w.subsample = {"conv2d": 4, "conv2d6": 6, "conv2d8": 8}[layer]
+        k2 = e.conv[2].weight.size(-1)
+        t["conv2_w"] = A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, k2 * k2 * d))
+        t["conv2_b"] = F(e.conv[2].bias)
+        if layer == "conv2d8":
+            t["conv3_w"] = A(e.conv[4].weight.permute(0, 2, 3, 1).reshape(d, 9 * d))
+            t["conv3_b"] = F(e.conv[4].bias)
+
     def _ensure_packed(self, device):
         p = self._packed
         if p is None or p["device"] != device or p["dtype"] != self.em_dtype:
@@ -270,9 +286,8 @@ class ConformerEncoder(torch.nn.Module):
         return table[tmax - T : tmax + T - 1]
 
     # ------------------------------------------------------------------ forward
-    @staticmethod
-    def output_frames(T_f: int) -> int:
-        return ((T_f - 1) // 2 - 1) // 2
+    def output_frames(self, T_f: int) -> int:
+        return conv_out_size(T_f, getattr(self, "input_layer", "conv2d"))
 
     def forward_device(self, feats: torch.Tensor, flens: List[int], flens_dev: torch.Tensor,
                        mvn_partial: Optional[torch.Tensor] = None, isolate: bool = False):
@@ -282,20 +297,22 @@ class ConformerEncoder(torch.nn.Module):
         B, T_f, D = feats.shape
         # check_short_utt (subsampling.py:31-49) via conformer_encoder.py:360-369; the reference sees one
         # utterance per call, so in a padded batch every row is held to the same limit
-        short = [b for b, n in enumerate(flens) if n < 7] if T_f >= 7 else list(range(B))
+        layer = getattr(self, "input_layer", "conv2d")
+        lim = SUBSAMPLING_MIN_FRAMES[layer]
+        short = [b for b, n in enumerate(flens) if n < lim] if T_f >= lim else list(range(B))
         if short:
             n0 = min(T_f, int(flens[short[0]]))
             raise L.TooShortUttError(
                 f"has {n0} frames and is too short for subsampling "
-                f"(it needs more than 7 frames), return empty results", n0, 7, indices=short)
+                f"(it needs more than {lim} frames), return empty results", n0, lim, indices=short)
         dev = feats.device
         pk = self._ensure_packed(dev)
         lib = L.load()
         T = self.output_frames(T_f)
         if isolate:  # every utterance as if it were the whole batch: tmax = its own length
-            olens = [conv2d_subsampled_lengths([n], int(n))[0] for n in flens]
+            olens = [conv2d_subsampled_lengths([n], int(n), layer)[0] for n in flens]
         else:  # the padded mask is sliced, so padded rows keep up to two frames more (subsampling.py:448)
-            olens = conv2d_subsampled_lengths(flens, T_f)
+            olens = conv2d_subsampled_lengths(flens, T_f, layer)
         okey = (tuple(olens), dev)
         olens_dev = self._olens_cache.get(okey)
         if olens_dev is None:  # kept on the device for repeating batch shapes (see encode_device)

@@ -85,7 +85,7 @@ class EBranchformerEncoder(ConformerEncoder):
                  gradient_checkpoint_layers: List[int] = [], compute_dtype: str = "bfloat16"):
         torch.nn.Module.__init__(self)
         bad = []
-        if input_layer != "conv2d": bad.append(f"input_layer={input_layer}")
+        if input_layer not in ("conv2d", "conv2d6", "conv2d8"): bad.append(f"input_layer={input_layer}")
         if attention_layer_type != "rel_selfattn": bad.append(f"attention_layer_type={attention_layer_type}")
         if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
         if rel_pos_type != "latest": bad.append(f"rel_pos_type={rel_pos_type}")
@@ -110,7 +110,8 @@ class EBranchformerEncoder(ConformerEncoder):
         self.merge_conv_kernel = merge_conv_kernel
         self.interctc_layer_idx, self.interctc_use_conditioning = [], False
         self.compute_dtype = compute_dtype
-        self.embed = _Conv2dSubsampling(input_size, output_size)
+        self.input_layer = input_layer
+        self.embed = _Conv2dSubsampling(input_size, output_size, input_layer)
         self.encoders = torch.nn.ModuleList(
             [_EBranchformerEncoderLayer(output_size, attention_heads, linear_units, cgmlp_linear_units,
                                         cgmlp_conv_kernel, merge_conv_kernel) for _ in range(num_blocks)])
@@ -144,11 +145,11 @@ class EBranchformerEncoder(ConformerEncoder):
         w.ff = ff or 0
         w.use_ffn, w.merge_conv = int(has_ffn), int(has_mconv)
         t = dict(conv1_w=F(e.conv[0].weight.reshape(d, 9)), conv1_b=F(e.conv[0].bias),
-                 conv2_w=A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, 9 * d)), conv2_b=F(e.conv[2].bias),
                  embed_w=A(e.out.weight.reshape(d, d, F2).permute(0, 2, 1).reshape(d, F2 * d)),
                  embed_b=F(e.out.bias),
                  wpos_all=A(torch.cat([l.attn.linear_pos.weight for l in self.encoders], dim=0)),
                  after_norm_g=F(self.after_norm.weight), after_norm_b=F(self.after_norm.bias))
+        self._pack_subsampling(w, t, A, F)
         for k, v in t.items():
             setattr(w, k, v.data_ptr())
         layers = (L.EmEBranchformerLayer * Lb)()
@@ -207,7 +208,7 @@ class BranchformerEncoder(EBranchformerEncoder):
         bad = []
         if not (use_attn and use_cgmlp): bad.append("use_attn and use_cgmlp must both be True")
         if merge_method != "concat": bad.append(f"merge_method={merge_method}")
-        if input_layer != "conv2d": bad.append(f"input_layer={input_layer}")
+        if input_layer not in ("conv2d", "conv2d6", "conv2d8"): bad.append(f"input_layer={input_layer}")
         if attention_layer_type != "rel_selfattn": bad.append(f"attention_layer_type={attention_layer_type}")
         if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
         if rel_pos_type != "latest": bad.append(f"rel_pos_type={rel_pos_type}")
@@ -226,7 +227,8 @@ class BranchformerEncoder(EBranchformerEncoder):
         self.merge_conv_kernel = None
         self.interctc_layer_idx, self.interctc_use_conditioning = [], False
         self.compute_dtype = compute_dtype
-        self.embed = _Conv2dSubsampling(input_size, output_size)
+        self.input_layer = input_layer
+        self.embed = _Conv2dSubsampling(input_size, output_size, input_layer)
         self.encoders = torch.nn.ModuleList(
             [_EBranchformerEncoderLayer(output_size, attention_heads, None, cgmlp_linear_units, cgmlp_conv_kernel,
                                         None) for _ in range(num_blocks)])

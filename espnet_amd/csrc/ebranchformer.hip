@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include "em_common.h"
+#include "subsample.h"
 
 namespace {
 
@@ -22,31 +23,23 @@ constexpr float LN_EPS = 1e-12f;
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Geo {
-  int T1, F1, T, F2;
-};
-inline Geo geo(int T_f, int n_mels) {
-  Geo g;
-  g.T1 = (T_f - 3) / 2 + 1;
-  g.F1 = (n_mels - 3) / 2 + 1;
-  g.T = (g.T1 - 3) / 2 + 1;
-  g.F2 = (g.F1 - 3) / 2 + 1;
-  return g;
-}
-
 struct Ws {
-  size_t c1, c2, x, xn, xn2, big, gn, gated, cat, tmp, ctx, pall, total;
+  size_t c1, c2, c3, x, xn, xn2, big, gn, gated, cat, tmp, ctx, pall, total;
 };
 inline Ws layout(int dtype, const EmEBranchformerWeights* w, int B, int T_f) {
   const size_t es = dtype == EM_BF16 ? 2 : 4;
-  Geo g = geo(T_f, w->n_mels);
-  const size_t M = (size_t)B * g.T, d = w->d;
+  em_sub::Geo g;
+  em_sub::geo(w->subsample, T_f, w->n_mels, &g);
+  const size_t M = (size_t)B * g.T_out, d = w->d;
+  size_t mb[3];
+  em_sub::map_bytes(g, B, w->d, es, mb);
   size_t wide = w->ff > 3 * w->d ? w->ff : 3 * w->d;
   if ((size_t)w->cg > wide) wide = w->cg;
   Ws s;
   size_t o = 0;
-  s.c1 = o; o += align_up((size_t)B * g.T1 * g.F1 * d * es);
-  s.c2 = o; o += align_up(M * g.F2 * d * es);
+  s.c1 = o; o += align_up(mb[0]);
+  s.c2 = o; o += align_up(mb[1]);
+  s.c3 = o; o += align_up(mb[2]);
   s.x = o; o += align_up(M * d * 4);
   s.xn = o; o += align_up(M * d * es);
   s.xn2 = o; o += align_up(M * d * es);
@@ -56,7 +49,7 @@ inline Ws layout(int dtype, const EmEBranchformerWeights* w, int B, int T_f) {
   s.cat = o; o += align_up(M * 2 * d * es);
   s.tmp = o; o += align_up(M * 2 * d * es);
   s.ctx = o; o += align_up(M * d * es);
-  s.pall = o; o += align_up((size_t)(2 * g.T - 1) * w->num_blocks * d * es);
+  s.pall = o; o += align_up((size_t)(2 * g.T_out - 1) * w->num_blocks * d * es);
   s.total = o;
   return s;
 }
@@ -79,7 +72,7 @@ inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const
 
 extern "C" size_t em_ebranchformer_workspace_bytes(int dtype, const EmEBranchformerWeights* w, int32_t B,
                                                    int32_t T_f) {
-  if (!w || B <= 0 || T_f < 7) return 0;
+  if (!w || B <= 0 || T_f < em_sub::min_frames(w->subsample)) return 0;
   return layout(dtype, w, B, T_f).total;
 }
 
@@ -92,18 +85,20 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   if (!w || !feats || !flens || !olens || !pos_emb || !workspace || !enc_out || !enc_act) return EM_ERR_BAD_ARG;
   if (dtype != EM_F32 && dtype != EM_BF16) return EM_ERR_BAD_ARG;
   if (B <= 0) return EM_ERR_BAD_ARG;
-  if (T_f < 7) return EM_ERR_TOO_SHORT;
+  if (T_f < em_sub::min_frames(w->subsample)) return EM_ERR_TOO_SHORT;
   const int d = w->d, h = w->heads, ff = w->ff, cg = w->cg, L = w->num_blocks, ch = cg / 2;
   const int kalign = dtype == EM_BF16 ? 64 : 32;
   if (d % 64 != 0 || h <= 0 || d / h != 64 || (w->use_ffn && ff % 64 != 0) || cg % 128 != 0 || ch % kalign != 0)
     return EM_ERR_UNSUPPORTED;
   const Ws s = layout(dtype, w, B, T_f);
   if (workspace_bytes < s.total) return EM_ERR_WORKSPACE;
-  const Geo g = geo(T_f, w->n_mels);
-  const int T = g.T, M = B * T;
+  em_sub::Geo g;
+  if (!em_sub::geo(w->subsample, T_f, w->n_mels, &g)) return EM_ERR_UNSUPPORTED;
+  const int T = g.T_out, M = B * T;
   unsigned char* ws = (unsigned char*)workspace;
   void* c1 = ws + s.c1;
   void* c2 = ws + s.c2;
+  void* c3 = ws + s.c3;
   float* x = (float*)(ws + s.x);
   void* xn = ws + s.xn;
   void* xn2 = ws + s.xn2;
@@ -116,20 +111,10 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   void* pall = ws + s.pall;
   const size_t es = dtype == EM_BF16 ? 2 : 4;
 
-  // ---- Conv2dSubsampling (+MVN) -> Linear, * sqrt(d); linear_pos of every block in one GEMM
-  EM_TRY(em_conv2d_sub1(dtype, feats, mvn_partial, flens, B, T_f, w->n_mels, w->conv1_w, w->conv1_b, d, c1,
-                        stream));
-  {
-    EmGemmArgs a = {};
-    a.A = c1; a.W = w->conv2_w; a.C = c2; a.bias = w->conv2_b;
-    a.M = M * g.F2; a.N = d; a.K = 9 * d; a.lda = 0; a.ldc = d; a.scale = 1.f;
-    a.T1 = g.T1; a.F1 = g.F1; a.T2 = T; a.F2 = g.F2; a.d = d;
-    EM_TRY(em_gemm(dtype, EM_EPI_RELU, EM_A_CONV2, &a, stream));
-  }
+  // ---- Conv2dSubsampling{,6,8} (+MVN) -> Linear, * sqrt(d) (subsample.h); linear_pos of every block in one GEMM
+  EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream));
   EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, 2 * T - 1, L * d, d, d, L * d, 1.f,
               stream));
-  EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d, g.F2 * d, d,
-              sqrtf((float)d), stream));
   const EmEBranchformerLayer* ly = w->layers;
   const bool ffn = w->use_ffn != 0;
   if (ffn)

@@ -11,6 +11,7 @@
 #include <math.h>
 
 #include "em_common.h"
+#include "subsample.h"
 
 namespace {
 
@@ -18,37 +19,29 @@ constexpr float LN_EPS = 1e-12f;  // transformer/layer_norm.py:23
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Geo {
-  int T1, F1, T, F2;
-};
-inline Geo geo(int T_f, int n_mels) {
-  Geo g;
-  g.T1 = (T_f - 3) / 2 + 1;
-  g.F1 = (n_mels - 3) / 2 + 1;
-  g.T = (g.T1 - 3) / 2 + 1;
-  g.F2 = (g.F1 - 3) / 2 + 1;
-  return g;
-}
-
 struct Ws {
-  size_t c1, c2, x, xn, big, g, g2, ctx, pall, total;
+  size_t c1, c2, c3, x, xn, big, g, g2, ctx, pall, total;
 };
 inline Ws layout(int dtype, const EmConformerWeights* w, int B, int T_f) {
   const size_t es = dtype == EM_BF16 ? 2 : 4;
-  Geo g = geo(T_f, w->n_mels);
-  const size_t M = (size_t)B * g.T, d = w->d;
+  em_sub::Geo g;
+  em_sub::geo(w->subsample, T_f, w->n_mels, &g);
+  const size_t M = (size_t)B * g.T_out, d = w->d;
+  size_t mb[3];
+  em_sub::map_bytes(g, B, w->d, es, mb);
   size_t wide = w->ff > 3 * w->d ? w->ff : 3 * w->d;
   Ws s;
   size_t o = 0;
-  s.c1 = o; o += align_up((size_t)B * g.T1 * g.F1 * d * es);
-  s.c2 = o; o += align_up(M * g.F2 * d * es);
+  s.c1 = o; o += align_up(mb[0]);
+  s.c2 = o; o += align_up(mb[1]);
+  s.c3 = o; o += align_up(mb[2]);
   s.x = o; o += align_up(M * d * 4);
   s.xn = o; o += align_up(M * d * es);
   s.big = o; o += align_up(M * wide * es);
   s.g = o; o += align_up(M * d * es);
   s.g2 = o; o += align_up(M * d * es);
   s.ctx = o; o += align_up(M * d * es);
-  s.pall = o; o += align_up((size_t)(2 * g.T - 1) * w->num_blocks * d * es);
+  s.pall = o; o += align_up((size_t)(2 * g.T_out - 1) * w->num_blocks * d * es);
   s.total = o;
   return s;
 }
@@ -84,7 +77,7 @@ inline int gemm_ln(int dtype, int epi, const void* A, const void* W, float* x, c
 
 extern "C" size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t B,
                                                int32_t T_f) {
-  if (!w || B <= 0 || T_f < 7) return 0;
+  if (!w || B <= 0 || T_f < em_sub::min_frames(w->subsample)) return 0;
   return layout(dtype, w, B, T_f).total;
 }
 
@@ -99,16 +92,18 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     return EM_ERR_BAD_ARG;
   if (dtype != EM_F32 && dtype != EM_BF16) return EM_ERR_BAD_ARG;
   if (B <= 0) return EM_ERR_BAD_ARG;
-  if (T_f < 7) return EM_ERR_TOO_SHORT;  // check_short_utt, subsampling.py:31-49
+  if (T_f < em_sub::min_frames(w->subsample)) return EM_ERR_TOO_SHORT;  // check_short_utt, subsampling.py:31-49
   const int d = w->d, h = w->heads, ff = w->ff, L = w->num_blocks;
   if (d % 64 != 0 || h <= 0 || d / h != 64 || ff % 64 != 0) return EM_ERR_UNSUPPORTED;
   const Ws s = layout(dtype, w, B, T_f);
   if (workspace_bytes < s.total) return EM_ERR_WORKSPACE;
-  const Geo g = geo(T_f, w->n_mels);
-  const int T = g.T, M = B * T;
+  em_sub::Geo g;
+  if (!em_sub::geo(w->subsample, T_f, w->n_mels, &g)) return EM_ERR_UNSUPPORTED;
+  const int T = g.T_out, M = B * T;
   unsigned char* ws = (unsigned char*)workspace;
   void* c1 = ws + s.c1;
   void* c2 = ws + s.c2;
+  void* c3 = ws + s.c3;
   float* x = (float*)(ws + s.x);
   void* xn = ws + s.xn;
   void* big = ws + s.big;
@@ -118,16 +113,8 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   void* pall = ws + s.pall;
   const size_t es = dtype == EM_BF16 ? 2 : 4;
 
-  // ---- Conv2dSubsampling: conv1 (+MVN) -> conv2 implicit GEMM -> Linear, * sqrt(d)
-  EM_TRY(em_conv2d_sub1(dtype, feats, mvn_partial, flens, B, T_f, w->n_mels, w->conv1_w,
-                        w->conv1_b, d, c1, stream));
-  {
-    EmGemmArgs a = {};
-    a.A = c1; a.W = w->conv2_w; a.C = c2; a.bias = w->conv2_b;
-    a.M = M * g.F2; a.N = d; a.K = 9 * d; a.lda = 0; a.ldc = d; a.scale = 1.f;
-    a.T1 = g.T1; a.F1 = g.F1; a.T2 = T; a.F2 = g.F2; a.d = d;
-    EM_TRY(em_gemm(dtype, EM_EPI_RELU, EM_A_CONV2, &a, stream));
-  }
+  // ---- Conv2dSubsampling{,6,8}: conv1 (+MVN) -> implicit-GEMM conv(s) -> Linear, * sqrt(d)  (subsample.h)
+  EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream));
   const EmConformerLayer* ly = w->layers;
   // ---- linear_pos of every block in one GEMM: pall[2T-1][L*d]
   EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, 2 * T - 1, L * d, d, d,
@@ -137,10 +124,10 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   // GEMM + stand-alone LN at B=32 (K=256: 16.4 vs 7.1+3.5 us, K=1024: 21.5 vs 12.2+3.5 us;
   // 250 single-resident workgroups with a long serial epilogue), so it is off.  profiles/ r01f.
   constexpr bool kFuseLayerNorm = false;
-  if (kFuseLayerNorm && d == 256) {
+  if (kFuseLayerNorm && d == 256 && em_sub::mode_of(w->subsample) == 4) {
     // every LayerNorm rides in the epilogue of the GEMM that produces its input row (one
     // workgroup owns whole 256-wide rows): no stand-alone LN launches, x is not re-read
-    EM_TRY(gemm_ln(dtype, EM_EPI_SCALE_LN, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d,
+    EM_TRY(gemm_ln(dtype, EM_EPI_SCALE_LN, c2, w->embed_w, x, w->embed_b, M, d, g.F_out * d,
                    sqrtf((float)d), ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, nullptr, nullptr, xn,
                    nullptr, stream));
     for (int l = 0; l < L; ++l) {
@@ -169,8 +156,6 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     }
     return EM_OK;
   }
-  EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, c2, w->embed_w, x, w->embed_b, M, d, g.F2 * d, g.F2 * d, d,
-              sqrtf((float)d), stream));
 
   // Fused feed-forward blocks (csrc/ffn.hip: LN + w_1 + Swish + w_2 + residual in one kernel, the
   // hidden activation never leaves the chip).  Correct and tested

@@ -42,6 +42,7 @@ struct LnArgs {
 
 struct ConvGeom {
   int T1, F1, T2, F2, d;
+  int kw, st;  // square kernel width and stride (3, 2: Conv2dSubsampling; 5, 3: second conv of Conv2dSubsampling6)
 };
 
 typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
       int per_b = g.T2 * g.F2;
       int bb = m / per_b, rem = m - bb * per_b;
       int t2 = rem / g.F2, f2 = rem - t2 * g.F2;
-      base = ((size_t)(bb * g.T1 + 2 * t2) * g.F1 + 2 * f2) * g.d;
+      base = ((size_t)(bb * g.T1 + g.st * t2) * g.F1 + g.st * f2) * g.d;
     } else {
       base = (size_t)m * lda;
     }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     size_t koff = (size_t)k0;
     if (AMODE == EM_A_CONV2) {
       int q = k0 / g.d, c0 = k0 - q * g.d;
-      int t3 = q / 3, f3 = q - t3 * 3;
+      int t3 = q / g.kw, f3 = q - t3 * g.kw;
       koff = (size_t)(t3 * g.F1 + f3) * g.d + c0;
     }
     unsigned char* sa = smem + buf * BUF;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
 
 template <typename T, int EPI, int AMODE>
 int launch(const EmGemmArgs* p, hipStream_t s) {
-  ConvGeom g{p->T1, p->F1, p->T2, p->F2, p->d};
+  ConvGeom g{p->T1, p->F1, p->T2, p->F2, p->d, p->conv_k > 0 ? p->conv_k : 3, p->conv_s > 0 ? p->conv_s : 2};
   LnArgs ln{};
   constexpr int BN = 128;
   const int nb = em_cdiv(p->N, BN);
@@ -442,7 +443,7 @@ int launch(const EmGemmArgs* p, hipStream_t s) {
 template <typename T, int EPI>
 int launch_ln(const EmGemmArgs* p, hipStream_t s) {
   if (p->N != 256 || p->ldc != p->N || !p->ln_g || !p->ln_b || !p->ln_out) return EM_ERR_UNSUPPORTED;
-  ConvGeom g{0, 0, 0, 0, 0};
+  ConvGeom g{0, 0, 0, 0, 0, 3, 2};
   LnArgs ln{p->ln_g, p->ln_b, p->ln2_g, p->ln2_b, p->ln_out, p->ln_out_f32, p->ln_eps};
   // K <= 256: W (<= 128 KiB) is cheap to re-stream, favour workgroup count (BM = 32);
   // longer K: halve the W re-reads (BM = 64)
@@ -496,7 +497,8 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   if (p->K % bk != 0) return EM_ERR_UNSUPPORTED;
   if (epilogue == EM_EPI_GLU && (p->N % 32 != 0)) return EM_ERR_UNSUPPORTED;
   if (a_mode == EM_A_CONV2) {
-    if (p->d <= 0 || p->d % bk != 0 || p->K != 9 * p->d) return EM_ERR_UNSUPPORTED;
+    const int kw = p->conv_k > 0 ? p->conv_k : 3;
+    if (p->d <= 0 || p->d % bk != 0 || p->K != kw * kw * p->d) return EM_ERR_UNSUPPORTED;
   } else if (a_mode != EM_A_PLAIN) {
     return EM_ERR_BAD_ARG;
   } else if (p->lda % (dtype == EM_BF16 ? 8 : 4) != 0) {

@@ -45,7 +45,7 @@ class EmGemmArgs(C.Structure):
                 ("d", C.c_int32),
                 ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln2_g", C.c_void_p),
                 ("ln2_b", C.c_void_p), ("ln_out", C.c_void_p), ("ln_out_f32", C.c_void_p),
-                ("ln_eps", C.c_float)]
+                ("ln_eps", C.c_float), ("conv_k", C.c_int32), ("conv_s", C.c_int32)]
 
 
 _LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b", "norm_conv_g",
@@ -65,7 +65,8 @@ class EmConformerWeights(C.Structure):
                 ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p),
                 ("conv2_b", C.c_void_p), ("embed_w", C.c_void_p), ("embed_b", C.c_void_p),
                 ("wpos_all", C.c_void_p), ("after_norm_g", C.c_void_p),
-                ("after_norm_b", C.c_void_p), ("layers", C.POINTER(EmConformerLayer))]
+                ("after_norm_b", C.c_void_p), ("layers", C.POINTER(EmConformerLayer)),
+                ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p)]
 
 
 # order of include/espnet_amd.h EmEBranchformerLayer
@@ -85,7 +86,8 @@ class EmEBranchformerWeights(C.Structure):
                                          "n_mels")] + \
                [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "embed_w", "embed_b",
                                           "wpos_all", "after_norm_g", "after_norm_b")] + \
-               [("layers", C.POINTER(EmEBranchformerLayer)), ("use_ffn", C.c_int32), ("merge_conv", C.c_int32)]
+               [("layers", C.POINTER(EmEBranchformerLayer)), ("use_ffn", C.c_int32), ("merge_conv", C.c_int32),
+                ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p)]
 
 
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",

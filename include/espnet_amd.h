@@ -58,7 +58,7 @@ extern "C" {
 
 /* A-operand addressing */
 #define EM_A_PLAIN 0 /* row m at A + m*lda */
-#define EM_A_CONV2 1 /* implicit GEMM of Conv2d(d,d,3,stride 2) over a channel-last (B,T1,F1,d) map */
+#define EM_A_CONV2 1 /* implicit GEMM of Conv2d(d,d,k,stride s) over a channel-last (B,T1,F1,d) map */
 
 typedef struct EmGemmArgs {
   const void* A;     /* act dtype */
@@ -74,6 +74,8 @@ typedef struct EmGemmArgs {
   void* ln_out;                             /* [M][N] act */
   float* ln_out_f32;                        /* optional f32 copy of ln_out, or NULL */
   float ln_eps;
+  int32_t conv_k, conv_s; /* EM_A_CONV2: square kernel width / stride; 0 = 3 / 2.  K = conv_k^2 * d
+                             (5, 3: the second conv of Conv2dSubsampling6, subsampling.py:706-711) */
 } EmGemmArgs;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -242,6 +244,12 @@ typedef struct EmConformerWeights {
   const void* wpos_all; /* [num_blocks*d][d] act: linear_pos of every block stacked */
   const float *after_norm_g, *after_norm_b;
   const EmConformerLayer* layers; /* [num_blocks], host array */
+  /* input layer (transformer/subsampling.py): 0 or 4 = Conv2dSubsampling (:386), 6 = Conv2dSubsampling6
+   * (:692: second conv 5x5 stride 3, conv2_w [d][25d]), 8 = Conv2dSubsampling8 (:785: a third 3x3
+   * stride-2 conv, conv3_w [d][9d] act, conv3_b).  embed_w is [d][F_out*d] with F_out of that stack. */
+  int32_t subsample;
+  const void* conv3_w;
+  const float* conv3_b;
 } EmConformerWeights;
 
 /* em_conformer_encode flags */
@@ -305,6 +313,9 @@ typedef struct EmEBranchformerWeights {
    * layer without the feed-forward modules and without the depthwise conv in front of merge_proj:   */
   int32_t use_ffn;    /* 1: macaron + final FFN (E-Branchformer); 0: none (ffm_ / ff_ / norm_ff fields unused) */
   int32_t merge_conv; /* 1: x += merge_proj(cat + dwconv(cat)); 0: x += merge_proj(cat) */
+  int32_t subsample;  /* as EmConformerWeights.subsample */
+  const void* conv3_w;
+  const float* conv3_b;
 } EmEBranchformerWeights;
 
 size_t em_ebranchformer_workspace_bytes(int dtype, const EmEBranchformerWeights* w, int32_t B, int32_t T_f);

@@ -96,24 +96,44 @@ def rel_pos_emb(T: int, d: int) -> Tensor:
     return pe
 
 
+def subsampling_kind(sd: Dict[str, Tensor], pre: str = "encoder.embed.") -> str:
+    """Which Conv2dSubsampling variant the state dict holds: "conv2d" (subsampling.py:386), "conv2d6" (:692,
+    second conv 5x5 stride 3) or "conv2d8" (:785, a third 3x3 stride-2 conv)."""
+    if pre + "conv.4.weight" in sd:
+        return "conv2d8"
+    return "conv2d6" if sd[pre + "conv.2.weight"].size(-1) == 5 else "conv2d"
+
+
 def conv2d_subsampling(sd: Dict[str, Tensor], feats: Tensor, pre: str = "encoder.embed.") -> Tensor:
-    """espnet2/legacy/nets/pytorch_backend/transformer/subsampling.py:432-447 (without pos-enc):
-    Conv2d(1,d,3,2)+ReLU, Conv2d(d,d,3,2)+ReLU, (b,c,t,f)->(b,t,c*f), Linear."""
+    """espnet2/legacy/nets/pytorch_backend/transformer/subsampling.py:432-447 / :752-756 / :846-850 (without
+    pos-enc): Conv2d(1,d,3,2)+ReLU, Conv2d(d,d,3,2 | 5,3)+ReLU[, Conv2d(d,d,3,2)+ReLU], (b,c,t,f)->(b,t,c*f),
+    Linear."""
+    kind = subsampling_kind(sd, pre)
     x = feats.unsqueeze(1)
     x = F.relu(F.conv2d(x, sd[pre + "conv.0.weight"], sd[pre + "conv.0.bias"], stride=2))
-    x = F.relu(F.conv2d(x, sd[pre + "conv.2.weight"], sd[pre + "conv.2.bias"], stride=2))
+    x = F.relu(F.conv2d(x, sd[pre + "conv.2.weight"], sd[pre + "conv.2.bias"], stride=3 if kind == "conv2d6" else 2))
+    if kind == "conv2d8":
+        x = F.relu(F.conv2d(x, sd[pre + "conv.4.weight"], sd[pre + "conv.4.bias"], stride=2))
     b, c, t, f = x.size()
     x = x.transpose(1, 2).contiguous().view(b, t, c * f)
     return F.linear(x, sd[pre + "out.weight"], sd[pre + "out.bias"])
 
 
-def subsampled_lengths(flens: Tensor, tmax: int) -> Tensor:
-    """Valid-frame counts after `mask[:, :, :-2:2][:, :, :-2:2]` (subsampling.py:448-449).  The
-    slicing acts on the PADDED mask of length tmax, so the result depends on tmax as well:
-    count = #{even i < tmax-2 : i < len}, applied twice."""
+def subsampled_lengths(flens: Tensor, tmax: int, kind: str = "conv2d") -> Tensor:
+    """Valid-frame counts after `mask[:, :, :-2:2][:, :, :-2:2]` (subsampling.py:448-449; conv2d6:
+    `[:-2:2][:-4:3]` :758; conv2d8: three `[:-2:2]` :851).  The slicing acts on the PADDED mask of length
+    tmax, so the result depends on tmax as well."""
     mask = ~make_pad_mask(flens, tmax)
-    mask = mask[:, :-2:2][:, :-2:2]
+    if kind == "conv2d6":
+        mask = mask[:, :-2:2][:, :-4:3]
+    elif kind == "conv2d8":
+        mask = mask[:, :-2:2][:, :-2:2][:, :-2:2]
+    else:
+        mask = mask[:, :-2:2][:, :-2:2]
     return mask.sum(1)
+
+
+SHORT_LIMIT = {"conv2d": 7, "conv2d6": 11, "conv2d8": 15}  # check_short_utt, subsampling.py:31-49
 
 
 def layer_norm(x: Tensor, sd, pre: str) -> Tensor:
@@ -202,16 +222,17 @@ def conformer_encoder(sd, feats: Tensor, flens: Tensor, heads: int, num_blocks: 
                       return_blocks: bool = False):
     """ConformerEncoder.forward (espnet2/asr/encoder/conformer_encoder.py:327-429) for
     input_layer=conv2d, rel_pos/rel_selfattn (latest), macaron, cnn module, normalize_before."""
-    if feats.size(1) < 7:
+    kind = subsampling_kind(sd)
+    if feats.size(1) < SHORT_LIMIT[kind]:
         raise TooShortUttError(
             f"has {feats.size(1)} frames and is too short for subsampling "
-            f"(it needs more than 7 frames), return empty results", feats.size(1), 7)
+            f"(it needs more than {SHORT_LIMIT[kind]} frames), return empty results", feats.size(1), SHORT_LIMIT[kind])
     x = conv2d_subsampling(sd, feats)
     d = x.size(-1)
     T = x.size(1)
     x = x * math.sqrt(d)  # embedding.py:328
     pos = rel_pos_emb(T, d).unsqueeze(0)
-    olens = subsampled_lengths(flens, feats.size(1))
+    olens = subsampled_lengths(flens, feats.size(1), kind)
     key_valid = ~make_pad_mask(olens, T)
     blocks = []
     for i in range(num_blocks):

@@ -84,6 +84,14 @@ def tiny(d=64, heads=1, ff=128, blocks=2, dec_blocks=2, kernel=31):
     return c
 
 
+def with_input_layer(conf, layer, blocks=None):
+    c = json.loads(json.dumps(conf))
+    c["encoder_conf"]["input_layer"] = layer
+    if blocks is not None:
+        c["encoder_conf"]["num_blocks"] = blocks
+    return c
+
+
 def build_reference(conf, vocab, workdir, **s2t_kwargs):
     from espnet2.bin.asr_inference import Speech2Text
     from espnet2.tasks.asr import ASRTask
@@ -610,6 +618,13 @@ CASES = {
     "bf_tiny_blocks": lambda: run_encode_case("bf_tiny_blocks", BF_TINY, 50, 33, [55, 56], [30000, 17000],
                                               with_blocks=True),
     "bf_small_4s": lambda: run_encode_case("bf_small_4s", BF_SMALL, 5000, 34, [57, 58], [64000, 40000], keep_every=4),
+    # other input layers: Conv2dSubsampling6 (5x5 stride-3 second conv) and Conv2dSubsampling8 (third conv)
+    "sub6_small_6s": lambda: run_encode_case("sub6_small_6s", with_input_layer(tiny(d=128, heads=2, ff=128), "conv2d6"),
+                                             50, 41, [61, 62], [96000, 50000], with_blocks=True),
+    "sub8_small_6s": lambda: run_encode_case("sub8_small_6s", with_input_layer(tiny(d=128, heads=2, ff=128), "conv2d8"),
+                                             50, 42, [63, 64], [96000, 41000], with_blocks=True),
+    "ebf_sub6_4s": lambda: run_encode_case("ebf_sub6_4s", with_input_layer(EBF_SMALL, "conv2d6", blocks=2), 50, 43,
+                                           [65, 66], [64000, 33000]),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

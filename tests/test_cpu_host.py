@@ -119,3 +119,18 @@ def test_rel_pos_table_matches_oracle():
 
     for T, d in [(24, 64), (249, 256)]:
         assert torch.equal(rel_pos_table(T, d), rel_pos_emb(T, d))
+
+
+@pytest.mark.parametrize("layer", ["conv2d", "conv2d6", "conv2d8"])
+def test_subsampled_lengths_match_mask_slicing(layer):
+    """Host length formulas of the three Conv2dSubsampling variants == counting the reference's mask slices
+    (subsampling.py:448-449, :758, :851) on the padded mask, for every (length, padded length) pair."""
+    from espnet_amd.nets_utils import conv2d_subsampled_lengths, conv_out_size
+    from oracle import conformer as oc
+
+    for tmax in (15, 16, 17, 40, 101, 250):
+        lens = list(range(1, tmax + 1))
+        want = oc.subsampled_lengths(torch.tensor(lens), tmax, layer).tolist()
+        assert conv2d_subsampled_lengths(lens, tmax, layer) == want
+        # an unpadded utterance keeps exactly the conv stack's output frames
+        assert conv2d_subsampled_lengths([tmax], tmax, layer)[0] == conv_out_size(tmax, layer)

@@ -31,7 +31,8 @@ def build(g, dtype):
     return model.cuda().eval()
 
 
-@pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "large_10s"])
+@pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "large_10s", "sub6_small_6s",
+                                  "sub8_small_6s"])
 def test_encode_float32_matches_reference(name):
     g = load_golden(name)
     model = build(g, "float32")

@@ -31,7 +31,8 @@ def test_stft_olens_formula():
     assert (feats[1, 8:] == 0).all()
 
 
-@pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "large_10s"])
+@pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "large_10s", "sub6_small_6s",
+                                  "sub8_small_6s"])
 def test_frontend_and_encoder_match_reference(name):
     g = load_golden(name)
     sd = golden_state_dict(g)
@@ -256,7 +257,7 @@ def test_online_beam_search_matches_reference_per_call(name):
     assert seen_events, "golden exercises no break / end event"
 
 
-@pytest.mark.parametrize("name", ["ebf_tiny_blocks", "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s"])
+@pytest.mark.parametrize("name", ["ebf_tiny_blocks", "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s", "ebf_sub6_4s"])
 def test_ebranchformer_encoder_matches_reference(name):
     """E-Branchformer (attention + cgMLP branches, depthwise-conv merge) — oracle vs
     the reference's `ESPnetASRModel.encode` with encoder=e_branchformer, incl. per-block outputs."""
