@@ -67,6 +67,7 @@ class BeamSearch:
             raise ValueError("beam search needs the decoder, the ctc and/or the lm scorer")
         self._bufs = {}
         self._graphs = {}
+        self.max_live_shapes = 3  # buffer sets (and their captured graphs) kept for recurring batch shapes
         self.step_chunk = 16  # steps enqueued between two polls of the `done` flags
         self.use_hipgraph = True  # replay a captured hipGraph of `step_chunk` search steps
 
@@ -77,9 +78,12 @@ class BatchBeamSearch(BeamSearch):
         key = (str(dev), act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl,
                None if lm is None else lm.search_key(), online)
         if key in self._bufs:
+            self._bufs[key] = self._bufs.pop(key)  # most recently used last
             return self._bufs[key]
-        self._bufs.clear()  # one live shape at a time
-        self._graphs.clear()  # graphs captured over the old buffers die with them
+        while len(self._bufs) >= self.max_live_shapes:  # evict the least recently used shape and the
+            old = self._bufs.pop(next(iter(self._bufs)))
+            for gk in [gk for gk in self._graphs if gk[0] == id(old)]:  # graphs captured over its buffers
+                del self._graphs[gk]
         n = B * W
         use_dec, use_ctc = "decoder" in self.scorers, "ctc" in self.scorers
         shapes = dict(
@@ -140,11 +144,20 @@ class BatchBeamSearch(BeamSearch):
                 ml = max(1, int(maxlenratio * tb))
             maxlens.append(ml)
             minlens.append(-1 * int(minlenratio) if minlenratio < 0 else int(minlenratio * tb))
-        Lmax = max(maxlens) + 2
+        # Shape bucketing: buffers, strides and the captured hipGraph depend on (B, T, Lmax); the memory is
+        # padded with zero frames to a multiple of 32 and the token capacity follows the bucket, so ragged
+        # batches of a decode run (bin/asr_inference.py `inference`) keep hitting the same allocation and
+        # graph.  Per-utterance xlens / maxlens bound every loop, so the padding changes no result.
+        Tb = (T + 31) // 32 * 32
+        if Tb != T:
+            enc_act = torch.nn.functional.pad(enc_act, (0, 0, 0, Tb - T))
+            T = Tb
+        lcap = max(max(maxlens), T if maxlenratio == 0 else 0)
+        Lmax = lcap + 2
         S = self.pre_beam_size if self.do_pre_beam else V
         NC = S + 1 if S < V else V
-        cap = W * (max(maxlens) + 1)
-        Tpad = (T + 31) // 32 * 32
+        cap = W * (lcap + 1)
+        Tpad = T
         nl = dec.num_blocks if dec is not None else 0
         ff = dec.linear_units if dec is not None else 0
         bufs = self._alloc(dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm)
