@@ -76,6 +76,16 @@ def model_config(name, dtype):
         model_conf=dict(ctc_weight=0.3), compute_dtype=dtype)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def synth_batch(first_utt, batch):
     wav = torch.empty(batch, N_SAMPLES)
     for i in range(batch):
@@ -123,6 +133,7 @@ def cpu_baseline(model, budget_s=12.0):
                 break
     med = sorted(times)[len(times) // 2]
     return {"value": round(AUDIO_SEC / med, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "cpu_model": _cpu_model(),
             "sample": f"oracle CPU-fp32 port, {len(times)} utterances of 10 s, batch 1, median "
                       f"{med*1e3:.1f} ms/utt (frontend + encoder + greedy CTC G1), 1 warm-up"}
 
@@ -158,6 +169,7 @@ def cpu_baseline_beam(model, beam, ctc_weight, budget_s=25.0):
                 break
     med = sorted(times)[len(times) // 2]
     return {"value": round(AUDIO_SEC / med, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "cpu_model": _cpu_model(),
             "sample": f"oracle CPU-fp32 port (K/V-cached restatement of Speech2Text beam search), "
                       f"{len(times)} utterances of 10 s, batch 1, median {med:.2f} s/utt "
                       f"(frontend + encoder + beam {beam} search, 249 steps), no warm-up"}
@@ -267,6 +279,7 @@ def cpu_baseline_stream(model, enc_conf, budget_s=15.0):
             i += 1
     med = sorted(times)[len(times) // 2]
     return {"value": round(AUDIO_SEC / med, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "cpu_model": _cpu_model(),
             "sample": f"oracle CPU-fp32 port of the streaming encoder (frontend + 64-frame chunks through "
                       f"forward_infer, no decoding), {len(times)} utterances of 10 s, median {med:.2f} s/utt"}
 
