@@ -137,10 +137,12 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
     // branch 2 (:154-163): cgMLP = Linear + GELU -> [r | g]; g <- LN(g); r * (dwconv(g) + b) -> Linear,
     // which lands in cat[:, d:]
     EM_TRY(gemm(dtype, EM_EPI_GELU, xn2, q.proj1_w, big, q.proj1_b, M, cg, d, d, cg, 1.f, stream));
-    EM_TRY(em_layernorm_act(dtype, (const unsigned char*)big + (size_t)ch * es, cg, q.csgu_norm_g,
-                            q.csgu_norm_b, M, ch, LN_EPS, gn, ch, stream));
-    EM_TRY(em_dwconv(dtype, EM_DW_GATE, gn, ch, q.csgu_conv_w, q.csgu_conv_b, conv_lens, B, T, ch,
-                     w->cg_kernel, big, cg, gated, ch, stream));
+    // (the LayerNorm of the gate half is applied by the conv's input stage from per-row statistics:
+    // the normalised half is never written)
+    EM_TRY(em_row_stats(dtype, (const unsigned char*)big + (size_t)ch * es, cg, M, ch, LN_EPS, (float*)gn, stream));
+    EM_TRY(em_dwconv_ln_gate(dtype, (const unsigned char*)big + (size_t)ch * es, cg, (const float*)gn,
+                             q.csgu_norm_g, q.csgu_norm_b, q.csgu_conv_w, q.csgu_conv_b, conv_lens, B, T, ch,
+                             w->cg_kernel, big, cg, gated, ch, stream));
     EM_TRY(gemm(dtype, EM_EPI_STORE, gated, q.proj2_w, cat + (size_t)d * es, q.proj2_b, M, d, ch, ch, 2 * d,
                 1.f, stream));
     // merge: E-Branchformer (:165-170) x += merge_proj(cat + dwconv(cat)); Branchformer (concat,

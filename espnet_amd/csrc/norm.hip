@@ -255,6 +255,70 @@ extern "C" int em_layernorm_inplace_f32(float* x, const float* g, const float* b
                              (hipStream_t)stream);
 }
 
+// (mean, 1/sqrt(var + eps)) of every row of an act-dtype matrix with a row stride: the statistics half of
+// layernorm_act_kernel, for consumers that normalise on load (conv.hip LNIN).
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, int ldx, int M, int n, float eps,
+                                                        float2* __restrict__ stats) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int NJ = NVA / EPC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* xr = x + (size_t)row * ldx;
+  const int nchunk = n / EPC;
+  float v[NJ][EPC];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+      const uint4 raw = *(const uint4*)(xr + (size_t)c * EPC);
+      const T* e = (const T*)&raw;
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) {
+        v[j][k] = to_f32(e[k]);
+        s += v[j][k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) v[j][k] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)n;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (lane + 64 * j < nchunk) {
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) {
+        const float c = v[j][k] - mean;
+        q += c * c;
+      }
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + eps);
+  if (lane == 0) stats[row] = make_float2(mean, rstd);
+}
+
+extern "C" int em_row_stats(int dtype, const void* x, int32_t ldx, int32_t M, int32_t n, float eps, float* stats,
+                            void* stream) {
+  if (!x || !stats || M <= 0 || n <= 0 || ldx < n) return EM_ERR_BAD_ARG;
+  if (n > 64 * NVA) return EM_ERR_UNSUPPORTED;
+  const int epc = dtype == EM_BF16 ? 8 : 4;
+  if (n % epc || ldx % epc || ((uintptr_t)x & 15)) return EM_ERR_UNSUPPORTED;
+  dim3 grid(em_cdiv(M, 4));
+  if (dtype == EM_F32)
+    hipLaunchKernelGGL(row_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, M, n,
+                       eps, (float2*)stats);
+  else if (dtype == EM_BF16)
+    hipLaunchKernelGGL(row_stats_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, M, n,
+                       eps, (float2*)stats);
+  else
+    return EM_ERR_BAD_ARG;
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
 extern "C" int em_layernorm_act(int dtype, const void* x, int32_t ldx, const float* g, const float* b,
                                 int32_t M, int32_t n, float eps, void* out, int32_t ldo, void* stream) {
   if (!x || !g || !b || !out || M <= 0 || n <= 0 || ldx < n || ldo < n) return EM_ERR_BAD_ARG;

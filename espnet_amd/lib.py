@@ -180,6 +180,9 @@ _SIGNATURES = {
     "em_ln_gemm": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "em_dwconv": (C.c_int, [C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp,
                             _i32, _vp]),
+    "em_row_stats": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "em_dwconv_ln_gate": (C.c_int, [C.c_int, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32,
+                                    _vp, _i32, _vp]),
     "em_layernorm_act": (C.c_int, [C.c_int, _vp, _i32, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "em_conformer_encode": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _vp, _vp, _vp,
                                       _i32, _i32, _vp, _vp, _sz, _vp, _vp, _i32, _vp]),

@@ -196,6 +196,16 @@ int em_dwconv(int dtype, int mode, const void* x, int32_t ldx, const float* w, c
 int em_layernorm_act(int dtype, const void* x, int32_t ldx, const float* g, const float* b, int32_t M,
                      int32_t n, float eps, void* out, int32_t ldo, void* stream);
 
+/*   The cgMLP gate path with the LayerNorm folded into the conv's input stage (cgmlp.py:61-79):
+ *   stats [B*T][2] = (mean, rstd) of every input row from em_row_stats; y = gate * (conv(LN(x)) + b).
+ *   Bit-identical to em_layernorm_act followed by em_dwconv(EM_DW_GATE); saves one write + read of x. */
+int em_row_stats(int dtype, const void* x, int32_t ldx, int32_t M, int32_t n, float eps, float* stats,
+                 void* stream);
+int em_dwconv_ln_gate(int dtype, const void* x, int32_t ldx, const float* stats, const float* ln_g,
+                      const float* ln_b, const float* w, const float* b, const int32_t* tlens, int32_t B,
+                      int32_t T, int32_t d, int32_t k, const void* gate, int32_t ldg, void* y, int32_t ldy,
+                      void* stream);
+
 /* ---- A11 / G1: CTC head.  argmax over vocab (asr/ctc.py:207-215), then groupby + drop
  *      blank/sos/eos (bin/asr_inference.py:574-575).  logits [M][V] f32.                        */
 int em_argmax_rows_f32(const float* logits, int32_t M, int32_t V, int32_t* ids, void* stream);

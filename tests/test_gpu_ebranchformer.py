@@ -138,6 +138,23 @@ def test_cgmlp_kernels_against_torch(prec):
         for bi in range(B):
             n = T if tl is None else tl[bi]
             assert (out[bi, :n].float().cpu() - ref_gate[bi, :n]).abs().max().item() < tol * 8
+    # LayerNorm folded into the conv's input stage: bit-identical to layernorm_act + gated conv
+    stats = torch.empty(M, 2, device="cuda")
+    L.check(lib.em_row_stats(dt, h.data_ptr() + ch * h.element_size(), cg, M, ch, 1e-12, stats.data_ptr(), sp), "stats")
+    ref_mean = hq[:, ch:].mean(1)
+    assert (stats[:, 0].cpu() - ref_mean).abs().max().item() < 1e-5
+    for tl in (None, [T, T // 2]):
+        tld = torch.tensor(tl, dtype=torch.int32, device="cuda") if tl is not None else None
+        unfused = torch.empty(B, T, ch, dtype=tdt, device="cuda")
+        fused = torch.empty(B, T, ch, dtype=tdt, device="cuda")
+        L.check(lib.em_dwconv(dt, L.EM_DW_GATE, gn.data_ptr(), ch, cwd.data_ptr(), cbd.data_ptr(), L.ptr(tld), B, T, ch,
+                              k, h.data_ptr(), cg, unfused.data_ptr(), ch, sp), "dw gate")
+        L.check(lib.em_dwconv_ln_gate(dt, h.data_ptr() + ch * h.element_size(), cg, stats.data_ptr(), gd.data_ptr(),
+                                      bd2.data_ptr(), cwd.data_ptr(), cbd.data_ptr(), L.ptr(tld), B, T, ch, k,
+                                      h.data_ptr(), cg, fused.data_ptr(), ch, sp), "dw ln gate")
+        for bi in range(B):
+            n = T if tl is None else tl[bi]
+            assert torch.equal(fused[bi, :n], unfused[bi, :n])
     # self-residual depthwise conv over a [.., 2d] matrix
     cat = (torch.randn(B, T, 2 * d, generator=g) * 0.5).to(tdt)
     mw = torch.randn(2 * d, 1, 7, generator=g) * 7 ** -0.5
