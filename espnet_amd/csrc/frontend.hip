@@ -153,26 +153,45 @@ extern "C" int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, in
 }
 
 // ---- utterance MVN: 8 partial column sums per utterance over the valid frames --------------
-__global__ __launch_bounds__(128) void utt_mvn_partial_kernel(const float* __restrict__ feats,
+// grid (8, B).  The 256 threads of a block are FL = 256 / n_mels frame lanes x n_mels columns: lane fl
+// walks frames t0 + fl, t0 + fl + FL, ... (coalesced over the columns), the FL lane sums meet in LDS.
+// (One lane per column and a serial walk over the block's ~125 frames was pure load latency: 33 us.)
+__global__ __launch_bounds__(256) void utt_mvn_partial_kernel(const float* __restrict__ feats,
                                                               const int* __restrict__ flens,
                                                               int T_f, int n_mels,
                                                               float* __restrict__ partial) {
+  __shared__ float s_acc[256];
   const int b = blockIdx.y, part = blockIdx.x;
   const int len = flens[b] < T_f ? flens[b] : T_f;
   const int chunk = (len + 7) / 8;
   const int t0 = part * chunk;
   const int t1 = (t0 + chunk) < len ? (t0 + chunk) : len;
-  for (int m = threadIdx.x; m < n_mels; m += blockDim.x) {
-    float acc = 0.f;
-    for (int t = t0; t < t1; ++t) acc += feats[((size_t)b * T_f + t) * n_mels + m];
-    partial[((size_t)b * 8 + part) * n_mels + m] = acc;
+  if (n_mels > 256) {  // wide features: one lane per column group, serial over frames
+    for (int m = threadIdx.x; m < n_mels; m += blockDim.x) {
+      float acc = 0.f;
+      for (int t = t0; t < t1; ++t) acc += feats[((size_t)b * T_f + t) * n_mels + m];
+      partial[((size_t)b * 8 + part) * n_mels + m] = acc;
+    }
+    return;
+  }
+  const int FL = 256 / n_mels;
+  const int fl = threadIdx.x / n_mels, m = threadIdx.x - fl * n_mels;
+  float acc = 0.f;
+  if (fl < FL)
+    for (int t = t0 + fl; t < t1; t += FL) acc += feats[((size_t)b * T_f + t) * n_mels + m];
+  s_acc[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < n_mels) {
+    float tot = 0.f;
+    for (int q = 0; q < FL; ++q) tot += s_acc[q * n_mels + threadIdx.x];
+    partial[((size_t)b * 8 + part) * n_mels + threadIdx.x] = tot;
   }
 }
 
 extern "C" int em_utt_mvn_partial_f32(const float* feats, const int32_t* flens, int32_t B,
                                       int32_t T_f, int32_t n_mels, float* partial, void* stream) {
   if (B <= 0 || T_f <= 0 || n_mels <= 0) return EM_ERR_BAD_ARG;
-  hipLaunchKernelGGL(utt_mvn_partial_kernel, dim3(8, B), dim3(128), 0, (hipStream_t)stream, feats,
+  hipLaunchKernelGGL(utt_mvn_partial_kernel, dim3(8, B), dim3(256), 0, (hipStream_t)stream, feats,
                      flens, T_f, n_mels, partial);
   EM_CHECK_LAUNCH();
   return EM_OK;

@@ -217,38 +217,76 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     return;
   }
   if constexpr (EPI == EM_EPI_ARGMAX_PART) {
-    // per-row (max, argmax) over this wave's 64 columns, straight from the accumulators: the 4
-    // in-lane fragments first, then the 16 lanes of a row group by shuffles (ties -> lowest column,
-    // = torch.argmax).  Cv: [M][ldc] pairs (f32 value, i32 column); group = n0/64 + wc.
+    // per-row (max, argmax) over this wave's 64 columns, straight from the accumulators (ties -> lowest
+    // column, = torch.argmax).  Cv: [M][ldc] pairs (f32 value, i32 column); group = n0/64 + wc.
+    // Each lane first reduces its 4 fragments (columns j*16 + lr), giving NVAL = MI*4 candidates per lane
+    // (one per row it touches); the 16 lanes of a row group then run a reduce-SCATTER butterfly: at every
+    // xor step a lane keeps half of its candidates and receives the partner's copy of exactly those, so
+    // the exchange volume halves each step (8+4+2+1 pairs instead of 16 x 4) and lane lr ends up owning
+    // the finished result of candidate lr.
     float2* part = (float2*)Cv;
     const int grp = (wn0 >> 6);
+    constexpr int NVAL = MI * 4;
+    float bv[NVAL];
+    int bi[NVAL];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float best = -INFINITY;
-        int bi = 0x7fffffff;
+        int idx = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int col = wn0 + j * 16 + lr;
           const float v = col < N ? acc[i][j][r] + (bias ? bias[col] : 0.f) : -INFINITY;
           if (v > best) {  // ascending columns: strict > keeps the lowest on ties
             best = v;
-            bi = col;
+            idx = col;
           }
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          const float ov = __shfl_xor(best, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          if (ov > best || (ov == best && oi < bi)) {
-            best = ov;
-            bi = oi;
-          }
-        }
-        const int m = wm0 + i * 16 + lg * 4 + r;
-        if (lr == 0 && m < M) part[(size_t)m * ldc + grp] = make_float2(best, __int_as_float(bi));
+        bv[i * 4 + r] = best;
+        bi[i * 4 + r] = idx;
       }
+    int owned = 0;  // candidate index this lane will own
+    auto better = [](float av, int ai, float ov, int oi) { return ov > av || (ov == av && oi < ai); };
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+      const int off = 8 >> step;
+      const bool hi = (lr & off) != 0;
+      const int cur = NVAL >> step;  // candidates still held before this step (compile-time after unrolling)
+      if (cur >= 2) {
+        const int h = cur >> 1;
+#pragma unroll
+        for (int k = 0; k < NVAL / 2; ++k) {
+          if (k < h) {
+            const float sv = hi ? bv[k] : bv[k + h];
+            const int si = hi ? bi[k] : bi[k + h];
+            const float ov = __shfl_xor(sv, off, 64);
+            const int oi = __shfl_xor(si, off, 64);
+            float mv = hi ? bv[k + h] : bv[k];
+            int mi = hi ? bi[k + h] : bi[k];
+            if (better(mv, mi, ov, oi)) {
+              mv = ov;
+              mi = oi;
+            }
+            bv[k] = mv;
+            bi[k] = mi;
+          }
+        }
+        owned += hi ? h : 0;
+      } else {  // a single candidate left but lanes to go: plain exchange
+        const float ov = __shfl_xor(bv[0], off, 64);
+        const int oi = __shfl_xor(bi[0], off, 64);
+        if (better(bv[0], bi[0], ov, oi)) {
+          bv[0] = ov;
+          bi[0] = oi;
+        }
+      }
+    }
+    // NVAL == 16: every lane owns one row; NVAL == 8: lanes lr and lr^1 hold the same row, the even one writes
+    const bool writer = NVAL >= 16 || (lr & 1) == 0;
+    const int m = wm0 + (owned >> 2) * 16 + lg * 4 + (owned & 3);
+    if (writer && m < M) part[(size_t)m * ldc + grp] = make_float2(bv[0], __int_as_float(bi[0]));
     return;
   }
   // per-wave LDS transpose of the whole wave tile: [BM/2 rows][64 cols] f32 (16 KiB per wave at
