@@ -343,3 +343,36 @@ def test_dec_src_attention(lib, prec, heads, d, W):
         sc = torch.matmul(q, k.transpose(1, 2)) / math.sqrt(dk)
         ref = torch.matmul(torch.softmax(sc, -1), v).transpose(0, 1).reshape(W, d)
         assert (ctx[b * W : (b + 1) * W].float().cpu() - ref).abs().max().item() < tol, b
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 6])
+def test_search_very_short_memories_match_oracle(T):
+    """Edge of the length logic: encoder memories of 1-6 frames (maxlen = T: the forced <eos> of
+    batch_beam_search.py:393-410 fires almost immediately, the CTC recurrence has 0-5 steps).  Device n-best ==
+    oracle n-best (token sequences; scores to fp32 round-off), alone and inside a ragged batch."""
+    from oracle import beam_search as ob
+
+    g = load_golden("tiny_beam5")
+    sd = golden_state_dict(g)
+    V = int(g["vocab"])
+    dc = g["config"]["decoder_conf"]
+    d = g["config"]["encoder_conf"]["output_size"]
+    torch.manual_seed(100 + T)
+    enc = torch.randn(T, d) * 0.7
+    ref = ob.beam_search(sd, enc, dc["attention_heads"], dc["num_blocks"], int(g["beam"]), float(g["ctc_weight"]),
+                         sos=V - 1, eos=V - 1)
+    bs = build_search(g, sd, "float32")
+    for graph in (False, True):
+        bs.use_hipgraph = graph
+        hyps = bs.search_batch(enc[None].cuda(), [T])[0]
+        assert len(hyps) == len(ref), (len(hyps), len(ref))
+        mine = {tuple(h.yseq.tolist()): float(h.score) for h in hyps}
+        for r in ref:
+            assert tuple(r["yseq"]) in mine
+            assert abs(mine[tuple(r["yseq"])] - r["score"]) < 2e-3
+    # the same utterance next to a long one
+    long = torch.randn(40, d) * 0.7
+    both = torch.zeros(2, 40, d)
+    both[0, :T], both[1] = enc, long
+    hb = bs.search_batch(both.cuda(), [T, 40])[0]
+    assert [h.yseq.tolist() for h in hb] == [h.yseq.tolist() for h in hyps]
