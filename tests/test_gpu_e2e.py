@@ -188,3 +188,38 @@ def test_isolated_utterance_batching_is_transparent_f32():
     a = model.encode_device(eq, [41000, 41000], isolate=True).enc_out
     b = model.encode_device(eq, [41000, 41000], isolate=False).enc_out
     assert torch.equal(a, b)
+
+
+def test_two_minute_utterance_greedy_and_search_limits():
+    """Maximum sizes: a 120 s utterance (T = 2 999 encoder frames) goes through frontend + encoder + greedy
+    CTC (property checks: token ids valid, no repeats of the collapsed kind, deterministic), while the joint
+    CTC/attention search refuses memories beyond its CTC frame capacity loudly instead of truncating."""
+    from espnet_amd.tasks.asr import ASRTask
+    from oracle.weights import synth_waveform
+
+    g = load_golden("small_10s")
+    cfg = dict(g["config"])
+    cfg["compute_dtype"] = "bfloat16"
+    model = ASRTask.build_model(cfg)
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model.cuda().eval()
+    n = 120 * 16000
+    wav = synth_waveform(77, n)[None].cuda()
+    st = model.encode_device(wav, [n])
+    assert st.olens == [2999]
+    assert torch.isfinite(st.enc_out).all()
+    ids, tokens, tlens = model.greedy_ctc_device(st)
+    k = int(tlens[0])
+    tok = tokens[0, :k].tolist()
+    V = int(g["vocab"])
+    assert 0 < k <= 2999 and all(0 < t < V - 1 for t in tok)  # blank / sos / eos never survive the collapse
+    ids_h = ids[0, :2999].tolist()
+    collapsed = [a for a, b in zip(ids_h, [None] + ids_h[:-1]) if a != b and a not in (0, V - 1)]
+    assert collapsed == tok  # G1 = groupby + drop blank/eos, recomputed on the host from the frame ids
+    ids2, tokens2, tlens2 = model.greedy_ctc_device(model.encode_device(wav, [n]))
+    assert torch.equal(tokens, tokens2) and torch.equal(tlens, tlens2)
+    from espnet_amd.nets.batch_beam_search import build_beam_search
+
+    bs = build_beam_search(model, beam_size=2, ctc_weight=0.3, penalty=0.0, token_list=model.token_list)
+    with pytest.raises(NotImplementedError):
+        bs.search_batch(st.enc_act, st.olens)
