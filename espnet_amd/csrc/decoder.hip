@@ -392,6 +392,9 @@ int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, c
                     int B, int W, int d, int heads, int Tn, int Tpad, void* ctx, hipStream_t s) {
   const int dk = d / heads;
   const size_t lds = (size_t)16 * (Tpad + 4) * 4 + 64 + (size_t)16 * (Tpad + 16 / sizeof(T)) * sizeof(T);
+  // the 16 score rows of a workgroup live in LDS: memories beyond ~1 690 frames (bf16; ~1 270 in f32) do
+  // not fit the 160 KB of a CU -- say so instead of failing at launch
+  if (lds > 160 * 1024) return EM_ERR_UNSUPPORTED;
   dim3 grid(heads, B, em_cdiv(W, 16));
   // (the attribute is raised once per process and size: no runtime API call on later launches,
   //  which also keeps the launch legal inside a stream capture)
