@@ -137,9 +137,17 @@ class ConformerEncoder(torch.nn.Module):
         if concat_after: bad.append("concat_after=True")
         if positionwise_layer_type != "linear": bad.append(f"positionwise_layer_type={positionwise_layer_type}")
         if not macaron_style: bad.append("macaron_style=False")
-        if rel_pos_type != "latest": bad.append(f"rel_pos_type={rel_pos_type}")
-        if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
-        if selfattention_layer_type != "rel_selfattn": bad.append(f"selfattention_layer_type={selfattention_layer_type}")
+        # conformer_encoder.py:127-136: rel_pos_type "legacy" turns rel_pos / rel_selfattn into their legacy_ forms
+        if rel_pos_type == "legacy":
+            pos_enc_layer_type = "legacy_rel_pos" if pos_enc_layer_type == "rel_pos" else pos_enc_layer_type
+            selfattention_layer_type = ("legacy_rel_selfattn" if selfattention_layer_type == "rel_selfattn"
+                                        else selfattention_layer_type)
+        elif rel_pos_type != "latest":
+            raise ValueError("unknown rel_pos_type: " + rel_pos_type)
+        legacy = pos_enc_layer_type == "legacy_rel_pos" and selfattention_layer_type == "legacy_rel_selfattn"
+        if not legacy:
+            if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
+            if selfattention_layer_type != "rel_selfattn": bad.append(f"selfattention_layer_type={selfattention_layer_type}")
         if activation_type != "swish": bad.append(f"activation_type={activation_type}")
         if not use_cnn_module: bad.append("use_cnn_module=False")
         if zero_triu: bad.append("zero_triu=True")
@@ -159,6 +167,7 @@ class ConformerEncoder(torch.nn.Module):
         self.interctc_use_conditioning = interctc_use_conditioning
         self.compute_dtype = compute_dtype
         self.input_layer = input_layer
+        self.legacy_relpos, self.max_pos_emb_len = legacy, max_pos_emb_len
         self.embed = _Conv2dSubsampling(input_size, output_size, input_layer)
         self.encoders = torch.nn.ModuleList(
             [_EncoderLayer(output_size, attention_heads, linear_units, cnn_module_kernel)
@@ -256,6 +265,7 @@ class ConformerEncoder(torch.nn.Module):
         e, d = self.embed, self._output_size
         layer = getattr(self, "input_layer", "conv2d")
         w.subsample = {"conv2d": 4, "conv2d6": 6, "conv2d8": 8}[layer]
+        w.legacy_relpos = int(getattr(self, "legacy_relpos", False))
         k2 = e.conv[2].weight.size(-1)
         t["conv2_w"] = A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, k2 * k2 * d))
         t["conv2_b"] = F(e.conv[2].bias)
@@ -274,6 +284,8 @@ class ConformerEncoder(torch.nn.Module):
         length, exactly as the reference slices its `pe` buffer (embedding.py:329-332).  Row k of the
         slice is the sinusoid of relative position T-1-k whatever the table length, so the values are
         bit-identical to a table built for T; the table grows by doubling (built once per size)."""
+        if getattr(self, "legacy_relpos", False):
+            return self._legacy_pos_emb(T, device)
         key = (str(device), self.em_dtype)
         tab = self._pos_cache.get(key)
         if tab is None or tab[0] < T:
@@ -284,6 +296,24 @@ class ConformerEncoder(torch.nn.Module):
             self._pos_cache[key] = tab
         tmax, table = tab
         return table[tmax - T : tmax + T - 1]
+
+    def _legacy_pos_emb(self, T: int, device) -> torch.Tensor:
+        """(T, d): LegacyRelPositionalEncoding rows (embedding.py:223-262 over PositionalEncoding(reverse=True)
+        :50-82): the reference builds positions max_len-1 .. 0 once and uses the first T rows, so row k is the
+        sinusoid of position max_len-1-k — a prefix of one table (rebuilt longer like `extend_pe` if needed)."""
+        key = ("legacy", str(device), self.em_dtype)
+        tab = self._pos_cache.get(key)
+        if tab is None or tab.size(0) < T:
+            n = max(T, self.max_pos_emb_len)
+            d = self._output_size
+            position = torch.arange(n - 1, -1, -1.0, dtype=torch.float32).unsqueeze(1)
+            div_term = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+            pe = torch.zeros(n, d)
+            pe[:, 0::2] = torch.sin(position * div_term)
+            pe[:, 1::2] = torch.cos(position * div_term)
+            tab = pe.to(self.act_dtype).to(device)
+            self._pos_cache[key] = tab
+        return tab[:T]
 
     # ------------------------------------------------------------------ forward
     def output_frames(self, T_f: int) -> int:

@@ -19,21 +19,30 @@ constexpr int QT = 64;  // queries per workgroup (4 waves x 16)
 constexpr int KT = 64;  // keys per tile
 constexpr int DK = 64;
 
-template <typename T>
+template <typename T, bool LEGACY = false>
 struct AttnLds {
   static constexpr int LDT = 64 + 16 / (int)sizeof(T);  // padded row (elements)
   static constexpr int LDB = 84;                         // padded BD row (floats)
+  // LEGACY keeps a second BD window per wave (its position rows reuse the sP staging area)
   static constexpr size_t bytes = (size_t)(64 + 64 + 128 + 64) * LDT * sizeof(T) +
-                                  (size_t)4 * 16 * LDB * sizeof(float);
+                                  (size_t)(LEGACY ? 2 : 1) * 4 * 16 * LDB * sizeof(float);
 };
 
-template <typename T>
+// LEGACY = LegacyRelPositionMultiHeadedAttention (attention.py:268-360, the class default
+// rel_pos_type="legacy" of older checkpoints): p has T rows (LegacyRelPositionalEncoding: the sinusoid of
+// position max_len-1-k in row k) and rel_shift (:296-316) is the square pad-and-reshape, which gives
+//     BD[i][j] = (q_i + v) . p[T-1-i+j]          j <= i       (the same index as the current scheme)
+//              = 0                                j == i+1
+//              = (q_{i+1} + v) . p[j-i-2]         j >  i+1     (the wrapped rows of the reshape)
+// The upper part is a second dense window, computed from the NEXT query row's fragments over the 80
+// position rows p[j0-iw0-17 ..]; both windows are read with the same skew 15 - i_local + j_local.
+template <typename T, bool LEGACY = false>
 __global__ __launch_bounds__(256) void relpos_attn_kernel(
     const T* __restrict__ qkv, const T* __restrict__ p, int ldp, const float* __restrict__ pos_u,
     const float* __restrict__ pos_v, const int* __restrict__ klens, int Tn, int h,
     T* __restrict__ ctx) {
   using M = Mma<T>;
-  constexpr int LDT = AttnLds<T>::LDT, LDB = AttnLds<T>::LDB;
+  constexpr int LDT = AttnLds<T, LEGACY>::LDT, LDB = AttnLds<T, LEGACY>::LDB;
   constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int PPR = DK / CH;             // chunks per 64-element row
   constexpr int KS = DK / M::K;            // MFMA steps over a 64-deep contraction
@@ -42,7 +51,7 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(
   T* sVt = sK + 64 * LDT;      // [64 dk][LDT keys]
   T* sP = sVt + 64 * LDT;      // [128 pos rows][LDT]
   T* sPr = sP + 128 * LDT;     // [4 waves][16][LDT]
-  float* sBD = (float*)(sPr + 64 * LDT);  // [4 waves][16][LDB]
+  float* sBD = (float*)(sPr + 64 * LDT);  // [4 waves][16][LDB] (LEGACY: x2)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = blockIdx.y, b = blockIdx.z;
@@ -52,9 +61,25 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(
   const int lr = lane & 15, lg = lane >> 4;
   T* myPr = sPr + wave * 16 * LDT;
   float* myBD = sBD + wave * 16 * LDB;
+  float* myBD2 = sBD + (4 + wave) * 16 * LDB;  // LEGACY only
 
   // ---- query fragments (A operand): row = iw0 + lr, k-slice lg
-  typename M::frag qu[KS], qv[KS];
+  typename M::frag qu[KS], qv[KS], qv2[LEGACY ? KS : 1];
+  if (LEGACY) {  // (q_{i+1} + v) for the wrapped upper part
+    int i = iw0 + lr + 1;
+    i = i < Tn ? i : Tn - 1;
+    const T* qrow = qkv + (size_t)(b * Tn + i) * ld + hh * DK;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      __attribute__((aligned(16))) T tv[M::EPL];
+#pragma unroll
+      for (int e = 0; e < M::EPL; ++e) {
+        int c = ks * M::K + lg * M::EPL + e;
+        tv[e] = from_f32<T>(to_f32(qrow[c]) + pos_v[hh * DK + c]);
+      }
+      qv2[ks] = M::load(tv);
+    }
+  }
   {
     int i = iw0 + lr;
     i = i < Tn ? i : Tn - 1;
@@ -104,7 +129,8 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(
     for (int c = tid; c < 128 * PPR; c += 256) {
       int row = c / PPR, piece = c - row * PPR;
       int pc = cbase + row;
-      pc = pc < 0 ? 0 : (pc > 2 * Tn - 2 ? 2 * Tn - 2 : pc);
+      const int pmax = LEGACY ? Tn - 1 : 2 * Tn - 2;
+      pc = pc < 0 ? 0 : (pc > pmax ? pmax : pc);
       *(uint4*)(sP + row * LDT + piece * CH) =
           *(const uint4*)(p + (size_t)pc * ldp + hh * DK + piece * CH);
     }
@@ -131,6 +157,31 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(
     for (int n = 0; n < 5; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) myBD[(lg * 4 + r) * LDB + n * 16 + lr] = acc_bd[n][r];
+    if (LEGACY) {
+      __syncthreads();  // every wave is done with the first position window
+      const int c2base = j0 - i0 - 65;
+      for (int c = tid; c < 128 * PPR; c += 256) {
+        int row = c / PPR, piece = c - row * PPR;
+        int pc = c2base + row;
+        pc = pc < 0 ? 0 : (pc > Tn - 1 ? Tn - 1 : pc);
+        *(uint4*)(sP + row * LDT + piece * CH) = *(const uint4*)(p + (size_t)pc * ldp + hh * DK + piece * CH);
+      }
+      __syncthreads();
+      f32x4 acc_b2[5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) acc_b2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int ko = ks * M::K + lg * M::EPL;
+#pragma unroll
+        for (int n = 0; n < 5; ++n)
+          acc_b2[n] = M::mma(qv2[ks], M::load(sP + (rbase + n * 16 + lr) * LDT + ko), acc_b2[n]);
+      }
+#pragma unroll
+      for (int n = 0; n < 5; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) myBD2[(lg * 4 + r) * LDB + n * 16 + lr] = acc_b2[n][r];
+    }
     __syncthreads();
 
     // ---- scores, mask, online softmax
@@ -142,7 +193,13 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int ii = lg * 4 + r, jj = n * 16 + lr;
-        float s = (acc_s[n][r] + myBD[ii * LDB + 15 - ii + jj]) * 0.125f;  // 1/sqrt(64)
+        float bd = myBD[ii * LDB + 15 - ii + jj];
+        if (LEGACY) {
+          const int i = iw0 + ii, j = j0 + jj;
+          if (j == i + 1) bd = 0.f;
+          else if (j > i + 1) bd = myBD2[ii * LDB + 15 - ii + jj];
+        }
+        float s = (acc_s[n][r] + bd) * 0.125f;  // 1/sqrt(64)
         s = (j0 + jj < klen) ? s : -INFINITY;
         acc_s[n][r] = s;
         tile_m[r] = fmaxf(tile_m[r], s);
@@ -205,15 +262,15 @@ __global__ __launch_bounds__(256) void relpos_attn_kernel(
   }
 }
 
-template <typename T>
+template <typename T, bool LEGACY>
 int launch_attn(const void* qkv, const void* p, int ldp, const float* pu, const float* pv,
                 const int* klens, int B, int Tn, int h, void* ctx, hipStream_t s) {
-  const size_t lds = AttnLds<T>::bytes;
-  hipError_t e = hipFuncSetAttribute((const void*)relpos_attn_kernel<T>,
+  const size_t lds = AttnLds<T, LEGACY>::bytes;
+  hipError_t e = hipFuncSetAttribute((const void*)relpos_attn_kernel<T, LEGACY>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(Tn, QT), h, B);
-  hipLaunchKernelGGL((relpos_attn_kernel<T>), grid, dim3(256), lds, s, (const T*)qkv, (const T*)p,
+  hipLaunchKernelGGL((relpos_attn_kernel<T, LEGACY>), grid, dim3(256), lds, s, (const T*)qkv, (const T*)p,
                      ldp, pu, pv, klens, Tn, h, (T*)ctx);
   EM_CHECK_LAUNCH();
   return EM_OK;
@@ -228,8 +285,21 @@ extern "C" int em_relpos_attention(int dtype, const void* qkv, const void* p, in
   if (B <= 0 || T <= 0 || h <= 0) return EM_ERR_BAD_ARG;
   if (dk != DK) return EM_ERR_UNSUPPORTED;
   if (dtype == EM_F32)
-    return launch_attn<float>(qkv, p, ldp, pos_u, pos_v, klens, B, T, h, ctx, (hipStream_t)stream);
+    return launch_attn<float, false>(qkv, p, ldp, pos_u, pos_v, klens, B, T, h, ctx, (hipStream_t)stream);
   if (dtype == EM_BF16)
-    return launch_attn<bf16>(qkv, p, ldp, pos_u, pos_v, klens, B, T, h, ctx, (hipStream_t)stream);
+    return launch_attn<bf16, false>(qkv, p, ldp, pos_u, pos_v, klens, B, T, h, ctx, (hipStream_t)stream);
+  return EM_ERR_BAD_ARG;
+}
+
+extern "C" int em_legacy_relpos_attention(int dtype, const void* qkv, const void* p, int32_t ldp,
+                                          const float* pos_u, const float* pos_v, const int32_t* klens,
+                                          int32_t B, int32_t T, int32_t h, int32_t dk, void* ctx,
+                                          void* stream) {
+  if (B <= 0 || T <= 0 || h <= 0) return EM_ERR_BAD_ARG;
+  if (dk != DK) return EM_ERR_UNSUPPORTED;
+  if (dtype == EM_F32)
+    return launch_attn<float, true>(qkv, p, ldp, pos_u, pos_v, klens, B, T, h, ctx, (hipStream_t)stream);
+  if (dtype == EM_BF16)
+    return launch_attn<bf16, true>(qkv, p, ldp, pos_u, pos_v, klens, B, T, h, ctx, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
 }

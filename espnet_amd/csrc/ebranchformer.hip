@@ -113,7 +113,7 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
 
   // ---- Conv2dSubsampling{,6,8} (+MVN) -> Linear, * sqrt(d) (subsample.h); linear_pos of every block in one GEMM
   EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream));
-  EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, 2 * T - 1, L * d, d, d, L * d, 1.f,
+  EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, w->legacy_relpos ? T : 2 * T - 1, L * d, d, d, L * d, 1.f,
               stream));
   const EmEBranchformerLayer* ly = w->layers;
   const bool ffn = w->use_ffn != 0;
@@ -131,7 +131,7 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
     EM_TRY(em_layernorm(dtype, x, q.norm_mlp_g, q.norm_mlp_b, M, d, LN_EPS, xn2, nullptr, stream));
     // branch 1 (:141-152): rel-pos self-attention; linear_out lands in cat[:, :d]
     EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
-    EM_TRY(em_relpos_attention(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
+    EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
                                q.pos_v, olens, B, T, h, 64, ctx, stream));
     EM_TRY(gemm(dtype, EM_EPI_STORE, ctx, q.wout, cat, q.bout, M, d, d, d, 2 * d, 1.f, stream));
     // branch 2 (:154-163): cgMLP = Linear + GELU -> [r | g]; g <- LN(g); r * (dwconv(g) + b) -> Linear,

@@ -117,7 +117,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream));
   const EmConformerLayer* ly = w->layers;
   // ---- linear_pos of every block in one GEMM: pall[2T-1][L*d]
-  EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, 2 * T - 1, L * d, d, d,
+  EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, w->legacy_relpos ? T : 2 * T - 1, L * d, d, d,
               L * d, 1.f, stream));
   // LayerNorm fused into the producing GEMM's epilogue (EM_EPI_*_LN, N == 256): correct and tested
   // (tests/test_gpu_kernels.py::test_gemm_layernorm_epilogue) but measured SLOWER on MI355X than
@@ -136,7 +136,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
       EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, 0.5f, q.norm_mha_g,
                      q.norm_mha_b, nullptr, nullptr, xn, nullptr, stream));
       EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
-      EM_TRY(em_relpos_attention(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
+      EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
                                  q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
       EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, ctx, q.wout, x, q.bout, M, d, d, 1.f, q.norm_conv_g,
                      q.norm_conv_b, nullptr, nullptr, xn, nullptr, stream));
@@ -172,7 +172,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
                                q.ffm_w2, q.ffm_b2, M, d, ff, 0.5f, stream));
       EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
       EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
-      EM_TRY(em_relpos_attention(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
+      EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
                                  q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
       EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
@@ -199,7 +199,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     // self-attention
     EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
-    EM_TRY(em_relpos_attention(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
+    EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
                                q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
     // convolution module

@@ -66,7 +66,8 @@ class EmConformerWeights(C.Structure):
                 ("conv2_b", C.c_void_p), ("embed_w", C.c_void_p), ("embed_b", C.c_void_p),
                 ("wpos_all", C.c_void_p), ("after_norm_g", C.c_void_p),
                 ("after_norm_b", C.c_void_p), ("layers", C.POINTER(EmConformerLayer)),
-                ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p)]
+                ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p),
+                ("legacy_relpos", C.c_int32)]
 
 
 # order of include/espnet_amd.h EmEBranchformerLayer
@@ -87,7 +88,8 @@ class EmEBranchformerWeights(C.Structure):
                [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "embed_w", "embed_b",
                                           "wpos_all", "after_norm_g", "after_norm_b")] + \
                [("layers", C.POINTER(EmEBranchformerLayer)), ("use_ffn", C.c_int32), ("merge_conv", C.c_int32),
-                ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p)]
+                ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p),
+                ("legacy_relpos", C.c_int32)]
 
 
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",
@@ -167,6 +169,8 @@ _SIGNATURES = {
     "em_ffn_fused_bf16": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "em_layernorm_inplace_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "em_relpos_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32,
+                                      _i32, _vp, _vp]),
+    "em_legacy_relpos_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _i32, _vp, _vp]),
     "em_dwconv_bn_swish": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "em_argmax_rows_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),

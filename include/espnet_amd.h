@@ -171,6 +171,15 @@ int em_relpos_attention(int dtype, const void* qkv, const void* p, int32_t ldp, 
                         const float* pos_v, const int32_t* klens, int32_t B, int32_t T, int32_t h,
                         int32_t dk, void* ctx, void* stream);
 
+/*   LegacyRelPositionMultiHeadedAttention (attention.py:268-360; `rel_pos_type: legacy`, the class default
+ *   that older checkpoints were trained with).  p [T][ldp] act = linear_pos of LegacyRelPositionalEncoding
+ *   rows (embedding.py:223-262: row k = sinusoid of position max_len-1-k); the square pad-and-reshape
+ *   rel_shift (:296-316) gives BD[i][j] = (q_i+v).p[T-1-i+j] for j <= i, 0 for j == i+1 and
+ *   (q_{i+1}+v).p[j-i-2] above (the wrapped rows), reproduced as index arithmetic.  zero_triu unsupported. */
+int em_legacy_relpos_attention(int dtype, const void* qkv, const void* p, int32_t ldp, const float* pos_u,
+                               const float* pos_v, const int32_t* klens, int32_t B, int32_t T, int32_t h,
+                               int32_t dk, void* ctx, void* stream);
+
 /* ---- A8 (middle): depthwise Conv1d(k, pad (k-1)/2) + eval BatchNorm1d (folded into w,b by the
  *      caller) + Swish (conformer/convolution.py:72-75).  x,y [B][T][d] act; w [k][d] f32 (tap-major).
  *      tlens [B] i32 or NULL: with lengths, input frames t >= tlens[b] read as zero (the utterance
@@ -260,6 +269,7 @@ typedef struct EmConformerWeights {
   int32_t subsample;
   const void* conv3_w;
   const float* conv3_b;
+  int32_t legacy_relpos; /* 1: rel_pos_type legacy (pos_emb has T rows, em_legacy_relpos_attention) */
 } EmConformerWeights;
 
 /* em_conformer_encode flags */
@@ -272,7 +282,8 @@ size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int3
  *   mvn_partial[B][8][n_mels] f32 from em_utt_mvn_partial_f32, or NULL for no mean subtraction
  *   flens      [B] i32 valid feature frames;  olens [B] i32 valid encoder frames (host computes
  *              both from the lengths exactly as the reference's masks do)
- *   pos_emb    [2T-1][d] act: RelPositionalEncoding table rows (embedding.py:286-332)
+ *   pos_emb    [2T-1][d] act: RelPositionalEncoding table rows (embedding.py:286-332); with
+ *              w->legacy_relpos [T][d]: LegacyRelPositionalEncoding rows (embedding.py:223-262)
  *   enc_out    [B][T][d] f32 out (after_norm applied); enc_act same in act dtype (input of the
  *              CTC / decoder projections), T = ((T_f-1)/2-1)/2
  *   flags      0: padded-batch semantics of ConformerEncoder.forward (padded frames leak through the
@@ -326,6 +337,7 @@ typedef struct EmEBranchformerWeights {
   int32_t subsample;  /* as EmConformerWeights.subsample */
   const void* conv3_w;
   const float* conv3_b;
+  int32_t legacy_relpos; /* as EmConformerWeights.legacy_relpos */
 } EmEBranchformerWeights;
 
 size_t em_ebranchformer_workspace_bytes(int dtype, const EmEBranchformerWeights* w, int32_t B, int32_t T_f);

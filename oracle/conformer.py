@@ -182,6 +182,46 @@ def rel_pos_attention(sd, x: Tensor, pos_emb: Tensor, key_valid: Tensor, pre: st
     return F.linear(ctx, sd[pre + "linear_out.weight"], sd[pre + "linear_out.bias"])
 
 
+def legacy_pos_emb(T: int, d: int, max_len: int = 5000) -> Tensor:
+    """LegacyRelPositionalEncoding (transformer/embedding.py:223-262 over PositionalEncoding(reverse=True)
+    :50-82): the table is built once for `max_len` with positions max_len-1 .. 0 and the first T rows are
+    used, so row k is the sinusoid of position max_len-1-k."""
+    position = torch.arange(max_len - 1, max_len - 1 - T, -1.0, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(T, d)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def legacy_rel_shift(x: Tensor) -> Tensor:
+    """LegacyRelPositionMultiHeadedAttention.rel_shift (transformer/attention.py:296-316), zero_triu=False."""
+    zero_pad = torch.zeros((*x.size()[:3], 1), dtype=x.dtype)
+    x_padded = torch.cat([zero_pad, x], dim=-1)
+    x_padded = x_padded.view(*x.size()[:2], x.size(3) + 1, x.size(2))
+    return x_padded[:, :, 1:].view_as(x)
+
+
+def legacy_rel_pos_attention(sd, x: Tensor, pos_emb: Tensor, key_valid: Tensor, pre: str, h: int) -> Tensor:
+    """LegacyRelPositionMultiHeadedAttention.forward (transformer/attention.py:318-360)."""
+    B, T, d = x.shape
+    dk = d // h
+    q = F.linear(x, sd[pre + "linear_q.weight"], sd[pre + "linear_q.bias"]).view(B, T, h, dk)
+    k = F.linear(x, sd[pre + "linear_k.weight"], sd[pre + "linear_k.bias"]).view(B, T, h, dk).transpose(1, 2)
+    v = F.linear(x, sd[pre + "linear_v.weight"], sd[pre + "linear_v.bias"]).view(B, T, h, dk).transpose(1, 2)
+    p = F.linear(pos_emb, sd[pre + "linear_pos.weight"]).view(1, -1, h, dk).transpose(1, 2)
+    q_u = (q + sd[pre + "pos_bias_u"]).transpose(1, 2)
+    q_v = (q + sd[pre + "pos_bias_v"]).transpose(1, 2)
+    ac = torch.matmul(q_u, k.transpose(-2, -1))
+    bd = legacy_rel_shift(torch.matmul(q_v, p.transpose(-2, -1)))
+    scores = (ac + bd) / math.sqrt(dk)
+    mask = ~key_valid[:, None, None, :]
+    scores = scores.masked_fill(mask, torch.finfo(scores.dtype).min)
+    attn = torch.softmax(scores, dim=-1).masked_fill(mask, 0.0)
+    ctx = torch.matmul(attn, v).transpose(1, 2).contiguous().view(B, T, d)
+    return F.linear(ctx, sd[pre + "linear_out.weight"], sd[pre + "linear_out.bias"])
+
+
 def conv_module(sd, x: Tensor, pre: str) -> Tensor:
     """ConvolutionModule.forward (conformer/convolution.py:56-79); eval-mode BatchNorm.
     NB: no padding mask inside (padded frames leak into their neighbours, as in the reference)."""
@@ -198,12 +238,13 @@ def conv_module(sd, x: Tensor, pre: str) -> Tensor:
     return x.transpose(1, 2)
 
 
-def conformer_block(sd, x: Tensor, pos_emb: Tensor, key_valid: Tensor, pre: str, h: int) -> Tensor:
+def conformer_block(sd, x: Tensor, pos_emb: Tensor, key_valid: Tensor, pre: str, h: int,
+                    legacy: bool = False) -> Tensor:
     """EncoderLayer.forward, eval mode, normalize_before, macaron, cnn module
     (conformer/encoder_layer.py:79-179; ff_scale 0.5 :65)."""
+    attn = legacy_rel_pos_attention if legacy else rel_pos_attention
     x = x + 0.5 * feed_forward(sd, layer_norm(x, sd, pre + "norm_ff_macaron."), pre + "feed_forward_macaron.")
-    x = x + rel_pos_attention(sd, layer_norm(x, sd, pre + "norm_mha."), pos_emb, key_valid,
-                              pre + "self_attn.", h)
+    x = x + attn(sd, layer_norm(x, sd, pre + "norm_mha."), pos_emb, key_valid, pre + "self_attn.", h)
     x = x + conv_module(sd, layer_norm(x, sd, pre + "norm_conv."), pre + "conv_module.")
     x = x + 0.5 * feed_forward(sd, layer_norm(x, sd, pre + "norm_ff."), pre + "feed_forward.")
     return layer_norm(x, sd, pre + "norm_final.")
@@ -219,7 +260,7 @@ class TooShortUttError(Exception):
 
 
 def conformer_encoder(sd, feats: Tensor, flens: Tensor, heads: int, num_blocks: int,
-                      return_blocks: bool = False):
+                      return_blocks: bool = False, rel_pos_type: str = "latest"):
     """ConformerEncoder.forward (espnet2/asr/encoder/conformer_encoder.py:327-429) for
     input_layer=conv2d, rel_pos/rel_selfattn (latest), macaron, cnn module, normalize_before."""
     kind = subsampling_kind(sd)
@@ -231,12 +272,13 @@ def conformer_encoder(sd, feats: Tensor, flens: Tensor, heads: int, num_blocks: 
     d = x.size(-1)
     T = x.size(1)
     x = x * math.sqrt(d)  # embedding.py:328
-    pos = rel_pos_emb(T, d).unsqueeze(0)
+    legacy = rel_pos_type == "legacy"
+    pos = (legacy_pos_emb(T, d) if legacy else rel_pos_emb(T, d)).unsqueeze(0)
     olens = subsampled_lengths(flens, feats.size(1), kind)
     key_valid = ~make_pad_mask(olens, T)
     blocks = []
     for i in range(num_blocks):
-        x = conformer_block(sd, x, pos, key_valid, f"encoder.encoders.{i}.", heads)
+        x = conformer_block(sd, x, pos, key_valid, f"encoder.encoders.{i}.", heads, legacy)
         if return_blocks:
             blocks.append(x)
     x = layer_norm(x, sd, "encoder.after_norm.")
@@ -246,13 +288,13 @@ def conformer_encoder(sd, feats: Tensor, flens: Tensor, heads: int, num_blocks: 
 
 
 def encode(sd, speech: Tensor, speech_lengths: Tensor, heads: int, num_blocks: int,
-           n_fft: int = 512, win_length: Optional[int] = None, hop: int = 160):
+           n_fft: int = 512, win_length: Optional[int] = None, hop: int = 160, rel_pos_type: str = "latest"):
     """ESPnetASRModel.encode (espnet2/asr/espnet_model.py:380-448) with DefaultFrontend +
     UtteranceMVN + ConformerEncoder."""
     feats, flens = frontend_feats(speech, speech_lengths, sd["frontend.logmel.melmat"], n_fft,
                                   win_length, hop)
     feats = utterance_mvn(feats, flens)
-    return conformer_encoder(sd, feats, flens, heads, num_blocks)
+    return conformer_encoder(sd, feats, flens, heads, num_blocks, rel_pos_type=rel_pos_type)
 
 
 # --------------------------------------------------------------------------- CTC head

@@ -92,6 +92,12 @@ def with_input_layer(conf, layer, blocks=None):
     return c
 
 
+def with_legacy(conf):
+    c = json.loads(json.dumps(conf))
+    c["encoder_conf"]["rel_pos_type"] = "legacy"
+    return c
+
+
 def build_reference(conf, vocab, workdir, **s2t_kwargs):
     from espnet2.bin.asr_inference import Speech2Text
     from espnet2.tasks.asr import ASRTask
@@ -625,6 +631,11 @@ CASES = {
                                              50, 42, [63, 64], [96000, 41000], with_blocks=True),
     "ebf_sub6_4s": lambda: run_encode_case("ebf_sub6_4s", with_input_layer(EBF_SMALL, "conv2d6", blocks=2), 50, 43,
                                            [65, 66], [64000, 33000]),
+    # rel_pos_type legacy (LegacyRelPositionMultiHeadedAttention + LegacyRelPositionalEncoding: older checkpoints)
+    "legacy_small_5s": lambda: run_encode_case("legacy_small_5s", with_legacy(tiny(d=128, heads=2, ff=128)), 50, 44,
+                                               [67, 68], [80000, 37000], with_blocks=True),
+    "legacy_small_12s": lambda: run_encode_case("legacy_small_12s", with_legacy(tiny(d=128, heads=2, ff=128)), 50, 45,
+                                                [69], [192000], keep_every=4),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

@@ -79,9 +79,16 @@ def test_unsupported_choices_raise():
     with pytest.raises(NotImplementedError):
         ASRTask.build_model(cfg)
     cfg = dict(g["config"])
-    cfg["encoder_conf"] = dict(cfg["encoder_conf"], rel_pos_type="legacy")
+    cfg["encoder_conf"] = dict(cfg["encoder_conf"], zero_triu=True)
     with pytest.raises(NotImplementedError):
         ASRTask.build_model(cfg)
+    cfg = dict(g["config"])
+    cfg["encoder_conf"] = dict(cfg["encoder_conf"], pos_enc_layer_type="abs_pos", selfattention_layer_type="selfattn")
+    with pytest.raises(NotImplementedError):
+        ASRTask.build_model(cfg)
+    cfg = dict(g["config"])  # rel_pos_type legacy IS on the fast path (LegacyRelPositionMultiHeadedAttention)
+    cfg["encoder_conf"] = dict(cfg["encoder_conf"], rel_pos_type="legacy", output_size=128, attention_heads=2)
+    assert ASRTask.build_model(cfg).encoder.legacy_relpos
 
 
 def test_lengths_match_oracle():

@@ -32,7 +32,7 @@ def build(g, dtype):
 
 
 @pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "large_10s", "sub6_small_6s",
-                                  "sub8_small_6s"])
+                                  "sub8_small_6s", "legacy_small_5s", "legacy_small_12s"])
 def test_encode_float32_matches_reference(name):
     g = load_golden(name)
     model = build(g, "float32")

@@ -288,6 +288,37 @@ def test_relpos_attention(lib, prec, T, klens):
     assert_close(ctx, ref, 2e-5 if prec == "f32" else 2e-2, f"attention {prec} T={T}")
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("T,klens", [(49, [49, 20]), (64, [64]), (65, [65, 64]), (249, [249, 130, 1]), (300, [300])])
+def test_legacy_relpos_attention(lib, prec, T, klens):
+    """LegacyRelPositionMultiHeadedAttention core (attention.py:318-360) incl. the wrapped upper part of its
+    square rel_shift, against the literal pad-and-reshape on the same (rounded) operands."""
+    dt, tdt = DT[prec]
+    B, h, dk = len(klens), 2, 64
+    d = h * dk
+    qkv = q(rnd(B, T, 3 * d, seed=36), tdt)
+    p = q(rnd(T, d, seed=37), tdt)
+    u, v = rnd(h, dk, seed=38, scale=0.3), rnd(h, dk, seed=39, scale=0.3)
+    qq = qkv[..., :d].reshape(B, T, h, dk)
+    kk = qkv[..., d:2 * d].reshape(B, T, h, dk).transpose(1, 2)
+    vv = qkv[..., 2 * d:].reshape(B, T, h, dk).transpose(1, 2)
+    pp = p.reshape(1, T, h, dk).transpose(1, 2)
+    q_u = q(qq + u, tdt).transpose(1, 2)
+    q_v = q(qq + v, tdt).transpose(1, 2)
+    ac = q_u @ kk.transpose(-2, -1)
+    bd = oc.legacy_rel_shift(q_v @ pp.transpose(-2, -1))
+    scores = (ac + bd) / math.sqrt(dk)
+    valid = ~oc.make_pad_mask(torch.tensor(klens), T)
+    mask = ~valid[:, None, None, :]
+    attn = torch.softmax(scores.masked_fill(mask, torch.finfo(torch.float32).min), -1).masked_fill(mask, 0.0)
+    ref = (attn @ vv).transpose(1, 2).reshape(B, T, d)
+    ctx = torch.zeros(B, T, d, dtype=tdt, device="cuda")
+    L.check(lib.em_legacy_relpos_attention(dt, L.ptr(dev(qkv.to(tdt))), L.ptr(dev(p.to(tdt))), d, L.ptr(dev(u)),
+                                           L.ptr(dev(v)), L.ptr(dev(torch.tensor(klens, dtype=torch.int32))),
+                                           B, T, h, dk, L.ptr(ctx), sptr()))
+    assert_close(ctx, ref, 2e-5 if prec == "f32" else 2e-2, f"legacy attention {prec} T={T}")
+
+
 # --------------------------------------------------------------------------- CTC head
 def test_argmax_logsoftmax_collapse(lib):
     M, V = 333, 5000

@@ -32,7 +32,7 @@ def test_stft_olens_formula():
 
 
 @pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "large_10s", "sub6_small_6s",
-                                  "sub8_small_6s"])
+                                  "sub8_small_6s", "legacy_small_5s", "legacy_small_12s"])
 def test_frontend_and_encoder_match_reference(name):
     g = load_golden(name)
     sd = golden_state_dict(g)
@@ -43,10 +43,19 @@ def test_frontend_and_encoder_match_reference(name):
     assert flens.tolist() == g["feats_lens"].tolist()
     np.testing.assert_allclose(feats.numpy(), g["feats"], atol=2e-4, rtol=0)
     enc, olens = oc.encode(sd, speech, lens, hp["heads"], hp["num_blocks"], hp["n_fft"],
-                           hp["win_length"], hp["hop"])
+                           hp["win_length"], hp["hop"],
+                           rel_pos_type=g["config"]["encoder_conf"].get("rel_pos_type", "latest"))
     assert olens.tolist() == g["enc_olens"].tolist()
     ke = int(g["enc_keep_every"])
     np.testing.assert_allclose(enc[:, ::ke].numpy(), g["enc_out"], atol=5e-4, rtol=0)
+    if "block_outs" in g and name.startswith("legacy"):
+        feats2 = oc.utterance_mvn(feats, flens)
+        _, _, blocks = oc.conformer_encoder(sd, feats2, flens, hp["heads"], hp["num_blocks"], return_blocks=True,
+                                            rel_pos_type="legacy")
+        for i, b in enumerate(blocks):
+            np.testing.assert_allclose(b.numpy(), g["block_outs"][i], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(oc.legacy_pos_emb(blocks[0].size(1), blocks[0].size(2)).numpy(), g["pos_emb"][0],
+                                   atol=1e-6)
     ids = oc.ctc_argmax(sd, enc).numpy()
     # argmax can only differ where the reference's own top-2 margin is within round-off
     diff = ids != g["ctc_ids"]
