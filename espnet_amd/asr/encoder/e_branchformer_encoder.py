@@ -86,9 +86,16 @@ class EBranchformerEncoder(ConformerEncoder):
         torch.nn.Module.__init__(self)
         bad = []
         if input_layer not in ("conv2d", "conv2d6", "conv2d8"): bad.append(f"input_layer={input_layer}")
-        if attention_layer_type != "rel_selfattn": bad.append(f"attention_layer_type={attention_layer_type}")
-        if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
-        if rel_pos_type != "latest": bad.append(f"rel_pos_type={rel_pos_type}")
+        # e_branchformer_encoder.py:226-235 / branchformer_encoder.py:330-339: "legacy" maps to the legacy_ classes
+        if rel_pos_type == "legacy":
+            pos_enc_layer_type = "legacy_rel_pos" if pos_enc_layer_type == "rel_pos" else pos_enc_layer_type
+            attention_layer_type = "legacy_rel_selfattn" if attention_layer_type == "rel_selfattn" else attention_layer_type
+        elif rel_pos_type != "latest":
+            raise ValueError("unknown rel_pos_type: " + rel_pos_type)
+        legacy = pos_enc_layer_type == "legacy_rel_pos" and attention_layer_type == "legacy_rel_selfattn"
+        if not legacy:
+            if attention_layer_type != "rel_selfattn": bad.append(f"attention_layer_type={attention_layer_type}")
+            if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
         if use_linear_after_conv: bad.append("use_linear_after_conv=True")
         if gate_activation != "identity": bad.append(f"gate_activation={gate_activation}")
         if not (use_ffn and macaron_ffn): bad.append("use_ffn/macaron_ffn must both be True")
@@ -111,6 +118,7 @@ class EBranchformerEncoder(ConformerEncoder):
         self.interctc_layer_idx, self.interctc_use_conditioning = [], False
         self.compute_dtype = compute_dtype
         self.input_layer = input_layer
+        self.legacy_relpos, self.max_pos_emb_len = legacy, max_pos_emb_len
         self.embed = _Conv2dSubsampling(input_size, output_size, input_layer)
         self.encoders = torch.nn.ModuleList(
             [_EBranchformerEncoderLayer(output_size, attention_heads, linear_units, cgmlp_linear_units,
@@ -209,9 +217,16 @@ class BranchformerEncoder(EBranchformerEncoder):
         if not (use_attn and use_cgmlp): bad.append("use_attn and use_cgmlp must both be True")
         if merge_method != "concat": bad.append(f"merge_method={merge_method}")
         if input_layer not in ("conv2d", "conv2d6", "conv2d8"): bad.append(f"input_layer={input_layer}")
-        if attention_layer_type != "rel_selfattn": bad.append(f"attention_layer_type={attention_layer_type}")
-        if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
-        if rel_pos_type != "latest": bad.append(f"rel_pos_type={rel_pos_type}")
+        # e_branchformer_encoder.py:226-235 / branchformer_encoder.py:330-339: "legacy" maps to the legacy_ classes
+        if rel_pos_type == "legacy":
+            pos_enc_layer_type = "legacy_rel_pos" if pos_enc_layer_type == "rel_pos" else pos_enc_layer_type
+            attention_layer_type = "legacy_rel_selfattn" if attention_layer_type == "rel_selfattn" else attention_layer_type
+        elif rel_pos_type != "latest":
+            raise ValueError("unknown rel_pos_type: " + rel_pos_type)
+        legacy = pos_enc_layer_type == "legacy_rel_pos" and attention_layer_type == "legacy_rel_selfattn"
+        if not legacy:
+            if attention_layer_type != "rel_selfattn": bad.append(f"attention_layer_type={attention_layer_type}")
+            if pos_enc_layer_type != "rel_pos": bad.append(f"pos_enc_layer_type={pos_enc_layer_type}")
         if use_linear_after_conv: bad.append("use_linear_after_conv=True")
         if gate_activation != "identity": bad.append(f"gate_activation={gate_activation}")
         if zero_triu: bad.append("zero_triu=True")
@@ -228,6 +243,7 @@ class BranchformerEncoder(EBranchformerEncoder):
         self.interctc_layer_idx, self.interctc_use_conditioning = [], False
         self.compute_dtype = compute_dtype
         self.input_layer = input_layer
+        self.legacy_relpos, self.max_pos_emb_len = legacy, 5000  # BranchformerEncoder has no max_pos_emb_len argument (pos_enc_class default)
         self.embed = _Conv2dSubsampling(input_size, output_size, input_layer)
         self.encoders = torch.nn.ModuleList(
             [_EBranchformerEncoderLayer(output_size, attention_heads, None, cgmlp_linear_units, cgmlp_conv_kernel,

@@ -636,6 +636,8 @@ CASES = {
                                                [67, 68], [80000, 37000], with_blocks=True),
     "legacy_small_12s": lambda: run_encode_case("legacy_small_12s", with_legacy(tiny(d=128, heads=2, ff=128)), 50, 45,
                                                 [69], [192000], keep_every=4),
+    "ebf_legacy_4s": lambda: run_encode_case("ebf_legacy_4s", with_legacy(with_input_layer(EBF_SMALL, "conv2d", blocks=2)),
+                                             50, 46, [70, 71], [64000, 29000]),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

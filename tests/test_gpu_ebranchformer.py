@@ -34,7 +34,7 @@ def test_state_dict_keys_equal_reference(gname):
            {k: v for k, v in ref.items() if k.startswith("encoder.")}
 
 
-@pytest.mark.parametrize("name", ["ebf_small_5s", "bf_small_4s", "ebf_sub6_4s"])
+@pytest.mark.parametrize("name", ["ebf_small_5s", "bf_small_4s", "ebf_sub6_4s", "ebf_legacy_4s"])
 def test_encode_float32_matches_reference(name):
     g = load_golden(name)
     model = build(g, "float32")

@@ -266,7 +266,8 @@ def test_online_beam_search_matches_reference_per_call(name):
     assert seen_events, "golden exercises no break / end event"
 
 
-@pytest.mark.parametrize("name", ["ebf_tiny_blocks", "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s", "ebf_sub6_4s"])
+@pytest.mark.parametrize("name", ["ebf_tiny_blocks", "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s", "ebf_sub6_4s",
+                                  "ebf_legacy_4s"])
 def test_ebranchformer_encoder_matches_reference(name):
     """E-Branchformer (attention + cgMLP branches, depthwise-conv merge) — oracle vs
     the reference's `ESPnetASRModel.encode` with encoder=e_branchformer, incl. per-block outputs."""
@@ -276,7 +277,8 @@ def test_ebranchformer_encoder_matches_reference(name):
     sd = golden_state_dict(g)
     hp = hparams(g)
     speech, lens = golden_speech(g)
-    enc, olens = oe.encode(sd, speech, lens, hp["heads"], hp["num_blocks"], hp["n_fft"], hp["win_length"], hp["hop"])
+    enc, olens = oe.encode(sd, speech, lens, hp["heads"], hp["num_blocks"], hp["n_fft"], hp["win_length"], hp["hop"],
+                           rel_pos_type=g["config"]["encoder_conf"].get("rel_pos_type", "latest"))
     assert olens.tolist() == g["enc_olens"].tolist()
     ke = int(g["enc_keep_every"])
     np.testing.assert_allclose(enc[:, ::ke].numpy(), g["enc_out"], atol=5e-4, rtol=0)
