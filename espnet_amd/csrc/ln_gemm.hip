@@ -12,8 +12,6 @@
 // W fragments straight from global memory (each W element is used by one wave only), 4 k-steps of
 // loads in flight.  Every workgroup of a column strip re-normalises the same rows: 64 KB of L2 reads
 // and ~2 us of ALU instead of a 5 us launch.
-#include <cstdlib>
-
 #include "em_common.h"
 
 namespace {
@@ -30,7 +28,7 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ 
                                                       const T* __restrict__ W,
                                                       const float* __restrict__ bias,
                                                       void* __restrict__ Cv, int M, int N, int K,
-                                                      int ldc, int dbg) {
+                                                      int ldc) {
   using MM = Mma<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
   T* sA = (T*)lg_smem;
@@ -52,17 +50,12 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ 
   typename MM::frag fw[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) fw[u] = MM::load(wrow + (size_t)(u < nsteps ? u : nsteps - 1) * MM::K);
-  if (dbg & 1) {  // ablation: no W traffic
-#pragma unroll
-    for (int u = 0; u < U; ++u) fw[u] = MM::load((const T*)lg_smem);
-  }
-
   // ---- prologue: LayerNorm of rows m0 .. m0+31 into LDS.  16 lanes per row (4 rows per wave at a time,
   // 2 passes): float4 loads (256 contiguous bytes per row and instruction), statistics reduced over 16
   // lanes only (xor 1, 2, 4, 8: DPP row operations, no LDS crossbar), 4 operand-dtype values per LDS
   // store.  The first version used one row per wave with 64-lane reductions and cost 6.5 us of the
-  // kernel's 11.7 (ablation EM_LNG_DBG, tools/ln_gemm_bench.py).
-  if (!(dbg & 2)) {
+  // kernel's 11.7 (phase ablation during development; tools/ln_gemm_bench.py times the result).
+  {
     const int grp = lane >> 4, li = lane & 15;
     float4 v[2][NV];
 #pragma unroll
@@ -116,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ 
   const T* a0 = sA + (size_t)lr * LDA + lg * MM::EPL;
   const T* a1 = a0 + (size_t)16 * LDA;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; s0 < ((dbg & 4) ? 0 : nsteps); s0 += U) {
+  for (int s0 = 0; s0 < nsteps; s0 += U) {
     if (s0 > 0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) fw[u] = MM::load(wrow + (size_t)(s0 + u < nsteps ? s0 + u : nsteps - 1) * MM::K);
@@ -160,10 +153,9 @@ int launch_ln_gemm_nv(const float* x, const float* g, const float* b, float eps,
       return EM_ERR_LAUNCH;
     attr_done = true;
   }
-  static const int dbg = getenv("EM_LNG_DBG") ? atoi(getenv("EM_LNG_DBG")) : 0;  // ablation bits (tools/)
   dim3 grid(em_cdiv(N, LG_BN), em_cdiv(M, LG_BM));
   hipLaunchKernelGGL((ln_gemm_kernel<T, EPI, NV>), grid, dim3(256), lds, s, x, g, b, eps, (const T*)W, bias, C,
-                     M, N, K, ldc, dbg);
+                     M, N, K, ldc);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
