@@ -82,6 +82,7 @@ class BatchBeamSearchOnline(BatchBeamSearch):
         return [k for k in ("decoder", "ctc", "length_bonus", "lm") if k in self.scorers]
 
     def _setup(self, x: torch.Tensor):
+        L.require_gpu(x, "x")  # no CPU path: the scores come from the device
         dev, d = x.device, x.size(-1)
         dec, ctc_sc, lm = self.scorers.get("decoder"), self.scorers.get("ctc"), self.scorers.get("lm")
         em_dtype = dec.em_dtype if dec is not None else (ctc_sc.ctc.em_dtype if ctc_sc is not None else lm.em_dtype)
@@ -163,6 +164,18 @@ class BatchBeamSearchOnline(BatchBeamSearch):
             scores.append({kk: r[col[kk]] for kk in keys})
         return _Rows(slots, yseq, score, scores)
 
+    def _commit(self):
+        """Device side of `prev_hyps = running_hyps; running_hyps = post_process(best)` (:459-462)."""
+        D = self._dev
+        L.check(L.load().em_search_online_commit(D["em_dtype"], C.byref(self._p), C.byref(D["bs"]), self.process_idx,
+                                                 L.current_stream_ptr()), "em_search_online_commit")
+
+    def _rewind(self):
+        """Device side of `running_hyps = prev_hyps` (:484-487)."""
+        D = self._dev
+        L.check(L.load().em_search_online_rewind(C.byref(self._p), C.byref(D["bs"]), L.current_stream_ptr()),
+                "em_search_online_rewind")
+
     def _post_process(self, i, maxlen, minlen, best: _Rows, ended: List[Hypothesis]) -> _Rows:
         """BatchBeamSearch.post_process (batch_beam_search.py:359-423), in place on `best`."""
         keys = self._keys()
@@ -183,7 +196,6 @@ class BatchBeamSearchOnline(BatchBeamSearch):
     # ------------------------------------------------------------------ reference control flow
     def process_one_block(self, h_len, is_final, maxlen, minlen, maxlenratio):
         """:394-493."""
-        D, lib = self._dev, L.load()
         self._see(h_len)
         local_ended_hyps = None
         keys = self._keys()
@@ -217,9 +229,7 @@ class BatchBeamSearchOnline(BatchBeamSearch):
             self.prev_hyps = self.running
             self.running = self._post_process(self.process_idx, maxlen, minlen, best, self.ended_hyps)
             if not forced:  # at maxlen - 1 every row ended: nothing runs on
-                L.check(lib.em_search_online_commit(D["em_dtype"], C.byref(self._p), C.byref(D["bs"]),
-                                                    self.process_idx, L.current_stream_ptr()),
-                        "em_search_online_commit")
+                self._commit()
             if is_final:
                 self.ended_hyps.extend(local_ended_hyps)
             if len(self.running) == 0:
@@ -230,8 +240,7 @@ class BatchBeamSearchOnline(BatchBeamSearch):
             return self.assemble_hyps(self.ended_hyps)
         rets = self.assemble_hyps((local_ended_hyps or []) + self.ended_hyps)
         if self.process_idx > 1 and self.prev_hyps is not None and len(self.prev_hyps) > 0:
-            L.check(lib.em_search_online_rewind(C.byref(self._p), C.byref(D["bs"]), L.current_stream_ptr()),
-                    "em_search_online_rewind")
+            self._rewind()
             self.running = self.prev_hyps
             self.process_idx -= 1
             self.prev_hyps = None
@@ -247,7 +256,6 @@ class BatchBeamSearchOnline(BatchBeamSearch):
     def forward(self, x: torch.Tensor, maxlenratio: float = 0.0, minlenratio: float = 0.0,
                 is_final: bool = True) -> List[Hypothesis]:
         """x (T_new, d): the encoder frames of this chunk ON THE GPU (may be empty).  :155-376."""
-        L.require_gpu(x, "x")
         if self._dev is None:
             self._setup(x)
         n_new = x.size(0)
