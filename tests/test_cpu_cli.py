@@ -201,3 +201,72 @@ def test_cli_refuses_cpu_and_multi_gpu(tmp_path):
         main(base + ["--ngpu", "0"])
     with pytest.raises(NotImplementedError, match="single GPU"):
         main(base + ["--ngpu", "2"])
+
+
+def test_inference_loop_orders_outputs_and_handles_short_utterances(tmp_path, monkeypatch):
+    """The decode loop of `inference()` on the CPU with a stand-in Speech2Text (the device work is covered by the
+    GPU suite): results written in INPUT order whatever the length bucketing did, one batch kept in flight,
+    too-short utterances replaced by the reference's placeholder row (asr_inference.py:851-858) without taking
+    their batch down, n-best files, RTF summary."""
+    import argparse
+
+    import torch
+
+    from espnet_amd.bin import asr_inference as ai
+    from espnet_amd.lib import TooShortUttError
+    from espnet_amd.nets.beam_search import Hypothesis
+
+    lens = [5000, 900, 16000, 300, 7000, 12000, 450, 8000, 9500]
+    lines = []
+    for i, n in enumerate(lens):
+        write_wav_pcm16(tmp_path / f"u{i}.wav", np.full(n, (i + 1) / 64.0, dtype=np.float32), 16000)
+        lines.append(f"utt{i} {tmp_path / f'u{i}.wav'}")
+    (tmp_path / "wav.scp").write_text("\n".join(lines) + "\n")
+    calls = []
+
+    class FakeS2T:
+        asr_train_args = argparse.Namespace(frontend_conf=dict(fs=16000), use_preprocessor=True, preprocessor_conf={})
+
+        def _decode(self, speech, lengths):
+            short = [i for i, n in enumerate(lengths) if n < 1000]
+            if short:
+                raise TooShortUttError("has 3 frames and is too short for subsampling", 3, 7, indices=short)
+            out = []
+            for row, n in zip(speech, lengths):
+                uid = int(round(float(row[0]) * 64.0)) - 1  # the constant sample value encodes the utterance
+                assert bool((row[:n] == row[0]).all()) and bool((row[n:] == 0).all())  # zero padded to the batch max
+                ids = [uid + 3, n % 97 + 3]
+                hyps = [Hypothesis(yseq=torch.tensor([49] + ids + [49]), score=torch.tensor(-float(k + uid)))
+                        for k in range(2)]
+                out.append([(f"t{ids[0]} t{ids[1]}", [f"t{v}" for v in ids], ids, h) for h in hyps])
+            return out
+
+        def batch_decode(self, speech, lengths):
+            calls.append(("sync", list(lengths)))
+            return self._decode(speech, lengths)
+
+        def batch_decode_async(self, speech, lengths):
+            calls.append(("async", list(lengths)))
+            res = self._decode(speech, lengths)
+            return ai._Done(res)
+
+    monkeypatch.setattr(ai.Speech2Text, "from_pretrained", staticmethod(lambda **kw: FakeS2T()))
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)
+    summary = ai.inference(output_dir=str(tmp_path / "out"), batch_size=4, bucket_window=2, num_workers=2, nbest=2,
+                           ngpu=1, data_path_and_name_and_type=[(str(tmp_path / "wav.scp"), "speech", "sound")],
+                           asr_train_config=None, asr_model_file=None, log_level="ERROR")
+    assert summary["utterances"] == len(lens) and abs(summary["audio_seconds"] - sum(lens) / 16000) < 1e-9
+    tok = (tmp_path / "out/1best_recog/token_int").read_text().splitlines()
+    assert [ln.split()[0] for ln in tok] == [f"utt{i}" for i in range(len(lens))]  # input order
+    for i, n in enumerate(lens):
+        want = "2" if n < 1000 else f"{i + 3} {n % 97 + 3}"
+        assert tok[i] == f"utt{i} {want}", tok[i]
+    for name in ("token", "token_int", "score", "text"):
+        for nb in (1, 2):
+            assert len((tmp_path / f"out/{nb}best_recog/{name}").read_text().splitlines()) == len(lens)
+    assert (tmp_path / "out/1best_recog/text").read_text().splitlines()[1] == "utt1  "  # placeholder text " "
+    # batches were cut from length-sorted windows (descending), short ones retried as a smaller synchronous batch
+    asyncs = [c[1] for c in calls if c[0] == "async"]
+    assert all(b == sorted(b, reverse=True) for b in asyncs) and max(len(b) for b in asyncs) <= 4
+    assert any(c[0] == "sync" for c in calls)
