@@ -87,3 +87,57 @@ def test_online_host_control_flow_matches_reference_per_call(name):
             assert set(mine.scores) == set(ref["scores"])
     bs.reset()
     assert bs.running is None and bs.n_enc == 0 and bs.ended_hyps == []
+
+
+@pytest.mark.parametrize("name", ["stream_frontend_gmvn", "stream_frontend_umvn"])
+def test_streaming_apply_frontend_host_logic_on_cpu(name):
+    """Speech2TextStreaming.apply_frontend's HOST side (waveform overlap buffer, residual samples, trimming of the
+    frames that see artificial chunk edges, asr_inference_streaming.py:205-293) with the feature extraction
+    stubbed by the CPU oracle: per-call frame counts and values equal the reference's.  (The same test with the
+    HIP frontend is tests/test_gpu_streaming.py.)"""
+    import types
+
+    import numpy as np
+
+    from espnet_amd.bin.asr_inference_streaming import Speech2TextStreaming
+    from espnet_amd.nets_utils import stft_frame_lengths
+    from oracle import conformer as oc
+    from oracle.weights import synth_waveform
+    from tests.helpers import GOLDEN
+
+    z = np.load(GOLDEN / f"{name}.npz")
+    fc = json.loads(str(z["frontend_conf"]))
+    mel = torch.from_numpy(z["melmat"])
+
+    class FE:
+        def feature_lengths(self, ns):
+            return stft_frame_lengths(ns, fc["n_fft"], fc["hop_length"])
+
+        def forward_device(self, wav, flens_dev, wlens_dev=None):
+            f, _ = oc.frontend_feats(wav, torch.tensor([wav.size(1)]), mel, fc["n_fft"], fc["win_length"],
+                                     fc["hop_length"])
+            return f
+
+    class Norm:
+        def forward_device(self, feats, flens_dev):
+            if bool(z["use_global_mvn"]):
+                return oc.global_mvn(feats, flens_dev.long(), torch.from_numpy(z["gmvn_mean"]),
+                                     torch.from_numpy(z["gmvn_std"]))
+            return oc.utterance_mvn(feats, flens_dev.long())
+
+    s2t = object.__new__(Speech2TextStreaming)
+    s2t.asr_model = types.SimpleNamespace(frontend=FE(), normalize=Norm())
+    s2t.device, s2t.n_fft, s2t.hop_length, s2t.win_length = "cpu", fc["n_fft"], fc["hop_length"], fc["win_length"]
+    n, cs = int(z["n_samples"]), int(z["chunk_samples"])
+    wav = synth_waveform(int(z["utt_id"]), n)
+    feats, lens, state, pos = [], [], None, 0
+    while pos < n:
+        nxt = min(n, pos + cs)
+        f, fl, state = s2t.apply_frontend(wav[pos:nxt], state, is_final=(nxt == n))
+        lens.append(-1 if f is None else int(f.size(1)))
+        if f is not None:
+            assert int(fl[0]) == f.size(1)
+            feats.append(f[0])
+        pos = nxt
+    assert lens == z["feat_lens"].tolist()
+    np.testing.assert_allclose(torch.cat(feats, 0).numpy(), z["feats"], atol=3e-4, rtol=0)
