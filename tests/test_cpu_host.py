@@ -141,3 +141,43 @@ def test_subsampled_lengths_match_mask_slicing(layer):
         assert conv2d_subsampled_lengths(lens, tmax, layer) == want
         # an unpadded utterance keeps exactly the conv stack's output frames
         assert conv2d_subsampled_lengths([tmax], tmax, layer)[0] == conv_out_size(tmax, layer)
+
+
+def test_collect_backtraces_token_tree_on_host():
+    """BatchBeamSearch._collect: the ended list (node position / slot, forced-<eos> flag, scores) is turned
+    into Hypothesis objects by walking `parent` through the token tree — host-only logic, checked on a hand
+    built tree: two utterances, shared prefixes, a forced <eos>, best-first ordering."""
+    from espnet_amd.nets.batch_beam_search import BatchBeamSearch
+    from espnet_amd.nets.scorers.ctc import CTCPrefixScorer
+
+    W, B, Lmax, cap, EOS = 2, 2, 6, 4, 9
+    n = B * W
+    bs = BatchBeamSearch(beam_size=W, weights=dict(ctc=1.0), scorers=dict(ctc=CTCPrefixScorer(ctc=None, eos=EOS)),
+                         sos=EOS, eos=EOS, vocab_size=10, token_list=[str(i) for i in range(10)])
+    tok = torch.full((Lmax, n), -7, dtype=torch.int32)
+    par = torch.full((Lmax, n), -1, dtype=torch.int32)
+    tok[0] = EOS  # <sos> == <eos> id
+    # utterance 0 (rows 0,1): sos-3-4-eos (ends at pos 3, slot 0) and sos-3-5 forced eos at pos 2, slot 1
+    tok[1, 0], par[1, 0] = 3, 0
+    tok[1, 1], par[1, 1] = 3, 0
+    tok[2, 0], par[2, 0] = 4, 0
+    tok[2, 1], par[2, 1] = 5, 1
+    tok[3, 0], par[3, 0] = EOS, 0
+    # utterance 1 (rows 2,3): sos-6-eos at pos 2, slot 3 (parent row 2)
+    tok[1, 2], par[1, 2] = 6, 2
+    tok[2, 3], par[2, 3] = EOS, 2
+    z = lambda *s: torch.zeros(*s)
+    bufs = dict(tok=tok, parent=par, end_count=torch.tensor([2, 1], dtype=torch.int32),
+                end_pos=torch.tensor([[2, 3, 0, 0], [2, 0, 0, 0]], dtype=torch.int32),
+                end_slot=torch.tensor([[1, 0, 0, 0], [3, 0, 0, 0]], dtype=torch.int32),
+                end_forced=torch.tensor([[1, 0, 0, 0], [0, 0, 0, 0]], dtype=torch.int32),
+                end_score=torch.tensor([[-5.0, -2.0, 0, 0], [-1.5, 0, 0, 0]]), end_sdec=z(B, cap),
+                end_sctc=torch.tensor([[-5.0, -2.0, 0, 0], [-1.5, 0, 0, 0]]), end_slen=z(B, cap))
+    out = bs._collect(bufs, B, W, [3, 3])
+    assert [h.yseq.tolist() for h in out[0]] == [[EOS, 3, 4, EOS], [EOS, 3, 5, EOS]]  # best (-2.0) first
+    assert [float(h.score) for h in out[0]] == [-2.0, -5.0]
+    assert float(out[0][0].scores["ctc"]) == -2.0 and set(out[0][0].scores) == {"ctc"}
+    assert [h.yseq.tolist() for h in out[1]] == [[EOS, 6, EOS]]
+    bs.normalize_length = True  # beam_search.py:453-459: score / (len - 1)
+    out = bs._collect(bufs, B, W, [3, 3])
+    assert [float(h.score) for h in out[0]] == [-2.0, -5.0]  # -2/3 > -5/3
