@@ -637,6 +637,9 @@ inline int ln_proj(int dtype, int epi, const float* x, const float* g, const flo
 }
 
 // ---- SequentialRNNLM (LSTM) step pieces (espnet2/lm/seq_rnn_lm.py:140-177 batch_score) -------
+// States of the rows of step i live in ring slot i % 3: a step reads its parents' states from slot (i-1) % 3.
+// Three slots, not two: the streaming search computes step i, may then rewind to step i-1
+// (batch_beam_search_online.py:484-487) and recompute it, which needs the states of step i-2 intact.
 // hin[l][r] = h of row r's PARENT after the previous step (zero state at step 0, :155-156)
 template <typename T>
 __global__ void rnn_gather_kernel(Ctx c, int i_host, int layers, int ld) {
@@ -646,7 +649,7 @@ __global__ void rnn_gather_kernel(Ctx c, int i_host, int layers, int ld) {
   const int r = blockIdx.x, l = blockIdx.y;
   int p = i > 0 ? c.b.parent[(size_t)i * n + r] : r;
   p = (p < 0 || p >= n) ? r : p;  // rows that never lived carry no parent
-  const T* src = (const T*)c.b.rnn_hs + (((size_t)((i + 1) & 1) * layers + l) * n + p) * ld;
+  const T* src = (const T*)c.b.rnn_hs + (((size_t)((i + 2) % 3) * layers + l) * n + p) * ld;
   T* dst = (T*)c.b.rnn_hin + ((size_t)l * n + r) * ld;
   for (int ch = threadIdx.x; ch < ld; ch += blockDim.x) dst[ch] = i > 0 ? src[ch] : from_f32<T>(0.f);
 }
@@ -661,9 +664,9 @@ __global__ void lstm_cell_kernel(Ctx c, int i_host, int layers, int l, int nhid,
   int p = i > 0 ? c.b.parent[(size_t)i * n + r] : r;
   p = (p < 0 || p >= n) ? r : p;
   const float* g = c.b.rnn_gates + (size_t)r * 4 * nhid;
-  const float* cprev = c.b.rnn_cs + (((size_t)((i + 1) & 1) * layers + l) * n + p) * ld;
-  float* cnew = c.b.rnn_cs + (((size_t)(i & 1) * layers + l) * n + r) * ld;
-  T* hnew = (T*)c.b.rnn_hs + (((size_t)(i & 1) * layers + l) * n + r) * ld;
+  const float* cprev = c.b.rnn_cs + (((size_t)((i + 2) % 3) * layers + l) * n + p) * ld;
+  float* cnew = c.b.rnn_cs + (((size_t)(i % 3) * layers + l) * n + r) * ld;
+  T* hnew = (T*)c.b.rnn_hs + (((size_t)(i % 3) * layers + l) * n + r) * ld;
   T* hout = (T*)c.b.rnn_hin + ((size_t)l * n + r) * ld;  // A operand of the next GEMM (fixed address)
   for (int ch = threadIdx.x; ch < nhid; ch += blockDim.x) {
     const float gi = 1.f / (1.f + expf(-g[ch])), gf = 1.f / (1.f + expf(-g[nhid + ch]));

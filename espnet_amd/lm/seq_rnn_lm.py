@@ -56,7 +56,7 @@ class SequentialRNNLM(torch.nn.Module):
 
     def search_buffers(self, n, V, Lmax, B, cap):
         d, eu = self._pad(self.nhid), self._pad(self.unit)
-        return dict(lm_e=(n, eu), lm_logp=(n, V), rnn_hs=(2, self.nlayers, n, d), rnn_cs=(2, self.nlayers, n, d),
+        return dict(lm_e=(n, eu), lm_logp=(n, V), rnn_hs=(3, self.nlayers, n, d), rnn_cs=(3, self.nlayers, n, d),
                     rnn_hin=(self.nlayers, n, d), rnn_gates=(n, 4 * self.nhid), run_slm=(n,), end_slm=(B, cap))
 
     def pack(self, device, pe_len: int = 0):

@@ -521,9 +521,10 @@ typedef struct EmSearchBuffers {
   void *lm_k, *lm_v;                        /* act [lm layers][Lmax][n][d] */
   float *run_slm, *end_slm;                 /* [n], [B][end_cap] accumulated LM score */
   /* LSTM language model (kind == EM_LM_LSTM; NULL otherwise).  States of the rows of step i live in
-   * parity i & 1; a row reads its parent's state (token-tree `parent`) of the other parity.          */
-  void* rnn_hs;                             /* act [2][layers][n][d] hidden states (pad columns zero) */
-  float* rnn_cs;                            /* f32 [2][layers][n][d] cell states */
+   * ring slot i % 3; a row reads its parent's state (token-tree `parent`) from slot (i-1) % 3; the third
+   * slot keeps step i-2 alive for the streaming search's one-step rewind.                             */
+  void* rnn_hs;                             /* act [3][layers][n][d] hidden states (pad columns zero) */
+  float* rnn_cs;                            /* f32 [3][layers][n][d] cell states */
   void* rnn_hin;                            /* act [layers][n][d] parent-gathered h, then this step's h */
   float* rnn_gates;                         /* f32 [n][4*nhid] */
   /* streaming search (em_search_online_*; NULL offline) */

@@ -383,7 +383,8 @@ def run_streaming_case(name, enc_conf, wseed, utt_id, n_samples, chunk_frames, k
 
 
 def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples, beam, ctc_weight, nbest,
-                           tweaks=None, disable_repetition_detection=False, penalty=0.0):
+                           tweaks=None, disable_repetition_detection=False, penalty=0.0, lm_conf=None,
+                           lm_name="transformer", lm_weight=0.0):
     """Speech2TextStreaming end to end (espnet2/bin/asr_inference_streaming.py:293-336): waveform chunks
     -> apply_frontend -> ContextualBlockConformerEncoder.forward_infer -> BatchBeamSearchOnline.forward
     (espnet2/legacy/nets/batch_beam_search_online.py:155-534, block 40 / hop 16 / look-ahead 16).
@@ -408,12 +409,28 @@ def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples,
 
     with tempfile.TemporaryDirectory() as td:
         _, cfg_text = build_reference(conf, vocab, td, beam_size=1, ctc_weight=1.0)
+        lm_cfg = None
+        if lm_conf is not None:  # asr_inference_streaming.py:97-102 (scorers["lm"] = lm.lm)
+            from espnet2.tasks.lm import LMTask
+
+            (Path(td) / "lm.yaml").write_text(yaml.safe_dump(dict(lm=lm_name, lm_conf=lm_conf)))
+            LMTask.main(cmd=["--dry_run", "true", "--output_dir", str(Path(td) / "lm"), "--token_list",
+                             str(Path(td) / "tokens.txt"), "--token_type", "word", "--config", str(Path(td) / "lm.yaml")])
+            lm_cfg = str(Path(td) / "lm" / "config.yaml")
         s2t = Speech2TextStreaming(asr_train_config=str(Path(td) / "asr" / "config.yaml"), asr_model_file=None,
+                                   lm_train_config=lm_cfg, lm_file=None,
                                    device="cpu", dtype="float32", beam_size=beam, ctc_weight=ctc_weight,
-                                   lm_weight=0.0, penalty=penalty, nbest=nbest,
+                                   lm_weight=lm_weight, penalty=penalty, nbest=nbest,
                                    disable_repetition_detection=disable_repetition_detection)
     model = s2t.asr_model
     shapes = load_recipe(model, wseed, tweaks)
+    lm_shapes = {}
+    if lm_conf is not None:
+        lm = s2t.beam_search.scorers["lm"]
+        lm_shapes = {k: tuple(v.shape) for k, v in lm.state_dict().items()}
+        lm_sd = recipe_state_dict({"lm." + k: v for k, v in lm_shapes.items()}, wseed, skip=())
+        lm.load_state_dict({k[3:]: v for k, v in lm_sd.items()}, strict=True)
+        lm.eval()
     h = Grab()
     logging.getLogger().addHandler(h)
     logging.getLogger().setLevel(logging.INFO)
@@ -447,7 +464,9 @@ def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples,
         disable_repetition_detection=np.array(disable_repetition_detection),
         state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
         melmat=model.frontend.logmel.melmat.numpy(), enc_all=enc_all.numpy(),
-        enc_lens=np.array([int(c.size(0)) for c in enc_chunks]), calls=np.array(json.dumps(calls)))
+        enc_lens=np.array([int(c.size(0)) for c in enc_chunks]), calls=np.array(json.dumps(calls)),
+        lm_conf=np.array(json.dumps(lm_conf)), lm_name=np.array(lm_name), lm_weight=np.array(lm_weight),
+        lm_state_shapes=np.array(json.dumps({k: list(v) for k, v in lm_shapes.items()})))
     print(f"[{name}] done in {time.time()-t0:.1f}s enc chunks {[int(c.size(0)) for c in enc_chunks]}")
     for k, c in enumerate(calls):
         print(f"   call {k}: searched={c['searched']} events={c['events']} n_hyps={len(c['hyps'])} "
@@ -638,6 +657,14 @@ CASES = {
                                                 [69], [192000], keep_every=4),
     "ebf_legacy_4s": lambda: run_encode_case("ebf_legacy_4s", with_legacy(with_input_layer(EBF_SMALL, "conv2d", blocks=2)),
                                              50, 46, [70, 71], [64000, 29000]),
+    # streaming decode with an LM scorer (asr_inference_streaming.py:97-102): TransformerLM and LSTM LM
+    "stream_search_lm": lambda: run_stream_search_case(
+        "stream_search_lm", 50, 24, 44, 64000, 10240, 4, 0.3, 3, tweaks=[["decoder.output_layer.bias", 49, 1.5]],
+        disable_repetition_detection=True,
+        lm_conf=dict(pos_enc=None, embed_unit=64, att_unit=64, head=1, unit=128, layer=2), lm_weight=0.5),
+    "stream_search_rnnlm": lambda: run_stream_search_case(
+        "stream_search_rnnlm", 50, 25, 45, 56000, 10240, 3, 0.4, 3, tweaks=[["decoder.output_layer.bias", 49, 2.0]],
+        lm_conf=dict(unit=64, nlayers=1), lm_name="seq_rnn", lm_weight=0.6),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from tests.helpers import golden_state_dict, load_golden  # noqa: E402
 from tests.test_gpu_search import _sub  # noqa: E402
 
-CASES = ["stream_search_a", "stream_search_b", "stream_search_c"]
+CASES = ["stream_search_a", "stream_search_b", "stream_search_c", "stream_search_lm", "stream_search_rnnlm"]
 
 
 def build_online(g, sd, dtype="float32"):
@@ -37,6 +37,11 @@ def build_online(g, sd, dtype="float32"):
     # asr_inference_streaming.py:88-136
     scorers = dict(decoder=dec, ctc=CTCPrefixScorer(ctc=ctc, eos=V - 1), length_bonus=LengthBonus(V))
     weights = dict(decoder=1.0 - cw, ctc=cw, lm=0.0, length_bonus=float(g["penalty"]))
+    if "lm_conf" in g and json.loads(str(g["lm_conf"])) is not None:  # asr_inference_streaming.py:97-102
+        from tests.test_gpu_search import build_lm
+
+        scorers["lm"] = build_lm(g, dtype)
+        weights["lm"] = float(g["lm_weight"])
     return BatchBeamSearchOnline(beam_size=int(g["beam"]), weights=weights, scorers=scorers, sos=V - 1, eos=V - 1,
                                  vocab_size=V, token_list=token_list(V),
                                  pre_beam_score_key=None if cw == 1.0 else "full",

@@ -228,7 +228,8 @@ def test_beam_search_with_lm_scorer_matches_reference(name):
             assert abs(res[k]["scores"][kk] - float(g["scores"][k, j])) < 1e-3
 
 
-@pytest.mark.parametrize("name", ["stream_search_a", "stream_search_b", "stream_search_c"])
+@pytest.mark.parametrize("name", ["stream_search_a", "stream_search_b", "stream_search_c", "stream_search_lm",
+                                  "stream_search_rnnlm"])
 def test_online_beam_search_matches_reference_per_call(name):
     """BatchBeamSearchOnline (block-synchronous search with CTC extend_prob /
     extend_state, repetition / local-<eos> breaks, rewind, end detection) — the oracle replays the
@@ -242,9 +243,16 @@ def test_online_beam_search_matches_reference_per_call(name):
     sd = golden_state_dict(g)
     V = int(g["vocab"])
     dc = g["config"]["decoder_conf"]
+    lm_kw = {}
+    if "lm_conf" in g and json.loads(str(g["lm_conf"])) is not None:
+        from oracle.weights import recipe_state_dict
+
+        shapes = {"lm." + k: tuple(v) for k, v in json.loads(str(g["lm_state_shapes"])).items()}
+        sd.update(recipe_state_dict(shapes, int(g["wseed"]), skip=()))
+        lm_kw = dict(lm_weight=float(g["lm_weight"]), lm_conf=json.loads(str(g["lm_conf"])))
     orc = OnlineBeamSearchOracle(sd, dc["attention_heads"], dc["num_blocks"], int(g["beam"]), float(g["ctc_weight"]),
                                  sos=V - 1, eos=V - 1, penalty=float(g["penalty"]),
-                                 disable_repetition_detection=bool(g["disable_repetition_detection"]))
+                                 disable_repetition_detection=bool(g["disable_repetition_detection"]), **lm_kw)
     enc_all = torch.from_numpy(g["enc_all"])
     calls = json.loads(str(g["calls"]))
     lens = g["enc_lens"].tolist()
