@@ -432,3 +432,25 @@ def test_ln_gemm_small_m(lib, prec, M, N, K):
         L.check(lib.em_ln_gemm(dt, epi, L.ptr(xd), L.ptr(gd), L.ptr(bd), 1e-12, L.ptr(wd), L.ptr(biasd), L.ptr(out),
                                M, N, K, N, sptr()), "em_ln_gemm")
         assert_close(out, r, tol, f"ln_gemm {prec} epi {epi}")
+
+
+@pytest.mark.parametrize("epi", ["STORE", "SWISH", "RELU", "GELU", "RESID_F32", "SCALE_F32", "STORE_F32"])
+def test_gemm_large_m_bf16_128x128_tile(lib, epi):
+    """Shapes big enough for the 128x128 tile (>= 384 workgroups; the other GEMM tests run the 64-row tile):
+    every LDS-transposed epilogue against torch fp32 on the rounded operands, incl. ragged M / N edges."""
+    M, N, K = 4001, 1160, 512
+    a = q(rnd(M, K, seed=41), torch.bfloat16)
+    w = q(rnd(N, K, seed=42, scale=K ** -0.5), torch.bfloat16)
+    bias = 0.1 * rnd(N, seed=43)
+    acc = a @ w.t() + bias
+    c0 = rnd(M, N, seed=44)
+    code = getattr(L, "EM_EPI_" + epi)
+    f32out = epi in ("RESID_F32", "SCALE_F32", "STORE_F32")
+    ref = {"STORE": acc, "SWISH": oc.swish(acc), "RELU": torch.relu(acc), "GELU": F.gelu(acc),
+           "RESID_F32": c0 + 0.5 * acc, "SCALE_F32": 0.5 * acc, "STORE_F32": acc}[epi]
+    out = dev(c0.clone()) if f32out else torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ad, wd, bd = dev(a.to(torch.bfloat16)), dev(w.to(torch.bfloat16)), dev(bias)
+    args = L.EmGemmArgs(A=ad.data_ptr(), W=wd.data_ptr(), C=out.data_ptr(), bias=bd.data_ptr(), M=M, N=N, K=K, lda=K,
+                        ldc=N, scale=0.5 if epi in ("RESID_F32", "SCALE_F32") else 1.0)
+    L.check(lib.em_gemm(L.EM_BF16, code, L.EM_A_PLAIN, args, sptr()), "em_gemm large")
+    assert_close(out, ref, 2e-4 if f32out else 2e-2, f"large-M gemm {epi}")
