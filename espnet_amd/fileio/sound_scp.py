@@ -62,7 +62,8 @@ def read_wav(path: Union[Path, str], dtype="float64", always_2d: bool = False) -
         if bits == 8:
             x = (np.frombuffer(data, dtype=np.uint8, count=n).astype(ft) - ft(128.0)) / ft(128.0)
         elif bits == 16:
-            x = np.frombuffer(data, dtype="<i2", count=n).astype(ft) * ft(1.0 / 32768.0)
+            # one pass: int16 samples are converted and scaled by the ufunc itself (exact: a power of two)
+            x = np.multiply(np.frombuffer(data, dtype="<i2", count=n), ft(1.0 / 32768.0), dtype=ft)
         elif bits == 24:
             b = np.frombuffer(data, dtype=np.uint8, count=n * 3).reshape(-1, 3).astype(np.int32)
             v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
