@@ -47,10 +47,10 @@ class _CGMLP(torch.nn.Module):
 
 class _EBranchformerEncoderLayer(torch.nn.Module):
     """Parameters of EBranchformerEncoderLayer (e_branchformer_encoder.py:68-108); with ff = None and
-    merge_kernel = None those of BranchformerEncoderLayer, merge_method="concat"
-    (branchformer_encoder.py:65-136)."""
+    merge_kernel = None those of BranchformerEncoderLayer (branchformer_encoder.py:65-136), whose
+    merge_method decides the merge parameters (:99-133)."""
 
-    def __init__(self, size, heads, ff, cg, cg_kernel, merge_kernel):
+    def __init__(self, size, heads, ff, cg, cg_kernel, merge_kernel, merge_method="concat"):
         super().__init__()
         self.attn = _RelPositionMultiHeadedAttention(heads, size)
         self.cgmlp = _CGMLP(size, cg, cg_kernel)
@@ -65,10 +65,16 @@ class _EBranchformerEncoderLayer(torch.nn.Module):
         if merge_kernel is not None:
             self.depthwise_conv_fusion = torch.nn.Conv1d(2 * size, 2 * size, merge_kernel, 1,
                                                          (merge_kernel - 1) // 2, groups=2 * size, bias=True)
-        self.merge_proj = torch.nn.Linear(2 * size, size)
+        if merge_method == "learned_ave":
+            self.pooling_proj1 = torch.nn.Linear(size, 1)
+            self.pooling_proj2 = torch.nn.Linear(size, 1)
+            self.weight_proj1 = torch.nn.Linear(size, 1)
+            self.weight_proj2 = torch.nn.Linear(size, 1)
+        self.merge_proj = torch.nn.Linear(2 * size if merge_method == "concat" else size, size)
 
 
 class EBranchformerEncoder(ConformerEncoder):
+    merge_method, cgmlp_weight = "concat", None
     _WS_FN, _ENC_FN = "em_ebranchformer_workspace_bytes", "em_ebranchformer_encode"
 
     def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4,
@@ -152,6 +158,7 @@ class EBranchformerEncoder(ConformerEncoder):
         has_ffn, has_mconv = ff is not None, self.merge_conv_kernel is not None
         w.ff = ff or 0
         w.use_ffn, w.merge_conv = int(has_ffn), int(has_mconv)
+        w.merge_method = L.EM_MERGE_LEARNED_AVE if self.merge_method == "learned_ave" else L.EM_MERGE_CONCAT
         t = dict(conv1_w=F(e.conv[0].weight.reshape(d, 9)), conv1_b=F(e.conv[0].bias),
                  embed_w=A(e.out.weight.reshape(d, d, F2).permute(0, 2, 1).reshape(d, F2 * d)),
                  embed_b=F(e.out.bias),
@@ -176,7 +183,18 @@ class EBranchformerEncoder(ConformerEncoder):
                 csgu_conv_w=F(cm.csgu.conv.weight.reshape(cg // 2, -1).t()),  # [k][cg/2] tap-major
                 csgu_conv_b=F(cm.csgu.conv.bias),
                 proj2_w=A(cm.channel_proj2.weight), proj2_b=F(cm.channel_proj2.bias),
-                merge_w=A(l.merge_proj.weight), merge_b=F(l.merge_proj.bias))
+                merge_b=F(l.merge_proj.bias))
+            mw = l.merge_proj.weight.detach().to(torch.float32)
+            if self.merge_method == "fixed_ave":
+                # merge_proj((1 - c) x1 + c x2) == [(1 - c) W | c W] [x1 | x2]: the concat launch sequence
+                c = float(self.cgmlp_weight[i])
+                mw = torch.cat([(1.0 - c) * mw, c * mw], dim=1)
+            elif self.merge_method == "learned_ave":
+                lt.update(pool_w=F(torch.cat([l.pooling_proj1.weight, l.pooling_proj2.weight], 0)),
+                          pool_b=F(torch.cat([l.pooling_proj1.bias, l.pooling_proj2.bias], 0)),
+                          wproj_w=F(torch.cat([l.weight_proj1.weight, l.weight_proj2.weight], 0)),
+                          wproj_b=F(torch.cat([l.weight_proj1.bias, l.weight_proj2.bias], 0)))
+            lt["merge_w"] = A(mw)
             if has_ffn:
                 lt.update(
                     norm_ff_mac_g=F(l.norm_ff_macaron.weight), norm_ff_mac_b=F(l.norm_ff_macaron.bias),
@@ -197,10 +215,13 @@ class EBranchformerEncoder(ConformerEncoder):
 
 
 class BranchformerEncoder(EBranchformerEncoder):
-    """BranchformerEncoder (espnet2/asr/encoder/branchformer_encoder.py:293-620) for merge_method="concat" with
-    both branches: the E-Branchformer layer without feed-forward modules and without the depthwise conv in
-    front of `merge_proj` (state-dict keys `encoders.N.{attn, cgmlp, norm_mha, norm_mlp, norm_final,
-    merge_proj}`); same kernels, `EmEBranchformerWeights.use_ffn = merge_conv = 0`."""
+    """BranchformerEncoder (espnet2/asr/encoder/branchformer_encoder.py:293-620) with both branches: the
+    E-Branchformer layer without feed-forward modules and without the depthwise conv in front of `merge_proj`
+    (state-dict keys `encoders.N.{attn, cgmlp, norm_mha, norm_mlp, norm_final, merge_proj}`, plus
+    `pooling_proj{1,2}` / `weight_proj{1,2}` for learned_ave); same kernels,
+    `EmEBranchformerWeights.use_ffn = merge_conv = 0`.  merge_method: concat; fixed_ave (0 < cgmlp_weight < 1,
+    a float or one per block — folded into the packed merge_proj weight); learned_ave (the pooled per-utterance
+    branch weights are computed on the device, `em_branch_learned_ave`; attn_branch_drop_rate is training-only)."""
 
     def __init__(self, input_size: int, output_size: int = 256, use_attn: bool = True, attention_heads: int = 4,
                  attention_layer_type: str = "rel_selfattn", pos_enc_layer_type: str = "rel_pos",
@@ -215,7 +236,17 @@ class BranchformerEncoder(EBranchformerEncoder):
         torch.nn.Module.__init__(self)
         bad = []
         if not (use_attn and use_cgmlp): bad.append("use_attn and use_cgmlp must both be True")
-        if merge_method != "concat": bad.append(f"merge_method={merge_method}")
+        if merge_method not in ("concat", "learned_ave", "fixed_ave"):
+            raise ValueError(f"unknown merge method: {merge_method}")  # branchformer_encoder.py:133
+        if isinstance(cgmlp_weight, (int, float)):  # :490-496
+            cgmlp_weight = [float(cgmlp_weight)] * num_blocks
+        if len(cgmlp_weight) != num_blocks:
+            raise ValueError(f"Length of cgmlp_weight ({len(cgmlp_weight)}) should be equal to "
+                             f"num_blocks ({num_blocks})")
+        if merge_method == "fixed_ave":
+            assert all(0.0 <= c <= 1.0 for c in cgmlp_weight), "cgmlp weight should be between 0.0 and 1.0"
+            if any(c in (0.0, 1.0) for c in cgmlp_weight):  # :120-127 drops one branch and its parameters
+                bad.append("fixed_ave with cgmlp_weight 0.0 / 1.0 (single-branch layers)")
         if input_layer not in ("conv2d", "conv2d6", "conv2d8"): bad.append(f"input_layer={input_layer}")
         # e_branchformer_encoder.py:226-235 / branchformer_encoder.py:330-339: "legacy" maps to the legacy_ classes
         if rel_pos_type == "legacy":
@@ -240,6 +271,7 @@ class BranchformerEncoder(EBranchformerEncoder):
         self.heads, self.linear_units, self.num_blocks = attention_heads, None, num_blocks
         self.cgmlp_linear_units, self.cgmlp_conv_kernel = cgmlp_linear_units, cgmlp_conv_kernel
         self.merge_conv_kernel = None
+        self.merge_method, self.cgmlp_weight = merge_method, [float(c) for c in cgmlp_weight]
         self.interctc_layer_idx, self.interctc_use_conditioning = [], False
         self.compute_dtype = compute_dtype
         self.input_layer = input_layer
@@ -247,6 +279,6 @@ class BranchformerEncoder(EBranchformerEncoder):
         self.embed = _Conv2dSubsampling(input_size, output_size, input_layer)
         self.encoders = torch.nn.ModuleList(
             [_EBranchformerEncoderLayer(output_size, attention_heads, None, cgmlp_linear_units, cgmlp_conv_kernel,
-                                        None) for _ in range(num_blocks)])
+                                        None, merge_method) for _ in range(num_blocks)])
         self.after_norm = LayerNorm(output_size)
         self._packed, self._pos_cache, self._ws, self._olens_cache = None, {}, None, {}

@@ -1,10 +1,12 @@
-// Host-side launch sequence of the E-Branchformer encoder (no device code here): one C call
-// enqueues every kernel of a forward pass on the caller's stream.
+// Host-side launch sequence of the E-Branchformer / Branchformer encoder: one C call enqueues every kernel
+// of a forward pass on the caller's stream.  The only device code here is the Branchformer learned_ave
+// merge (two small kernels at the end of the anonymous namespace).
 //
 // Reference call graph being reproduced:
 //   EBranchformerEncoder.forward       espnet2/asr/encoder/e_branchformer_encoder.py:418-520
 //   EBranchformerEncoderLayer.forward  espnet2/asr/encoder/e_branchformer_encoder.py:110-183
 //   ConvolutionalGatingMLP / CSGU      espnet2/asr/layers/cgmlp.py:14-145
+//   BranchformerEncoderLayer.forward   espnet2/asr/encoder/branchformer_encoder.py:138-290 (merges :207-278)
 //   Conv2dSubsampling, RelPositionalEncoding, RelPositionMultiHeadedAttention, PositionwiseFeedForward:
 //   the Conformer ones (see encoder.hip)
 //
@@ -24,7 +26,7 @@ constexpr float LN_EPS = 1e-12f;
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws {
-  size_t c1, c2, c3, x, xn, xn2, big, gn, gated, cat, tmp, ctx, pall, total;
+  size_t c1, c2, c3, x, xn, xn2, big, gn, gated, cat, tmp, ctx, pall, mw, total;
 };
 inline Ws layout(int dtype, const EmEBranchformerWeights* w, int B, int T_f) {
   const size_t es = dtype == EM_BF16 ? 2 : 4;
@@ -50,6 +52,7 @@ inline Ws layout(int dtype, const EmEBranchformerWeights* w, int B, int T_f) {
   s.tmp = o; o += align_up(M * 2 * d * es);
   s.ctx = o; o += align_up(M * d * es);
   s.pall = o; o += align_up((size_t)(2 * g.T_out - 1) * w->num_blocks * d * es);
+  s.mw = o; o += align_up((size_t)B * 2 * sizeof(float));
   s.total = o;
   return s;
 }
@@ -68,7 +71,98 @@ inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const
     if (rc__ != EM_OK) return rc__; \
   } while (0)
 
+// ---- Branchformer learned_ave (branchformer_encoder.py:212-270).  Branch k of utterance b is attention-pooled
+// over its valid frames with scores (x_t . pool_w + pool_b) / sqrt(d), and the pooled vector is projected to
+// one scalar: weight = (sum_t softmax_t x_t) . wproj_w + wproj_b = sum_t softmax_t (x_t . wproj_w) + wproj_b,
+// so one pass over the rows with two dot products per row and an online softmax does it.
+// grid (B, 2), 4 waves; wave w takes rows w, w+4, ...
+template <typename T>
+__global__ __launch_bounds__(256) void branch_pool_kernel(const T* __restrict__ cat, const int32_t* __restrict__ lens,
+                                                          int Tn, int d, const float* __restrict__ pool_w,
+                                                          const float* __restrict__ pool_b,
+                                                          const float* __restrict__ wproj_w,
+                                                          const float* __restrict__ wproj_b, float* __restrict__ mw) {
+  const int b = blockIdx.x, k = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int n = lens[b];
+  n = n < Tn ? n : Tn;
+  const float* pw = pool_w + (size_t)k * d;
+  const float* ww = wproj_w + (size_t)k * d;
+  const float inv = 1.f / sqrtf((float)d), pb = pool_b[k];
+  float m = -INFINITY, l = 0.f, acc = 0.f;
+  for (int t = wave; t < n; t += 4) {
+    const T* row = cat + ((size_t)b * Tn + t) * 2 * d + (size_t)k * d;
+    float s = 0.f, u = 0.f;
+    for (int c = lane; c < d; c += 64) {
+      const float v = to_f32(row[c]);
+      s += v * pw[c];
+      u += v * ww[c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      u += __shfl_xor(u, o, 64);
+    }
+    s = (s + pb) * inv;
+    const float mn = fmaxf(m, s), a = expf(m - mn), e = expf(s - mn);
+    l = l * a + e;
+    acc = acc * a + e * u;
+    m = mn;
+  }
+  __shared__ float sm[4], sl[4], sa[4];
+  if (lane == 0) {
+    sm[wave] = m;
+    sl[wave] = l;
+    sa[wave] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), L = 0.f, A = 0.f;
+    for (int w = 0; w < 4; ++w)
+      if (sl[w] > 0.f) {
+        const float a = expf(sm[w] - M);
+        L += sl[w] * a;
+        A += sa[w] * a;
+      }
+    mw[b * 2 + k] = A / L + wproj_b[k];
+  }
+}
+
+// out[b,t,:] = w1 x1 + w2 x2 with (w1, w2) = softmax(mw[b]) (:260-269)
+template <typename T>
+__global__ __launch_bounds__(256) void branch_mix_kernel(const T* __restrict__ cat, const float* __restrict__ mw,
+                                                         int Tn, int d, T* __restrict__ out) {
+  const int row = blockIdx.x, b = row / Tn;
+  const float a = mw[b * 2], c2 = mw[b * 2 + 1], mx = fmaxf(a, c2);
+  const float e1 = expf(a - mx), e2 = expf(c2 - mx), w1 = e1 / (e1 + e2), w2 = e2 / (e1 + e2);
+  const T* x1 = cat + (size_t)row * 2 * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    out[(size_t)row * d + c] = from_f32<T>(w1 * to_f32(x1[c]) + w2 * to_f32(x1[d + c]));
+}
+
 }  // namespace
+
+extern "C" int em_branch_learned_ave(int dtype, const void* cat, const int32_t* lens, int32_t B, int32_t T,
+                                     int32_t d, const float* pool_w, const float* pool_b, const float* wproj_w,
+                                     const float* wproj_b, float* mw_ws, void* out, void* stream) {
+  if (!cat || !lens || !pool_w || !pool_b || !wproj_w || !wproj_b || !mw_ws || !out) return EM_ERR_BAD_ARG;
+  if (B <= 0 || T <= 0 || d <= 0) return EM_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == EM_BF16) {
+    hipLaunchKernelGGL(branch_pool_kernel<bf16>, dim3(B, 2), dim3(256), 0, s, (const bf16*)cat, lens, T, d, pool_w,
+                       pool_b, wproj_w, wproj_b, mw_ws);
+    hipLaunchKernelGGL(branch_mix_kernel<bf16>, dim3(B * T), dim3(256), 0, s, (const bf16*)cat, mw_ws, T, d,
+                       (bf16*)out);
+  } else if (dtype == EM_F32) {
+    hipLaunchKernelGGL(branch_pool_kernel<float>, dim3(B, 2), dim3(256), 0, s, (const float*)cat, lens, T, d, pool_w,
+                       pool_b, wproj_w, wproj_b, mw_ws);
+    hipLaunchKernelGGL(branch_mix_kernel<float>, dim3(B * T), dim3(256), 0, s, (const float*)cat, mw_ws, T, d,
+                       (float*)out);
+  } else {
+    return EM_ERR_BAD_ARG;
+  }
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
 
 extern "C" size_t em_ebranchformer_workspace_bytes(int dtype, const EmEBranchformerWeights* w, int32_t B,
                                                    int32_t T_f) {
@@ -85,6 +179,8 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   if (!w || !feats || !flens || !olens || !pos_emb || !workspace || !enc_out || !enc_act) return EM_ERR_BAD_ARG;
   if (dtype != EM_F32 && dtype != EM_BF16) return EM_ERR_BAD_ARG;
   if (B <= 0) return EM_ERR_BAD_ARG;
+  if (w->merge_method != EM_MERGE_CONCAT && (w->merge_method != EM_MERGE_LEARNED_AVE || w->merge_conv))
+    return EM_ERR_UNSUPPORTED;
   if (T_f < em_sub::min_frames(w->subsample)) return EM_ERR_TOO_SHORT;
   const int d = w->d, h = w->heads, ff = w->ff, cg = w->cg, L = w->num_blocks, ch = cg / 2;
   const int kalign = dtype == EM_BF16 ? 64 : 32;
@@ -145,15 +241,23 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
                              w->cg_kernel, big, cg, gated, ch, stream));
     EM_TRY(gemm(dtype, EM_EPI_STORE, gated, q.proj2_w, cat + (size_t)d * es, q.proj2_b, M, d, ch, ch, 2 * d,
                 1.f, stream));
-    // merge: E-Branchformer (:165-170) x += merge_proj(cat + dwconv(cat)); Branchformer (concat,
-    // branchformer_encoder.py:207-211) x += merge_proj(cat)
-    const void* merged = cat;
-    if (w->merge_conv) {
-      EM_TRY(em_dwconv(dtype, EM_DW_SELFRES, cat, 2 * d, q.merge_conv_w, q.merge_conv_b, conv_lens, B, T, 2 * d,
-                       w->merge_kernel, nullptr, 0, tmp, 2 * d, stream));
-      merged = tmp;
+    // merge: E-Branchformer (:165-170) x += merge_proj(cat + dwconv(cat)); Branchformer (branchformer_encoder.py:
+    // 207-278) concat: x += merge_proj(cat); fixed_ave: the same launch, the host packs merge_proj as
+    // [(1-w) W | w W]; learned_ave: x += merge_proj(w1 x1 + w2 x2) with per-utterance pooled weights
+    if (w->merge_method == EM_MERGE_LEARNED_AVE) {
+      if (!q.pool_w || !q.pool_b || !q.wproj_w || !q.wproj_b) return EM_ERR_BAD_ARG;
+      EM_TRY(em_branch_learned_ave(dtype, cat, olens, B, T, d, q.pool_w, q.pool_b, q.wproj_w, q.wproj_b,
+                                   (float*)(ws + s.mw), tmp, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, tmp, q.merge_w, x, q.merge_b, M, d, d, d, d, 1.f, stream));
+    } else {
+      const void* merged = cat;
+      if (w->merge_conv) {
+        EM_TRY(em_dwconv(dtype, EM_DW_SELFRES, cat, 2 * d, q.merge_conv_w, q.merge_conv_b, conv_lens, B, T, 2 * d,
+                         w->merge_kernel, nullptr, 0, tmp, 2 * d, stream));
+        merged = tmp;
+      }
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, merged, q.merge_w, x, q.merge_b, M, d, 2 * d, 2 * d, d, 1.f, stream));
     }
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, merged, q.merge_w, x, q.merge_b, M, d, 2 * d, 2 * d, d, 1.f, stream));
     if (ffn) {
       // FFN (:172-176)
       EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));

@@ -654,28 +654,58 @@ __global__ void rnn_gather_kernel(Ctx c, int i_host, int layers, int ld) {
   for (int ch = threadIdx.x; ch < ld; ch += blockDim.x) dst[ch] = i > 0 ? src[ch] : from_f32<T>(0.f);
 }
 
-// gates [n][4*nhid] (i | f | g | o, already W_ih x + W_hh h + b) -> c, h (torch.nn.LSTM cell)
-template <typename T>
-__global__ void lstm_cell_kernel(Ctx c, int i_host, int layers, int l, int nhid, int ld) {
+// Recurrent cell of torch.nn.{LSTM,GRU,RNN} on the summed gate pre-activations `gates` (f32, W_ih x + W_hh h
+// + b from the two GEMMs).  The f32 master state lives in rnn_cs (c for the LSTM, h for the GRU); the
+// activation-type copy of h in rnn_hs feeds the next step's GEMM.
+//   LSTM      gates [n][4*nhid] = i | f | g | o:    c' = s(f) c + s(i) tanh(g),  h' = s(o) tanh(c')
+//   GRU       gates [n][4*nhid] = r | z | n_x | n_h (the candidate's input and hidden parts kept apart by
+//             zero weight blocks, see EmRnnLayer):  n = tanh(n_x + s(r) n_h),  h' = (1 - s(z)) n + s(z) h
+//   RNN       gates [n][nhid]:                        h' = tanh(g) | relu(g)
+template <typename T, int KIND>
+__global__ void rnn_cell_kernel(Ctx c, int i_host, int layers, int l, int nhid, int ld) {
   const int i = c.b.step ? *c.b.step : i_host;
   if (i >= c.p.Lmax - 1) return;
   const int n = c.p.B * c.p.W;
   const int r = blockIdx.x;
   int p = i > 0 ? c.b.parent[(size_t)i * n + r] : r;
   p = (p < 0 || p >= n) ? r : p;
-  const float* g = c.b.rnn_gates + (size_t)r * 4 * nhid;
-  const float* cprev = c.b.rnn_cs + (((size_t)((i + 2) % 3) * layers + l) * n + p) * ld;
-  float* cnew = c.b.rnn_cs + (((size_t)(i % 3) * layers + l) * n + r) * ld;
+  constexpr int G = (KIND == EM_LM_LSTM || KIND == EM_LM_GRU) ? 4 : 1;
+  const float* g = c.b.rnn_gates + (size_t)r * G * nhid;
+  const float* sprev = c.b.rnn_cs + (((size_t)((i + 2) % 3) * layers + l) * n + p) * ld;
+  float* snew = c.b.rnn_cs + (((size_t)(i % 3) * layers + l) * n + r) * ld;
   T* hnew = (T*)c.b.rnn_hs + (((size_t)(i % 3) * layers + l) * n + r) * ld;
   T* hout = (T*)c.b.rnn_hin + ((size_t)l * n + r) * ld;  // A operand of the next GEMM (fixed address)
   for (int ch = threadIdx.x; ch < nhid; ch += blockDim.x) {
-    const float gi = 1.f / (1.f + expf(-g[ch])), gf = 1.f / (1.f + expf(-g[nhid + ch]));
-    const float gg = tanhf(g[2 * nhid + ch]), go = 1.f / (1.f + expf(-g[3 * nhid + ch]));
-    const float cc = gf * (i > 0 ? cprev[ch] : 0.f) + gi * gg;
-    const float hh = go * tanhf(cc);
-    cnew[ch] = cc;
+    float hh;
+    if constexpr (KIND == EM_LM_LSTM) {
+      const float gi = 1.f / (1.f + expf(-g[ch])), gf = 1.f / (1.f + expf(-g[nhid + ch]));
+      const float gg = tanhf(g[2 * nhid + ch]), go = 1.f / (1.f + expf(-g[3 * nhid + ch]));
+      const float cc = gf * (i > 0 ? sprev[ch] : 0.f) + gi * gg;
+      hh = go * tanhf(cc);
+      snew[ch] = cc;
+    } else if constexpr (KIND == EM_LM_GRU) {
+      const float gr = 1.f / (1.f + expf(-g[ch])), gz = 1.f / (1.f + expf(-g[nhid + ch]));
+      const float nn = tanhf(g[2 * nhid + ch] + gr * g[3 * nhid + ch]);
+      hh = (1.f - gz) * nn + gz * (i > 0 ? sprev[ch] : 0.f);
+      snew[ch] = hh;
+    } else if constexpr (KIND == EM_LM_RNN_TANH) {
+      hh = tanhf(g[ch]);
+    } else {
+      hh = fmaxf(g[ch], 0.f);
+    }
     hnew[ch] = from_f32<T>(hh);
     hout[ch] = from_f32<T>(hh);
+  }
+}
+
+template <typename T>
+void rnn_cell_launch(int kind, hipStream_t s, const Ctx& c, int i, int Ln, int l, int nh, int d) {
+  const int n = c.p.B * c.p.W;
+  switch (kind) {
+    case EM_LM_LSTM: hipLaunchKernelGGL((rnn_cell_kernel<T, EM_LM_LSTM>), dim3(n), dim3(128), 0, s, c, i, Ln, l, nh, d); break;
+    case EM_LM_GRU: hipLaunchKernelGGL((rnn_cell_kernel<T, EM_LM_GRU>), dim3(n), dim3(128), 0, s, c, i, Ln, l, nh, d); break;
+    case EM_LM_RNN_TANH: hipLaunchKernelGGL((rnn_cell_kernel<T, EM_LM_RNN_TANH>), dim3(n), dim3(128), 0, s, c, i, Ln, l, nh, d); break;
+    default: hipLaunchKernelGGL((rnn_cell_kernel<T, EM_LM_RNN_RELU>), dim3(n), dim3(128), 0, s, c, i, Ln, l, nh, d); break;
   }
 }
 
@@ -696,9 +726,10 @@ int check(const EmSearchParams* p, const EmSearchBuffers* b) {
 // Encoder.forward_one_step): embedding -> input Linear + LayerNorm(1e-5) + ReLU (+ pos-enc) ->
 // pre-norm self-attention / ReLU feed-forward layers over the token-tree K/V cache -> after_norm ->
 // vocabulary projection (logits; the log-softmax is fused into the pre-beam kernel).
-int lstm_lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i, void* stream) {
+int rnn_lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i, void* stream) {
   const EmLmWeights* lm = b->lm;
   const int n = p->B * p->W, V = p->V, d = lm->d, nh = lm->nhid, eu = lm->embed_unit, Ln = lm->num_blocks;
+  const int gw = (lm->kind == EM_LM_LSTM || lm->kind == EM_LM_GRU ? 4 : 1) * nh;  // gate row width
   if (!lm->rnn || !b->rnn_hs || !b->rnn_cs || !b->rnn_hin || !b->rnn_gates || !b->lm_e) return EM_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   Ctx c{*p, *b};
@@ -716,12 +747,10 @@ int lstm_lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, i
     const void* x = l == 0 ? b->lm_e : (const void*)((const unsigned char*)b->rnn_hin + (size_t)(l - 1) * n * d * es);
     const int kin = l == 0 ? eu : d;
     const void* hin = (const unsigned char*)b->rnn_hin + (size_t)l * n * d * es;
-    EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, x, q.w_ih, b->rnn_gates, q.bias, n, 4 * nh, kin, kin, 4 * nh, 1.f, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, hin, q.w_hh, b->rnn_gates, nullptr, n, 4 * nh, d, d, 4 * nh, 1.f, stream));
-    if (dtype == EM_BF16)
-      hipLaunchKernelGGL(lstm_cell_kernel<bf16>, dim3(n), dim3(128), 0, s, c, i, Ln, l, nh, d);
-    else
-      hipLaunchKernelGGL(lstm_cell_kernel<float>, dim3(n), dim3(128), 0, s, c, i, Ln, l, nh, d);
+    EM_TRY(gemm(dtype, EM_EPI_SCALE_F32, x, q.w_ih, b->rnn_gates, q.bias, n, gw, kin, kin, gw, 1.f, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, hin, q.w_hh, b->rnn_gates, nullptr, n, gw, d, d, gw, 1.f, stream));
+    if (dtype == EM_BF16) rnn_cell_launch<bf16>(lm->kind, s, c, i, Ln, l, nh, d);
+    else rnn_cell_launch<float>(lm->kind, s, c, i, Ln, l, nh, d);
   }
   const void* top = (const unsigned char*)b->rnn_hin + (size_t)(Ln - 1) * n * d * es;
   EM_TRY(gemm(dtype, EM_EPI_STORE_F32, top, lm->out_w, b->lm_logp, lm->out_b, n, V, d, d, V, 1.f, stream));
@@ -731,7 +760,7 @@ int lstm_lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, i
 
 int lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i, void* stream) {
   const EmLmWeights* lm = b->lm;
-  if (lm->kind == EM_LM_LSTM) return lstm_lm_step(dtype, p, b, i, stream);
+  if (lm->kind != EM_LM_TRANSFORMER) return rnn_lm_step(dtype, p, b, i, stream);
   const int n = p->B * p->W, V = p->V, d = lm->d, ff = lm->ff, eu = lm->embed_unit;
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   const int* anc = (i & 1) ? b->anc_b : b->anc_a;

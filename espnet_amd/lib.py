@@ -75,7 +75,9 @@ _EBF_LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b",
                    "norm_ff_g", "norm_ff_b", "norm_final_g", "norm_final_b", "ffm_w1", "ffm_w2", "ff_w1", "ff_w2",
                    "ffm_b1", "ffm_b2", "ff_b1", "ff_b2", "wqkv", "bqkv", "pos_u", "pos_v", "wout", "bout",
                    "proj1_w", "proj1_b", "csgu_norm_g", "csgu_norm_b", "csgu_conv_w", "csgu_conv_b", "proj2_w",
-                   "proj2_b", "merge_conv_w", "merge_conv_b", "merge_w", "merge_b"]
+                   "proj2_b", "merge_conv_w", "merge_conv_b", "merge_w", "merge_b", "pool_w", "pool_b", "wproj_w",
+                   "wproj_b"]
+EM_MERGE_CONCAT, EM_MERGE_LEARNED_AVE = 0, 1
 
 
 class EmEBranchformerLayer(C.Structure):
@@ -89,7 +91,7 @@ class EmEBranchformerWeights(C.Structure):
                                           "wpos_all", "after_norm_g", "after_norm_b")] + \
                [("layers", C.POINTER(EmEBranchformerLayer)), ("use_ffn", C.c_int32), ("merge_conv", C.c_int32),
                 ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p),
-                ("legacy_relpos", C.c_int32)]
+                ("legacy_relpos", C.c_int32), ("merge_method", C.c_int32)]
 
 
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",
@@ -127,7 +129,7 @@ class EmRnnLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w_ih", "w_hh", "bias")]
 
 
-EM_LM_TRANSFORMER, EM_LM_LSTM = 0, 1
+EM_LM_TRANSFORMER, EM_LM_LSTM, EM_LM_GRU, EM_LM_RNN_TANH, EM_LM_RNN_RELU = 0, 1, 2, 3, 4
 
 
 class EmLmWeights(C.Structure):
@@ -181,6 +183,7 @@ _SIGNATURES = {
     "em_ebranchformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmEBranchformerWeights), _i32, _i32]),
     "em_ebranchformer_encode": (C.c_int, [C.c_int, C.POINTER(EmEBranchformerWeights), _vp, _vp, _vp, _vp,
                                           _i32, _i32, _vp, _vp, _sz, _vp, _vp, _i32, _vp]),
+    "em_branch_learned_ave": (C.c_int, [C.c_int, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "em_ln_gemm": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "em_dwconv": (C.c_int, [C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp,
                             _i32, _vp]),

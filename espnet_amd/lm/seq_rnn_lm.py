@@ -1,9 +1,9 @@
-"""SequentialRNNLM (LSTM) as a beam-search scorer on the MI355X.
+"""SequentialRNNLM (LSTM / GRU / tanh- / relu-RNN) as a beam-search scorer on the MI355X.
 
 Mirrors espnet2/lm/seq_rnn_lm.py:14-177 (constructor keywords; state-dict keys `encoder.weight`,
 `rnn.{weight,bias}_{ih,hh}_l{k}`, `decoder.{weight,bias}`).  `batch_score` (:140-177) is fulfilled inside
-the fused device search (csrc/search.hip `lstm_lm_step`): per step the last token's embedding and the
-PARENT hypothesis' (h, c) go through the LSTM cells; the logits' log-softmax is summed with the other
+the fused device search (csrc/search.hip `rnn_lm_step`): per step the last token's embedding and the
+PARENT hypothesis' state ((h, c) for the LSTM, h otherwise, :80-89) go through the recurrent cells; the logits' log-softmax is summed with the other
 full scorers in the pre-beam kernel.  Hidden sizes are zero-padded to the GEMM K step at pack time
 (unit = 650 is the class default), which leaves every product unchanged.
 The torch.nn layers are parameter containers only.
@@ -16,18 +16,28 @@ import torch
 from espnet_amd import lib as L
 
 
+_KINDS = {"LSTM": L.EM_LM_LSTM, "GRU": L.EM_LM_GRU, "RNN_TANH": L.EM_LM_RNN_TANH, "RNN_RELU": L.EM_LM_RNN_RELU}
+
+
 class SequentialRNNLM(torch.nn.Module):
     def __init__(self, vocab_size: int, unit: int = 650, nhid: Optional[int] = None, nlayers: int = 2,
                  dropout_rate: float = 0.0, tie_weights: bool = False, rnn_type: str = "lstm",
                  ignore_id: int = 0, compute_dtype: str = "bfloat16"):
         super().__init__()
-        if rnn_type.upper() != "LSTM":
-            raise NotImplementedError(f"rnn_type={rnn_type!r}: only the LSTM (the class default) is on the MI355X path")
+        rnn_type = rnn_type.upper()
+        if rnn_type not in _KINDS:  # seq_rnn_lm.py:48-52
+            raise ValueError("An invalid option for `--model` was supplied, "
+                             "options are ['LSTM', 'GRU', 'RNN_TANH' or 'RNN_RELU']")
         nhid = unit if nhid is None else nhid
+        self.rnn_type = rnn_type
         self.vocab_size, self.unit, self.nhid, self.nlayers = vocab_size, unit, nhid, nlayers
         self.compute_dtype = compute_dtype
         self.encoder = torch.nn.Embedding(vocab_size, unit, padding_idx=ignore_id)
-        self.rnn = torch.nn.LSTM(unit, nhid, nlayers, dropout=dropout_rate, batch_first=True)
+        if rnn_type in ("LSTM", "GRU"):
+            self.rnn = getattr(torch.nn, rnn_type)(unit, nhid, nlayers, dropout=dropout_rate, batch_first=True)
+        else:
+            self.rnn = torch.nn.RNN(unit, nhid, nlayers, nonlinearity=rnn_type[4:].lower(), dropout=dropout_rate,
+                                    batch_first=True)
         self.decoder = torch.nn.Linear(nhid, vocab_size)
         if tie_weights:
             if nhid != unit:
@@ -52,12 +62,17 @@ class SequentialRNNLM(torch.nn.Module):
         return (v + 63) // 64 * 64
 
     def search_key(self):
-        return ("seq_rnn", self.unit, self.nhid, self.nlayers)
+        return ("seq_rnn", self.rnn_type, self.unit, self.nhid, self.nlayers)
+
+    @property
+    def gate_blocks(self) -> int:
+        """Gate blocks of nhid rows per layer on the device (EmRnnLayer): the GRU carries 4, see `pack`."""
+        return 1 if self.rnn_type.startswith("RNN") else 4
 
     def search_buffers(self, n, V, Lmax, B, cap):
         d, eu = self._pad(self.nhid), self._pad(self.unit)
         return dict(lm_e=(n, eu), lm_logp=(n, V), rnn_hs=(3, self.nlayers, n, d), rnn_cs=(3, self.nlayers, n, d),
-                    rnn_hin=(self.nlayers, n, d), rnn_gates=(n, 4 * self.nhid), run_slm=(n,), end_slm=(B, cap))
+                    rnn_hin=(self.nlayers, n, d), rnn_gates=(n, self.gate_blocks * self.nhid), run_slm=(n,), end_slm=(B, cap))
 
     def pack(self, device, pe_len: int = 0):
         dev = torch.device(device)
@@ -81,7 +96,7 @@ class SequentialRNNLM(torch.nn.Module):
             return t
 
         w = L.EmLmWeights()
-        w.kind, w.d, w.nhid, w.embed_unit, w.num_blocks, w.vocab = L.EM_LM_LSTM, d, nh, eu, self.nlayers, self.vocab_size
+        w.kind, w.d, w.nhid, w.embed_unit, w.num_blocks, w.vocab = _KINDS[self.rnn_type], d, nh, eu, self.nlayers, self.vocab_size
         w.heads = w.ff = 0
         top = dict(embed=F(padk(self.encoder.weight, eu)), out_w=A(padk(self.decoder.weight, d)),
                    out_b=F(self.decoder.bias))
@@ -89,8 +104,17 @@ class SequentialRNNLM(torch.nn.Module):
             setattr(w, k, v.data_ptr())
         layers = (L.EmRnnLayer * self.nlayers)()
         for l in range(self.nlayers):
-            w_ih, w_hh = getattr(self.rnn, f"weight_ih_l{l}"), getattr(self.rnn, f"weight_hh_l{l}")
-            b = getattr(self.rnn, f"bias_ih_l{l}").detach().float() + getattr(self.rnn, f"bias_hh_l{l}").detach().float()
+            w_ih, w_hh = (getattr(self.rnn, f"weight_{k}_l{l}").detach().float() for k in ("ih", "hh"))
+            b_ih, b_hh = (getattr(self.rnn, f"bias_{k}_l{l}").detach().float() for k in ("ih", "hh"))
+            if self.rnn_type == "GRU":
+                # r | z | n -> r | z | n_x | n_h: the candidate gate's input and hidden parts stay separate
+                # (n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), torch.nn.GRU), zero blocks keep them apart
+                zi, zh = torch.zeros(nh, w_ih.size(1)), torch.zeros(nh, w_hh.size(1))
+                w_ih = torch.cat([w_ih, zi])
+                w_hh = torch.cat([w_hh[: 2 * nh], zh, w_hh[2 * nh:]])
+                b = torch.cat([b_ih[: 2 * nh] + b_hh[: 2 * nh], b_ih[2 * nh:], b_hh[2 * nh:]])
+            else:
+                b = b_ih + b_hh
             lt = dict(w_ih=A(padk(w_ih, eu if l == 0 else d)), w_hh=A(padk(w_hh, d)), bias=F(b))
             for k, v in lt.items():
                 setattr(layers[l], k, v.data_ptr())

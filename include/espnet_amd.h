@@ -316,9 +316,16 @@ typedef struct EmEBranchformerLayer {
   const void* proj2_w;                    /* cgmlp.channel_proj2 [d][cg/2] act */
   const float* proj2_b;
   const float *merge_conv_w, *merge_conv_b; /* depthwise_conv_fusion [km][2d] tap-major, [2d] */
-  const void* merge_w;                      /* merge_proj [d][2d] act */
+  const void* merge_w;                      /* merge_proj [d][2d] act ([d][d] for EM_MERGE_LEARNED_AVE) */
   const float* merge_b;
+  /* Branchformer merge_method="learned_ave" (branchformer_encoder.py:102-112); NULL otherwise */
+  const float *pool_w, *pool_b;   /* pooling_proj1 | pooling_proj2: [2][d], [2] */
+  const float *wproj_w, *wproj_b; /* weight_proj1 | weight_proj2:   [2][d], [2] */
 } EmEBranchformerLayer;
+
+#define EM_MERGE_CONCAT 0      /* x += merge_proj([x1 | x2]); also fixed_ave, whose host packing is
+                                  merge_w = [(1 - cgmlp_weight) W | cgmlp_weight W] (:271-276) */
+#define EM_MERGE_LEARNED_AVE 1 /* x += merge_proj(w1 x1 + w2 x2), (w1, w2) per utterance (:212-270) */
 
 typedef struct EmEBranchformerWeights {
   int32_t d, heads, ff, cg, num_blocks, cg_kernel, merge_kernel, n_mels;
@@ -338,7 +345,17 @@ typedef struct EmEBranchformerWeights {
   const void* conv3_w;
   const float* conv3_b;
   int32_t legacy_relpos; /* as EmConformerWeights.legacy_relpos */
+  int32_t merge_method;  /* EM_MERGE_* (Branchformer; requires merge_conv = 0 unless EM_MERGE_CONCAT) */
 } EmEBranchformerWeights;
+
+/* ---- Branchformer learned_ave merge input (BranchformerEncoderLayer.forward, branchformer_encoder.py:212-270).
+ *   cat [B*T][2d] act = [x1 | x2] (attention | cgMLP branch outputs); lens [B] valid frames (the pad mask).
+ *   Per utterance and branch k: score_t = softmax over the valid frames of (x_k[t] . pool_w[k] + pool_b[k]) /
+ *   sqrt(d); weight_k = (sum_t score_t x_k[t]) . wproj_w[k] + wproj_b[k]; (w1, w2) = softmax(weight_1, weight_2).
+ *   mw_ws [B][2] f32: receives (weight_1, weight_2); out [B*T][d] act = w1 x1 + w2 x2.                      */
+int em_branch_learned_ave(int dtype, const void* cat, const int32_t* lens, int32_t B, int32_t T, int32_t d,
+                          const float* pool_w, const float* pool_b, const float* wproj_w,
+                          const float* wproj_b, float* mw_ws, void* out, void* stream);
 
 size_t em_ebranchformer_workspace_bytes(int dtype, const EmEBranchformerWeights* w, int32_t B, int32_t T_f);
 /*   Arguments as em_conformer_encode.  flags: EM_ENC_ISOLATE_UTTS masks both depthwise convs (cgMLP and
@@ -468,21 +485,31 @@ typedef struct EmLmWeights {
   const void* out_w;                /* [V][d] act: lm.decoder */
   const float* out_b;
   const EmLmLayer* layers;          /* [num_blocks], host array */
-  /* kind == EM_LM_LSTM: SequentialRNNLM with an LSTM (espnet2/lm/seq_rnn_lm.py:14-177).  d = nhid padded
+  /* kind >= EM_LM_LSTM: SequentialRNNLM (espnet2/lm/seq_rnn_lm.py:14-177; rnn_type lstm | gru | rnn_tanh |
+   * rnn_relu, :40-58).  d = nhid padded
    * to the GEMM K step (ld of every hidden-state row), embed_unit = unit padded likewise (embed is
    * [V][embed_unit] with zero pad columns), num_blocks = nlayers, out_w [V][d] act, out_b; the
    * transformer-only fields are NULL.                                                              */
-  int32_t kind;                     /* EM_LM_TRANSFORMER (0) | EM_LM_LSTM (1) */
+  int32_t kind;                     /* EM_LM_TRANSFORMER | EM_LM_LSTM | EM_LM_GRU | EM_LM_RNN_TANH | EM_LM_RNN_RELU */
   int32_t nhid;                     /* true hidden size (<= d) */
   const struct EmRnnLayer* rnn;     /* [num_blocks], host array */
 } EmLmWeights;
 
 #define EM_LM_TRANSFORMER 0
 #define EM_LM_LSTM 1
+#define EM_LM_GRU 2
+#define EM_LM_RNN_TANH 3
+#define EM_LM_RNN_RELU 4
+/* One recurrent layer; G gate blocks of nhid rows each, in_pad = embed_unit (layer 0) or d.
+ *   LSTM (G = 4): PyTorch order i | f | g | o, bias = bias_ih + bias_hh.
+ *   GRU  (G = 4): r | z | n_x | n_h.  torch.nn.GRU's candidate n = tanh(W_in x + b_in + r * (W_hn h + b_hn))
+ *        needs its input and hidden parts apart, so w_ih = [W_ir; W_iz; W_in; 0], w_hh = [W_hr; W_hz; 0; W_hn],
+ *        bias = [b_ir + b_hr; b_iz + b_hz; b_in; b_hn] (packed by the host, lm/seq_rnn_lm.py).
+ *   RNN  (G = 1): bias = bias_ih + bias_hh.                                                              */
 typedef struct EmRnnLayer {
-  const void* w_ih;  /* [4*nhid][in_pad] act, PyTorch gate order i | f | g | o; in_pad = embed_unit (layer 0) or d */
-  const void* w_hh;  /* [4*nhid][d] act */
-  const float* bias; /* [4*nhid] = bias_ih + bias_hh */
+  const void* w_ih;  /* [G*nhid][in_pad] act */
+  const void* w_hh;  /* [G*nhid][d] act */
+  const float* bias; /* [G*nhid] */
 } EmRnnLayer;
 
 typedef struct EmSearchBuffers {
@@ -520,13 +547,13 @@ typedef struct EmSearchBuffers {
   float *lm_x, *lm_logp;                    /* f32: [n][d], [n][V] */
   void *lm_k, *lm_v;                        /* act [lm layers][Lmax][n][d] */
   float *run_slm, *end_slm;                 /* [n], [B][end_cap] accumulated LM score */
-  /* LSTM language model (kind == EM_LM_LSTM; NULL otherwise).  States of the rows of step i live in
+  /* recurrent language model (kind >= EM_LM_LSTM; NULL otherwise).  States of the rows of step i live in
    * ring slot i % 3; a row reads its parent's state (token-tree `parent`) from slot (i-1) % 3; the third
    * slot keeps step i-2 alive for the streaming search's one-step rewind.                             */
   void* rnn_hs;                             /* act [3][layers][n][d] hidden states (pad columns zero) */
-  float* rnn_cs;                            /* f32 [3][layers][n][d] cell states */
+  float* rnn_cs;                            /* f32 [3][layers][n][d] master state: LSTM c, GRU h */
   void* rnn_hin;                            /* act [layers][n][d] parent-gathered h, then this step's h */
-  float* rnn_gates;                         /* f32 [n][4*nhid] */
+  float* rnn_gates;                         /* f32 [n][G*nhid] */
   /* streaming search (em_search_online_*; NULL offline) */
   float *online_best;                       /* [n][8] valid, parent slot, token, total, dec, ctc, len, lm */
   float *online_psi;                        /* [n] log psi of the selected candidates (next s_prev) */

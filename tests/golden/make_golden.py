@@ -556,6 +556,16 @@ BF_TINY["encoder_conf"].update(output_size=64, attention_heads=1, cgmlp_linear_u
                                cgmlp_conv_kernel=7)
 BF_TINY["decoder_conf"].update(attention_heads=1, linear_units=128, num_blocks=1)
 
+
+
+def with_merge(conf, method, d=128, heads=2, blocks=2, **kw):
+    """Branchformer config with another merge_method (branchformer_encoder.py:99-133)."""
+    c = json.loads(json.dumps(conf))
+    c["encoder_conf"].update(merge_method=method, output_size=d, attention_heads=heads, num_blocks=blocks,
+                             cgmlp_linear_units=256, cgmlp_conv_kernel=15, **kw)
+    return c
+
+
 CASES = {
     # config 0/1 of BASELINE.json: Conformer-small, one 10 s utterance
     "small_10s": lambda: run_encode_case("small_10s", SMALL, 5000, 11, [0], [160000], keep_every=4),
@@ -639,10 +649,29 @@ CASES = {
     "tiny_beam4_rnnlm_nhid": lambda: run_lm_search_case(
         "tiny_beam4_rnnlm_nhid", tiny(d=64, heads=2, ff=128), 50, 7, 19, 24000, 4, 0.5, 1.0, 4,
         dict(unit=64, nhid=128, nlayers=1), lm_name="seq_rnn"),
+    # the other rnn_type choices of SequentialRNNLM (seq_rnn_lm.py:40-58): GRU, tanh / relu RNN
+    "tiny_beam5_gru": lambda: run_lm_search_case(
+        "tiny_beam5_gru", tiny(d=64, heads=2, ff=128), 50, 7, 20, 28000, 5, 0.3, 0.7, 5,
+        dict(unit=64, nlayers=2, rnn_type="gru"), lm_name="seq_rnn"),
+    "tiny_beam4_gru_nhid": lambda: run_lm_search_case(
+        "tiny_beam4_gru_nhid", tiny(d=64, heads=2, ff=128), 50, 7, 21, 24000, 4, 0.5, 1.0, 4,
+        dict(unit=64, nhid=96, nlayers=1, rnn_type="gru"), lm_name="seq_rnn"),
+    "tiny_beam4_rnn_tanh": lambda: run_lm_search_case(
+        "tiny_beam4_rnn_tanh", tiny(d=64, heads=2, ff=128), 50, 7, 22, 24000, 4, 0.4, 0.8, 4,
+        dict(unit=64, nlayers=2, rnn_type="rnn_tanh"), lm_name="seq_rnn"),
+    "tiny_beam4_rnn_relu": lambda: run_lm_search_case(
+        "tiny_beam4_rnn_relu", tiny(d=64, heads=2, ff=128), 50, 7, 23, 24000, 4, 0.4, 0.8, 4,
+        dict(unit=64, nhid=128, nlayers=1, rnn_type="rnn_relu"), lm_name="seq_rnn"),
     # Branchformer (merge_method concat): the E-Branchformer layer without FFNs and merge conv
     "bf_tiny_blocks": lambda: run_encode_case("bf_tiny_blocks", BF_TINY, 50, 33, [55, 56], [30000, 17000],
                                               with_blocks=True),
     "bf_small_4s": lambda: run_encode_case("bf_small_4s", BF_SMALL, 5000, 34, [57, 58], [64000, 40000], keep_every=4),
+    # Branchformer merge_method learned_ave (attention-pooled branch weights) and fixed_ave (per-block cgmlp_weight)
+    "bf_learned_ave_4s": lambda: run_encode_case("bf_learned_ave_4s", with_merge(BF_SMALL, "learned_ave"), 50, 47,
+                                                 [72, 73], [64000, 30000], with_blocks=True),
+    "bf_fixed_ave_4s": lambda: run_encode_case("bf_fixed_ave_4s",
+                                               with_merge(BF_SMALL, "fixed_ave", cgmlp_weight=[0.3, 0.65]), 50, 48,
+                                               [74, 75], [64000, 35000], with_blocks=True),
     # other input layers: Conv2dSubsampling6 (5x5 stride-3 second conv) and Conv2dSubsampling8 (third conv)
     "sub6_small_6s": lambda: run_encode_case("sub6_small_6s", with_input_layer(tiny(d=128, heads=2, ff=128), "conv2d6"),
                                              50, 41, [61, 62], [96000, 50000], with_blocks=True),
@@ -665,6 +694,9 @@ CASES = {
     "stream_search_rnnlm": lambda: run_stream_search_case(
         "stream_search_rnnlm", 50, 25, 45, 56000, 10240, 3, 0.4, 3, tweaks=[["decoder.output_layer.bias", 49, 2.0]],
         lm_conf=dict(unit=64, nlayers=1), lm_name="seq_rnn", lm_weight=0.6),
+    "stream_search_gru": lambda: run_stream_search_case(
+        "stream_search_gru", 50, 26, 46, 56000, 10240, 3, 0.4, 3, tweaks=[["decoder.output_layer.bias", 49, 2.0]],
+        lm_conf=dict(unit=64, nlayers=2, rnn_type="gru"), lm_name="seq_rnn", lm_weight=0.6),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

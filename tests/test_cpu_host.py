@@ -34,7 +34,8 @@ def test_no_cpu_fallback():
 
 
 @pytest.mark.parametrize("name", ["tiny_blocks", "small_10s", "large_10s", "tiny_beam5", "ebf_tiny_blocks",
-                                  "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s", "stream_search_a"])
+                                  "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s", "stream_search_a",
+                                  "bf_learned_ave_4s", "bf_fixed_ave_4s"])
 def test_state_dict_table_equals_reference(name):
     from espnet_amd.tasks.asr import ASRTask
 
@@ -51,7 +52,8 @@ def test_state_dict_table_equals_reference(name):
     assert model.sos == model.eos == int(g["vocab"]) - 1 and model.blank_id == 0
 
 
-@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid"])
+@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid", "tiny_beam5_gru", "tiny_beam4_gru_nhid",
+                                  "tiny_beam4_rnn_tanh", "tiny_beam4_rnn_relu"])
 def test_lm_state_dict_table_equals_reference(name):
     """LM scorers expose the reference's own state-dict keys/shapes (espnet2/lm/{transformer_lm,seq_rnn_lm}.py),
     through LMTask's registry names (espnet2/tasks/lm.py:36-44)."""

@@ -22,7 +22,7 @@ def build(g, dtype):
     return model.cuda().eval()
 
 
-@pytest.mark.parametrize("gname", ["ebf_tiny_blocks", "bf_tiny_blocks"])
+@pytest.mark.parametrize("gname", ["ebf_tiny_blocks", "bf_tiny_blocks", "bf_learned_ave_4s", "bf_fixed_ave_4s"])
 def test_state_dict_keys_equal_reference(gname):
     g = load_golden(gname)
     model = build(g, "float32")
@@ -34,7 +34,8 @@ def test_state_dict_keys_equal_reference(gname):
            {k: v for k, v in ref.items() if k.startswith("encoder.")}
 
 
-@pytest.mark.parametrize("name", ["ebf_small_5s", "bf_small_4s", "ebf_sub6_4s", "ebf_legacy_4s"])
+@pytest.mark.parametrize("name", ["ebf_small_5s", "bf_small_4s", "ebf_sub6_4s", "ebf_legacy_4s", "bf_learned_ave_4s",
+                                  "bf_fixed_ave_4s"])
 def test_encode_float32_matches_reference(name):
     g = load_golden(name)
     model = build(g, "float32")
@@ -83,8 +84,60 @@ def test_encode_bfloat16_within_tolerance_and_isolated_rows(gname):
         assert (st.enc_out[b, :T].cpu() - r[0]).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("gname", ["bf_learned_ave_4s", "bf_fixed_ave_4s"])
+def test_branchformer_merge_methods_bfloat16(gname):
+    """merge_method learned_ave / fixed_ave in bf16: relative error of the encoder output vs the fp32 reference."""
+    g = load_golden(gname)
+    speech, lens = golden_speech(g)
+    model = build(g, "bfloat16")
+    enc, olens = model.encode(speech.cuda(), lens)
+    assert olens.tolist() == g["enc_olens"].tolist()
+    ke = int(g["enc_keep_every"])
+    ref = torch.from_numpy(g["enc_out"])
+    for b in range(enc.size(0)):
+        n = (int(olens[b]) + ke - 1) // ke
+        rel = (enc[b, ::ke].cpu()[:n] - ref[b, :n]).norm() / ref[b, :n].norm()
+        assert rel < 3e-2, (b, float(rel))
+
+
 def _dev(t):
     return t.cuda().contiguous()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_branch_learned_ave_against_torch(prec):
+    """em_branch_learned_ave (masked attention pooling of both branches -> softmax of the two scalars ->
+    weighted sum) against the reference's formulation in plain torch fp32 (branchformer_encoder.py:212-270);
+    ragged lengths incl. fewer valid frames than the 4 waves of the pooling workgroup."""
+    from espnet_amd import lib as L
+
+    lib = L.load()
+    dt, tdt, tol = (L.EM_F32, torch.float32, 2e-5) if prec == "f32" else (L.EM_BF16, torch.bfloat16, 2e-2)
+    gen = torch.Generator().manual_seed(11)
+    B, T, d = 3, 50, 192
+    lens = [50, 3, 21]
+    cat = (torch.randn(B, T, 2 * d, generator=gen)).to(tdt)
+    pw, pb = torch.randn(2, d, generator=gen) * 0.3, torch.randn(2, generator=gen)
+    ww, wb = torch.randn(2, d, generator=gen) * 0.3, torch.randn(2, generator=gen)
+    x = cat.float()
+    ws = []
+    for k in range(2):
+        xb = x[..., k * d:(k + 1) * d]
+        score = (F.linear(xb, pw[k:k + 1], pb[k:k + 1]).transpose(1, 2)) / d ** 0.5
+        m = torch.arange(T)[None, None, :] >= torch.tensor(lens)[:, None, None]
+        score = torch.softmax(score.masked_fill(m, torch.finfo(torch.float32).min), -1).masked_fill(m, 0.0)
+        ws.append(F.linear(torch.matmul(score, xb).squeeze(1), ww[k:k + 1], wb[k:k + 1]))
+    raw = torch.cat(ws, -1)
+    mwr = torch.softmax(raw, -1)
+    ref = mwr[:, 0, None, None] * x[..., :d] + mwr[:, 1, None, None] * x[..., d:]
+    catd, ld = _dev(cat), torch.tensor(lens, dtype=torch.int32, device="cuda")
+    mw = torch.empty(B, 2, device="cuda")
+    out = torch.empty(B, T, d, dtype=tdt, device="cuda")
+    args = [_dev(t) for t in (pw, pb, ww, wb)]
+    L.check(lib.em_branch_learned_ave(dt, catd.data_ptr(), ld.data_ptr(), B, T, d, *[a.data_ptr() for a in args],
+                                      mw.data_ptr(), out.data_ptr(), L.current_stream_ptr()), "learned_ave")
+    assert (mw.cpu() - raw).abs().max().item() < 1e-4 * (1 + raw.abs().max().item())
+    assert (out.float().cpu() - ref).abs().max().item() < tol * (1 + ref.abs().max().item())
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])

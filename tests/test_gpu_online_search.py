@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 from tests.helpers import golden_state_dict, load_golden  # noqa: E402
 from tests.test_gpu_search import _sub  # noqa: E402
 
-CASES = ["stream_search_a", "stream_search_b", "stream_search_c", "stream_search_lm", "stream_search_rnnlm"]
+CASES = ["stream_search_a", "stream_search_b", "stream_search_c", "stream_search_lm", "stream_search_rnnlm",
+         "stream_search_gru"]
 
 
 def build_online(g, sd, dtype="float32"):

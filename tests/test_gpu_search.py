@@ -118,7 +118,8 @@ def test_search_f32_matches_reference_nbest(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam60_lm_v300",
-                                  "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid"])
+                                  "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid", "tiny_beam5_gru", "tiny_beam4_gru_nhid",
+                                  "tiny_beam4_rnn_tanh", "tiny_beam4_rnn_relu"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_search_with_lm_scorer_f32_matches_reference_nbest(name, graph):
     """SURVEY §8(f) rank 1: decoder + CTC prefix + TransformerLM scorers fused in the device search;
@@ -136,7 +137,7 @@ def test_search_with_lm_scorer_f32_matches_reference_nbest(name, graph):
             assert hyps[0].yseq.tolist() == g["yseq"][0, : g["yseq_lens"][0]].tolist()
 
 
-@pytest.mark.parametrize("gname", ["tiny_beam4_lm_posenc", "tiny_beam5_rnnlm"])
+@pytest.mark.parametrize("gname", ["tiny_beam4_lm_posenc", "tiny_beam5_rnnlm", "tiny_beam5_gru"])
 def test_search_with_lm_scorer_bf16_and_batched(gname):
     """bf16 LM + decoder: score level vs the fp32 reference, additivity of the per-scorer scores, and
     utterance batching stays transparent with the LM cache / LSTM state in play."""

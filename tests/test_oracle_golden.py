@@ -200,7 +200,8 @@ def test_streaming_encoder_oracle_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam60_lm_v300", "e2e_beam5_lm",
-                                  "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid"])
+                                  "tiny_beam5_rnnlm", "tiny_beam4_rnnlm_nhid", "tiny_beam5_gru", "tiny_beam4_gru_nhid",
+                                  "tiny_beam4_rnn_tanh", "tiny_beam4_rnn_relu"])
 def test_beam_search_with_lm_scorer_matches_reference(name):
     """TransformerLM as a full scorer (lm_weight) — oracle vs reference n-best."""
     import json
@@ -229,7 +230,7 @@ def test_beam_search_with_lm_scorer_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["stream_search_a", "stream_search_b", "stream_search_c", "stream_search_lm",
-                                  "stream_search_rnnlm"])
+                                  "stream_search_rnnlm", "stream_search_gru"])
 def test_online_beam_search_matches_reference_per_call(name):
     """BatchBeamSearchOnline (block-synchronous search with CTC extend_prob /
     extend_state, repetition / local-<eos> breaks, rewind, end detection) — the oracle replays the
@@ -275,7 +276,7 @@ def test_online_beam_search_matches_reference_per_call(name):
 
 
 @pytest.mark.parametrize("name", ["ebf_tiny_blocks", "ebf_small_5s", "bf_tiny_blocks", "bf_small_4s", "ebf_sub6_4s",
-                                  "ebf_legacy_4s"])
+                                  "ebf_legacy_4s", "bf_learned_ave_4s", "bf_fixed_ave_4s"])
 def test_ebranchformer_encoder_matches_reference(name):
     """E-Branchformer (attention + cgMLP branches, depthwise-conv merge) — oracle vs
     the reference's `ESPnetASRModel.encode` with encoder=e_branchformer, incl. per-block outputs."""
@@ -286,7 +287,8 @@ def test_ebranchformer_encoder_matches_reference(name):
     hp = hparams(g)
     speech, lens = golden_speech(g)
     enc, olens = oe.encode(sd, speech, lens, hp["heads"], hp["num_blocks"], hp["n_fft"], hp["win_length"], hp["hop"],
-                           rel_pos_type=g["config"]["encoder_conf"].get("rel_pos_type", "latest"))
+                           rel_pos_type=g["config"]["encoder_conf"].get("rel_pos_type", "latest"),
+                           cgmlp_weight=g["config"]["encoder_conf"].get("cgmlp_weight", 0.5))
     assert olens.tolist() == g["enc_olens"].tolist()
     ke = int(g["enc_keep_every"])
     np.testing.assert_allclose(enc[:, ::ke].numpy(), g["enc_out"], atol=5e-4, rtol=0)
@@ -294,7 +296,8 @@ def test_ebranchformer_encoder_matches_reference(name):
         feats, flens = oc.frontend_feats(speech, lens, sd["frontend.logmel.melmat"], hp["n_fft"], hp["win_length"],
                                          hp["hop"])
         feats = oc.utterance_mvn(feats, flens)
-        _, _, blocks = oe.ebranchformer_encoder(sd, feats, flens, hp["heads"], hp["num_blocks"], return_blocks=True)
+        _, _, blocks = oe.ebranchformer_encoder(sd, feats, flens, hp["heads"], hp["num_blocks"], return_blocks=True,
+                                                cgmlp_weight=g["config"]["encoder_conf"].get("cgmlp_weight", 0.5))
         for i, b in enumerate(blocks):
             np.testing.assert_allclose(b.numpy(), g["block_outs"][i], atol=1e-4, rtol=0)
     ids = oc.ctc_argmax(sd, enc).numpy()
