@@ -104,8 +104,8 @@ class SequentialRNNLM(torch.nn.Module):
             setattr(w, k, v.data_ptr())
         layers = (L.EmRnnLayer * self.nlayers)()
         for l in range(self.nlayers):
-            w_ih, w_hh = (getattr(self.rnn, f"weight_{k}_l{l}").detach().float() for k in ("ih", "hh"))
-            b_ih, b_hh = (getattr(self.rnn, f"bias_{k}_l{l}").detach().float() for k in ("ih", "hh"))
+            w_ih, w_hh = (getattr(self.rnn, f"weight_{k}_l{l}").detach().float().cpu() for k in ("ih", "hh"))
+            b_ih, b_hh = (getattr(self.rnn, f"bias_{k}_l{l}").detach().float().cpu() for k in ("ih", "hh"))
             if self.rnn_type == "GRU":
                 # r | z | n -> r | z | n_x | n_h: the candidate gate's input and hidden parts stay separate
                 # (n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), torch.nn.GRU), zero blocks keep them apart
