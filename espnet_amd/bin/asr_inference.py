@@ -140,20 +140,24 @@ class Speech2Text:
         return self._finish_greedy_host(tokens, tlens)
 
     def _finish_greedy_host(self, tokens, tlens):
+        """Host tensors (B, T) / (B,) of one batch -> reference-shaped results.  One (B, T+2) int64 matrix holds
+        every `yseq` (<sos> ids <eos>); the per-utterance tensors are row views of it."""
         sos, eos = self.asr_model.sos, self.asr_model.eos
-        out = []
-        for b in range(tokens.size(0)):
-            ids = tokens[b, : int(tlens[b])].tolist()
-            yseq = torch.tensor([sos] + ids + [eos], dtype=torch.long)
-            out.append(self._format([Hypothesis(yseq=yseq)]))
-        return out
+        tok, lens = tokens.numpy(), tlens.numpy().tolist()
+        B, T = tok.shape
+        y = np.empty((B, T + 2), dtype=np.int64)
+        y[:, 0] = sos
+        y[:, 1 : T + 1] = tok
+        for b, n in enumerate(lens):
+            y[b, n + 1] = eos
+        yt = torch.from_numpy(y)
+        return [self._format([Hypothesis(yseq=yt[b, : n + 2])]) for b, n in enumerate(lens)]
 
     def _format(self, nbest_hyps):
         """asr_inference.py:652-677: strip sos/eos, drop id 0, ids -> tokens -> text."""
         results = []
         for hyp in nbest_hyps:
-            token_int = hyp.yseq[1:-1].tolist()
-            token_int = list(filter(lambda x: x != 0, token_int))
+            token_int = [x for x in hyp.yseq[1:-1].tolist() if x != 0]
             token = self.converter.ids2tokens(token_int)
             text = self.tokenizer.tokens2text(token) if self.tokenizer is not None else None
             results.append((text, token, token_int, hyp))
@@ -301,7 +305,9 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
     dt = time.perf_counter() - t0
     audio_s = n_samples / fs
     summary = dict(utterances=written, audio_seconds=audio_s, wall_seconds=dt,
-                   rtf=dt / audio_s if audio_s else float("nan"))
+                   rtf=dt / audio_s if audio_s else float("nan"),
+                   native_reader_windows=getattr(loader, "native_windows", 0),
+                   reader_seconds=dict(getattr(getattr(loader, "_wav", None), "seconds", {})))
     logger.info("decoded %d utterances, %.1f audio-s in %.2f s: RTF %.5f (%.0f audio-s/s)", written, audio_s,
                 dt, summary["rtf"], audio_s / dt if dt else float("nan"))
     return summary

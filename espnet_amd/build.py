@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 
 
 def _sources():
-    return sorted(CSRC.glob("*.hip"))
+    return sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.cpp"))  # .cpp: host-only code of the C ABI
 
 
 def _deps_mtime():
@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+        flags = FLAGS if src.suffix == ".hip" else ["-O3", "-std=c++17", "-fPIC", "-pthread"]
+        cmd = [HIPCC, *flags, "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr}")
@@ -54,7 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
     if jobs or not LIB.exists():
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", str(LIB), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -11,6 +11,7 @@ extern "C" const char* em_error_string(int code) {
     case EM_ERR_TOO_SHORT: return "utterance too short for Conv2dSubsampling (needs >= 7 frames)";
     case EM_ERR_LAUNCH: return "HIP kernel launch failed";
     case EM_ERR_WORKSPACE: return "workspace too small";
+    case EM_ERR_IO: return "file I/O failed";
   }
   return "unknown error";
 }

@@ -12,7 +12,7 @@ from pathlib import Path
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libespnet_amd.so"
 
 EM_OK = 0
-EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE = -1, -2, -3, -4, -5
+EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE, EM_ERR_IO = -1, -2, -3, -4, -5, -6
 EM_F32, EM_BF16 = 0, 1
 (EM_EPI_STORE, EM_EPI_SWISH, EM_EPI_RELU, EM_EPI_RESID_F32, EM_EPI_SCALE_F32, EM_EPI_GLU,
  EM_EPI_STORE_F32, EM_EPI_RESID_LN, EM_EPI_SCALE_LN, EM_EPI_ARGMAX_PART, EM_EPI_GELU) = range(11)
@@ -92,6 +92,11 @@ class EmEBranchformerWeights(C.Structure):
                [("layers", C.POINTER(EmEBranchformerLayer)), ("use_ffn", C.c_int32), ("merge_conv", C.c_int32),
                 ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p),
                 ("legacy_relpos", C.c_int32), ("merge_method", C.c_int32)]
+
+
+class EmWavInfo(C.Structure):
+    _fields_ = [("frames", C.c_int64), ("data_offset", C.c_int64), ("rate", C.c_int32), ("channels", C.c_int32),
+                ("bits", C.c_int32), ("format", C.c_int32), ("status", C.c_int32)]
 
 
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",
@@ -183,6 +188,8 @@ _SIGNATURES = {
     "em_ebranchformer_workspace_bytes": (_sz, [C.c_int, C.POINTER(EmEBranchformerWeights), _i32, _i32]),
     "em_ebranchformer_encode": (C.c_int, [C.c_int, C.POINTER(EmEBranchformerWeights), _vp, _vp, _vp, _vp,
                                           _i32, _i32, _vp, _vp, _sz, _vp, _vp, _i32, _vp]),
+    "em_wav_probe": (C.c_int, [C.POINTER(C.c_char_p), _i32, C.POINTER(EmWavInfo), _i32]),
+    "em_wav_load_rows": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(EmWavInfo), _i32, _vp, C.c_int64, _i32]),
     "em_branch_learned_ave": (C.c_int, [C.c_int, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "em_ln_gemm": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "em_dwconv": (C.c_int, [C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp,

@@ -106,7 +106,7 @@ class ASRTask:
             assert model_file is not None
             config_file = Path(model_file).parent / "config.yaml"
         with Path(config_file).open("r", encoding="utf-8") as f:
-            args = argparse.Namespace(**yaml.safe_load(f))
+            args = argparse.Namespace(**yaml.load(f, Loader=getattr(yaml, "CSafeLoader", yaml.SafeLoader)))
         if compute_dtype is not None:
             args.compute_dtype = compute_dtype
         model = cls.build_model(args)
@@ -152,6 +152,8 @@ class ASRTask:
                 data["speech"] = sp
             return data
 
+        # 1-D float samples pass through untouched: the native batch reader may skip the call
+        preprocess.keeps_mono_samples = vol is None
         return preprocess
 
     @classmethod

@@ -35,7 +35,7 @@ class LMTask:
     def build_model_from_file(cls, config_file: Union[Path, str], model_file: Union[Path, str, None] = None,
                               device: str = "cuda", compute_dtype: Optional[str] = None):
         with Path(config_file).open("r", encoding="utf-8") as f:
-            args = argparse.Namespace(**yaml.safe_load(f))
+            args = argparse.Namespace(**yaml.load(f, Loader=getattr(yaml, "CSafeLoader", yaml.SafeLoader)))
         if compute_dtype is not None:
             args.compute_dtype = compute_dtype
         model = cls.build_model(args)

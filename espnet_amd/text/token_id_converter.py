@@ -26,7 +26,8 @@ class TokenIDConverter:
         return len(self.token_list)
 
     def ids2tokens(self, integers) -> List[str]:
-        return [self.token_list[int(i)] for i in integers]
+        tl = self.token_list  # ints, numpy / torch integer scalars all index a list
+        return [tl[i] for i in integers]
 
     def tokens2ids(self, tokens: Iterable[str]) -> List[int]:
         return [self.token2id.get(t, self.unk_id) for t in tokens]

@@ -10,6 +10,10 @@ MI355X-first difference: the reference decodes one utterance per step (`batch_si
 asr_inference.py:760-761).  Here a window of `bucket_window * batch_size` utterances is read ahead by
 a pool of reader threads while the GPU decodes, sorted by length and cut into batches so padding
 waste stays small; `key_order` records the original order so the writer can emit results in it.
+When the data is one `sound` scp of mono RIFF/WAVE files and no preprocessing touches the samples (the
+decode CLI's normal case) the window goes through the native reader (`fileio/sound_scp.WavBatchReader` ->
+`em_wav_probe` / `em_wav_load_rows`, csrc/host_io.cpp): files are decoded by C++ threads directly into
+the pinned batch matrix, with the same values as the Python reader + collate (tests compare bit for bit).
 """
 import queue
 import threading
@@ -121,12 +125,25 @@ def common_collate_fn(data: List[Tuple[str, Dict[str, np.ndarray]]], float_pad_v
     return uids, out
 
 
+def _is_zero_padding_collate(fn) -> bool:
+    """`common_collate_fn`, possibly as a functools.partial (ASRTask.build_collate_fn), padding floats with 0.0."""
+    import functools
+
+    kw = {}
+    while isinstance(fn, functools.partial):
+        if fn.args:
+            return False
+        kw = {**fn.keywords, **kw}
+        fn = fn.func
+    return fn is common_collate_fn and float(kw.get("float_pad_value", 0.0)) == 0.0
+
+
 class StreamingBatchIterator:
     """Iterable of `(keys, batch)`; `key_order` grows with the original key order as windows are read."""
 
     def __init__(self, dataset: IterableESPnetDataset, batch_size: int = 1, bucket_window: int = 8,
                  num_workers: int = 1, collate_fn=common_collate_fn, length_key: Optional[str] = None,
-                 prefetch_batches: int = 4, pin_memory: bool = False):
+                 prefetch_batches: int = 4, pin_memory: bool = False, native_reader: bool = True):
         if batch_size < 1 or bucket_window < 1:
             raise ValueError("batch_size and bucket_window must be >= 1")
         self.dataset, self.batch_size, self.window = dataset, batch_size, batch_size * bucket_window
@@ -134,6 +151,15 @@ class StreamingBatchIterator:
         self.length_key = length_key or dataset.names()[0]
         self.prefetch, self.pin_memory = prefetch_batches, pin_memory
         self.key_order: List[str] = []
+        self.native_windows = 0  # windows served by the native reader (observability / tests)
+        self._wav = None
+        pre = dataset.preprocess
+        if (native_reader and _is_zero_padding_collate(collate_fn) and dataset.float_dtype == "float32"
+                and [(n, k) for _, n, k in dataset.path_name_type_list] == [(self.length_key, "sound")]
+                and (pre is None or getattr(pre, "keeps_mono_samples", False))):
+            from espnet_amd.fileio.sound_scp import WavBatchReader
+
+            self._wav = WavBatchReader(self.num_workers)
 
     def _windows(self):
         buf = []
@@ -145,10 +171,44 @@ class StreamingBatchIterator:
         if buf:
             yield buf
 
+    def _put(self, q, stop, item) -> bool:
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _native_window(self, win, q, stop):
+        """One window through the native reader.  None: not eligible (the Python reader takes the window);
+        False: the consumer stopped; True: every batch of the window is queued."""
+        probed = self._wav.probe([values[0] for _, values in win])
+        if probed is None:
+            return None
+        lens = [int(w.frames) for w in probed[1]]
+        self.key_order.extend(u for u, _ in win)
+        self.native_windows += 1
+        order = sorted(range(len(win)), key=lambda i: -lens[i])  # as below: longest first, stable
+        for s in range(0, len(order), self.batch_size):
+            idx = order[s : s + self.batch_size]
+            speech, blens = self._wav.load(probed, idx, self.pin_memory)
+            batch = {self.length_key: speech,
+                     self.length_key + "_lengths": torch.tensor(blens, dtype=torch.long)}
+            if not self._put(q, stop, ([win[i][0] for i in idx], batch)):
+                return False
+        return True
+
     def _produce(self, q: "queue.Queue", stop: threading.Event):
         try:
             with ThreadPoolExecutor(self.num_workers) as pool:
                 for win in self._windows():
+                    if self._wav is not None:
+                        done = self._native_window(win, q, stop)
+                        if done is False:
+                            return
+                        if done:
+                            continue
                     loaded = list(pool.map(lambda e: (e[0], self.dataset.load(*e)), win))
                     self.key_order.extend(u for u, _ in loaded)
                     # longest first, ties in file order (stable): batches of near-equal length
@@ -157,13 +217,7 @@ class StreamingBatchIterator:
                         keys, batch = self.collate_fn([loaded[i] for i in order[s : s + self.batch_size]])
                         if self.pin_memory:
                             batch = {k: v.pin_memory() for k, v in batch.items()}
-                        while not stop.is_set():
-                            try:
-                                q.put((keys, batch), timeout=0.1)
-                                break
-                            except queue.Full:
-                                continue
-                        if stop.is_set():
+                        if not self._put(q, stop, (keys, batch)):
                             return
             q.put(None)
         except BaseException as e:  # surface reader errors in the consumer

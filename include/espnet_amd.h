@@ -30,6 +30,7 @@ extern "C" {
 #define EM_ERR_TOO_SHORT (-3) /* < 7 feature frames: TooShortUttError, subsampling.py:31-49 */
 #define EM_ERR_LAUNCH (-4)    /* hipGetLastError() != hipSuccess after a launch */
 #define EM_ERR_WORKSPACE (-5) /* workspace too small */
+#define EM_ERR_IO (-6)        /* host file I/O failed (em_wav_*) */
 
 #define EM_F32 0
 #define EM_BF16 1
@@ -644,6 +645,27 @@ int em_profile_read(EmProfile* prof, float* ms, double* flops, int32_t max_n, in
 
 /* f32 -> act dtype copy (lets reference-shaped f32 entry points feed the act-dtype GEMMs) */
 int em_cast_f32(int dtype, const float* src, size_t n, void* dst, void* stream);
+
+/* ---- host audio reader of the decode CLI (host code only, no GPU needed):
+ *      `soundfile.read(path, dtype=float32)` of espnet2/fileio/sound_scp.py:13-155 / the `sound` entry of
+ *      espnet2/train/iterable_dataset.py:44-67, fused with CommonCollateFn's zero padding
+ *      (espnet2/train/collate_fn.py:17-95): every file is decoded straight into its row of the batch matrix.
+ *      Handled: RIFF/WAVE, mono, PCM 8/16/24/32-bit (value / 2^(bits-1), 8-bit unsigned offset 128) and IEEE
+ *      float 32/64.  Anything else sets that file's status to EM_ERR_UNSUPPORTED (EM_ERR_IO if unreadable) and
+ *      the caller reads it through the Python reader (espnet_amd/fileio/sound_scp.py), which names the problem. */
+typedef struct EmWavInfo {
+  int64_t frames;      /* samples per channel in the data chunk (clipped to the file size) */
+  int64_t data_offset; /* byte offset of the first sample */
+  int32_t rate, channels, bits;
+  int32_t format;      /* WAVE format tag: 1 PCM, 3 IEEE float (WAVE_FORMAT_EXTENSIBLE resolved) */
+  int32_t status;      /* EM_OK or the EM_ERR_* code of this file */
+} EmWavInfo;
+/*   Parse the headers of n files (paths: NUL-terminated strings) with up to `threads` threads.  Returns EM_OK
+ *   or one of the per-file error codes; info[i].status tells which files.                                    */
+int em_wav_probe(const char* const* paths, int32_t n, EmWavInfo* info, int32_t threads);
+/*   out [n][ld] f32: row i <- the info[i].frames samples of file i, zero filled up to ld (>= every frames).   */
+int em_wav_load_rows(const char* const* paths, const EmWavInfo* info, int32_t n, float* out, int64_t ld,
+                     int32_t threads);
 
 #ifdef __cplusplus
 }

@@ -172,6 +172,97 @@ def test_iterator_surfaces_reader_errors(tmp_path):
         list(it)
 
 
+def _riff(fmt_tag, nch, rate, bits, body, extensible=False, junk=b"", data_size=None):
+    blk = nch * bits // 8
+    if extensible:  # WAVE_FORMAT_EXTENSIBLE: the real tag sits in the SubFormat GUID
+        fmt = struct.pack("<HHIIHH", 0xFFFE, nch, rate, rate * blk, blk, bits) + struct.pack("<HHI", 22, bits, 0) \
+              + struct.pack("<H", fmt_tag) + b"\x00" * 14
+    else:
+        fmt = struct.pack("<HHIIHH", fmt_tag, nch, rate, rate * blk, blk, bits)
+    riff = b"WAVE" + junk + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + \
+           struct.pack("<I", len(body) if data_size is None else data_size) + body
+    return b"RIFF" + struct.pack("<I", len(riff)) + riff
+
+
+def _wav_zoo(tmp_path):
+    """Mono wavs of every sample format the readers take, plus awkward containers; returns scp lines."""
+    rng = np.random.default_rng(5)
+    junk = b"LIST" + struct.pack("<I", 3) + b"abc" + b"\x00"
+    files = {
+        "pcm16_a": _riff(1, 1, 16000, 16, rng.integers(-32768, 32768, 4001).astype("<i2").tobytes()),
+        "pcm16_ext": _riff(1, 1, 16000, 16, rng.integers(-32768, 32768, 2500).astype("<i2").tobytes(), extensible=True),
+        "pcm8": _riff(1, 1, 8000, 8, rng.integers(0, 256, 1777).astype(np.uint8).tobytes(), junk=junk),
+        "pcm24": _riff(1, 1, 16000, 24, b"".join(int(v).to_bytes(3, "little", signed=True)
+                                                  for v in rng.integers(-2 ** 23, 2 ** 23, 1234))),
+        "pcm32": _riff(1, 1, 16000, 32, rng.integers(-2 ** 31, 2 ** 31, 999).astype("<i4").tobytes()),
+        "f32": _riff(3, 1, 16000, 32, rng.normal(0, 0.3, 3100).astype("<f4").tobytes()),
+        "f64": _riff(3, 1, 16000, 64, rng.normal(0, 0.3, 2100).astype("<f8").tobytes()),
+        "trunc": _riff(1, 1, 16000, 16, rng.integers(-32768, 32768, 700).astype("<i2").tobytes(), data_size=4000),
+        "pcm16_b": _riff(1, 1, 16000, 16, rng.integers(-32768, 32768, 4001).astype("<i2").tobytes()),
+        "empty": _riff(1, 1, 16000, 16, b""),
+    }
+    lines = []
+    for k, blob in files.items():
+        (tmp_path / f"{k}.wav").write_bytes(blob)
+        lines.append(f"{k} {tmp_path / f'{k}.wav'}")
+    return lines
+
+
+@pytest.mark.parametrize("batch_size,window,workers", [(4, 8, 3), (3, 1, 1), (16, 1, 2)])
+def test_native_wav_reader_equals_python_reader_bit_for_bit(tmp_path, batch_size, window, workers):
+    """em_wav_probe / em_wav_load_rows (csrc/host_io.cpp) behind StreamingBatchIterator: same batches, keys,
+    lengths and sample VALUES (incl. the zero padding) as read_wav + common_collate_fn, for every PCM width,
+    IEEE float, WAVE_FORMAT_EXTENSIBLE, extra chunks, a truncated data chunk and an empty file."""
+    (tmp_path / "wav.scp").write_text("\n".join(_wav_zoo(tmp_path)) + "\n")
+    spec = [(str(tmp_path / "wav.scp"), "speech", "sound")]
+    runs = []
+    for native in (True, False):
+        it = StreamingBatchIterator(IterableESPnetDataset(spec), batch_size=batch_size, bucket_window=window,
+                                    num_workers=workers, native_reader=native)
+        runs.append(([(k, {n: v.clone() for n, v in b.items()}) for k, b in it], it.key_order, it.native_windows))
+    (nat, nat_order, nat_windows), (ref, ref_order, ref_windows) = runs
+    assert nat_windows == -(-10 // (batch_size * window)) and ref_windows == 0
+    assert nat_order == ref_order and len(nat) == len(ref)
+    for (k1, b1), (k2, b2) in zip(nat, ref):
+        assert k1 == k2 and set(b1) == set(b2) == {"speech", "speech_lengths"}
+        assert b1["speech"].dtype == b2["speech"].dtype and b1["speech_lengths"].dtype == b2["speech_lengths"].dtype
+        assert b1["speech_lengths"].tolist() == b2["speech_lengths"].tolist()
+        assert b1["speech"].shape == b2["speech"].shape
+        assert np.array_equal(b1["speech"].numpy().view(np.uint32), b2["speech"].numpy().view(np.uint32))
+
+
+def test_native_wav_reader_leaves_other_inputs_to_the_python_reader(tmp_path):
+    """Stereo / non-wav / missing files, a preprocessor that changes samples, npy entries: the window is read by
+    the Python path (same results and the same descriptive errors as before)."""
+    from espnet_amd.tasks.asr import ASRTask
+
+    lines = _wav_zoo(tmp_path)[:3]
+    st = np.random.default_rng(1).integers(-32768, 32768, (300, 2)).astype("<i2")
+    (tmp_path / "stereo.wav").write_bytes(_riff(1, 2, 16000, 16, st.tobytes()))
+    (tmp_path / "wav.scp").write_text("\n".join(lines + [f"st {tmp_path / 'stereo.wav'}"]) + "\n")
+    spec = [(str(tmp_path / "wav.scp"), "speech", "sound")]
+    it = StreamingBatchIterator(IterableESPnetDataset(spec), batch_size=1, bucket_window=8)
+    got = dict((k[0], b["speech"]) for k, b in it)
+    assert it.native_windows == 0 and got["st"].shape == (1, 300, 2)
+    np.testing.assert_array_equal(got["st"][0].numpy(), st.astype(np.float32) / 32768)
+    # volume normalisation rewrites the samples -> not eligible; the identity preprocessor is
+    for vol, want in ((0.5, 0), (None, 1)):
+        pre = ASRTask.build_preprocess_fn(dict(use_preprocessor=True, speech_volume_normalize=vol), False)
+        (tmp_path / "wav.scp").write_text("\n".join(lines) + "\n")
+        it = StreamingBatchIterator(IterableESPnetDataset(spec, preprocess=pre), batch_size=2, bucket_window=8,
+                                    collate_fn=ASRTask.build_collate_fn(None, False))  # the CLI's partial
+        out = list(it)
+        assert it.native_windows == want and sum(len(k) for k, _ in out) == 3
+    # a missing file surfaces the Python reader's error
+    (tmp_path / "wav.scp").write_text(f"gone {tmp_path / 'gone.wav'}\n")
+    with pytest.raises(FileNotFoundError):
+        list(StreamingBatchIterator(IterableESPnetDataset(spec), batch_size=1))
+    (tmp_path / "a.flac").write_bytes(b"fLaC" + b"\0" * 40)
+    (tmp_path / "wav.scp").write_text(f"fl {tmp_path / 'a.flac'}\n")
+    with pytest.raises(NotImplementedError):
+        list(StreamingBatchIterator(IterableESPnetDataset(spec), batch_size=1))
+
+
 def test_parser_matches_reference_option_table():
     """Every option of the reference CLI is accepted; defaults are the reference's except the three
     documented ones (ngpu: no CPU path; dtype: MFMA mode names; token_type also lists "word")."""
