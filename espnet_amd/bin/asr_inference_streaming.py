@@ -217,3 +217,165 @@ class Speech2TextStreaming:
             text = self.tokenizer.tokens2text(token) if self.tokenizer is not None else None
             results.append((text, token, token_int, hyp))
         return results
+
+
+# ---------------------------------------------------------------------- streaming decode CLI (asr.sh stage 12,
+# `use_streaming=true`: python -m espnet2.bin.asr_inference_streaming)
+def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.0, batch_size: int = 1,
+              dtype: str = "bfloat16", beam_size: int = 20, ngpu: int = 1, seed: int = 0, ctc_weight: float = 0.5,
+              lm_weight: float = 1.0, penalty: float = 0.0, nbest: int = 1, normalize_length: bool = False,
+              num_workers: int = 1, log_level: Union[int, str] = "INFO", data_path_and_name_and_type=None,
+              key_file: Optional[str] = None, asr_train_config: Optional[str] = None,
+              asr_model_file: Optional[str] = None, lm_train_config: Optional[str] = None,
+              lm_file: Optional[str] = None, word_lm_train_config: Optional[str] = None,
+              word_lm_file: Optional[str] = None, token_type: Optional[str] = None, bpemodel: Optional[str] = None,
+              allow_variable_data_keys: bool = False, sim_chunk_length: int = 0,
+              disable_repetition_detection: bool = False, encoded_feat_length_limit: int = 0,
+              decoder_text_length_limit: int = 0):
+    """The reference's streaming `inference()` (espnet2/bin/asr_inference_streaming.py:362-494): one utterance at
+    a time in input order, fed to `Speech2TextStreaming` whole (`sim_chunk_length == 0`) or in simulated chunks of
+    `sim_chunk_length` samples with the remainder as the final call (:462-475); same result files and the same
+    TooShortUttError placeholder (:476-479).  Returns an RTF summary like the offline CLI."""
+    import time
+
+    from espnet_amd.fileio.datadir_writer import DatadirWriter
+    from espnet_amd.lib import TooShortUttError
+
+    if batch_size > 1:
+        raise NotImplementedError("batch decoding is not implemented")
+    if word_lm_train_config is not None:
+        raise NotImplementedError("Word LM is not implemented")
+    if ngpu > 1:
+        raise NotImplementedError("only single GPU decoding is supported")
+    if ngpu < 1:
+        raise RuntimeError("espnet_amd decodes on an MI355X only: pass --ngpu 1 (no CPU fallback)")
+    logging.basicConfig(level=log_level,
+                        format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    speech2text = Speech2TextStreaming(
+        asr_train_config=asr_train_config, asr_model_file=asr_model_file, lm_train_config=lm_train_config,
+        lm_file=lm_file, token_type=token_type, bpemodel=bpemodel, device="cuda", maxlenratio=maxlenratio,
+        minlenratio=minlenratio, dtype=dtype, beam_size=beam_size, ctc_weight=ctc_weight, lm_weight=lm_weight,
+        penalty=penalty, nbest=nbest, normalize_length=normalize_length,
+        disable_repetition_detection=disable_repetition_detection,
+        decoder_text_length_limit=decoder_text_length_limit, encoded_feat_length_limit=encoded_feat_length_limit)
+    loader = ASRTask.build_streaming_iterator(
+        data_path_and_name_and_type, dtype="float32", batch_size=1, key_file=key_file, num_workers=num_workers,
+        preprocess_fn=ASRTask.build_preprocess_fn(speech2text.asr_train_args, False),
+        collate_fn=ASRTask.build_collate_fn(speech2text.asr_train_args, False),
+        allow_variable_data_keys=allow_variable_data_keys, inference=True, ngpu=ngpu,
+        bucket_window=1)  # a window of one utterance: results leave in input order, as the reference writes them
+    fs = 16000
+    fconf = getattr(speech2text.asr_train_args, "frontend_conf", None) or {}
+    if isinstance(fconf.get("fs", None), int):
+        fs = fconf["fs"]
+    n_utts, n_samples = 0, 0
+    t0 = time.perf_counter()
+    with DatadirWriter(output_dir) as writer:
+        for keys, batch in loader:
+            assert all(isinstance(s, str) for s in keys), keys
+            assert len(keys) == 1 == batch["speech"].size(0), keys
+            speech = batch["speech"][0]
+            try:
+                if sim_chunk_length == 0:
+                    results = speech2text(speech=speech, is_final=True)
+                else:
+                    n_full = len(speech) // sim_chunk_length
+                    for i in range(n_full):
+                        speech2text(speech=speech[i * sim_chunk_length : (i + 1) * sim_chunk_length],
+                                    is_final=False)
+                    # the remainder (possibly empty) closes the utterance; an utterance shorter than one
+                    # chunk is a single final call (the reference's loop variable is undefined there)
+                    results = speech2text(speech=speech[n_full * sim_chunk_length :], is_final=True)
+            except TooShortUttError as e:
+                logger.warning(f"Utterance {keys} {e}")
+                speech2text.reset()
+                hyp = Hypothesis(score=0.0, scores={}, states={}, yseq=[])
+                results = [[" ", ["<space>"], [2], hyp]] * nbest
+            key = keys[0]
+            for n, (text, token, token_int, hyp) in zip(range(1, nbest + 1), results):
+                w = writer[f"{n}best_recog"]
+                w["token"][key] = " ".join(token)
+                w["token_int"][key] = " ".join(map(str, token_int))
+                w["score"][key] = str(hyp.score)
+                if text is not None:
+                    w["text"][key] = text
+            n_utts += 1
+            n_samples += len(speech)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    audio_s = n_samples / fs
+    summary = dict(utterances=n_utts, audio_seconds=audio_s, wall_seconds=dt,
+                   rtf=dt / audio_s if audio_s else float("nan"))
+    logger.info("decoded %d utterances, %.1f audio-s in %.2f s: RTF %.5f", n_utts, audio_s, dt, summary["rtf"])
+    return summary
+
+
+def get_parser():
+    """Option names, types and defaults of espnet2/bin/asr_inference_streaming.py:497-629 (`--config` yaml files
+    work like config_argparse).  Differences, as in the offline CLI: `--ngpu` defaults to 1 (there is no CPU
+    path), `--dtype` names the MFMA mode, `asr_model_file` is optional (random init when omitted)."""
+    import argparse
+
+    from espnet_amd.bin.asr_inference import _str2bool, _str2triple_str, _str_or_none
+
+    p = argparse.ArgumentParser(description="ASR Decoding (MI355X, streaming)",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--config", type=str, default=None, help="yaml file with option defaults")
+    p.add_argument("--log_level", type=lambda x: x.upper(), default="INFO",
+                   choices=("CRITICAL", "ERROR", "WARNING", "INFO", "DEBUG", "NOTSET"))
+    p.add_argument("--output_dir", type=str, required=True)
+    p.add_argument("--ngpu", type=int, default=1, help="must be 1: one MI355X per process")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"],
+                   help="MFMA mode of the encoder/decoder (float32 = exact-f32 MFMA)")
+    p.add_argument("--num_workers", type=int, default=1, help="audio reader threads")
+    g = p.add_argument_group("Input data related")
+    g.add_argument("--data_path_and_name_and_type", type=_str2triple_str, required=True, action="append")
+    g.add_argument("--key_file", type=_str_or_none)
+    g.add_argument("--allow_variable_data_keys", type=_str2bool, default=False)
+    g.add_argument("--sim_chunk_length", type=int, default=0,
+                   help="The length of one chunk, to which speech will be divided for evaluation of streaming "
+                        "processing.")
+    g = p.add_argument_group("The model configuration related")
+    g.add_argument("--asr_train_config", type=str, required=True)
+    for name in ("asr_model_file", "lm_train_config", "lm_file", "word_lm_train_config", "word_lm_file"):
+        g.add_argument(f"--{name}", type=str)
+    g = p.add_argument_group("Beam-search related")
+    g.add_argument("--batch_size", type=int, default=1)
+    g.add_argument("--nbest", type=int, default=1)
+    g.add_argument("--beam_size", type=int, default=20)
+    g.add_argument("--penalty", type=float, default=0.0)
+    g.add_argument("--maxlenratio", type=float, default=0.0)
+    g.add_argument("--minlenratio", type=float, default=0.0)
+    g.add_argument("--ctc_weight", type=float, default=0.5)
+    g.add_argument("--lm_weight", type=float, default=1.0)
+    g.add_argument("--disable_repetition_detection", type=_str2bool, default=False)
+    g.add_argument("--encoded_feat_length_limit", type=int, default=0)
+    g.add_argument("--decoder_text_length_limit", type=int, default=0)
+    g = p.add_argument_group("Text converter related")
+    g.add_argument("--token_type", type=_str_or_none, default=None, choices=["char", "bpe", "word", None])
+    g.add_argument("--bpemodel", type=_str_or_none, default=None)
+    g.add_argument("--normalize_length", type=_str2bool, default=False)
+    return p
+
+
+def main(cmd=None):
+    import sys
+
+    import yaml
+
+    print(" ".join(sys.argv), file=sys.stderr)
+    parser = get_parser()
+    pre, _ = parser.parse_known_args(cmd)
+    if pre.config is not None:  # config_argparse: yaml values become defaults, flags still win
+        with open(pre.config, encoding="utf-8") as f:
+            parser.set_defaults(**(yaml.safe_load(f) or {}))
+    kwargs = vars(parser.parse_args(cmd))
+    kwargs.pop("config", None)
+    return inference(**kwargs)
+
+
+if __name__ == "__main__":
+    main()

@@ -700,6 +700,21 @@ CASES = {
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 
+def dump_cli_options(module: str, out_name: str):
+    """Option table (dest -> default / required / choices) of a reference decode CLI's `get_parser()`."""
+    import importlib
+
+    parser = importlib.import_module(module).get_parser()
+    table = {a.dest: dict(default=a.default, required=a.required, choices=list(a.choices) if a.choices else None)
+             for a in parser._actions if a.dest != "help"}
+    (HERE / out_name).write_text(json.dumps(table, indent=1, sort_keys=True, default=str) + "\n")
+    print(f"[{out_name}] {len(table)} options")
+
+
+CASES["cli_options"] = lambda: dump_cli_options("espnet2.bin.asr_inference", "asr_inference_cli_options.json")
+CASES["cli_options_streaming"] = lambda: dump_cli_options("espnet2.bin.asr_inference_streaming",
+                                                          "asr_inference_streaming_cli_options.json")
+
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 1)
     names = sys.argv[1:] or list(CASES)

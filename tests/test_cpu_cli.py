@@ -361,3 +361,92 @@ def test_inference_loop_orders_outputs_and_handles_short_utterances(tmp_path, mo
     asyncs = [c[1] for c in calls if c[0] == "async"]
     assert all(b == sorted(b, reverse=True) for b in asyncs) and max(len(b) for b in asyncs) <= 4
     assert any(c[0] == "sync" for c in calls)
+
+
+def test_streaming_parser_matches_reference_option_table():
+    """Every option of the reference's streaming decode CLI (espnet2/bin/asr_inference_streaming.py:497-629) is
+    accepted with the reference default, except the documented ones (ngpu, dtype, optional asr_model_file,
+    token_type also lists "word")."""
+    from espnet_amd.bin.asr_inference_streaming import get_parser
+
+    ref = json.loads((GOLD / "asr_inference_streaming_cli_options.json").read_text())
+    mine = {a.dest: a for a in get_parser()._actions if a.dest != "help"}
+    assert set(ref) == set(mine), set(ref) ^ set(mine)
+    for name, r in ref.items():
+        a = mine[name]
+        if name in ("ngpu", "dtype"):
+            continue
+        assert a.required == (r["required"] and name != "asr_model_file"), name
+        assert a.default == r["default"], (name, a.default, r["default"])
+    assert mine["ngpu"].default == 1 and mine["dtype"].default == "bfloat16"
+
+
+def test_streaming_inference_loop_chunks_like_the_reference(tmp_path, monkeypatch):
+    """`asr_inference_streaming.inference()` on the CPU with a stand-in Speech2TextStreaming: input order, the
+    sim_chunk_length split (full chunks with is_final=False, the remainder — possibly empty — as the final call,
+    asr_inference_streaming.py:462-475), an utterance shorter than one chunk, the TooShortUttError placeholder."""
+    import argparse
+
+    import torch
+
+    from espnet_amd.bin import asr_inference_streaming as st
+    from espnet_amd.lib import TooShortUttError
+    from espnet_amd.nets.beam_search import Hypothesis
+
+    lens = [2500, 400, 3000, 90, 1000]
+    lines = []
+    for i, n in enumerate(lens):
+        x = (np.arange(n) % 100 / 128.0 + i / 8.0 - 0.5).astype(np.float32)
+        write_wav_pcm16(tmp_path / f"u{i}.wav", x, 16000)
+        lines.append(f"utt{i} {tmp_path / f'u{i}.wav'}")
+    (tmp_path / "wav.scp").write_text("\n".join(lines) + "\n")
+    log = []
+
+    class FakeStreaming:
+        asr_train_args = argparse.Namespace(frontend_conf=dict(fs=16000), use_preprocessor=True, preprocessor_conf={})
+
+        def __init__(self, **kw):
+            self.kw, self.buf = kw, []
+
+        def reset(self):
+            self.buf = []
+
+        def __call__(self, speech, is_final=True):
+            assert isinstance(speech, torch.Tensor) and speech.dim() == 1
+            self.buf.append(speech.clone())
+            log.append((len(speech), is_final))
+            if not is_final:
+                return []
+            whole = torch.cat(self.buf)
+            self.buf = []
+            if len(whole) < 100:
+                raise TooShortUttError("has 3 frames and is too short for subsampling", 3, 7)
+            ids = [len(whole) % 41 + 3, int(round(float(whole[0] + 0.5) * 8)) + 3]
+            return [(f"t{ids[0]} t{ids[1]}", [f"t{v}" for v in ids], ids,
+                     Hypothesis(yseq=torch.tensor([49] + ids + [49]), score=torch.tensor(-1.5)))]
+
+    monkeypatch.setattr(st, "Speech2TextStreaming", FakeStreaming)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)
+    common = dict(data_path_and_name_and_type=[(str(tmp_path / "wav.scp"), "speech", "sound")],
+                  asr_train_config=None, asr_model_file=None, log_level="ERROR", num_workers=2)
+    for chunk in (0, 1000):
+        log.clear()
+        out = tmp_path / f"out{chunk}"
+        s = st.inference(output_dir=str(out), sim_chunk_length=chunk, **common)
+        assert s["utterances"] == len(lens) and abs(s["audio_seconds"] - sum(lens) / 16000) < 1e-9
+        tok = (out / "1best_recog/token_int").read_text().splitlines()
+        assert [ln.split()[0] for ln in tok] == [f"utt{i}" for i in range(len(lens))]
+        for i, n in enumerate(lens):
+            want = "2" if n < 100 else f"{n % 41 + 3} {i + 3}"  # the chunks were reassembled in order
+            assert tok[i] == f"utt{i} {want}", (chunk, tok[i])
+        assert (out / "1best_recog/text").read_text().splitlines()[3] == "utt3  "
+        if chunk == 0:
+            assert log == [(n, True) for n in lens]
+        else:
+            assert log == [(1000, False), (1000, False), (500, True), (400, True), (1000, False), (1000, False),
+                           (1000, False), (0, True), (90, True), (1000, False), (0, True)]
+    with pytest.raises(NotImplementedError):
+        st.inference(output_dir=str(tmp_path / "x"), batch_size=2, **common)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        st.inference(output_dir=str(tmp_path / "x"), ngpu=0, **common)

@@ -95,3 +95,57 @@ def test_cli_batching_is_transparent_and_bf16_runs(tmp_path):
     assert len(bf["1best_recog/token_int"].splitlines()) == len(one["1best_recog/token_int"].splitlines())
     _, gr = _run(tmp_path, "g1", "--batch_size", "4", "--ctc_greedy", "true", "--nbest", "1")
     assert set(gr) == {"1best_recog/score", "1best_recog/text", "1best_recog/token", "1best_recog/token_int"}
+
+
+def test_streaming_cli_equals_the_object_api(tmp_path):
+    """`python -m espnet_amd.bin.asr_inference_streaming` (espnet2/bin/asr_inference_streaming.py:362-494): the
+    result files equal what feeding `Speech2TextStreaming` the same chunks by hand gives (the object API is what
+    tests/test_gpu_online_search.py pins against the reference's per-call goldens), for whole-utterance calls and
+    for simulated chunks, in input order."""
+    from espnet_amd.bin.asr_inference_streaming import Speech2TextStreaming, main
+    from espnet_amd.fileio.sound_scp import read_wav, write_wav_pcm16
+    from oracle.weights import synth_waveform
+
+    g = load_golden("stream_search_a")
+    (tmp_path / "config.yaml").write_text(str(g["config_yaml"]))
+    torch.save(golden_state_dict(g), tmp_path / "model.pth")
+    n0, chunk = int(g["n_samples"]), int(g["chunk_samples"])
+    utts = [("b_long", int(g["utt_id"]), n0), ("a_short", int(g["utt_id"]) + 1, n0 // 2 + 123)]
+    lines = []
+    for key, u, n in utts:
+        write_wav_pcm16(tmp_path / f"{key}.wav", synth_waveform(u, n).numpy(), 16000)
+        lines.append(f"{key} {tmp_path / (key + '.wav')}")
+    (tmp_path / "wav.scp").write_text("\n".join(lines) + "\n")
+    opts = dict(beam_size=int(g["beam"]), ctc_weight=float(g["ctc_weight"]), penalty=float(g["penalty"]),
+                nbest=int(g["nbest"]), disable_repetition_detection=bool(g["disable_repetition_detection"]))
+    s2t = Speech2TextStreaming(str(tmp_path / "config.yaml"), str(tmp_path / "model.pth"), device="cuda",
+                               dtype="float32", **opts)
+    for sim in (0, chunk):
+        out = tmp_path / f"out{sim}"
+        summary = main(["--output_dir", str(out), "--ngpu", "1", "--dtype", "float32",
+                        "--data_path_and_name_and_type", f"{tmp_path / 'wav.scp'},speech,sound",
+                        "--asr_train_config", str(tmp_path / "config.yaml"),
+                        "--asr_model_file", str(tmp_path / "model.pth"), "--sim_chunk_length", str(sim),
+                        "--beam_size", str(opts["beam_size"]), "--ctc_weight", str(opts["ctc_weight"]),
+                        "--penalty", str(opts["penalty"]), "--nbest", str(opts["nbest"]),
+                        "--disable_repetition_detection", str(opts["disable_repetition_detection"]),
+                        "--log_level", "WARNING"])
+        assert summary["utterances"] == 2
+        tok = (out / "1best_recog/token_int").read_text().splitlines()
+        score = (out / "1best_recog/score").read_text().splitlines()
+        assert [ln.split()[0] for ln in tok] == ["b_long", "a_short"]  # input order
+        for i, (key, _, n) in enumerate(utts):
+            wav = torch.from_numpy(read_wav(tmp_path / f"{key}.wav", dtype="float32")[0])
+            if sim == 0:
+                res = s2t(wav, is_final=True)
+            else:
+                k = n // sim
+                for j in range(k):
+                    s2t(wav[j * sim : (j + 1) * sim], is_final=False)
+                res = s2t(wav[k * sim :], is_final=True)
+            assert res, key
+            assert tok[i] == f"{key} " + " ".join(map(str, res[0][2])), (sim, key)
+            import re
+
+            written = float(re.search(r"-?\d+\.?\d*(e[-+]?\d+)?", score[i].split(maxsplit=1)[1]).group(0))
+            assert abs(written - float(res[0][3].score)) < 1e-3 + 1e-5 * abs(written), (sim, key)
