@@ -36,7 +36,7 @@ class ESPnetASRModel(torch.nn.Module):
                  sym_blank: str = "<blank>", transducer_multi_blank_durations: List = [],
                  transducer_multi_blank_sigma: float = 0.05, sym_sos: str = "<sos/eos>",
                  sym_eos: str = "<sos/eos>", extract_feats_in_collect_stats: bool = True,
-                 lang_token_id: int = -1):
+                 lang_token_id: int = -1, autocast_frontend: bool = False):
         assert 0.0 <= ctc_weight <= 1.0, ctc_weight
         assert 0.0 <= interctc_weight < 1.0, interctc_weight
         super().__init__()

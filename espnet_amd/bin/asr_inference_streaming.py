@@ -39,7 +39,7 @@ class Speech2TextStreaming:
                  lm_train_config=None, lm_file=None, token_type: Optional[str] = None,
                  bpemodel: Optional[str] = None, device: str = "cuda", maxlenratio: float = 0.0,
                  minlenratio: float = 0.0, batch_size: int = 1, dtype: str = "float32",
-                 beam_size: int = 1, ctc_weight: float = 0.5, lm_weight: float = 0.0,
+                 beam_size: int = 20, ctc_weight: float = 0.5, lm_weight: float = 1.0,
                  penalty: float = 0.0, nbest: int = 1, disable_repetition_detection: bool = False,
                  decoder_text_length_limit: int = 0, encoded_feat_length_limit: int = 0,
                  normalize_length: bool = False, use_hipgraph: bool = True, search: Optional[str] = None):

@@ -711,6 +711,54 @@ def dump_cli_options(module: str, out_name: str):
     print(f"[{out_name}] {len(table)} options")
 
 
+API_TARGETS = [  # (reference dotted path, attribute) -> espnet_amd counterpart is listed in tests/test_cpu_host.py
+    ("espnet2.bin.asr_inference", "Speech2Text.__init__"), ("espnet2.bin.asr_inference", "Speech2Text.__call__"),
+    ("espnet2.bin.asr_inference", "inference"),
+    ("espnet2.bin.asr_inference_streaming", "Speech2TextStreaming.__init__"),
+    ("espnet2.bin.asr_inference_streaming", "Speech2TextStreaming.__call__"),
+    ("espnet2.bin.asr_inference_streaming", "inference"),
+    ("espnet2.asr.espnet_model", "ESPnetASRModel.__init__"), ("espnet2.asr.espnet_model", "ESPnetASRModel.encode"),
+    ("espnet2.asr.frontend.default", "DefaultFrontend.__init__"),
+    ("espnet2.asr.encoder.conformer_encoder", "ConformerEncoder.__init__"),
+    ("espnet2.asr.encoder.e_branchformer_encoder", "EBranchformerEncoder.__init__"),
+    ("espnet2.asr.encoder.branchformer_encoder", "BranchformerEncoder.__init__"),
+    ("espnet2.asr.encoder.contextual_block_conformer_encoder", "ContextualBlockConformerEncoder.__init__"),
+    ("espnet2.asr.decoder.transformer_decoder", "TransformerDecoder.__init__"),
+    ("espnet2.asr.ctc", "CTC.__init__"),
+    ("espnet2.lm.transformer_lm", "TransformerLM.__init__"), ("espnet2.lm.seq_rnn_lm", "SequentialRNNLM.__init__"),
+    ("espnet2.legacy.nets.beam_search", "BeamSearch.__init__"),
+    ("espnet2.legacy.nets.batch_beam_search_online", "BatchBeamSearchOnline.__init__"),
+]
+
+
+def dump_api_signatures():
+    """Parameter names and (JSON-representable) defaults of the reference callables the drop-in mirrors."""
+    import importlib
+    import inspect
+
+    table = {}
+    for mod, attr in API_TARGETS:
+        obj = importlib.import_module(mod)
+        for part in attr.split("."):
+            obj = getattr(obj, part)
+        obj = inspect.unwrap(obj)
+        params = {}
+        for name, p in inspect.signature(obj).parameters.items():
+            if name == "self" or p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD):
+                continue
+            d = p.default
+            if d is inspect.Parameter.empty:
+                params[name] = {"required": True}
+            elif d is None or isinstance(d, (bool, int, float, str)) or (isinstance(d, (list, tuple, dict)) and not d):
+                params[name] = {"required": False, "default": d if not isinstance(d, tuple) else list(d)}
+            else:
+                params[name] = {"required": False, "default_repr": repr(d)}
+        table[f"{mod}:{attr}"] = params
+    (HERE / "api_signatures.json").write_text(json.dumps(table, indent=1, sort_keys=True) + "\n")
+    print(f"[api_signatures.json] {len(table)} callables")
+
+
+CASES["api_signatures"] = dump_api_signatures
 CASES["cli_options"] = lambda: dump_cli_options("espnet2.bin.asr_inference", "asr_inference_cli_options.json")
 CASES["cli_options_streaming"] = lambda: dump_cli_options("espnet2.bin.asr_inference_streaming",
                                                           "asr_inference_streaming_cli_options.json")

@@ -183,3 +183,67 @@ def test_collect_backtraces_token_tree_on_host():
     bs.normalize_length = True  # beam_search.py:453-459: score / (len - 1)
     out = bs._collect(bufs, B, W, [3, 3])
     assert [float(h.score) for h in out[0]] == [-2.0, -5.0]  # -2/3 > -5/3
+
+
+# reference callable (tests/golden/api_signatures.json, dumped from /root/reference by make_golden.py api_signatures)
+# -> (espnet_amd module, attribute)
+_API_MAP = {
+    "espnet2.bin.asr_inference:Speech2Text.__init__": ("espnet_amd.bin.asr_inference", "Speech2Text.__init__"),
+    "espnet2.bin.asr_inference:Speech2Text.__call__": ("espnet_amd.bin.asr_inference", "Speech2Text.__call__"),
+    "espnet2.bin.asr_inference:inference": ("espnet_amd.bin.asr_inference", "inference"),
+    "espnet2.bin.asr_inference_streaming:Speech2TextStreaming.__init__":
+        ("espnet_amd.bin.asr_inference_streaming", "Speech2TextStreaming.__init__"),
+    "espnet2.bin.asr_inference_streaming:Speech2TextStreaming.__call__":
+        ("espnet_amd.bin.asr_inference_streaming", "Speech2TextStreaming.__call__"),
+    "espnet2.bin.asr_inference_streaming:inference": ("espnet_amd.bin.asr_inference_streaming", "inference"),
+    "espnet2.asr.espnet_model:ESPnetASRModel.__init__": ("espnet_amd.asr.espnet_model", "ESPnetASRModel.__init__"),
+    "espnet2.asr.espnet_model:ESPnetASRModel.encode": ("espnet_amd.asr.espnet_model", "ESPnetASRModel.encode"),
+    "espnet2.asr.frontend.default:DefaultFrontend.__init__": ("espnet_amd.asr.frontend.default", "DefaultFrontend.__init__"),
+    "espnet2.asr.encoder.conformer_encoder:ConformerEncoder.__init__":
+        ("espnet_amd.asr.encoder.conformer_encoder", "ConformerEncoder.__init__"),
+    "espnet2.asr.encoder.e_branchformer_encoder:EBranchformerEncoder.__init__":
+        ("espnet_amd.asr.encoder.e_branchformer_encoder", "EBranchformerEncoder.__init__"),
+    "espnet2.asr.encoder.branchformer_encoder:BranchformerEncoder.__init__":
+        ("espnet_amd.asr.encoder.e_branchformer_encoder", "BranchformerEncoder.__init__"),
+    "espnet2.asr.encoder.contextual_block_conformer_encoder:ContextualBlockConformerEncoder.__init__":
+        ("espnet_amd.asr.encoder.contextual_block_conformer_encoder", "ContextualBlockConformerEncoder.__init__"),
+    "espnet2.asr.decoder.transformer_decoder:TransformerDecoder.__init__":
+        ("espnet_amd.asr.decoder.transformer_decoder", "TransformerDecoder.__init__"),
+    "espnet2.asr.ctc:CTC.__init__": ("espnet_amd.asr.ctc", "CTC.__init__"),
+    "espnet2.lm.transformer_lm:TransformerLM.__init__": ("espnet_amd.lm.transformer_lm", "TransformerLM.__init__"),
+    "espnet2.lm.seq_rnn_lm:SequentialRNNLM.__init__": ("espnet_amd.lm.seq_rnn_lm", "SequentialRNNLM.__init__"),
+    "espnet2.legacy.nets.beam_search:BeamSearch.__init__": ("espnet_amd.nets.batch_beam_search", "BatchBeamSearch.__init__"),
+    "espnet2.legacy.nets.batch_beam_search_online:BatchBeamSearchOnline.__init__":
+        ("espnet_amd.nets.batch_beam_search_online", "BatchBeamSearchOnline.__init__"),
+}
+# the only deliberate default differences: there is no CPU path
+_API_DEFAULT_EXCEPTIONS = {("Speech2Text.__init__", "device"), ("Speech2TextStreaming.__init__", "device")}
+
+
+def test_public_signatures_cover_the_reference():
+    """Drop-in at the API level: every parameter of the reference callables on the path is accepted by its
+    espnet_amd counterpart under the same name with the same default (keyword-only extras such as
+    `compute_dtype` are allowed; options of other decoding modes may be taken by `**kwargs`, which the
+    constructors check against the reference defaults)."""
+    import importlib
+    import inspect
+    import json
+
+    ref = json.loads((REPO / "tests" / "golden" / "api_signatures.json").read_text())
+    assert set(ref) == set(_API_MAP)
+    for key, params in ref.items():
+        mod, attr = _API_MAP[key]
+        obj = importlib.import_module(mod)
+        for part in attr.split("."):
+            obj = getattr(obj, part)
+        mine = {n: p for n, p in inspect.signature(obj).parameters.items() if n != "self"}
+        has_kw = any(p.kind == p.VAR_KEYWORD for p in mine.values())
+        for name, r in params.items():
+            if name not in mine:
+                assert has_kw, f"{key}: parameter {name!r} is not accepted"
+                continue
+            if "default" not in r or (attr, name) in _API_DEFAULT_EXCEPTIONS:
+                continue
+            d = mine[name].default
+            assert d is not inspect.Parameter.empty, f"{key}: {name} is optional in the reference"
+            assert (list(d) if isinstance(d, tuple) else d) == r["default"], (key, name, d, r["default"])
