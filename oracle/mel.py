@@ -5,10 +5,14 @@ reference: /root/reference/pyproject.toml:40) as called from
 /root/reference/espnet2/layers/log_mel.py:38-52 with
 `sr=fs, n_fft, n_mels, fmin=0, fmax=fs/2, htk=False` (=> Slaney scale, norm="slaney", float32).
 
-PARITY UNPINNED for the matrix values: no reference test pins them and librosa is not installed
-here.  Mitigation: the matrix is a persistent buffer (`frontend.logmel.melmat`) in every reference
-checkpoint and the HIP frontend takes it as an INPUT, so both sides of every parity test use the
-very same matrix.
+PARITY UNPINNED against librosa itself for the matrix values: no reference test pins them and librosa
+is not installed here.  What does pin them (tests/test_oracle_golden.py): an INDEPENDENT implementation of
+the same published algorithm that ships in this image — `transformers.audio_utils.mel_filter_bank(norm=
+"slaney", mel_scale="slaney")`, which its own project tests against librosa — agrees to float32 round-off
+(1.6e-9) with identical supports on four configurations, and the value librosa's documentation prints for
+`librosa.filters.mel(sr=22050, n_fft=2048)[0, 1]` (0.016) is reproduced.  Mitigation beyond that: the matrix
+is a persistent buffer (`frontend.logmel.melmat`) in every reference checkpoint and the HIP frontend takes it
+as an INPUT, so both sides of every parity test use the very same matrix.
 
 Published algorithm (librosa/core/convert.py `hz_to_mel`/`mel_to_hz`, librosa/filters.py `mel`):
   * Slaney mel scale: linear 200/3 Hz per mel below 1 kHz, logarithmic above with

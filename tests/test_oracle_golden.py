@@ -11,6 +11,24 @@ from tests.helpers import golden_speech, golden_state_dict, hparams, load_golden
 torch.set_grad_enabled(False)
 
 
+@pytest.mark.parametrize("sr,n_fft,n_mels,fmin,fmax", [(16000, 512, 80, 0, 8000), (16000, 400, 80, 0, 8000),
+                                                       (22050, 2048, 128, 0, 11025), (8000, 256, 40, 50, 3800)])
+def test_mel_filterbank_against_an_independent_implementation(sr, n_fft, n_mels, fmin, fmax):
+    """librosa is absent, so the restatement of `librosa.filters.mel` is pinned against an independent
+    implementation of the same published algorithm that is in the image (Hugging Face transformers' Slaney
+    filterbank, itself tested against librosa upstream): equal to float32 round-off, same non-zero support; and
+    against the value librosa's own documentation prints for its default example."""
+    tau = pytest.importorskip("transformers.audio_utils")
+    mine = slaney_mel_filterbank(sr=sr, n_fft=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax)
+    other = tau.mel_filter_bank(num_frequency_bins=1 + n_fft // 2, num_mel_filters=n_mels, min_frequency=fmin,
+                                max_frequency=fmax, sampling_rate=sr, norm="slaney", mel_scale="slaney").T
+    assert mine.dtype == np.float32 and mine.shape == other.shape == (n_mels, 1 + n_fft // 2)
+    assert np.abs(mine.astype(np.float64) - other).max() < 5e-9
+    assert ((mine > 0) == (other > 0)).all()
+    if (sr, n_fft, n_mels) == (22050, 2048, 128):  # >>> librosa.filters.mel(sr=22050, n_fft=2048) -> [[0., 0.016, ...
+        assert round(float(mine[0, 1]), 3) == 0.016 and mine[0, 0] == 0.0
+
+
 def test_melmat_matches_reference_buffer():
     g = load_golden("small_10s")
     m = slaney_mel_filterbank(sr=16000, n_fft=512, n_mels=80, fmin=0, fmax=8000).T
