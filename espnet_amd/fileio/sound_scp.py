@@ -1,11 +1,14 @@
 """Audio readers for the decode CLI (espnet2/fileio/sound_scp.py:13-155, npy_scp.py, and the
 `sound` / `npy` entries of espnet2/train/iterable_dataset.py:44-67).
 
-The reference reads through `soundfile` (libsndfile), which is not in this image; RIFF/WAVE PCM is
-decoded here directly with the same sample convention libsndfile uses for float reads:
-integer PCM of width w bytes -> value / 2**(8w-1) (8-bit is unsigned, offset 128); IEEE float is
-taken as is.  Other containers (flac, sph, pipes `cmd |`) raise NotImplementedError naming the file:
-convert them to wav with the recipe's `format_wav_scp.sh` stage, as the recipes already do.
+The reference reads through `soundfile` (libsndfile), which is not in this image.  The two containers the
+recipes produce (`format_wav_scp.sh --audio-format wav|flac`; flac is the default, egs2/TEMPLATE/asr1/asr.sh:56)
+are decoded here directly, with the sample convention libsndfile uses for float reads:
+  * RIFF/WAVE: integer PCM of width w bytes -> value / 2**(8w-1) (8-bit is unsigned, offset 128); IEEE float
+    taken as is;
+  * FLAC (RFC 9639): `read_flac`, every subframe type and channel assignment, CRCs verified -> value / 2**(bits-1).
+Anything else (ogg, sph, pipes `cmd |`) raises NotImplementedError naming the file.  `WavBatchReader` is the
+batched fast path of the CLI on the C-ABI host reader (csrc/host_io.cpp), which decodes mono wav and flac natively.
 """
 import collections.abc
 import struct
@@ -20,15 +23,215 @@ from espnet_amd.fileio.read_text import read_2columns_text
 _WAVE_FORMAT_PCM, _WAVE_FORMAT_IEEE_FLOAT, _WAVE_FORMAT_EXTENSIBLE = 0x0001, 0x0003, 0xFFFE
 
 
+class _Bits:
+    """MSB-first bit reader over bytes (FLAC is a big-endian bit stream)."""
+
+    def __init__(self, data: bytes, pos: int = 0):
+        self.d, self.pos = data, pos * 8
+
+    def bits(self, k: int) -> int:
+        if k == 0:
+            return 0
+        a, b = self.pos >> 3, (self.pos + k + 7) >> 3
+        if b > len(self.d):
+            raise EOFError("FLAC stream ends inside a frame")
+        v = int.from_bytes(self.d[a:b], "big") >> (b * 8 - self.pos - k)
+        self.pos += k
+        return v & ((1 << k) - 1)
+
+    def sbits(self, k: int) -> int:
+        v = self.bits(k)
+        return v - (1 << k) if k and v >> (k - 1) else v
+
+    def unary(self) -> int:
+        q = 0
+        while True:  # byte at a time: count leading zeros of what is left of the current byte
+            i, off = self.pos >> 3, self.pos & 7
+            if i >= len(self.d):
+                raise EOFError("FLAC stream ends inside a Rice code")
+            rest = (self.d[i] << off) & 0xFF
+            if rest == 0:
+                q += 8 - off
+                self.pos += 8 - off
+                continue
+            lz = 8 - rest.bit_length()
+            self.pos += lz + 1
+            return q + lz
+
+
+def _crc(data: bytes, poly: int, width: int) -> int:
+    c, top, mask = 0, 1 << (width - 1), (1 << width) - 1
+    for byte in data:
+        c ^= byte << (width - 8)
+        for _ in range(8):
+            c = ((c << 1) ^ poly) & mask if c & top else (c << 1) & mask
+    return c
+
+
+_FIXED = ((), (1,), (2, -1), (3, -3, 1), (4, -6, 4, -1))
+
+
+def _flac_subframe(br: _Bits, bs: int, bps: int) -> list:
+    if br.bits(1):
+        raise ValueError("subframe padding bit set")
+    kind = br.bits(6)
+    wasted = br.unary() + 1 if br.bits(1) else 0
+    bps -= wasted
+    if bps <= 0:
+        raise ValueError("wasted bits >= sample size")
+    if kind == 0:
+        out = [br.sbits(bps)] * bs
+    elif kind == 1:
+        out = [br.sbits(bps) for _ in range(bs)]
+    elif 8 <= kind <= 12 or kind >= 32:
+        lpc = kind >= 32
+        order = (kind & 31) + 1 if lpc else kind - 8
+        if order > bs:
+            raise ValueError("predictor order > block size")
+        out = [br.sbits(bps) for _ in range(order)]
+        shift = 0
+        if lpc:
+            prec = br.bits(4) + 1
+            shift = br.sbits(5)
+            if prec == 16 or shift < 0:
+                raise ValueError("invalid LPC precision / shift")
+            coef = [br.sbits(prec) for _ in range(order)]
+        else:
+            coef = list(_FIXED[order])
+        method = br.bits(2)
+        if method > 1:
+            raise ValueError("reserved residual coding method")
+        pbits, esc = (4, 15) if method == 0 else (5, 31)
+        po = br.bits(4)
+        if po and (bs % (1 << po) or (bs >> po) < order):
+            raise ValueError("invalid partition order")
+        res = []
+        for pt in range(1 << po):
+            cnt = (bs >> po) - (order if pt == 0 else 0)
+            param = br.bits(pbits)
+            if param == esc:
+                nb = br.bits(5)
+                res.extend(br.sbits(nb) for _ in range(cnt))
+            else:
+                for _ in range(cnt):
+                    u = (br.unary() << param) | br.bits(param)
+                    res.append((u >> 1) ^ -(u & 1))
+        if len(res) != bs - order:
+            raise ValueError("residual count mismatch")
+        for r in res:  # s[k] = r + (sum_j coef[j] * s[k-1-j] >> shift)
+            acc = 0
+            for j in range(order):
+                acc += coef[j] * out[-1 - j]
+            out.append(r + (acc >> shift))
+    else:
+        raise ValueError(f"reserved subframe type {kind}")
+    return [v << wasted for v in out] if wasted else out
+
+
+def read_flac(path: Union[Path, str], dtype="float64", always_2d: bool = False) -> Tuple[np.ndarray, int]:
+    """FLAC decoder written from the format specification (RFC 9639), the Python counterpart of
+    csrc/host_io.cpp (which decodes mono streams for the batched fast path): all subframe types, Rice / Rice2
+    residuals with escaped partitions, wasted bits, every channel assignment, CRC-8 and CRC-16 verified.
+    Samples -> value / 2**(bits-1), like libsndfile's float read of a FLAC file."""
+    data = Path(path).read_bytes()
+    if data[:4] != b"fLaC":
+        raise NotImplementedError(f"{path}: not a FLAC stream")
+    o, last, si = 4, False, None
+    while not last:
+        if o + 4 > len(data):
+            raise RuntimeError(f"{path}: truncated FLAC metadata")
+        last, kind = bool(data[o] & 0x80), data[o] & 0x7F
+        n = int.from_bytes(data[o + 1 : o + 4], "big")
+        if si is None:
+            if kind != 0 or n < 34:
+                raise RuntimeError(f"{path}: STREAMINFO must be the first metadata block")
+            s = _Bits(data, o + 4)
+            s.bits(16), s.bits(16), s.bits(24), s.bits(24)
+            si = dict(rate=s.bits(20), channels=s.bits(3) + 1, bits=s.bits(5) + 1, total=s.bits(36))
+        o += 4 + n
+    nch, bits, total = si["channels"], si["bits"], si["total"]
+    chans = [[] for _ in range(nch)]
+    sizes = {1: 8, 2: 12, 4: 16, 5: 20, 6: 24, 7: 32}
+    while o + 2 <= len(data) and (total == 0 or len(chans[0]) < total):
+        if data[o] != 0xFF or (data[o + 1] & 0xFE) != 0xF8:
+            if total == 0:
+                break  # trailing tag after the last frame of a stream of unknown length
+            raise RuntimeError(f"{path}: lost FLAC frame sync at byte {o}")
+        br = _Bits(data, o)
+        br.bits(16)
+        bs_code, sr_code, ch_code, sz_code = br.bits(4), br.bits(4), br.bits(4), br.bits(3)
+        if br.bits(1):
+            raise RuntimeError(f"{path}: reserved frame header bit set")
+        lead = br.bits(8)
+        if lead & 0x80:
+            extra = 0
+            while lead & (0x40 >> extra):
+                extra += 1
+            if not 1 <= extra <= 6:
+                raise RuntimeError(f"{path}: bad coded frame number")
+            for _ in range(extra):
+                if br.bits(8) & 0xC0 != 0x80:
+                    raise RuntimeError(f"{path}: bad coded frame number")
+        if bs_code == 0 or sr_code == 15 or sz_code == 3:
+            raise RuntimeError(f"{path}: reserved frame header code")
+        bs = (192 if bs_code == 1 else 576 << (bs_code - 2) if bs_code <= 5 else br.bits(8) + 1 if bs_code == 6
+              else br.bits(16) + 1 if bs_code == 7 else 256 << (bs_code - 8))
+        if sr_code == 12:
+            br.bits(8)
+        elif sr_code in (13, 14):
+            br.bits(16)
+        bps = bits if sz_code == 0 else sizes[sz_code]
+        hdr = br.pos // 8 - o
+        if _crc(data[o : o + hdr], 0x07, 8) != br.bits(8):
+            raise RuntimeError(f"{path}: FLAC frame header CRC mismatch at byte {o}")
+        n_sub = ch_code + 1 if ch_code < 8 else 2
+        if ch_code > 10 or n_sub != nch or bps != bits:
+            raise RuntimeError(f"{path}: frame layout differs from STREAMINFO")
+        # the side channel of a decorrelated pair carries one more bit
+        side = {8: 1, 9: 0, 10: 1}.get(ch_code)
+        sub = [_flac_subframe(br, bs, bps + (1 if side == c else 0)) for c in range(n_sub)]
+        if ch_code == 8:  # left, side
+            sub[1] = [l - s for l, s in zip(sub[0], sub[1])]
+        elif ch_code == 9:  # side, right
+            sub[0] = [s + r for s, r in zip(sub[0], sub[1])]
+        elif ch_code == 10:  # mid, side
+            left, right = [], []
+            for m, s in zip(sub[0], sub[1]):
+                m = (m << 1) | (s & 1)
+                left.append((m + s) >> 1)
+                right.append((m - s) >> 1)
+            sub = [left, right]
+        br.pos = (br.pos + 7) & ~7
+        end = br.pos // 8
+        if end + 2 > len(data) or _crc(data[o:end], 0x8005, 16) != int.from_bytes(data[end : end + 2], "big"):
+            raise RuntimeError(f"{path}: FLAC frame CRC mismatch at byte {o}")
+        o = end + 2
+        for c in range(nch):
+            chans[c].extend(sub[c])
+    if total and len(chans[0]) < total:
+        raise RuntimeError(f"{path}: {len(chans[0])} samples decoded, STREAMINFO announces {total}")
+    x = np.array(chans, dtype=np.int64).T  # (N, C)
+    if total:
+        x = x[:total]
+    ft = np.float32 if np.dtype(dtype) == np.float32 and bits <= 24 else np.float64
+    x = x.astype(ft) * ft(1.0 / (1 << (bits - 1)))
+    if nch == 1 and not always_2d:
+        x = x[:, 0]
+    return x.astype(dtype, copy=False), si["rate"]
+
+
 def read_wav(path: Union[Path, str], dtype="float64", always_2d: bool = False) -> Tuple[np.ndarray, int]:
-    """(samples, rate): mono -> (N,), multi-channel -> (N, C); float in [-1, 1) like soundfile.read."""
+    """(samples, rate): mono -> (N,), multi-channel -> (N, C); float in [-1, 1) like soundfile.read.
+    RIFF/WAVE is parsed here; a FLAC stream (the recipes' default audio_format) goes to `read_flac`."""
     path = str(path)
     if path.rstrip().endswith("|"):
         raise NotImplementedError(f"piped wav.scp entries are not supported: {path!r}")
     with open(path, "rb") as f:
         head = f.read(12)
+        if head[:4] == b"fLaC":
+            return read_flac(path, dtype=dtype, always_2d=always_2d)
         if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
-            raise NotImplementedError(f"{path}: only RIFF/WAVE (PCM or IEEE float) is read natively")
+            raise NotImplementedError(f"{path}: only RIFF/WAVE (PCM or IEEE float) and FLAC are read natively")
         fmt = None
         data = None
         while True:
@@ -98,8 +301,8 @@ class WavBatchReader:
     (csrc/host_io.cpp): headers of a whole window are parsed first (lengths for the length bucketing), then
     every batch is decoded by a native thread pool straight into its zero-padded (B, Lmax) float32 matrix —
     the combined effect of `read_wav` per file and `common_collate_fn`, bit for bit, without holding the GIL.
-    `probe` returns None when any file is outside what the native reader handles (not RIFF/WAVE, multi-channel,
-    unreadable): the caller then takes the Python reader for that window, which raises the descriptive error."""
+    `probe` returns None when any file is outside what the native reader handles (neither RIFF/WAVE nor FLAC,
+    multi-channel, a FLAC stream of unknown length, unreadable): the caller then takes the Python reader for that window, which raises the descriptive error."""
 
     def __init__(self, threads: int = 4):
         import ctypes as C

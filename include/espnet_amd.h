@@ -651,13 +651,16 @@ int em_cast_f32(int dtype, const float* src, size_t n, void* dst, void* stream);
  *      espnet2/train/iterable_dataset.py:44-67, fused with CommonCollateFn's zero padding
  *      (espnet2/train/collate_fn.py:17-95): every file is decoded straight into its row of the batch matrix.
  *      Handled: RIFF/WAVE, mono, PCM 8/16/24/32-bit (value / 2^(bits-1), 8-bit unsigned offset 128) and IEEE
- *      float 32/64.  Anything else sets that file's status to EM_ERR_UNSUPPORTED (EM_ERR_IO if unreadable) and
- *      the caller reads it through the Python reader (espnet_amd/fileio/sound_scp.py), which names the problem. */
+ *      float 32/64; FLAC (RFC 9639; the recipes' default audio_format, egs2/TEMPLATE/asr1/asr.sh:56), mono with
+ *      the length in STREAMINFO, every subframe type, CRC-8 / CRC-16 verified, value / 2^(bits-1).  Anything
+ *      else sets that file's status to EM_ERR_UNSUPPORTED (EM_ERR_IO if unreadable or a CRC fails) and the
+ *      caller reads it through the Python reader (espnet_amd/fileio/sound_scp.py), which names the problem. */
+#define EM_AUDIO_FORMAT_FLAC 0xF1AC /* EmWavInfo.format of a FLAC stream (WAVE tags are 1 = PCM, 3 = float) */
 typedef struct EmWavInfo {
   int64_t frames;      /* samples per channel in the data chunk (clipped to the file size) */
   int64_t data_offset; /* byte offset of the first sample */
   int32_t rate, channels, bits;
-  int32_t format;      /* WAVE format tag: 1 PCM, 3 IEEE float (WAVE_FORMAT_EXTENSIBLE resolved) */
+  int32_t format;      /* WAVE format tag: 1 PCM, 3 IEEE float (WAVE_FORMAT_EXTENSIBLE resolved); EM_AUDIO_FORMAT_FLAC */
   int32_t status;      /* EM_OK or the EM_ERR_* code of this file */
 } EmWavInfo;
 /*   Parse the headers of n files (paths: NUL-terminated strings) with up to `threads` threads.  Returns EM_OK

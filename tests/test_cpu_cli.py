@@ -82,8 +82,11 @@ def test_read_wav_float_extra_chunks_and_errors(tmp_path):
     y, rate = read_wav(f, dtype="float32")
     assert rate == 16000
     np.testing.assert_array_equal(y, x)
-    (tmp_path / "a.flac").write_bytes(b"fLaC" + b"\0" * 40)
+    (tmp_path / "a.ogg").write_bytes(b"OggS" + b"\0" * 40)
     with pytest.raises(NotImplementedError):
+        read_wav(tmp_path / "a.ogg")
+    (tmp_path / "a.flac").write_bytes(b"fLaC" + b"\0" * 40)  # FLAC is decoded (tests/test_cpu_flac.py); this is not one
+    with pytest.raises(RuntimeError):
         read_wav(tmp_path / "a.flac")
     with pytest.raises(NotImplementedError):
         read_wav("sox a.wav -t wav - |")
@@ -257,8 +260,8 @@ def test_native_wav_reader_leaves_other_inputs_to_the_python_reader(tmp_path):
     (tmp_path / "wav.scp").write_text(f"gone {tmp_path / 'gone.wav'}\n")
     with pytest.raises(FileNotFoundError):
         list(StreamingBatchIterator(IterableESPnetDataset(spec), batch_size=1))
-    (tmp_path / "a.flac").write_bytes(b"fLaC" + b"\0" * 40)
-    (tmp_path / "wav.scp").write_text(f"fl {tmp_path / 'a.flac'}\n")
+    (tmp_path / "a.ogg").write_bytes(b"OggS" + b"\0" * 40)
+    (tmp_path / "wav.scp").write_text(f"og {tmp_path / 'a.ogg'}\n")
     with pytest.raises(NotImplementedError):
         list(StreamingBatchIterator(IterableESPnetDataset(spec), batch_size=1))
 
