@@ -385,6 +385,11 @@ int probe_flac(FILE* f, EmWavInfo* w) {
   w->frames = si.total;
   w->data_offset = (int64_t)o;
   if (si.total <= 0) return EM_ERR_UNSUPPORTED;  // unknown length: the Python reader decodes to find out
+  // a damaged STREAMINFO must not make the caller allocate an absurd row: a frame takes >= 10 bytes and holds
+  // at most max_block samples, and 2^28 samples (4.6 h at 16 kHz) is more than one utterance ever is
+  const int64_t payload = (int64_t)fsize - (int64_t)o;
+  const int64_t max_block = si.max_block > 0 ? si.max_block : 65536;
+  if (si.total > (1ll << 28) || si.total > (payload / 10 + 1) * max_block) return EM_ERR_UNSUPPORTED;
   return si.channels == 1 ? EM_OK : EM_ERR_UNSUPPORTED;
 }
 

@@ -198,6 +198,14 @@ def test_corruption_is_detected_never_silently_decoded(tmp_path):
             rd.load(probed, [0])
         caught += 1
     assert caught == 150
+    # a STREAMINFO announcing an absurd length is refused by the probe (no giant row is ever allocated)
+    b = bytearray(good)
+    b[21] |= 0x0F  # top bits of the 36-bit total-samples field
+    b[22] = 0xFF
+    p.write_bytes(bytes(b))
+    assert rd.probe([str(p)]) is None
+    with pytest.raises(RuntimeError, match="announces"):
+        read_flac(p)
     # damage to the metadata: probe refuses or the frames no longer match; never a crash
     for trial in range(100):
         b = bytearray(good)
