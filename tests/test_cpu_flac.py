@@ -46,7 +46,7 @@ def _native(path, threads=2):
 def test_specification_example_stream_verifies_crcs_and_md5(tmp_path):
     p = tmp_path / "rfc1.flac"
     p.write_bytes(RFC_EXAMPLE_1)
-    x, rate = read_flac(p, always_2d=True)  # raises on any CRC mismatch
+    x, rate = read_flac(p, always_2d=True, native=False)  # raises on any CRC mismatch
     assert rate == 44100 and x.shape == (1, 2)
     pcm = np.rint(x * 32768).astype("<i2")
     assert pcm.tolist() == [[25588, 10416]]
@@ -98,7 +98,7 @@ def test_every_coding_tool_round_trips_through_both_decoders(tmp_path, bits):
     for name, bs, plan in _plans(x, bits):
         p = tmp_path / f"{name}.flac"
         p.write_bytes(encode_flac([x], bits, 16000, bs, plan))
-        py, rate = read_flac(p, dtype="float32")
+        py, rate = read_flac(p, dtype="float32", native=False)
         assert rate == 16000 and py.dtype == np.float32 and py.shape == (n,), name
         assert np.array_equal(py.view(np.uint32), want.view(np.uint32)), name
         nat = _native(p)
@@ -127,7 +127,7 @@ def test_silence_wasted_bits_noise_and_32_bit(tmp_path):
         p = tmp_path / f"{name}.flac"
         p.write_bytes(encode_flac([x], bits, 16000, 1024, plan))
         want64 = x.astype(np.float64) / (1 << (bits - 1))
-        py, _ = read_flac(p)
+        py, _ = read_flac(p, native=False)
         assert np.array_equal(py, want64), name
         nat = _native(p)
         assert nat is not None and np.array_equal(nat, want64.astype(np.float32)), name
@@ -141,7 +141,7 @@ def test_stereo_channel_assignments(tmp_path, assignment):
     plan = lambda fi, ci, s, bps: dict(kind="fixed", order=2, po=2) if fi % 2 else dict(kind="verbatim")  # noqa: E731
     p = tmp_path / "st.flac"
     p.write_bytes(encode_flac([left, right], 16, 16000, 1152, plan, assignment=assignment))
-    y, rate = read_flac(p)
+    y, rate = read_flac(p, native=False)
     assert y.shape == (5000, 2)
     assert np.array_equal(y * 32768, np.stack([left, right], 1))
     assert _native(p) is None  # multi-channel windows go through the Python reader
@@ -164,14 +164,14 @@ def test_metadata_blocks_unknown_length_and_trailers(tmp_path):
     blocks = [(4, vorbis), (3, b"\x00" * 18), (6, b"\x00" * 5000), (1, b"\x00" * 37)]  # comment, seek, picture, pad
     p = tmp_path / "meta.flac"
     p.write_bytes(encode_flac([x], 16, 16000, 512, plan, extra_blocks=blocks))
-    assert np.array_equal(read_flac(p, dtype="float32")[0], want) and np.array_equal(_native(p), want)
+    assert np.array_equal(read_flac(p, dtype="float32", native=False)[0], want) and np.array_equal(_native(p), want)
     # a stream whose STREAMINFO leaves the length open, followed by an ID3v1-style tag: the Python reader decodes to
     # the end of the frames; the native reader does not guess and passes
     p.write_bytes(encode_flac([x], 16, 16000, 512, plan, total_in_header=False, trailer=b"TAG" + b"\x00" * 125))
-    assert np.array_equal(read_flac(p, dtype="float32")[0], want) and _native(p) is None
+    assert np.array_equal(read_flac(p, dtype="float32", native=False)[0], want) and _native(p) is None
     # known length + trailer: both stop after the announced samples
     p.write_bytes(encode_flac([x], 16, 16000, 512, plan, trailer=b"TAG" + b"\x00" * 125))
-    assert np.array_equal(read_flac(p, dtype="float32")[0], want) and np.array_equal(_native(p), want)
+    assert np.array_equal(read_flac(p, dtype="float32", native=False)[0], want) and np.array_equal(_native(p), want)
 
 
 def test_corruption_is_detected_never_silently_decoded(tmp_path):
@@ -191,7 +191,7 @@ def test_corruption_is_detected_never_silently_decoded(tmp_path):
             b[pos] ^= 1 << int(rng.integers(0, 8))
         p.write_bytes(bytes(b))
         with pytest.raises((RuntimeError, ValueError, EOFError)):
-            read_flac(p)
+            read_flac(p, native=False)
         probed = rd.probe([str(p)])
         assert probed is not None  # the header is intact ...
         with pytest.raises(OSError):  # ... the damage is found while decoding (CRC / sync / short stream)
