@@ -159,7 +159,9 @@ class StreamingBatchIterator:
                 and (pre is None or getattr(pre, "keeps_mono_samples", False))):
             from espnet_amd.fileio.sound_scp import WavBatchReader
 
-            self._wav = WavBatchReader(self.num_workers)
+            # the native pool only runs while a batch is being decoded: give it a few threads even at the
+            # reference's default --num_workers 1 (a 10 s FLAC utterance costs ~2 ms of one core)
+            self._wav = WavBatchReader(max(self.num_workers, 4))
 
     def _windows(self):
         buf = []
