@@ -41,6 +41,17 @@ struct BitReader {  // MSB-first, 64-bit window refilled a byte at a time
   bool bad = false;
   BitReader(const unsigned char* p_, size_t n_) : p(p_), n(n_) {}
   inline void refill() {
+    if (byte + 8 <= n) {  // one unaligned big-endian 64-bit load tops the window up to >= 57 bits
+      uint64_t w;
+      memcpy(&w, p + byte, 8);
+      w = __builtin_bswap64(w);
+      cache |= cbits ? (w >> cbits) : w;
+      const int add = (64 - cbits) >> 3;  // whole bytes that fit
+      byte += (size_t)add;
+      cbits += add * 8;
+      if (cbits < 64) cache &= ~0ull << (64 - cbits);  // invariant: bits beyond cbits are zero
+      return;
+    }
     while (cbits <= 56 && byte < n) {
       cache |= (uint64_t)p[byte++] << (56 - cbits);
       cbits += 8;
@@ -116,20 +127,25 @@ inline uint8_t crc8(const unsigned char* p, size_t n) {
   return c;
 }
 
-struct Crc16Table {
-  uint16_t t[256];
+struct Crc16Table {  // slicing-by-4 tables of the MSB-first CRC-16 (poly 0x8005, init 0)
+  uint16_t t[4][256];
   Crc16Table() {
     for (int i = 0; i < 256; ++i) {
       uint16_t c = (uint16_t)(i << 8);
       for (int k = 0; k < 8; ++k) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x8005 : (c << 1));
-      t[i] = c;
+      t[0][i] = c;
     }
+    for (int i = 0; i < 256; ++i)
+      for (int s = 1; s < 4; ++s) t[s][i] = (uint16_t)((t[s - 1][i] << 8) ^ t[0][t[s - 1][i] >> 8]);
   }
 };
 inline uint16_t crc16(const unsigned char* p, size_t n) {
   static const Crc16Table tab;
   uint16_t c = 0;
-  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ tab.t[((c >> 8) ^ p[i]) & 0xFF]);
+  size_t i = 0;
+  for (; i + 4 <= n; i += 4)  // four message bytes per step: the first two meet the running remainder
+    c = (uint16_t)(tab.t[3][(c >> 8) ^ p[i]] ^ tab.t[2][(c & 0xFF) ^ p[i + 1]] ^ tab.t[1][p[i + 2]] ^ tab.t[0][p[i + 3]]);
+  for (; i < n; ++i) c = (uint16_t)((c << 8) ^ tab.t[0][((c >> 8) ^ p[i]) & 0xFF]);
   return c;
 }
 
