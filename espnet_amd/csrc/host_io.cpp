@@ -184,16 +184,17 @@ int flac_stream_info(const unsigned char* d, size_t n, FlacStreamInfo* si) {
   return (si->bits >= 4 && si->bits <= 32 && si->rate > 0) ? EM_OK : EM_ERR_UNSUPPORTED;
 }
 
-// out[k] += (sum_j coef[j] * out[k-1-j]) >> shift for k >= ORDER; the common orders are unrolled
+// out[k] += (sum_j coef[j] * out[k-1-j]) >> shift for k >= ORDER; the common orders are unrolled.  The sums
+// wrap modulo 2^64 (unsigned arithmetic): valid streams never get near that, damaged ones must not be UB.
 template <int ORDER>
 inline void flac_predict_n(int64_t* out, int bs, const int64_t* coef, int shift) {
-  int64_t c[ORDER];
-  for (int j = 0; j < ORDER; ++j) c[j] = coef[j];
+  uint64_t c[ORDER];
+  for (int j = 0; j < ORDER; ++j) c[j] = (uint64_t)coef[j];
   for (int k = ORDER; k < bs; ++k) {
-    int64_t acc = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < ORDER; ++j) acc += c[j] * out[k - 1 - j];
-    out[k] += acc >> shift;
+    for (int j = 0; j < ORDER; ++j) acc += c[j] * (uint64_t)out[k - 1 - j];
+    out[k] = (int64_t)((uint64_t)out[k] + (uint64_t)((int64_t)acc >> shift));
   }
 }
 inline void flac_predict(int64_t* out, int bs, int order, const int64_t* coef, int shift) {
@@ -213,9 +214,9 @@ inline void flac_predict(int64_t* out, int bs, int order, const int64_t* coef, i
     case 12: return flac_predict_n<12>(out, bs, coef, shift);
   }
   for (int k = order; k < bs; ++k) {
-    int64_t acc = 0;
-    for (int j = 0; j < order; ++j) acc += coef[j] * out[k - 1 - j];
-    out[k] += acc >> shift;
+    uint64_t acc = 0;
+    for (int j = 0; j < order; ++j) acc += (uint64_t)coef[j] * (uint64_t)out[k - 1 - j];
+    out[k] = (int64_t)((uint64_t)out[k] + (uint64_t)((int64_t)acc >> shift));
   }
 }
 
