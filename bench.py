@@ -477,16 +477,16 @@ def main():
                        "parallelism": f"utterance-dp{world}", "greedy_tokens_last_step_rank0": n_tok,
                        **({"inputs": "host (pinned) -> device copy inside the timed step"} if args.h2d else {})},
         }
-    # ---- roofline of the dominant kernel family (GEMM template): HIP events around every launch
+    # ---- roofline of the MFMA kernel families: HIP events around every launch (on the launch stream)
     if rank == 0 and not args.no_roofline:
         lib = L.load()
         cap = 32768
         prof = lib.em_profile_create(cap)
         ms = (C.c_float * cap)()
         fl = (C.c_double * cap)()
+        tg = (C.c_int32 * cap)()
         cnt = C.c_int32(0)
-        tot_ms = tot_fl = 0.0
-        launches = 0
+        fam = {}  # tag -> [ms, flops, launches]
         nprof = max(1, min(args.steps, 5 if beam_search is None else 1))
         graph.clear()  # event bracketing needs live launches
         with torch.no_grad():
@@ -494,28 +494,37 @@ def main():
                 lib.em_profile_attach(prof)
                 step(do_collate=False)
                 lib.em_profile_attach(None)
-                L.check(lib.em_profile_read(prof, ms, fl, cap, C.byref(cnt)), "em_profile_read")
-                tot_ms += sum(ms[i] for i in range(cnt.value))
-                tot_fl += sum(fl[i] for i in range(cnt.value))
-                launches += cnt.value
+                L.check(lib.em_profile_read2(prof, ms, fl, tg, cap, C.byref(cnt)), "em_profile_read2")
+                for i in range(cnt.value):
+                    f = fam.setdefault(tg[i], [0.0, 0.0, 0])
+                    f[0] += ms[i]
+                    f[1] += fl[i]
+                    f[2] += 1
         lib.em_profile_destroy(prof)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-        # HBM traffic of the same kernel family from rocprofv3 PMC passes of this command
-        # (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 read correction applied; see
-        # profiles/r01_pmc_gemm_traffic.json).  Only quoted for the workload it was measured on.
-        traffic = None
-        tj = REPO / "profiles" / "r01_pmc_gemm_traffic.json"
-        if tj.exists() and beam_search is None and args.model == "small" and B == 32 and args.dtype == "bfloat16":
-            traffic = json.loads(tj.read_text())["gemm_family"]["hbm_bytes_per_launch"]
+        names = {L.EM_PROF_GEMM: "gemm_kernel<T,EPI,AMODE> (all instantiations)",
+                 L.EM_PROF_BLOCK: "block_kernel<MODE> (fused Conformer block, csrc/block.hip)",
+                 L.EM_PROF_ATTN: "relpos_attn2_kernel (csrc/attention2.hip)"}
+        tot_ms = sum(f[0] for f in fam.values())
+        tot_fl = sum(f[1] for f in fam.values())
+        launches = sum(f[2] for f in fam.values())
+        dom = max(fam, key=lambda t: fam[t][0])
+        d_ms, d_fl, d_n = fam[dom]
+        achieved = d_fl / (d_ms * 1e-3) / 1e12
         out["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "kernel": "gemm_kernel<T,EPI,AMODE> (all instantiations)",
-            "launches_per_step": launches // nprof,
-            "avg_launch_us": round(tot_ms * 1e3 / launches, 2),
-            "algorithmic_gflop_per_step": round(tot_fl / nprof / 1e9, 2),
-            "gemm_ms_per_step": round(tot_ms / nprof, 3),
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": names[dom], "launches_per_step": d_n // nprof,
+            "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
+            "algorithmic_gflop_per_step": round(d_fl / nprof / 1e9, 2),
+            "kernel_ms_per_step": round(d_ms / nprof, 3),
+            "all_mfma_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                 "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
+                                 "launches_per_step": launches // nprof, "ms_per_step": round(tot_ms / nprof, 3),
+                                 "algorithmic_gflop_per_step": round(tot_fl / nprof / 1e9, 2)},
+            "families": {names[t].split(" ")[0]: {"ms_per_step": round(f[0] / nprof, 3),
+                                                  "tflops": round(f[1] / (f[0] * 1e-3) / 1e12, 1),
+                                                  "launches_per_step": f[2] // nprof} for t, f in fam.items()},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = (cpu_baseline(model) if beam_search is None

@@ -98,6 +98,14 @@ class _EncoderLayer(torch.nn.Module):
         self.norm_final = LayerNorm(size)
 
 
+def _fused_enabled(enc) -> bool:
+    """The fused per-block kernels are the default where they apply; `enc.fused = False` or
+    ESPNET_AMD_FUSED=0 keeps the one-operator-per-launch sequence (A/B measurements, bisecting)."""
+    import os
+
+    return bool(getattr(enc, "fused", True)) and os.environ.get("ESPNET_AMD_FUSED", "1") != "0"
+
+
 def rel_pos_table(T: int, d: int) -> torch.Tensor:
     """RelPositionalEncoding rows for a length-T input (embedding.py:286-332): row k is the
     sinusoid of relative position T-1-k.  Built on the host with the same fp32 torch ops the
@@ -255,10 +263,59 @@ class ConformerEncoder(torch.nn.Module):
             )
             for k, v in lt.items():
                 setattr(layers[i], k, v.data_ptr())
+        if self._fusable():
+            self._pack_fused(layers, A, F)
         w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))
         self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype)
         self._pos_cache = {}
         return self._packed
+
+    def _fusable(self) -> bool:
+        """Shapes the row-block fused kernels cover (csrc/block.hip); everything else keeps the per-operator launches."""
+        return (self.em_dtype == L.EM_BF16 and self._output_size == 256 and self.heads == 4
+                and self.linear_units <= 1024 and self.cnn_module_kernel == 31
+                and not getattr(self, "legacy_relpos", False))
+
+    def _pack_fused(self, layers, A, F):
+        """Operands of em_conformer_block_fused (include/espnet_amd.h): pointwise_conv1 in 64-row value / gate
+        granules and the bias / LayerNorm vectors of every kernel as groups of EM_BLOCK_PARAM_GROUP floats in the
+        order the kernel consumes them."""
+        d, G = self._output_size, L.EM_BLOCK_PARAM_GROUP
+
+        def group(*vecs):
+            v = torch.cat([t.detach().to(torch.float32).reshape(-1).cpu() for t in vecs])
+            assert v.numel() <= G
+            return torch.nn.functional.pad(v, (0, G - v.numel()))
+
+        def pad_ff(b):
+            return torch.nn.functional.pad(b.detach().to(torch.float32).cpu(), (0, 1024 - b.numel()))
+
+        perm = torch.cat([torch.cat([torch.arange(64 * j, 64 * j + 64), torch.arange(d + 64 * j, d + 64 * j + 64)])
+                          for j in range(d // 64)])
+
+        def a_groups(l):
+            sa = l.self_attn
+            return [group(l.norm_ff_macaron.weight, l.norm_ff_macaron.bias, pad_ff(l.feed_forward_macaron.w_1.bias),
+                          l.feed_forward_macaron.w_2.bias),
+                    group(l.norm_mha.weight, l.norm_mha.bias, sa.linear_q.bias, sa.linear_k.bias, sa.linear_v.bias)]
+
+        n = len(self.encoders)
+        for i, l in enumerate(self.encoders):
+            cm = l.conv_module
+            pw1 = cm.pointwise_conv1.weight.reshape(2 * d, d)
+            d_groups = [group(cm.pointwise_conv2.bias, l.norm_ff.weight, l.norm_ff.bias),
+                        group(pad_ff(l.feed_forward.w_1.bias), l.feed_forward.w_2.bias, l.norm_final.weight,
+                              l.norm_final.bias)]
+            tail = a_groups(self.encoders[i + 1]) if i + 1 < n else [group(self.after_norm.weight,
+                                                                           self.after_norm.bias)]
+            lt = dict(pw1f=A(pw1[perm]),
+                      fp_c=F(group(l.self_attn.linear_out.bias, l.norm_conv.weight, l.norm_conv.bias,
+                                   cm.pointwise_conv1.bias[perm])),
+                      fp_da=F(torch.cat(d_groups + tail)))
+            if i == 0:
+                lt["fp_a"] = F(torch.cat(a_groups(l)))
+            for k, v in lt.items():
+                setattr(layers[i], k, v.data_ptr())
 
     def _pack_subsampling(self, w, t, A, F):
         """conv.2 (and conv.4): [d][k*k*d] with column (kt*k + kf)*d + c_in, the implicit GEMM's K order."""
@@ -366,7 +423,8 @@ class ConformerEncoder(torch.nn.Module):
         rc = getattr(lib, self._ENC_FN)(
             self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
             L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(ws),
-            ws.numel(), L.ptr(enc_out), L.ptr(enc_act), L.EM_ENC_ISOLATE_UTTS if isolate else 0,
+            ws.numel(), L.ptr(enc_out), L.ptr(enc_act),
+            (L.EM_ENC_ISOLATE_UTTS if isolate else 0) | (0 if _fused_enabled(self) else L.EM_ENC_NO_FUSED),
             L.current_stream_ptr())
         L.check(rc, self._ENC_FN)
         return enc_out, enc_act, olens, olens_dev

@@ -91,3 +91,7 @@ __device__ __forceinline__ float wave_max(float v) {
   } while (0)
 
 static inline int em_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// per-launch timing of the MFMA kernel families (csrc/gemm.hip; bench.py's roofline leg)
+bool em_prof_begin(void* stream);
+void em_prof_end(void* stream, double flops, int tag);

@@ -20,8 +20,10 @@ constexpr float LN_EPS = 1e-12f;  // transformer/layer_norm.py:23
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws {
-  size_t c1, c2, c3, x, xn, big, g, g2, ctx, pall, total;
+  size_t c1, c2, c3, x, xn, big, g, g2, ctx, pall, qh, kh, vt, total;
+  int Tpad;
 };
+inline int fused_tpad(int T) { return (T + 255) / 256 * 256; }
 inline Ws layout(int dtype, const EmConformerWeights* w, int B, int T_f) {
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   em_sub::Geo g;
@@ -42,6 +44,12 @@ inline Ws layout(int dtype, const EmConformerWeights* w, int B, int T_f) {
   s.g2 = o; o += align_up(M * d * es);
   s.ctx = o; o += align_up(M * d * es);
   s.pall = o; o += align_up((size_t)(2 * g.T_out - 1) * w->num_blocks * d * es);
+  // fused path (csrc/block.hip, csrc/attention2.hip): Q, K [B][H][Tpad][64], V^T [B][H][64][Tpad]
+  s.Tpad = fused_tpad(g.T_out);
+  const size_t per_head = (size_t)B * d * s.Tpad * es;
+  s.qh = o; o += align_up(per_head);
+  s.kh = o; o += align_up(per_head);
+  s.vt = o; o += align_up(per_head);
   s.total = o;
   return s;
 }
@@ -119,6 +127,41 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   // ---- linear_pos of every block in one GEMM: pall[2T-1][L*d]
   EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, w->legacy_relpos ? T : 2 * T - 1, L * d, d, d,
               L * d, 1.f, stream));
+  // ---- fused per Conformer block (csrc/block.hip): three launches per block instead of nineteen
+  bool fused = dtype == EM_BF16 && d == 256 && h == 4 && ff <= 1024 && w->kernel == 31 && !w->legacy_relpos &&
+               !(flags & EM_ENC_NO_FUSED) && ly[0].fp_a != nullptr;
+  for (int l = 0; fused && l < L; ++l) fused = ly[l].pw1f && ly[l].fp_c && ly[l].fp_da;
+  if (fused) {
+    void* qh = ws + s.qh;
+    void* kh = ws + s.kh;
+    void* vt = ws + s.vt;
+    // key columns >= 32 * ceil(T / 32) of V^T are never written and meet probability 0 in P.V: they must be finite
+    if (hipMemsetAsync(vt, 0, (size_t)B * d * s.Tpad * es, (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
+    EmBlockArgs ba = {};
+    ba.B = B; ba.T = T; ba.Tpad = s.Tpad; ba.d = d; ba.ff = ff; ba.kernel = w->kernel; ba.eps = LN_EPS;
+    ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = qh; ba.kh = kh; ba.vt = vt;
+    ba.enc_out = enc_out; ba.enc_act = enc_act; ba.tlens = conv_lens;
+    auto set_a = [&](const EmConformerLayer& q) { ba.ffm_w1 = q.ffm_w1; ba.ffm_w2 = q.ffm_w2; ba.wqkv = q.wqkv; };
+    set_a(ly[0]);
+    ba.params = ly[0].fp_a;
+    EM_TRY(em_conformer_block_fused(EM_BLOCK_A, &ba, stream));
+    for (int l = 0; l < L; ++l) {
+      const EmConformerLayer& q = ly[l];
+      EM_TRY(em_relpos_attention2_bf16(qh, kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
+                                       q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
+      ba.wout = q.wout; ba.pw1f = q.pw1f; ba.params = q.fp_c;
+      EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
+      ba.pw2 = q.pw2; ba.ff_w1 = q.ff_w1; ba.ff_w2 = q.ff_w2; ba.dw_w = q.dw_w; ba.dw_b = q.dw_b;
+      ba.params = q.fp_da;
+      if (l + 1 < L) {
+        set_a(ly[l + 1]);
+        EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_A, &ba, stream));
+      } else {
+        EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_FINAL, &ba, stream));
+      }
+    }
+    return EM_OK;
+  }
   // LayerNorm fused into the producing GEMM's epilogue (EM_EPI_*_LN, N == 256): correct and tested
   // (tests/test_gpu_kernels.py::test_gemm_layernorm_epilogue) but measured SLOWER on MI355X than
   // GEMM + stand-alone LN at B=32 (K=256: 16.4 vs 7.1+3.5 us, K=1024: 21.5 vs 12.2+3.5 us;

@@ -24,8 +24,25 @@ struct EmProfile {
   int capacity, count;
   hipEvent_t *start, *stop;
   double* flops;
+  int* tag;
 };
 static thread_local EmProfile* tl_profile = nullptr;
+
+// Launch bracketing shared by every MFMA kernel family (em_common.h): a start event when a profile is
+// attached and has room, then the stop event with the launch's algorithmic flops and its family tag.
+bool em_prof_begin(void* stream) {
+  EmProfile* prof = tl_profile;
+  if (!prof || prof->count >= prof->capacity) return false;
+  hipEventRecord(prof->start[prof->count], (hipStream_t)stream);
+  return true;
+}
+void em_prof_end(void* stream, double flops, int tag) {
+  EmProfile* prof = tl_profile;
+  hipEventRecord(prof->stop[prof->count], (hipStream_t)stream);
+  prof->flops[prof->count] = flops;
+  prof->tag[prof->count] = tag;
+  prof->count++;
+}
 
 namespace {
 
@@ -542,9 +559,7 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   } else if (p->lda % (dtype == EM_BF16 ? 8 : 4) != 0) {
     return EM_ERR_UNSUPPORTED;  // 16-byte aligned rows
   }
-  EmProfile* prof = tl_profile;
-  const bool rec = prof && prof->count < prof->capacity;
-  if (rec) hipEventRecord(prof->start[prof->count], (hipStream_t)stream);
+  const bool rec = em_prof_begin(stream);
   int rc = EM_ERR_UNSUPPORTED;
   // very few rows (streaming encoder step, single-utterance beam): latency-bound weight streaming
   if (a_mode == EM_A_PLAIN && p->M <= 48) rc = em_gemm_skinny(dtype, epilogue, p, stream);
@@ -553,11 +568,7 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
     if (dtype == EM_F32) rc = dispatch<float>(epilogue, a_mode, p, (hipStream_t)stream);
     else if (dtype == EM_BF16) rc = dispatch<bf16>(epilogue, a_mode, p, (hipStream_t)stream);
   }
-  if (rec) {
-    hipEventRecord(prof->stop[prof->count], (hipStream_t)stream);
-    prof->flops[prof->count] = 2.0 * (double)p->M * (double)p->N * (double)p->K;
-    prof->count++;
-  }
+  if (rec) em_prof_end(stream, 2.0 * (double)p->M * (double)p->N * (double)p->K, EM_PROF_GEMM);
   return rc;
 }
 
@@ -570,6 +581,7 @@ extern "C" EmProfile* em_profile_create(int32_t capacity) {
   pr->start = new hipEvent_t[capacity];
   pr->stop = new hipEvent_t[capacity];
   pr->flops = new double[capacity];
+  pr->tag = new int[capacity];
   for (int i = 0; i < capacity; ++i) {
     hipEventCreate(&pr->start[i]);
     hipEventCreate(&pr->stop[i]);
@@ -587,21 +599,27 @@ extern "C" void em_profile_destroy(EmProfile* pr) {
   delete[] pr->start;
   delete[] pr->stop;
   delete[] pr->flops;
+  delete[] pr->tag;
   delete pr;
 }
 
 extern "C" void em_profile_attach(EmProfile* pr) { tl_profile = pr; }
 
-extern "C" int em_profile_read(EmProfile* pr, float* ms, double* flops, int32_t max_n,
-                               int32_t* count) {
+extern "C" int em_profile_read2(EmProfile* pr, float* ms, double* flops, int32_t* tags, int32_t max_n,
+                                int32_t* count) {
   if (!pr || !ms || !flops || !count) return EM_ERR_BAD_ARG;
   int n = pr->count < max_n ? pr->count : max_n;
   if (n > 0) hipEventSynchronize(pr->stop[n - 1]);
   for (int i = 0; i < n; ++i) {
     if (hipEventElapsedTime(&ms[i], pr->start[i], pr->stop[i]) != hipSuccess) return EM_ERR_LAUNCH;
     flops[i] = pr->flops[i];
+    if (tags) tags[i] = pr->tag[i];
   }
   *count = n;
   pr->count = 0;
   return EM_OK;
+}
+
+extern "C" int em_profile_read(EmProfile* pr, float* ms, double* flops, int32_t max_n, int32_t* count) {
+  return em_profile_read2(pr, ms, flops, nullptr, max_n, count);
 }

@@ -19,7 +19,11 @@ EM_F32, EM_BF16 = 0, 1
 EM_A_PLAIN, EM_A_CONV2 = 0, 1
 
 EM_DW_SWISH, EM_DW_LINEAR, EM_DW_GATE, EM_DW_SELFRES = range(4)
-EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flag (include/espnet_amd.h)
+EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flags (include/espnet_amd.h)
+EM_ENC_NO_FUSED = 2
+EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL = 1, 2, 4, 8
+EM_BLOCK_PARAM_GROUP = 1792
+EM_PROF_GEMM, EM_PROF_BLOCK, EM_PROF_ATTN = 0, 1, 2
 DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
 
 
@@ -52,11 +56,18 @@ _LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b", "no
                "norm_conv_b", "norm_ff_g", "norm_ff_b", "norm_final_g", "norm_final_b",
                "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "wqkv", "bqkv", "pos_u", "pos_v", "wout",
                "bout", "pw1", "pw1_b", "dw_w", "dw_b", "pw2", "pw2_b", "ff_w1", "ff_b1", "ff_w2",
-               "ff_b2"]
+               "ff_b2", "pw1f", "fp_c", "fp_da", "fp_a"]
 
 
 class EmConformerLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _LAYER_PTRS]
+
+
+class EmBlockArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "T", "Tpad", "d", "ff", "kernel")] + [("eps", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("x", "ctx", "glu", "qh", "kh", "vt", "enc_out", "enc_act", "tlens", "wout",
+                                          "pw1f", "pw2", "ff_w1", "ff_w2", "dw_w", "dw_b", "ffm_w1", "ffm_w2", "wqkv",
+                                          "params")]
 
 
 class EmConformerWeights(C.Structure):
@@ -212,6 +223,10 @@ _SIGNATURES = {
     "em_profile_destroy": (None, [_vp]),
     "em_profile_attach": (None, [_vp]),
     "em_profile_read": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "em_profile_read2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
+    "em_conformer_block_fused": (C.c_int, [C.c_int, C.POINTER(EmBlockArgs), _vp]),
+    "em_relpos_attention2_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
+                                            _vp]),
     "em_cast_f32": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),
     "em_dec_embed_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "em_dec_self_attention": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,

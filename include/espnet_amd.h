@@ -252,6 +252,11 @@ typedef struct EmConformerLayer {
   const float* ff_b1;
   const void* ff_w2;
   const float* ff_b2;
+  /* row-block fused path (em_conformer_block_fused; bf16, d = 256): NULL when the host did not pack it */
+  const void* pw1f;      /* [2d][d] act: pointwise_conv1 rows in 64-row granules [v0..63, g0..63, v64..127, ...] */
+  const float* fp_c;     /* parameter groups of block<C> for this layer (EM_BLOCK_PARAM_GROUP floats each) */
+  const float* fp_da;    /* groups of block<D|A> (D part of this layer, A part of the next) or block<D|FINAL> */
+  const float* fp_a;     /* groups of block<A> (layer 0 only) */
 } EmConformerLayer;
 
 typedef struct EmConformerWeights {
@@ -275,6 +280,7 @@ typedef struct EmConformerWeights {
 
 /* em_conformer_encode flags */
 #define EM_ENC_ISOLATE_UTTS 1 /* every utterance of a ragged batch encodes as if it were alone */
+#define EM_ENC_NO_FUSED 2     /* keep the one-operator-per-launch sequence even where the fused block kernels apply */
 
 /* bytes of scratch em_conformer_encode needs for (B, T_f) */
 size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t B, int32_t T_f);
@@ -295,6 +301,55 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
                         int32_t B, int32_t T_f, const void* pos_emb, void* workspace,
                         size_t workspace_bytes, float* enc_out, void* enc_act, int32_t flags,
                         void* stream);
+
+/* ---- A6-A10 fused per Conformer block (bf16, d = 256, ff <= 1024, cnn_module_kernel 31): a workgroup
+ *      carries 32 frames of one utterance through every row-local operator of EncoderLayer.forward
+ *      (conformer/encoder_layer.py:79-179); weights stream through an LDS ring (csrc/block.hip).
+ *   mode  EM_BLOCK_C                : ctx -> linear_out + residual -> norm_conv -> pointwise_conv1 + GLU -> glu
+ *         EM_BLOCK_D | EM_BLOCK_A   : glu -> depthwise conv + BN + Swish -> pointwise_conv2 + residual -> norm_ff
+ *                                     -> FFN + residual -> norm_final; next block: norm_ff_macaron -> macaron FFN
+ *                                     + residual -> norm_mha -> q / k / v projections
+ *         EM_BLOCK_A                : the second half alone (first block, after the embedding)
+ *         EM_BLOCK_D | EM_BLOCK_FINAL: the first half, then after_norm -> enc_out (f32) / enc_act (bf16)
+ *   x     [B*T][256] f32 residual stream, updated in place (block<C> and the A part write it back)
+ *   q / k [B][H][Tpad][64] bf16, vt [B][H][64][Tpad] bf16 (V transposed): inputs of em_relpos_attention2;
+ *         Tpad % 64 == 0, Tpad >= 32 * ceil(T / 32); frames >= T of the last block hold finite padding
+ *   params: f32 groups of EM_BLOCK_PARAM_GROUP floats, in the order the kernel consumes them:
+ *     C      : [bout 256 | norm_conv g 256 | b 256 | pointwise_conv1 bias in pw1f row order 512]
+ *     D part : [pw2 bias 256 | norm_ff g | b] , [ff b1 (1024 slots) | ff b2 256 | norm_final g | b]
+ *     A part : [norm_ff_macaron g | b | ffm b1 (1024 slots) | ffm b2] , [norm_mha g | b | bq bk bv 768]
+ *     FINAL  : [after_norm g | b]     (D part + A part / FINAL concatenated for the combined modes)   */
+#define EM_BLOCK_C 1
+#define EM_BLOCK_D 2
+#define EM_BLOCK_A 4
+#define EM_BLOCK_FINAL 8
+#define EM_BLOCK_PARAM_GROUP 1792
+typedef struct EmBlockArgs {
+  int32_t B, T, Tpad, d, ff, kernel;
+  float eps;                        /* LayerNorm eps (1e-12, layer_norm.py:23) */
+  float* x;
+  const void* ctx;                  /* C in:  [B*T][256] bf16 */
+  void* glu;                        /* C out / D in: [B*T][256] bf16 */
+  void *qh, *kh, *vt;               /* A out */
+  float* enc_out;                   /* FINAL out [B*T][256] f32 */
+  void* enc_act;                    /* FINAL out bf16 */
+  const int32_t* tlens;             /* D: valid frames per utterance for the depthwise conv, or NULL (= T) */
+  const void *wout, *pw1f;          /* C */
+  const void *pw2, *ff_w1, *ff_w2;  /* D */
+  const float *dw_w, *dw_b;         /* D: [31][256] tap-major, [256] (BatchNorm folded) */
+  const void *ffm_w1, *ffm_w2, *wqkv; /* A */
+  const float* params;
+} EmBlockArgs;
+int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
+
+/* ---- A7, LDS-resident form (bf16, d_k = 64): RelPositionMultiHeadedAttention.forward core
+ *      (transformer/attention.py:416-459, rel_shift :391-408) over per-head operands.  One workgroup
+ *      per (utterance, head, 128 queries); K, V^T and the position window of 256 keys sit in LDS.
+ *   qh / kh [B][H][Tpad][64], vt [B][H][64][Tpad] bf16 (Tpad % 256 == 0), p [2T-1][ldp] bf16 (this block's
+ *   linear_pos rows), ctx [B*T][H*64] bf16 out.                                                      */
+int em_relpos_attention2_bf16(const void* qh, const void* kh, const void* vt, const void* p, int32_t ldp,
+                              const float* pos_u, const float* pos_v, const int32_t* klens, int32_t B,
+                              int32_t T, int32_t Tpad, int32_t h, void* ctx, void* stream);
 
 /* ---- §8(f) rank 4: E-Branchformer encoder (espnet2/asr/encoder/e_branchformer_encoder.py:55-520) for
  *      input_layer=conv2d, rel_pos / rel_selfattn (latest), use_ffn + macaron_ffn, swish FFN,
@@ -642,6 +697,13 @@ EmProfile* em_profile_create(int32_t capacity);
 void em_profile_destroy(EmProfile* prof);
 void em_profile_attach(EmProfile* prof); /* NULL detaches */
 int em_profile_read(EmProfile* prof, float* ms, double* flops, int32_t max_n, int32_t* count);
+/*   the same with the kernel family of every record: EM_PROF_GEMM (em_gemm), EM_PROF_BLOCK
+ *   (em_conformer_block_fused: flops of its GEMM-shaped stages), EM_PROF_ATTN (em_relpos_attention2_bf16:
+ *   6 B h T^2 d_k for AC, BD and P.V).  tags may be NULL.                                          */
+#define EM_PROF_GEMM 0
+#define EM_PROF_BLOCK 1
+#define EM_PROF_ATTN 2
+int em_profile_read2(EmProfile* prof, float* ms, double* flops, int32_t* tags, int32_t max_n, int32_t* count);
 
 /* f32 -> act dtype copy (lets reference-shaped f32 entry points feed the act-dtype GEMMs) */
 int em_cast_f32(int dtype, const float* src, size_t n, void* dst, void* stream);

@@ -31,6 +31,12 @@ def build(g, dtype):
     return model.cuda().eval()
 
 
+# frames whose arg-max may differ from the reference's because the reference's own top-2 log-prob margin is
+# below 1e-3 (f32 round-off decides them): bounded per fixture, printed by the test
+EXCUSED_FRAMES = {"tiny_blocks": 0, "small_ragged": 2, "small_10s": 2, "large_10s": 2, "sub6_small_6s": 2,
+                  "sub8_small_6s": 2, "legacy_small_5s": 2, "legacy_small_12s": 2}
+
+
 @pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "large_10s", "sub6_small_6s",
                                   "sub8_small_6s", "legacy_small_5s", "legacy_small_12s"])
 def test_encode_float32_matches_reference(name):
@@ -48,31 +54,85 @@ def test_encode_float32_matches_reference(name):
     assert err < 2e-3, f"{name}: encoder max abs err {err:.3e}"
     ids, tokens, tlens = model.greedy_ctc_device(st)
     ids = ids.cpu().numpy()
-    diff = ids != g["ctc_ids"]
+    valid = np.arange(ids.shape[1])[None, :] < g["enc_olens"][:, None]
+    diff = (ids != g["ctc_ids"]) & valid
     assert (g["ctc_margin"][diff] < 1e-3).all(), "argmax differs on a frame that is not a near-tie"
-    if not diff.any():
-        for b in range(ids.shape[0]):
-            n = int(tlens[b])
-            assert n == int(g["g1_lens"][b])
-            assert tokens[b, :n].cpu().tolist() == g["g1_tokens"][b, :n].tolist()
+    n_excused = int(diff.sum())
+    print(f"[{name}] f32 greedy ids: {n_excused} of {int(valid.sum())} frames differ, all with a reference "
+          f"top-2 margin < 1e-3")
+    assert n_excused <= EXCUSED_FRAMES[name], (name, n_excused)
+    # G1 tokens are ALWAYS compared: the reference's per-frame ids with only the excused near-tie frames
+    # replaced by the device's choice, collapsed by the reference rule (asr_inference.py:574-575), must
+    # equal the device's tokens; with no excused frame this is the golden g1_tokens itself.
+    blank, sos_eos = 0, int(g["vocab"]) - 1
+    for b in range(ids.shape[0]):
+        n_fr = int(g["enc_olens"][b])
+        want_ids = np.where(diff[b], ids[b], g["ctc_ids"][b])[:n_fr]
+        want = oc.g1_collapse(want_ids.tolist(), (blank, sos_eos))
+        if not diff[b].any():
+            assert want == g["g1_tokens"][b, : int(g["g1_lens"][b])].tolist()
+        n = int(tlens[b])
+        assert tokens[b, :n].cpu().tolist() == want, (name, b)
 
 
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["small_ragged", "small_10s", "large_10s"])
-def test_encode_bfloat16_within_tolerance(name):
+def test_encode_bfloat16_within_tolerance(name, fused):
+    """bf16 MFMA mode (the timed mode), both launch sequences: the fused per-block kernels (csrc/block.hip; they
+    apply to the 256-wide fixtures) and the one-operator-per-launch sequence."""
     g = load_golden(name)
     model = build(g, "bfloat16")
+    model.encoder.fused = fused
     speech, lens = golden_speech(g)
     st = model.encode_device(speech.cuda(), lens.tolist())
     ke = int(g["enc_keep_every"])
     enc = st.enc_out.cpu().numpy()[:, ::ke]
     err = np.abs(enc - g["enc_out"])
-    print(f"[{name}] bf16 encoder err max {err.max():.3e} mean {err.mean():.3e}")
+    print(f"[{name} fused={fused}] bf16 encoder err max {err.max():.3e} mean {err.mean():.3e}")
     assert err.max() < 0.15 and err.mean() < 2e-2
-    ids, _, _ = model.greedy_ctc_device(st)
+    ids, tokens, tlens = model.greedy_ctc_device(st)
     valid = np.arange(ids.shape[1])[None, :] < g["enc_olens"][:, None]
     mism = ((ids.cpu().numpy() != g["ctc_ids"]) & valid).sum() / valid.sum()
-    print(f"[{name}] bf16 greedy-id mismatch rate {mism:.3%}")
+    # token level: edit distance between the device's G1 tokens and the reference's, per reference token
+    dist = ref_len = 0
+    for b in range(ids.shape[0]):
+        want = g["g1_tokens"][b, : int(g["g1_lens"][b])].tolist()
+        dist += _edit_distance(tokens[b, : int(tlens[b])].cpu().tolist(), want)
+        ref_len += len(want)
+    print(f"[{name} fused={fused}] bf16 greedy-id mismatch rate {mism:.3%}, G1 token edit distance "
+          f"{dist} / {ref_len} reference tokens")
     assert mism < 0.25
+    assert dist <= 0.35 * max(ref_len, 1)
+
+
+def test_fused_blocks_match_per_operator_sequence_bf16():
+    """The two bf16 launch sequences round at the same points (LayerNorm output, FFN hidden, GLU and conv
+    outputs, q / k / v, attention probabilities and context) and differ only in f32 summation order: their
+    encoder outputs agree far more closely than either agrees with the f32 reference."""
+    for name in ("small_10s", "small_ragged", "tiny_blocks"):
+        g = load_golden(name)
+        model = build(g, "bfloat16")
+        speech, lens = golden_speech(g)
+        outs = []
+        for fused in (True, False):
+            model.encoder.fused = fused
+            for isolate in (False, True):
+                st = model.encode_device(speech.cuda(), lens.tolist(), isolate=isolate)
+                outs.append(st.enc_out.float().cpu())
+        for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+            d = (a - b).abs()
+            print(f"[{name}] fused vs per-operator bf16: max {d.max():.3e} mean {d.mean():.3e}")
+            assert d.max() < 0.08 and d.mean() < 6e-3
 
 
 def test_reference_api_encode_and_ctc():
