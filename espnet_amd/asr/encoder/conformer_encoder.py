@@ -106,6 +106,12 @@ def _fused_enabled(enc) -> bool:
     return bool(getattr(enc, "fused", True)) and os.environ.get("ESPNET_AMD_FUSED", "1") != "0"
 
 
+def pack_w2(w: torch.Tensor) -> torch.Tensor:
+    """[d][ff] -> [ff/64][d][64]: the 64-deep K slices the fused block kernel streams, each one contiguous."""
+    d, ff = w.shape
+    return w.detach().reshape(d, ff // 64, 64).permute(1, 0, 2).contiguous()
+
+
 def rel_pos_table(T: int, d: int) -> torch.Tensor:
     """RelPositionalEncoding rows for a length-T input (embedding.py:286-332): row k is the
     sinusoid of relative position T-1-k.  Built on the host with the same fp32 torch ops the
@@ -308,7 +314,8 @@ class ConformerEncoder(torch.nn.Module):
                               l.norm_final.bias)]
             tail = a_groups(self.encoders[i + 1]) if i + 1 < n else [group(self.after_norm.weight,
                                                                            self.after_norm.bias)]
-            lt = dict(pw1f=A(pw1[perm]),
+            lt = dict(pw1f=A(pw1[perm]), ffm_w2p=A(pack_w2(l.feed_forward_macaron.w_2.weight)),
+                      ff_w2p=A(pack_w2(l.feed_forward.w_2.weight)),
                       fp_c=F(group(l.self_attn.linear_out.bias, l.norm_conv.weight, l.norm_conv.bias,
                                    cm.pointwise_conv1.bias[perm])),
                       fp_da=F(torch.cat(d_groups + tail)))

@@ -254,6 +254,7 @@ typedef struct EmConformerLayer {
   const float* ff_b2;
   /* row-block fused path (em_conformer_block_fused; bf16, d = 256): NULL when the host did not pack it */
   const void* pw1f;      /* [2d][d] act: pointwise_conv1 rows in 64-row granules [v0..63, g0..63, v64..127, ...] */
+  const void *ffm_w2p, *ff_w2p; /* [ff/64][d][64] act: w_2 of the two FFNs in 64-deep K slices (contiguous 32 KiB units) */
   const float* fp_c;     /* parameter groups of block<C> for this layer (EM_BLOCK_PARAM_GROUP floats each) */
   const float* fp_da;    /* groups of block<D|A> (D part of this layer, A part of the next) or block<D|FINAL> */
   const float* fp_a;     /* groups of block<A> (layer 0 only) */
@@ -335,7 +336,7 @@ typedef struct EmBlockArgs {
   void* enc_act;                    /* FINAL out bf16 */
   const int32_t* tlens;             /* D: valid frames per utterance for the depthwise conv, or NULL (= T) */
   const void *wout, *pw1f;          /* C */
-  const void *pw2, *ff_w1, *ff_w2;  /* D */
+  const void *pw2, *ff_w1, *ff_w2;  /* D; ff_w2 / ffm_w2 PACKED as [ff/64][256][64]: w2p[c][n][k] = w_2.weight[n][64 c + k] */
   const float *dw_w, *dw_b;         /* D: [31][256] tap-major, [256] (BatchNorm folded) */
   const void *ffm_w1, *ffm_w2, *wqkv; /* A */
   const float* params;
