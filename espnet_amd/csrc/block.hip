@@ -30,18 +30,17 @@
 // That makes residual / bias / LayerNorm / bf16 packing 16- or 8-byte operations and lets the
 // activation fragments (32 rows x K = 256) stay in registers for a whole GEMM.
 //
-// Four waves, wave w owning the 16-column slice nf = w of every 64-column group and BOTH 16-frame
-// halves (measured: with eight waves in lockstep behind the per-unit barrier the kernel was bound by
-// instruction issue -- two waves per SIMD repeating the same control code -- not by ingest; profiles/
-// r02b).  A "K unit" is 64 weight rows x K = 256 (per wave one weight fragment column x two frame
+// Four compute waves, wave w owning the 16-column slice nf = w of every 64-column group and BOTH 16-frame
+// halves, plus four loader waves that only issue the LDS-DMA (a global_load_lds costs its issuing wave 60-185
+// cycles and the scalar table walk stalls it; neither belongs in the MFMA stream).  The loaders follow the
+// compute waves barrier by barrier through a code word in LDS, so the compute path carries no control code
+// for the ring at all (tools/experiments/barrier_bench.hip: a bare 8-wave barrier is 48 cycles; the branchy
+// shared code path of the first versions spent ~500 per interval).  A "K unit" is 64 weight rows x K = 256 (per wave one weight fragment column x two frame
 // fragments: 16 MFMAs); a "W2 unit" is all 256 rows x a 64-deep K slice of the FFN's second matrix
 // (four weight fragments x two frame fragments x two k-steps: 16 MFMAs).  Both are 32 KiB = 256 LDS
 // rows of 128 B, XOR-swizzled on the source address like csrc/gemm.hip.  The order and addresses of the
 // units are a table built by the host per launch (a kernel argument, read with scalar loads), so the
 // per-unit control code is a handful of scalar instructions.
-#include <stdio.h>
-#include <stdlib.h>
-
 #include "em_common.h"
 
 namespace {
@@ -49,16 +48,24 @@ namespace {
 constexpr int D = 256;
 constexpr int BM = 32;
 constexpr int NT = 512;                      // threads per workgroup: 4 compute waves + 4 loader waves
+constexpr int NC = 256;                      // compute threads
 constexpr int UNIT = 32768;
 constexpr int NSLOT = 4;
-constexpr int ABUF_OFF = NSLOT * UNIT;       // 16 KiB: LN(x) as four [32][64] k-tiles; the FFN's H tile aliases tile 0
+constexpr int ABUF_OFF = NSLOT * UNIT;       // 16 KiB: LN(x) as four [32][64] k-tiles; the FFN's two H tiles alias tiles 0, 1
 constexpr int RED_OFF = ABUF_OFF + 16384;    // 1 KiB: LayerNorm partial sums [2][4][32]
 constexpr int PAR_OFF = RED_OFF + 1024;      // 2 x 7 KiB: bias / LayerNorm vectors, double buffered per group
 constexpr int PAR_FLOATS = EM_BLOCK_PARAM_GROUP;
 constexpr int PAR_BYTES = PAR_FLOATS * 4;
-constexpr int SMEM_BYTES = PAR_OFF + 2 * PAR_BYTES;  // 162 816 B of the 163 840 B LDS
+constexpr int SYNC_OFF = PAR_OFF + 2 * PAR_BYTES;  // 64 B: barrier codes, compute waves -> loader waves
+constexpr int SMEM_BYTES = SYNC_OFF + 64;          // 162 880 B of the 163 840 B LDS
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile (lives in ring slot 3)
 constexpr int MAX_UNITS = 96;
+
+// code word of a barrier (compute thread 0 -> loader waves)
+constexpr int BAR_UNIT = 1;    // this barrier opens the interval of the next unit of the stream
+constexpr int BAR_PARAMS = 2;  // the older parameter buffer is dead: bring in the next group
+constexpr int BAR_TILE = 4;    // ring slot 3 still holds the depthwise-conv tile
+constexpr int BAR_LAST = 8;    // nothing follows: the loader waves leave
 
 // Unit g of the weight stream: byte address of its 32 contiguous KiB; bit 0 set = W2 unit (256 rows of 128 B),
 // clear = K unit (64 rows of 512 B).
@@ -118,8 +125,7 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
 #define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int MODE>
-__global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const UnitTable tab, const int total, const int dbg,
-                                                   long long* __restrict__ stamps) {
+__global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const UnitTable tab, const int total) {
   using MM = Mma<bf16>;
   constexpr bool HAS_C = (MODE & EM_BLOCK_C) != 0, HAS_D = (MODE & EM_BLOCK_D) != 0;
   constexpr bool HAS_A = (MODE & EM_BLOCK_A) != 0, FINAL = (MODE & EM_BLOCK_FINAL) != 0;
@@ -128,109 +134,103 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
   unsigned char* const abuf = smem + ABUF_OFF;
   float* const red = (float*)(smem + RED_OFF);
   const float* const par = (const float*)(smem + PAR_OFF);
+  volatile int* const sync = (volatile int*)(smem + SYNC_OFF);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Waves 0..3 compute (wave = 16-column slice nf of every 64-column group); waves 4..7 only move data: a
-  // global_load_lds costs its issuing wave 60-185 cycles (MI355X_MICROARCH.md), 8 of them per unit and wave, and a
-  // wave that also computes cannot overlap that with its own MFMAs (measured: compute-only 50 us + DMA-only
-  // 22 us = the 73 us of the version whose compute waves issued their own loads; profiles/ r02b).  Loader wave
-  // 4 + q fills the quarter of every unit that compute wave q used to fill.  All eight waves execute every
-  // s_barrier.
-  const bool ldr = wave >= 4;
-  const int nf = wave & 3;
+  const int nf = wave & 3;  // compute wave: 16-column slice of every 64-column group; loader wave: quarter of every unit
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.y, t0 = blockIdx.x * BM, T = a.T;
-  // this lane's two frames: mi * 16 + lr
-  bool row_ok[2];
-  size_t mrow[2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int t = t0 + mi * 16 + lr;
-    row_ok[mi] = t < T && !ldr;
-    mrow[mi] = (size_t)b * T + (t < T ? t : T - 1);  // clamped: tail rows recompute frame T-1
-  }
-  const int ncol = nf * 16 + lg * 4;                   // + 64 f: the four consecutive columns of fragment f
-  const int swz = lr & 7;
-  // byte offset of (frame lr, columns ncol .. ncol + 3) inside a [32][64] bf16 k-tile of abuf (+ 2048 for frame 16 + lr)
-  const int tile_wr = lr * 128 + (((2 * nf + (lg >> 1)) ^ swz) << 4) + (lg & 1) * 8;
 
-  // valid frames of the utterance for the depthwise conv; read before any LDS-DMA is in flight (the wait for
-  // this load would otherwise cover the ring prefetch as well)
-  int Tv = T;
-  if (HAS_D && a.tlens) Tv = a.tlens[b] < T ? a.tlens[b] : T;
-
-  // ---- weight stream ------------------------------------------------------------------------
-  const int nch = a.ff >> 6;  // 64-wide chunks of the FFN hidden dimension
-  // glds instruction i (0..7) of this wave fills LDS rows R = 64 nf + 8 i + (lane >> 3) of the unit, lane l
-  // supplying the 16-byte chunk (l & 7) ^ (R & 7) of that row's 128 B.
-  //   K unit : LDS row R = kt * 64 + n  (kt = 64-deep K tile = nf here, n = weight row inside the unit)
-  //   W2 unit: LDS row R = n            (256 weight rows, one 64-deep K slice; the host packs the FFN's second
-  //            matrix as [ff/64][256][64] so that this slice is 32 contiguous KiB too: as a 128-byte column of
-  //            the row-major [256][ff] matrix its 256 rows sit 2 ff bytes apart and all land on the same few L2
-  //            channels -- measured 3-4x slower per unit than a contiguous one)
-  int kofs[8], w2ofs[8];
-  {
+  // ======================= loader waves (4 .. 7) =================================================
+  // A loader wave never computes; it follows the compute waves barrier by barrier.  Before barrier k compute
+  // thread 0 publishes a code word in sync[k & 1] (BAR_* bits); the loaders read it after the barrier, so their
+  // loop needs no knowledge of the stage sequence.  Invariants: `started` units have had their interval opened
+  // (a barrier with BAR_UNIT); at any barrier every unit below `started` is finished, so units below
+  // started + NSLOT may be in the ring (one fewer while the conv tile occupies the last slot, BAR_TILE).  Before
+  // every barrier the loader makes sure unit `started` has landed, whether or not this barrier opens its
+  // interval.  Parameter loads are older than the unit loads counted here, and vmcnt retires loads in order.
+  if (wave >= 4) {
+    __builtin_amdgcn_s_setprio(3);  // few instructions, but a late DMA stalls all eight waves
     const int gc = (lane & 7) ^ (lane >> 3);
+    // glds instruction i (0..7) fills LDS rows R = 64 nf + 8 i + (lane >> 3) of the unit, lane l supplying the
+    // 16-byte chunk (l & 7) ^ (R & 7) of that row's 128 B.  K unit: LDS row R = kt * 64 + n (kt = 64-deep K tile
+    // = nf here, n = weight row inside the unit); W2 unit: LDS row R = n (the host packs the FFN's second matrix
+    // as [ff/64][256][64], so a 64-deep K slice of all 256 rows is 32 contiguous KiB).
+    int kofs[8], w2ofs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int n = 8 * i + (lane >> 3);
       kofs[i] = n * (D * 2) + nf * 128 + gc * 16;
       w2ofs[i] = (64 * nf + n) * 128 + gc * 16;
     }
-  }
-  auto issue_unit = [&](int g) {
-    if (dbg & 2) return;  // ablation: no DMA
-    const unsigned long long d = tab.u[g];
-    const unsigned char* base = uniform_ptr((const unsigned char*)(d & ~1ull));
-    const bool w2 = (d & 1ull) != 0;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)((g & (NSLOT - 1)) * UNIT + nf * 8192));  // smem is the only LDS object: offset 0
-    glds16x4(base, w2 ? w2ofs[0] : kofs[0], w2 ? w2ofs[1] : kofs[1], w2 ? w2ofs[2] : kofs[2],
-             w2 ? w2ofs[3] : kofs[3], dst);
-    glds16x4(base, w2 ? w2ofs[4] : kofs[4], w2 ? w2ofs[5] : kofs[5], w2 ? w2ofs[6] : kofs[6],
-             w2 ? w2ofs[7] : kofs[7], dst + 4096);
-  };
-  // parameter group grp (7 KiB of f32 vectors) -> LDS buffer grp & 1; wave w moves pieces w and w + 4
-  auto issue_params = [&](int grp) {
-    if (!ldr) return;
-    const unsigned char* src = uniform_ptr((const unsigned char*)(a.params + (size_t)grp * PAR_FLOATS));
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(PAR_OFF + (grp & 1) * PAR_BYTES));
-    glds16(src, nf * 1024 + lane * 16, dst + nf * 1024);
-    if (nf < 3) glds16(src, (nf + 4) * 1024 + lane * 16, dst + (nf + 4) * 1024);
-  };
-  // developer profiling (EM_BLOCK_STAMPS): a few stage-level cycle stamps of wave 0 of workgroup (0, 0)
-  int nts = 0;
-  auto stamp = [&]() {
-    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nts < 64) stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
-    ++nts;
-  };
-  stamp();
-  int gs = 0;  // units consumed so far (= index of the first unit of the next interval)
-  int gi = 0;  // units issued so far
-  // The ring is kept full: after the barrier that opens an interval (every wave is then past its last read of
-  // the units before gs) every unit below gs + NSLOT is issued.  An interval consumes n = 1 or 2 units behind
-  // ONE barrier.  Waiting for units gs .. gs + n - 1: only the 8 loads of each LATER unit already issued may
-  // still be in flight; parameter loads and global stores issued in between only make the wait stricter
-  // (vmcnt retires loads in order; nothing relies on the order of stores).
-  // (compute waves only pass the barrier; the unit table is the loaders' business)
-  auto begin = [&](int n) {
-    if (ldr && !(dbg & 2)) {
-      const int later = gi - gs - n;
-      if (later >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    auto issue_unit = [&](int g) {
+      const unsigned long long d = tab.u[g];
+      const unsigned char* base = uniform_ptr((const unsigned char*)(d & ~1ull));
+      const bool w2 = (d & 1ull) != 0;
+      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)((g & (NSLOT - 1)) * UNIT + nf * 8192));
+      glds16x4(base, w2 ? w2ofs[0] : kofs[0], w2 ? w2ofs[1] : kofs[1], w2 ? w2ofs[2] : kofs[2],
+               w2 ? w2ofs[3] : kofs[3], dst);
+      glds16x4(base, w2 ? w2ofs[4] : kofs[4], w2 ? w2ofs[5] : kofs[5], w2 ? w2ofs[6] : kofs[6],
+               w2 ? w2ofs[7] : kofs[7], dst + 4096);
+    };
+    auto issue_params = [&](int grp) {  // 7 KiB group -> LDS buffer grp & 1; wave w moves pieces w and w + 4
+      const unsigned char* src = uniform_ptr((const unsigned char*)(a.params + (size_t)grp * PAR_FLOATS));
+      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(PAR_OFF + (grp & 1) * PAR_BYTES));
+      glds16(src, nf * 1024 + lane * 16, dst + nf * 1024);
+      if (nf < 3) glds16(src, (nf + 4) * 1024 + lane * 16, dst + (nf + 4) * 1024);
+    };
+    issue_params(0);
+    if (!HAS_C) issue_params(1);
+    int gi = 0, started = 0, pgrp = 2;
+    for (; gi < NSLOT - 1 && gi < total; ++gi) issue_unit(gi);
+    for (int k = 0;; ++k) {
+      const int need = started + 1 < gi ? started + 1 : gi;  // units below `need` must have landed
+      const int later = gi - need;
+      if (later >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int code = __builtin_amdgcn_readfirstlane(sync[k & 1]);
+      const int cap = started + ((code & BAR_TILE) ? NSLOT - 1 : NSLOT);
+      for (; gi < total && gi < cap; ++gi) issue_unit(gi);
+      if (code & BAR_PARAMS) issue_params(pgrp++);
+      if (code & BAR_UNIT) ++started;
+      if (code & BAR_LAST) break;
     }
+    return;
+  }
+
+  // ======================= compute waves (0 .. 3) ===============================================
+  // this lane's two frames: mi * 16 + lr
+  bool row_ok[2];
+  size_t mrow[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int t = t0 + mi * 16 + lr;
+    row_ok[mi] = t < T;
+    mrow[mi] = (size_t)b * T + (t < T ? t : T - 1);  // clamped: tail rows recompute frame T-1
+  }
+  const int ncol = nf * 16 + lg * 4;                   // + 64 f: the four consecutive columns of fragment f
+  const int swz = lr & 7;
+  // byte offset of (frame lr, columns ncol .. ncol + 3) inside a [32][64] bf16 k-tile of abuf (+ 2048 for frame 16 + lr)
+  const int tile_wr = lr * 128 + (((2 * nf + (lg >> 1)) ^ swz) << 4) + (lg & 1) * 8;
+  const int nch = a.ff >> 6;  // 64-wide chunks of the FFN hidden dimension
+  int gs = 0;    // units whose interval has been opened; unit g lives in ring slot g & 3
+  int nbar = 0;  // barriers passed
+  // every barrier goes through here: publish its code for the loaders, retire own LDS operations, synchronise
+  auto bar = [&](int code) {
+    if (tid == 0) sync[nbar & 1] = code;
+    ++nbar;
     EM_LGKM0();
-    __builtin_amdgcn_s_barrier();  // units gs .. gs + n - 1 visible to every wave; everything below gs released
-    if (ldr)
-      for (; gi < total && gi < gs + NSLOT; ++gi) issue_unit(gi);
+    __builtin_amdgcn_s_barrier();
   };
 
   // ---- row state ------------------------------------------------------------------------------
   float4 xr[2][4];     // residual x[frame mi][64 f + ncol .. + 3], f32
   bf16x8 act[2][8];    // activation fragments of the running GEMM: frame mi*16 + lr, k = 32 ks + 8 lg ..
   auto load_x = [&]() {
-    if (ldr) return;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -245,7 +245,6 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       }
   };
   auto load_act = [&]() {  // from abuf, after a barrier
-    if (ldr) return;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -253,8 +252,8 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         act[mi][ks] = *(const bf16x8*)(abuf + ((ks >> 1) * 32 + mi * 16 + lr) * 128 + ((((ks & 1) * 4 + lg) ^ swz) << 4));
   };
   // LayerNorm statistics of the 32 rows (two-pass, as layer_norm.py / torch: mean, then the variance of
-  // the centred values).  A row is spread over 4 lane groups x 4 waves.  Two barriers.
-  auto ln_stats = [&](float mean[2], float rstd[2]) {
+  // the centred values).  A row is spread over 4 lane groups x 4 waves.  Two barriers; `code` rides on the second.
+  auto ln_stats = [&](float mean[2], float rstd[2], int code) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       float s = 0.f;
@@ -262,10 +261,9 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       for (int f = 0; f < 4; ++f) s += (xr[mi][f].x + xr[mi][f].y) + (xr[mi][f].z + xr[mi][f].w);
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (lg == 0 && !ldr) red[nf * 32 + mi * 16 + lr] = s;
+      if (lg == 0) red[nf * 32 + mi * 16 + lr] = s;
     }
-    EM_LGKM0();
-    __builtin_amdgcn_s_barrier();
+    bar(0);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int m = mi * 16 + lr;
@@ -279,10 +277,9 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       }
       q += __shfl_xor(q, 16, 64);
       q += __shfl_xor(q, 32, 64);
-      if (lg == 0 && !ldr) red[128 + nf * 32 + m] = q;
+      if (lg == 0) red[128 + nf * 32 + m] = q;
     }
-    EM_LGKM0();
-    __builtin_amdgcn_s_barrier();
+    bar(code);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int m = mi * 16 + lr;
@@ -291,9 +288,9 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     }
   };
   // y = LN(x; g, b) with g, b at float offsets go / bo of parameter buffer pb
-  auto ln_apply = [&](const float* pb, int go, int bo, float4 y[2][4]) {
+  auto ln_apply = [&](const float* pb, int go, int bo, float4 y[2][4], int code) {
     float mean[2], rstd[2];
-    ln_stats(mean, rstd);
+    ln_stats(mean, rstd, code);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const float4 g4 = *(const float4*)(pb + go + 64 * f + ncol);
@@ -307,40 +304,36 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       }
     }
   };
-  // LN(x) -> bf16 -> abuf -> activation fragments.  One more barrier.
-  auto ln_to_act = [&](const float* pb, int go, int bo) {
+  // LN(x) -> bf16 -> abuf -> activation fragments.  One more barrier, carrying `code` (the parameter reads of
+  // this LayerNorm precede it).
+  auto ln_to_act = [&](const float* pb, int go, int bo, int code) {
     float4 y[2][4];
-    ln_apply(pb, go, bo, y);
-    if (!ldr) {
+    ln_apply(pb, go, bo, y, 0);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          bf16x4 pk = {(bf16)y[mi][f].x, (bf16)y[mi][f].y, (bf16)y[mi][f].z, (bf16)y[mi][f].w};
-          *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
-        }
-    }
-    EM_LGKM0();
-    __builtin_amdgcn_s_barrier();
+      for (int f = 0; f < 4; ++f) {
+        bf16x4 pk = {(bf16)y[mi][f].x, (bf16)y[mi][f].y, (bf16)y[mi][f].z, (bf16)y[mi][f].w};
+        *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
+      }
+    bar(code);
     load_act();
   };
-  // K unit g: fragments C^T[n = nf*16 + lg*4 + r][m = mi*16 + lr]
-  // (swap: C[m = mi*16 + lg*4 + r][n = nf*16 + lr])
-  auto k_unit = [&](int g, bool swap, f32x4 out[2], auto&& between) {
-    out[0] = out[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (ldr || (dbg & 1)) return;  // dbg 1: ablation, no compute
-    const unsigned char* su = ring + (g & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
+  // the next K unit of the stream (one barrier): fragments C^T[n = nf*16 + lg*4 + r][m = mi*16 + lr]
+  // (swap: C[m = mi*16 + lg*4 + r][n = nf*16 + lr]).  `between` runs after the fragment reads have been
+  // requested: deferred VALU / LDS work that fills the issue gaps between the MFMAs.
+  auto k_unit = [&](bool swap, f32x4 out[2], auto&& between, int code) {
+    bar(BAR_UNIT | code);
+    const unsigned char* su = ring + (gs & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
+    ++gs;
     f32x4 c[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) c[mi][0] = c[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // all eight weight fragments are requested before the first MFMA: one exposed LDS latency per unit
-    // instead of one per pair of reads (hipcc otherwise interleaves read, wait, MFMA; a single wave per SIMD
-    // has nothing to hide those waits with)
     bf16x8 w[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) w[ks] = *(const bf16x8*)(su + (ks >> 1) * 8192 + ((((ks & 1) * 4 + lg) ^ swz) << 4));
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // 8 DS reads first
-    between();  // deferred epilogue of the previous unit: VALU / LDS work for the gaps between the MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // all 8 DS reads first: one exposed LDS latency per unit
+    between();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -350,11 +343,11 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     out[1] = c[1][0] + c[1][1];
   };
   auto nothing = []() {};
-  // x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o.  2 * nch units, software
-  // pipelined so that one barrier interval carries the first GEMM of chunk c + 1 (K unit -> H[(c+1) & 1]) AND
-  // the second GEMM of chunk c (W2 unit, reading H[c & 1]): two independent MFMA streams and the Swish
-  // epilogue to interleave, half the barriers.  Unit order (build_units): K0, (K1, W2_0), (K2, W2_1), ...,
-  // W2_last.  The two H tiles [32][64] alias abuf's first two k-tiles.
+  // x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o.  2 * nch units in the order
+  // K0 | K1 + epilogue(K0) | W2_0 | K2 + epilogue(K1) | W2_1 | ... | W2_last (build_units): the Swish epilogue of
+  // chunk c (bias, exp, rcp, bf16 pack, LDS store of H[c & 1]) is deferred into the interval of K unit c + 1,
+  // where it fills the issue gaps between that unit's MFMAs; W2 unit c runs one interval later.  The two H
+  // tiles [32][64] alias abuf's first two k-tiles (the activation fragments are in registers by then).
   auto ffn = [&](const float* pb, int b1o, int b2o, float scale) {
     f32x4 acc2[2][4];
 #pragma unroll
@@ -362,7 +355,6 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc2[mi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto h_store = [&](const f32x4 h[2], int c) {
-      if (ldr || (dbg & 1)) return;
       const float4 bb = *(const float4*)(pb + b1o + c * 64 + ncol);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -371,9 +363,10 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         *(bf16x4*)(abuf + (c & 1) * 4096 + mi * 2048 + tile_wr) = pk;  // H[c & 1][m][k = ncol ..]
       }
     };
-    auto w2_unit = [&](int g, int c) {
-      if (ldr || (dbg & 1)) return;
-      const unsigned char* su = ring + (g & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
+    auto w2_unit = [&](int c) {
+      bar(BAR_UNIT);
+      const unsigned char* su = ring + (gs & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
+      ++gs;
       const unsigned char* sh = abuf + (c & 1) * 4096 + lr * 128;
       bf16x8 hf[2][2], w[2][4];
 #pragma unroll
@@ -394,29 +387,18 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // 12 DS reads
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMA
     };
-    // K0 | K1 + epilogue(K0) | W2_0 | K2 + epilogue(K1) | W2_1 | ... | W2_last: the Swish epilogue of chunk c
-    // (bias, exp, rcp, bf16 pack, LDS store of H[c & 1]) is deferred into the interval of K unit c + 1, where
-    // it fills the issue gaps between that unit's MFMAs; W2 unit c runs one interval later.
     f32x4 hp[2];
-    begin(1);
-    k_unit(gs, false, hp, nothing);
-    gs += 1;
+    k_unit(false, hp, nothing, 0);
     for (int c = 0; c < nch; ++c) {
       if (c + 1 < nch) {
         f32x4 hn[2];
-        begin(1);
-        k_unit(gs, false, hn, [&]() { h_store(hp, c); });
-        gs += 1;
-        begin(1);
-        w2_unit(gs, c);
-        gs += 1;
+        k_unit(false, hn, [&]() { h_store(hp, c); }, 0);
+        w2_unit(c);
         hp[0] = hn[0];
         hp[1] = hn[1];
       } else {
         h_store(hp, c);
-        begin(1);
-        w2_unit(gs, c);
-        gs += 1;
+        w2_unit(c);
       }
     }
 #pragma unroll
@@ -431,28 +413,19 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       }
     }
   };
-  // x += (W . act + bias): four K units (N = 256), two per interval
+  // x += (W . act + bias): four K units (N = 256)
   auto proj_resid = [&](const float* pb, int bo) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      f32x4 c[2][2];
-      begin(1);
-      k_unit(gs, false, c[0], nothing);
-      gs += 1;
-      begin(1);
-      k_unit(gs, false, c[1], nothing);
-      gs += 1;
+    for (int f = 0; f < 4; ++f) {
+      f32x4 c[2];
+      k_unit(false, c, nothing, 0);
+      const float4 b4 = *(const float4*)(pb + bo + 64 * f + ncol);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int f = 2 * i + j;
-        const float4 b4 = *(const float4*)(pb + bo + 64 * f + ncol);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          xr[mi][f].x += c[j][mi][0] + b4.x;
-          xr[mi][f].y += c[j][mi][1] + b4.y;
-          xr[mi][f].z += c[j][mi][2] + b4.z;
-          xr[mi][f].w += c[j][mi][3] + b4.w;
-        }
+      for (int mi = 0; mi < 2; ++mi) {
+        xr[mi][f].x += c[mi][0] + b4.x;
+        xr[mi][f].y += c[mi][1] + b4.y;
+        xr[mi][f].z += c[mi][2] + b4.z;
+        xr[mi][f].w += c[mi][3] + b4.w;
       }
     }
   };
@@ -460,50 +433,25 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
   const float* const pb0 = par;
   const float* const pb1 = par + PAR_FLOATS;
 
-  // ---- prologue: start the streams, then load the block's inputs ------------------------------
-  issue_params(0);
-  if (!HAS_C) issue_params(1);
-  for (; gi < NSLOT - 1 && gi < total; ++gi)  // slot 3 stays free for the conv tile
-    if (ldr) issue_unit(gi);
-  // the parameter groups are older than these unit loads: they have landed once at most 3 x 8 loads are in flight
-  // (block<A> normalises before its first interval; the first barrier publishes them to the compute waves)
-  if (ldr) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-
   if (HAS_C) {
     // linear_out over the attention context: activation fragments straight from global memory
     // (attention.py:151 linear_out; encoder_layer.py:142-147 residual)
-    if (!ldr) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const bf16* crow = (const bf16*)a.ctx + mrow[mi] * D + lg * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) act[mi][ks] = *(const bf16x8*)(crow + ks * 32);
-      }
-    }
-    load_x();
-    // hipcc counts only its own loads: left alone it waits for these at their first use, i.e. after the
-    // next unit has been issued, and the count then drains the ring.  Make it wait here instead.
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+      const bf16* crow = (const bf16*)a.ctx + mrow[mi] * D + lg * 8;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(act[mi][ks]));
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-        asm volatile("" : "+v"(xr[mi][f].x), "+v"(xr[mi][f].y), "+v"(xr[mi][f].z), "+v"(xr[mi][f].w));
+      for (int ks = 0; ks < 8; ++ks) act[mi][ks] = *(const bf16x8*)(crow + ks * 32);
     }
+    load_x();
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
     proj_resid(pb0, 0);
     store_x();
-    ln_to_act(pb0, 256, 512);
+    ln_to_act(pb0, 256, 512, 0);
     // pointwise_conv1 + GLU (convolution.py:66-69): unit 2j = value rows 64j.., unit 2j+1 = their gates
     for (int j = 0; j < 4; ++j) {
       f32x4 v[2], gt[2];
-      begin(1);
-      k_unit(gs, false, v, nothing);
-      gs += 1;
-      begin(1);
-      k_unit(gs, false, gt, nothing);
-      gs += 1;
+      k_unit(false, v, nothing, 0);
+      k_unit(false, gt, nothing, 0);
       const float4 bv = *(const float4*)(pb0 + 768 + (2 * j) * 64 + ncol);
       const float4 bg = *(const float4*)(pb0 + 768 + (2 * j + 1) * 64 + ncol);
 #pragma unroll
@@ -515,6 +463,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         if (row_ok[mi]) *(bf16x4*)((bf16*)a.glu + mrow[mi] * D + 64 * j + ncol) = pk;
       }
     }
+    bar(BAR_LAST);
     return;
   }
 
@@ -523,29 +472,28 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     // the 62-row input tile of this block (frames t0 - 15 .. t0 + 46 of the utterance, zero outside
     // [0, Tv)) goes through LDS; thread c (= channel) produces the 32 frames of the block.
     unsigned char* const tile = ring + (NSLOT - 1) * UNIT;  // [62][256] bf16
-    if (!ldr) {
-      load_x();
-      uint4 stage[8];
+    int Tv = T;
+    if (a.tlens) Tv = a.tlens[b] < T ? a.tlens[b] : T;
+    uint4 stage[8];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {  // unconditional loads from a clamped row (a load under a lane mask is
-        const int q = tid + it * 256, r = q >> 5, ch = q & 31;  // waited for on the spot), zeroed afterwards
-        const int t = t0 - HALF + r;
-        const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
-        stage[it] = *(const uint4*)((const bf16*)a.glu + ((size_t)b * T + tc) * D + ch * 8);
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int q = tid + it * 256, t = t0 - HALF + (q >> 5);
-        if (q < TROWS * 32) *(uint4*)(tile + q * 16) = (t >= 0 && t < Tv) ? stage[it] : make_uint4(0u, 0u, 0u, 0u);
-      }
+    for (int it = 0; it < 8; ++it) {  // unconditional loads from a clamped row (a load under a lane mask is
+      const int q = tid + it * NC, r = q >> 5, ch = q & 31;  // waited for on the spot), zeroed afterwards
+      const int t = t0 - HALF + r;
+      const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
+      stage[it] = *(const uint4*)((const bf16*)a.glu + ((size_t)b * T + tc) * D + ch * 8);
     }
-    EM_LGKM0();
-    __builtin_amdgcn_s_barrier();
-    if (!ldr) {
-      float wk[KW];
+    float wk[KW];  // requested together with the tile: one global-memory latency for the whole prologue
 #pragma unroll
-      for (int k = 0; k < KW; ++k) wk[k] = a.dw_w[k * D + tid];
-      const float bc = a.dw_b[tid];
+    for (int k = 0; k < KW; ++k) wk[k] = a.dw_w[k * D + tid];
+    const float bc = a.dw_b[tid];
+    load_x();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int q = tid + it * NC, t = t0 - HALF + (q >> 5);
+      if (q < TROWS * 32) *(uint4*)(tile + q * 16) = (t >= 0 && t < Tv) ? stage[it] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    bar(BAR_TILE);
+    {
       const bf16* col = (const bf16*)tile + tid;
       const int kt = tid >> 6, kl = tid & 63;
 #pragma unroll
@@ -567,31 +515,24 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         }
       }
     }
-    EM_LGKM0();
-    __builtin_amdgcn_s_barrier();  // conv output visible; the tile (slot 3) is free
+    bar(0);  // conv output visible; the tile (slot 3) is free
     load_act();
-    stamp();  // 1: conv prologue done
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]
-    proj_resid(pb0, 0);                  // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
-    stamp();  // 2
-    ln_to_act(pb0, 256, 512);            // norm_ff
-    stamp();  // 3
-    issue_params(2);                     // G0 is dead (the barrier inside ln_to_act followed its last read)
-    ffn(pb1, 0, 1024, 0.5f);             // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
-    stamp();  // 4
+    proj_resid(pb0, 0);                        // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
+    ln_to_act(pb0, 256, 512, BAR_PARAMS);      // norm_ff; G0 is dead after it: group 2 replaces it
+    ffn(pb1, 0, 1024, 0.5f);                   // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
     {
       float4 y[2][4];
-      ln_apply(pb1, 1280, 1536, y);      // norm_final (encoder_layer.py:170-171): the block's output
+      ln_apply(pb1, 1280, 1536, y, 0);         // norm_final (encoder_layer.py:170-171): the block's output
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int f = 0; f < 4; ++f) xr[mi][f] = y[mi][f];
     }
-    stamp();  // 5: norm_final
     if (FINAL) {
       // after_norm (conformer_encoder.py:423-424); G2: [after_norm g 256][b 256]
       float4 y[2][4];
-      ln_apply(pb0, 0, 256, y);
+      ln_apply(pb0, 0, 256, y, BAR_LAST);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
         if (row_ok[mi]) {
@@ -611,71 +552,39 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
   if (HAS_A) {
     // GA (buffer 0): [norm_ff_macaron g 256][b 256][ffm b1 1024][ffm b2 256]
     // GA+1 (buffer 1): [norm_mha g 256][b 256][bq | bk | bv 768]
-    {
-      // first LayerNorm of the next block.  Inside ln_stats the first barrier follows norm_final's last
-      // read of G1, so the next group may replace it.
-      float mean[2], rstd[2];
-      ln_stats(mean, rstd);
-      if (HAS_D) issue_params(3);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const float4 g4 = *(const float4*)(pb0 + 64 * f + ncol);
-        const float4 b4 = *(const float4*)(pb0 + 256 + 64 * f + ncol);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          bf16x4 pk = {(bf16)((xr[mi][f].x - mean[mi]) * rstd[mi] * g4.x + b4.x),
-                       (bf16)((xr[mi][f].y - mean[mi]) * rstd[mi] * g4.y + b4.y),
-                       (bf16)((xr[mi][f].z - mean[mi]) * rstd[mi] * g4.z + b4.z),
-                       (bf16)((xr[mi][f].w - mean[mi]) * rstd[mi] * g4.w + b4.w)};
-          if (!ldr) *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
-        }
-      }
-      EM_LGKM0();
-      __builtin_amdgcn_s_barrier();
-      load_act();
-    }
-    stamp();  // 6: norm_ff_macaron
-    ffn(pb0, 512, 1536, 0.5f);           // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
-    stamp();  // 7: macaron FFN
+    // norm_ff_macaron.  After a D part, buffer 1 still holds G1 (norm_final read it just before this
+    // LayerNorm's first barrier): its successor may come in at this LayerNorm's last barrier.
+    ln_to_act(pb0, 0, 256, HAS_D ? BAR_PARAMS : 0);
+    ffn(pb0, 512, 1536, 0.5f);                 // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
     store_x();
-    ln_to_act(pb1, 0, 256);              // norm_mha (encoder_layer.py:123-127)
-    stamp();  // 8: norm_mha
+    ln_to_act(pb1, 0, 256, 0);                 // norm_mha (encoder_layer.py:123-127)
     // q / k / v projections (attention.py:91-97), written per head: Q, K as [B][H][Tpad][64], V transposed
     // as [B][H][64][Tpad] (computed with the MFMA operands swapped so a lane holds 4 consecutive frames).
     const int H = D / 64;
-    for (int u0 = 0; u0 < 12; u0 += 2) {
-      const int which = u0 >> 2;
-      f32x4 c[2][2];
-      begin(1);
-      k_unit(gs, which == 2, c[0], nothing);
-      gs += 1;
-      begin(1);
-      k_unit(gs, which == 2, c[1], nothing);
-      gs += 1;
+    for (int u = 0; u < 12; ++u) {
+      const int which = u >> 2, head = u & 3;
+      const size_t bh = (size_t)b * H + head;
+      f32x4 c[2];
+      k_unit(which == 2, c, nothing, 0);
+      if (which < 2) {
+        const float4 b4 = *(const float4*)(pb1 + 512 + u * 64 + ncol);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int u = u0 + j, head = u & 3;
-        const size_t bh = (size_t)b * H + head;
-        if (which < 2) {
-          const float4 b4 = *(const float4*)(pb1 + 512 + u * 64 + ncol);
+        for (int mi = 0; mi < 2; ++mi) {
+          bf16x4 pk = {(bf16)(c[mi][0] + b4.x), (bf16)(c[mi][1] + b4.y), (bf16)(c[mi][2] + b4.z),
+                       (bf16)(c[mi][3] + b4.w)};
+          *(bf16x4*)((bf16*)(which ? a.kh : a.qh) + (bh * a.Tpad + t0 + mi * 16 + lr) * 64 + ncol) = pk;
+        }
+      } else {
+        const float bvv = pb1[512 + u * 64 + nf * 16 + lr];
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            bf16x4 pk = {(bf16)(c[j][mi][0] + b4.x), (bf16)(c[j][mi][1] + b4.y), (bf16)(c[j][mi][2] + b4.z),
-                         (bf16)(c[j][mi][3] + b4.w)};
-            if (!ldr) *(bf16x4*)((bf16*)(which ? a.kh : a.qh) + (bh * a.Tpad + t0 + mi * 16 + lr) * 64 + ncol) = pk;
-          }
-        } else {
-          const float bvv = pb1[512 + u * 64 + nf * 16 + lr];
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            bf16x4 pk = {(bf16)(c[j][mi][0] + bvv), (bf16)(c[j][mi][1] + bvv), (bf16)(c[j][mi][2] + bvv),
-                         (bf16)(c[j][mi][3] + bvv)};
-            if (!ldr) *(bf16x4*)((bf16*)a.vt + (bh * 64 + nf * 16 + lr) * a.Tpad + t0 + mi * 16 + lg * 4) = pk;
-          }
+        for (int mi = 0; mi < 2; ++mi) {
+          bf16x4 pk = {(bf16)(c[mi][0] + bvv), (bf16)(c[mi][1] + bvv), (bf16)(c[mi][2] + bvv),
+                       (bf16)(c[mi][3] + bvv)};
+          *(bf16x4*)((bf16*)a.vt + (bh * 64 + nf * 16 + lr) * a.Tpad + t0 + mi * 16 + lg * 4) = pk;
         }
       }
     }
-    stamp();  // 9: q k v
+    bar(BAR_LAST);
   }
 }
 
@@ -720,26 +629,12 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
   UnitTable tab = {};
   const int total = build_units(MODE, a, &tab);
   dim3 grid(em_cdiv(a->T, BM), a->B);
-  static const int dbg = getenv("EM_BLOCK_DBG") ? atoi(getenv("EM_BLOCK_DBG")) : 0;  // ablations for tools/block_bench.py
-  static long long* stamps = nullptr;
-  static const bool want_stamps = getenv("EM_BLOCK_STAMPS") != nullptr;
-  if (want_stamps && !stamps) hipMalloc((void**)&stamps, 64 * sizeof(long long));
-  if (want_stamps) hipMemsetAsync(stamps, 0, 64 * sizeof(long long), s);
-  hipLaunchKernelGGL((block_kernel<MODE>), grid, dim3(NT), SMEM_BYTES, s, *a, tab, total, dbg, stamps);
-  if (want_stamps) {
-    long long h[64];
-    hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
-    printf("[block<%d> stamps, cycles since kernel start]", MODE);
-    for (int i = 1; i < 64 && h[i]; ++i) printf(" %lld", h[i] - h[0]);
-    printf("\n");
-    fflush(stdout);
-  }
+  hipLaunchKernelGGL((block_kernel<MODE>), grid, dim3(NT), SMEM_BYTES, s, *a, tab, total);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
 
 }  // namespace
-
 extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* stream) {
   if (!a || !a->x || !a->params || a->B <= 0 || a->T <= 0) return EM_ERR_BAD_ARG;
   if (a->d != D || a->ff <= 0 || a->ff % 64 != 0 || a->ff > 1024) return EM_ERR_UNSUPPORTED;
