@@ -41,6 +41,9 @@
 // rows of 128 B, XOR-swizzled on the source address like csrc/gemm.hip.  The order and addresses of the
 // units are a table built by the host per launch (a kernel argument, read with scalar loads), so the
 // per-unit control code is a handful of scalar instructions.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "em_common.h"
 
 namespace {
@@ -56,8 +59,7 @@ constexpr int RED_OFF = ABUF_OFF + 16384;    // 1 KiB: LayerNorm partial sums [2
 constexpr int PAR_OFF = RED_OFF + 1024;      // 2 x 7 KiB: bias / LayerNorm vectors, double buffered per group
 constexpr int PAR_FLOATS = EM_BLOCK_PARAM_GROUP;
 constexpr int PAR_BYTES = PAR_FLOATS * 4;
-constexpr int SYNC_OFF = PAR_OFF + 2 * PAR_BYTES;  // 64 B: barrier codes, compute waves -> loader waves
-constexpr int SMEM_BYTES = SYNC_OFF + 64;          // 162 880 B of the 163 840 B LDS
+constexpr int SMEM_BYTES = PAR_OFF + 2 * PAR_BYTES;  // 162 816 B of the 163 840 B LDS
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile (lives in ring slot 3)
 constexpr int MAX_UNITS = 96;
 
@@ -71,6 +73,16 @@ constexpr int BAR_LAST = 8;    // nothing follows: the loader waves leave
 // clear = K unit (64 rows of 512 B).
 struct UnitTable {
   unsigned long long u[MAX_UNITS];
+};
+// Code of every barrier of the launch, in order (host-built, build_schedule): what the loader waves need to know
+// about the compute waves' progress.  (They used to read it from an LDS word the compute waves wrote before each
+// barrier; a ds_read issued behind a wave's own LDS-DMA instructions waits for those transfers -- +0.16 us per
+// unit in tools/experiments/glds_bench.hip -- so the loaders must not touch LDS.)
+constexpr int MAX_BARRIERS = 160;
+struct Schedule {  // 4 bits per barrier, eight per word: a byte array would be read with a VECTOR load, whose
+  unsigned w[MAX_BARRIERS / 8];  // completion wait (vmcnt(0)) drains the loader's whole DMA queue every interval
+  __host__ __device__ int get(int k) const { return (w[k >> 3] >> ((k & 7) * 4)) & 15; }
+  void set(int k, int code) { w[k >> 3] |= (unsigned)code << ((k & 7) * 4); }
 };
 
 // LDS-DMA issued from inline asm: global_load_lds_dwordx4 with a wave-uniform 64-bit base (SGPR pair)
@@ -125,7 +137,8 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
 #define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int MODE>
-__global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const UnitTable tab, const int total) {
+__global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const UnitTable tab, const Schedule sched,
+                                                   const int total, const int dbg, long long* __restrict__ stamps) {
   using MM = Mma<bf16>;
   constexpr bool HAS_C = (MODE & EM_BLOCK_C) != 0, HAS_D = (MODE & EM_BLOCK_D) != 0;
   constexpr bool HAS_A = (MODE & EM_BLOCK_A) != 0, FINAL = (MODE & EM_BLOCK_FINAL) != 0;
@@ -134,7 +147,6 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
   unsigned char* const abuf = smem + ABUF_OFF;
   float* const red = (float*)(smem + RED_OFF);
   const float* const par = (const float*)(smem + PAR_OFF);
-  volatile int* const sync = (volatile int*)(smem + SYNC_OFF);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,8 +176,8 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       kofs[i] = n * (D * 2) + nf * 128 + gc * 16;
       w2ofs[i] = (64 * nf + n) * 128 + gc * 16;
     }
-    auto issue_unit = [&](int g) {
-      const unsigned long long d = tab.u[g];
+    auto issue_unit = [&](int g, unsigned long long d) {  // d = tab.u[g], fetched one interval earlier
+      if (dbg & 2) return;
       const unsigned char* base = uniform_ptr((const unsigned char*)(d & ~1ull));
       const bool w2 = (d & 1ull) != 0;
       const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)((g & (NSLOT - 1)) * UNIT + nf * 8192));
@@ -183,21 +195,38 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     issue_params(0);
     if (!HAS_C) issue_params(1);
     int gi = 0, started = 0, pgrp = 2;
-    for (; gi < NSLOT - 1 && gi < total; ++gi) issue_unit(gi);
+    for (; gi < NSLOT - 1 && gi < total; ++gi) issue_unit(gi, tab.u[gi]);
+    // The loader's own chain per interval is what paces the ring when it is long (measured: barrier -> LDS read
+    // of the code word -> scalar load of the table entry -> 8 DMA issues = 1 100 cycles, and every interval
+    // waited for it whether or not the compute waves had anything to do).  So: the table entry of the next unit
+    // is fetched an interval ahead, the unit is issued IMMEDIATELY after the barrier (what may be issued depends
+    // only on the codes of EARLIER barriers: every unit below `started` is finished at any barrier), and this
+    // barrier's code word is read afterwards, while the DMA is already on its way.
+    unsigned long long dnext = tab.u[gi < total ? gi : 0];
+    int code = sched.get(0);
     for (int k = 0;; ++k) {
       const int need = started + 1 < gi ? started + 1 : gi;  // units below `need` must have landed
-      const int later = gi - need;
+      const int later = (dbg & 2) ? 3 : gi - need;
       if (later >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       else if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const int code = __builtin_amdgcn_readfirstlane(sync[k & 1]);
+      // every unit below `started` is finished; the conv tile occupies slot 3 while BAR_TILE
       const int cap = started + ((code & BAR_TILE) ? NSLOT - 1 : NSLOT);
-      for (; gi < total && gi < cap; ++gi) issue_unit(gi);
+      if (gi < total && gi < cap) {
+        issue_unit(gi, dnext);
+        ++gi;
+        dnext = tab.u[gi < total ? gi : 0];
+      }
+      for (; gi < total && gi < cap; ++gi) {  // more than one free slot: only around stage boundaries
+        issue_unit(gi, tab.u[gi]);
+        dnext = tab.u[gi + 1 < total ? gi + 1 : 0];
+      }
       if (code & BAR_PARAMS) issue_params(pgrp++);
       if (code & BAR_UNIT) ++started;
       if (code & BAR_LAST) break;
+      code = sched.get(k + 1);
     }
     return;
   }
@@ -217,11 +246,19 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
   // byte offset of (frame lr, columns ncol .. ncol + 3) inside a [32][64] bf16 k-tile of abuf (+ 2048 for frame 16 + lr)
   const int tile_wr = lr * 128 + (((2 * nf + (lg >> 1)) ^ swz) << 4) + (lg & 1) * 8;
   const int nch = a.ff >> 6;  // 64-wide chunks of the FFN hidden dimension
+  // developer profiling (EM_BLOCK_STAMPS / EM_BLOCK_DBG, tools/block_bench.py): stage-level cycle stamps of thread 0
+  // of workgroup (0, 0); dbg 1 = no MFMA / epilogue work, dbg 2 = no DMA
+  int nts = 0;
+  auto stamp = [&]() {
+    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nts < 64) stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
+    ++nts;
+  };
+  stamp();
   int gs = 0;    // units whose interval has been opened; unit g lives in ring slot g & 3
   int nbar = 0;  // barriers passed
   // every barrier goes through here: publish its code for the loaders, retire own LDS operations, synchronise
-  auto bar = [&](int code) {
-    if (tid == 0) sync[nbar & 1] = code;
+  auto bar = [&](int code) {  // `code` documents what build_schedule() tells the loaders about this barrier
+    (void)code;
     ++nbar;
     EM_LGKM0();
     __builtin_amdgcn_s_barrier();
@@ -326,6 +363,10 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     bar(BAR_UNIT | code);
     const unsigned char* su = ring + (gs & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
     ++gs;
+    if (dbg & 1) {
+      out[0] = out[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      return;
+    }
     f32x4 c[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) c[mi][0] = c[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -355,6 +396,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc2[mi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto h_store = [&](const f32x4 h[2], int c) {
+      if (dbg & 1) return;
       const float4 bb = *(const float4*)(pb + b1o + c * 64 + ncol);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -367,6 +409,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       bar(BAR_UNIT);
       const unsigned char* su = ring + (gs & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
       ++gs;
+      if (dbg & 1) return;
       const unsigned char* sh = abuf + (c & 1) * 4096 + lr * 128;
       bf16x8 hf[2][2], w[2][4];
 #pragma unroll
@@ -517,10 +560,14 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     }
     bar(0);  // conv output visible; the tile (slot 3) is free
     load_act();
+    stamp();  // 1 conv prologue
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]
     proj_resid(pb0, 0);                        // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
+    stamp();  // 2
     ln_to_act(pb0, 256, 512, BAR_PARAMS);      // norm_ff; G0 is dead after it: group 2 replaces it
+    stamp();  // 3
     ffn(pb1, 0, 1024, 0.5f);                   // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
+    stamp();  // 4
     {
       float4 y[2][4];
       ln_apply(pb1, 1280, 1536, y, 0);         // norm_final (encoder_layer.py:170-171): the block's output
@@ -554,10 +601,14 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     // GA+1 (buffer 1): [norm_mha g 256][b 256][bq | bk | bv 768]
     // norm_ff_macaron.  After a D part, buffer 1 still holds G1 (norm_final read it just before this
     // LayerNorm's first barrier): its successor may come in at this LayerNorm's last barrier.
+    stamp();  // 5 norm_final
     ln_to_act(pb0, 0, 256, HAS_D ? BAR_PARAMS : 0);
+    stamp();  // 6 norm_ff_macaron
     ffn(pb0, 512, 1536, 0.5f);                 // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
+    stamp();  // 7 macaron FFN
     store_x();
     ln_to_act(pb1, 0, 256, 0);                 // norm_mha (encoder_layer.py:123-127)
+    stamp();  // 8 norm_mha
     // q / k / v projections (attention.py:91-97), written per head: Q, K as [B][H][Tpad][64], V transposed
     // as [B][H][64][Tpad] (computed with the MFMA operands swapped so a lane holds 4 consecutive frames).
     const int H = D / 64;
@@ -584,6 +635,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         }
       }
     }
+    stamp();  // 9 q k v
     bar(BAR_LAST);
   }
 }
@@ -617,6 +669,47 @@ int build_units(int mode, const EmBlockArgs* a, UnitTable* t) {
   return n;
 }
 
+// The barrier sequence of block_kernel<mode>, barrier by barrier (keep in step with the kernel: every bar(code)
+// there appears here, in order).
+int build_schedule(int mode, const EmBlockArgs* a, Schedule* sc) {
+  int n = 0;
+  const int nch = a->ff / 64;
+  auto put = [&](int code, int count = 1) {
+    for (int i = 0; i < count && n < MAX_BARRIERS; ++i) sc->set(n++, code);
+  };
+  if (mode & EM_BLOCK_C) {
+    put(BAR_UNIT, 4);       // linear_out
+    put(0, 3);              // norm_conv: two statistics barriers, one publishing LN(x)
+    put(BAR_UNIT, 8);       // pointwise_conv1
+    put(BAR_LAST);
+    return n;
+  }
+  if (mode & EM_BLOCK_D) {
+    put(BAR_TILE);          // conv tile staged
+    put(0);                 // conv output published
+    put(BAR_UNIT, 4);       // pointwise_conv2
+    put(0, 2);              // norm_ff statistics
+    put(BAR_PARAMS);        // norm_ff published; parameter group 0 is dead
+    put(BAR_UNIT, 2 * nch); // FFN
+    put(0);                 // norm_final statistics
+    put(0);
+    if (mode & EM_BLOCK_FINAL) {
+      put(0);               // after_norm statistics
+      put(BAR_LAST);
+      return n;
+    }
+  }
+  if (mode & EM_BLOCK_A) {
+    put(0, 2);              // norm_ff_macaron statistics
+    put((mode & EM_BLOCK_D) ? BAR_PARAMS : 0);  // published; after a D part parameter group 1 is dead
+    put(BAR_UNIT, 2 * nch); // macaron FFN
+    put(0, 3);              // norm_mha
+    put(BAR_UNIT, 12);      // q, k, v
+    put(BAR_LAST);
+  }
+  return n;
+}
+
 template <int MODE>
 int launch_block(const EmBlockArgs* a, hipStream_t s) {
   static bool attr_set = false;
@@ -628,8 +721,23 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
   }
   UnitTable tab = {};
   const int total = build_units(MODE, a, &tab);
+  Schedule sched = {};
+  build_schedule(MODE, a, &sched);
   dim3 grid(em_cdiv(a->T, BM), a->B);
-  hipLaunchKernelGGL((block_kernel<MODE>), grid, dim3(NT), SMEM_BYTES, s, *a, tab, total);
+  static const int dbg = getenv("EM_BLOCK_DBG") ? atoi(getenv("EM_BLOCK_DBG")) : 0;
+  static long long* stamps = nullptr;
+  static const bool want_stamps = getenv("EM_BLOCK_STAMPS") != nullptr;
+  if (want_stamps && !stamps) hipMalloc((void**)&stamps, 64 * sizeof(long long));
+  if (want_stamps) hipMemsetAsync(stamps, 0, 64 * sizeof(long long), s);
+  hipLaunchKernelGGL((block_kernel<MODE>), grid, dim3(NT), SMEM_BYTES, s, *a, tab, sched, total, dbg, stamps);
+  if (want_stamps) {
+    long long h[64];
+    hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+    printf("[block<%d> stamps, cycles since kernel start]", MODE);
+    for (int i = 1; i < 64 && h[i]; ++i) printf(" %lld", h[i] - h[0]);
+    printf("\n");
+    fflush(stdout);
+  }
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
