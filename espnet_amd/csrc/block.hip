@@ -356,13 +356,33 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     bar(code);
     load_act();
   };
-  // the next K unit of the stream (one barrier): fragments C^T[n = nf*16 + lg*4 + r][m = mi*16 + lr]
-  // (swap: C[m = mi*16 + lg*4 + r][n = nf*16 + lr]).  `between` runs after the fragment reads have been
-  // requested: deferred VALU / LDS work that fills the issue gaps between the MFMAs.
-  auto k_unit = [&](bool swap, f32x4 out[2], auto&& between, int code) {
+  // ---- units: fragment reads run ONE INTERVAL AHEAD of the MFMAs ---------------------------------------
+  // open(): the barrier that makes the next unit of the stream visible (and releases the previous one: its
+  // fragments are in registers by then); read_k / read_w2: its eight fragments LDS -> registers.  A stage
+  // processes unit u from registers while the reads of unit u + 1 are in flight, so the LDS latency hides behind
+  // matrix work instead of opening every interval (a single wave per SIMD has no other wave to hide it with).
+  struct WF {
+    bf16x8 v[8];
+  };
+  auto open = [&](int code) -> const unsigned char* {
     bar(BAR_UNIT | code);
     const unsigned char* su = ring + (gs & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
     ++gs;
+    return su;
+  };
+  auto read_k = [&](const unsigned char* su, WF& w) {  // K unit: fragment ks at v[ks]
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w.v[ks] = *(const bf16x8*)(su + (ks >> 1) * 8192 + ((((ks & 1) * 4 + lg) ^ swz) << 4));
+  };
+  auto read_w2 = [&](const unsigned char* su, WF& w) {  // W2 unit: fragment (f, ks) at v[2 f + ks]
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) w.v[2 * f + ks] = *(const bf16x8*)(su + f * 8192 + (((ks * 4 + lg) ^ swz) << 4));
+  };
+  // 16 MFMAs of a K unit: out[mi] = C^T[n = nf*16 + lg*4 + r][m = mi*16 + lr]
+  // (swap: C[m = mi*16 + lg*4 + r][n = nf*16 + lr])
+  auto mma_k = [&](const WF& w, bool swap, f32x4 out[2]) {
     if (dbg & 1) {
       out[0] = out[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       return;
@@ -370,26 +390,40 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     f32x4 c[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) c[mi][0] = c[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 w[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) w[ks] = *(const bf16x8*)(su + (ks >> 1) * 8192 + ((((ks & 1) * 4 + lg) ^ swz) << 4));
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // all 8 DS reads first: one exposed LDS latency per unit
-    between();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        c[mi][ks & 1] = swap ? MM::mma(act[mi][ks], w[ks], c[mi][ks & 1]) : MM::mma(w[ks], act[mi][ks], c[mi][ks & 1]);
+        c[mi][ks & 1] = swap ? MM::mma(act[mi][ks], w.v[ks], c[mi][ks & 1]) : MM::mma(w.v[ks], act[mi][ks], c[mi][ks & 1]);
     out[0] = c[0][0] + c[0][1];
     out[1] = c[1][0] + c[1][1];
   };
-  auto nothing = []() {};
-  // x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o.  2 * nch units in the order
-  // K0 | K1 + epilogue(K0) | W2_0 | K2 + epilogue(K1) | W2_1 | ... | W2_last (build_units): the Swish epilogue of
-  // chunk c (bias, exp, rcp, bf16 pack, LDS store of H[c & 1]) is deferred into the interval of K unit c + 1,
-  // where it fills the issue gaps between that unit's MFMAs; W2 unit c runs one interval later.  The two H
-  // tiles [32][64] alias abuf's first two k-tiles (the activation fragments are in registers by then).
-  auto ffn = [&](const float* pb, int b1o, int b2o, float scale) {
+  // LN(x) -> bf16 -> abuf; the publishing barrier also opens the first unit of the stage that consumes it
+  auto ln_to_act_open = [&](const float* pb, int go, int bo, int code, WF& w0) {
+    float4 y[2][4];
+    ln_apply(pb, go, bo, y, 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        bf16x4 pk = {(bf16)y[mi][f].x, (bf16)y[mi][f].y, (bf16)y[mi][f].z, (bf16)y[mi][f].w};
+        *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
+      }
+    const unsigned char* su = open(code);
+    read_k(su, w0);
+    load_act();
+  };
+  // x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o.  Units in the order
+  // K0 K1 W2_0 K2 W2_1 ... K_last W2_last-1 W2_last (build_units); K0 has been opened by the caller, its
+  // fragments are arriving in wa.  Interval by interval (r = fragment reads of the unit just opened):
+  //   r K1   | mma K0 -> h0
+  //   r W2_0 | Swish(h0) -> H[0] | mma K1 -> h1
+  //   r K2   | Swish(h1) -> H[1] | mma W2_0 (H[0])
+  //   r W2_1 |                     mma K2 -> h2           ... and so on; the last interval has nothing to read.
+  // The Swish epilogue of chunk c (bias, exp, rcp, bf16 pack, LDS store of H[c & 1]) always shares an interval
+  // with the MFMAs of another unit.  2 nch barriers, the last one plain.  The two H tiles [32][64] alias abuf's
+  // first two k-tiles (the activation fragments are in registers by then).
+  auto ffn = [&](const float* pb, int b1o, int b2o, float scale, WF& wa) {
     f32x4 acc2[2][4];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -405,44 +439,67 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         *(bf16x4*)(abuf + (c & 1) * 4096 + mi * 2048 + tile_wr) = pk;  // H[c & 1][m][k = ncol ..]
       }
     };
-    auto w2_unit = [&](int c) {
-      bar(BAR_UNIT);
-      const unsigned char* su = ring + (gs & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
-      ++gs;
+    auto mma_w2 = [&](const WF& w, int c) {
       if (dbg & 1) return;
       const unsigned char* sh = abuf + (c & 1) * 4096 + lr * 128;
-      bf16x8 hf[2][2], w[2][4];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int coff = ((ks * 4 + lg) ^ swz) << 4;
-        hf[ks][0] = *(const bf16x8*)(sh + coff);
-        hf[ks][1] = *(const bf16x8*)(sh + 2048 + coff);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) w[ks][f] = *(const bf16x8*)(su + f * 8192 + coff);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        const bf16x8 h0 = *(const bf16x8*)(sh + coff);
+        const bf16x8 h1 = *(const bf16x8*)(sh + 2048 + coff);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          acc2[0][f] = MM::mma(w[ks][f], hf[ks][0], acc2[0][f]);
-          acc2[1][f] = MM::mma(w[ks][f], hf[ks][1], acc2[1][f]);
+          acc2[0][f] = MM::mma(w.v[2 * f + ks], h0, acc2[0][f]);
+          acc2[1][f] = MM::mma(w.v[2 * f + ks], h1, acc2[1][f]);
         }
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // 12 DS reads
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMA
+      }
     };
+    // An interval that carries a Swish epilogue next to 16 MFMAs: all LDS reads first (next unit's fragments,
+    // bias, H fragments), then the epilogue's VALU / transcendental instructions dealt into the issue gaps between
+    // the MFMAs (left alone hipcc emits the whole epilogue, then the MFMAs: serial on a single wave per SIMD).
+#define EM_INTERLEAVE(NREADS)                                 \
+  do {                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {       \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      \
+    }                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);        \
+  } while (0)
+    WF wb;
     f32x4 hp[2];
-    k_unit(false, hp, nothing, 0);
-    for (int c = 0; c < nch; ++c) {
-      if (c + 1 < nch) {
+    if (nch == 1) {
+      read_w2(open(0), wb);
+      mma_k(wa, false, hp);
+      h_store(hp, 0);
+      bar(0);
+      mma_w2(wb, 0);
+    } else {
+      read_k(open(0), wb);       // K1
+      mma_k(wa, false, hp);      // h0
+      read_w2(open(0), wa);      // W2_0
+      {
         f32x4 hn[2];
-        k_unit(false, hn, [&]() { h_store(hp, c); }, 0);
-        w2_unit(c);
+        h_store(hp, 0);
+        mma_k(wb, false, hn);    // h1
+        EM_INTERLEAVE(9);
         hp[0] = hn[0];
         hp[1] = hn[1];
-      } else {
-        h_store(hp, c);
-        w2_unit(c);
       }
+      for (int c = 0; c + 2 < nch; ++c) {
+        read_k(open(0), wb);     // K_{c+2}
+        h_store(hp, c + 1);
+        mma_w2(wa, c);
+        EM_INTERLEAVE(13);
+        read_w2(open(0), wa);    // W2_{c+1}
+        mma_k(wb, false, hp);    // h_{c+2}
+      }
+      read_w2(open(0), wb);      // W2_last
+      h_store(hp, nch - 1);
+      mma_w2(wa, nch - 2);
+      EM_INTERLEAVE(13);
+      bar(0);
+      mma_w2(wb, nch - 1);
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -456,12 +513,16 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       }
     }
   };
-  // x += (W . act + bias): four K units (N = 256)
-  auto proj_resid = [&](const float* pb, int bo) {
+  // x += (W . act + bias): four K units (N = 256), the first already opened into w[0]
+  auto proj_resid = [&](const float* pb, int bo, WF& w0) {
+    WF w1;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
+      WF& cur = (f & 1) ? w1 : w0;
+      WF& nxt = (f & 1) ? w0 : w1;
+      if (f + 1 < 4) read_k(open(0), nxt);
       f32x4 c[2];
-      k_unit(false, c, nothing, 0);
+      mma_k(cur, false, c);
       const float4 b4 = *(const float4*)(pb + bo + 64 * f + ncol);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -475,6 +536,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
 
   const float* const pb0 = par;
   const float* const pb1 = par + PAR_FLOATS;
+  WF w0;  // fragments of the unit a stage starts with
 
   if (HAS_C) {
     // linear_out over the attention context: activation fragments straight from global memory
@@ -487,26 +549,35 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     }
     load_x();
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
-    proj_resid(pb0, 0);
+    read_k(open(0), w0);
+    proj_resid(pb0, 0, w0);
     store_x();
-    ln_to_act(pb0, 256, 512, 0);
+    ln_to_act_open(pb0, 256, 512, 0, w0);
     // pointwise_conv1 + GLU (convolution.py:66-69): unit 2j = value rows 64j.., unit 2j+1 = their gates
-    for (int j = 0; j < 4; ++j) {
-      f32x4 v[2], gt[2];
-      k_unit(false, v, nothing, 0);
-      k_unit(false, gt, nothing, 0);
-      const float4 bv = *(const float4*)(pb0 + 768 + (2 * j) * 64 + ncol);
-      const float4 bg = *(const float4*)(pb0 + 768 + (2 * j + 1) * 64 + ncol);
+    WF w1;
+    f32x4 v[2], gt[2];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        bf16x4 pk = {(bf16)((v[mi][0] + bv.x) * sigmoidf_(gt[mi][0] + bg.x)),
-                     (bf16)((v[mi][1] + bv.y) * sigmoidf_(gt[mi][1] + bg.y)),
-                     (bf16)((v[mi][2] + bv.z) * sigmoidf_(gt[mi][2] + bg.z)),
-                     (bf16)((v[mi][3] + bv.w) * sigmoidf_(gt[mi][3] + bg.w))};
-        if (row_ok[mi]) *(bf16x4*)((bf16*)a.glu + mrow[mi] * D + 64 * j + ncol) = pk;
+    for (int u = 0; u < 8; ++u) {
+      WF& cur = (u & 1) ? w1 : w0;
+      WF& nxt = (u & 1) ? w0 : w1;
+      if (u + 1 < 8) read_k(open(u + 2 == 8 ? BAR_LAST : 0), nxt);
+      if (!(u & 1)) {
+        mma_k(cur, false, v);
+      } else {
+        mma_k(cur, false, gt);
+        const int j = u >> 1;
+        const float4 bv = *(const float4*)(pb0 + 768 + (2 * j) * 64 + ncol);
+        const float4 bg = *(const float4*)(pb0 + 768 + (2 * j + 1) * 64 + ncol);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          bf16x4 pk = {(bf16)((v[mi][0] + bv.x) * sigmoidf_(gt[mi][0] + bg.x)),
+                       (bf16)((v[mi][1] + bv.y) * sigmoidf_(gt[mi][1] + bg.y)),
+                       (bf16)((v[mi][2] + bv.z) * sigmoidf_(gt[mi][2] + bg.z)),
+                       (bf16)((v[mi][3] + bv.w) * sigmoidf_(gt[mi][3] + bg.w))};
+          if (row_ok[mi]) *(bf16x4*)((bf16*)a.glu + mrow[mi] * D + 64 * j + ncol) = pk;
+        }
       }
     }
-    bar(BAR_LAST);
     return;
   }
 
@@ -558,19 +629,19 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         }
       }
     }
-    bar(0);  // conv output visible; the tile (slot 3) is free
+    read_k(open(0), w0);  // conv output visible, the tile (slot 3) is free, pointwise_conv2's first unit open
     load_act();
     stamp();  // 1 conv prologue
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]
-    proj_resid(pb0, 0);                        // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
+    proj_resid(pb0, 0, w0);                        // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
     stamp();  // 2
-    ln_to_act(pb0, 256, 512, BAR_PARAMS);      // norm_ff; G0 is dead after it: group 2 replaces it
+    ln_to_act_open(pb0, 256, 512, BAR_PARAMS, w0); // norm_ff; G0 is dead after it: group 2 replaces it
     stamp();  // 3
-    ffn(pb1, 0, 1024, 0.5f);                   // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
+    ffn(pb1, 0, 1024, 0.5f, w0);                   // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
     stamp();  // 4
     {
       float4 y[2][4];
-      ln_apply(pb1, 1280, 1536, y, 0);         // norm_final (encoder_layer.py:170-171): the block's output
+      ln_apply(pb1, 1280, 1536, y, 0);             // norm_final (encoder_layer.py:170-171): the block's output
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -602,21 +673,26 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     // norm_ff_macaron.  After a D part, buffer 1 still holds G1 (norm_final read it just before this
     // LayerNorm's first barrier): its successor may come in at this LayerNorm's last barrier.
     stamp();  // 5 norm_final
-    ln_to_act(pb0, 0, 256, HAS_D ? BAR_PARAMS : 0);
+    ln_to_act_open(pb0, 0, 256, HAS_D ? BAR_PARAMS : 0, w0);
     stamp();  // 6 norm_ff_macaron
-    ffn(pb0, 512, 1536, 0.5f);                 // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
+    ffn(pb0, 512, 1536, 0.5f, w0);                 // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
     stamp();  // 7 macaron FFN
     store_x();
-    ln_to_act(pb1, 0, 256, 0);                 // norm_mha (encoder_layer.py:123-127)
+    ln_to_act_open(pb1, 0, 256, 0, w0);            // norm_mha (encoder_layer.py:123-127)
     stamp();  // 8 norm_mha
     // q / k / v projections (attention.py:91-97), written per head: Q, K as [B][H][Tpad][64], V transposed
     // as [B][H][64][Tpad] (computed with the MFMA operands swapped so a lane holds 4 consecutive frames).
     const int H = D / 64;
+    WF w1;
+#pragma unroll
     for (int u = 0; u < 12; ++u) {
+      WF& cur = (u & 1) ? w1 : w0;
+      WF& nxt = (u & 1) ? w0 : w1;
+      if (u + 1 < 12) read_k(open(u + 2 == 12 ? BAR_LAST : 0), nxt);
       const int which = u >> 2, head = u & 3;
       const size_t bh = (size_t)b * H + head;
       f32x4 c[2];
-      k_unit(which == 2, c, nothing, 0);
+      mma_k(cur, which == 2, c);
       if (which < 2) {
         const float4 b4 = *(const float4*)(pb1 + 512 + u * 64 + ncol);
 #pragma unroll
@@ -636,7 +712,6 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       }
     }
     stamp();  // 9 q k v
-    bar(BAR_LAST);
   }
 }
 
@@ -678,34 +753,39 @@ int build_schedule(int mode, const EmBlockArgs* a, Schedule* sc) {
     for (int i = 0; i < count && n < MAX_BARRIERS; ++i) sc->set(n++, code);
   };
   if (mode & EM_BLOCK_C) {
-    put(BAR_UNIT, 4);       // linear_out
-    put(0, 3);              // norm_conv: two statistics barriers, one publishing LN(x)
-    put(BAR_UNIT, 8);       // pointwise_conv1
-    put(BAR_LAST);
+    put(BAR_UNIT, 4);             // linear_out: one barrier opens each unit
+    put(0, 2);                    // norm_conv statistics
+    put(BAR_UNIT);                // LN(x) published + first unit of pointwise_conv1
+    put(BAR_UNIT, 6);
+    put(BAR_UNIT | BAR_LAST);
     return n;
   }
-  if (mode & EM_BLOCK_D) {
-    put(BAR_TILE);          // conv tile staged
-    put(0);                 // conv output published
-    put(BAR_UNIT, 4);       // pointwise_conv2
-    put(0, 2);              // norm_ff statistics
-    put(BAR_PARAMS);        // norm_ff published; parameter group 0 is dead
-    put(BAR_UNIT, 2 * nch); // FFN
-    put(0);                 // norm_final statistics
+  auto ffn_bars = [&]() {         // the first unit is opened by the LayerNorm before; one plain barrier at the end
+    put(BAR_UNIT, 2 * nch - 1);
     put(0);
+  };
+  if (mode & EM_BLOCK_D) {
+    put(BAR_TILE);                // conv tile staged
+    put(BAR_UNIT);                // conv output published + first unit of pointwise_conv2
+    put(BAR_UNIT, 3);
+    put(0, 2);                    // norm_ff statistics
+    put(BAR_PARAMS | BAR_UNIT);   // norm_ff published, parameter group 0 dead, FFN's first unit
+    ffn_bars();
+    put(0, 2);                    // norm_final statistics
     if (mode & EM_BLOCK_FINAL) {
-      put(0);               // after_norm statistics
+      put(0);                     // after_norm statistics
       put(BAR_LAST);
       return n;
     }
   }
   if (mode & EM_BLOCK_A) {
-    put(0, 2);              // norm_ff_macaron statistics
-    put((mode & EM_BLOCK_D) ? BAR_PARAMS : 0);  // published; after a D part parameter group 1 is dead
-    put(BAR_UNIT, 2 * nch); // macaron FFN
-    put(0, 3);              // norm_mha
-    put(BAR_UNIT, 12);      // q, k, v
-    put(BAR_LAST);
+    put(0, 2);                    // norm_ff_macaron statistics
+    put(((mode & EM_BLOCK_D) ? BAR_PARAMS : 0) | BAR_UNIT);  // published; after a D part parameter group 1 is dead
+    ffn_bars();
+    put(0, 2);                    // norm_mha statistics
+    put(BAR_UNIT);                // published + first q unit
+    put(BAR_UNIT, 10);
+    put(BAR_UNIT | BAR_LAST);
   }
   return n;
 }
