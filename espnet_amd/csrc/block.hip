@@ -55,11 +55,11 @@ constexpr int NC = 256;                      // compute threads
 constexpr int UNIT = 32768;
 constexpr int NSLOT = 4;
 constexpr int ABUF_OFF = NSLOT * UNIT;       // 16 KiB: LN(x) as four [32][64] k-tiles; the FFN's two H tiles alias tiles 0, 1
-constexpr int RED_OFF = ABUF_OFF + 16384;    // 1 KiB: LayerNorm partial sums [2][4][32]
-constexpr int PAR_OFF = RED_OFF + 1024;      // 2 x 7 KiB: bias / LayerNorm vectors, double buffered per group
+constexpr int RED_OFF = ABUF_OFF + 16384;    // 2 x 1 KiB: LayerNorm partials [2][4][32], alternating between consecutive LayerNorms
+constexpr int PAR_OFF = RED_OFF + 2048;      // 2 x 7 KiB: bias / LayerNorm vectors, double buffered per group
 constexpr int PAR_FLOATS = EM_BLOCK_PARAM_GROUP;
 constexpr int PAR_BYTES = PAR_FLOATS * 4;
-constexpr int SMEM_BYTES = PAR_OFF + 2 * PAR_BYTES;  // 162 816 B of the 163 840 B LDS
+constexpr int SMEM_BYTES = PAR_OFF + 2 * PAR_BYTES;  // all 163 840 B of the LDS
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile (lives in ring slot 3)
 constexpr int MAX_UNITS = 96;
 
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const ring = smem;
   unsigned char* const abuf = smem + ABUF_OFF;
-  float* const red = (float*)(smem + RED_OFF);
+  float* const red0 = (float*)(smem + RED_OFF);
   const float* const par = (const float*)(smem + PAR_OFF);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -288,40 +288,51 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       for (int ks = 0; ks < 8; ++ks)
         act[mi][ks] = *(const bf16x8*)(abuf + ((ks >> 1) * 32 + mi * 16 + lr) * 128 + ((((ks & 1) * 4 + lg) ^ swz) << 4));
   };
-  // LayerNorm statistics of the 32 rows (two-pass, as layer_norm.py / torch: mean, then the variance of
-  // the centred values).  A row is spread over 4 lane groups x 4 waves.  Two barriers; `code` rides on the second.
+  // LayerNorm statistics of the 32 rows.  A row is spread over 4 lane groups x 4 waves: every holder reduces its
+  // 16 values to (sum, sum of squares about its own mean), the lane groups combine with Chan's update over two
+  // shuffles, the four waves through ONE LDS exchange (instead of the mean pass + centred pass with a barrier
+  // each; same result to f32 round-off: nothing is formed as a difference of large numbers).  One barrier.
+  int nln = 0;  // LayerNorms so far: consecutive ones alternate the exchange buffer (there is no barrier between one's reads and the next one's writes)
   auto ln_stats = [&](float mean[2], float rstd[2], int code) {
+    float* const red = red0 + (nln & 1) * 256;
+    ++nln;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       float s = 0.f;
 #pragma unroll
       for (int f = 0; f < 4; ++f) s += (xr[mi][f].x + xr[mi][f].y) + (xr[mi][f].z + xr[mi][f].w);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (lg == 0) red[nf * 32 + mi * 16 + lr] = s;
-    }
-    bar(0);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = mi * 16 + lr;
-      mean[mi] = ((red[m] + red[32 + m]) + (red[64 + m] + red[96 + m])) * (1.0f / D);
+      const float m0 = s * (1.0f / 16.0f);
       float q = 0.f;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const float dx = xr[mi][f].x - mean[mi], dy = xr[mi][f].y - mean[mi], dz = xr[mi][f].z - mean[mi],
-                    dw = xr[mi][f].w - mean[mi];
+        const float dx = xr[mi][f].x - m0, dy = xr[mi][f].y - m0, dz = xr[mi][f].z - m0, dw = xr[mi][f].w - m0;
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
-      if (lg == 0) red[128 + nf * 32 + m] = q;
+      // combine equal-sized groups: n doubles, M2 = M2a + M2b + (sa - sb)^2 / (2 n)
+      float so = __shfl_xor(s, 16, 64), qo = __shfl_xor(q, 16, 64);
+      q = q + qo + (s - so) * (s - so) * (1.0f / 32.0f);
+      s += so;
+      so = __shfl_xor(s, 32, 64);
+      qo = __shfl_xor(q, 32, 64);
+      q = q + qo + (s - so) * (s - so) * (1.0f / 64.0f);
+      s += so;
+      if (lg == 0) {
+        red[nf * 32 + mi * 16 + lr] = s;        // sum over this wave's 64 columns
+        red[128 + nf * 32 + mi * 16 + lr] = q;  // sum of squares about their mean
+      }
     }
     bar(code);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int m = mi * 16 + lr;
-      const float var = ((red[128 + m] + red[160 + m]) + (red[192 + m] + red[224 + m])) * (1.0f / D);
-      rstd[mi] = 1.0f / sqrtf(var + a.eps);
+      const float s0 = red[m], s1 = red[32 + m], s2 = red[64 + m], s3 = red[96 + m];
+      const float q0 = red[128 + m], q1 = red[160 + m], q2 = red[192 + m], q3 = red[224 + m];
+      const float sa = s0 + s1, sb = s2 + s3;
+      const float qa = q0 + q1 + (s0 - s1) * (s0 - s1) * (1.0f / 128.0f);
+      const float qb = q2 + q3 + (s2 - s3) * (s2 - s3) * (1.0f / 128.0f);
+      const float qq = qa + qb + (sa - sb) * (sa - sb) * (1.0f / 256.0f);
+      mean[mi] = (sa + sb) * (1.0f / D);
+      rstd[mi] = 1.0f / sqrtf(qq * (1.0f / D) + a.eps);
     }
   };
   // y = LN(x; g, b) with g, b at float offsets go / bo of parameter buffer pb
@@ -754,7 +765,7 @@ int build_schedule(int mode, const EmBlockArgs* a, Schedule* sc) {
   };
   if (mode & EM_BLOCK_C) {
     put(BAR_UNIT, 4);             // linear_out: one barrier opens each unit
-    put(0, 2);                    // norm_conv statistics
+    put(0);                       // norm_conv statistics
     put(BAR_UNIT);                // LN(x) published + first unit of pointwise_conv1
     put(BAR_UNIT, 6);
     put(BAR_UNIT | BAR_LAST);
@@ -768,21 +779,20 @@ int build_schedule(int mode, const EmBlockArgs* a, Schedule* sc) {
     put(BAR_TILE);                // conv tile staged
     put(BAR_UNIT);                // conv output published + first unit of pointwise_conv2
     put(BAR_UNIT, 3);
-    put(0, 2);                    // norm_ff statistics
+    put(0);                       // norm_ff statistics
     put(BAR_PARAMS | BAR_UNIT);   // norm_ff published, parameter group 0 dead, FFN's first unit
     ffn_bars();
-    put(0, 2);                    // norm_final statistics
+    put(0);                       // norm_final statistics
     if (mode & EM_BLOCK_FINAL) {
-      put(0);                     // after_norm statistics
-      put(BAR_LAST);
+      put(BAR_LAST);              // after_norm statistics
       return n;
     }
   }
   if (mode & EM_BLOCK_A) {
-    put(0, 2);                    // norm_ff_macaron statistics
+    put(0);                       // norm_ff_macaron statistics
     put(((mode & EM_BLOCK_D) ? BAR_PARAMS : 0) | BAR_UNIT);  // published; after a D part parameter group 1 is dead
     ffn_bars();
-    put(0, 2);                    // norm_mha statistics
+    put(0);                       // norm_mha statistics
     put(BAR_UNIT);                // published + first q unit
     put(BAR_UNIT, 10);
     put(BAR_UNIT | BAR_LAST);
