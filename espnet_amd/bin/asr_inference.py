@@ -28,6 +28,22 @@ from espnet_amd.text.token_id_converter import TokenIDConverter, build_tokenizer
 logger = logging.getLogger(__name__)
 
 
+def resolve_dtype(dtype: str) -> str:
+    """The reference's --dtype values onto the two MFMA modes: float32 (exact-f32 MFMA, the parity mode) and
+    bfloat16 (bf16 MFMA, f32 accumulate).  float16 / float64 have no counterpart on this path: they run as the
+    nearest mode and say so."""
+    if dtype in ("float32", "bfloat16"):
+        return dtype
+    if dtype == "float16":
+        logger.warning("dtype float16 runs as bfloat16 on the MI355X path (bf16 MFMA, f32 accumulate)")
+        return "bfloat16"
+    if dtype == "float64":
+        logger.warning("dtype float64 runs as float32 on the MI355X path (exact-f32 MFMA)")
+        return "float32"
+    raise ValueError(f"unknown dtype {dtype!r}")
+
+
+
 class Speech2Text:
     def __init__(self, asr_train_config: Union[Path, str, None] = None,
                  asr_model_file: Union[Path, str, None] = None, transducer_conf: Optional[Dict] = None,
@@ -48,6 +64,7 @@ class Speech2Text:
         if not str(device).startswith("cuda"):
             raise RuntimeError("espnet_amd.Speech2Text runs on an MI355X only (device='cuda'); no CPU fallback")
         # the reference's `dtype` is the model dtype; here it selects the MFMA mode
+        dtype = resolve_dtype(dtype)
         asr_model, asr_train_args = ASRTask.build_model_from_file(
             asr_train_config, asr_model_file, device, compute_dtype=dtype)
         self.asr_model = asr_model
@@ -194,7 +211,7 @@ class _PendingGreedy:
 
 # ---------------------------------------------------------------------- decode CLI (asr.sh stage 12)
 def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.0, batch_size: int = 1,
-              dtype: str = "bfloat16", beam_size: int = 20, ngpu: int = 1, seed: int = 0,
+              dtype: str = "float32", beam_size: int = 20, ngpu: int = 1, seed: int = 0,
               ctc_weight: float = 0.5, lm_weight: float = 1.0, ngram_weight: float = 0.9,
               penalty: float = 0.0, nbest: int = 1, normalize_length: bool = False, num_workers: int = 1,
               log_level: Union[int, str] = "INFO", data_path_and_name_and_type=None,
@@ -347,8 +364,10 @@ def get_parser():
     p.add_argument("--output_dir", type=str, required=True)
     p.add_argument("--ngpu", type=int, default=1, help="must be 1: one MI355X per process")
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"],
-                   help="MFMA mode of the encoder/decoder (float32 = exact-f32 MFMA)")
+    p.add_argument("--dtype", default="float32", choices=["float16", "float32", "float64", "bfloat16"],
+                   help="Data type (the reference's option and default).  float32 = exact-f32 MFMA (the parity mode); "
+                        "bfloat16 = bf16 MFMA with f32 accumulation (the fast mode); float16 runs as bfloat16 and "
+                        "float64 as float32, with a warning")
     p.add_argument("--num_workers", type=int, default=1, help="audio reader threads")
     g = p.add_argument_group("Input data related")
     g.add_argument("--data_path_and_name_and_type", type=_str2triple_str, required=True, action="append")

@@ -52,6 +52,9 @@ class Speech2TextStreaming:
         if not str(device).startswith("cuda"):
             raise RuntimeError("espnet_amd runs on an MI355X only (device='cuda'); no CPU fallback")
         assert batch_size == 1
+        from espnet_amd.bin.asr_inference import resolve_dtype
+
+        dtype = resolve_dtype(dtype)
         asr_model, args = ASRTask.build_model_from_file(asr_train_config, asr_model_file, device,
                                                         compute_dtype=dtype)
         if not isinstance(asr_model.encoder, ContextualBlockConformerEncoder):
@@ -222,7 +225,7 @@ class Speech2TextStreaming:
 # ---------------------------------------------------------------------- streaming decode CLI (asr.sh stage 12,
 # `use_streaming=true`: python -m espnet2.bin.asr_inference_streaming)
 def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.0, batch_size: int = 1,
-              dtype: str = "bfloat16", beam_size: int = 20, ngpu: int = 1, seed: int = 0, ctc_weight: float = 0.5,
+              dtype: str = "float32", beam_size: int = 20, ngpu: int = 1, seed: int = 0, ctc_weight: float = 0.5,
               lm_weight: float = 1.0, penalty: float = 0.0, nbest: int = 1, normalize_length: bool = False,
               num_workers: int = 1, log_level: Union[int, str] = "INFO", data_path_and_name_and_type=None,
               key_file: Optional[str] = None, asr_train_config: Optional[str] = None,
@@ -328,8 +331,10 @@ def get_parser():
     p.add_argument("--output_dir", type=str, required=True)
     p.add_argument("--ngpu", type=int, default=1, help="must be 1: one MI355X per process")
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"],
-                   help="MFMA mode of the encoder/decoder (float32 = exact-f32 MFMA)")
+    p.add_argument("--dtype", default="float32", choices=["float16", "float32", "float64", "bfloat16"],
+                   help="Data type (the reference's option and default).  float32 = exact-f32 MFMA (the parity mode); "
+                        "bfloat16 = bf16 MFMA with f32 accumulation (the fast mode); float16 runs as bfloat16 and "
+                        "float64 as float32, with a warning")
     p.add_argument("--num_workers", type=int, default=1, help="audio reader threads")
     g = p.add_argument_group("Input data related")
     g.add_argument("--data_path_and_name_and_type", type=_str2triple_str, required=True, action="append")

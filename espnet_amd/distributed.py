@@ -29,7 +29,9 @@ def pack_hypotheses(token_ids: Sequence[Sequence[int]], scores: Sequence[float],
     lens = torch.full((slab,), -1, dtype=torch.int32)
     sc = torch.zeros(slab, dtype=torch.float32)
     for k, (t, s) in enumerate(zip(token_ids, scores)):
-        t = list(t)[:max_len]
+        t = list(t)
+        if len(t) > max_len:  # a silently shortened hypothesis would be a wrong result on every rank
+            raise ValueError(f"hypothesis {k} has {len(t)} tokens, the collective's record holds {max_len}")
         ids[k, : len(t)] = torch.tensor(t, dtype=torch.int32)
         lens[k] = len(t)
         sc[k] = float(s)

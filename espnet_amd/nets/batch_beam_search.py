@@ -118,7 +118,21 @@ class BatchBeamSearch(BeamSearch):
     def search_batch(self, enc_act: torch.Tensor, olens: List[int], maxlenratio: float = 0.0,
                      minlenratio: float = 0.0) -> List[List[Hypothesis]]:
         """enc_act (B, T, d) encoder output in the compute dtype ON THE GPU; olens host ints.
-        Returns the ended hypotheses of every utterance, best first (beam_search.py:453-461)."""
+        Returns the ended hypotheses of every utterance, best first (beam_search.py:453-461).  An utterance
+        that ends no hypothesis is searched again with minlenratio lowered by 0.1, as BeamSearch.forward does
+        for its single utterance (beam_search.py:462-474), until it yields one or minlenratio < 0.1."""
+        out = self._search_batch_once(enc_act, olens, maxlenratio, minlenratio)
+        empty = [b for b, h in enumerate(out) if len(h) == 0]
+        if empty and minlenratio >= 0.1:
+            idx = torch.tensor(empty, device=enc_act.device)
+            again = self.search_batch(enc_act.index_select(0, idx), [olens[b] for b in empty], maxlenratio,
+                                      max(0.0, minlenratio - 0.1))
+            for b, h in zip(empty, again):
+                out[b] = h
+        return out
+
+    def _search_batch_once(self, enc_act: torch.Tensor, olens: List[int], maxlenratio: float = 0.0,
+                           minlenratio: float = 0.0) -> List[List[Hypothesis]]:
         L.require_gpu(enc_act, "enc_act")
         lib = L.load()
         dev = enc_act.device
@@ -284,8 +298,8 @@ class BatchBeamSearch(BeamSearch):
         L.require_gpu(x, "x")
         logger.info("decoder input length: " + str(x.shape[0]))
         nbest = self.search_batch(x.unsqueeze(0), [int(x.shape[0])], maxlenratio, minlenratio)[0]
-        if len(nbest) == 0:
-            return [] if minlenratio < 0.1 else self.forward(x, maxlenratio, max(0.0, minlenratio - 0.1))
+        if len(nbest) == 0:  # search_batch has already backed minlenratio off (beam_search.py:462-474)
+            return []
         best = nbest[0]
         for k, v in best.scores.items():
             logger.info(f"{float(v):6.2f} * {self.weights[k]:3} = {float(v) * self.weights[k]:6.2f} for {k}")

@@ -221,9 +221,9 @@ class StreamingBatchIterator:
                             batch = {k: v.pin_memory() for k, v in batch.items()}
                         if not self._put(q, stop, (keys, batch)):
                             return
-            q.put(None)
-        except BaseException as e:  # surface reader errors in the consumer
-            q.put(e)
+            self._put(q, stop, None)
+        except BaseException as e:  # surface reader errors in the consumer; never block on a consumer that left
+            self._put(q, stop, e)
 
     def __iter__(self):
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
@@ -241,4 +241,9 @@ class StreamingBatchIterator:
                 yield item
         finally:
             stop.set()
+            try:  # a reader blocked on a full queue sees `stop` within its put timeout; release what it queued
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
             th.join(timeout=5.0)

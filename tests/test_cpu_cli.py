@@ -267,8 +267,9 @@ def test_native_wav_reader_leaves_other_inputs_to_the_python_reader(tmp_path):
 
 
 def test_parser_matches_reference_option_table():
-    """Every option of the reference CLI is accepted; defaults are the reference's except the three
-    documented ones (ngpu: no CPU path; dtype: MFMA mode names; token_type also lists "word")."""
+    """Every option of the reference CLI is accepted; defaults are the reference's except the documented
+    ones (ngpu: no CPU path; token_type also lists "word").  --dtype keeps the reference's default (float32, the
+    exact-f32 parity mode) and choices, plus bfloat16 for the bf16 MFMA mode."""
     from espnet_amd.bin.asr_inference import get_parser
 
     ref = json.loads((GOLD / "asr_inference_cli_options.json").read_text())
@@ -278,13 +279,26 @@ def test_parser_matches_reference_option_table():
     for name, r in ref.items():
         a = mine[name]
         assert a.required == r["required"], name
-        if name in ("ngpu", "dtype"):
+        if name == "ngpu":
             continue
+        if name == "dtype":
+            assert set(r["choices"]) <= set(a.choices) and "bfloat16" in a.choices
         d = r["default"]
         if name == "hugging_face_decoder_conf":
             d = {}
         assert a.default == d, (name, a.default, d)
-    assert mine["ngpu"].default == 1 and mine["dtype"].default == "bfloat16"
+    assert mine["ngpu"].default == 1 and mine["dtype"].default == "float32"
+
+
+def test_dtype_names_of_the_reference_map_onto_the_two_mfma_modes(caplog):
+    from espnet_amd.bin.asr_inference import resolve_dtype
+
+    assert resolve_dtype("float32") == "float32" and resolve_dtype("bfloat16") == "bfloat16"
+    with caplog.at_level("WARNING"):
+        assert resolve_dtype("float16") == "bfloat16" and resolve_dtype("float64") == "float32"
+    assert "float16" in caplog.text and "float64" in caplog.text
+    with pytest.raises(ValueError):
+        resolve_dtype("int8")
 
 
 def test_cli_refuses_cpu_and_multi_gpu(tmp_path):
@@ -377,11 +391,24 @@ def test_streaming_parser_matches_reference_option_table():
     assert set(ref) == set(mine), set(ref) ^ set(mine)
     for name, r in ref.items():
         a = mine[name]
-        if name in ("ngpu", "dtype"):
+        if name == "ngpu":
             continue
+        if name == "dtype":
+            assert set(r["choices"]) <= set(a.choices) and "bfloat16" in a.choices
         assert a.required == (r["required"] and name != "asr_model_file"), name
         assert a.default == r["default"], (name, a.default, r["default"])
-    assert mine["ngpu"].default == 1 and mine["dtype"].default == "bfloat16"
+    assert mine["ngpu"].default == 1 and mine["dtype"].default == "float32"
+
+
+def test_dtype_names_of_the_reference_map_onto_the_two_mfma_modes(caplog):
+    from espnet_amd.bin.asr_inference import resolve_dtype
+
+    assert resolve_dtype("float32") == "float32" and resolve_dtype("bfloat16") == "bfloat16"
+    with caplog.at_level("WARNING"):
+        assert resolve_dtype("float16") == "bfloat16" and resolve_dtype("float64") == "float32"
+    assert "float16" in caplog.text and "float64" in caplog.text
+    with pytest.raises(ValueError):
+        resolve_dtype("int8")
 
 
 def test_streaming_inference_loop_chunks_like_the_reference(tmp_path, monkeypatch):
