@@ -69,3 +69,34 @@ def load_stream_golden(name):
     g["shapes"] = {k: tuple(v) for k, v in json.loads(str(g["state_shapes"])).items()}
     g["sd"] = recipe_state_dict(g["shapes"], int(g["wseed"]), skip=())
     return g
+
+
+def oracle_rescore(sd, enc, yseq, heads, num_blocks, ctc_weight, eos, maxlen=None):
+    """Teacher-forced score of ONE given hypothesis under the oracle's scorers (oracle/beam_search.py:
+    DecoderOracle.step and CtcPrefixScorer.score, the same calls `beam_search` makes, only along a fixed
+    token path instead of inside the pruned search).  enc (T, d) valid frames; yseq incl. sos and eos.
+    Returns dict(decoder, ctc, score).  The <eos> the search force-appends at maxlen carries no score
+    (batch_beam_search.py:393-410), so at most `maxlen` (= T for maxlenratio 0) tokens are scored."""
+    import torch.nn.functional as F
+
+    from oracle import beam_search as ob
+
+    T = enc.size(0)
+    maxlen = T if maxlen is None else maxlen
+    n_scored = min(len(yseq) - 1, maxlen)
+    dec = ob.DecoderOracle(sd, enc, heads, num_blocks, maxlen)
+    cache = dec.init_cache()
+    logp = F.log_softmax(F.linear(enc, sd["ctc.ctc_lo.weight"], sd["ctc.ctc_lo.bias"]), dim=-1)
+    ctc = ob.CtcPrefixScorer(logp, eos)
+    r_prev, s_prev = ctc.initial_state()
+    s_dec = s_ctc = 0.0
+    with torch.no_grad():
+        for i in range(n_scored):
+            last = torch.tensor([yseq[i]], dtype=torch.long)
+            nxt = int(yseq[i + 1])
+            lp, cache = dec.step(last, i, cache)
+            s_dec += float(lp[0, nxt])
+            delta, r_new, log_psi = ctc.score(i, last, r_prev, s_prev, torch.tensor([[nxt]]))
+            s_ctc += float(delta[0, nxt])
+            r_prev, s_prev = r_new[:, :, :, 0], log_psi[:, nxt]
+    return {"decoder": s_dec, "ctc": s_ctc, "score": (1.0 - ctc_weight) * s_dec + ctc_weight * s_ctc}
