@@ -8,9 +8,11 @@ Mirrors espnet2/asr/decoder/transformer_decoder.py:393-468 (constructor) and :19
 The arithmetic is csrc/decoder.hip + csrc/gemm.hip + csrc/norm.hip, driven per search step by
 csrc/search.hip (`em_search_steps`); `pack()` repacks the reference-layout parameters once
 (q|k|v rows concatenated for self-attention, k|v for source attention, absolute sinusoid table).
-The scorer-interface methods (`batch_score`, `score`, `select_state`) of the reference are
-fulfilled inside the fused device search (espnet_amd/nets/batch_beam_search.py) rather than
-through per-step Python calls.
+Inside the fused device search (espnet_amd/nets/batch_beam_search.py) the decoder step never returns to
+Python.  The reference's scorer interface (`init_state`, `batch_init_state`, `select_state`, `score`,
+`batch_score`, `final_score`; legacy/nets/scorer_interface.py:29-122) is implemented on the same device code
+through `em_decoder_memory` + `em_decoder_step`, one call per search step, so the reference's own
+BatchBeamSearch can be driven by this class.
 """
 import ctypes as C
 import math
@@ -20,6 +22,7 @@ import torch
 
 from espnet_amd import lib as L
 from espnet_amd.asr.encoder.conformer_encoder import LayerNorm, _PositionwiseFeedForward
+from espnet_amd.nets.scorer_interface import BatchScorerInterface
 
 
 def abs_pos_table(length: int, d: int) -> torch.Tensor:
@@ -60,7 +63,7 @@ class _PosEncPlaceholder(torch.nn.Module):
     """`embed.1` of the reference (PositionalEncoding, no parameters/buffers)."""
 
 
-class TransformerDecoder(torch.nn.Module):
+class TransformerDecoder(torch.nn.Module, BatchScorerInterface):
     def __init__(self, vocab_size: int, encoder_output_size: int, attention_heads: int = 4,
                  linear_units: int = 2048, num_blocks: int = 6, dropout_rate: float = 0.1,
                  positional_dropout_rate: float = 0.1, self_attention_dropout_rate: float = 0.0,
@@ -83,9 +86,11 @@ class TransformerDecoder(torch.nn.Module):
         self.decoders = torch.nn.ModuleList(
             [_DecoderLayer(d, attention_heads, linear_units) for _ in range(num_blocks)])
         self._packed = None
+        self._mem = None
 
     def invalidate(self):
         self._packed = None
+        self._mem = None
 
     @property
     def em_dtype(self) -> int:
@@ -145,3 +150,128 @@ class TransformerDecoder(torch.nn.Module):
         if p is None or p["device"] != device or p["dtype"] != self.em_dtype or p["pe_len"] < pe_len:
             p = self.pack(device, max(1024, pe_len))
         return p
+
+    # ------------------------------------------------------------------ scorer interface (one call per step)
+    def init_state(self, x: torch.Tensor):
+        """transformer_decoder.py:249-251 (BatchScorerInterface default): no state before the first token."""
+        self._mem = None
+        return None
+
+    def batch_init_state(self, x: torch.Tensor):
+        self._mem = None  # a new utterance: drop the projected memory of the previous one
+        return None
+
+    def select_state(self, state, i: int, new_id: int = None):
+        """scorer_interface.py:41-52: the state of hypothesis i (full scorers ignore new_id)."""
+        return None if state is None else state[i]
+
+    def final_score(self, state) -> float:
+        return 0.0
+
+    def _memory(self, xs: torch.Tensor, pk):
+        """Source-attention K | V and V^T of the memory, once per memory tensor (the reference recomputes
+        `linear_k/linear_v(memory)` for every hypothesis, layer and step).  xs (n, T, d): hypotheses of ONE
+        utterance arrive as an expanded view (stride 0, batch_beam_search.py:283-285) and share one memory."""
+        n, T, d = xs.shape
+        shared = n == 1 or xs.stride(0) == 0
+        base = xs[0:1] if shared else xs
+        key = (base.data_ptr(), tuple(base.shape), base._version, base.dtype, pk["dtype"], n if not shared else 0)
+        if self._mem is not None and self._mem["key"] == key:
+            return self._mem
+        dev, act = xs.device, self.act_dtype
+        B = base.size(0)
+        Tpad = (T + 31) // 32 * 32
+        src = base.to(torch.float32).contiguous()
+        enc = torch.empty(src.shape, dtype=act, device=dev)
+        lib = L.load()
+        L.check(lib.em_cast_f32(self.em_dtype, L.ptr(src), src.numel(), L.ptr(enc), L.current_stream_ptr()),
+                "em_cast_f32")
+        mem_kv = torch.empty(self.num_blocks, B * T, 2 * d, dtype=act, device=dev)
+        mem_vT = torch.zeros(self.num_blocks, B, d, Tpad, dtype=act, device=dev)
+        L.check(lib.em_decoder_memory(self.em_dtype, C.byref(pk["w"]), L.ptr(enc), B, T, Tpad, L.ptr(mem_kv),
+                                      L.ptr(mem_vT), L.current_stream_ptr()), "em_decoder_memory")
+        # `base` is kept alive with the entry: its address cannot be handed to another tensor meanwhile
+        self._mem = dict(key=key, base=base, B=B, T=T, Tpad=Tpad, mem_kv=mem_kv, mem_vT=mem_vT, shared=shared,
+                         xlens=torch.full((B,), T, dtype=torch.int32, device=dev))
+        return self._mem
+
+    @torch.no_grad()
+    def batch_score(self, ys: torch.Tensor, states, xs: torch.Tensor):
+        """transformer_decoder.py:270-311.  ys (n, L) int64 prefixes incl. <sos>; states list[n] of None or
+        this class's opaque per-hypothesis cache (self-attention K/V of the prefix, (2, layers, L-1, d) in the
+        compute dtype); xs (n, T, d) encoder output on the GPU.  Returns (log-probs (n, V) f32, states list[n])."""
+        L.require_gpu(xs, "xs")
+        dev = xs.device
+        n, Lc = ys.shape
+        pos = Lc - 1
+        pk = self.ensure_packed(dev, pos + 2)
+        mem = self._memory(xs, pk)
+        B, W = (1, n) if mem["shared"] else (n, 1)
+        Lmax = pos + 1
+        nl, d, ff, V, act = self.num_blocks, self.d, self.linear_units, self.vocab_size, self.act_dtype
+        kv = torch.empty(2, nl, Lmax, n, d, dtype=act, device=dev)
+        if pos > 0:
+            if states is None or any(s is None for s in states):
+                raise ValueError("batch_score: a prefix longer than <sos> needs the state of its previous step")
+            kv[:, :, :pos] = torch.stack(list(states), 0).permute(1, 2, 3, 0, 4)
+        tok = ys.t().to(device=dev, dtype=torch.int32).contiguous()
+        anc = torch.arange(n, dtype=torch.int32, device=dev).unsqueeze(1).expand(n, Lmax).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        x = torch.empty(n, d, **f32)
+        xn, qs, ctx = (torch.empty(n, d, dtype=act, device=dev) for _ in range(3))
+        qkv = torch.empty(n, 3 * d, dtype=act, device=dev)
+        hbuf = torch.empty(n, ff, dtype=act, device=dev)
+        logits = torch.empty(n, V, **f32)
+        a = L.EmDecoderStepArgs(B=B, W=W, T=mem["T"], Tpad=mem["Tpad"], Lmax=Lmax, pos=pos, tok=L.ptr(tok),
+                                anc=L.ptr(anc), xlens=L.ptr(mem["xlens"]), self_k=kv[0].data_ptr(),
+                                self_v=kv[1].data_ptr(), mem_kv=L.ptr(mem["mem_kv"]), mem_vT=L.ptr(mem["mem_vT"]),
+                                x=L.ptr(x), xn=L.ptr(xn), qkv=L.ptr(qkv), qs=L.ptr(qs), ctx=L.ptr(ctx),
+                                hbuf=L.ptr(hbuf), logits=L.ptr(logits))
+        lib = L.load()
+        L.check(lib.em_decoder_step(self.em_dtype, C.byref(pk["w"]), C.byref(a), L.current_stream_ptr()),
+                "em_decoder_step")
+        L.check(lib.em_log_softmax_rows_f32(L.ptr(logits), n, V, L.current_stream_ptr()), "em_log_softmax_rows_f32")
+        out = kv.permute(3, 0, 1, 2, 4)  # (n, 2, layers, L, d) views of the one cache tensor
+        return logits, [out[r] for r in range(n)]
+
+    @torch.no_grad()
+    def forward(self, hs_pad: torch.Tensor, hlens: torch.Tensor, ys_in_pad: torch.Tensor, ys_in_lens: torch.Tensor):
+        """transformer_decoder.py:100-189 (AbsDecoder.forward, inference only: no autograd): hs_pad (B, T, d),
+        hlens (B,), ys_in_pad (B, L) int64 starting with <sos> -> (scores before softmax (B, L, V) f32,
+        ys_in_lens).  The causal mask makes position j depend on tokens <= j only, so the sequence is fed
+        position by position through the step kernels over one K/V cache."""
+        L.require_gpu(hs_pad, "hs_pad")
+        dev = hs_pad.device
+        B, T, d = hs_pad.shape
+        Lc = ys_in_pad.size(1)
+        pk = self.ensure_packed(dev, Lc + 1)
+        act, nl, ff, V = self.act_dtype, self.num_blocks, self.linear_units, self.vocab_size
+        self._mem = None
+        mem = self._memory(hs_pad if B > 1 else hs_pad[0:1], pk)
+        mem["xlens"] = torch.as_tensor(hlens).to(device=dev, dtype=torch.int32).contiguous()
+        kv = torch.empty(2, nl, Lc, B, d, dtype=act, device=dev)
+        tok = ys_in_pad.t().to(device=dev, dtype=torch.int32).clamp_(0, V - 1).contiguous()
+        anc = torch.arange(B, dtype=torch.int32, device=dev).unsqueeze(1).expand(B, Lc).contiguous()
+        x = torch.empty(B, d, dtype=torch.float32, device=dev)
+        xn, qs, ctx = (torch.empty(B, d, dtype=act, device=dev) for _ in range(3))
+        qkv = torch.empty(B, 3 * d, dtype=act, device=dev)
+        hbuf = torch.empty(B, ff, dtype=act, device=dev)
+        out = torch.empty(B, Lc, V, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, V, dtype=torch.float32, device=dev)
+        lib = L.load()
+        for pos in range(Lc):
+            a = L.EmDecoderStepArgs(B=B, W=1, T=T, Tpad=mem["Tpad"], Lmax=Lc, pos=pos, tok=L.ptr(tok), anc=L.ptr(anc),
+                                    xlens=L.ptr(mem["xlens"]), self_k=kv[0].data_ptr(), self_v=kv[1].data_ptr(),
+                                    mem_kv=L.ptr(mem["mem_kv"]), mem_vT=L.ptr(mem["mem_vT"]), x=L.ptr(x),
+                                    xn=L.ptr(xn), qkv=L.ptr(qkv), qs=L.ptr(qs), ctx=L.ptr(ctx), hbuf=L.ptr(hbuf),
+                                    logits=L.ptr(logits))
+            L.check(lib.em_decoder_step(self.em_dtype, C.byref(pk["w"]), C.byref(a), L.current_stream_ptr()),
+                    "em_decoder_step")
+            out[:, pos] = logits
+        self._mem = None
+        return out, ys_in_lens
+
+    def score(self, ys: torch.Tensor, state, x: torch.Tensor):
+        """transformer_decoder.py:253-268: one hypothesis.  ys (L,), x (T, d)."""
+        logp, st = self.batch_score(ys.unsqueeze(0), [state], x.unsqueeze(0))
+        return logp[0], st[0]

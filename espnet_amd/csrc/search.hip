@@ -276,6 +276,32 @@ __global__ __launch_bounds__(64) void prebeam_kernel(Ctx c) {
   }
 }
 
+// log psi of one (prefix, label) pair by one wave, lanes over frames (ctc_prefix_score.py:166-181):
+// logsumexp_t(log_phi[t-1] + x[t]) (+) r[start-1, 0].  rprev = the prefix's forward variables, xc = the
+// label's log-prob column, same = label equals the prefix's last label (:135-144), i = prefix length.
+__device__ __forceinline__ float ctc_psi_wave(const float2* __restrict__ rprev, const float* __restrict__ xc,
+                                              bool same, int i, int xlen, int lane) {
+  const int start = i > 1 ? i : 1;
+  // lane-local online logsumexp over its frames, then a wave combine
+  float m = -INFINITY, sm = 0.f;
+  if (lane == 0) {  // the r[start-1, 0] term (:176-178): x[0] for the empty prefix, else logzero
+    m = (i == 0) ? xc[0] : LOGZERO;
+    sm = 1.f;
+  }
+  for (int t = start + lane; t < xlen; t += 64) {
+    const float2 rp = rprev[t - 1];
+    const float phi = same ? rp.y : logaddexp_(rp.x, rp.y);  // :135-144
+    const float term = phi + xc[t];
+    const float mm = fmaxf(m, term);
+    sm = sm * expf(m - mm) + expf(term - mm);
+    m = mm;
+  }
+  const float M = wave_max(m);
+  sm = (m > -INFINITY) ? sm * expf(m - M) : 0.f;
+  sm = wave_sum(sm);
+  return M + logf(sm);
+}
+
 // ---- step 2: candidate totals.  One wave per (row, candidate slot), 4 waves per block ----------
 //   pre-beam mode  : slots 0..S-1 = cand_tok, slot S = <eos> (always scored, :186-187)
 //   all-vocab mode : slot s = token s (S == V, NC == V)
@@ -338,25 +364,7 @@ __global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i_host) {
     } else {
       const bool same = (tokc == c.b.tok[(size_t)i * c.p.B * c.p.W + r]);
       const float* xc = c.b.ctc_lpT + (size_t)tokc * c.p.B * LT + (size_t)b * LT;
-      const int start = i > 1 ? i : 1;
-      // lane-local online logsumexp over its frames, then a wave combine
-      float m = -INFINITY, sm = 0.f;
-      if (lane == 0) {  // the r[start-1, 0] term (:176-178): x[0] for the empty prefix, else logzero
-        m = (i == 0) ? xc[0] : LOGZERO;
-        sm = 1.f;
-      }
-      for (int t = start + lane; t < xlen; t += 64) {
-        const float2 rp = rprev[t - 1];
-        const float phi = same ? rp.y : logaddexp_(rp.x, rp.y);  // :135-144
-        const float term = phi + xc[t];
-        const float mm = fmaxf(m, term);
-        sm = sm * expf(m - mm) + expf(term - mm);
-        m = mm;
-      }
-      const float M = wave_max(m);
-      sm = (m > -INFINITY) ? sm * expf(m - M) : 0.f;
-      sm = wave_sum(sm);
-      psi = M + logf(sm);
+      psi = ctc_psi_wave(rprev, xc, same, i, xlen, lane);
     }
     if (lane == 0) c.b.cand_psi[(size_t)r * NC + s] = psi;
     total = total + c.p.w_ctc * (psi - c.b.s_prev[r]);
@@ -407,6 +415,37 @@ __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
 // walks the chain LDS -> LDS, all lanes write the result back coalesced.  Only t >= max(i,1)-1
 // is produced: a later step's recurrence starts at t = i+1 and reads r_prev[t-1].
 constexpr int CTC_TMAX = 2048;
+// Forward variables r[t] = (r^n, r^b) of prefix + label (ctc_prefix_score.py:131-132, 158-164) by one
+// 64-thread workgroup: all lanes stage x[t][label], x[t][blank] and the phi terms in LDS with coalesced
+// reads, lane 0 walks the sequential chain LDS -> LDS, all lanes write the result back coalesced.  Only
+// t >= max(i,1)-1 is produced: a later step's recurrence starts at t = i+1 and reads r_prev[t-1].
+__device__ __forceinline__ void ctc_chain_wg(const float2* __restrict__ rprev, const float* __restrict__ xc,
+                                             const float* __restrict__ xb, bool same, int i, int xlen,
+                                             float2* __restrict__ rout, int lane, float* s_xn, float* s_xb,
+                                             float* s_phi, float2* s_out) {
+  const int start = i > 1 ? i : 1;
+  for (int t = start + lane; t < xlen; t += 64) {
+    s_xn[t] = xc[t];
+    s_xb[t] = xb[t];
+    const float2 rp = rprev[t - 1];
+    s_phi[t] = same ? rp.y : logaddexp_(rp.x, rp.y);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float rn = (i == 0) ? xc[0] : LOGZERO, rb = LOGZERO;  // r[0,0] = x[0] (:131-132)
+    s_out[start - 1] = make_float2(rn, rb);
+#pragma unroll 4
+    for (int t = start; t < xlen; ++t) {
+      const float nn = logaddexp_(rn, s_phi[t]) + s_xn[t];
+      const float nb = logaddexp_(rn, rb) + s_xb[t];
+      rn = nn;
+      rb = nb;
+      s_out[t] = make_float2(rn, rb);
+    }
+  }
+  __syncthreads();
+  for (int t = start - 1 + lane; t < xlen; t += 64) rout[t] = s_out[t];
+}
 __global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i_host) {
   const int i = c.b.step ? *c.b.step : i_host;
   if (i >= c.p.Lmax - 1) return;
@@ -430,28 +469,7 @@ __global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i_host) {
   const float2* rprev = (const float2*)((i & 1) ? c.b.r_b : c.b.r_a) + (size_t)prow * LT;
   float2* rout = (float2*)((i & 1) ? c.b.r_a : c.b.r_b) + (size_t)rnew * LT;
   const bool same = (tk == c.b.tok[(size_t)i * n + prow]);
-  const int start = i > 1 ? i : 1;
-  for (int t = start + lane; t < xlen; t += 64) {
-    s_xn[t] = xc[t];
-    s_xb[t] = xb[t];
-    const float2 rp = rprev[t - 1];
-    s_phi[t] = same ? rp.y : logaddexp_(rp.x, rp.y);
-  }
-  __syncthreads();
-  if (lane == 0) {
-    float rn = (i == 0) ? xc[0] : LOGZERO, rb = LOGZERO;  // r[0,0] = x[0] (:131-132)
-    s_out[start - 1] = make_float2(rn, rb);
-#pragma unroll 4
-    for (int t = start; t < xlen; ++t) {
-      const float nn = logaddexp_(rn, s_phi[t]) + s_xn[t];
-      const float nb = logaddexp_(rn, rb) + s_xb[t];
-      rn = nn;
-      rb = nb;
-      s_out[t] = make_float2(rn, rb);
-    }
-  }
-  __syncthreads();
-  for (int t = start - 1 + lane; t < xlen; t += 64) rout[t] = s_out[t];
+  ctc_chain_wg(rprev, xc, xb, same, i, xlen, rout, lane, s_xn, s_xb, s_phi, s_out);
 }
 
 // ---- step 4: build the new rows (batch_beam_search.py:317-357 + post_process :359-423) ---------
@@ -845,6 +863,60 @@ extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecode
 
 namespace {
 
+// One TransformerDecoder.forward_one_step (espnet2/asr/decoder/transformer_decoder.py:191-247) for the
+// n = B*W rows of a search step: embedding + position, the pre-norm decoder layers over the token-tree
+// K/V cache and the per-utterance memory K / V^T, after_norm + output_layer -> logits [n][V] (the
+// log-softmax is fused into the pre-beam kernel, or em_log_softmax_rows_f32 for em_decoder_step callers).
+struct DecStep {
+  int B, W, T, Tpad, Lmax, pos;
+  const int32_t* pos_dev;           // graph mode: position read from device memory (then tok = table base)
+  const int32_t* tok;               // [Lmax][n] token table
+  const int32_t *anc_a, *anc_b;     // ancestor tables by step parity (the same table twice when not double buffered)
+  const int32_t* xlens;
+  void *self_k, *self_v;
+  const void *mem_kv, *mem_vT;
+  float* x;
+  void *xn, *qkv, *qs, *ctx, *hbuf;
+  float* logits;
+};
+
+int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* stream) {
+  const int n = a.B * a.W, V = dw->vocab, i = a.pos;
+  const size_t es = dtype == EM_BF16 ? 2 : 4;
+  const int d = dw->d, ff = dw->ff, h = dw->heads;
+  const int* anc = (i & 1) ? a.anc_b : a.anc_a;
+  if (a.pos_dev)
+    EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, a.tok, n, V, d, 0, a.pos_dev, a.Lmax, a.x, stream));
+  else
+    EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, a.tok + (size_t)i * n, n, V, d, i, nullptr, dw->pe_len, a.x,
+                            stream));
+  for (int l = 0; l < dw->num_blocks; ++l) {
+    const EmDecoderLayer& q = dw->layers[l];
+    unsigned char* kc = (unsigned char*)a.self_k + (size_t)l * a.Lmax * n * d * es;
+    unsigned char* vc = (unsigned char*)a.self_v + (size_t)l * a.Lmax * n * d * es;
+    const unsigned char* kv = (const unsigned char*)a.mem_kv + (size_t)l * a.B * a.T * 2 * d * es;
+    const unsigned char* vT = (const unsigned char*)a.mem_vT + (size_t)l * a.B * d * a.Tpad * es;
+    // every pre-norm LayerNorm rides in the prologue of the projection that consumes it (ln_gemm.hip)
+    EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm1_g, q.norm1_b, q.self_wqkv, q.self_bqkv, a.qkv, a.xn, n,
+                   3 * d, d, stream));
+    if (a.pos_dev)
+      EM_TRY(em_dec_self_attention(dtype, a.qkv, kc, vc, a.anc_a, a.anc_b, n, d, h, a.Lmax, 0, a.pos_dev,
+                                   (a.W + 1) / 2, nullptr, a.ctx, stream));
+    else
+      EM_TRY(em_dec_self_attention(dtype, a.qkv, kc, vc, anc, anc, n, d, h, a.Lmax, i, nullptr, (a.W + 1) / 2,
+                                   nullptr, a.ctx, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.self_wout, a.x, q.self_bout, n, d, d, d, d, 1.f, stream));
+    EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm2_g, q.norm2_b, q.src_wq, q.src_bq, a.qs, a.xn, n, d, d,
+                   stream));
+    EM_TRY(em_dec_src_attention(dtype, a.qs, kv, 2 * d, vT, a.xlens, a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.src_wout, a.x, q.src_bout, n, d, d, d, d, 1.f, stream));
+    EM_TRY(ln_proj(dtype, EM_EPI_RELU, a.x, q.norm3_g, q.norm3_b, q.w1, q.b1, a.hbuf, a.xn, n, ff, d, stream));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.hbuf, q.w2, a.x, q.b2, n, d, ff, ff, d, 1.f, stream));
+  }
+  return ln_proj(dtype, EM_EPI_STORE_F32, a.x, dw->after_norm_g, dw->after_norm_b, dw->out_w, dw->out_b,
+                 a.logits, a.xn, n, V, d, stream);
+}
+
 // One label step up to the per-utterance top-W selection: decoder (+ LM) step for the n rows,
 // log-softmax + pre-beam, CTC prefix scores of the candidates, selection.  Nothing of the search
 // state (tree, ancestor tables, running scores, r) is modified; the decoder / LM K/V caches get
@@ -856,38 +928,9 @@ int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, 
   const int n = p->B * p->W, V = p->V;
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   if (p->w_dec != 0.f) {
-    const int d = dw->d, ff = dw->ff, h = dw->heads;
-    const int* anc = (i & 1) ? b->anc_b : b->anc_a;
-    if (b->step)
-      EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok, n, V, d, 0, b->step, p->Lmax, b->x, stream));
-    else
-      EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, b->tok + (size_t)i * n, n, V, d, i, nullptr,
-                              dw->pe_len, b->x, stream));
-    for (int l = 0; l < dw->num_blocks; ++l) {
-      const EmDecoderLayer& q = dw->layers[l];
-      unsigned char* kc = (unsigned char*)b->self_k + (size_t)l * p->Lmax * n * d * es;
-      unsigned char* vc = (unsigned char*)b->self_v + (size_t)l * p->Lmax * n * d * es;
-      const unsigned char* kv = (const unsigned char*)b->mem_kv + (size_t)l * p->B * p->T * 2 * d * es;
-      const unsigned char* vT = (const unsigned char*)b->mem_vT + (size_t)l * p->B * d * p->Tpad * es;
-      // every pre-norm LayerNorm rides in the prologue of the projection that consumes it (ln_gemm.hip)
-      EM_TRY(ln_proj(dtype, EM_EPI_STORE, b->x, q.norm1_g, q.norm1_b, q.self_wqkv, q.self_bqkv, b->qkv, b->xn, n,
-                     3 * d, d, stream));
-      if (b->step)
-        EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, b->anc_a, b->anc_b, n, d, h, p->Lmax, 0,
-                                     b->step, (p->W + 1) / 2, nullptr, b->ctx, stream));
-      else
-        EM_TRY(em_dec_self_attention(dtype, b->qkv, kc, vc, anc, anc, n, d, h, p->Lmax, i, nullptr,
-                                     (p->W + 1) / 2, nullptr, b->ctx, stream));
-      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.self_wout, b->x, q.self_bout, n, d, d, d, d, 1.f, stream));
-      EM_TRY(ln_proj(dtype, EM_EPI_STORE, b->x, q.norm2_g, q.norm2_b, q.src_wq, q.src_bq, b->qs, b->xn, n, d, d,
-                     stream));
-      EM_TRY(em_dec_src_attention(dtype, b->qs, kv, 2 * d, vT, b->xlens, p->B, p->W, d, h, p->T, p->Tpad, b->ctx, stream));
-      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->ctx, q.src_wout, b->x, q.src_bout, n, d, d, d, d, 1.f, stream));
-      EM_TRY(ln_proj(dtype, EM_EPI_RELU, b->x, q.norm3_g, q.norm3_b, q.w1, q.b1, b->hbuf, b->xn, n, ff, d, stream));
-      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->hbuf, q.w2, b->x, q.b2, n, d, ff, ff, d, 1.f, stream));
-    }
-    EM_TRY(ln_proj(dtype, EM_EPI_STORE_F32, b->x, dw->after_norm_g, dw->after_norm_b, dw->out_w, dw->out_b,
-                   b->dec_logp, b->xn, n, V, d, stream));
+    DecStep a{p->B, p->W, p->T, p->Tpad, p->Lmax, i, b->step, b->tok, b->anc_a, b->anc_b, b->xlens, b->self_k,
+              b->self_v, b->mem_kv, b->mem_vT, b->x, b->xn, b->qkv, b->qs, b->ctx, b->hbuf, b->dec_logp};
+    EM_TRY(decoder_step(dtype, dw, a, stream));
   }
   if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));
   if (p->w_dec != 0.f || p->w_lm != 0.f || p->w_len != 0.f) {
@@ -1112,6 +1155,153 @@ extern "C" int em_search_online_rewind(const EmSearchParams* p, const EmSearchBu
   Ctx c{*p, *b};
   hipLaunchKernelGGL(online_snapshot_kernel, dim3(em_cdiv(p->B * p->W, 64)), dim3(64), 0,
                      (hipStream_t)stream, c, 1);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+// ---- per-call scorer entry points (the reference's scorer interface, one call per search step) -----
+// The fused search above never leaves the device; these expose its stages one by one so that a
+// label-synchronous search written against `BatchScorerInterface` / `BatchPartialScorerInterface`
+// (espnet2/legacy/nets/scorer_interface.py:29-190) -- the reference's own BatchBeamSearch -- can be
+// driven by the same kernels (espnet_amd TransformerDecoder.batch_score, CTCPrefixScorer.batch_score_partial,
+// TransformerLM / SequentialRNNLM.batch_score).
+namespace {
+
+// log psi (and score = log psi - s_prev) of the S candidates (+ <eos> in slot S when cand != NULL) of every
+// row: one wave per (row, slot); CTCPrefixScoreTH.__call__ ctc_prefix_score.py:71-191 without the recurrence.
+__global__ __launch_bounds__(256) void ctc_prefix_score_kernel(
+    const float* __restrict__ lpT, const int* __restrict__ xlens, const float2* __restrict__ r_prev,
+    const float* __restrict__ s_prev, const int* __restrict__ last, const int* __restrict__ cand, int B, int W,
+    int S, int NC, int LT, int i, int eos, int blank, float* __restrict__ log_psi, float* __restrict__ scores) {
+  const int lane = threadIdx.x & 63;
+  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= (long)B * W * NC) return;
+  const int r = (int)(idx / NC), s = (int)(idx - (long)r * NC);
+  const int b = r / W;
+  const int tk = cand ? (s < S ? cand[(size_t)r * S + s] : eos) : s;
+  const int xlen = xlens[b];
+  const float2* rp = r_prev + (size_t)r * LT;
+  float psi;
+  if (tk == blank && eos != blank) {
+    psi = LOGZERO;  // :188-190
+  } else if (tk == eos) {
+    const float2 re = rp[xlen - 1];
+    psi = logaddexp_(re.x, re.y);  // :184-186
+  } else {
+    psi = ctc_psi_wave(rp, lpT + (size_t)tk * B * LT + (size_t)b * LT, tk == last[r], i, xlen, lane);
+  }
+  if (lane == 0) {
+    log_psi[(size_t)r * NC + s] = psi;
+    if (scores) scores[(size_t)r * NC + s] = psi - s_prev[r];
+  }
+}
+
+// forward variables of prefix(row) + label for m (row, label) pairs: one workgroup per pair
+__global__ __launch_bounds__(64) void ctc_prefix_state_kernel(
+    const float* __restrict__ lpT, const int* __restrict__ xlens, const float2* __restrict__ r_prev,
+    const int* __restrict__ last, const int* __restrict__ rows, const int* __restrict__ toks, int B, int W,
+    int LT, int i, int blank, float2* __restrict__ r_out) {
+  __shared__ float s_xn[CTC_TMAX], s_xb[CTC_TMAX], s_phi[CTC_TMAX];
+  __shared__ float2 s_out[CTC_TMAX];
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const int r = rows[k], tk = toks[k];
+  const int b = r / W, xlen = xlens[b];
+  const size_t BT = (size_t)B * LT;
+  ctc_chain_wg(r_prev + (size_t)r * LT, lpT + (size_t)tk * BT + (size_t)b * LT,
+               lpT + (size_t)blank * BT + (size_t)b * LT, tk == last[r], i, xlen, r_out + (size_t)k * LT, lane,
+               s_xn, s_xb, s_phi, s_out);
+}
+
+// r_prev of the empty prefix (ctc_prefix_score.py:87-99): r^n = logzero, r^b[t] = cumsum of blank log-probs
+__global__ __launch_bounds__(64) void ctc_prefix_init_kernel(const float* __restrict__ lpT,
+                                                            const int* __restrict__ xlens, int B, int LT,
+                                                            int blank, float2* __restrict__ r0) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const float* xb = lpT + (size_t)blank * B * LT + (size_t)b * LT;
+  float acc = 0.f;
+  for (int t = 0; t < LT; ++t) {
+    if (t < xlens[b]) acc += xb[t];
+    r0[(size_t)b * LT + t] = make_float2(LOGZERO, t < xlens[b] ? acc : LOGZERO);
+  }
+}
+
+}  // namespace
+
+extern "C" int em_decoder_memory(int dtype, const EmDecoderWeights* dw, const void* enc_act, int32_t B,
+                                 int32_t T, int32_t Tpad, void* mem_kv, void* mem_vT, void* stream) {
+  if (!dw || !enc_act || !mem_kv || !mem_vT || B <= 0 || T <= 0 || Tpad < T) return EM_ERR_BAD_ARG;
+  EmSearchParams p = {};
+  p.B = B; p.T = T; p.Tpad = Tpad;
+  EmSearchBuffers b = {};
+  b.mem_kv = mem_kv; b.mem_vT = mem_vT;
+  return project_memory(dtype, &p, dw, &b, enc_act, stream);
+}
+
+extern "C" int em_decoder_step(int dtype, const EmDecoderWeights* dw, const EmDecoderStepArgs* a, void* stream) {
+  if (!dw || !a || a->B <= 0 || a->W <= 0 || a->T <= 0 || a->Tpad < a->T || a->Lmax < 1) return EM_ERR_BAD_ARG;
+  if (a->pos < 0 || a->pos >= a->Lmax || a->pos >= dw->pe_len) return EM_ERR_BAD_ARG;
+  if (!a->tok || !a->anc || !a->xlens || !a->self_k || !a->self_v || !a->mem_kv || !a->mem_vT || !a->x || !a->xn ||
+      !a->qkv || !a->qs || !a->ctx || !a->hbuf || !a->logits)
+    return EM_ERR_BAD_ARG;
+  DecStep s{a->B, a->W, a->T, a->Tpad, a->Lmax, a->pos, nullptr, a->tok, a->anc, a->anc, a->xlens, a->self_k,
+            a->self_v, a->mem_kv, a->mem_vT, a->x, a->xn, a->qkv, a->qs, a->ctx, a->hbuf, a->logits};
+  return decoder_step(dtype, dw, s, stream);
+}
+
+extern "C" int em_lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int32_t i, void* stream) {
+  if (!p || !b || !b->lm || !b->lm_logp || !b->tok || p->B <= 0 || p->W <= 0 || i < 0 || i >= p->Lmax)
+    return EM_ERR_BAD_ARG;
+  if (b->step) return EM_ERR_BAD_ARG;  // host-driven positions only
+  return lm_step(dtype, p, b, i, stream);
+}
+
+extern "C" int em_ctc_log_probs_t(int dtype, const void* enc_act, int32_t B, int32_t T, int32_t d_model,
+                                  const void* ctc_w, const float* ctc_b, int32_t V, float* lpT, void* stream) {
+  if (B <= 0 || T <= 0 || V <= 1 || !lpT) return EM_ERR_BAD_ARG;
+  EmSearchParams p = {};
+  p.B = B; p.T = T; p.V = V;
+  EmSearchBuffers b = {};
+  b.ctc_lpT = lpT;
+  return ctc_log_probs(dtype, &p, &b, enc_act, d_model, ctc_w, ctc_b, stream);
+}
+
+extern "C" int em_ctc_prefix_init(const float* lpT, const int32_t* xlens, int32_t B, int32_t T, int32_t blank,
+                                  float* r0, void* stream) {
+  if (!lpT || !xlens || !r0 || B <= 0 || T <= 0) return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ctc_prefix_init_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, lpT, xlens, B, T, blank,
+                     (float2*)r0);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_ctc_prefix_score(const float* lpT, const int32_t* xlens, const float* r_prev, const float* s_prev,
+                                   const int32_t* last_ids, const int32_t* cand_ids, int32_t B, int32_t W, int32_t S,
+                                   int32_t T, int32_t V, int32_t out_len, int32_t eos, int32_t blank, float* log_psi,
+                                   float* scores, void* stream) {
+  if (!lpT || !xlens || !r_prev || !last_ids || !log_psi || B <= 0 || W <= 0 || T <= 0 || T > CTC_TMAX || V <= 1 ||
+      out_len < 0)
+    return EM_ERR_BAD_ARG;
+  if (scores && !s_prev) return EM_ERR_BAD_ARG;
+  if (cand_ids ? (S <= 0 || S >= V) : S != V) return EM_ERR_BAD_ARG;
+  const int NC = cand_ids ? S + 1 : V;
+  const long waves = (long)B * W * NC;
+  hipLaunchKernelGGL(ctc_prefix_score_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     lpT, xlens, (const float2*)r_prev, s_prev, last_ids, cand_ids, B, W, S, NC, T, out_len, eos,
+                     blank, log_psi, scores);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_ctc_prefix_state(const float* lpT, const int32_t* xlens, const float* r_prev,
+                                   const int32_t* last_ids, const int32_t* rows, const int32_t* toks, int32_t m,
+                                   int32_t B, int32_t W, int32_t T, int32_t out_len, int32_t blank, float* r_out,
+                                   void* stream) {
+  if (!lpT || !xlens || !r_prev || !last_ids || !rows || !toks || !r_out || m <= 0 || B <= 0 || W <= 0 || T <= 0 ||
+      T > CTC_TMAX || out_len < 0)
+    return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ctc_prefix_state_kernel, dim3(m), dim3(64), 0, (hipStream_t)stream, lpT, xlens,
+                     (const float2*)r_prev, last_ids, rows, toks, B, W, T, out_len, blank, (float2*)r_out);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

@@ -127,6 +127,12 @@ class EmDecoderWeights(C.Structure):
                 ("layers", C.POINTER(EmDecoderLayer))]
 
 
+class EmDecoderStepArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "W", "T", "Tpad", "Lmax", "pos")] + \
+               [(n, C.c_void_p) for n in ("tok", "anc", "xlens", "self_k", "self_v", "mem_kv", "mem_vT", "x",
+                                          "xn", "qkv", "qs", "ctx", "hbuf", "logits")]
+
+
 class EmSearchParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "W", "V", "T", "Tpad", "S", "NC", "Lmax", "end_cap",
                                          "sos", "eos", "blank", "use_end_detect")] + \
@@ -247,6 +253,15 @@ _SIGNATURES = {
     "em_search_online_commit": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmSearchBuffers),
                                           _i32, _vp]),
     "em_search_online_rewind": (C.c_int, [C.POINTER(EmSearchParams), C.POINTER(EmSearchBuffers), _vp]),
+    "em_decoder_memory": (C.c_int, [C.c_int, C.POINTER(EmDecoderWeights), _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "em_decoder_step": (C.c_int, [C.c_int, C.POINTER(EmDecoderWeights), C.POINTER(EmDecoderStepArgs), _vp]),
+    "em_lm_step": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmSearchBuffers), _i32, _vp]),
+    "em_ctc_log_probs_t": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "em_ctc_prefix_init": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "em_ctc_prefix_score": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                      _i32, _vp, _vp, _vp]),
+    "em_ctc_prefix_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
+                                      _vp]),
     "em_ctc_greedy": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32,
                                 _vp, _vp, _vp, _vp, _vp]),
 }

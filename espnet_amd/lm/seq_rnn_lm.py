@@ -2,7 +2,8 @@
 
 Mirrors espnet2/lm/seq_rnn_lm.py:14-177 (constructor keywords; state-dict keys `encoder.weight`,
 `rnn.{weight,bias}_{ih,hh}_l{k}`, `decoder.{weight,bias}`).  `batch_score` (:140-177) is fulfilled inside
-the fused device search (csrc/search.hip `rnn_lm_step`): per step the last token's embedding and the
+the fused device search (csrc/search.hip `rnn_lm_step`) and, as the reference's per-step call, by `batch_score`
+below on the same code (`em_lm_step`): per step the last token's embedding and the
 PARENT hypothesis' state ((h, c) for the LSTM, h otherwise, :80-89) go through the recurrent cells; the logits' log-softmax is summed with the other
 full scorers in the pre-beam kernel.  Hidden sizes are zero-padded to the GEMM K step at pack time
 (unit = 650 is the class default), which leaves every product unchanged.
@@ -14,12 +15,13 @@ from typing import Optional
 import torch
 
 from espnet_amd import lib as L
+from espnet_amd.nets.scorer_interface import BatchScorerInterface
 
 
 _KINDS = {"LSTM": L.EM_LM_LSTM, "GRU": L.EM_LM_GRU, "RNN_TANH": L.EM_LM_RNN_TANH, "RNN_RELU": L.EM_LM_RNN_RELU}
 
 
-class SequentialRNNLM(torch.nn.Module):
+class SequentialRNNLM(torch.nn.Module, BatchScorerInterface):
     def __init__(self, vocab_size: int, unit: int = 650, nhid: Optional[int] = None, nlayers: int = 2,
                  dropout_rate: float = 0.0, tie_weights: bool = False, rnn_type: str = "lstm",
                  ignore_id: int = 0, compute_dtype: str = "bfloat16"):
@@ -127,3 +129,59 @@ class SequentialRNNLM(torch.nn.Module):
         if p is None or p["device"] != device or p["dtype"] != self.em_dtype:
             p = self.pack(device)
         return p
+
+    # ------------------------------------------------------------------ scorer interface (one call per step)
+    @torch.no_grad()
+    def batch_score(self, ys: torch.Tensor, states, xs: torch.Tensor):
+        """seq_rnn_lm.py:140-177.  ys (n, L) int64 prefixes (only the last token is consumed, :92); states
+        list[n] of None (zero state, :155-156) or this class's opaque state: (h in the compute dtype, f32 master
+        state), each (nlayers, padded nhid).  Returns (log-probs (n, V) f32, states list[n])."""
+        from espnet_amd.lm.step import lm_step
+
+        L.require_gpu(xs, "xs")
+        dev = xs.device
+        n = ys.size(0)
+        act = torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32
+        d = self._pad(self.nhid)
+        hs = torch.zeros(3, self.nlayers, n, d, dtype=act, device=dev)
+        cs = torch.zeros(3, self.nlayers, n, d, dtype=torch.float32, device=dev)
+        first = states is None or states[0] is None
+        i = 0 if first else 1  # step i reads ring slot (i - 1) % 3 and writes slot i % 3
+        if not first:
+            hs[0] = torch.stack([s[0] for s in states], 1)
+            cs[0] = torch.stack([s[1] for s in states], 1)
+        tok = torch.zeros(3, n, dtype=torch.int32, device=dev)
+        tok[i] = ys[:, -1].to(device=dev, dtype=torch.int32)
+        logp, _ = lm_step(self, dev, n, 3, i, tok, dict(rnn_hs=hs, rnn_cs=cs))
+        return logp, [(hs[i, :, r], cs[i, :, r]) for r in range(n)]
+
+    @torch.no_grad()
+    def forward(self, input: torch.Tensor, hidden=None):
+        """seq_rnn_lm.py:91-116 (AbsLM.forward): input (B, L) int64, hidden = None or the list of per-row states
+        `batch_score` returns -> (logits (B, L, V) f32, hidden), one recurrent step per position."""
+        from espnet_amd.lm.step import lm_step
+
+        L.require_gpu(input, "input")
+        dev = input.device
+        n, Lc = input.shape
+        act = torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32
+        d = self._pad(self.nhid)
+        out = torch.empty(n, Lc, self.vocab_size, dtype=torch.float32, device=dev)
+        states = hidden
+        for pos in range(Lc):
+            hs = torch.zeros(3, self.nlayers, n, d, dtype=act, device=dev)
+            cs = torch.zeros(3, self.nlayers, n, d, dtype=torch.float32, device=dev)
+            i = 0 if states is None else 1
+            if states is not None:
+                hs[0] = torch.stack([s[0] for s in states], 1)
+                cs[0] = torch.stack([s[1] for s in states], 1)
+            tok = torch.zeros(3, n, dtype=torch.int32, device=dev)
+            tok[i] = input[:, pos].to(torch.int32)
+            out[:, pos] = lm_step(self, dev, n, 3, i, tok, dict(rnn_hs=hs, rnn_cs=cs), log_softmax=False)[0]
+            states = [(hs[i, :, r], cs[i, :, r]) for r in range(n)]
+        return out, states
+
+    def score(self, y: torch.Tensor, state, x: torch.Tensor):
+        """seq_rnn_lm.py:118-138: one hypothesis."""
+        logp, st = self.batch_score(y.unsqueeze(0), [state], x.unsqueeze(0))
+        return logp[0], st[0]

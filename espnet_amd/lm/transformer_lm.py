@@ -3,9 +3,10 @@
 Mirrors espnet2/lm/transformer_lm.py:12-137 (constructor keywords, state-dict keys `embed`,
 `encoder.embed.{0,1}`, `encoder.encoders.N.{self_attn,feed_forward,norm1,norm2}`,
 `encoder.after_norm`, `decoder`) and espnet2/lm/espnet_model.py:13-22 (`ESPnetLanguageModel` with
-`.lm`).  The scorer-interface methods (`batch_score`, `select_state`) are fulfilled inside the fused
-device search (csrc/search.hip `lm_step`): one step per search step over the same token-tree K/V
-cache mechanism as the attention decoder.  The torch.nn layers are parameter containers only.
+`.lm`).  Inside the fused device search the LM step runs in csrc/search.hip `lm_step` over the same
+token-tree K/V cache mechanism as the attention decoder; `batch_score` / `score` / `select_state` are the
+reference's per-step scorer interface on the same code (`em_lm_step`).  The torch.nn layers are parameter
+containers only.
 """
 import ctypes as C
 from typing import Optional
@@ -15,6 +16,7 @@ import torch
 from espnet_amd import lib as L
 from espnet_amd.asr.decoder.transformer_decoder import abs_pos_table
 from espnet_amd.asr.encoder.conformer_encoder import LayerNorm, _PositionwiseFeedForward
+from espnet_amd.nets.scorer_interface import BatchScorerInterface
 
 
 class _MultiHeadedAttention(torch.nn.Module):
@@ -49,7 +51,7 @@ class _Encoder(torch.nn.Module):
         self.after_norm = LayerNorm(d)
 
 
-class TransformerLM(torch.nn.Module):
+class TransformerLM(torch.nn.Module, BatchScorerInterface):
     def __init__(self, vocab_size: int, pos_enc: Optional[str] = None, embed_unit: int = 128,
                  att_unit: int = 256, head: int = 2, unit: int = 1024, layer: int = 4,
                  dropout_rate: float = 0.1, positional_dropout_rate: float = 0.1,
@@ -139,6 +141,54 @@ class TransformerLM(torch.nn.Module):
         if p is None or p["device"] != device or p["dtype"] != self.em_dtype or p["pe_len"] < pe_len:
             p = self.pack(device, max(1024, pe_len))
         return p
+
+    # ------------------------------------------------------------------ scorer interface (one call per step)
+    @torch.no_grad()
+    def batch_score(self, ys: torch.Tensor, states, xs: torch.Tensor):
+        """transformer_lm.py:103-137.  ys (n, L) int64 prefixes; states list[n] of None or this class's opaque
+        cache (self-attention K/V of the prefix, (2, layers, L-1, att_unit) in the compute dtype); xs is only
+        used for its device.  Returns (log-probs (n, V) f32, states list[n])."""
+        from espnet_amd.lm.step import lm_step
+
+        L.require_gpu(xs, "xs")
+        dev = xs.device
+        n, Lc = ys.shape
+        pos, Lmax = Lc - 1, Lc + 1
+        act = torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32
+        kv = torch.zeros(2, self.layer, Lmax, n, self.att_unit, dtype=act, device=dev)
+        if pos > 0:
+            if states is None or any(s is None for s in states):
+                raise ValueError("batch_score: a prefix longer than <sos> needs the state of its previous step")
+            kv[:, :, :pos] = torch.stack(list(states), 0).permute(1, 2, 3, 0, 4)
+        tok = torch.zeros(Lmax, n, dtype=torch.int32, device=dev)
+        tok[:Lc] = ys.t().to(device=dev, dtype=torch.int32)
+        logp, _ = lm_step(self, dev, n, Lmax, pos, tok, dict(lm_k=kv[0], lm_v=kv[1]))
+        out = kv[:, :, :Lc].permute(3, 0, 1, 2, 4)
+        return logp, [out[r] for r in range(n)]
+
+    @torch.no_grad()
+    def forward(self, input: torch.Tensor, hidden=None):
+        """transformer_lm.py:59-75 (AbsLM.forward): input (B, L) int64 -> (logits (B, L, V) f32, None).  Causal
+        self-attention makes position j depend on tokens <= j only, so the sequence is fed position by position
+        through the step kernels over one K/V cache (inference-only class: no autograd)."""
+        from espnet_amd.lm.step import lm_step
+
+        L.require_gpu(input, "input")
+        dev = input.device
+        n, Lc = input.shape
+        act = torch.bfloat16 if self.em_dtype == L.EM_BF16 else torch.float32
+        kv = torch.zeros(2, self.layer, Lc + 1, n, self.att_unit, dtype=act, device=dev)
+        tok = torch.zeros(Lc + 1, n, dtype=torch.int32, device=dev)
+        tok[:Lc] = input.t().to(torch.int32)
+        out = torch.empty(n, Lc, self.vocab_size, dtype=torch.float32, device=dev)
+        for pos in range(Lc):
+            out[:, pos] = lm_step(self, dev, n, Lc + 1, pos, tok, dict(lm_k=kv[0], lm_v=kv[1]), log_softmax=False)[0]
+        return out, None
+
+    def score(self, y: torch.Tensor, state, x: torch.Tensor):
+        """transformer_lm.py:77-101: one hypothesis."""
+        logp, st = self.batch_score(y.unsqueeze(0), [state], x.unsqueeze(0))
+        return logp[0], st[0]
 
 
 class ESPnetLanguageModel(torch.nn.Module):

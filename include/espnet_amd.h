@@ -631,6 +631,63 @@ int em_search_init(int dtype, const EmSearchParams* p, const EmDecoderWeights* d
 int em_search_steps(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw,
                     const EmSearchBuffers* b, int32_t i0, int32_t i1, void* stream);
 
+/* ---- The reference's scorer interface, one call per search step.
+ *      em_search_steps keeps a whole search on the device; a search written against
+ *      BatchScorerInterface / BatchPartialScorerInterface (espnet2/legacy/nets/scorer_interface.py:29-190) --
+ *      the reference's own BatchBeamSearch.search, legacy/nets/batch_beam_search.py:253-357 -- calls its
+ *      scorers once per step instead.  These entry points are those calls on the same kernels; the host
+ *      mirrors are espnet_amd TransformerDecoder.batch_score, CTCPrefixScorer.batch_score_partial /
+ *      select_state, TransformerLM / SequentialRNNLM.batch_score.                                        */
+/*   K | V and V^T of the encoder memory for every decoder layer (MultiHeadedAttention.forward_qkv of
+ *   src_attn, transformer/attention.py:77-119; the reference recomputes it per hypothesis and step):
+ *   enc_act [B][T][d] act -> mem_kv act [layers][B*T][2d], mem_vT act [layers][B][d][Tpad] (zeroed by
+ *   the caller, Tpad % 32 == 0).                                                                        */
+int em_decoder_memory(int dtype, const EmDecoderWeights* dw, const void* enc_act, int32_t B, int32_t T,
+                      int32_t Tpad, void* mem_kv, void* mem_vT, void* stream);
+/*   TransformerDecoder.forward_one_step / batch_score (espnet2/asr/decoder/transformer_decoder.py:191-311)
+ *   for n = B*W hypotheses (W rows per memory): consumes the token at position `pos` of every row, appends
+ *   that position's self-attention K/V to the caller's cache and writes the next-token LOGITS [n][V]
+ *   (log-softmax: em_log_softmax_rows_f32).  The cache is the persistent handle: self_k / self_v act
+ *   [layers][Lmax][n][d], `anc` [n][Lmax] names the cache slot holding position j of row r's prefix
+ *   (identity r for independent rows), tok [Lmax][n] the token table (row `pos` is read).              */
+typedef struct EmDecoderStepArgs {
+  int32_t B, W, T, Tpad, Lmax, pos;
+  const int32_t *tok, *anc, *xlens;  /* [Lmax][n], [n][Lmax], [B] valid memory frames */
+  void *self_k, *self_v;
+  const void *mem_kv, *mem_vT;       /* em_decoder_memory */
+  float* x;                          /* [n][d] f32 workspace */
+  void *xn, *qkv, *qs, *ctx, *hbuf;  /* act workspaces [n][d], [n][3d], [n][d], [n][d], [n][ff] */
+  float* logits;                     /* [n][V] out */
+} EmDecoderStepArgs;
+int em_decoder_step(int dtype, const EmDecoderWeights* dw, const EmDecoderStepArgs* a, void* stream);
+/*   The language-model stage of search step i on caller-provided search state (TransformerLM.batch_score
+ *   espnet2/lm/transformer_lm.py:103-137, SequentialRNNLM.batch_score espnet2/lm/seq_rnn_lm.py:140-177):
+ *   reads p->{B,W,V,Lmax} and b->{lm, tok, anc_a, anc_b, parent, lm_*, rnn_*}; writes LOGITS to
+ *   b->lm_logp [n][V] and the step's K/V (or ring-slot i % 3 recurrent state).  b->step must be NULL.     */
+int em_lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int32_t i, void* stream);
+/*   CTC.log_softmax(enc) (espnet2/asr/ctc.py:197-205, scorers/ctc.py:96-98) TRANSPOSED: lpT [V][B*T] f32. */
+int em_ctc_log_probs_t(int dtype, const void* enc_act, int32_t B, int32_t T, int32_t d_model,
+                       const void* ctc_w, const float* ctc_b, int32_t V, float* lpT, void* stream);
+/*   r_prev of the empty prefix (CTCPrefixScoreTH.__call__ state None, ctc_prefix_score.py:87-99):
+ *   r0 [B][T][2] = (logzero, cumsum of the blank log-probs).                                            */
+int em_ctc_prefix_init(const float* lpT, const int32_t* xlens, int32_t B, int32_t T, int32_t blank,
+                       float* r0, void* stream);
+/*   CTCPrefixScoreTH.__call__ (legacy/nets/ctc_prefix_score.py:71-191) for n = B*W prefixes of length
+ *   out_len (without <sos>): r_prev [n][T][2], s_prev [n], last_ids [n]; cand_ids [n][S] (the pre-beam
+ *   ids; slot S of every row is <eos>, which the reference always scores, :184-186) or NULL = all labels
+ *   (S == V).  log_psi [n][S+1] (or [n][V]) out; scores = log_psi - s_prev (may be NULL).  The forward
+ *   variables of the chosen candidates come from em_ctc_prefix_state (the reference materialises r for
+ *   every candidate and indexes it in select_state, scorers/ctc.py:40-63).                              */
+int em_ctc_prefix_score(const float* lpT, const int32_t* xlens, const float* r_prev, const float* s_prev,
+                        const int32_t* last_ids, const int32_t* cand_ids, int32_t B, int32_t W, int32_t S,
+                        int32_t T, int32_t V, int32_t out_len, int32_t eos, int32_t blank, float* log_psi,
+                        float* scores, void* stream);
+/*   r of prefix(rows[k]) + toks[k] for k < m (ctc_prefix_score.py:131-132,158-164): r_out [m][T][2]; frames
+ *   below max(out_len,1)-1 are not written (logzero in the reference; the caller pre-fills).             */
+int em_ctc_prefix_state(const float* lpT, const int32_t* xlens, const float* r_prev, const int32_t* last_ids,
+                        const int32_t* rows, const int32_t* toks, int32_t m, int32_t B, int32_t W, int32_t T,
+                        int32_t out_len, int32_t blank, float* r_out, void* stream);
+
 /* ---- §8(f) rank 3: block-synchronous streaming search, BatchBeamSearchOnline
  *      (espnet2/legacy/nets/batch_beam_search_online.py:155-534).  The host mirrors the reference's
  *      control flow (block loop :296-376, process_one_block :394-493: repetition / local-<eos> breaks,

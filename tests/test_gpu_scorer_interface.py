@@ -1,0 +1,176 @@
+"""The reference's per-step scorer interface on the device kernels:
+`TransformerDecoder.batch_score`, `CTCPrefixScorer.batch_score_partial / select_state`, `LengthBonus.batch_score`,
+`TransformerLM / SequentialRNNLM.batch_score` driven the way the reference's BatchBeamSearch drives them
+(tests/scorer_driver.py, the reference's control flow restated and pinned to the reference by
+tests/test_cpu_reference_binding.py) must reproduce the reference's own n-best fixtures -- all through the C-ABI
+(`em_decoder_memory`, `em_decoder_step`, `em_ctc_log_probs_t`, `em_ctc_prefix_init/score/state`, `em_lm_step`)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import golden_state_dict, load_golden  # noqa: E402
+from tests.scorer_driver import drive_search  # noqa: E402
+from tests.test_gpu_search import _sub, build_lm, oracle_enc  # noqa: E402
+
+
+def build_scorers(g, sd, dtype="float32", lm=None):
+    from espnet_amd.asr.ctc import CTC
+    from espnet_amd.asr.decoder.transformer_decoder import TransformerDecoder
+    from espnet_amd.nets.scorers.ctc import CTCPrefixScorer
+    from espnet_amd.nets.scorers.length_bonus import LengthBonus
+
+    V = int(g["vocab"])
+    d = g["config"]["encoder_conf"]["output_size"]
+    dec = TransformerDecoder(V, d, compute_dtype=dtype, **g["config"]["decoder_conf"])
+    dec.load_state_dict(_sub(sd, "decoder."), strict=True)
+    ctc = CTC(V, d, compute_dtype=dtype)
+    ctc.load_state_dict(_sub(sd, "ctc."), strict=True)
+    cw = float(g["ctc_weight"])
+    scorers = dict(decoder=dec.cuda(), ctc=CTCPrefixScorer(ctc=ctc.cuda(), eos=V - 1), length_bonus=LengthBonus(V))
+    weights = dict(decoder=1.0 - cw, ctc=cw, length_bonus=float(g["penalty"]) if "penalty" in g else 0.0)
+    if lm is not None:
+        scorers["lm"] = lm
+        weights["lm"] = float(g["lm_weight"])
+    return scorers, weights, V, cw
+
+
+def check(g, nbest, tol_abs=2e-3, tol_rel=2e-5):
+    keys = json.loads(str(g["score_keys"]))
+    mine = {tuple(h["yseq"]): h for h in nbest}
+    for k in range(len(g["yseq_lens"])):
+        ref = tuple(g["yseq"][k, : g["yseq_lens"][k]].tolist())
+        assert ref in mine, f"reference hypothesis #{k} missing"
+        h = mine[ref]
+        tol = tol_abs + tol_rel * abs(float(g["score"][k]))
+        assert abs(h["score"] - float(g["score"][k])) < tol, (k, h["score"], float(g["score"][k]))
+        for j, kk in enumerate(keys):
+            assert abs(h["scores"][kk] - float(g["scores"][k, j])) < tol + tol_rel * abs(float(g["scores"][k, j])), kk
+    if len(g["score"]) > 1 and float(g["score"][0] - g["score"][1]) > 1e-2:
+        assert nbest[0]["yseq"] == g["yseq"][0, : g["yseq_lens"][0]].tolist()
+
+
+@pytest.mark.parametrize("name", ["tiny_beam5", "tiny_beam3_attn_only", "tiny_beam4_early_eos", "tiny_beam4_minlen",
+                                  "small_g2_3s"])
+def test_reference_search_flow_over_accelerated_scorers_f32(name):
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    scorers, weights, V, cw = build_scorers(g, sd)
+    kw = {k: float(g[k]) for k in ("maxlenratio", "minlenratio") if k in g}
+    x = enc[0, : int(olens[0])].cuda()
+    nbest = drive_search(scorers, weights, int(g["beam"]), V, V - 1, V - 1, x,
+                         pre_beam_score_key=None if cw == 1.0 else "full", **kw)
+    check(g, nbest)
+
+
+@pytest.mark.parametrize("name", ["tiny_beam5_lm", "tiny_beam4_lm_posenc", "tiny_beam5_rnnlm", "tiny_beam4_gru_nhid",
+                                  "tiny_beam4_rnn_tanh"])
+def test_reference_search_flow_with_lm_scorer_f32(name):
+    g = load_golden(name)
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    scorers, weights, V, cw = build_scorers(g, sd, lm=build_lm(g, "float32"))
+    x = enc[0, : int(olens[0])].cuda()
+    nbest = drive_search(scorers, weights, int(g["beam"]), V, V - 1, V - 1, x)
+    check(g, nbest)
+
+
+def test_decoder_batch_score_and_forward_match_oracle_steps():
+    """Unit level: `batch_score` against the oracle's K/V-cached decoder step (oracle/beam_search.py DecoderOracle)
+    for n hypotheses with different prefixes, fed state by state; `score` (one hypothesis) and the teacher-forced
+    `forward` give the same numbers."""
+    from oracle import beam_search as ob
+
+    g = load_golden("tiny_beam5")
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    scorers, _, V, _ = build_scorers(g, sd)
+    dec = scorers["decoder"]
+    dc = g["config"]["decoder_conf"]
+    e = enc[0, : int(olens[0])]
+    n, Lc = 4, 6
+    gen = torch.Generator().manual_seed(5)
+    ys = torch.randint(1, V - 1, (n, Lc), generator=gen)
+    ys[:, 0] = V - 1
+    orc = ob.DecoderOracle(sd, e, dc["attention_heads"], dc["num_blocks"], Lc + 2)
+    cache = [(k.expand(n, -1, -1), v.expand(n, -1, -1)) for k, v in orc.init_cache()]
+    xs = e.cuda().expand(n, *e.shape)
+    states = [None] * n
+    rows = []
+    for pos in range(Lc):
+        want, cache = orc.step(ys[:, pos], pos, cache)
+        got, states = dec.batch_score(ys[:, : pos + 1].cuda(), states, xs)
+        assert (got.cpu() - want).abs().max().item() < 2e-4, pos
+        rows.append(want)
+    one, _ = dec.score(ys[2, :1].cuda(), None, e.cuda())
+    assert (one.cpu() - rows[0][2]).abs().max().item() < 2e-4
+    # teacher-forced forward: scores before softmax, (B, L, V)
+    out, _ = dec.forward(e.cuda().unsqueeze(0).expand(n, -1, -1).contiguous(), torch.tensor([e.size(0)] * n),
+                         ys.cuda(), torch.tensor([Lc] * n))
+    got = torch.log_softmax(out, dim=-1).cpu()
+    assert (got - torch.stack(rows, 1)).abs().max().item() < 2e-4
+
+
+def test_ctc_prefix_scorer_matches_oracle_steps():
+    """Unit level: batch_score_partial / select_state against oracle CtcPrefixScorer.score, with and without a
+    candidate list, incl. a repeated last label and the <eos> / blank columns."""
+    from oracle import beam_search as ob
+    from oracle import conformer as oc
+
+    g = load_golden("tiny_beam5")
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    scorers, _, V, _ = build_scorers(g, sd)
+    sc = scorers["ctc"]
+    e = enc[0, : int(olens[0])]
+    logp = oc.ctc_log_softmax(sd, e.unsqueeze(0))[0]
+    orc = ob.CtcPrefixScorer(logp, V - 1)
+    sc.batch_init_state(e.cuda())
+    n = 3
+    r_prev, s_prev = orc.initial_state()
+    r_prev, s_prev = r_prev.expand(-1, -1, n).contiguous(), s_prev.expand(n).contiguous()
+    states = [None] * n
+    ys = torch.full((n, 1), V - 1, dtype=torch.int64)
+    gen = torch.Generator().manual_seed(11)
+    for step in range(5):
+        ids = None if step == 3 else torch.stack([torch.randperm(V - 2, generator=gen)[:7] + 1 for _ in range(n)])
+        if ids is not None and step > 0:
+            ids[0, 0] = ys[0, -1]  # the candidate repeats the last label of prefix 0
+        want, r_all, psi = orc.score(step, ys[:, -1], r_prev, s_prev, ids)
+        got, st = sc.batch_score_partial(ys.cuda(), None if ids is None else ids.cuda(), states, e.cuda())
+        seen = torch.zeros(n, V, dtype=torch.bool)
+        if ids is None:
+            seen[:] = True
+        else:
+            seen.scatter_(1, ids, True)
+        seen[:, V - 1] = True
+        diff = (got.cpu() - want)[seen].abs().max().item()
+        assert diff < 2e-4 * max(1.0, want[seen].abs().max().item() * 1e-2), (step, diff)
+        assert bool((got.cpu()[~seen] < -1e9).all())
+        nxt = torch.tensor([int(ids[k, k % 7]) if ids is not None else 3 + k for k in range(n)])
+        new_states = [sc.select_state(st, k, int(nxt[k])) for k in range(n)]
+        for k in range(n):
+            col = int((ids[k] == nxt[k]).nonzero()[0]) if ids is not None else int(nxt[k])
+            rr = r_all[:, :, k, col]
+            m = (new_states[k][0].cpu() - rr).abs()
+            valid = rr > -1e9
+            assert m[valid].max().item() < 2e-3, (step, k)
+        r_prev = torch.stack([r_all[:, :, k, int((ids[k] == nxt[k]).nonzero()[0]) if ids is not None else int(nxt[k])]
+                              for k in range(n)], dim=2)
+        s_prev = psi[torch.arange(n), nxt]
+        states = new_states
+        ys = torch.cat([ys, nxt.unsqueeze(1)], dim=1)
+
+
+def test_length_bonus_interface():
+    from espnet_amd.nets.scorers.length_bonus import LengthBonus
+
+    lb = LengthBonus(11)
+    s, st = lb.batch_score(torch.zeros(3, 2, dtype=torch.int64), [None] * 3, torch.zeros(3, 4, 8, device="cuda"))
+    assert s.shape == (3, 11) and bool((s == 1).all()) and st is None and s.is_cuda
+    s1, _ = lb.score(torch.zeros(2, dtype=torch.int64), None, torch.zeros(4, 8, device="cuda"))
+    assert s1.shape == (11,) and bool((s1 == 1).all())
