@@ -6,21 +6,33 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over one batch of synthetic utterances already resident in
-HBM: HIP STFT/log-mel frontend -> HIP Conformer encoder -> greedy CTC (G1) decode, all ranks'
-hypotheses collated with one RCCL all-gather per step (N > 1).  Workload = BASELINE.json
-configs[1]: Conformer-small (12 x 256d, 4 heads, ff 1024), batch 32 x 10 s @ 16 kHz per GPU
-(weak scaling: per-GPU batch fixed).  Random-init weights (torch.manual_seed(0)), synthetic
+HBM: HIP STFT/log-mel frontend -> HIP Conformer encoder (fused block kernels) -> greedy CTC (G1)
+decode -> the hypotheses of ALL ranks collated by `espnet_amd.distributed` (fixed-shape records, one
+RCCL all-gather per tensor when N > 1) and copied to the host (pinned, asynchronous; step k's records are
+delivered while step k+1 is being launched, all K delivered inside the timed region).  Workload =
+BASELINE.json configs[1]: Conformer-small (12 x 256d, 4 heads, ff 1024), batch 32 x 10 s @ 16 kHz per
+GPU (weak scaling: per-GPU batch fixed).  Random-init weights (torch.manual_seed(0)), synthetic
 N(0, 0.1^2) waveforms.
 
-One JSON line on rank 0 carries the throughput, the roofline of the dominant kernel family (the
-MFMA GEMM template, measured live with HIP events around every GEMM launch of extra steps run
-right after the timed region), and the CPU baseline (the oracle port on this box's host cores).
+One JSON line on rank 0 carries the throughput and, at N = 1: `roofline` (the dominant MFMA kernel family
+measured live with HIP events around every launch, HBM traffic from two `rocprofv3 --pmc` passes of this
+same script), `cpu_baseline` (the oracle port on this box's host cores + the reference figure it stands in
+for), `pcie_inclusive` (waveforms arriving in pinned host memory, H2D overlapped with compute),
+`f32_mode`, `bf16_vs_f32` (id mismatch rate of the timed mode on the bench batch), `frontend` (GB/s vs
+HBM peak), `beam` (configs[2] with the roofline of the search), `beam_cfg3_per_gpu` (configs[3]'s per-GPU
+batch on one GPU) and `stream` (configs[4] + the 40 ms-per-call stress case).  `--quick` keeps only the
+main line, `roofline` and `cpu_baseline`.
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -34,6 +46,21 @@ AUDIO_SEC = 10.0
 N_SAMPLES = 160000
 VOCAB = 5000
 MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+FRONTEND_BYTES_PER_UTT = 160000 * 4 + 1001 * 80 * 4  # wave in + log-mel out (f32)
+# the reference's own Speech2Text on CPU (the path cpu_baseline stands in for)
+REFERENCE_MEASURED = {  # 8 vCPU Xeon @ 2.1 GHz survey container, torch CPU fp32, one 10 s utterance
+    "greedy": {"value": 2.2, "unit": "audio-s/s", "seconds_per_utt": 4.51,
+               "what": "reference Speech2Text(device=cpu, float32, ctc_weight=1.0, beam_size=1), Conformer-small: its "
+                       "G1 route is a width-1 CTC prefix search of 249 steps; encode() + ctc.argmax alone (what the "
+                       "port times) took 64-133 ms = 75-156 audio-s/s (BASELINE.md §2)"},
+    "beam": {"value": 0.73, "unit": "audio-s/s", "seconds_per_utt": 13.8,
+             "what": "reference Speech2Text(device=cpu, float32, beam_size=10, ctc_weight=0.3), Conformer-large + "
+                     "6-layer decoder, 249 steps (BASELINE.md §2)"},
+    "stream": {"value": 1.76, "unit": "audio-s/s", "seconds_per_utt": 5.69,
+               "what": "reference Speech2TextStreaming(device=cpu), contextual_block_conformer 12x256d, 16 chunks of "
+                       "640 ms, CTC-only beam 1; encoder forward_infer alone 0.44 s = 23 audio-s/s (BASELINE.md §2)"},
+}
 
 CONFIGS = {
     "small": dict(d=256, heads=4, ff=1024, win_length=400),
@@ -133,12 +160,12 @@ def cpu_baseline(model, budget_s=12.0):
                 break
     med = sorted(times)[len(times) // 2]
     return {"value": round(AUDIO_SEC / med, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "cpu_model": _cpu_model(),
+            "cpu_model": _cpu_model(), "reference_measured": REFERENCE_MEASURED["greedy"],
             "sample": f"oracle CPU-fp32 port, {len(times)} utterances of 10 s, batch 1, median "
                       f"{med*1e3:.1f} ms/utt (frontend + encoder + greedy CTC G1), 1 warm-up"}
 
 
-def cpu_baseline_beam(model, beam, ctc_weight, budget_s=25.0):
+def cpu_baseline_beam(model, beam, ctc_weight, budget_s=15.0):
     """Oracle port of the reference Speech2Text beam search (oracle/beam_search.py; K/V-cached,
     i.e. FASTER than the reference's own CPU path, which measured 13.3 s/utt here) on host cores."""
     from oracle import beam_search as ob
@@ -169,25 +196,22 @@ def cpu_baseline_beam(model, beam, ctc_weight, budget_s=25.0):
                 break
     med = sorted(times)[len(times) // 2]
     return {"value": round(AUDIO_SEC / med, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "cpu_model": _cpu_model(),
+            "cpu_model": _cpu_model(), "reference_measured": REFERENCE_MEASURED["beam"],
             "sample": f"oracle CPU-fp32 port (K/V-cached restatement of Speech2Text beam search), "
                       f"{len(times)} utterances of 10 s, batch 1, median {med:.2f} s/utt "
                       f"(frontend + encoder + beam {beam} search, 249 steps), no warm-up"}
 
 
-def main_stream(args):
+def run_stream(dtype, steps, warmup, chunk=10240, stream_beam=1, cpu_base=True):
     """BASELINE.json configs[4]: streaming contextual-block Conformer (aishell recipe shape: 12 x
     256d, 4 heads, ff 2048, conv k 15, block 40 / hop 16 / look-ahead 16), one audio stream fed in
-    640 ms chunks through Speech2TextStreaming (HIP frontend -> hipGraph-captured encoder step ->
-    incremental greedy CTC).  A step = one 10 s utterance = 16 chunks."""
-    import tempfile
-
+    chunks of `chunk` samples (10 240 = 640 ms, the reference's sim_chunk_length; 640 = the 40 ms-per-call
+    stress case) through Speech2TextStreaming (HIP frontend -> hipGraph-captured encoder step ->
+    incremental greedy CTC).  A step = one 10 s utterance."""
     import yaml
 
     from espnet_amd.bin.asr_inference_streaming import Speech2TextStreaming
 
-    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload stream is single-stream"
-    torch.cuda.set_device(0)
     enc_conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12,
                     input_layer="conv2d", normalize_before=True, activation_type="swish",
                     macaron_style=True, use_cnn_module=True, cnn_module_kernel=15, block_size=40,
@@ -201,9 +225,8 @@ def main_stream(args):
     torch.manual_seed(0)
     with tempfile.TemporaryDirectory() as td:
         (Path(td) / "config.yaml").write_text(yaml.safe_dump(cfg))
-        s2t = Speech2TextStreaming(str(Path(td) / "config.yaml"), None, device="cuda", dtype=args.dtype,
-                                   beam_size=args.stream_beam, ctc_weight=0.3)
-    chunk = 10240
+        s2t = Speech2TextStreaming(str(Path(td) / "config.yaml"), None, device="cuda", dtype=dtype,
+                                   beam_size=stream_beam, ctc_weight=0.3)
     wav = synth_batch(0, 1)[0]
     chunks = [wav[p : p + chunk] for p in range(0, N_SAMPLES, chunk)]
 
@@ -215,40 +238,48 @@ def main_stream(args):
             lat.append(time.perf_counter() - t0)
         return out, lat
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     lats = []
-    for _ in range(args.steps):
+    for _ in range(steps):
         out, lat = step()
-        lats += lat[2:-1]  # steady-state chunks (the first two only buffer, the last is final)
+        lats += lat[2:-1]  # steady-state calls (the first two only buffer, the last is final)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lats.sort()
-    res = {"metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances", "value":
-           round(AUDIO_SEC * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+    res = {"value": round(AUDIO_SEC * steps / elapsed, 1), "unit": "audio-s/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": "bf16" if dtype == "bfloat16" else "f32",
            "config": {"workload": "BASELINE.json configs[4]: streaming contextual_block_conformer (12x256d, "
-                                  "block 40 / hop 16 / look-ahead 16), ONE stream, 640 ms chunks, hipGraph-"
-                                  "captured encoder step, " + ("incremental greedy CTC" if args.stream_beam <= 1 else
-                                                               "block-synchronous online beam search"),
-                      "chunk_ms": 640, "chunks_per_utt": len(chunks),
-                      "chunk_latency_ms_median": round(lats[len(lats) // 2] * 1e3, 3),
-                      "chunk_latency_ms_p95": round(lats[int(len(lats) * 0.95)] * 1e3, 3),
+                                  "block 40 / hop 16 / look-ahead 16), ONE stream, hipGraph-captured encoder step, "
+                                  + ("incremental greedy CTC" if stream_beam <= 1 else
+                                     "block-synchronous online beam search"),
+                      "chunk_ms": chunk / 16.0, "calls_per_utt": len(chunks),
+                      "call_latency_ms_median": round(lats[len(lats) // 2] * 1e3, 3),
+                      "call_latency_ms_p95": round(lats[int(len(lats) * 0.95)] * 1e3, 3),
+                      "realtime_factor_of_one_stream": round(elapsed / steps / AUDIO_SEC, 5),
                       "hipgraph_replays": s2t._runner.n_replays if s2t._runner else 0,
-                      **({"search": f"BatchBeamSearchOnline beam {args.stream_beam}, ctc_weight 0.3",
-                          "search_steps_per_utt": s2t.beam_search.n_steps // (args.steps + args.warmup)}
-                         if args.stream_beam > 1 else {}),
+                      **({"search": f"BatchBeamSearchOnline beam {stream_beam}, ctc_weight 0.3",
+                          "search_steps_per_utt": s2t.beam_search.n_steps // (steps + warmup)}
+                         if stream_beam > 1 else {}),
                       "tokens_last_utt": len(out[0][2]) if out else 0}}
-    if not args.no_cpu_baseline:
+    if cpu_base:
         res["cpu_baseline"] = cpu_baseline_stream(s2t.asr_model, enc_conf)
+    return res
+
+
+def main_stream(args):
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload stream is single-stream"
+    torch.cuda.set_device(0)
+    res = run_stream(args.dtype, args.steps, args.warmup, args.stream_chunk, args.stream_beam,
+                     cpu_base=not args.no_cpu_baseline)
+    res = {"metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances", **res, "n_gpus": 1,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     print(json.dumps(res), flush=True)
 
 
-def cpu_baseline_stream(model, enc_conf, budget_s=15.0):
+def cpu_baseline_stream(model, enc_conf, budget_s=8.0):
     from oracle import conformer as oc
     from oracle.streaming import CBEncoderOracle
 
@@ -279,46 +310,268 @@ def cpu_baseline_stream(model, enc_conf, budget_s=15.0):
             i += 1
     med = sorted(times)[len(times) // 2]
     return {"value": round(AUDIO_SEC / med, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "cpu_model": _cpu_model(),
+            "cpu_model": _cpu_model(), "reference_measured": REFERENCE_MEASURED["stream"],
             "sample": f"oracle CPU-fp32 port of the streaming encoder (frontend + 64-frame chunks through "
                       f"forward_infer, no decoding), {len(times)} utterances of 10 s, median {med:.2f} s/utt"}
+
+
+class HypothesisSink:
+    """Collation of a step's hypotheses: `espnet_amd.distributed.gather_records` (one all-gather per tensor over
+    RCCL when N > 1; identity at N = 1), then -- on rank 0, the rank that owns the results -- an asynchronous copy
+    into pinned host buffers and `unpack_records` into global utterance order.  Two buffer sets: step k's records
+    are delivered while step k+1 is already enqueued, so the GPU never waits for the host; `drain()` delivers the
+    last one (inside the timed region)."""
+
+    def __init__(self, rank, world, B, width, dev, host_gloo=False):
+        from espnet_amd import distributed as D
+
+        self.D, self.rank, self.world, self.n_items, self.host_gloo = D, rank, world, world * B, host_gloo
+        self.zero = torch.zeros(B, dtype=torch.float32, device=dev)
+        rows = world * B
+        self.pinned = [(torch.empty(rows, width, dtype=torch.int32).pin_memory(),
+                        torch.empty(rows, dtype=torch.int32).pin_memory(),
+                        torch.empty(rows, dtype=torch.float32).pin_memory()) for _ in range(2)]
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.pending, self.k, self.delivered, self.last = None, 0, 0, None
+
+    def push(self, ids, lens, scores=None):
+        scores = self.zero if scores is None else scores
+        if self.host_gloo:  # developer check on a one-GPU box: the collective runs on host copies over gloo
+            g = self.D.gather_records(ids.cpu(), lens.cpu(), scores.cpu())
+        else:
+            g = self.D.gather_records(ids, lens, scores)
+        if self.rank != 0:
+            return
+        slot = self.k & 1
+        for dst, src in zip(self.pinned[slot], g):
+            dst.copy_(src, non_blocking=True)
+        self.events[slot].record()
+        prev, self.pending = self.pending, slot
+        self.k += 1
+        if prev is not None:
+            self._deliver(prev)
+
+    def _deliver(self, slot):
+        self.events[slot].synchronize()
+        self.last = self.D.unpack_records(*self.pinned[slot], self.n_items, self.world, as_arrays=True)
+        self.delivered += 1
+
+    def drain(self):
+        if self.pending is not None:
+            self._deliver(self.pending)
+            self.pending = None
+
+
+class HostFeeder:
+    """Waveforms arriving in pinned host memory (the boundary's real input): batch k+1 is copied host -> device
+    on a copy stream into the second device buffer while batch k computes."""
+
+    def __init__(self, wav_host, dev):
+        self.host = wav_host.pin_memory()
+        self.bufs = [torch.empty_like(wav_host, device=dev) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.copied = [torch.cuda.Event(), torch.cuda.Event()]
+        self.consumed = [None, None]
+        self.k = 0
+        self._prefetch(0)
+
+    def _prefetch(self, slot):
+        with torch.cuda.stream(self.copy_stream):
+            if self.consumed[slot] is not None:
+                self.copy_stream.wait_event(self.consumed[slot])
+            self.bufs[slot].copy_(self.host, non_blocking=True)
+            self.copied[slot].record(self.copy_stream)
+
+    def acquire(self):
+        slot = self.k & 1
+        torch.cuda.current_stream().wait_event(self.copied[slot])
+        return self.bufs[slot]
+
+    def release(self):
+        slot = self.k & 1
+        ev = torch.cuda.Event()
+        ev.record()
+        self.consumed[slot] = ev
+        self.k += 1
+        self._prefetch(self.k & 1)
+
+
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def timed_loop(step, steps, warmup, barrier, finish=None):
+    with torch.no_grad():
+        for _ in range(warmup):
+            step()
+        if finish:
+            finish()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if finish:
+            finish()
+        barrier()
+        return time.perf_counter() - t0
+
+
+def decoder_step_bytes(model, B, W, T, NC, steps, es):
+    """Algorithmic HBM bytes of ONE label step of the joint search (DESIGN.md §search roofline): every decoder
+    weight once, the per-utterance memory K / V^T once, the self-attention K/V of the prefixes (average length
+    steps/2), the logits written and read, the CTC log-prob columns of the NC candidates and the forward
+    variables read + written."""
+    dec = model.decoder
+    d, ff, L, V = dec.d, dec.linear_units, dec.num_blocks, dec.vocab_size
+    n = B * W
+    w = L * (3 * d * d + d * d + d * d + d * d + 2 * d * ff) * es + d * V * es  # src K/V projections run at init
+    mem = B * L * T * 2 * d * es
+    cache = n * L * (steps / 2.0) * 2 * d * es
+    logits = n * V * 4 * 2
+    ctc = n * NC * T * 4 + n * T * 8 * 2
+    return w + mem + cache + logits + ctc
+
+
+def run_beam(args, dev, B, beam, steps, warmup, cpu_base, sink_factory):
+    """configs[2] / configs[3]'s per-GPU batch: Conformer-large + 6-layer decoder, joint CTC/attention beam search."""
+    from espnet_amd import distributed as D
+    from espnet_amd.nets.batch_beam_search import build_beam_search
+    from espnet_amd.tasks.asr import ASRTask
+
+    torch.manual_seed(0)
+    model = ASRTask.build_model(model_config("large", args.dtype)).to(dev).eval()
+    bs = build_beam_search(model, beam_size=beam, ctc_weight=args.ctc_weight, penalty=0.0,
+                           token_list=model.token_list)
+    rank = int(os.environ.get("RANK", "0"))
+    wav = synth_batch(rank * B, B).to(dev)
+    lens = [N_SAMPLES] * B
+    T = model.encoder.output_frames(1 + N_SAMPLES // 160)
+    sink = sink_factory(B, T + 2)
+    t_search = [0.0, 0]
+
+    def step(instrument=False):
+        st = model.encode_device(wav, lens)
+        if instrument:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        nbest = bs.search_batch(st.enc_act, st.olens)
+        if instrument:
+            t_search[0] += time.perf_counter() - t0
+            t_search[1] += bs.last_steps
+        toks = [[t for t in h[0].yseq[1:-1].tolist()] if h else [] for h in nbest]
+        sc = [float(h[0].score) if h else 0.0 for h in nbest]
+        sink.push(*D.pack_hypotheses(toks, sc, T + 2, B, dev))
+
+    def barrier():
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    elapsed = timed_loop(step, steps, warmup, barrier, sink.drain)
+    with torch.no_grad():
+        step(instrument=True)
+        sink.drain()
+    es = 2 if args.dtype == "bfloat16" else 4
+    S = bs.pre_beam_size if bs.do_pre_beam else VOCAB
+    n_steps = t_search[1]
+    per_step = decoder_step_bytes(model, B, beam, T, S + 1, n_steps, es)
+    res = {"model": model, "elapsed": elapsed, "tokens": int(sink.last[1].sum()) if sink.last else 0,
+           "search": {"ms_per_search_step": round(t_search[0] / max(1, n_steps) * 1e3, 4),
+                      "search_steps_per_utt_batch": n_steps, "steps_per_s": round(n_steps / t_search[0], 1),
+                      "rows": B * beam,
+                      "roofline": {"bound": "hbm", "achieved": round(per_step * n_steps / t_search[0] / 1e9, 1),
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(per_step * n_steps / t_search[0] / 1e9 / HBM_PEAK_GBS, 5),
+                                   "traffic": None,
+                                   "algorithmic_mb_per_search_step": round(per_step / 1e6, 2),
+                                   "what": "decoder weights + memory K/V + self-attention cache + logits + CTC "
+                                           "columns and forward variables per label step (bench.py "
+                                           "decoder_step_bytes), over the wall time of search_batch"}}}
+    if cpu_base:
+        res["cpu_baseline"] = cpu_baseline_beam(model, beam, args.ctc_weight)
+    return res
+
+
+def collect_traffic(kernel_substr, args):
+    """HBM bytes per launch of the dominant kernel from two `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE:
+    they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") of this script's own main loop.
+    gfx950 correction of that guide's HBM section: FETCH_SIZE counts 64 B per 128-B request -> doubled."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", td, "-o", "t", "--output-format", "csv", "--",
+                   sys.executable, str(REPO / "bench.py"), "--quick", "--no-roofline", "--no-cpu-baseline",
+                   "--steps", "3", "--warmup", "2", "--dtype", args.dtype, "--batch", str(args.batch),
+                   "--model", args.model]
+            env = dict(os.environ, TMPDIR="/tmp", ESPNET_AMD_BENCH_INNER="1")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr}: timeout"
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr}: rc {r.returncode}, {len(files)} csv"
+            tot, n = 0.0, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr and kernel_substr in row["Kernel_Name"]:
+                        tot += float(row["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None, f"no {kernel_substr} dispatch in the {ctr} pass"
+            out[ctr] = (tot / n, n)
+    fetch_kb, write_kb = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return (2.0 * fetch_kb + write_kb) * 1024.0, (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+                                                  f"{out['FETCH_SIZE'][1]} launches: FETCH_SIZE {fetch_kb:.1f} KB x 2 "
+                                                  f"(gfx950 correction) + WRITE_SIZE {write_kb:.1f} KB per launch")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step")
     ap.add_argument("--model", default=None, choices=sorted(CONFIGS))
     ap.add_argument("--workload", default="greedy", choices=["greedy", "beam", "stream"],
                     help="greedy = BASELINE.json configs[1] (the bench line); beam = configs[2]: "
-                         "Conformer-large, joint CTC/attention beam 10, batch 16")
+                         "Conformer-large, joint CTC/attention beam 10, batch 16; stream = configs[4]")
     ap.add_argument("--beam", type=int, default=10)
     ap.add_argument("--ctc-weight", type=float, default=0.3)
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
-    ap.add_argument("--streams", type=int, default=1,
-                    help="split the per-GPU batch over this many HIP streams (independent utterances)")
     ap.add_argument("--stream-beam", type=int, default=1,
                     help="--workload stream: beam size; > 1 decodes with the block-synchronous online search "
                          "(BatchBeamSearchOnline) instead of incremental greedy CTC")
+    ap.add_argument("--stream-chunk", type=int, default=10240, help="--workload stream: samples per call")
     ap.add_argument("--h2d", action="store_true",
-                    help="also copy the waveforms host->device inside every timed step (pinned host memory): the "
-                         "PCIe-inclusive rate quoted in DESIGN.md; never the headline `value`")
-    ap.add_argument("--graph", action="store_true",
-                    help="greedy workload: capture the whole pass (all --streams branches) in one hipGraph")
+                    help="main loop with the waveforms arriving in pinned host memory (H2D overlapped with "
+                         "compute); the default run reports this as the `pcie_inclusive` sub-object instead")
+    ap.add_argument("--quick", action="store_true", help="main line + roofline + cpu_baseline only")
     ap.add_argument("--dist-debug-one-gpu", action="store_true",
                     help="developer check of the multi-rank control flow on a ONE-GPU box: every rank uses "
                          "cuda:0 and the collectives go through gloo on host copies (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic null)")
     args = ap.parse_args()
+    inner = os.environ.get("ESPNET_AMD_BENCH_INNER") == "1"
     if args.workload == "stream":
         return main_stream(args)
     if args.model is None:
         args.model = "small" if args.workload == "greedy" else "large"
     if args.batch is None:
         args.batch = 32 if args.workload == "greedy" else 16
+    if args.workload == "beam" and args.steps == 200 and args.warmup == 20:
+        args.steps, args.warmup = 5, 1  # a beam step is ~100x a greedy one
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -341,144 +594,83 @@ def main():
     from espnet_amd import lib as L
     from espnet_amd.tasks.asr import ASRTask
 
-    torch.manual_seed(0)
-    model = ASRTask.build_model(model_config(args.model, args.dtype)).to(dev).eval()
-    B = args.batch
-    wav_host = synth_batch(rank * B, B).pin_memory() if args.h2d else None
-    wav = synth_batch(rank * B, B).to(dev)
-    lens = [N_SAMPLES] * B
-    T = model.encoder.output_frames(1 + N_SAMPLES // 160)
-    # hypotheses are collated with ONE fixed-shape all-gather per step: (B, T + 1) int32 records,
-    # token ids padded with -1 and the token count in the last column
-    gathered = torch.empty(world * B, T + 1, dtype=torch.int32, device=dev) if world > 1 else None
-
-    def collate(tokens, tlens):
-        rec = torch.cat([tokens, tlens.view(-1, 1)], dim=1).contiguous()
-        if args.dist_debug_one_gpu:
-            parts = [torch.empty(rec.shape, dtype=rec.dtype) for _ in range(world)]
-            dist.all_gather(parts, rec.cpu())
-            gathered.copy_(torch.cat(parts, 0))
-            return
-        dist.all_gather_into_tensor(gathered, rec)
-
-    beam_search = None
-    if args.workload == "beam":
-        from espnet_amd.nets.batch_beam_search import build_beam_search
-
-        beam_search = build_beam_search(model, beam_size=args.beam, ctc_weight=args.ctc_weight,
-                                        penalty=0.0, token_list=model.token_list)
-
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
-
-    def step_multistream():
-        # utterances are independent: each slice of the batch runs the whole path on its own
-        # stream, so the small latency-bound kernels of different slices overlap on the chip
-        main = torch.cuda.current_stream()
-        outs = []
-        per = (B + len(streams) - 1) // len(streams)
-        for k, s in enumerate(streams):
-            s.wait_stream(main)
-            with torch.cuda.stream(s):
-                sl = slice(k * per, min(B, (k + 1) * per))
-                st = model.encode_device(wav[sl], lens[sl])
-                outs.append(model.greedy_ctc_device(st)[1:])
-        for s in streams:
-            main.wait_stream(s)
-        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
-
-    graph = {}
-
-    def step(do_collate=True):
-        # do_collate=False: rank 0's event-instrumented passes after the timed region run alone, so
-        # they must not enter a collective the other ranks never join
-        if graph:
-            graph["g"].replay()
-            if world > 1 and do_collate:
-                collate(*graph["out"])
-            return graph["out"]
-        if streams and beam_search is None:
-            tokens, tlens = step_multistream()
-            if world > 1 and do_collate:
-                collate(tokens, tlens)
-            return tokens, tlens
-        if wav_host is not None:
-            wav.copy_(wav_host, non_blocking=True)
-        st = model.encode_device(wav, lens)
-        if beam_search is None:
-            _, tokens, tlens = model.greedy_ctc_device(st)
-        else:  # n-best lists are rebuilt on the host; the best one is padded back for collation
-            nbest = beam_search.search_batch(st.enc_act, st.olens)
-            tokens = torch.full((B, T), -1, dtype=torch.int32)
-            tl = []
-            for b, hyps in enumerate(nbest):
-                ids = [t for t in hyps[0].yseq[1:-1].tolist() if t != 0][:T] if hyps else []
-                tokens[b, : len(ids)] = torch.tensor(ids, dtype=torch.int32)
-                tl.append(len(ids))
-            tokens = tokens.to(dev)
-            tlens = torch.tensor(tl, dtype=torch.int32, device=dev)
-        if world > 1 and do_collate:  # collate hypotheses: one RCCL all-gather of fixed-shape ids + lengths
-            collate(tokens, tlens)
-        return tokens, tlens
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        if args.graph and beam_search is None:
-            # the pass has no host-dependent control flow (lengths live on the device), so the whole
-            # frontend -> encoder -> greedy CTC chain, with its fork/join over --streams, is one graph
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                if streams:
-                    out_g = step_multistream()
-                else:
-                    out_g = model.greedy_ctc_device(model.encode_device(wav, lens))[1:]
-            graph.update(g=g, out=out_g)
-            for _ in range(2):
-                step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            tokens, tlens = step()
-        barrier()
-        elapsed = time.perf_counter() - t0
+    def sink_factory(B, width):
+        return HypothesisSink(rank, world, B, width, dev, host_gloo=args.dist_debug_one_gpu)
+
+    B = args.batch
+    extras = {}
+    if args.workload == "beam":
+        r = run_beam(args, dev, B, args.beam, args.steps, args.warmup,
+                     cpu_base=(rank == 0 and world == 1 and not args.no_cpu_baseline), sink_factory=sink_factory)
+        model, elapsed, n_tok = r.pop("model"), r.pop("elapsed"), r.pop("tokens")
+        extras = r
+        step_plain = None
+    else:
+        torch.manual_seed(0)
+        model = ASRTask.build_model(model_config(args.model, args.dtype)).to(dev).eval()
+        wav_host = synth_batch(rank * B, B)
+        wav = wav_host.to(dev)
+        lens = [N_SAMPLES] * B
+        T = model.encoder.output_frames(1 + N_SAMPLES // 160)
+        sink = sink_factory(B, T)
+        feeder = HostFeeder(wav_host, dev) if args.h2d else None
+
+        def step_plain(src=None):
+            st = model.encode_device(wav if src is None else src, lens)
+            return model.greedy_ctc_device(st)
+
+        def step():
+            if feeder is not None:
+                ids, tokens, tlens = step_plain(feeder.acquire())
+                feeder.release()
+            else:
+                ids, tokens, tlens = step_plain()
+            sink.push(tokens, tlens)
+
+        elapsed = timed_loop(step, args.steps, args.warmup, barrier, sink.drain)
+        n_tok = int(sink.last[1].sum()) if sink.last is not None else 0
+        assert rank != 0 or sink.delivered == args.steps + args.warmup, (sink.delivered, args.steps, args.warmup)
     el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.dist_debug_one_gpu else dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    n_tok = int(tlens.sum().item())
 
     out = None
+    cfgm = CONFIGS[args.model]
     if rank == 0:
         value = world * B * AUDIO_SEC * args.steps / elapsed
+        if args.workload == "greedy":
+            wl = ((f"BASELINE.json configs[1]: Conformer-{args.model} (12x{cfgm['d']}d, {cfgm['heads']} heads), "
+                   if "ebf" not in cfgm else
+                   "SURVEY 8(f) rank 4: E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31), ") +
+                  f"HIP STFT/log-mel + HIP encoder + greedy CTC (G1) + hypotheses collated to the host, "
+                  f"{B} x 10 s utterances per GPU per step, V={VOCAB}")
+        else:
+            wl = (f"BASELINE.json configs[2]: Conformer-{args.model} (12x{cfgm['d']}d, {cfgm['heads']} heads) + 6-layer "
+                  f"attention decoder, joint CTC/attention beam search beam={args.beam} ctc_weight={args.ctc_weight}, "
+                  f"{B} x 10 s utterances per GPU per step, V={VOCAB}")
         out = {
             "metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances",
             "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
-            "config": {"workload": ((f"BASELINE.json configs[1]: Conformer-{args.model} "
-                                     f"(12x{CONFIGS[args.model]['d']}d, {CONFIGS[args.model]['heads']} heads), "
-                                     if "ebf" not in CONFIGS[args.model] else
-                                     "SURVEY 8(f) rank 4: E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31), ") +
-                                    f"HIP STFT/log-mel + HIP encoder + greedy CTC (G1), "
-                                    f"{B} x 10 s utterances per GPU per step, V={VOCAB}")
-                       if beam_search is None else
-                       (f"BASELINE.json configs[2]: Conformer-{args.model} "
-                        f"(12x{CONFIGS[args.model]['d']}d, {CONFIGS[args.model]['heads']} heads) + 6-layer "
-                        f"attention decoder, joint CTC/attention beam search beam={args.beam} "
-                        f"ctc_weight={args.ctc_weight}, {B} x 10 s utterances per GPU per step, V={VOCAB}"),
-                       "batch_per_gpu": B, "global_batch": world * B, "audio_seconds_per_utt": AUDIO_SEC,
-                       "parallelism": f"utterance-dp{world}", "greedy_tokens_last_step_rank0": n_tok,
-                       **({"inputs": "host (pinned) -> device copy inside the timed step"} if args.h2d else {})},
+            "config": {"workload": wl, "batch_per_gpu": B, "global_batch": world * B,
+                       "audio_seconds_per_utt": AUDIO_SEC, "parallelism": f"utterance-dp{world}",
+                       "collation": "espnet_amd.distributed gather_records (all-gather of fixed-shape records when "
+                                    "N > 1) + async D2H + unpack_records on rank 0, inside the timed step",
+                       "inputs": ("pinned host -> device copy inside the timed step (double buffered)" if args.h2d
+                                  else "resident in HBM"),
+                       "tokens_last_step": n_tok},
         }
+        out.update(extras)
     # ---- roofline of the MFMA kernel families: HIP events around every launch (on the launch stream)
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and step_plain is not None:
         lib = L.load()
         cap = 32768
         prof = lib.em_profile_create(cap)
@@ -487,12 +679,11 @@ def main():
         tg = (C.c_int32 * cap)()
         cnt = C.c_int32(0)
         fam = {}  # tag -> [ms, flops, launches]
-        nprof = max(1, min(args.steps, 5 if beam_search is None else 1))
-        graph.clear()  # event bracketing needs live launches
+        nprof = max(1, min(args.steps, 5))
         with torch.no_grad():
             for _ in range(nprof):
                 lib.em_profile_attach(prof)
-                step(do_collate=False)
+                step_plain()
                 lib.em_profile_attach(None)
                 L.check(lib.em_profile_read2(prof, ms, fl, tg, cap, C.byref(cnt)), "em_profile_read2")
                 for i in range(cnt.value):
@@ -505,19 +696,31 @@ def main():
         names = {L.EM_PROF_GEMM: "gemm_kernel<T,EPI,AMODE> (all instantiations)",
                  L.EM_PROF_BLOCK: "block_kernel<MODE> (fused Conformer block, csrc/block.hip)",
                  L.EM_PROF_ATTN: "relpos_attn2_kernel (csrc/attention2.hip)"}
+        match = {L.EM_PROF_GEMM: "gemm_kernel", L.EM_PROF_BLOCK: "block_kernel", L.EM_PROF_ATTN: "relpos_attn2_kernel"}
         tot_ms = sum(f[0] for f in fam.values())
         tot_fl = sum(f[1] for f in fam.values())
         launches = sum(f[2] for f in fam.values())
         dom = max(fam, key=lambda t: fam[t][0])
         d_ms, d_fl, d_n = fam[dom]
         achieved = d_fl / (d_ms * 1e-3) / 1e12
+        traffic, traffic_note = (None, "skipped")
+        if world == 1 and not inner and not args.no_traffic and not args.quick:
+            try:
+                traffic, traffic_note = collect_traffic(match[dom], args)
+            except Exception as e:  # measurement helper: never lose the bench line to it
+                traffic, traffic_note = None, f"{type(e).__name__}: {e}"
         out["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": None if traffic is None else round(traffic),
+            "traffic_source": traffic_note,
             "kernel": names[dom], "launches_per_step": d_n // nprof,
             "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
+            "algorithmic_gflop_per_launch": round(d_fl / d_n / 1e9, 3),
             "algorithmic_gflop_per_step": round(d_fl / nprof / 1e9, 2),
             "kernel_ms_per_step": round(d_ms / nprof, 3),
+            "whole_step": {"algorithmic_gflop_per_step": round(tot_fl / nprof / 1e9, 2),
+                           "frac_of_mfma_peak_over_wall_time": round(
+                               tot_fl / nprof / (elapsed / args.steps) / 1e12 / peak, 4)},
             "all_mfma_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                  "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
                                  "launches_per_step": launches // nprof, "ms_per_step": round(tot_ms / nprof, 3),
@@ -526,9 +729,125 @@ def main():
                                                   "tflops": round(f[1] / (f[0] * 1e-3) / 1e12, 1),
                                                   "launches_per_step": f[2] // nprof} for t, f in fam.items()},
         }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = (cpu_baseline(model) if beam_search is None
-                               else cpu_baseline_beam(model, args.beam, args.ctc_weight))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "greedy":
+        out["cpu_baseline"] = cpu_baseline(model)
+
+    # ---- the other rows of the measurement contract, as sub-objects of the one line (N = 1 only) -------------
+    if rank == 0 and world == 1 and args.workload == "greedy" and not args.quick and not inner:
+        def guarded(name, fn):
+            try:
+                out[name] = fn()
+            except Exception as e:  # a sub-measurement must never cost the headline line
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+        def frontend_leg():
+            flens = model.frontend.feature_lengths(lens)
+            flens_dev = torch.tensor(flens, dtype=torch.int32, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 50
+            with torch.no_grad():
+                for _ in range(5):
+                    model.frontend.forward_device(wav, flens_dev, None)
+                e0.record()
+                for _ in range(n):
+                    model.frontend.forward_device(wav, flens_dev, None)
+                e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / n * 1e-3
+            gbs = B * FRONTEND_BYTES_PER_UTT / t / 1e9
+            return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "us_per_batch": round(t * 1e6, 1),
+                    "algorithmic_bytes_per_utt": FRONTEND_BYTES_PER_UTT,
+                    "kernel": "frontend_logmel (STFT + power + log-mel, csrc/frontend.hip), HIP events on the launch "
+                              "stream over 50 launches"}
+
+        def pcie_leg():
+            fd = HostFeeder(wav_host, dev)
+            sk = sink_factory(B, T)
+
+            def st():
+                _, tokens, tlens = step_plain(fd.acquire())
+                fd.release()
+                sk.push(tokens, tlens)
+
+            k = min(args.steps, 100)
+            t = timed_loop(st, k, 5, barrier, sk.drain)
+            return {"value": round(B * AUDIO_SEC * k / t, 1), "unit": "audio-s/s", "ms_per_step": round(t / k * 1e3, 3),
+                    "steps": k, "what": "the same step with the waveforms arriving in pinned host memory: H2D of "
+                                        f"{B * N_SAMPLES * 4 / 1e6:.1f} MB per step on a copy stream, double buffered, "
+                                        "overlapped with the previous step's compute; D2H of the hypotheses as in `value`"}
+
+        ids_bf16 = {}
+
+        def parity_leg():
+            with torch.no_grad():
+                ids_b, tok_b, tl_b = (t.cpu() for t in step_plain())
+                model.set_compute_dtype("float32")
+                ids_f, tok_f, tl_f = (t.cpu() for t in step_plain())
+            mism = float((ids_b != ids_f).float().mean())
+            dist_, nref = 0, 0
+            for b in range(B):
+                ref = tok_f[b, : int(tl_f[b])].tolist()
+                dist_ += _edit_distance(tok_b[b, : int(tl_b[b])].tolist(), ref)
+                nref += len(ref)
+            ids_bf16["done"] = True
+            return {"frame_id_mismatch_rate": round(mism, 5), "token_edit_distance": dist_, "reference_tokens": nref,
+                    "token_error_rate": round(dist_ / max(1, nref), 5),
+                    "what": "timed mode (bf16 MFMA, fused blocks) against the f32 parity mode of the same weights on "
+                            "the bench batch: per-frame CTC arg-max ids and G1 tokens (tests/test_gpu_fullsize.py "
+                            "bounds the same numbers against the oracle)"}
+
+        def f32_leg():
+            if not ids_bf16:
+                model.set_compute_dtype("float32")
+            sk = sink_factory(B, T)
+
+            def st():
+                _, tokens, tlens = step_plain()
+                sk.push(tokens, tlens)
+
+            k = min(args.steps, 30)
+            t = timed_loop(st, k, 3, barrier, sk.drain)
+            model.set_compute_dtype(args.dtype)
+            return {"value": round(B * AUDIO_SEC * k / t, 1), "unit": "audio-s/s", "ms_per_step": round(t / k * 1e3, 3),
+                    "steps": k, "dtype": "f32", "what": "the exact-f32 parity mode (the mode the element-wise oracle "
+                                                        "tests run in) on the same batch"}
+
+        def beam_leg(Bb, steps, cpu):
+            def fn():
+                a2 = argparse.Namespace(**vars(args))
+                a2.model = "large"
+                r = run_beam(a2, dev, Bb, 10, steps, 1, cpu_base=cpu and not args.no_cpu_baseline,
+                             sink_factory=sink_factory)
+                r.pop("model")
+                el_, tok_ = r.pop("elapsed"), r.pop("tokens")
+                torch.cuda.empty_cache()
+                return {"value": round(Bb * AUDIO_SEC * steps / el_, 1), "unit": "audio-s/s",
+                        "ms_per_step": round(el_ / steps * 1e3, 2), "steps": steps, "warmup": 1,
+                        "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
+                        "config": {"workload": f"Conformer-large (12x512d, 8 heads) + 6-layer attention decoder, joint "
+                                               f"CTC/attention beam search beam=10 ctc_weight={args.ctc_weight}, "
+                                               f"{Bb} x 10 s utterances per step, V={VOCAB}", "tokens_last_step": tok_},
+                        **r}
+            return fn
+
+        def stream_leg():
+            r = run_stream(args.dtype, 3, 1, 10240, 1, cpu_base=not args.no_cpu_baseline)
+            s = run_stream(args.dtype, 2, 1, 640, 1, cpu_base=False)
+            r["stress_40ms_calls"] = {"value": s["value"], "ms_per_step": s["ms_per_step"], **{
+                k: s["config"][k] for k in ("chunk_ms", "calls_per_utt", "call_latency_ms_median",
+                                            "call_latency_ms_p95", "realtime_factor_of_one_stream")}}
+            return r
+
+        guarded("frontend", frontend_leg)
+        guarded("pcie_inclusive", pcie_leg)
+        guarded("bf16_vs_f32", parity_leg)
+        guarded("f32_mode", f32_leg)
+        del model
+        torch.cuda.empty_cache()
+        guarded("beam", beam_leg(16, 3, True))
+        guarded("beam_cfg3_per_gpu", beam_leg(64, 2, False))
+        guarded("stream", stream_leg)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

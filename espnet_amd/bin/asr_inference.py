@@ -235,9 +235,12 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
 
     if word_lm_train_config is not None:
         raise NotImplementedError("Word LM is not implemented")
-    if ngpu > 1:
-        raise NotImplementedError("only single GPU decoding is supported per process: split the key file "
-                                  "like asr.sh does, or use espnet_amd.distributed.decode_sharded")
+    if ngpu > 1:  # the reference raises here (:760-765) and scales by split key files in asr.sh; one node, one call:
+        kw = dict(locals())
+        kw.update(kw.pop("unsupported"))
+        for k in ("time", "deque", "DatadirWriter"):
+            kw.pop(k, None)
+        return inference_multi_gpu(**kw)
     if ngpu < 1:
         raise RuntimeError("espnet_amd decodes on an MI355X only: pass --ngpu 1 (no CPU fallback)")
     logging.basicConfig(level=log_level,
@@ -330,6 +333,152 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
     return summary
 
 
+# ---------------------------------------------------------------------- --ngpu N: one process per GPU
+def _read_keys(data_path_and_name_and_type, key_file):
+    path = key_file if key_file is not None else data_path_and_name_and_type[0][0]
+    with open(path, encoding="utf-8") as f:
+        return [ln.split(maxsplit=1)[0] for ln in f if ln.strip()]
+
+
+def merge_shard_outputs(output_dir, keys, world: int, nbest: int):
+    """`output_dir/output.{r+1}/{n}best_recog/{token,token_int,score,text}` of the ranks -> the same files under
+    `output_dir`, rows in key order (asr.sh:1636-1648 does this with cat + sort -k1)."""
+    from pathlib import Path
+
+    out = Path(output_dir)
+    for n in range(1, nbest + 1):
+        for name in ("token", "token_int", "score", "text"):
+            rows = {}
+            for r in range(world):
+                f = out / f"output.{r + 1}" / f"{n}best_recog" / name
+                if f.exists():
+                    for ln in f.read_text(encoding="utf-8").splitlines():
+                        k, _, v = ln.partition(" ")
+                        rows[k] = v
+            if rows:
+                (out / f"{n}best_recog").mkdir(parents=True, exist_ok=True)
+                with (out / f"{n}best_recog" / name).open("w", encoding="utf-8") as w:
+                    for k in keys:
+                        if k in rows:
+                            w.write(f"{k} {rows[k]}\n")
+
+
+def sharded_decode_rank(decode_slab, keys, output_dir, nbest: int, max_len: int, device):
+    """One rank of `--ngpu N`: `decode_slab(slab_keys, shard_dir)` decodes this rank's contiguous slab of the key
+    list (espnet_amd.distributed.shard_bounds) into `output_dir/output.{rank+1}` and returns (token-id lists,
+    scores) of its 1-best; `decode_sharded` collates them on every rank with the fixed-shape all-gather, rank 0
+    merges the shard files and cross-checks them against the collated records."""
+    from pathlib import Path
+
+    import torch.distributed as dist
+
+    from espnet_amd.distributed import decode_sharded
+
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    shard_dir = Path(output_dir) / f"output.{rank + 1}"
+    stats = {}
+
+    def decode_fn(lo, hi):
+        toks, scores, st = decode_slab(keys[lo:hi], shard_dir)
+        stats.update(st)
+        return toks, scores
+
+    hyps = decode_sharded(decode_fn, len(keys), max_len, device)
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
+        merge_shard_outputs(output_dir, keys, world, nbest)
+        f = Path(output_dir) / "1best_recog" / "token_int"
+        merged = {ln.partition(" ")[0]: [int(t) for t in ln.partition(" ")[2].split()]
+                  for ln in f.read_text(encoding="utf-8").splitlines()} if f.exists() else {}
+        for k, (toks, _) in zip(keys, hyps):
+            assert merged.get(k, []) == toks, f"collated record of {k} differs from the merged shard file"
+    return hyps, stats
+
+
+def _multi_gpu_worker(rank: int, world: int, port: int, kw: dict, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        q.put((rank, _inference_rank(kw)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _inference_rank(kw: dict):
+    from pathlib import Path
+
+    keys = _read_keys(kw["data_path_and_name_and_type"], kw["key_file"])
+    nbest = kw["nbest"]
+
+    def decode_slab(slab_keys, shard_dir):
+        shard_dir.mkdir(parents=True, exist_ok=True)
+        kf = shard_dir / "keys"
+        kf.write_text("".join(f"{k}\n" for k in slab_keys), encoding="utf-8")
+        sub = dict(kw, output_dir=str(shard_dir), key_file=str(kf), ngpu=1)
+        st = inference(**sub) if slab_keys else {}
+        ti, sc = shard_dir / "1best_recog" / "token_int", shard_dir / "1best_recog" / "score"
+        rows = {ln.partition(" ")[0]: ln.partition(" ")[2] for ln in ti.read_text().splitlines()} if ti.exists() else {}
+        srow = {ln.partition(" ")[0]: ln.partition(" ")[2] for ln in sc.read_text().splitlines()} if sc.exists() else {}
+        return ([[int(t) for t in rows.get(k, "").split()] for k in slab_keys],
+                [float(srow.get(k, "0").replace("tensor(", "").rstrip(")")) for k in slab_keys], st)
+
+    hyps, st = sharded_decode_rank(decode_slab, keys, kw["output_dir"], nbest, 4096, torch.device("cuda"))
+    return dict(st, utterances_total=len(hyps))
+
+
+def inference_multi_gpu(ngpu: int, **kw):
+    """`--ngpu N` on one node: N processes (one per MI355X) each decode a contiguous slab of the key file; the
+    hypotheses are collated with `espnet_amd.distributed.decode_sharded` (RCCL all-gather of fixed-shape records)
+    and the per-rank files merged in key order.  Under torchrun (RANK / WORLD_SIZE set) this process is one of
+    the ranks; otherwise the ranks are spawned here."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    kw = dict(kw, ngpu=ngpu)
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == ngpu:
+        local = int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        try:
+            return _inference_rank(kw)
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
+    if torch.cuda.device_count() < ngpu:
+        raise RuntimeError(f"--ngpu {ngpu} but {torch.cuda.device_count()} GPUs are visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = torch.multiprocessing.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_multi_gpu_worker, args=(r, ngpu, port, kw, q)) for r in range(ngpu)]
+    for p in procs:
+        p.start()
+    res = dict(q.get() for _ in procs)
+    for p in procs:
+        p.join()
+        if p.exitcode != 0:
+            raise RuntimeError(f"rank process exited with {p.exitcode}")
+    audio = sum(r.get("audio_seconds", 0.0) for r in res.values())
+    wall = max(r.get("wall_seconds", 0.0) for r in res.values())
+    return dict(utterances=sum(r.get("utterances", 0) for r in res.values()), audio_seconds=audio, wall_seconds=wall,
+                rtf=wall / audio if audio else float("nan"), ranks=ngpu)
+
+
 def _str2bool(v: str) -> bool:
     if v.lower() in ("true", "1", "yes", "y", "t"):
         return True
@@ -362,7 +511,9 @@ def get_parser():
     p.add_argument("--log_level", type=lambda x: x.upper(), default="INFO",
                    choices=("CRITICAL", "ERROR", "WARNING", "INFO", "DEBUG", "NOTSET"))
     p.add_argument("--output_dir", type=str, required=True)
-    p.add_argument("--ngpu", type=int, default=1, help="must be 1: one MI355X per process")
+    p.add_argument("--ngpu", type=int, default=1,
+                   help="1 = this process decodes on one MI355X; N > 1 = N processes, one per GPU, each decoding a "
+                        "slab of the key file (espnet_amd.distributed); 0 is rejected (no CPU fallback)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--dtype", default="float32", choices=["float16", "float32", "float64", "bfloat16"],
                    help="Data type (the reference's option and default).  float32 = exact-f32 MFMA (the parity mode); "

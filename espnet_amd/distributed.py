@@ -38,31 +38,53 @@ def pack_hypotheses(token_ids: Sequence[Sequence[int]], scores: Sequence[float],
     return ids.to(device), lens.to(device), sc.to(device)
 
 
+def gather_records(ids: torch.Tensor, lens: torch.Tensor, scores: torch.Tensor, group=None):
+    """The collective itself: one all-gather per tensor of the ranks' fixed-shape slabs (RCCL over xGMI on the
+    GPU box; the ≈ 64 KB per rank are latency-bound).  Returns the (world * slab, ...) tensors on the callers'
+    device, rank-major; nothing is copied to the host and nothing synchronises."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return ids, lens, scores
+    slab = ids.size(0)
+    g_ids = torch.empty((world * slab, ids.size(1)), dtype=ids.dtype, device=ids.device)
+    g_lens = torch.empty((world * slab,), dtype=lens.dtype, device=lens.device)
+    g_sc = torch.empty((world * slab,), dtype=scores.dtype, device=scores.device)
+    dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
+    dist.all_gather_into_tensor(g_lens, lens.contiguous(), group=group)
+    dist.all_gather_into_tensor(g_sc, scores.contiguous(), group=group)
+    return g_ids, g_lens, g_sc
+
+
+def record_rows(n_items: int, world: int, slab: int) -> torch.Tensor:
+    """Row of the gathered (world * slab) record table that holds utterance u, for u < n_items (global utterance
+    order; rank r's slab starts at r * slab and holds shard_bounds(n_items, r, world))."""
+    rows = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_items, r, world)
+        rows.extend(range(r * slab, r * slab + hi - lo))
+    return torch.tensor(rows, dtype=torch.int64)
+
+
+def unpack_records(g_ids, g_lens, g_sc, n_items: int, world: int, as_arrays: bool = False):
+    """Host side of the collation: gathered HOST tensors -> the n_items hypotheses in global utterance order.
+    as_arrays=True keeps them as (ids (n_items, max_len) padded with -1, lens, scores) numpy arrays -- no
+    per-utterance Python, which is what a rank that only forwards results (or a benchmark loop) wants."""
+    slab = g_ids.size(0) // world
+    rows = record_rows(n_items, world, slab)
+    ids, lens, sc = g_ids[rows], g_lens[rows], g_sc[rows]
+    assert int(lens.min()) >= 0 if n_items else True, "padding record inside a rank's slab"
+    if as_arrays:
+        return ids.numpy(), lens.numpy(), sc.numpy()
+    return [(ids[k, : int(lens[k])].tolist(), float(sc[k])) for k in range(n_items)]
+
+
 def gather_hypotheses(ids: torch.Tensor, lens: torch.Tensor, scores: torch.Tensor, n_items: int,
                       group=None) -> List[Tuple[List[int], float]]:
     """One all-gather per tensor of the ranks' fixed-shape slabs; returns the n_items hypotheses in
     global utterance order on EVERY rank (rank 0 is the one that writes results)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        g_ids, g_lens, g_sc = ids, lens, scores
-    else:
-        slab = ids.size(0)
-        g_ids = torch.empty((world * slab, ids.size(1)), dtype=ids.dtype, device=ids.device)
-        g_lens = torch.empty((world * slab,), dtype=lens.dtype, device=lens.device)
-        g_sc = torch.empty((world * slab,), dtype=scores.dtype, device=scores.device)
-        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
-        dist.all_gather_into_tensor(g_lens, lens.contiguous(), group=group)
-        dist.all_gather_into_tensor(g_sc, scores.contiguous(), group=group)
-    g_ids, g_lens, g_sc = g_ids.cpu(), g_lens.cpu(), g_sc.cpu()
-    slab = g_ids.size(0) // world
-    out = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_items, r, world)
-        for k in range(hi - lo):
-            n = int(g_lens[r * slab + k])
-            assert n >= 0, "padding record inside a rank's slab"
-            out.append((g_ids[r * slab + k, :n].tolist(), float(g_sc[r * slab + k])))
-    return out
+    g_ids, g_lens, g_sc = gather_records(ids, lens, scores, group)
+    return unpack_records(g_ids.cpu(), g_lens.cpu(), g_sc.cpu(), n_items, world)
 
 
 def decode_sharded(decode_fn, n_items: int, max_len: int, device, group=None):

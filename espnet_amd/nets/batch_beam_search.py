@@ -234,6 +234,7 @@ class BatchBeamSearch(BeamSearch):
                 i += K
                 if i < imax and bool(bufs["done"].all().item()):
                     break
+            self.last_steps = min(i, imax)  # label steps enqueued by this search (bench.py's search roofline)
             return self._collect(bufs, B, W, maxlens)
         i = 0
         while i < imax:
@@ -242,6 +243,7 @@ class BatchBeamSearch(BeamSearch):
             i = j
             if i < imax and bool(bufs["done"].all().item()):  # the only host sync of the search
                 break
+        self.last_steps = i
         return self._collect(bufs, B, W, maxlens)
 
     # ------------------------------------------------------------------ readout (host)

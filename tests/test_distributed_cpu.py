@@ -72,3 +72,117 @@ def test_single_process_path():
     out = decode_sharded(fake_decode, 5, max_len=8, device="cpu")
     t, s = fake_decode(0, 5)
     assert [a for a, _ in out] == t
+
+
+# ---- bench.py's per-step record layout: greedy tokens (B, T) i32 padded with -1, token counts (B,), scores (B,),
+#      collated by gather_records + unpack_records(as_arrays=True) -- the functions HypothesisSink in bench.py calls
+def _bench_records(rank, B, T):
+    g = torch.Generator().manual_seed(100 + rank)
+    lens = torch.randint(0, T + 1, (B,), generator=g, dtype=torch.int32)
+    ids = torch.randint(1, 4999, (B, T), generator=g, dtype=torch.int32)
+    ids[torch.arange(T).unsqueeze(0) >= lens.unsqueeze(1)] = -1
+    return ids, lens, torch.full((B,), float(rank), dtype=torch.float32)
+
+
+def _bench_worker(rank, world, port, B, T, q):
+    from espnet_amd.distributed import gather_records, unpack_records
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = gather_records(*_bench_records(rank, B, T))
+        ids, lens, sc = unpack_records(*g, world * B, world, as_arrays=True)
+        hyps = unpack_records(*g, world * B, world)
+        q.put((rank, ids.tolist(), lens.tolist(), sc.tolist(), hyps))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_bench_record_layout_two_ranks():
+    world, B, T = 2, 4, 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, B, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [_bench_records(r, B, T) for r in range(world)]
+    w_ids = torch.cat([w[0] for w in want]).tolist()
+    w_lens = torch.cat([w[1] for w in want]).tolist()
+    w_sc = torch.cat([w[2] for w in want]).tolist()
+    for r in range(world):  # rank-major == global utterance order when every rank holds a full slab
+        ids, lens, sc, hyps = got[r]
+        assert ids == w_ids and lens == w_lens and sc == w_sc
+        assert len(hyps) == world * B
+        for u, (toks, s) in enumerate(hyps):
+            assert toks == w_ids[u][: w_lens[u]] and s == w_sc[u]
+
+
+def test_record_rows_uneven_slabs():
+    from espnet_amd.distributed import record_rows
+
+    # 7 utterances over 2 ranks: slabs of 4 (rank 0 holds 4, rank 1 holds 3 + one padding record)
+    assert record_rows(7, 2, 4).tolist() == [0, 1, 2, 3, 4, 5, 6]
+    # 5 over 4 ranks: slab 2; ranks hold 2, 1, 1, 1
+    assert record_rows(5, 4, 2).tolist() == [0, 1, 2, 4, 6]
+
+
+# ---- `inference(--ngpu N)`: slab per rank -> shard files -> decode_sharded collation -> merged files in key order
+def _fake_slab_decoder(slab_keys, shard_dir):
+    """Stand-in for the single-GPU `inference()` of one rank: writes the files it would write."""
+    toks = [[(11 * int(k[3:]) + j) % 4999 + 1 for j in range(2 + int(k[3:]) % 4)] for k in slab_keys]
+    scores = [-0.5 * int(k[3:]) for k in slab_keys]
+    d = shard_dir / "1best_recog"
+    d.mkdir(parents=True, exist_ok=True)
+    with (d / "token_int").open("w") as f1, (d / "score").open("w") as f2, (d / "text").open("w") as f3:
+        for k, t, s in zip(slab_keys, toks, scores):
+            f1.write(f"{k} {' '.join(map(str, t))}\n")
+            f2.write(f"{k} {s}\n")
+            f3.write(f"{k} text of {k}\n")
+    return toks, scores, {"utterances": len(slab_keys)}
+
+
+def _ngpu_worker(rank, world, port, keys, out_dir, q):
+    from espnet_amd.bin.asr_inference import sharded_decode_rank
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hyps, st = sharded_decode_rank(_fake_slab_decoder, keys, out_dir, 1, 16, "cpu")
+        q.put((rank, hyps, st))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_ngpu_sharded_inference_merges_in_key_order(tmp_path):
+    from pathlib import Path
+
+    world = 2
+    keys = [f"utt{u}" for u in (5, 3, 9, 0, 7)]  # input order is not sorted: the merged files must keep it
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ngpu_worker, args=(r, world, port, keys, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_t, want_s, _ = _fake_slab_decoder(keys, Path(tmp_path) / "scratch")
+    for r in range(world):
+        assert [t for t, _ in got[r][0]] == want_t
+        assert [s for _, s in got[r][0]] == pytest.approx(want_s)
+    assert got[0][1]["utterances"] == 3 and got[1][1]["utterances"] == 2  # slabs of 3 + 2
+    rows = (Path(tmp_path) / "1best_recog" / "token_int").read_text().splitlines()
+    assert [ln.split()[0] for ln in rows] == keys
+    assert [[int(t) for t in ln.split()[1:]] for ln in rows] == want_t
+    assert (Path(tmp_path) / "1best_recog" / "text").read_text().splitlines()[2] == "utt9 text of utt9"
