@@ -94,3 +94,13 @@ class CTC(torch.nn.Module):
                                        L.ptr(logits), L.ptr(ids), L.ptr(tokens), L.ptr(tlens),
                                        L.current_stream_ptr()), "em_ctc_greedy")
         return ids, tokens, tlens
+
+    def collapse_device(self, ids: torch.Tensor, olens_dev: torch.Tensor, blank: int, sos_eos: int):
+        """groupby + drop blank / <sos/eos> (bin/asr_inference.py:574-575) over given per-frame ids (B, T) i32:
+        returns (ids, tokens padded with -1, token_lens), no host sync."""
+        B, T = ids.shape
+        tokens = torch.empty(B, T, dtype=torch.int32, device=ids.device)
+        tlens = torch.empty(B, dtype=torch.int32, device=ids.device)
+        L.check(L.load().em_ctc_collapse(L.ptr(ids), L.ptr(olens_dev), B, T, blank, sos_eos, L.ptr(tokens),
+                                         L.ptr(tlens), L.current_stream_ptr()), "em_ctc_collapse")
+        return ids, tokens, tlens

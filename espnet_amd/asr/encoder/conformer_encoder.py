@@ -191,6 +191,8 @@ class ConformerEncoder(torch.nn.Module):
         self._pos_cache = {}
         self._ws = None
         self._olens_cache = {}
+        self.last_ctc_ids = None
+        object.__setattr__(self, "fused_ctc", None)  # set by the model: a CTC head to fuse (not a submodule of the encoder)
 
     def output_size(self) -> int:
         return self._output_size
@@ -271,6 +273,7 @@ class ConformerEncoder(torch.nn.Module):
                 setattr(layers[i], k, v.data_ptr())
         if self._fusable():
             self._pack_fused(layers, A, F)
+            self._pack_fused_ctc(w, A, F)
         w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))
         self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype)
         self._pos_cache = {}
@@ -323,6 +326,28 @@ class ConformerEncoder(torch.nn.Module):
                 lt["fp_a"] = F(torch.cat(a_groups(l)))
             for k, v in lt.items():
                 setattr(layers[i], k, v.data_ptr())
+
+    def _pack_fused_ctc(self, w, A, F):
+        """The CTC head the model attached (`fused_ctc`, a espnet_amd.asr.ctc.CTC): its weight zero-padded to 64-row
+        units and its bias padded with -3e38, for the arg-max stage of the last block kernel (EM_BLOCK_CTC)."""
+        ctc = getattr(self, "fused_ctc", None)
+        if ctc is None or ctc.eprojs != self._output_size:
+            return
+        V = ctc.odim
+        units = (V + 63) // 64
+        if units > L.EM_BLOCK_CTC_MAX_UNITS:
+            return
+        wt = torch.zeros(units * 64, self._output_size, dtype=torch.float32)
+        wt[:V] = ctc.ctc_lo.weight.detach().to(torch.float32).cpu()
+        bt = torch.full((units * 64,), -3.0e38, dtype=torch.float32)
+        bt[:V] = ctc.ctc_lo.bias.detach().to(torch.float32).cpu()
+        w.ctc_w, w.ctc_b, w.ctc_units = A(wt).data_ptr(), F(bt).data_ptr(), units
+        self._ctc_stamp = self._ctc_version(ctc)
+
+    @staticmethod
+    def _ctc_version(ctc):
+        lo = ctc.ctc_lo
+        return (lo.weight.data_ptr(), lo.weight._version, lo.bias.data_ptr(), lo.bias._version)
 
     def _pack_subsampling(self, w, t, A, F):
         """conv.2 (and conv.4): [d][k*k*d] with column (kt*k + kf)*d + c_in, the implicit GEMM's K order."""
@@ -401,6 +426,9 @@ class ConformerEncoder(torch.nn.Module):
                 f"(it needs more than {lim} frames), return empty results", n0, lim, indices=short)
         dev = feats.device
         pk = self._ensure_packed(dev)
+        ctc = getattr(self, "fused_ctc", None)
+        if ctc is not None and getattr(pk["w"], "ctc_units", 0) > 0 and self._ctc_stamp != self._ctc_version(ctc):
+            pk = self.pack(dev)  # the head's parameters were replaced after packing
         lib = L.load()
         T = self.output_frames(T_f)
         if isolate:  # every utterance as if it were the whole batch: tmax = its own length
@@ -427,6 +455,13 @@ class ConformerEncoder(torch.nn.Module):
         d = self._output_size
         enc_out = torch.empty(B, T, d, dtype=torch.float32, device=dev)
         enc_act = torch.empty(B, T, d, dtype=self.act_dtype, device=dev)
+        # the fused path also hands back the CTC head's per-frame arg-max (EM_BLOCK_CTC): no logits, no second pass
+        self.last_ctc_ids = None
+        if getattr(pk["w"], "ctc_units", 0) > 0 and _fused_enabled(self):
+            self.last_ctc_ids = torch.empty(B, T, dtype=torch.int32, device=dev)
+            pk["w"].ctc_ids = self.last_ctc_ids.data_ptr()
+        elif hasattr(pk["w"], "ctc_ids"):
+            pk["w"].ctc_ids = None
         rc = getattr(lib, self._ENC_FN)(
             self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
             L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(ws),

@@ -19,12 +19,13 @@ from espnet_amd import lib as L
 class EncoderState:
     """Device-resident result of one encode call."""
 
-    __slots__ = ("enc_out", "enc_act", "olens", "olens_dev", "feats", "flens")
+    __slots__ = ("enc_out", "enc_act", "olens", "olens_dev", "feats", "flens", "ctc_ids")
 
-    def __init__(self, enc_out, enc_act, olens, olens_dev, feats, flens):
+    def __init__(self, enc_out, enc_act, olens, olens_dev, feats, flens, ctc_ids=None):
         self.enc_out, self.enc_act = enc_out, enc_act
         self.olens, self.olens_dev = olens, olens_dev
         self.feats, self.flens = feats, flens
+        self.ctc_ids = ctc_ids  # (B, T) i32 per-frame CTC arg-max when the encoder's last kernel produced it
 
 
 class ESPnetASRModel(torch.nn.Module):
@@ -63,6 +64,10 @@ class ESPnetASRModel(torch.nn.Module):
         # espnet_model.py:167-192
         self.decoder = decoder if ctc_weight < 1.0 else None
         self.ctc = None if ctc_weight == 0.0 else ctc
+        # the fused encoder path can take the CTC head's arg-max inside its last kernel (csrc/block.hip EM_BLOCK_CTC);
+        # a plain attribute, not a submodule: the head's parameters stay under `ctc.` only
+        if self.ctc is not None and hasattr(self.encoder, "_pack_fused_ctc"):
+            object.__setattr__(self.encoder, "fused_ctc", self.ctc)
 
     # ------------------------------------------------------------------ packing
     def set_compute_dtype(self, dtype: str):
@@ -119,7 +124,8 @@ class ESPnetASRModel(torch.nn.Module):
                 feats = self.normalize.forward_device(feats, flens_dev)
         enc_out, enc_act, olens, olens_dev = self.encoder.forward_device(feats, flens, flens_dev, partial,
                                                                          isolate=isolate)
-        return EncoderState(enc_out, enc_act, olens, olens_dev, feats, flens)
+        return EncoderState(enc_out, enc_act, olens, olens_dev, feats, flens,
+                            getattr(self.encoder, "last_ctc_ids", None))
 
     def encode(self, speech: torch.Tensor, speech_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Frontend + Encoder (espnet_model.py:380-448).  speech (B, N), speech_lengths (B,)."""
@@ -140,4 +146,6 @@ class ESPnetASRModel(torch.nn.Module):
         if self.ctc is None:
             raise RuntimeError("model has no CTC head (ctc_weight == 0)")
         sos_eos = self.sos if self.sos == self.eos else -2
+        if st.ctc_ids is not None:  # arg-max already taken inside the encoder's last kernel
+            return self.ctc.collapse_device(st.ctc_ids, st.olens_dev, self.blank_id, sos_eos)
         return self.ctc.greedy_device(st.enc_act, st.olens_dev, self.blank_id, sos_eos)

@@ -61,7 +61,7 @@ constexpr int PAR_FLOATS = EM_BLOCK_PARAM_GROUP;
 constexpr int PAR_BYTES = PAR_FLOATS * 4;
 constexpr int SMEM_BYTES = PAR_OFF + 2 * PAR_BYTES;  // all 163 840 B of the LDS
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile (lives in ring slot 3)
-constexpr int MAX_UNITS = 96;
+constexpr int MAX_UNITS = 128;
 
 // code word of a barrier (compute thread 0 -> loader waves)
 constexpr int BAR_UNIT = 1;    // this barrier opens the interval of the next unit of the stream
@@ -78,7 +78,7 @@ struct UnitTable {
 // about the compute waves' progress.  (They used to read it from an LDS word the compute waves wrote before each
 // barrier; a ds_read issued behind a wave's own LDS-DMA instructions waits for those transfers -- +0.16 us per
 // unit in tools/experiments/glds_bench.hip -- so the loaders must not touch LDS.)
-constexpr int MAX_BARRIERS = 160;
+constexpr int MAX_BARRIERS = 192;
 struct Schedule {  // 4 bits per barrier, eight per word: a byte array would be read with a VECTOR load, whose
   unsigned w[MAX_BARRIERS / 8];  // completion wait (vmcnt(0)) drains the loader's whole DMA queue every interval
   __host__ __device__ int get(int k) const { return (w[k >> 3] >> ((k & 7) * 4)) & 15; }
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
   using MM = Mma<bf16>;
   constexpr bool HAS_C = (MODE & EM_BLOCK_C) != 0, HAS_D = (MODE & EM_BLOCK_D) != 0;
   constexpr bool HAS_A = (MODE & EM_BLOCK_A) != 0, FINAL = (MODE & EM_BLOCK_FINAL) != 0;
+  constexpr bool CTC = (MODE & EM_BLOCK_CTC) != 0;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const ring = smem;
   unsigned char* const abuf = smem + ABUF_OFF;
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     if (FINAL) {
       // after_norm (conformer_encoder.py:423-424); G2: [after_norm g 256][b 256]
       float4 y[2][4];
-      ln_apply(pb0, 0, 256, y, BAR_LAST);
+      ln_apply(pb0, 0, 256, y, CTC ? 0 : BAR_LAST);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
         if (row_ok[mi]) {
@@ -672,6 +673,84 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
             *(bf16x4*)((bf16*)a.enc_act + mrow[mi] * D + 64 * f + ncol) = pk;
           }
         }
+      if (!CTC) return;
+      // ---- CTC head (asr/ctc.py:207-215 argmax over ctc_lo): the 32 rows stay in registers as activation
+      // fragments, the [V][256] weight streams through the ring 64 labels at a time, every lane keeps the running
+      // (max, label) of its frames.  Labels ascend with the unit and inside a lane, so a strict > keeps the lowest
+      // label on ties, as torch.argmax does; the cross-lane / cross-wave merges break ties the same way.
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          bf16x4 pk = {(bf16)y[mi][f].x, (bf16)y[mi][f].y, (bf16)y[mi][f].z, (bf16)y[mi][f].w};
+          *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
+        }
+      read_k(open(0), w0);
+      load_act();
+      float best[2] = {-INFINITY, -INFINITY};
+      int bidx[2] = {0, 0};
+      const int NU = a.ctc_units;
+      auto ctc_unit = [&](const WF& w, int u) {
+        const float4 bb = *(const float4*)(a.ctc_b + u * 64 + ncol);
+        f32x4 c[2];
+        mma_k(w, false, c);
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = c[mi][r] + bv[r];
+            if (v > best[mi]) {
+              best[mi] = v;
+              bidx[mi] = u * 64 + ncol + r;
+            }
+          }
+      };
+      WF w1;
+      for (int u = 0; u < NU; u += 2) {
+        if (u + 1 < NU) read_k(open(0), w1);
+        ctc_unit(w0, u);
+        if (u + 1 < NU) {
+          if (u + 2 < NU) read_k(open(0), w0);
+          ctc_unit(w1, u + 1);
+        }
+      }
+      float* const cred = red0 + (nln & 1) * 256;  // [4 waves][32 frames] value, then label
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float ov = __shfl_xor(best[mi], o, 64);
+          const int oi = __shfl_xor(bidx[mi], o, 64);
+          if (ov > best[mi] || (ov == best[mi] && oi < bidx[mi])) {
+            best[mi] = ov;
+            bidx[mi] = oi;
+          }
+        }
+        if (lg == 0) {
+          cred[nf * 32 + mi * 16 + lr] = best[mi];
+          ((int*)cred)[128 + nf * 32 + mi * 16 + lr] = bidx[mi];
+        }
+      }
+      bar(BAR_LAST);
+      if (nf == 0 && lg == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int m = mi * 16 + lr;
+          float bv = cred[m];
+          int bi = ((const int*)cred)[128 + m];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) {
+            const float ov = cred[w * 32 + m];
+            const int oi = ((const int*)cred)[128 + w * 32 + m];
+            if (ov > bv || (ov == bv && oi < bi)) {
+              bv = ov;
+              bi = oi;
+            }
+          }
+          if (row_ok[mi]) a.ctc_ids[mrow[mi]] = bi;
+        }
+      }
       return;
     }
   } else {
@@ -752,6 +831,7 @@ int build_units(int mode, const EmBlockArgs* a, UnitTable* t) {
     ffn_units(a->ffm_w1, a->ffm_w2);
     k_units(a->wqkv, 12);
   }
+  if (mode & EM_BLOCK_CTC) k_units(a->ctc_w, a->ctc_units);
   return n;
 }
 
@@ -783,6 +863,12 @@ int build_schedule(int mode, const EmBlockArgs* a, Schedule* sc) {
     put(BAR_PARAMS | BAR_UNIT);   // norm_ff published, parameter group 0 dead, FFN's first unit
     ffn_bars();
     put(0);                       // norm_final statistics
+    if (mode & EM_BLOCK_CTC) {
+      put(0);                     // after_norm statistics
+      put(BAR_UNIT, a->ctc_units); // rows published + first CTC unit, then one barrier per further unit
+      put(BAR_LAST);              // arg-max exchange between the waves
+      return n;
+    }
     if (mode & EM_BLOCK_FINAL) {
       put(BAR_LAST);              // after_norm statistics
       return n;
@@ -847,13 +933,21 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
     if (a->kernel != KW) return EM_ERR_UNSUPPORTED;
   }
   if (mode == EM_BLOCK_C && (!a->ctx || !a->glu || !a->wout || !a->pw1f)) return EM_ERR_BAD_ARG;
-  if (mode == (EM_BLOCK_D | EM_BLOCK_FINAL) && (!a->enc_out || !a->enc_act)) return EM_ERR_BAD_ARG;
+  if ((mode & EM_BLOCK_FINAL) && (!a->enc_out || !a->enc_act)) return EM_ERR_BAD_ARG;
+  if (mode & EM_BLOCK_CTC) {
+    if (mode != (EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC) || !a->ctc_w || !a->ctc_b || !a->ctc_ids) return EM_ERR_BAD_ARG;
+    // unit table / barrier schedule capacity (kernel arguments): pw2 + FFN + CTC units
+    if (a->ctc_units <= 0 || 4 + 2 * (a->ff / 64) + a->ctc_units > MAX_UNITS ||
+        8 + 2 * (a->ff / 64) + a->ctc_units + 2 > MAX_BARRIERS)
+      return EM_ERR_UNSUPPORTED;
+  }
   // algorithmic flops of the GEMM-shaped stages (the depthwise conv and LayerNorms are VALU work)
   const double M = (double)a->B * a->T;
   double flops = 0.0;
   if (mode & EM_BLOCK_C) flops += 2.0 * M * D * (D + 2 * D);
   if (mode & EM_BLOCK_D) flops += 2.0 * M * D * (D + 2.0 * a->ff);
   if (mode & EM_BLOCK_A) flops += 2.0 * M * D * (2.0 * a->ff + 3 * D);
+  if (mode & EM_BLOCK_CTC) flops += 2.0 * M * D * 64.0 * a->ctc_units;
   const bool rec = em_prof_begin(stream);
   int rc = EM_ERR_BAD_ARG;
   switch (mode) {
@@ -861,6 +955,9 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
     case EM_BLOCK_A: rc = launch_block<EM_BLOCK_A>(a, s); break;
     case EM_BLOCK_D | EM_BLOCK_A: rc = launch_block<EM_BLOCK_D | EM_BLOCK_A>(a, s); break;
     case EM_BLOCK_D | EM_BLOCK_FINAL: rc = launch_block<EM_BLOCK_D | EM_BLOCK_FINAL>(a, s); break;
+    case EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC:
+      rc = launch_block<EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC>(a, s);
+      break;
   }
   if (rec) em_prof_end(stream, flops, EM_PROF_BLOCK);
   return rc;

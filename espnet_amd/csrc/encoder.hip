@@ -156,6 +156,9 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
       if (l + 1 < L) {
         set_a(ly[l + 1]);
         EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_A, &ba, stream));
+      } else if (w->ctc_ids && w->ctc_w && w->ctc_b && w->ctc_units > 0) {
+        ba.ctc_w = w->ctc_w; ba.ctc_b = w->ctc_b; ba.ctc_ids = w->ctc_ids; ba.ctc_units = w->ctc_units;
+        EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC, &ba, stream));
       } else {
         EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_FINAL, &ba, stream));
       }

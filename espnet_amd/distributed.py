@@ -7,8 +7,10 @@ The reference scales inference the same way, with independent processes over spl
 merged afterwards (egs2/TEMPLATE/asr1/asr.sh:1589-1619, 1636-1648; `ngpu > 1` is rejected inside
 one process, espnet2/bin/asr_inference.py:760-765).  SURVEY.md §8(e).
 """
+import functools
 from typing import List, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -55,26 +57,34 @@ def gather_records(ids: torch.Tensor, lens: torch.Tensor, scores: torch.Tensor, 
     return g_ids, g_lens, g_sc
 
 
-def record_rows(n_items: int, world: int, slab: int) -> torch.Tensor:
-    """Row of the gathered (world * slab) record table that holds utterance u, for u < n_items (global utterance
-    order; rank r's slab starts at r * slab and holds shard_bounds(n_items, r, world))."""
+@functools.lru_cache(maxsize=64)
+def _record_rows_np(n_items: int, world: int, slab: int):
     rows = []
     for r in range(world):
         lo, hi = shard_bounds(n_items, r, world)
         rows.extend(range(r * slab, r * slab + hi - lo))
-    return torch.tensor(rows, dtype=torch.int64)
+    return np.asarray(rows, dtype=np.int64)
+
+
+def record_rows(n_items: int, world: int, slab: int) -> torch.Tensor:
+    """Row of the gathered (world * slab) record table that holds utterance u, for u < n_items (global utterance
+    order; rank r's slab starts at r * slab and holds shard_bounds(n_items, r, world))."""
+    return torch.from_numpy(_record_rows_np(n_items, world, slab).copy())
 
 
 def unpack_records(g_ids, g_lens, g_sc, n_items: int, world: int, as_arrays: bool = False):
-    """Host side of the collation: gathered HOST tensors -> the n_items hypotheses in global utterance order.
-    as_arrays=True keeps them as (ids (n_items, max_len) padded with -1, lens, scores) numpy arrays -- no
-    per-utterance Python, which is what a rank that only forwards results (or a benchmark loop) wants."""
-    slab = g_ids.size(0) // world
-    rows = record_rows(n_items, world, slab)
-    ids, lens, sc = g_ids[rows], g_lens[rows], g_sc[rows]
-    assert int(lens.min()) >= 0 if n_items else True, "padding record inside a rank's slab"
+    """Host side of the collation: gathered HOST tensors (or numpy arrays) -> the n_items hypotheses in global
+    utterance order.  as_arrays=True keeps them as (ids (n_items, max_len) padded with -1, lens, scores) numpy
+    arrays -- no per-utterance Python, which is what a rank that only forwards results (or a benchmark loop)
+    wants.  Plain numpy on purpose: this runs once per step next to a GPU that is being fed by the same thread."""
+    a_ids, a_lens, a_sc = (t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t) for t in (g_ids, g_lens, g_sc))
+    slab = a_ids.shape[0] // world
+    rows = _record_rows_np(n_items, world, slab)
+    ids, lens, sc = a_ids[rows], a_lens[rows], a_sc[rows]
+    if n_items and int(lens.min()) < 0:
+        raise AssertionError("padding record inside a rank's slab")
     if as_arrays:
-        return ids.numpy(), lens.numpy(), sc.numpy()
+        return ids, lens, sc
     return [(ids[k, : int(lens[k])].tolist(), float(sc[k])) for k in range(n_items)]
 
 

@@ -21,8 +21,9 @@ EM_A_PLAIN, EM_A_CONV2 = 0, 1
 EM_DW_SWISH, EM_DW_LINEAR, EM_DW_GATE, EM_DW_SELFRES = range(4)
 EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flags (include/espnet_amd.h)
 EM_ENC_NO_FUSED = 2
-EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL = 1, 2, 4, 8
+EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC = 1, 2, 4, 8, 16
 EM_BLOCK_PARAM_GROUP = 1792
+EM_BLOCK_CTC_MAX_UNITS = 88  # csrc/block.hip: unit-table capacity left for the CTC head at ff = 1024
 EM_PROF_GEMM, EM_PROF_BLOCK, EM_PROF_ATTN = 0, 1, 2
 DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
 
@@ -67,7 +68,7 @@ class EmBlockArgs(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "T", "Tpad", "d", "ff", "kernel")] + [("eps", C.c_float)] + \
                [(n, C.c_void_p) for n in ("x", "ctx", "glu", "qh", "kh", "vt", "enc_out", "enc_act", "tlens", "wout",
                                           "pw1f", "pw2", "ff_w1", "ff_w2", "dw_w", "dw_b", "ffm_w1", "ffm_w2", "wqkv",
-                                          "params")]
+                                          "params", "ctc_w", "ctc_b", "ctc_ids")] + [("ctc_units", C.c_int32)]
 
 
 class EmConformerWeights(C.Structure):
@@ -78,7 +79,8 @@ class EmConformerWeights(C.Structure):
                 ("wpos_all", C.c_void_p), ("after_norm_g", C.c_void_p),
                 ("after_norm_b", C.c_void_p), ("layers", C.POINTER(EmConformerLayer)),
                 ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p),
-                ("legacy_relpos", C.c_int32)]
+                ("legacy_relpos", C.c_int32), ("ctc_w", C.c_void_p), ("ctc_b", C.c_void_p),
+                ("ctc_ids", C.c_void_p), ("ctc_units", C.c_int32)]
 
 
 # order of include/espnet_amd.h EmEBranchformerLayer

@@ -277,6 +277,12 @@ typedef struct EmConformerWeights {
   const void* conv3_w;
   const float* conv3_b;
   int32_t legacy_relpos; /* 1: rel_pos_type legacy (pos_emb has T rows, em_legacy_relpos_attention) */
+  /* optional CTC head fused into the last block kernel (EmBlockArgs.ctc_*; bf16 fused path only): with ctc_ids
+   * non-NULL em_conformer_encode also writes the per-frame CTC arg-max ids [B][T] i32 there.               */
+  const void* ctc_w;
+  const float* ctc_b;
+  int32_t* ctc_ids;
+  int32_t ctc_units;
 } EmConformerWeights;
 
 /* em_conformer_encode flags */
@@ -324,6 +330,7 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
 #define EM_BLOCK_D 2
 #define EM_BLOCK_A 4
 #define EM_BLOCK_FINAL 8
+#define EM_BLOCK_CTC 16 /* with D | FINAL: + the CTC head's per-frame arg-max */
 #define EM_BLOCK_PARAM_GROUP 1792
 typedef struct EmBlockArgs {
   int32_t B, T, Tpad, d, ff, kernel;
@@ -340,6 +347,14 @@ typedef struct EmBlockArgs {
   const float *dw_w, *dw_b;         /* D: [31][256] tap-major, [256] (BatchNorm folded) */
   const void *ffm_w1, *ffm_w2, *wqkv; /* A */
   const float* params;
+  /* EM_BLOCK_CTC (with D | FINAL): the CTC head's arg-max (CTC.argmax, espnet2/asr/ctc.py:207-215) straight from
+   * the after_norm rows in registers: ctc_w [64 * ctc_units][256] act = ctc_lo.weight zero-padded to a multiple
+   * of 64 rows, ctc_b [64 * ctc_units] f32 = ctc_lo.bias padded with -3e38, ctc_ids [B][T] i32 out (lowest
+   * index on ties, as torch.argmax).  The logits never exist in memory.                                    */
+  const void* ctc_w;
+  const float* ctc_b;
+  int32_t* ctc_ids;
+  int32_t ctc_units;
 } EmBlockArgs;
 int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
 

@@ -283,3 +283,33 @@ def test_two_minute_utterance_greedy_and_search_limits():
     bs = build_beam_search(model, beam_size=2, ctc_weight=0.3, penalty=0.0, token_list=model.token_list)
     with pytest.raises(NotImplementedError):
         bs.search_batch(st.enc_act, st.olens)
+
+
+@pytest.mark.parametrize("name", ["small_ragged", "small_10s"])
+def test_fused_ctc_argmax_equals_ctc_head_on_same_rows(name):
+    """The last fused block kernel also takes the CTC head's per-frame arg-max (EM_BLOCK_CTC: the logits never reach
+    memory).  Same ids as `CTC.argmax` (the tiled GEMM + arg-max kernels) over the SAME encoder rows; the two sum
+    their 256 products in different orders, so a frame may differ only where its top-2 logit margin is round-off."""
+    g = load_golden(name)
+    model = build(g, "bfloat16")
+    speech, lens = golden_speech(g)
+    st = model.encode_device(speech.cuda(), lens.tolist())
+    assert st.ctc_ids is not None and st.ctc_ids.dtype == torch.int32
+    ids_fused, tok_fused, tl_fused = model.greedy_ctc_device(st)
+    assert ids_fused.data_ptr() == st.ctc_ids.data_ptr()
+    blank, sos = model.blank_id, model.sos
+    ids_ref, tok_ref, tl_ref = model.ctc.greedy_device(st.enc_act, st.olens_dev, blank, sos if sos == model.eos else -2)
+    B, T = ids_ref.shape
+    valid = (torch.arange(T)[None, :] < torch.tensor(st.olens)[:, None])
+    logits = model.ctc.logits_device(st.enc_act).view(B, T, -1)
+    top2 = logits.topk(2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1]).cpu()
+    diff = (ids_fused.cpu() != ids_ref.cpu()) & valid
+    assert bool((margin[diff] < 1e-3).all()), int(diff.sum())
+    assert int(diff.sum()) <= 2
+    assert int(ids_fused.cpu()[valid].min()) >= 0 and int(ids_fused.cpu()[valid].max()) < model.vocab_size
+    if not diff.any():
+        assert torch.equal(tok_fused.cpu(), tok_ref.cpu()) and torch.equal(tl_fused.cpu(), tl_ref.cpu())
+    # the one-operator-per-launch sequence has no fused head
+    model.encoder.fused = False
+    assert model.encode_device(speech.cuda(), lens.tolist()).ctc_ids is None
