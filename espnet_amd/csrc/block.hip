@@ -690,8 +690,12 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       float best[2] = {-INFINITY, -INFINITY};
       int bidx[2] = {0, 0};
       const int NU = a.ctc_units;
+      // the bias of unit u + 1 is requested while unit u computes: a global load issued next to its use would
+      // put its L2 latency into every one of the 79 intervals
+      float4 bnext = *(const float4*)(a.ctc_b + ncol);
       auto ctc_unit = [&](const WF& w, int u) {
-        const float4 bb = *(const float4*)(a.ctc_b + u * 64 + ncol);
+        const float4 bb = bnext;
+        bnext = *(const float4*)(a.ctc_b + (u + 1 < NU ? u + 1 : u) * 64 + ncol);
         f32x4 c[2];
         mma_k(w, false, c);
         const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
