@@ -138,15 +138,7 @@ int em_gemm_splitk(int dtype, int epilogue, const EmGemmArgs* p, void* stream) {
   if (p->M <= 48 || p->M > SK_MAXM || p->N % SK_BN != 0 || p->N > SK_MAXN) return EM_ERR_UNSUPPORTED;
   if (p->K < 512 || p->K % SK_KS != 0 || p->K / SK_KS > SK_MAXS || p->ldc % 4 != 0) return EM_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  Scratch own, *sc = nullptr;
-  if (p->splitk_ws) {  // caller-owned: [64 ticket words][K/128 slices][192][N] f32
-    if (p->splitk_ws_bytes < EM_GEMM_SPLITK_WS_BYTES(p->N, p->K)) return EM_ERR_WORKSPACE;
-    own.tickets = (unsigned*)p->splitk_ws;
-    own.part = (float*)((unsigned char*)p->splitk_ws + 256);
-    sc = &own;
-  } else {
-    sc = scratch_for(s);
-  }
+  Scratch* sc = scratch_for(s);
   if (!sc) return EM_ERR_UNSUPPORTED;
   dim3 grid(p->N / SK_BN, p->K / SK_KS);
   if (dtype == EM_BF16)

@@ -624,15 +624,11 @@ __global__ __launch_bounds__(256) void col_logsoftmax_kernel(float* __restrict__
 __global__ void step_advance_kernel(int* step) { *step += 1; }
 
 inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
-                int N, int K, int lda, int ldc, float scale, void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
+                int N, int K, int lda, int ldc, float scale, void* stream) {
   EmGemmArgs a = {};
   a.A = A; a.W = W; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.scale = scale;
   a.T1 = a.F1 = a.T2 = a.F2 = a.d = 0;
-  if (ws && ws_bytes >= EM_GEMM_SPLITK_WS_BYTES(N, K)) {  // split-K scratch of the search's buffer set
-    a.splitk_ws = ws;
-    a.splitk_ws_bytes = ws_bytes;
-  }
   return em_gemm(dtype, epi, EM_A_PLAIN, &a, stream);
 }
 
@@ -803,11 +799,9 @@ int lm_step(int dtype, const EmSearchParams* p, const EmSearchBuffers* b, int i,
     else
       EM_TRY(em_dec_self_attention(dtype, b->lm_qkv, kc, vc, anc, anc, n, d, lm->heads, p->Lmax, i,
                                    nullptr, (p->W + 1) / 2, b->tok, b->lm_ctx, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->lm_ctx, q.wout, b->lm_x, q.bout, n, d, d, d, d, 1.f, stream, b->gemm_ws,
-                b->gemm_ws_bytes));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->lm_ctx, q.wout, b->lm_x, q.bout, n, d, d, d, d, 1.f, stream));
     EM_TRY(ln_proj(dtype, EM_EPI_RELU, b->lm_x, q.norm2_g, q.norm2_b, q.w1, q.b1, b->lm_h, b->lm_xn, n, ff, d, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->lm_h, q.w2, b->lm_x, q.b2, n, d, ff, ff, d, 1.f, stream, b->gemm_ws,
-                b->gemm_ws_bytes));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, b->lm_h, q.w2, b->lm_x, q.b2, n, d, ff, ff, d, 1.f, stream));
   }
   EM_TRY(ln_proj(dtype, EM_EPI_STORE_F32, b->lm_x, lm->after_norm_g, lm->after_norm_b, lm->out_w, lm->out_b,
                  b->lm_logp, b->lm_xn, n, V, d, stream));
@@ -884,8 +878,6 @@ struct DecStep {
   float* x;
   void *xn, *qkv, *qs, *ctx, *hbuf;
   float* logits;
-  void* gemm_ws = nullptr;  // split-K scratch (EmSearchBuffers.gemm_ws) or NULL
-  size_t gemm_ws_bytes = 0;
 };
 
 int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* stream) {
@@ -913,16 +905,13 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
     else
       EM_TRY(em_dec_self_attention(dtype, a.qkv, kc, vc, anc, anc, n, d, h, a.Lmax, i, nullptr, (a.W + 1) / 2,
                                    nullptr, a.ctx, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.self_wout, a.x, q.self_bout, n, d, d, d, d, 1.f, stream, a.gemm_ws,
-                a.gemm_ws_bytes));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.self_wout, a.x, q.self_bout, n, d, d, d, d, 1.f, stream));
     EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm2_g, q.norm2_b, q.src_wq, q.src_bq, a.qs, a.xn, n, d, d,
                    stream));
     EM_TRY(em_dec_src_attention(dtype, a.qs, kv, 2 * d, vT, a.xlens, a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.src_wout, a.x, q.src_bout, n, d, d, d, d, 1.f, stream, a.gemm_ws,
-                a.gemm_ws_bytes));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.src_wout, a.x, q.src_bout, n, d, d, d, d, 1.f, stream));
     EM_TRY(ln_proj(dtype, EM_EPI_RELU, a.x, q.norm3_g, q.norm3_b, q.w1, q.b1, a.hbuf, a.xn, n, ff, d, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.hbuf, q.w2, a.x, q.b2, n, d, ff, ff, d, 1.f, stream, a.gemm_ws,
-                a.gemm_ws_bytes));
+    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.hbuf, q.w2, a.x, q.b2, n, d, ff, ff, d, 1.f, stream));
   }
   return ln_proj(dtype, EM_EPI_STORE_F32, a.x, dw->after_norm_g, dw->after_norm_b, dw->out_w, dw->out_b,
                  a.logits, a.xn, n, V, d, stream);
@@ -940,8 +929,7 @@ int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, 
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   if (p->w_dec != 0.f) {
     DecStep a{p->B, p->W, p->T, p->Tpad, p->Lmax, i, b->step, b->tok, b->anc_a, b->anc_b, b->xlens, b->self_k,
-              b->self_v, b->mem_kv, b->mem_vT, b->x, b->xn, b->qkv, b->qs, b->ctx, b->hbuf, b->dec_logp,
-              b->gemm_ws, b->gemm_ws_bytes};
+              b->self_v, b->mem_kv, b->mem_vT, b->x, b->xn, b->qkv, b->qs, b->ctx, b->hbuf, b->dec_logp};
     EM_TRY(decoder_step(dtype, dw, a, stream));
   }
   if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));

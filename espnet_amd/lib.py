@@ -50,8 +50,7 @@ class EmGemmArgs(C.Structure):
                 ("d", C.c_int32),
                 ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln2_g", C.c_void_p),
                 ("ln2_b", C.c_void_p), ("ln_out", C.c_void_p), ("ln_out_f32", C.c_void_p),
-                ("ln_eps", C.c_float), ("conv_k", C.c_int32), ("conv_s", C.c_int32),
-                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t)]
+                ("ln_eps", C.c_float), ("conv_k", C.c_int32), ("conv_s", C.c_int32)]
 
 
 _LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b", "norm_conv_g",
@@ -172,17 +171,12 @@ SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "an
                   "end_sctc", "end_slen", "best_all", "best_by_len", "done", "step", "x", "xn", "qkv", "qs",
                   "ctx", "hbuf", "dec_logp", "self_k", "self_v", "mem_kv", "mem_vT",
                   "lm", "lm_e", "lm_xn", "lm_qkv", "lm_ctx", "lm_h", "lm_x", "lm_logp", "lm_k", "lm_v",
-                  "run_slm", "end_slm", "rnn_hs", "rnn_cs", "rnn_hin", "rnn_gates", "gemm_ws", "gemm_ws_bytes",
+                  "run_slm", "end_slm", "rnn_hs", "rnn_cs", "rnn_hin", "rnn_gates",
                   "online_best", "online_psi", "online_snap"]
 
 
 class EmSearchBuffers(C.Structure):
-    _fields_ = [(n, C.c_size_t if n == "gemm_ws_bytes" else C.c_void_p) for n in SEARCH_BUFFERS]
-
-
-def gemm_splitk_ws_bytes(N: int, K: int) -> int:
-    """EM_GEMM_SPLITK_WS_BYTES of include/espnet_amd.h."""
-    return 256 + (K // 128) * 192 * N * 4
+    _fields_ = [(n, C.c_void_p) for n in SEARCH_BUFFERS]
 
 
 _i32, _f32, _vp, _sz = C.c_int32, C.c_float, C.c_void_p, C.c_size_t

@@ -84,10 +84,6 @@ class TransformerLM(torch.nn.Module, BatchScorerInterface):
     def search_key(self):
         return ("transformer", self.att_unit, self.unit, self.layer, self.embed_unit)
 
-    def splitk_dims(self):
-        """(N, K) of this scorer's largest residual GEMM: sizes the search's split-K scratch."""
-        return (self.att_unit, max(self.att_unit, self.unit))
-
     def search_buffers(self, n, V, Lmax, B, cap):
         """name -> shape of the EmSearchBuffers entries this scorer needs (nets/batch_beam_search.py)."""
         dl = self.att_unit

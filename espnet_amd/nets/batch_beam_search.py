@@ -113,10 +113,6 @@ class BatchBeamSearch(BeamSearch):
                           mem_kv=(nl, B * T, 2 * d), mem_vT=(nl, B, d, Tpad))
         if lm is not None:
             shapes.update(lm.search_buffers(n, V, Lmax, B, cap))
-        # scratch of the split-K residual GEMMs (csrc/gemm_splitk.hip; a beam's worth of rows): caller-owned so that
-        # a captured graph of search steps can use it
-        ws_dims = ([(d, max(d, ff))] if use_dec else []) + ([lm.splitk_dims()] if lm is not None and hasattr(lm, "splitk_dims") else [])
-        ws_bytes = max([L.gemm_splitk_ws_bytes(a, b_) for a, b_ in ws_dims], default=0) if 48 < n <= 192 else 0
         if online:  # em_search_online_* (batch_beam_search_online.py)
             shapes.update(online_best=(n, 8), online_psi=(n,), online_snap=(n, 8))
         t = {}
@@ -125,8 +121,6 @@ class BatchBeamSearch(BeamSearch):
                 continue
             dt = torch.int32 if name in _I32 else (act if name in _ACT else torch.float32)
             t[name] = (torch.zeros if name in _ZERO else torch.empty)(shp, dtype=dt, device=dev)
-        if ws_bytes:
-            t["gemm_ws"] = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
         self._bufs[key] = t
         return t
 
@@ -255,10 +249,7 @@ class BatchBeamSearch(BeamSearch):
                              w_lm=float(self.weights.get("lm", 0.0)) if lm is not None else 0.0)
         bs = L.EmSearchBuffers()
         for name in L.SEARCH_BUFFERS:
-            if name == "gemm_ws_bytes":
-                bs.gemm_ws_bytes = bufs["gemm_ws"].numel() if "gemm_ws" in bufs else 0
-            else:
-                setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
+            setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
         if not self.use_hipgraph:
             bs.step = None
         lmw = lm.ensure_packed(dev, Lmax)["w"] if lm is not None else None

@@ -101,10 +101,7 @@ class BatchBeamSearchOnline(BatchBeamSearch):
         bufs["minlens"].zero_()
         bs = L.EmSearchBuffers()
         for name in L.SEARCH_BUFFERS:
-            if name == "gemm_ws_bytes":
-                bs.gemm_ws_bytes = bufs["gemm_ws"].numel() if "gemm_ws" in bufs else 0
-            else:
-                setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
+            setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
         bs.step = None
         lmw = lm.ensure_packed(dev, Lmax)["w"] if lm is not None else None
         if lmw is not None:

@@ -77,14 +77,7 @@ typedef struct EmGemmArgs {
   float ln_eps;
   int32_t conv_k, conv_s; /* EM_A_CONV2: square kernel width / stride; 0 = 3 / 2.  K = conv_k^2 * d
                              (5, 3: the second conv of Conv2dSubsampling6, subsampling.py:706-711) */
-  /* optional caller-owned scratch of the split-K path (48 < M <= 192, EM_EPI_RESID_F32: decoder step), zeroed
-   * once by the caller: 256 bytes of ticket counters + (K / 128) * 192 * N floats of partial tiles
-   * (EM_GEMM_SPLITK_WS_BYTES).  NULL: the library keeps one scratch per stream, which it cannot allocate
-   * while that stream is being captured (the tiled kernel runs instead).                                  */
-  void* splitk_ws;
-  size_t splitk_ws_bytes;
 } EmGemmArgs;
-#define EM_GEMM_SPLITK_WS_BYTES(N, K) (256 + (size_t)((K) / 128) * 192 * (size_t)(N) * 4)
 
 /* ---- library ------------------------------------------------------------------------------- */
 int em_version(void);
@@ -633,9 +626,6 @@ typedef struct EmSearchBuffers {
   float* rnn_cs;                            /* f32 [3][layers][n][d] master state: LSTM c, GRU h */
   void* rnn_hin;                            /* act [layers][n][d] parent-gathered h, then this step's h */
   float* rnn_gates;                         /* f32 [n][G*nhid] */
-  void* gemm_ws;                            /* optional: EmGemmArgs.splitk_ws for the step's residual GEMMs, zeroed by the
-                                               caller, EM_GEMM_SPLITK_WS_BYTES(d, max(d, ff)) bytes (gemm_ws_bytes)   */
-  size_t gemm_ws_bytes;
   /* streaming search (em_search_online_*; NULL offline) */
   float *online_best;                       /* [n][8] valid, parent slot, token, total, dec, ctc, len, lm */
   float *online_psi;                        /* [n] log psi of the selected candidates (next s_prev) */
