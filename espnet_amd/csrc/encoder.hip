@@ -63,17 +63,6 @@ inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const
   return em_gemm(dtype, epi, EM_A_PLAIN, &a, stream);
 }
 
-// GEMM + residual/scale + fused LayerNorm(s) (EM_EPI_RESID_LN / EM_EPI_SCALE_LN, N == 256)
-inline int gemm_ln(int dtype, int epi, const void* A, const void* W, float* x, const float* bias,
-                   int M, int N, int K, float scale, const float* g1, const float* b1,
-                   const float* g2, const float* b2, void* out, float* out_f32, void* stream) {
-  EmGemmArgs a = {};
-  a.A = A; a.W = W; a.C = x; a.bias = bias;
-  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N; a.scale = scale;
-  a.ln_g = g1; a.ln_b = b1; a.ln2_g = g2; a.ln2_b = b2; a.ln_out = out; a.ln_out_f32 = out_f32;
-  a.ln_eps = 1e-12f;
-  return em_gemm(dtype, epi, EM_A_PLAIN, &a, stream);
-}
 
 #define EM_TRY(expr)            \
   do {                          \
@@ -165,76 +154,11 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     }
     return EM_OK;
   }
-  // LayerNorm fused into the producing GEMM's epilogue (EM_EPI_*_LN, N == 256): correct and tested
-  // (tests/test_gpu_kernels.py::test_gemm_layernorm_epilogue) but measured SLOWER on MI355X than
-  // GEMM + stand-alone LN at B=32 (K=256: 16.4 vs 7.1+3.5 us, K=1024: 21.5 vs 12.2+3.5 us;
-  // 250 single-resident workgroups with a long serial epilogue), so it is off.  profiles/ r01f.
-  constexpr bool kFuseLayerNorm = false;
-  if (kFuseLayerNorm && d == 256 && em_sub::mode_of(w->subsample) == 4) {
-    // every LayerNorm rides in the epilogue of the GEMM that produces its input row (one
-    // workgroup owns whole 256-wide rows): no stand-alone LN launches, x is not re-read
-    EM_TRY(gemm_ln(dtype, EM_EPI_SCALE_LN, c2, w->embed_w, x, w->embed_b, M, d, g.F_out * d,
-                   sqrtf((float)d), ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, nullptr, nullptr, xn,
-                   nullptr, stream));
-    for (int l = 0; l < L; ++l) {
-      const EmConformerLayer& q = ly[l];
-      EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
-      EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, 0.5f, q.norm_mha_g,
-                     q.norm_mha_b, nullptr, nullptr, xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
-      EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
-                                 q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
-      EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, ctx, q.wout, x, q.bout, M, d, d, 1.f, q.norm_conv_g,
-                     q.norm_conv_b, nullptr, nullptr, xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
-      EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, conv_lens, B, T, d, w->kernel, g2, stream));
-      EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, g2, q.pw2, x, q.pw2_b, M, d, d, 1.f, q.norm_ff_g,
-                     q.norm_ff_b, nullptr, nullptr, xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
-      if (l + 1 < L)
-        EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, big, q.ff_w2, x, q.ff_b2, M, d, ff, 0.5f,
-                       q.norm_final_g, q.norm_final_b, ly[l + 1].norm_ff_mac_g,
-                       ly[l + 1].norm_ff_mac_b, xn, nullptr, stream));
-      else
-        EM_TRY(gemm_ln(dtype, EM_EPI_RESID_LN, big, q.ff_w2, x, q.ff_b2, M, d, ff, 0.5f,
-                       q.norm_final_g, q.norm_final_b, w->after_norm_g, w->after_norm_b, enc_act,
-                       enc_out, stream));
-    }
-    return EM_OK;
-  }
 
-  // Fused feed-forward blocks (csrc/ffn.hip: LN + w_1 + Swish + w_2 + residual in one kernel, the
-  // hidden activation never leaves the chip).  Correct and tested
-  // (tests/test_gpu_kernels.py::test_ffn_fused_bf16) but measured SLOWER on MI355X at B = 32:
-  // 45 us per FFN vs 29.6 us for LN + two GEMMs.  A row-block workgroup has to stream all of
-  // W1 + W2 (1 MiB) through one CU; the ablation (tools/ffn_bench.py, EM_FFN_DBG) shows 14 us of
-  // weight streaming (73 GB/s per CU), 11 us of MFMA, 5 us of Swish and 14 us of prologue /
-  // epilogue / barriers that do not overlap.  Off until the weights are split across workgroups.
-  constexpr bool kUseFusedFfn = false;
-  if (kUseFusedFfn && dtype == EM_BF16 && d == 256 && ff % 128 == 0 && ff <= 2048) {
-    for (int l = 0; l < L; ++l) {
-      const EmConformerLayer& q = ly[l];
-      EM_TRY(em_ffn_fused_bf16(x, q.norm_ff_mac_g, q.norm_ff_mac_b, LN_EPS, q.ffm_w1, q.ffm_b1,
-                               q.ffm_w2, q.ffm_b2, M, d, ff, 0.5f, stream));
-      EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
-      EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
-                                 q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
-      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
-      EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
-      EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
-      EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, conv_lens, B, T, d, w->kernel, g2, stream));
-      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
-      EM_TRY(em_ffn_fused_bf16(x, q.norm_ff_g, q.norm_ff_b, LN_EPS, q.ff_w1, q.ff_b1, q.ff_w2,
-                               q.ff_b2, M, d, ff, 0.5f, stream));
-      if (l + 1 < L)
-        EM_TRY(em_layernorm_inplace_f32(x, q.norm_final_g, q.norm_final_b, M, d, LN_EPS, stream));
-      else
-        EM_TRY(em_layernorm2(dtype, x, q.norm_final_g, q.norm_final_b, w->after_norm_g,
-                             w->after_norm_b, M, d, LN_EPS, enc_act, enc_out, stream));
-    }
-    return EM_OK;
-  }
+  // ---- one operator per launch (f32 parity mode, the 512-wide model, legacy rel-pos, EM_ENC_NO_FUSED).  Two
+  // earlier fusions of this sequence -- LayerNorm in a whole-row GEMM epilogue and a row-block fused FFN --
+  // measured slower than what follows and live on only as records (tools/experiments/gemm_ln_epilogue.hip.txt,
+  // ffn_fused_rowblock.hip.txt).
   EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr,
                       stream));
   for (int l = 0; l < L; ++l) {

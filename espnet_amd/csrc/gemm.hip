@@ -48,15 +48,6 @@ namespace {
 
 constexpr int ROWB = 128;  // bytes of K per LDS row per K-step
 
-// LayerNorm fused into the epilogue of a GEMM whose N-tile spans the whole row (BN == N):
-// EM_EPI_RESID_LN / EM_EPI_SCALE_LN.  g2 != NULL selects the double form (x <- LN1(x), out = LN2(x)).
-struct LnArgs {
-  const float *g1, *b1, *g2, *b2;
-  void* out;       // act dtype [M][N]
-  float* out_f32;  // optional f32 copy of `out`
-  float eps;
-};
-
 struct ConvGeom {
   int T1, F1, T2, F2, d;
   int kw, st;  // square kernel width and stride (3, 2: Conv2dSubsampling; 5, 3: second conv of Conv2dSubsampling6)
@@ -74,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
                                                    const T* __restrict__ W, void* __restrict__ Cv,
                                                    const float* __restrict__ bias, int M, int N,
                                                    int K, int lda, int ldc, float scale,
-                                                   ConvGeom g, LnArgs ln) {
+                                                   ConvGeom g) {
   using MM = Mma<T>;
   constexpr int BK = ROWB / (int)sizeof(T);  // K elements per step
   constexpr int KSUB = BK / MM::K;           // MFMA k-steps per K-step
@@ -329,86 +320,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
       vals[i * 4 + jr] = *(const float4*)(ep + (i * 16 + jr * 4 + lg) * 64 + ((jg ^ jr) << 4) + cin);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  if constexpr (EPI == EM_EPI_RESID_LN || EPI == EM_EPI_SCALE_LN) {
-    // ---- residual / scale update, then LayerNorm over the full row (BN == N, WAVES_M == 1: the
-    // four waves hold the four 64-column slices of the same WM rows).  Two-pass statistics
-    // (mean, then centred sum of squares) reduced over the 16 lanes of a row slice by shuffles and
-    // over the four waves through LDS.
-    static_assert(WAVES_M == 1, "LN epilogue needs the whole row inside the workgroup");
-    float* red_a = (float*)smem + 4 * WROWS * 64;  // [4][WM]
-    float* red_b = red_a + 4 * WROWS;
-    const int ncl = wn0 + (lane & 15) * 4;
-    const float4 b4l = bias ? *(const float4*)(bias + ncl) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 xv[MI * 4];
-#pragma unroll
-    for (int q = 0; q < MI * 4; ++q) {
-      const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
-      float4 v = vals[q];
-      v.x = scale * (v.x + b4l.x); v.y = scale * (v.y + b4l.y);
-      v.z = scale * (v.z + b4l.z); v.w = scale * (v.w + b4l.w);
-      if (EPI == EM_EPI_RESID_LN && m < M) {
-        const float4 x = *(const float4*)((const float*)Cv + (size_t)m * ldc + ncl);
-        v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-      }
-      xv[q] = v;
-    }
-    const float inv_n = 1.0f / (float)N;
-    auto layer_norm = [&](const float* __restrict__ gg, const float* __restrict__ bb) {
-      float mean[MI * 4], rstd[MI * 4];
-#pragma unroll
-      for (int q = 0; q < MI * 4; ++q) {
-        float sm = (xv[q].x + xv[q].y) + (xv[q].z + xv[q].w);
-        sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64);
-        sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
-        if ((lane & 15) == 0) red_a[wave * WROWS + (q >> 2) * 16 + (q & 3) * 4 + lg] = sm;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < MI * 4; ++q) {
-        const int rl = (q >> 2) * 16 + (q & 3) * 4 + lg;
-        mean[q] = ((red_a[rl] + red_a[WROWS + rl]) + (red_a[2 * WROWS + rl] + red_a[3 * WROWS + rl])) * inv_n;
-        const float dx = xv[q].x - mean[q], dy = xv[q].y - mean[q], dz = xv[q].z - mean[q], dw = xv[q].w - mean[q];
-        float sq = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64);
-        sq += __shfl_xor(sq, 4, 64); sq += __shfl_xor(sq, 8, 64);
-        if ((lane & 15) == 0) red_b[wave * WROWS + rl] = sq;
-      }
-      __syncthreads();
-      const float4 g4 = *(const float4*)(gg + ncl), be4 = *(const float4*)(bb + ncl);
-#pragma unroll
-      for (int q = 0; q < MI * 4; ++q) {
-        const int rl = (q >> 2) * 16 + (q & 3) * 4 + lg;
-        const float var = ((red_b[rl] + red_b[WROWS + rl]) + (red_b[2 * WROWS + rl] + red_b[3 * WROWS + rl])) * inv_n;
-        rstd[q] = 1.0f / sqrtf(var + ln.eps);
-        xv[q].x = (xv[q].x - mean[q]) * rstd[q] * g4.x + be4.x;
-        xv[q].y = (xv[q].y - mean[q]) * rstd[q] * g4.y + be4.y;
-        xv[q].z = (xv[q].z - mean[q]) * rstd[q] * g4.z + be4.z;
-        xv[q].w = (xv[q].w - mean[q]) * rstd[q] * g4.w + be4.w;
-      }
-    };
-    if (ln.g2 != nullptr) layer_norm(ln.g1, ln.b1);  // x <- LN1(x) first (norm_final)
-#pragma unroll
-    for (int q = 0; q < MI * 4; ++q) {
-      const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
-      if (m < M) *(float4*)((float*)Cv + (size_t)m * ldc + ncl) = xv[q];
-    }
-    if (ln.g2 != nullptr) layer_norm(ln.g2, ln.b2);
-    else layer_norm(ln.g1, ln.b1);
-#pragma unroll
-    for (int q = 0; q < MI * 4; ++q) {
-      const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
-      if (m >= M) continue;
-      const size_t o = (size_t)m * N + ncl;
-      if (sizeof(T) == 2) {
-        bf16x4 pk = {(bf16)xv[q].x, (bf16)xv[q].y, (bf16)xv[q].z, (bf16)xv[q].w};
-        *(bf16x4*)((T*)ln.out + o) = pk;
-      } else {
-        *(float4*)((T*)ln.out + o) = xv[q];
-      }
-      if (ln.out_f32) *(float4*)(ln.out_f32 + o) = xv[q];
-    }
-    return;
-  }
   const int c4 = (lane & 15) * 4;  // 4 consecutive output columns handled by this lane
   const int ncol = wn0 + c4;
   if (ncol >= N) return;
@@ -476,7 +387,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
 template <typename T, int EPI, int AMODE>
 int launch(const EmGemmArgs* p, hipStream_t s) {
   ConvGeom g{p->T1, p->F1, p->T2, p->F2, p->d, p->conv_k > 0 ? p->conv_k : 3, p->conv_s > 0 ? p->conv_s : 2};
-  LnArgs ln{};
   constexpr int BN = 128;
   const int nb = em_cdiv(p->N, BN);
   // fewer than ~1.5 workgroups per CU at BM=128 -> halve the M tile to fill the 256 CUs
@@ -484,36 +394,11 @@ int launch(const EmGemmArgs* p, hipStream_t s) {
   if (small) {
     dim3 grid(8 * em_cdiv(nb * em_cdiv(p->M, 64), 8));
     hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE, 64, BN>), grid, dim3(256), 0, s, (const T*)p->A,
-                       (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g, ln);
+                       (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
   } else {
     dim3 grid(8 * em_cdiv(nb * em_cdiv(p->M, 128), 8));
     hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE, 128, BN>), grid, dim3(256), 0, s, (const T*)p->A,
-                       (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g, ln);
-  }
-  EM_CHECK_LAUNCH();
-  return EM_OK;
-}
-
-// GEMM + (residual | scale) + LayerNorm(s) with the whole row in one workgroup: N == 256.
-template <typename T, int EPI>
-int launch_ln(const EmGemmArgs* p, hipStream_t s) {
-  if (p->N != 256 || p->ldc != p->N || !p->ln_g || !p->ln_b || !p->ln_out) return EM_ERR_UNSUPPORTED;
-  ConvGeom g{0, 0, 0, 0, 0, 3, 2};
-  LnArgs ln{p->ln_g, p->ln_b, p->ln2_g, p->ln2_b, p->ln_out, p->ln_out_f32, p->ln_eps};
-  // K <= 256: W (<= 128 KiB) is cheap to re-stream, favour workgroup count (BM = 32);
-  // longer K: halve the W re-reads (BM = 64)
-  static const char* force = getenv("EM_LN_BM");  // developer knob for tools/gemm_bench.py
-  const bool bm32 = force ? (force[0] == '3') : (p->K <= 256 || em_cdiv(p->M, 64) < 128);
-  if (bm32) {
-    dim3 grid(8 * em_cdiv(em_cdiv(p->M, 32), 8));
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, EM_A_PLAIN, 32, 256>), grid, dim3(256), 0, s,
-                       (const T*)p->A, (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda,
-                       p->ldc, p->scale, g, ln);
-  } else {
-    dim3 grid(8 * em_cdiv(em_cdiv(p->M, 64), 8));
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, EM_A_PLAIN, 64, 256>), grid, dim3(256), 0, s,
-                       (const T*)p->A, (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda,
-                       p->ldc, p->scale, g, ln);
+                       (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
   }
   EM_CHECK_LAUNCH();
   return EM_OK;
@@ -535,8 +420,6 @@ int dispatch(int epi, int amode, const EmGemmArgs* p, hipStream_t s) {
     case EM_EPI_GLU: return launch<T, EM_EPI_GLU, EM_A_PLAIN>(p, s);
     case EM_EPI_STORE_F32: return launch<T, EM_EPI_STORE_F32, EM_A_PLAIN>(p, s);
     case EM_EPI_ARGMAX_PART: return launch<T, EM_EPI_ARGMAX_PART, EM_A_PLAIN>(p, s);
-    case EM_EPI_RESID_LN: return launch_ln<T, EM_EPI_RESID_LN>(p, s);
-    case EM_EPI_SCALE_LN: return launch_ln<T, EM_EPI_SCALE_LN>(p, s);
   }
   return EM_ERR_BAD_ARG;
 }

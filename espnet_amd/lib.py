@@ -15,7 +15,7 @@ EM_OK = 0
 EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE, EM_ERR_IO = -1, -2, -3, -4, -5, -6
 EM_F32, EM_BF16 = 0, 1
 (EM_EPI_STORE, EM_EPI_SWISH, EM_EPI_RELU, EM_EPI_RESID_F32, EM_EPI_SCALE_F32, EM_EPI_GLU,
- EM_EPI_STORE_F32, EM_EPI_RESID_LN, EM_EPI_SCALE_LN, EM_EPI_ARGMAX_PART, EM_EPI_GELU) = range(11)
+ EM_EPI_STORE_F32, _EM_EPI_UNUSED_7, _EM_EPI_UNUSED_8, EM_EPI_ARGMAX_PART, EM_EPI_GELU) = range(11)
 EM_A_PLAIN, EM_A_CONV2 = 0, 1
 
 EM_DW_SWISH, EM_DW_LINEAR, EM_DW_GATE, EM_DW_SELFRES = range(4)
@@ -47,10 +47,7 @@ class EmGemmArgs(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldc", C.c_int32), ("scale", C.c_float),
                 ("T1", C.c_int32), ("F1", C.c_int32), ("T2", C.c_int32), ("F2", C.c_int32),
-                ("d", C.c_int32),
-                ("ln_g", C.c_void_p), ("ln_b", C.c_void_p), ("ln2_g", C.c_void_p),
-                ("ln2_b", C.c_void_p), ("ln_out", C.c_void_p), ("ln_out_f32", C.c_void_p),
-                ("ln_eps", C.c_float), ("conv_k", C.c_int32), ("conv_s", C.c_int32)]
+                ("d", C.c_int32), ("conv_k", C.c_int32), ("conv_s", C.c_int32)]
 
 
 _LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b", "norm_conv_g",
@@ -192,7 +189,6 @@ _SIGNATURES = {
     "em_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(EmGemmArgs), _vp]),
     "em_layernorm": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
     "em_layernorm2": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
-    "em_ffn_fused_bf16": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "em_layernorm_inplace_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "em_relpos_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32,
                                       _i32, _vp, _vp]),

@@ -44,13 +44,6 @@ extern "C" {
 #define EM_EPI_GLU 5       /* C[act][n/2] = (acc_v+b_v) * sigmoid(acc_g+b_g); W rows interleaved
                               in 16-row granules [v0..15,g0..15,v16..31,...] (convolution.py:68-69) */
 #define EM_EPI_STORE_F32 6 /* C[f32]  = acc + bias              (CTC / decoder logits) */
-/* GEMM + LayerNorm fused (N == 256: one workgroup owns whole rows; transformer/layer_norm.py:12-42):
- *   x = C[f32] (+)= scale * (acc + bias);  ln2_g == NULL: C <- x,          ln_out[act] = LN(x; ln_g, ln_b)
- *                                          ln2_g != NULL: C <- LN(x; ln_g, ln_b) =: y, ln_out = LN(y; ln2_g, ln2_b)
- *   (the second form is EncoderLayer.norm_final followed by the next block's first norm or by
- *   after_norm, encoder_layer.py:170-171, conformer_encoder.py:423-424)                          */
-#define EM_EPI_RESID_LN 7  /* x = C + scale * (acc + bias) */
-#define EM_EPI_SCALE_LN 8  /* x = scale * (acc + bias)     */
 /* GEMM + per-row partial arg-max (CTC.argmax without materialising the (M, V) logits, asr/ctc.py:207-215):
  *   C[m][g] = (max, argmax) of (acc + bias) over the 64 columns [64 g, 64 g + 64) as an (f32, i32) pair;
  *   ldc = number of 64-column groups = 2 * ceil(N / 128); finish with em_argmax_partials.        */
@@ -70,11 +63,6 @@ typedef struct EmGemmArgs {
   int32_t lda, ldc;  /* in elements */
   float scale;
   int32_t T1, F1, T2, F2, d; /* EM_A_CONV2 only: M = B*T2*F2, K = 9*d */
-  /* EM_EPI_*_LN only */
-  const float *ln_g, *ln_b, *ln2_g, *ln2_b; /* [N] f32 */
-  void* ln_out;                             /* [M][N] act */
-  float* ln_out_f32;                        /* optional f32 copy of ln_out, or NULL */
-  float ln_eps;
   int32_t conv_k, conv_s; /* EM_A_CONV2: square kernel width / stride; 0 = 3 / 2.  K = conv_k^2 * d
                              (5, 3: the second conv of Conv2dSubsampling6, subsampling.py:706-711) */
 } EmGemmArgs;
@@ -142,14 +130,6 @@ int em_layernorm2(int dtype, float* x, const float* g1, const float* b1, const f
                   const float* b2, int32_t M, int32_t d, float eps, void* out, float* out_f32,
                   void* stream);
 
-/* ---- A9 + A10 fused (bf16, d == 256, ff % 128 == 0, ff <= 2048): the macaron feed-forward of
- *      EncoderLayer.forward (conformer/encoder_layer.py:108-121, 160-168):
- *      x += scale * (w_2 . swish(w_1 . LayerNorm(x; ln_g, ln_b) + b1) + b2)
- *      (positionwise_feed_forward.py:30-32, layer_norm.py:12-42).  x [M][d] f32 in/out;
- *      w1 [ff][d], w2 [d][ff] bf16.  The hidden activation never leaves the chip.               */
-int em_ffn_fused_bf16(float* x, const float* ln_g, const float* ln_b, float eps, const void* w1,
-                      const float* b1, const void* w2, const float* b2, int32_t M, int32_t d,
-                      int32_t ff, float scale, void* stream);
 /*   x <- LayerNorm(x; g, b) in place (EncoderLayer.norm_final, encoder_layer.py:170-171)         */
 int em_layernorm_inplace_f32(float* x, const float* g, const float* b, int32_t M, int32_t d,
                              float eps, void* stream);

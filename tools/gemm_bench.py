@@ -23,9 +23,6 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("ffn_w1 large", 3984, 2048, 512, L.EM_EPI_SWISH),
     ("ffn_w2 large", 3984, 512, 2048, L.EM_EPI_RESID_F32),
     ("square 4096", 4096, 4096, 4096, L.EM_EPI_STORE),
-    ("ln out small", 7968, 256, 256, L.EM_EPI_RESID_LN),
-    ("ln w2 small", 7968, 256, 1024, L.EM_EPI_RESID_LN),
-    ("ln embed small", 7968, 256, 4864, L.EM_EPI_SCALE_LN),
 ]
 
 
@@ -33,18 +30,11 @@ def run(name, M, N, K, epi, iters=50):
     a = torch.randn(M, K, device=dev).bfloat16()
     w = torch.randn(N, K, device=dev).bfloat16()
     nout = N // 2 if epi == L.EM_EPI_GLU else N
-    f32out = epi in (L.EM_EPI_RESID_F32, L.EM_EPI_SCALE_F32, L.EM_EPI_STORE_F32, L.EM_EPI_RESID_LN,
-                     L.EM_EPI_SCALE_LN)
+    f32out = epi in (L.EM_EPI_RESID_F32, L.EM_EPI_SCALE_F32, L.EM_EPI_STORE_F32)
     c = torch.zeros(M, nout, device=dev, dtype=torch.float32 if f32out else torch.bfloat16)
     bias = torch.randn(N, device=dev)
     args = L.EmGemmArgs(A=a.data_ptr(), W=w.data_ptr(), C=c.data_ptr(), bias=bias.data_ptr(), M=M,
                         N=N, K=K, lda=K, ldc=nout, scale=0.5)
-    if epi in (L.EM_EPI_RESID_LN, L.EM_EPI_SCALE_LN):
-        g = torch.ones(N, device=dev)
-        lo = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-        args.ln_g, args.ln_b, args.ln_out, args.ln_eps = g.data_ptr(), bias.data_ptr(), lo.data_ptr(), 1e-12
-        if "embed" not in name:
-            args.ln2_g, args.ln2_b = g.data_ptr(), bias.data_ptr()
     st = L.current_stream_ptr()
     for _ in range(5):
         L.check(lib.em_gemm(L.EM_BF16, epi, L.EM_A_PLAIN, args, st), name)
