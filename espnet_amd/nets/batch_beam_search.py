@@ -74,7 +74,7 @@ class BeamSearch:
         # A search step is ~60 dependent launches of 12-120 workgroups each: latency, not throughput, on a 256-CU
         # part.  Utterances are independent, so a batch CAN be cut into `search_lanes` contiguous sub-batches that run
         # the same search concurrently on their own HIP streams (own buffers, own captured graph).  Measured on
-        # MI355X (configs[2], B = 16 x beam 10, profiles/r02_search_lanes.txt): 1 lane 0.646 ms per label step,
+        # MI355X (configs[2], B = 16 x beam 10, profiles/r02_experiments_not_kept.txt): 1 lane 0.646 ms per label step,
         # 2 lanes 0.740, 4 lanes 1.332 -- the per-launch floor (~4.7 us even for a one-thread kernel) is paid per
         # lane and the lanes' launches do not overlap, so the default stays ONE search over the whole batch.
         self.search_lanes = int(os.environ.get("ESPNET_AMD_SEARCH_LANES", "1"))
