@@ -505,6 +505,9 @@ def collect_traffic(kernel_substr, args):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get(
+            "LD_PRELOAD", ""):
+        return None, "already running under a profiler: no nested rocprofv3 passes"
     out = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
@@ -514,7 +517,7 @@ def collect_traffic(kernel_substr, args):
                    "--model", args.model]
             env = dict(os.environ, TMPDIR="/tmp", ESPNET_AMD_BENCH_INNER="1")
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             except subprocess.TimeoutExpired:
                 return None, f"rocprofv3 --pmc {ctr}: timeout"
             files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
