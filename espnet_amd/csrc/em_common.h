@@ -95,12 +95,3 @@ static inline int em_cdiv(int a, int b) { return (a + b - 1) / b; }
 // per-launch timing of the MFMA kernel families (csrc/gemm.hip; bench.py's roofline leg)
 bool em_prof_begin(void* stream);
 void em_prof_end(void* stream, double flops, int tag);
-
-// csrc/decoder.hip: the whole TransformerDecoder step in one launch (XCD-local phases), for <= 32 rows per XCD
-// (ceil(B / 8) utterances x W <= 16 rows each), d <= 512 with d_k = 64, <= 8 layers.  EM_ERR_UNSUPPORTED = the
-// caller keeps the per-operator sequence.  `bar`: 128 zeroed u32 (8 XCDs x 16), re-armed by every launch.
-int em_decoder_mega_step(int dtype, const EmDecoderWeights* dw, int B, int W, int T, int Tpad, int Lmax, int pos,
-                         const int32_t* pos_dev, const int32_t* tok, const int32_t* anc_a, const int32_t* anc_b,
-                         const int32_t* xlens, void* self_k, void* self_v, const void* mem_kv, const void* mem_vT,
-                         float* x, void* qkv, void* qs, void* ctx, void* hbuf, float* logits, void* bar,
-                         void* stream);

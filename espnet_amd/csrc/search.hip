@@ -22,7 +22,6 @@
 // frames; the forward-variable recurrence itself (sequential in t) runs only for the W winners
 // per utterance, in the update kernel.  CTC log-probs are kept transposed ([V][B*T]).
 #include <math.h>
-#include <stdlib.h>
 
 #include "em_common.h"
 
@@ -879,20 +878,10 @@ struct DecStep {
   float* x;
   void *xn, *qkv, *qs, *ctx, *hbuf;
   float* logits;
-  void* mega_bar = nullptr;  // EmSearchBuffers.mega_bar: barrier words of the one-launch step, or NULL
 };
 
 int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* stream) {
   const int n = a.B * a.W, V = dw->vocab, i = a.pos;
-  // the whole step in ONE launch where the shape fits (csrc/decoder.hip dec_mega_kernel); EM_DEC_MEGA=0 keeps
-  // the per-operator sequence (A/B measurements)
-  static const bool mega_on = !(getenv("EM_DEC_MEGA") && atoi(getenv("EM_DEC_MEGA")) == 0);
-  if (a.mega_bar && mega_on) {
-    const int rc = em_decoder_mega_step(dtype, dw, a.B, a.W, a.T, a.Tpad, a.Lmax, a.pos, a.pos_dev, a.tok, a.anc_a,
-                                        a.anc_b, a.xlens, a.self_k, a.self_v, a.mem_kv, a.mem_vT, a.x, a.qkv, a.qs,
-                                        a.ctx, a.hbuf, a.logits, a.mega_bar, stream);
-    if (rc != EM_ERR_UNSUPPORTED) return rc;
-  }
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   const int d = dw->d, ff = dw->ff, h = dw->heads;
   const int* anc = (i & 1) ? a.anc_b : a.anc_a;
@@ -940,7 +929,7 @@ int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, 
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   if (p->w_dec != 0.f) {
     DecStep a{p->B, p->W, p->T, p->Tpad, p->Lmax, i, b->step, b->tok, b->anc_a, b->anc_b, b->xlens, b->self_k,
-              b->self_v, b->mem_kv, b->mem_vT, b->x, b->xn, b->qkv, b->qs, b->ctx, b->hbuf, b->dec_logp, b->mega_bar};
+              b->self_v, b->mem_kv, b->mem_vT, b->x, b->xn, b->qkv, b->qs, b->ctx, b->hbuf, b->dec_logp};
     EM_TRY(decoder_step(dtype, dw, a, stream));
   }
   if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));

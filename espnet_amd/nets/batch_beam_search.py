@@ -26,10 +26,10 @@ from espnet_amd.nets.scorers.length_bonus import LengthBonus
 logger = logging.getLogger(__name__)
 
 _I32 = {"xlens", "maxlens", "minlens", "tok", "parent", "anc_a", "anc_b", "alive", "cand_tok",
-        "sel_idx", "end_count", "end_pos", "end_slot", "end_forced", "done", "step", "mega_bar"}
+        "sel_idx", "end_count", "end_pos", "end_slot", "end_forced", "done", "step"}
 _ACT = {"xn", "qkv", "qs", "ctx", "hbuf", "self_k", "self_v", "mem_kv", "mem_vT", "lm_e", "lm_xn",
         "lm_qkv", "lm_ctx", "lm_h", "lm_k", "lm_v", "rnn_hs", "rnn_hin"}
-_ZERO = {"mem_vT", "rnn_hs", "rnn_cs", "rnn_hin", "mega_bar"}  # pad columns / tails that must read as zero
+_ZERO = {"mem_vT", "rnn_hs", "rnn_cs", "rnn_hin"}  # pad columns / tails that must read as zero
 
 
 class BeamSearch:
@@ -110,8 +110,7 @@ class BatchBeamSearch(BeamSearch):
         if use_dec:
             shapes.update(x=(n, d), xn=(n, d), qkv=(n, 3 * d), qs=(n, d), ctx=(n, d), hbuf=(n, ff),
                           dec_logp=(n, V), self_k=(nl, Lmax, n, d), self_v=(nl, Lmax, n, d),
-                          mem_kv=(nl, B * T, 2 * d), mem_vT=(nl, B, d, Tpad),
-                          mega_bar=(128,))  # barrier words of the one-launch decoder step (csrc/decoder.hip)
+                          mem_kv=(nl, B * T, 2 * d), mem_vT=(nl, B, d, Tpad))
         if lm is not None:
             shapes.update(lm.search_buffers(n, V, Lmax, B, cap))
         if online:  # em_search_online_* (batch_beam_search_online.py)

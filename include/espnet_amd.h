@@ -606,8 +606,6 @@ typedef struct EmSearchBuffers {
   float* rnn_cs;                            /* f32 [3][layers][n][d] master state: LSTM c, GRU h */
   void* rnn_hin;                            /* act [layers][n][d] parent-gathered h, then this step's h */
   float* rnn_gates;                         /* f32 [n][G*nhid] */
-  uint32_t* mega_bar;                       /* optional: 128 zeroed words (8 XCDs x 16) for the one-launch decoder step
-                                               (csrc/decoder.hip dec_mega_kernel); NULL keeps one launch per operator */
   /* streaming search (em_search_online_*; NULL offline) */
   float *online_best;                       /* [n][8] valid, parent slot, token, total, dec, ctc, len, lm */
   float *online_psi;                        /* [n] log psi of the selected candidates (next s_prev) */
