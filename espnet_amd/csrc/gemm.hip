@@ -427,7 +427,6 @@ int dispatch(int epi, int amode, const EmGemmArgs* p, hipStream_t s) {
 }  // namespace
 
 int em_gemm_skinny(int dtype, int epilogue, const EmGemmArgs* p, void* stream);  // gemm_skinny.hip
-int em_act_gemm_resid_small(int dtype, const EmGemmArgs* p, void* stream);       // ln_gemm.hip
 
 extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p, void* stream) {
   if (!p || !p->A || !p->W || !p->C) return EM_ERR_BAD_ARG;
@@ -447,8 +446,6 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   int rc = EM_ERR_UNSUPPORTED;
   // very few rows (streaming encoder step, single-utterance beam): latency-bound weight streaming
   if (a_mode == EM_A_PLAIN && p->M <= 48) rc = em_gemm_skinny(dtype, epilogue, p, stream);
-  // a beam's worth of rows with the residual epilogue (decoder / LM step): rows staged once, K streamed per wave
-  else if (a_mode == EM_A_PLAIN && epilogue == EM_EPI_RESID_F32 && p->M <= 256) rc = em_act_gemm_resid_small(dtype, p, stream);
   if (rc == EM_ERR_UNSUPPORTED) {
     rc = EM_ERR_BAD_ARG;
     if (dtype == EM_F32) rc = dispatch<float>(epilogue, a_mode, p, (hipStream_t)stream);

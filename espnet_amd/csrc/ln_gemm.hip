@@ -142,84 +142,6 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ 
   }
 }
 
-
-// The same contraction for an operand-dtype A (no LayerNorm) with the residual epilogue:
-//     C[f32][M][N] += scale * (A[M][K] W[N][K]^T + bias),
-// the decoder step's output projections (K = d) and second feed-forward matrices (K = ff) at M = B * beam rows.
-// The tiled kernel of gemm.hip runs these on 12 workgroups and walks K with two barriers per 64-deep step (7 us at
-// K = 512, 16 us at K = 2048; profiles/r02f_bench_beam_large_b16.md); here a workgroup stages its 32 rows once and
-// every wave streams the whole K of its 16 columns with two chunks of 16 weight-fragment loads in flight.
-template <typename T>
-__global__ __launch_bounds__(256) void act_gemm_resid_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
-                                                             const float* __restrict__ bias, float* __restrict__ C,
-                                                             int M, int N, int K, int ldc, float scale) {
-  using MM = Mma<T>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lg_smem[];
-  T* sA = (T*)lg_smem;
-  const int LDA = K + 16 / (int)sizeof(T);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, lg = lane >> 4;
-  const int n0 = blockIdx.x * LG_BN, m0 = blockIdx.y * LG_BM;
-  constexpr int U = 16;
-  const int nsteps = K / MM::K;
-  int n = n0 + wave * 16 + lr;
-  n = n < N ? n : N - 1;
-  const T* wrow = W + (size_t)n * K + lg * MM::EPL;
-  typename MM::frag fa[U], fb[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) fa[u] = MM::load(wrow + (size_t)(u < nsteps ? u : nsteps - 1) * MM::K);
-  // A rows m0 .. m0+31 -> LDS, 16 bytes per thread and step (rows beyond M repeat row M-1: never stored)
-  {
-    constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
-    const int cpr = K / EPC;                  // chunks per row
-    for (int c = tid; c < LG_BM * cpr; c += 256) {
-      const int r = c / cpr, cc = c - r * cpr;
-      int m = m0 + r;
-      m = m < M ? m : M - 1;
-      *(uint4*)(sA + (size_t)r * LDA + cc * EPC) = *(const uint4*)(A + (size_t)m * lda + cc * EPC);
-    }
-  }
-  __syncthreads();
-  const T* a0 = sA + (size_t)lr * LDA + lg * MM::EPL;
-  const T* a1 = a0 + (size_t)16 * LDA;
-  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; s0 < nsteps; s0 += 2 * U) {
-    // chunk s0 is in fa; request chunk s0 + U into fb, then chunk s0 + 2U into fa while fb is consumed
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      fb[u] = MM::load(wrow + (size_t)(s0 + U + u < nsteps ? s0 + U + u : nsteps - 1) * MM::K);
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (s0 + u < nsteps) {
-        acc0 = MM::mma(MM::load(a0 + (size_t)(s0 + u) * MM::K), fa[u], acc0);
-        acc1 = MM::mma(MM::load(a1 + (size_t)(s0 + u) * MM::K), fa[u], acc1);
-      }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      fa[u] = MM::load(wrow + (size_t)(s0 + 2 * U + u < nsteps ? s0 + 2 * U + u : nsteps - 1) * MM::K);
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (s0 + U + u < nsteps) {
-        acc0 = MM::mma(MM::load(a0 + (size_t)(s0 + U + u) * MM::K), fb[u], acc0);
-        acc1 = MM::mma(MM::load(a1 + (size_t)(s0 + U + u) * MM::K), fb[u], acc1);
-      }
-  }
-  const int ncol = n0 + wave * 16 + lr;
-  if (ncol >= N) return;
-  const float bv = bias ? bias[ncol] : 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const f32x4 a = i ? acc1 : acc0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + i * 16 + lg * 4 + r;
-      if (m >= M) continue;
-      C[(size_t)m * ldc + ncol] += scale * (a[r] + bv);
-    }
-  }
-}
-
 template <typename T, int EPI, int NV>
 int launch_ln_gemm_nv(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
                       void* C, int M, int N, int K, int ldc, hipStream_t s) {
@@ -271,38 +193,4 @@ extern "C" int em_ln_gemm(int dtype, int epilogue, const float* x, const float* 
   if (dtype == EM_BF16)
     return dispatch_ln_gemm<bf16>(epilogue, x, ln_g, ln_b, eps, W, bias, C, M, N, K, ldc, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
-}
-
-// Internal (csrc/gemm.hip dispatch): residual GEMM of a beam's worth of rows.  EM_ERR_UNSUPPORTED = not this shape.
-int em_act_gemm_resid_small(int dtype, const EmGemmArgs* p, void* stream) {
-  const size_t es = dtype == EM_BF16 ? 2 : 4;
-  const size_t lds = (size_t)LG_BM * (p->K + 16 / es) * es;
-  if (p->M <= 48 || p->M > 256 || p->N < 64 || p->K < 256 || p->K % 64 != 0 || lds > 150 * 1024) return EM_ERR_UNSUPPORTED;
-  if ((p->lda * es) % 16 != 0) return EM_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(em_cdiv(p->N, LG_BN), em_cdiv(p->M, LG_BM));
-  static size_t attr_bf = 0, attr_f = 0;
-  if (dtype == EM_BF16) {
-    if (lds > attr_bf) {
-      if (hipFuncSetAttribute((const void*)act_gemm_resid_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024) != hipSuccess)
-        return EM_ERR_LAUNCH;
-      attr_bf = 150 * 1024;
-    }
-    hipLaunchKernelGGL(act_gemm_resid_kernel<bf16>, grid, dim3(256), lds, s, (const bf16*)p->A, p->lda,
-                       (const bf16*)p->W, p->bias, (float*)p->C, p->M, p->N, p->K, p->ldc, p->scale);
-  } else if (dtype == EM_F32) {
-    if (lds > attr_f) {
-      if (hipFuncSetAttribute((const void*)act_gemm_resid_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              150 * 1024) != hipSuccess)
-        return EM_ERR_LAUNCH;
-      attr_f = 150 * 1024;
-    }
-    hipLaunchKernelGGL(act_gemm_resid_kernel<float>, grid, dim3(256), lds, s, (const float*)p->A, p->lda,
-                       (const float*)p->W, p->bias, (float*)p->C, p->M, p->N, p->K, p->ldc, p->scale);
-  } else {
-    return EM_ERR_BAD_ARG;
-  }
-  EM_CHECK_LAUNCH();
-  return EM_OK;
 }
