@@ -340,6 +340,14 @@ def _read_keys(data_path_and_name_and_type, key_file):
         return [ln.split(maxsplit=1)[0] for ln in f if ln.strip()]
 
 
+def _first_float(text: str) -> float:
+    """The score column as the writer formats it (`str(hyp.score)`: a float, or `tensor(-12.3, ...)`)."""
+    import re
+
+    m = re.search(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?|[-+]?(?:inf|nan)", text)
+    return float(m.group(0)) if m else 0.0
+
+
 def merge_shard_outputs(output_dir, keys, world: int, nbest: int):
     """`output_dir/output.{r+1}/{n}best_recog/{token,token_int,score,text}` of the ranks -> the same files under
     `output_dir`, rows in key order (asr.sh:1636-1648 does this with cat + sort -k1)."""
@@ -430,7 +438,7 @@ def _inference_rank(kw: dict):
         rows = {ln.partition(" ")[0]: ln.partition(" ")[2] for ln in ti.read_text().splitlines()} if ti.exists() else {}
         srow = {ln.partition(" ")[0]: ln.partition(" ")[2] for ln in sc.read_text().splitlines()} if sc.exists() else {}
         return ([[int(t) for t in rows.get(k, "").split()] for k in slab_keys],
-                [float(srow.get(k, "0").replace("tensor(", "").rstrip(")")) for k in slab_keys], st)
+                [_first_float(srow.get(k, "0")) for k in slab_keys], st)
 
     hyps, st = sharded_decode_rank(decode_slab, keys, kw["output_dir"], nbest, 4096, torch.device("cuda"))
     return dict(st, utterances_total=len(hyps))
