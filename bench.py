@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — audio-seconds/sec (RTF^-1) of the ASR-inference hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 2000 --warmup 50
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -541,8 +541,9 @@ def collect_traffic(kernel_substr, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000,
+                    help="timed steps (default: ~3 s of the greedy workload, long enough for coarse GPU-busy sampling)")
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step")
     ap.add_argument("--model", default=None, choices=sorted(CONFIGS))
     ap.add_argument("--workload", default="greedy", choices=["greedy", "beam", "stream"],
@@ -568,12 +569,14 @@ def main():
     args = ap.parse_args()
     inner = os.environ.get("ESPNET_AMD_BENCH_INNER") == "1"
     if args.workload == "stream":
+        if args.steps == 2000 and args.warmup == 50:
+            args.steps, args.warmup = 20, 2  # a step is a whole 10 s utterance fed chunk by chunk
         return main_stream(args)
     if args.model is None:
         args.model = "small" if args.workload == "greedy" else "large"
     if args.batch is None:
         args.batch = 32 if args.workload == "greedy" else 16
-    if args.workload == "beam" and args.steps == 200 and args.warmup == 20:
+    if args.workload == "beam" and args.steps == 2000 and args.warmup == 50:
         args.steps, args.warmup = 5, 1  # a beam step is ~100x a greedy one
 
     rank = int(os.environ.get("RANK", "0"))
