@@ -7,8 +7,8 @@
 
 A "step" = one pass of the hot path over one batch of synthetic utterances already resident in
 HBM: HIP STFT/log-mel frontend -> HIP Conformer encoder (fused block kernels) -> greedy CTC (G1)
-decode -> the hypotheses of ALL ranks collated by `espnet_amd.distributed` (fixed-shape records, one
-RCCL all-gather per tensor when N > 1) and copied to the host (pinned, asynchronous; step k's records are
+decode -> the hypotheses of ALL ranks collated by `espnet_amd.distributed` (fixed-shape records, ONE
+RCCL all-gather per step when N > 1) and copied to the host (pinned, asynchronous; step k's records are
 delivered while step k+1 is being launched, all K delivered inside the timed region).  Workload =
 BASELINE.json configs[1]: Conformer-small (12 x 256d, 4 heads, ff 1024), batch 32 x 10 s @ 16 kHz per
 GPU (weak scaling: per-GPU batch fixed).  Random-init weights (torch.manual_seed(0)), synthetic
@@ -668,7 +668,7 @@ def main():
             "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": world * B,
                        "audio_seconds_per_utt": AUDIO_SEC, "parallelism": f"utterance-dp{world}",
-                       "collation": "espnet_amd.distributed gather_records (all-gather of fixed-shape records when "
+                       "collation": "espnet_amd.distributed gather_records (one all-gather of fixed-shape records when "
                                     "N > 1) + async D2H + unpack_records on rank 0, inside the timed step",
                        "inputs": ("pinned host -> device copy inside the timed step (double buffered)" if args.h2d
                                   else "resident in HBM"),

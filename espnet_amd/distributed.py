@@ -41,20 +41,20 @@ def pack_hypotheses(token_ids: Sequence[Sequence[int]], scores: Sequence[float],
 
 
 def gather_records(ids: torch.Tensor, lens: torch.Tensor, scores: torch.Tensor, group=None):
-    """The collective itself: one all-gather per tensor of the ranks' fixed-shape slabs (RCCL over xGMI on the
-    GPU box; the ≈ 64 KB per rank are latency-bound).  Returns the (world * slab, ...) tensors on the callers'
-    device, rank-major; nothing is copied to the host and nothing synchronises."""
+    """The collective itself: ONE all-gather of the ranks' fixed-shape slabs (RCCL over xGMI on the GPU box; the
+    ≈ 32 KB per rank are latency-bound, so token ids, counts and scores travel as one int32 record
+    `[ids (L) | count | score bits]` per hypothesis instead of three collectives).  Returns the (world * slab, ...)
+    tensors on the callers' device, rank-major, as views of the gathered record table; nothing is copied to the
+    host and nothing synchronises."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return ids, lens, scores
-    slab = ids.size(0)
-    g_ids = torch.empty((world * slab, ids.size(1)), dtype=ids.dtype, device=ids.device)
-    g_lens = torch.empty((world * slab,), dtype=lens.dtype, device=lens.device)
-    g_sc = torch.empty((world * slab,), dtype=scores.dtype, device=scores.device)
-    dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
-    dist.all_gather_into_tensor(g_lens, lens.contiguous(), group=group)
-    dist.all_gather_into_tensor(g_sc, scores.contiguous(), group=group)
-    return g_ids, g_lens, g_sc
+    slab, L = ids.shape
+    rec = torch.cat([ids.to(torch.int32), lens.to(torch.int32).view(slab, 1),
+                     scores.to(torch.float32).contiguous().view(torch.int32).view(slab, 1)], dim=1).contiguous()
+    g = torch.empty((world * slab, L + 2), dtype=torch.int32, device=ids.device)
+    dist.all_gather_into_tensor(g, rec, group=group)
+    return g[:, :L], g[:, L], g[:, L + 1].contiguous().view(torch.float32)
 
 
 @functools.lru_cache(maxsize=64)
