@@ -106,10 +106,22 @@ def _fused_enabled(enc) -> bool:
     return bool(getattr(enc, "fused", True)) and os.environ.get("ESPNET_AMD_FUSED", "1") != "0"
 
 
+def pack_k_units(w: torch.Tensor) -> torch.Tensor:
+    """[N][256] -> the fragment-major "K units" of the fused block kernel (include/espnet_amd.h, EmBlockArgs): per
+    64 rows one 32 KiB unit [nf][ks][lg][lr][e] = w[64 u + 16 nf + lr][32 ks + 8 lg + e], so that each MFMA weight
+    operand of a wave is one contiguous 1 KiB line."""
+    n, k = w.shape
+    assert k == 256 and n % 64 == 0, (n, k)
+    return w.detach().reshape(n // 64, 4, 16, 8, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(n, k)
+
+
 def pack_w2(w: torch.Tensor) -> torch.Tensor:
-    """[d][ff] -> [ff/64][d][64]: the 64-deep K slices the fused block kernel streams, each one contiguous."""
+    """[256][ff] -> [ff/64] fragment-major "W2 units": unit c is the 64-deep K slice w[:, 64 c : 64 c + 64] laid out
+    [nf][f][ks][lg][lr][e] = w[64 f + 16 nf + lr][64 c + 32 ks + 8 lg + e]."""
     d, ff = w.shape
-    return w.detach().reshape(d, ff // 64, 64).permute(1, 0, 2).contiguous()
+    assert d == 256 and ff % 64 == 0, (d, ff)
+    u = w.detach().reshape(d, ff // 64, 64).permute(1, 0, 2)  # [c][256][64]
+    return u.reshape(ff // 64, 4, 4, 16, 2, 4, 8).permute(0, 2, 1, 4, 5, 3, 6).contiguous().reshape(ff // 64, d, 64)
 
 
 def rel_pos_table(T: int, d: int) -> torch.Tensor:
@@ -317,8 +329,14 @@ class ConformerEncoder(torch.nn.Module):
                               l.norm_final.bias)]
             tail = a_groups(self.encoders[i + 1]) if i + 1 < n else [group(self.after_norm.weight,
                                                                            self.after_norm.bias)]
-            lt = dict(pw1f=A(pw1[perm]), ffm_w2p=A(pack_w2(l.feed_forward_macaron.w_2.weight)),
+            sa = l.self_attn
+            lt = dict(pw1f=A(pack_k_units(pw1[perm])), ffm_w2p=A(pack_w2(l.feed_forward_macaron.w_2.weight)),
                       ff_w2p=A(pack_w2(l.feed_forward.w_2.weight)),
+                      woutp=A(pack_k_units(sa.linear_out.weight)),
+                      pw2p=A(pack_k_units(cm.pointwise_conv2.weight.reshape(d, d))),
+                      ff_w1p=A(pack_k_units(l.feed_forward.w_1.weight)),
+                      ffm_w1p=A(pack_k_units(l.feed_forward_macaron.w_1.weight)),
+                      wqkvp=A(pack_k_units(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0))),
                       fp_c=F(group(l.self_attn.linear_out.bias, l.norm_conv.weight, l.norm_conv.bias,
                                    cm.pointwise_conv1.bias[perm])),
                       fp_da=F(torch.cat(d_groups + tail)))
@@ -341,7 +359,7 @@ class ConformerEncoder(torch.nn.Module):
         wt[:V] = ctc.ctc_lo.weight.detach().to(torch.float32).cpu()
         bt = torch.full((units * 64,), -3.0e38, dtype=torch.float32)
         bt[:V] = ctc.ctc_lo.bias.detach().to(torch.float32).cpu()
-        w.ctc_w, w.ctc_b, w.ctc_units = A(wt).data_ptr(), F(bt).data_ptr(), units
+        w.ctc_w, w.ctc_b, w.ctc_units = A(pack_k_units(wt)).data_ptr(), F(bt).data_ptr(), units
         self._ctc_stamp = self._ctc_version(ctc)
 
     @staticmethod

@@ -19,6 +19,10 @@ LIB = OUT / "libespnet_amd.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result"]
+# per-file extras.  block.hip: its kernels live at the 256-VGPR line with MFMA accumulators carried around loops; in
+# hipcc's default "AGPR form" every loop trip copies the accumulators VGPR <-> AGPR (~100 v_accvgpr moves per FFN
+# iteration, as much issue time as the MFMAs).  VGPR form keeps them where the VALU epilogues need them.
+EXTRA_FLAGS = {"block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _sources():
@@ -43,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def cc(job):
         src, obj = job
-        flags = FLAGS if src.suffix == ".hip" else ["-O3", "-std=c++17", "-fPIC", "-pthread"]
+        flags = FLAGS + EXTRA_FLAGS.get(src.name, []) if src.suffix == ".hip" else ["-O3", "-std=c++17", "-fPIC", "-pthread"]
         cmd = [HIPCC, *flags, "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

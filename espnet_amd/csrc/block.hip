@@ -44,110 +44,58 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "em_common.h"
 
 namespace {
 
 constexpr int D = 256;
 constexpr int BM = 32;
-constexpr int NT = 512;                      // threads per workgroup: 4 compute waves + 4 loader waves
-constexpr int NC = 256;                      // compute threads
-constexpr int UNIT = 32768;
-constexpr int NSLOT = 4;
-constexpr int ABUF_OFF = NSLOT * UNIT;       // 16 KiB: LN(x) as four [32][64] k-tiles; the FFN's two H tiles alias tiles 0, 1
+constexpr int NT = 256;                      // threads per workgroup: 4 waves, wave w = 16-column slice nf = w
+constexpr int NC = 256;
+constexpr int UNIT = 32768;                  // bytes of one weight unit (64 rows x K = 256, or 256 rows x 64-deep K slice)
+constexpr int TILE_OFF = 0;                  // 32 KiB: the depthwise conv's 62-row input tile
+constexpr int ABUF_OFF = TILE_OFF + 32768;   // 16 KiB: LN(x) as four [32][64] k-tiles; the FFN's two H tiles alias tiles 0, 1
 constexpr int RED_OFF = ABUF_OFF + 16384;    // 2 x 1 KiB: LayerNorm partials [2][4][32], alternating between consecutive LayerNorms
-constexpr int PAR_OFF = RED_OFF + 2048;      // 2 x 7 KiB: bias / LayerNorm vectors, double buffered per group
+constexpr int PAR_OFF = RED_OFF + 2048;      // up to 4 x 7 KiB: every bias / LayerNorm group of the launch
 constexpr int PAR_FLOATS = EM_BLOCK_PARAM_GROUP;
 constexpr int PAR_BYTES = PAR_FLOATS * 4;
-constexpr int SMEM_BYTES = PAR_OFF + 2 * PAR_BYTES;  // all 163 840 B of the LDS
-constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile (lives in ring slot 3)
-constexpr int MAX_UNITS = 128;
+constexpr int MAX_GROUPS = 4;
+constexpr int TOUCH_OFF = PAR_OFF + MAX_GROUPS * PAR_BYTES;  // 1 KiB: where the L2 warm-up's LDS-DMA lands (never read)
+constexpr int SMEM_BYTES = TOUCH_OFF + 1024;  // 80 KiB
+constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile
 
-// code word of a barrier (compute thread 0 -> loader waves)
-constexpr int BAR_UNIT = 1;    // this barrier opens the interval of the next unit of the stream
-constexpr int BAR_PARAMS = 2;  // the older parameter buffer is dead: bring in the next group
-constexpr int BAR_TILE = 4;    // ring slot 3 still holds the depthwise-conv tile
-constexpr int BAR_LAST = 8;    // nothing follows: the loader waves leave
+// what a barrier is for (documentation only since the loader waves are gone)
+// weight units are read through GLOBAL-address-space pointers: a pointer rebuilt from the unit table's integers is
+// generic otherwise, and flat loads count on lgkmcnt too and force vmcnt(0) (they may return out of order)
+typedef const __attribute__((address_space(1))) unsigned char* GU8;
+typedef const __attribute__((address_space(1))) bf16x8* GFRAG;
+constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;
 
-// Unit g of the weight stream: byte address of its 32 contiguous KiB; bit 0 set = W2 unit (256 rows of 128 B),
-// clear = K unit (64 rows of 512 B).
-struct UnitTable {
-  unsigned long long u[MAX_UNITS];
-};
-// Code of every barrier of the launch, in order (host-built, build_schedule): what the loader waves need to know
-// about the compute waves' progress.  (They used to read it from an LDS word the compute waves wrote before each
-// barrier; a ds_read issued behind a wave's own LDS-DMA instructions waits for those transfers -- +0.16 us per
-// unit in tools/experiments/glds_bench.hip -- so the loaders must not touch LDS.)
-constexpr int MAX_BARRIERS = 192;
-struct Schedule {  // 4 bits per barrier, eight per word: a byte array would be read with a VECTOR load, whose
-  unsigned w[MAX_BARRIERS / 8];  // completion wait (vmcnt(0)) drains the loader's whole DMA queue every interval
-  __host__ __device__ int get(int k) const { return (w[k >> 3] >> ((k & 7) * 4)) & 15; }
-  void set(int k, int code) { w[k >> 3] |= (unsigned)code << ((k & 7) * 4); }
-};
-
-// LDS-DMA issued from inline asm: global_load_lds_dwordx4 with a wave-uniform 64-bit base (SGPR pair)
-// and a per-lane 32-bit byte offset; the LDS destination goes through M0 (saved / restored: M0 is
-// compiler-reserved; s_nop 0 = the wait state an M0 write needs before an LDS-DMA).  Hidden from hipcc on
-// purpose: told about an LDS-DMA (the builtin), its waitcnt pass puts s_waitcnt vmcnt(0) in front of every
-// ds_read it cannot prove disjoint (here: every parameter / bias read), which drains the weight ring once
-// per step.  All completion counting is by hand (vmcnt in step_begin).
-__device__ __forceinline__ void glds16x4(const unsigned char* sbase, int o0, int o1, int o2, int o3, unsigned d0) {
-  unsigned keep;
-  const unsigned d1 = d0 + 1024, d2 = d0 + 2048, d3 = d0 + 3072;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %6\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %5\n\t"
-      "s_mov_b32 m0, %7\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, %5\n\t"
-      "s_mov_b32 m0, %8\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %5\n\t"
-      "s_mov_b32 m0, %9\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %4, %5\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(sbase), "s"(d0), "s"(d1), "s"(d2), "s"(d3)
-      : "memory");
-}
-__device__ __forceinline__ void glds16(const unsigned char* sbase, int voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_dst)
-      : "memory");
-}
-
-// "s" asm operands must be provably wave-uniform: make it explicit
-__device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
-}
+// Unit g of the weight stream: byte address of its 32 contiguous KiB, FRAGMENT-MAJOR: [wave nf][fragment q][lane][16 B]
+// (host: pack_k_units / pack_w2 in asr/encoder/conformer_encoder.py), so that one wave-wide load instruction reads 1 KiB
+// contiguous.  tools/experiments/direct_frag_bench.hip: such loads stream 128 GB/s per CU (0.257 us per unit) WITH the
+// unit's 16 MFMAs and a Swish epilogue hidden behind them; the same fragments fetched from row-major weights reach 37
+// GB/s, and the LDS-DMA ring this kernel used before (DMA write + fragment read = 64 KB of LDS traffic per unit, a
+// barrier per unit, four loader waves) ~0.43 us per unit.
+#ifndef EM_BLOCK_DBG
+#define EM_BLOCK_DBG 0  // developer builds: 1 = no MFMA / epilogue work (what does the streaming cost alone?)
+#endif
 
 #define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int MODE>
-__global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const UnitTable tab, const Schedule sched,
-                                                   const int total, const int dbg, long long* __restrict__ stamps) {
+__global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long long* __restrict__ stamps) {
+  constexpr int dbg = EM_BLOCK_DBG;
   using MM = Mma<bf16>;
   constexpr bool HAS_C = (MODE & EM_BLOCK_C) != 0, HAS_D = (MODE & EM_BLOCK_D) != 0;
   constexpr bool HAS_A = (MODE & EM_BLOCK_A) != 0, FINAL = (MODE & EM_BLOCK_FINAL) != 0;
   constexpr bool CTC = (MODE & EM_BLOCK_CTC) != 0;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  unsigned char* const ring = smem;
   unsigned char* const abuf = smem + ABUF_OFF;
   float* const red0 = (float*)(smem + RED_OFF);
-  const float* const par = (const float*)(smem + PAR_OFF);
+  float* const par = (float*)(smem + PAR_OFF);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,84 +103,6 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.y, t0 = blockIdx.x * BM, T = a.T;
 
-  // ======================= loader waves (4 .. 7) =================================================
-  // A loader wave never computes; it follows the compute waves barrier by barrier.  Before barrier k compute
-  // thread 0 publishes a code word in sync[k & 1] (BAR_* bits); the loaders read it after the barrier, so their
-  // loop needs no knowledge of the stage sequence.  Invariants: `started` units have had their interval opened
-  // (a barrier with BAR_UNIT); at any barrier every unit below `started` is finished, so units below
-  // started + NSLOT may be in the ring (one fewer while the conv tile occupies the last slot, BAR_TILE).  Before
-  // every barrier the loader makes sure unit `started` has landed, whether or not this barrier opens its
-  // interval.  Parameter loads are older than the unit loads counted here, and vmcnt retires loads in order.
-  if (wave >= 4) {
-    __builtin_amdgcn_s_setprio(3);  // few instructions, but a late DMA stalls all eight waves
-    const int gc = (lane & 7) ^ (lane >> 3);
-    // glds instruction i (0..7) fills LDS rows R = 64 nf + 8 i + (lane >> 3) of the unit, lane l supplying the
-    // 16-byte chunk (l & 7) ^ (R & 7) of that row's 128 B.  K unit: LDS row R = kt * 64 + n (kt = 64-deep K tile
-    // = nf here, n = weight row inside the unit); W2 unit: LDS row R = n (the host packs the FFN's second matrix
-    // as [ff/64][256][64], so a 64-deep K slice of all 256 rows is 32 contiguous KiB).
-    int kofs[8], w2ofs[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int n = 8 * i + (lane >> 3);
-      kofs[i] = n * (D * 2) + nf * 128 + gc * 16;
-      w2ofs[i] = (64 * nf + n) * 128 + gc * 16;
-    }
-    auto issue_unit = [&](int g, unsigned long long d) {  // d = tab.u[g], fetched one interval earlier
-      if (dbg & 2) return;
-      const unsigned char* base = uniform_ptr((const unsigned char*)(d & ~1ull));
-      const bool w2 = (d & 1ull) != 0;
-      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)((g & (NSLOT - 1)) * UNIT + nf * 8192));
-      glds16x4(base, w2 ? w2ofs[0] : kofs[0], w2 ? w2ofs[1] : kofs[1], w2 ? w2ofs[2] : kofs[2],
-               w2 ? w2ofs[3] : kofs[3], dst);
-      glds16x4(base, w2 ? w2ofs[4] : kofs[4], w2 ? w2ofs[5] : kofs[5], w2 ? w2ofs[6] : kofs[6],
-               w2 ? w2ofs[7] : kofs[7], dst + 4096);
-    };
-    auto issue_params = [&](int grp) {  // 7 KiB group -> LDS buffer grp & 1; wave w moves pieces w and w + 4
-      const unsigned char* src = uniform_ptr((const unsigned char*)(a.params + (size_t)grp * PAR_FLOATS));
-      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(PAR_OFF + (grp & 1) * PAR_BYTES));
-      glds16(src, nf * 1024 + lane * 16, dst + nf * 1024);
-      if (nf < 3) glds16(src, (nf + 4) * 1024 + lane * 16, dst + (nf + 4) * 1024);
-    };
-    issue_params(0);
-    if (!HAS_C) issue_params(1);
-    int gi = 0, started = 0, pgrp = 2;
-    for (; gi < NSLOT - 1 && gi < total; ++gi) issue_unit(gi, tab.u[gi]);
-    // The loader's own chain per interval is what paces the ring when it is long (measured: barrier -> LDS read
-    // of the code word -> scalar load of the table entry -> 8 DMA issues = 1 100 cycles, and every interval
-    // waited for it whether or not the compute waves had anything to do).  So: the table entry of the next unit
-    // is fetched an interval ahead, the unit is issued IMMEDIATELY after the barrier (what may be issued depends
-    // only on the codes of EARLIER barriers: every unit below `started` is finished at any barrier), and this
-    // barrier's code word is read afterwards, while the DMA is already on its way.
-    unsigned long long dnext = tab.u[gi < total ? gi : 0];
-    int code = sched.get(0);
-    for (int k = 0;; ++k) {
-      const int need = started + 1 < gi ? started + 1 : gi;  // units below `need` must have landed
-      const int later = (dbg & 2) ? 3 : gi - need;
-      if (later >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      // every unit below `started` is finished; the conv tile occupies slot 3 while BAR_TILE
-      const int cap = started + ((code & BAR_TILE) ? NSLOT - 1 : NSLOT);
-      if (gi < total && gi < cap) {
-        issue_unit(gi, dnext);
-        ++gi;
-        dnext = tab.u[gi < total ? gi : 0];
-      }
-      for (; gi < total && gi < cap; ++gi) {  // more than one free slot: only around stage boundaries
-        issue_unit(gi, tab.u[gi]);
-        dnext = tab.u[gi + 1 < total ? gi + 1 : 0];
-      }
-      if (code & BAR_PARAMS) issue_params(pgrp++);
-      if (code & BAR_UNIT) ++started;
-      if (code & BAR_LAST) break;
-      code = sched.get(k + 1);
-    }
-    return;
-  }
-
-  // ======================= compute waves (0 .. 3) ===============================================
   // this lane's two frames: mi * 16 + lr
   bool row_ok[2];
   size_t mrow[2];
@@ -255,10 +125,9 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     ++nts;
   };
   stamp();
-  int gs = 0;    // units whose interval has been opened; unit g lives in ring slot g & 3
   int nbar = 0;  // barriers passed
   // every barrier goes through here: publish its code for the loaders, retire own LDS operations, synchronise
-  auto bar = [&](int code) {  // `code` documents what build_schedule() tells the loaders about this barrier
+  auto bar = [&](int code) {  // `code` documents what the barrier is for
     (void)code;
     ++nbar;
     EM_LGKM0();
@@ -368,34 +237,105 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     bar(code);
     load_act();
   };
-  // ---- units: fragment reads run ONE INTERVAL AHEAD of the MFMAs ---------------------------------------
-  // open(): the barrier that makes the next unit of the stream visible (and releases the previous one: its
-  // fragments are in registers by then); read_k / read_w2: its eight fragments LDS -> registers.  A stage
-  // processes unit u from registers while the reads of unit u + 1 are in flight, so the LDS latency hides behind
-  // matrix work instead of opening every interval (a single wave per SIMD has no other wave to hide it with).
+  // ---- units: weight fragments go global memory -> registers, THREE UNITS AHEAD of the MFMAs ------------
+  // A unit is 32 contiguous KiB, fragment-major; this wave's eight fragments are eight 1 KiB lines at
+  // unit + nf * 8 KiB + q * 1 KiB, one wave-wide 16-byte load each.  A single wave per SIMD has no other wave to
+  // hide a load's latency with, so a stage keeps a ring of four fragment sets: unit u computes from ring[u & 3]
+  // while units u + 1 .. u + 3 are in flight (their L2 / MALL latency is several unit times).  No table, no
+  // barrier: a stage knows its matrix (a kernel argument in SGPRs) and counts units.
   struct WF {
     bf16x8 v[8];
   };
-  auto open = [&](int code) -> const unsigned char* {
-    bar(BAR_UNIT | code);
-    const unsigned char* su = ring + (gs & (NSLOT - 1)) * UNIT + (nf * 16 + lr) * 128;
-    ++gs;
-    return su;
-  };
-  auto read_k = [&](const unsigned char* su, WF& w) {  // K unit: fragment ks at v[ks]
+  WF ring[4];
+  const unsigned voff = nf * 8192 + lane * 16;
+  auto read_unit = [&](const void* base, int u, WF& w) {
+    GU8 su = (GU8)base + (size_t)u * UNIT + voff;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) w.v[ks] = *(const bf16x8*)(su + (ks >> 1) * 8192 + ((((ks & 1) * 4 + lg) ^ swz) << 4));
+    for (int q = 0; q < 8; ++q) w.v[q] = *(GFRAG)(su + q * 1024);
   };
-  auto read_w2 = [&](const unsigned char* su, WF& w) {  // W2 unit: fragment (f, ks) at v[2 f + ks]
+  // request the first units of a stage's K stream into ring[0 ..]: called as early as the ring is free (before
+  // the LayerNorm / convolution that precedes the stage)
+  auto k_pre = [&](const void* base, int n) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) w.v[2 * f + ks] = *(const bf16x8*)(su + f * 8192 + (((ks * 4 + lg) ^ swz) << 4));
+    for (int j = 0; j < 3; ++j) read_unit(base, j < n ? j : n - 1, ring[j]);
   };
+  // N K units of `base` (compile-time count: fully unrolled, the body sees constants), the first min(3, N) already
+  // requested by k_pre: body(fragments, u) per unit
+  auto stream_k = [&](const void* base, auto count, auto&& body) {
+    constexpr int N = decltype(count)::value;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      if (u + 3 < N) read_unit(base, u + 3, ring[(u + 3) & 3]);
+      body(ring[u & 3], u);
+    }
+  };
+  // ---- L2 warm-up ------------------------------------------------------------------------------------------
+  // Every workgroup of an XCD reads every weight unit of the launch at about the same moment, so each unit is an
+  // L2 MISS for all of them (hit-on-miss at best): its latency is the MALL / HBM latency, and three units in
+  // flight per wave then bound the stream at ~48 GB/s per CU where L2 hits run at the 128 GB/s ingest limit.  So
+  // the workgroups of an XCD share out the launch's weights in 8 KiB chunks (64 lines: one wave-wide dword load,
+  // a lane per line) and touch them all while the prologue's own global loads are in flight; the weights are in
+  // the XCD's L2 by the time the streams ask for them.  XCD of a workgroup = linear id % 8 (dispatch order).
+  constexpr int MAXT = 16;  // chunks per wave at most: small grids warm what they can
+  auto touch = [&]() {
+#ifdef EM_BLOCK_NO_TOUCH
+    return;
+#endif
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+    const int xcd = wg & 7;
+    const int nworker = ((nwg - 1 - xcd) / 8 + 1) * 4;      // waves of this XCD
+    const int worker = (wg >> 3) * 4 + wave;
+    const unsigned dst = TOUCH_OFF + wave * 256;
+    const int loff = lane * 128;
+    int total = (HAS_C ? 48 : 0) + (HAS_D ? 16 + 8 * nch : 0) + (HAS_A ? 48 + 8 * nch : 0);  // 8 KiB chunks of the launch
+    if (CTC) total += a.ctc_units * 4;
+#pragma unroll 1
+    for (int i = 0; i < MAXT && worker + i * nworker < total; ++i) {
+      int j = worker + i * nworker;                         // chunk of the launch's weight list (wave-uniform)
+      const unsigned char* p = nullptr;
+      auto take = [&](const void* base, int n) {
+        if (p == nullptr) {
+          if (j < n) p = (const unsigned char*)base + (size_t)j * 8192;
+          else j -= n;
+        }
+      };
+      if (HAS_C) {
+        take(a.wout, 16);
+        take(a.pw1f, 32);
+      }
+      if (HAS_D) {
+        take(a.pw2, 16);
+        take(a.ff_w1, nch * 4);
+        take(a.ff_w2, nch * 4);
+      }
+      if (HAS_A) {
+        take(a.ffm_w1, nch * 4);
+        take(a.ffm_w2, nch * 4);
+        take(a.wqkv, 48);
+      }
+      if (CTC) take(a.ctc_w, a.ctc_units * 4);
+      // LDS-DMA (global_load_lds_dword: the word goes to LDS at M0 + 4 * lane, no destination register that a
+      // late return could clobber), from inline asm: a C++ load with no use is dropped, one with a use only at
+      // the kernel's exit is sunk down to it.  hipcc's wait counting does not see them: a wait for a load
+      // issued BEFORE them is still exact (in-order return), a wait for a later one can only over-wait.
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dword %1, %2\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(loff), "s"(p), "s"(dst)
+          : "memory");
+    }
+  };
+  auto touch_done = [&]() {};
+
   // 16 MFMAs of a K unit: out[mi] = C^T[n = nf*16 + lg*4 + r][m = mi*16 + lr]
   // (swap: C[m = mi*16 + lg*4 + r][n = nf*16 + lr])
   auto mma_k = [&](const WF& w, bool swap, f32x4 out[2]) {
-    if (dbg & 1) {
+    if constexpr (dbg & 1) {
       out[0] = out[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       return;
     }
@@ -410,114 +350,142 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     out[0] = c[0][0] + c[0][1];
     out[1] = c[1][0] + c[1][1];
   };
-  // LN(x) -> bf16 -> abuf; the publishing barrier also opens the first unit of the stage that consumes it
-  auto ln_to_act_open = [&](const float* pb, int go, int bo, int code, WF& w0) {
-    float4 y[2][4];
-    ln_apply(pb, go, bo, y, 0);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        bf16x4 pk = {(bf16)y[mi][f].x, (bf16)y[mi][f].y, (bf16)y[mi][f].z, (bf16)y[mi][f].w};
-        *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
-      }
-    const unsigned char* su = open(code);
-    read_k(su, w0);
-    load_act();
+  // x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o.  K_c = rows 64 c .. of W1 (a K
+  // unit), W2_c = the 64-deep slice c of W2.  ring[0], ring[1] alternate the K units, ring[2], ring[3] the W2 units;
+  // ffn_pre() has requested K0, K1, W2_0, W2_1.  Iteration c:
+  //     request K_{c+3} | barrier | Swish(h_{c+1}) -> H[(c+1) & 1] | mma W2_c (H[c & 1]) | request W2_{c+2} | mma K_{c+2} -> h_{c+2}
+  // so a K unit is requested ~1.5 iterations (3 units of work) before its MFMAs and a W2 unit two iterations before.
+  // One barrier per iteration: it publishes H[c & 1] (written an iteration ago) and frees H[(c+1) & 1] (read an
+  // iteration ago).  The two H tiles [32][64] alias abuf's first two k-tiles (the activation fragments are in
+  // registers by then: the barrier before the first H store sees to that).
+  auto ffn_pre = [&](const void* w1, const void* w2) {
+    read_unit(w1, 0, ring[0]);
+    read_unit(w2, 0, ring[2]);
+    read_unit(w1, nch > 1 ? 1 : 0, ring[1]);
+    read_unit(w2, nch > 1 ? 1 : 0, ring[3]);
   };
-  // x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o.  Units in the order
-  // K0 K1 W2_0 K2 W2_1 ... K_last W2_last-1 W2_last (build_units); K0 has been opened by the caller, its
-  // fragments are arriving in wa.  Interval by interval (r = fragment reads of the unit just opened):
-  //   r K1   | mma K0 -> h0
-  //   r W2_0 | Swish(h0) -> H[0] | mma K1 -> h1
-  //   r K2   | Swish(h1) -> H[1] | mma W2_0 (H[0])
-  //   r W2_1 |                     mma K2 -> h2           ... and so on; the last interval has nothing to read.
-  // The Swish epilogue of chunk c (bias, exp, rcp, bf16 pack, LDS store of H[c & 1]) always shares an interval
-  // with the MFMAs of another unit.  2 nch barriers, the last one plain.  The two H tiles [32][64] alias abuf's
-  // first two k-tiles (the activation fragments are in registers by then).
-  auto ffn = [&](const float* pb, int b1o, int b2o, float scale, WF& wa) {
+  auto ffn = [&](const float* pb, int b1o, int b2o, float scale, const void* w1, const void* w2) {
     f32x4 acc2[2][4];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc2[mi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x4 hdbg[2] = {};
     auto h_store = [&](const f32x4 h[2], int c) {
-      if (dbg & 1) return;
+      if constexpr (dbg & 1) return;
       const float4 bb = *(const float4*)(pb + b1o + c * 64 + ncol);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        bf16x4 pk = {(bf16)swishf_(h[mi][0] + bb.x), (bf16)swishf_(h[mi][1] + bb.y),
-                     (bf16)swishf_(h[mi][2] + bb.z), (bf16)swishf_(h[mi][3] + bb.w)};
-        *(bf16x4*)(abuf + (c & 1) * 4096 + mi * 2048 + tile_wr) = pk;  // H[c & 1][m][k = ncol ..]
+        bf16x4 pk;
+        if constexpr (dbg & 16)
+          pk = (bf16x4){(bf16)(h[mi][0] + bb.x), (bf16)(h[mi][1] + bb.y), (bf16)(h[mi][2] + bb.z), (bf16)(h[mi][3] + bb.w)};
+        else
+          pk = (bf16x4){(bf16)swishf_(h[mi][0] + bb.x), (bf16)swishf_(h[mi][1] + bb.y),
+                        (bf16)swishf_(h[mi][2] + bb.z), (bf16)swishf_(h[mi][3] + bb.w)};
+        if constexpr (dbg & 8)
+          hdbg[mi] = pk;
+        else
+          *(bf16x4*)(abuf + (c & 1) * 4096 + mi * 2048 + tile_wr) = pk;  // H[c & 1][m][k = ncol ..]
       }
     };
-    auto mma_w2 = [&](const WF& w, int c) {
-      if (dbg & 1) return;
+    // the W2 MFMAs of chunk c: H[c & 1] fragments LDS -> registers (h_load), then 16 MFMAs (mma_w2).  Two steps so
+    // that the LDS reads can be placed BEFORE the H store of the same interval in program order: hipcc cannot prove
+    // that the store (H[(c+1) & 1]) and the reads (H[c & 1]) do not alias, and reads placed after the store would
+    // chain the MFMAs behind the whole Swish epilogue.
+    auto h_load = [&](int c, bf16x8 hf[4]) {
+      if constexpr (dbg & 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          hf[i] = (bf16x8){hdbg[0][0], hdbg[0][1], hdbg[0][2], hdbg[0][3], hdbg[1][0], hdbg[1][1], hdbg[1][2], hdbg[1][3]};
+        return;
+      }
       const unsigned char* sh = abuf + (c & 1) * 4096 + lr * 128;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int coff = ((ks * 4 + lg) ^ swz) << 4;
-        const bf16x8 h0 = *(const bf16x8*)(sh + coff);
-        const bf16x8 h1 = *(const bf16x8*)(sh + 2048 + coff);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          acc2[0][f] = MM::mma(w.v[2 * f + ks], h0, acc2[0][f]);
-          acc2[1][f] = MM::mma(w.v[2 * f + ks], h1, acc2[1][f]);
-        }
+        hf[2 * ks] = *(const bf16x8*)(sh + coff);
+        hf[2 * ks + 1] = *(const bf16x8*)(sh + 2048 + coff);
       }
     };
-    // An interval that carries a Swish epilogue next to 16 MFMAs: all LDS reads first (next unit's fragments,
-    // bias, H fragments), then the epilogue's VALU / transcendental instructions dealt into the issue gaps between
-    // the MFMAs (left alone hipcc emits the whole epilogue, then the MFMAs: serial on a single wave per SIMD).
-#define EM_INTERLEAVE(NREADS)                                 \
-  do {                                                        \
-    __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {       \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      \
-    }                                                         \
-    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);        \
-  } while (0)
-    WF wb;
+    auto mma_w2 = [&](const WF& w, const bf16x8 hf[4]) {
+      if constexpr (dbg & 1) return;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          acc2[0][f] = MM::mma(w.v[2 * f + ks], hf[2 * ks], acc2[0][f]);
+          acc2[1][f] = MM::mma(w.v[2 * f + ks], hf[2 * ks + 1], acc2[1][f]);
+        }
+    };
+    // the residual is not needed until the end: its 32 registers are parked in LDS (the conv tile's space, lane-major:
+    // conflict-free, private to the lane, no barrier) so that ring + activations + accumulators stay in the 256
+    // architectural VGPRs
+    float4* const xpark = (float4*)(smem + TILE_OFF) + tid;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) xpark[(mi * 4 + f) * NT] = xr[mi][f];
     f32x4 hp[2];
-    if (nch == 1) {
-      read_w2(open(0), wb);
-      mma_k(wa, false, hp);
-      h_store(hp, 0);
-      bar(0);
-      mma_w2(wb, 0);
-    } else {
-      read_k(open(0), wb);       // K1
-      mma_k(wa, false, hp);      // h0
-      read_w2(open(0), wa);      // W2_0
-      {
-        f32x4 hn[2];
-        h_store(hp, 0);
-        mma_k(wb, false, hn);    // h1
-        EM_INTERLEAVE(9);
-        hp[0] = hn[0];
-        hp[1] = hn[1];
+    mma_k(ring[0], false, hp);                       // h0
+    read_unit(w1, nch > 2 ? 2 : nch - 1, ring[0]);
+    bar(0);                                          // every wave holds its activation fragments: abuf may become H
+    h_store(hp, 0);
+    if (nch > 1) mma_k(ring[1], false, hp);          // h1
+    // kc2 holds K_{c+2}, kc3 receives K_{c+3}, wc holds W2_c and receives W2_{c+2}
+    // The requests are UNCONDITIONAL (past the end they repeat the last unit, which nobody waits for): a load under
+    // a branch makes hipcc's wait-count pass assume it may not have been issued, and every wait for an older load
+    // degrades to "wait for everything" - the whole point of the ring.
+    const int last = nch - 1;
+    auto iter = [&](int c, WF& kc2, WF& kc3, WF& wc) {
+      read_unit(w1, c + 3 < nch ? c + 3 : last, kc3);
+      if constexpr (!(dbg & 4)) bar(0);
+      // No branches from here to the next barrier (the last two iterations store an H nobody reads and compute an h
+      // nobody stores): one scheduling region, so that the Swish epilogue's VALU / transcendental instructions can
+      // be dealt into the issue gaps between the W2 MFMAs (left alone hipcc emits the whole epilogue, then the
+      // MFMAs: serial on a single wave per SIMD).  LDS reads (bias, H fragments) first, LDS writes last.
+      bf16x8 hf[4];
+      h_load(c, hf);
+      h_store(hp, c + 1);
+      mma_w2(wc, hf);
+      read_unit(w2, c + 2 < nch ? c + 2 : last, wc);
+      f32x4 hn[2];
+      mma_k(kc2, false, hn);                         // h_{c+2}
+      // the epilogue is ~64 VALU + 16 quarter-rate transcendental instructions, about the issue time of all 32 MFMAs of
+      // the iteration: spread it over both MFMA groups
+      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+      for (int i_ = 0; i_ < 16; ++i_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
       }
-      for (int c = 0; c + 2 < nch; ++c) {
-        read_k(open(0), wb);     // K_{c+2}
-        h_store(hp, c + 1);
-        mma_w2(wa, c);
-        EM_INTERLEAVE(13);
-        read_w2(open(0), wa);    // W2_{c+1}
-        mma_k(wb, false, hp);    // h_{c+2}
+      __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+#pragma unroll
+      for (int i_ = 0; i_ < 16; ++i_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
       }
-      read_w2(open(0), wb);      // W2_last
-      h_store(hp, nch - 1);
-      mma_w2(wa, nch - 2);
-      EM_INTERLEAVE(13);
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+      hp[0] = hn[0];
+      hp[1] = hn[1];
+    };
+    int c = 0;
+#pragma unroll 1
+    for (; c + 1 < nch; c += 2) {
+      iter(c, ring[0], ring[1], ring[2]);
+      iter(c + 1, ring[1], ring[0], ring[3]);
+    }
+    if (c < nch) {  // odd chunk count: the last W2 unit
       bar(0);
-      mma_w2(wb, nch - 1);
+      bf16x8 hf[4];
+      h_load(c, hf);
+      mma_w2(ring[2], hf);
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const float4 b4 = *(const float4*)(pb + b2o + 64 * f + ncol);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
+        xr[mi][f] = xpark[(mi * 4 + f) * NT];
         xr[mi][f].x += scale * (acc2[mi][f][0] + b4.x);
         xr[mi][f].y += scale * (acc2[mi][f][1] + b4.y);
         xr[mi][f].z += scale * (acc2[mi][f][2] + b4.z);
@@ -525,14 +493,9 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
       }
     }
   };
-  // x += (W . act + bias): four K units (N = 256), the first already opened into w[0]
-  auto proj_resid = [&](const float* pb, int bo, WF& w0) {
-    WF w1;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      WF& cur = (f & 1) ? w1 : w0;
-      WF& nxt = (f & 1) ? w0 : w1;
-      if (f + 1 < 4) read_k(open(0), nxt);
+  // x += (W . act + bias): four K units (N = 256), requested by k_pre(w, 4)
+  auto proj_resid = [&](const float* pb, int bo, const void* w) {
+    stream_k(w, std::integral_constant<int, 4>{}, [&](const WF& cur, int f) {
       f32x4 c[2];
       mma_k(cur, false, c);
       const float4 b4 = *(const float4*)(pb + bo + 64 * f + ncol);
@@ -543,12 +506,32 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         xr[mi][f].z += c[mi][2] + b4.z;
         xr[mi][f].w += c[mi][3] + b4.w;
       }
-    }
+    });
   };
 
+  // every parameter group of the launch sits in LDS from the start (C: 1 group, A: 2, D|FINAL: 3, D|A: 4)
+  // (all loads first, then all stores: a load -> store loop pays the memory latency once per trip; the stores wait
+  // behind whatever the stage issues next, the first barrier of every mode publishes them)
+  {
+    constexpr int NG = HAS_C ? 1 : (HAS_D ? (HAS_A ? 4 : 3) : 2);
+    constexpr int PV = NG * (PAR_FLOATS / 4), PIT = (PV + NT - 1) / NT;
+    const float4* src = (const float4*)a.params;
+    float4 pst[PIT];
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int i = tid + it * NT;
+      pst[it] = src[i < PV ? i : PV - 1];
+    }
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int i = tid + it * NT;
+      if (i < PV) ((float4*)par)[i] = pst[it];
+    }
+  }
   const float* const pb0 = par;
   const float* const pb1 = par + PAR_FLOATS;
-  WF w0;  // fragments of the unit a stage starts with
+  const float* const pb2 = par + 2 * PAR_FLOATS;
+  const float* const pb3 = par + 3 * PAR_FLOATS;
 
   if (HAS_C) {
     // linear_out over the attention context: activation fragments straight from global memory
@@ -559,20 +542,18 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) act[mi][ks] = *(const bf16x8*)(crow + ks * 32);
     }
+    k_pre(a.wout, 4);
     load_x();
+    touch();
+    bar(0);  // the parameter groups are in LDS
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
-    read_k(open(0), w0);
-    proj_resid(pb0, 0, w0);
+    proj_resid(pb0, 0, a.wout);
     store_x();
-    ln_to_act_open(pb0, 256, 512, 0, w0);
+    k_pre(a.pw1f, 8);
+    ln_to_act(pb0, 256, 512, 0);
     // pointwise_conv1 + GLU (convolution.py:66-69): unit 2j = value rows 64j.., unit 2j+1 = their gates
-    WF w1;
     f32x4 v[2], gt[2];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      WF& cur = (u & 1) ? w1 : w0;
-      WF& nxt = (u & 1) ? w0 : w1;
-      if (u + 1 < 8) read_k(open(u + 2 == 8 ? BAR_LAST : 0), nxt);
+    stream_k(a.pw1f, std::integral_constant<int, 8>{}, [&](const WF& cur, int u) {
       if (!(u & 1)) {
         mma_k(cur, false, v);
       } else {
@@ -589,7 +570,8 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
           if (row_ok[mi]) *(bf16x4*)((bf16*)a.glu + mrow[mi] * D + 64 * j + ncol) = pk;
         }
       }
-    }
+    });
+    touch_done();
     return;
   }
 
@@ -597,7 +579,8 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     // ---- depthwise conv (k = 31, zero padded) + folded BatchNorm + Swish (convolution.py:72-75):
     // the 62-row input tile of this block (frames t0 - 15 .. t0 + 46 of the utterance, zero outside
     // [0, Tv)) goes through LDS; thread c (= channel) produces the 32 frames of the block.
-    unsigned char* const tile = ring + (NSLOT - 1) * UNIT;  // [62][256] bf16
+    unsigned char* const tile = smem + TILE_OFF;  // [62][256] bf16
+    k_pre(a.pw2, 4);  // pointwise_conv2's first units travel while the convolution runs
     int Tv = T;
     if (a.tlens) Tv = a.tlens[b] < T ? a.tlens[b] : T;
     uint4 stage[8];
@@ -613,6 +596,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     for (int k = 0; k < KW; ++k) wk[k] = a.dw_w[k * D + tid];
     const float bc = a.dw_b[tid];
     load_x();
+    touch();
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int q = tid + it * NC, t = t0 - HALF + (q >> 5);
@@ -641,15 +625,16 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
         }
       }
     }
-    read_k(open(0), w0);  // conv output visible, the tile (slot 3) is free, pointwise_conv2's first unit open
+    bar(0);  // conv output visible
     load_act();
     stamp();  // 1 conv prologue
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]
-    proj_resid(pb0, 0, w0);                        // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
+    proj_resid(pb0, 0, a.pw2);                     // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
     stamp();  // 2
-    ln_to_act_open(pb0, 256, 512, BAR_PARAMS, w0); // norm_ff; G0 is dead after it: group 2 replaces it
+    ffn_pre(a.ff_w1, a.ff_w2);
+    ln_to_act(pb0, 256, 512, 0);                   // norm_ff
     stamp();  // 3
-    ffn(pb1, 0, 1024, 0.5f, w0);                   // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
+    ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2);     // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
     stamp();  // 4
     {
       float4 y[2][4];
@@ -662,7 +647,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     if (FINAL) {
       // after_norm (conformer_encoder.py:423-424); G2: [after_norm g 256][b 256]
       float4 y[2][4];
-      ln_apply(pb0, 0, 256, y, CTC ? 0 : BAR_LAST);
+      ln_apply(pb2, 0, 256, y, CTC ? 0 : BAR_LAST);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
         if (row_ok[mi]) {
@@ -673,7 +658,10 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
             *(bf16x4*)((bf16*)a.enc_act + mrow[mi] * D + 64 * f + ncol) = pk;
           }
         }
-      if (!CTC) return;
+      if (!CTC) {
+        touch_done();
+        return;
+      }
       // ---- CTC head (asr/ctc.py:207-215 argmax over ctc_lo): the 32 rows stay in registers as activation
       // fragments, the [V][256] weight streams through the ring 64 labels at a time, every lane keeps the running
       // (max, label) of its frames.  Labels ascend with the unit and inside a lane, so a strict > keeps the lowest
@@ -685,11 +673,12 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
           bf16x4 pk = {(bf16)y[mi][f].x, (bf16)y[mi][f].y, (bf16)y[mi][f].z, (bf16)y[mi][f].w};
           *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
         }
-      read_k(open(0), w0);
+      const int NU = a.ctc_units;
+      k_pre(a.ctc_w, NU);
+      bar(0);
       load_act();
       float best[2] = {-INFINITY, -INFINITY};
       int bidx[2] = {0, 0};
-      const int NU = a.ctc_units;
       // the bias of unit u + 1 is requested while unit u computes: a global load issued next to its use would
       // put its L2 latency into every one of the 79 intervals
       float4 bnext = *(const float4*)(a.ctc_b + ncol);
@@ -710,13 +699,13 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
             }
           }
       };
-      WF w1;
-      for (int u = 0; u < NU; u += 2) {
-        if (u + 1 < NU) read_k(open(0), w1);
-        ctc_unit(w0, u);
-        if (u + 1 < NU) {
-          if (u + 2 < NU) read_k(open(0), w0);
-          ctc_unit(w1, u + 1);
+#pragma unroll 1
+      for (int u0 = 0; u0 < NU; u0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int u = u0 + j;
+          read_unit(a.ctc_w, u + 3 < NU ? u + 3 : NU - 1, ring[(j + 3) & 3]);  // unconditional: see ffn()
+          if (u < NU) ctc_unit(ring[j], u);
         }
       }
       float* const cred = red0 + (nln & 1) * 256;  // [4 waves][32 frames] value, then label
@@ -755,6 +744,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
           if (row_ok[mi]) a.ctc_ids[mrow[mi]] = bi;
         }
       }
+      touch_done();
       return;
     }
   } else {
@@ -767,28 +757,28 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
     // norm_ff_macaron.  After a D part, buffer 1 still holds G1 (norm_final read it just before this
     // LayerNorm's first barrier): its successor may come in at this LayerNorm's last barrier.
     stamp();  // 5 norm_final
-    ln_to_act_open(pb0, 0, 256, HAS_D ? BAR_PARAMS : 0, w0);
+    const float* const pa0 = HAS_D ? pb2 : pb0;  // GA
+    const float* const pa1 = HAS_D ? pb3 : pb1;  // GA + 1
+    ffn_pre(a.ffm_w1, a.ffm_w2);
+    if (!HAS_D) touch();
+    ln_to_act(pa0, 0, 256, 0);
     stamp();  // 6 norm_ff_macaron
-    ffn(pb0, 512, 1536, 0.5f, w0);                 // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
+    ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2); // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
     stamp();  // 7 macaron FFN
     store_x();
-    ln_to_act_open(pb1, 0, 256, 0, w0);            // norm_mha (encoder_layer.py:123-127)
+    k_pre(a.wqkv, 12);
+    ln_to_act(pa1, 0, 256, 0);                     // norm_mha (encoder_layer.py:123-127)
     stamp();  // 8 norm_mha
     // q / k / v projections (attention.py:91-97), written per head: Q, K as [B][H][Tpad][64], V transposed
     // as [B][H][64][Tpad] (computed with the MFMA operands swapped so a lane holds 4 consecutive frames).
     const int H = D / 64;
-    WF w1;
-#pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      WF& cur = (u & 1) ? w1 : w0;
-      WF& nxt = (u & 1) ? w0 : w1;
-      if (u + 1 < 12) read_k(open(u + 2 == 12 ? BAR_LAST : 0), nxt);
+    stream_k(a.wqkv, std::integral_constant<int, 12>{}, [&](const WF& cur, int u) {
       const int which = u >> 2, head = u & 3;
       const size_t bh = (size_t)b * H + head;
       f32x4 c[2];
       mma_k(cur, which == 2, c);
       if (which < 2) {
-        const float4 b4 = *(const float4*)(pb1 + 512 + u * 64 + ncol);
+        const float4 b4 = *(const float4*)(pa1 + 512 + u * 64 + ncol);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           bf16x4 pk = {(bf16)(c[mi][0] + b4.x), (bf16)(c[mi][1] + b4.y), (bf16)(c[mi][2] + b4.z),
@@ -796,7 +786,7 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
           *(bf16x4*)((bf16*)(which ? a.kh : a.qh) + (bh * a.Tpad + t0 + mi * 16 + lr) * 64 + ncol) = pk;
         }
       } else {
-        const float bvv = pb1[512 + u * 64 + nf * 16 + lr];
+        const float bvv = pa1[512 + u * 64 + nf * 16 + lr];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           bf16x4 pk = {(bf16)(c[mi][0] + bvv), (bf16)(c[mi][1] + bvv), (bf16)(c[mi][2] + bvv),
@@ -804,90 +794,10 @@ __global__ __launch_bounds__(NT) void block_kernel(const EmBlockArgs a, const Un
           *(bf16x4*)((bf16*)a.vt + (bh * 64 + nf * 16 + lr) * a.Tpad + t0 + mi * 16 + lg * 4) = pk;
         }
       }
-    }
+    });
     stamp();  // 9 q k v
   }
-}
-
-// order of the weight units of one launch (see the kernel: pointwise_conv2 | FFN | macaron FFN of the next
-// block | q k v;  linear_out | pointwise_conv1)
-int build_units(int mode, const EmBlockArgs* a, UnitTable* t) {
-  int n = 0;
-  auto k_units = [&](const void* w, int count) {
-    for (int u = 0; u < count; ++u) t->u[n++] = (unsigned long long)((const unsigned char*)w + (size_t)u * UNIT);
-  };
-  auto ffn_units = [&](const void* w1, const void* w2) {
-    const int nch = a->ff / 64;  // K0, (K1, W2_0), (K2, W2_1), ..., W2_last: the kernel's software pipeline
-    for (int c = 0; c <= nch; ++c) {
-      if (c < nch) t->u[n++] = (unsigned long long)((const unsigned char*)w1 + (size_t)c * UNIT);
-      if (c > 0) t->u[n++] = (unsigned long long)((const unsigned char*)w2 + (size_t)(c - 1) * UNIT) | 1ull;
-    }
-  };
-  if (mode & EM_BLOCK_C) {
-    k_units(a->wout, 4);
-    k_units(a->pw1f, 8);
-  }
-  if (mode & EM_BLOCK_D) {
-    k_units(a->pw2, 4);
-    ffn_units(a->ff_w1, a->ff_w2);
-  }
-  if (mode & EM_BLOCK_A) {
-    ffn_units(a->ffm_w1, a->ffm_w2);
-    k_units(a->wqkv, 12);
-  }
-  if (mode & EM_BLOCK_CTC) k_units(a->ctc_w, a->ctc_units);
-  return n;
-}
-
-// The barrier sequence of block_kernel<mode>, barrier by barrier (keep in step with the kernel: every bar(code)
-// there appears here, in order).
-int build_schedule(int mode, const EmBlockArgs* a, Schedule* sc) {
-  int n = 0;
-  const int nch = a->ff / 64;
-  auto put = [&](int code, int count = 1) {
-    for (int i = 0; i < count && n < MAX_BARRIERS; ++i) sc->set(n++, code);
-  };
-  if (mode & EM_BLOCK_C) {
-    put(BAR_UNIT, 4);             // linear_out: one barrier opens each unit
-    put(0);                       // norm_conv statistics
-    put(BAR_UNIT);                // LN(x) published + first unit of pointwise_conv1
-    put(BAR_UNIT, 6);
-    put(BAR_UNIT | BAR_LAST);
-    return n;
-  }
-  auto ffn_bars = [&]() {         // the first unit is opened by the LayerNorm before; one plain barrier at the end
-    put(BAR_UNIT, 2 * nch - 1);
-    put(0);
-  };
-  if (mode & EM_BLOCK_D) {
-    put(BAR_TILE);                // conv tile staged
-    put(BAR_UNIT);                // conv output published + first unit of pointwise_conv2
-    put(BAR_UNIT, 3);
-    put(0);                       // norm_ff statistics
-    put(BAR_PARAMS | BAR_UNIT);   // norm_ff published, parameter group 0 dead, FFN's first unit
-    ffn_bars();
-    put(0);                       // norm_final statistics
-    if (mode & EM_BLOCK_CTC) {
-      put(0);                     // after_norm statistics
-      put(BAR_UNIT, a->ctc_units); // rows published + first CTC unit, then one barrier per further unit
-      put(BAR_LAST);              // arg-max exchange between the waves
-      return n;
-    }
-    if (mode & EM_BLOCK_FINAL) {
-      put(BAR_LAST);              // after_norm statistics
-      return n;
-    }
-  }
-  if (mode & EM_BLOCK_A) {
-    put(0);                       // norm_ff_macaron statistics
-    put(((mode & EM_BLOCK_D) ? BAR_PARAMS : 0) | BAR_UNIT);  // published; after a D part parameter group 1 is dead
-    ffn_bars();
-    put(0);                       // norm_mha statistics
-    put(BAR_UNIT);                // published + first q unit
-    put(BAR_UNIT, 10);
-    put(BAR_UNIT | BAR_LAST);
-  }
-  return n;
+  touch_done();
 }
 
 template <int MODE>
@@ -899,17 +809,12 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
       return EM_ERR_LAUNCH;
     attr_set = true;
   }
-  UnitTable tab = {};
-  const int total = build_units(MODE, a, &tab);
-  Schedule sched = {};
-  build_schedule(MODE, a, &sched);
   dim3 grid(em_cdiv(a->T, BM), a->B);
-  static const int dbg = getenv("EM_BLOCK_DBG") ? atoi(getenv("EM_BLOCK_DBG")) : 0;
   static long long* stamps = nullptr;
   static const bool want_stamps = getenv("EM_BLOCK_STAMPS") != nullptr;
   if (want_stamps && !stamps) hipMalloc((void**)&stamps, 64 * sizeof(long long));
   if (want_stamps) hipMemsetAsync(stamps, 0, 64 * sizeof(long long), s);
-  hipLaunchKernelGGL((block_kernel<MODE>), grid, dim3(NT), SMEM_BYTES, s, *a, tab, sched, total, dbg, stamps);
+  hipLaunchKernelGGL((block_kernel<MODE>), grid, dim3(NT), SMEM_BYTES, s, *a, stamps);
   if (want_stamps) {
     long long h[64];
     hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
@@ -940,10 +845,7 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   if ((mode & EM_BLOCK_FINAL) && (!a->enc_out || !a->enc_act)) return EM_ERR_BAD_ARG;
   if (mode & EM_BLOCK_CTC) {
     if (mode != (EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC) || !a->ctc_w || !a->ctc_b || !a->ctc_ids) return EM_ERR_BAD_ARG;
-    // unit table / barrier schedule capacity (kernel arguments): pw2 + FFN + CTC units
-    if (a->ctc_units <= 0 || 4 + 2 * (a->ff / 64) + a->ctc_units > MAX_UNITS ||
-        8 + 2 * (a->ff / 64) + a->ctc_units + 2 > MAX_BARRIERS)
-      return EM_ERR_UNSUPPORTED;
+    if (a->ctc_units <= 0) return EM_ERR_BAD_ARG;
   }
   // algorithmic flops of the GEMM-shaped stages (the depthwise conv and LayerNorms are VALU work)
   const double M = (double)a->B * a->T;

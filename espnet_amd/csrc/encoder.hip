@@ -119,7 +119,8 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   // ---- fused per Conformer block (csrc/block.hip): three launches per block instead of nineteen
   bool fused = dtype == EM_BF16 && d == 256 && h == 4 && ff <= 1024 && w->kernel == 31 && !w->legacy_relpos &&
                !(flags & EM_ENC_NO_FUSED) && ly[0].fp_a != nullptr;
-  for (int l = 0; fused && l < L; ++l) fused = ly[l].pw1f && ly[l].fp_c && ly[l].fp_da && ly[l].ffm_w2p && ly[l].ff_w2p;
+  for (int l = 0; fused && l < L; ++l) fused = ly[l].pw1f && ly[l].fp_c && ly[l].fp_da && ly[l].ffm_w2p && ly[l].ff_w2p && ly[l].woutp && ly[l].pw2p &&
+                                           ly[l].ff_w1p && ly[l].ffm_w1p && ly[l].wqkvp;
   if (fused) {
     void* qh = ws + s.qh;
     void* kh = ws + s.kh;
@@ -130,7 +131,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     ba.B = B; ba.T = T; ba.Tpad = s.Tpad; ba.d = d; ba.ff = ff; ba.kernel = w->kernel; ba.eps = LN_EPS;
     ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = qh; ba.kh = kh; ba.vt = vt;
     ba.enc_out = enc_out; ba.enc_act = enc_act; ba.tlens = conv_lens;
-    auto set_a = [&](const EmConformerLayer& q) { ba.ffm_w1 = q.ffm_w1; ba.ffm_w2 = q.ffm_w2p; ba.wqkv = q.wqkv; };
+    auto set_a = [&](const EmConformerLayer& q) { ba.ffm_w1 = q.ffm_w1p; ba.ffm_w2 = q.ffm_w2p; ba.wqkv = q.wqkvp; };
     set_a(ly[0]);
     ba.params = ly[0].fp_a;
     EM_TRY(em_conformer_block_fused(EM_BLOCK_A, &ba, stream));
@@ -138,9 +139,9 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
       const EmConformerLayer& q = ly[l];
       EM_TRY(em_relpos_attention2_bf16(qh, kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
                                        q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
-      ba.wout = q.wout; ba.pw1f = q.pw1f; ba.params = q.fp_c;
+      ba.wout = q.woutp; ba.pw1f = q.pw1f; ba.params = q.fp_c;
       EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
-      ba.pw2 = q.pw2; ba.ff_w1 = q.ff_w1; ba.ff_w2 = q.ff_w2p; ba.dw_w = q.dw_w; ba.dw_b = q.dw_b;
+      ba.pw2 = q.pw2p; ba.ff_w1 = q.ff_w1p; ba.ff_w2 = q.ff_w2p; ba.dw_w = q.dw_w; ba.dw_b = q.dw_b;
       ba.params = q.fp_da;
       if (l + 1 < L) {
         set_a(ly[l + 1]);

@@ -54,7 +54,7 @@ _LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b", "no
                "norm_conv_b", "norm_ff_g", "norm_ff_b", "norm_final_g", "norm_final_b",
                "ffm_w1", "ffm_b1", "ffm_w2", "ffm_b2", "wqkv", "bqkv", "pos_u", "pos_v", "wout",
                "bout", "pw1", "pw1_b", "dw_w", "dw_b", "pw2", "pw2_b", "ff_w1", "ff_b1", "ff_w2",
-               "ff_b2", "pw1f", "ffm_w2p", "ff_w2p", "fp_c", "fp_da", "fp_a"]
+               "ff_b2", "pw1f", "ffm_w2p", "ff_w2p", "woutp", "pw2p", "ff_w1p", "ffm_w1p", "wqkvp", "fp_c", "fp_da", "fp_a"]
 
 
 class EmConformerLayer(C.Structure):

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from espnet_amd import lib as L
-from espnet_amd.asr.encoder.conformer_encoder import pack_w2
+from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w2
 from oracle import conformer as oc
 
 pytestmark = pytest.mark.gpu
@@ -200,8 +200,8 @@ def test_block_a(lib, B, T, ff):
     xd = dev(x0.clone())
     qh, kh = (torch.zeros(B, H, Tp, 64, dtype=BF, device="cuda") for _ in range(2))
     vt = torch.zeros(B, H, 64, Tp, dtype=BF, device="cuda")
-    a = block_args(B, T, ff, x=xd, qh=qh, kh=kh, vt=vt, ffm_w1=dev(ly.ffm_w1.to(BF)), ffm_w2=dev(pack_w2(ly.ffm_w2).to(BF)),
-                   wqkv=dev(ly.wqkv.to(BF)), params=dev(torch.cat(ly.a_groups())))
+    a = block_args(B, T, ff, x=xd, qh=qh, kh=kh, vt=vt, ffm_w1=dev(pack_k_units(ly.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(ly.ffm_w2).to(BF)),
+                   wqkv=dev(pack_k_units(ly.wqkv).to(BF)), params=dev(torch.cat(ly.a_groups())))
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_A, a, L.current_stream_ptr()), "block<A>")
     assert_close(xd, x_ref, 4e-3, "block<A> x")
     assert_close(split_heads(qh, B, T), qkv_ref[:, :D], 2e-2, "block<A> q")
@@ -218,8 +218,8 @@ def test_block_c(lib, B, T, ff):
     x_ref, glu_ref = ly.part_c(x0, ctx)
     xd = dev(x0.clone())
     glu = torch.zeros(B * T, D, dtype=BF, device="cuda")
-    a = block_args(B, T, ff, x=xd, ctx=dev(ctx.to(BF)), glu=glu, wout=dev(ly.wout.to(BF)),
-                   pw1f=dev(ly.pw1[ly.perm()].to(BF)), params=dev(ly.c_group()))
+    a = block_args(B, T, ff, x=xd, ctx=dev(ctx.to(BF)), glu=glu, wout=dev(pack_k_units(ly.wout).to(BF)),
+                   pw1f=dev(pack_k_units(ly.pw1[ly.perm()]).to(BF)), params=dev(ly.c_group()))
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_C, a, L.current_stream_ptr()), "block<C>")
     assert_close(xd, x_ref, 4e-3, "block<C> x")
     assert_close(glu, glu_ref, 2e-2, "block<C> glu")
@@ -237,8 +237,8 @@ def test_block_d_final(lib, B, T, ff, masked):
     xd = dev(x0.clone())
     out = torch.zeros(B * T, D, dtype=torch.float32, device="cuda")
     act = torch.zeros(B * T, D, dtype=BF, device="cuda")
-    a = block_args(B, T, ff, x=xd, glu=dev(glu.to(BF)), enc_out=out, enc_act=act, pw2=dev(ly.pw2.to(BF)),
-                   ff_w1=dev(ly.ff_w1.to(BF)), ff_w2=dev(pack_w2(ly.ff_w2).to(BF)), dw_w=dev(ly.dw_w), dw_b=dev(ly.dw_b),
+    a = block_args(B, T, ff, x=xd, glu=dev(glu.to(BF)), enc_out=out, enc_act=act, pw2=dev(pack_k_units(ly.pw2).to(BF)),
+                   ff_w1=dev(pack_k_units(ly.ff_w1).to(BF)), ff_w2=dev(pack_w2(ly.ff_w2).to(BF)), dw_w=dev(ly.dw_w), dw_b=dev(ly.dw_b),
                    tlens=dev(torch.tensor(tl, dtype=torch.int32)) if masked else None,
                    params=dev(torch.cat(ly.d_groups() + [group(ag, ab), torch.zeros(G)])))
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_D | L.EM_BLOCK_FINAL, a, L.current_stream_ptr()), "block<D|F>")
@@ -255,9 +255,9 @@ def test_block_da(lib, B, T, ff):
     xd = dev(x0.clone())
     qh, kh = (torch.zeros(B, H, Tp, 64, dtype=BF, device="cuda") for _ in range(2))
     vt = torch.zeros(B, H, 64, Tp, dtype=BF, device="cuda")
-    a = block_args(B, T, ff, x=xd, glu=dev(glu.to(BF)), qh=qh, kh=kh, vt=vt, pw2=dev(l0.pw2.to(BF)),
-                   ff_w1=dev(l0.ff_w1.to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
-                   ffm_w1=dev(l1.ffm_w1.to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(l1.wqkv.to(BF)),
+    a = block_args(B, T, ff, x=xd, glu=dev(glu.to(BF)), qh=qh, kh=kh, vt=vt, pw2=dev(pack_k_units(l0.pw2).to(BF)),
+                   ff_w1=dev(pack_k_units(l0.ff_w1).to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
+                   ffm_w1=dev(pack_k_units(l1.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(pack_k_units(l1.wqkv).to(BF)),
                    params=dev(torch.cat(l0.d_groups() + l1.a_groups())))
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_D | L.EM_BLOCK_A, a, L.current_stream_ptr()), "block<D|A>")
     assert_close(xd, x_ref, 6e-3, "block<D|A> x")
@@ -288,9 +288,9 @@ def test_block_repeatable_under_load(lib):
     vt = torch.zeros(B, H, 64, Tp, dtype=BF, device="cuda")
     xd = dev(x0.clone())
     x0d = dev(x0)
-    a = block_args(B, T, ff, x=xd, glu=glu, qh=qh, kh=kh, vt=vt, pw2=dev(l0.pw2.to(BF)),
-                   ff_w1=dev(l0.ff_w1.to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
-                   ffm_w1=dev(l1.ffm_w1.to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(l1.wqkv.to(BF)),
+    a = block_args(B, T, ff, x=xd, glu=glu, qh=qh, kh=kh, vt=vt, pw2=dev(pack_k_units(l0.pw2).to(BF)),
+                   ff_w1=dev(pack_k_units(l0.ff_w1).to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
+                   ffm_w1=dev(pack_k_units(l1.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(pack_k_units(l1.wqkv).to(BF)),
                    params=dev(torch.cat(l0.d_groups() + l1.a_groups())))
     first = None
     for it in range(20):
