@@ -63,7 +63,7 @@ constexpr int PAR_FLOATS = EM_BLOCK_PARAM_GROUP;
 constexpr int PAR_BYTES = PAR_FLOATS * 4;
 constexpr int MAX_GROUPS = 4;
 constexpr int TOUCH_OFF = PAR_OFF + MAX_GROUPS * PAR_BYTES;  // 1 KiB: where the L2 warm-up's LDS-DMA lands (never read)
-constexpr int SMEM_BYTES = TOUCH_OFF + 1024 + 64;  // 80 KiB
+constexpr int SMEM_BYTES = TOUCH_OFF + 1024;  // 80 KiB
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile
 
 // what a barrier is for (documentation only since the loader waves are gone)
@@ -84,10 +84,6 @@ constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;
 #endif
 
 #define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-// L2 warm-up bookkeeping: workgroups that arrived on each XCC so far (all launches; one counter per 128-byte line).
-// A workgroup's arrival number modulo the launch's workgroups per XCC is its share of the weight list.
-__device__ unsigned g_xcc_arrivals[8 * 32];
 
 template <int MODE>
 __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long long* __restrict__ stamps) {
@@ -123,15 +119,6 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   const int nch = a.ff >> 6;  // 64-wide chunks of the FFN hidden dimension
   // developer profiling (EM_BLOCK_STAMPS / EM_BLOCK_DBG, tools/block_bench.py): stage-level cycle stamps of thread 0
   // of workgroup (0, 0); dbg 1 = no MFMA / epilogue work, dbg 2 = no DMA
-  // L2 warm-up (see touch()): which XCC is this, and the how-manyth workgroup on it?  Asked first of all (the answer
-  // is needed after the first barrier) by one lane; HW_REG_XCC_ID rather than "workgroup id % 8": the dispatch
-  // order is a property of the driver configuration, and a share computed for the wrong XCD warms the wrong L2.
-  unsigned* const touch_slot = (unsigned*)(smem + TOUCH_OFF + 1024);
-  unsigned my_arrival = 0;
-  if (tid == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // HW_REG_XCC_ID
-    my_arrival = __hip_atomic_fetch_add(&g_xcc_arrivals[xcc * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   int nts = 0;
   auto stamp = [&]() {
     if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nts < 64) stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
@@ -288,17 +275,16 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // flight per wave then bound the stream at ~48 GB/s per CU where L2 hits run at the 128 GB/s ingest limit.  So
   // the workgroups of an XCD share out the launch's weights in 8 KiB chunks (64 lines: one wave-wide dword load,
   // a lane per line) and touch them all while the prologue's own global loads are in flight; the weights are in
-  // the XCD's L2 by the time the streams ask for them.  Called after the first barrier of the launch (publish_arrival()
-  // before it).
+  // the XCD's L2 by the time the streams ask for them.  XCD of a workgroup = linear id % 8 (dispatch order).
   constexpr int MAXT = 16;  // chunks per wave at most: small grids warm what they can
   auto touch = [&]() {
 #ifdef EM_BLOCK_NO_TOUCH
     return;
 #endif
-    const int nwg = gridDim.x * gridDim.y;
-    const int per_xcc = (nwg + 7) >> 3;                      // workgroups of this launch on an XCC (balanced dispatch)
-    const int nworker = per_xcc * 4;                         // their waves
-    const int worker = (int)(__builtin_amdgcn_readfirstlane(*touch_slot) % (unsigned)per_xcc) * 4 + wave;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+    const int xcd = wg & 7;
+    const int nworker = ((nwg - 1 - xcd) / 8 + 1) * 4;      // waves of this XCD
+    const int worker = (wg >> 3) * 4 + wave;
     const unsigned dst = TOUCH_OFF + wave * 256;
     const int loff = lane * 128;
     int total = (HAS_C ? 48 : 0) + (HAS_D ? 16 + 8 * nch : 0) + (HAS_A ? 48 + 8 * nch : 0);  // 8 KiB chunks of the launch
@@ -345,9 +331,6 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     }
   };
   auto touch_done = [&]() {};
-  auto publish_arrival = [&]() {
-    if (tid == 0) *touch_slot = my_arrival;
-  };
 
   // 16 MFMAs of a K unit: out[mi] = C^T[n = nf*16 + lg*4 + r][m = mi*16 + lr]
   // (swap: C[m = mi*16 + lg*4 + r][n = nf*16 + lr])
@@ -561,9 +544,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     }
     k_pre(a.wout, 4);
     load_x();
-    publish_arrival();
-    bar(0);  // the parameter groups are in LDS
     touch();
+    bar(0);  // the parameter groups are in LDS
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
     proj_resid(pb0, 0, a.wout);
     store_x();
@@ -614,14 +596,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     for (int k = 0; k < KW; ++k) wk[k] = a.dw_w[k * D + tid];
     const float bc = a.dw_b[tid];
     load_x();
-    publish_arrival();
+    touch();
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int q = tid + it * NC, t = t0 - HALF + (q >> 5);
       if (q < TROWS * 32) *(uint4*)(tile + q * 16) = (t >= 0 && t < Tv) ? stage[it] : make_uint4(0u, 0u, 0u, 0u);
     }
     bar(BAR_TILE);
-    touch();
     {
       const bf16* col = (const bf16*)tile + tid;
       const int kt = tid >> 6, kl = tid & 63;
@@ -779,9 +760,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     const float* const pa0 = HAS_D ? pb2 : pb0;  // GA
     const float* const pa1 = HAS_D ? pb3 : pb1;  // GA + 1
     ffn_pre(a.ffm_w1, a.ffm_w2);
-    if (!HAS_D) publish_arrival();
-    ln_to_act(pa0, 0, 256, 0);
     if (!HAS_D) touch();
+    ln_to_act(pa0, 0, 256, 0);
     stamp();  // 6 norm_ff_macaron
     ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2); // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
     stamp();  // 7 macaron FFN
