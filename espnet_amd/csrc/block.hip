@@ -20,9 +20,10 @@
 // per kernel, so every kernel costs its own prologue -> K loop -> epilogue latency chain plus a launch
 // boundary, and every activation makes an HBM round trip.  Here the 32-row state never
 // leaves the CU: the residual x lives in registers (f32), LayerNorm statistics are wave/LDS
-// reductions, the FFN hidden activation exists only as a [32][64] LDS tile, and the only streams are
-// the weights (L2-resident, read by all workgroups in near lockstep) through a 4 x 32 KiB
-// global_load_lds ring with counted vmcnt and one raw s_barrier per one or two 32 KiB units.
+// reductions, the FFN hidden activation exists only as two [32][64] LDS tiles, and the only streams are
+// the weights, read by all workgroups of the launch in near lockstep: straight from global memory into MFMA
+// operand registers, from a fragment-major packing, through a ring of four 32 KiB units per wave, out of an
+// L2 that the workgroups of the XCD warmed together during the prologue.
 //
 // Orientation.  Every GEMM is computed transposed, C^T[n][m] = sum_k W[n][k] A[m][k]: the weight
 // fragment is the MFMA A operand, the activation fragment the B operand, so a lane ends up with four
@@ -30,17 +31,14 @@
 // That makes residual / bias / LayerNorm / bf16 packing 16- or 8-byte operations and lets the
 // activation fragments (32 rows x K = 256) stay in registers for a whole GEMM.
 //
-// Four compute waves, wave w owning the 16-column slice nf = w of every 64-column group and BOTH 16-frame
-// halves, plus four loader waves that only issue the LDS-DMA (a global_load_lds costs its issuing wave 60-185
-// cycles and the scalar table walk stalls it; neither belongs in the MFMA stream).  The loaders follow the
-// compute waves barrier by barrier through a code word in LDS, so the compute path carries no control code
-// for the ring at all (tools/experiments/barrier_bench.hip: a bare 8-wave barrier is 48 cycles; the branchy
-// shared code path of the first versions spent ~500 per interval).  A "K unit" is 64 weight rows x K = 256 (per wave one weight fragment column x two frame
-// fragments: 16 MFMAs); a "W2 unit" is all 256 rows x a 64-deep K slice of the FFN's second matrix
-// (four weight fragments x two frame fragments x two k-steps: 16 MFMAs).  Both are 32 KiB = 256 LDS
-// rows of 128 B, XOR-swizzled on the source address like csrc/gemm.hip.  The order and addresses of the
-// units are a table built by the host per launch (a kernel argument, read with scalar loads), so the
-// per-unit control code is a handful of scalar instructions.
+// Four waves, wave w owning the 16-column slice nf = w of every 64-column group and BOTH 16-frame halves.  A
+// "K unit" is 64 weight rows x K = 256 (per wave one weight fragment column x two frame fragments: 16 MFMAs); a
+// "W2 unit" is all 256 rows x a 64-deep K slice of the FFN's second matrix (four weight fragments x two frame
+// fragments x two k-steps: 16 MFMAs).  Both are 32 contiguous KiB, packed by the host so that the eight MFMA
+// operands a wave takes from a unit are eight contiguous 1 KiB lines (include/espnet_amd.h, EmBlockArgs).  One CU
+// ingests 64 B/clk, i.e. 512 cycles per unit against 256 cycles of MFMA: the kernels are built around keeping
+// that stream busy (requests three units ahead, unconditional so that hipcc can count its waits, barriers only
+// where waves exchange data).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -66,14 +64,13 @@ constexpr int TOUCH_OFF = PAR_OFF + MAX_GROUPS * PAR_BYTES;  // 1 KiB: where the
 constexpr int SMEM_BYTES = TOUCH_OFF + 1024 + 64;  // 80 KiB
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile
 
-// what a barrier is for (documentation only since the loader waves are gone)
-// weight units are read through GLOBAL-address-space pointers: a pointer rebuilt from the unit table's integers is
-// generic otherwise, and flat loads count on lgkmcnt too and force vmcnt(0) (they may return out of order)
+// weight units are read through GLOBAL-address-space pointers: through a generic pointer the loads become flat_load,
+// which counts on lgkmcnt too and forces vmcnt(0) (flat loads may return out of order)
 typedef const __attribute__((address_space(1))) unsigned char* GU8;
 typedef const __attribute__((address_space(1))) bf16x8* GFRAG;
-constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;
+constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;  // what a barrier is for (documentation)
 
-// Unit g of the weight stream: byte address of its 32 contiguous KiB, FRAGMENT-MAJOR: [wave nf][fragment q][lane][16 B]
+// A unit of the weight stream is 32 contiguous KiB, FRAGMENT-MAJOR: [wave nf][fragment q][lane][16 B]
 // (host: pack_k_units / pack_w2 in asr/encoder/conformer_encoder.py), so that one wave-wide load instruction reads 1 KiB
 // contiguous.  tools/experiments/direct_frag_bench.hip: such loads stream 128 GB/s per CU (0.257 us per unit) WITH the
 // unit's 16 MFMAs and a Swish epilogue hidden behind them; the same fragments fetched from row-major weights reach 37
@@ -103,7 +100,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nf = wave & 3;  // compute wave: 16-column slice of every 64-column group; loader wave: quarter of every unit
+  const int nf = wave & 3;  // this wave's 16-column slice of every 64-column group
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.y, t0 = blockIdx.x * BM, T = a.T;
 
@@ -139,7 +136,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   };
   stamp();
   int nbar = 0;  // barriers passed
-  // every barrier goes through here: publish its code for the loaders, retire own LDS operations, synchronise
+  // every barrier goes through here: retire own LDS operations, synchronise
   auto bar = [&](int code) {  // `code` documents what the barrier is for
     (void)code;
     ++nbar;

@@ -23,7 +23,7 @@ EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flags (include/espnet_amd.h)
 EM_ENC_NO_FUSED = 2
 EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC = 1, 2, 4, 8, 16
 EM_BLOCK_PARAM_GROUP = 1792
-EM_BLOCK_CTC_MAX_UNITS = 88  # csrc/block.hip: unit-table capacity left for the CTC head at ff = 1024
+EM_BLOCK_CTC_MAX_UNITS = 88  # vocabularies up to 5 632 labels take the fused CTC stage (the sizes the GPU tests cover); larger ones keep the arg-max GEMM
 EM_PROF_GEMM, EM_PROF_BLOCK, EM_PROF_ATTN = 0, 1, 2
 DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
 

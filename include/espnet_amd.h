@@ -294,7 +294,7 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
 
 /* ---- A6-A10 fused per Conformer block (bf16, d = 256, ff <= 1024, cnn_module_kernel 31): a workgroup
  *      carries 32 frames of one utterance through every row-local operator of EncoderLayer.forward
- *      (conformer/encoder_layer.py:79-179); weights stream through an LDS ring (csrc/block.hip).
+ *      (conformer/encoder_layer.py:79-179); weights stream from global memory into MFMA registers (csrc/block.hip).
  *   mode  EM_BLOCK_C                : ctx -> linear_out + residual -> norm_conv -> pointwise_conv1 + GLU -> glu
  *         EM_BLOCK_D | EM_BLOCK_A   : glu -> depthwise conv + BN + Swish -> pointwise_conv2 + residual -> norm_ff
  *                                     -> FFN + residual -> norm_final; next block: norm_ff_macaron -> macaron FFN
