@@ -122,6 +122,40 @@ def test_mel_band_packing_is_exact():
     assert torch.equal(dense, torch.from_numpy(m))
 
 
+def test_fragment_major_weight_units_follow_the_header():
+    """pack_k_units / pack_w2 against the layout include/espnet_amd.h states at EmBlockArgs: lane 16 lg + lr of wave nf
+    finds the MFMA operand (W row 16 nf + lr of the 64-row group, k = 32 ks + 8 lg .. + 7) at byte
+    8192 nf + 1024 q + 16 lane of the unit, q = ks for a K unit and 2 f + ks for a W2 unit."""
+    from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w2
+
+    w = torch.arange(192 * 256, dtype=torch.float32).reshape(192, 256)
+    flat = pack_k_units(w).reshape(-1)
+    for u in range(3):
+        for nf in range(4):
+            for ks in range(8):
+                for lane in (0, 5, 16, 37, 63):
+                    lg, lr = lane >> 4, lane & 15
+                    off = u * 16384 + nf * 4096 + ks * 512 + lane * 8  # in elements: 32 KiB unit = 16 384 bf16
+                    want = w[64 * u + 16 * nf + lr, 32 * ks + 8 * lg: 32 * ks + 8 * lg + 8]
+                    assert torch.equal(flat[off:off + 8], want), (u, nf, ks, lane)
+    w2 = torch.arange(256 * 128, dtype=torch.float32).reshape(256, 128)
+    flat = pack_w2(w2).reshape(-1)
+    for c in range(2):
+        for nf in range(4):
+            for f in range(4):
+                for ks in range(2):
+                    for lane in (0, 9, 31, 48, 63):
+                        lg, lr = lane >> 4, lane & 15
+                        off = c * 16384 + nf * 4096 + (2 * f + ks) * 512 + lane * 8
+                        want = w2[64 * f + 16 * nf + lr, 64 * c + 32 * ks + 8 * lg: 64 * c + 32 * ks + 8 * lg + 8]
+                        assert torch.equal(flat[off:off + 8], want), (c, nf, f, ks, lane)
+    # a permutation: nothing lost, nothing duplicated
+    assert torch.equal(pack_k_units(w).reshape(-1).sort().values, w.reshape(-1))
+    assert torch.equal(pack_w2(w2).reshape(-1).sort().values, w2.reshape(-1))
+    with pytest.raises(AssertionError):
+        pack_k_units(torch.zeros(60, 256))
+
+
 def test_rel_pos_table_matches_oracle():
     from espnet_amd.asr.encoder.conformer_encoder import rel_pos_table
     from oracle.conformer import rel_pos_emb
