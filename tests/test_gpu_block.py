@@ -188,7 +188,7 @@ def split_heads(buf, B, T):
     return buf[:, :, :T].permute(0, 2, 1, 3).reshape(B * T, D)
 
 
-SHAPES = [(2, 249, 1024), (3, 70, 256), (1, 32, 1024), (2, 31, 64)]
+SHAPES = [(2, 249, 1024), (3, 70, 256), (1, 32, 1024), (2, 31, 64), (1, 40, 192), (2, 100, 576)]  # ff / 64 even, 1, odd
 
 
 @pytest.mark.parametrize("B,T,ff", SHAPES)
