@@ -1,0 +1,19 @@
+#!/bin/bash
+# Developer builds of csrc/block.hip next to the product library, selected with ESPNET_AMD_LIB=... (espnet_amd/lib.py):
+#   espnet_amd/lib/dbg/lib_nt.so   -DEM_BLOCK_NO_TOUCH   (no L2 warm-up)
+#   espnet_amd/lib/dbg/lib_<d>.so  -DEM_BLOCK_DBG=<d>    (1 no MFMA / epilogue, 4 no FFN barrier, 8 no H exchange, 16 no Swish)
+# Used by tools/r02_call8.sh, r02_call9.sh, r02_call11.sh, r02_call12.sh (profiles/r02l, r02m, r02o, r02q).  Wrong results by
+# design: timing only.   usage: bash tools/build_block_variants.sh nt 4 8 12 28
+set -eu
+cd "$(dirname "$0")/.."
+python -m espnet_amd.build >/dev/null
+mkdir -p espnet_amd/lib/dbg
+objs=$(ls espnet_amd/lib/*.o | grep -v "/block.o")
+for v in "$@"; do
+  def="-DEM_BLOCK_DBG=$v"
+  [ "$v" = nt ] && def="-DEM_BLOCK_NO_TOUCH=1"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form \
+    $def -Iinclude -Iespnet_amd/csrc -c espnet_amd/csrc/block.hip -o espnet_amd/lib/dbg/block_$v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o espnet_amd/lib/dbg/lib_$v.so $objs espnet_amd/lib/dbg/block_$v.o
+  echo "built espnet_amd/lib/dbg/lib_$v.so"
+done
