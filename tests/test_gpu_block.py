@@ -277,8 +277,9 @@ def test_block_fused_rejects_outside_its_shapes(lib):
 
 
 def test_block_repeatable_under_load(lib):
-    """The weight ring hands LDS-DMA data between waves by counted vmcnt + barriers: run the D|A kernel
-    many times back to back at the bench shape and require bit-identical outputs (a read that raced its DMA
+    """The weight stream runs three units ahead of the MFMAs on counted vmcnt waits, the H tiles and LayerNorm partials
+    change hands between waves at barriers, and the L2 warm-up's share depends on arrival order: run the D|A kernel
+    many times back to back at the bench shape and require bit-identical outputs (a read that raced its producer
     would show up as run-to-run differences)."""
     B, T, ff = 32, 249, 1024
     l0, l1 = Layer(600, ff), Layer(700, ff)
