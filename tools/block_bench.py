@@ -17,10 +17,27 @@ from espnet_amd import lib as L  # noqa: E402
 from tests.test_gpu_block import BF, D, G, H, Layer, block_args, group, rnd, tpad  # noqa: E402
 
 
+_COLD = None  # --cold: a buffer streamed through the L2s between the timed launches
+
+
 def timeit(fn, iters):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
+    if _COLD is not None:
+        # in the encoder a block kernel finds its weights in no L2 (36 MB of weights pass through 8 x 4 MB); back to
+        # back in this tool they stay resident.  Cold mode evicts them before every launch and times the launches
+        # one by one (events on torch's stream = the launch stream).
+        tot = 0.0
+        for _ in range(iters):
+            _COLD.add_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot * 1e3 / iters
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -36,7 +53,12 @@ def main():
     ap.add_argument("--T", type=int, default=249)
     ap.add_argument("--ff", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--cold", action="store_true", help="evict the L2s before every timed launch (in-situ conditions; "
+                                                         "single-launch event timing adds a few us)")
     args = ap.parse_args()
+    if args.cold:
+        global _COLD
+        _COLD = torch.zeros(96 * 1024 * 1024, device="cuda")  # 384 MB: past the 256 MB Infinity Cache too
     B, T, ff = args.B, args.T, args.ff
     lib = L.load()
     sp = L.current_stream_ptr
