@@ -53,8 +53,8 @@ def main():
     ap.add_argument("--T", type=int, default=249)
     ap.add_argument("--ff", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--cold", action="store_true", help="evict the L2s before every timed launch (in-situ conditions; "
-                                                         "single-launch event timing adds a few us)")
+    ap.add_argument("--cold", action="store_true", help="evict the L2s before every timed launch, one launch per measurement (NOT a proxy for the "
+                                                         "encoder's launch sequence: profiles/r02y vs r02m)")
     args = ap.parse_args()
     if args.cold:
         global _COLD
