@@ -53,12 +53,14 @@ def main():
     ap.add_argument("--T", type=int, default=249)
     ap.add_argument("--ff", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--cold-mb", type=int, default=48, help="size of the eviction buffer: 48 MB clears the L2s and leaves the "
+                    "weights in the 256 MB Infinity Cache, 384 MB clears that too (the encoder streams > 1 GB per step)")
     ap.add_argument("--cold", action="store_true", help="evict the L2s before every timed launch, one launch per measurement (NOT a proxy for the "
                                                          "encoder's launch sequence: profiles/r02y vs r02m)")
     args = ap.parse_args()
     if args.cold:
         global _COLD
-        _COLD = torch.zeros(12 * 1024 * 1024, device="cuda")  # 48 MB read + written: 6 MB through each 4 MB L2, the Infinity Cache keeps the weights (as in the encoder)
+        _COLD = torch.zeros(args.cold_mb * 256 * 1024, device="cuda")  # read + written before every launch
     B, T, ff = args.B, args.T, args.ff
     lib = L.load()
     sp = L.current_stream_ptr
