@@ -142,21 +142,13 @@ def rel_pos_table(T: int, d: int) -> torch.Tensor:
 class ConformerEncoder(torch.nn.Module):
     _WS_FN, _ENC_FN = "em_conformer_workspace_bytes", "em_conformer_encode"  # C-ABI entry points of forward_device
 
-    def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4,
-                 linear_units: int = 2048, num_blocks: int = 6, dropout_rate: float = 0.1,
-                 positional_dropout_rate: float = 0.1, attention_dropout_rate: float = 0.0,
-                 input_layer: Optional[str] = "conv2d", normalize_before: bool = True,
-                 concat_after: bool = False, positionwise_layer_type: str = "linear",
-                 positionwise_conv_kernel_size: int = 3, macaron_style: bool = False,
-                 rel_pos_type: str = "legacy", pos_enc_layer_type: str = "rel_pos",
-                 selfattention_layer_type: str = "rel_selfattn", activation_type: str = "swish",
-                 use_cnn_module: bool = True, zero_triu: bool = False, cnn_module_kernel: int = 31,
-                 padding_idx: int = -1, interctc_layer_idx: List[int] = [],
-                 interctc_use_conditioning: bool = False, ctc_trim: bool = False,
-                 stochastic_depth_rate=0.0, layer_drop_rate: float = 0.0,
-                 max_pos_emb_len: int = 5000, qk_norm: bool = False, use_flash_attn: bool = True,
-                 compute_dtype: str = "bfloat16"):
-        super().__init__()
+    @staticmethod
+    def _option_check(*, input_layer, normalize_before, concat_after, positionwise_layer_type, macaron_style,
+                      rel_pos_type, pos_enc_layer_type, selfattention_layer_type, activation_type, use_cnn_module,
+                      zero_triu, interctc_layer_idx, interctc_use_conditioning, ctc_trim, qk_norm, output_size,
+                      attention_heads, linear_units, cnn_module_kernel):
+        """Options of espnet2/asr/encoder/conformer_encoder.py:89-121 that the MI355X kernels do not cover ->
+        (list of "name=value" strings, legacy rel-pos flag).  An empty list = the fast path applies."""
         bad = []
         if input_layer not in SUBSAMPLING_CONVS: bad.append(f"input_layer={input_layer}")
         if not normalize_before: bad.append("normalize_before=False")
@@ -182,6 +174,46 @@ class ConformerEncoder(torch.nn.Module):
         if output_size % 64 or output_size // attention_heads != 64: bad.append("d_k != 64")
         if linear_units % 64: bad.append("linear_units % 64 != 0")
         if cnn_module_kernel not in (3, 7, 15, 31): bad.append(f"cnn_module_kernel={cnn_module_kernel}")
+        return bad, legacy
+
+    @classmethod
+    def unsupported_options(cls, *args, **kwargs) -> List[str]:
+        """The constructor arguments (positional or keyword, reference defaults applied) that fall outside the fast
+        path, without building anything: what `espnet_amd.integration.espnet2_adapters` consults to hand such a
+        configuration to the stock espnet2 class under the same yaml name."""
+        import inspect
+
+        ba = inspect.signature(cls.__init__).bind(None, *args, **kwargs)
+        ba.apply_defaults()
+        names = inspect.signature(cls._option_check).parameters
+        try:
+            return cls._option_check(**{k: ba.arguments[k] for k in names})[0]
+        except ValueError as e:
+            return [str(e)]
+
+    def __init__(self, input_size: int, output_size: int = 256, attention_heads: int = 4,
+                 linear_units: int = 2048, num_blocks: int = 6, dropout_rate: float = 0.1,
+                 positional_dropout_rate: float = 0.1, attention_dropout_rate: float = 0.0,
+                 input_layer: Optional[str] = "conv2d", normalize_before: bool = True,
+                 concat_after: bool = False, positionwise_layer_type: str = "linear",
+                 positionwise_conv_kernel_size: int = 3, macaron_style: bool = False,
+                 rel_pos_type: str = "legacy", pos_enc_layer_type: str = "rel_pos",
+                 selfattention_layer_type: str = "rel_selfattn", activation_type: str = "swish",
+                 use_cnn_module: bool = True, zero_triu: bool = False, cnn_module_kernel: int = 31,
+                 padding_idx: int = -1, interctc_layer_idx: List[int] = [],
+                 interctc_use_conditioning: bool = False, ctc_trim: bool = False,
+                 stochastic_depth_rate=0.0, layer_drop_rate: float = 0.0,
+                 max_pos_emb_len: int = 5000, qk_norm: bool = False, use_flash_attn: bool = True,
+                 compute_dtype: str = "bfloat16"):
+        super().__init__()
+        bad, legacy = self._option_check(
+            input_layer=input_layer, normalize_before=normalize_before, concat_after=concat_after,
+            positionwise_layer_type=positionwise_layer_type, macaron_style=macaron_style, rel_pos_type=rel_pos_type,
+            pos_enc_layer_type=pos_enc_layer_type, selfattention_layer_type=selfattention_layer_type,
+            activation_type=activation_type, use_cnn_module=use_cnn_module, zero_triu=zero_triu,
+            interctc_layer_idx=interctc_layer_idx, interctc_use_conditioning=interctc_use_conditioning,
+            ctc_trim=ctc_trim, qk_norm=qk_norm, output_size=output_size, attention_heads=attention_heads,
+            linear_units=linear_units, cnn_module_kernel=cnn_module_kernel)
         if bad:
             raise NotImplementedError("outside the MI355X Conformer fast path: " + ", ".join(bad))
         self._output_size = output_size
@@ -474,18 +506,27 @@ class ConformerEncoder(torch.nn.Module):
         enc_out = torch.empty(B, T, d, dtype=torch.float32, device=dev)
         enc_act = torch.empty(B, T, d, dtype=self.act_dtype, device=dev)
         # the fused path also hands back the CTC head's per-frame arg-max (EM_BLOCK_CTC): no logits, no second pass
+        # (whether they WILL be written is the library's decision, asked through em_conformer_encode_plan: the host does
+        # not re-derive the kernel's shape conditions)
         self.last_ctc_ids = None
-        if getattr(pk["w"], "ctc_units", 0) > 0 and _fused_enabled(self):
-            self.last_ctc_ids = torch.empty(B, T, dtype=torch.int32, device=dev)
-            pk["w"].ctc_ids = self.last_ctc_ids.data_ptr()
-        elif hasattr(pk["w"], "ctc_ids"):
+        enc_flags = (L.EM_ENC_ISOLATE_UTTS if isolate else 0) | (0 if _fused_enabled(self) else L.EM_ENC_NO_FUSED)
+        if hasattr(pk["w"], "ctc_ids"):
             pk["w"].ctc_ids = None
+            if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "ctc_units", 0) > 0:
+                ids = torch.empty(B, T, dtype=torch.int32, device=dev)
+                pk["w"].ctc_ids = ids.data_ptr()
+                plan = lib.em_conformer_encode_plan(self.em_dtype, C.byref(pk["w"]), enc_flags)
+                if plan < 0:
+                    L.check(plan, "em_conformer_encode_plan")
+                if plan & L.EM_ENC_PLAN_CTC_IDS:
+                    self.last_ctc_ids = ids
+                else:
+                    pk["w"].ctc_ids = None
         rc = getattr(lib, self._ENC_FN)(
             self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
             L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(ws),
             ws.numel(), L.ptr(enc_out), L.ptr(enc_act),
-            (L.EM_ENC_ISOLATE_UTTS if isolate else 0) | (0 if _fused_enabled(self) else L.EM_ENC_NO_FUSED),
-            L.current_stream_ptr())
+            enc_flags, L.current_stream_ptr())
         L.check(rc, self._ENC_FN)
         return enc_out, enc_act, olens, olens_dev
 

@@ -416,10 +416,19 @@ def _multi_gpu_worker(rank: int, world: int, port: int, kw: dict, q):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     try:
-        q.put((rank, _inference_rank(kw)))
-    finally:
-        dist.barrier()
-        dist.destroy_process_group()
+        res = _inference_rank(kw)
+    except BaseException as e:  # tell the parent, then leave WITHOUT a collective: the peers are not in a matching one
+        import traceback
+
+        q.put((rank, RuntimeError(f"rank {rank}: {type(e).__name__}: {e}\n{traceback.format_exc()}")))
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        raise SystemExit(1)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _inference_rank(kw: dict):
@@ -442,6 +451,42 @@ def _inference_rank(kw: dict):
 
     hyps, st = sharded_decode_rank(decode_slab, keys, kw["output_dir"], nbest, 4096, torch.device("cuda"))
     return dict(st, utterances_total=len(hyps))
+
+
+def _collect_ranks(procs, q, poll_s: float = 0.5):
+    """One result per rank process from `q`, or an exception: a rank that reports a failure or dies without
+    reporting (killed, out of memory in native code) ends the whole job - the surviving ranks are terminated
+    instead of being left inside a collective nobody will complete (the reference's split-job flow surfaces a
+    failed job the same way, asr.sh:1636-1648)."""
+    import queue as _queue
+
+    res, err = {}, None
+    while len(res) < len(procs) and err is None:
+        try:
+            rank, r = q.get(timeout=poll_s)
+        except _queue.Empty:
+            dead = [i for i, p in enumerate(procs) if p.exitcode not in (None, 0) and i not in res]
+            if dead:
+                err = RuntimeError(f"rank process {dead[0]} exited with {procs[dead[0]].exitcode} before reporting")
+            elif all(p.exitcode is not None for p in procs) and q.empty():
+                err = RuntimeError("rank processes exited without reporting a result")
+            continue
+        if isinstance(r, BaseException):
+            err = r
+        else:
+            res[rank] = r
+    if err is not None:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+        raise RuntimeError(f"--ngpu {len(procs)}: {err}") from (err if isinstance(err, BaseException) else None)
+    for p in procs:
+        p.join()
+        if p.exitcode != 0:
+            raise RuntimeError(f"rank process exited with {p.exitcode}")
+    return res
 
 
 def inference_multi_gpu(ngpu: int, **kw):
@@ -476,11 +521,7 @@ def inference_multi_gpu(ngpu: int, **kw):
     procs = [ctx.Process(target=_multi_gpu_worker, args=(r, ngpu, port, kw, q)) for r in range(ngpu)]
     for p in procs:
         p.start()
-    res = dict(q.get() for _ in procs)
-    for p in procs:
-        p.join()
-        if p.exitcode != 0:
-            raise RuntimeError(f"rank process exited with {p.exitcode}")
+    res = _collect_ranks(procs, q)
     audio = sum(r.get("audio_seconds", 0.0) for r in res.values())
     wall = max(r.get("wall_seconds", 0.0) for r in res.values())
     return dict(utterances=sum(r.get("utterances", 0) for r in res.values()), audio_seconds=audio, wall_seconds=wall,

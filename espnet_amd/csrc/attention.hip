@@ -266,9 +266,8 @@ template <typename T, bool LEGACY>
 int launch_attn(const void* qkv, const void* p, int ldp, const float* pu, const float* pv,
                 const int* klens, int B, int Tn, int h, void* ctx, hipStream_t s) {
   const size_t lds = AttnLds<T, LEGACY>::bytes;
-  hipError_t e = hipFuncSetAttribute((const void*)relpos_attn_kernel<T, LEGACY>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return EM_ERR_LAUNCH;
+  static EmLdsCap cap = {};
+  if (em_raise_lds_cap((const void*)relpos_attn_kernel<T, LEGACY>, lds, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(Tn, QT), h, B);
   hipLaunchKernelGGL((relpos_attn_kernel<T, LEGACY>), grid, dim3(256), lds, s, (const T*)qkv, (const T*)p,
                      ldp, pu, pv, klens, Tn, h, (T*)ctx);

@@ -227,13 +227,8 @@ extern "C" int em_relpos_attention2_bf16(const void* qh, const void* kh, const v
   if (!qh || !kh || !vt || !p || !pos_u || !pos_v || !klens || !ctx) return EM_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || h <= 0) return EM_ERR_BAD_ARG;
   if (Tpad % KSUP != 0 || Tpad < T || ldp % 8 != 0) return EM_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)relpos_attn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            SMEM_BYTES) != hipSuccess)
-      return EM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static EmLdsCap cap = {};
+  if (em_raise_lds_cap((const void*)relpos_attn2_kernel, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(T, QB), h, B);
   const bool rec = em_prof_begin(stream);
   hipLaunchKernelGGL(relpos_attn2_kernel, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,

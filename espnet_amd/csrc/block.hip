@@ -82,8 +82,13 @@ constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;  // what
 
 #define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-// L2 warm-up bookkeeping: workgroups that arrived on each XCC so far (all launches; one counter per 128-byte line).
-// A workgroup's arrival number modulo the launch's workgroups per XCC is its share of the weight list.
+// L2 warm-up bookkeeping: workgroups of the RUNNING launch that have arrived on each XCC (one counter per 128-byte
+// line).  Every workgroup adds one on entry and takes it back on exit (leave_xcc()), so the counters are zero again at
+// every kernel boundary and a workgroup's arrival number IS its index among the launch's workgroups on that XCC: its
+// share of the weight list.  (Round 2 let the counters run on across launches and took the number modulo the launch's
+// workgroups per XCC: right only while every launch puts exactly 1/8 of its workgroups on each XCC.)  Grids larger
+// than one residency round hand out some shares twice - by then the list is warm; launches overlapping on two streams
+// mix their numbers: the warm-up is a performance hint, never a correctness matter.
 __device__ unsigned g_xcc_arrivals[8 * 32];
 
 template <int MODE>
@@ -124,10 +129,10 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // is needed after the first barrier) by one lane; HW_REG_XCC_ID rather than "workgroup id % 8": the dispatch
   // order is a property of the driver configuration, and a share computed for the wrong XCD warms the wrong L2.
   unsigned* const touch_slot = (unsigned*)(smem + TOUCH_OFF + 1024);
-  unsigned my_arrival = 0;
+  unsigned my_arrival = 0, my_xcc = 0;
   if (tid == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // HW_REG_XCC_ID
-    my_arrival = __hip_atomic_fetch_add(&g_xcc_arrivals[xcc * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // HW_REG_XCC_ID
+    my_arrival = __hip_atomic_fetch_add(&g_xcc_arrivals[my_xcc * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   int nts = 0;
   auto stamp = [&]() {
@@ -341,7 +346,10 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           : "memory");
     }
   };
-  auto touch_done = [&]() {};
+  // every exit of the kernel: give the arrival back (no return value: fire and forget)
+  auto touch_done = [&]() {
+    if (tid == 0) __hip_atomic_fetch_add(&g_xcc_arrivals[my_xcc * 32], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   auto publish_arrival = [&]() {
     if (tid == 0) *touch_slot = my_arrival;
   };
@@ -819,13 +827,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 
 template <int MODE>
 int launch_block(const EmBlockArgs* a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)block_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            SMEM_BYTES) != hipSuccess)
-      return EM_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static EmLdsCap cap = {};
+  if (em_raise_lds_cap((const void*)block_kernel<MODE>, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(a->T, BM), a->B);
   static long long* stamps = nullptr;
   static const bool want_stamps = getenv("EM_BLOCK_STAMPS") != nullptr;

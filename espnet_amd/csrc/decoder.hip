@@ -396,25 +396,15 @@ int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, c
   // not fit the 160 KB of a CU -- say so instead of failing at launch
   if (lds > 160 * 1024) return EM_ERR_UNSUPPORTED;
   dim3 grid(heads, B, em_cdiv(W, 16));
-  // (the attribute is raised once per process and size: no runtime API call on later launches,
+  // (the attribute is raised once per device and size: no runtime API call on later launches,
   //  which also keeps the launch legal inside a stream capture)
-  static size_t attr64 = 0, attr32 = 0;
+  static EmLdsCap cap64 = {}, cap32 = {};
   if (dk == 64) {
-    if (lds > attr64) {
-      if (hipFuncSetAttribute((const void*)dec_src_attn_kernel<T, 64>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return EM_ERR_LAUNCH;
-      attr64 = lds;
-    }
+    if (em_raise_lds_cap((const void*)dec_src_attn_kernel<T, 64>, lds, &cap64) != EM_OK) return EM_ERR_LAUNCH;
     hipLaunchKernelGGL((dec_src_attn_kernel<T, 64>), grid, dim3(256), lds, s, (const T*)qs,
                        (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx);
   } else if (dk == 32) {
-    if (lds > attr32) {
-      if (hipFuncSetAttribute((const void*)dec_src_attn_kernel<T, 32>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return EM_ERR_LAUNCH;
-      attr32 = lds;
-    }
+    if (em_raise_lds_cap((const void*)dec_src_attn_kernel<T, 32>, lds, &cap32) != EM_OK) return EM_ERR_LAUNCH;
     hipLaunchKernelGGL((dec_src_attn_kernel<T, 32>), grid, dim3(256), lds, s, (const T*)qs,
                        (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx);
   } else {

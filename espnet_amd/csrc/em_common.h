@@ -92,6 +92,23 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int em_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) of ONE kernel: the attribute is per DEVICE, so the
+// high-water mark is kept per device (a per-process flag would leave the second GPU of a process at the 64 KB default and
+// its launches would fail).  Raised only when a launch needs more than the device has been given: no runtime API call
+// on later launches, which keeps them legal inside a stream capture.  Concurrent first launches may both set it (idempotent).
+struct EmLdsCap {
+  int bytes[64];
+};
+static inline int em_raise_lds_cap(const void* fn, size_t bytes, EmLdsCap* cap) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return EM_ERR_LAUNCH;
+  if ((int)bytes > __atomic_load_n(&cap->bytes[dev], __ATOMIC_ACQUIRE)) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return EM_ERR_LAUNCH;
+    __atomic_store_n(&cap->bytes[dev], (int)bytes, __ATOMIC_RELEASE);
+  }
+  return EM_OK;
+}
+
 // per-launch timing of the MFMA kernel families (csrc/gemm.hip; bench.py's roofline leg)
 bool em_prof_begin(void* stream);
 void em_prof_end(void* stream, double flops, int tag);

@@ -64,6 +64,21 @@ inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const
 }
 
 
+// Which launch sequence em_conformer_encode takes: the ONE place that decides (the host layer asks through
+// em_conformer_encode_plan instead of re-deriving the shape conditions).
+inline int encode_plan(int dtype, const EmConformerWeights* w, int flags) {
+  const int d = w->d, h = w->heads, ff = w->ff, L = w->num_blocks;
+  const EmConformerLayer* ly = w->layers;
+  bool fused = dtype == EM_BF16 && d == 256 && h == 4 && ff <= 1024 && w->kernel == 31 && !w->legacy_relpos &&
+               !(flags & EM_ENC_NO_FUSED) && ly && L > 0 && ly[0].fp_a != nullptr;
+  for (int l = 0; fused && l < L; ++l)
+    fused = ly[l].pw1f && ly[l].fp_c && ly[l].fp_da && ly[l].ffm_w2p && ly[l].ff_w2p && ly[l].woutp && ly[l].pw2p &&
+            ly[l].ff_w1p && ly[l].ffm_w1p && ly[l].wqkvp;
+  if (!fused) return 0;
+  const bool ctc = w->ctc_ids && w->ctc_w && w->ctc_b && w->ctc_units > 0;
+  return EM_ENC_PLAN_FUSED | (ctc ? EM_ENC_PLAN_CTC_IDS : 0);
+}
+
 #define EM_TRY(expr)            \
   do {                          \
     int rc__ = (expr);          \
@@ -76,6 +91,11 @@ extern "C" size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeigh
                                                int32_t T_f) {
   if (!w || B <= 0 || T_f < em_sub::min_frames(w->subsample)) return 0;
   return layout(dtype, w, B, T_f).total;
+}
+
+extern "C" int em_conformer_encode_plan(int dtype, const EmConformerWeights* w, int32_t flags) {
+  if (!w || (dtype != EM_F32 && dtype != EM_BF16)) return EM_ERR_BAD_ARG;
+  return encode_plan(dtype, w, flags);
 }
 
 extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* feats,
@@ -117,10 +137,8 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, w->legacy_relpos ? T : 2 * T - 1, L * d, d, d,
               L * d, 1.f, stream));
   // ---- fused per Conformer block (csrc/block.hip): three launches per block instead of nineteen
-  bool fused = dtype == EM_BF16 && d == 256 && h == 4 && ff <= 1024 && w->kernel == 31 && !w->legacy_relpos &&
-               !(flags & EM_ENC_NO_FUSED) && ly[0].fp_a != nullptr;
-  for (int l = 0; fused && l < L; ++l) fused = ly[l].pw1f && ly[l].fp_c && ly[l].fp_da && ly[l].ffm_w2p && ly[l].ff_w2p && ly[l].woutp && ly[l].pw2p &&
-                                           ly[l].ff_w1p && ly[l].ffm_w1p && ly[l].wqkvp;
+  const int plan = encode_plan(dtype, w, flags);
+  const bool fused = (plan & EM_ENC_PLAN_FUSED) != 0;
   if (fused) {
     void* qh = ws + s.qh;
     void* kh = ws + s.kh;
@@ -146,7 +164,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
       if (l + 1 < L) {
         set_a(ly[l + 1]);
         EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_A, &ba, stream));
-      } else if (w->ctc_ids && w->ctc_w && w->ctc_b && w->ctc_units > 0) {
+      } else if (plan & EM_ENC_PLAN_CTC_IDS) {
         ba.ctc_w = w->ctc_w; ba.ctc_b = w->ctc_b; ba.ctc_ids = w->ctc_ids; ba.ctc_units = w->ctc_units;
         EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC, &ba, stream));
       } else {

@@ -148,11 +148,8 @@ template <typename T, int EPI, int BNT>
 int launch_skinny(const EmGemmArgs* p, hipStream_t s) {
   const int mt = (p->M + 15) / 16;
   const size_t lds = (size_t)4 * mt * BNT * 64 * 4 * sizeof(float);
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)skinny_gemm_kernel<T, EPI, BNT>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return EM_ERR_LAUNCH;
-  }
+  static EmLdsCap cap = {};
+  if (lds > 64 * 1024 && em_raise_lds_cap((const void*)skinny_gemm_kernel<T, EPI, BNT>, lds, &cap) != EM_OK) return EM_ERR_LAUNCH;
   hipLaunchKernelGGL((skinny_gemm_kernel<T, EPI, BNT>), dim3(em_cdiv(p->N, 16 * BNT)), dim3(256), lds, s,
                      (const T*)p->A, (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc,
                      p->scale);

@@ -146,13 +146,8 @@ template <typename T, int EPI, int NV>
 int launch_ln_gemm_nv(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
                       void* C, int M, int N, int K, int ldc, hipStream_t s) {
   const size_t lds = (size_t)LG_BM * (K + 16 / sizeof(T)) * sizeof(T);
-  static bool attr_done = false;  // per instantiation: raise the dynamic-LDS cap once (not per launch:
-  if (!attr_done) {               // launches may be inside a hipGraph capture)
-    if (hipFuncSetAttribute((const void*)ln_gemm_kernel<T, EPI, NV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024 - 1024) != hipSuccess)
-      return EM_ERR_LAUNCH;
-    attr_done = true;
-  }
+  static EmLdsCap cap = {};  // per instantiation and device: raised once (not per launch: launches may be inside a hipGraph capture)
+  if (em_raise_lds_cap((const void*)ln_gemm_kernel<T, EPI, NV>, 160 * 1024 - 1024, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(N, LG_BN), em_cdiv(M, LG_BM));
   hipLaunchKernelGGL((ln_gemm_kernel<T, EPI, NV>), grid, dim3(256), lds, s, x, g, b, eps, (const T*)W, bias, C,
                      M, N, K, ldc);

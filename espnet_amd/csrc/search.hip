@@ -1226,7 +1226,35 @@ __global__ __launch_bounds__(64) void ctc_prefix_init_kernel(const float* __rest
   }
 }
 
+// CTCPrefixScoreTH.extend_state (ctc_prefix_score.py:248-270) on stand-alone scorer states: r_old [n][T_old][2] ->
+// r_new [n][T_new][2]; frames below max(T_old, 1) are copied, the new ones continue along the blank path only
+// (r^n = logzero, r^b[t] = r^b[t-1] + logp[t][blank]), in the reference's own left-to-right order.  One wave per state.
+__global__ __launch_bounds__(64) void ctc_prefix_extend_kernel(const float* __restrict__ lp_blank, const float2* __restrict__ r_old,
+                                                              int T_old, int T_new, float2* __restrict__ r_new) {
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const float2* ro = r_old + (size_t)k * T_old;
+  float2* rn = r_new + (size_t)k * T_new;
+  const int start = T_old > 1 ? T_old : 1;
+  for (int t = lane; t < start; t += 64) rn[t] = t < T_old ? ro[t] : make_float2(LOGZERO, LOGZERO);
+  if (lane == 0) {
+    float cum = T_old > 0 ? ro[start - 1].y : LOGZERO;
+    for (int t = start; t < T_new; ++t) {
+      cum += lp_blank[t];
+      rn[t] = make_float2(LOGZERO, cum);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int em_ctc_prefix_extend(const float* lpT, int32_t T_new, int32_t blank, const float* r_old, int32_t n,
+                                    int32_t T_old, float* r_new, void* stream) {
+  if (!lpT || !r_old || !r_new || n <= 0 || T_old < 0 || T_new < T_old || T_new <= 0 || blank < 0) return EM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ctc_prefix_extend_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, lpT + (size_t)blank * T_new,
+                     (const float2*)r_old, T_old, T_new, (float2*)r_new);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
 
 extern "C" int em_decoder_memory(int dtype, const EmDecoderWeights* dw, const void* enc_act, int32_t B,
                                  int32_t T, int32_t Tpad, void* mem_kv, void* mem_vT, void* stream) {

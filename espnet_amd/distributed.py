@@ -103,7 +103,25 @@ def decode_sharded(decode_fn, n_items: int, max_len: int, device, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     lo, hi = shard_bounds(n_items, rank, world)
-    toks, scores = decode_fn(lo, hi) if hi > lo else ([], [])
     slab = (n_items + world - 1) // world
-    ids, lens, sc = pack_hypotheses(toks, scores, max_len, slab, device)
+    # A rank that fails before the collective (bad audio, out of memory, a hypothesis longer than the record) must
+    # not leave its peers waiting inside the all-gather: every rank first agrees on an error flag (one tiny
+    # all-reduce), and one rank's failure becomes an exception on every rank.
+    err = None
+    ids = lens = sc = None
+    try:
+        toks, scores = decode_fn(lo, hi) if hi > lo else ([], [])
+        ids, lens, sc = pack_hypotheses(toks, scores, max_len, slab, device)
+    except Exception as e:  # re-raised below, after the peers have been told
+        err = e
+    if world > 1:
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        failed = int(flag.item()) != 0
+    else:
+        failed = err is not None
+    if err is not None:
+        raise err
+    if failed:
+        raise RuntimeError(f"rank {rank}: another rank failed before the hypothesis collation; nothing was gathered")
     return gather_hypotheses(ids, lens, sc, n_items, group)

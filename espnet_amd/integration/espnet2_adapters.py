@@ -34,7 +34,25 @@ from espnet_amd.nets.scorers.length_bonus import LengthBonus as _LengthBonus
 
 class MI355XConformerEncoder(_ConformerEncoder, AbsEncoder):
     """forward(xs_pad (B,L,D), ilens (B,), prev_states=None) -> (ys (B,L',d), olens, None);
-    keywords of espnet2/asr/encoder/conformer_encoder.py:89-121."""
+    keywords of espnet2/asr/encoder/conformer_encoder.py:89-121.
+
+    Option combinations the MI355X kernels do not cover (the reference's own defaults among them:
+    `macaron_style=False`, conformer_encoder.py:103) do not fail at `build_model`: the same yaml name then builds the
+    STOCK espnet2 `ConformerEncoder` with the same arguments, and says so in the log (never silently: the stock
+    module is the reference's code path, not an accelerated one)."""
+
+    def __new__(cls, *args, **kwargs):
+        bad = _ConformerEncoder.unsupported_options(*args, **kwargs)
+        if bad:
+            import logging
+
+            from espnet2.asr.encoder.conformer_encoder import ConformerEncoder as _Stock
+
+            kwargs.pop("compute_dtype", None)  # the one keyword the stock class does not know
+            logging.warning("mi355x_conformer: %s outside the MI355X fast path -> stock espnet2 ConformerEncoder "
+                            "(reference code path, not accelerated)", ", ".join(bad))
+            return _Stock(*args, **kwargs)  # not an instance of cls: Python does not call cls.__init__ on it
+        return super().__new__(cls)
 
 
 class MI355XEBranchformerEncoder(_EBranchformerEncoder, AbsEncoder):

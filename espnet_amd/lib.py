@@ -21,6 +21,7 @@ EM_A_PLAIN, EM_A_CONV2 = 0, 1
 EM_DW_SWISH, EM_DW_LINEAR, EM_DW_GATE, EM_DW_SELFRES = range(4)
 EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flags (include/espnet_amd.h)
 EM_ENC_NO_FUSED = 2
+EM_ENC_PLAN_FUSED, EM_ENC_PLAN_CTC_IDS = 1, 2
 EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC = 1, 2, 4, 8, 16
 EM_BLOCK_PARAM_GROUP = 1792
 EM_BLOCK_CTC_MAX_UNITS = 88  # vocabularies up to 5 632 labels take the fused CTC stage (the sizes the GPU tests cover); larger ones keep the arg-max GEMM
@@ -260,6 +261,8 @@ _SIGNATURES = {
                                       _i32, _vp, _vp, _vp]),
     "em_ctc_prefix_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                       _vp]),
+    "em_conformer_encode_plan": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _i32]),
+    "em_ctc_prefix_extend": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "em_ctc_greedy": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32,
                                 _vp, _vp, _vp, _vp, _vp]),
 }

@@ -71,27 +71,22 @@ class BeamSearch:
         self.max_live_shapes = 3  # buffer sets (and their captured graphs) kept for recurring batch shapes
         self.step_chunk = 16  # steps enqueued between two polls of the `done` flags
         self.use_hipgraph = True  # replay a captured hipGraph of `step_chunk` search steps
-        # A search step is ~60 dependent launches of 12-120 workgroups each: latency, not throughput, on a 256-CU
-        # part.  Utterances are independent, so a batch CAN be cut into `search_lanes` contiguous sub-batches that run
-        # the same search concurrently on their own HIP streams (own buffers, own captured graph).  Measured on
-        # MI355X (configs[2], B = 16 x beam 10, profiles/r02_experiments_not_kept.txt): 1 lane 0.646 ms per label step,
-        # 2 lanes 0.740, 4 lanes 1.332 -- the per-launch floor (~4.7 us even for a one-thread kernel) is paid per
-        # lane and the lanes' launches do not overlap, so the default stays ONE search over the whole batch.
-        self.search_lanes = int(os.environ.get("ESPNET_AMD_SEARCH_LANES", "1"))
+        # (Round 2 also cut the batch into sub-batch searches on concurrent HIP streams: 0.646 -> 0.740 (2 lanes) ->
+        # 1.332 ms (4) per label step, profiles/r02_experiments_not_kept.txt - the launches of the lanes do not
+        # overlap.  Removed in round 3; the search is one generator over the whole batch.)
         if os.environ.get("ESPNET_AMD_SEARCH_GRAPH") == "0":
             self.use_hipgraph = False
-        self.min_lane_batch = 2
 
 
 class BatchBeamSearch(BeamSearch):
     # ------------------------------------------------------------------ buffers
-    def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm=None, online=False, lane=0):
+    def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm=None, online=False):
         key = (str(dev), act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl,
-               None if lm is None else lm.search_key(), online, lane)
+               None if lm is None else lm.search_key(), online)
         if key in self._bufs:
             self._bufs[key] = self._bufs.pop(key)  # most recently used last
             return self._bufs[key]
-        while len(self._bufs) >= max(self.max_live_shapes, 2 * self.search_lanes):  # evict the least recently used shape and the
+        while len(self._bufs) >= self.max_live_shapes:  # evict the least recently used shape and the
             old = self._bufs.pop(next(iter(self._bufs)))
             for gk in [gk for gk in self._graphs if gk[0] == id(old)]:  # graphs captured over its buffers
                 del self._graphs[gk]
@@ -132,7 +127,8 @@ class BatchBeamSearch(BeamSearch):
         Returns the ended hypotheses of every utterance, best first (beam_search.py:453-461).  An utterance
         that ends no hypothesis is searched again with minlenratio lowered by 0.1, as BeamSearch.forward does
         for its single utterance (beam_search.py:462-474), until it yields one or minlenratio < 0.1."""
-        out = self._search_lanes(enc_act, olens, maxlenratio, minlenratio)
+        out = self._search_once(enc_act, olens, maxlenratio, minlenratio)
+        steps = self.last_steps  # of THIS search: the back-off below recurses and must not overwrite it
         empty = [b for b, h in enumerate(out) if len(h) == 0]
         if empty and minlenratio >= 0.1:
             idx = torch.tensor(empty, device=enc_act.device)
@@ -140,57 +136,25 @@ class BatchBeamSearch(BeamSearch):
                                       max(0.0, minlenratio - 0.1))
             for b, h in zip(empty, again):
                 out[b] = h
+        self.last_steps = steps
         return out
 
-    def _search_lanes(self, enc_act: torch.Tensor, olens: List[int], maxlenratio: float,
-                      minlenratio: float) -> List[List[Hypothesis]]:
-        """Runs the search of the batch as up to `search_lanes` independent sub-batch searches on separate HIP
-        streams.  Every lane is a generator (`_search_run`) that enqueues its work without synchronising and
-        yields where the reference loop looks at the host (the `done` flags between step chunks): all lanes are
-        advanced first, then their polls are resolved, so while the host waits for one lane the others keep the
-        GPU busy.  Results are the sub-batches' n-best lists in utterance order."""
+    def _search_once(self, enc_act: torch.Tensor, olens: List[int], maxlenratio: float,
+                     minlenratio: float) -> List[List[Hypothesis]]:
+        """Drives the search generator (`_search_run`): it enqueues its work without synchronising and yields the
+        device `done` flags where the reference loop looks at the host (between step chunks); the answer sent back
+        is "every utterance is done"."""
         L.require_gpu(enc_act, "enc_act")
-        B = enc_act.size(0)
-        n_lanes = max(1, min(self.search_lanes, B // max(1, self.min_lane_batch)))
-        self._lane_steps = {}
-        if n_lanes == 1:
-            gen = self._search_run(enc_act, olens, maxlenratio, minlenratio, 0)
-            msg = None
-            while True:
-                try:
-                    req = gen.send(msg)
-                except StopIteration as e:
-                    return e.value
-                msg = bool(req.all().item())
-        from espnet_amd.distributed import shard_bounds
+        gen = self._search_run(enc_act, olens, maxlenratio, minlenratio)
+        msg = None
+        while True:
+            try:
+                req = gen.send(msg)
+            except StopIteration as e:
+                return e.value
+            msg = bool(req.all().item())
 
-        dev = enc_act.device
-        if not hasattr(self, "_lane_streams") or len(self._lane_streams) < n_lanes:
-            self._lane_streams = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]
-        cur = torch.cuda.current_stream()
-        spans = [shard_bounds(B, k, n_lanes) for k in range(n_lanes)]
-        gens, msgs, reqs, results = {}, {}, {}, {}
-        for k, (lo, hi) in enumerate(spans):
-            self._lane_streams[k].wait_stream(cur)
-            gens[k] = self._search_run(enc_act[lo:hi], olens[lo:hi], maxlenratio, minlenratio, k)
-            msgs[k] = None
-        while gens:
-            for k in list(gens):
-                with torch.cuda.stream(self._lane_streams[k]):
-                    try:
-                        reqs[k] = gens[k].send(msgs[k])
-                    except StopIteration as e:
-                        results[k] = e.value
-                        del gens[k]
-            for k in gens:
-                with torch.cuda.stream(self._lane_streams[k]):
-                    msgs[k] = bool(reqs[k].all().item())
-        for k in range(n_lanes):
-            cur.wait_stream(self._lane_streams[k])
-        self.last_steps = max(self._lane_steps.values()) if getattr(self, "_lane_steps", None) else 0
-        return [h for k in range(n_lanes) for h in results[k]]
-
-    def _search_run(self, enc_act: torch.Tensor, olens: List[int], maxlenratio: float, minlenratio: float, lane: int):
+    def _search_run(self, enc_act: torch.Tensor, olens: List[int], maxlenratio: float, minlenratio: float):
         """Generator: one search over a (sub-)batch on the CURRENT stream.  Yields the device `done` flags wherever
         the host decides whether to go on (send back True when every utterance is done); returns the n-best."""
         L.require_gpu(enc_act, "enc_act")
@@ -234,7 +198,7 @@ class BatchBeamSearch(BeamSearch):
         Tpad = T
         nl = dec.num_blocks if dec is not None else 0
         ff = dec.linear_units if dec is not None else 0
-        bufs = self._alloc(dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm, lane=lane)
+        bufs = self._alloc(dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm)
         bufs["xlens"].copy_(torch.tensor(olens, dtype=torch.int32))
         bufs["maxlens"].copy_(torch.tensor(maxlens, dtype=torch.int32))
         bufs["minlens"].copy_(torch.tensor(minlens, dtype=torch.int32))
@@ -294,7 +258,7 @@ class BatchBeamSearch(BeamSearch):
                 i += K
                 if i < imax and (yield bufs["done"]):
                     break
-            self._note_steps(lane, min(i, imax))  # label steps enqueued by this search (bench.py's search roofline)
+            self.last_steps = min(i, imax)  # label steps enqueued by this search (bench.py's search roofline)
             return self._collect(bufs, B, W, maxlens)
         i = 0
         while i < imax:
@@ -303,12 +267,8 @@ class BatchBeamSearch(BeamSearch):
             i = j
             if i < imax and (yield bufs["done"]):  # the only host sync of the search
                 break
-        self._note_steps(lane, i)
+        self.last_steps = i
         return self._collect(bufs, B, W, maxlens)
-
-    def _note_steps(self, lane: int, n: int):
-        self._lane_steps[lane] = n
-        self.last_steps = n
 
     # ------------------------------------------------------------------ readout (host)
     def _collect(self, bufs, B, W, maxlens) -> List[List[Hypothesis]]:

@@ -29,6 +29,20 @@ class _BatchState:
         self._cache = {}
 
 
+class _PartialStates:
+    """The per-candidate states of `score_partial`: `st[i]` = state of the prefix extended by ids[i] (the reference
+    holds an array of all of them, scorers/ctc.py:83-86; here each is materialised when the search selects it)."""
+
+    def __init__(self, scorer, bst, ids):
+        self.scorer, self.bst, self.ids = scorer, bst, ids
+
+    def __getitem__(self, i):
+        return self.scorer.select_state(self.bst, 0, int(self.ids[int(i)]))
+
+    def __len__(self):
+        return int(self.ids.numel())
+
+
 class CTCPrefixScorer(BatchPartialScorerInterface):
     def __init__(self, ctc, eos: int):
         self.ctc = ctc
@@ -57,9 +71,11 @@ class CTCPrefixScorer(BatchPartialScorerInterface):
         return None
 
     def init_state(self, x: torch.Tensor):
-        """scorers/ctc.py:27-38 (the non-batched set-up): same device tables."""
+        """scorers/ctc.py:25-38 (the non-batched set-up): `(0, initial state)`; same device tables as the batched
+        set-up (the reference switches to the numpy CTCPrefixScore here, ctc_prefix_score.py:273-370: same recursion,
+        one prefix at a time)."""
         self.batch_init_state(x)
-        return None
+        return 0.0, None
 
     # ---------------------------------------------------------------- per-step scoring
     @torch.no_grad()
@@ -103,17 +119,27 @@ class CTCPrefixScorer(BatchPartialScorerInterface):
         return scores, _BatchState(self, out_len, r_prev, last, log_psi)
 
     def score_partial(self, y, ids, state, x):
-        """scorers/ctc.py:65-86, through the batched entry (one prefix)."""
-        scores, st = self.batch_score_partial(y.unsqueeze(0), None if ids is None else ids.unsqueeze(0),
-                                              [state], x)
-        return scores[0], st
+        """scorers/ctc.py:65-86: scores of the candidates `ids` ONLY, shape (len(ids),), and the next state
+        `(presub_score (len(ids),), per-candidate states)` that `select_state(state, i)` indexes by the POSITION i
+        inside ids (scorers/ctc.py:51-55).  Runs through the batched device entry with one prefix."""
+        prev_score, st = state
+        scores, bst = self.batch_score_partial(y.unsqueeze(0), ids.unsqueeze(0), [st], x)
+        idx = ids.to(scores.device)
+        presub = bst.log_psi[0].index_select(0, idx)
+        tscore = (presub - prev_score).to(dtype=x.dtype if x.dtype.is_floating_point else torch.float32)
+        return tscore, (presub, _PartialStates(self, bst, idx))
 
     def select_state(self, state, i, new_id=None):
         """scorers/ctc.py:40-63: the state of prefix i extended by `new_id`."""
         if state is None:
             return None
+        if type(state) is tuple and len(state) == 2:  # score_partial's state: index by position in ids (:51-55)
+            sc, st = state
+            return sc[int(i)], st[int(i)]
         if not isinstance(state, _BatchState):  # a list of per-hypothesis states (batchfy): scorers/ctc.py:63
             return state[i]
+        if new_id is None:
+            raise ValueError("select_state on a batch_score_partial state needs new_id (scorers/ctc.py:56-62)")
         i, new_id = int(i), int(new_id)
         key = (i, new_id)
         if key not in state._cache:
@@ -129,8 +155,47 @@ class CTCPrefixScorer(BatchPartialScorerInterface):
             state._cache[key] = (r[0], state.log_psi[i, new_id], new_id)
         return state._cache[key]
 
+    # ---------------------------------------------------------------- streaming (block-synchronous) decoding
+    @torch.no_grad()
     def extend_prob(self, x: torch.Tensor):
-        raise NotImplementedError("streaming: BatchBeamSearchOnline drives em_search_online_extend directly")
+        """scorers/ctc.py:128-139 -> CTCPrefixScoreTH.extend_prob (ctc_prefix_score.py:226-246): the visible memory
+        grew to x (T_new, d).  Log-probs of all T_new frames; the frames already seen keep the values they had
+        (:243), and nothing happens unless the memory actually grew (:231)."""
+        if self._lpT is None:
+            raise RuntimeError("batch_init_state(x) must run before extend_prob")
+        L.require_gpu(x, "x")
+        T_new = x.size(0)
+        if T_new <= self._T:
+            return
+        old, T_old = self._lpT, self._T
+        self.batch_init_state(x)              # lpT (V, T_new), xlens, r0 of the empty prefix over T_new frames
+        self._lpT[:, :T_old].copy_(old)
+        if T_old > 0:                         # r0 follows the kept frames
+            L.check(L.load().em_ctc_prefix_init(L.ptr(self._lpT), L.ptr(self._xlens), 1, T_new, self.blank,
+                                                L.ptr(self._r0), L.current_stream_ptr()), "em_ctc_prefix_init")
 
+    @torch.no_grad()
     def extend_state(self, state):
-        raise NotImplementedError("streaming: BatchBeamSearchOnline drives em_search_online_extend directly")
+        """scorers/ctc.py:141-157 -> CTCPrefixScoreTH.extend_state (ctc_prefix_score.py:248-270) for every
+        hypothesis state of the list: the forward variables continue over the new frames along the blank path
+        (Eq. 14 of arXiv:2006.14941).  One device launch for the whole list (`em_ctc_prefix_extend`)."""
+        if self._lpT is None:
+            raise RuntimeError("batch_init_state(x) must run before extend_state")
+        live = [k for k, s in enumerate(state) if s is not None]
+        out = list(state)
+        if not live:
+            return out
+        T_new = self._T
+        T_old = state[live[0]][0].size(0)
+        if any(state[k][0].size(0) != T_old for k in live):
+            raise ValueError("extend_state: the states of one beam cover different frame counts")
+        if T_old >= T_new:
+            return out
+        dev = self._lpT.device
+        r_old = torch.stack([state[k][0] for k in live], 0).to(device=dev, dtype=torch.float32).contiguous()
+        r_new = torch.empty(len(live), T_new, 2, dtype=torch.float32, device=dev)
+        L.check(L.load().em_ctc_prefix_extend(L.ptr(self._lpT), T_new, self.blank, L.ptr(r_old), len(live), T_old,
+                                              L.ptr(r_new), L.current_stream_ptr()), "em_ctc_prefix_extend")
+        for j, k in enumerate(live):
+            out[k] = (r_new[j],) + tuple(state[k][1:])
+        return out

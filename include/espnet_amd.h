@@ -272,6 +272,12 @@ typedef struct EmConformerWeights {
 #define EM_ENC_ISOLATE_UTTS 1 /* every utterance of a ragged batch encodes as if it were alone */
 #define EM_ENC_NO_FUSED 2     /* keep the one-operator-per-launch sequence even where the fused block kernels apply */
 
+/* Which launch sequence em_conformer_encode will take for these weights and flags (>= 0; negative = status):
+ * the single source of that decision, so that the host layer never re-derives the shape conditions.           */
+#define EM_ENC_PLAN_FUSED 1   /* fused per-block kernels (csrc/block.hip) */
+#define EM_ENC_PLAN_CTC_IDS 2 /* ... and w->ctc_ids [B][T] WILL be written by the last block kernel */
+int em_conformer_encode_plan(int dtype, const EmConformerWeights* w, int32_t flags);
+
 /* bytes of scratch em_conformer_encode needs for (B, T_f) */
 size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t B, int32_t T_f);
 
@@ -691,6 +697,13 @@ int em_ctc_prefix_score(const float* lpT, const int32_t* xlens, const float* r_p
 int em_ctc_prefix_state(const float* lpT, const int32_t* xlens, const float* r_prev, const int32_t* last_ids,
                         const int32_t* rows, const int32_t* toks, int32_t m, int32_t B, int32_t W, int32_t T,
                         int32_t out_len, int32_t blank, float* r_out, void* stream);
+/*   CTCPrefixScoreTH.extend_state (legacy/nets/ctc_prefix_score.py:248-270; driven by CTCPrefixScorer.extend_state,
+ *   legacy/nets/scorers/ctc.py:141-157) for n stand-alone hypothesis states of ONE utterance whose visible memory grew
+ *   from T_old to T_new frames: r_old [n][T_old][2] -> r_new [n][T_new][2].  Frames below max(T_old, 1) are copied;
+ *   the new frames continue along the blank path only, r[t] = (logzero, r[t-1][1] + lpT[blank][t]), accumulated
+ *   left to right like the reference's loop.  lpT [V][T_new] = em_ctc_log_probs_t of the T_new frames (B = 1).   */
+int em_ctc_prefix_extend(const float* lpT, int32_t T_new, int32_t blank, const float* r_old, int32_t n,
+                         int32_t T_old, float* r_new, void* stream);
 
 /* ---- §8(f) rank 3: block-synchronous streaming search, BatchBeamSearchOnline
  *      (espnet2/legacy/nets/batch_beam_search_online.py:155-534).  The host mirrors the reference's

@@ -40,6 +40,14 @@ from espnet_amd.asr.ctc import CTC  # noqa: E402
 
 inst["MI355XCTCPrefixScorer"] = A.MI355XCTCPrefixScorer(CTC(V, d), V - 1)
 out["instantiated"] = sorted(inst)
+# the reference's OWN defaults (macaron_style=False, rel_pos_type="legacy": conformer_encoder.py:89-121) are outside
+# the fast path: the same name must then hand back the stock class instead of failing at build_model
+from espnet2.asr.encoder.conformer_encoder import ConformerEncoder as RefConformer  # noqa: E402
+
+stock = A.MI355XConformerEncoder(80, output_size=d, attention_heads=1, linear_units=128, num_blocks=1)
+out["defaults_build_stock"] = type(stock) is RefConformer and not isinstance(stock, A.MI355XConformerEncoder)
+out["fast_path_is_adapter"] = type(inst["MI355XConformerEncoder"]) is A.MI355XConformerEncoder
+out["unsupported_of_defaults"] = A.MI355XConformerEncoder.unsupported_options(80)
 tables = A.register()
 out["registered"] = {k: sorted(n for n in t.classes if n.startswith("mi355x_")) for k, t in tables.items()}
 out["get_class"] = tables["decoder"].get_class("mi355x_transformer").__name__

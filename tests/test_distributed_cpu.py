@@ -186,3 +186,102 @@ def test_ngpu_sharded_inference_merges_in_key_order(tmp_path):
     assert [ln.split()[0] for ln in rows] == keys
     assert [[int(t) for t in ln.split()[1:]] for ln in rows] == want_t
     assert (Path(tmp_path) / "1best_recog" / "text").read_text().splitlines()[2] == "utt9 text of utt9"
+
+
+# ---- failure of one rank: no hang (a rank that failed before the collective left its peers in the all-gather)
+def _failing_decode(lo, hi):
+    if lo > 0:  # rank 1's slab
+        raise ValueError("hypothesis 0 has 99 tokens, the collective's record holds 8")
+    return fake_decode(lo, hi)
+
+
+def _failing_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        decode_sharded(_failing_decode, 6, max_len=8, device="cpu")
+        q.put((rank, "no exception"))
+    except Exception as e:
+        q.put((rank, f"{type(e).__name__}: {e}"))
+    dist.destroy_process_group()
+
+
+def test_one_failing_rank_raises_on_every_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1].startswith("ValueError")           # the rank that failed re-raises its own error
+    assert got[0].startswith("RuntimeError") and "another rank failed" in got[0]  # its peer is told, not left waiting
+
+
+def _report_then_hang(rank, q):
+    import time
+
+    if rank == 1:
+        q.put((rank, RuntimeError("rank 1: ValueError: bad audio")))
+        raise SystemExit(1)
+    time.sleep(600)  # a peer stuck in a collective nobody will complete
+
+
+def _die_silently(rank, q):
+    import time
+
+    if rank == 1:
+        os._exit(9)
+    time.sleep(600)
+
+
+@pytest.mark.parametrize("target", [_report_then_hang, _die_silently])
+def test_collect_ranks_terminates_survivors(target):
+    from espnet_amd.bin.asr_inference import _collect_ranks
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    with pytest.raises(RuntimeError, match="bad audio|exited with 9"):
+        _collect_ranks(procs, q, poll_s=0.2)
+    assert all(not p.is_alive() for p in procs)
+
+
+def test_bench_gpus_n_without_launcher_becomes_the_launcher(monkeypatch):
+    """`python bench.py --gpus 8` with no WORLD_SIZE in the environment must re-launch itself as the contract's
+    torchrun command line (one rank per GPU, 127.0.0.1 rendezvous) instead of dying on the world-size assertion."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

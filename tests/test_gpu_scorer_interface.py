@@ -174,3 +174,95 @@ def test_length_bonus_interface():
     assert s.shape == (3, 11) and bool((s == 1).all()) and st is None and s.is_cuda
     s1, _ = lb.score(torch.zeros(2, dtype=torch.int64), None, torch.zeros(4, 8, device="cuda"))
     assert s1.shape == (11,) and bool((s1 == 1).all())
+
+
+def test_ctc_prefix_scorer_extend_prob_and_state_match_reference_recursion():
+    """Streaming interface of the scorer (scorers/ctc.py:128-157 -> ctc_prefix_score.py:226-270): after the memory
+    grows from T1 to T2 frames, extend_prob keeps the old frames' log-probs, extend_state continues every
+    hypothesis state along the blank path, and the next batch_score_partial over the extended states equals the
+    oracle's CtcPrefixScorer given the same (restated) extension."""
+    from oracle import beam_search as ob
+    from oracle import conformer as oc
+
+    g = load_golden("tiny_beam5")
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    scorers, _, V, _ = build_scorers(g, sd)
+    sc = scorers["ctc"]
+    e = enc[0, : int(olens[0])]
+    T2 = e.size(0)
+    T1 = max(4, T2 // 2)
+    logp = oc.ctc_log_softmax(sd, e.unsqueeze(0))[0]
+    o1 = ob.CtcPrefixScorer(logp[:T1], V - 1)
+    sc.batch_init_state(e[:T1].cuda())
+    n = 3
+    r_prev, s_prev = o1.initial_state()
+    r_prev, s_prev = r_prev.expand(-1, -1, n).contiguous(), s_prev.expand(n).contiguous()
+    ys = torch.full((n, 1), V - 1, dtype=torch.int64)
+    states = [None] * n
+    for step in range(2):  # two label steps on the first block
+        ids = torch.stack([torch.arange(1 + 3 * k + step, 8 + 3 * k + step) for k in range(n)])
+        want, r_all, psi = o1.score(step, ys[:, -1], r_prev, s_prev, ids)
+        got, st = sc.batch_score_partial(ys.cuda(), ids.cuda(), states, e[:T1].cuda())
+        nxt = ids[:, 2]
+        states = [sc.select_state(st, k, int(nxt[k])) for k in range(n)]
+        r_prev = torch.stack([r_all[:, :, k, 2] for k in range(n)], dim=2)
+        s_prev = psi[torch.arange(n), nxt]
+        ys = torch.cat([ys, nxt.unsqueeze(1)], dim=1)
+    # ---- the block grows: extend_prob + extend_state
+    lp_before = sc._lpT.clone()
+    sc.extend_prob(e.cuda())
+    assert sc._T == T2 and torch.equal(sc._lpT[:, :T1], lp_before)            # old frames keep their values (:243)
+    assert (sc._lpT[:, T1:].cpu().T - logp[T1:]).abs().max().item() < 2e-4
+    sc.extend_prob(e[: T2 - 1].cuda())                                        # not longer: nothing happens (:231)
+    assert sc._T == T2
+    new_states = sc.extend_state(states + [None])
+    assert new_states[-1] is None and len(new_states) == n + 1
+    o2 = ob.CtcPrefixScorer(logp, V - 1)
+    r_ext = torch.full((T2, 2, n), ob.LOGZERO)
+    r_ext[:T1] = r_prev
+    for t in range(T1, T2):                                                   # ctc_prefix_score.py:266-268
+        r_ext[t, 1] = r_ext[t - 1, 1] + o2.x[0, t, 0]
+    for k in range(n):
+        got_r = new_states[k][0].cpu()
+        assert got_r.shape == (T2, 2)
+        assert torch.equal(got_r[:T1], states[k][0].cpu())
+        assert bool((got_r[T1:, 0] < -1e9).all())
+        assert (got_r[T1:, 1] - r_ext[T1:, 1, k]).abs().max().item() < 2e-3
+    # ---- and the search goes on over the extended states
+    ids = torch.stack([torch.arange(2 + k, 9 + k) for k in range(n)])
+    want, _, _ = o2.score(2, ys[:, -1], r_ext, s_prev, ids)
+    got, _ = sc.batch_score_partial(ys.cuda(), ids.cuda(), new_states[:n], e.cuda())
+    seen = torch.zeros(n, V, dtype=torch.bool).scatter_(1, ids, True)
+    seen[:, V - 1] = True
+    assert (got.cpu() - want)[seen].abs().max().item() < 2e-3
+
+
+def test_ctc_prefix_scorer_non_batched_contract():
+    """scorers/ctc.py:25-86: init_state -> (0, state); score_partial -> (len(ids),) scores and a state that
+    select_state(state, i) indexes by the position inside ids (the reference's BeamSearch.merge_states,
+    beam_search.py:313, calls it without new_id).  Checked against the batched entry of the same object."""
+    g = load_golden("tiny_beam5")
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    scorers, _, V, _ = build_scorers(g, sd)
+    sc = scorers["ctc"]
+    e = enc[0, : int(olens[0])].cuda()
+    st0 = sc.init_state(e)
+    assert isinstance(st0, tuple) and len(st0) == 2 and st0[0] == 0
+    y = torch.tensor([V - 1], dtype=torch.int64, device="cuda")
+    ids = torch.tensor([5, 9, 2, V - 1, 17], dtype=torch.int64, device="cuda")
+    s1, st1 = sc.score_partial(y, ids, st0, e)
+    assert s1.shape == (5,)
+    full, bst = sc.batch_score_partial(y.unsqueeze(0), ids.unsqueeze(0), [None], e)
+    assert torch.allclose(s1, full[0, ids])
+    sel = sc.select_state(st1, 1)              # position 1 -> label 9
+    assert float(sel[0]) == pytest.approx(float(bst.log_psi[0, 9]))
+    ref = sc.select_state(bst, 0, 9)
+    assert torch.equal(sel[1][0], ref[0]) and int(sel[1][2]) == 9
+    # second step from the selected state: equals the batched call on the same state
+    y2 = torch.tensor([V - 1, 9], dtype=torch.int64, device="cuda")
+    ids2 = torch.tensor([9, 3, 11], dtype=torch.int64, device="cuda")
+    s2, _ = sc.score_partial(y2, ids2, sel, e)
+    full2, _ = sc.batch_score_partial(y2.unsqueeze(0), ids2.unsqueeze(0), [ref], e)
+    assert torch.allclose(s2, full2[0, ids2])

@@ -2,7 +2,7 @@
 # Developer builds of csrc/block.hip next to the product library, selected with ESPNET_AMD_LIB=... (espnet_amd/lib.py):
 #   espnet_amd/lib/dbg/lib_nt.so   -DEM_BLOCK_NO_TOUCH   (no L2 warm-up)
 #   espnet_amd/lib/dbg/lib_<d>.so  -DEM_BLOCK_DBG=<d>    (1 no MFMA / epilogue, 4 no FFN barrier, 8 no H exchange, 16 no Swish)
-# Used by tools/r02_call8.sh, r02_call9.sh, r02_call11.sh, r02_call12.sh (profiles/r02l, r02m, r02o, r02q).  Wrong results by
+# Used for profiles/r02l, r02m, r02o, r02q and the round-3 A/B calls (tools/r03_ab.sh).  dbg builds give wrong results by
 # design: timing only.   usage: bash tools/build_block_variants.sh nt 4 8 12 28
 set -eu
 cd "$(dirname "$0")/.."
