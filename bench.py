@@ -803,8 +803,17 @@ def main():
             with torch.no_grad():
                 ids_b, tok_b, tl_b = (t.cpu() for t in step_plain())
                 model.set_compute_dtype("float32")
-                ids_f, tok_f, tl_f = (t.cpu() for t in step_plain())
-            mism = float((ids_b != ids_f).float().mean())
+                st_f = model.encode_device(wav, lens)
+                ids_f, tok_f, tl_f = (t.cpu() for t in model.greedy_ctc_device(st_f))
+                # top-2 log-prob margin of the f32 result per frame (checker arithmetic in torch, not the product path)
+                lo = model.ctc.ctc_lo
+                lp = torch.log_softmax(st_f.enc_out.float() @ lo.weight.float().t() + lo.bias.float(), dim=-1)
+                top2 = lp.topk(2, dim=-1).values
+                margin = (top2[..., 0] - top2[..., 1]).cpu()
+                del lp, top2
+            flipped = ids_b != ids_f
+            mism = float(flipped.float().mean())
+            worst = float(margin[flipped].max()) if bool(flipped.any()) else 0.0
             dist_, nref = 0, 0
             for b in range(B):
                 ref = tok_f[b, : int(tl_f[b])].tolist()
@@ -813,9 +822,14 @@ def main():
             ids_bf16["done"] = True
             return {"frame_id_mismatch_rate": round(mism, 5), "token_edit_distance": dist_, "reference_tokens": nref,
                     "token_error_rate": round(dist_ / max(1, nref), 5),
+                    "max_reference_margin_at_mismatch": round(worst, 6),
+                    "frames_with_margin_below_that": round(float((margin <= worst).float().mean()), 5),
                     "what": "timed mode (bf16 MFMA, fused blocks) against the f32 parity mode of the same weights on "
-                            "the bench batch: per-frame CTC arg-max ids and G1 tokens (tests/test_gpu_fullsize.py "
-                            "bounds the same numbers against the oracle)"}
+                            "the bench batch: per-frame CTC arg-max ids and G1 tokens; max_reference_margin_at_mismatch = "
+                            "the largest f32 top-2 log-prob margin among the frames whose id flipped (random-init "
+                            "posteriors are nearly flat: only such near-ties may flip; tests/test_gpu_fullsize.py and "
+                            "tests/test_gpu_e2e.py assert it against the oracle / the reference fixtures, and require exact "
+                            "tokens on the peaked-posterior fixture)"}
 
         def f32_leg():
             if not ids_bf16:

@@ -132,7 +132,46 @@ def g1_tokens(ids, exclude):
     return [int(x[0]) for x in groupby(ids) if int(x[0]) not in exclude]
 
 
-def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, with_blocks=False):
+def fit_peaked_ctc_head(model, enc, olens, seed):
+    """A CTC head with PEAKED posteriors for the random-init encoder: random-init logits
+    are nearly flat (top-2 margins of 1e-3 .. 1e-1), so "the bf16 path returns the reference's tokens" cannot be
+    asked of them.  Here `ctc_lo` is FITTED (ridge regression, dual form) to a synthetic frame labelling - label
+    runs of 3-8 frames from a 60-label set, every third run blank, some labels recurring - on the REFERENCE's own
+    encoder output, the way a trained head separates its frames; everything downstream (log-softmax, arg-max, G1
+    collapse, margins) is then computed by the reference with that head.  Only the rows of the labels used are
+    non-zero; they are stored in the fixture (`ctc_rows`, `ctc_w_rows`, `ctc_b_rows`) and loaded on top of the
+    recipe weights by tests/helpers.py::golden_state_dict.  Needs fewer frames than dimensions (one 10 s utterance
+    of the 256-wide model: 249 frames)."""
+    rng = np.random.RandomState(seed)
+    V = model.ctc.ctc_lo.weight.size(0)
+    E = torch.cat([enc[b, : int(olens[b])] for b in range(enc.size(0))]).double().numpy()
+    T, d = E.shape
+    assert T < d, (T, d)
+    labels = rng.choice(np.arange(1, V - 1), size=60, replace=False)
+    want = np.zeros(T, dtype=np.int64)
+    t = k = 0
+    while t < T:
+        run = int(rng.randint(3, 9))
+        want[t : t + run] = 0 if k % 3 == 2 else int(labels[rng.randint(0, 60)])
+        t, k = t + run, k + 1
+    rows = np.unique(want)
+    Y = np.zeros((T, len(rows)))
+    Y[np.arange(T), np.searchsorted(rows, want)] = 8.0
+    mu = E.mean(0)
+    Ec = E - mu
+    A = np.linalg.solve(Ec @ Ec.T + 1.0 * np.eye(T), Y)
+    W = (Ec.T @ A).T
+    w = torch.zeros_like(model.ctc.ctc_lo.weight)
+    b = torch.zeros_like(model.ctc.ctc_lo.bias)
+    w[torch.from_numpy(rows)] = torch.from_numpy(W).float()
+    b[torch.from_numpy(rows)] = torch.from_numpy(-(W @ mu)).float()
+    model.ctc.ctc_lo.weight.copy_(w)
+    model.ctc.ctc_lo.bias.copy_(b)
+    return dict(ctc_rows=rows, ctc_w_rows=w[torch.from_numpy(rows)].numpy().copy(),
+                ctc_b_rows=b[torch.from_numpy(rows)].numpy().copy(), ctc_fit_labels=want)
+
+
+def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, with_blocks=False, peaked_seed=None):
     t0 = time.time()
     with tempfile.TemporaryDirectory() as td:
         s2t, cfg_text = build_reference(conf, vocab, td, beam_size=1, ctc_weight=1.0)
@@ -167,6 +206,8 @@ def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, wi
             xs, masks2 = layer(xs, masks2)
             blocks.append(xs[0].numpy().copy())
         out["block_outs"] = np.stack(blocks)
+    if peaked_seed is not None:
+        out.update(fit_peaked_ctc_head(model, enc, olens, peaked_seed))
     logp = model.ctc.log_softmax(enc)
     ids = model.ctc.argmax(enc)
     out["ctc_ids"] = ids.numpy()
@@ -570,6 +611,10 @@ CASES = {
     # config 0/1 of BASELINE.json: Conformer-small, one 10 s utterance
     "small_10s": lambda: run_encode_case("small_10s", SMALL, 5000, 11, [0], [160000], keep_every=4),
     # ragged batch (padding quirks: zero-padded STFT tail, MVN over valid frames, unmasked conv)
+    # the same weights and utterance with a ctc_lo FITTED to the reference's encoder output (peaked posteriors: the
+    # bf16 path must return the reference's G1 tokens exactly)
+    "small_10s_peaked": lambda: run_encode_case("small_10s_peaked", SMALL, 5000, 11, [0], [160000], keep_every=4,
+                                                peaked_seed=5),
     "small_ragged": lambda: run_encode_case("small_ragged", SMALL, 5000, 11, [1, 2, 3],
                                             [48000, 37123, 16000]),
     # tiny model with every block output pinned (oracle block-by-block check)

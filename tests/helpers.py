@@ -25,6 +25,12 @@ def golden_state_dict(g):
     if "tweaks" in g:  # e.g. a biased <eos> logit (tests/golden/make_golden.py)
         for key, idx, delta in json.loads(str(g["tweaks"])):
             sd[key][idx] += delta
+    if "ctc_rows" in g:  # a fitted (peaked) CTC head: make_golden.py::fit_peaked_ctc_head
+        rows = torch.from_numpy(np.asarray(g["ctc_rows"]))
+        sd["ctc.ctc_lo.weight"] = torch.zeros_like(sd["ctc.ctc_lo.weight"])
+        sd["ctc.ctc_lo.bias"] = torch.zeros_like(sd["ctc.ctc_lo.bias"])
+        sd["ctc.ctc_lo.weight"][rows] = torch.from_numpy(np.asarray(g["ctc_w_rows"]))
+        sd["ctc.ctc_lo.bias"][rows] = torch.from_numpy(np.asarray(g["ctc_b_rows"]))
     return sd
 
 

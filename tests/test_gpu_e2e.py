@@ -7,9 +7,11 @@ Stated tolerances:
                  final LayerNorm); per-frame argmax ids bit-exact except where the REFERENCE's own
                  top-2 log-prob margin is below 1e-3 (a tie at f32 resolution); G1 tokens exact
                  when no such frame exists.
-  bfloat16 mode: encoder activations abs 0.15 / mean-abs 2e-2 (bf16 operands, f32 accumulate);
-                 id mismatch rate reported and bounded (< 25 % of frames on random-init weights,
-                 whose logits are nearly flat), never asserted bit-exact.
+  bfloat16 mode: encoder activations abs 4e-2 / mean-abs 6e-3 (bf16 operands, f32 accumulate; 2x what is
+                 measured).  Random-init posteriors are nearly flat, so frame ids / tokens CAN flip - but only
+                 where the REFERENCE's own top-2 log-prob margin is below BF16_MARGIN: every mismatching frame
+                 is checked for that, the rate is bounded at 3 %, and on the fixture with a fitted (peaked) CTC
+                 head (`small_10s_peaked`) the bf16 path must return the reference's G1 tokens EXACTLY.
 """
 import numpy as np
 import pytest
@@ -85,11 +87,29 @@ def _edit_distance(a, b):
     return prev[-1]
 
 
+# A bf16 frame-id flip is legitimate only on a frame the reference itself barely decides: its top-2 log-prob margin
+# must be below this (measured on MI355X, round 3: the largest reference margin at a flipped frame is printed by the
+# tests and by bench.py's `bf16_vs_f32.max_reference_margin_at_mismatch`; the bound is ~2x the largest seen).
+BF16_MARGIN = 0.04
+
+
+def margin_report(tag, margins_at_mismatch):
+    """Histogram of the reference's top-2 margins at the mismatching frames (printed: run pytest -s)."""
+    m = np.asarray(margins_at_mismatch, dtype=np.float64)
+    edges = [0, 1e-3, 2e-3, 5e-3, 1e-2, 2e-2, 4e-2, 1e-1, 1e9]
+    hist = np.histogram(m, bins=edges)[0].tolist() if m.size else [0] * (len(edges) - 1)
+    print(f"[{tag}] {m.size} mismatching frames; reference top-2 margin there: max "
+          f"{(m.max() if m.size else 0.0):.3e}; histogram over {edges[:-1]} + inf: {hist}")
+    return float(m.max()) if m.size else 0.0
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["small_ragged", "small_10s", "large_10s"])
 def test_encode_bfloat16_within_tolerance(name, fused):
     """bf16 MFMA mode (the timed mode), both launch sequences: the fused per-block kernels (csrc/block.hip; they
-    apply to the 256-wide fixtures) and the one-operator-per-launch sequence."""
+    apply to the 256-wide fixtures) and the one-operator-per-launch sequence.  Falsifiable form (VERDICT r02
+    item 3): every frame whose arg-max differs from the reference's must be a frame the reference itself decides
+    by less than BF16_MARGIN; bounds at ~2x the measured values."""
     g = load_golden(name)
     model = build(g, "bfloat16")
     model.encoder.fused = fused
@@ -99,10 +119,13 @@ def test_encode_bfloat16_within_tolerance(name, fused):
     enc = st.enc_out.cpu().numpy()[:, ::ke]
     err = np.abs(enc - g["enc_out"])
     print(f"[{name} fused={fused}] bf16 encoder err max {err.max():.3e} mean {err.mean():.3e}")
-    assert err.max() < 0.15 and err.mean() < 2e-2
+    assert err.max() < 4e-2 and err.mean() < 6e-3
     ids, tokens, tlens = model.greedy_ctc_device(st)
     valid = np.arange(ids.shape[1])[None, :] < g["enc_olens"][:, None]
-    mism = ((ids.cpu().numpy() != g["ctc_ids"]) & valid).sum() / valid.sum()
+    diff = (ids.cpu().numpy() != g["ctc_ids"]) & valid
+    mism = diff.sum() / valid.sum()
+    worst = margin_report(f"{name} fused={fused}", g["ctc_margin"][diff])
+    assert worst < BF16_MARGIN, f"a frame the reference decides by {worst:.3e} flipped in bf16"
     # token level: edit distance between the device's G1 tokens and the reference's, per reference token
     dist = ref_len = 0
     for b in range(ids.shape[0]):
@@ -111,8 +134,30 @@ def test_encode_bfloat16_within_tolerance(name, fused):
         ref_len += len(want)
     print(f"[{name} fused={fused}] bf16 greedy-id mismatch rate {mism:.3%}, G1 token edit distance "
           f"{dist} / {ref_len} reference tokens")
-    assert mism < 0.25
-    assert dist <= 0.35 * max(ref_len, 1)
+    assert mism < 0.03
+    assert dist <= 0.03 * max(ref_len, 1) + 1
+
+
+@pytest.mark.parametrize("dtype,fused", [("float32", False), ("bfloat16", True), ("bfloat16", False)])
+def test_peaked_posteriors_tokens_exact(dtype, fused):
+    """`small_10s_peaked`: the small model with a CTC head fitted to the reference's encoder output (reference
+    top-2 margins all > 1, tests/golden/make_golden.py::fit_peaked_ctc_head).  With posteriors like a trained
+    model's, bf16 round-off has no frame to flip: the timed bf16 fused path - CTC arg-max inside the last block
+    kernel - must return the reference's per-frame ids and G1 tokens exactly (asr_inference.py:574-575)."""
+    g = load_golden("small_10s_peaked")
+    assert float(g["ctc_margin"].min()) > 1.0
+    model = build(g, dtype)
+    model.encoder.fused = fused
+    speech, lens = golden_speech(g)
+    st = model.encode_device(speech.cuda(), lens.tolist())
+    ids, tokens, tlens = model.greedy_ctc_device(st)
+    if fused:
+        assert model.encoder.last_ctc_ids is not None  # the arg-max really came from block<D|FINAL|CTC>
+    n_fr = int(g["enc_olens"][0])
+    assert ids[0, :n_fr].cpu().tolist() == g["ctc_ids"][0, :n_fr].tolist()
+    want = g["g1_tokens"][0, : int(g["g1_lens"][0])].tolist()
+    assert len(want) >= 20
+    assert tokens[0, : int(tlens[0])].cpu().tolist() == want
 
 
 def test_fused_blocks_match_per_operator_sequence_bf16():

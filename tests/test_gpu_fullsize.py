@@ -121,7 +121,7 @@ def test_greedy_b32_matches_oracle_elementwise():
     frames); the timed bf16 mode (fused block kernels) reports its frame-id mismatch rate and token edit distance
     against the same oracle output under a written bound."""
     from oracle import conformer as oc
-    from tests.test_gpu_e2e import _edit_distance
+    from tests.test_gpu_e2e import BF16_MARGIN, _edit_distance, margin_report
 
     B, N = 32, bench.N_SAMPLES
     wav = bench.synth_batch(0, B)
@@ -167,8 +167,11 @@ def test_greedy_b32_matches_oracle_elementwise():
         n_ref = sum(len(t) for t in ref_tokens)
         print(f"[configs[1] bf16 fused={fused}] encoder err max {e.max():.3e} mean {e.mean():.3e}; frame-id "
               f"mismatch {mism:.4f}; token edit distance {dist} over {n_ref} reference tokens")
-        assert e.max() < 0.15 and e.mean() < 2e-2
+        assert e.max() < 4e-2 and e.mean() < 6e-3     # measured 1.8e-2 / 3.1e-3
         assert mism < 0.02 and dist <= 0.02 * n_ref  # measured: 1.1-1.2 % of frames, 1.2-1.3 % of tokens
+        # ... and WHERE they are: only frames the oracle itself decides by less than BF16_MARGIN may flip
+        worst = margin_report(f"configs[1] bf16 fused={fused}", ref_margin[idb.cpu() != ref_ids].numpy())
+        assert worst < BF16_MARGIN, f"a frame the oracle decides by {worst:.3e} flipped in bf16"
 
 
 def test_beam10_b16_rows_match_oracle():
