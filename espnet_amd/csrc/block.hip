@@ -61,7 +61,8 @@ constexpr int PAR_FLOATS = EM_BLOCK_PARAM_GROUP;
 constexpr int PAR_BYTES = PAR_FLOATS * 4;
 constexpr int MAX_GROUPS = 4;
 constexpr int TOUCH_OFF = PAR_OFF + MAX_GROUPS * PAR_BYTES;  // 1 KiB: where the L2 warm-up's LDS-DMA lands (never read)
-constexpr int SMEM_BYTES = TOUCH_OFF + 1024 + 64;  // 80 KiB
+constexpr int WK_OFF = TOUCH_OFF + 1024;     // 32 KiB: depthwise conv weights [31][256] f32 (tap-major) + bias [256]
+constexpr int SMEM_BYTES = WK_OFF + 32768;   // 111 KiB
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile
 
 // weight units are read through GLOBAL-address-space pointers: through a generic pointer the loads become flat_load,
@@ -80,16 +81,14 @@ constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;  // what
 #define EM_BLOCK_DBG 0  // developer builds: 1 = no MFMA / epilogue work (what does the streaming cost alone?)
 #endif
 
-#define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifndef EM_BLOCK_VAR
+#define EM_BLOCK_VAR 0  // developer A/B builds (tools/build_block_variants.sh): 1 pinned-group FFN iteration, 2 inputs requested
+#endif                  // before parameters / weights in the D prologue, 4 FFN chunk order rotated per utterance
+#ifndef EM_BLOCK_FINE
+#define EM_BLOCK_FINE 0  // 1: EM_BLOCK_STAMPS records every wave of workgroup (3, 5) at sub-stage granularity
+#endif
 
-// L2 warm-up bookkeeping: workgroups of the RUNNING launch that have arrived on each XCC (one counter per 128-byte
-// line).  Every workgroup adds one on entry and takes it back on exit (leave_xcc()), so the counters are zero again at
-// every kernel boundary and a workgroup's arrival number IS its index among the launch's workgroups on that XCC: its
-// share of the weight list.  (Round 2 let the counters run on across launches and took the number modulo the launch's
-// workgroups per XCC: right only while every launch puts exactly 1/8 of its workgroups on each XCC.)  Grids larger
-// than one residency round hand out some shares twice - by then the list is warm; launches overlapping on two streams
-// mix their numbers: the warm-up is a performance hint, never a correctness matter.
-__device__ unsigned g_xcc_arrivals[8 * 32];
+#define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int MODE>
 __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long long* __restrict__ stamps) {
@@ -125,21 +124,26 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   const int nch = a.ff >> 6;  // 64-wide chunks of the FFN hidden dimension
   // developer profiling (EM_BLOCK_STAMPS / EM_BLOCK_DBG, tools/block_bench.py): stage-level cycle stamps of thread 0
   // of workgroup (0, 0); dbg 1 = no MFMA / epilogue work, dbg 2 = no DMA
-  // L2 warm-up (see touch()): which XCC is this, and the how-manyth workgroup on it?  Asked first of all (the answer
-  // is needed after the first barrier) by one lane; HW_REG_XCC_ID rather than "workgroup id % 8": the dispatch
-  // order is a property of the driver configuration, and a share computed for the wrong XCD warms the wrong L2.
-  unsigned* const touch_slot = (unsigned*)(smem + TOUCH_OFF + 1024);
-  unsigned my_arrival = 0, my_xcc = 0;
-  if (tid == 0) {
-    my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;  // HW_REG_XCC_ID
-    my_arrival = __hip_atomic_fetch_add(&g_xcc_arrivals[my_xcc * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   int nts = 0;
-  auto stamp = [&]() {
-    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nts < 64) stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
+  // stamp(code): (code << 56) | cycle counter.  Codes: 1 kernel entry, 2 D prologue inputs requested, 3 inputs landed (tile
+  // stored), 4 tile barrier passed, 5 conv computed, 6 conv output stored, 7 activations loaded, 10 pointwise_conv2 done,
+  // 11-14 LayerNorm (partials written, first barrier, applied + tiles written, second barrier), 15 LayerNorm done /
+  // activations loaded, 20 FFN h0 done, 21 FFN loop done, 22 FFN residual done, 30 norm_final done, 31 x stored,
+  // 40 q k v done, 50 linear_out done, 51 pointwise_conv1 + GLU done
+  auto stamp = [&](int code) {
+    if constexpr (EM_BLOCK_FINE) {
+      if (stamps && blockIdx.x == 3 && blockIdx.y == 5 && lane == 0 && nts < 64)
+        stamps[wave * 64 + nts] = ((long long)code << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffll);
+    } else {
+      if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nts < 64)
+        stamps[nts] = ((long long)code << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffll);
+    }
     ++nts;
   };
-  stamp();
+  auto fstamp = [&](int code) {  // sub-stage stamps: fine builds only
+    if constexpr (EM_BLOCK_FINE) stamp(code);
+  };
+  stamp(1);
   int nbar = 0;  // barriers passed
   // every barrier goes through here: retire own LDS operations, synchronise
   auto bar = [&](int code) {  // `code` documents what the barrier is for
@@ -206,7 +210,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         red[128 + nf * 32 + mi * 16 + lr] = q;  // sum of squares about their mean
       }
     }
+    fstamp(11);
     bar(code);
+    fstamp(12);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int m = mi * 16 + lr;
@@ -217,7 +223,10 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       const float qb = q2 + q3 + (s2 - s3) * (s2 - s3) * (1.0f / 128.0f);
       const float qq = qa + qb + (sa - sb) * (sa - sb) * (1.0f / 256.0f);
       mean[mi] = (sa + sb) * (1.0f / D);
-      rstd[mi] = 1.0f / sqrtf(qq * (1.0f / D) + a.eps);
+      // v_rsq_f32 (1 ulp) + one Newton step: f32-accurate without the IEEE sqrt + division sequences
+      const float var = qq * (1.0f / D) + a.eps;
+      const float y0 = __builtin_amdgcn_rsqf(var);
+      rstd[mi] = y0 * (1.5f - 0.5f * var * y0 * y0);
     }
   };
   // y = LN(x; g, b) with g, b at float offsets go / bo of parameter buffer pb
@@ -249,7 +258,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         bf16x4 pk = {(bf16)y[mi][f].x, (bf16)y[mi][f].y, (bf16)y[mi][f].z, (bf16)y[mi][f].w};
         *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
       }
+    fstamp(13);
     bar(code);
+    fstamp(14);
     load_act();
   };
   // ---- units: weight fragments go global memory -> registers, THREE UNITS AHEAD of the MFMAs ------------
@@ -290,8 +301,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // flight per wave then bound the stream at ~48 GB/s per CU where L2 hits run at the 128 GB/s ingest limit.  So
   // the workgroups of an XCD share out the launch's weights in 8 KiB chunks (64 lines: one wave-wide dword load,
   // a lane per line) and touch them all while the prologue's own global loads are in flight; the weights are in
-  // the XCD's L2 by the time the streams ask for them.  Called after the first barrier of the launch (publish_arrival()
-  // before it).
+  // the XCD's L2 by the time the streams ask for them.  A workgroup's share is its index among the launch's workgroups
+  // on its XCD, taken as (linear workgroup id / 8): consecutive ids go round-robin over the 8 XCDs on every box
+  // measured (tools/experiments/xcc_map.hip, profiles/r02t_xcc_map.txt).  That map is driver behaviour, not a
+  // contract - under another map some chunks are touched twice and some not at all, which costs speed, never
+  // correctness.  (Round 2 asked HW_REG_XCC_ID and a per-XCC arrival counter instead: equally fast,
+  // profiles/r02u_static_vs_xcc_share.txt, but the returning atomic sat in front of every other request of the
+  // prologue.)  Called as soon as the prologue's own requests are out.
   constexpr int MAXT = 16;  // chunks per wave at most: small grids warm what they can
   auto touch = [&]() {
 #ifdef EM_BLOCK_NO_TOUCH
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     const int nwg = gridDim.x * gridDim.y;
     const int per_xcc = (nwg + 7) >> 3;                      // workgroups of this launch on an XCC (balanced dispatch)
     const int nworker = per_xcc * 4;                         // their waves
-    const int worker = (int)(__builtin_amdgcn_readfirstlane(*touch_slot) % (unsigned)per_xcc) * 4 + wave;
+    const int worker = (int)((blockIdx.y * gridDim.x + blockIdx.x) >> 3) * 4 + wave;
     const unsigned dst = TOUCH_OFF + wave * 256;
     const int loff = lane * 128;
     int total = (HAS_C ? 48 : 0) + (HAS_D ? 16 + 8 * nch : 0) + (HAS_A ? 48 + 8 * nch : 0);  // 8 KiB chunks of the launch
@@ -346,12 +362,32 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           : "memory");
     }
   };
-  // every exit of the kernel: give the arrival back (no return value: fire and forget)
-  auto touch_done = [&]() {
-    if (tid == 0) __hip_atomic_fetch_add(&g_xcc_arrivals[my_xcc * 32], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto publish_arrival = [&]() {
-    if (tid == 0) *touch_slot = my_arrival;
+  auto touch_done = [&]() {};
+
+  // ---- prologue staging: parameter groups (and the depthwise conv's weights) go global memory -> LDS by LDS-DMA,
+  // 1 KiB per wave-instruction, lines dealt round-robin to the four waves.  No registers, no wait at the point of
+  // issue: the lines are requested FIRST, the stage's own inputs after them, and since memory operations complete
+  // in issue order a wave's first wait for one of its inputs also covers its DMA lines; the first barrier then
+  // publishes them to the other waves.  (Until round 3 this was a register copy that hipcc serialised into one
+  // global round trip per 16 bytes - load, s_waitcnt vmcnt(0), ds_write, repeat - in front of every other request:
+  // 6 dependent round trips in block<D|A>, next to the returning atomic of the warm-up and a vmcnt(0) for `tlens`.)
+  auto dma_lines = [&](const void* g, unsigned lds_off, int n1k) {
+    const unsigned voff16 = lane * 16;
+#pragma unroll 1
+    for (int j = wave; j < n1k; j += 4) {
+      const unsigned char* p = (const unsigned char*)g + (size_t)j * 1024;
+      const unsigned dst = lds_off + j * 1024;
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, %2\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(voff16), "s"(p), "s"(dst)
+          : "memory");
+    }
   };
 
   // 16 MFMAs of a K unit: out[mi] = C^T[n = nf*16 + lg*4 + r][m = mi*16 + lr]
@@ -380,11 +416,22 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // One barrier per iteration: it publishes H[c & 1] (written an iteration ago) and frees H[(c+1) & 1] (read an
   // iteration ago).  The two H tiles [32][64] alias abuf's first two k-tiles (the activation fragments are in
   // registers by then: the barrier before the first H store sees to that).
+  // (EM_BLOCK_VAR & 4, developer A/B: the chunks of the hidden dimension are visited in an order rotated per utterance,
+  // so the workgroups of an XCD do not all ask the L2 for the same lines at the same moment)
+  const int crot = (EM_BLOCK_VAR & 4) ? (int)((blockIdx.y * 5u) % (unsigned)nch) : 0;
+  auto cm = [&](int c) {
+    if constexpr (EM_BLOCK_VAR & 4) {
+      const int m = c + crot;
+      return m >= nch ? m - nch : m;
+    } else {
+      return c;
+    }
+  };
   auto ffn_pre = [&](const void* w1, const void* w2) {
-    read_unit(w1, 0, ring[0]);
-    read_unit(w2, 0, ring[2]);
-    read_unit(w1, nch > 1 ? 1 : 0, ring[1]);
-    read_unit(w2, nch > 1 ? 1 : 0, ring[3]);
+    read_unit(w1, cm(0), ring[0]);
+    read_unit(w2, cm(0), ring[2]);
+    read_unit(w1, cm(nch > 1 ? 1 : 0), ring[1]);
+    read_unit(w2, cm(nch > 1 ? 1 : 0), ring[3]);
   };
   auto ffn = [&](const float* pb, int b1o, int b2o, float scale, const void* w1, const void* w2) {
     f32x4 acc2[2][4];
@@ -395,7 +442,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     bf16x4 hdbg[2] = {};
     auto h_store = [&](const f32x4 h[2], int c) {
       if constexpr (dbg & 1) return;
-      const float4 bb = *(const float4*)(pb + b1o + c * 64 + ncol);
+      const float4 bb = *(const float4*)(pb + b1o + cm(c < nch ? c : nch - 1) * 64 + ncol);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         bf16x4 pk;
@@ -449,7 +496,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       for (int f = 0; f < 4; ++f) xpark[(mi * 4 + f) * NT] = xr[mi][f];
     f32x4 hp[2];
     mma_k(ring[0], false, hp);                       // h0
-    read_unit(w1, nch > 2 ? 2 : nch - 1, ring[0]);
+    read_unit(w1, cm(nch > 2 ? 2 : nch - 1), ring[0]);
     bar(0);                                          // every wave holds its activation fragments: abuf may become H
     h_store(hp, 0);
     if (nch > 1) mma_k(ring[1], false, hp);          // h1
@@ -459,7 +506,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // degrades to "wait for everything" - the whole point of the ring.
     const int last = nch - 1;
     auto iter = [&](int c, WF& kc2, WF& kc3, WF& wc) {
-      read_unit(w1, c + 3 < nch ? c + 3 : last, kc3);
+      read_unit(w1, cm(c + 3 < nch ? c + 3 : last), kc3);
       if constexpr (!(dbg & 4)) bar(0);
       // No branches from here to the next barrier (the last two iterations store an H nobody reads and compute an h
       // nobody stores): one scheduling region, so that the Swish epilogue's VALU / transcendental instructions can
@@ -469,7 +516,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       h_load(c, hf);
       h_store(hp, c + 1);
       mma_w2(wc, hf);
-      read_unit(w2, c + 2 < nch ? c + 2 : last, wc);
+      read_unit(w2, cm(c + 2 < nch ? c + 2 : last), wc);
       f32x4 hn[2];
       mma_k(kc2, false, hn);                         // h_{c+2}
       // the epilogue is ~64 VALU + 16 quarter-rate transcendental instructions, about the issue time of all 32 MFMAs of
@@ -490,12 +537,69 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       hp[0] = hn[0];
       hp[1] = hn[1];
     };
+    // EM_BLOCK_VAR & 1 (developer A/B): the same iteration with the order written out by hand and pinned (sched_barrier
+    // between groups): 16 groups of two MFMAs, ONE weight request (the W2_{c+2} line that replaces the fragment the
+    // group's MFMAs just consumed, or a K_{c+3} line into the free K buffer) and half an element of the Swish
+    // epilogue; opaque address offsets keep hipcc from collecting the requests into bursts.
+    auto iter2 = [&](int c, WF& kc2, WF& kc3, WF& wc) {
+      bar(0);
+      bf16x8 hf[4];
+      h_load(c, hf);
+      const float4 bb = *(const float4*)(pb + b1o + cm(c + 1 < nch ? c + 1 : last) * 64 + ncol);
+      const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+      GU8 s2 = (GU8)w2 + (size_t)cm(c + 2 < nch ? c + 2 : last) * UNIT + voff;
+      GU8 s1 = (GU8)w1 + (size_t)cm(c + 3 < nch ? c + 3 : last) * UNIT + voff;
+      float t[8];
+      float e[8];
+      unsigned o1 = 0, o2 = 0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {  // W2_c . H[c & 1]: fragment q = 2 f + ks, dead after its two MFMAs
+        const int ks = g >> 2, f = g & 3, q = 2 * f + ks;
+        acc2[0][f] = MM::mma(wc.v[q], hf[2 * ks], acc2[0][f]);
+        acc2[1][f] = MM::mma(wc.v[q], hf[2 * ks + 1], acc2[1][f]);
+        asm volatile("" : "+s"(o2));  // opaque: the request below cannot be hoisted above this point or clustered
+        wc.v[q] = *(GFRAG)(s2 + o2 + q * 1024);
+        float hv = hp[g >> 2][g & 3];
+        asm volatile("" : "+v"(hv));  // opaque: this element's epilogue stays in this group
+        t[g] = hv + bbv[g & 3];
+        e[g] = __expf(-t[g]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x4 cc[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) cc[mi][0] = cc[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {  // K_{c+2} . act -> h_{c+2}
+        cc[0][ks & 1] = MM::mma(kc2.v[ks], act[0][ks], cc[0][ks & 1]);
+        cc[1][ks & 1] = MM::mma(kc2.v[ks], act[1][ks], cc[1][ks & 1]);
+        asm volatile("" : "+s"(o1));
+        kc3.v[ks] = *(GFRAG)(s1 + o1 + ks * 1024);
+        float ev = e[ks];
+        asm volatile("" : "+v"(ev));
+        t[ks] = t[ks] * __builtin_amdgcn_rcpf(1.0f + ev);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        bf16x4 pk = {(bf16)t[mi * 4 + 0], (bf16)t[mi * 4 + 1], (bf16)t[mi * 4 + 2], (bf16)t[mi * 4 + 3]};
+        *(bf16x4*)(abuf + ((c + 1) & 1) * 4096 + mi * 2048 + tile_wr) = pk;  // H[(c+1) & 1]
+      }
+      hp[0] = cc[0][0] + cc[0][1];
+      hp[1] = cc[1][0] + cc[1][1];
+    };
+    fstamp(20);
     int c = 0;
 #pragma unroll 1
     for (; c + 1 < nch; c += 2) {
-      iter(c, ring[0], ring[1], ring[2]);
-      iter(c + 1, ring[1], ring[0], ring[3]);
+      if constexpr ((EM_BLOCK_VAR & 1) && dbg == 0) {
+        iter2(c, ring[0], ring[1], ring[2]);
+        iter2(c + 1, ring[1], ring[0], ring[3]);
+      } else {
+        iter(c, ring[0], ring[1], ring[2]);
+        iter(c + 1, ring[1], ring[0], ring[3]);
+      }
     }
+    fstamp(21);
     if (c < nch) {  // odd chunk count: the last W2 unit
       bar(0);
       bf16x8 hf[4];
@@ -531,23 +635,14 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     });
   };
 
-  // every parameter group of the launch sits in LDS from the start (C: 1 group, A: 2, D|FINAL: 3, D|A: 4)
-  // (all loads first, then all stores: a load -> store loop pays the memory latency once per trip; the stores wait
-  // behind whatever the stage issues next, the first barrier of every mode publishes them)
+  // every parameter group of the launch sits in LDS from the start (C: 1 group, A: 2, D|FINAL: 3, D|A: 4; 7 KiB each),
+  // and with a D part the depthwise conv's weights [31][256] f32 + bias [256]
   {
     constexpr int NG = HAS_C ? 1 : (HAS_D ? (HAS_A ? 4 : 3) : 2);
-    constexpr int PV = NG * (PAR_FLOATS / 4), PIT = (PV + NT - 1) / NT;
-    const float4* src = (const float4*)a.params;
-    float4 pst[PIT];
-#pragma unroll
-    for (int it = 0; it < PIT; ++it) {
-      const int i = tid + it * NT;
-      pst[it] = src[i < PV ? i : PV - 1];
-    }
-#pragma unroll
-    for (int it = 0; it < PIT; ++it) {
-      const int i = tid + it * NT;
-      if (i < PV) ((float4*)par)[i] = pst[it];
+    dma_lines(a.params, PAR_OFF, NG * (PAR_BYTES / 1024));
+    if (HAS_D) {
+      dma_lines(a.dw_w, WK_OFF, KW);
+      dma_lines(a.dw_b, WK_OFF + KW * 1024, 1);
     }
   }
   const float* const pb0 = par;
@@ -564,16 +659,20 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) act[mi][ks] = *(const bf16x8*)(crow + ks * 32);
     }
-    k_pre(a.wout, 4);
     load_x();
-    publish_arrival();
-    bar(0);  // the parameter groups are in LDS
+    k_pre(a.wout, 4);
+    // this wave's parameter lines were requested before the 48 loads above: in LDS once at most 48 are outstanding
+    asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
     touch();
+    bar(0);  // the parameter groups are in LDS
+    fstamp(4);
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
     proj_resid(pb0, 0, a.wout);
+    fstamp(50);
     store_x();
     k_pre(a.pw1f, 8);
     ln_to_act(pb0, 256, 512, 0);
+    fstamp(15);
     // pointwise_conv1 + GLU (convolution.py:66-69): unit 2j = value rows 64j.., unit 2j+1 = their gates
     f32x4 v[2], gt[2];
     stream_k(a.pw1f, std::integral_constant<int, 8>{}, [&](const WF& cur, int u) {
@@ -594,6 +693,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         }
       }
     });
+    fstamp(51);
     touch_done();
     return;
   }
@@ -603,9 +703,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // the 62-row input tile of this block (frames t0 - 15 .. t0 + 46 of the utterance, zero outside
     // [0, Tv)) goes through LDS; thread c (= channel) produces the 32 frames of the block.
     unsigned char* const tile = smem + TILE_OFF;  // [62][256] bf16
-    k_pre(a.pw2, 4);  // pointwise_conv2's first units travel while the convolution runs
-    int Tv = T;
-    if (a.tlens) Tv = a.tlens[b] < T ? a.tlens[b] : T;
+    // ONE burst of requests: (parameter + conv-weight lines by LDS-DMA, above), the 62-row tile, the residual rows, the
+    // first units of pointwise_conv2, the L2 warm-up - and only then the first wait
     uint4 stage[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {  // unconditional loads from a clamped row (a load under a lane mask is
@@ -614,19 +713,55 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
       stage[it] = *(const uint4*)((const bf16*)a.glu + ((size_t)b * T + tc) * D + ch * 8);
     }
-    float wk[KW];  // requested together with the tile: one global-memory latency for the whole prologue
-#pragma unroll
-    for (int k = 0; k < KW; ++k) wk[k] = a.dw_w[k * D + tid];
-    const float bc = a.dw_b[tid];
     load_x();
-    publish_arrival();
+    k_pre(a.pw2, 4);  // pointwise_conv2's first units travel while the convolution runs
+    touch();
+    int Tv = T;
+    if (a.tlens) {  // a scalar load (uniform address), after everything else is on its way
+      int tl;
+      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl) : "s"(a.tlens + b) : "memory");
+      Tv = tl < T ? tl : T;
+    }
+    fstamp(2);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int q = tid + it * NC, t = t0 - HALF + (q >> 5);
       if (q < TROWS * 32) *(uint4*)(tile + q * 16) = (t >= 0 && t < Tv) ? stage[it] : make_uint4(0u, 0u, 0u, 0u);
     }
+    fstamp(3);
     bar(BAR_TILE);
-    touch();
+    fstamp(4);
+    if constexpr (EM_BLOCK_VAR & 16) {
+      // developer A/B: two adjacent channels x 16 frames per thread on packed f32 FMAs (v_pk_fma_f32): half the LDS reads
+      // (one 4-byte word = both channels' bf16), half the FMA instructions
+      const int cp = tid & 127, hh = tid >> 7;
+      f32x2 wk2[KW];
+#pragma unroll
+      for (int k = 0; k < KW; ++k) wk2[k] = *(const f32x2*)(smem + WK_OFF + (k * D + 2 * cp) * 4);
+      const f32x2 bc2 = *(const f32x2*)(smem + WK_OFF + (KW * D + 2 * cp) * 4);
+      f32x2 acc[16];
+#pragma unroll
+      for (int o = 0; o < 16; ++o) acc[o] = bc2;
+#pragma unroll
+      for (int r = 0; r < 16 + KW - 1; ++r) {
+        const unsigned u = *(const unsigned*)(tile + ((hh * 16 + r) * D + 2 * cp) * 2);
+        const f32x2 v = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+          if (r - o >= 0 && r - o < KW) acc[o] = __builtin_elementwise_fma(wk2[r - o], v, acc[o]);
+      }
+      const int ch = 2 * cp, kt = ch >> 6, kl = ch & 63;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) {
+        const int m = hh * 16 + o;
+        bf16x2 pk = {(bf16)swishf_(acc[o][0]), (bf16)swishf_(acc[o][1])};
+        *(bf16x2*)(abuf + (kt * 32 + m) * 128 + (((kl >> 3) ^ (m & 7)) << 4) + (kl & 7) * 2) = pk;
+      }
+    } else {
+    float wk[KW];  // this thread's channel of the depthwise weights (tap-major in LDS: conflict-free)
+#pragma unroll
+    for (int k = 0; k < KW; ++k) wk[k] = ((const float*)(smem + WK_OFF))[k * D + tid];
+    const float bc = ((const float*)(smem + WK_OFF))[KW * D + tid];
     {
       const bf16* col = (const bf16*)tile + tid;
       const int kt = tid >> 6, kl = tid & 63;
@@ -649,17 +784,20 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         }
       }
     }
+    }
+    fstamp(5);
+    fstamp(6);
     bar(0);  // conv output visible
     load_act();
-    stamp();  // 1 conv prologue
+    stamp(7);
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]
     proj_resid(pb0, 0, a.pw2);                     // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
-    stamp();  // 2
+    stamp(10);
     ffn_pre(a.ff_w1, a.ff_w2);
     ln_to_act(pb0, 256, 512, 0);                   // norm_ff
-    stamp();  // 3
+    stamp(15);
     ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2);     // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
-    stamp();  // 4
+    stamp(22);
     {
       float4 y[2][4];
       ln_apply(pb1, 1280, 1536, y, 0);             // norm_final (encoder_layer.py:170-171): the block's output
@@ -780,20 +918,19 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // GA+1 (buffer 1): [norm_mha g 256][b 256][bq | bk | bv 768]
     // norm_ff_macaron.  After a D part, buffer 1 still holds G1 (norm_final read it just before this
     // LayerNorm's first barrier): its successor may come in at this LayerNorm's last barrier.
-    stamp();  // 5 norm_final
+    stamp(30);
     const float* const pa0 = HAS_D ? pb2 : pb0;  // GA
     const float* const pa1 = HAS_D ? pb3 : pb1;  // GA + 1
     ffn_pre(a.ffm_w1, a.ffm_w2);
-    if (!HAS_D) publish_arrival();
-    ln_to_act(pa0, 0, 256, 0);
     if (!HAS_D) touch();
-    stamp();  // 6 norm_ff_macaron
+    ln_to_act(pa0, 0, 256, 0);
+    stamp(15);
     ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2); // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
-    stamp();  // 7 macaron FFN
+    stamp(22);
     store_x();
     k_pre(a.wqkv, 12);
     ln_to_act(pa1, 0, 256, 0);                     // norm_mha (encoder_layer.py:123-127)
-    stamp();  // 8 norm_mha
+    stamp(15);
     // q / k / v projections (attention.py:91-97), written per head: Q, K as [B][H][Tpad][64], V transposed
     // as [B][H][64][Tpad] (computed with the MFMA operands swapped so a lane holds 4 consecutive frames).
     const int H = D / 64;
@@ -820,7 +957,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         }
       }
     });
-    stamp();  // 9 q k v
+    stamp(40);
   }
   touch_done();
 }
@@ -832,15 +969,19 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
   dim3 grid(em_cdiv(a->T, BM), a->B);
   static long long* stamps = nullptr;
   static const bool want_stamps = getenv("EM_BLOCK_STAMPS") != nullptr;
-  if (want_stamps && !stamps) hipMalloc((void**)&stamps, 64 * sizeof(long long));
-  if (want_stamps) hipMemsetAsync(stamps, 0, 64 * sizeof(long long), s);
+  if (want_stamps && !stamps) hipMalloc((void**)&stamps, 256 * sizeof(long long));
+  if (want_stamps) hipMemsetAsync(stamps, 0, 256 * sizeof(long long), s);
   hipLaunchKernelGGL((block_kernel<MODE>), grid, dim3(NT), SMEM_BYTES, s, *a, stamps);
   if (want_stamps) {
-    long long h[64];
+    long long h[256];
     hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
-    printf("[block<%d> stamps, cycles since kernel start]", MODE);
-    for (int i = 1; i < 64 && h[i]; ++i) printf(" %lld", h[i] - h[0]);
-    printf("\n");
+    const long long M56 = 0xffffffffffffffll;
+    for (int wv = 0; wv < (EM_BLOCK_FINE ? 4 : 1); ++wv) {
+      printf("[block<%d> wave %d stamps code:cycles since entry]", MODE, wv);
+      for (int i = 0; i < 64 && h[wv * 64 + i]; ++i)
+        printf(" %d:%lld", (int)(h[wv * 64 + i] >> 56), (h[wv * 64 + i] & M56) - (h[wv * 64] & M56));
+      printf("\n");
+    }
     fflush(stdout);
   }
   EM_CHECK_LAUNCH();
