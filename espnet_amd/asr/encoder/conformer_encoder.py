@@ -115,13 +115,30 @@ def pack_k_units(w: torch.Tensor) -> torch.Tensor:
     return w.detach().reshape(n // 64, 4, 16, 8, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().reshape(n, k)
 
 
+def _pad_chunks(ff: int) -> int:
+    """FFN width as the fused kernel walks it: whole PAIRS of 64-wide chunks."""
+    assert ff % 64 == 0, ff
+    return (ff + 127) // 128 * 128
+
+
+def pack_w1(w: torch.Tensor) -> torch.Tensor:
+    """First matrix of an FFN, [ff][256] -> K units, zero-padded to an even number of 64-row chunks (the padded
+    chunk's hidden activation is swish(0 + 0) = 0 and meets zero columns of w_2)."""
+    ff = w.shape[0]
+    return pack_k_units(torch.nn.functional.pad(w.detach(), (0, 0, 0, _pad_chunks(ff) - ff)))
+
+
 def pack_w2(w: torch.Tensor) -> torch.Tensor:
-    """[256][ff] -> [ff/64] fragment-major "W2 units": unit c is the 64-deep K slice w[:, 64 c : 64 c + 64] laid out
-    [nf][f][ks][lg][lr][e] = w[64 f + 16 nf + lr][64 c + 32 ks + 8 lg + e]."""
+    """Second matrix of an FFN, [256][ff] -> 64 KiB per pair of hidden chunks in the order the kernel's waves hold the
+    hidden activation (include/espnet_amd.h, EmBlockArgs):
+    pair[p][w][f][lg][lr][e] = W[16 f + lr][64 (2 p + (e >> 2)) + 16 w + 4 lg + (e & 3)]."""
     d, ff = w.shape
     assert d == 256 and ff % 64 == 0, (d, ff)
-    u = w.detach().reshape(d, ff // 64, 64).permute(1, 0, 2)  # [c][256][64]
-    return u.reshape(ff // 64, 4, 4, 16, 2, 4, 8).permute(0, 2, 1, 4, 5, 3, 6).contiguous().reshape(ff // 64, d, 64)
+    ffp = _pad_chunks(ff)
+    wp = torch.nn.functional.pad(w.detach(), (0, ffp - ff))
+    # [o = 16 f + lr][hidden = 128 p + 64 ci + 16 wv + 4 lg + r] -> [p][wv][f][lg][lr][ci][r]
+    u = wp.reshape(16, 16, ffp // 128, 2, 4, 4, 4).permute(2, 4, 0, 5, 1, 3, 6).contiguous()
+    return u.reshape(ffp // 128, 4 * 16 * 64 * 8)
 
 
 def rel_pos_table(T: int, d: int) -> torch.Tensor:
@@ -366,8 +383,8 @@ class ConformerEncoder(torch.nn.Module):
                       ff_w2p=A(pack_w2(l.feed_forward.w_2.weight)),
                       woutp=A(pack_k_units(sa.linear_out.weight)),
                       pw2p=A(pack_k_units(cm.pointwise_conv2.weight.reshape(d, d))),
-                      ff_w1p=A(pack_k_units(l.feed_forward.w_1.weight)),
-                      ffm_w1p=A(pack_k_units(l.feed_forward_macaron.w_1.weight)),
+                      ff_w1p=A(pack_w1(l.feed_forward.w_1.weight)),
+                      ffm_w1p=A(pack_w1(l.feed_forward_macaron.w_1.weight)),
                       wqkvp=A(pack_k_units(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0))),
                       fp_c=F(group(l.self_attn.linear_out.bias, l.norm_conv.weight, l.norm_conv.bias,
                                    cm.pointwise_conv1.bias[perm])),

@@ -53,16 +53,19 @@ constexpr int BM = 32;
 constexpr int NT = 256;                      // threads per workgroup: 4 waves, wave w = 16-column slice nf = w
 constexpr int NC = 256;
 constexpr int UNIT = 32768;                  // bytes of one weight unit (64 rows x K = 256, or 256 rows x 64-deep K slice)
-constexpr int TILE_OFF = 0;                  // 32 KiB: the depthwise conv's 62-row input tile
-constexpr int ABUF_OFF = TILE_OFF + 32768;   // 16 KiB: LN(x) as four [32][64] k-tiles; the FFN's two H tiles alias tiles 0, 1
-constexpr int RED_OFF = ABUF_OFF + 16384;    // 2 x 1 KiB: LayerNorm partials [2][4][32], alternating between consecutive LayerNorms
-constexpr int PAR_OFF = RED_OFF + 2048;      // up to 4 x 7 KiB: every bias / LayerNorm group of the launch
 constexpr int PAR_FLOATS = EM_BLOCK_PARAM_GROUP;
 constexpr int PAR_BYTES = PAR_FLOATS * 4;
 constexpr int MAX_GROUPS = 4;
-constexpr int TOUCH_OFF = PAR_OFF + MAX_GROUPS * PAR_BYTES;  // 1 KiB: where the L2 warm-up's LDS-DMA lands (never read)
-constexpr int WK_OFF = TOUCH_OFF + 1024;     // 32 KiB: depthwise conv weights [31][256] f32 (tap-major) + bias [256]
-constexpr int SMEM_BYTES = WK_OFF + 32768;   // 111 KiB
+constexpr int PAR_OFF = 0;                                   // up to 4 x 7 KiB: every bias / LayerNorm group of the launch
+constexpr int RED_OFF = PAR_OFF + MAX_GROUPS * PAR_BYTES;    // 2 x 1 KiB: LayerNorm partials [2][4][32], alternating between consecutive LayerNorms
+constexpr int TOUCH_OFF = RED_OFF + 2048;                    // 1 KiB: where the L2 warm-up's LDS-DMA lands (never read)
+constexpr int TILE_OFF = TOUCH_OFF + 1024;                   // 32 KiB: the depthwise conv's 62-row input tile; during an FFN the parked residual
+constexpr int ABUF_OFF = TILE_OFF + 32768;                   // 16 KiB: LN(x) as four [32][64] k-tiles
+constexpr int WK_OFF = ABUF_OFF + 16384;                     // 32 KiB: depthwise conv weights [31][256] f32 (tap-major) + bias [256]
+constexpr int XCH_OFF = WK_OFF + 32768;                      // 48 KiB more: with ABUF and WK the 96 KiB of the FFN's cross-wave reduction
+constexpr int XSLOT = 8192;                                  // one (destination wave, source wave) slot: [4 fragments][2 halves][64 lanes] f32x4
+constexpr int SMEM_BYTES = XCH_OFF + 49152;                  // 159 KiB
+static_assert(ABUF_OFF % 1024 == 0 && TILE_OFF % 1024 == 0 && SMEM_BYTES <= 160 * 1024, "LDS layout");
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile
 
 // weight units are read through GLOBAL-address-space pointers: through a generic pointer the loads become flat_load,
@@ -82,8 +85,8 @@ constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;  // what
 #endif
 
 #ifndef EM_BLOCK_VAR
-#define EM_BLOCK_VAR 0  // developer A/B builds (tools/build_block_variants.sh): 1 pinned-group FFN iteration, 2 inputs requested
-#endif                  // before parameters / weights in the D prologue, 4 FFN chunk order rotated per utterance
+#define EM_BLOCK_VAR 0  // developer A/B builds (tools/build_block_variants.sh): 16 = packed-f32 depthwise conv
+#endif
 #ifndef EM_BLOCK_FINE
 #define EM_BLOCK_FINE 0  // 1: EM_BLOCK_STAMPS records every wave of workgroup (3, 5) at sub-stage granularity
 #endif
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   const int swz = lr & 7;
   // byte offset of (frame lr, columns ncol .. ncol + 3) inside a [32][64] bf16 k-tile of abuf (+ 2048 for frame 16 + lr)
   const int tile_wr = lr * 128 + (((2 * nf + (lg >> 1)) ^ swz) << 4) + (lg & 1) * 8;
-  const int nch = a.ff >> 6;  // 64-wide chunks of the FFN hidden dimension
+  const int nch = ((a.ff >> 6) + 1) & ~1;  // 64-wide chunks of the FFN hidden dimension, rounded up to whole PAIRS (the host pads with a zero chunk)
   // developer profiling (EM_BLOCK_STAMPS / EM_BLOCK_DBG, tools/block_bench.py): stage-level cycle stamps of thread 0
   // of workgroup (0, 0); dbg 1 = no MFMA / epilogue work, dbg 2 = no DMA
   int nts = 0;
@@ -408,215 +411,137 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     out[0] = c[0][0] + c[0][1];
     out[1] = c[1][0] + c[1][1];
   };
-  // x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o.  K_c = rows 64 c .. of W1 (a K
-  // unit), W2_c = the 64-deep slice c of W2.  ring[0], ring[1] alternate the K units, ring[2], ring[3] the W2 units;
-  // ffn_pre() has requested K0, K1, W2_0, W2_1.  Iteration c:
-  //     request K_{c+3} | barrier | Swish(h_{c+1}) -> H[(c+1) & 1] | mma W2_c (H[c & 1]) | request W2_{c+2} | mma K_{c+2} -> h_{c+2}
-  // so a K unit is requested ~1.5 iterations (3 units of work) before its MFMAs and a W2 unit two iterations before.
-  // One barrier per iteration: it publishes H[c & 1] (written an iteration ago) and frees H[(c+1) & 1] (read an
-  // iteration ago).  The two H tiles [32][64] alias abuf's first two k-tiles (the activation fragments are in
-  // registers by then: the barrier before the first H store sees to that).
-  // (EM_BLOCK_VAR & 4, developer A/B: the chunks of the hidden dimension are visited in an order rotated per utterance,
-  // so the workgroups of an XCD do not all ask the L2 for the same lines at the same moment)
-  const int crot = (EM_BLOCK_VAR & 4) ? (int)((blockIdx.y * 5u) % (unsigned)nch) : 0;
-  auto cm = [&](int c) {
-    if constexpr (EM_BLOCK_VAR & 4) {
-      const int m = c + crot;
-      return m >= nch ? m - nch : m;
-    } else {
-      return c;
-    }
+  // ---- FFN: x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o -------------------------
+  // Round 3: the hidden activation never leaves the wave that computed it.  Wave w owns the 16 hidden columns
+  // 16 w .. 16 w + 15 of every 64-wide chunk c (the K unit c of W1: 16 MFMAs over K = 256, as before).  In the
+  // transposed orientation its lane (lr, lg) ends up with h[frame lr][hidden 4 lg .. 4 lg + 3] - and that is exactly
+  // a B-operand fragment of the second GEMM if the contraction index of that GEMM is ORDERED to match: for a PAIR
+  // of chunks (2p, 2p + 1) the wave's 32-deep K slice is k = 8 lg + j  <->  hidden 64 (2p + (j >> 2)) + 16 w + 4 lg
+  // + (j & 3), i.e. the lane's own eight values (bias + Swish + bf16 in registers, no LDS, no barrier).  The host
+  // packs W2 in that order (pack_w2_pairs): per pair and wave 16 output fragments x 1 KiB = two 8 KiB sub-units.
+  // Every wave therefore accumulates a partial sum of ALL 256 output columns over its own quarter of the hidden
+  // dimension (16 x 2 accumulator fragments: AGPRs) and the four partials meet ONCE per FFN in LDS.  Until round 3
+  // the four waves shared every chunk's H through LDS tiles: a barrier, an LDS round trip and a Swish epilogue per
+  // 64-wide chunk, 16 times per FFN - stage stamps put that at ~400 of the 1 600 cycles per iteration, and the
+  // barrier made every wave wait for the slowest wave's weight lines every 32 MFMAs (profiles/r03a_*).
+  // The weight stream is unchanged in bytes: per pair and wave 2 x 8 KiB of W1 (ring[0], ring[1]) and 2 x 8 KiB of
+  // W2 (ring[2], ring[3]); a ring slot is refilled as soon as its 16 MFMAs are issued, i.e. requested one whole
+  // iteration (64 MFMAs) ahead of its use.  The host pads odd chunk counts with a zero chunk (nch is even here).
+  auto read_w2 = [&](const void* w2, int p, int half, WF& w) {
+    GU8 su = (GU8)w2 + (size_t)p * (2 * UNIT) + nf * 16384 + half * 8192 + lane * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w.v[q] = *(GFRAG)(su + q * 1024);
   };
   auto ffn_pre = [&](const void* w1, const void* w2) {
-    read_unit(w1, cm(0), ring[0]);
-    read_unit(w2, cm(0), ring[2]);
-    read_unit(w1, cm(nch > 1 ? 1 : 0), ring[1]);
-    read_unit(w2, cm(nch > 1 ? 1 : 0), ring[3]);
+    read_unit(w1, 0, ring[0]);
+    read_unit(w1, 1, ring[1]);
+    read_w2(w2, 0, 0, ring[2]);
+    read_w2(w2, 0, 1, ring[3]);
   };
   auto ffn = [&](const float* pb, int b1o, int b2o, float scale, const void* w1, const void* w2) {
-    f32x4 acc2[2][4];
+    const int np = nch >> 1, lastc = nch - 1;
+    f32x4 acc2[16][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int f = 0; f < 4; ++f) acc2[mi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x4 hdbg[2] = {};
-    auto h_store = [&](const f32x4 h[2], int c) {
-      if constexpr (dbg & 1) return;
-      const float4 bb = *(const float4*)(pb + b1o + cm(c < nch ? c : nch - 1) * 64 + ncol);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        bf16x4 pk;
-        if constexpr (dbg & 16)
-          pk = (bf16x4){(bf16)(h[mi][0] + bb.x), (bf16)(h[mi][1] + bb.y), (bf16)(h[mi][2] + bb.z), (bf16)(h[mi][3] + bb.w)};
-        else
-          pk = (bf16x4){(bf16)swishf_(h[mi][0] + bb.x), (bf16)swishf_(h[mi][1] + bb.y),
-                        (bf16)swishf_(h[mi][2] + bb.z), (bf16)swishf_(h[mi][3] + bb.w)};
-        if constexpr (dbg & 8)
-          hdbg[mi] = pk;
-        else
-          *(bf16x4*)(abuf + (c & 1) * 4096 + mi * 2048 + tile_wr) = pk;  // H[c & 1][m][k = ncol ..]
-      }
-    };
-    // the W2 MFMAs of chunk c: H[c & 1] fragments LDS -> registers (h_load), then 16 MFMAs (mma_w2).  Two steps so
-    // that the LDS reads can be placed BEFORE the H store of the same interval in program order: hipcc cannot prove
-    // that the store (H[(c+1) & 1]) and the reads (H[c & 1]) do not alias, and reads placed after the store would
-    // chain the MFMAs behind the whole Swish epilogue.
-    auto h_load = [&](int c, bf16x8 hf[4]) {
-      if constexpr (dbg & 8) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          hf[i] = (bf16x8){hdbg[0][0], hdbg[0][1], hdbg[0][2], hdbg[0][3], hdbg[1][0], hdbg[1][1], hdbg[1][2], hdbg[1][3]};
-        return;
-      }
-      const unsigned char* sh = abuf + (c & 1) * 4096 + lr * 128;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int coff = ((ks * 4 + lg) ^ swz) << 4;
-        hf[2 * ks] = *(const bf16x8*)(sh + coff);
-        hf[2 * ks + 1] = *(const bf16x8*)(sh + 2048 + coff);
-      }
-    };
-    auto mma_w2 = [&](const WF& w, const bf16x8 hf[4]) {
-      if constexpr (dbg & 1) return;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          acc2[0][f] = MM::mma(w.v[2 * f + ks], hf[2 * ks], acc2[0][f]);
-          acc2[1][f] = MM::mma(w.v[2 * f + ks], hf[2 * ks + 1], acc2[1][f]);
-        }
-    };
+    for (int f = 0; f < 16; ++f) acc2[f][0] = acc2[f][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // the residual is not needed until the end: its 32 registers are parked in LDS (the conv tile's space, lane-major:
-    // conflict-free, private to the lane, no barrier) so that ring + activations + accumulators stay in the 256
-    // architectural VGPRs
+    // conflict-free, private to the lane, no barrier)
     float4* const xpark = (float4*)(smem + TILE_OFF) + tid;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int f = 0; f < 4; ++f) xpark[(mi * 4 + f) * NT] = xr[mi][f];
-    f32x4 hp[2];
-    mma_k(ring[0], false, hp);                       // h0
-    read_unit(w1, cm(nch > 2 ? 2 : nch - 1), ring[0]);
-    bar(0);                                          // every wave holds its activation fragments: abuf may become H
-    h_store(hp, 0);
-    if (nch > 1) mma_k(ring[1], false, hp);          // h1
-    // kc2 holds K_{c+2}, kc3 receives K_{c+3}, wc holds W2_c and receives W2_{c+2}
+    // bias + Swish + bf16 of the two chunks' 16 hidden columns of this wave -> the B fragments of the pair
+    auto swish_pack = [&](const f32x4 h[2][2], int p, bf16x8 hb[2]) {
+      const float4 b0 = *(const float4*)(pb + b1o + (2 * p) * 64 + ncol);
+      const float4 b1 = *(const float4*)(pb + b1o + (2 * p + 1) * 64 + ncol);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        hb[mi] = (bf16x8){(bf16)swishf_(h[0][mi][0] + b0.x), (bf16)swishf_(h[0][mi][1] + b0.y),
+                          (bf16)swishf_(h[0][mi][2] + b0.z), (bf16)swishf_(h[0][mi][3] + b0.w),
+                          (bf16)swishf_(h[1][mi][0] + b1.x), (bf16)swishf_(h[1][mi][1] + b1.y),
+                          (bf16)swishf_(h[1][mi][2] + b1.z), (bf16)swishf_(h[1][mi][3] + b1.w)};
+    };
+    // 16 MFMAs of a W2 sub-unit: output fragments 8 half .. 8 half + 7, both frame halves
+    auto mma_w2 = [&](const WF& w, int half, const bf16x8 hb[2]) {
+      if constexpr (dbg & 1) return;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        acc2[half * 8 + q][0] = MM::mma(w.v[q], hb[0], acc2[half * 8 + q][0]);
+        acc2[half * 8 + q][1] = MM::mma(w.v[q], hb[1], acc2[half * 8 + q][1]);
+      }
+    };
+    f32x4 h[2][2];
+    bf16x8 hb[2];
+    mma_k(ring[0], false, h[0]);
+    read_unit(w1, 2 < nch ? 2 : lastc, ring[0]);
+    mma_k(ring[1], false, h[1]);
+    read_unit(w1, 3 < nch ? 3 : lastc, ring[1]);
+    swish_pack(h, 0, hb);
+    // every wave holds its activation fragments and has read the conv weights: ABUF / WK may receive partial sums
+    // from a wave that finishes early (the only barrier of the FFN besides the reduction's)
+    bar(0);
+    fstamp(20);
     // The requests are UNCONDITIONAL (past the end they repeat the last unit, which nobody waits for): a load under
     // a branch makes hipcc's wait-count pass assume it may not have been issued, and every wait for an older load
     // degrades to "wait for everything" - the whole point of the ring.
-    const int last = nch - 1;
-    auto iter = [&](int c, WF& kc2, WF& kc3, WF& wc) {
-      read_unit(w1, cm(c + 3 < nch ? c + 3 : last), kc3);
-      if constexpr (!(dbg & 4)) bar(0);
-      // No branches from here to the next barrier (the last two iterations store an H nobody reads and compute an h
-      // nobody stores): one scheduling region, so that the Swish epilogue's VALU / transcendental instructions can
-      // be dealt into the issue gaps between the W2 MFMAs (left alone hipcc emits the whole epilogue, then the
-      // MFMAs: serial on a single wave per SIMD).  LDS reads (bias, H fragments) first, LDS writes last.
-      bf16x8 hf[4];
-      h_load(c, hf);
-      h_store(hp, c + 1);
-      mma_w2(wc, hf);
-      read_unit(w2, cm(c + 2 < nch ? c + 2 : last), wc);
-      f32x4 hn[2];
-      mma_k(kc2, false, hn);                         // h_{c+2}
-      // the epilogue is ~64 VALU + 16 quarter-rate transcendental instructions, about the issue time of all 32 MFMAs of
-      // the iteration: spread it over both MFMA groups
-      __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-#pragma unroll
-      for (int i_ = 0; i_ < 16; ++i_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
-#pragma unroll
-      for (int i_ = 0; i_ < 16; ++i_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-      hp[0] = hn[0];
-      hp[1] = hn[1];
-    };
-    // EM_BLOCK_VAR & 1 (developer A/B): the same iteration with the order written out by hand and pinned (sched_barrier
-    // between groups): 16 groups of two MFMAs, ONE weight request (the W2_{c+2} line that replaces the fragment the
-    // group's MFMAs just consumed, or a K_{c+3} line into the free K buffer) and half an element of the Swish
-    // epilogue; opaque address offsets keep hipcc from collecting the requests into bursts.
-    auto iter2 = [&](int c, WF& kc2, WF& kc3, WF& wc) {
-      bar(0);
-      bf16x8 hf[4];
-      h_load(c, hf);
-      const float4 bb = *(const float4*)(pb + b1o + cm(c + 1 < nch ? c + 1 : last) * 64 + ncol);
-      const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
-      GU8 s2 = (GU8)w2 + (size_t)cm(c + 2 < nch ? c + 2 : last) * UNIT + voff;
-      GU8 s1 = (GU8)w1 + (size_t)cm(c + 3 < nch ? c + 3 : last) * UNIT + voff;
-      float t[8];
-      float e[8];
-      unsigned o1 = 0, o2 = 0;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {  // W2_c . H[c & 1]: fragment q = 2 f + ks, dead after its two MFMAs
-        const int ks = g >> 2, f = g & 3, q = 2 * f + ks;
-        acc2[0][f] = MM::mma(wc.v[q], hf[2 * ks], acc2[0][f]);
-        acc2[1][f] = MM::mma(wc.v[q], hf[2 * ks + 1], acc2[1][f]);
-        asm volatile("" : "+s"(o2));  // opaque: the request below cannot be hoisted above this point or clustered
-        wc.v[q] = *(GFRAG)(s2 + o2 + q * 1024);
-        float hv = hp[g >> 2][g & 3];
-        asm volatile("" : "+v"(hv));  // opaque: this element's epilogue stays in this group
-        t[g] = hv + bbv[g & 3];
-        e[g] = __expf(-t[g]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      f32x4 cc[2][2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) cc[mi][0] = cc[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {  // K_{c+2} . act -> h_{c+2}
-        cc[0][ks & 1] = MM::mma(kc2.v[ks], act[0][ks], cc[0][ks & 1]);
-        cc[1][ks & 1] = MM::mma(kc2.v[ks], act[1][ks], cc[1][ks & 1]);
-        asm volatile("" : "+s"(o1));
-        kc3.v[ks] = *(GFRAG)(s1 + o1 + ks * 1024);
-        float ev = e[ks];
-        asm volatile("" : "+v"(ev));
-        t[ks] = t[ks] * __builtin_amdgcn_rcpf(1.0f + ev);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        bf16x4 pk = {(bf16)t[mi * 4 + 0], (bf16)t[mi * 4 + 1], (bf16)t[mi * 4 + 2], (bf16)t[mi * 4 + 3]};
-        *(bf16x4*)(abuf + ((c + 1) & 1) * 4096 + mi * 2048 + tile_wr) = pk;  // H[(c+1) & 1]
-      }
-      hp[0] = cc[0][0] + cc[0][1];
-      hp[1] = cc[1][0] + cc[1][1];
-    };
-    fstamp(20);
-    int c = 0;
 #pragma unroll 1
-    for (; c + 1 < nch; c += 2) {
-      if constexpr ((EM_BLOCK_VAR & 1) && dbg == 0) {
-        iter2(c, ring[0], ring[1], ring[2]);
-        iter2(c + 1, ring[1], ring[0], ring[3]);
-      } else {
-        iter(c, ring[0], ring[1], ring[2]);
-        iter(c + 1, ring[1], ring[0], ring[3]);
-      }
+    for (int p = 0; p + 1 < np; ++p) {
+      mma_k(ring[0], false, h[0]);                             // chunk 2p + 2
+      read_unit(w1, 2 * p + 4 < nch ? 2 * p + 4 : lastc, ring[0]);
+      mma_k(ring[1], false, h[1]);                             // chunk 2p + 3
+      read_unit(w1, 2 * p + 5 < nch ? 2 * p + 5 : lastc, ring[1]);
+      mma_w2(ring[2], 0, hb);                                  // pair p
+      read_w2(w2, p + 1, 0, ring[2]);
+      mma_w2(ring[3], 1, hb);
+      read_w2(w2, p + 1, 1, ring[3]);
+      swish_pack(h, p + 1, hb);
     }
+    mma_w2(ring[2], 0, hb);                                    // the last pair
+    mma_w2(ring[3], 1, hb);
     fstamp(21);
-    if (c < nch) {  // odd chunk count: the last W2 unit
-      bar(0);
-      bf16x8 hf[4];
-      h_load(c, hf);
-      mma_w2(ring[2], hf);
-    }
+    // ---- the four partial sums meet: wave w keeps the output fragments f = 4 f4 + w (its columns of the residual
+    // layout) and hands the other twelve to their owners through 8 KiB slots (destination, source); summed in wave
+    // order 0, 1, 2, 3 whatever the arrival order: deterministic
+    auto reduce_as = [&](auto nfc) {
+      constexpr int NF = decltype(nfc)::value;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const float4 b4 = *(const float4*)(pb + b2o + 64 * f + ncol);
+      for (int dst = 0; dst < 4; ++dst) {
+        if (dst == NF) continue;
+        unsigned char* slot = smem + ABUF_OFF + (dst * 3 + (NF > dst ? NF - 1 : NF)) * XSLOT + lane * 16;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        xr[mi][f] = xpark[(mi * 4 + f) * NT];
-        xr[mi][f].x += scale * (acc2[mi][f][0] + b4.x);
-        xr[mi][f].y += scale * (acc2[mi][f][1] + b4.y);
-        xr[mi][f].z += scale * (acc2[mi][f][2] + b4.z);
-        xr[mi][f].w += scale * (acc2[mi][f][3] + b4.w);
+        for (int f4 = 0; f4 < 4; ++f4)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) *(f32x4*)(slot + (f4 * 2 + mi) * 1024) = acc2[4 * f4 + dst][mi];
       }
+      bar(0);
+#pragma unroll
+      for (int f4 = 0; f4 < 4; ++f4) {
+        const float4 b4 = *(const float4*)(pb + b2o + 64 * f4 + ncol);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          f32x4 sum;
+          bool first = true;
+#pragma unroll
+          for (int src = 0; src < 4; ++src) {
+            f32x4 v;
+            if (src == NF) v = acc2[4 * f4 + NF][mi];
+            else v = *(const f32x4*)(smem + ABUF_OFF + (NF * 3 + (src > NF ? src - 1 : src)) * XSLOT + lane * 16 + (f4 * 2 + mi) * 1024);
+            sum = first ? v : sum + v;
+            first = false;
+          }
+          xr[mi][f4] = xpark[(mi * 4 + f4) * NT];
+          xr[mi][f4].x += scale * (sum[0] + b4.x);
+          xr[mi][f4].y += scale * (sum[1] + b4.y);
+          xr[mi][f4].z += scale * (sum[2] + b4.z);
+          xr[mi][f4].w += scale * (sum[3] + b4.w);
+        }
+      }
+    };
+    switch (nf) {
+      case 0: reduce_as(std::integral_constant<int, 0>{}); break;
+      case 1: reduce_as(std::integral_constant<int, 1>{}); break;
+      case 2: reduce_as(std::integral_constant<int, 2>{}); break;
+      default: reduce_as(std::integral_constant<int, 3>{}); break;
     }
   };
   // x += (W . act + bias): four K units (N = 256), requested by k_pre(w, 4)
@@ -635,15 +560,18 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     });
   };
 
-  // every parameter group of the launch sits in LDS from the start (C: 1 group, A: 2, D|FINAL: 3, D|A: 4; 7 KiB each),
-  // and with a D part the depthwise conv's weights [31][256] f32 + bias [256]
-  {
-    constexpr int NG = HAS_C ? 1 : (HAS_D ? (HAS_A ? 4 : 3) : 2);
+  // every parameter group of the launch goes to LDS once (C: 1 group, A: 2, D|FINAL: 3, D|A: 4; 7 KiB each), and with a
+  // D part the depthwise conv's weights [31][256] f32 + bias [256].  With a D part the conv's own inputs go FIRST (its
+  // weights here, the tile below) and everything the conv does not need is requested behind the tile barrier, to
+  // travel while the conv computes: per-wave stamps (profiles/r03a_block_stamps_fine.txt) showed the workgroup
+  // sitting 7 500 cycles in the ISSUE of one 240 KiB burst (every CU of the chip asks at once: ~33 B/clk per CU)
+  // before the conv could start on the 64 KiB it actually needs.
+  constexpr int NG = HAS_C ? 1 : (HAS_D ? (HAS_A ? 4 : 3) : 2);
+  if (HAS_D) {
+    dma_lines(a.dw_w, WK_OFF, KW);
+    dma_lines(a.dw_b, WK_OFF + KW * 1024, 1);
+  } else {
     dma_lines(a.params, PAR_OFF, NG * (PAR_BYTES / 1024));
-    if (HAS_D) {
-      dma_lines(a.dw_w, WK_OFF, KW);
-      dma_lines(a.dw_b, WK_OFF + KW * 1024, 1);
-    }
   }
   const float* const pb0 = par;
   const float* const pb1 = par + PAR_FLOATS;
@@ -659,8 +587,11 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) act[mi][ks] = *(const bf16x8*)(crow + ks * 32);
     }
+    read_unit(a.wout, 0, ring[0]);
+    __builtin_amdgcn_sched_barrier(0);  // what the first MFMAs wait for goes first (left alone hipcc requests unit 0 last)
     load_x();
-    k_pre(a.wout, 4);
+    read_unit(a.wout, 1, ring[1]);
+    read_unit(a.wout, 2, ring[2]);
     // this wave's parameter lines were requested before the 48 loads above: in LDS once at most 48 are outstanding
     asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
     touch();
@@ -703,8 +634,6 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // the 62-row input tile of this block (frames t0 - 15 .. t0 + 46 of the utterance, zero outside
     // [0, Tv)) goes through LDS; thread c (= channel) produces the 32 frames of the block.
     unsigned char* const tile = smem + TILE_OFF;  // [62][256] bf16
-    // ONE burst of requests: (parameter + conv-weight lines by LDS-DMA, above), the 62-row tile, the residual rows, the
-    // first units of pointwise_conv2, the L2 warm-up - and only then the first wait
     uint4 stage[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {  // unconditional loads from a clamped row (a load under a lane mask is
@@ -713,11 +642,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
       stage[it] = *(const uint4*)((const bf16*)a.glu + ((size_t)b * T + tc) * D + ch * 8);
     }
-    load_x();
-    k_pre(a.pw2, 4);  // pointwise_conv2's first units travel while the convolution runs
-    touch();
     int Tv = T;
-    if (a.tlens) {  // a scalar load (uniform address), after everything else is on its way
+    if (a.tlens) {  // a scalar load (uniform address), behind the tile requests
       int tl;
       asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl) : "s"(a.tlens + b) : "memory");
       Tv = tl < T ? tl : T;
@@ -729,8 +655,14 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       if (q < TROWS * 32) *(uint4*)(tile + q * 16) = (t >= 0 && t < Tv) ? stage[it] : make_uint4(0u, 0u, 0u, 0u);
     }
     fstamp(3);
-    bar(BAR_TILE);
+    bar(BAR_TILE);  // (the conv-weight lines were requested before the tile: a wave that has its tile rows has them too)
     fstamp(4);
+    // behind the conv: the parameter groups, the residual rows, pointwise_conv2's first units, the L2 warm-up
+    dma_lines(a.params, PAR_OFF, NG * (PAR_BYTES / 1024));
+    load_x();
+    k_pre(a.pw2, 4);
+    touch();
+    __builtin_amdgcn_sched_barrier(0);  // requests first, convolution after: hipcc must not sink them into it
     if constexpr (EM_BLOCK_VAR & 16) {
       // developer A/B: two adjacent channels x 16 frames per thread on packed f32 FMAs (v_pk_fma_f32): half the LDS reads
       // (one 4-byte word = both channels' bf16), half the FMA instructions
@@ -787,7 +719,10 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     }
     fstamp(5);
     fstamp(6);
-    bar(0);  // conv output visible
+    // this wave's parameter lines were requested before the 32 loads of x and pointwise_conv2: landed once at most 32 are
+    // outstanding (the barrier then publishes them with the conv output)
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    bar(0);  // conv output + parameter groups visible
     load_act();
     stamp(7);
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]

@@ -236,7 +236,7 @@ typedef struct EmConformerLayer {
   /* every matrix below is bf16 in FRAGMENT-MAJOR 32 KiB units (see EmBlockArgs): a wave's MFMA weight operand is
    * one contiguous 1 KiB line, lane l reading bytes [16 l, 16 l + 16) */
   const void* pw1f;      /* [2d][d]: pointwise_conv1 rows in 64-row granules [v0..63, g0..63, v64..127, ...], K units */
-  const void *ffm_w2p, *ff_w2p; /* [ff/64] W2 units: w_2 of the two FFNs in 64-deep K slices */
+  const void *ffm_w2p, *ff_w2p; /* w_2 of the two FFNs, packed per pair of hidden chunks (EmBlockArgs) */
   const void *woutp, *pw2p, *ff_w1p, *ffm_w1p, *wqkvp; /* K units of wout, pw2, ff_w1, ffm_w1, wqkv */
   const float* fp_c;     /* parameter groups of block<C> for this layer (EM_BLOCK_PARAM_GROUP floats each) */
   const float* fp_da;    /* groups of block<D|A> (D part of this layer, A part of the next) or block<D|FINAL> */
@@ -334,9 +334,14 @@ typedef struct EmBlockArgs {
   /* Weight matrices (bf16) are streamed in 32 KiB units packed FRAGMENT-MAJOR, so that the eight MFMA operands a
    * wave needs from a unit are eight contiguous 1 KiB lines (lane l = 16 lg + lr reads bytes [16 l, 16 l + 16)):
    *   K unit  u of a [N][256] matrix W (rows 64 u .. 64 u + 63):   unit[nf][ks][lg][lr][e] = W[64 u + 16 nf + lr][32 ks + 8 lg + e]
-   *   W2 unit c of a [256][ff] matrix W (columns 64 c .. 64 c + 63): unit[nf][f][ks][lg][lr][e] = W[64 f + 16 nf + lr][64 c + 32 ks + 8 lg + e]
-   * with nf, f < 4, ks < 8 (K) or 2 (W2), lg < 4, lr < 16, e < 8.  wout, pw1f, pw2, ff_w1, ffm_w1, wqkv and ctc_w
-   * are K units, ff_w2 / ffm_w2 are W2 units (espnet_amd.asr.encoder.conformer_encoder.pack_k_units / pack_w2). */
+   * with nf < 4, ks < 8, lg < 4, lr < 16, e < 8.  wout, pw1f, pw2, ff_w1, ffm_w1, wqkv and ctc_w are K units.
+   * The second matrix of an FFN (ff_w2 / ffm_w2, [256][ff]) is packed per PAIR of 64-wide hidden chunks, 64 KiB per
+   * pair p, in the order in which the wave that computed a slice of the hidden activation holds it in registers
+   * (csrc/block.hip, ffn()): wave w contracts over its own 16 hidden columns of both chunks,
+   *   pair[p][w][f][lg][lr][e] = W[16 f + lr][64 (2 p + (e >> 2)) + 16 w + 4 lg + (e & 3)],   w < 4, f < 16,
+   * i.e. for every wave 16 output-fragment lines of 1 KiB.  ff that is an odd multiple of 64 is padded with one zero
+   * chunk (zero rows of w_1, zero bias, zero columns of w_2) by the host packers
+   * (espnet_amd.asr.encoder.conformer_encoder.pack_k_units / pack_w1 / pack_w2); the kernel takes the true ff. */
   const void *wout, *pw1f;          /* C */
   const void *pw2, *ff_w1, *ff_w2;  /* D */
   const float *dw_w, *dw_b;         /* D: [31][256] tap-major, [256] (BatchNorm folded) */

@@ -123,10 +123,11 @@ def test_mel_band_packing_is_exact():
 
 
 def test_fragment_major_weight_units_follow_the_header():
-    """pack_k_units / pack_w2 against the layout include/espnet_amd.h states at EmBlockArgs: lane 16 lg + lr of wave nf
-    finds the MFMA operand (W row 16 nf + lr of the 64-row group, k = 32 ks + 8 lg .. + 7) at byte
-    8192 nf + 1024 q + 16 lane of the unit, q = ks for a K unit and 2 f + ks for a W2 unit."""
-    from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w2
+    """pack_k_units / pack_w1 / pack_w2 against the layouts include/espnet_amd.h states at EmBlockArgs.  K unit: lane
+    16 lg + lr of wave nf finds the MFMA operand (W row 16 nf + lr of the 64-row group, k = 32 ks + 8 lg .. + 7) at
+    byte 8192 nf + 1024 ks + 16 lane of the unit.  FFN second matrix: per pair of hidden chunks and wave, 16
+    output-fragment lines whose eight elements per lane are the wave's OWN hidden columns of the two chunks."""
+    from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w1, pack_w2
 
     w = torch.arange(192 * 256, dtype=torch.float32).reshape(192, 256)
     flat = pack_k_units(w).reshape(-1)
@@ -138,20 +139,23 @@ def test_fragment_major_weight_units_follow_the_header():
                     off = u * 16384 + nf * 4096 + ks * 512 + lane * 8  # in elements: 32 KiB unit = 16 384 bf16
                     want = w[64 * u + 16 * nf + lr, 32 * ks + 8 * lg: 32 * ks + 8 * lg + 8]
                     assert torch.equal(flat[off:off + 8], want), (u, nf, ks, lane)
-    w2 = torch.arange(256 * 128, dtype=torch.float32).reshape(256, 128)
+    w2 = torch.arange(256 * 256, dtype=torch.float32).reshape(256, 256) + 1.0
     flat = pack_w2(w2).reshape(-1)
-    for c in range(2):
-        for nf in range(4):
-            for f in range(4):
-                for ks in range(2):
-                    for lane in (0, 9, 31, 48, 63):
-                        lg, lr = lane >> 4, lane & 15
-                        off = c * 16384 + nf * 4096 + (2 * f + ks) * 512 + lane * 8
-                        want = w2[64 * f + 16 * nf + lr, 64 * c + 32 * ks + 8 * lg: 64 * c + 32 * ks + 8 * lg + 8]
-                        assert torch.equal(flat[off:off + 8], want), (c, nf, f, ks, lane)
+    for p in range(2):
+        for wv in range(4):
+            for f in (0, 3, 8, 15):
+                for lane in (0, 9, 31, 48, 63):
+                    lg, lr = lane >> 4, lane & 15
+                    off = p * 32768 + wv * 8192 + f * 512 + lane * 8  # elements: 64 KiB pair = 32 768 bf16
+                    cols = [64 * (2 * p + (e >> 2)) + 16 * wv + 4 * lg + (e & 3) for e in range(8)]
+                    assert torch.equal(flat[off:off + 8], w2[16 * f + lr, cols]), (p, wv, f, lane)
     # a permutation: nothing lost, nothing duplicated
     assert torch.equal(pack_k_units(w).reshape(-1).sort().values, w.reshape(-1))
-    assert torch.equal(pack_w2(w2).reshape(-1).sort().values, w2.reshape(-1))
+    assert torch.equal(pack_w2(w2).reshape(-1).sort().values, w2.reshape(-1).sort().values)
+    # an odd chunk count is padded with one zero chunk on both matrices
+    w1o, w2o = torch.ones(192, 256), torch.ones(256, 192)
+    assert pack_w1(w1o).shape == (256, 256) and float(pack_w1(w1o).sum()) == 192 * 256
+    assert pack_w2(w2o).shape == (2, 32768) and float(pack_w2(w2o).sum()) == 192 * 256
     with pytest.raises(AssertionError):
         pack_k_units(torch.zeros(60, 256))
 

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from espnet_amd import lib as L
-from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w2
+from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w1, pack_w2
 from oracle import conformer as oc
 
 pytestmark = pytest.mark.gpu
@@ -200,7 +200,7 @@ def test_block_a(lib, B, T, ff):
     xd = dev(x0.clone())
     qh, kh = (torch.zeros(B, H, Tp, 64, dtype=BF, device="cuda") for _ in range(2))
     vt = torch.zeros(B, H, 64, Tp, dtype=BF, device="cuda")
-    a = block_args(B, T, ff, x=xd, qh=qh, kh=kh, vt=vt, ffm_w1=dev(pack_k_units(ly.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(ly.ffm_w2).to(BF)),
+    a = block_args(B, T, ff, x=xd, qh=qh, kh=kh, vt=vt, ffm_w1=dev(pack_w1(ly.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(ly.ffm_w2).to(BF)),
                    wqkv=dev(pack_k_units(ly.wqkv).to(BF)), params=dev(torch.cat(ly.a_groups())))
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_A, a, L.current_stream_ptr()), "block<A>")
     assert_close(xd, x_ref, 4e-3, "block<A> x")
@@ -238,7 +238,7 @@ def test_block_d_final(lib, B, T, ff, masked):
     out = torch.zeros(B * T, D, dtype=torch.float32, device="cuda")
     act = torch.zeros(B * T, D, dtype=BF, device="cuda")
     a = block_args(B, T, ff, x=xd, glu=dev(glu.to(BF)), enc_out=out, enc_act=act, pw2=dev(pack_k_units(ly.pw2).to(BF)),
-                   ff_w1=dev(pack_k_units(ly.ff_w1).to(BF)), ff_w2=dev(pack_w2(ly.ff_w2).to(BF)), dw_w=dev(ly.dw_w), dw_b=dev(ly.dw_b),
+                   ff_w1=dev(pack_w1(ly.ff_w1).to(BF)), ff_w2=dev(pack_w2(ly.ff_w2).to(BF)), dw_w=dev(ly.dw_w), dw_b=dev(ly.dw_b),
                    tlens=dev(torch.tensor(tl, dtype=torch.int32)) if masked else None,
                    params=dev(torch.cat(ly.d_groups() + [group(ag, ab), torch.zeros(G)])))
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_D | L.EM_BLOCK_FINAL, a, L.current_stream_ptr()), "block<D|F>")
@@ -256,8 +256,8 @@ def test_block_da(lib, B, T, ff):
     qh, kh = (torch.zeros(B, H, Tp, 64, dtype=BF, device="cuda") for _ in range(2))
     vt = torch.zeros(B, H, 64, Tp, dtype=BF, device="cuda")
     a = block_args(B, T, ff, x=xd, glu=dev(glu.to(BF)), qh=qh, kh=kh, vt=vt, pw2=dev(pack_k_units(l0.pw2).to(BF)),
-                   ff_w1=dev(pack_k_units(l0.ff_w1).to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
-                   ffm_w1=dev(pack_k_units(l1.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(pack_k_units(l1.wqkv).to(BF)),
+                   ff_w1=dev(pack_w1(l0.ff_w1).to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
+                   ffm_w1=dev(pack_w1(l1.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(pack_k_units(l1.wqkv).to(BF)),
                    params=dev(torch.cat(l0.d_groups() + l1.a_groups())))
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_D | L.EM_BLOCK_A, a, L.current_stream_ptr()), "block<D|A>")
     assert_close(xd, x_ref, 6e-3, "block<D|A> x")
@@ -290,8 +290,8 @@ def test_block_repeatable_under_load(lib):
     xd = dev(x0.clone())
     x0d = dev(x0)
     a = block_args(B, T, ff, x=xd, glu=glu, qh=qh, kh=kh, vt=vt, pw2=dev(pack_k_units(l0.pw2).to(BF)),
-                   ff_w1=dev(pack_k_units(l0.ff_w1).to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
-                   ffm_w1=dev(pack_k_units(l1.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(pack_k_units(l1.wqkv).to(BF)),
+                   ff_w1=dev(pack_w1(l0.ff_w1).to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
+                   ffm_w1=dev(pack_w1(l1.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(pack_k_units(l1.wqkv).to(BF)),
                    params=dev(torch.cat(l0.d_groups() + l1.a_groups())))
     first = None
     for it in range(20):

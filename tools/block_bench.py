@@ -74,9 +74,9 @@ def main():
     vt = torch.zeros(B, H, 64, Tp, dtype=BF, device="cuda")
     out = torch.zeros(M, D, device="cuda")
     act = torch.zeros(M, D, dtype=BF, device="cuda")
-    from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w2
+    from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w1, pack_w2
 
-    w = {k: c(pack_k_units(getattr(l0, k)).to(BF)) for k in ("pw2", "ff_w1", "wout", "ffm_w1", "wqkv")}
+    w = {k: c((pack_w1 if k.endswith("w1") else pack_k_units)(getattr(l0, k)).to(BF)) for k in ("pw2", "ff_w1", "wout", "ffm_w1", "wqkv")}
     w["ff_w2"], w["ffm_w2"] = c(pack_w2(l0.ff_w2).to(BF)), c(pack_w2(l0.ffm_w2).to(BF))
     w["pw1f"] = c(pack_k_units(l0.pw1[l0.perm()]).to(BF))
     w["dw_w"], w["dw_b"] = c(l0.dw_w), c(l0.dw_b)
