@@ -85,7 +85,7 @@ constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;  // what
 #endif
 
 #ifndef EM_BLOCK_VAR
-#define EM_BLOCK_VAR 0  // developer A/B builds (tools/build_block_variants.sh): 16 = packed-f32 depthwise conv
+#define EM_BLOCK_VAR 0  // developer A/B builds (tools/build_block_variants.sh)
 #endif
 #ifndef EM_BLOCK_FINE
 #define EM_BLOCK_FINE 0  // 1: EM_BLOCK_STAMPS records every wave of workgroup (3, 5) at sub-stage granularity
@@ -374,10 +374,16 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // publishes them to the other waves.  (Until round 3 this was a register copy that hipcc serialised into one
   // global round trip per 16 bytes - load, s_waitcnt vmcnt(0), ds_write, repeat - in front of every other request:
   // 6 dependent round trips in block<D|A>, next to the returning atomic of the warm-up and a vmcnt(0) for `tlens`.)
-  auto dma_lines = [&](const void* g, unsigned lds_off, int n1k) {
+  // (n1k is a compile-time count and every wave issues ceil(n1k / 4) requests, the surplus ones repeating the last line:
+  // no loop, no branch.  Behind a LOOP around the asm hipcc put an s_waitcnt vmcnt(0) at the loop exit, i.e. a full
+  // round trip for the lines just requested.)
+  auto dma_lines = [&](const void* g, unsigned lds_off, auto n1k_c) {
+    constexpr int n1k = decltype(n1k_c)::value;
     const unsigned voff16 = lane * 16;
-#pragma unroll 1
-    for (int j = wave; j < n1k; j += 4) {
+#pragma unroll
+    for (int i = 0; i < (n1k + 3) / 4; ++i) {
+      int j = wave + 4 * i;
+      j = j < n1k ? j : n1k - 1;
       const unsigned char* p = (const unsigned char*)g + (size_t)j * 1024;
       const unsigned dst = lds_off + j * 1024;
       unsigned keep;
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     read_w2(w2, 0, 0, ring[2]);
     read_w2(w2, 0, 1, ring[3]);
   };
-  auto ffn = [&](const float* pb, int b1o, int b2o, float scale, const void* w1, const void* w2) {
+  auto ffn = [&](const float* pb, int b1o, int b2o, float scale, const void* w1, const void* w2, bool repark) {
     const int np = nch >> 1, lastc = nch - 1;
     f32x4 acc2[16][2];
 #pragma unroll
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           xr[mi][f4].y += scale * (sum[1] + b4.y);
           xr[mi][f4].z += scale * (sum[2] + b4.z);
           xr[mi][f4].w += scale * (sum[3] + b4.w);
+          if (repark) xpark[(mi * 4 + f4) * NT] = xr[mi][f4];  // the caller stores x from here at the very end of the kernel
         }
       }
     };
@@ -568,10 +575,10 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // before the conv could start on the 64 KiB it actually needs.
   constexpr int NG = HAS_C ? 1 : (HAS_D ? (HAS_A ? 4 : 3) : 2);
   if (HAS_D) {
-    dma_lines(a.dw_w, WK_OFF, KW);
-    dma_lines(a.dw_b, WK_OFF + KW * 1024, 1);
+    dma_lines(a.dw_w, WK_OFF, std::integral_constant<int, KW>{});
+    dma_lines(a.dw_b, WK_OFF + KW * 1024, std::integral_constant<int, 1>{});
   } else {
-    dma_lines(a.params, PAR_OFF, NG * (PAR_BYTES / 1024));
+    dma_lines(a.params, PAR_OFF, std::integral_constant<int, NG * (PAR_BYTES / 1024)>{});
   }
   const float* const pb0 = par;
   const float* const pb1 = par + PAR_FLOATS;
@@ -600,8 +607,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
     proj_resid(pb0, 0, a.wout);
     fstamp(50);
-    store_x();
-    k_pre(a.pw1f, 8);
+    k_pre(a.pw1f, 8);   // (x is stored at the end of the kernel, behind the last weight request: see the A part)
     ln_to_act(pb0, 256, 512, 0);
     fstamp(15);
     // pointwise_conv1 + GLU (convolution.py:66-69): unit 2j = value rows 64j.., unit 2j+1 = their gates
@@ -624,6 +630,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         }
       }
     });
+    store_x();
     fstamp(51);
     touch_done();
     return;
@@ -657,15 +664,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     fstamp(3);
     bar(BAR_TILE);  // (the conv-weight lines were requested before the tile: a wave that has its tile rows has them too)
     fstamp(4);
-    // behind the conv: the parameter groups, the residual rows, pointwise_conv2's first units, the L2 warm-up
-    dma_lines(a.params, PAR_OFF, NG * (PAR_BYTES / 1024));
-    load_x();
-    k_pre(a.pw2, 4);
-    touch();
-    __builtin_amdgcn_sched_barrier(0);  // requests first, convolution after: hipcc must not sink them into it
-    if constexpr (EM_BLOCK_VAR & 16) {
-      // developer A/B: two adjacent channels x 16 frames per thread on packed f32 FMAs (v_pk_fma_f32): half the LDS reads
-      // (one 4-byte word = both channels' bf16), half the FMA instructions
+    // Behind the tile barrier, IN the convolution: the parameter groups, the residual rows, pointwise_conv2's first units
+    // and the L2 warm-up, in three pieces of <= 64 KiB dealt into the conv's row loop.  Requested in one go they
+    // block the wave in their issue (the memory pipeline of a CU takes ~64 KiB before it makes the issuing wave
+    // wait: ~5 000 cycles for the 190 KiB, profiles/r03b_block_stamps_fine.txt) and the conv starts that much later.
+    // The conv itself: two adjacent channels x 16 frames per thread on packed f32 FMAs (v_pk_fma_f32): one 4-byte LDS
+    // word carries both channels' bf16, weights [k][256] f32 tap-major in LDS (conflict-free 8-byte reads).
+    {
       const int cp = tid & 127, hh = tid >> 7;
       f32x2 wk2[KW];
 #pragma unroll
@@ -674,14 +679,35 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       f32x2 acc[16];
 #pragma unroll
       for (int o = 0; o < 16; ++o) acc[o] = bc2;
+      dma_lines(a.params, PAR_OFF, std::integral_constant<int, NG * (PAR_BYTES / 1024)>{});
+      load_x();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16 + KW - 1; ++r) {
+        // (pinned: the opaque asm ties a zero offset of the request addresses to ALL accumulators of the running
+        // convolution, so the requests can neither be hoisted above this row nor the rows before it sunk below them;
+        // a sched_barrier alone does not do it: instruction selection places arithmetic freely around it)
+        if (r == 15 || r == 30) {
+          unsigned o = 0;
+          asm volatile("" : "+s"(o), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+                       "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]),
+                       "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+          const unsigned char* wp = (const unsigned char*)a.pw2 + o;
+          if (r == 15) {
+            read_unit(wp, 0, ring[0]);
+            read_unit(wp, 1, ring[1]);
+          } else {
+            read_unit(wp, 2, ring[2]);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // ... nor sink below the rows that follow
+        }
         const unsigned u = *(const unsigned*)(tile + ((hh * 16 + r) * D + 2 * cp) * 2);
         const f32x2 v = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 #pragma unroll
         for (int o = 0; o < 16; ++o)
           if (r - o >= 0 && r - o < KW) acc[o] = __builtin_elementwise_fma(wk2[r - o], v, acc[o]);
       }
+      touch();  // (its chunk loop must stay OUT of the row loop: with a loop inside, hipcc does not unroll the rows and the accumulators go to scratch)
       const int ch = 2 * cp, kt = ch >> 6, kl = ch & 63;
 #pragma unroll
       for (int o = 0; o < 16; ++o) {
@@ -689,33 +715,6 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         bf16x2 pk = {(bf16)swishf_(acc[o][0]), (bf16)swishf_(acc[o][1])};
         *(bf16x2*)(abuf + (kt * 32 + m) * 128 + (((kl >> 3) ^ (m & 7)) << 4) + (kl & 7) * 2) = pk;
       }
-    } else {
-    float wk[KW];  // this thread's channel of the depthwise weights (tap-major in LDS: conflict-free)
-#pragma unroll
-    for (int k = 0; k < KW; ++k) wk[k] = ((const float*)(smem + WK_OFF))[k * D + tid];
-    const float bc = ((const float*)(smem + WK_OFF))[KW * D + tid];
-    {
-      const bf16* col = (const bf16*)tile + tid;
-      const int kt = tid >> 6, kl = tid & 63;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {  // two halves of 16 frames: 16 accumulators live at a time
-        float acc[16];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = bc;
-#pragma unroll
-        for (int r = 0; r < 16 + KW - 1; ++r) {
-          const float v = (float)col[(hh * 16 + r) * D];
-#pragma unroll
-          for (int o = 0; o < 16; ++o)
-            if (r - o >= 0 && r - o < KW) acc[o] = fmaf(wk[r - o], v, acc[o]);
-        }
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-          const int m = hh * 16 + o;
-          *(bf16*)(abuf + (kt * 32 + m) * 128 + (((kl >> 3) ^ (m & 7)) << 4) + (kl & 7) * 2) = (bf16)swishf_(acc[o]);
-        }
-      }
-    }
     }
     fstamp(5);
     fstamp(6);
@@ -731,7 +730,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     ffn_pre(a.ff_w1, a.ff_w2);
     ln_to_act(pb0, 256, 512, 0);                   // norm_ff
     stamp(15);
-    ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2);     // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
+    ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false);  // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
     stamp(22);
     {
       float4 y[2][4];
@@ -860,9 +859,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     if (!HAS_D) touch();
     ln_to_act(pa0, 0, 256, 0);
     stamp(15);
-    ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2); // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
+    ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2, true);  // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
     stamp(22);
-    store_x();
+    // (x is stored at the very END of the kernel, from its LDS parking place: its eight 16-byte stores per lane, issued
+    // in front of the q / k / v weight requests, sat in the same in-order count the waits for those requests use and
+    // their slow acknowledgement from L2 stalled the stream - norm_mha took 4 300 cycles to its first barrier against
+    // 3 100 for the other LayerNorms.  The q / k / v stores themselves stay inside the stream: batched behind it they
+    // cost MORE, a store-issue tail of 3 300 cycles that the stream otherwise hides; profiles/r03c_*)
     k_pre(a.wqkv, 12);
     ln_to_act(pa1, 0, 256, 0);                     // norm_mha (encoder_layer.py:123-127)
     stamp(15);
@@ -892,6 +895,14 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         }
       }
     });
+    {
+      const float4* const xp = (const float4*)(smem + TILE_OFF) + tid;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) xr[mi][f] = xp[(mi * 4 + f) * NT];
+      store_x();
+    }
     stamp(40);
   }
   touch_done();

@@ -149,13 +149,16 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
   constexpr int UN = sizeof(T) == 2 ? 8 : 4;
   for (int it0 = 0; it0 < niter; it0 += UN) {
     Raw8<T> k8[UN];
+    // UNCONDITIONAL gathers from a clamped position (positions past the prefix repeat the current row; their scores are
+    // never written): under `if (j <= pos)` every load was followed by s_waitcnt vmcnt(0) - hipcc's wait counting
+    // gives up at a branch - so the UN loads "in flight" were UN dependent round trips (38 such waits in the kernel,
+    // tools/isa_waits.py; 16.9 us per launch in the label step, round 3)
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int j = (it0 + u) * NJ + jsub;
-      if (j <= pos) {
-        const T* kr = (j == pos) ? row + d : kc + ((size_t)j * n + a_s[j]) * d + h * DK;
-        k8[u].load(kr + ch * 8);
-      }
+      const int jc = j < pos ? j : pos;
+      const T* kr = (jc == pos) ? row + d : kc + ((size_t)jc * n + a_s[jc]) * d + h * DK;
+      k8[u].load(kr + ch * 8);
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -189,12 +192,11 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
   for (int it0 = 0; it0 < niter; it0 += UN) {
     Raw8<T> v8[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
+    for (int u = 0; u < UN; ++u) {  // unconditional, as for the keys
       const int j = (it0 + u) * NJ + jsub;
-      if (j <= pos) {
-        const T* vr = (j == pos) ? row + 2 * d : vc + ((size_t)j * n + a_s[j]) * d + h * DK;
-        v8[u].load(vr + ch * 8);
-      }
+      const int jc = j < pos ? j : pos;
+      const T* vr = (jc == pos) ? row + 2 * d : vc + ((size_t)jc * n + a_s[jc]) * d + h * DK;
+      v8[u].load(vr + ch * 8);
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {

@@ -18,6 +18,8 @@
 //     per lane over 128-256 B contiguous row segments (bias / activation / residual fused).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "em_common.h"
 
 struct EmProfile {
@@ -156,16 +158,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
   // the previous store): -1.5 us per launch at M = 7968.
   constexpr bool PREFETCH_C = (EPI == EM_EPI_RESID_F32);
   float4 cpre[PREFETCH_C ? MI * 4 : 1];
+  float4 bpre = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (PREFETCH_C) {
-    const int ncol_p = n0 + wc * 64 + (lane & 15) * 4;
-    if ((ncol_p + 3 < N) && ((ldc & 3) == 0)) {
+    // UNCONDITIONAL (row and column clamped; em_gemm admits this epilogue only with N % 4 == 0 and ldc % 4 == 0): under a
+    // branch hipcc's wait counting gives up and every later use of cpre - one per store below - waits for EVERYTHING
+    // outstanding, the previous row's store included
+    int ncol_p = n0 + wc * 64 + (lane & 15) * 4;
+    ncol_p = ncol_p + 3 < N ? ncol_p : N - 4;
 #pragma unroll
-      for (int q = 0; q < MI * 4; ++q) {
-        int m = m0 + wr * WM + (q >> 2) * 16 + (q & 3) * 4 + lg;
-        m = m < M ? m : M - 1;
-        cpre[q] = *(const float4*)((const float*)Cv + (size_t)m * ldc + ncol_p);
-      }
+    for (int q = 0; q < MI * 4; ++q) {
+      int m = m0 + wr * WM + (q >> 2) * 16 + (q & 3) * 4 + lg;
+      m = m < M ? m : M - 1;
+      cpre[q] = *(const float4*)((const float*)Cv + (size_t)m * ldc + ncol_p);
     }
+    if (bias) bpre = *(const float4*)(bias + ncol_p);  // with the residual rows: not a round trip of its own in the epilogue
   }
 
   const int nk = K / BK;
@@ -323,6 +329,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
   const int c4 = (lane & 15) * 4;  // 4 consecutive output columns handled by this lane
   const int ncol = wn0 + c4;
   if (ncol >= N) return;
+  if constexpr (EPI == EM_EPI_RESID_F32) {
+    // Residual rows leave through a raw buffer resource: a row past M gets an out-of-range offset and the hardware
+    // drops its store - no per-row branch.  (With `if (m < M)` around each store hipcc put an s_waitcnt vmcnt(0)
+    // in front of every one of them: eight serialized store round trips in the epilogue of the decoder step's output
+    // projections, 18 launches per label step; tools/isa_waits.py, round 3.)  em_gemm admits this epilogue only
+    // with N % 4 == 0, ldc % 4 == 0 and M * ldc * 4 < 4 GiB.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (int)((size_t)M * ldc * 4), 0x00020000);
+    const float4 b4 = bpre;
+#pragma unroll
+    for (int q = 0; q < MI * 4; ++q) {
+      const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
+      float4 x = cpre[q];
+      x.x += scale * (vals[q].x + b4.x); x.y += scale * (vals[q].y + b4.y);
+      x.z += scale * (vals[q].z + b4.z); x.w += scale * (vals[q].w + b4.w);
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const u32x4 raw = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
+      const unsigned off = m < M ? (unsigned)(((size_t)m * ldc + ncol) * 4) : 0xffffffffu;
+      __builtin_amdgcn_raw_buffer_store_b128(raw, rs, off, 0, 0);
+    }
+    return;
+  }
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) {
     b4.x = bias[ncol];
@@ -331,11 +358,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     b4.w = ncol + 3 < N ? bias[ncol + 3] : 0.f;
   }
   const bool full4 = (ncol + 3 < N) && ((ldc & 3) == 0);
-#pragma unroll
-  for (int q = 0; q < MI * 4; ++q) {
-    const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
-    if (m >= M) continue;
-    float4 v = vals[q];
+  auto activate = [&](float4 v) {
     v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
     if (EPI == EM_EPI_SWISH) {
       v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w);
@@ -343,44 +366,50 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     } else if (EPI == EM_EPI_GELU) {
       v.x = geluf_(v.x); v.y = geluf_(v.y); v.z = geluf_(v.z); v.w = geluf_(v.w);
+    } else if (EPI == EM_EPI_SCALE_F32) {
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
     }
+    return v;
+  };
+  constexpr bool OUT_ACT = EPI == EM_EPI_STORE || EPI == EM_EPI_SWISH || EPI == EM_EPI_RELU || EPI == EM_EPI_GELU;
+  constexpr size_t ES = OUT_ACT ? sizeof(T) : 4;
+  // Vector path (the rule: whole 4-column groups, 16-byte aligned rows, the matrix behind one 4 GiB buffer resource):
+  // the MI * 4 row stores of a lane leave back to back through raw buffer stores, a row past M carrying an
+  // out-of-range offset that the hardware drops.  With `if (m < M)` around every store hipcc put an
+  // s_waitcnt vmcnt(0) in front of EACH of them - 16 serialized store round trips per 128-row tile, about as long
+  // as the K loop of the conv2 implicit GEMM itself (tools/isa_waits.py; round 3).
+  if (full4 && (size_t)M * ldc * ES < ((size_t)1 << 32) - 64) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (int)(unsigned)((size_t)M * ldc * ES), 0x00020000);
+#pragma unroll
+    for (int q = 0; q < MI * 4; ++q) {
+      const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
+      const float4 v = activate(vals[q]);
+      const unsigned off = m < M ? (unsigned)(((size_t)m * ldc + ncol) * ES) : 0xffffffffu;
+      if constexpr (OUT_ACT && sizeof(T) == 2) {
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        const bf16x4 pk = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, off, 0, 0);
+      } else {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const u32x4 raw = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(raw, rs, off, 0, 0);
+      }
+    }
+    return;
+  }
+  // edge columns / unaligned rows / matrices beyond 4 GiB: element by element
+#pragma unroll
+  for (int q = 0; q < MI * 4; ++q) {
+    const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
+    if (m >= M) continue;
+    const float4 v = activate(vals[q]);
     const size_t o = (size_t)m * ldc + ncol;
-    if (EPI == EM_EPI_STORE || EPI == EM_EPI_SWISH || EPI == EM_EPI_RELU || EPI == EM_EPI_GELU) {
-      T* C = (T*)Cv + o;
-      if (full4) {
-        if (sizeof(T) == 2) {
-          bf16x4 pk = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
-          *(bf16x4*)C = pk;
-        } else {
-          *(float4*)C = v;
-        }
-      } else {
-        float vv[4] = {v.x, v.y, v.z, v.w};
-        for (int e = 0; e < 4; ++e)
-          if (ncol + e < N) C[e] = from_f32<T>(vv[e]);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int e = 0; e < 4; ++e)
+      if (ncol + e < N) {
+        if constexpr (OUT_ACT) ((T*)Cv)[o + e] = from_f32<T>(vv[e]);
+        else ((float*)Cv)[o + e] = vv[e];
       }
-    } else {
-      float* C = (float*)Cv + o;
-      if (full4) {
-        if constexpr (EPI == EM_EPI_RESID_F32) {
-          float4 x = cpre[q];
-          x.x += scale * v.x; x.y += scale * v.y; x.z += scale * v.z; x.w += scale * v.w;
-          *(float4*)C = x;
-        } else if (EPI == EM_EPI_SCALE_F32) {
-          *(float4*)C = make_float4(scale * v.x, scale * v.y, scale * v.z, scale * v.w);
-        } else {
-          *(float4*)C = v;
-        }
-      } else {
-        float vv[4] = {v.x, v.y, v.z, v.w};
-        for (int e = 0; e < 4; ++e)
-          if (ncol + e < N) {
-            if (EPI == EM_EPI_RESID_F32) C[e] += scale * vv[e];
-            else if (EPI == EM_EPI_SCALE_F32) C[e] = scale * vv[e];
-            else C[e] = vv[e];
-          }
-      }
-    }
   }
 }
 
@@ -434,6 +463,8 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   const int bk = dtype == EM_BF16 ? 64 : 32;
   if (p->K % bk != 0) return EM_ERR_UNSUPPORTED;
   if (epilogue == EM_EPI_GLU && (p->N % 32 != 0)) return EM_ERR_UNSUPPORTED;
+  if (epilogue == EM_EPI_RESID_F32 && (p->N % 4 != 0 || p->ldc % 4 != 0 || (size_t)p->M * p->ldc * 4 >= ((size_t)1 << 31)))
+    return EM_ERR_UNSUPPORTED;  // 16-byte residual rows behind one buffer resource
   if (a_mode == EM_A_CONV2) {
     const int kw = p->conv_k > 0 ? p->conv_k : 3;
     if (p->d <= 0 || p->d % bk != 0 || p->K != kw * kw * p->d) return EM_ERR_UNSUPPORTED;

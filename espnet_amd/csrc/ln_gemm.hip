@@ -21,8 +21,8 @@ constexpr int LG_MAXV = 16;  // K <= 64 * LG_MAXV
 
 // NV = float4 chunks per lane per row (K <= 64 * NV).  All loads of a wave's 8 rows are in flight before
 // any reduction: loading row by row serialises the global round trips.
-template <typename T, int EPI, int NV>
-__global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ x,
+template <typename T, int EPI, int NV, bool EXACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ln_gemm_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ g,
                                                       const float* __restrict__ be, float eps,
                                                       const T* __restrict__ W,
@@ -37,13 +37,16 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.x * LG_BN, m0 = blockIdx.y * LG_BM;
-  const int nv = K >> 6;
+  // EXACT: K == 64 * NV, so `j < nv` folds away.  With a runtime nv every row / gamma / beta load sits under a (uniform)
+  // branch, hipcc follows each with s_waitcnt vmcnt(0) - its wait counting gives up at a branch - and the prologue
+  // is a chain of dependent global round trips (tools/isa_waits.py: 3 before the statistics at K = 512; round 3).
+  const int nv = EXACT ? NV : (K >> 6);
 
   // ---- the first U k-steps of this wave's W rows are requested before anything else: they do not depend
   // on the LayerNorm, so their latency overlaps the x loads and the statistics (one global round trip
   // for the whole kernel when K <= U * MM::K, i.e. K <= 512 in bf16)
   constexpr int U = 16;
-  const int nsteps = K / MM::K;
+  const int nsteps = (EXACT ? 64 * NV : K) / MM::K;
   int n = n0 + wave * 16 + lr;
   n = n < N ? n : N - 1;
   const T* wrow = W + (size_t)n * K + lg * MM::EPL;
@@ -72,6 +75,10 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ 
       g4[j] = j < nv ? *(const float4*)(g + (j * 16 + li) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       b4[j] = j < nv ? *(const float4*)(be + (j * 16 + li) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // every request of the kernel is out before the first reduction: a memory-clobbering (empty) asm is a line no load
+    // may be moved across - left alone hipcc sinks the weight prefetch and the second pass's rows behind the first
+    // pass's statistics to save registers, and the prologue becomes three dependent round trips
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       float s = 0.f;
@@ -142,14 +149,14 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const float* __restrict__ 
   }
 }
 
-template <typename T, int EPI, int NV>
+template <typename T, int EPI, int NV, bool EXACT>
 int launch_ln_gemm_nv(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
                       void* C, int M, int N, int K, int ldc, hipStream_t s) {
   const size_t lds = (size_t)LG_BM * (K + 16 / sizeof(T)) * sizeof(T);
   static EmLdsCap cap = {};  // per instantiation and device: raised once (not per launch: launches may be inside a hipGraph capture)
-  if (em_raise_lds_cap((const void*)ln_gemm_kernel<T, EPI, NV>, 160 * 1024 - 1024, &cap) != EM_OK) return EM_ERR_LAUNCH;
+  if (em_raise_lds_cap((const void*)ln_gemm_kernel<T, EPI, NV, EXACT>, 160 * 1024 - 1024, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(N, LG_BN), em_cdiv(M, LG_BM));
-  hipLaunchKernelGGL((ln_gemm_kernel<T, EPI, NV>), grid, dim3(256), lds, s, x, g, b, eps, (const T*)W, bias, C,
+  hipLaunchKernelGGL((ln_gemm_kernel<T, EPI, NV, EXACT>), grid, dim3(256), lds, s, x, g, b, eps, (const T*)W, bias, C,
                      M, N, K, ldc);
   EM_CHECK_LAUNCH();
   return EM_OK;
@@ -159,10 +166,15 @@ template <typename T, int EPI>
 int launch_ln_gemm(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
                    void* C, int M, int N, int K, int ldc, hipStream_t s) {
   const int nv = K / 64;
-  if (nv <= 1) return launch_ln_gemm_nv<T, EPI, 1>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
-  if (nv <= 4) return launch_ln_gemm_nv<T, EPI, 4>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
-  if (nv <= 8) return launch_ln_gemm_nv<T, EPI, 8>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
-  return launch_ln_gemm_nv<T, EPI, LG_MAXV>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  switch (nv) {  // the model widths in use get branch-free prologues
+    case 4: return launch_ln_gemm_nv<T, EPI, 4, true>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+    case 8: return launch_ln_gemm_nv<T, EPI, 8, true>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+    case 16: return launch_ln_gemm_nv<T, EPI, 16, true>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  }
+  if (nv <= 1) return launch_ln_gemm_nv<T, EPI, 1, false>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  if (nv <= 4) return launch_ln_gemm_nv<T, EPI, 4, false>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  if (nv <= 8) return launch_ln_gemm_nv<T, EPI, 8, false>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  return launch_ln_gemm_nv<T, EPI, LG_MAXV, false>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
 }
 
 template <typename T>

@@ -379,6 +379,47 @@ __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
   const int W = c.p.W, NC = c.p.NC;
   const int total = W * NC;
   float* tot = c.b.cand_total + (size_t)b * total;
+  // Up to 64 * KM candidates (beam 10 x 21 = 210, beam 20 x 41 = 820 ...) live in registers for all W rounds: ONE
+  // global round trip for the kernel.  (Until round 3 every round re-read the totals from global memory and knocked
+  // its winner out there: W dependent round trips, 10.9 us for 210 numbers.)  Same order as before: largest total,
+  // lowest flat index on ties.
+  constexpr int KM = 16;
+  if (total <= 64 * KM) {
+    float x[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      const int v = lane + 64 * k;
+      const float t = tot[v < total ? v : total - 1];  // unconditional load, masked afterwards
+      x[k] = v < total ? t : -INFINITY;
+    }
+    for (int r = 0; r < W; ++r) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < KM; ++k)
+        if (x[k] > best) {
+          best = x[k];
+          bi = lane + 64 * k;
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      if (lane == 0) {
+        c.b.sel_idx[b * W + r] = (best > -INFINITY) ? bi : -1;
+        c.b.sel_total[b * W + r] = best;
+      }
+#pragma unroll
+      for (int k = 0; k < KM; ++k)
+        if (bi == lane + 64 * k) x[k] = -INFINITY;  // the winner leaves its owner's registers
+    }
+    return;
+  }
   for (int k = 0; k < W; ++k) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -419,6 +460,27 @@ constexpr int CTC_TMAX = 2048;
 // 64-thread workgroup: all lanes stage x[t][label], x[t][blank] and the phi terms in LDS with coalesced
 // reads, lane 0 walks the sequential chain LDS -> LDS, all lanes write the result back coalesced.  Only
 // t >= max(i,1)-1 is produced: a later step's recurrence starts at t = i+1 and reads r_prev[t-1].
+//
+// Round 3: the chain is no longer walked by one lane.  In the log semiring the step t is LINEAR in (r^n, r^b, 1):
+//     r^n[t] = logsum(x_n[t] + r^n[t-1], (x_n[t] + phi[t]) + 0)        r^b[t] = logsum(x_b[t] + r^n[t-1], x_b[t] + r^b[t-1])
+// i.e. a matrix M_t = [[a, -, c], [d, e, f], [-, -, 0]] with a = x_n, c = x_n + phi, d = e = x_b, f = "zero", and
+// products of such matrices keep that shape (five numbers).  So: every lane composes the steps of its own chunk of
+// ceil(T / 64) frames, an inclusive scan over the 64 lanes composes the chunks (6 shuffle rounds), and every lane
+// re-walks its chunk from the state the scan hands it, writing its frames.  ~4 + 6 + 4 dependent compositions
+// instead of ~250 dependent steps on one lane (23 us per label step before).  The result differs from the
+// sequential walk only by f32 reassociation of log-sums (the tests' score tolerance is 2e-3 + 2e-5 |score|).
+struct CtcMap {
+  float a, c, d, e, f;
+};
+__device__ __forceinline__ CtcMap ctc_compose(const CtcMap& hi, const CtcMap& lo) {  // hi after lo
+  CtcMap m;
+  m.a = hi.a + lo.a;
+  m.c = logaddexp_(hi.a + lo.c, hi.c);
+  m.d = logaddexp_(hi.d + lo.a, hi.e + lo.d);
+  m.e = hi.e + lo.e;
+  m.f = logaddexp_(logaddexp_(hi.d + lo.c, hi.e + lo.f), hi.f);
+  return m;
+}
 __device__ __forceinline__ void ctc_chain_wg(const float2* __restrict__ rprev, const float* __restrict__ xc,
                                              const float* __restrict__ xb, bool same, int i, int xlen,
                                              float2* __restrict__ rout, int lane, float* s_xn, float* s_xb,
@@ -431,17 +493,45 @@ __device__ __forceinline__ void ctc_chain_wg(const float2* __restrict__ rprev, c
     s_phi[t] = same ? rp.y : logaddexp_(rp.x, rp.y);
   }
   __syncthreads();
-  if (lane == 0) {
-    float rn = (i == 0) ? xc[0] : LOGZERO, rb = LOGZERO;  // r[0,0] = x[0] (:131-132)
-    s_out[start - 1] = make_float2(rn, rb);
-#pragma unroll 4
-    for (int t = start; t < xlen; ++t) {
-      const float nn = logaddexp_(rn, s_phi[t]) + s_xn[t];
-      const float nb = logaddexp_(rn, rb) + s_xb[t];
-      rn = nn;
-      rb = nb;
-      s_out[t] = make_float2(rn, rb);
-    }
+  const int steps = xlen - start;
+  const int chunk = (steps + 63) >> 6;
+  const int t_lo = start + lane * chunk;
+  const int t_hi = t_lo + chunk < xlen ? t_lo + chunk : xlen;
+  CtcMap m = {0.f, LOGZERO, LOGZERO, 0.f, LOGZERO};  // identity
+  for (int t = t_lo; t < t_hi; ++t) {
+    const CtcMap st = {s_xn[t], s_xn[t] + s_phi[t], s_xb[t], s_xb[t], LOGZERO};
+    m = ctc_compose(st, m);
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    CtcMap lo;
+    lo.a = __shfl_up(m.a, o, 64);
+    lo.c = __shfl_up(m.c, o, 64);
+    lo.d = __shfl_up(m.d, o, 64);
+    lo.e = __shfl_up(m.e, o, 64);
+    lo.f = __shfl_up(m.f, o, 64);
+    if (lane >= o) m = ctc_compose(m, lo);
+  }
+  // exclusive prefix = what happened before this lane's chunk
+  CtcMap pre;
+  pre.a = __shfl_up(m.a, 1, 64);
+  pre.c = __shfl_up(m.c, 1, 64);
+  pre.d = __shfl_up(m.d, 1, 64);
+  pre.e = __shfl_up(m.e, 1, 64);
+  pre.f = __shfl_up(m.f, 1, 64);
+  const float rn0 = (i == 0) ? xc[0] : LOGZERO, rb0 = LOGZERO;  // r[0,0] = x[0] (:131-132)
+  float rn = rn0, rb = rb0;
+  if (lane > 0) {
+    rn = logaddexp_(pre.a + rn0, pre.c);
+    rb = logaddexp_(logaddexp_(pre.d + rn0, pre.e + rb0), pre.f);
+  }
+  if (lane == 0) s_out[start - 1] = make_float2(rn0, rb0);
+  for (int t = t_lo; t < t_hi; ++t) {
+    const float nn = logaddexp_(rn, s_phi[t]) + s_xn[t];
+    const float nb = logaddexp_(rn, rb) + s_xb[t];
+    rn = nn;
+    rb = nb;
+    s_out[t] = make_float2(rn, rb);
   }
   __syncthreads();
   for (int t = start - 1 + lane; t < xlen; t += 64) rout[t] = s_out[t];
@@ -474,9 +564,23 @@ __global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i_host) {
 
 // ---- step 4: build the new rows (batch_beam_search.py:317-357 + post_process :359-423) ---------
 // one workgroup (64 threads) per utterance
+// Graph mode (c.b.step != NULL): this is the LAST kernel of a label step and it also advances the device step counter:
+// every workgroup has read the step index by the time it takes a ticket at step[1], and the workgroup that takes
+// the last one resets the ticket and adds one to step[0] (a launch of its own until round 3: 4.5 us per step).
+__device__ __forceinline__ void step_advance(const Ctx& c, int lane) {
+  if (!c.b.step || lane != 0) return;
+  const unsigned t = __hip_atomic_fetch_add((unsigned*)c.b.step + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == gridDim.x - 1) {
+    __hip_atomic_store((unsigned*)c.b.step + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add((unsigned*)c.b.step, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
   const int i = c.b.step ? *c.b.step : i_host;
-  if (i >= c.p.Lmax - 1) return;
+  if (i >= c.p.Lmax - 1) {
+    step_advance(c, threadIdx.x);
+    return;
+  }
   const int b = blockIdx.x, lane = threadIdx.x;
   const int W = c.p.W, NC = c.p.NC, V = c.p.V, Lmax = c.p.Lmax, n = c.p.B * c.p.W;
   __shared__ int s_prev_row[64], s_tok[64], s_valid[64], s_end[64];
@@ -588,6 +692,7 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
     }
     if (done) c.b.done[b] = 1;
   }
+  step_advance(c, lane);
 }
 
 // x[v][col] <- log_softmax over v of (x[v][col] + bias[v]), columns = (utterance, frame) pairs.
@@ -621,7 +726,6 @@ __global__ __launch_bounds__(256) void col_logsoftmax_kernel(float* __restrict__
     }
 }
 
-__global__ void step_advance_kernel(int* step) { *step += 1; }
 
 inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
                 int N, int K, int lda, int ldc, float scale, void* stream) {
@@ -856,7 +960,7 @@ extern "C" int em_search_init(int dtype, const EmSearchParams* p, const EmDecode
   if (p->w_ctc != 0.f) EM_TRY(ctc_log_probs(dtype, p, b, enc_act, d_model, ctc_w, ctc_b, stream));
   hipLaunchKernelGGL(search_init_rows_kernel, dim3(em_cdiv(n, 64)), dim3(64), 0, s, c);
   hipLaunchKernelGGL(search_init_utt_kernel, dim3(em_cdiv(p->B, 64)), dim3(64), 0, s, c);
-  if (b->step) hipMemsetAsync(b->step, 0, sizeof(int32_t), s);
+  if (b->step) hipMemsetAsync(b->step, 0, 2 * sizeof(int32_t), s);  // [0] step index, [1] arrival ticket of update_kernel
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
@@ -1090,7 +1194,6 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
     EM_TRY(search_core(dtype, p, dw, b, i, stream));
     if (p->w_ctc != 0.f) hipLaunchKernelGGL(ctc_state_kernel, dim3(n), dim3(64), 0, s, c, i);
     hipLaunchKernelGGL(update_kernel, dim3(p->B), dim3(64), 0, s, c, i);
-    if (b->step) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, b->step);
     EM_CHECK_LAUNCH();
   }
   return EM_OK;

@@ -99,7 +99,7 @@ class BatchBeamSearch(BeamSearch):
             r_a=(n, T, 2) if use_ctc else (1,), r_b=(n, T, 2) if use_ctc else (1,),
             ctc_lpT=(V, B * T) if use_ctc else None,
             cand_tok=(n, NC), cand_full=(n, NC), cand_psi=(n, NC), cand_total=(n, NC),
-            sel_idx=(n,), sel_total=(n,), step=(1,), end_count=(B,), end_pos=(B, cap), end_slot=(B, cap),
+            sel_idx=(n,), sel_total=(n,), step=(2,), end_count=(B,), end_pos=(B, cap), end_slot=(B, cap),
             end_forced=(B, cap), end_score=(B, cap), end_sdec=(B, cap), end_sctc=(B, cap),
             end_slen=(B, cap), best_all=(B,), best_by_len=(B, Lmax + 2), done=(B,))
         if use_dec:

@@ -603,10 +603,10 @@ typedef struct EmSearchBuffers {
   float *end_score, *end_sdec, *end_sctc, *end_slen; /* [B][end_cap] */
   float *best_all, *best_by_len;            /* [B], [B][Lmax+2] end-detection statistics */
   int32_t* done;                            /* [B] */
-  int32_t* step;                            /* device step counter, or NULL.  Non-NULL = graph mode: every
-                                               step kernel reads the step index from here (kernel
-                                               arguments are frozen in a captured hipGraph) and
-                                               em_search_steps advances it after each step */
+  int32_t* step;                            /* [2] device step counter + arrival ticket, or NULL.  Non-NULL = graph
+                                               mode: every step kernel reads the step index from step[0] (kernel
+                                               arguments are frozen in a captured hipGraph) and the last
+                                               kernel of a step advances it (step[1] counts its workgroups) */
   float* x;                                 /* [n][d] f32 decoder residual stream */
   void *xn, *qkv, *qs, *ctx, *hbuf;         /* act: [n][d], [n][3d], [n][d], [n][d], [n][ff] */
   float* dec_logp;                          /* [n][V] */
