@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
     if jobs or not LIB.exists():
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", str(LIB), *map(str, objs)]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-Wl,-z,defs", "-o", str(LIB), *map(str, objs)]  # -z defs: an undefined symbol fails HERE, not at the first call on the GPU box
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -456,7 +456,6 @@ int dispatch(int epi, int amode, const EmGemmArgs* p, hipStream_t s) {
 }  // namespace
 
 int em_gemm_skinny(int dtype, int epilogue, const EmGemmArgs* p, void* stream);  // gemm_skinny.hip
-int em_gemm256_bf16(int epilogue, int a_mode, const EmGemmArgs* p, void* stream);  // gemm256.hip
 
 extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p, void* stream) {
   if (!p || !p->A || !p->W || !p->C) return EM_ERR_BAD_ARG;
@@ -478,9 +477,6 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   int rc = EM_ERR_UNSUPPORTED;
   // very few rows (streaming encoder step, single-utterance beam): latency-bound weight streaming
   if (a_mode == EM_A_PLAIN && p->M <= 48) rc = em_gemm_skinny(dtype, epilogue, p, stream);
-  // many rows x N % 256 == 0 (the conv2 implicit GEMM): the 256 x 256 tile (ESPNET_AMD_GEMM256=0: A/B against the 128s)
-  static const bool use256 = !(getenv("ESPNET_AMD_GEMM256") && getenv("ESPNET_AMD_GEMM256")[0] == '0');
-  if (rc == EM_ERR_UNSUPPORTED && dtype == EM_BF16 && use256) rc = em_gemm256_bf16(epilogue, a_mode, p, stream);
   if (rc == EM_ERR_UNSUPPORTED) {
     rc = EM_ERR_BAD_ARG;
     if (dtype == EM_F32) rc = dispatch<float>(epilogue, a_mode, p, (hipStream_t)stream);

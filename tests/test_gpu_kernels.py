@@ -398,45 +398,3 @@ def test_gemm_large_m_bf16_128x128_tile(lib, epi):
     L.check(lib.em_gemm(L.EM_BF16, code, L.EM_A_PLAIN, args, sptr()), "em_gemm large")
     assert_close(out, ref, 2e-4 if f32out else 2e-2, f"large-M gemm {epi}")
 
-
-# --------------------------------------------------------------------------- 256 x 256 tile (csrc/gemm256.hip)
-@pytest.mark.parametrize("epi", ["STORE", "RELU", "SWISH", "STORE_F32"])
-def test_gemm256_tile_plain(lib, epi):
-    """Shapes that take the eight-wave 256 x 256 tile (N % 256 == 0, >= 384 tiles): against torch fp32 on the rounded
-    operands, ragged last row tile, two column tiles."""
-    M, N, K = 384 * 128 + 77, 512, 192
-    a = q(rnd(M, K, seed=51), torch.bfloat16)
-    w = q(rnd(N, K, seed=52, scale=K ** -0.5), torch.bfloat16)
-    bias = 0.1 * rnd(N, seed=53)
-    acc = a @ w.t() + bias
-    ref = {"STORE": acc, "SWISH": oc.swish(acc), "RELU": torch.relu(acc), "STORE_F32": acc}[epi]
-    f32out = epi == "STORE_F32"
-    out = torch.full((M + 3, N), 7.0, dtype=torch.float32 if f32out else torch.bfloat16, device="cuda")  # 3 guard rows
-    ad, wd, bd = dev(a.to(torch.bfloat16)), dev(w.to(torch.bfloat16)), dev(bias)
-    args = L.EmGemmArgs(A=ad.data_ptr(), W=wd.data_ptr(), C=out.data_ptr(), bias=bd.data_ptr(), M=M, N=N, K=K, lda=K,
-                        ldc=N, scale=1.0)
-    L.check(lib.em_gemm(L.EM_BF16, getattr(L, "EM_EPI_" + epi), L.EM_A_PLAIN, args, sptr()), "em_gemm 256")
-    assert_close(out[:M], ref, 2e-4 if f32out else 2e-2, f"gemm256 {epi}")
-    assert bool((out[M:].float() == 7.0).all()), "rows past M were written"
-
-
-def test_gemm256_tile_conv2(lib):
-    """The conv2 implicit GEMM at a size that takes the 256 x 256 tile (B = 24 x 500 x 39 -> 113 000 rows): against
-    F.conv2d on the first two and the last utterance."""
-    B, T1, F1, d = 24, 500, 39, 256
-    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
-    g = torch.Generator().manual_seed(61)
-    xcl = (torch.randn(B, T1, F1, d, generator=g) * 0.5).to(torch.bfloat16)
-    w = q(rnd(d, d, 3, 3, seed=62, scale=(9 * d) ** -0.5), torch.bfloat16)
-    b = rnd(d, seed=63)
-    wp = dev(w.permute(0, 2, 3, 1).reshape(d, 9 * d).to(torch.bfloat16))
-    xd, bd = dev(xcl), dev(b)
-    M = B * T2 * F2
-    assert (M + 255) // 256 >= 384
-    C = torch.zeros(M, d, dtype=torch.bfloat16, device="cuda")
-    gemm(lib, L.EM_BF16, L.EM_EPI_RELU, xd, wp, C, bd, M, d, 9 * d, 0, d, amode=L.EM_A_CONV2, conv=(T1, F1, T2, F2, d))
-    ref = F.relu(F.conv2d(xcl[:2].float().permute(0, 3, 1, 2), w, b, stride=2))  # (2, d, T2, F2)
-    got = C[: 2 * T2 * F2].float().cpu().reshape(2, T2, F2, d).permute(0, 3, 1, 2)
-    assert_close(got, ref, 1e-2, "conv2 256 tile vs conv2d")
-    last = C[-T2 * F2:].float().cpu().reshape(1, T2, F2, d).permute(0, 3, 1, 2)
-    assert_close(last, F.relu(F.conv2d(xcl[-1:].float().permute(0, 3, 1, 2), w, b, stride=2)), 1e-2, "last utterance")
