@@ -71,6 +71,16 @@ __device__ __forceinline__ void store8<float>(float* __restrict__ p, const float
   *(float4*)(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::frag zero_frag();
+template <>
+__device__ __forceinline__ bf16x8 zero_frag<bf16>() {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  return __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+}
+template <>
+__device__ __forceinline__ float zero_frag<float>() { return 0.f; }
+
 // 8 consecutive elements kept in their storage form (16 B for bf16, 32 B for f32) so that many
 // row loads can be in flight without spending 8 VGPRs each on converted floats.
 template <typename T> struct Raw8;
@@ -94,9 +104,17 @@ template <> struct Raw8<float> {
 // anc [n][Lmax].  ctx [n][d].
 // Lane = (position sub-index jsub, 8-channel chunk ch): one wave-wide load instruction covers
 // NJ = 64/(DK/8) prefix positions x the whole head (16-byte loads for bf16), so a 250-token prefix
-// is 32 iterations for QK^T and 32 for PV; partial dots are reduced across the chunk lanes,
-// partial contexts across the position lanes.
-constexpr int SA_MAXL = 4096;  // Lmax scores + Lmax ancestor slots per wave must fit the 64 KiB default LDS
+// is 32 position groups.
+//
+// Round 3: ONE pass with an online softmax.  Until then the kernel ran QK^T over the whole prefix, a softmax through
+// LDS and two barriers, and then P.V over the whole prefix again: two sequences of dependent gather round trips (the
+// V rows were only requested after the softmax) and a ds_bpermute chain of three per position for the dot products -
+// 12.5 us per launch, six launches per label step (profiles/r03f_search_kernel_stats.csv).  Now a batch requests the K
+// AND the V rows of its UN position groups together (half the round trips), every position slot jsub keeps its own
+// running (max, sum, context) over the positions j = jsub (mod NJ) - no LDS, no barrier - and the NJ partial states are
+// merged once at the end.  The dot product's cross-lane sum runs on DPP.  The result differs from the two-pass form by
+// f32 rounding of the rescaling only.
+constexpr int SA_MAXL = 4096;  // Lmax ancestor slots per wave must fit the 64 KiB default LDS
 template <typename T, int DK>
 __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict__ qkv,
                                                            T* __restrict__ kc, T* __restrict__ vc,
@@ -116,19 +134,22 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
     if (pos & 1) anc = anc_odd;
   }
   constexpr int NCH = DK / 8;   // lanes per position
-  constexpr int NJ = 64 / NCH;  // positions per iteration
-  extern __shared__ float sa_lds[];  // per wave: Lmax scores + Lmax ancestor slots
+  constexpr int NJ = 64 / NCH;  // positions per group
+  static_assert(NCH == 8 || NCH == 4, "d_k 64 or 32");
+  extern __shared__ int sa_lds[];  // per wave: Lmax ancestor slots
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* p_s = sa_lds + (size_t)wave * 2 * Lmax;
-  int* a_s = (int*)(p_s + Lmax);
+  int* a_s = sa_lds + (size_t)wave * Lmax;
   const int h = blockIdx.x;
   int r = blockIdx.y * (blockDim.x >> 6) + wave;
-  const bool live = r < n;  // the last group may be partial; keep every wave in the barriers
+  const bool live = r < n;  // the last group may be partial
   r = live ? r : n - 1;
   const int ch = lane % NCH, jsub = lane / NCH;
   const T* row = qkv + (size_t)r * 3 * d + h * DK;
   float q[8];
   load8<T>(row + ch * 8, q);
+  const float scale = rsqrtf((float)DK);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q[e] *= scale;
   // append this position's K/V to the cache (read back by later steps only)
   if (lane < NCH && live) {
     const size_t o = ((size_t)pos * n + r) * d + h * DK + lane * 8;
@@ -138,80 +159,85 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
     load8<T>(row + 2 * d + lane * 8, t8);
     store8<T>(vc + o, t8);
   }
-  const float scale = rsqrtf((float)DK);
   // ancestor slots of the prefix: one coalesced read into LDS, so the K/V row addresses of the
-  // loops below do not hang off a second dependent global load
+  // loop below do not hang off a second dependent global load.  The slots are private to the wave.
   for (int j = lane; j < pos; j += 64) a_s[j] = anc[(size_t)r * Lmax + j];
   __syncthreads();
   const int niter = (pos + NJ) / NJ;  // ceil((pos+1)/NJ)
-  // The gathers are latency-bound (one 128-byte row per position, scattered over the cache): keep
-  // UN row loads per lane in flight before the first use.
+  // The gathers are latency-bound (one 128-byte row per position, scattered over the cache): UN K rows and UN V rows
+  // per lane are in flight before the first use.
   constexpr int UN = sizeof(T) == 2 ? 8 : 4;
+  float m_run = -INFINITY, l_run = 0.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int* const tt = tok_tab ? tok_tab : anc;
   for (int it0 = 0; it0 < niter; it0 += UN) {
-    Raw8<T> k8[UN];
-    // UNCONDITIONAL gathers from a clamped position (positions past the prefix repeat the current row; their scores are
-    // never written): under `if (j <= pos)` every load was followed by s_waitcnt vmcnt(0) - hipcc's wait counting
-    // gives up at a branch - so the UN loads "in flight" were UN dependent round trips (38 such waits in the kernel,
-    // tools/isa_waits.py; 16.9 us per launch in the label step, round 3)
+    Raw8<T> k8[UN], v8[UN];
+    int tkv[UN];
+    // UNCONDITIONAL gathers from a clamped position (positions past the prefix repeat the current row and are masked
+    // below): a load under `if (j <= pos)` is followed by s_waitcnt vmcnt(0) - hipcc's wait counting gives up at a
+    // branch - and the UN loads "in flight" become UN dependent round trips (tools/isa_waits.py)
+    int slot[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {  // the batch's ancestor slots first, back to back (one LDS latency, not UN)
+      const int j = (it0 + u) * NJ + jsub;
+      slot[u] = a_s[j < pos ? j : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int j = (it0 + u) * NJ + jsub;
-      const int jc = j < pos ? j : pos;
-      const T* kr = (jc == pos) ? row + d : kc + ((size_t)jc * n + a_s[jc]) * d + h * DK;
-      k8[u].load(kr + ch * 8);
+      const bool cur = j >= pos;  // the current token's own row (and the clamp for positions past it)
+      const size_t o = ((size_t)(cur ? pos : j) * n + slot[u]) * d + h * DK + ch * 8;
+      k8[u].load(cur ? row + d + ch * 8 : kc + o);
+      v8[u].load(cur ? row + 2 * d + ch * 8 : vc + o);
+      // the key's token id (LM mask), requested with the rows; without a table the load repeats anc[0] and is ignored
+      tkv[u] = tt[tok_tab ? (size_t)(cur ? pos : j) * n + (cur ? r : slot[u]) : 0];
     }
+    __builtin_amdgcn_sched_barrier(0);  // every request of the batch is out before its first use (left alone hipcc sinks the loads next to their uses)
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int j = (it0 + u) * NJ + jsub;
       float dot = 0.f;
-      if (j <= pos) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dot = fmaf(q[e], k8[u].at(e), dot);
-      }
+      for (int e = 0; e < 8; ++e) dot = fmaf(q[e], k8[u].at(e), dot);
+      dot += dpp_f32<DPP_XOR1>(dot);
+      dot += dpp_f32<DPP_XOR2>(dot);
+      if constexpr (NCH == 8) dot += dpp_f32<DPP_HALF_MIRROR>(dot);  // the quads are uniform: lane 7 - i holds the other quad's sum
+      const bool valid = (j <= pos) & ((tok_tab == nullptr) | (tkv[u] != 0));  // (bitwise: no branch for hipcc to sink a load into)
+      // online softmax of this position slot: (m, l, acc) <- merge with (dot, 1, v)
+      const float m_new = valid ? fmaxf(m_run, dot) : m_run;
+      const float alpha = (m_run > -INFINITY) ? __expf(m_run - m_new) : 0.f;  // m_new == m_run == -inf: nothing yet
+      const float p = valid ? __expf(dot - m_new) : 0.f;
+      l_run = l_run * alpha + p;
 #pragma unroll
-      for (int o = 1; o < NCH; o <<= 1) dot += __shfl_xor(dot, o, 64);
-      if (ch == 0 && j <= pos) {
-        const bool masked = tok_tab && tok_tab[(size_t)j * n + (j == pos ? r : a_s[j])] == 0;
-        p_s[j] = masked ? -INFINITY : dot * scale;
-      }
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v8[u].at(e), acc[e] * alpha);
+      m_run = m_new;
     }
   }
-  __syncthreads();
-  float mx = -INFINITY;
-  for (int j = lane; j <= pos; j += 64) mx = fmaxf(mx, p_s[j]);
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int j = lane; j <= pos; j += 64) {
-    const float p = mx > -INFINITY ? expf(p_s[j] - mx) : 0.f;  // all keys masked -> zeros
-    p_s[j] = p;
-    sum += p;
+  // merge the NJ position slots: rotations inside the 16-lane rows on DPP, then across the rows
+  float M = m_run;
+  if constexpr (NCH == 4) M = fmaxf(M, dpp_f32<DPP_ROR4>(M));
+  M = fmaxf(M, dpp_f32<DPP_ROR8>(M));
+  M = fmaxf(M, __shfl_xor(M, 16, 64));
+  M = fmaxf(M, __shfl_xor(M, 32, 64));
+  const float f = (m_run > -INFINITY) ? __expf(m_run - M) : 0.f;  // all keys masked: every slot is empty -> zeros
+  float sum = l_run * f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] *= f;
+  if constexpr (NCH == 4) {
+    sum += dpp_f32<DPP_ROR4>(sum);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += dpp_f32<DPP_ROR4>(acc[e]);
   }
-  sum = wave_sum(sum);
-  __syncthreads();
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int it0 = 0; it0 < niter; it0 += UN) {
-    Raw8<T> v8[UN];
+  sum += dpp_f32<DPP_ROR8>(sum);
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {  // unconditional, as for the keys
-      const int j = (it0 + u) * NJ + jsub;
-      const int jc = j < pos ? j : pos;
-      const T* vr = (jc == pos) ? row + 2 * d : vc + ((size_t)jc * n + a_s[jc]) * d + h * DK;
-      v8[u].load(vr + ch * 8);
-    }
+  for (int e = 0; e < 8; ++e) acc[e] += dpp_f32<DPP_ROR8>(acc[e]);
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int j = (it0 + u) * NJ + jsub;
-      if (j <= pos) {
-        const float p = p_s[j];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v8[u].at(e), acc[e]);
-      }
-    }
-  }
-#pragma unroll
-  for (int o = NCH; o < 64; o <<= 1)
+  for (int o = 16; o < 64; o <<= 1) {
+    sum += __shfl_xor(sum, o, 64);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
   if (lane < NCH && live) {
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
 #pragma unroll
@@ -223,6 +249,13 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
 // Source attention of the W hypotheses of one utterance over its encoder memory.
 // grid (heads, B, ceil(W/16)), 256 threads.  qs [n][d]; kmem rows at stride ldk (K part of the
 // per-layer [B*T][2d] projection); vT [B][d][Tpad] (V transposed, zero padded); klens [B].
+//
+// Round 3: the kernel's global loads are requested up front.  Before, the QK^T loop fetched one key tile per trip
+// (load, wait, MFMA, LDS store: Tpad / 64 dependent round trips per wave) and the P.V loop one V fragment per trip
+// (Tpad / 32 more), with a shuffle-chain softmax between them: 10.3 us per launch for 64 KB of operands, six launches
+// per label step.  Now a wave requests the key tiles of a batch (UT tiles x KS fragments) AND its first UV fragments
+// of V^T - which do not depend on the softmax - in one burst before its first MFMA, the softmax reductions run on DPP,
+// and only the rows that exist (W of the 16) are normalised, dealt round-robin to the waves.
 template <typename T, int DK>
 __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__ qs,
                                                            const T* __restrict__ kmem, int ldk,
@@ -232,6 +265,8 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
                                                            T* __restrict__ ctx) {
   using M = Mma<T>;
   constexpr int KS = DK / M::K;
+  constexpr int UT = sizeof(T) == 2 ? 4 : 2;  // key tiles per wave and batch (UT * KS operand loads in flight)
+  constexpr int UV = 8;                       // V^T fragments per batch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int LDS_S = Tpad + 4;                       // f32 score row stride
   const int LDS_P = Tpad + 16 / (int)sizeof(T);     // probability row stride (elements)
@@ -240,12 +275,15 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
   T* P = (T*)(sums + 16);                           // [16][LDS_P]
 
   const int h = blockIdx.x, b = blockIdx.y, rg = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const int row0 = b * W + rg * 16;
   const int nrows = (W - rg * 16) < 16 ? (W - rg * 16) : 16;
   const int klen = klens[b] < Tn ? klens[b] : Tn;
   const float scale = rsqrtf((float)DK);
+  const int ntile = Tpad / 16, nkk = Tpad / M::K;
+  const bool pv_wave = wave < DK / 16;
 
   typename M::frag qf[KS];
   {
@@ -255,40 +293,70 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
     for (int ks = 0; ks < KS; ++ks) qf[ks] = M::load(qrow + ks * M::K + lg * M::EPL);
   }
   const T* kb = kmem + (size_t)b * Tn * ldk + h * DK;
-  for (int nt = wave; nt < Tpad / 16; nt += 4) {
-    int key = nt * 16 + lr;
-    const int kc_ = key < Tn ? key : Tn - 1;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const T* vb = vT + ((size_t)b * d + h * DK + (pv_wave ? wave : 0) * 16 + lr) * Tpad;
+  // the first batch of V^T fragments: requested before the scores exist
+  typename M::frag vf[UV];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      acc = M::mma(qf[ks], M::load(kb + (size_t)kc_ * ldk + ks * M::K + lg * M::EPL), acc);
+  for (int u = 0; u < UV; ++u) vf[u] = M::load(vb + (u < nkk ? u : nkk - 1) * M::K + lg * M::EPL);
+  for (int nt0 = 0; nt0 < ntile; nt0 += 4 * UT) {
+    typename M::frag kf[UT][KS];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      S[(lg * 4 + r) * LDS_S + key] = key < klen ? acc[r] * scale : -INFINITY;
+    for (int u = 0; u < UT; ++u) {  // unconditional, from clamped rows (tiles past the end are computed and dropped)
+      const int key = (nt0 + wave + 4 * u) * 16 + lr;
+      const int kc_ = key < Tn ? key : Tn - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[u][ks] = M::load(kb + (size_t)kc_ * ldk + ks * M::K + lg * M::EPL);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int nt = nt0 + wave + 4 * u;
+      const int key = nt * 16 + lr;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = M::mma(qf[ks], kf[u][ks], acc);
+      if (nt < ntile) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(lg * 4 + r) * LDS_S + key] = key < klen ? acc[r] * scale : -INFINITY;
+      }
+    }
   }
   __syncthreads();
-  // softmax numerators per row (4 rows per wave); P holds exp(s - max) in the act dtype and
-  // sums[] the sum of the ROUNDED values, so the normalisation below is exact for what PV sees
-  for (int rr = wave * 4; rr < wave * 4 + 4; ++rr) {
+  // softmax numerators of the rows that exist, dealt round-robin to the waves; P holds exp(s - max) in the act dtype
+  // and sums[] the sum of the ROUNDED values, so the normalisation below is exact for what PV sees.  Rows past nrows
+  // (W < 16) get zero probabilities: their P.V lanes are computed and never stored.
+  for (int rr = wave; rr < 16; rr += 4) {
+    if (rr >= nrows) {
+      for (int j = lane; j < Tpad; j += 64) P[rr * LDS_P + j] = from_f32<T>(0.f);
+      continue;
+    }
     float mx = -INFINITY;
     for (int j = lane; j < Tpad; j += 64) mx = fmaxf(mx, S[rr * LDS_S + j]);
-    mx = wave_max(mx);
+    mx = wave_allmax_dpp(mx);
     float sum = 0.f;
     for (int j = lane; j < Tpad; j += 64) {
-      T pt = from_f32<T>(expf(S[rr * LDS_S + j] - mx));
+      T pt = from_f32<T>(__expf(S[rr * LDS_S + j] - mx));
       P[rr * LDS_P + j] = pt;
       sum += to_f32(pt);
     }
-    sum = wave_sum(sum);
+    sum = wave_allsum_dpp(sum);
     if (lane == 0) sums[rr] = sum;
   }
   __syncthreads();
-  if (wave < DK / 16) {
-    const T* vb = vT + ((size_t)b * d + h * DK + wave * 16 + lr) * Tpad;
+  if (pv_wave) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kk = 0; kk < Tpad / M::K; ++kk) {
-      const int ko = kk * M::K + lg * M::EPL;
-      acc = M::mma(M::load(P + lr * LDS_P + ko), M::load(vb + ko), acc);
+    for (int kk0 = 0; kk0 < nkk; kk0 += UV) {
+      if (kk0 > 0) {
+#pragma unroll
+        for (int u = 0; u < UV; ++u) vf[u] = M::load(vb + (kk0 + u < nkk ? kk0 + u : nkk - 1) * M::K + lg * M::EPL);
+      }
+#pragma unroll
+      for (int u = 0; u < UV; ++u) {
+        const int kk = kk0 + u < nkk ? kk0 + u : nkk - 1;
+        typename M::frag pf = M::load(P + lr * LDS_P + kk * M::K + lg * M::EPL);
+        if (kk0 + u >= nkk) pf = zero_frag<T>();
+        acc = M::mma(pf, vf[u], acc);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -374,9 +442,9 @@ int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const 
                      const int* tok_tab, void* ctx, hipStream_t s) {
   const int dk = d / heads;
   group = group < 1 ? 1 : (group > 16 ? 16 : group);
-  while (group > 1 && (size_t)group * 2 * Lmax * sizeof(float) > 64 * 1024) --group;  // default LDS limit
+  while (group > 1 && (size_t)group * Lmax * sizeof(int) > 64 * 1024) --group;  // default LDS limit
   dim3 grid(heads, em_cdiv(n, group)), block(64 * group);
-  const size_t lds = (size_t)group * 2 * Lmax * sizeof(float);
+  const size_t lds = (size_t)group * Lmax * sizeof(int);
   if (dk == 64)
     hipLaunchKernelGGL((dec_self_attn_kernel<T, 64>), grid, block, lds, s, (const T*)qkv, (T*)kc,
                        (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, tok_tab, (T*)ctx);

@@ -84,6 +84,54 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- cross-lane moves on the DPP path (VALU rate, ~8 cycles) instead of ds_bpermute (an LDS-pipe round trip of
+// 100+ cycles): a chain of __shfl_xor steps is a chain of dependent LDS round trips, and the search kernels' arg-max
+// rounds were exactly that (profiles/r03f_search_kernel_stats.csv: pre-beam 30 us, selection 9.7 us).
+// ctrl: quad_perm 0x00-0xff, row_ror:n 0x120+n, row_mirror 0x140, row_half_mirror 0x141 (rows = 16 lanes).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+constexpr int DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;
+// all-lanes maximum / minimum of a wave: four DPP steps inside the 16-lane rows, then the four row results through
+// scalar registers.  Every lane returns the same value.
+__device__ __forceinline__ float wave_allmax_dpp(float v) {
+  v = fmaxf(v, dpp_f32<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
+  v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_allsum_dpp(float v) {
+  v += dpp_f32<DPP_XOR1>(v);
+  v += dpp_f32<DPP_XOR2>(v);
+  v += dpp_f32<DPP_HALF_MIRROR>(v);
+  v += dpp_f32<DPP_MIRROR>(v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
+}
+__device__ __forceinline__ int wave_allmin_dpp(int v) {
+  v = min(v, dpp_i32<DPP_XOR1>(v));
+  v = min(v, dpp_i32<DPP_XOR2>(v));
+  v = min(v, dpp_i32<DPP_HALF_MIRROR>(v));
+  v = min(v, dpp_i32<DPP_MIRROR>(v));
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+
 #define EM_CHECK_LAUNCH()                                  \
   do {                                                     \
     hipError_t e__ = hipGetLastError();                    \

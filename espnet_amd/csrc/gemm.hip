@@ -456,6 +456,7 @@ int dispatch(int epi, int amode, const EmGemmArgs* p, hipStream_t s) {
 }  // namespace
 
 int em_gemm_skinny(int dtype, int epilogue, const EmGemmArgs* p, void* stream);  // gemm_skinny.hip
+int em_gemm_mid(int dtype, int epilogue, const EmGemmArgs* p, void* stream);     // gemm_mid.hip
 
 extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p, void* stream) {
   if (!p || !p->A || !p->W || !p->C) return EM_ERR_BAD_ARG;
@@ -475,8 +476,14 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   }
   const bool rec = em_prof_begin(stream);
   int rc = EM_ERR_UNSUPPORTED;
+  static const bool no_mid = getenv("ESPNET_AMD_NO_MID_GEMM") != nullptr;  // developer A/B switch (tools/gemm_bench.py)
   // very few rows (streaming encoder step, single-utterance beam): latency-bound weight streaming
   if (a_mode == EM_A_PLAIN && p->M <= 48) rc = em_gemm_skinny(dtype, epilogue, p, stream);
+  // a few hundred rows x a few hundred columns (the residual projections of a beam-search label step): the tiled grid
+  // would be a dozen workgroups walking K as a chain of dependent round trips; gemm_mid.hip splits K inside the workgroup
+  else if (a_mode == EM_A_PLAIN && !no_mid && (long)em_cdiv(p->M, 64) * em_cdiv(p->N, 128) < 96 &&
+           (long)em_cdiv(p->M, 32) * em_cdiv(p->N, 32) <= 2048)
+    rc = em_gemm_mid(dtype, epilogue, p, stream);
   if (rc == EM_ERR_UNSUPPORTED) {
     rc = EM_ERR_BAD_ARG;
     if (dtype == EM_F32) rc = dispatch<float>(epilogue, a_mode, p, (hipStream_t)stream);

@@ -18,44 +18,76 @@ namespace {
 
 constexpr int MAXMT = 3;  // 16-row tiles: M <= 48
 
+__device__ __forceinline__ bf16x8 keep_frag(bf16x8 v, bool live) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 r = __builtin_bit_cast(u32x4, v);
+  r = live ? r : (u32x4){0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ float keep_frag(float v, bool live) { return live ? v : 0.f; }
+
 // Epilogue of one 16-row tile i held in the standard C/D layout (col = lr, row = lg*4 + r).
 template <typename T, int EPI, int BNT>
 __device__ __forceinline__ void skinny_epilogue(const f32x4 (&v)[BNT], int i, int n0, int lr, int lg,
                                                 void* __restrict__ Cv,
-                                                const float* __restrict__ bias, int M, int N,
+                                                const float (&bpre)[BNT], int M, int N,
                                                 int ldc, float scale) {
-  if (EPI == EM_EPI_GLU) {
+  if constexpr (EPI == EM_EPI_GLU) {
     // BNT == 2: fragment 0 = 16 value columns, fragment 1 = their 16 gate columns
     const int ncol = n0 + lr;
-    if (ncol < N) {
-      const float bv = bias ? bias[ncol] : 0.f, bg = bias ? bias[ncol + 16] : 0.f;
-      const int ocol = n0 / 2 + lr;
+    const float bv = bpre[0], bg = bpre[BNT - 1];
+    const int ocol = n0 / 2 + lr;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (int)(unsigned)((size_t)M * ldc * sizeof(T)), 0x00020000);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = i * 16 + lg * 4 + r;
-        if (m < M)
-          ((T*)Cv)[(size_t)m * ldc + ocol] = from_f32<T>((v[0][r] + bv) * sigmoidf_(v[BNT - 1][r] + bg));
+    for (int r = 0; r < 4; ++r) {
+      const int m = i * 16 + lg * 4 + r;
+      const float y = (v[0][r] + bv) * sigmoidf_(v[BNT - 1][r] + bg);
+      const unsigned o = (m < M && ncol < N) ? (unsigned)(((size_t)m * ldc + ocol) * sizeof(T)) : 0xffffffffu;
+      if constexpr (sizeof(T) == 2) {
+        const bf16 hv = (bf16)y;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rg, o, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rg, o, 0, 0);
       }
     }
     return;
   }
+  // Everything goes through one raw buffer resource: an element past the edge gets the offset ~0, which the hardware
+  // drops (stores) or answers with 0 (loads).  Under `if (m < M)` branches hipcc put an s_waitcnt vmcnt(0) in front of
+  // every single store (and of every residual load): BNT * 4 dependent round trips at the end of a ~5 us kernel
+  // (tools/isa_waits.py, round 3).
+  constexpr bool OUT_ACT = (EPI == EM_EPI_STORE || EPI == EM_EPI_SWISH || EPI == EM_EPI_RELU);
+  constexpr unsigned ES = OUT_ACT ? sizeof(T) : 4;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (int)(unsigned)((size_t)M * ldc * ES), 0x00020000);
+  unsigned off[BNT][4];
+  float res[BNT][4];
 #pragma unroll
   for (int j = 0; j < BNT; ++j) {
     const int ncol = n0 + j * 16 + lr;
-    if (ncol >= N) continue;
-    const float b = bias ? bias[ncol] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = i * 16 + lg * 4 + r;
-      if (m >= M) continue;
+      off[j][r] = (m < M && ncol < N) ? (unsigned)(((size_t)m * ldc + ncol) * ES) : 0xffffffffu;
+      res[j][r] = 0.f;
+      if constexpr (EPI == EM_EPI_RESID_F32) res[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off[j][r], 0, 0));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BNT; ++j) {
+    const float b = bpre[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
       float x = v[j][r] + b;
-      const size_t o = (size_t)m * ldc + ncol;
       if (EPI == EM_EPI_SWISH) x = swishf_(x);
       if (EPI == EM_EPI_RELU) x = fmaxf(x, 0.f);
-      if (EPI == EM_EPI_STORE || EPI == EM_EPI_SWISH || EPI == EM_EPI_RELU) ((T*)Cv)[o] = from_f32<T>(x);
-      else if (EPI == EM_EPI_RESID_F32) ((float*)Cv)[o] += scale * x;
-      else if (EPI == EM_EPI_SCALE_F32) ((float*)Cv)[o] = scale * x;
-      else ((float*)Cv)[o] = x;  // EM_EPI_STORE_F32
+      if (EPI == EM_EPI_RESID_F32) x = res[j][r] + scale * x;
+      if (EPI == EM_EPI_SCALE_F32) x = scale * x;
+      if constexpr (OUT_ACT && sizeof(T) == 2) {
+        const bf16 hv = (bf16)x;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rs, off[j][r], 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, off[j][r], 0, 0);
+      }
     }
   }
 }
@@ -90,34 +122,42 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const T* __restrict__ 
   }
   const T* arow0 = A + lg * MM::EPL;
   const int nsteps = K / MM::K;
-  // wave w takes k-steps w, w+4, w+8, ...; 4 of its steps are issued back to back
+  float bpre[BNT];  // the bias of this lane's columns: requested with the operands, used after the reduction
+#pragma unroll
+  for (int j = 0; j < BNT; ++j) {
+    const int nc = n0 + j * 16 + lr;
+    bpre[j] = bias ? bias[nc < N ? nc : N - 1] : 0.f;
+  }
+  // wave w takes k-steps w, w+4, w+8, ...; 4 of its steps are requested back to back, for W and for all MAXMT row tiles,
+  // BEFORE the first MFMA.  Nothing in the batch is conditional: steps past the end repeat the last step and contribute
+  // through a zeroed A operand, row tiles past mt repeat row M-1 and are never stored.  (With `if (i < mt)` around the A
+  // loads and `if (step < nsteps)` around the MFMAs hipcc issued ONE load at a time and waited for it with
+  // s_waitcnt vmcnt(0): twelve dependent global round trips per batch instead of one - tools/isa_waits.py, round 3.
+  // This kernel is every projection of the streaming encoder step.)
   for (int s0 = wave; s0 < nsteps; s0 += 16) {
-    typename MM::frag fw[4][BNT];
+    typename MM::frag fw[4][BNT], fa[MAXMT][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int s = s0 + 4 * u;
       const int so = s < nsteps ? s : nsteps - 1;
 #pragma unroll
       for (int j = 0; j < BNT; ++j) fw[u][j] = MM::load(wrow[j] + (size_t)so * MM::K);
-    }
 #pragma unroll
-    for (int i = 0; i < MAXMT; ++i) {
-      if (i < mt) {
+      for (int i = 0; i < MAXMT; ++i) {
         int m = i * 16 + lr;
         m = m < M ? m : M - 1;
-        const T* ar = arow0 + (size_t)m * lda;
-        typename MM::frag fa[4];
+        fa[i][u] = MM::load(arow0 + (size_t)m * lda + (size_t)so * MM::K);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int s = s0 + 4 * u;
-          fa[u] = MM::load(ar + (size_t)(s < nsteps ? s : nsteps - 1) * MM::K);
-        }
+    for (int u = 0; u < 4; ++u) {
+      const bool live = s0 + 4 * u < nsteps;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (s0 + 4 * u < nsteps) {
+      for (int i = 0; i < MAXMT; ++i) {
+        const typename MM::frag a = keep_frag(fa[i][u], live);
 #pragma unroll
-            for (int j = 0; j < BNT; ++j) acc[i][j] = MM::mma(fa[u], fw[u][j], acc[i][j]);
-          }
+        for (int j = 0; j < BNT; ++j) acc[i][j] = MM::mma(a, fw[u][j], acc[i][j]);
       }
     }
   }
@@ -140,7 +180,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const T* __restrict__ 
       for (int w = 0; w < 4; ++w)
         v[j] += *(const f32x4*)(red + ((((size_t)w * mt + i) * BNT + j) * 64 + lane) * 4);
     }
-    skinny_epilogue<T, EPI, BNT>(v, i, n0, lr, lg, Cv, bias, M, N, ldc, scale);
+    skinny_epilogue<T, EPI, BNT>(v, i, n0, lr, lg, Cv, bpre, M, N, ldc, scale);
   }
 }
 

@@ -17,6 +17,16 @@
 namespace {
 
 constexpr int LG_BM = 32, LG_BN = 64;
+
+// sum over the 16 lanes of a row, in every lane, on DPP (hipcc turns __shfl_xor(., 4) and (., 8) into ds_bpermute: four
+// dependent LDS round trips per statistic)
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp_f32<DPP_XOR1>(v);
+  v += dpp_f32<DPP_XOR2>(v);
+  v += dpp_f32<DPP_HALF_MIRROR>(v);
+  v += dpp_f32<DPP_MIRROR>(v);
+  return v;
+}
 constexpr int LG_MAXV = 16;  // K <= 64 * LG_MAXV
 
 // NV = float4 chunks per lane per row (K <= 64 * NV).  All loads of a wave's 8 rows are in flight before
@@ -53,6 +63,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   typename MM::frag fw[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) fw[u] = MM::load(wrow + (size_t)(u < nsteps ? u : nsteps - 1) * MM::K);
+  const int ncol = n0 + wave * 16 + lr;
+  const float bv = bias ? bias[ncol < N ? ncol : N - 1] : 0.f;  // requested with the weights, used after the last MFMA
   // ---- prologue: LayerNorm of rows m0 .. m0+31 into LDS.  16 lanes per row (4 rows per wave at a time,
   // 2 passes): float4 loads (256 contiguous bytes per row and instruction), statistics reduced over 16
   // lanes only (xor 1, 2, 4, 8: DPP row operations, no LDS crossbar), 4 operand-dtype values per LDS
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < NV; ++j) s += (v[ps][j].x + v[ps][j].y) + (v[ps][j].z + v[ps][j].w);
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+      s = row16_allsum(s);
       const float mean = s / (float)K;
       float q = 0.f;
 #pragma unroll
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const float a = v[ps][j].x - mean, b2 = v[ps][j].y - mean, c = v[ps][j].z - mean, d2 = v[ps][j].w - mean;
           q += (a * a + b2 * b2) + (c * c + d2 * d2);
         }
-      q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+      q = row16_allsum(q);
       const float rstd = 1.0f / sqrtf(q / (float)K + eps);
       T* dst = sA + (size_t)(wave * 8 + ps * 4 + grp) * LDA;
 #pragma unroll
@@ -129,22 +141,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
   }
 
-  // ---- epilogue.  C/D layout: col = lr, row = lg*4 + r
-  const int ncol = n0 + wave * 16 + lr;
-  if (ncol >= N) return;
-  const float bv = bias ? bias[ncol] : 0.f;
+  // ---- epilogue.  C/D layout: col = lr, row = lg*4 + r.  Stores through a raw buffer resource: an element past the
+  // edge gets the offset ~0, which the hardware drops.  (Under `if (m < M)` branches hipcc put an s_waitcnt vmcnt(0) in
+  // front of every one of the eight stores - eight dependent store round trips at the end of a 7 us kernel - and the
+  // bias was loaded HERE, one more round trip after the last MFMA; tools/isa_waits.py, round 3.)
+  constexpr unsigned ES = EPI == EM_EPI_STORE_F32 ? 4 : sizeof(T);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (int)(unsigned)((size_t)M * ldc * ES), 0x00020000);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const f32x4 a = i ? acc1 : acc0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + i * 16 + lg * 4 + r;
-      if (m >= M) continue;
       float y = a[r] + bv;
       if (EPI == EM_EPI_RELU) y = fmaxf(y, 0.f);
-      const size_t o = (size_t)m * ldc + ncol;
-      if (EPI == EM_EPI_STORE_F32) ((float*)Cv)[o] = y;
-      else ((T*)Cv)[o] = from_f32<T>(y);
+      const unsigned off = (m < M && ncol < N) ? (unsigned)(((size_t)m * ldc + ncol) * ES) : 0xffffffffu;
+      if constexpr (EPI == EM_EPI_STORE_F32 || sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs, off, 0, 0);
+      } else {
+        const bf16 hv = (bf16)y;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rs, off, 0, 0);
+      }
     }
   }
 }

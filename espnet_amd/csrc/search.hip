@@ -22,6 +22,7 @@
 // frames; the forward-variable recurrence itself (sequential in t) runs only for the W winners
 // per utterance, in the update kernel.  CTC log-probs are kept transposed ([V][B*T]).
 #include <math.h>
+#include <stdlib.h>
 
 #include "em_common.h"
 
@@ -98,19 +99,42 @@ __global__ void search_init_utt_kernel(Ctx c) {
   }
 }
 
-// ---- step 1: decoder log-softmax + pre-beam, one 256-thread workgroup per row ----------------
+// ---- steps 1 + 2: decoder log-softmax + pre-beam + candidate totals, one 256-thread workgroup per row -----------
 // logits -> log-probs in place (transformer_decoder.py:233), then the top-S token ids of the
 // weighted full scores w_dec*logp + w_len (batch_beam_search.py:289-302), S rounds of block
 // arg-max over register-resident values (ties -> lowest id).  NV values per thread: V <= 256*NV.
+//
+// Round 3.  (a) The arg-max rounds reduce on DPP (wave_allmax_dpp / wave_allmin_dpp, em_common.h): with __shfl_xor
+// every round was a chain of twelve dependent ds_bpermute round trips, S rounds per wave and S more for the merge -
+// 30 us per label step for 5 000 numbers (profiles/r03f_search_kernel_stats.csv).  (b) The candidate totals of the
+// row's S + 1 slots (candidate_kernel below: CTC log psi of every pre-beam candidate, batch_beam_search.py:289-314)
+// are computed HERE, by the workgroup that has just chosen the candidates: one launch less per label step, the phi
+// terms of the row's prefix are built once in LDS for all slots instead of once per slot, and a slot is worked by
+// one 16-lane row (four slots per wave in lockstep, their log-prob columns requested UNT frames deep).
 constexpr int PREBEAM_SMAX = 128;  // pre-beam width of the fused row kernel (beam_size <= 85)
+constexpr int CTC_TMAX = 2048;
 
 template <int NV>
-__global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
+__global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c, int i_host) {
   __shared__ float s_v[4];
-  __shared__ int s_i[4];
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int V = c.p.V, S = c.p.S, NC = c.p.NC;
-  if (!c.b.alive[r]) return;
+  __shared__ float m_v[4 * PREBEAM_SMAX];
+  __shared__ int m_i[4 * PREBEAM_SMAX];
+  __shared__ float s_cf[PREBEAM_SMAX];  // the row's pre-beam: weighted full score
+  __shared__ int s_ct[PREBEAM_SMAX];    //                     token id
+  __shared__ float s_eosfull;
+  __shared__ float s_phi_same[CTC_TMAX], s_phi_diff[CTC_TMAX];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int V = c.p.V, S = c.p.S, NC = c.p.NC, W = c.p.W;
+  const int i = c.b.step ? *c.b.step : i_host;
+  const bool with_cand = S < V;  // pre-beam mode: this kernel also produces the candidate totals
+  if (with_cand && i >= c.p.Lmax - 1) return;
+  const int b = r / W;
+  if (!c.b.alive[r] || (with_cand && c.b.done[b])) {
+    if (with_cand)
+      for (int s = tid; s < NC; s += 256) c.b.cand_total[(size_t)r * NC + s] = -INFINITY;
+    return;
+  }
   // log-softmax of one logits row in place (block-wide), returning this thread's NV log-probs
   auto row_log_softmax = [&](float* lp, float (&out)[NV]) {
     float mx = -INFINITY;
@@ -120,7 +144,7 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
       out[k] = v < V ? lp[v] : -INFINITY;
       mx = fmaxf(mx, out[k]);
     }
-    mx = wave_max(mx);
+    mx = wave_allmax_dpp(mx);
     if (lane == 0) s_v[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]));
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) sum += (tid + 256 * k < V) ? expf(out[k] - mx) : 0.f;
-    sum = wave_sum(sum);
+    sum = wave_allsum_dpp(sum);
     if (lane == 0) s_v[wave] = sum;
     __syncthreads();
     const float lse = mx + logf(s_v[0] + s_v[1] + s_v[2] + s_v[3]);
@@ -167,10 +191,12 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
       if (tid + 256 * k < V) w[k] += c.p.w_lm * l[k];
   }
   if (S >= V) return;
+  // the <eos> slot's full score (always scored, :186-187), before the rounds knock values out
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (tid + 256 * k == c.p.eos) s_eosfull = w[k];
   // each wave extracts the top-S of its own 64*NV values with wave-level ops only (no block
   // barrier inside the rounds); the 4*S survivors are merged by wave 0
-  __shared__ float m_v[4 * PREBEAM_SMAX];
-  __shared__ int m_i[4 * PREBEAM_SMAX];
   const int SS = S < PREBEAM_SMAX ? S : PREBEAM_SMAX;
   for (int k = 0; k < SS; ++k) {
     float best = -INFINITY;
@@ -181,22 +207,15 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
         best = w[q];
         bi = tid + 256 * q;
       }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > best || (ov == best && oi < bi)) {
-        best = ov;
-        bi = oi;
-      }
-    }
+    const float wb = wave_allmax_dpp(best);
+    const int wi = wave_allmin_dpp(best == wb ? bi : 0x7fffffff);  // lowest id among the holders of the maximum
     if (lane == 0) {
-      m_v[wave * SS + k] = best;
-      m_i[wave * SS + k] = bi;
+      m_v[wave * SS + k] = wb;
+      m_i[wave * SS + k] = wi;
     }
 #pragma unroll
     for (int q = 0; q < NV; ++q)
-      if (tid + 256 * q == bi) w[q] = -INFINITY;
+      if (tid + 256 * q == wi) w[q] = -INFINITY;
   }
   __syncthreads();
   if (wave == 0) {
@@ -218,22 +237,98 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c) {
           best = cv[q];
           bi = ci[q];
         }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) {
-          best = ov;
-          bi = oi;
-        }
-      }
+      const float wb = wave_allmax_dpp(best);
+      const int wi = wave_allmin_dpp(best == wb ? bi : 0x7fffffff);
       if (lane == 0) {
-        c.b.cand_tok[(size_t)r * NC + k] = bi;
-        c.b.cand_full[(size_t)r * NC + k] = best;
+        c.b.cand_tok[(size_t)r * NC + k] = wi;
+        c.b.cand_full[(size_t)r * NC + k] = wb;
+        s_ct[k] = wi;
+        s_cf[k] = wb;
       }
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        if (ci[q] == bi) cv[q] = -INFINITY;
+        if (ci[q] == wi) cv[q] = -INFINITY;
+    }
+  }
+  // ---- candidate totals of the row's NC = S + 1 slots: slots 0..S-1 = the pre-beam, slot S = <eos>
+  //      total = (w_dec*dec + w_len + w_lm*lm) + w_ctc*(psi - s_prev) + running score   (batch_beam_search.py:289-314)
+  const bool ctc = c.p.w_ctc != 0.f;
+  const int xlen = ctc ? c.b.xlens[b] : 0;
+  const int LT = ldt(c.p);
+  const float2* rprev = (const float2*)((i & 1) ? c.b.r_b : c.b.r_a) + (size_t)r * LT;
+  if (ctc) {  // phi of the prefix, both forms (ctc_prefix_score.py:135-144), once for all slots
+    for (int t = tid; t < xlen; t += 256) {
+      const float2 rp = rprev[t];
+      s_phi_same[t] = rp.y;
+      s_phi_diff[t] = logaddexp_(rp.x, rp.y);
+    }
+  }
+  __syncthreads();
+  const int lr = lane & 15, q4 = lane >> 4;
+  const int last_tok = c.b.tok[(size_t)i * c.p.B * W + r];
+  const float base = c.b.run_score[r], sprev = ctc ? c.b.s_prev[r] : 0.f;
+  constexpr int UNT = 8;
+  for (int s0 = 0; s0 < NC; s0 += 16) {
+    const int s = s0 + wave * 4 + q4;       // this 16-lane row's slot
+    const bool slot_ok = s < NC;
+    const bool eos_slot = s >= S;
+    const int tokc = (slot_ok && !eos_slot) ? s_ct[s] : c.p.eos;
+    float full = (slot_ok && !eos_slot) ? s_cf[s] : s_eosfull;
+    bool dup = false;  // <eos> already among the pre-beam candidates: that slot carries it
+    if (eos_slot)
+      for (int k = 0; k < S; ++k) dup |= (s_ct[k] == tokc);
+    float total = full;
+    float psi = 0.f;
+    if (ctc) {
+      // log psi = logsumexp_t(phi[t-1] + x[t]) (+) r[start-1, 0]  (:166-181), lanes of the row over frames
+      const bool same = tokc == last_tok;
+      const float* ph = same ? s_phi_same : s_phi_diff;
+      const float* xc = c.b.ctc_lpT + (size_t)tokc * c.p.B * LT + (size_t)b * LT;
+      const int start = i > 1 ? i : 1;
+      float m = -INFINITY, sm = 0.f;
+      if (lr == 0) {  // the r[start-1, 0] term (:176-178): x[0] for the empty prefix, else logzero
+        m = (i == 0) ? xc[0] : LOGZERO;
+        sm = 1.f;
+      }
+      for (int tb = start; tb < xlen; tb += 16 * UNT) {  // (wave-uniform trip count)
+        float xv[UNT];
+#pragma unroll
+        for (int u = 0; u < UNT; ++u) {  // unconditional requests from clamped frames
+          const int t = tb + lr + 16 * u;
+          xv[u] = xc[t < xlen ? t : xlen - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < UNT; ++u) {
+          const int t = tb + lr + 16 * u;
+          if (t < xlen) {
+            const float term = ph[t - 1] + xv[u];
+            const float mm = fmaxf(m, term);
+            sm = sm * expf(m - mm) + expf(term - mm);
+            m = mm;
+          }
+        }
+      }
+      // the 16 lanes of the row combine (DPP, all-reduce inside the row)
+      float M = m;
+      M = fmaxf(M, dpp_f32<DPP_XOR1>(M));
+      M = fmaxf(M, dpp_f32<DPP_XOR2>(M));
+      M = fmaxf(M, dpp_f32<DPP_HALF_MIRROR>(M));
+      M = fmaxf(M, dpp_f32<DPP_MIRROR>(M));
+      sm = (m > -INFINITY) ? sm * expf(m - M) : 0.f;
+      sm += dpp_f32<DPP_XOR1>(sm);
+      sm += dpp_f32<DPP_XOR2>(sm);
+      sm += dpp_f32<DPP_HALF_MIRROR>(sm);
+      sm += dpp_f32<DPP_MIRROR>(sm);
+      psi = M + logf(sm);
+      if (tokc == c.p.blank && c.p.eos != c.p.blank) psi = LOGZERO;        // :188-190
+      else if (tokc == c.p.eos) psi = s_phi_diff[xlen - 1];                // :184-186
+      total = total + c.p.w_ctc * (psi - sprev);
+    }
+    total = dup ? -INFINITY : total + base;
+    if (slot_ok && lr == 0) {
+      if (eos_slot) c.b.cand_tok[(size_t)r * NC + s] = tokc;
+      if (ctc && !dup) c.b.cand_psi[(size_t)r * NC + s] = psi;
+      c.b.cand_total[(size_t)r * NC + s] = total;
     }
   }
 }
@@ -374,50 +469,53 @@ __global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i_host) {
 
 // ---- step 3: per-utterance top-W over the W*NC candidate totals (batch_beam :98-122) -----------
 // one wave per utterance; W rounds of arg-max, ties -> lowest flat index (row-major slot order)
+// The register-resident form (one wave, up to 64 * SEL_KM candidates: beam 10 x 16 = 160, beam 20 x 31 = 620 ...): ONE
+// global round trip, W rounds of arg-max on DPP (until round 3 the rounds were __shfl_xor chains - twelve dependent
+// ds_bpermute round trips per round, 9.7 us per label step).  Largest total, lowest flat index on ties.  s_sel / s_tot
+// (LDS, may be NULL) receive the winners for a caller that goes on in the same workgroup.
+constexpr int SEL_KM = 16;
+__device__ __forceinline__ void select_wave(const Ctx& c, int b, int lane, int* s_sel, float* s_tot) {
+  const int W = c.p.W, total = W * c.p.NC;
+  const float* tot = c.b.cand_total + (size_t)b * total;
+  float x[SEL_KM];
+#pragma unroll
+  for (int k = 0; k < SEL_KM; ++k) {
+    const int v = lane + 64 * k;
+    const float t = tot[v < total ? v : total - 1];  // unconditional load, masked afterwards
+    x[k] = v < total ? t : -INFINITY;
+  }
+  for (int r = 0; r < W; ++r) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < SEL_KM; ++k)
+      if (x[k] > best) {
+        best = x[k];
+        bi = lane + 64 * k;
+      }
+    const float wb = wave_allmax_dpp(best);
+    const int wi = wave_allmin_dpp(best == wb ? bi : 0x7fffffff);
+    if (lane == 0) {
+      const int sel = (wb > -INFINITY) ? wi : -1;
+      c.b.sel_idx[b * W + r] = sel;
+      c.b.sel_total[b * W + r] = wb;
+      if (s_sel) {
+        s_sel[r] = sel;
+        s_tot[r] = wb;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SEL_KM; ++k)
+      if (wi == lane + 64 * k) x[k] = -INFINITY;  // the winner leaves its owner's registers
+  }
+}
 __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int W = c.p.W, NC = c.p.NC;
   const int total = W * NC;
   float* tot = c.b.cand_total + (size_t)b * total;
-  // Up to 64 * KM candidates (beam 10 x 21 = 210, beam 20 x 41 = 820 ...) live in registers for all W rounds: ONE
-  // global round trip for the kernel.  (Until round 3 every round re-read the totals from global memory and knocked
-  // its winner out there: W dependent round trips, 10.9 us for 210 numbers.)  Same order as before: largest total,
-  // lowest flat index on ties.
-  constexpr int KM = 16;
-  if (total <= 64 * KM) {
-    float x[KM];
-#pragma unroll
-    for (int k = 0; k < KM; ++k) {
-      const int v = lane + 64 * k;
-      const float t = tot[v < total ? v : total - 1];  // unconditional load, masked afterwards
-      x[k] = v < total ? t : -INFINITY;
-    }
-    for (int r = 0; r < W; ++r) {
-      float best = -INFINITY;
-      int bi = 0x7fffffff;
-#pragma unroll
-      for (int k = 0; k < KM; ++k)
-        if (x[k] > best) {
-          best = x[k];
-          bi = lane + 64 * k;
-        }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) {
-          best = ov;
-          bi = oi;
-        }
-      }
-      if (lane == 0) {
-        c.b.sel_idx[b * W + r] = (best > -INFINITY) ? bi : -1;
-        c.b.sel_total[b * W + r] = best;
-      }
-#pragma unroll
-      for (int k = 0; k < KM; ++k)
-        if (bi == lane + 64 * k) x[k] = -INFINITY;  // the winner leaves its owner's registers
-    }
+  if (total <= 64 * SEL_KM) {
+    select_wave(c, b, lane, nullptr, nullptr);
     return;
   }
   for (int k = 0; k < W; ++k) {
@@ -430,15 +528,10 @@ __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
         bi = v;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > best || (ov == best && oi < bi)) {
-        best = ov;
-        bi = oi;
-      }
-    }
+    const float wb = wave_allmax_dpp(best);
+    const int wi = wave_allmin_dpp(best == wb ? bi : 0x7fffffff);
+    best = wb;
+    bi = wi;
     if (lane == 0) {
       c.b.sel_idx[b * W + k] = (best > -INFINITY) ? bi : -1;
       c.b.sel_total[b * W + k] = best;
@@ -455,7 +548,6 @@ __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
 // (:135-144, computed in parallel from the prefix's r_prev) in LDS with coalesced reads, lane 0
 // walks the chain LDS -> LDS, all lanes write the result back coalesced.  Only t >= max(i,1)-1
 // is produced: a later step's recurrence starts at t = i+1 and reads r_prev[t-1].
-constexpr int CTC_TMAX = 2048;
 // Forward variables r[t] = (r^n, r^b) of prefix + label (ctc_prefix_score.py:131-132, 158-164) by one
 // 64-thread workgroup: all lanes stage x[t][label], x[t][blank] and the phi terms in LDS with coalesced
 // reads, lane 0 walks the sequential chain LDS -> LDS, all lanes write the result back coalesced.  Only
@@ -481,6 +573,19 @@ __device__ __forceinline__ CtcMap ctc_compose(const CtcMap& hi, const CtcMap& lo
   m.f = logaddexp_(logaddexp_(hi.d + lo.c, hi.e + lo.f), hi.f);
   return m;
 }
+// WG_SYNC: the 64 threads are a workgroup of their own (__syncthreads); otherwise one wave of a larger workgroup working
+// in LDS arrays private to it: DS operations of a wave execute in issue order, so only the compiler has to be kept from
+// reordering across the hand-over points.
+template <bool WG_SYNC>
+__device__ __forceinline__ void ctc_sync() {
+  if constexpr (WG_SYNC) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+template <bool WG_SYNC>
 __device__ __forceinline__ void ctc_chain_wg(const float2* __restrict__ rprev, const float* __restrict__ xc,
                                              const float* __restrict__ xb, bool same, int i, int xlen,
                                              float2* __restrict__ rout, int lane, float* s_xn, float* s_xb,
@@ -492,7 +597,7 @@ __device__ __forceinline__ void ctc_chain_wg(const float2* __restrict__ rprev, c
     const float2 rp = rprev[t - 1];
     s_phi[t] = same ? rp.y : logaddexp_(rp.x, rp.y);
   }
-  __syncthreads();
+  ctc_sync<WG_SYNC>();
   const int steps = xlen - start;
   const int chunk = (steps + 63) >> 6;
   const int t_lo = start + lane * chunk;
@@ -533,7 +638,7 @@ __device__ __forceinline__ void ctc_chain_wg(const float2* __restrict__ rprev, c
     rb = nb;
     s_out[t] = make_float2(rn, rb);
   }
-  __syncthreads();
+  ctc_sync<WG_SYNC>();
   for (int t = start - 1 + lane; t < xlen; t += 64) rout[t] = s_out[t];
 }
 __global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i_host) {
@@ -559,7 +664,7 @@ __global__ __launch_bounds__(64) void ctc_state_kernel(Ctx c, int i_host) {
   const float2* rprev = (const float2*)((i & 1) ? c.b.r_b : c.b.r_a) + (size_t)prow * LT;
   float2* rout = (float2*)((i & 1) ? c.b.r_a : c.b.r_b) + (size_t)rnew * LT;
   const bool same = (tk == c.b.tok[(size_t)i * n + prow]);
-  ctc_chain_wg(rprev, xc, xb, same, i, xlen, rout, lane, s_xn, s_xb, s_phi, s_out);
+  ctc_chain_wg<true>(rprev, xc, xb, same, i, xlen, rout, lane, s_xn, s_xb, s_phi, s_out);
 }
 
 // ---- step 4: build the new rows (batch_beam_search.py:317-357 + post_process :359-423) ---------
@@ -693,6 +798,156 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
     if (done) c.b.done[b] = 1;
   }
   step_advance(c, lane);
+}
+
+// ---- steps 3 + 3b + 4 in ONE launch (round 3): per-utterance selection, the winners' CTC forward variables and the
+// new rows.  One workgroup per utterance, one wave per beam slot.  Until round 3 these were three dependent launches
+// (select 9.7 us, ctc_state 6.7 us, update 12 us per label step): the selection's rounds were ds_bpermute chains (now
+// DPP, select_wave), and update copied the W ancestor rows one after the other in one wave - W x ceil(i / 64) dependent
+// load -> store round trips - where here wave k copies row k while it also walks row k's CTC chain.
+// Same arithmetic, same order of the ended list as the three kernels (which stay for W > 16, long memories whose
+// chains do not fit the LDS W at a time, and the streaming search, which commits rows under the host's control).
+__global__ __launch_bounds__(1024) void tail_kernel(Ctx c, int i_host, int lt_cap) {
+  extern __shared__ float tail_lds[];  // per wave: s_xn, s_xb, s_phi [lt_cap] + s_out [lt_cap] float2
+  __shared__ int s_prev_row[64], s_tok[64], s_valid[64], s_end[64], s_sel[64];
+  __shared__ float s_seltot[64], s_rec[4][64];
+  const int i = c.b.step ? *c.b.step : i_host;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (i >= c.p.Lmax - 1) {
+    step_advance(c, tid);
+    return;
+  }
+  const int b = blockIdx.x;
+  const int W = c.p.W, NC = c.p.NC, V = c.p.V, Lmax = c.p.Lmax, n = c.p.B * c.p.W;
+  const int* anc_old = (i & 1) ? c.b.anc_b : c.b.anc_a;
+  int* anc_new = (i & 1) ? c.b.anc_a : c.b.anc_b;
+  const bool was_done = c.b.done[b] != 0;
+  const int maxlen = c.b.maxlens[b], minlen = c.b.minlens[b];
+  // ---- selection (batch_beam :98-122): wave 0
+  if (wave == 0) select_wave(c, b, lane, s_sel, s_seltot);
+  __syncthreads();
+  // ---- the new rows' records (batch_beam_search.py:317-357), wave 0, a lane per row
+  float n_score = -INFINITY, n_sdec = 0.f, n_sctc = 0.f, n_slen = 0.f, n_sprev = 0.f, n_slm = 0.f;
+  if (wave == 0 && lane < W) {
+    const int sel = was_done ? -1 : s_sel[lane];
+    int valid = sel >= 0, prow = b * W, tk = c.p.eos;
+    if (valid) {
+      const int pk = sel / NC, sl = sel - pk * NC;
+      prow = b * W + pk;
+      tk = c.b.cand_tok[(size_t)prow * NC + sl];
+      n_score = s_seltot[lane];
+      if (c.p.w_dec != 0.f) n_sdec = c.b.run_sdec[prow] + c.b.dec_logp[(size_t)prow * V + tk];
+      if (c.p.w_len != 0.f) n_slen = c.b.run_slen[prow] + 1.0f;
+      if (c.p.w_lm != 0.f) n_slm = c.b.run_slm[prow] + c.b.lm_logp[(size_t)prow * V + tk];
+      if (c.p.w_ctc != 0.f) {
+        const float psi = c.b.cand_psi[(size_t)prow * NC + sl];
+        n_sctc = c.b.run_sctc[prow] + (psi - c.b.s_prev[prow]);
+        n_sprev = psi;  // select_state: s = log_psi[i, new_id] (scorers/ctc.py:56)
+      }
+    }
+    s_prev_row[lane] = prow;
+    s_tok[lane] = tk;
+    s_valid[lane] = valid;
+    // ended: the new token is <eos>, or <eos> is forced at the last position (:393-410)
+    s_end[lane] = valid && (tk == c.p.eos || i == maxlen - 1);
+  }
+  __syncthreads();  // every read of the old per-row scalars is done (wave 0 made them all)
+  // ---- wave k: row k's ancestor table and CTC forward variables (scorers/ctc.py:54-62)
+  if (wave < W && s_valid[wave]) {
+    const int k = wave, rnew = b * W + k, prow = s_prev_row[k], tk = s_tok[k];
+    const int* src = anc_old + (size_t)prow * Lmax;
+    int* dst = anc_new + (size_t)rnew * Lmax;
+    for (int j = lane; j <= i; j += 64) dst[j] = src[j];
+    if (lane == 0 && i + 1 < Lmax) dst[i + 1] = rnew;
+    if (c.p.w_ctc != 0.f && !s_end[k]) {  // ended rows need no state
+      const int xlen = c.b.xlens[b];
+      const int LT = ldt(c.p);
+      const size_t BT = (size_t)c.p.B * LT;
+      const float* xc = c.b.ctc_lpT + (size_t)tk * BT + (size_t)b * LT;
+      const float* xb = c.b.ctc_lpT + (size_t)c.p.blank * BT + (size_t)b * LT;
+      const float2* rprev = (const float2*)((i & 1) ? c.b.r_b : c.b.r_a) + (size_t)prow * LT;
+      float2* rout = (float2*)((i & 1) ? c.b.r_a : c.b.r_b) + (size_t)rnew * LT;
+      const bool same = (tk == c.b.tok[(size_t)i * n + prow]);
+      float* base = tail_lds + (size_t)wave * 5 * lt_cap;
+      ctc_chain_wg<false>(rprev, xc, xb, same, i, xlen, rout, lane, base, base + lt_cap, base + 2 * lt_cap,
+                          (float2*)(base + 3 * lt_cap));
+    }
+  }
+  // ---- wave 0: the rows' scalars, the ended list, end detection (as update_kernel)
+  if (wave == 0) {
+    if (lane < W) {
+      const int rnew = b * W + lane;
+      if (s_valid[lane]) {
+        c.b.tok[(size_t)(i + 1) * n + rnew] = s_tok[lane];
+        c.b.parent[(size_t)(i + 1) * n + rnew] = s_prev_row[lane];
+      }
+      const int alive = s_valid[lane] && !s_end[lane];
+      c.b.alive[rnew] = alive;
+      c.b.run_score[rnew] = alive ? n_score : -INFINITY;
+      c.b.run_sdec[rnew] = n_sdec;
+      c.b.run_sctc[rnew] = n_sctc;
+      c.b.run_slen[rnew] = n_slen;
+      if (c.b.run_slm) c.b.run_slm[rnew] = n_slm;
+      c.b.s_prev[rnew] = n_sprev;
+      c.b.sel_total[rnew] = n_score;  // (what update_kernel leaves there)
+      s_seltot[lane] = n_score;
+      s_rec[0][lane] = n_sdec;
+      s_rec[1][lane] = n_sctc;
+      s_rec[2][lane] = n_slen;
+      s_rec[3][lane] = n_slm;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && !was_done) {
+      // ended list, in row order (the reference appends in batch order)
+      int cnt = c.b.end_count[b];
+      const int cap = c.p.end_cap;
+      int n_alive = 0;
+      for (int k = 0; k < W; ++k) {
+        const int rnew = b * W + k;
+        if (!s_valid[k]) continue;
+        if (!s_end[k]) {
+          ++n_alive;
+          continue;
+        }
+        if (i < minlen) continue;  // :417-418
+        const int forced = (i == maxlen - 1);
+        const int ylen = i + 2 + forced;  // <sos> + (i+1) tokens [+ forced <eos>]
+        const float sc = s_seltot[k];
+        if (cnt < cap) {
+          const size_t e = (size_t)b * cap + cnt;
+          c.b.end_pos[e] = i + 1;
+          c.b.end_slot[e] = rnew;
+          c.b.end_forced[e] = forced;
+          c.b.end_score[e] = sc;
+          c.b.end_sdec[e] = s_rec[0][k];
+          c.b.end_sctc[e] = s_rec[1][k];
+          c.b.end_slen[e] = s_rec[2][k];
+          if (c.b.end_slm) c.b.end_slm[e] = s_rec[3][k];
+          ++cnt;
+        }
+        if (sc > c.b.best_all[b]) c.b.best_all[b] = sc;
+        float* bl = c.b.best_by_len + (size_t)b * (Lmax + 2) + ylen;
+        if (sc > *bl) *bl = sc;
+      }
+      c.b.end_count[b] = cnt;
+      // end detection (e2e_asr_common.py:14-44) and "no hypothesis" (beam_search.py:446-448)
+      int done = (n_alive == 0);
+      if (!done && c.p.use_end_detect && cnt > 0) {
+        int count = 0;
+        for (int m = 0; m < 3; ++m) {
+          const int len = i - m;
+          if (len < 0) continue;
+          const float v = c.b.best_by_len[(size_t)b * (Lmax + 2) + len];
+          if (v > -INFINITY && v - c.b.best_all[b] < D_END) ++count;
+        }
+        if (count == 3) done = 1;
+      }
+      if (done) c.b.done[b] = 1;
+    }
+  }
+  step_advance(c, tid);
 }
 
 // x[v][col] <- log_softmax over v of (x[v][col] + bias[v]), columns = (utterance, frame) pairs.
@@ -1026,7 +1281,7 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
 // state (tree, ancestor tables, running scores, r) is modified; the decoder / LM K/V caches get
 // their position-i entries.
 int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, const EmSearchBuffers* b,
-                int i, void* stream) {
+                int i, void* stream, bool with_select = true) {
   hipStream_t s = (hipStream_t)stream;
   Ctx c{*p, *b};
   const int n = p->B * p->W, V = p->V;
@@ -1037,6 +1292,7 @@ int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, 
     EM_TRY(decoder_step(dtype, dw, a, stream));
   }
   if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));
+  bool cand_done = false;  // the fused row kernel also produced the candidate totals
   if (p->w_dec != 0.f || p->w_lm != 0.f || p->w_len != 0.f) {
     if ((p->S > PREBEAM_SMAX && p->S < V) || V > 256 * 40) {
       if (p->w_lm != 0.f || p->w_dec == 0.f) return EM_ERR_UNSUPPORTED;  // needs the fused row kernel
@@ -1044,18 +1300,21 @@ int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, 
       if (p->S < V)
         hipLaunchKernelGGL(prebeam_kernel, dim3(n), dim3(64), (size_t)V * sizeof(float), s, c);
     } else if (V <= 256 * 8) {
-      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<8>, dim3(n), dim3(256), 0, s, c);
+      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<8>, dim3(n), dim3(256), 0, s, c, i);
+      cand_done = p->S < V;
     } else if (V <= 256 * 20) {
-      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<20>, dim3(n), dim3(256), 0, s, c);
+      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<20>, dim3(n), dim3(256), 0, s, c, i);
+      cand_done = p->S < V;
     } else {
-      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<40>, dim3(n), dim3(256), 0, s, c);
+      hipLaunchKernelGGL(logsoftmax_prebeam_kernel<40>, dim3(n), dim3(256), 0, s, c, i);
+      cand_done = p->S < V;
     }
   }
-  {
+  if (!cand_done) {  // all-vocabulary mode (no pre-beam) and the generic pre-beam: candidate totals as a launch of their own
     const long waves = (long)n * p->NC;
     hipLaunchKernelGGL(candidate_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, c, i);
   }
-  hipLaunchKernelGGL(select_kernel, dim3(p->B), dim3(64), 0, s, c);
+  if (with_select) hipLaunchKernelGGL(select_kernel, dim3(p->B), dim3(64), 0, s, c);
   return EM_OK;
 }
 
@@ -1190,10 +1449,21 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
   hipStream_t s = (hipStream_t)stream;
   Ctx c{*p, *b};
   const int n = p->B * p->W;
+  // selection + the winners' CTC state + the new rows in one launch where a beam's chains fit the LDS side by side
+  const int lt_cap = ldt(*p);
+  const size_t tail_lds = p->w_ctc != 0.f ? (size_t)p->W * 5 * lt_cap * sizeof(float) : 0;
+  static const bool no_tail = getenv("ESPNET_AMD_NO_TAIL_FUSION") != nullptr;  // developer A/B switch
+  const bool fused_tail = !no_tail && p->W <= 16 && p->W * p->NC <= 64 * SEL_KM && tail_lds <= 144 * 1024;
+  static EmLdsCap cap = {};
+  if (fused_tail && tail_lds > 64 * 1024 && em_raise_lds_cap((const void*)tail_kernel, tail_lds, &cap) != EM_OK) return EM_ERR_LAUNCH;
   for (int i = i0; i < i1; ++i) {
-    EM_TRY(search_core(dtype, p, dw, b, i, stream));
-    if (p->w_ctc != 0.f) hipLaunchKernelGGL(ctc_state_kernel, dim3(n), dim3(64), 0, s, c, i);
-    hipLaunchKernelGGL(update_kernel, dim3(p->B), dim3(64), 0, s, c, i);
+    EM_TRY(search_core(dtype, p, dw, b, i, stream, !fused_tail));
+    if (fused_tail) {
+      hipLaunchKernelGGL(tail_kernel, dim3(p->B), dim3(64 * p->W), tail_lds, s, c, i, lt_cap);
+    } else {
+      if (p->w_ctc != 0.f) hipLaunchKernelGGL(ctc_state_kernel, dim3(n), dim3(64), 0, s, c, i);
+      hipLaunchKernelGGL(update_kernel, dim3(p->B), dim3(64), 0, s, c, i);
+    }
     EM_CHECK_LAUNCH();
   }
   return EM_OK;
@@ -1310,7 +1580,7 @@ __global__ __launch_bounds__(64) void ctc_prefix_state_kernel(
   const int r = rows[k], tk = toks[k];
   const int b = r / W, xlen = xlens[b];
   const size_t BT = (size_t)B * LT;
-  ctc_chain_wg(r_prev + (size_t)r * LT, lpT + (size_t)tk * BT + (size_t)b * LT,
+  ctc_chain_wg<true>(r_prev + (size_t)r * LT, lpT + (size_t)tk * BT + (size_t)b * LT,
                lpT + (size_t)blank * BT + (size_t)b * LT, tk == last[r], i, xlen, r_out + (size_t)k * LT, lane,
                s_xn, s_xb, s_phi, s_out);
 }

@@ -105,7 +105,9 @@ def test_gemm_store_f32(lib, prec, M, N, K):
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128),  # tiled kernel
-                                   (5, 64, 64), (42, 256, 2048), (48, 96, 256), (160, 1536, 512)])  # skinny (M <= 48) / tiled
+                                   (5, 64, 64), (42, 256, 2048), (48, 96, 256), (160, 1536, 512),  # skinny (M <= 48) / tiled
+                                   (160, 512, 2048), (160, 512, 512), (640, 512, 2048), (77, 192, 192),  # gemm_mid.hip
+                                   (50, 64, 64), (1000, 640, 256)])
 def test_gemm_epilogues(lib, prec, M, N, K):
     dt, tdt = DT[prec]
     tol = 1e-5 if prec == "f32" else 1e-2
