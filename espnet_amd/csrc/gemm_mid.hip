@@ -16,6 +16,8 @@
 // f32 (the parity mode) runs the same kernel: a 16-byte operand load then carries four consecutive k of a row, used
 // as element s of four v_mfma_f32_16x16x4_f32 steps (A and W use the same k assignment, so any assignment contracts
 // correctly).
+#include <stdlib.h>
+
 #include "em_common.h"
 
 namespace {
@@ -162,9 +164,8 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
   }
 }
 
-template <typename T, int EPI>
-int launch_mid(const EmGemmArgs* p, hipStream_t s) {
-  constexpr int BMT = 2, BNT = 2;
+template <typename T, int EPI, int BMT, int BNT>
+int launch_mid_tile(const EmGemmArgs* p, hipStream_t s) {
   static_assert(BMT * BNT <= NW, "one finishing wave per fragment");
   dim3 grid(em_cdiv(p->N, 16 * BNT), em_cdiv(p->M, 16 * BMT));
   const int per = em_cdiv(p->K / Frag16<T>::KS, NW);  // steps per wave: K = 512 bf16 -> 2, K = 2048 -> 8
@@ -177,6 +178,26 @@ int launch_mid(const EmGemmArgs* p, hipStream_t s) {
 #undef EM_MID_LAUNCH
   EM_CHECK_LAUNCH();
   return EM_OK;
+}
+
+template <typename T, int EPI>
+int launch_mid(const EmGemmArgs* p, hipStream_t s) {
+  // 16 x 32 tiles while 32 x 32 ones would not even give every CU a workgroup: at 160 x 512 the label step runs 0.383
+  // against 0.399 ms with them (profiles/r03h: more workgroups beat fewer operand bytes; 16 x 16 and 32 x 16 do not
+  // help further, 16 x 64 and 32 x 64 lose).  Developer A/B switch: ESPNET_AMD_MID_TILE = "11" | "12" | "21" | "22" | "14" | "24".
+  static const int force = [] {
+    const char* e = getenv("ESPNET_AMD_MID_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  const int tile = force ? force : ((long)em_cdiv(p->M, 32) * em_cdiv(p->N, 32) < 256 ? 12 : 22);
+  switch (tile) {
+    case 11: return launch_mid_tile<T, EPI, 1, 1>(p, s);
+    case 12: return launch_mid_tile<T, EPI, 1, 2>(p, s);
+    case 21: return launch_mid_tile<T, EPI, 2, 1>(p, s);
+    case 14: return launch_mid_tile<T, EPI, 1, 4>(p, s);
+    case 24: return launch_mid_tile<T, EPI, 2, 4>(p, s);
+    default: return launch_mid_tile<T, EPI, 2, 2>(p, s);
+  }
 }
 
 template <typename T>

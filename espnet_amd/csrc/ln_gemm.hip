@@ -12,6 +12,8 @@
 // W fragments straight from global memory (each W element is used by one wave only), 4 k-steps of
 // loads in flight.  Every workgroup of a column strip re-normalises the same rows: 64 KB of L2 reads
 // and ~2 us of ALU instead of a 5 us launch.
+#include <stdlib.h>
+
 #include "em_common.h"
 
 namespace {
@@ -31,7 +33,7 @@ constexpr int LG_MAXV = 16;  // K <= 64 * LG_MAXV
 
 // NV = float4 chunks per lane per row (K <= 64 * NV).  All loads of a wave's 8 rows are in flight before
 // any reduction: loading row by row serialises the global round trips.
-template <typename T, int EPI, int NV, bool EXACT>
+template <typename T, int EPI, int NV, bool EXACT, int RT>  // RT: 16-row tiles per workgroup (2: 32 rows, 1: 16 rows)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ln_gemm_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ g,
                                                       const float* __restrict__ be, float eps,
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int n0 = blockIdx.x * LG_BN, m0 = blockIdx.y * LG_BM;
+  const int n0 = blockIdx.x * LG_BN, m0 = blockIdx.y * 16 * RT;
   // EXACT: K == 64 * NV, so `j < nv` folds away.  With a runtime nv every row / gamma / beta load sits under a (uniform)
   // branch, hipcc follows each with s_waitcnt vmcnt(0) - its wait counting gives up at a branch - and the prologue
   // is a chain of dependent global round trips (tools/isa_waits.py: 3 before the statistics at K = 512; round 3).
@@ -72,10 +74,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // kernel's 11.7 (phase ablation during development; tools/ln_gemm_bench.py times the result).
   {
     const int grp = lane >> 4, li = lane & 15;
-    float4 v[2][NV];
+    float4 v[RT][NV];
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      int m = m0 + wave * 8 + ps * 4 + grp;
+    for (int ps = 0; ps < RT; ++ps) {
+      int m = m0 + wave * 4 * RT + ps * 4 + grp;
       m = m < M ? m : M - 1;
       const float4* xr = (const float4*)(x + (size_t)m * K);
 #pragma unroll
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // pass's statistics to save registers, and the prologue becomes three dependent round trips
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
+    for (int ps = 0; ps < RT; ++ps) {
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < NV; ++j) s += (v[ps][j].x + v[ps][j].y) + (v[ps][j].z + v[ps][j].w);
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       q = row16_allsum(q);
       const float rstd = 1.0f / sqrtf(q / (float)K + eps);
-      T* dst = sA + (size_t)(wave * 8 + ps * 4 + grp) * LDA;
+      T* dst = sA + (size_t)(wave * 4 * RT + ps * 4 + grp) * LDA;
 #pragma unroll
       for (int j = 0; j < NV; ++j)
         if (j < nv) {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int u = 0; u < U; ++u)
       if (s0 + u < nsteps) {
         acc0 = MM::mma(MM::load(a0 + (size_t)(s0 + u) * MM::K), fw[u], acc0);
-        acc1 = MM::mma(MM::load(a1 + (size_t)(s0 + u) * MM::K), fw[u], acc1);
+        if constexpr (RT == 2) acc1 = MM::mma(MM::load(a1 + (size_t)(s0 + u) * MM::K), fw[u], acc1);
       }
   }
 
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr unsigned ES = EPI == EM_EPI_STORE_F32 ? 4 : sizeof(T);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (int)(unsigned)((size_t)M * ldc * ES), 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < RT; ++i) {
     const f32x4 a = i ? acc1 : acc0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -166,17 +168,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <typename T, int EPI, int NV, bool EXACT>
-int launch_ln_gemm_nv(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
+template <typename T, int EPI, int NV, bool EXACT, int RT>
+int launch_ln_gemm_rt(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
                       void* C, int M, int N, int K, int ldc, hipStream_t s) {
-  const size_t lds = (size_t)LG_BM * (K + 16 / sizeof(T)) * sizeof(T);
+  const size_t lds = (size_t)16 * RT * (K + 16 / sizeof(T)) * sizeof(T);
   static EmLdsCap cap = {};  // per instantiation and device: raised once (not per launch: launches may be inside a hipGraph capture)
-  if (em_raise_lds_cap((const void*)ln_gemm_kernel<T, EPI, NV, EXACT>, 160 * 1024 - 1024, &cap) != EM_OK) return EM_ERR_LAUNCH;
-  dim3 grid(em_cdiv(N, LG_BN), em_cdiv(M, LG_BM));
-  hipLaunchKernelGGL((ln_gemm_kernel<T, EPI, NV, EXACT>), grid, dim3(256), lds, s, x, g, b, eps, (const T*)W, bias, C,
+  if (em_raise_lds_cap((const void*)ln_gemm_kernel<T, EPI, NV, EXACT, RT>, 160 * 1024 - 1024, &cap) != EM_OK) return EM_ERR_LAUNCH;
+  dim3 grid(em_cdiv(N, LG_BN), em_cdiv(M, 16 * RT));
+  hipLaunchKernelGGL((ln_gemm_kernel<T, EPI, NV, EXACT, RT>), grid, dim3(256), lds, s, x, g, b, eps, (const T*)W, bias, C,
                      M, N, K, ldc);
   EM_CHECK_LAUNCH();
   return EM_OK;
+}
+template <typename T, int EPI, int NV, bool EXACT>
+int launch_ln_gemm_nv(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
+                      void* C, int M, int N, int K, int ldc, hipStream_t s) {
+  // 16-row workgroups where 32-row ones would leave most of the chip idle (developer switch: ESPNET_AMD_LNG_RT = 1 | 2)
+  static const int force = [] {
+    const char* e = getenv("ESPNET_AMD_LNG_RT");
+    return e ? atoi(e) : 0;
+  }();
+  const bool rt1 = force ? force == 1 : (long)em_cdiv(N, LG_BN) * em_cdiv(M, 32) < 144;  // (160 rows: the q / k / v and source-q projections 6.0 -> 4.8 us, the 2048-wide FFN projection 6.6 -> 7.3 us with 16-row workgroups: profiles/r03h, r03j)
+  if (rt1) return launch_ln_gemm_rt<T, EPI, NV, EXACT, 1>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
+  return launch_ln_gemm_rt<T, EPI, NV, EXACT, 2>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
 }
 
 template <typename T, int EPI>

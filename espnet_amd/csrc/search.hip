@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c, int i_ho
     __syncthreads();
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) sum += (tid + 256 * k < V) ? expf(out[k] - mx) : 0.f;
+    for (int k = 0; k < NV; ++k) sum += (tid + 256 * k < V) ? __expf(out[k] - mx) : 0.f;  // (v_exp_f32: ~1 ulp; the sum of 5 000 terms rounds more)
     sum = wave_allsum_dpp(sum);
     if (lane == 0) s_v[wave] = sum;
     __syncthreads();
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c, int i_ho
           if (t < xlen) {
             const float term = ph[t - 1] + xv[u];
             const float mm = fmaxf(m, term);
-            sm = sm * expf(m - mm) + expf(term - mm);
+            sm = sm * __expf(m - mm) + __expf(term - mm);
             m = mm;
           }
         }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c, int i_ho
       M = fmaxf(M, dpp_f32<DPP_XOR2>(M));
       M = fmaxf(M, dpp_f32<DPP_HALF_MIRROR>(M));
       M = fmaxf(M, dpp_f32<DPP_MIRROR>(M));
-      sm = (m > -INFINITY) ? sm * expf(m - M) : 0.f;
+      sm = (m > -INFINITY) ? sm * __expf(m - M) : 0.f;
       sm += dpp_f32<DPP_XOR1>(sm);
       sm += dpp_f32<DPP_XOR2>(sm);
       sm += dpp_f32<DPP_HALF_MIRROR>(sm);
@@ -474,21 +474,31 @@ __global__ __launch_bounds__(256) void candidate_kernel(Ctx c, int i_host) {
 // ds_bpermute round trips per round, 9.7 us per label step).  Largest total, lowest flat index on ties.  s_sel / s_tot
 // (LDS, may be NULL) receive the winners for a caller that goes on in the same workgroup.
 constexpr int SEL_KM = 16;
-__device__ __forceinline__ void select_wave(const Ctx& c, int b, int lane, int* s_sel, float* s_tot) {
+// WITH_REC: the winners' token and log psi are handed over too (s_tok / s_psi), read with the totals in the same
+// round trip: the caller's per-row records then need no cand_tok -> dec_logp chain of dependent loads.
+template <int KM, bool WITH_REC>
+__device__ __forceinline__ void select_wave(const Ctx& c, int b, int lane, int* s_sel, float* s_tot, int* s_tok,
+                                            float* s_psi) {
   const int W = c.p.W, total = W * c.p.NC;
   const float* tot = c.b.cand_total + (size_t)b * total;
-  float x[SEL_KM];
+  float x[KM], xp[KM];
+  int xt[KM];
 #pragma unroll
-  for (int k = 0; k < SEL_KM; ++k) {
+  for (int k = 0; k < KM; ++k) {
     const int v = lane + 64 * k;
-    const float t = tot[v < total ? v : total - 1];  // unconditional load, masked afterwards
+    const int vc = v < total ? v : total - 1;  // unconditional loads, masked afterwards
+    const float t = tot[vc];
+    if constexpr (WITH_REC) {
+      xt[k] = c.b.cand_tok[(size_t)b * total + vc];
+      xp[k] = c.b.cand_psi ? c.b.cand_psi[(size_t)b * total + vc] : 0.f;
+    }
     x[k] = v < total ? t : -INFINITY;
   }
   for (int r = 0; r < W; ++r) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
 #pragma unroll
-    for (int k = 0; k < SEL_KM; ++k)
+    for (int k = 0; k < KM; ++k)
       if (x[k] > best) {
         best = x[k];
         bi = lane + 64 * k;
@@ -505,8 +515,14 @@ __device__ __forceinline__ void select_wave(const Ctx& c, int b, int lane, int* 
       }
     }
 #pragma unroll
-    for (int k = 0; k < SEL_KM; ++k)
-      if (wi == lane + 64 * k) x[k] = -INFINITY;  // the winner leaves its owner's registers
+    for (int k = 0; k < KM; ++k)
+      if (wi == lane + 64 * k) {  // the winner leaves its owner's registers
+        x[k] = -INFINITY;
+        if constexpr (WITH_REC) {
+          s_tok[r] = xt[k];
+          s_psi[r] = xp[k];
+        }
+      }
   }
 }
 __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
@@ -514,8 +530,12 @@ __global__ __launch_bounds__(64) void select_kernel(Ctx c) {
   const int W = c.p.W, NC = c.p.NC;
   const int total = W * NC;
   float* tot = c.b.cand_total + (size_t)b * total;
+  if (total <= 64 * 4) {
+    select_wave<4, false>(c, b, lane, nullptr, nullptr, nullptr, nullptr);
+    return;
+  }
   if (total <= 64 * SEL_KM) {
-    select_wave(c, b, lane, nullptr, nullptr);
+    select_wave<SEL_KM, false>(c, b, lane, nullptr, nullptr, nullptr, nullptr);
     return;
   }
   for (int k = 0; k < W; ++k) {
@@ -810,7 +830,8 @@ __global__ __launch_bounds__(64) void update_kernel(Ctx c, int i_host) {
 __global__ __launch_bounds__(1024) void tail_kernel(Ctx c, int i_host, int lt_cap) {
   extern __shared__ float tail_lds[];  // per wave: s_xn, s_xb, s_phi [lt_cap] + s_out [lt_cap] float2
   __shared__ int s_prev_row[64], s_tok[64], s_valid[64], s_end[64], s_sel[64];
-  __shared__ float s_seltot[64], s_rec[4][64];
+  __shared__ float s_seltot[64], s_rec[4][64], s_wpsi[64];
+  __shared__ int s_wtok[64];
   const int i = c.b.step ? *c.b.step : i_host;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -824,8 +845,12 @@ __global__ __launch_bounds__(1024) void tail_kernel(Ctx c, int i_host, int lt_ca
   int* anc_new = (i & 1) ? c.b.anc_a : c.b.anc_b;
   const bool was_done = c.b.done[b] != 0;
   const int maxlen = c.b.maxlens[b], minlen = c.b.minlens[b];
+  const int cnt0 = c.b.end_count[b];  // (read at entry: not one more dependent round trip at the end)
   // ---- selection (batch_beam :98-122): wave 0
-  if (wave == 0) select_wave(c, b, lane, s_sel, s_seltot);
+  if (wave == 0) {
+    if (W * NC <= 64 * 4) select_wave<4, true>(c, b, lane, s_sel, s_seltot, s_wtok, s_wpsi);
+    else select_wave<SEL_KM, true>(c, b, lane, s_sel, s_seltot, s_wtok, s_wpsi);
+  }
   __syncthreads();
   // ---- the new rows' records (batch_beam_search.py:317-357), wave 0, a lane per row
   float n_score = -INFINITY, n_sdec = 0.f, n_sctc = 0.f, n_slen = 0.f, n_sprev = 0.f, n_slm = 0.f;
@@ -833,15 +858,15 @@ __global__ __launch_bounds__(1024) void tail_kernel(Ctx c, int i_host, int lt_ca
     const int sel = was_done ? -1 : s_sel[lane];
     int valid = sel >= 0, prow = b * W, tk = c.p.eos;
     if (valid) {
-      const int pk = sel / NC, sl = sel - pk * NC;
+      const int pk = sel / NC;
       prow = b * W + pk;
-      tk = c.b.cand_tok[(size_t)prow * NC + sl];
+      tk = s_wtok[lane];  // (= cand_tok[prow][slot], handed over by the selection with the totals)
       n_score = s_seltot[lane];
       if (c.p.w_dec != 0.f) n_sdec = c.b.run_sdec[prow] + c.b.dec_logp[(size_t)prow * V + tk];
       if (c.p.w_len != 0.f) n_slen = c.b.run_slen[prow] + 1.0f;
       if (c.p.w_lm != 0.f) n_slm = c.b.run_slm[prow] + c.b.lm_logp[(size_t)prow * V + tk];
       if (c.p.w_ctc != 0.f) {
-        const float psi = c.b.cand_psi[(size_t)prow * NC + sl];
+        const float psi = s_wpsi[lane];
         n_sctc = c.b.run_sctc[prow] + (psi - c.b.s_prev[prow]);
         n_sprev = psi;  // select_state: s = log_psi[i, new_id] (scorers/ctc.py:56)
       }
@@ -899,9 +924,16 @@ __global__ __launch_bounds__(1024) void tail_kernel(Ctx c, int i_host, int lt_ca
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0 && !was_done) {
+    // The serial pass below is needed only when a row ended, when nobody is left alive, or when end detection has
+    // something to compare (an ended list): on every other step (all of them, for a beam that runs to maxlen) it is
+    // skipped - it cost ~10 us per label step when it ran unconditionally (profiles/r03i: timing attribution).
+    const bool lanerow = lane < W;
+    const unsigned long long endm = __ballot(lanerow && s_end[lanerow ? lane : 0]);
+    const unsigned long long alivem = __ballot(lanerow && s_valid[lanerow ? lane : 0] && !s_end[lanerow ? lane : 0]);
+    const bool need_tail = endm != 0ull || alivem == 0ull || (c.p.use_end_detect && cnt0 > 0);
+    if (lane == 0 && !was_done && need_tail) {
       // ended list, in row order (the reference appends in batch order)
-      int cnt = c.b.end_count[b];
+      int cnt = cnt0;
       const int cap = c.p.end_cap;
       int n_alive = 0;
       for (int k = 0; k < W; ++k) {
