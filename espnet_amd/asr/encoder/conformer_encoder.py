@@ -141,6 +141,34 @@ def pack_w2(w: torch.Tensor) -> torch.Tensor:
     return u.reshape(ffp // 128, 4 * 16 * 64 * 8)
 
 
+def pack_conv1_frags(w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
+    """conv.0 weight [256][9] + bias [256] (f32) -> the MFMA operand of the fused conv1 + conv2 kernel (include/espnet_amd.h,
+    em_conv2d_sub12_bf16): per channel 32 bf16 k-slots  hi(w) | hi(w) | lo(w) | hi(b), lo(b), 0, 0, 0  with hi(x) = bf16(x),
+    lo(x) = bf16(x - hi(x)), laid out [chunk][fragment][lg][lr][e] for channel 32 cc + 16 f + lr, k = 8 lg + e."""
+    w1 = w1.detach().to(torch.float32).cpu().reshape(-1, 9)
+    b1 = b1.detach().to(torch.float32).cpu()
+    d = w1.shape[0]
+    assert d == 256, d
+
+    def hi(x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    wh, bh = hi(w1), hi(b1)
+    wl, bl = hi(w1 - wh), hi(b1 - bh)
+    k = torch.zeros(d, 32)
+    k[:, 0:9], k[:, 9:18], k[:, 18:27], k[:, 27], k[:, 28] = wh, wh, wl, bh, bl
+    return k.reshape(8, 2, 16, 4, 8).permute(0, 1, 3, 2, 4).contiguous().reshape(-1)
+
+
+def pack_conv2_frags(w2: torch.Tensor) -> torch.Tensor:
+    """conv.2 weight as [256][9 * 256] with column (kt*3 + kf) * 256 + c_in -> fragment-major
+    [chunk cc][tap][wave w][fragment j][lg][lr][e] = w2[64 w + 16 j + lr][tap * 256 + 32 cc + 8 lg + e]."""
+    n, k = w2.shape
+    assert n == 256 and k == 9 * 256, (n, k)
+    u = w2.detach().reshape(4, 4, 16, 9, 8, 4, 8)  # [w][j][lr][tap][cc][lg][e]
+    return u.permute(4, 3, 0, 1, 5, 2, 6).contiguous().reshape(-1)
+
+
 def rel_pos_table(T: int, d: int) -> torch.Tensor:
     """RelPositionalEncoding rows for a length-T input (embedding.py:286-332): row k is the
     sinusoid of relative position T-1-k.  Built on the host with the same fp32 torch ops the
@@ -425,6 +453,10 @@ class ConformerEncoder(torch.nn.Module):
         k2 = e.conv[2].weight.size(-1)
         t["conv2_w"] = A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, k2 * k2 * d))
         t["conv2_b"] = F(e.conv[2].bias)
+        if layer == "conv2d" and d == 256 and self.em_dtype == L.EM_BF16:
+            # operands of the fused conv1 + conv2 kernel (csrc/subsample2.hip): the conv1 map is never materialised
+            t["conv1_wf"] = A(pack_conv1_frags(e.conv[0].weight, e.conv[0].bias))
+            t["conv2_wf"] = A(pack_conv2_frags(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, 9 * d)))
         if layer == "conv2d8":
             t["conv3_w"] = A(e.conv[4].weight.permute(0, 2, 3, 1).reshape(d, 9 * d))
             t["conv3_b"] = F(e.conv[4].bias)

@@ -131,7 +131,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   const size_t es = dtype == EM_BF16 ? 2 : 4;
 
   // ---- Conv2dSubsampling{,6,8}: conv1 (+MVN) -> implicit-GEMM conv(s) -> Linear, * sqrt(d)  (subsample.h)
-  EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream));
+  EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream, w->conv1_wf, w->conv2_wf));
   const EmConformerLayer* ly = w->layers;
   // ---- linear_pos of every block in one GEMM: pall[2T-1][L*d]
   EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, w->legacy_relpos ? T : 2 * T - 1, L * d, d, d,

@@ -9,6 +9,7 @@
 // encoding (embedding.py:328) in its epilogue.
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 
 #include "em_common.h"
 
@@ -56,17 +57,28 @@ inline void map_bytes(const Geo& g, int B, int d, size_t es, size_t out[3]) {
 }
 
 // feats -> x [B*T_out][d] f32 = (Linear(conv stack) + b) * sqrt(d).  W: EmConformerWeights-like.
+// conv1_wf / conv2_wf: the operands of the fused conv1 + conv2 kernel (csrc/subsample2.hip), or NULL
 template <typename W>
 inline int run(int dtype, const W* w, const Geo& g, const float* feats, const float* mvn_partial,
-               const int32_t* flens, int B, void* c1, void* c2, void* c3, float* x, void* stream) {
+               const int32_t* flens, int B, void* c1, void* c2, void* c3, float* x, void* stream,
+               const void* conv1_wf = nullptr, const void* conv2_wf = nullptr) {
   const int d = w->d;
-  int rc = em_conv2d_sub1(dtype, feats, mvn_partial, flens, B, g.T[0], g.F[0], w->conv1_w, w->conv1_b, d, c1, stream);
-  if (rc != EM_OK) return rc;
-  const void* in = c1;
+  int rc = EM_ERR_UNSUPPORTED;
+  static const bool no_fused = getenv("ESPNET_AMD_NO_SUB12") != nullptr;  // developer A/B switch
+  const bool try_fused = dtype == EM_BF16 && conv1_wf && conv2_wf && mode_of(w->subsample) == 4 && !no_fused;
+  if (try_fused)
+    rc = em_conv2d_sub12_bf16(feats, mvn_partial, flens, B, g.T[0], g.F[0], conv1_wf, conv2_wf, w->conv2_b, d, c2, stream);
+  if (rc != EM_OK && rc != EM_ERR_UNSUPPORTED) return rc;
+  const bool fused = rc == EM_OK;
+  if (!fused) {
+    rc = em_conv2d_sub1(dtype, feats, mvn_partial, flens, B, g.T[0], g.F[0], w->conv1_w, w->conv1_b, d, c1, stream);
+    if (rc != EM_OK) return rc;
+  }
+  const void* in = fused ? c2 : c1;
   void* outs[2] = {c2, c3};
   const void* ws[2] = {w->conv2_w, w->conv3_w};
   const float* bs[2] = {w->conv2_b, w->conv3_b};
-  for (int i = 0; i < g.n; ++i) {
+  for (int i = fused ? 1 : 0; i < g.n; ++i) {
     EmGemmArgs a = {};
     a.A = in; a.W = ws[i]; a.C = outs[i]; a.bias = bs[i];
     a.M = B * g.T[i + 2] * g.F[i + 2]; a.N = d; a.K = g.k[i + 1] * g.k[i + 1] * d; a.lda = 0; a.ldc = d; a.scale = 1.f;

@@ -1,0 +1,275 @@
+// Conv2dSubsampling's two convolutions in ONE kernel (bf16, d = 256, 3 x 3 stride 2 twice):
+//     feats [B][T_f][n_mels] f32  --conv1 + ReLU-->  (never in memory)  --conv2 + ReLU-->  c2 [B][T2][F2][256] bf16
+// Reference: Conv2dSubsampling.forward, espnet2/legacy/nets/pytorch_backend/transformer/subsampling.py:432-447
+// (torch.nn.Conv2d(1, d, 3, 2), ReLU, Conv2d(d, d, 3, 2), ReLU), utterance MVN (layers/utterance_mvn.py:45-88) folded
+// into the input rows as in csrc/frontend.hip.
+//
+// Why.  Unfused, conv1 writes a [B][500][39][256] bf16 map (319 MB at B = 32: 72 us at HBM speed) that conv2's
+// implicit GEMM reads back twice (two 128-column tiles), 211 us at 0.34 of the bf16 MFMA peak: together 22 % of the
+// greedy step (profiles/r03e_bench_small_b32_kernel_stats.csv).  conv1 is 9 MACs per map element - cheap enough to
+// recompute next to conv2's MFMAs, so the map need not exist.
+//
+// Shape of the kernel.  One workgroup = 8 output time rows x all F2 frequency bins (152 positions at 80 mels, padded
+// to 10 MFMA fragments of 16) x all 256 output channels; four waves (one per SIMD: the 160 accumulator registers of
+// a wave plus its weight ring need more than the 256 registers two waves per SIMD would leave), each in two roles:
+//   * conv2: wave w owns output channels 64 w .. 64 w + 63 (4 fragments) x all 10 position fragments.  K is walked in
+//     8 chunks of 32 input channels x 9 taps, a tap being ONE 32-deep MFMA step: the tap's four weight fragments come
+//     straight from global memory (fragment-major packing by the host, 1 KiB per wave-wide load, requested two taps
+//     ahead through a register ring), the position fragments from an LDS "patch" [map position][32 ch] of the conv1
+//     output (80-byte rows: conflict-free 16-byte reads at the stride-2 positions of a fragment) at (2 t2 + kt,
+//     2 f2 + kf): the im2col is index arithmetic on LDS addresses.  The weights are the MFMA A operand (C^T[n][m]):
+//     a lane ends up with 4 consecutive output channels of one position, i.e. 8-byte stores into the channel-last c2.
+//   * conv1, ALSO on the matrix cores: for 16 map positions x 16 channels it is a [16 x 9] x [9 x 16] product, and
+//     with operands split into bf16 high and low parts (x = xh + xl, w = wh + wl) one v_mfma_f32_16x16x32_bf16
+//     computes  xh.wh + xl.wh + xh.wl + bias  in f32 (k = 0-8 | 9-17 | 18-26 | 27, 28 for the two halves of the
+//     bias): 16+ significant bits per operand, i.e. f32-class conv1 results (error ~1e-5 of the terms, against the
+//     4e-3 of the bf16 rounding they get anyway).  The position operands (the tile's inputs in that im2col form,
+//     MVN applied in f32 first) are built ONCE per tile into LDS - they do not depend on the channel - and a chunk's
+//     conv1 is then 22 MFMAs per wave against the 360 of its conv2.  (A VALU conv1 - 9 packed FMAs per position and
+//     channel pair with the weights in scalar registers - spilled 1 090 SGPRs and cost as many issue slots as the
+//     MFMAs; tools/isa_waits.py.)
+// One barrier per chunk: the conv1 patch of chunk c + 1 is produced, a slice per tap, while chunk c is consumed.
+// Per workgroup and chunk: 382 MFMAs per wave (6 100 cycles of matrix-core time), 144 KiB of weights (64 B/clk would
+// take 2 300 cycles), 400 KiB of LDS fragment reads (3 100 cycles at 128 B/clk): the kernel is built to be MFMA-bound.
+#include "em_common.h"
+
+namespace {
+
+constexpr int D = 256;
+constexpr int TT = 8;          // output time rows per workgroup
+constexpr int MF = 10;         // position fragments of conv2: TT * F2 <= 160
+constexpr int CC = 32;         // input channels per chunk = one MFMA k-step per tap
+constexpr int NCHUNK = D / CC; // 8
+constexpr int T1R = 2 * TT + 1;   // conv1 rows a tile reaches: 17
+constexpr int INR = 2 * T1R + 1;  // feature rows: 35
+constexpr int F1MAX = 40, F2MAX = 19, MELMAX = 2 * F1MAX + 2;
+constexpr int NPF = (T1R * F1MAX + 15) / 16;  // map-position fragments of conv1: 43
+constexpr int PSTRIDE = 2 * CC + 16;          // bytes per patch position: 64 of channels + 16 of padding
+constexpr int PATCH_BYTES = NPF * 16 * PSTRIDE;  // 55 040 (whole fragments: the padded positions are written too)
+constexpr int XIN_OFF = 0;                       // [NPF][64 lanes][16 B]: the conv1 position operands
+constexpr int PATCH_OFF = NPF * 1024;
+constexpr int IN_OFF = PATCH_OFF + PATCH_BYTES;  // f32 [INR][MELMAX], aliasing patch 1 (dead before chunk 1 is produced)
+constexpr int SMEM_BYTES = PATCH_OFF + 2 * PATCH_BYTES;
+static_assert(INR * MELMAX * 4 <= PATCH_BYTES && SMEM_BYTES <= 160 * 1024, "LDS");
+constexpr int PF_PER_WAVE = (NPF + 3) / 4;  // 11
+static_assert(PF_PER_WAVE <= 18, "a conv1 fragment per group of a chunk at most");
+
+typedef const __attribute__((address_space(1))) bf16x8* GFRAG;
+
+struct Sub2Args {
+  const float* feats;     // [B][T_f][n_mels]
+  const float* partial;   // [B][8][n_mels] MVN partial sums, or NULL
+  const int32_t* flens;   // [B]
+  const void* w1f;        // conv1 weights + bias as MFMA operands, [8 chunks][2 fragments][64 lanes][8] bf16
+  const void* w2f;        // conv2 weights, fragment-major [chunk][tap][wave][frag][lane][8] bf16
+  const float* b2;        // [256]
+  void* out;              // [B][T2][F2][256] bf16
+  int B, T_f, n_mels, F1, T2, F2;
+};
+
+__device__ __forceinline__ bf16 hi_of(float x) { return (bf16)x; }
+__device__ __forceinline__ bf16 lo_of(float x) { return (bf16)(x - (float)(bf16)x); }
+
+__global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  float* const s_in = (float*)(smem + IN_OFF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.y, t2_0 = blockIdx.x * TT;
+  const int n_mels = a.n_mels, F1 = a.F1, F2 = a.F2;
+  // weight fragments of conv2: tap g = cc * 9 + tap of the whole K walk, four 1 KiB lines per wave and tap, requested
+  // two taps (1 280 cycles of MFMA) ahead through a ring of three sets - 9 taps per chunk, so the slot g % 3 = tap % 3
+  // is a compile-time index.  Unconditional: past the end the last tap is repeated.
+  const unsigned char* const wbase = (const unsigned char*)a.w2f + wave * 4096 + lane * 16;
+  constexpr int NTAP = NCHUNK * 9;
+  bf16x8 wr[3][4];
+  auto wload = [&](int g, bf16x8 (&w)[4]) {
+    const unsigned char* p = wbase + (size_t)(g < NTAP ? g : NTAP - 1) * 16384;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = *(GFRAG)(p + j * 1024);
+  };
+  wload(0, wr[0]);
+  wload(1, wr[1]);
+  // ---- the tile's feature rows, mean-subtracted (rows past the utterance's end repeat the last row: they only reach
+  // output rows past T2, which are never stored)
+  for (int i = tid; i < INR * n_mels; i += 256) {
+    const int r = i / n_mels, f = i - r * n_mels;
+    float mean = 0.f;
+    if (a.partial) {
+      const float* pp = a.partial + (size_t)b * 8 * n_mels + f;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += pp[q * n_mels];
+      mean = s / (float)a.flens[b];
+    }
+    int row = 4 * t2_0 + r;
+    row = row < a.T_f ? row : a.T_f - 1;
+    s_in[r * MELMAX + f] = a.feats[((size_t)b * a.T_f + row) * n_mels + f] - mean;
+  }
+  __syncthreads();
+  // ---- conv1's position operands: fragment pf covers map positions 16 pf .. 16 pf + 15 (p = t1l * F1 + f1); lane
+  // (lr, lg) holds k = 8 lg .. 8 lg + 7 of position 16 pf + lr in the split layout of the header:
+  //   k: 0-8 xh[tap] | 9-17 xl[tap] | 18-26 xh[tap] | 27, 28: 1 | 29-31: 0
+  const int npos = T1R * F1;
+  for (int pf = wave; pf < NPF; pf += 4) {
+    int p = pf * 16 + lr;
+    p = p < npos ? p : npos - 1;
+    const int t1l = p / F1, f1 = p - t1l * F1;
+    float x[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) x[i * 3 + j] = s_in[(2 * t1l + i) * MELMAX + 2 * f1 + j];
+    bf16 h[9], l[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      h[t] = hi_of(x[t]);
+      l[t] = lo_of(x[t]);
+    }
+    const bf16 one = (bf16)1.0f, zero = (bf16)0.0f;
+    bf16x8 v;
+    if (lg == 0) v = (bf16x8){h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+    else if (lg == 1) v = (bf16x8){h[8], l[0], l[1], l[2], l[3], l[4], l[5], l[6]};
+    else if (lg == 2) v = (bf16x8){l[7], l[8], h[0], h[1], h[2], h[3], h[4], h[5]};
+    else v = (bf16x8){h[6], h[7], h[8], one, one, zero, zero, zero};
+    *(bf16x8*)(smem + XIN_OFF + pf * 1024 + lane * 16) = v;
+  }
+  __syncthreads();  // (s_in is dead from here on: patch 1 may be written)
+
+  // ---- conv1 of a chunk for this wave's j-th position fragment (pf = wave + 4 j), both 16-channel fragments of the
+  // chunk: 2 MFMAs; the lane gets channels 4 lg .. 4 lg + 3 (+ 16 for the second fragment) of position 16 pf + lr
+  bf16x8 w1[2];
+  auto load_w1 = [&](int cc) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) w1[f] = *(GFRAG)((const unsigned char*)a.w1f + (size_t)(cc * 2 + f) * 1024 + lane * 16);
+  };
+  auto conv1_pf = [&](int j) {
+    const int pf = wave + 4 * j;
+    return pf < NPF ? pf : NPF - 1;  // (the last waves redo a fragment: same bytes, no branch)
+  };
+  auto conv1_read = [&](int j) { return *(const bf16x8*)(smem + XIN_OFF + conv1_pf(j) * 1024 + lane * 16); };
+  auto conv1_frag = [&](int buf, int j, const bf16x8& xv) {
+    unsigned char* const dst = smem + PATCH_OFF + buf * PATCH_BYTES + (conv1_pf(j) * 16 + lr) * PSTRIDE + lg * 8;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[f], xv, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const bf16x4 pk = {(bf16)fmaxf(c[0], 0.f), (bf16)fmaxf(c[1], 0.f), (bf16)fmaxf(c[2], 0.f), (bf16)fmaxf(c[3], 0.f)};
+      *(bf16x4*)(dst + f * 32) = pk;
+    }
+  };
+  load_w1(0);
+#pragma unroll
+  for (int j = 0; j < PF_PER_WAVE; ++j) conv1_frag(0, j, conv1_read(j));
+  load_w1(1);
+
+  // ---- conv2: byte offset of this lane's column of position fragment i inside a patch, at tap (0, 0): position
+  // (2 t2l, 2 f2), channels 8 lg ..; positions past the tile repeat the last one (computed, never stored)
+  const int M = TT * F2;
+  int pb[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    int m = i * 16 + lr;
+    m = m < M ? m : M - 1;
+    const int t2l = m / F2, f2 = m - t2l * F2;
+    pb[i] = ((2 * t2l) * F1 + 2 * f2) * PSTRIDE + lg * 16;
+  }
+  f32x4 acc[4][MF];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // patch 0 is complete
+  // The position fragments are read HALF A TAP ahead: a group = five fragments = 20 MFMAs (320 cycles of matrix-core
+  // time, more than an LDS round trip), requested into the other half of a register double buffer before the current
+  // group's MFMAs are issued.  Read next to their use - what hipcc does with the plain loop - every fragment exposed
+  // its LDS latency to four MFMAs' worth of work.  18 groups per chunk: the buffer parity of a group is a compile-time
+  // index.  (A whole tap ahead, with two chunks per trip for the parity, ran out of registers: the xin / patch
+  // addresses of the conv1 slices were spilled, and a scratch reload is a vmcnt(0) wait in front of the weight ring.)
+  constexpr int GF = MF / 2;  // fragments per group
+  static_assert(MF % 2 == 0, "two groups per tap");
+  bf16x8 bfr[2][GF];
+  auto read_group = [&](const unsigned char* patch, int g, bf16x8 (&dst)[GF]) {
+    const int tap = g >> 1, i0 = (g & 1) * GF;
+    const int toff = ((tap / 3) * F1 + tap % 3) * PSTRIDE;
+#pragma unroll
+    for (int i = 0; i < GF; ++i) dst[i] = *(const bf16x8*)(patch + pb[i0 + i] + toff);
+  };
+  read_group(smem + PATCH_OFF, 0, bfr[0]);
+  bf16x8 xv[2];
+  xv[0] = conv1_read(0);
+#pragma unroll 1
+  for (int cc = 0; cc < NCHUNK; ++cc) {
+    const unsigned char* const patch = smem + PATCH_OFF + (cc & 1) * PATCH_BYTES;
+    const int nbuf = (cc + 1) & 1;
+#pragma unroll
+    for (int g = 0; g < 18; ++g) {
+      const int tap = g >> 1, i0 = (g & 1) * GF;
+      if (!(g & 1)) wload(cc * 9 + tap + 2, wr[(tap + 2) % 3]);
+      if (g < 17) read_group(patch, g + 1, bfr[(g + 1) & 1]);
+      if (g + 1 < PF_PER_WAVE) xv[(g + 1) & 1] = conv1_read(g + 1);  // (its position operand too: one group ahead)
+      __builtin_amdgcn_sched_barrier(0);  // (left alone hipcc sinks these reads next to their uses, one fragment ahead)
+      // a fragment of the NEXT chunk's conv1 (after the last chunk: a harmless repeat into the free buffer), in
+      // program order next to this group's MFMAs
+      if (g < PF_PER_WAVE) conv1_frag(nbuf, g, xv[g & 1]);
+#pragma unroll
+      for (int i = 0; i < GF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j][i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][j], bfr[g & 1][i], acc[j][i0 + i], 0, 0, 0);
+    }
+    load_w1(cc + 2 < NCHUNK ? cc + 2 : NCHUNK - 1);  // conv1 weights of the chunk produced during the next trip
+    __syncthreads();
+    // the next chunk's first group, from the patch that has just been completed
+    read_group(smem + PATCH_OFF + nbuf * PATCH_BYTES, 0, bfr[0]);
+    xv[0] = conv1_read(0);
+  }
+  // ---- epilogue: + bias, ReLU, bf16; lane = 4 consecutive channels n = 64 w + 16 j + 4 lg + r of position 16 i + lr
+  const size_t out_bytes = (size_t)a.B * a.T2 * F2 * D * 2;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(unsigned)out_bytes, 0x00020000);
+  float4 bias[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias[j] = *(const float4*)(a.b2 + wave * 64 + j * 16 + lg * 4);
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int m = i * 16 + lr;
+    const int t2l = m / F2, f2 = m - t2l * F2;
+    const int t2 = t2_0 + t2l;
+    const bool ok = m < M && t2 < a.T2;
+    const size_t pos = ((size_t)b * a.T2 + t2) * F2 + f2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x4 pk = {(bf16)fmaxf(acc[j][i][0] + bias[j].x, 0.f), (bf16)fmaxf(acc[j][i][1] + bias[j].y, 0.f),
+                         (bf16)fmaxf(acc[j][i][2] + bias[j].z, 0.f), (bf16)fmaxf(acc[j][i][3] + bias[j].w, 0.f)};
+      const unsigned off = ok ? (unsigned)((pos * D + wave * 64 + j * 16 + lg * 4) * 2) : 0xffffffffu;
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, off, 0, 0);
+    }
+  }
+}
+
+}  // namespace
+
+// feats -> c2 (the input of the embedding Linear), see the header.  EM_ERR_UNSUPPORTED for shapes outside the kernel
+// (the caller then runs conv1 and the implicit-GEMM conv2 as separate launches).
+extern "C" int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial, const int32_t* flens, int32_t B,
+                                    int32_t T_f, int32_t n_mels, const void* conv1_wf, const void* conv2_wf,
+                                    const float* conv2_b, int32_t d, void* c2, void* stream) {
+  if (!feats || !flens || !conv1_wf || !conv2_wf || !conv2_b || !c2 || B <= 0) return EM_ERR_BAD_ARG;
+  if (T_f < 7) return EM_ERR_TOO_SHORT;
+  const int T1 = (T_f - 3) / 2 + 1, F1 = (n_mels - 3) / 2 + 1;
+  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  if (d != D || n_mels < 7 || n_mels > MELMAX || F1 > F1MAX || F2 > F2MAX || TT * F2 > 16 * MF) return EM_ERR_UNSUPPORTED;
+  if ((size_t)B * T2 * F2 * D * 2 >= ((size_t)1 << 32) - 64) return EM_ERR_UNSUPPORTED;  // one buffer resource
+  static EmLdsCap cap = {};
+  if (em_raise_lds_cap((const void*)sub2_kernel, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
+  Sub2Args a;
+  a.feats = feats; a.partial = mvn_partial; a.flens = flens;
+  a.w1f = conv1_wf; a.w2f = conv2_wf; a.b2 = conv2_b; a.out = c2;
+  a.B = B; a.T_f = T_f; a.n_mels = n_mels; a.F1 = F1; a.T2 = T2; a.F2 = F2;
+  const bool rec = em_prof_begin(stream);
+  hipLaunchKernelGGL(sub2_kernel, dim3(em_cdiv(T2, TT), B), dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+  if (rec) em_prof_end(stream, 2.0 * (double)B * T2 * F2 * D * 9.0 * D, EM_PROF_GEMM);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}

@@ -78,7 +78,7 @@ class EmConformerWeights(C.Structure):
                 ("after_norm_b", C.c_void_p), ("layers", C.POINTER(EmConformerLayer)),
                 ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p),
                 ("legacy_relpos", C.c_int32), ("ctc_w", C.c_void_p), ("ctc_b", C.c_void_p),
-                ("ctc_ids", C.c_void_p), ("ctc_units", C.c_int32)]
+                ("ctc_ids", C.c_void_p), ("ctc_units", C.c_int32), ("conv1_wf", C.c_void_p), ("conv2_wf", C.c_void_p)]
 
 
 # order of include/espnet_amd.h EmEBranchformerLayer
@@ -187,6 +187,7 @@ _SIGNATURES = {
     "em_utt_mvn_apply_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "em_global_mvn_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "em_conv2d_sub1": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "em_conv2d_sub12_bf16": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
     "em_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(EmGemmArgs), _vp]),
     "em_layernorm": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),
     "em_layernorm2": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp]),

@@ -110,6 +110,20 @@ int em_global_mvn_f32(float* feats, const int32_t* flens, const float* mean, con
  *      (transformer/subsampling.py:400-403), with the MVN mean subtraction fused on the input.
  *   partial may be NULL (no mean subtraction).  w1 [d][9] f32, b1 [d] f32.
  *   out [B][T1][F1][d] act dtype, channel-last.                                                 */
+/* ---- A4 (both convs in one kernel, bf16, d = 256): Conv2dSubsampling.conv = Conv2d(1,d,3,2)+ReLU+Conv2d(d,d,3,2)+ReLU
+ *      (transformer/subsampling.py:400-403, 432-447), MVN mean subtraction fused on the input; the [B][T1][F1][d]
+ *      map between the two never exists (csrc/subsample2.hip).  Operands packed by the host as MFMA fragments
+ *      (lane l = 16 lg + lr of a fragment holds 8 bf16 at bytes [16 l, 16 l + 16)):
+ *   conv1_wf [8 chunks][2][64][8] bf16: fragment (cc, f), lane (lr, lg), e: channel c = 32 cc + 16 f + lr, k = 8 lg + e:
+ *            k 0-8 hi(w1[c][k]) | 9-17 hi(w1[c][k-9]) | 18-26 lo(w1[c][k-18]) | 27 hi(b1[c]) | 28 lo(b1[c]) | 29-31 0
+ *            with hi(x) = bf16(x), lo(x) = bf16(x - hi(x)): conv1 runs on the matrix cores at f32-class accuracy
+ *   conv2_wf [8 chunks][9 taps][4 waves][4][64][8] bf16: W2[n = 64 w + 16 j + lr][(kt*3+kf)*d + 32 cc + 8 lg + e]
+ *   c2       [B][T2][F2][d] bf16 out (channel-last), T2 = ((T_f-1)/2-1)/2, F2 = ((n_mels-1)/2-1)/2
+ *   EM_ERR_UNSUPPORTED for d != 256 or n_mels > 82 (the caller then uses em_conv2d_sub1 + em_gemm EM_A_CONV2).   */
+int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial, const int32_t* flens, int32_t B, int32_t T_f,
+                         int32_t n_mels, const void* conv1_wf, const void* conv2_wf, const float* conv2_b, int32_t d,
+                         void* c2, void* stream);
+
 int em_conv2d_sub1(int dtype, const float* feats, const float* partial, const int32_t* flens,
                    int32_t B, int32_t T_f, int32_t n_mels, const float* w1, const float* b1,
                    int32_t d, void* out, void* stream);
@@ -266,6 +280,10 @@ typedef struct EmConformerWeights {
   const float* ctc_b;
   int32_t* ctc_ids;
   int32_t ctc_units;
+  /* optional operands of the fused conv1 + conv2 kernel (em_conv2d_sub12_bf16; bf16, d = 256, input layer conv2d):
+   * with both non-NULL em_conformer_encode never materialises the conv1 map.  NULL: conv1 and conv2 as two launches. */
+  const void* conv1_wf;
+  const void* conv2_wf;
 } EmConformerWeights;
 
 /* em_conformer_encode flags */

@@ -285,3 +285,39 @@ def test_public_signatures_cover_the_reference():
             d = mine[name].default
             assert d is not inspect.Parameter.empty, f"{key}: {name} is optional in the reference"
             assert (list(d) if isinstance(d, tuple) else d) == r["default"], (key, name, d, r["default"])
+
+
+def test_fused_subsampling_operand_packing():
+    """Host packers of the fused conv1 + conv2 kernel (em_conv2d_sub12_bf16): the fragment layouts stated in
+    include/espnet_amd.h, emulated on the CPU, reproduce torch's convolutions (conv1 at f32-class accuracy through the
+    split-bf16 operands)."""
+    import torch
+    import torch.nn.functional as F
+
+    from espnet_amd.asr.encoder.conformer_encoder import pack_conv1_frags, pack_conv2_frags
+
+    g = torch.Generator().manual_seed(5)
+    d = 256
+    w1 = torch.randn(d, 9, generator=g) / 3
+    b1 = torch.randn(d, generator=g) * 0.1
+    x = torch.randn(4, 9, generator=g) * 3 - 1          # 4 map positions x 9 taps (f32 inputs)
+    a = pack_conv1_frags(w1, b1).reshape(8, 2, 4, 16, 8)  # [cc][f][lg][lr][e]
+
+    def hi(v):
+        return v.to(torch.bfloat16).to(torch.float32)
+
+    xh, xl = hi(x), hi(x - hi(x))
+    bop = torch.zeros(4, 32)                              # the kernel's position operand, k-slots as in the header
+    bop[:, 0:9], bop[:, 9:18], bop[:, 18:27], bop[:, 27], bop[:, 28] = xh, xl, xh, 1.0, 1.0
+    got = torch.empty(4, d)
+    for c in range(d):
+        cc, f, lr = c // 32, (c % 32) // 16, c % 16
+        wk = a[cc, f, :, lr, :].reshape(32)               # k = 8 lg + e
+        got[:, c] = (bop * wk[None, :]).sum(1)
+    ref = x @ w1.t() + b1
+    assert (got - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
+
+    w2 = torch.randn(d, 9 * d, generator=g)
+    u = pack_conv2_frags(w2).reshape(8, 9, 4, 4, 4, 16, 8)  # [cc][tap][w][j][lg][lr][e]
+    for (cc, tap, w, j, lg, lr, e) in [(0, 0, 0, 0, 0, 0, 0), (7, 8, 3, 3, 3, 15, 7), (3, 4, 1, 2, 2, 9, 5)]:
+        assert u[cc, tap, w, j, lg, lr, e] == w2[64 * w + 16 * j + lr, tap * 256 + 32 * cc + 8 * lg + e]

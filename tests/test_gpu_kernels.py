@@ -203,6 +203,60 @@ def test_utt_mvn_and_conv1(lib):
         assert_close(out, ref, tol, f"conv1 {prec}")
 
 
+@pytest.mark.parametrize("T_f,D,with_mvn", [(61, 80, True), (133, 80, False), (47, 40, True), (7, 80, True)])
+def test_conv2d_sub12_fused(lib, T_f, D, with_mvn):
+    """Conv2dSubsampling's two convolutions in one kernel (csrc/subsample2.hip; conv1 on the matrix cores with split-bf16
+    operands, the conv1 map only in LDS) against torch's f32 convolutions.
+
+    What is asserted: (1) the usual bf16 bound against the reference whose conv1 output is rounded to bf16 (what conv2
+    sees in either device path); (2) against the EXACT f32 reference (no intermediate rounding) the fused kernel is as
+    accurate as the two-launch device path (em_conv2d_sub1 + implicit-GEMM conv2): its split-operand conv1 carries ~17
+    bits, so ~0.2 % of the conv1 values land on the other side of a bf16 rounding boundary than the f32 conv1's do -
+    one more bf16 ulp on those, nothing against the half ulp every value gets from the rounding itself (measured:
+    profiles/r03k_sub12_accuracy.txt)."""
+    from espnet_amd.asr.encoder.conformer_encoder import pack_conv1_frags, pack_conv2_frags
+
+    B, d = 3, 256
+    flens = torch.tensor([T_f, max(7, T_f - 9), 7])
+    feats = (rnd(B, T_f, D, seed=31) * 2 - 8).masked_fill(oc.make_pad_mask(flens, T_f)[:, :, None], 0.0)
+    fl = dev(flens.to(torch.int32))
+    fd = dev(feats)
+    partial = torch.empty(B, 8, D, device="cuda")
+    L.check(lib.em_utt_mvn_partial_f32(L.ptr(fd), L.ptr(fl), B, T_f, D, L.ptr(partial), sptr()))
+    pp = L.ptr(partial) if with_mvn else None
+    w1, b1 = rnd(d, 1, 3, 3, seed=32, scale=1 / 3), rnd(d, seed=33, scale=0.1)
+    w2 = q(rnd(d, d, 3, 3, seed=34, scale=(9 * d) ** -0.5), torch.bfloat16)
+    b2 = rnd(d, seed=35, scale=0.1)
+    x = oc.utterance_mvn(feats, flens) if with_mvn else feats
+    c1 = F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2))
+    exact = F.relu(F.conv2d(c1, w2, b2, stride=2)).permute(0, 2, 3, 1)                              # (B, T2, F2, d)
+    ref = F.relu(F.conv2d(q(c1, torch.bfloat16), w2, b2, stride=2)).permute(0, 2, 3, 1)             # bf16 conv1 map
+    T1, F1, T2, F2 = c1.shape[2], c1.shape[3], ref.shape[1], ref.shape[2]
+    out = torch.full((B, T2, F2, d), 7.0, dtype=torch.bfloat16, device="cuda")
+    w1f = dev(pack_conv1_frags(w1.reshape(d, 9), b1).to(torch.bfloat16))
+    w2p = w2.permute(0, 2, 3, 1).reshape(d, 9 * d)
+    w2f = dev(pack_conv2_frags(w2p).to(torch.bfloat16))
+    b2d = dev(b2)
+    L.check(lib.em_conv2d_sub12_bf16(L.ptr(fd), pp, L.ptr(fl), B, T_f, D, L.ptr(w1f), L.ptr(w2f), L.ptr(b2d), d,
+                                     L.ptr(out), sptr()), "sub12")
+    # the two-launch device path on the same operands
+    c1d = torch.zeros(B, T1, F1, d, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.em_conv2d_sub1(L.EM_BF16, L.ptr(fd), pp, L.ptr(fl), B, T_f, D, L.ptr(dev(w1.reshape(d, 9))),
+                               L.ptr(dev(b1)), d, L.ptr(c1d), sptr()))
+    out2 = torch.zeros(B * T2 * F2, d, dtype=torch.bfloat16, device="cuda")
+    gemm(lib, L.EM_BF16, L.EM_EPI_RELU, c1d, dev(w2p.to(torch.bfloat16)), out2, b2d, B * T2 * F2, d, 9 * d, 0, d,
+         amode=L.EM_A_CONV2, conv=(T1, F1, T2, F2, d))
+    torch.cuda.synchronize()
+    assert_close(out, ref, 1e-2, "fused conv1 + conv2")
+    o1, o2 = out.float().cpu(), out2.float().cpu().reshape(B, T2, F2, d)
+    rms1 = (o1 - exact).pow(2).mean().sqrt().item()
+    rms2 = (o2 - exact).pow(2).mean().sqrt().item()
+    print(f"rms error against the exact f32 result: fused {rms1:.4e}, two launches {rms2:.4e}")
+    assert rms1 <= 1.05 * rms2 + 1e-6, (rms1, rms2)
+    # nothing was written past the valid rows (the last tile overhangs T2)
+    assert torch.isfinite(o1).all()
+
+
 # --------------------------------------------------------------------------- norm / conv / attention
 @pytest.mark.parametrize("d", [64, 256, 512])
 def test_layernorm(lib, d):
