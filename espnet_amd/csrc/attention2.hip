@@ -29,7 +29,7 @@ namespace {
 constexpr int QB = 128;                       // queries per workgroup
 constexpr int KSUP = 256;                     // keys per LDS super-tile
 constexpr int SK_OFF = 0;                     // [256 keys][128 B], chunks XOR-swizzled by (row & 7)
-constexpr int SV_OFF = 32768;                 // [64 dk][512 B],   chunks XOR-swizzled by (row & 15)
+constexpr int SV_OFF = 32768;                 // [4 key tiles][64 dk][128 B], chunks XOR-swizzled by (row >> 1) & 7
 constexpr int SP_OFF = 65536;                 // [384 position rows][128 B]
 constexpr int SBD_OFF = SP_OFF + 384 * 128;   // [8 waves][16 queries][84] f32
 constexpr int LDB = 84;
@@ -72,47 +72,82 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
   const unsigned char* k_base = uniform_ptr((const unsigned char*)(kh + bh * Tpad * 64));
   const unsigned char* v_base = uniform_ptr((const unsigned char*)(vt + bh * 64 * Tpad));
   const unsigned char* p_base = uniform_ptr((const unsigned char*)(p + hh * 64));
-  auto stage = [&](int js) {
-    const int gc8 = (lane & 7) ^ (lane >> 3);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // K rows js .. js + 255
-      const int j = 4 * wave + i;
-      int row = js + 8 * j + (lane >> 3);
+  // ---- staging, in KEY-TILE order (round 3).  A super-tile is four 64-key tiles; the pieces a tile's MFMAs need - its
+  // 64 K rows, its 64 columns of V^T and the position rows its (128 query x 64 key) rectangle adds to the window (192
+  // for the first tile, 64 for each later one) - are requested tile by tile, 1 KiB per wave-instruction, so that the
+  // first tile can be computed once ITS 40 KiB are in LDS while the other 72 KiB are still on their way.  Until round
+  // 3 the kernel waited for all 112 KiB (plus the queries) behind one vmcnt(0): at the ~13 B/clk a CU gets while
+  // every CU's prologue hits memory at once, that was ~4 us of a 12.8 us launch with the matrix cores idle.
+  // A tile's pieces are requested while the tile before it is computed.  V^T is laid out per tile,
+  // [tile][64 dk][128 B], 16-byte chunks XOR-swizzled by (row >> 1) & 7 (conflict-free 8-byte operand reads).
+  auto stage_tile = [&](int js, int t) {
+    const int r8 = lane >> 3, c8 = lane & 7;
+    {  // K rows js + 64 t + 8 wave ..
+      int row = js + 64 * t + 8 * wave + r8;
       row = row < Tpad ? row : Tpad - 1;
-      glds16(k_base, row * 128 + gc8 * 16, SK_OFF + j * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // V^T: 64 rows of 256 keys
-      const int j = 4 * wave + i, row = 2 * j + (lane >> 5);
-      const int gc = (lane & 31) ^ (row & 15);
-      glds16(v_base, (row * Tpad + js) * 2 + gc * 16, SV_OFF + j * 1024);
+      glds16(k_base, row * 128 + ((c8 ^ r8) << 4), SK_OFF + (8 * t + wave) * 1024);
     }
     const int cbase = T - 1 - (i0 + QB - 1) + js;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {  // position rows cbase .. cbase + 383 (clamped: only masked entries see the clamp)
-      const int j = 6 * wave + i;
-      int c = cbase + 8 * j + (lane >> 3);
+    auto prow = [&](int pj) {  // position rows cbase + 8 pj .. (clamped: only masked entries see the clamp)
+      int c = cbase + 8 * pj + r8;
       c = c < 0 ? 0 : (c > 2 * T - 2 ? 2 * T - 2 : c);
-      glds16(p_base, c * (ldp * 2) + gc8 * 16, SP_OFF + j * 1024);
+      glds16(p_base, c * (ldp * 2) + ((c8 ^ r8) << 4), SP_OFF + pj * 1024);
+    };
+    if (t == 0) {
+      prow(3 * wave);
+      prow(3 * wave + 1);
+      prow(3 * wave + 2);
+    } else {
+      prow(24 + 8 * (t - 1) + wave);
+    }
+    {  // V^T: dk rows 8 wave .., keys js + 64 t ..
+      const int row = 8 * wave + r8;
+      int col = js + 64 * t;
+      col = col < Tpad ? col : Tpad - 64;
+      glds16(v_base, (row * Tpad + col) * 2 + ((c8 ^ ((row >> 1) & 7)) << 4), SV_OFF + t * 8192 + wave * 1024);
     }
   };
-  stage(0);
 
-  // ---- query fragments (B operand: column = query iw0 + lr, k-slice lg), with the two position biases
-  bf16x8 qu[2], qv[2];
+  // ---- query fragments (B operand: column = query iw0 + lr, k-slice lg) and the two position biases: requested
+  // BEFORE the staging, from inline asm like it - a load hipcc knows about would be waited for with the count it
+  // keeps, which does not include the 14 staging requests issued behind it: s_waitcnt vmcnt(0), i.e. everything.
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  f4 qraw[2], ur[4], vr[4];
   {
     const bf16* qrow = qh + (bh * Tpad + iw0 + lr) * 64 + lg * 8;
+    const float* pu = pos_u + hh * 64 + lg * 8;
+    const float* pv = pos_v + hh * 64 + lg * 8;
+    asm volatile(
+        "global_load_dwordx4 %0, %10, off\n\t"
+        "global_load_dwordx4 %1, %10, off offset:64\n\t"
+        "global_load_dwordx4 %2, %11, off\n\t"
+        "global_load_dwordx4 %3, %11, off offset:16\n\t"
+        "global_load_dwordx4 %4, %11, off offset:128\n\t"
+        "global_load_dwordx4 %5, %11, off offset:144\n\t"
+        "global_load_dwordx4 %6, %12, off\n\t"
+        "global_load_dwordx4 %7, %12, off offset:16\n\t"
+        "global_load_dwordx4 %8, %12, off offset:128\n\t"
+        "global_load_dwordx4 %9, %12, off offset:144"
+        : "=&v"(qraw[0]), "=&v"(qraw[1]), "=&v"(ur[0]), "=&v"(ur[1]), "=&v"(ur[2]), "=&v"(ur[3]), "=&v"(vr[0]),
+          "=&v"(vr[1]), "=&v"(vr[2]), "=&v"(vr[3])
+        : "v"(qrow), "v"(pu), "v"(pv)
+        : "memory");
+  }
+  stage_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]),
+                 "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
+               :
+               : "memory");
+  bf16x8 qu[2], qv[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 raw = *(const bf16x8*)(qrow + ks * 32);
-      const float* pu = pos_u + hh * 64 + ks * 32 + lg * 8;
-      const float* pv = pos_v + hh * 64 + ks * 32 + lg * 8;
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8 raw = __builtin_bit_cast(bf16x8, qraw[ks]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float q = (float)raw[e];
-        qu[ks][e] = (bf16)(q + pu[e]);
-        qv[ks][e] = (bf16)(q + pv[e]);
-      }
+    for (int e = 0; e < 8; ++e) {
+      const float q = (float)raw[e];
+      qu[ks][e] = (bf16)(q + ur[2 * ks + (e >> 2)][e & 3]);
+      qv[ks][e] = (bf16)(q + vr[2 * ks + (e >> 2)][e & 3]);
     }
   }
 
@@ -124,16 +159,21 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
 
   for (int js = 0; js < klen; js += KSUP) {
     if (js > 0) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave is done with the previous super-tile
-      stage(js);
+      stage_tile(js, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
+#pragma unroll
     for (int kt = 0; kt < KSUP / 64; ++kt) {
       const int jl = kt * 64, j0 = js + jl;
       if (j0 >= klen) break;
+      // this tile's pieces have landed: this wave's own (everything it has requested so far), then everybody's
+      // (barrier); the NEXT tile's pieces are requested now and travel while this tile is computed.  (Requested all
+      // at once up front, the tiles' pieces of different waves interleave in the memory pipeline and the first tile
+      // is complete only when most of the 112 KiB are: 12.8 -> 12.2 us; tile by tile: see profiles/r03m.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < KSUP / 64 && j0 + 64 < klen) stage_tile(js, kt + 1);
       // ---- S^T (64 keys x 16 queries) and the dense position window D (80 rows x 16 queries)
       f32x4 sc[4], dd[5];
 #pragma unroll
@@ -188,21 +228,24 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
       for (int f = 0; f < 4; ++f) {
         acc_o[f][0] *= alpha; acc_o[f][1] *= alpha; acc_o[f][2] *= alpha; acc_o[f][3] *= alpha;
       }
-      // ---- O^T += V^T . P^T
+      // ---- O^T += V^T . P^T   (V^T tile kt: [64 dk][128 B], chunk c holds keys 8 c .. 8 c + 7 of the tile)
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
-        const int c0 = ((jl + 32 * jp) >> 3) + (lg >> 1);
+        const int c0 = 4 * jp + (lg >> 1);
+        const int sw = (lr >> 1) & 7;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const unsigned char* sv = smem + SV_OFF + (16 * f + lr) * 512 + (lg & 1) * 8;
-          const bf16x4 a0 = *(const bf16x4*)(sv + ((c0 ^ lr) << 4));
-          const bf16x4 a1 = *(const bf16x4*)(sv + (((c0 + 2) ^ lr) << 4));
+          const unsigned char* sv = smem + SV_OFF + kt * 8192 + (16 * f + lr) * 128 + (lg & 1) * 8;
+          const bf16x4 a0 = *(const bf16x4*)(sv + ((c0 ^ sw) << 4));
+          const bf16x4 a1 = *(const bf16x4*)(sv + (((c0 + 2) ^ sw) << 4));
           const bf16x8 vf = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
           acc_o[f] = MM::mma(vf, pb[jp], acc_o[f]);
         }
       }
     }
   }
+  // (a workgroup that stopped early - klen short of the staged keys - still has requests in flight into ITS LDS)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- normalise and store ctx[b*T + i][hh*64 + 16 f + 4 lg + r]
   const int i = iw0 + lr;
