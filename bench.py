@@ -438,7 +438,7 @@ def decoder_step_bytes(model, B, W, T, NC, steps, es):
     return w + mem + cache + logits + ctc
 
 
-def run_beam(args, dev, B, beam, steps, warmup, cpu_base, sink_factory):
+def run_beam(args, dev, B, beam, steps, warmup, cpu_base, sink_factory, want_traffic=True):
     """configs[2] / configs[3]'s per-GPU batch: Conformer-large + 6-layer decoder, joint CTC/attention beam search."""
     from espnet_amd import distributed as D
     from espnet_amd.nets.batch_beam_search import build_beam_search
@@ -493,6 +493,15 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, sink_factory):
                                    "what": "decoder weights + memory K/V + self-attention cache + logits + CTC "
                                            "columns and forward variables per label step (bench.py "
                                            "decoder_step_bytes), over the wall time of search_batch"}}}
+    inner = os.environ.get("ESPNET_AMD_BENCH_INNER") == "1"
+    if (want_traffic and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not inner and not args.no_traffic
+            and not getattr(args, "quick", False)):
+        try:
+            traffic, note = collect_search_traffic(args, B, beam)
+        except Exception as e:  # noqa: BLE001 - the bench line must still be printed
+            traffic, note = None, f"{type(e).__name__}: {e}"
+        res["search"]["roofline"]["traffic"] = None if traffic is None else round(traffic)
+        res["search"]["roofline"]["traffic_source"] = note
     if cpu_base:
         res["cpu_baseline"] = cpu_baseline_beam(model, beam, args.ctc_weight)
     return res
@@ -536,6 +545,57 @@ def collect_traffic(kernel_substr, args):
     return (2.0 * fetch_kb + write_kb) * 1024.0, (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
                                                   f"{out['FETCH_SIZE'][1]} launches: FETCH_SIZE {fetch_kb:.1f} KB x 2 "
                                                   f"(gfx950 correction) + WRITE_SIZE {write_kb:.1f} KB per launch")
+
+
+SEARCH_STEP_KERNELS = ("ln_gemm_kernel", "mid_gemm_kernel", "dec_self_attn_kernel", "dec_src_attn_kernel",
+                       "dec_embed_kernel", "logsoftmax_prebeam_kernel", "tail_kernel", "candidate_kernel",
+                       "select_kernel", "ctc_state_kernel", "update_kernel", "layernorm4_kernel", "Li6ELi0ELi64ELi128E")
+
+
+def collect_search_traffic(args, B, beam):
+    """HBM bytes per LABEL STEP of the beam search from two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE) of this
+    script's own beam leg: the counters of every dispatch of the label step's kernels (SEARCH_STEP_KERNELS: decoder step,
+    pre-beam, tail; the final LayerNorm and the vocabulary GEMM share their kernel templates with a few launches of the
+    encoder / search initialisation, < 1 % of the sum) summed and divided by the number of label steps (= dispatches of
+    the step's last kernel).  Same gfx950 correction as collect_traffic."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get(
+            "LD_PRELOAD", ""):
+        return None, "already running under a profiler: no nested rocprofv3 passes"
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", td, "-o", "t", "--output-format", "csv", "--",
+                   sys.executable, str(REPO / "bench.py"), "--workload", "beam", "--no-cpu-baseline", "--steps", "1",
+                   "--warmup", "0", "--dtype", args.dtype, "--batch", str(B), "--beam", str(beam),
+                   "--ctc-weight", str(args.ctc_weight)]
+            env = dict(os.environ, TMPDIR="/tmp", ESPNET_AMD_BENCH_INNER="1")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=400)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr}: timeout"
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr}: rc {r.returncode}, {len(files)} csv"
+            tot, n_steps = 0.0, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    name = row["Kernel_Name"]
+                    if any(k in name for k in SEARCH_STEP_KERNELS):
+                        tot += float(row["Counter_Value"])
+                    if "tail_kernel" in name or "update_kernel" in name:
+                        n_steps += 1
+            if n_steps == 0:
+                return None, f"no label step in the {ctr} pass"
+            out[ctr] = (tot / n_steps, n_steps)
+    fetch_kb, write_kb = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return (2.0 * fetch_kb + write_kb) * 1024.0, (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+                                                  f"{out['FETCH_SIZE'][1]} label steps: FETCH_SIZE {fetch_kb:.1f} KB x 2 "
+                                                  f"(gfx950 correction) + WRITE_SIZE {write_kb:.1f} KB per label step")
 
 
 def main():
@@ -852,7 +912,7 @@ def main():
                 a2 = argparse.Namespace(**vars(args))
                 a2.model = "large"
                 r = run_beam(a2, dev, Bb, 10, steps, 1, cpu_base=cpu and not args.no_cpu_baseline,
-                             sink_factory=sink_factory)
+                             sink_factory=sink_factory, want_traffic=cpu)  # counters for the configs[2] leg only
                 r.pop("model")
                 el_, tok_ = r.pop("elapsed"), r.pop("tokens")
                 torch.cuda.empty_cache()
