@@ -269,11 +269,72 @@ def run_stream(dtype, steps, warmup, chunk=10240, stream_beam=1, cpu_base=True):
     return res
 
 
+def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240):
+    """configs[4] as a SERVER runs it: n_streams live connections fed 640 ms chunks in lock step, one launch sequence
+    per tick for all of them (Speech2TextStreaming.batch_call: batched HIP frontend -> forward_infer_batch -> greedy
+    CTC, one device -> host read per tick).  A step = n_streams utterances of 10 s."""
+    import yaml
+
+    from espnet_amd.bin.asr_inference_streaming import Speech2TextStreaming
+
+    enc_conf = dict(output_size=256, attention_heads=4, linear_units=2048, num_blocks=12,
+                    input_layer="conv2d", normalize_before=True, activation_type="swish",
+                    macaron_style=True, use_cnn_module=True, cnn_module_kernel=15, block_size=40,
+                    hop_size=16, look_ahead=16, init_average=True, ctx_pos_enc=True)
+    cfg = dict(token_list=["<blank>", "<unk>"] + [f"t{i}" for i in range(VOCAB - 3)] + ["<sos/eos>"],
+               frontend="default", frontend_conf=dict(n_fft=512, hop_length=160, win_length=400),
+               normalize="utterance_mvn", normalize_conf={}, encoder="contextual_block_conformer",
+               encoder_conf=enc_conf, decoder="transformer",
+               decoder_conf=dict(attention_heads=4, linear_units=2048, num_blocks=6),
+               model_conf=dict(ctc_weight=0.3))
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as td:
+        (Path(td) / "config.yaml").write_text(yaml.safe_dump(cfg))
+        s2t = Speech2TextStreaming(str(Path(td) / "config.yaml"), None, device="cuda", dtype=dtype, beam_size=1,
+                                   ctc_weight=0.3, use_hipgraph=False)
+    wav = synth_batch(0, n_streams)  # (S, N) host
+    bounds = [(p, min(N_SAMPLES, p + chunk)) for p in range(0, N_SAMPLES, chunk)]
+    # a tick's audio arrives in pinned host memory (what a server's receive buffers are): from pageable memory the
+    # 1.3 MB copies of 32 streams stall ~90 ms every few ticks inside the HIP runtime (profiles/r03q_stream_batch_ticks.txt)
+    ticks = [wav[:, lo:hi].contiguous().pin_memory() for lo, hi in bounds]
+
+    def step():
+        lat = []
+        for k in range(len(bounds)):
+            t0 = time.perf_counter()
+            out = s2t.batch_call(ticks[k], is_final=(k == len(bounds) - 1))  # ends with a host read of the new ids
+            lat.append(time.perf_counter() - t0)
+        return out, lat
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lats = []
+    for _ in range(steps):
+        out, lat = step()
+        lats += lat[2:-1]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lats.sort()
+    return {"value": round(n_streams * AUDIO_SEC * steps / elapsed, 1), "unit": "audio-s/s", "streams": n_streams,
+            "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "tick_latency_ms_median": round(lats[len(lats) // 2] * 1e3, 3),
+            "tick_latency_ms_p95": round(lats[int(len(lats) * 0.95)] * 1e3, 3),
+            "chunk_ms": chunk / 16.0, "ticks_per_utt": len(bounds),
+            "realtime_multiple": int(n_streams * (chunk / 16.0) / (lats[len(lats) // 2] * 1e3)),  # audio ms per wall ms of a tick
+            "tokens_stream0": len(out[0]) if out else 0,
+            "what": f"{n_streams} lock-step streams, 640 ms chunks, one launch sequence per tick for all of them "
+                    f"(eager launches, waveform chunks from pinned host memory, greedy CTC ids read back once per tick)"}
+
+
 def main_stream(args):
     assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "--workload stream is single-stream"
     torch.cuda.set_device(0)
     res = run_stream(args.dtype, args.steps, args.warmup, args.stream_chunk, args.stream_beam,
                      cpu_base=not args.no_cpu_baseline)
+    if args.stream_beam <= 1 and args.stream_chunk == 10240:
+        res["batch32"] = run_stream_batch(args.dtype, 32, max(1, args.steps), 1)
     res = {"metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances", **res, "n_gpus": 1,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     print(json.dumps(res), flush=True)
@@ -931,6 +992,7 @@ def main():
             r["stress_40ms_calls"] = {"value": s["value"], "ms_per_step": s["ms_per_step"], **{
                 k: s["config"][k] for k in ("chunk_ms", "calls_per_utt", "call_latency_ms_median",
                                             "call_latency_ms_p95", "realtime_factor_of_one_stream")}}
+            r["batch32"] = run_stream_batch(args.dtype, 32, 3, 1)
             return r
 
         guarded("frontend", frontend_leg)

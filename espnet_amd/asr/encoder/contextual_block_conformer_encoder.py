@@ -348,6 +348,121 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
                               n_processed_blocks=n_proc + block_num, past_encoder_ctx=next_ctx)
 
 
+    # ------------------------------------------------------------------ a batch of lock-step streams
+    def _embed_device_batch(self, xs: torch.Tensor) -> torch.Tensor:
+        """Conv2dSubsamplingWOPosEnc.forward for S streams at once: xs (S, t, idim) f32 on the GPU -> (S, t', d)."""
+        pk = self._ensure_packed(xs.device)
+        lib, w = L.load(), pk["w"]
+        S, t, nm = xs.shape
+        d = self._output_size
+        T1, F1 = (t - 3) // 2 + 1, (nm - 3) // 2 + 1
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        dev, act, st = xs.device, self.act_dtype, L.current_stream_ptr()
+        flen = torch.full((S,), t, dtype=torch.int32, device=dev)
+        c1 = torch.empty(S * T1 * F1 * d, dtype=act, device=dev)
+        L.check(lib.em_conv2d_sub1(self.em_dtype, L.ptr(xs), None, L.ptr(flen), S, t, nm, w.conv1_w,
+                                   w.conv1_b, d, L.ptr(c1), st), "em_conv2d_sub1")
+        c2 = torch.empty(S * T2 * F2 * d, dtype=act, device=dev)
+        a = L.EmGemmArgs(A=c1.data_ptr(), W=w.conv2_w, C=c2.data_ptr(), bias=w.conv2_b, M=S * T2 * F2, N=d,
+                         K=9 * d, lda=0, ldc=d, scale=1.0, T1=T1, F1=F1, T2=T2, F2=F2, d=d)
+        L.check(lib.em_gemm(self.em_dtype, L.EM_EPI_RELU, L.EM_A_CONV2, a, st), "em_gemm(conv2)")
+        out = torch.empty(S, T2, d, dtype=torch.float32, device=dev)
+        a = L.EmGemmArgs(A=c2.data_ptr(), W=w.embed_w, C=out.data_ptr(), bias=w.embed_b, M=S * T2, N=d,
+                         K=F2 * d, lda=F2 * d, ldc=d, scale=1.0)
+        L.check(lib.em_gemm(self.em_dtype, L.EM_EPI_SCALE_F32, L.EM_A_PLAIN, a, st), "em_gemm(embed.out)")
+        return out
+
+    @torch.no_grad()
+    def forward_infer_batch(self, xs_pad: torch.Tensor, prev_states=None, is_final: bool = False):
+        """`forward_infer` (contextual_block_conformer_encoder.py:386-600) for S streams in LOCK STEP: every stream is
+        fed a chunk of the same length at every call (a server batching its live connections), so the streams share
+        the integer part of the state (buffer lengths, number of processed blocks) and differ in tensor contents only.
+        xs_pad (S, t, idim) f32 ON THE GPU.  Returns (ys (S, t_out, d), t_out, state); row s equals what
+        `forward_infer` returns for stream s alone (tests/test_gpu_streaming.py::test_batch_of_streams).  The dense
+        operators of a call see S * n_blk independent blocks - one launch sequence for all streams."""
+        L.require_gpu(xs_pad, "xs_pad")
+        dev = xs_pad.device
+        pk = self._ensure_packed(dev)
+        lib = L.load()
+        S = xs_pad.size(0)
+        d, bs, hs, la, sub = self._output_size, self.block_size, self.hop_size, self.look_ahead, self.subsample
+        st = prev_states or dict(prev_addin=None, buffer_before_downsampling=None, buffer_after_downsampling=None,
+                                 n_processed_blocks=0, past_encoder_ctx=None)
+        prev_addin, buf_after = st["prev_addin"], st["buffer_after_downsampling"]
+        n_proc, past_ctx = st["n_processed_blocks"], st["past_encoder_ctx"]
+        xs = xs_pad.to(torch.float32)
+        if st["buffer_before_downsampling"] is not None:
+            xs = torch.cat([st["buffer_before_downsampling"], xs], dim=1)
+        empty = xs.new_zeros(S, 0, d)
+        if is_final:
+            buf_before = None
+        else:
+            n_samples = xs.size(1) // sub - 1
+            if n_samples < 2:  # :424-438
+                return empty, 0, dict(st, buffer_before_downsampling=xs)
+            n_res = xs.size(1) % sub + sub * 2
+            buf_before = xs[:, xs.size(1) - n_res:].contiguous()
+            xs = xs[:, : n_samples * sub]
+        x = self._embed_device_batch(xs.contiguous())
+        if buf_after is not None:
+            x = torch.cat([buf_after, x], dim=1)
+        total = x.size(1)
+        if is_final:
+            block_num = math.ceil(float(total - (bs - hs - la) - la) / float(hs))
+            buf_after = None
+        else:
+            if total <= bs:  # :474-487
+                return empty, 0, dict(prev_addin=prev_addin, buffer_before_downsampling=buf_before,
+                                      buffer_after_downsampling=x, n_processed_blocks=n_proc,
+                                      past_encoder_ctx=past_ctx)
+            overlap = bs - hs
+            block_num = max(0, total - overlap) // hs
+            res = total - hs * block_num
+            buf_after = x[:, total - res:].contiguous()
+            x = x[:, : block_num * hs + overlap]
+        x = x.contiguous()
+        stream = L.current_stream_ptr()
+        if n_proc == 0 and total <= bs and is_final:  # short utterances (:496-505): no context slots
+            xc = torch.empty(S, total, d, dtype=torch.float32, device=dev)
+            for s_ in range(S):  # (rare path: one launch per stream)
+                L.check(lib.em_stream_pos_enc_f32(L.ptr(x[s_]), L.ptr(pk["pe"]), 0, total, d, L.ptr(xc[s_]), stream),
+                        "em_stream_pos_enc_f32")
+            ws = self._workspace(dev, S, total)
+            L.check(lib.em_cb_encode_blocks(self.em_dtype, C.byref(pk["w"]), L.ptr(xc), S, total, 0, None, None,
+                                            L.ptr(ws), ws.numel(), stream), "em_cb_encode_blocks")
+            return self._after_norm(xc.view(S * total, d)).view(S, total, d), total, None
+        Lb = bs + 2
+        chunks = torch.empty(S, block_num, Lb, d, dtype=torch.float32, device=dev)
+        addin = torch.empty(S, d, dtype=torch.float32, device=dev)
+        L.check(lib.em_cb_build_blocks_batch_f32(L.ptr(x), L.ptr(pk["pe"]), L.ptr(prev_addin), n_proc, S, block_num,
+                                                 x.size(1), bs, hs, d, L.ptr(chunks), L.ptr(addin), stream),
+                "em_cb_build_blocks_batch_f32")
+        next_ctx = torch.empty(S, self.num_blocks, d, dtype=torch.float32, device=dev)
+        ws = self._workspace(dev, S * block_num, Lb)
+        L.check(lib.em_cb_encode_blocks_batch(self.em_dtype, C.byref(pk["w"]), L.ptr(chunks), S, block_num, Lb, 1,
+                                              L.ptr(past_ctx), L.ptr(next_ctx), L.ptr(ws), ws.numel(), stream),
+                "em_cb_encode_blocks_batch")
+        ys_chunk = chunks[:, :, 1 : bs + 1]
+        offset = bs - la - hs
+        if is_final:
+            y_len = x.size(1) if n_proc == 0 else x.size(1) - offset
+        else:
+            y_len = block_num * hs + (offset if n_proc == 0 else 0)
+        ys = torch.zeros(S, y_len, d, dtype=torch.float32, device=dev)
+        if n_proc == 0:
+            ys[:, :offset] = ys_chunk[:, 0, :offset]
+        for i in range(block_num):  # :565-576 (slicing only)
+            cur = i * hs + (offset if n_proc == 0 else 0)
+            clen = min(bs - offset, y_len - cur) if (i == block_num - 1 and is_final) else hs
+            ys[:, cur : cur + clen] = ys_chunk[:, i, offset : offset + clen]
+        ys = self._after_norm(ys.view(S * y_len, d)).view(S, y_len, d)
+        if is_final:
+            return ys, y_len, None
+        return ys, y_len, dict(prev_addin=addin, buffer_before_downsampling=buf_before,
+                               buffer_after_downsampling=buf_after, n_processed_blocks=n_proc + block_num,
+                               past_encoder_ctx=next_ctx)
+
+
 class StreamingStepGraph:
     """hipGraph replay of the steady-state streaming step (BASELINE config 5).
 

@@ -112,6 +112,7 @@ class Speech2TextStreaming:
     def reset(self):
         self.frontend_states = None
         self.encoder_states = None
+        self._batch = None
         self._enc_chunks = []
         self._last_id = -1
         self._partial_ids: List[int] = []
@@ -179,6 +180,80 @@ class Speech2TextStreaming:
         if is_final:
             self.reset()
         return ret
+
+    # ------------------------------------------------------------------ a batch of lock-step streams (greedy CTC)
+    def apply_frontend_batch(self, speech: torch.Tensor, prev_states=None, is_final: bool = False):
+        """`apply_frontend` (:205-293) for S streams that are fed equal chunks at the same times: speech (S, n) host or
+        device tensor.  Returns (feats (S, t, n_mels) on the device or None, state)."""
+        # the chunk goes to the device first (one copy, asynchronous from pinned memory); the carried buffer lives there
+        speech = speech.to(self.device, dtype=torch.float32, non_blocking=True)
+        if prev_states is not None:
+            speech = torch.cat([prev_states["waveform_buffer"], speech], dim=1)
+        n_all = speech.size(1)
+        if n_all <= self.win_length:
+            if is_final:
+                speech = torch.cat([speech, speech.new_zeros(speech.size(0), self.win_length - n_all)], dim=1)
+            else:
+                return None, {"waveform_buffer": speech.clone()}
+        edge = math.ceil(math.ceil(self.win_length / self.hop_length) / 2)
+        if is_final:
+            to_process, waveform_buffer = speech, None
+        else:
+            n_frames = speech.size(1) // self.hop_length
+            n_residual = speech.size(1) % self.hop_length
+            to_process = speech.narrow(1, 0, n_frames * self.hop_length)
+            keep = (edge * 2 - 1) * self.hop_length + n_residual
+            waveform_buffer = speech.narrow(1, speech.size(1) - keep, keep).clone()
+        wav = to_process.contiguous()
+        S, n = wav.shape
+        m = self.asr_model
+        flens = m.frontend.feature_lengths([n] * S)
+        flens_dev = torch.tensor(flens, dtype=torch.int32).to(wav.device)
+        feats = m.frontend.forward_device(wav, flens_dev)
+        if m.normalize is not None:
+            feats = m.normalize.forward_device(feats, flens_dev)
+        if is_final:
+            if prev_states is not None:
+                feats = feats.narrow(1, edge, feats.size(1) - edge)
+        elif prev_states is None:
+            feats = feats.narrow(1, 0, feats.size(1) - edge)
+        else:
+            feats = feats.narrow(1, edge, feats.size(1) - 2 * edge)
+        return feats, (None if is_final else {"waveform_buffer": waveform_buffer})
+
+    @torch.no_grad()
+    def batch_call(self, speech: torch.Tensor, is_final: bool = False) -> List[List[int]]:
+        """One chunk of S lock-step streams, greedy CTC (what a server that batches its live connections calls per tick):
+        speech (S, n) f32.  Returns, per stream, the token ids decoded so far (incremental G1: per-frame arg-max, repeats
+        collapsed across chunk seams, blank / <sos/eos> dropped).  Stream s sees exactly what `__call__` gives it alone
+        (tests/test_gpu_streaming.py::test_batch_call_equals_single_streams); one launch sequence serves all S streams
+        (ContextualBlockConformerEncoder.forward_infer_batch).  The object holds the batch's state until is_final."""
+        if self.search == "online":
+            raise NotImplementedError("batch_call decodes greedily; the block-synchronous beam search is per stream")
+        if isinstance(speech, np.ndarray):
+            speech = torch.tensor(speech)
+        S = speech.size(0)
+        if self._batch is None:
+            self._batch = dict(frontend=None, encoder=None, last=[-1] * S, ids=[[] for _ in range(S)])
+        bst = self._batch
+        feats, bst["frontend"] = self.apply_frontend_batch(speech, bst["frontend"], is_final=is_final)
+        m = self.asr_model
+        if feats is not None:
+            enc, y_len, bst["encoder"] = m.encoder.forward_infer_batch(feats.contiguous(), bst["encoder"], is_final)
+            if y_len > 0:
+                ids = m.ctc.argmax(enc).cpu().tolist()  # ONE device -> host read per tick for all streams
+                drop = (m.blank_id, m.sos, m.eos)
+                for s_ in range(S):
+                    last, out = bst["last"][s_], bst["ids"][s_]
+                    for t in ids[s_]:
+                        if t != last and t not in drop:
+                            out.append(t)
+                        last = t
+                    bst["last"][s_] = last
+        res = [list(v) for v in bst["ids"]]
+        if is_final:
+            self._batch = None
+        return res
 
     def _encode_chunk(self, feats: torch.Tensor, is_final: bool) -> torch.Tensor:
         enc = self.asr_model.encoder

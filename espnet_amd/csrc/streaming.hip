@@ -16,6 +16,8 @@
 // The dense parts reuse gemm.hip / norm.hip / conv.hip.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "em_common.h"
 
 namespace {
@@ -35,6 +37,13 @@ __global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __res
                                                               float* __restrict__ x,
                                                               float* __restrict__ addin_out) {
   const int i = blockIdx.x, L = bs + 2;
+  // blockIdx.y = stream of a batch of lock-step streams (em_cb_build_blocks_batch_f32): its frames, its carried
+  // context, its blocks
+  const int sidx = blockIdx.y;
+  xs += (size_t)sidx * total * d;
+  if (prev_addin) prev_addin += (size_t)sidx * d;
+  x += (size_t)sidx * gridDim.x * L * d;
+  addin_out += (size_t)sidx * d;
   // the number of blocks already processed feeds the positional-encoding offsets; a hipGraph-
   // captured step reads it from device memory (kernel arguments are frozen at capture)
   const int n_proc = n_proc_dev ? *n_proc_dev : n_proc_host;
@@ -130,8 +139,12 @@ __global__ __launch_bounds__(256) void block_mha_kernel(const T* __restrict__ qk
 __global__ __launch_bounds__(256) void cb_propagate_ctx_kernel(float* __restrict__ x,
                                                                const float* __restrict__ past_ctx,
                                                                float* __restrict__ next_ctx,
-                                                               int n_blk, int L, int d) {
+                                                               int n_blk, int L, int d, int ctx_stride) {
   const int b = blockIdx.x;
+  // blockIdx.y = stream of a batch of lock-step streams: its blocks, its context vectors (ctx_stride floats apart)
+  x += (size_t)blockIdx.y * n_blk * L * d;
+  if (past_ctx) past_ctx += (size_t)blockIdx.y * ctx_stride;
+  if (next_ctx) next_ctx += (size_t)blockIdx.y * ctx_stride;
   float* xb = x + (size_t)b * L * d;
   for (int c = threadIdx.x; c < d; c += blockDim.x) {
     float v;
@@ -204,6 +217,18 @@ extern "C" int em_cb_build_blocks_f32(const float* xs, const float* pe, const fl
   return EM_OK;
 }
 
+extern "C" int em_cb_build_blocks_batch_f32(const float* xs, const float* pe, const float* prev_addin, int32_t n_proc,
+                                            int32_t n_streams, int32_t n_blk, int32_t total, int32_t bs, int32_t hs,
+                                            int32_t d, float* x, float* addin_out, void* stream) {
+  if (!xs || !pe || !x || !addin_out || n_streams <= 0 || n_blk <= 0 || total <= 0 || bs <= 0 || hs <= 0 || d <= 0)
+    return EM_ERR_BAD_ARG;
+  if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
+  hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
+                     prev_addin, n_proc, (const int*)nullptr, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
 extern "C" int em_stream_pos_enc_f32(const float* xs, const float* pe, int32_t start, int32_t n,
                                      int32_t d, float* out, void* stream) {
   if (!xs || !pe || !out || n <= 0 || d <= 0 || start < 0) return EM_ERR_BAD_ARG;
@@ -237,7 +262,7 @@ extern "C" int em_cb_propagate_ctx_f32(float* x, const float* past_ctx, float* n
                                        int32_t n_blk, int32_t L, int32_t d, void* stream) {
   if (!x || n_blk <= 0 || L < 2 || d <= 0) return EM_ERR_BAD_ARG;
   hipLaunchKernelGGL(cb_propagate_ctx_kernel, dim3(n_blk), dim3(256), 0, (hipStream_t)stream, x,
-                     past_ctx, next_ctx, n_blk, L, d);
+                     past_ctx, next_ctx, n_blk, L, d, 0);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
@@ -253,39 +278,68 @@ extern "C" size_t em_cb_workspace_bytes(int dtype, const EmConformerWeights* w, 
 // utterance; both NULL with mask_mode 0 = short-utterance path without context slots).
 // EmConformerLayer fields are reused: norm_mha = norm1, norm_ff = norm2, no pos_u / pos_v; the
 // feed-forward activation is ReLU (contextual_block_conformer_encoder.py:148-154).
-extern "C" int em_cb_encode_blocks(int dtype, const EmConformerWeights* w, float* x, int32_t n_blk,
-                                   int32_t L, int32_t mask_mode, const float* past_ctx,
-                                   float* next_ctx, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
-  if (!w || !x || !workspace || n_blk <= 0 || L <= 0) return EM_ERR_BAD_ARG;
+static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* x, int32_t n_streams, int32_t n_blk_s,
+                                 int32_t L, int32_t mask_mode, const float* past_ctx, float* next_ctx, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!w || !x || !workspace || n_streams <= 0 || n_blk_s <= 0 || L <= 0) return EM_ERR_BAD_ARG;
   if (dtype != EM_F32 && dtype != EM_BF16) return EM_ERR_BAD_ARG;
+  // n_streams lock-step streams of n_blk_s blocks each: the dense operators see n_streams * n_blk_s independent blocks;
+  // only the context hand-over between layers knows which blocks follow each other
+  const int n_blk = n_streams * n_blk_s;
   const int d = w->d, h = w->heads, ff = w->ff, NL = w->num_blocks, M = n_blk * L;
   if (d % 64 != 0 || ff % 64 != 0 || (d / h != 64 && d / h != 32)) return EM_ERR_UNSUPPORTED;
   const CbWs s = cb_layout(dtype, w, M);
   if (workspace_bytes < s.total) return EM_ERR_WORKSPACE;
   unsigned char* ws = (unsigned char*)workspace;
   void *xn = ws + s.xn, *big = ws + s.big, *gl = ws + s.g, *g2 = ws + s.g2, *ctx = ws + s.ctx;
+  // A pre-norm LayerNorm rides in the prologue of the projection that consumes it (csrc/ln_gemm.hip) where that kernel
+  // has the epilogue (plain / ReLU): three launches less per layer.  A step is ~200 dependent launches of ~5.6 us for
+  // 42 rows - launch latency, nothing else - so the count is what matters (round 3: 1.30 -> see profiles/r03p).
+  static const bool no_lng = getenv("ESPNET_AMD_STREAM_NO_LN_GEMM") != nullptr;  // developer A/B switch
+  const bool lng = !no_lng && d % 64 == 0 && d <= 1024;
+  auto ln_proj = [&](int epi, const float* g, const float* be, const void* W, const float* bias, void* C, int N) {
+    if (lng) return em_ln_gemm(dtype, epi, x, g, be, LN_EPS, W, bias, C, M, N, d, N, stream);
+    int rc = em_layernorm(dtype, x, g, be, M, d, LN_EPS, xn, nullptr, stream);
+    if (rc != EM_OK) return rc;
+    return gemm(dtype, epi, xn, W, C, bias, M, N, d, d, N, 1.f, stream);
+  };
   for (int l = 0; l < NL; ++l) {
     const EmConformerLayer& q = w->layers[l];
-    EM_TRY(em_layernorm(dtype, x, q.norm_ff_mac_g, q.norm_ff_mac_b, M, d, LN_EPS, xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RELU, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
+    EM_TRY(ln_proj(EM_EPI_RELU, q.norm_ff_mac_g, q.norm_ff_mac_b, q.ffm_w1, q.ffm_b1, big, ff));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
-    EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
+    EM_TRY(ln_proj(EM_EPI_STORE, q.norm_mha_g, q.norm_mha_b, q.wqkv, q.bqkv, big, 3 * d));
     EM_TRY(em_block_mha(dtype, big, n_blk, L, d, h, mask_mode, ctx, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
     EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
     EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, nullptr, n_blk, L, d, w->kernel, g2, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
-    EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RELU, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
+    EM_TRY(ln_proj(EM_EPI_RELU, q.norm_ff_g, q.norm_ff_b, q.ff_w1, q.ff_b1, big, ff));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ff_w2, x, q.ff_b2, M, d, ff, ff, d, 0.5f, stream));
     EM_TRY(em_layernorm_inplace_f32(x, q.norm_final_g, q.norm_final_b, M, d, LN_EPS, stream));
-    if (mask_mode)
-      EM_TRY(em_cb_propagate_ctx_f32(x, past_ctx ? past_ctx + (size_t)l * d : nullptr,
-                                     next_ctx ? next_ctx + (size_t)l * d : nullptr, n_blk, L, d,
-                                     stream));
+    if (mask_mode) {
+      hipLaunchKernelGGL(cb_propagate_ctx_kernel, dim3(n_blk_s, n_streams), dim3(256), 0, (hipStream_t)stream, x,
+                         past_ctx ? past_ctx + (size_t)l * d : nullptr, next_ctx ? next_ctx + (size_t)l * d : nullptr,
+                         n_blk_s, L, d, NL * d);
+      EM_CHECK_LAUNCH();
+    }
   }
   return EM_OK;
+}
+
+extern "C" int em_cb_encode_blocks(int dtype, const EmConformerWeights* w, float* x, int32_t n_blk,
+                                   int32_t L, int32_t mask_mode, const float* past_ctx,
+                                   float* next_ctx, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  return cb_encode_blocks_impl(dtype, w, x, 1, n_blk, L, mask_mode, past_ctx, next_ctx, workspace, workspace_bytes,
+                               stream);
+}
+
+// The same for a batch of n_streams lock-step streams: x [n_streams][n_blk][L][d], past_ctx / next_ctx
+// [n_streams][num_blocks][d]; workspace for n_streams * n_blk blocks (em_cb_workspace_bytes).
+extern "C" int em_cb_encode_blocks_batch(int dtype, const EmConformerWeights* w, float* x, int32_t n_streams,
+                                         int32_t n_blk, int32_t L, int32_t mask_mode, const float* past_ctx,
+                                         float* next_ctx, void* workspace, size_t workspace_bytes, void* stream) {
+  return cb_encode_blocks_impl(dtype, w, x, n_streams, n_blk, L, mask_mode, past_ctx, next_ctx, workspace,
+                               workspace_bytes, stream);
 }

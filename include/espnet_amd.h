@@ -785,6 +785,18 @@ int em_cb_encode_blocks(int dtype, const EmConformerWeights* w, float* x, int32_
                         int32_t mask_mode, const float* past_ctx, float* next_ctx, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/*   Batch of n_streams LOCK-STEP streams (a server feeding equal chunks to many streams at once): the same two calls
+ *   with a leading stream dimension - xs [n_streams][total][d], prev_addin / addin_out [n_streams][d] (prev_addin NULL
+ *   on the streams' first call), x [n_streams][n_blk][bs+2][d]; past_ctx / next_ctx [n_streams][num_blocks][d];
+ *   workspace for n_streams * n_blk blocks.  The dense operators see n_streams * n_blk independent blocks; only block
+ *   assembly and the context hand-over between layers know the streams.                                         */
+int em_cb_build_blocks_batch_f32(const float* xs, const float* pe, const float* prev_addin, int32_t n_proc,
+                                 int32_t n_streams, int32_t n_blk, int32_t total, int32_t bs, int32_t hs, int32_t d,
+                                 float* x, float* addin_out, void* stream);
+int em_cb_encode_blocks_batch(int dtype, const EmConformerWeights* w, float* x, int32_t n_streams, int32_t n_blk,
+                              int32_t L, int32_t mask_mode, const float* past_ctx, float* next_ctx, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- optional per-launch timing of the GEMM kernel family (measurement only; bench.py's
  *      `roofline` leg).  While a profile is attached to the calling thread every em_gemm launch
  *      (direct or from em_conformer_encode / em_ctc_greedy) is bracketed by hipEventRecord on its

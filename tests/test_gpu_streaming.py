@@ -211,3 +211,79 @@ def test_speech2text_streaming_end_to_end(tmp_path):
         eager = s2t(wav[pos:nxt], is_final=(nxt == 80000))
     assert eager[0][2] == chunked
     assert isinstance(oneshot, list)
+
+
+@pytest.mark.parametrize("name,dtype,atol", [("stream_tiny_4s", "float32", 2e-4), ("stream_small_6s", "float32", 2e-4),
+                                             ("stream_small_6s", "bfloat16", 0.12)])
+def test_batch_of_streams(name, dtype, atol):
+    """Lock-step batch of streams (forward_infer_batch: one launch sequence for S streams) == every stream encoded
+    alone, call by call: same frames emitted per call, same values (f32: the GEMMs pick other tiles at other row
+    counts, so summation order only; bf16: operand rounding of intermediate activations differs with it)."""
+    g = load_stream_golden(name)
+    n, cf = int(g["n_samples"]), int(g["chunk_frames"])
+    feats = torch.stack([stream_feats(int(g["utt_id"]) + s, n) for s in range(3)])  # (S, T, 80): three utterances
+    enc = build(g, dtype)
+    singles, lens_single = [], None
+    for s in range(feats.size(0)):
+        ys, lens = run_chunks(enc, feats[s], cf)
+        singles.append(ys)
+        lens_single = lens
+    outs, lens, state, pos = [], [], None, 0
+    T = feats.size(1)
+    while pos < T:
+        nxt = min(T, pos + cf)
+        y, y_len, state = enc.forward_infer_batch(feats[:, pos:nxt].cuda(), state, is_final=(nxt == T))
+        assert y.shape[:2] == (3, y_len)
+        outs.append(y)
+        lens.append(y_len)
+        pos = nxt
+    assert lens == lens_single
+    got = torch.cat(outs, 1).cpu()
+    for s in range(3):
+        err = (got[s] - singles[s].cpu()).abs().max().item()
+        assert err < atol, (s, err)
+    # the three streams are different utterances: rows must not be copies of each other
+    assert (got[0] - got[1]).abs().max().item() > 0.1
+
+
+def test_batch_call_equals_single_streams(tmp_path):
+    """Speech2TextStreaming.batch_call (S lock-step streams, one launch sequence per tick: batched HIP frontend ->
+    forward_infer_batch -> incremental greedy CTC) returns for every stream the tokens `__call__` returns for it alone
+    (f32, eager single-stream runs)."""
+    import yaml
+
+    from espnet_amd.bin.asr_inference_streaming import Speech2TextStreaming
+    from oracle.weights import recipe_state_dict, synth_waveform, token_list
+
+    g = load_stream_golden("stream_small_6s")
+    V = 50
+    cfg = dict(token_list=token_list(V), frontend="default",
+               frontend_conf=dict(n_fft=512, hop_length=160, win_length=400), normalize="utterance_mvn",
+               normalize_conf={}, encoder="contextual_block_conformer", encoder_conf=g["conf"],
+               decoder="transformer", decoder_conf=dict(attention_heads=4, linear_units=256, num_blocks=1),
+               model_conf=dict(ctc_weight=0.3))
+    (tmp_path / "config.yaml").write_text(yaml.safe_dump(cfg))
+    s2t = Speech2TextStreaming(str(tmp_path / "config.yaml"), None, device="cuda", dtype="float32", beam_size=1,
+                               use_hipgraph=False)
+    sd = s2t.asr_model.state_dict()
+    new = recipe_state_dict({k: tuple(v.shape) for k, v in sd.items()}, 31)
+    new["frontend.logmel.melmat"] = sd["frontend.logmel.melmat"].clone()
+    s2t.asr_model.load_state_dict(new, strict=True)
+    N, CH, S = 80000, 10240, 3
+    wavs = torch.stack([synth_waveform(40 + s, N) for s in range(S)])
+    singles = []
+    for s in range(S):
+        res = []
+        for pos in range(0, N, CH):
+            nxt = min(N, pos + CH)
+            res = s2t(wavs[s, pos:nxt], is_final=(nxt == N))
+        singles.append(res[0][2])
+    got = []
+    for pos in range(0, N, CH):
+        nxt = min(N, pos + CH)
+        got = s2t.batch_call(wavs[:, pos:nxt], is_final=(nxt == N))
+    assert len(got) == S
+    # token_int of __call__ drops id 0 (= blank, already dropped here); compare the id lists
+    for s in range(S):
+        assert got[s] == singles[s], (s, got[s][:10], singles[s][:10])
+    assert got[0] != got[1]
