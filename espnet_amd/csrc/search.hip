@@ -196,58 +196,117 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(Ctx c, int i_ho
   for (int k = 0; k < NV; ++k)
     if (tid + 256 * k == c.p.eos) s_eosfull = w[k];
   // each wave extracts the top-S of its own 64*NV values with wave-level ops only (no block
-  // barrier inside the rounds); the 4*S survivors are merged by wave 0
+  // barrier inside the rounds); the 4*S survivors are merged by wave 0.
+  // Fast path: a thread first sorts out its own three largest values (one scan of its NV registers); a round then
+  // compares ONE value per lane (the head of that list) and pops the winner's list - ~45 instructions per round
+  // instead of ~190 for the rounds that rescan all NV registers.  A thread whose list runs empty might still own a
+  // value the wave needs: the wave then redoes its rounds the exact way (wave-uniform, rare: three of a wave's top S
+  // in one thread's NV strided values).  Same order as the exact rounds: largest value, lowest id on ties (ids ascend
+  // within a thread and a later equal value never displaces an earlier one).
   const int SS = S < PREBEAM_SMAX ? S : PREBEAM_SMAX;
-  for (int k = 0; k < SS; ++k) {
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
+  {
+    float v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
+    int i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < NV; ++q)
-      if (w[q] > best) {  // ascending ids within a thread: strict > keeps the lowest
-        best = w[q];
-        bi = tid + 256 * q;
-      }
-    const float wb = wave_allmax_dpp(best);
-    const int wi = wave_allmin_dpp(best == wb ? bi : 0x7fffffff);  // lowest id among the holders of the maximum
-    if (lane == 0) {
-      m_v[wave * SS + k] = wb;
-      m_i[wave * SS + k] = wi;
+    for (int q = 0; q < NV; ++q) {
+      const float x = w[q];
+      const int ix = tid + 256 * q;
+      const bool g1 = x > v1, g2 = x > v2, g3 = x > v3;
+      v3 = g2 ? v2 : (g3 ? x : v3);
+      i3 = g2 ? i2 : (g3 ? ix : i3);
+      v2 = g1 ? v1 : (g2 ? x : v2);
+      i2 = g1 ? i1 : (g2 ? ix : i2);
+      v1 = g1 ? x : v1;
+      i1 = g1 ? ix : i1;
     }
+    int pops = 0;
+    bool exact = false;
+    for (int k = 0; k < SS; ++k) {
+      const float wb = wave_allmax_dpp(v1);
+      const int wi = wave_allmin_dpp(v1 == wb ? i1 : 0x7fffffff);  // lowest id among the holders of the maximum
+      if (lane == 0) {
+        m_v[wave * SS + k] = wb;
+        m_i[wave * SS + k] = wi;
+      }
+      const bool mine = (wi == i1) && (wi != 0x7fffffff);
+      if (mine) {
+        v1 = v2; i1 = i2;
+        v2 = v3; i2 = i3;
+        v3 = -INFINITY; i3 = 0x7fffffff;
+        ++pops;
+      }
+      if (__any(pops == 3 && k + 1 < SS)) {  // (its fourth value is unknown: the list cannot answer the next round)
+        exact = true;
+        break;
+      }
+    }
+    if (exact) {
+      for (int k = 0; k < SS; ++k) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < NV; ++q)
-      if (tid + 256 * q == wi) w[q] = -INFINITY;
+        for (int q = 0; q < NV; ++q)
+          if (w[q] > best) {  // ascending ids within a thread: strict > keeps the lowest
+            best = w[q];
+            bi = tid + 256 * q;
+          }
+        const float wb = wave_allmax_dpp(best);
+        const int wi = wave_allmin_dpp(best == wb ? bi : 0x7fffffff);
+        if (lane == 0) {
+          m_v[wave * SS + k] = wb;
+          m_i[wave * SS + k] = wi;
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+          if (tid + 256 * q == wi) w[q] = -INFINITY;
+      }
+    }
   }
   __syncthreads();
   if (wave == 0) {
-    constexpr int NQ = 4 * PREBEAM_SMAX / 64;
-    float cv[NQ];
-    int ci[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int j = lane + 64 * q;
-      cv[q] = j < 4 * SS ? m_v[j] : -INFINITY;
-      ci[q] = j < 4 * SS ? m_i[j] : 0x7fffffff;
-    }
-    for (int k = 0; k < SS; ++k) {
-      float best = -INFINITY;
-      int bi = 0x7fffffff;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (cv[q] > best || (cv[q] == best && ci[q] < bi)) {
-          best = cv[q];
-          bi = ci[q];
-        }
-      const float wb = wave_allmax_dpp(best);
-      const int wi = wave_allmin_dpp(best == wb ? bi : 0x7fffffff);
+    auto emit = [&](int k, float wb, int wi) {
       if (lane == 0) {
         c.b.cand_tok[(size_t)r * NC + k] = wi;
         c.b.cand_full[(size_t)r * NC + k] = wb;
         s_ct[k] = wi;
         s_cf[k] = wb;
       }
+    };
+    if (4 * SS <= 64) {  // one survivor per lane (beam <= 10): a round is two reductions and a select
+      float cv = lane < 4 * SS ? m_v[lane] : -INFINITY;
+      const int ci = lane < 4 * SS ? m_i[lane] : 0x7fffffff;
+      for (int k = 0; k < SS; ++k) {
+        const float wb = wave_allmax_dpp(cv);
+        const int wi = wave_allmin_dpp(cv == wb ? ci : 0x7fffffff);
+        emit(k, wb, wi);
+        if (ci == wi) cv = -INFINITY;
+      }
+    } else {
+      constexpr int NQ = 4 * PREBEAM_SMAX / 64;
+      float cv[NQ];
+      int ci[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (ci[q] == wi) cv[q] = -INFINITY;
+      for (int q = 0; q < NQ; ++q) {
+        const int j = lane + 64 * q;
+        cv[q] = j < 4 * SS ? m_v[j] : -INFINITY;
+        ci[q] = j < 4 * SS ? m_i[j] : 0x7fffffff;
+      }
+      for (int k = 0; k < SS; ++k) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (cv[q] > best || (cv[q] == best && ci[q] < bi)) {
+            best = cv[q];
+            bi = ci[q];
+          }
+        const float wb = wave_allmax_dpp(best);
+        const int wi = wave_allmin_dpp(best == wb ? bi : 0x7fffffff);
+        emit(k, wb, wi);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (ci[q] == wi) cv[q] = -INFINITY;
+      }
     }
   }
   // ---- candidate totals of the row's NC = S + 1 slots: slots 0..S-1 = the pre-beam, slot S = <eos>
@@ -1039,7 +1098,8 @@ inline int ln_proj(int dtype, int epi, const float* x, const float* g, const flo
                    const float* bias, void* C, void* xn_scratch, int n, int N, int K, void* stream) {
   const long wgs = (long)em_cdiv(N, 64) * em_cdiv(n, 32);
   // n <= 48 (one stream): LayerNorm + the skinny GEMM is 6.6 us, the fused kernel 7.5
-  if (n > 48 && wgs <= 256 && K % 64 == 0 && K <= 1024)
+  static const int wide = getenv("ESPNET_AMD_LNG_WIDE") ? atoi(getenv("ESPNET_AMD_LNG_WIDE")) : 256;  // developer A/B switch
+  if (n > 48 && wgs <= wide && K % 64 == 0 && K <= 1024)
     return em_ln_gemm(dtype, epi, x, g, be, LN_EPS, W, bias, C, n, N, K, N, stream);
   EM_TRY(em_layernorm(dtype, x, g, be, n, K, LN_EPS, xn_scratch, nullptr, stream));
   return gemm(dtype, epi, xn_scratch, W, C, bias, n, N, K, K, N, 1.f, stream);

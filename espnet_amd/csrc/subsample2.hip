@@ -31,6 +31,9 @@
 // One barrier per chunk: the conv1 patch of chunk c + 1 is produced, a slice per tap, while chunk c is consumed.
 // Per workgroup and chunk: 382 MFMAs per wave (6 100 cycles of matrix-core time), 144 KiB of weights (64 B/clk would
 // take 2 300 cycles), 400 KiB of LDS fragment reads (3 100 cycles at 128 B/clk): the kernel is built to be MFMA-bound.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "em_common.h"
 
 namespace {
@@ -65,6 +68,7 @@ struct Sub2Args {
   const float* b2;        // [256]
   void* out;              // [B][T2][F2][256] bf16
   int B, T_f, n_mels, F1, T2, F2;
+  long long* stamps;      // developer timing (EM_SUB2_STAMPS): cycle stamps of workgroup (3, 5), wave 0
 };
 
 __device__ __forceinline__ bf16 hi_of(float x) { return (bf16)x; }
@@ -78,6 +82,12 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   const int lr = lane & 15, lg = lane >> 4;
   const int b = blockIdx.y, t2_0 = blockIdx.x * TT;
   const int n_mels = a.n_mels, F1 = a.F1, F2 = a.F2;
+  int nts = 0;
+  auto stamp = [&]() {
+    if (a.stamps && blockIdx.x == 3 && blockIdx.y == 5 && tid == 0 && nts < 32) a.stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
+    ++nts;
+  };
+  stamp();
   // weight fragments of conv2: tap g = cc * 9 + tap of the whole K walk, four 1 KiB lines per wave and tap, requested
   // two taps (1 280 cycles of MFMA) ahead through a ring of three sets - 9 taps per chunk, so the slot g % 3 = tap % 3
   // is a compile-time index.  Unconditional: past the end the last tap is repeated.
@@ -92,20 +102,45 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   wload(0, wr[0]);
   wload(1, wr[1]);
   // ---- the tile's feature rows, mean-subtracted (rows past the utterance's end repeat the last row: they only reach
-  // output rows past T2, which are never stored)
-  for (int i = tid; i < INR * n_mels; i += 256) {
-    const int r = i / n_mels, f = i - r * n_mels;
+  // output rows past T2, which are never stored).  The per-bin means first (one request burst by n_mels threads), then
+  // the rows with every request of a thread out before its first use.  (Round 3, EM_SUB2_STAMPS: the first version
+  // re-read the eight MVN partial sums per ELEMENT under `if (partial)` - eleven dependent round trips per thread,
+  // 20 400 cycles = 19 % of the workgroup's time before the first MFMA; now 13 000.)
+  float* const s_mean = (float*)(smem + XIN_OFF);  // (xin is built after the rows have been read)
+  if (tid < n_mels) {
     float mean = 0.f;
     if (a.partial) {
-      const float* pp = a.partial + (size_t)b * 8 * n_mels + f;
+      const float* pp = a.partial + (size_t)b * 8 * n_mels + tid;
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) s += pp[q * n_mels];
       mean = s / (float)a.flens[b];
     }
-    int row = 4 * t2_0 + r;
-    row = row < a.T_f ? row : a.T_f - 1;
-    s_in[r * MELMAX + f] = a.feats[((size_t)b * a.T_f + row) * n_mels + f] - mean;
+    s_mean[tid] = mean;
+  }
+  {
+    constexpr int PER = (INR * MELMAX + 255) / 256;  // elements per thread at most
+    float v[PER];
+    const float* fb = a.feats + (size_t)b * a.T_f * n_mels;
+    const int nel = INR * n_mels;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int i = tid + 256 * k;
+      i = i < nel ? i : nel - 1;
+      const int r = i / n_mels, f = i - r * n_mels;
+      int row = 4 * t2_0 + r;
+      row = row < a.T_f ? row : a.T_f - 1;
+      v[k] = fb[(size_t)row * n_mels + f];
+    }
+    __syncthreads();  // the means are in LDS
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + 256 * k;
+      if (i < nel) {
+        const int r = i / n_mels, f = i - r * n_mels;
+        s_in[r * MELMAX + f] = v[k] - s_mean[f];
+      }
+    }
   }
   __syncthreads();
   // ---- conv1's position operands: fragment pf covers map positions 16 pf .. 16 pf + 15 (p = t1l * F1 + f1); lane
@@ -136,6 +171,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     *(bf16x8*)(smem + XIN_OFF + pf * 1024 + lane * 16) = v;
   }
   __syncthreads();  // (s_in is dead from here on: patch 1 may be written)
+  stamp();
 
   // ---- conv1 of a chunk for this wave's j-th position fragment (pf = wave + 4 j), both 16-channel fragments of the
   // chunk: 2 MFMAs; the lane gets channels 4 lg .. 4 lg + 3 (+ 16 for the second fragment) of position 16 pf + lr
@@ -180,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
 #pragma unroll
     for (int i = 0; i < MF; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();  // patch 0 is complete
+  stamp();
   // The position fragments are read HALF A TAP ahead: a group = five fragments = 20 MFMAs (320 cycles of matrix-core
   // time, more than an LDS round trip), requested into the other half of a register double buffer before the current
   // group's MFMAs are issued.  Read next to their use - what hipcc does with the plain loop - every fragment exposed
@@ -219,7 +256,9 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
           acc[j][i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][j], bfr[g & 1][i], acc[j][i0 + i], 0, 0, 0);
     }
     load_w1(cc + 2 < NCHUNK ? cc + 2 : NCHUNK - 1);  // conv1 weights of the chunk produced during the next trip
+    stamp();
     __syncthreads();
+    stamp();
     // the next chunk's first group, from the patch that has just been completed
     read_group(smem + PATCH_OFF + nbuf * PATCH_BYTES, 0, bfr[0]);
     xv[0] = conv1_read(0);
@@ -246,6 +285,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, off, 0, 0);
     }
   }
+  stamp();
 }
 
 }  // namespace
@@ -267,8 +307,22 @@ extern "C" int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial
   a.feats = feats; a.partial = mvn_partial; a.flens = flens;
   a.w1f = conv1_wf; a.w2f = conv2_wf; a.b2 = conv2_b; a.out = c2;
   a.B = B; a.T_f = T_f; a.n_mels = n_mels; a.F1 = F1; a.T2 = T2; a.F2 = F2;
+  static long long* stamps = nullptr;
+  static const bool want_stamps = getenv("EM_SUB2_STAMPS") != nullptr;
+  if (want_stamps && !stamps && hipMalloc((void**)&stamps, 32 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
+  if (want_stamps && hipMemsetAsync(stamps, 0, 32 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
+  a.stamps = want_stamps ? stamps : nullptr;
   const bool rec = em_prof_begin(stream);
   hipLaunchKernelGGL(sub2_kernel, dim3(em_cdiv(T2, TT), B), dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+  if (want_stamps) {
+    long long h[32];
+    if (hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      printf("[sub2 stamps, cycles since entry]");
+      for (int i = 1; i < 32 && h[i]; ++i) printf(" %lld", h[i] - h[0]);
+      printf("\n");
+      fflush(stdout);
+    }
+  }
   if (rec) em_prof_end(stream, 2.0 * (double)B * T2 * F2 * D * 9.0 * D, EM_PROF_GEMM);
   EM_CHECK_LAUNCH();
   return EM_OK;
