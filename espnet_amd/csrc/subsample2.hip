@@ -51,13 +51,40 @@ constexpr int PSTRIDE = 2 * CC + 16;          // bytes per patch position: 64 of
 constexpr int PATCH_BYTES = NPF * 16 * PSTRIDE;  // 55 040 (whole fragments: the padded positions are written too)
 constexpr int XIN_OFF = 0;                       // [NPF][64 lanes][16 B]: the conv1 position operands
 constexpr int PATCH_OFF = NPF * 1024;
-constexpr int IN_OFF = PATCH_OFF + PATCH_BYTES;  // f32 [INR][MELMAX], aliasing patch 1 (dead before chunk 1 is produced)
-constexpr int SMEM_BYTES = PATCH_OFF + 2 * PATCH_BYTES;
-static_assert(INR * MELMAX * 4 <= PATCH_BYTES && SMEM_BYTES <= 160 * 1024, "LDS");
+constexpr int IN_OFF = PATCH_OFF + PATCH_BYTES;  // f32 [INR][n_mels] (contiguous rows: filled by LDS-DMA), aliasing patch 1 (dead before chunk 1 is produced)
+constexpr int MAXK = 16;                              // tiles per persistent workgroup at most (the host sizes the grid)
+constexpr int MEAN_OFF = PATCH_OFF + 2 * PATCH_BYTES;  // f32 [MAXK][MELMAX]: per-bin means of the utterances of this workgroup's tiles
+constexpr int BIAS_OFF = MEAN_OFF + MAXK * MELMAX * 4;  // f32 [D]: conv2's bias (read in the epilogue without touching vmcnt)
+constexpr int SMEM_BYTES = BIAS_OFF + D * 4;
+static_assert(INR * MELMAX * 4 + 1024 <= PATCH_BYTES && SMEM_BYTES <= 160 * 1024, "LDS");
+constexpr int N_STORES = MF * 4;  // buffer stores of a wave's epilogue (the wait that lets the next tile's inputs pass them counts on it)
+static_assert(N_STORES <= 63, "vmcnt");
 constexpr int PF_PER_WAVE = (NPF + 3) / 4;  // 11
 static_assert(PF_PER_WAVE <= 18, "a conv1 fragment per group of a chunk at most");
 
 typedef const __attribute__((address_space(1))) bf16x8* GFRAG;
+
+// LDS-DMA from inline asm (see csrc/block.hip: hidden from hipcc's waitcnt pass on purpose): 64 lanes x 16 bytes from
+// sbase + voff to LDS at lds_dst + 16 * lane
+__device__ __forceinline__ void glds16(const unsigned char* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
+}
 
 struct Sub2Args {
   const float* feats;     // [B][T_f][n_mels]
@@ -80,73 +107,118 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.y, t2_0 = blockIdx.x * TT;
   const int n_mels = a.n_mels, F1 = a.F1, F2 = a.F2;
+  // Persistent workgroups (one per CU): workgroup g walks the tiles g, g + gridDim.x, ...  The NEXT tile's inputs are
+  // requested right after the last MFMA of a tile, BEFORE its output stores - the 35 feature rows by LDS-DMA into the
+  // patch that has just gone dead, the MVN partial sums into a register - and memory operations complete in issue
+  // order: the next tile waits for "all but the 40 stores", builds its operands (no memory access) and computes its
+  // first conv1 chunk while the stores drain.  With one workgroup per tile (round 3's first version, EM_SUB2_STAMPS)
+  // every tile paid 13 K cycles of input latency + operand building before its first conv2 MFMA and 10 K cycles for
+  // its stores at the end - all 256 CUs store their 80 KiB at the same moment, four times per launch - of 100 K.
+  // (Prefetching the rows into registers instead spilled: the kernel lives at 254 VGPRs.)
+  const int tiles_t = (a.T2 + TT - 1) / TT, ntiles = tiles_t * a.B;
+  int tile = blockIdx.x;
   int nts = 0;
   auto stamp = [&]() {
-    if (a.stamps && blockIdx.x == 3 && blockIdx.y == 5 && tid == 0 && nts < 32) a.stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
+    if (a.stamps && blockIdx.x == 7 && tid == 0 && nts < 32) a.stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
     ++nts;
   };
   stamp();
   // weight fragments of conv2: tap g = cc * 9 + tap of the whole K walk, four 1 KiB lines per wave and tap, requested
   // two taps (1 280 cycles of MFMA) ahead through a ring of three sets - 9 taps per chunk, so the slot g % 3 = tap % 3
-  // is a compile-time index.  Unconditional: past the end the last tap is repeated.
+  // is a compile-time index.  Unconditional: past the end the walk wraps around (the next tile's first taps).
   const unsigned char* const wbase = (const unsigned char*)a.w2f + wave * 4096 + lane * 16;
   constexpr int NTAP = NCHUNK * 9;
+  static_assert(NTAP % 3 == 0, "the ring slot of a tap must not depend on the tile");
   bf16x8 wr[3][4];
   auto wload = [&](int g, bf16x8 (&w)[4]) {
-    const unsigned char* p = wbase + (size_t)(g < NTAP ? g : NTAP - 1) * 16384;
+    const unsigned char* p = wbase + (size_t)(g < NTAP ? g : g - NTAP) * 16384;
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = *(GFRAG)(p + j * 1024);
   };
-  wload(0, wr[0]);
-  wload(1, wr[1]);
-  // ---- the tile's feature rows, mean-subtracted (rows past the utterance's end repeat the last row: they only reach
-  // output rows past T2, which are never stored).  The per-bin means first (one request burst by n_mels threads), then
-  // the rows with every request of a thread out before its first use.  (Round 3, EM_SUB2_STAMPS: the first version
-  // re-read the eight MVN partial sums per ELEMENT under `if (partial)` - eleven dependent round trips per thread,
-  // 20 400 cycles = 19 % of the workgroup's time before the first MFMA; now 13 000.)
-  float* const s_mean = (float*)(smem + XIN_OFF);  // (xin is built after the rows have been read)
-  if (tid < n_mels) {
-    float mean = 0.f;
-    if (a.partial) {
-      const float* pp = a.partial + (size_t)b * 8 * n_mels + tid;
-      float s = 0.f;
+  // ---- a tile's inputs.  Rows past the utterance's end repeat the last row (they only reach output rows past T2,
+  // which are never stored).  The rows are contiguous in memory and in LDS: 1 KiB per wave-instruction.
+  const int rowb = n_mels * 4, tileb = INR * rowb, npiece = (tileb + 1023) >> 10;
+  auto request_inputs = [&](int tl) {
+    const int bb = tl / tiles_t, tt0 = (tl - bb * tiles_t) * TT;
+    if (4 * tt0 + INR <= a.T_f) {
+      // the tile's rows are one contiguous block of the utterance: base in scalar registers, lane * 16 the only VGPR
+      // (at this point of the kernel there are no free ones: computed per lane, the addresses were spilled and every
+      // request waited for a scratch reload - and with it for the request before it)
+      const unsigned char* fb = uniform_ptr((const unsigned char*)(a.feats + ((size_t)bb * a.T_f + 4 * tt0) * n_mels));
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += pp[q * n_mels];
-      mean = s / (float)a.flens[b];
-    }
-    s_mean[tid] = mean;
-  }
-  {
-    constexpr int PER = (INR * MELMAX + 255) / 256;  // elements per thread at most
-    float v[PER];
-    const float* fb = a.feats + (size_t)b * a.T_f * n_mels;
-    const int nel = INR * n_mels;
+      for (int i = 0; i < 3; ++i) {
+        int j = wave + 4 * i;
+        j = j < npiece ? j : npiece - 1;  // (surplus requests repeat the last piece: same bytes, no branch)
+        int jb = j * 1024;
+        jb = jb + 1024 <= tileb ? jb : tileb - 1024;  // (the last piece is shifted back inside the tile: same bytes twice)
+        glds16(fb + jb, (unsigned)(lane * 16), IN_OFF + jb);
+      }
+    } else {  // the utterance's last tile: rows past its end repeat the last row (one tile in 32)
+      const unsigned char* fb = uniform_ptr((const unsigned char*)(a.feats + (size_t)bb * a.T_f * n_mels));
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int i = tid + 256 * k;
-      i = i < nel ? i : nel - 1;
-      const int r = i / n_mels, f = i - r * n_mels;
-      int row = 4 * t2_0 + r;
-      row = row < a.T_f ? row : a.T_f - 1;
-      v[k] = fb[(size_t)row * n_mels + f];
-    }
-    __syncthreads();  // the means are in LDS
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = tid + 256 * k;
-      if (i < nel) {
-        const int r = i / n_mels, f = i - r * n_mels;
-        s_in[r * MELMAX + f] = v[k] - s_mean[f];
+      for (int i = 0; i < 3; ++i) {
+        int j = wave + 4 * i;
+        j = j < npiece ? j : npiece - 1;
+        int jb = j * 1024;
+        jb = jb + 1024 <= tileb ? jb : tileb - 1024;
+        const int o = jb + lane * 16;
+        const int r = o / rowb, col = o - r * rowb;
+        int row = 4 * tt0 + r;
+        row = row < a.T_f ? row : a.T_f - 1;
+        glds16(fb, (unsigned)(row * rowb + col), IN_OFF + jb);
       }
     }
+  };
+  static_assert(3 * 4 * 1024 >= INR * MELMAX * 4, "three pieces per wave cover a tile");
+  request_inputs(tile);
+  // the per-bin means (MVN) of the utterances of ALL this workgroup's tiles, once, while registers are plentiful
+  float* const s_means = (float*)(smem + MEAN_OFF);
+  float* const s_bias = (float*)(smem + BIAS_OFF);
+  s_bias[tid] = a.b2[tid];  // (256 threads = D channels)
+  for (int k = 0, tl = tile; tl < ntiles && k < MAXK; ++k, tl += gridDim.x) {
+    const int bb = tl / tiles_t;
+    if (tid < n_mels) {
+      float mean = 0.f;
+      if (a.partial) {
+        const float* pp = a.partial + (size_t)bb * 8 * n_mels + tid;
+        float pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pv[q] = pp[q * n_mels];
+        float sm = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sm += pv[q];
+        mean = sm / (float)a.flens[bb];
+      }
+      s_means[k * MELMAX + tid] = mean;
+    }
   }
+  const int npos = T1R * F1;
+  const int M = TT * F2;
+  bool first = true;
+  int kt = 0;  // index of the tile among this workgroup's
+
+  for (;;) {
+  const int b = tile / tiles_t, t2_0 = (tile - b * tiles_t) * TT;
+  // ---- this tile's inputs have landed once everything but the previous tile's stores has (issue order); then the
+  // mean subtraction in place
+  if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
+  __syncthreads();  // every wave's pieces have landed (and, first tile, the means are in LDS)
+  if (first) {
+    wload(0, wr[0]);
+    wload(1, wr[1]);
+    first = false;
+  }
+  {
+    const float* const s_mean = s_means + kt * MELMAX;
+    for (int i = tid; i < INR * n_mels; i += 256) s_in[i] -= s_mean[i % n_mels];
+  }
+  ++kt;
   __syncthreads();
   // ---- conv1's position operands: fragment pf covers map positions 16 pf .. 16 pf + 15 (p = t1l * F1 + f1); lane
   // (lr, lg) holds k = 8 lg .. 8 lg + 7 of position 16 pf + lr in the split layout of the header:
   //   k: 0-8 xh[tap] | 9-17 xl[tap] | 18-26 xh[tap] | 27, 28: 1 | 29-31: 0
-  const int npos = T1R * F1;
   for (int pf = wave; pf < NPF; pf += 4) {
     int p = pf * 16 + lr;
     p = p < npos ? p : npos - 1;
@@ -155,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) x[i * 3 + j] = s_in[(2 * t1l + i) * MELMAX + 2 * f1 + j];
+      for (int j = 0; j < 3; ++j) x[i * 3 + j] = s_in[(2 * t1l + i) * n_mels + 2 * f1 + j];
     bf16 h[9], l[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -201,7 +273,6 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
 
   // ---- conv2: byte offset of this lane's column of position fragment i inside a patch, at tap (0, 0): position
   // (2 t2l, 2 f2), channels 8 lg ..; positions past the tile repeat the last one (computed, never stored)
-  const int M = TT * F2;
   int pb[MF];
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
@@ -255,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
         for (int j = 0; j < 4; ++j)
           acc[j][i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][j], bfr[g & 1][i], acc[j][i0 + i], 0, 0, 0);
     }
-    load_w1(cc + 2 < NCHUNK ? cc + 2 : NCHUNK - 1);  // conv1 weights of the chunk produced during the next trip
+    load_w1(cc + 2 < NCHUNK ? cc + 2 : 0);  // conv1 weights of the chunk produced during the next trip (wraps: the next tile's chunk 0)
     stamp();
     __syncthreads();
     stamp();
@@ -263,29 +334,40 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     read_group(smem + PATCH_OFF + nbuf * PATCH_BYTES, 0, bfr[0]);
     xv[0] = conv1_read(0);
   }
-  // ---- epilogue: + bias, ReLU, bf16; lane = 4 consecutive channels n = 64 w + 16 j + 4 lg + r of position 16 i + lr
+  // ---- epilogue: + bias, ReLU, bf16; lane = 4 consecutive channels n = 64 w + 16 j + 4 lg + r of position 16 i + lr.
+  // The next tile's inputs go out first (see the top of the loop); exactly N_STORES stores follow them.
   const size_t out_bytes = (size_t)a.B * a.T2 * F2 * D * 2;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(unsigned)out_bytes, 0x00020000);
   float4 bias[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias[j] = *(const float4*)(a.b2 + wave * 64 + j * 16 + lg * 4);
+  for (int j = 0; j < 4; ++j) bias[j] = *(const float4*)(s_bias + wave * 64 + j * 16 + lg * 4);
+  // (from LDS: a global load here would be counted by hipcc in front of the stores, but the requests below are asm it
+  // does not see - its vmcnt(n) for the bias would in fact wait for the next tile's inputs)
+  const int next = tile + gridDim.x;
+  request_inputs(next < ntiles ? next : tile);
+  // position m = t2l * F2 + f2 of the tile IS its row offset in the output, so a lane's byte offsets are linear in the
+  // fragment index (one VGPR + constants; per-fragment quotients would be hoisted out of the tile loop and spilled:
+  // a scratch reload in front of every group of stores, each one a wait for all the stores before it)
+  int mlim = (a.T2 - t2_0) * F2;
+  mlim = mlim < M ? mlim : M;
+  const unsigned base0 = (unsigned)(((((size_t)b * a.T2 + t2_0) * F2 + lr) * D + wave * 64 + lg * 4) * 2);
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
-    const int m = i * 16 + lr;
-    const int t2l = m / F2, f2 = m - t2l * F2;
-    const int t2 = t2_0 + t2l;
-    const bool ok = m < M && t2 < a.T2;
-    const size_t pos = ((size_t)b * a.T2 + t2) * F2 + f2;
+    const bool ok = i * 16 + lr < mlim;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bf16x4 pk = {(bf16)fmaxf(acc[j][i][0] + bias[j].x, 0.f), (bf16)fmaxf(acc[j][i][1] + bias[j].y, 0.f),
                          (bf16)fmaxf(acc[j][i][2] + bias[j].z, 0.f), (bf16)fmaxf(acc[j][i][3] + bias[j].w, 0.f)};
-      const unsigned off = ok ? (unsigned)((pos * D + wave * 64 + j * 16 + lg * 4) * 2) : 0xffffffffu;
+      const unsigned off = ok ? base0 + (unsigned)(i * 16 * D * 2 + j * 32) : 0xffffffffu;
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, off, 0, 0);
     }
   }
   stamp();
+  if (next >= ntiles) break;
+  tile = next;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last tile requested inputs once more: nothing may land in a freed LDS)
 }
 
 }  // namespace
@@ -299,6 +381,7 @@ extern "C" int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial
   if (T_f < 7) return EM_ERR_TOO_SHORT;
   const int T1 = (T_f - 3) / 2 + 1, F1 = (n_mels - 3) / 2 + 1;
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+  if (n_mels % 4 != 0) return EM_ERR_UNSUPPORTED;  // 16-byte LDS-DMA pieces of whole rows
   if (d != D || n_mels < 7 || n_mels > MELMAX || F1 > F1MAX || F2 > F2MAX || TT * F2 > 16 * MF) return EM_ERR_UNSUPPORTED;
   if ((size_t)B * T2 * F2 * D * 2 >= ((size_t)1 << 32) - 64) return EM_ERR_UNSUPPORTED;  // one buffer resource
   static EmLdsCap cap = {};
@@ -313,7 +396,19 @@ extern "C" int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial
   if (want_stamps && hipMemsetAsync(stamps, 0, 32 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   a.stamps = want_stamps ? stamps : nullptr;
   const bool rec = em_prof_begin(stream);
-  hipLaunchKernelGGL(sub2_kernel, dim3(em_cdiv(T2, TT), B), dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+  static int ncu_of[64];  // compute units per device (asked once: no runtime call on later launches, legal under stream capture)
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (ncu_of[dev] == 0) {
+      hipDeviceProp_t prop;
+      ncu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    ncu = ncu_of[dev];
+  }
+  const int ntiles = em_cdiv(T2, TT) * B;
+  int grid = ntiles < ncu ? ntiles : ncu;
+  if (em_cdiv(ntiles, grid) > MAXK) grid = em_cdiv(ntiles, MAXK);  // (very large batches: more than one workgroup per CU in sequence)
+  hipLaunchKernelGGL(sub2_kernel, dim3(grid), dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
   if (want_stamps) {
     long long h[32];
     if (hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
