@@ -51,14 +51,14 @@ constexpr int PSTRIDE = 2 * CC + 16;          // bytes per patch position: 64 of
 constexpr int PATCH_BYTES = NPF * 16 * PSTRIDE;  // 55 040 (whole fragments: the padded positions are written too)
 constexpr int XIN_OFF = 0;                       // [NPF][64 lanes][16 B]: the conv1 position operands
 constexpr int PATCH_OFF = NPF * 1024;
-constexpr int IN_OFF = PATCH_OFF + PATCH_BYTES;  // f32 [INR][n_mels] (contiguous rows: filled by LDS-DMA), aliasing patch 1 (dead before chunk 1 is produced)
+constexpr int IN_OFF = PATCH_OFF;  // f32 [INR][n_mels] (contiguous rows: filled by LDS-DMA), aliasing patch 0: free during a tile's LAST chunk (which reads patch 1 and produces nothing)
 constexpr int MAXK = 16;                              // tiles per persistent workgroup at most (the host sizes the grid)
 constexpr int MEAN_OFF = PATCH_OFF + 2 * PATCH_BYTES;  // f32 [MAXK][MELMAX]: per-bin means of the utterances of this workgroup's tiles
 constexpr int BIAS_OFF = MEAN_OFF + MAXK * MELMAX * 4;  // f32 [D]: conv2's bias (read in the epilogue without touching vmcnt)
 constexpr int SMEM_BYTES = BIAS_OFF + D * 4;
 static_assert(INR * MELMAX * 4 + 1024 <= PATCH_BYTES && SMEM_BYTES <= 160 * 1024, "LDS");
-constexpr int N_STORES = MF * 4;  // buffer stores of a wave's epilogue (the wait that lets the next tile's inputs pass them counts on it)
-static_assert(N_STORES <= 63, "vmcnt");
+static_assert(NCHUNK % 2 == 0, "the last chunk must read patch 1");
+template <bool V> struct Flag { static constexpr bool value = V; };
 constexpr int PF_PER_WAVE = (NPF + 3) / 4;  // 11
 static_assert(PF_PER_WAVE <= 18, "a conv1 fragment per group of a chunk at most");
 
@@ -98,6 +98,14 @@ struct Sub2Args {
   long long* stamps;      // developer timing (EM_SUB2_STAMPS): cycle stamps of workgroup (3, 5), wave 0
 };
 
+// conv2's MFMA with the accumulator pinned to the AGPR half of the register file.  Through the builtin hipcc kept a
+// third of the 160 accumulator registers in VGPRs and copied them in and out around the MFMAs (four v_accvgpr_write
+// plus hazard nops per MFMA, as much issue time as the MFMA itself: a chunk took 9 000 cycles for 5 800 of MFMA).
+// Nothing reads an accumulator within hundreds of cycles of its last MFMA here (a barrier and an LDS wait lie
+// before the epilogue), so the hazard nops hipcc cannot insert for asm are not needed.
+__device__ __forceinline__ void mfma_acc(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ bf16 hi_of(float x) { return (bf16)x; }
 __device__ __forceinline__ bf16 lo_of(float x) { return (bf16)(x - (float)(bf16)x); }
 
@@ -108,14 +116,13 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const int n_mels = a.n_mels, F1 = a.F1, F2 = a.F2;
-  // Persistent workgroups (one per CU): workgroup g walks the tiles g, g + gridDim.x, ...  The NEXT tile's inputs are
-  // requested right after the last MFMA of a tile, BEFORE its output stores - the 35 feature rows by LDS-DMA into the
-  // patch that has just gone dead, the MVN partial sums into a register - and memory operations complete in issue
-  // order: the next tile waits for "all but the 40 stores", builds its operands (no memory access) and computes its
-  // first conv1 chunk while the stores drain.  With one workgroup per tile (round 3's first version, EM_SUB2_STAMPS)
-  // every tile paid 13 K cycles of input latency + operand building before its first conv2 MFMA and 10 K cycles for
-  // its stores at the end - all 256 CUs store their 80 KiB at the same moment, four times per launch - of 100 K.
-  // (Prefetching the rows into registers instead spilled: the kernel lives at 254 VGPRs.)
+  // Persistent workgroups (one per CU): workgroup g walks the tiles g, g + gridDim.x, ...  With one workgroup per
+  // tile (round 3's first version, EM_SUB2_STAMPS) every tile paid 13 K cycles of input latency + operand building
+  // before its first conv2 MFMA and 10 K cycles to get its stores accepted at the end - all 256 CUs store their 80 KiB
+  // at the same moment, four times per launch - of 100 K.  Here the NEXT tile's 35 feature rows are requested by
+  // LDS-DMA at the start of a tile's last chunk (into patch 0, which that chunk neither reads nor produces), and its
+  // conv1 operands are built BETWEEN the output stores of the epilogue: LDS and VALU work that needs no memory, done
+  // while the stores wait for the fabric.  (Prefetching the rows into registers spilled: the kernel lives at 255 VGPRs.)
   const int tiles_t = (a.T2 + TT - 1) / TT, ntiles = tiles_t * a.B;
   int tile = blockIdx.x;
   int nts = 0;
@@ -195,39 +202,23 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   }
   const int npos = T1R * F1;
   const int M = TT * F2;
-  bool first = true;
-  int kt = 0;  // index of the tile among this workgroup's
-
-  for (;;) {
-  const int b = tile / tiles_t, t2_0 = (tile - b * tiles_t) * TT;
-  // ---- this tile's inputs have landed once everything but the previous tile's stores has (issue order); then the
-  // mean subtraction in place
-  if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
-  __syncthreads();  // every wave's pieces have landed (and, first tile, the means are in LDS)
-  if (first) {
-    wload(0, wr[0]);
-    wload(1, wr[1]);
-    first = false;
-  }
-  {
-    const float* const s_mean = s_means + kt * MELMAX;
-    for (int i = tid; i < INR * n_mels; i += 256) s_in[i] -= s_mean[i % n_mels];
-  }
-  ++kt;
-  __syncthreads();
   // ---- conv1's position operands: fragment pf covers map positions 16 pf .. 16 pf + 15 (p = t1l * F1 + f1); lane
   // (lr, lg) holds k = 8 lg .. 8 lg + 7 of position 16 pf + lr in the split layout of the header:
   //   k: 0-8 xh[tap] | 9-17 xl[tap] | 18-26 xh[tap] | 27, 28: 1 | 29-31: 0
-  for (int pf = wave; pf < NPF; pf += 4) {
+  // MVN: the utterance's per-bin mean comes off in f32 first.
+  const int f1_inv = (65536 + F1 - 1) / F1;
+  auto build_xin = [&](int pf, const float* s_mean) {
     int p = pf * 16 + lr;
     p = p < npos ? p : npos - 1;
-    const int t1l = p / F1, f1 = p - t1l * F1;
+    const int t1l = (p * f1_inv) >> 16, f1 = p - t1l * F1;  // (exact: p < 688, F1 <= 40)
+    float mu[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) mu[j] = s_mean[2 * f1 + j];
     float x[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) x[i * 3 + j] = s_in[(2 * t1l + i) * n_mels + 2 * f1 + j];
+      for (int j = 0; j < 3; ++j) x[i * 3 + j] = s_in[(2 * t1l + i) * n_mels + 2 * f1 + j] - mu[j];
     bf16 h[9], l[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -241,17 +232,15 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     else if (lg == 2) v = (bf16x8){l[7], l[8], h[0], h[1], h[2], h[3], h[4], h[5]};
     else v = (bf16x8){h[6], h[7], h[8], one, one, zero, zero, zero};
     *(bf16x8*)(smem + XIN_OFF + pf * 1024 + lane * 16) = v;
-  }
-  __syncthreads();  // (s_in is dead from here on: patch 1 may be written)
-  stamp();
-
+  };
   // ---- conv1 of a chunk for this wave's j-th position fragment (pf = wave + 4 j), both 16-channel fragments of the
   // chunk: 2 MFMAs; the lane gets channels 4 lg .. 4 lg + 3 (+ 16 for the second fragment) of position 16 pf + lr
-  bf16x8 w1[2];
-  auto load_w1 = [&](int cc) {
+  bf16x8 w1[2], w1b[2];
+  auto load_w1_into = [&](int cc, bf16x8 (&w)[2]) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f) w1[f] = *(GFRAG)((const unsigned char*)a.w1f + (size_t)(cc * 2 + f) * 1024 + lane * 16);
+    for (int f = 0; f < 2; ++f) w[f] = *(GFRAG)((const unsigned char*)a.w1f + (size_t)(cc * 2 + f) * 1024 + lane * 16);
   };
+  auto load_w1 = [&](int cc) { load_w1_into(cc, w1); };
   auto conv1_pf = [&](int j) {
     const int pf = wave + 4 * j;
     return pf < NPF ? pf : NPF - 1;  // (the last waves redo a fragment: same bytes, no branch)
@@ -266,12 +255,27 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
       *(bf16x4*)(dst + f * 32) = pk;
     }
   };
+  // "use" of everything requested ahead for the next tile - conv1 weights of chunks 0 and 1, conv2 weights of taps 0 and
+  // 1: after it hipcc has nothing to wait for at the top of the tile loop, where a wait would be for the forty stores
+  // of the tile before (memory operations complete in issue order)
+  auto settle = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(w1[0]), "+v"(w1[1]), "+v"(w1b[0]), "+v"(w1b[1]));
+    asm volatile("" : "+v"(wr[0][0]), "+v"(wr[0][1]), "+v"(wr[0][2]), "+v"(wr[0][3]), "+v"(wr[1][0]), "+v"(wr[1][1]),
+                 "+v"(wr[1][2]), "+v"(wr[1][3]));
+  };
+  // ---- the first tile: rows landed, operands built
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // every wave's pieces have landed; the means and the bias are in LDS
+  wload(0, wr[0]);
+  wload(1, wr[1]);
   load_w1(0);
-#pragma unroll
-  for (int j = 0; j < PF_PER_WAVE; ++j) conv1_frag(0, j, conv1_read(j));
-  load_w1(1);
-
-  // ---- conv2: byte offset of this lane's column of position fragment i inside a patch, at tap (0, 0): position
+  load_w1_into(1, w1b);
+#pragma unroll 1
+  for (int j = 0; j < PF_PER_WAVE; ++j) build_xin(conv1_pf(j), s_means);
+  settle();
+  int kt = 0;  // index of the tile among this workgroup's
+  // conv2: byte offset of this lane's column of position fragment i inside a patch, at tap (0, 0): position
   // (2 t2l, 2 f2), channels 8 lg ..; positions past the tile repeat the last one (computed, never stored)
   int pb[MF];
 #pragma unroll
@@ -281,6 +285,20 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     const int t2l = m / F2, f2 = m - t2l * F2;
     pb[i] = ((2 * t2l) * F1 + 2 * f2) * PSTRIDE + lg * 16;
   }
+  const size_t out_bytes = (size_t)a.B * a.T2 * F2 * D * 2;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(unsigned)out_bytes, 0x00020000);
+
+  for (;;) {
+  const int b = tile / tiles_t, t2_0 = (tile - b * tiles_t) * TT;
+  const int next = tile + gridDim.x;
+  __syncthreads();  // the operands are complete (and the rows they were built from dead: patch 0 may be written)
+  stamp();
+#pragma unroll 1  // (rolled: unrolled, the eleven patch addresses are tile invariants - hoisted, then spilled)
+  for (int j = 0; j < PF_PER_WAVE; ++j) conv1_frag(0, j, conv1_read(j));
+  // chunk 1's conv1 weights were requested BEFORE the previous tile's stores (memory operations complete in issue
+  // order: a load issued here would be a wait for all forty of them)
+#pragma unroll
+  for (int f = 0; f < 2; ++f) w1[f] = w1b[f];
   f32x4 acc[4][MF];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -306,51 +324,69 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   read_group(smem + PATCH_OFF, 0, bfr[0]);
   bf16x8 xv[2];
   xv[0] = conv1_read(0);
-#pragma unroll 1
-  for (int cc = 0; cc < NCHUNK; ++cc) {
-    const unsigned char* const patch = smem + PATCH_OFF + (cc & 1) * PATCH_BYTES;
+  // a chunk: 9 taps x 2 groups; all but the last also produce the next chunk's patch, a conv1 fragment per group
+  auto chunk = [&](int cc, auto last) {
+    constexpr bool LAST = decltype(last)::value;
+    const unsigned char* const patch = smem + PATCH_OFF + (LAST ? 1 : (cc & 1)) * PATCH_BYTES;
     const int nbuf = (cc + 1) & 1;
 #pragma unroll
     for (int g = 0; g < 18; ++g) {
       const int tap = g >> 1, i0 = (g & 1) * GF;
-      if (!(g & 1)) wload(cc * 9 + tap + 2, wr[(tap + 2) % 3]);
+      if (!(g & 1)) wload(cc * 9 + tap + 2, wr[(tap + 2) % 3]);  // (past the end the walk wraps: the next tile's first taps)
       if (g < 17) read_group(patch, g + 1, bfr[(g + 1) & 1]);
-      if (g + 1 < PF_PER_WAVE) xv[(g + 1) & 1] = conv1_read(g + 1);  // (its position operand too: one group ahead)
+      if (!LAST && g + 1 < PF_PER_WAVE) xv[(g + 1) & 1] = conv1_read(g + 1);  // (its position operand too: one group ahead)
       __builtin_amdgcn_sched_barrier(0);  // (left alone hipcc sinks these reads next to their uses, one fragment ahead)
-      // a fragment of the NEXT chunk's conv1 (after the last chunk: a harmless repeat into the free buffer), in
-      // program order next to this group's MFMAs
-      if (g < PF_PER_WAVE) conv1_frag(nbuf, g, xv[g & 1]);
+      // a fragment of the NEXT chunk's conv1, in program order next to this group's MFMAs
+      if (!LAST && g < PF_PER_WAVE) conv1_frag(nbuf, g, xv[g & 1]);
 #pragma unroll
       for (int i = 0; i < GF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[j][i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[tap % 3][j], bfr[g & 1][i], acc[j][i0 + i], 0, 0, 0);
+          mfma_acc(acc[j][i0 + i], wr[tap % 3][j], bfr[g & 1][i]);
     }
-    load_w1(cc + 2 < NCHUNK ? cc + 2 : 0);  // conv1 weights of the chunk produced during the next trip (wraps: the next tile's chunk 0)
+  };
+#pragma unroll 1
+  for (int cc = 0; cc < NCHUNK - 1; ++cc) {
+    chunk(cc, Flag<false>{});
+    load_w1(cc + 2 < NCHUNK ? cc + 2 : 0);  // conv1 weights of the chunk produced during the next trip (at the end: the next tile's chunk 0)
     stamp();
     __syncthreads();
     stamp();
     // the next chunk's first group, from the patch that has just been completed
-    read_group(smem + PATCH_OFF + nbuf * PATCH_BYTES, 0, bfr[0]);
+    read_group(smem + PATCH_OFF + ((cc + 1) & 1) * PATCH_BYTES, 0, bfr[0]);
     xv[0] = conv1_read(0);
   }
+  // ---- the last chunk; the next tile's rows are requested first (patch 0 is dead: every wave is past the barrier)
+  request_inputs(next < ntiles ? next : tile);
+  {
+    // (the chunk index through an opaque copy: as a constant, the 36 weight addresses of this chunk are invariants of the
+    // tile loop, which hipcc hoists out of it - and spills: 72 registers the kernel does not have)
+    int cc_last = NCHUNK - 1;
+    asm volatile("" : "+s"(cc_last));
+    chunk(cc_last, Flag<true>{});
+  }
+  stamp();
   // ---- epilogue: + bias, ReLU, bf16; lane = 4 consecutive channels n = 64 w + 16 j + 4 lg + r of position 16 i + lr.
-  // The next tile's inputs go out first (see the top of the loop); exactly N_STORES stores follow them.
-  const size_t out_bytes = (size_t)a.B * a.T2 * F2 * D * 2;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(unsigned)out_bytes, 0x00020000);
   float4 bias[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bias[j] = *(const float4*)(s_bias + wave * 64 + j * 16 + lg * 4);
-  // (from LDS: a global load here would be counted by hipcc in front of the stores, but the requests below are asm it
-  // does not see - its vmcnt(n) for the bias would in fact wait for the next tile's inputs)
-  const int next = tile + gridDim.x;
-  request_inputs(next < ntiles ? next : tile);
+  // (from LDS: a global load here would be counted by hipcc in front of the stores, with the asm requests it does
+  // not see in between)
+  load_w1_into(1, w1b);
+  // this wave's pieces of the next tile's rows (requested a chunk ago)
+  // (... and the conv1 weights of the next tile's chunks 0 and 1: "used" here, so that hipcc has nothing left to wait
+  // for at the top of the tile loop, where its wait would be for the stores below)
+  settle();
+  __syncthreads();                                   // ... and every other wave's
+  stamp();
   // position m = t2l * F2 + f2 of the tile IS its row offset in the output, so a lane's byte offsets are linear in the
   // fragment index (one VGPR + constants; per-fragment quotients would be hoisted out of the tile loop and spilled:
   // a scratch reload in front of every group of stores, each one a wait for all the stores before it)
   int mlim = (a.T2 - t2_0) * F2;
   mlim = mlim < M ? mlim : M;
   const unsigned base0 = (unsigned)(((((size_t)b * a.T2 + t2_0) * F2 + lr) * D + wave * 64 + lg * 4) * 2);
+  ++kt;
+  const float* const s_mean_next = s_means + (next < ntiles ? kt : kt - 1) * MELMAX;
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const bool ok = i * 16 + lr < mlim;
@@ -362,12 +398,19 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, off, 0, 0);
     }
+    // a fragment of the next tile's conv1 operands between the stores (after the last tile: the same tile's again)
+    // (the fragment index through an opaque copy, for the same reason: its quotients and addresses are tile invariants)
+    int pf = conv1_pf(i);
+    asm volatile("" : "+s"(pf));
+    build_xin(pf, s_mean_next);
+    __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll 1
+  for (int j = MF; j < PF_PER_WAVE; ++j) build_xin(conv1_pf(j), s_mean_next);
   stamp();
   if (next >= ntiles) break;
   tile = next;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last tile requested inputs once more: nothing may land in a freed LDS)
 }
 
 }  // namespace
