@@ -162,11 +162,13 @@ def pack_conv1_frags(w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
 
 def pack_conv2_frags(w2: torch.Tensor) -> torch.Tensor:
     """conv.2 weight as [256][9 * 256] with column (kt*3 + kf) * 256 + c_in -> fragment-major
-    [chunk cc][tap][wave w][fragment j][lg][lr][e] = w2[64 w + 16 j + lr][tap * 256 + 32 cc + 8 lg + e]."""
+    [chunk cc][tap][wave w][fragment j][lg][lr][e] = w2[64 w + 16 (lr // 4) + 4 j + lr % 4][tap * 256 + 32 cc + 8 lg + e]:
+    MFMA row lr of a wave's fragment j is an output channel chosen so that a lane's 16 results of a position
+    (4 fragments x 4 rows) are 16 CONSECUTIVE channels - two 16-byte stores instead of four 8-byte ones."""
     n, k = w2.shape
     assert n == 256 and k == 9 * 256, (n, k)
-    u = w2.detach().reshape(4, 4, 16, 9, 8, 4, 8)  # [w][j][lr][tap][cc][lg][e]
-    return u.permute(4, 3, 0, 1, 5, 2, 6).contiguous().reshape(-1)
+    u = w2.detach().reshape(4, 4, 4, 4, 9, 8, 4, 8)  # [w][q = lr // 4][j][r = lr % 4][tap][cc][lg][e]
+    return u.permute(5, 4, 0, 2, 6, 1, 3, 7).contiguous().reshape(-1)
 
 
 def rel_pos_table(T: int, d: int) -> torch.Tensor:

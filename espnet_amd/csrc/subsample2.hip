@@ -60,7 +60,7 @@ static_assert(INR * MELMAX * 4 + 1024 <= PATCH_BYTES && SMEM_BYTES <= 160 * 1024
 static_assert(NCHUNK % 2 == 0, "the last chunk must read patch 1");
 template <bool V> struct Flag { static constexpr bool value = V; };
 constexpr int PF_PER_WAVE = (NPF + 3) / 4;  // 11
-static_assert(PF_PER_WAVE <= 18, "a conv1 fragment per group of a chunk at most");
+static_assert(PF_PER_WAVE <= 17, "a conv1 fragment per group of a chunk at most, finished in the group after");
 
 typedef const __attribute__((address_space(1))) bf16x8* GFRAG;
 
@@ -134,14 +134,19 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   // weight fragments of conv2: tap g = cc * 9 + tap of the whole K walk, four 1 KiB lines per wave and tap, requested
   // two taps (1 280 cycles of MFMA) ahead through a ring of three sets - 9 taps per chunk, so the slot g % 3 = tap % 3
   // is a compile-time index.  Unconditional: past the end the walk wraps around (the next tile's first taps).
-  const unsigned char* const wbase = (const unsigned char*)a.w2f + wave * 4096 + lane * 16;
+  // (through a buffer resource: the tap's offset is a scalar register, the fragment's an immediate - no per-load 64-bit
+  // vector address arithmetic in a loop whose issue slots are what it runs out of, see below)
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w2f), 0, NCHUNK * 9 * 16384, 0x00020000);
+  const unsigned wvoff = (unsigned)(wave * 4096 + lane * 16);
   constexpr int NTAP = NCHUNK * 9;
   static_assert(NTAP % 3 == 0, "the ring slot of a tap must not depend on the tile");
   bf16x8 wr[3][4];
   auto wload = [&](int g, bf16x8 (&w)[4]) {
-    const unsigned char* p = wbase + (size_t)(g < NTAP ? g : g - NTAP) * 16384;
+    const unsigned so = (unsigned)(g < NTAP ? g : g - NTAP) * 16384u;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = *(GFRAG)(p + j * 1024);
+    for (int j = 0; j < 4; ++j)
+      w[j] = __builtin_bit_cast(bf16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + j * 1024, so, 0));
   };
   // ---- a tile's inputs.  Rows past the utterance's end repeat the last row (they only reach output rows past T2,
   // which are never stored).  The rows are contiguous in memory and in LDS: 1 KiB per wave-instruction.
@@ -246,6 +251,15 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     return pf < NPF ? pf : NPF - 1;  // (the last waves redo a fragment: same bytes, no branch)
   };
   auto conv1_read = [&](int j) { return *(const bf16x8*)(smem + XIN_OFF + conv1_pf(j) * 1024 + lane * 16); };
+  // Inside the chunk loop conv1 is split over two groups: the two MFMAs of a fragment are issued in one group (asm,
+  // results in VGPRs), their ReLU / bf16 / LDS write in the NEXT one - with one wave per SIMD an MFMA hides three other
+  // instructions at most, and waiting for a just-issued MFMA's result stalls the twenty behind it.  (No hazard nops
+  // needed: 20 MFMAs lie between the write and the read.)
+  auto relu = [](float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));  // (fmaxf costs a canonicalising second v_max)
+    return y;
+  };
   auto conv1_frag = [&](int buf, int j, const bf16x8& xv) {
     unsigned char* const dst = smem + PATCH_OFF + buf * PATCH_BYTES + (conv1_pf(j) * 16 + lr) * PSTRIDE + lg * 8;
 #pragma unroll
@@ -325,24 +339,55 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   bf16x8 xv[2];
   xv[0] = conv1_read(0);
   // a chunk: 9 taps x 2 groups; all but the last also produce the next chunk's patch, a conv1 fragment per group
+  // With one wave per SIMD nothing else issues while this wave waits, and an MFMA (16 cycles of the matrix core) hides
+  // three other instructions at most - so everything that is not a conv2 MFMA is dealt out BETWEEN them, one small piece
+  // per MFMA, in exactly this order (sched_barrier after every slot; left to hipcc the pieces end up in one block
+  // between the groups, ~120 cycles per group during which the matrix core has nothing to do):
+  //   slots 0-4    the next group's position fragments (LDS)          slots 10-13  the previous conv1 fragment: ReLU, bf16
+  //   slot  5      the next conv1 fragment's position operand (LDS)   slot  14     ... its LDS write
+  //   slots 6-9    the weights two taps ahead (even groups)           slots 16-17  this group's two conv1 MFMAs
   auto chunk = [&](int cc, auto last) {
     constexpr bool LAST = decltype(last)::value;
     const unsigned char* const patch = smem + PATCH_OFF + (LAST ? 1 : (cc & 1)) * PATCH_BYTES;
     const int nbuf = (cc + 1) & 1;
+    f32x4 c1[2];
+    unsigned pk1[2][2];
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #pragma unroll
     for (int g = 0; g < 18; ++g) {
       const int tap = g >> 1, i0 = (g & 1) * GF;
-      if (!(g & 1)) wload(cc * 9 + tap + 2, wr[(tap + 2) % 3]);  // (past the end the walk wraps: the next tile's first taps)
-      if (g < 17) read_group(patch, g + 1, bfr[(g + 1) & 1]);
-      if (!LAST && g + 1 < PF_PER_WAVE) xv[(g + 1) & 1] = conv1_read(g + 1);  // (its position operand too: one group ahead)
-      __builtin_amdgcn_sched_barrier(0);  // (left alone hipcc sinks these reads next to their uses, one fragment ahead)
-      // a fragment of the NEXT chunk's conv1, in program order next to this group's MFMAs
-      if (!LAST && g < PF_PER_WAVE) conv1_frag(nbuf, g, xv[g & 1]);
+      const bool fin = !LAST && g >= 1 && g - 1 < PF_PER_WAVE;  // a conv1 fragment issued in the previous group
+      const bool iss = !LAST && g < PF_PER_WAVE;
 #pragma unroll
-      for (int i = 0; i < GF; ++i)
+      for (int k = 0; k < 4 * GF; ++k) {
+        const int i = k >> 2, j = k & 3;
+        mfma_acc(acc[j][i0 + i], wr[tap % 3][j], bfr[g & 1][i]);
+        if (k < GF && g < 17) {
+          const int g1 = g + 1, tap1 = g1 >> 1;
+          bfr[g1 & 1][k] = *(const bf16x8*)(patch + pb[(g1 & 1) * GF + k] + ((tap1 / 3) * F1 + tap1 % 3) * PSTRIDE);
+        }
+        if (k == 5 && !LAST && g + 1 < PF_PER_WAVE) xv[(g + 1) & 1] = conv1_read(g + 1);
+        if (k >= 6 && k < 10 && !(g & 1)) {
+          const int gt = cc * 9 + tap + 2;  // (past the end the walk wraps: the next tile's first taps)
+          const unsigned so = (unsigned)(gt < NTAP ? gt : gt - NTAP) * 16384u;
+          wr[(tap + 2) % 3][k - 6] = __builtin_bit_cast(bf16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + (k - 6) * 1024, so, 0));
+        }
+        if (fin && k >= 10 && k < 14) {
+          const int f = (k - 10) >> 1, h = (k - 10) & 1;
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+          const bf16x2 v = {(bf16)relu(c1[f][2 * h]), (bf16)relu(c1[f][2 * h + 1])};
+          pk1[f][h] = __builtin_bit_cast(unsigned, v);
+        }
+        if (fin && k == 14) {
+          unsigned char* const dst = smem + PATCH_OFF + nbuf * PATCH_BYTES + (conv1_pf(g - 1) * 16 + lr) * PSTRIDE + lg * 8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          mfma_acc(acc[j][i0 + i], wr[tap % 3][j], bfr[g & 1][i]);
+          for (int f = 0; f < 2; ++f) *(u32x2*)(dst + f * 32) = (u32x2){pk1[f][0], pk1[f][1]};
+        }
+        if (iss && (k == 16 || k == 17))
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c1[k - 16]) : "v"(w1[k - 16]), "v"(xv[g & 1]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 #pragma unroll 1
@@ -366,10 +411,11 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     chunk(cc_last, Flag<true>{});
   }
   stamp();
-  // ---- epilogue: + bias, ReLU, bf16; lane = 4 consecutive channels n = 64 w + 16 j + 4 lg + r of position 16 i + lr.
+  // ---- epilogue: + bias, ReLU, bf16; lane = 16 consecutive channels n = 64 w + 16 lg + 4 j + r of position 16 i + lr
+  // (the host packs the weights' rows in that order): two 16-byte stores per fragment row.
   float4 bias[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias[j] = *(const float4*)(s_bias + wave * 64 + j * 16 + lg * 4);
+  for (int j = 0; j < 4; ++j) bias[j] = *(const float4*)(s_bias + wave * 64 + lg * 16 + j * 4);
   // (from LDS: a global load here would be counted by hipcc in front of the stores, with the asm requests it does
   // not see in between)
   load_w1_into(1, w1b);
@@ -384,19 +430,26 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   // a scratch reload in front of every group of stores, each one a wait for all the stores before it)
   int mlim = (a.T2 - t2_0) * F2;
   mlim = mlim < M ? mlim : M;
-  const unsigned base0 = (unsigned)(((((size_t)b * a.T2 + t2_0) * F2 + lr) * D + wave * 64 + lg * 4) * 2);
+  const unsigned base0 = (unsigned)(((((size_t)b * a.T2 + t2_0) * F2 + lr) * D + wave * 64 + lg * 16) * 2);
   ++kt;
   const float* const s_mean_next = s_means + (next < ntiles ? kt : kt - 1) * MELMAX;
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const bool ok = i * 16 + lr < mlim;
+    const unsigned off = ok ? base0 + (unsigned)(i * 16 * D * 2) : 0xffffffffu;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16x4 pk = {(bf16)fmaxf(acc[j][i][0] + bias[j].x, 0.f), (bf16)fmaxf(acc[j][i][1] + bias[j].y, 0.f),
-                         (bf16)fmaxf(acc[j][i][2] + bias[j].z, 0.f), (bf16)fmaxf(acc[j][i][3] + bias[j].w, 0.f)};
-      const unsigned off = ok ? base0 + (unsigned)(i * 16 * D * 2 + j * 32) : 0xffffffffu;
-      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, off, 0, 0);
+    for (int h = 0; h < 2; ++h) {  // fragments 2 h, 2 h + 1: channels 8 h .. 8 h + 7 of the lane's sixteen
+      bf16x8 pk;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * h + jj;
+        pk[4 * jj + 0] = (bf16)fmaxf(acc[j][i][0] + bias[j].x, 0.f);
+        pk[4 * jj + 1] = (bf16)fmaxf(acc[j][i][1] + bias[j].y, 0.f);
+        pk[4 * jj + 2] = (bf16)fmaxf(acc[j][i][2] + bias[j].z, 0.f);
+        pk[4 * jj + 3] = (bf16)fmaxf(acc[j][i][3] + bias[j].w, 0.f);
+      }
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rs, ok ? off + h * 16 : 0xffffffffu, 0, 0);
     }
     // a fragment of the next tile's conv1 operands between the stores (after the last tile: the same tile's again)
     // (the fragment index through an opaque copy, for the same reason: its quotients and addresses are tile invariants)

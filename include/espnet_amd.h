@@ -117,7 +117,7 @@ int em_global_mvn_f32(float* feats, const int32_t* flens, const float* mean, con
  *   conv1_wf [8 chunks][2][64][8] bf16: fragment (cc, f), lane (lr, lg), e: channel c = 32 cc + 16 f + lr, k = 8 lg + e:
  *            k 0-8 hi(w1[c][k]) | 9-17 hi(w1[c][k-9]) | 18-26 lo(w1[c][k-18]) | 27 hi(b1[c]) | 28 lo(b1[c]) | 29-31 0
  *            with hi(x) = bf16(x), lo(x) = bf16(x - hi(x)): conv1 runs on the matrix cores at f32-class accuracy
- *   conv2_wf [8 chunks][9 taps][4 waves][4][64][8] bf16: W2[n = 64 w + 16 j + lr][(kt*3+kf)*d + 32 cc + 8 lg + e]
+ *   conv2_wf [8 chunks][9 taps][4 waves][4][64][8] bf16: W2[n = 64 w + 16 (lr / 4) + 4 j + lr % 4][(kt*3+kf)*d + 32 cc + 8 lg + e]
  *   c2       [B][T2][F2][d] bf16 out (channel-last), T2 = ((T_f-1)/2-1)/2, F2 = ((n_mels-1)/2-1)/2
  *   EM_ERR_UNSUPPORTED for d != 256 or n_mels > 82 (the caller then uses em_conv2d_sub1 + em_gemm EM_A_CONV2).   */
 int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial, const int32_t* flens, int32_t B, int32_t T_f,

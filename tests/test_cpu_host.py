@@ -320,4 +320,4 @@ def test_fused_subsampling_operand_packing():
     w2 = torch.randn(d, 9 * d, generator=g)
     u = pack_conv2_frags(w2).reshape(8, 9, 4, 4, 4, 16, 8)  # [cc][tap][w][j][lg][lr][e]
     for (cc, tap, w, j, lg, lr, e) in [(0, 0, 0, 0, 0, 0, 0), (7, 8, 3, 3, 3, 15, 7), (3, 4, 1, 2, 2, 9, 5)]:
-        assert u[cc, tap, w, j, lg, lr, e] == w2[64 * w + 16 * j + lr, tap * 256 + 32 * cc + 8 * lg + e]
+        assert u[cc, tap, w, j, lg, lr, e] == w2[64 * w + 16 * (lr // 4) + 4 * j + lr % 4, tap * 256 + 32 * cc + 8 * lg + e]
