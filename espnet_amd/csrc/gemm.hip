@@ -62,7 +62,7 @@ __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* ld
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int EPI, int AMODE, int BM, int BN>
+template <typename T, int EPI, int AMODE, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
                                                    const T* __restrict__ W, void* __restrict__ Cv,
                                                    const float* __restrict__ bias, int M, int N,
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
   constexpr int W_LD = BN / 32;
   constexpr int NLOADS = A_LD + W_LD;
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, BUF = A_BYTES + W_BYTES;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+  static_assert(NS >= 2 && (NS - 2) * NLOADS <= 63 && NS * BUF >= 4 * (BM / WAVES_M) * 64 * 4, "stages");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // NS stages of BUF bytes (the epilogue's staging after them)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WAVES_N, wc = wave % WAVES_N;
@@ -174,17 +175,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     if (bias) bpre = *(const float4*)(bias + ncol_p);  // with the residual rows: not a round trip of its own in the epilogue
   }
 
+  // K loop over a ring of NS LDS stages, NS - 1 tiles requested ahead, ONE barrier per tile: after it every wave's
+  // pieces of tile kt have landed and every wave is done with tile kt - 1, whose stage is then refilled with tile
+  // kt + NS - 1.  (With two stages - rounds 1 and 2 - a tile's loads had one tile's MFMAs, ~270 cycles, to cross a
+  // memory system whose latency is 900: the embedding GEMM, K = 4 864, spent 1 140 cycles per tile.)  The requests are
+  // unconditional - past the end the last tile is requested again into a dead stage - so the wait is one constant.
   const int nk = K / BK;
-  issue(0, 0);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s < nk ? s : nk - 1, s);
+  int cur = 0, fill = NS - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      issue(kt + 1, cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NLOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+      const int kn = kt + NS - 1;
+      issue(kn < nk ? kn : nk - 1, fill);
     }
-    __builtin_amdgcn_s_barrier();  // tile kt has landed for every wave
     const unsigned char* sa = smem + cur * BUF;
     const unsigned char* sw = sa + A_BYTES;
 #pragma unroll
@@ -202,9 +208,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave is done reading buf[cur]
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    fill = fill + 1 == NS ? 0 : fill + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the surplus requests too: the epilogue reuses the stages)
+  __builtin_amdgcn_s_barrier();
 
   // ---- epilogue.  C/D layout: col = lane & 15, row = (lane >> 4) * 4 + r.
   const int wm0 = m0 + wr * WM, wn0 = n0 + wc * 64;
@@ -413,24 +421,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
   }
 }
 
+template <typename T, int EPI, int AMODE, int BM, int NS>
+int launch_tile(const EmGemmArgs* p, hipStream_t s, const ConvGeom& g) {
+  constexpr int BN = 128;
+  constexpr int lds = NS * (BM + BN) * ROWB;
+  auto* fn = gemm_kernel<T, EPI, AMODE, BM, BN, NS>;
+  static EmLdsCap cap = {};
+  if (lds > 64 * 1024 && em_raise_lds_cap((const void*)fn, lds, &cap) != EM_OK) return EM_ERR_LAUNCH;
+  dim3 grid(8 * em_cdiv(em_cdiv(p->N, BN) * em_cdiv(p->M, BM), 8));
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, (const T*)p->A, (const T*)p->W, p->C, p->bias, p->M, p->N, p->K,
+                     p->lda, p->ldc, p->scale, g);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
 template <typename T, int EPI, int AMODE>
 int launch(const EmGemmArgs* p, hipStream_t s) {
   ConvGeom g{p->T1, p->F1, p->T2, p->F2, p->d, p->conv_k > 0 ? p->conv_k : 3, p->conv_s > 0 ? p->conv_s : 2};
-  constexpr int BN = 128;
-  const int nb = em_cdiv(p->N, BN);
+  const int nb = em_cdiv(p->N, 128);
   // fewer than ~1.5 workgroups per CU at BM=128 -> halve the M tile to fill the 256 CUs
   const bool small = (long)nb * em_cdiv(p->M, 128) < 384;
-  if (small) {
-    dim3 grid(8 * em_cdiv(nb * em_cdiv(p->M, 64), 8));
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE, 64, BN>), grid, dim3(256), 0, s, (const T*)p->A,
-                       (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
-  } else {
-    dim3 grid(8 * em_cdiv(nb * em_cdiv(p->M, 128), 8));
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, AMODE, 128, BN>), grid, dim3(256), 0, s, (const T*)p->A,
-                       (const T*)p->W, p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale, g);
-  }
-  EM_CHECK_LAUNCH();
-  return EM_OK;
+  // Stages of the LDS ring.  A long K walked by at most ~two workgroups per CU has nothing else to hide a tile's memory
+  // latency behind: four stages (96 / 128 KiB of LDS, one workgroup per CU) - the embedding Linear, K = 19 d: 46.0 ->
+  // 40.7 us at d = 256, 82.8 -> 72.3 at d = 512 (profiles/r03t_gemm_bench.txt).  Short K (the d x d and d x 4 d
+  // projections) and larger grids keep two stages and two or three co-resident workgroups per CU, which cover each
+  // other's waits and cost no three-tile prologue: four stages are 25-50 % slower there.  ESPNET_AMD_GEMM_STAGES = 2 | 4:
+  // developer A/B.
+  static const int forced = [] { const char* e = getenv("ESPNET_AMD_GEMM_STAGES"); return e ? atoi(e) : 0; }();
+  const long wgs = (long)nb * em_cdiv(p->M, small ? 64 : 128);
+  const bool deep = forced ? forced >= 4 : wgs <= 2 * 256 && p->K >= 2048;
+  if (small) return deep ? launch_tile<T, EPI, AMODE, 64, 4>(p, s, g) : launch_tile<T, EPI, AMODE, 64, 2>(p, s, g);
+  return deep ? launch_tile<T, EPI, AMODE, 128, 4>(p, s, g) : launch_tile<T, EPI, AMODE, 128, 2>(p, s, g);
 }
 
 template <typename T>

@@ -188,12 +188,16 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   float* const s_means = (float*)(smem + MEAN_OFF);
   float* const s_bias = (float*)(smem + BIAS_OFF);
   s_bias[tid] = a.b2[tid];  // (256 threads = D channels)
-  for (int k = 0, tl = tile; tl < ntiles && k < MAXK; ++k, tl += gridDim.x) {
-    const int bb = tl / tiles_t;
-    if (tid < n_mels) {
+  {
+    // (tile, bin) pairs dealt over all 256 threads: one or two round trips for the usual four tiles per workgroup
+    int kn = (ntiles - tile + (int)gridDim.x - 1) / (int)gridDim.x;
+    kn = kn < MAXK ? kn : MAXK;
+    for (int item = tid; item < kn * n_mels; item += 256) {
+      const int k = item / n_mels, bin = item - k * n_mels;
+      const int bb = (tile + k * (int)gridDim.x) / tiles_t;
       float mean = 0.f;
       if (a.partial) {
-        const float* pp = a.partial + (size_t)bb * 8 * n_mels + tid;
+        const float* pp = a.partial + (size_t)bb * 8 * n_mels + bin;
         float pv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) pv[q] = pp[q * n_mels];
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
         for (int q = 0; q < 8; ++q) sm += pv[q];
         mean = sm / (float)a.flens[bb];
       }
-      s_means[k * MELMAX + tid] = mean;
+      s_means[k * MELMAX + bin] = mean;
     }
   }
   const int npos = T1R * F1;
@@ -216,14 +220,18 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     int p = pf * 16 + lr;
     p = p < npos ? p : npos - 1;
     const int t1l = (p * f1_inv) >> 16, f1 = p - t1l * F1;  // (exact: p < 688, F1 <= 40)
-    float mu[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) mu[j] = s_mean[2 * f1 + j];
+    // (columns 2 f1, 2 f1 + 1 as one 8-byte read - n_mels is a multiple of 4 - and 2 f1 + 2 as a third dword)
+    const float2 mu01 = *(const float2*)(s_mean + 2 * f1);
+    const float mu[3] = {mu01.x, mu01.y, s_mean[2 * f1 + 2]};
     float x[9];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) x[i * 3 + j] = s_in[(2 * t1l + i) * n_mels + 2 * f1 + j] - mu[j];
+    for (int i = 0; i < 3; ++i) {
+      const float* row = s_in + (2 * t1l + i) * n_mels + 2 * f1;
+      const float2 x01 = *(const float2*)row;
+      x[i * 3 + 0] = x01.x - mu[0];
+      x[i * 3 + 1] = x01.y - mu[1];
+      x[i * 3 + 2] = row[2] - mu[2];
+    }
     bf16 h[9], l[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -255,10 +263,15 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   // results in VGPRs), their ReLU / bf16 / LDS write in the NEXT one - with one wave per SIMD an MFMA hides three other
   // instructions at most, and waiting for a just-issued MFMA's result stalls the twenty behind it.  (No hazard nops
   // needed: 20 MFMAs lie between the write and the read.)
-  auto relu = [](float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));  // (fmaxf costs a canonicalising second v_max)
-    return y;
+  // ReLU of two values AFTER the conversion, on the packed pair: as 16-bit integers negative bf16 values (sign bit
+  // set, -0 included) are negative, so max(., 0) is the ReLU - one v_pk_max_i16 for what fmaxf does in four v_max_f32
+  // (each fmaxf brings a canonicalising second one)
+  auto relu_pack = [](float x, float y) {
+    // (asm: from `(bf16)x, (bf16)y` hipcc makes two conversions and a v_perm, and as plain arithmetic the pieces drift out
+    // of the slots they are dealt into below)
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(r) : "v"(x), "v"(y));
+    return r;
   };
   auto conv1_frag = [&](int buf, int j, const bf16x8& xv) {
     unsigned char* const dst = smem + PATCH_OFF + buf * PATCH_BYTES + (conv1_pf(j) * 16 + lr) * PSTRIDE + lg * 8;
@@ -307,8 +320,14 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   const int next = tile + gridDim.x;
   __syncthreads();  // the operands are complete (and the rows they were built from dead: patch 0 may be written)
   stamp();
-#pragma unroll 1  // (rolled: unrolled, the eleven patch addresses are tile invariants - hoisted, then spilled)
-  for (int j = 0; j < PF_PER_WAVE; ++j) conv1_frag(0, j, conv1_read(j));
+  // (rolled: unrolled, the eleven patch addresses are tile invariants - hoisted, then spilled; two fragments per trip so
+  // that one's LDS read -> MFMA -> convert -> LDS write chain runs in the shadow of the other's)
+#pragma unroll 1
+  for (int j = 0; j < PF_PER_WAVE; j += 2) {
+    const bf16x8 x0 = conv1_read(j), x1 = conv1_read(j + 1);  // (j + 1 past the end: conv1_pf clamps, a harmless repeat)
+    conv1_frag(0, j, x0);
+    conv1_frag(0, j + 1, x1);
+  }
   // chunk 1's conv1 weights were requested BEFORE the previous tile's stores (memory operations complete in issue
   // order: a load issued here would be a wait for all forty of them)
 #pragma unroll
@@ -375,9 +394,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
         }
         if (fin && k >= 10 && k < 14) {
           const int f = (k - 10) >> 1, h = (k - 10) & 1;
-          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-          const bf16x2 v = {(bf16)relu(c1[f][2 * h]), (bf16)relu(c1[f][2 * h + 1])};
-          pk1[f][h] = __builtin_bit_cast(unsigned, v);
+          pk1[f][h] = relu_pack(c1[f][2 * h], c1[f][2 * h + 1]);
         }
         if (fin && k == 14) {
           unsigned char* const dst = smem + PATCH_OFF + nbuf * PATCH_BYTES + (conv1_pf(g - 1) * 16 + lr) * PSTRIDE + lg * 8;
@@ -439,17 +456,15 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     const unsigned off = ok ? base0 + (unsigned)(i * 16 * D * 2) : 0xffffffffu;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // fragments 2 h, 2 h + 1: channels 8 h .. 8 h + 7 of the lane's sixteen
-      bf16x8 pk;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      u32x4 pk;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = 2 * h + jj;
-        pk[4 * jj + 0] = (bf16)fmaxf(acc[j][i][0] + bias[j].x, 0.f);
-        pk[4 * jj + 1] = (bf16)fmaxf(acc[j][i][1] + bias[j].y, 0.f);
-        pk[4 * jj + 2] = (bf16)fmaxf(acc[j][i][2] + bias[j].z, 0.f);
-        pk[4 * jj + 3] = (bf16)fmaxf(acc[j][i][3] + bias[j].w, 0.f);
+        pk[2 * jj + 0] = relu_pack(acc[j][i][0] + bias[j].x, acc[j][i][1] + bias[j].y);
+        pk[2 * jj + 1] = relu_pack(acc[j][i][2] + bias[j].z, acc[j][i][3] + bias[j].w);
       }
-      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rs, ok ? off + h * 16 : 0xffffffffu, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(pk, rs, ok ? off + h * 16 : 0xffffffffu, 0, 0);
     }
     // a fragment of the next tile's conv1 operands between the stores (after the last tile: the same tile's again)
     // (the fragment index through an opaque copy, for the same reason: its quotients and addresses are tile invariants)

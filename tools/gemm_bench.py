@@ -23,6 +23,10 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("ffn_w1 large", 3984, 2048, 512, L.EM_EPI_SWISH),
     ("ffn_w2 large", 3984, 512, 2048, L.EM_EPI_RESID_F32),
     ("square 4096", 4096, 4096, 4096, L.EM_EPI_STORE),
+    ("embed small", 7968, 256, 4864, L.EM_EPI_SCALE_F32),
+    ("embed large", 3984, 512, 9728, L.EM_EPI_SCALE_F32),
+    ("qkv large", 3984, 1536, 512, L.EM_EPI_STORE),
+    ("out large", 3984, 512, 512, L.EM_EPI_RESID_F32),
 ]
 
 
