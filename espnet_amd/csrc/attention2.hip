@@ -22,6 +22,9 @@
 // match with two 8-byte LDS loads.)  rel_shift is index arithmetic: the dense window
 // D[c][i] = p[c] . (q_i + v) over the 80 position rows a (16 query, 64 key) tile can reach is written to
 // a per-wave scratch and read back skewed, BD^T[j][i] = D[15 - i + j][i].
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "em_common.h"
 
 namespace {
@@ -59,7 +62,7 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
 __global__ __launch_bounds__(512) void relpos_attn2_kernel(
     const bf16* __restrict__ qh, const bf16* __restrict__ kh, const bf16* __restrict__ vt,
     const bf16* __restrict__ p, int ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v,
-    const int* __restrict__ klens, int T, int Tpad, int H, bf16* __restrict__ ctx) {
+    const int* __restrict__ klens, int T, int Tpad, int H, bf16* __restrict__ ctx, long long* __restrict__ stamps) {
   using MM = Mma<bf16>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -68,6 +71,14 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
   const int hh = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * QB, iw0 = i0 + 16 * wave;
   const int klen = klens[b] < T ? klens[b] : T;
   const size_t bh = (size_t)b * H + hh;
+  // developer timing (EM_ATTN2_STAMPS): cycle stamps of wave 0 of workgroup (0, 1, 3)
+  int nts = 0;
+  auto stamp = [&]() {
+    if (stamps && blockIdx.x == 0 && blockIdx.y == 1 && blockIdx.z == 3 && tid == 0 && nts < 32)
+      stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
+    ++nts;
+  };
+  stamp();
 
   const unsigned char* k_base = uniform_ptr((const unsigned char*)(kh + bh * Tpad * 64));
   const unsigned char* v_base = uniform_ptr((const unsigned char*)(vt + bh * 64 * Tpad));
@@ -139,6 +150,7 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
                  "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
                :
                : "memory");
+  stamp();
   bf16x8 qu[2], qv[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -146,15 +158,22 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float q = (float)raw[e];
-      qu[ks][e] = (bf16)(q + ur[2 * ks + (e >> 2)][e & 3]);
-      qv[ks][e] = (bf16)(q + vr[2 * ks + (e >> 2)][e & 3]);
+      // 1 / sqrt(64) goes into the operands: a power of two, so (AC + BD) / 8 comes out bit for bit the same and the
+      // sixteen multiplications per lane and tile are gone
+      qu[ks][e] = (bf16)((q + ur[2 * ks + (e >> 2)][e & 3]) * 0.125f);
+      qv[ks][e] = (bf16)((q + vr[2 * ks + (e >> 2)][e & 3]) * 0.125f);
     }
   }
 
   f32x4 acc_o[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) acc_o[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float row_m = -INFINITY, row_l = 0.f;
+  float row_m = -INFINITY;
+  // the softmax denominator rides on the matrix core: a fifth "V^T fragment" of ones makes O^T's extra rows the sum of the
+  // (bf16-rounded) probabilities over ALL the keys of a query - no per-element accumulation, no cross-lane reduction
+  f32x4 acc_l = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+  constexpr float LOG2E = 1.4426950408889634f;
   float* const bd = (float*)(smem + SBD_OFF) + wave * 16 * LDB;
 
   for (int js = 0; js < klen; js += KSUP) {
@@ -173,6 +192,7 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
       // is complete only when most of the 112 KiB are: 12.8 -> 12.2 us; tile by tile: see profiles/r03m.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      stamp();
       if (kt + 1 < KSUP / 64 && j0 + 64 < klen) stage_tile(js, kt + 1);
       // ---- S^T (64 keys x 16 queries) and the dense position window D (80 rows x 16 queries)
       f32x4 sc[4], dd[5];
@@ -190,6 +210,8 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
 #pragma unroll
         for (int n = 0; n < 5; ++n) dd[n] = MM::mma(*(const bf16x8*)(sp + n * 2048 + coff), qv[ks], dd[n]);
       }
+      if (stamps) asm volatile("s_nop 0" : "+v"(sc[3]), "+v"(dd[4]));  // (developer timing: the MFMAs have finished)
+      stamp();
       // ---- rel_shift: D[c][i] -> scratch[i][c], read back at c = 15 - i + j
 #pragma unroll
       for (int n = 0; n < 5; ++n)
@@ -199,38 +221,57 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s = (sc[n][r] + bdr[16 * n + r]) * 0.125f;  // 1 / sqrt(64)
-          s = (j0 + 16 * n + 4 * lg + r < klen) ? s : -INFINITY;
-          sc[n][r] = s;
-          tm = fmaxf(tm, s);
-        }
-      // ---- online softmax; this lane's query is iw0 + lr, its keys the 16 (n, r) of lane group lg
-      tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
-      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-      const float mn = fmaxf(row_m, tm);
-      const float alpha = __expf(row_m - mn);
-      row_m = mn;
-      float ps = 0.f;
-      bf16x8 pb[2];
+        for (int r = 0; r < 4; ++r) sc[n][r] += bdr[16 * n + r];
+      if (j0 + 64 > klen) {  // (uniform: only the tile that holds the utterance's end masks anything)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[n][r] = (j0 + 16 * n + 4 * lg + r < klen) ? sc[n][r] : -INFINITY;
+      }
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bf16 pr = (bf16)__expf(sc[n][r] - mn);  // masked: exp(-inf) = 0
-          ps += (float)pr;
-          pb[n >> 1][(n & 1) * 4 + r] = pr;
+        for (int r = 0; r < 4; ++r) tm = fmaxf(tm, sc[n][r]);
+      // ---- online softmax; this lane's query is iw0 + lr, its keys the 16 (n, r) of lane group lg
+      if (stamps) asm volatile("s_nop 0" : "+v"(tm));
+      stamp();
+      tm = wave_xor16_max(tm);  // the four lane groups of a query: two register swaps (gfx950), no LDS round trip
+      tm = wave_xor32_max(tm);
+      const float mn = fmaxf(row_m, tm);
+      const float alpha = __expf(row_m - mn);
+      row_m = mn;
+      const float mnl = mn * LOG2E;
+      unsigned pbu[2][4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 (masked: 2^-inf = 0); two values per conversion
+          const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[n][2 * h], LOG2E, -mnl));
+          const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[n][2 * h + 1], LOG2E, -mnl));
+          // (as a vector conversion: one v_cvt_pk_bf16_f32, and hipcc places the wait state a v_exp_f32 result needs
+          // before a VALU read - from inline asm it does not, and the conversion read stale registers)
+          typedef __attribute__((ext_vector_type(2))) float f32x2;
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+          pbu[n >> 1][(n & 1) * 2 + h] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
         }
-      ps += __shfl_xor(ps, 16, 64);
-      ps += __shfl_xor(ps, 32, 64);
-      row_l = row_l * alpha + ps;
+      bf16x8 pb[2];
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        pb[jp] = __builtin_bit_cast(bf16x8, (u32x4){pbu[jp][0], pbu[jp][1], pbu[jp][2], pbu[jp][3]});
+      }
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         acc_o[f][0] *= alpha; acc_o[f][1] *= alpha; acc_o[f][2] *= alpha; acc_o[f][3] *= alpha;
       }
+      acc_l[0] *= alpha;  // (the other three rows of the ones fragment carry the same sum; only this one is read)
+      if (stamps) asm volatile("s_nop 0" : "+v"(acc_o[3]));
+      stamp();
       // ---- O^T += V^T . P^T   (V^T tile kt: [64 dk][128 B], chunk c holds keys 8 c .. 8 c + 7 of the tile)
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
+        acc_l = MM::mma(ones, pb[jp], acc_l);
         const int c0 = 4 * jp + (lg >> 1);
         const int sw = (lr >> 1) & 7;
 #pragma unroll
@@ -246,10 +287,13 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
   }
   // (a workgroup that stopped early - klen short of the staged keys - still has requests in flight into ITS LDS)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stamps) asm volatile("s_nop 0" : "+v"(acc_o[3]));
+  stamp();
 
   // ---- normalise and store ctx[b*T + i][hh*64 + 16 f + 4 lg + r]
   const int i = iw0 + lr;
   if (i < T) {
+    const float row_l = acc_l[0];
     const float inv = row_l > 0.f ? 1.0f / row_l : 0.f;
     bf16* o = ctx + ((size_t)b * T + i) * (H * 64) + hh * 64 + 4 * lg;
 #pragma unroll
@@ -273,10 +317,23 @@ extern "C" int em_relpos_attention2_bf16(const void* qh, const void* kh, const v
   static EmLdsCap cap = {};
   if (em_raise_lds_cap((const void*)relpos_attn2_kernel, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(T, QB), h, B);
+  static long long* stamps = nullptr;
+  static const bool want_stamps = getenv("EM_ATTN2_STAMPS") != nullptr;
+  if (want_stamps && !stamps && hipMalloc((void**)&stamps, 32 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
+  if (want_stamps && hipMemsetAsync(stamps, 0, 32 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
   hipLaunchKernelGGL(relpos_attn2_kernel, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
                      (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h,
-                     (bf16*)ctx);
+                     (bf16*)ctx, want_stamps ? stamps : nullptr);
+  if (want_stamps) {
+    long long hs[32];
+    if (hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess) {
+      printf("[attn2 stamps, cycles since entry]");
+      for (int i = 1; i < 32 && hs[i]; ++i) printf(" %lld", hs[i] - hs[0]);
+      printf("\n");
+      fflush(stdout);
+    }
+  }
   if (rec) em_prof_end(stream, 6.0 * B * h * (double)T * T * 64, EM_PROF_ATTN);
   EM_CHECK_LAUNCH();
   return EM_OK;

@@ -100,6 +100,18 @@ constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIR
 constexpr int DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;
 // all-lanes maximum / minimum of a wave: four DPP steps inside the 16-lane rows, then the four row results through
 // scalar registers.  Every lane returns the same value.
+// max over the lanes l, l ^ 16 (resp. l ^ 32) through gfx950's register swaps: v_permlane16_swap exchanges the odd 16-lane
+// rows of one operand with the even rows of the other, v_permlane32_swap the upper half of one with the lower half of the
+// other - with both operands = x, every lane ends up holding its own value in one result and its partner's in the other.
+// One VALU instruction instead of a ds_bpermute round trip through the LDS crossbar.
+__device__ __forceinline__ float wave_xor16_max(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float wave_xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 __device__ __forceinline__ float wave_allmax_dpp(float v) {
   v = fmaxf(v, dpp_f32<DPP_XOR1>(v));
   v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
