@@ -16,6 +16,8 @@
 //   * source-attention K / V^T of the memory are computed once per utterance (em_search_init) and
 //     shared by the W hypotheses of that utterance (one workgroup per (utterance, head): MFMA
 //     QK^T and PV over a 16-row query tile).
+#include <stdlib.h>
+
 #include "em_common.h"
 
 namespace {
@@ -114,7 +116,16 @@ template <> struct Raw8<float> {
 // running (max, sum, context) over the positions j = jsub (mod NJ) - no LDS, no barrier - and the NJ partial states are
 // merged once at the end.  The dot product's cross-lane sum runs on DPP.  The result differs from the two-pass form by
 // f32 rounding of the rescaling only.
-constexpr int SA_MAXL = 4096;  // Lmax ancestor slots per wave must fit the 64 KiB default LDS
+//
+// Round 3, later: SPLIT waves per (row, head).  A wave's batch - 64 positions, K and V rows of 128 bytes each scattered
+// over the cache - is one dependent round trip of ~3.5 us whatever the grid looks like (rows per workgroup 10 -> 1:
+// 0.368 -> 0.363 ms per label step, profiles/r03v), and a 190-token prefix was four of them in sequence.  Now the
+// batches of a prefix are dealt round-robin to SPLIT waves of the same workgroup, each carrying its own online-softmax
+// state, merged through LDS at the end: one round trip up to 64 SPLIT positions.  (Measured, profiles/r03w: with four
+// waves per row the launch time no longer depends on the prefix length - 10.7 +- 0.9 us against 5.3 .. 19.4 - but every
+// wave brings ~1.5 us of fixed cost, query load to merge; two waves per row is the best trade at 160 rows.)
+constexpr int SA_MAXL = 4096;  // Lmax ancestor slots per row must fit the 64 KiB default LDS
+constexpr int SA_MERGE_FLOATS = 16 * 8 * 10;  // [wave][channel chunk][m, l, acc[8]]
 template <typename T, int DK>
 __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict__ qkv,
                                                            T* __restrict__ kc, T* __restrict__ vc,
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
                                                            int d, int Lmax, int pos,
                                                            const int* __restrict__ pos_dev,
                                                            const int* __restrict__ tok_tab,
-                                                           T* __restrict__ ctx) {
+                                                           T* __restrict__ ctx, int SA_SPLIT) {
   // tok_tab != NULL ([Lmax][n] token table): keys whose token id is 0 are masked
   // (TransformerLM._target_mask, espnet2/lm/transformer_lm.py:54-57).
   // pos_dev != NULL (hipGraph-captured search step): position from device memory; the ancestor
@@ -136,11 +147,13 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
   constexpr int NCH = DK / 8;   // lanes per position
   constexpr int NJ = 64 / NCH;  // positions per group
   static_assert(NCH == 8 || NCH == 4, "d_k 64 or 32");
-  extern __shared__ int sa_lds[];  // per wave: Lmax ancestor slots
+  extern __shared__ int sa_lds[];  // merge buffer, then per row: Lmax ancestor slots
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int* a_s = sa_lds + (size_t)wave * Lmax;
+  const int rloc = wave / SA_SPLIT, slice = wave % SA_SPLIT;  // the row of the workgroup, and which of its batches
+  float* const mrg = (float*)sa_lds;
+  int* a_s = sa_lds + SA_MERGE_FLOATS + (size_t)rloc * Lmax;
   const int h = blockIdx.x;
-  int r = blockIdx.y * (blockDim.x >> 6) + wave;
+  int r = blockIdx.y * ((blockDim.x >> 6) / SA_SPLIT) + rloc;
   const bool live = r < n;  // the last group may be partial
   r = live ? r : n - 1;
   const int ch = lane % NCH, jsub = lane / NCH;
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
 #pragma unroll
   for (int e = 0; e < 8; ++e) q[e] *= scale;
   // append this position's K/V to the cache (read back by later steps only)
-  if (lane < NCH && live) {
+  if (lane < NCH && live && slice == 0) {
     const size_t o = ((size_t)pos * n + r) * d + h * DK + lane * 8;
     float t8[8];
     load8<T>(row + d + lane * 8, t8);
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
   }
   // ancestor slots of the prefix: one coalesced read into LDS, so the K/V row addresses of the
   // loop below do not hang off a second dependent global load.  The slots are private to the wave.
-  for (int j = lane; j < pos; j += 64) a_s[j] = anc[(size_t)r * Lmax + j];
+  for (int j = slice * 64 + lane; j < pos; j += 64 * SA_SPLIT) a_s[j] = anc[(size_t)r * Lmax + j];
   __syncthreads();
   const int niter = (pos + NJ) / NJ;  // ceil((pos+1)/NJ)
   // The gathers are latency-bound (one 128-byte row per position, scattered over the cache): UN K rows and UN V rows
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
   float m_run = -INFINITY, l_run = 0.f;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int* const tt = tok_tab ? tok_tab : anc;
-  for (int it0 = 0; it0 < niter; it0 += UN) {
+  for (int it0 = slice * UN; it0 < niter; it0 += UN * SA_SPLIT) {
     Raw8<T> k8[UN], v8[UN];
     int tkv[UN];
     // UNCONDITIONAL gathers from a clamped position (positions past the prefix repeat the current row and are masked
@@ -238,11 +251,30 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   }
-  if (lane < NCH && live) {
-    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  // ---- the SPLIT partial states of the row -> its first wave (every lane of a wave holds the wave's totals of its chunk)
+  if (lane < NCH) {
+    float* o = mrg + (wave * 8 + lane) * 10;
+    o[0] = M;
+    o[1] = sum;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] *= inv;
-    store8<T>(ctx + (size_t)r * d + h * DK + lane * 8, acc);
+    for (int e = 0; e < 8; ++e) o[2 + e] = acc[e];
+  }
+  __syncthreads();
+  if (lane < NCH && live && slice == 0) {
+    float Mx = -INFINITY;
+    for (int q = 0; q < SA_SPLIT; ++q) Mx = fmaxf(Mx, mrg[((wave + q) * 8 + lane) * 10]);
+    float tot = 0.f, out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < SA_SPLIT; ++q) {
+      const float* o = mrg + ((wave + q) * 8 + lane) * 10;
+      const float fq = (o[0] > -INFINITY) ? __expf(o[0] - Mx) : 0.f;  // (a slice without positions, or all of them masked)
+      tot += o[1] * fq;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[e] += o[2 + e] * fq;
+    }
+    const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] *= inv;
+    store8<T>(ctx + (size_t)r * d + h * DK + lane * 8, out);
   }
 }
 
@@ -441,16 +473,26 @@ int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const 
                      int d, int heads, int Lmax, int pos, const int* pos_dev, int group,
                      const int* tok_tab, void* ctx, hipStream_t s) {
   const int dk = d / heads;
-  group = group < 1 ? 1 : (group > 16 ? 16 : group);
-  while (group > 1 && (size_t)group * Lmax * sizeof(int) > 64 * 1024) --group;  // default LDS limit
-  dim3 grid(heads, em_cdiv(n, group)), block(64 * group);
-  const size_t lds = (size_t)group * Lmax * sizeof(int);
+  // waves per row: batches of 64 positions run in parallel instead of in sequence once a prefix is longer than that
+  static const int fsplit = [] { const char* e = getenv("ESPNET_AMD_SA_SPLIT"); return e ? atoi(e) : 0; }();
+  const int SA_SPLIT = fsplit > 0 ? (fsplit > 8 ? 8 : fsplit) : 2;  // (two: 0.369 -> 0.358 ms per label step; four 0.363, eight 0.392 - every wave has its fixed cost; profiles/r03x)
+  group = group < 1 ? 1 : (group > 16 / SA_SPLIT ? 16 / SA_SPLIT : group);  // 16 waves per workgroup
+  while (group > 1 && (size_t)(group * Lmax + SA_MERGE_FLOATS) * sizeof(int) > 64 * 1024) --group;  // default LDS limit
+  // Rows of a beam on one CU share their ancestors' cache rows in its L1, but three quarters of the chip idle with
+  // 160 rows x 4 heads in 64 workgroups: fewer rows per workgroup until the grid covers the CUs (the L2 still serves
+  // the shared rows once).  ESPNET_AMD_SA_GROUP: developer A/B.
+  static const int forced = [] { const char* e = getenv("ESPNET_AMD_SA_GROUP"); return e ? atoi(e) : 0; }();
+  if (forced > 0) group = forced < group ? forced : group;
+  else while (group > 1 && heads * em_cdiv(n, group) < 512) --group;
+  if ((size_t)(group * Lmax + SA_MERGE_FLOATS) * sizeof(int) > 64 * 1024) return EM_ERR_UNSUPPORTED;
+  dim3 grid(heads, em_cdiv(n, group)), block(64 * group * SA_SPLIT);
+  const size_t lds = (size_t)(group * Lmax + SA_MERGE_FLOATS) * sizeof(int);
   if (dk == 64)
     hipLaunchKernelGGL((dec_self_attn_kernel<T, 64>), grid, block, lds, s, (const T*)qkv, (T*)kc,
-                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, tok_tab, (T*)ctx);
+                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, tok_tab, (T*)ctx, SA_SPLIT);
   else if (dk == 32)
     hipLaunchKernelGGL((dec_self_attn_kernel<T, 32>), grid, block, lds, s, (const T*)qkv, (T*)kc,
-                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, tok_tab, (T*)ctx);
+                       (T*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, tok_tab, (T*)ctx, SA_SPLIT);
   else
     return EM_ERR_UNSUPPORTED;
   EM_CHECK_LAUNCH();
