@@ -1482,7 +1482,8 @@ __global__ void online_snapshot_kernel(Ctx c, int restore) {
 
 // running_hyps = post_process(best) (:460-462 with batch_beam_search.py:412-423): the rows of `best`
 // that did not end with <eos> become the running rows; tree, ancestor tables and scores as offline.
-__global__ __launch_bounds__(64) void online_commit_kernel(Ctx c, int i) {
+__global__ __launch_bounds__(64) void online_commit_kernel(Ctx c, int i_host) {
+  const int i = c.b.step ? *c.b.step : i_host;  // (graph mode: the host writes the step index before the replay)
   const int b = blockIdx.x, lane = threadIdx.x;
   const int W = c.p.W, Lmax = c.p.Lmax, n = c.p.B * c.p.W;
   __shared__ int s_prow[64], s_tok[64], s_valid[64];
@@ -1525,7 +1526,10 @@ __global__ __launch_bounds__(64) void online_commit_kernel(Ctx c, int i) {
 
 int check_online(const EmSearchParams* p, const EmSearchBuffers* b) {
   EM_TRY(check(p, b));
-  if (p->B != 1 || b->step) return EM_ERR_BAD_ARG;  // one stream; host-driven steps
+  // one stream, host-driven steps.  b->step != NULL (graph mode): every kernel of a step reads the step index from
+  // step[0], which the HOST writes before each em_search_online_core / _commit - nothing advances it on the device (the
+  // select / online kernels have no step_advance) - so one captured launch sequence serves every step of a block.
+  if (p->B != 1) return EM_ERR_BAD_ARG;
   if (!b->online_best || !b->online_psi || !b->online_snap) return EM_ERR_BAD_ARG;
   if (p->ldT < p->T) return EM_ERR_BAD_ARG;
   return EM_OK;

@@ -23,6 +23,7 @@ token sequences and the ended list live on the host, exactly like the reference'
 There is no CPU path for the scores: without the HIP library the calls raise.
 """
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -60,7 +61,18 @@ class BatchBeamSearchOnline(BatchBeamSearch):
         self.block_size, self.hop_size, self.look_ahead = block_size, hop_size, look_ahead
         self.disable_repetition_detection = disable_repetition_detection
         self.max_frames = max_frames  # frame capacity of one stream (source attention keeps T scores in LDS)
-        self.use_hipgraph = False
+        # The ~50 launches of a label step can be replayed as one captured hipGraph: the step index lives in device memory
+        # (written by the host before each replay - a block may rewind by one), the number of visible frames is baked
+        # into the launches, so there is one graph per (buffer set, T); the block schedule is the same for every
+        # utterance of a stream slot, so the keys repeat, and a graph is captured the third time its key is used.
+        # Bit-identical to the eager sequence (tests/test_gpu_online_search.py::test_online_search_graph_replay_equals_eager)
+        # and NOT faster: 131.8 ms per 10 s utterance against 125.3 eager (beam 10, 279 label steps, profiles/r03z) -
+        # the step is bound by its ~50 dependent kernels on the GPU, and the eager launches of a step already run ahead
+        # of them.  Off unless ESPNET_AMD_ONLINE_GRAPH=1.
+        self.use_hipgraph = os.environ.get("ESPNET_AMD_ONLINE_GRAPH", "0") == "1"
+        self.graph_after = 2  # eager uses of a (buffers, T) key before it is captured
+        self._graph_uses = {}
+        self.n_replays = 0  # label steps served by a graph replay (diagnostics / tests)
         self.events: List[str] = []  # log markers of the reference, kept for tests / diagnostics
         self.n_steps = 0  # label steps computed on the device since construction (diagnostics)
         self.reset()
@@ -102,7 +114,7 @@ class BatchBeamSearchOnline(BatchBeamSearch):
         bs = L.EmSearchBuffers()
         for name in L.SEARCH_BUFFERS:
             setattr(bs, name, bufs[name].data_ptr() if name in bufs else None)
-        bs.step = None
+        bs.step = bufs["step"].data_ptr() if self.use_hipgraph else None  # graph mode: step index in device memory
         lmw = lm.ensure_packed(dev, Lmax)["w"] if lm is not None else None
         if lmw is not None:
             bs.lm = C.addressof(lmw)
@@ -110,7 +122,10 @@ class BatchBeamSearchOnline(BatchBeamSearch):
         self._dev = dict(dev=dev, d=d, em_dtype=em_dtype, act=act, bufs=bufs, bs=bs, lmw=lmw, dw=dw,
                          dwp=C.byref(dw) if dw is not None else None, S=S, NC=NC, Lmax=Lmax, Tcap=Tcap,
                          ctc_pk=ctc_sc.ctc._pack(dev) if ctc_sc is not None else None,
-                         best_host=torch.empty(W, 8, dtype=torch.float32).pin_memory())
+                         best_host=torch.empty(W, 8, dtype=torch.float32).pin_memory(),
+                         step_host=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                         gkey=(id(bufs), em_dtype, id(dec._packed) if dec is not None else 0,
+                               id(lm._packed) if lm is not None else 0))
         self.encbuffer = torch.empty(Tcap, d, dtype=act, device=dev)
 
     def _params(self, T: int) -> L.EmSearchParams:
@@ -146,8 +161,33 @@ class BatchBeamSearchOnline(BatchBeamSearch):
         """best = self.search(self.running_hyps, h) (:400)."""
         D, lib = self._dev, L.load()
         self.n_steps += 1
-        L.check(lib.em_search_online_core(D["em_dtype"], C.byref(self._p), D["dwp"], C.byref(D["bs"]),
-                                          self.process_idx, L.current_stream_ptr()), "em_search_online_core")
+
+        def core():
+            L.check(lib.em_search_online_core(D["em_dtype"], C.byref(self._p), D["dwp"], C.byref(D["bs"]),
+                                              self.process_idx, L.current_stream_ptr()), "em_search_online_core")
+
+        if self.use_hipgraph:
+            # (the previous step's host sync lies between this write and the copy that read the buffer last)
+            D["step_host"][0] = self.process_idx
+            D["bufs"]["step"].copy_(D["step_host"], non_blocking=True)
+            gkey = D["gkey"] + (bytes(self._p),)
+            ent = self._graphs.get(gkey)
+            if ent is not None:
+                ent[0].replay()
+                self.n_replays += 1
+            else:
+                core()
+                uses = self._graph_uses.get(gkey, 0) + 1
+                self._graph_uses[gkey] = uses
+                if uses > self.graph_after:
+                    torch.cuda.current_stream().synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):  # (captured, not executed: the eager call above did this step)
+                        core()
+                    self._graphs[gkey] = (g, self._p, D["bs"], D["lmw"], D["dw"])  # argument blocks kept alive
+                    del self._graph_uses[gkey]
+        else:
+            core()
         D["best_host"].copy_(D["bufs"]["online_best"], non_blocking=True)
         torch.cuda.current_stream().synchronize()  # the one host sync of a step
         rec = D["best_host"].tolist()
