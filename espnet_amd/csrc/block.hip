@@ -201,13 +201,18 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
       // combine equal-sized groups: n doubles, M2 = M2a + M2b + (sa - sb)^2 / (2 n)
-      float so = __shfl_xor(s, 16, 64), qo = __shfl_xor(q, 16, 64);
-      q = q + qo + (s - so) * (s - so) * (1.0f / 32.0f);
-      s += so;
-      so = __shfl_xor(s, 32, 64);
-      qo = __shfl_xor(q, 32, 64);
-      q = q + qo + (s - so) * (s - so) * (1.0f / 64.0f);
-      s += so;
+      // (the partner's values through gfx950's register swaps: own + partner's come back as a pair, and the update is
+      // symmetric in them - one VALU instruction where __shfl_xor was a ds_bpermute round trip, eight per LayerNorm)
+      {
+        const Pair2 ps = wave_xor16_pair(s), pq = wave_xor16_pair(q);
+        q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 32.0f);
+        s = ps.a + ps.b;
+      }
+      {
+        const Pair2 ps = wave_xor32_pair(s), pq = wave_xor32_pair(q);
+        q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 64.0f);
+        s = ps.a + ps.b;
+      }
       if (lg == 0) {
         red[nf * 32 + mi * 16 + lr] = s;        // sum over this wave's 64 columns
         red[128 + nf * 32 + mi * 16 + lr] = q;  // sum of squares about their mean
@@ -877,22 +882,47 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       const size_t bh = (size_t)b * H + head;
       f32x4 c[2];
       mma_k(cur, which == 2, c);
+      // The two 8-byte pieces of a lane (frame halves mi = 0, 1) become ONE 16-byte store: lanes l and l ^ 16 - lane
+      // groups 2 j and 2 j + 1, adjacent 4-column (q, k) resp. 4-frame (v) pieces of the same rows - trade halves through
+      // v_permlane16_swap, the even group keeps half mi = 0 of both, the odd group half mi = 1.  Half as many store
+      // instructions in the kernel's store-bound tail (every CU writes its 80 KiB of q, k, v and x within the same
+      // few microseconds; 16-byte stores halve the issue side of it, MI355X_MICROARCH.md "store tail").
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      u32x2 h[2];
       if (which < 2) {
         const float4 b4 = *(const float4*)(pa1 + 512 + u * 64 + ncol);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-          bf16x4 pk = {(bf16)(c[mi][0] + b4.x), (bf16)(c[mi][1] + b4.y), (bf16)(c[mi][2] + b4.z),
-                       (bf16)(c[mi][3] + b4.w)};
-          *(bf16x4*)((bf16*)(which ? a.kh : a.qh) + (bh * a.Tpad + t0 + mi * 16 + lr) * 64 + ncol) = pk;
+          const bf16x4 pk = {(bf16)(c[mi][0] + b4.x), (bf16)(c[mi][1] + b4.y), (bf16)(c[mi][2] + b4.z),
+                             (bf16)(c[mi][3] + b4.w)};
+          h[mi] = __builtin_bit_cast(u32x2, pk);
         }
       } else {
         const float bvv = pa1[512 + u * 64 + nf * 16 + lr];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-          bf16x4 pk = {(bf16)(c[mi][0] + bvv), (bf16)(c[mi][1] + bvv), (bf16)(c[mi][2] + bvv),
-                       (bf16)(c[mi][3] + bvv)};
-          *(bf16x4*)((bf16*)a.vt + (bh * 64 + nf * 16 + lr) * a.Tpad + t0 + mi * 16 + lg * 4) = pk;
+          const bf16x4 pk = {(bf16)(c[mi][0] + bvv), (bf16)(c[mi][1] + bvv), (bf16)(c[mi][2] + bvv),
+                             (bf16)(c[mi][3] + bvv)};
+          h[mi] = __builtin_bit_cast(u32x2, pk);
         }
+      }
+      // swap(A = half 0, B = half 1): A' = [A.row0, B.row0, A.row2, B.row2], B' = [A.row1, B.row1, A.row3, B.row3]
+      // -> even lane groups: (own half 0, partner's half 0) = (A', B'); odd groups: (partner's half 1, own half 1) = (A', B')
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const auto r = __builtin_amdgcn_permlane16_swap(h[0][e], h[1][e], false, false);
+        o[e] = r[0];
+        o[2 + e] = r[1];
+      }
+      const int odd = lg & 1;  // this lane now holds half mi = odd of lane groups (lg & ~1) and (lg | 1)
+      if (which < 2) {
+        bf16* const dst = (bf16*)(which ? a.kh : a.qh) + (bh * a.Tpad + t0 + odd * 16 + lr) * 64 + nf * 16 + (lg & ~1) * 4;
+        *(u32x4*)dst = o;
+      } else {
+        bf16* const dst = (bf16*)a.vt + (bh * 64 + nf * 16 + lr) * a.Tpad + t0 + odd * 16 + (lg & ~1) * 4;
+        *(u32x4*)dst = o;
       }
     });
     {

@@ -104,6 +104,17 @@ constexpr int DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;
 // rows of one operand with the even rows of the other, v_permlane32_swap the upper half of one with the lower half of the
 // other - with both operands = x, every lane ends up holding its own value in one result and its partner's in the other.
 // One VALU instruction instead of a ds_bpermute round trip through the LDS crossbar.
+struct Pair2 {
+  float a, b;  // a lane's own value and that of lane ^ 16 (resp. ^ 32), in an order that depends on the lane
+};
+__device__ __forceinline__ Pair2 wave_xor16_pair(float x) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ Pair2 wave_xor32_pair(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
 __device__ __forceinline__ float wave_xor16_max(float x) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
