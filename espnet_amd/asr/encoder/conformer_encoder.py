@@ -469,6 +469,36 @@ class ConformerEncoder(torch.nn.Module):
             p = self.pack(device)
         return p
 
+    def _pos_projected(self, T: int, device, pk, pos: torch.Tensor) -> torch.Tensor:
+        """pos (2T-1 | T, d) x wpos_all^T -> (rows, num_blocks * d) in the activation dtype, through the same em_gemm
+        call the encoder entry point makes without EM_ENC_POS_PROJECTED (bit-identical); kept for the last few lengths
+        of the current packing."""
+        cache = self.__dict__.setdefault("_pos_proj_cache", {})
+        key = (T, str(device), id(pk["w"]))
+        ent = cache.get(key)
+        cur = torch.cuda.current_stream()
+        if ent is not None:
+            out, ev, sid = ent
+            if sid != cur.cuda_stream:  # produced on another stream (concurrent batches): order this one behind it
+                cur.wait_event(ev)
+            return out
+        out = None
+        if out is None:
+            pos = pos.contiguous()
+            rows, d = pos.shape
+            n = self.num_blocks * d
+            out = torch.empty(rows, n, dtype=self.act_dtype, device=device)
+            args = L.EmGemmArgs(A=pos.data_ptr(), W=pk["w"].wpos_all, C=out.data_ptr(), bias=None, M=rows, N=n, K=d,
+                                lda=d, ldc=n, scale=1.0)
+            L.check(L.load().em_gemm(self.em_dtype, L.EM_EPI_STORE, L.EM_A_PLAIN, C.byref(args),
+                                     L.current_stream_ptr()), "em_gemm(linear_pos)")
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            while len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            cache[key] = (out, ev, cur.cuda_stream)
+        return out
+
     def _pos_emb(self, T: int, device) -> torch.Tensor:
         """(2T-1, d) rows for a length-T input: a contiguous row slice of one table built for a maximum
         length, exactly as the reference slices its `pe` buffer (embedding.py:329-332).  Row k of the
@@ -573,9 +603,14 @@ class ConformerEncoder(torch.nn.Module):
                     self.last_ctc_ids = ids
                 else:
                     pk["w"].ctc_ids = None
+        pos = self._pos_emb(T, dev)
+        if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "wpos_all", None):
+            # linear_pos of every block depends on T and the weights only: projected once per length, handed over ready
+            pos = self._pos_projected(T, dev, pk, pos)
+            enc_flags |= L.EM_ENC_POS_PROJECTED
         rc = getattr(lib, self._ENC_FN)(
             self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
-            L.ptr(olens_dev), B, T_f, L.ptr(self._pos_emb(T, dev)), L.ptr(ws),
+            L.ptr(olens_dev), B, T_f, L.ptr(pos), L.ptr(ws),
             ws.numel(), L.ptr(enc_out), L.ptr(enc_act),
             enc_flags, L.current_stream_ptr())
         L.check(rc, self._ENC_FN)

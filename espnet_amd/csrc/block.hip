@@ -625,6 +625,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         const int j = u >> 1;
         const float4 bv = *(const float4*)(pb0 + 768 + (2 * j) * 64 + ncol);
         const float4 bg = *(const float4*)(pb0 + 768 + (2 * j + 1) * 64 + ncol);
+        // (8-byte pieces, as they come: traded into 16-byte stores through v_permlane16_swap like q / k / v in the A part
+        // this kernel got SLOWER, 12.46 -> 12.83 us - its tail is the 32 KiB of x, not the 16 KiB of glu; profiles/r03ac)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           bf16x4 pk = {(bf16)((v[mi][0] + bv.x) * sigmoidf_(gt[mi][0] + bg.x)),

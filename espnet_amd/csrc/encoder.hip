@@ -134,8 +134,12 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream, w->conv1_wf, w->conv2_wf));
   const EmConformerLayer* ly = w->layers;
   // ---- linear_pos of every block in one GEMM: pall[2T-1][L*d]
-  EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, w->legacy_relpos ? T : 2 * T - 1, L * d, d, d,
-              L * d, 1.f, stream));
+  // (EM_ENC_POS_PROJECTED: the caller did it once for this length - the product depends on T and the weights only)
+  if (flags & EM_ENC_POS_PROJECTED)
+    pall = const_cast<void*>(pos_emb);
+  else
+    EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, w->legacy_relpos ? T : 2 * T - 1, L * d, d, d,
+                L * d, 1.f, stream));
   // ---- fused per Conformer block (csrc/block.hip): three launches per block instead of nineteen
   const int plan = encode_plan(dtype, w, flags);
   const bool fused = (plan & EM_ENC_PLAN_FUSED) != 0;
@@ -143,8 +147,12 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     void* qh = ws + s.qh;
     void* kh = ws + s.kh;
     void* vt = ws + s.vt;
-    // key columns >= 32 * ceil(T / 32) of V^T are never written and meet probability 0 in P.V: they must be finite
-    if (hipMemsetAsync(vt, 0, (size_t)B * d * s.Tpad * es, (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
+    // key columns >= 32 * ceil(T / 32) of V^T are never written and meet probability 0 in P.V: they must be finite.
+    // (When the 32-frame row blocks cover Tpad - T = 249: 8 x 32 = 256 - every column is written by the block kernels,
+    // frames past T as recomputed copies of frame T - 1: no memset, 5 us of a 1.07 ms step.)
+    if (32 * em_cdiv(T, 32) < s.Tpad &&
+        hipMemsetAsync(vt, 0, (size_t)B * d * s.Tpad * es, (hipStream_t)stream) != hipSuccess)
+      return EM_ERR_LAUNCH;
     EmBlockArgs ba = {};
     ba.B = B; ba.T = T; ba.Tpad = s.Tpad; ba.d = d; ba.ff = ff; ba.kernel = w->kernel; ba.eps = LN_EPS;
     ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = qh; ba.kh = kh; ba.vt = vt;

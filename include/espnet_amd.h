@@ -289,6 +289,8 @@ typedef struct EmConformerWeights {
 /* em_conformer_encode flags */
 #define EM_ENC_ISOLATE_UTTS 1 /* every utterance of a ragged batch encodes as if it were alone */
 #define EM_ENC_NO_FUSED 2     /* keep the one-operator-per-launch sequence even where the fused block kernels apply */
+#define EM_ENC_POS_PROJECTED 4 /* pos_emb is ALREADY linear_pos of every block: [2T-1 (legacy: T)][L*d] act, i.e. pos_emb x wpos_all^T
+                               * (it depends on T and the weights only: a caller decoding many batches of one length projects once) */
 
 /* Which launch sequence em_conformer_encode will take for these weights and flags (>= 0; negative = status):
  * the single source of that decision, so that the host layer never re-derives the shape conditions.           */
