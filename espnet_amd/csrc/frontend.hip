@@ -123,16 +123,45 @@ __global__ __launch_bounds__(256) void frontend_logmel_kernel(
   const bool valid_frame = t < flens[b];
   if (t_raw < T_f) {
     float* out = feats + ((size_t)b * T_f + t) * n_mels;
-    for (int m = lane; m < n_mels; m += 64) {
+    auto band = [&](int m, int s0, int s1) {
       float acc = 0.f;
-      int lo = mel_lo[m];
-      for (int s = 0; s < mel_maxlen; ++s) {
+      const int lo = mel_lo[m];
+      for (int s = s0; s < s1; ++s) {
         int k = lo + s;
         k = k < 256 ? k : 256;
         acc = fmaf(pw[k], melw[s * n_mels + m], acc);
       }
-      acc = fmaxf(acc, 1e-10f);
+      return acc;
+    };
+    // whole rounds of 64 filters: a lane per filter
+    const int nfull = n_mels & ~63;
+    for (int m = lane; m < nfull; m += 64) {
+      const float acc = fmaxf(band(m, 0, mel_maxlen), 1e-10f);
       out[m] = valid_frame ? logf(acc) : 0.f;
+    }
+    // the rest (80 filters: 16): with at most 16 filters left, FOUR lanes per filter, a quarter of the band each, summed
+    // over the lane groups with two register swaps - 9 trips instead of 33 with three quarters of the wave idle
+    const int rest = n_mels - nfull;
+    if (rest > 16) {
+      const int m = nfull + lane;
+      if (m < n_mels) {
+        const float acc = fmaxf(band(m, 0, mel_maxlen), 1e-10f);
+        out[m] = valid_frame ? logf(acc) : 0.f;
+      }
+    } else if (rest > 0) {
+      const int q = lane >> 4, mm = nfull + (lane & 15);
+      const int m = mm < n_mels ? mm : n_mels - 1;
+      const int per = (mel_maxlen + 3) >> 2;
+      const int s0 = q * per, s1 = (s0 + per < mel_maxlen) ? s0 + per : mel_maxlen;
+      float acc = band(m, s0, s1);
+      {
+        const Pair2 p16 = wave_xor16_pair(acc);
+        acc = p16.a + p16.b;
+        const Pair2 p32 = wave_xor32_pair(acc);
+        acc = p32.a + p32.b;
+      }
+      acc = fmaxf(acc, 1e-10f);
+      if (q == 0 && mm < n_mels) out[mm] = valid_frame ? logf(acc) : 0.f;
     }
   }
 }
