@@ -474,11 +474,13 @@ class ConformerEncoder(torch.nn.Module):
         call the encoder entry point makes without EM_ENC_POS_PROJECTED (bit-identical); kept for the last few lengths
         of the current packing."""
         cache = self.__dict__.setdefault("_pos_proj_cache", {})
-        key = (T, str(device), id(pk["w"]))
+        key = (T, str(device), self.em_dtype, id(pk["w"]))
         ent = cache.get(key)
         cur = torch.cuda.current_stream()
+        if ent is not None and ent[3] is not pk["w"]:  # (an id reused by a later packing: not this weight block)
+            ent = None
         if ent is not None:
-            out, ev, sid = ent
+            out, ev, sid, _ = ent
             if sid != cur.cuda_stream:  # produced on another stream (concurrent batches): order this one behind it
                 cur.wait_event(ev)
             return out
@@ -496,7 +498,7 @@ class ConformerEncoder(torch.nn.Module):
             ev.record(cur)
             while len(cache) >= 8:
                 cache.pop(next(iter(cache)))
-            cache[key] = (out, ev, cur.cuda_stream)
+            cache[key] = (out, ev, cur.cuda_stream, pk["w"])  # (the weight block is kept alive with its projection)
         return out
 
     def _pos_emb(self, T: int, device) -> torch.Tensor:

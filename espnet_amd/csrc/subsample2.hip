@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
           for (int f = 0; f < 2; ++f) *(u32x2*)(dst + f * 32) = (u32x2){pk1[f][0], pk1[f][1]};
         }
         if (iss && (k == 16 || k == 17))
-          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c1[k - 16]) : "v"(w1[k - 16]), "v"(xv[g & 1]));
+          // (early-clobber: an MFMA's destination must not overlap its A / B operands, and xv is dead after slot 17)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c1[k - 16]) : "v"(w1[k - 16]), "v"(xv[g & 1]));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
