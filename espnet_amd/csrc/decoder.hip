@@ -475,7 +475,9 @@ int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const 
   const int dk = d / heads;
   // waves per row: batches of 64 positions run in parallel instead of in sequence once a prefix is longer than that
   static const int fsplit = [] { const char* e = getenv("ESPNET_AMD_SA_SPLIT"); return e ? atoi(e) : 0; }();
-  const int SA_SPLIT = fsplit > 0 ? (fsplit > 8 ? 8 : fsplit) : 2;  // (two: 0.369 -> 0.358 ms per label step; four 0.363, eight 0.392 - every wave has its fixed cost; profiles/r03x)
+  // (only while the launch is small: at 640 rows x 8 heads the second wave per row costs more than the shorter chains
+  // give back - 0.704 -> 0.769 ms per label step, profiles/r03af - and the rows themselves fill the chip)
+  const int SA_SPLIT = fsplit > 0 ? (fsplit > 8 ? 8 : fsplit) : (heads * n <= 2048 ? 2 : 1);  // (two: 0.369 -> 0.358 ms per label step; four 0.363, eight 0.392 - every wave has its fixed cost; profiles/r03x)
   group = group < 1 ? 1 : (group > 16 / SA_SPLIT ? 16 / SA_SPLIT : group);  // 16 waves per workgroup
   while (group > 1 && (size_t)(group * Lmax + SA_MERGE_FLOATS) * sizeof(int) > 64 * 1024) --group;  // default LDS limit
   // Rows of a beam on one CU share their ancestors' cache rows in its L1, but three quarters of the chip idle with

@@ -175,22 +175,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     if (bias) bpre = *(const float4*)(bias + ncol_p);  // with the residual rows: not a round trip of its own in the epilogue
   }
 
-  // K loop over a ring of NS LDS stages, NS - 1 tiles requested ahead, ONE barrier per tile: after it every wave's
-  // pieces of tile kt have landed and every wave is done with tile kt - 1, whose stage is then refilled with tile
-  // kt + NS - 1.  (With two stages - rounds 1 and 2 - a tile's loads had one tile's MFMAs, ~270 cycles, to cross a
-  // memory system whose latency is 900: the embedding GEMM, K = 4 864, spent 1 140 cycles per tile.)  The requests are
-  // unconditional - past the end the last tile is requested again into a dead stage - so the wait is one constant.
   const int nk = K / BK;
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s < nk ? s : nk - 1, s);
-  int cur = 0, fill = NS - 1;
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NLOADS) : "memory");
-    __builtin_amdgcn_s_barrier();
-    {
-      const int kn = kt + NS - 1;
-      issue(kn < nk ? kn : nk - 1, fill);
-    }
+  // one tile's MFMAs from stage `cur`
+  auto compute = [&](int cur) {
     const unsigned char* sa = smem + cur * BUF;
     const unsigned char* sw = sa + A_BYTES;
 #pragma unroll
@@ -208,11 +195,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(fa[i], fb[j], acc[i][j]);
     }
-    cur = cur + 1 == NS ? 0 : cur + 1;
-    fill = fill + 1 == NS ? 0 : fill + 1;
+  };
+  if constexpr (NS == 2) {
+    // two stages (rounds 1 and 2): the next tile is requested BEFORE the wait for the current one, so two tiles are on
+    // their way while the wave waits; two barriers per tile.  (The one-barrier ring below with two stages can only
+    // request a tile after the one before it has landed: measured slower on the label step's vocabulary GEMM.)
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {
+        issue(kt + 1, cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // tile kt has landed for every wave
+      compute(cur);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done reading buf[cur]
+    }
+  } else {
+    // a ring of NS >= 3 LDS stages, NS - 1 tiles requested ahead, ONE barrier per tile: after it every wave's pieces of
+    // tile kt have landed and every wave is done with tile kt - 1, whose stage is then refilled with tile kt + NS - 1.
+    // (With two stages a tile's loads had one tile's MFMAs, ~270 cycles, to cross a memory system whose latency is 900:
+    // the embedding GEMM, K = 4 864, spent 1 140 cycles per tile.)  The requests are unconditional - past the end the
+    // last tile is requested again into a dead stage - so the wait is one constant.
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s < nk ? s : nk - 1, s);
+    int cur = 0, fill = NS - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NLOADS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      {
+        const int kn = kt + NS - 1;
+        issue(kn < nk ? kn : nk - 1, fill);
+      }
+      compute(cur);
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the surplus requests too: the epilogue reuses the stages)
+    __builtin_amdgcn_s_barrier();
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the surplus requests too: the epilogue reuses the stages)
-  __builtin_amdgcn_s_barrier();
 
   // ---- epilogue.  C/D layout: col = lane & 15, row = (lane >> 4) * 4 + r.
   const int wm0 = m0 + wr * WM, wn0 = n0 + wc * 64;
