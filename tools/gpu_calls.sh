@@ -1,0 +1,52 @@
+#!/bin/bash
+# The GPU-box calls of round 3 in one place (each was one `gpurun -- bash tools/gpu_calls.sh <what> <tag>`; output under
+# gpurun_out/<tag>/, the summaries that are quoted in DESIGN.md copied to profiles/<tag>_*).
+#   full         the whole `pytest -m gpu` suite, smoke, the default bench line, rocprofv3 table of the greedy step
+#   bench        smoke, the default bench line (roofline + traffic + cpu baseline + beam + stream legs), rocprofv3 table
+#   sub2         fused subsampling kernel: cycle stamps of one workgroup, the conv tests, per-kernel stats, quick bench line
+#   search-stats per-kernel stats of the beam-search label step
+#   search-pmc   ... plus SQ wave-cycle breakdown and HBM traffic (FETCH_SIZE / WRITE_SIZE in their own passes)
+#   sa-ab        decoder self-attention: waves per row x rows per workgroup (ESPNET_AMD_SA_SPLIT / _GROUP), label-step A/B
+#   attn-stamps  relpos_attn2 cycle stamps (EM_ATTN2_STAMPS)
+set -u
+what=${1:-bench}; tag=${2:-r03}; out=$PWD/gpurun_out/$tag; mkdir -p "$out"
+export TMPDIR=/tmp
+R=$PWD
+stats() {  # <dir> <cmd...>: rocprofv3 --kernel-trace --stats of a command, summary kept, trace dropped
+  local d=$1; shift
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$d" -o s --output-format csv -- "$@" > "$d.log" 2>&1 < /dev/null)
+  find "$d" -name "*_kernel_trace.csv" -delete 2>/dev/null
+  local f; f=$(find "$d" -name "*kernel_stats.csv" 2>/dev/null | head -1)
+  if [ -n "$f" ]; then head -16 "$f" | cut -c1-170; else echo "no stats file"; tail -5 "$d.log"; fi
+}
+beam_line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['search']['ms_per_search_step'])"; }
+case "$what" in
+  full|bench)
+    if [ "$what" = full ]; then
+      echo "== pytest -m gpu"; (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) 2>&1 | tee "$out/pytest_gpu.txt"
+    fi
+    echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -4 | tee "$out/smoke.txt"
+    echo "== default bench"; (time timeout 900 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5
+    echo "== rocprofv3 kernel stats, greedy"
+    stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10 ;;
+  sub2)
+    echo "== stamps"
+    EM_SUB2_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 3 --warmup 2 2>&1 | grep "sub2 stamps" | head -2 | tee "$out/stamps.txt"
+    echo "== tests"; timeout 300 python -m pytest tests/test_gpu_kernels.py -q -x -k "sub12 or conv2d or subsampl" 2>&1 | tail -3
+    echo "== kernel stats"; stats "$out/stats" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 50 --warmup 5
+    echo "== bench"; timeout 200 python bench.py --quick --no-traffic --no-cpu-baseline --steps 600 --warmup 30 2>/dev/null < /dev/null | tee "$out/bench_quick.json" | cut -c1-260 ;;
+  search-stats)
+    stats "$out/search_stats" python "$R/bench.py" --workload beam --steps 1 --warmup 1 --no-cpu-baseline --no-traffic ;;
+  search-pmc)
+    bash tools/r03_search_pmc.sh "$tag" ;;
+  sa-ab)
+    for cfg in "1 10" "1 2" "2 2" "2 1" "4 1" "4 2" "8 1"; do
+      set -- $cfg
+      export ESPNET_AMD_SA_SPLIT=$1 ESPNET_AMD_SA_GROUP=$2
+      echo -n "split $1 group $2: "
+      timeout 300 python bench.py --workload beam --steps 2 --warmup 1 --no-cpu-baseline --no-traffic 2>/dev/null < /dev/null | beam_line
+    done ;;
+  attn-stamps)
+    EM_ATTN2_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "attn2 stamps" | sed -n "13,15p" | tee "$out/attn2_stamps.txt" ;;
+  *) echo "unknown call: $what"; exit 2 ;;
+esac
