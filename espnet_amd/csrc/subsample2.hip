@@ -17,8 +17,9 @@
 //     straight from global memory (fragment-major packing by the host, 1 KiB per wave-wide load, requested two taps
 //     ahead through a register ring), the position fragments from an LDS "patch" [map position][32 ch] of the conv1
 //     output (80-byte rows: conflict-free 16-byte reads at the stride-2 positions of a fragment) at (2 t2 + kt,
-//     2 f2 + kf): the im2col is index arithmetic on LDS addresses.  The weights are the MFMA A operand (C^T[n][m]):
-//     a lane ends up with 4 consecutive output channels of one position, i.e. 8-byte stores into the channel-last c2.
+//     2 f2 + kf): the im2col is index arithmetic on LDS addresses.  The weights are the MFMA A operand (C^T[n][m]), and
+//     the host packs their rows so that row lr of a wave's fragment j is output channel 64 w + 16 (lr / 4) + 4 j + lr % 4:
+//     a lane ends up with 16 consecutive output channels of one position, i.e. two 16-byte stores into the channel-last c2.
 //   * conv1, ALSO on the matrix cores: for 16 map positions x 16 channels it is a [16 x 9] x [9 x 16] product, and
 //     with operands split into bf16 high and low parts (x = xh + xl, w = wh + wl) one v_mfma_f32_16x16x32_bf16
 //     computes  xh.wh + xl.wh + xh.wl + bias  in f32 (k = 0-8 | 9-17 | 18-26 | 27, 28 for the two halves of the
@@ -28,9 +29,12 @@
 //     conv1 is then 22 MFMAs per wave against the 360 of its conv2.  (A VALU conv1 - 9 packed FMAs per position and
 //     channel pair with the weights in scalar registers - spilled 1 090 SGPRs and cost as many issue slots as the
 //     MFMAs; tools/isa_waits.py.)
-// One barrier per chunk: the conv1 patch of chunk c + 1 is produced, a slice per tap, while chunk c is consumed.
+// One barrier per chunk: the conv1 patch of chunk c + 1 is produced, a fragment per half tap, while chunk c is consumed.
 // Per workgroup and chunk: 382 MFMAs per wave (6 100 cycles of matrix-core time), 144 KiB of weights (64 B/clk would
-// take 2 300 cycles), 400 KiB of LDS fragment reads (3 100 cycles at 128 B/clk): the kernel is built to be MFMA-bound.
+// take 2 300 cycles), 400 KiB of LDS fragment reads (1 600 - 3 100 cycles): the kernel is built to be MFMA-bound, and
+// measures 7 400 cycles per chunk (EM_SUB2_STAMPS; 8 850 before everything that is not a conv2 MFMA was dealt out one
+// piece per MFMA slot, see the chunk loop).  The workgroups are persistent: tile loop, next tile's inputs and operand
+// build overlapped with the current tile's last chunk and stores (see the kernel body); DESIGN.md section 4c.
 #include <stdio.h>
 #include <stdlib.h>
 
