@@ -52,7 +52,15 @@ constexpr int INR = 2 * T1R + 1;  // feature rows: 35
 constexpr int F1MAX = 40, F2MAX = 19, MELMAX = 2 * F1MAX + 2;
 constexpr int NPF = (T1R * F1MAX + 15) / 16;  // map-position fragments of conv1: 43
 constexpr int PSTRIDE = 2 * CC + 16;          // bytes per patch position: 64 of channels + 16 of padding
-constexpr int PATCH_BYTES = NPF * 16 * PSTRIDE;  // 55 040 (whole fragments: the padded positions are written too)
+// A patch is [T1R map rows][F1 positions][PSTRIDE] with a row pitch of ROWP bytes, chosen so that the step from the last
+// position of an output row's window to the first of the next one (2 ROWP - (F2 - 1) * 2 * PSTRIDE) is the same number of
+// LDS banks as the step between neighbouring positions (2 * PSTRIDE = 40 banks) for F2 = 19, the 80-mel case: a 16-position
+// fragment that wraps over a row end then reads as conflict-free as one inside a row.  With the dense pitch F1 * PSTRIDE
+// the wrap shifted the rest of the fragment by 32 banks, onto the banks of its first lanes: SQ_LDS_BANK_CONFLICT was
+// 39 % of SQ_LDS_IDX_ACTIVE (profiles/r03ah_greedy_pmc_sq.json), seven of the ten fragments of a tile wrap.
+constexpr int ROWP = F1MAX * PSTRIDE + 112;      // 3 312: >= F1 * PSTRIDE, = 19 * 80 (mod 128)
+static_assert(ROWP % 16 == 0 && (2 * ROWP - 18 * 2 * PSTRIDE) % 256 == (2 * PSTRIDE) % 256, "bank-neutral row wrap at F2 = 19");
+constexpr int PATCH_BYTES = 55 * 1024;           // >= T1R * ROWP = 56 304, a multiple of 1 KiB
 constexpr int XIN_OFF = 0;                       // [NPF][64 lanes][16 B]: the conv1 position operands
 constexpr int PATCH_OFF = NPF * 1024;
 constexpr int IN_OFF = PATCH_OFF;  // f32 [INR][n_mels] (contiguous rows: filled by LDS-DMA), aliasing patch 0: free during a tile's LAST chunk (which reads patch 1 and produces nothing)
@@ -277,8 +285,16 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(r) : "v"(x), "v"(y));
     return r;
   };
+  // byte offset inside a patch of this lane's map position of conv1 fragment pf (position 16 pf + lr, clamped like the
+  // operand build: the lanes past the map repeat its last position - same value, same address)
+  auto patch_pos = [&](int pf) {
+    int p = pf * 16 + lr;
+    p = p < npos ? p : npos - 1;
+    const int t1l = (p * f1_inv) >> 16;
+    return t1l * ROWP + (p - t1l * F1) * PSTRIDE;
+  };
   auto conv1_frag = [&](int buf, int j, const bf16x8& xv) {
-    unsigned char* const dst = smem + PATCH_OFF + buf * PATCH_BYTES + (conv1_pf(j) * 16 + lr) * PSTRIDE + lg * 8;
+    unsigned char* const dst = smem + PATCH_OFF + buf * PATCH_BYTES + patch_pos(conv1_pf(j)) + lg * 8;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[f], xv, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     int m = i * 16 + lr;
     m = m < M ? m : M - 1;
     const int t2l = m / F2, f2 = m - t2l * F2;
-    pb[i] = ((2 * t2l) * F1 + 2 * f2) * PSTRIDE + lg * 16;
+    pb[i] = (2 * t2l) * ROWP + (2 * f2) * PSTRIDE + lg * 16;
   }
   const size_t out_bytes = (size_t)a.B * a.T2 * F2 * D * 2;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(unsigned)out_bytes, 0x00020000);
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   bf16x8 bfr[2][GF];
   auto read_group = [&](const unsigned char* patch, int g, bf16x8 (&dst)[GF]) {
     const int tap = g >> 1, i0 = (g & 1) * GF;
-    const int toff = ((tap / 3) * F1 + tap % 3) * PSTRIDE;
+    const int toff = (tap / 3) * ROWP + (tap % 3) * PSTRIDE;
 #pragma unroll
     for (int i = 0; i < GF; ++i) dst[i] = *(const bf16x8*)(patch + pb[i0 + i] + toff);
   };
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   // per MFMA, in exactly this order (sched_barrier after every slot; left to hipcc the pieces end up in one block
   // between the groups, ~120 cycles per group during which the matrix core has nothing to do):
   //   slots 0-4    the next group's position fragments (LDS)          slots 10-13  the previous conv1 fragment: ReLU, bf16
-  //   slot  5      the next conv1 fragment's position operand (LDS)   slot  14     ... its LDS write
+  //   slot  5      the next conv1 fragment's position operand (LDS)   slots 14-15  ... its patch address, its LDS write
   //   slots 6-9    the weights two taps ahead (even groups)           slots 16-17  this group's two conv1 MFMAs
   auto chunk = [&](int cc, auto last) {
     constexpr bool LAST = decltype(last)::value;
@@ -375,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     const int nbuf = (cc + 1) & 1;
     f32x4 c1[2];
     unsigned pk1[2][2];
+    int wdst = 0;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #pragma unroll
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
         mfma_acc(acc[j][i0 + i], wr[tap % 3][j], bfr[g & 1][i]);
         if (k < GF && g < 17) {
           const int g1 = g + 1, tap1 = g1 >> 1;
-          bfr[g1 & 1][k] = *(const bf16x8*)(patch + pb[(g1 & 1) * GF + k] + ((tap1 / 3) * F1 + tap1 % 3) * PSTRIDE);
+          bfr[g1 & 1][k] = *(const bf16x8*)(patch + pb[(g1 & 1) * GF + k] + (tap1 / 3) * ROWP + (tap1 % 3) * PSTRIDE);
         }
         if (k == 5 && !LAST && g + 1 < PF_PER_WAVE) xv[(g + 1) & 1] = conv1_read(g + 1);
         if (k >= 6 && k < 10 && !(g & 1)) {
@@ -400,10 +417,10 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
           const int f = (k - 10) >> 1, h = (k - 10) & 1;
           pk1[f][h] = relu_pack(c1[f][2 * h], c1[f][2 * h + 1]);
         }
-        if (fin && k == 14) {
-          unsigned char* const dst = smem + PATCH_OFF + nbuf * PATCH_BYTES + (conv1_pf(g - 1) * 16 + lr) * PSTRIDE + lg * 8;
+        if (fin && k == 14) wdst = PATCH_OFF + nbuf * PATCH_BYTES + patch_pos(conv1_pf(g - 1)) + lg * 8;  // (its address: a slot of its own)
+        if (fin && k == 15) {
 #pragma unroll
-          for (int f = 0; f < 2; ++f) *(u32x2*)(dst + f * 32) = (u32x2){pk1[f][0], pk1[f][1]};
+          for (int f = 0; f < 2; ++f) *(u32x2*)(smem + wdst + f * 32) = (u32x2){pk1[f][0], pk1[f][1]};
         }
         if (iss && (k == 16 || k == 17))
           // (early-clobber: an MFMA's destination must not overlap its A / B operands, and xv is dead after slot 17)

@@ -8,6 +8,7 @@
 #   search-pmc   ... plus SQ wave-cycle breakdown and HBM traffic (FETCH_SIZE / WRITE_SIZE in their own passes)
 #   sa-ab        decoder self-attention: waves per row x rows per workgroup (ESPNET_AMD_SA_SPLIT / _GROUP), label-step A/B
 #   attn-stamps  relpos_attn2 cycle stamps (EM_ATTN2_STAMPS)
+#   greedy-pmc   SQ counters (wave cycles, waits, MFMA busy, LDS bank conflicts) of the greedy step's main kernels
 set -u
 what=${1:-bench}; tag=${2:-r03}; out=$PWD/gpurun_out/$tag; mkdir -p "$out"
 export TMPDIR=/tmp
@@ -48,5 +49,12 @@ case "$what" in
     done ;;
   attn-stamps)
     EM_ATTN2_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "attn2 stamps" | sed -n "13,15p" | tee "$out/attn2_stamps.txt" ;;
+  greedy-pmc)
+    ctrs="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+    (cd /tmp && timeout 400 rocprofv3 --pmc $ctrs --kernel-trace -d "$out/pmc" -o p --output-format csv -- python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 10 --warmup 3 > "$out/pmc.log" 2>&1 < /dev/null)
+    find "$out/pmc" -name "*_kernel_trace.csv" -delete 2>/dev/null
+    python tools/pmc_summary.py "$out/pmc" --match sub2_kernel relpos_attn2 block_kernel frontend_logmel gemm_kernel --source "bench.py --quick --steps 10 --warmup 3" > "$out/pmc_sq.json" 2>"$out/pmc_sq.err"
+    find "$out/pmc" -name "*counter_collection.csv" -delete 2>/dev/null
+    head -c 3000 "$out/pmc_sq.json" ;;
   *) echo "unknown call: $what"; exit 2 ;;
 esac
