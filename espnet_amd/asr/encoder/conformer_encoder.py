@@ -15,6 +15,7 @@ arithmetic is csrc/{frontend,gemm,norm,attention,conv,encoder}.hip.
 """
 import ctypes as C
 import math
+import threading
 from typing import List, Optional, Tuple
 
 import torch
@@ -22,6 +23,8 @@ import torch
 from espnet_amd import lib as L
 from espnet_amd.nets_utils import (SUBSAMPLING_CONVS, SUBSAMPLING_MIN_FRAMES, conv2d_subsampled_lengths,
                                    conv_out_size)
+
+_POS_PROJ_LOCK = threading.Lock()
 
 LN_EPS = 1e-12  # transformer/layer_norm.py:23
 
@@ -474,16 +477,19 @@ class ConformerEncoder(torch.nn.Module):
         call the encoder entry point makes without EM_ENC_POS_PROJECTED (bit-identical); kept for the last few lengths
         of the current packing."""
         cache = self.__dict__.setdefault("_pos_proj_cache", {})
+        lock = _POS_PROJ_LOCK  # (concurrent batches on host threads; module-level: a lock in __dict__ is not picklable)
         key = (T, str(device), self.em_dtype, id(pk["w"]))
-        ent = cache.get(key)
         cur = torch.cuda.current_stream()
-        if ent is not None and ent[3] is not pk["w"]:  # (an id reused by a later packing: not this weight block)
-            ent = None
-        if ent is not None:
-            out, ev, sid, _ = ent
-            if sid != cur.cuda_stream:  # produced on another stream (concurrent batches): order this one behind it
-                cur.wait_event(ev)
-            return out
+        with lock:
+            ent = cache.get(key)
+            if ent is not None and ent[3] is not pk["w"]:  # (an id reused by a later packing: not this weight block)
+                ent = None
+            if ent is not None:
+                out, ev, sid, _ = ent
+                if sid != cur.cuda_stream:  # produced on another stream (concurrent batches): order this one behind
+                    cur.wait_event(ev)      # it, and keep the block from being recycled under this stream's readers
+                    out.record_stream(cur)  # when the entry is evicted (a same-stream free is ordered anyway)
+                return out
         out = None
         if out is None:
             pos = pos.contiguous()
@@ -496,9 +502,10 @@ class ConformerEncoder(torch.nn.Module):
                                      L.current_stream_ptr()), "em_gemm(linear_pos)")
             ev = torch.cuda.Event()
             ev.record(cur)
-            while len(cache) >= 8:
-                cache.pop(next(iter(cache)))
-            cache[key] = (out, ev, cur.cuda_stream, pk["w"])  # (the weight block is kept alive with its projection)
+            with lock:
+                while len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+                cache[key] = (out, ev, cur.cuda_stream, pk["w"])  # (the weight block is kept alive with its projection)
         return out
 
     def _pos_emb(self, T: int, device) -> torch.Tensor:

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
     store8<T>(vc + o, t8);
   }
   // ancestor slots of the prefix: one coalesced read into LDS, so the K/V row addresses of the
-  // loop below do not hang off a second dependent global load.  The slots are private to the wave.
+  // loop below do not hang off a second dependent global load.  (Filled by all the row's waves together, read after the
+  // barrier.)
   for (int j = slice * 64 + lane; j < pos; j += 64 * SA_SPLIT) a_s[j] = anc[(size_t)r * Lmax + j];
   __syncthreads();
   const int niter = (pos + NJ) / NJ;  // ceil((pos+1)/NJ)

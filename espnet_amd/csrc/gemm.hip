@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
     for (int s = 0; s < NS - 1; ++s) issue(s < nk ? s : nk - 1, s);
     int cur = 0, fill = NS - 1;
     for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NLOADS) : "memory");
+      // lgkmcnt(0): this wave's fragment reads of tile kt - 1 have RETURNED before it passes the barrier that lets
+      // another wave's LDS-DMA refill that stage (gfx950 barriers do not wait for outstanding LDS reads themselves)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NLOADS) : "memory");
       __builtin_amdgcn_s_barrier();
       {
         const int kn = kt + NS - 1;
@@ -509,8 +511,24 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   const int bk = dtype == EM_BF16 ? 64 : 32;
   if (p->K % bk != 0) return EM_ERR_UNSUPPORTED;
   if (epilogue == EM_EPI_GLU && (p->N % 32 != 0)) return EM_ERR_UNSUPPORTED;
-  if (epilogue == EM_EPI_RESID_F32 && (p->N % 4 != 0 || p->ldc % 4 != 0 || (size_t)p->M * p->ldc * 4 >= ((size_t)1 << 31)))
-    return EM_ERR_UNSUPPORTED;  // 16-byte residual rows behind one buffer resource
+  if (epilogue == EM_EPI_RESID_F32 && (p->N % 4 != 0 || p->ldc % 4 != 0)) return EM_ERR_UNSUPPORTED;  // 16-byte residual rows
+  if (epilogue == EM_EPI_RESID_F32 && a_mode == EM_A_PLAIN && (size_t)p->M * p->ldc * 4 >= ((size_t)1 << 31)) {
+    // the residual rows sit behind ONE buffer resource (31-bit offsets): a taller matrix runs as row slabs, each a
+    // launch of its own over its own resource (rows are independent; a very large batch must not turn into an error)
+    const size_t esz = dtype == EM_BF16 ? 2 : 4;
+    const int slab = (int)((((size_t)1 << 31) - 64) / ((size_t)p->ldc * 4));
+    if (slab <= 0) return EM_ERR_UNSUPPORTED;
+    for (int m0 = 0; m0 < p->M; m0 += slab) {
+      EmGemmArgs q = *p;
+      q.M = p->M - m0 < slab ? p->M - m0 : slab;
+      q.A = (const char*)p->A + (size_t)m0 * p->lda * esz;
+      q.C = (char*)p->C + (size_t)m0 * p->ldc * 4;
+      const int rc = em_gemm(dtype, epilogue, a_mode, &q, stream);
+      if (rc != EM_OK) return rc;
+    }
+    return EM_OK;
+  }
+  if (epilogue == EM_EPI_RESID_F32 && (size_t)p->M * p->ldc * 4 >= ((size_t)1 << 31)) return EM_ERR_UNSUPPORTED;
   if (a_mode == EM_A_CONV2) {
     const int kw = p->conv_k > 0 ? p->conv_k : 3;
     if (p->d <= 0 || p->d % bk != 0 || p->K != kw * kw * p->d) return EM_ERR_UNSUPPORTED;

@@ -220,6 +220,7 @@ int dispatch_mid(int epi, const EmGemmArgs* p, hipStream_t s) {
 int em_gemm_mid(int dtype, int epilogue, const EmGemmArgs* p, void* stream) {
   const int ks = dtype == EM_BF16 ? 32 : 16;
   if (p->K % ks != 0 || p->lda % (16 / (dtype == EM_BF16 ? 2 : 4)) != 0) return EM_ERR_UNSUPPORTED;
+  if ((size_t)p->M * p->ldc * 4 >= 0xffffffc0ull) return EM_ERR_UNSUPPORTED;  // 32-bit offsets of the raw-buffer epilogue
   if (dtype == EM_F32) return dispatch_mid<float>(epilogue, p, (hipStream_t)stream);
   if (dtype == EM_BF16) return dispatch_mid<bf16>(epilogue, p, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;

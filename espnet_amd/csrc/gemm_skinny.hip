@@ -217,6 +217,7 @@ int dispatch_skinny(int epi, const EmGemmArgs* p, hipStream_t s) {
 // for epilogues it does not implement (the tiled kernel then takes the launch).
 int em_gemm_skinny(int dtype, int epilogue, const EmGemmArgs* p, void* stream) {
   if (p->M > 16 * MAXMT) return EM_ERR_UNSUPPORTED;
+  if ((size_t)p->M * p->ldc * 4 >= 0xffffffc0ull) return EM_ERR_UNSUPPORTED;  // 32-bit offsets of the raw-buffer epilogue
   if (dtype == EM_F32) return dispatch_skinny<float>(epilogue, p, (hipStream_t)stream);
   if (dtype == EM_BF16) return dispatch_skinny<bf16>(epilogue, p, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;

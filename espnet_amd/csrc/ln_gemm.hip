@@ -226,6 +226,7 @@ extern "C" int em_ln_gemm(int dtype, int epilogue, const float* x, const float* 
                           int32_t K, int32_t ldc, void* stream) {
   if (!x || !ln_g || !ln_b || !W || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return EM_ERR_BAD_ARG;
   if (K % 64 != 0 || K > 64 * LG_MAXV) return EM_ERR_UNSUPPORTED;
+  if ((size_t)M * ldc * 4 >= 0xffffffc0ull) return EM_ERR_UNSUPPORTED;  // 32-bit offsets of the raw-buffer epilogue
   if (dtype == EM_F32)
     return dispatch_ln_gemm<float>(epilogue, x, ln_g, ln_b, eps, W, bias, C, M, N, K, ldc, (hipStream_t)stream);
   if (dtype == EM_BF16)

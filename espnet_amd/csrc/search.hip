@@ -709,7 +709,7 @@ __device__ __forceinline__ void ctc_chain_wg(const float2* __restrict__ rprev, c
     rn = logaddexp_(pre.a + rn0, pre.c);
     rb = logaddexp_(logaddexp_(pre.d + rn0, pre.e + rb0), pre.f);
   }
-  if (lane == 0) s_out[start - 1] = make_float2(rn0, rb0);
+  if (lane == 0 && start - 1 < xlen) s_out[start - 1] = make_float2(rn0, rb0);  // (i >= xlen: empty chain, slot out of range)
   for (int t = t_lo; t < t_hi; ++t) {
     const float nn = logaddexp_(rn, s_phi[t]) + s_xn[t];
     const float nb = logaddexp_(rn, rb) + s_xb[t];

@@ -42,6 +42,8 @@ class MI355XConformerEncoder(_ConformerEncoder, AbsEncoder):
     module is the reference's code path, not an accelerated one)."""
 
     def __new__(cls, *args, **kwargs):
+        if not args and not kwargs:  # copy.deepcopy / pickle re-create a Module through cls.__new__(cls) alone
+            return super().__new__(cls)
         bad = _ConformerEncoder.unsupported_options(*args, **kwargs)
         if bad:
             import logging

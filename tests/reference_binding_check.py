@@ -48,6 +48,17 @@ stock = A.MI355XConformerEncoder(80, output_size=d, attention_heads=1, linear_un
 out["defaults_build_stock"] = type(stock) is RefConformer and not isinstance(stock, A.MI355XConformerEncoder)
 out["fast_path_is_adapter"] = type(inst["MI355XConformerEncoder"]) is A.MI355XConformerEncoder
 out["unsupported_of_defaults"] = A.MI355XConformerEncoder.unsupported_options(80)
+# copy.deepcopy / pickle re-create a Module through cls.__new__(cls) with no arguments: the adapter's
+# stock-class fall-back in __new__ must not break them (espnet2's quantize_dynamic path, EMA copies, torch.save(model))
+import copy  # noqa: E402
+import pickle  # noqa: E402
+
+enc0 = inst["MI355XConformerEncoder"]
+dup = copy.deepcopy(enc0)
+rt = pickle.loads(pickle.dumps(enc0))
+out["deepcopy_ok"] = all(type(m) is A.MI355XConformerEncoder and
+                         all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), enc0.state_dict().values()))
+                         for m in (dup, rt))
 tables = A.register()
 out["registered"] = {k: sorted(n for n in t.classes if n.startswith("mi355x_")) for k, t in tables.items()}
 out["get_class"] = tables["decoder"].get_class("mi355x_transformer").__name__

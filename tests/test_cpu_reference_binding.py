@@ -30,6 +30,7 @@ def test_adapters_bind_to_reference_and_driver_equals_reference_search():
         "frontend": ["mi355x_default"], "normalize": ["mi355x_global_mvn", "mi355x_utterance_mvn"],
         "decoder": ["mi355x_transformer"], "lm": ["mi355x_seq_rnn", "mi355x_transformer"]}
     assert out["defaults_build_stock"] and out["fast_path_is_adapter"]
+    assert out["deepcopy_ok"]  # deepcopy / pickle of the adapter encoder (cls.__new__(cls) with no arguments)
     assert out["unsupported_of_defaults"] == ["macaron_style=False"]
     assert out["get_class"] == "MI355XTransformerDecoder"
     assert out["ref_search_full"] == ["decoder", "length_bonus", "lm"] and out["ref_search_part"] == ["ctc"]

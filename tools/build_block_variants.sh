@@ -5,7 +5,7 @@
 #   espnet_amd/lib/dbg/lib_v<n>.so   -DEM_BLOCK_VAR=<n>    (A/B variants: 1 pinned-group FFN iteration, 4 FFN chunk order
 #                                                           rotated per utterance, 16 packed-f32 depthwise conv; sums combine)
 #   espnet_amd/lib/dbg/lib_fine.so   -DEM_BLOCK_FINE=1     (EM_BLOCK_STAMPS=1 prints sub-stage stamps of all four waves)
-# Used for profiles/r02l, r02m, r02o, r02q and the round-3 A/B calls (tools/r03_ab.sh).  dbg builds give wrong results by
+# Used for profiles/r02l, r02m, r02o, r02q and the round-3 A/B calls (tools/gpu_calls.sh).  dbg builds give wrong results by
 # design: timing only.   usage: bash tools/build_block_variants.sh nt 4 v1 v16 fine
 set -eu
 cd "$(dirname "$0")/.."
