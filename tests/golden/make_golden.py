@@ -132,7 +132,7 @@ def g1_tokens(ids, exclude):
     return [int(x[0]) for x in groupby(ids) if int(x[0]) not in exclude]
 
 
-def fit_peaked_ctc_head(model, enc, olens, seed):
+def fit_peaked_ctc_head(model, enc, olens, seed, level=None):
     """A CTC head with PEAKED posteriors for the random-init encoder: random-init logits
     are nearly flat (top-2 margins of 1e-3 .. 1e-1), so "the bf16 path returns the reference's tokens" cannot be
     asked of them.  Here `ctc_lo` is FITTED (ridge regression, dual form) to a synthetic frame labelling - label
@@ -156,7 +156,11 @@ def fit_peaked_ctc_head(model, enc, olens, seed):
         t, k = t + run, k + 1
     rows = np.unique(want)
     Y = np.zeros((T, len(rows)))
-    Y[np.arange(T), np.searchsorted(rows, want)] = 8.0
+    # level None: logit 8 on the intended label (margins > 1).  level (lo, hi): the logit of frame t is drawn
+    # log-uniformly from [lo, hi] - the reference's top-2 margins then POPULATE that range (every other label sits at
+    # ~0), which is where a trained model's hard frames live (BF16_MARGIN probed from above)
+    amp = np.full(T, 8.0) if level is None else np.exp(rng.uniform(np.log(level[0]), np.log(level[1]), size=T))
+    Y[np.arange(T), np.searchsorted(rows, want)] = amp
     mu = E.mean(0)
     Ec = E - mu
     A = np.linalg.solve(Ec @ Ec.T + 1.0 * np.eye(T), Y)
@@ -171,7 +175,130 @@ def fit_peaked_ctc_head(model, enc, olens, seed):
                 ctc_b_rows=b[torch.from_numpy(rows)].numpy().copy(), ctc_fit_labels=want)
 
 
-def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, with_blocks=False, peaked_seed=None):
+def _ridge_rows(H, Y, lam):
+    """Rows (W, b) with W h_s + b ~= Y[s] for the states H (S, d), ridge regression in its dual form around the
+    mean state (S < d: an interpolating fit, as a trained head separates its training frames)."""
+    mu = H.mean(0)
+    Hc = H - mu
+    A = np.linalg.solve(Hc @ Hc.T + lam * np.eye(H.shape[0]), Y - Y.mean(0))
+    W = (Hc.T @ A).T
+    return W, Y.mean(0) - W @ mu
+
+
+def fit_peaked_search_heads(model, enc, olens, seed, g_adjust=None):
+    """PEAKED posteriors for the joint CTC/attention search of a random-init model: with flat
+    random-init posteriors the reference's own n-best hypotheses differ by 1e-3 in score, so "the bf16 search returns
+    the reference's n-best" cannot be asked of them.  Here `ctc.ctc_lo` and `decoder.output_layer` are FITTED on the
+    REFERENCE's own encoder output / decoder states to a synthetic transcript y* (label runs of 2-4 frames between
+    blank runs of 1-3) the way trained heads behave: on the frames of token k the CTC head puts logit 12 on y*_k and,
+    at five positions, 12 - c_k on ONE confusable label alt_k; after the prefix y*_<k (or the same prefix with earlier
+    tokens replaced by their confusables) the decoder puts 12 on y*_k and 12 - g_k on alt_k, <eos> after the last
+    token.  The hypothesis space the search then explores is y* and its substitution variants with designed, well
+    separated costs (0.7 g_k + 0.3 x CTC cost); every other row of both heads keeps its recipe weights (no exact ties).
+    Everything downstream - log-softmax, prefix scores, pre-beam, pruning, n-best - is computed by the reference with
+    those heads.  The fitted rows are stored in the fixture (`ctcov_*`, `decov_*`) and laid over the recipe weights by
+    tests/helpers.py::golden_state_dict."""
+    rng = np.random.RandomState(seed)
+    V = model.ctc.ctc_lo.weight.size(0)
+    T = int(olens[0])
+    E = enc[0, :T].double().numpy()
+    d = E.shape[1]
+    npool = min(200, V - 3)
+    pool = rng.choice(np.arange(2, V - 1), size=npool, replace=False)
+    # frame labelling
+    want = np.zeros(T, dtype=np.int64)
+    runs = []
+    t, used = 0, 0
+    while True:
+        t += int(rng.randint(1, 4))
+        run = int(rng.randint(2, 5))
+        if t + run > T - 1:
+            break
+        # (all labels distinct: a random-init decoder's state is dominated by the embedding of the last token - the
+        # position and the rest of the prefix are 1/sqrt(d)-sized corrections - so a label that recurs would ask the
+        # head for two different continuations of nearly the same state)
+        lab, used = int(pool[used]), used + 1
+        want[t : t + run] = lab
+        runs.append((lab, t, run))
+        t += run
+    L = len(runs)
+    y_star = [r[0] for r in runs]
+    # Five positions get a confusable label.  Their substitution costs (in joint score: 0.7 x decoder logit gap +
+    # 0.3 x CTC cost) are DESIGNED so that the ten cheapest subsets of substitutions - the n-best of a beam-10 search:
+    # the decoder's state hardly depends on earlier tokens, so substitutions combine additively - are 0.54 apart
+    # (random search over 4e5 cost vectors for the largest minimum gap of the eleven smallest subset sums, all ten
+    # within 7 of the best so that they stay clear of the unfitted hypotheses, which cost ~ 9.5).  55 % of a cost sits
+    # in the decoder (logit gap <= 5.8: the confusable stays far above the recipe rows' logits, |.| < 2, so it is in
+    # every pre-beam), 45 % in the CTC head.
+    design = np.array([1.51851315, 2.0921559, 2.63192038, 5.28805857, 7.39653826])
+    alt_pos = np.sort(rng.choice(np.arange(1, L - 1), size=5, replace=False))
+    design = design[rng.permutation(5)]
+    alts = [-1] * L
+    c, g = np.zeros(L), np.zeros(L)
+    for q, k in enumerate(alt_pos):
+        alts[k] = int(pool[npool - 5 + q])
+        c[k] = 0.45 * design[q] / 0.3 / runs[k][2]
+        g[k] = 0.55 * design[q] / 0.7
+        if g_adjust is not None:  # (later passes: the CTC cost of a run is only roughly run x c; see run_search_case)
+            g[k] += g_adjust[q]
+    TOP = 12.0  # logit of the intended label (p ~ 0.97 against 5 000 recipe-weight rows)
+    assert T < d
+    # ---- CTC head: rows of blank, y*, alts
+    rows_c = np.unique(np.array([0] + y_star + [a for a in alts if a >= 0]))
+    Yc = np.zeros((T, len(rows_c)))
+    col = {int(r): i for i, r in enumerate(rows_c)}
+    Yc[:, col[0]] = np.where(want == 0, TOP, 0.0)
+    for k, (lab, t0, run) in enumerate(runs):
+        Yc[t0 : t0 + run, col[lab]] = TOP
+        if alts[k] >= 0:
+            Yc[t0 : t0 + run, col[alts[k]]] = TOP - c[k]
+    Wc, bc = _ridge_rows(E, Yc, 1.0)
+    rc = torch.from_numpy(rows_c)
+    model.ctc.ctc_lo.weight[rc] = torch.from_numpy(Wc).float()
+    model.ctc.ctc_lo.bias[rc] = torch.from_numpy(bc).float()
+    # ---- decoder head: states of y* and of every single-substitution variant, teacher-forced through the reference
+    eos = V - 1
+    states, targets = [], []
+    rows_d = np.unique(np.array(y_star + [a for a in alts if a >= 0] + [eos]))
+    cold = {int(r): i for i, r in enumerate(rows_d)}
+    grabbed = []
+    hook = model.decoder.output_layer.register_forward_hook(lambda m, inp, out: grabbed.append(inp[0].detach()))
+    seqs = [(0, list(y_star))] + [(int(k) + 1, y_star[:k] + [alts[k]] + y_star[k + 1 :]) for k in alt_pos]
+    for first, seq in seqs:  # (the variant with position k replaced shares its states 0..k with y*)
+        ys_in = torch.tensor([[eos] + seq], dtype=torch.long)
+        grabbed.clear()
+        model.decoder(enc[:, :T], torch.tensor([T]), ys_in, torch.tensor([L + 1]))
+        h = grabbed[0][0].double().numpy()  # (L + 1, d): state j predicts token j
+        for j in range(first, L + 1):
+            y = np.zeros(len(rows_d))
+            if j < L:
+                y[cold[y_star[j]]] = TOP
+                if alts[j] >= 0:
+                    y[cold[alts[j]]] = TOP - g[j]
+            else:
+                y[cold[eos]] = TOP
+            states.append(h[j])
+            targets.append(y)
+    hook.remove()
+    H, Yd = np.stack(states), np.stack(targets)
+    assert H.shape[0] < d, H.shape
+    Wd, bd = _ridge_rows(H, Yd, 1.0)
+    rd = torch.from_numpy(rows_d)
+    model.decoder.output_layer.weight[rd] = torch.from_numpy(Wd).float()
+    model.decoder.output_layer.bias[rd] = torch.from_numpy(bd).float()
+    fit_err = float(np.abs(H @ Wd.T + bd - Yd).max())
+    print(f"  fitted heads: L={L} tokens, {H.shape[0]} decoder states, |W_dec row| max {np.linalg.norm(Wd, axis=1).max():.2f}, "
+          f"|W_ctc row| max {np.linalg.norm(Wc, axis=1).max():.2f}, decoder fit err {fit_err:.3f}")
+    return dict(ctcov_rows=rows_c, ctcov_w=model.ctc.ctc_lo.weight[rc].numpy().copy(),
+                ctcov_b=model.ctc.ctc_lo.bias[rc].numpy().copy(),
+                decov_rows=rows_d, decov_w=model.decoder.output_layer.weight[rd].numpy().copy(),
+                decov_b=model.decoder.output_layer.bias[rd].numpy().copy(),
+                y_star=np.array(y_star), y_alts=np.array(alts), fit_frames=want, alt_pos=alt_pos,
+                design_cost=design)
+
+
+def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, with_blocks=False, peaked_seed=None,
+                    peaked_level=None):
     t0 = time.time()
     with tempfile.TemporaryDirectory() as td:
         s2t, cfg_text = build_reference(conf, vocab, td, beam_size=1, ctc_weight=1.0)
@@ -207,7 +334,7 @@ def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, wi
             blocks.append(xs[0].numpy().copy())
         out["block_outs"] = np.stack(blocks)
     if peaked_seed is not None:
-        out.update(fit_peaked_ctc_head(model, enc, olens, peaked_seed))
+        out.update(fit_peaked_ctc_head(model, enc, olens, peaked_seed, peaked_level))
     logp = model.ctc.log_softmax(enc)
     ids = model.ctc.argmax(enc)
     out["ctc_ids"] = ids.numpy()
@@ -227,8 +354,30 @@ def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, wi
           f"min margin={out['ctc_margin'].min():.2e}")
 
 
+def qualify_peaked_nbest(model, enc, results, beam, ctc_weight, noise, seeds=4):
+    """Is the reference's n-best separated by more than a reduced-precision implementation's error?  The oracle search
+    (pinned to the reference: without noise it must reproduce `results` exactly) is re-run with N(0, noise^2) added to
+    every decoder log-probability and CTC log-posterior; the n-best token sequences must not move."""
+    from oracle import beam_search as ob
+
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    dc = model.decoder
+    heads = dc.decoders[0].self_attn.h
+    ref = [h.yseq.tolist() for _, _, _, h in results]
+    for k in range(seeds + 1):
+        got = ob.beam_search(sd, enc, heads, len(dc.decoders), beam, ctc_weight, model.sos, model.eos,
+                             noise=noise if k else 0.0, noise_seed=k)
+        mine = [r["yseq"] for r in got[: len(ref)]]
+        if mine != ref:
+            moved = [i for i, (a, b) in enumerate(zip(mine, ref)) if a != b]
+            raise AssertionError(f"n-best moved under noise {noise if k else 0.0} (seed {k}): ranks {moved}; "
+                                 f"scores {[round(r['score'], 3) for r in got[:len(ref)]]}")
+    return noise
+
+
 def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weight, nbest,
-                    keep_every=1, penalty=0.0, maxlenratio=0.0, minlenratio=0.0, tweaks=None):
+                    keep_every=1, penalty=0.0, maxlenratio=0.0, minlenratio=0.0, tweaks=None, peaked_seed=None,
+                    qualify_noise=0.05):
     t0 = time.time()
     with tempfile.TemporaryDirectory() as td:
         s2t, cfg_text = build_reference(conf, vocab, td, beam_size=beam, ctc_weight=ctc_weight,
@@ -238,9 +387,42 @@ def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weigh
     shapes = load_recipe(model, wseed, tweaks)
     wav = synth_waveform(utt_id, n_samples)
     enc, olens = model.encode(wav[None], torch.tensor([n_samples]))
+    extra = {}
+    if peaked_seed is not None:
+        # fit, measure the realised cost of each single substitution (teacher-forced under the oracle's scorers), move
+        # the decoder gaps by the difference to the designed costs, fit again
+        from tests.helpers import oracle_rescore
+
+        adjust = np.zeros(5)
+        dcf = conf["decoder_conf"]
+        for it in range(3):
+            extra = fit_peaked_search_heads(model, enc, olens, peaked_seed, adjust)
+            sd_now = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            e = enc[0, : int(olens[0])]
+            ys = [int(x) for x in extra["y_star"]]
+            eos = vocab - 1
+            base = oracle_rescore(sd_now, e, [eos] + ys + [eos], dcf["attention_heads"], dcf["num_blocks"], ctc_weight, eos)
+            real = []
+            for q, k in enumerate(extra["alt_pos"]):
+                v = list(ys)
+                v[int(k)] = int(extra["y_alts"][int(k)])
+                r = oracle_rescore(sd_now, e, [eos] + v + [eos], dcf["attention_heads"], dcf["num_blocks"], ctc_weight, eos)
+                real.append(base["score"] - r["score"])
+            real = np.array(real)
+            print(f"  pass {it}: realised single-substitution costs {np.round(real, 3)} designed {np.round(extra['design_cost'], 3)}")
+            adjust = adjust + (extra["design_cost"] - real) / (1.0 - ctc_weight)
+        extra["realised_cost"] = real
     t1 = time.time()
     results = s2t(wav.numpy())
     t_dec = time.time() - t1
+    if peaked_seed is not None:
+        sc = [float(h.score) for _, _, _, h in results]
+        print("  n-best scores", [round(x, 3) for x in sc], "lens", [len(h.yseq) for _, _, _, h in results])
+        extra["nbest_min_gap"] = np.array(min(a - b for a, b in zip(sc, sc[1:])))
+        if os.environ.get("PEAKED_NOQUAL"):  # (debugging a candidate fixture: dump it unqualified)
+            qualify_noise = 0.0
+        extra["noise_qualified"] = np.array(qualify_peaked_nbest(model, enc[0, : int(olens[0])], results, beam,
+                                                                 ctc_weight, qualify_noise))
     L = max(len(h.yseq) for _, _, _, h in results)
     yseq = np.full((len(results), L), -1, dtype=np.int64)
     for i, (_, _, _, h) in enumerate(results):
@@ -263,6 +445,7 @@ def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weigh
         token_int_best=np.array(results[0][2], dtype=np.int64),
         ref_seconds=np.array(t_dec),
     )
+    out.update(extra)
     np.savez_compressed(HERE / f"{name}.npz", **out)
     print(f"[{name}] done in {time.time()-t0:.1f}s (Speech2Text {t_dec:.1f}s) T={enc.shape[1]} "
           f"best len={len(results[0][3].yseq)} score={float(results[0][3].score):.4f} keys={keys}")
@@ -425,7 +608,8 @@ def run_streaming_case(name, enc_conf, wseed, utt_id, n_samples, chunk_frames, k
 
 def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples, beam, ctc_weight, nbest,
                            tweaks=None, disable_repetition_detection=False, penalty=0.0, lm_conf=None,
-                           lm_name="transformer", lm_weight=0.0):
+                           lm_name="transformer", lm_weight=0.0, width=64, heads=1, peaked_seed=None,
+                           qualify_noise=0.05):
     """Speech2TextStreaming end to end (espnet2/bin/asr_inference_streaming.py:293-336): waveform chunks
     -> apply_frontend -> ContextualBlockConformerEncoder.forward_infer -> BatchBeamSearchOnline.forward
     (espnet2/legacy/nets/batch_beam_search_online.py:155-534, block 40 / hop 16 / look-ahead 16).
@@ -435,9 +619,9 @@ def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples,
     from espnet2.bin.asr_inference_streaming import Speech2TextStreaming
 
     t0 = time.time()
-    conf = tiny(d=64, heads=1, ff=128)
+    conf = tiny(d=width, heads=heads, ff=128)
     conf["encoder"] = "contextual_block_conformer"
-    conf["encoder_conf"] = dict(STREAM_TINY)
+    conf["encoder_conf"] = dict(STREAM_TINY, output_size=width, attention_heads=heads)
     events = []
 
     class Grab(logging.Handler):
@@ -484,17 +668,71 @@ def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples,
         return orig_bs(x=x, maxlenratio=maxlenratio, minlenratio=minlenratio, is_final=is_final)
 
     s2t.beam_search.forward = spy
-    pos = 0
-    while pos < n_samples:
-        nxt = min(n_samples, pos + chunk_samples)
-        n_before = len(enc_chunks)
-        ev0 = len(events)
-        res = s2t(wav[pos:nxt].numpy(), is_final=(nxt == n_samples))
-        calls.append(dict(
-            searched=len(enc_chunks) > n_before, events=events[ev0:],
-            hyps=[dict(yseq=[int(v) for v in hy.yseq.tolist()], score=float(hy.score),
-                       scores={k: float(v) for k, v in hy.scores.items()}) for _, _, _, hy in res]))
-        pos = nxt
+
+    def decode_stream():
+        pos = 0
+        while pos < n_samples:
+            nxt = min(n_samples, pos + chunk_samples)
+            n_before = len(enc_chunks)
+            ev0 = len(events)
+            res = s2t(wav[pos:nxt].numpy(), is_final=(nxt == n_samples))
+            calls.append(dict(
+                searched=len(enc_chunks) > n_before, events=events[ev0:],
+                hyps=[dict(yseq=[int(v) for v in hy.yseq.tolist()], score=float(hy.score),
+                           scores={k: float(v) for k, v in hy.scores.items()}) for _, _, _, hy in res]))
+            pos = nxt
+
+    decode_stream()
+    extra = {}
+    if peaked_seed is not None:
+        # the encoder does not depend on the heads: take the frames of a first pass, fit both heads on them
+        # (fit_peaked_search_heads: the decoder states are teacher-forced over the WHOLE memory; the online search
+        # sees it block by block, so its costs are near, not at, the designed ones), decode the stream again
+        enc_first = torch.cat(enc_chunks, 0)
+        extra = fit_peaked_search_heads(model, enc_first[None], torch.tensor([enc_first.size(0)]), peaked_seed)
+        calls.clear(), enc_chunks.clear(), events.clear()
+        decode_stream()
+        assert torch.equal(torch.cat(enc_chunks, 0), enc_first)
+        final = calls[-1]["hyps"]
+        sc = [hy["score"] for hy in final]
+        print("  final n-best scores", [round(x, 3) for x in sc], "lens", [len(hy["yseq"]) for hy in final])
+        # The block-synchronous search keeps what the offline one prunes (hypotheses that took a local <eos>, the
+        # reference's duplicates at the end of a block), so the tail of its n-best is again decided among unfitted,
+        # flat alternatives.  What is pinned is the SEPARATED HEAD of every call's list: the leading hypotheses up to
+        # the first gap below 0.5 between different scores (exact duplicates count as one).
+        def separated_head(hyps):
+            n, i = 0, 0
+            while i < len(hyps):
+                j = i
+                while j + 1 < len(hyps) and hyps[j + 1]["yseq"] == hyps[i]["yseq"]:
+                    j += 1  # a group of exact duplicates
+                if j + 1 < len(hyps) and hyps[i]["score"] - hyps[j + 1]["score"] < 0.5:
+                    break
+                n, i = j + 1, j + 1
+            return n
+
+        sep = [separated_head(c["hyps"]) for c in calls]
+        print("  separated head per call:", sep)
+        assert sep[-1] >= 1
+        extra["sep_counts"] = np.array(sep)
+        # qualification as for the offline fixture: the oracle's online search under noise returns the same separated
+        # head at every call
+        from oracle.beam_search_online import OnlineBeamSearchOracle
+
+        sd_now = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        dcf = conf["decoder_conf"]
+        for k in range(5):
+            orc = OnlineBeamSearchOracle(sd_now, dcf["attention_heads"], dcf["num_blocks"], beam, ctc_weight,
+                                         sos=vocab - 1, eos=vocab - 1, penalty=penalty,
+                                         disable_repetition_detection=disable_repetition_detection,
+                                         noise=qualify_noise if k else 0.0, noise_seed=k)
+            p2 = 0
+            for ci, (call, c) in enumerate(zip(calls, enc_chunks)):
+                res = orc.forward(c, is_final=(ci == len(calls) - 1))[:nbest]
+                got = [r["yseq"] for r in res][: sep[ci]]
+                want = [hy["yseq"] for hy in call["hyps"]][: sep[ci]]
+                assert got == want, f"online n-best moved under noise {qualify_noise if k else 0.0} (seed {k}, call {ci})"
+        extra["noise_qualified"] = np.array(qualify_noise)
     logging.getLogger().removeHandler(h)
     enc_all = torch.cat(enc_chunks, 0) if enc_chunks else torch.zeros(0, 64)
     np.savez_compressed(
@@ -507,7 +745,7 @@ def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples,
         melmat=model.frontend.logmel.melmat.numpy(), enc_all=enc_all.numpy(),
         enc_lens=np.array([int(c.size(0)) for c in enc_chunks]), calls=np.array(json.dumps(calls)),
         lm_conf=np.array(json.dumps(lm_conf)), lm_name=np.array(lm_name), lm_weight=np.array(lm_weight),
-        lm_state_shapes=np.array(json.dumps({k: list(v) for k, v in lm_shapes.items()})))
+        lm_state_shapes=np.array(json.dumps({k: list(v) for k, v in lm_shapes.items()})), **extra)
     print(f"[{name}] done in {time.time()-t0:.1f}s enc chunks {[int(c.size(0)) for c in enc_chunks]}")
     for k, c in enumerate(calls):
         print(f"   call {k}: searched={c['searched']} events={c['events']} n_hyps={len(c['hyps'])} "
@@ -615,6 +853,10 @@ CASES = {
     # bf16 path must return the reference's G1 tokens exactly)
     "small_10s_peaked": lambda: run_encode_case("small_10s_peaked", SMALL, 5000, 11, [0], [160000], keep_every=4,
                                                 peaked_seed=5),
+    # ... and with the fitted logits scaled down so that the reference's top-2 margins fill 0.05 .. 1.5: frames a
+    # trained model finds hard, all above the bf16 flip bound
+    "small_10s_midmargin": lambda: run_encode_case("small_10s_midmargin", SMALL, 5000, 11, [0], [160000], keep_every=4,
+                                                   peaked_seed=5, peaked_level=(0.06, 1.5)),
     "small_ragged": lambda: run_encode_case("small_ragged", SMALL, 5000, 11, [1, 2, 3],
                                             [48000, 37123, 16000]),
     # tiny model with every block output pinned (oracle block-by-block check)
@@ -630,6 +872,10 @@ CASES = {
                                                0.3, 10, keep_every=2),
     "large_beam10_10s": lambda: run_search_case("large_beam10_10s", LARGE, 5000, 13, 9, 160000,
                                                 10, 0.3, 10, keep_every=8),
+    # the same search with heads FITTED to a synthetic transcript (peaked posteriors, separated n-best: the bf16 search
+    # must return the reference's n-best token sequences exactly)
+    "large_beam10_3s_peaked": lambda: run_search_case("large_beam10_3s_peaked", LARGE, 5000, 13, 8, 48000, 10,
+                                                      0.3, 10, keep_every=2, peaked_seed=3),
     # tiny joint search (fast unit-level fixture for the search restatement)
     "tiny_beam5": lambda: run_search_case("tiny_beam5", tiny(d=64, heads=2, ff=128), 50, 7, 10,
                                           24000, 5, 0.3, 5),
@@ -742,6 +988,10 @@ CASES = {
     "stream_search_gru": lambda: run_stream_search_case(
         "stream_search_gru", 50, 26, 46, 56000, 10240, 3, 0.4, 3, tweaks=[["decoder.output_layer.bias", 49, 2.0]],
         lm_conf=dict(unit=64, nlayers=2, rnn_type="gru"), lm_name="seq_rnn", lm_weight=0.6),
+    # streaming decode on PEAKED posteriors (heads fitted to a transcript, as large_beam10_3s_peaked): the bf16 online
+    # search must return the reference's n-best at every call
+    "stream_search_peaked": lambda: run_stream_search_case(
+        "stream_search_peaked", 300, 27, 47, 48000, 10240, 5, 0.3, 5, width=128, heads=2, peaked_seed=4),
     "stream_tiny_short": lambda: run_streaming_case("stream_tiny_short", STREAM_TINY, 18, 22, 4800, 1000),
 }
 

@@ -31,6 +31,11 @@ def golden_state_dict(g):
         sd["ctc.ctc_lo.bias"] = torch.zeros_like(sd["ctc.ctc_lo.bias"])
         sd["ctc.ctc_lo.weight"][rows] = torch.from_numpy(np.asarray(g["ctc_w_rows"]))
         sd["ctc.ctc_lo.bias"][rows] = torch.from_numpy(np.asarray(g["ctc_b_rows"]))
+    for key, pre in (("ctc.ctc_lo", "ctcov"), ("decoder.output_layer", "decov")):
+        if pre + "_rows" in g:  # fitted rows laid over the recipe weights: make_golden.py::fit_peaked_search_heads
+            rows = torch.from_numpy(np.asarray(g[pre + "_rows"]))
+            sd[key + ".weight"][rows] = torch.from_numpy(np.asarray(g[pre + "_w"]))
+            sd[key + ".bias"][rows] = torch.from_numpy(np.asarray(g[pre + "_b"]))
     return sd
 
 
@@ -106,3 +111,10 @@ def oracle_rescore(sd, enc, yseq, heads, num_blocks, ctc_weight, eos, maxlen=Non
             s_ctc += float(delta[0, nxt])
             r_prev, s_prev = r_new[:, :, :, 0], log_psi[:, nxt]
     return {"decoder": s_dec, "ctc": s_ctc, "score": (1.0 - ctc_weight) * s_dec + ctc_weight * s_ctc}
+
+
+def oracle_rescore_batch(sd, enc, yseqs, heads, num_blocks, ctc_weight, eos, maxlen=None, lm_conf=None):
+    """oracle.beam_search.rescore_batch (kept under this name for the tests)."""
+    from oracle.beam_search import rescore_batch
+
+    return rescore_batch(sd, enc, yseqs, heads, num_blocks, ctc_weight, eos, maxlen=maxlen, lm_conf=lm_conf)

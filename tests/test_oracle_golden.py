@@ -49,7 +49,7 @@ def test_stft_olens_formula():
     assert (feats[1, 8:] == 0).all()
 
 
-@pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "small_10s_peaked", "large_10s",
+@pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "small_10s_peaked", "small_10s_midmargin", "large_10s",
                                   "sub6_small_6s", "sub8_small_6s", "legacy_small_5s", "legacy_small_12s"])
 def test_frontend_and_encoder_match_reference(name):
     g = load_golden(name)
@@ -125,7 +125,7 @@ def test_too_short():
 
 # --------------------------------------------------------------------------- beam search (A12-A14)
 SEARCH_CASES = ["tiny_beam5", "tiny_beam3_attn_only", "tiny_beam4_early_eos", "tiny_beam4_minlen",
-                "small_g2_3s", "large_beam10_3s"]
+                "small_g2_3s", "large_beam10_3s", "large_beam10_3s_peaked"]
 
 
 def run_oracle_search(g):
@@ -250,7 +250,7 @@ def test_beam_search_with_lm_scorer_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["stream_search_a", "stream_search_b", "stream_search_c", "stream_search_lm",
-                                  "stream_search_rnnlm", "stream_search_gru"])
+                                  "stream_search_rnnlm", "stream_search_gru", "stream_search_peaked"])
 def test_online_beam_search_matches_reference_per_call(name):
     """BatchBeamSearchOnline (block-synchronous search with CTC extend_prob /
     extend_state, repetition / local-<eos> breaks, rewind, end detection) — the oracle replays the
