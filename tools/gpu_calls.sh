@@ -1,5 +1,5 @@
 #!/bin/bash
-# The GPU-box calls of round 3 in one place (each was one `gpurun -- bash tools/gpu_calls.sh <what> <tag>`; output under
+# The GPU-box calls of rounds 3 and 4 in one place (each was one `gpurun -- bash tools/gpu_calls.sh <what> <tag>`; output under
 # gpurun_out/<tag>/, the summaries that are quoted in DESIGN.md copied to profiles/<tag>_*).
 #   full         the whole `pytest -m gpu` suite, smoke, the default bench line, rocprofv3 table of the greedy step
 #   bench        smoke, the default bench line (roofline + traffic + cpu baseline + beam + stream legs), rocprofv3 table
@@ -22,6 +22,14 @@ stats() {  # <dir> <cmd...>: rocprofv3 --kernel-trace --stats of a command, summ
 }
 beam_line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['search']['ms_per_search_step'])"; }
 case "$what" in
+  parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
+    echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
+    echo "== new parity tests"
+    (time timeout 900 python -m pytest -q -s -x tests/test_gpu_search.py tests/test_gpu_online_search.py tests/test_gpu_fullsize.py tests/test_gpu_e2e.py \
+       -k "peaked or bf16 or midmargin or structure or lm_scorer_bf16 or restarts" 2>&1 | grep -v "^$" | tail -60) 2>&1 | tee "$out/pytest_parity.txt"
+    echo "== large encoder B=64: kernel stats"
+    stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3
+    echo "== default bench"; (time timeout 900 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5 ;;
   full|bench)
     if [ "$what" = full ]; then
       echo "== pytest -m gpu"; (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) 2>&1 | tee "$out/pytest_gpu.txt"
