@@ -7,9 +7,9 @@
 
 A "step" = one pass of the hot path over one batch of synthetic utterances already resident in
 HBM: HIP STFT/log-mel frontend -> HIP Conformer encoder (fused block kernels) -> greedy CTC (G1)
-decode -> the hypotheses of ALL ranks collated by `espnet_amd.distributed` (fixed-shape records, ONE
-RCCL all-gather per step when N > 1) and copied to the host (pinned, asynchronous; step k's records are
-delivered while step k+1 is being launched, all K delivered inside the timed region).  Workload =
+decode -> the hypotheses of ALL ranks collated by `espnet_amd.distributed.RecordRing` (fixed-shape records
+written in place into a device ring; ONE RCCL all-gather when N > 1 and ONE pinned, asynchronous device->host
+copy per 16 steps, delivered while the next steps run, all K delivered inside the timed region).  Workload =
 BASELINE.json configs[1]: Conformer-small (12 x 256d, 4 heads, ff 1024), batch 32 x 10 s @ 16 kHz per
 GPU (weak scaling: per-GPU batch fixed).  Random-init weights (torch.manual_seed(0)), synthetic
 N(0, 0.1^2) waveforms.
@@ -48,6 +48,7 @@ N_SAMPLES = 160000
 VOCAB = 5000
 MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+RING_STEPS = 16  # steps per collation macro-batch (espnet_amd.distributed.RecordRing)
 FRONTEND_BYTES_PER_UTT = 160000 * 4 + 1001 * 80 * 4  # wave in + log-mel out (f32)
 # the reference's own Speech2Text on CPU (the path cpu_baseline stands in for)
 REFERENCE_MEASURED = {  # 8 vCPU Xeon @ 2.1 GHz survey container, torch CPU fp32, one 10 s utterance
@@ -411,53 +412,6 @@ def cpu_baseline_stream(model, enc_conf, budget_s=8.0):
                       f"forward_infer, no decoding), {len(times)} utterances of 10 s, median {med:.2f} s/utt"}
 
 
-class HypothesisSink:
-    """Collation of a step's hypotheses: `espnet_amd.distributed.gather_records` (one all-gather per tensor over
-    RCCL when N > 1; identity at N = 1), then -- on rank 0, the rank that owns the results -- an asynchronous copy
-    into pinned host buffers and `unpack_records` into global utterance order.  Two buffer sets: step k's records
-    are delivered while step k+1 is already enqueued, so the GPU never waits for the host; `drain()` delivers the
-    last one (inside the timed region)."""
-
-    def __init__(self, rank, world, B, width, dev, host_gloo=False):
-        from espnet_amd import distributed as D
-
-        self.D, self.rank, self.world, self.n_items, self.host_gloo = D, rank, world, world * B, host_gloo
-        self.zero = torch.zeros(B, dtype=torch.float32, device=dev)
-        rows = world * B
-        self.pinned = [(torch.empty(rows, width, dtype=torch.int32).pin_memory(),
-                        torch.empty(rows, dtype=torch.int32).pin_memory(),
-                        torch.empty(rows, dtype=torch.float32).pin_memory()) for _ in range(2)]
-        self.events = [torch.cuda.Event(), torch.cuda.Event()]
-        self.pending, self.k, self.delivered, self.last = None, 0, 0, None
-
-    def push(self, ids, lens, scores=None):
-        scores = self.zero if scores is None else scores
-        if self.host_gloo:  # developer check on a one-GPU box: the collective runs on host copies over gloo
-            g = self.D.gather_records(ids.cpu(), lens.cpu(), scores.cpu())
-        else:
-            g = self.D.gather_records(ids, lens, scores)
-        if self.rank != 0:
-            return
-        slot = self.k & 1
-        for dst, src in zip(self.pinned[slot], g):
-            dst.copy_(src, non_blocking=True)
-        self.events[slot].record()
-        prev, self.pending = self.pending, slot
-        self.k += 1
-        if prev is not None:
-            self._deliver(prev)
-
-    def _deliver(self, slot):
-        self.events[slot].synchronize()
-        self.last = self.D.unpack_records(*self.pinned[slot], self.n_items, self.world, as_arrays=True)
-        self.delivered += 1
-
-    def drain(self):
-        if self.pending is not None:
-            self._deliver(self.pending)
-            self.pending = None
-
-
 class HostFeeder:
     """Waveforms arriving in pinned host memory (the boundary's real input): batch k+1 is copied host -> device
     on a copy stream into the second device buffer while batch k computes."""
@@ -534,7 +488,7 @@ def decoder_step_bytes(model, B, W, T, NC, steps, es):
     return w + mem + cache + logits + ctc
 
 
-def run_beam(args, dev, B, beam, steps, warmup, cpu_base, sink_factory, want_traffic=True):
+def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True):
     """configs[2] / configs[3]'s per-GPU batch: Conformer-large + 6-layer decoder, joint CTC/attention beam search."""
     from espnet_amd import distributed as D
     from espnet_amd.nets.batch_beam_search import build_beam_search
@@ -545,10 +499,10 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, sink_factory, want_tra
     bs = build_beam_search(model, beam_size=beam, ctc_weight=args.ctc_weight, penalty=0.0,
                            token_list=model.token_list)
     rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     wav = synth_batch(rank * B, B).to(dev)
     lens = [N_SAMPLES] * B
     T = model.encoder.output_frames(1 + N_SAMPLES // 160)
-    sink = sink_factory(B, T + 2)
     t_search = [0.0, 0]
     last = {}
 
@@ -561,26 +515,38 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, sink_factory, want_tra
         if instrument:
             t_search[0] += time.perf_counter() - t0
             t_search[1] += bs.last_steps
+            last["nbest0"], last["enc0"] = nbest[0], st.enc_act[0, : int(st.olens[0])].clone()
         toks = [[t for t in h[0].yseq[1:-1].tolist()] if h else [] for h in nbest]
         sc = [float(h[0].score) if h else 0.0 for h in nbest]
-        sink.push(*D.pack_hypotheses(toks, sc, T + 2, B, dev))
-        if instrument:
-            last["nbest0"], last["enc0"] = nbest[0], st.enc_act[0, : int(st.olens[0])].clone()
+        return toks, sc
 
     def barrier():
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    elapsed = timed_loop(step, steps, warmup, barrier, sink.drain)
+    # N > 1: DYNAMIC dispatch - the job is world * steps batches, ranks pull batch indices from a shared counter
+    # (espnet_amd.distributed.decode_dynamic), records carry their global utterance index and are collated once at the
+    # end of the timed region: a slow GPU or early-ending beams cost the job their own share only.  N = 1: the same
+    # loop, the counter is local.
+    run_id = run_beam.calls = getattr(run_beam, "calls", 0) + 1
     with torch.no_grad():
+        for _ in range(warmup):
+            step()
+        barrier()
+        counter = D.SharedCounter(D.work_store() if world > 1 else None, f"bench_beam_{run_id}")
+        t0 = time.perf_counter()
+        hyps, mine = D.decode_dynamic(lambda u: (list(range(u * B, u * B + B)), *step()), world * steps,
+                                      world * steps * B, T + 2, dev, counter=counter)
+        barrier()
+        elapsed = time.perf_counter() - t0
         step(instrument=True)
-        sink.drain()
+    n_tok = sum(len(t) for t, _ in hyps[-B:])
     es = 2 if args.dtype == "bfloat16" else 4
     S = bs.pre_beam_size if bs.do_pre_beam else VOCAB
     n_steps = t_search[1]
     per_step = decoder_step_bytes(model, B, beam, T, S + 1, n_steps, es)
-    res = {"model": model, "elapsed": elapsed, "tokens": int(sink.last[1].sum()) if sink.last else 0,
+    res = {"model": model, "elapsed": elapsed, "tokens": n_tok, "steps_this_rank": len(mine),
            "search": {"ms_per_search_step": round(t_search[0] / max(1, n_steps) * 1e3, 4),
                       "search_steps_per_utt_batch": n_steps, "steps_per_s": round(n_steps / t_search[0], 1),
                       "rows": B * beam,
@@ -894,14 +860,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from espnet_amd import distributed as D
+
     def sink_factory(B, width):
-        return HypothesisSink(rank, world, B, width, dev, host_gloo=args.dist_debug_one_gpu)
+        # device ring of RING_STEPS steps' records, written in place by the CTC collapse kernel; one all-gather (N > 1)
+        # and one device->host copy per RING_STEPS steps, delivered while the next steps run
+        return D.RecordRing(rank, world, B, width, RING_STEPS, dev, host_gloo=args.dist_debug_one_gpu)
 
     B = args.batch
     extras = {}
     if args.workload == "beam":
         r = run_beam(args, dev, B, args.beam, args.steps, args.warmup,
-                     cpu_base=(rank == 0 and world == 1 and not args.no_cpu_baseline), sink_factory=sink_factory)
+                     cpu_base=(rank == 0 and world == 1 and not args.no_cpu_baseline))
         model, elapsed, n_tok = r.pop("model"), r.pop("elapsed"), r.pop("tokens")
         extras = r
         step_plain = None
@@ -915,17 +885,18 @@ def main():
         sink = sink_factory(B, T)
         feeder = HostFeeder(wav_host, dev) if args.h2d else None
 
-        def step_plain(src=None):
+        def step_plain(src=None, out=None):
             st = model.encode_device(wav if src is None else src, lens)
-            return model.greedy_ctc_device(st)
+            return model.greedy_ctc_device(st, out=out)
 
         def step():
+            tok_v, len_v, _ = sink.slot()
             if feeder is not None:
-                ids, tokens, tlens = step_plain(feeder.acquire())
+                step_plain(feeder.acquire(), out=(tok_v, len_v))
                 feeder.release()
             else:
-                ids, tokens, tlens = step_plain()
-            sink.push(tokens, tlens)
+                step_plain(out=(tok_v, len_v))
+            sink.commit()
 
         elapsed = timed_loop(step, args.steps, args.warmup, barrier, sink.drain)
         n_tok = int(sink.last[1].sum()) if sink.last is not None else 0
@@ -957,8 +928,11 @@ def main():
             "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": world * B,
                        "audio_seconds_per_utt": AUDIO_SEC, "parallelism": f"utterance-dp{world}",
-                       "collation": "espnet_amd.distributed gather_records (one all-gather of fixed-shape records when "
-                                    "N > 1) + async D2H + unpack_records on rank 0, inside the timed step",
+                       "collation": ("espnet_amd.distributed.RecordRing: records written in place into a device ring, one "
+                                     f"all-gather (N > 1) + one async D2H per {RING_STEPS} steps, all delivered inside "
+                                     "the timed region" if args.workload == "greedy" else
+                                     "espnet_amd.distributed.decode_dynamic: batches pulled from a shared counter, "
+                                     "indexed records collated once at the end of the timed region"),
                        "inputs": ("pinned host -> device copy inside the timed step (double buffered)" if args.h2d
                                   else "resident in HBM when the timed region starts (the bench contract of this "
                                        "repository; SURVEY 8(d) counts the H2D copy of the waveforms: that rate is "
@@ -1017,9 +991,10 @@ def main():
             sk = sink_factory(B, T)
 
             def st():
-                _, tokens, tlens = step_plain(fd.acquire())
+                tok_v, len_v, _ = sk.slot()
+                step_plain(fd.acquire(), out=(tok_v, len_v))
                 fd.release()
-                sk.push(tokens, tlens)
+                sk.commit()
 
             k = min(args.steps, 100)
             t = timed_loop(st, k, 5, barrier, sk.drain)
@@ -1068,8 +1043,9 @@ def main():
             sk = sink_factory(B, T)
 
             def st():
-                _, tokens, tlens = step_plain()
-                sk.push(tokens, tlens)
+                tok_v, len_v, _ = sk.slot()
+                step_plain(out=(tok_v, len_v))
+                sk.commit()
 
             k = min(args.steps, 30)
             t = timed_loop(st, k, 3, barrier, sk.drain)
@@ -1088,12 +1064,13 @@ def main():
             ls = [N_SAMPLES] * Bl
             sk = sink_factory(Bl, T)
 
-            def sp():
-                return m.greedy_ctc_device(m.encode_device(w, ls))
+            def sp(out=None):
+                return m.greedy_ctc_device(m.encode_device(w, ls), out=out)
 
             def st():
-                _, tokens, tlens = sp()
-                sk.push(tokens, tlens)
+                tok_v, len_v, _ = sk.slot()
+                sp(out=(tok_v, len_v))
+                sk.commit()
 
             k = 30
             t = timed_loop(st, k, 3, barrier, sk.drain)
@@ -1117,7 +1094,7 @@ def main():
                 a2 = argparse.Namespace(**vars(args))
                 a2.model = "large"
                 r = run_beam(a2, dev, Bb, 10, steps, 1, cpu_base=cpu and not args.no_cpu_baseline,
-                             sink_factory=sink_factory, want_traffic=cpu)  # counters for the configs[2] leg only
+                             want_traffic=cpu)  # counters for the configs[2] leg only
                 r.pop("model")
                 el_, tok_ = r.pop("elapsed"), r.pop("tokens")
                 torch.cuda.empty_cache()

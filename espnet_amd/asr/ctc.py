@@ -79,7 +79,20 @@ class CTC(torch.nn.Module):
                                             L.current_stream_ptr()), "em_argmax_rows_f32")
         return ids.to(torch.int64)
 
-    def greedy_device(self, enc_act: torch.Tensor, olens_dev: torch.Tensor, blank: int, sos_eos: int):
+    @staticmethod
+    def _token_outputs(B, T, dev, out):
+        """(tokens (B,T) i32, token_lens (B,) i32): fresh tensors, or the caller's (`out`: e.g. the current slot of an
+        `espnet_amd.distributed.RecordRing`, so the records are written where the collation reads them)."""
+        if out is None:
+            return torch.empty(B, T, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+        tokens, tlens = out
+        if (tuple(tokens.shape) != (B, T) or tuple(tlens.shape) != (B,) or tokens.dtype != torch.int32
+                or tlens.dtype != torch.int32 or not tokens.is_contiguous() or not tlens.is_contiguous()):
+            raise ValueError(f"out must be contiguous int32 ({B}, {T}) and ({B},) tensors")
+        L.require_gpu(tokens, "out tokens")
+        return tokens, tlens
+
+    def greedy_device(self, enc_act: torch.Tensor, olens_dev: torch.Tensor, blank: int, sos_eos: int, out=None):
         """Fused G1 path (bin/asr_inference.py:574-575): returns (ids (B,T) i32, tokens (B,T) i32
         padded with -1, token_lens (B,) i32), all on the device, no host sync."""
         p = self._pack(enc_act.device)
@@ -87,20 +100,18 @@ class CTC(torch.nn.Module):
         dev = enc_act.device
         logits = torch.empty(B * T, self.odim, dtype=torch.float32, device=dev)
         ids = torch.empty(B, T, dtype=torch.int32, device=dev)
-        tokens = torch.empty(B, T, dtype=torch.int32, device=dev)
-        tlens = torch.empty(B, dtype=torch.int32, device=dev)
+        tokens, tlens = self._token_outputs(B, T, dev, out)
         L.check(L.load().em_ctc_greedy(self.em_dtype, L.ptr(enc_act), L.ptr(p["w"]), L.ptr(p["b"]),
                                        B, T, d, self.odim, L.ptr(olens_dev), blank, sos_eos,
                                        L.ptr(logits), L.ptr(ids), L.ptr(tokens), L.ptr(tlens),
                                        L.current_stream_ptr()), "em_ctc_greedy")
         return ids, tokens, tlens
 
-    def collapse_device(self, ids: torch.Tensor, olens_dev: torch.Tensor, blank: int, sos_eos: int):
+    def collapse_device(self, ids: torch.Tensor, olens_dev: torch.Tensor, blank: int, sos_eos: int, out=None):
         """groupby + drop blank / <sos/eos> (bin/asr_inference.py:574-575) over given per-frame ids (B, T) i32:
         returns (ids, tokens padded with -1, token_lens), no host sync."""
         B, T = ids.shape
-        tokens = torch.empty(B, T, dtype=torch.int32, device=ids.device)
-        tlens = torch.empty(B, dtype=torch.int32, device=ids.device)
+        tokens, tlens = self._token_outputs(B, T, ids.device, out)
         L.check(L.load().em_ctc_collapse(L.ptr(ids), L.ptr(olens_dev), B, T, blank, sos_eos, L.ptr(tokens),
                                          L.ptr(tlens), L.current_stream_ptr()), "em_ctc_collapse")
         return ids, tokens, tlens

@@ -140,12 +140,13 @@ class ESPnetASRModel(torch.nn.Module):
         return self.frontend(speech, speech_lengths)
 
     # ------------------------------------------------------------------ greedy CTC (G1)
-    def greedy_ctc_device(self, st: EncoderState):
+    def greedy_ctc_device(self, st: EncoderState, out=None):
         """argmax + groupby + drop blank/sos/eos (bin/asr_inference.py:574-575) for the whole batch
-        on the device.  Returns (ids, tokens, token_lens) device tensors (int32)."""
+        on the device.  Returns (ids, tokens, token_lens) device tensors (int32); `out` = (tokens, token_lens)
+        tensors to write into instead of fresh ones (the collation's record slot)."""
         if self.ctc is None:
             raise RuntimeError("model has no CTC head (ctc_weight == 0)")
         sos_eos = self.sos if self.sos == self.eos else -2
         if st.ctc_ids is not None:  # arg-max already taken inside the encoder's last kernel
-            return self.ctc.collapse_device(st.ctc_ids, st.olens_dev, self.blank_id, sos_eos)
-        return self.ctc.greedy_device(st.enc_act, st.olens_dev, self.blank_id, sos_eos)
+            return self.ctc.collapse_device(st.ctc_ids, st.olens_dev, self.blank_id, sos_eos, out=out)
+        return self.ctc.greedy_device(st.enc_act, st.olens_dev, self.blank_id, sos_eos, out=out)

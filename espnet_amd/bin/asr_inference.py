@@ -222,7 +222,7 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
               model_tag: Optional[str] = None, token_type: Optional[str] = None,
               bpemodel: Optional[str] = None, allow_variable_data_keys: bool = False,
               transducer_conf: Optional[dict] = None, streaming: bool = False, ctc_greedy: bool = False,
-              bucket_window: int = 8, **unsupported):
+              bucket_window: int = 8, window_claim=None, **unsupported):
     """The reference's `inference()` (espnet2/bin/asr_inference.py:716-906) for the MI355X path: same
     keywords, same `output_dir/{n}best_recog/{token,token_int,score,text}` files in the key order of the
     input, same per-utterance TooShortUttError fallback (:851-858) — but `batch_size > 1` decodes
@@ -259,7 +259,7 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
         num_workers=num_workers, preprocess_fn=ASRTask.build_preprocess_fn(speech2text.asr_train_args, False),
         collate_fn=ASRTask.build_collate_fn(speech2text.asr_train_args, False),
         allow_variable_data_keys=allow_variable_data_keys, inference=True, ngpu=ngpu,
-        bucket_window=bucket_window)
+        bucket_window=bucket_window, window_claim=window_claim)
     fs = 16000
     fconf = getattr(speech2text.asr_train_args, "frontend_conf", None) or {}
     if isinstance(fconf.get("fs", None), int):
@@ -371,28 +371,45 @@ def merge_shard_outputs(output_dir, keys, world: int, nbest: int):
                             w.write(f"{k} {rows[k]}\n")
 
 
-def sharded_decode_rank(decode_slab, keys, output_dir, nbest: int, max_len: int, device):
-    """One rank of `--ngpu N`: `decode_slab(slab_keys, shard_dir)` decodes this rank's contiguous slab of the key
-    list (espnet_amd.distributed.shard_bounds) into `output_dir/output.{rank+1}` and returns (token-id lists,
-    scores) of its 1-best; `decode_sharded` collates them on every rank with the fixed-shape all-gather, rank 0
-    merges the shard files and cross-checks them against the collated records."""
+def sharded_decode_rank(decode_claimed, keys, output_dir, nbest: int, max_len: int, device, window: int = 1):
+    """One rank of `--ngpu N`, DYNAMIC dispatch (round 4; was: one static contiguous slab per rank).  The key list is
+    cut into windows of `window` utterances (the loader's read-ahead window); `decode_claimed(claim, shard_dir)` runs
+    this rank's ONE decode loop over the windows `claim(w)` grants it (espnet_amd.distributed.WindowClaimer over a
+    shared counter: a rank asks for its next window when it reaches the previous one, so a slow GPU or a run of long
+    utterances takes fewer) into `output_dir/output.{rank+1}` and returns {key: (token ids, score)} of its 1-best.
+    The records travel with their global utterance index and are collated ONCE, at the end
+    (`gather_variable_records`); rank 0 merges the shard files in key order and cross-checks them against the
+    collated records.  A failing rank makes every rank raise (no one is left inside a collective)."""
     from pathlib import Path
 
     import torch.distributed as dist
 
-    from espnet_amd.distributed import decode_sharded
+    from espnet_amd import distributed as D
 
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     shard_dir = Path(output_dir) / f"output.{rank + 1}"
-    stats = {}
-
-    def decode_fn(lo, hi):
-        toks, scores, st = decode_slab(keys[lo:hi], shard_dir)
-        stats.update(st)
-        return toks, scores
-
-    hyps = decode_sharded(decode_fn, len(keys), max_len, device)
+    claim = D.WindowClaimer(D.SharedCounter(D.work_store() if world > 1 else None, "asr_inference_windows"))
+    err, stats, rec = None, {}, None
+    try:
+        mine, stats = decode_claimed(claim, shard_dir)
+        index = {k: u for u, k in enumerate(keys)}
+        ks = sorted(mine, key=index.__getitem__)
+        rec = D.pack_indexed_records([index[k] for k in ks], [mine[k][0] for k in ks], [mine[k][1] for k in ks],
+                                     max_len, device)
+    except Exception as e:  # re-raised below, after the peers have been told
+        err = e
+    if world > 1:
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = int(flag.item()) != 0
+    else:
+        failed = err is not None
+    if err is not None:
+        raise err
+    if failed:
+        raise RuntimeError(f"rank {rank}: another rank failed before the hypothesis collation; nothing was gathered")
+    hyps = D.unpack_indexed_records(D.gather_variable_records(rec), len(keys))
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:
@@ -402,7 +419,7 @@ def sharded_decode_rank(decode_slab, keys, output_dir, nbest: int, max_len: int,
                   for ln in f.read_text(encoding="utf-8").splitlines()} if f.exists() else {}
         for k, (toks, _) in zip(keys, hyps):
             assert merged.get(k, []) == toks, f"collated record of {k} differs from the merged shard file"
-    return hyps, stats
+    return hyps, dict(stats, windows=list(claim.claimed))
 
 
 def _multi_gpu_worker(rank: int, world: int, port: int, kw: dict, q):
@@ -432,24 +449,20 @@ def _multi_gpu_worker(rank: int, world: int, port: int, kw: dict, q):
 
 
 def _inference_rank(kw: dict):
-    from pathlib import Path
-
     keys = _read_keys(kw["data_path_and_name_and_type"], kw["key_file"])
     nbest = kw["nbest"]
+    window = max(1, int(kw.get("batch_size", 1))) * max(1, int(kw.get("bucket_window", 8)))
 
-    def decode_slab(slab_keys, shard_dir):
+    def decode_claimed(claim, shard_dir):
         shard_dir.mkdir(parents=True, exist_ok=True)
-        kf = shard_dir / "keys"
-        kf.write_text("".join(f"{k}\n" for k in slab_keys), encoding="utf-8")
-        sub = dict(kw, output_dir=str(shard_dir), key_file=str(kf), ngpu=1)
-        st = inference(**sub) if slab_keys else {}
+        sub = dict(kw, output_dir=str(shard_dir), ngpu=1, window_claim=claim)  # the whole key list, claimed windows only
+        st = inference(**sub)
         ti, sc = shard_dir / "1best_recog" / "token_int", shard_dir / "1best_recog" / "score"
         rows = {ln.partition(" ")[0]: ln.partition(" ")[2] for ln in ti.read_text().splitlines()} if ti.exists() else {}
         srow = {ln.partition(" ")[0]: ln.partition(" ")[2] for ln in sc.read_text().splitlines()} if sc.exists() else {}
-        return ([[int(t) for t in rows.get(k, "").split()] for k in slab_keys],
-                [_first_float(srow.get(k, "0")) for k in slab_keys], st)
+        return {k: ([int(t) for t in v.split()], _first_float(srow.get(k, "0"))) for k, v in rows.items()}, st
 
-    hyps, st = sharded_decode_rank(decode_slab, keys, kw["output_dir"], nbest, 4096, torch.device("cuda"))
+    hyps, st = sharded_decode_rank(decode_claimed, keys, kw["output_dir"], nbest, 4096, torch.device("cuda"), window)
     return dict(st, utterances_total=len(hyps))
 
 
@@ -490,9 +503,10 @@ def _collect_ranks(procs, q, poll_s: float = 0.5):
 
 
 def inference_multi_gpu(ngpu: int, **kw):
-    """`--ngpu N` on one node: N processes (one per MI355X) each decode a contiguous slab of the key file; the
-    hypotheses are collated with `espnet_amd.distributed.decode_sharded` (RCCL all-gather of fixed-shape records)
-    and the per-rank files merged in key order.  Under torchrun (RANK / WORLD_SIZE set) this process is one of
+    """`--ngpu N` on one node: N processes (one per MI355X) pull read-ahead windows of the key file from a shared
+    counter (dynamic dispatch, `sharded_decode_rank`); the hypotheses are collated once at the end with
+    `espnet_amd.distributed.gather_variable_records` (RCCL all-gather of fixed-width indexed records) and the
+    per-rank files merged in key order.  Under torchrun (RANK / WORLD_SIZE set) this process is one of
     the ranks; otherwise the ranks are spawned here."""
     import os
     import socket

@@ -169,9 +169,11 @@ class ASRTask:
     def build_streaming_iterator(cls, data_path_and_name_and_type, preprocess_fn=None, collate_fn=None,
                                  key_file: Optional[str] = None, batch_size: int = 1, dtype="float32",
                                  num_workers: int = 1, allow_variable_data_keys: bool = False, ngpu: int = 0,
-                                 inference: bool = False, bucket_window: int = 8):
+                                 inference: bool = False, bucket_window: int = 8, window_claim=None):
         """espnet2/tasks/abs_task.py:2403-2451, with utterance batches (batch_size > 1) cut from a
-        length-sorted read-ahead window; `.key_order` on the result gives the original order."""
+        length-sorted read-ahead window; `.key_order` on the result gives the original order.  `window_claim`
+        (`--ngpu N`): a callable window index -> bool; only claimed windows are read and decoded by this process
+        (espnet_amd.distributed.WindowClaimer: dynamic dispatch over a shared counter)."""
         from espnet_amd.train.iterable_dataset import (IterableESPnetDataset, StreamingBatchIterator,
                                                        common_collate_fn)
 
@@ -188,4 +190,4 @@ class ASRTask:
                 raise RuntimeError(f"The data-name must be one of ('speech', 'text'): {sorted(extra)}")
         return StreamingBatchIterator(ds, batch_size=batch_size, bucket_window=bucket_window,
                                       num_workers=num_workers, collate_fn=collate_fn or common_collate_fn,
-                                      length_key="speech", pin_memory=ngpu > 0)
+                                      length_key="speech", pin_memory=ngpu > 0, window_claim=window_claim)

@@ -143,7 +143,8 @@ class StreamingBatchIterator:
 
     def __init__(self, dataset: IterableESPnetDataset, batch_size: int = 1, bucket_window: int = 8,
                  num_workers: int = 1, collate_fn=common_collate_fn, length_key: Optional[str] = None,
-                 prefetch_batches: int = 4, pin_memory: bool = False, native_reader: bool = True):
+                 prefetch_batches: int = 4, pin_memory: bool = False, native_reader: bool = True,
+                 window_claim: Optional[Callable[[int], bool]] = None):
         if batch_size < 1 or bucket_window < 1:
             raise ValueError("batch_size and bucket_window must be >= 1")
         self.dataset, self.batch_size, self.window = dataset, batch_size, batch_size * bucket_window
@@ -151,6 +152,9 @@ class StreamingBatchIterator:
         self.length_key = length_key or dataset.names()[0]
         self.prefetch, self.pin_memory = prefetch_batches, pin_memory
         self.key_order: List[str] = []
+        # several processes over ONE key list (`--ngpu N`): window w is read and decoded only by the process whose
+        # `window_claim(w)` says so (espnet_amd.distributed.WindowClaimer); `key_order` then holds this process's keys
+        self.window_claim = window_claim
         self.native_windows = 0  # windows served by the native reader (observability / tests)
         self._wav = None
         pre = dataset.preprocess
@@ -164,13 +168,14 @@ class StreamingBatchIterator:
             self._wav = WavBatchReader(max(self.num_workers, 4))
 
     def _windows(self):
-        buf = []
+        buf, w = [], 0
         for e in self.dataset.entries():
             buf.append(e)
             if len(buf) == self.window:
-                yield buf
-                buf = []
-        if buf:
+                if self.window_claim is None or self.window_claim(w):
+                    yield buf
+                buf, w = [], w + 1
+        if buf and (self.window_claim is None or self.window_claim(w)):
             yield buf
 
     def _put(self, q, stop, item) -> bool:

@@ -133,59 +133,164 @@ def test_record_rows_uneven_slabs():
     assert record_rows(5, 4, 2).tolist() == [0, 1, 2, 4, 6]
 
 
-# ---- `inference(--ngpu N)`: slab per rank -> shard files -> decode_sharded collation -> merged files in key order
-def _fake_slab_decoder(slab_keys, shard_dir):
-    """Stand-in for the single-GPU `inference()` of one rank: writes the files it would write."""
-    toks = [[(11 * int(k[3:]) + j) % 4999 + 1 for j in range(2 + int(k[3:]) % 4)] for k in slab_keys]
-    scores = [-0.5 * int(k[3:]) for k in slab_keys]
-    d = shard_dir / "1best_recog"
-    d.mkdir(parents=True, exist_ok=True)
-    with (d / "token_int").open("w") as f1, (d / "score").open("w") as f2, (d / "text").open("w") as f3:
-        for k, t, s in zip(slab_keys, toks, scores):
-            f1.write(f"{k} {' '.join(map(str, t))}\n")
-            f2.write(f"{k} {s}\n")
-            f3.write(f"{k} text of {k}\n")
-    return toks, scores, {"utterances": len(slab_keys)}
+# ---- `inference(--ngpu N)`: windows claimed from a shared counter -> shard files -> indexed-record collation ->
+#      merged files in key order (dynamic dispatch, round 4)
+def _fake_window_decoder(keys, window, delay_s=0.0):
+    """Stand-in for the single-GPU `inference(window_claim=...)` of one rank: walks the windows of the key list in order,
+    decodes the ones `claim` grants it and writes the files the real loop would write."""
+    import time
+
+    def decode_claimed(claim, shard_dir):
+        mine = {}
+        for w in range((len(keys) + window - 1) // window):
+            if not claim(w):
+                continue
+            time.sleep(delay_s)
+            for k in keys[w * window : (w + 1) * window]:
+                u = int(k[3:])
+                mine[k] = ([(11 * u + j) % 4999 + 1 for j in range(2 + u % 4)], -0.5 * u)
+        d = shard_dir / "1best_recog"
+        d.mkdir(parents=True, exist_ok=True)
+        with (d / "token_int").open("w") as f1, (d / "score").open("w") as f2, (d / "text").open("w") as f3:
+            for k, (t, s) in mine.items():
+                f1.write(f"{k} {' '.join(map(str, t))}\n")
+                f2.write(f"{k} {s}\n")
+                f3.write(f"{k} text of {k}\n")
+        return mine, {"utterances": len(mine)}
+
+    return decode_claimed
 
 
-def _ngpu_worker(rank, world, port, keys, out_dir, q):
+def _ngpu_worker(rank, world, port, keys, out_dir, window, delays, q):
     from espnet_amd.bin.asr_inference import sharded_decode_rank
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        hyps, st = sharded_decode_rank(_fake_slab_decoder, keys, out_dir, 1, 16, "cpu")
+        hyps, st = sharded_decode_rank(_fake_window_decoder(keys, window, delays[rank]), keys, out_dir, 1, 16, "cpu", window)
         q.put((rank, hyps, st))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def test_ngpu_sharded_inference_merges_in_key_order(tmp_path):
-    from pathlib import Path
-
+def _run_ngpu(tmp_path, keys, window, delays):
     world = 2
-    keys = [f"utt{u}" for u in (5, 3, 9, 0, 7)]  # input order is not sorted: the merged files must keep it
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ngpu_worker, args=(r, world, port, keys, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_ngpu_worker, args=(r, world, port, keys, str(tmp_path), window, delays, q))
+             for r in range(world)]
     for p in procs:
         p.start()
     got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want_t, want_s, _ = _fake_slab_decoder(keys, Path(tmp_path) / "scratch")
-    for r in range(world):
-        assert [t for t, _ in got[r][0]] == want_t
-        assert [s for _, s in got[r][0]] == pytest.approx(want_s)
-    assert got[0][1]["utterances"] == 3 and got[1][1]["utterances"] == 2  # slabs of 3 + 2
+    return got
+
+
+def test_ngpu_dynamic_inference_merges_in_key_order(tmp_path):
+    from pathlib import Path
+
+    keys = [f"utt{u}" for u in (5, 3, 9, 0, 7)]  # input order is not sorted: the merged files must keep it
+    got = _run_ngpu(tmp_path, keys, 2, [0.0, 0.0])
+    want = {k: ([(11 * int(k[3:]) + j) % 4999 + 1 for j in range(2 + int(k[3:]) % 4)], -0.5 * int(k[3:])) for k in keys}
+    for r in range(2):  # every rank holds the full result in key order
+        assert [t for t, _ in got[r][0]] == [want[k][0] for k in keys]
+        assert [s for _, s in got[r][0]] == pytest.approx([want[k][1] for k in keys])
+    w0, w1 = got[0][1]["windows"], got[1][1]["windows"]
+    assert sorted(w0 + w1) == [0, 1, 2] and not set(w0) & set(w1)  # every window decoded exactly once
+    assert got[0][1]["utterances"] + got[1][1]["utterances"] == len(keys)
     rows = (Path(tmp_path) / "1best_recog" / "token_int").read_text().splitlines()
     assert [ln.split()[0] for ln in rows] == keys
-    assert [[int(t) for t in ln.split()[1:]] for ln in rows] == want_t
+    assert [[int(t) for t in ln.split()[1:]] for ln in rows] == [want[k][0] for k in keys]
     assert (Path(tmp_path) / "1best_recog" / "text").read_text().splitlines()[2] == "utt9 text of utt9"
+
+
+def test_ngpu_dynamic_dispatch_takes_the_slow_rank_out_of_the_critical_path(tmp_path):
+    """one rank four times slower (a slow-state GPU).  With static slabs the job would take
+    20 windows x 80 ms = 1.6 s on the slow rank; with the shared counter the fast rank takes ~4/5 of the windows and
+    the job finishes in about total / (sum of rates): asserted at 1.35x that ideal, and every window exactly once."""
+    import time
+
+    n_win, window = 40, 2
+    keys = [f"utt{u}" for u in range(n_win * window)]
+    fast, slow = 0.02, 0.08
+    t0 = time.perf_counter()
+    got = _run_ngpu(tmp_path, keys, window, [fast, slow])
+    wall = time.perf_counter() - t0
+    w0, w1 = got[0][1]["windows"], got[1][1]["windows"]
+    assert sorted(w0 + w1) == list(range(n_win))
+    assert len(w0) >= 2.5 * len(w1), (len(w0), len(w1))       # ~4 : 1
+    busy = max(len(w0) * fast, len(w1) * slow)                  # the ranks' own decode time (spawn / rendezvous aside)
+    ideal = n_win / (1 / fast + 1 / slow)                       # total work / sum of rates = 0.64 s
+    static = (n_win // 2) * slow                                # what contiguous slabs cost: 1.6 s
+    assert busy <= 1.35 * ideal < static, (busy, ideal, static, wall)
+
+
+# ---- RecordRing: bench.py's per-step records, collated once per M steps
+def _ring_worker(rank, world, port, B, W, M, steps, q):
+    from espnet_amd.distributed import RecordRing
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ring = RecordRing(rank, world, B, W, M, "cpu")
+        seen = []
+        for k in range(steps):
+            ids, cnt, sc = ring.slot()
+            ids.fill_(-1)
+            n = (k + rank) % (W + 1)
+            ids[:, :n] = 100 * rank + k
+            cnt.fill_(n)
+            sc.fill_(float(k) + 0.5 * rank)
+            ring.commit()
+            if ring.last is not None:
+                seen.append((ring.delivered, ring.last[0][:, 0].tolist(), ring.last[1].tolist(), ring.last[2].tolist()))
+        ring.drain()
+        last = None if ring.last is None else (ring.last[0][:, 0].tolist(), ring.last[1].tolist(), ring.last[2].tolist())
+        q.put((rank, ring.delivered, last, len(seen)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps", [37, 32, 5])
+def test_record_ring_two_ranks(steps):
+    world, B, W, M = 2, 3, 6, 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, B, W, M, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r][0] == steps  # every step delivered, none twice
+    # rank 0 owns the results: the last delivered step is the job's last step, rank-major
+    k = steps - 1
+    first_col, counts, scores = got[0][1]
+    want_counts = [(k + r) % (W + 1) for r in range(world) for _ in range(B)]
+    assert counts == want_counts
+    assert scores == [float(k) + 0.5 * r for r in range(world) for _ in range(B)]
+    assert first_col == [(100 * r + k) if (k + r) % (W + 1) > 0 else -1 for r in range(world) for _ in range(B)]
+
+
+def test_gather_variable_records_single_process():
+    from espnet_amd.distributed import pack_indexed_records, unpack_indexed_records
+
+    rec = pack_indexed_records([2, 0, 1], [[5, 6], [], [7]], [-1.0, 0.0, -2.5], 4, "cpu")
+    assert unpack_indexed_records(rec, 3) == [([], 0.0), ([7], -2.5), ([5, 6], -1.0)]
+    with pytest.raises(AssertionError, match="decoded by no rank"):
+        unpack_indexed_records(rec[:2], 3)
+    with pytest.raises(AssertionError, match="decoded twice"):
+        unpack_indexed_records(torch.cat([rec, rec[:1]]), 3)
 
 
 # ---- failure of one rank: no hang (ADVICE r02: a rank that failed before the collective left its peers in the all-gather)

@@ -229,11 +229,16 @@ def test_beam10_b16_rows_match_oracle():
 
 
 # bf16 beam search (the mode configs[2] / configs[3] are timed in) against the oracle's f32 scorers at the bench's own
-# size.  Per scored token and scorer; bounds = 2x the largest value measured on MI355X (printed by every run).
-BF16_BEAM_EPS = {"decoder": 2e-2, "ctc": 2e-2}
-# what bf16 pruning may lose: oracle score of the device's best hypothesis vs the oracle search's best on the same
-# encoder rows (joint score, nats).  The oracle's own 10-best span 0.3-0.6 at this size (flat random-init posteriors).
-BF16_BEAM_BEST_LOSS = 0.5
+# size.  Per scored token and scorer (measured on MI355X, round 4: decoder 1.1e-4, ctc 7e-5 - the errors of 249 tokens
+# largely cancel; `beam.bf16_vs_oracle` of the bench line reports them live).
+BF16_BEAM_EPS = {"decoder": 1e-3, "ctc": 1e-3}
+# What reduced-precision pruning may lose: oracle best minus the oracle's score of the device's best, joint score in
+# nats.  Measured on rows 0 / 7 / 15: -0.74 (the device's hypothesis is BETTER than the oracle search's best), +0.04,
+# +2.45 of scores around -1738: on flat random-init posteriors the oracle's own 10-best span 0.14-0.25 and the ten
+# running hypotheses are decided by margins of 1e-3, so a 1e-4-per-token perturbation sends the beam down another
+# path whose end point is a few nats better or worse - beam search is a heuristic, and this is its path noise, not a
+# scoring error ((a) bounds that, and the peaked fixture pins the n-best where the posteriors decide).  Bound = 2x.
+BF16_BEAM_BEST_LOSS = 5.0
 
 
 def test_beam10_b16_rows_bf16_vs_oracle():
@@ -279,4 +284,5 @@ def test_beam10_b16_rows_bf16_vs_oracle():
         print(f"[configs[2] bf16 row {b}] device best (oracle-scored) {mine_best:.4f} vs oracle best {orc[0]['score']:.4f} "
               f"(oracle 10-best span {span:.3f}); {survive} of {len(orc)} oracle hypotheses in the device n-best")
         assert mine_best >= orc[0]["score"] - BF16_BEAM_BEST_LOSS, (b, mine_best, orc[0]["score"])
+        assert mine_best <= orc[0]["score"] + BF16_BEAM_BEST_LOSS  # (and a "better" end point is path noise of the same size)
     print(f"[configs[2] bf16] worst per-token error vs oracle: decoder {worst['decoder']:.2e}, ctc {worst['ctc']:.2e}")

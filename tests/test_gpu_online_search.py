@@ -111,8 +111,9 @@ def test_online_search_restarts_cleanly_and_bf16_runs():
         assert abs(tot - float(h.score)) < 2e-2 + 1e-4 * abs(tot)
 
 
-# per scored token: |bf16 device score - f32 reference score| along the same token sequence (measured on MI355X, x2)
-BF16_ONLINE_EPS = 4e-2
+# per scored token: |bf16 device score - f32 reference score| along the same token sequence (measured on MI355X, round 4:
+# 1.2e-3 on the peaked fixture; d = 64 / 128 models, so relatively coarser than the 512-wide offline fixtures)
+BF16_ONLINE_EPS = 5e-3
 
 
 def test_online_search_bf16_peaked_head_exact():

@@ -28,9 +28,10 @@ SEARCH_CASES = ["tiny_beam5", "tiny_beam3_attn_only", "tiny_beam4_early_eos", "t
                 "small_g2_3s", "large_beam10_3s", "large_beam10_3s_peaked"]
 
 # bf16 search against the oracle's scorers along the SAME token path (teacher-forced): |device - oracle| per scored
-# token, per scorer.  Bounds = 2x the largest value measured on MI355X over these tests and
-# tests/test_gpu_fullsize.py::test_beam10_b16_rows_bf16_vs_oracle (printed by every run).
-BF16_EPS = {"decoder": 2e-2, "ctc": 2e-2, "lm": 2e-2}
+# token, per scorer.  Measured on MI355X (round 4, printed by every run): decoder 2.3e-4 and ctc 1.9e-3 on the peaked
+# fixture (logits of +-12 through heads with row norms up to 7), 1e-4 at the bench's own size
+# (tests/test_gpu_fullsize.py::test_beam10_b16_rows_bf16_vs_oracle); bounds ~2x the largest value seen.
+BF16_EPS = {"decoder": 2e-3, "ctc": 5e-3, "lm": 2e-2}
 
 
 def bf16_rescore_check(tag, g, sd, enc_row, hyps, ctc_weight, lm_conf=None, eps=None):

@@ -25,8 +25,8 @@ case "$what" in
   parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
     echo "== new parity tests"
-    (time timeout 900 python -m pytest -q -s -x tests/test_gpu_search.py tests/test_gpu_online_search.py tests/test_gpu_fullsize.py tests/test_gpu_e2e.py \
-       -k "peaked or bf16 or midmargin or structure or lm_scorer_bf16 or restarts" 2>&1 | grep -v "^$" | tail -60) 2>&1 | tee "$out/pytest_parity.txt"
+    (time timeout 900 python -m pytest -q -s tests/test_gpu_search.py tests/test_gpu_online_search.py tests/test_gpu_fullsize.py tests/test_gpu_e2e.py \
+       -k "peaked or bf16 or midmargin or structure or lm_scorer_bf16 or restarts" > "$out/pytest_parity_full.txt" 2>&1; grep -E "^\[|passed|failed|Error|assert " "$out/pytest_parity_full.txt" | cut -c1-260 | tail -60) 2>&1 | tee "$out/pytest_parity.txt"
     echo "== large encoder B=64: kernel stats"
     stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3
     echo "== default bench"; (time timeout 900 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5 ;;
