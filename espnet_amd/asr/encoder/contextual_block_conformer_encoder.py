@@ -374,9 +374,12 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
 
     @torch.no_grad()
     def forward_infer_batch(self, xs_pad: torch.Tensor, prev_states=None, is_final: bool = False):
-        """`forward_infer` (contextual_block_conformer_encoder.py:386-600) for S streams in LOCK STEP: every stream is
-        fed a chunk of the same length at every call (a server batching its live connections), so the streams share
-        the integer part of the state (buffer lengths, number of processed blocks) and differ in tensor contents only.
+        """`forward_infer` (contextual_block_conformer_encoder.py:386-600) for S streams whose carried buffers have the
+        same SHAPES: every stream is fed a chunk of the same length at this call (a server batching its live
+        connections) and they agree on the buffer lengths and on whether they have processed a block yet; the NUMBER
+        of blocks a stream has processed may differ per stream (`n_processed_blocks` a list of S ints: streams that
+        joined at different times - it only moves the positional-encoding offsets, em_cb_build_blocks_rows_f32).
+        Streams in different phases are grouped by `espnet_amd.bin.asr_inference_streaming.StreamPool`.
         xs_pad (S, t, idim) f32 ON THE GPU.  Returns (ys (S, t_out, d), t_out, state); row s equals what
         `forward_infer` returns for stream s alone (tests/test_gpu_streaming.py::test_batch_of_streams).  The dense
         operators of a call see S * n_blk independent blocks - one launch sequence for all streams."""
@@ -390,6 +393,14 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
                                  n_processed_blocks=0, past_encoder_ctx=None)
         prev_addin, buf_after = st["prev_addin"], st["buffer_after_downsampling"]
         n_proc, past_ctx = st["n_processed_blocks"], st["past_encoder_ctx"]
+        n_rows = None  # per-stream block counts (all zero or all positive: the callers group streams that way)
+        if isinstance(n_proc, (list, tuple)):
+            n_rows = [int(v) for v in n_proc]
+            if len(n_rows) != S or (min(n_rows) == 0) != (max(n_rows) == 0):
+                raise ValueError("n_processed_blocks: one count per stream, all zero or all positive")
+            n_proc = n_rows[0] if len(set(n_rows)) == 1 else (1 if n_rows[0] > 0 else 0)
+            if len(set(n_rows)) == 1:
+                n_rows = None
         xs = xs_pad.to(torch.float32)
         if st["buffer_before_downsampling"] is not None:
             xs = torch.cat([st["buffer_before_downsampling"], xs], dim=1)
@@ -413,7 +424,7 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
         else:
             if total <= bs:  # :474-487
                 return empty, 0, dict(prev_addin=prev_addin, buffer_before_downsampling=buf_before,
-                                      buffer_after_downsampling=x, n_processed_blocks=n_proc,
+                                      buffer_after_downsampling=x, n_processed_blocks=st["n_processed_blocks"],
                                       past_encoder_ctx=past_ctx)
             overlap = bs - hs
             block_num = max(0, total - overlap) // hs
@@ -434,9 +445,15 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
         Lb = bs + 2
         chunks = torch.empty(S, block_num, Lb, d, dtype=torch.float32, device=dev)
         addin = torch.empty(S, d, dtype=torch.float32, device=dev)
-        L.check(lib.em_cb_build_blocks_batch_f32(L.ptr(x), L.ptr(pk["pe"]), L.ptr(prev_addin), n_proc, S, block_num,
-                                                 x.size(1), bs, hs, d, L.ptr(chunks), L.ptr(addin), stream),
-                "em_cb_build_blocks_batch_f32")
+        if n_rows is None:
+            L.check(lib.em_cb_build_blocks_batch_f32(L.ptr(x), L.ptr(pk["pe"]), L.ptr(prev_addin), n_proc, S, block_num,
+                                                     x.size(1), bs, hs, d, L.ptr(chunks), L.ptr(addin), stream),
+                    "em_cb_build_blocks_batch_f32")
+        else:
+            rows_dev = torch.tensor(n_rows, dtype=torch.int32).to(dev, non_blocking=True)
+            L.check(lib.em_cb_build_blocks_rows_f32(L.ptr(x), L.ptr(pk["pe"]), L.ptr(prev_addin), L.ptr(rows_dev), S,
+                                                    block_num, x.size(1), bs, hs, d, L.ptr(chunks), L.ptr(addin), stream),
+                    "em_cb_build_blocks_rows_f32")
         next_ctx = torch.empty(S, self.num_blocks, d, dtype=torch.float32, device=dev)
         ws = self._workspace(dev, S * block_num, Lb)
         L.check(lib.em_cb_encode_blocks_batch(self.em_dtype, C.byref(pk["w"]), L.ptr(chunks), S, block_num, Lb, 1,
@@ -458,8 +475,9 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
         ys = self._after_norm(ys.view(S * y_len, d)).view(S, y_len, d)
         if is_final:
             return ys, y_len, None
+        n_next = n_proc + block_num if n_rows is None else [v + block_num for v in n_rows]
         return ys, y_len, dict(prev_addin=addin, buffer_before_downsampling=buf_before,
-                               buffer_after_downsampling=buf_after, n_processed_blocks=n_proc + block_num,
+                               buffer_after_downsampling=buf_after, n_processed_blocks=n_next,
                                past_encoder_ctx=next_ctx)
 
 

@@ -255,6 +255,10 @@ class Speech2TextStreaming:
             self._batch = None
         return res
 
+    def stream_pool(self) -> "StreamPool":
+        """A pool of independent streams served by batched launches (streams may join, pause, finish at any tick)."""
+        return StreamPool(self)
+
     def _encode_chunk(self, feats: torch.Tensor, is_final: bool) -> torch.Tensor:
         enc = self.asr_model.encoder
         if self.use_hipgraph:
@@ -295,6 +299,118 @@ class Speech2TextStreaming:
             text = self.tokenizer.tokens2text(token) if self.tokenizer is not None else None
             results.append((text, token, token_int, hyp))
         return results
+
+
+class StreamPool:
+    """Many independent streams on one GPU WITHOUT lock step (a server's connections join, leave and finish
+    at different times; the reference keeps all streaming state per `Speech2TextStreaming` object,
+    espnet2/bin/asr_inference_streaming.py:205-336, so nothing forbids it).  Every stream has its own state - carried
+    waveform samples, feature / subsampled-frame buffers, context vectors, number of processed blocks (= its position
+    offset), last frame id and tokens so far.  `tick({stream id: (samples, is_final)})` serves whatever subset of the
+    streams delivered audio at this tick (the rest are simply not active): the active streams are GROUPED by the shapes
+    of their state - chunk length, buffer lengths, first block or not, final or not - and every group runs through the
+    batched frontend / encoder launch sequence once (`apply_frontend_batch`, `forward_infer_batch` with one block count
+    per row).  Streams fed equal chunks walk through the same short cycle of shapes whenever they joined, so a pool of
+    live connections falls into a handful of groups.  Greedy CTC (incremental G1), as `batch_call`.  A stream's results
+    equal what `Speech2TextStreaming.__call__` gives it alone (tests/test_gpu_streaming.py::test_stream_pool_ragged)."""
+
+    def __init__(self, s2t: "Speech2TextStreaming"):
+        if s2t.search == "online":
+            raise NotImplementedError("the pool decodes greedily; the block-synchronous beam search is per stream")
+        self.s2t = s2t
+        self.streams = {}   # id -> dict(frontend, encoder, last, ids)
+        self.groups_last_tick = 0
+
+    @staticmethod
+    def _shape(t):
+        return None if t is None else tuple(t.shape[1:])
+
+    def _signature(self, st, n, is_final):
+        fe, en = st["frontend"], st["encoder"]
+        wb = None if fe is None else self._shape(fe["waveform_buffer"])
+        if en is None:
+            es = None
+        else:
+            es = (self._shape(en["buffer_before_downsampling"]), self._shape(en["buffer_after_downsampling"]),
+                  en["prev_addin"] is None, en["past_encoder_ctx"] is None, en["n_processed_blocks"] == 0)
+        return (int(n), bool(is_final), fe is None, wb, es)
+
+    @staticmethod
+    def _stack(parts):
+        """Per-stream state dicts (tensors with a leading stream dimension of 1, ints, None) -> one batched dict."""
+        out = {}
+        for k in parts[0]:
+            vals = [p[k] for p in parts]
+            if vals[0] is None:
+                out[k] = None
+            elif isinstance(vals[0], torch.Tensor):
+                out[k] = torch.cat(vals, dim=0)
+            else:
+                out[k] = [int(v) for v in vals]  # n_processed_blocks: one per row
+        return out
+
+    @staticmethod
+    def _unstack(state, i):
+        if state is None:
+            return None
+        out = {}
+        for k, v in state.items():
+            if v is None:
+                out[k] = None
+            elif isinstance(v, torch.Tensor):
+                out[k] = v[i : i + 1]
+            elif isinstance(v, (list, tuple)):
+                out[k] = int(v[i])
+            else:
+                out[k] = v
+        return out
+
+    @torch.no_grad()
+    def tick(self, chunks) -> dict:
+        """chunks: {stream id: (samples (n,) float tensor / array, is_final)}.  Unknown ids join the pool; a stream whose
+        chunk is final leaves it after this tick.  Returns {stream id: token ids decoded so far} for the active streams."""
+        s2t, m = self.s2t, self.s2t.asr_model
+        groups = {}
+        for sid, (speech, is_final) in chunks.items():
+            if isinstance(speech, np.ndarray):
+                speech = torch.from_numpy(speech)
+            st = self.streams.setdefault(sid, dict(frontend=None, encoder=None, last=-1, ids=[]))
+            groups.setdefault(self._signature(st, speech.numel(), is_final), []).append((sid, speech))
+        self.groups_last_tick = len(groups)
+        dev = next(m.parameters()).device
+        drop = (m.blank_id, m.sos, m.eos)
+        for sig, members in groups.items():
+            is_final = sig[1]
+            sts = [self.streams[sid] for sid, _ in members]
+            wav = torch.stack([sp.to(torch.float32) for _, sp in members]).to(dev, non_blocking=True)
+            fe = None if sts[0]["frontend"] is None else self._stack([st["frontend"] for st in sts])
+            feats, fe_next = s2t.apply_frontend_batch(wav, fe, is_final=is_final)
+            en_next, ids = None, None
+            if feats is not None:
+                en = None if sts[0]["encoder"] is None else self._stack([st["encoder"] for st in sts])
+                if en is not None and isinstance(en["n_processed_blocks"], list) and len(set(en["n_processed_blocks"])) == 1:
+                    en["n_processed_blocks"] = en["n_processed_blocks"][0]
+                enc, y_len, en_next = m.encoder.forward_infer_batch(feats.contiguous(), en, is_final)
+                if y_len > 0:
+                    ids = m.ctc.argmax(enc).cpu().tolist()  # one device -> host read per group and tick
+            else:
+                en_next = None if sts[0]["encoder"] is None else self._stack([st["encoder"] for st in sts])
+            for i, (sid, _) in enumerate(members):
+                st = self.streams[sid]
+                st["frontend"] = self._unstack(fe_next, i)
+                st["encoder"] = self._unstack(en_next, i) if feats is not None else st["encoder"]
+                if ids is not None:
+                    last, out = st["last"], st["ids"]
+                    for t in ids[i]:
+                        if t != last and t not in drop:
+                            out.append(t)
+                        last = t
+                    st["last"] = last
+        res = {sid: list(self.streams[sid]["ids"]) for sid in chunks}
+        for sid, (_, is_final) in chunks.items():
+            if is_final:
+                del self.streams[sid]
+        return res
 
 
 # ---------------------------------------------------------------------- streaming decode CLI (asr.sh stage 12,

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __res
                                                               const float* __restrict__ pe,
                                                               const float* __restrict__ prev_addin,
                                                               int n_proc_host,
-                                                              const int* __restrict__ n_proc_dev,
+                                                              const int* __restrict__ n_proc_dev, int np_stride,
                                                               int total, int bs, int hs,
                                                               int d, float xscale,
                                                               float* __restrict__ x,
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __res
   addin_out += (size_t)sidx * d;
   // the number of blocks already processed feeds the positional-encoding offsets; a hipGraph-
   // captured step reads it from device memory (kernel arguments are frozen at capture)
-  const int n_proc = n_proc_dev ? *n_proc_dev : n_proc_host;
+  // (np_stride 1: one count PER STREAM - streams of a batch that joined at different times, em_cb_build_blocks_rows_f32)
+  const int n_proc = n_proc_dev ? n_proc_dev[(size_t)sidx * np_stride] : n_proc_host;
   float* xb = x + (size_t)i * L * d;
   const int cur = i * hs;
   const int clen = (total - cur) < bs ? (total - cur) : bs;
@@ -212,7 +213,7 @@ extern "C" int em_cb_build_blocks_f32(const float* xs, const float* pe, const fl
     return EM_ERR_BAD_ARG;
   if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
   hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk), dim3(256), 0, (hipStream_t)stream, xs, pe,
-                     prev_addin, n_proc, n_proc_dev, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+                     prev_addin, n_proc, n_proc_dev, 0, total, bs, hs, d, sqrtf((float)d), x, addin_out);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
@@ -224,7 +225,20 @@ extern "C" int em_cb_build_blocks_batch_f32(const float* xs, const float* pe, co
     return EM_ERR_BAD_ARG;
   if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
   hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
-                     prev_addin, n_proc, (const int*)nullptr, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+                     prev_addin, n_proc, (const int*)nullptr, 0, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
+extern "C" int em_cb_build_blocks_rows_f32(const float* xs, const float* pe, const float* prev_addin,
+                                           const int32_t* n_proc_rows, int32_t n_streams, int32_t n_blk, int32_t total,
+                                           int32_t bs, int32_t hs, int32_t d, float* x, float* addin_out, void* stream) {
+  if (!xs || !pe || !x || !addin_out || !n_proc_rows || n_streams <= 0 || n_blk <= 0 || total <= 0 || bs <= 0 ||
+      hs <= 0 || d <= 0)
+    return EM_ERR_BAD_ARG;
+  if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
+  hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
+                     prev_addin, 0, n_proc_rows, 1, total, bs, hs, d, sqrtf((float)d), x, addin_out);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

@@ -227,6 +227,7 @@ _SIGNATURES = {
     "em_cb_encode_blocks": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _i32, _i32, _i32,
                                       _vp, _vp, _vp, _sz, _vp]),
     "em_cb_build_blocks_batch_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "em_cb_build_blocks_rows_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "em_cb_encode_blocks_batch": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _vp, _i32, _i32, _i32, _i32,
                                             _vp, _vp, _vp, _sz, _vp]),
     "em_profile_create": (_vp, [_i32]),

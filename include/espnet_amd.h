@@ -795,6 +795,13 @@ int em_cb_encode_blocks(int dtype, const EmConformerWeights* w, float* x, int32_
 int em_cb_build_blocks_batch_f32(const float* xs, const float* pe, const float* prev_addin, int32_t n_proc,
                                  int32_t n_streams, int32_t n_blk, int32_t total, int32_t bs, int32_t hs, int32_t d,
                                  float* x, float* addin_out, void* stream);
+/*   ... for streams that did NOT start together (a server's connections join and leave: the reference keeps the state
+ *   per object, espnet2/bin/asr_inference_streaming.py:205-336, so nothing forbids it): the number of blocks a stream
+ *   has already processed - it sets the positional-encoding offsets of its blocks - per stream, n_proc_rows [n_streams]
+ *   i32 on the device.  Everything else as em_cb_build_blocks_batch_f32.                                            */
+int em_cb_build_blocks_rows_f32(const float* xs, const float* pe, const float* prev_addin, const int32_t* n_proc_rows,
+                                int32_t n_streams, int32_t n_blk, int32_t total, int32_t bs, int32_t hs, int32_t d,
+                                float* x, float* addin_out, void* stream);
 int em_cb_encode_blocks_batch(int dtype, const EmConformerWeights* w, float* x, int32_t n_streams, int32_t n_blk,
                               int32_t L, int32_t mask_mode, const float* past_ctx, float* next_ctx, void* workspace,
                               size_t workspace_bytes, void* stream);

@@ -30,6 +30,18 @@ case "$what" in
     echo "== large encoder B=64: kernel stats"
     stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3
     echo "== default bench"; (time timeout 900 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5 ;;
+  r04b)     # stream pool, RecordRing / dynamic dispatch on the GPU (two ranks on one GPU through gloo), parity prints, GEMM stage A/B
+    echo "== stream pool + new parity"
+    (time timeout 900 python -m pytest -q -s tests/test_gpu_streaming.py tests/test_gpu_search.py tests/test_gpu_online_search.py tests/test_gpu_fullsize.py tests/test_gpu_e2e.py \
+       -k "pool or peaked or bf16 or midmargin or structure or lm_scorer_bf16 or restarts or batch_call" > "$out/pytest_parity_full.txt" 2>&1; grep -E "^\[|passed|failed|Error|assert " "$out/pytest_parity_full.txt" | cut -c1-260 | tail -60) 2>&1 | tee "$out/pytest_parity.txt"
+    echo "== bench quick (RecordRing path)"; timeout 300 python bench.py --quick --no-traffic --no-cpu-baseline --steps 600 --warmup 30 2>"$out/bench_quick.err" < /dev/null | tee "$out/bench_quick.json" | cut -c1-200
+    echo "== two ranks on one GPU (gloo): greedy ring + beam dynamic dispatch"
+    timeout 300 python bench.py --gpus 2 --dist-debug-one-gpu --quick --no-traffic --no-cpu-baseline --no-roofline --steps 40 --warmup 5 2>"$out/bench_2rank.err" < /dev/null | tee "$out/bench_2rank_greedy.json" | cut -c1-260; tail -3 "$out/bench_2rank.err"
+    timeout 400 python bench.py --gpus 2 --dist-debug-one-gpu --workload beam --batch 4 --no-traffic --no-cpu-baseline --steps 3 --warmup 1 2>"$out/bench_2rank_beam.err" < /dev/null | tee "$out/bench_2rank_beam.json" | cut -c1-400; tail -3 "$out/bench_2rank_beam.err"
+    echo "== large encoder B=64: GEMM stages A/B"
+    for st in 0 2 4; do
+      echo -n "stages $st: "; ESPNET_AMD_GEMM_STAGES=$st timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180
+    done ;;
   full|bench)
     if [ "$what" = full ]; then
       echo "== pytest -m gpu"; (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) 2>&1 | tee "$out/pytest_gpu.txt"
