@@ -11,6 +11,14 @@
 //                           -> Q, K, V^T projections
 //   (block<A> opens the stack after the embedding, block<D|FINAL> closes it with after_norm.)
 //
+// Round 4: block<C|D|...> FOLDS the C part into the launch that follows it (two launches per Conformer block): the
+// depthwise conv needs the GLU output of 15 frames either side of the workgroup's 32, so the workgroup computes the C
+// part for 64 frames (four 16-frame fragments: its own two and a halo fragment either side - the 12 weight units are
+// ingested once, at 32 MFMAs per unit the matrix cores now take as long as the ingest), keeps its own rows' residual
+// in registers and writes the GLU output straight into the conv's LDS tile.  The `glu` round trip through HBM, twelve
+// launches per step and their cold prologues go; the residual stream is read from `x` and written to `x_out`
+// (another workgroup of the same launch reads this one's rows as ITS halo).
+//
 // Reference being reproduced: EncoderLayer.forward (conformer/encoder_layer.py:79-179),
 // ConvolutionModule.forward (conformer/convolution.py:56-79), PositionwiseFeedForward
 // (transformer/positionwise_feed_forward.py:30-32), LayerNorm (transformer/layer_norm.py:12-42),
@@ -67,6 +75,16 @@ constexpr int XSLOT = 8192;                                  // one (destination
 constexpr int SMEM_BYTES = XCH_OFF + 49152;                  // 159 KiB
 static_assert(ABUF_OFF % 1024 == 0 && TILE_OFF % 1024 == 0 && SMEM_BYTES <= 160 * 1024, "LDS layout");
 constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile
+// Row pitch of the conv tile: 512 + 16 bytes.  The conv reads a row's 256 channels contiguously (any pitch will do);
+// the folded C part WRITES it from the GEMM layout - lane (lr, lg) 8 bytes of row lr - and with the dense pitch the 16
+// rows of a fragment fall on the same banks (16-way conflict); 132 words per row step them by 4 banks: conflict-free.
+constexpr int TPITCH = 528;
+static_assert(TROWS * TPITCH <= 32768, "conv tile");
+// The folded C part borrows the FFN's exchange area (idle until the first FFN): its parameter group and LN(x) of its 64
+// rows as four [64][64] bf16 k-tiles.
+constexpr int CPAR_OFF = XCH_OFF;
+constexpr int ABUF64_OFF = XCH_OFF + 8192;
+static_assert(PAR_BYTES <= 8192 && ABUF64_OFF + 32768 <= SMEM_BYTES, "fold layout");
 
 // weight units are read through GLOBAL-address-space pointers: through a generic pointer the loads become flat_load,
 // which counts on lgkmcnt too and forces vmcnt(0) (flat loads may return out of order)
@@ -100,6 +118,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   constexpr bool HAS_C = (MODE & EM_BLOCK_C) != 0, HAS_D = (MODE & EM_BLOCK_D) != 0;
   constexpr bool HAS_A = (MODE & EM_BLOCK_A) != 0, FINAL = (MODE & EM_BLOCK_FINAL) != 0;
   constexpr bool CTC = (MODE & EM_BLOCK_CTC) != 0;
+  constexpr bool FOLD = HAS_C && HAS_D;  // the C part computed in this launch, for 64 frames (round 4)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const abuf = smem + ABUF_OFF;
   float* const red0 = (float*)(smem + RED_OFF);
@@ -165,12 +184,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll
       for (int f = 0; f < 4; ++f) xr[mi][f] = *(const float4*)(a.x + mrow[mi] * D + 64 * f + ncol);
   };
+  float* const xdst = FOLD ? a.x_out : a.x;  // (folded: neighbours read this workgroup's rows of x as their halo)
   auto store_x = [&]() {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
       if (row_ok[mi]) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) *(float4*)(a.x + mrow[mi] * D + 64 * f + ncol) = xr[mi][f];
+        for (int f = 0; f < 4; ++f) *(float4*)(xdst + mrow[mi] * D + 64 * f + ncol) = xr[mi][f];
       }
   };
   auto load_act = [&]() {  // from abuf, after a barrier
@@ -185,19 +205,18 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // shuffles, the four waves through ONE LDS exchange (instead of the mean pass + centred pass with a barrier
   // each; same result to f32 round-off: nothing is formed as a difference of large numbers).  One barrier.
   int nln = 0;  // LayerNorms so far: consecutive ones alternate the exchange buffer (there is no barrier between one's reads and the next one's writes)
-  auto ln_stats = [&](float mean[2], float rstd[2], int code) {
-    float* const red = red0 + (nln & 1) * 256;
-    ++nln;
+  // (two halves so that the folded C part can run the statistics of its 64 rows - own rows and halo rows - through ONE barrier)
+  auto ln_partials = [&](const float4 (&v)[2][4], float* red) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       float s = 0.f;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) s += (xr[mi][f].x + xr[mi][f].y) + (xr[mi][f].z + xr[mi][f].w);
+      for (int f = 0; f < 4; ++f) s += (v[mi][f].x + v[mi][f].y) + (v[mi][f].z + v[mi][f].w);
       const float m0 = s * (1.0f / 16.0f);
       float q = 0.f;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const float dx = xr[mi][f].x - m0, dy = xr[mi][f].y - m0, dz = xr[mi][f].z - m0, dw = xr[mi][f].w - m0;
+        const float dx = v[mi][f].x - m0, dy = v[mi][f].y - m0, dz = v[mi][f].z - m0, dw = v[mi][f].w - m0;
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
       // combine equal-sized groups: n doubles, M2 = M2a + M2b + (sa - sb)^2 / (2 n)
@@ -218,9 +237,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         red[128 + nf * 32 + mi * 16 + lr] = q;  // sum of squares about their mean
       }
     }
-    fstamp(11);
-    bar(code);
-    fstamp(12);
+  };
+  auto ln_finish = [&](const float* red, float mean[2], float rstd[2]) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int m = mi * 16 + lr;
@@ -236,6 +254,15 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       const float y0 = __builtin_amdgcn_rsqf(var);
       rstd[mi] = y0 * (1.5f - 0.5f * var * y0 * y0);
     }
+  };
+  auto ln_stats = [&](float mean[2], float rstd[2], int code) {
+    float* const red = red0 + (nln & 1) * 256;
+    ++nln;
+    ln_partials(xr, red);
+    fstamp(11);
+    bar(code);
+    fstamp(12);
+    ln_finish(red, mean, rstd);
   };
   // y = LN(x; g, b) with g, b at float offsets go / bo of parameter buffer pb
   auto ln_apply = [&](const float* pb, int go, int bo, float4 y[2][4], int code) {
@@ -406,7 +433,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 
   // 16 MFMAs of a K unit: out[mi] = C^T[n = nf*16 + lg*4 + r][m = mi*16 + lr]
   // (swap: C[m = mi*16 + lg*4 + r][n = nf*16 + lr])
-  auto mma_k = [&](const WF& w, bool swap, f32x4 out[2]) {
+  auto mma_of = [&](const bf16x8 (&av)[2][8], const WF& w, bool swap, f32x4 out[2]) {
     if constexpr (dbg & 1) {
       out[0] = out[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       return;
@@ -418,10 +445,11 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        c[mi][ks & 1] = swap ? MM::mma(act[mi][ks], w.v[ks], c[mi][ks & 1]) : MM::mma(w.v[ks], act[mi][ks], c[mi][ks & 1]);
+        c[mi][ks & 1] = swap ? MM::mma(av[mi][ks], w.v[ks], c[mi][ks & 1]) : MM::mma(w.v[ks], av[mi][ks], c[mi][ks & 1]);
     out[0] = c[0][0] + c[0][1];
     out[1] = c[1][0] + c[1][1];
   };
+  auto mma_k = [&](const WF& w, bool swap, f32x4 out[2]) { mma_of(act, w, swap, out); };
   // ---- FFN: x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o -------------------------
   // Round 3: the hidden activation never leaves the wave that computed it.  Wave w owns the 16 hidden columns
   // 16 w .. 16 w + 15 of every 64-wide chunk c (the K unit c of W1: 16 MFMAs over K = 256, as before).  In the
@@ -578,8 +606,10 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // travel while the conv computes: per-wave stamps (profiles/r03a_block_stamps_fine.txt) showed the workgroup
   // sitting 7 500 cycles in the ISSUE of one 240 KiB burst (every CU of the chip asks at once: ~33 B/clk per CU)
   // before the conv could start on the 64 KiB it actually needs.
-  constexpr int NG = HAS_C ? 1 : (HAS_D ? (HAS_A ? 4 : 3) : 2);
-  if (HAS_D) {
+  constexpr int NG = HAS_D ? (HAS_A ? 4 : 3) : (HAS_C ? 1 : 2);
+  if (FOLD) {
+    dma_lines(a.params_c, CPAR_OFF, std::integral_constant<int, PAR_BYTES / 1024>{});  // the C part's group goes first
+  } else if (HAS_D) {
     dma_lines(a.dw_w, WK_OFF, std::integral_constant<int, KW>{});
     dma_lines(a.dw_b, WK_OFF + KW * 1024, std::integral_constant<int, 1>{});
   } else {
@@ -590,7 +620,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   const float* const pb2 = par + 2 * PAR_FLOATS;
   const float* const pb3 = par + 3 * PAR_FLOATS;
 
-  if (HAS_C) {
+  if (HAS_C && !HAS_D) {
     // linear_out over the attention context: activation fragments straight from global memory
     // (attention.py:151 linear_out; encoder_layer.py:142-147 residual)
 #pragma unroll
@@ -647,30 +677,177 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // ---- depthwise conv (k = 31, zero padded) + folded BatchNorm + Swish (convolution.py:72-75):
     // the 62-row input tile of this block (frames t0 - 15 .. t0 + 46 of the utterance, zero outside
     // [0, Tv)) goes through LDS; thread c (= channel) produces the 32 frames of the block.
-    unsigned char* const tile = smem + TILE_OFF;  // [62][256] bf16
-    uint4 stage[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {  // unconditional loads from a clamped row (a load under a lane mask is
-      const int q = tid + it * NC, r = q >> 5, ch = q & 31;  // waited for on the spot), zeroed afterwards
-      const int t = t0 - HALF + r;
-      const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
-      stage[it] = *(const uint4*)((const bf16*)a.glu + ((size_t)b * T + tc) * D + ch * 8);
-    }
+    unsigned char* const tile = smem + TILE_OFF;  // [62][256] bf16, TPITCH bytes per row
     int Tv = T;
-    if (a.tlens) {  // a scalar load (uniform address), behind the tile requests
-      int tl;
-      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl) : "s"(a.tlens + b) : "memory");
-      Tv = tl < T ? tl : T;
-    }
-    fstamp(2);
+    if constexpr (!FOLD) {
+      uint4 stage[8];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int q = tid + it * NC, t = t0 - HALF + (q >> 5);
-      if (q < TROWS * 32) *(uint4*)(tile + q * 16) = (t >= 0 && t < Tv) ? stage[it] : make_uint4(0u, 0u, 0u, 0u);
+      for (int it = 0; it < 8; ++it) {  // unconditional loads from a clamped row (a load under a lane mask is
+        const int q = tid + it * NC, r = q >> 5, ch = q & 31;  // waited for on the spot), zeroed afterwards
+        const int t = t0 - HALF + r;
+        const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
+        stage[it] = *(const uint4*)((const bf16*)a.glu + ((size_t)b * T + tc) * D + ch * 8);
+      }
+      if (a.tlens) {  // a scalar load (uniform address), behind the tile requests
+        int tl;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl) : "s"(a.tlens + b) : "memory");
+        Tv = tl < T ? tl : T;
+      }
+      fstamp(2);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int q = tid + it * NC, t = t0 - HALF + (q >> 5);
+        if (q < TROWS * 32)
+          *(uint4*)(tile + (q >> 5) * TPITCH + (q & 31) * 16) = (t >= 0 && t < Tv) ? stage[it] : make_uint4(0u, 0u, 0u, 0u);
+      }
+      fstamp(3);
+      bar(BAR_TILE);  // (the conv-weight lines were requested before the tile: a wave that has its tile rows has them too)
+    } else {
+      // ---- the C part, folded (round 4): linear_out + residual -> norm_conv -> pointwise_conv1 + GLU for the 64 frames
+      // t0 - 16 .. t0 + 47 as four 16-frame fragments: 1 and 2 are this workgroup's own rows (mi = 0, 1 of everything
+      // that follows), 0 and 3 the halo the depthwise conv needs (hi = 0, 1).  GLU rows go straight into the conv tile.
+      const float* const cpar = (const float*)(smem + CPAR_OFF);  // [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
+      unsigned char* const abuf64 = smem + ABUF64_OFF;
+      int th[2];
+      size_t hrow[2];
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        th[hi] = t0 - 16 + hi * 48 + lr;
+        hrow[hi] = (size_t)b * T + (th[hi] < 0 ? 0 : (th[hi] < T ? th[hi] : T - 1));
+      }
+      bf16x8 acth[2][8];
+      float4 xh[2][4];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const bf16* crow = (const bf16*)a.ctx + mrow[mi] * D + lg * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) act[mi][ks] = *(const bf16x8*)(crow + ks * 32);
+      }
+      read_unit(a.wout, 0, ring[0]);
+      __builtin_amdgcn_sched_barrier(0);  // what the first MFMAs wait for goes first
+      load_x();
+#pragma unroll
+      for (int hi = 0; hi < 2; ++hi) {
+        const bf16* crow = (const bf16*)a.ctx + hrow[hi] * D + lg * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acth[hi][ks] = *(const bf16x8*)(crow + ks * 32);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) xh[hi][f] = *(const float4*)(a.x + hrow[hi] * D + 64 * f + ncol);
+      }
+      read_unit(a.wout, 1, ring[1]);
+      read_unit(a.wout, 2, ring[2]);
+      if (a.tlens) {
+        int tl;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl) : "s"(a.tlens + b) : "memory");
+        Tv = tl < T ? tl : T;
+      }
+      // this wave's two parameter lines were requested before the 80 loads above: landed once at most 63 are outstanding
+      // (the counter's range; it asks for a few of the loads behind them as well)
+      asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      touch();
+      bar(0);  // the C part's parameter group is in LDS
+      fstamp(4);
+      // linear_out + residual (attention.py:151; encoder_layer.py:142-147), own and halo rows from the same unit
+      stream_k(a.wout, std::integral_constant<int, 4>{}, [&](const WF& cur, int f) {
+        f32x4 c[2], ch[2];
+        mma_of(act, cur, false, c);
+        mma_of(acth, cur, false, ch);
+        const float4 b4 = *(const float4*)(cpar + 64 * f + ncol);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          xr[mi][f].x += c[mi][0] + b4.x;
+          xr[mi][f].y += c[mi][1] + b4.y;
+          xr[mi][f].z += c[mi][2] + b4.z;
+          xr[mi][f].w += c[mi][3] + b4.w;
+          xh[mi][f].x += ch[mi][0] + b4.x;
+          xh[mi][f].y += ch[mi][1] + b4.y;
+          xh[mi][f].z += ch[mi][2] + b4.z;
+          xh[mi][f].w += ch[mi][3] + b4.w;
+        }
+      });
+      fstamp(50);
+      // The conv's weights travel while the C part computes (nothing reads WK before the tile barrier).  Requested HERE:
+      // no register load is outstanding at this point, so hipcc's wait counts for the units that follow stay exact (it
+      // does not see these requests), and the 32 KiB land during the LayerNorm's two barriers.
+      dma_lines(a.dw_w, WK_OFF, std::integral_constant<int, KW>{});
+      dma_lines(a.dw_b, WK_OFF + KW * 1024, std::integral_constant<int, 1>{});
+      k_pre(a.pw1f, 8);
+      // norm_conv of the 64 rows (encoder_layer.py:149-152): both statistics through one barrier
+      {
+        float mean[2], rstd[2], meanh[2], rstdh[2];
+        ln_partials(xr, red0);
+        ln_partials(xh, red0 + 256);
+        bar(0);
+        ln_finish(red0, mean, rstd);
+        ln_finish(red0 + 256, meanh, rstdh);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const float4 g4 = *(const float4*)(cpar + 256 + 64 * f + ncol);
+          const float4 b4 = *(const float4*)(cpar + 512 + 64 * f + ncol);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const bf16x4 pc = {(bf16)((xr[mi][f].x - mean[mi]) * rstd[mi] * g4.x + b4.x),
+                               (bf16)((xr[mi][f].y - mean[mi]) * rstd[mi] * g4.y + b4.y),
+                               (bf16)((xr[mi][f].z - mean[mi]) * rstd[mi] * g4.z + b4.z),
+                               (bf16)((xr[mi][f].w - mean[mi]) * rstd[mi] * g4.w + b4.w)};
+            const bf16x4 ph = {(bf16)((xh[mi][f].x - meanh[mi]) * rstdh[mi] * g4.x + b4.x),
+                               (bf16)((xh[mi][f].y - meanh[mi]) * rstdh[mi] * g4.y + b4.y),
+                               (bf16)((xh[mi][f].z - meanh[mi]) * rstdh[mi] * g4.z + b4.z),
+                               (bf16)((xh[mi][f].w - meanh[mi]) * rstdh[mi] * g4.w + b4.w)};
+            *(bf16x4*)(abuf64 + f * 8192 + (1 + mi) * 2048 + tile_wr) = pc;   // fragments 1, 2
+            *(bf16x4*)(abuf64 + f * 8192 + (3 * mi) * 2048 + tile_wr) = ph;   // fragments 0, 3
+          }
+        }
+        bar(0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const int o = (ks >> 1) * 8192 + lr * 128 + ((((ks & 1) * 4 + lg) ^ swz) << 4);
+            act[mi][ks] = *(const bf16x8*)(abuf64 + o + (1 + mi) * 2048);
+            acth[mi][ks] = *(const bf16x8*)(abuf64 + o + (3 * mi) * 2048);
+          }
+      }
+      fstamp(15);
+      // pointwise_conv1 + GLU (convolution.py:66-69): unit 2j = value rows 64j.., unit 2j+1 = their gates; the GLU row of
+      // frame t goes to tile row t - (t0 - 15), zero outside [0, Tv) like the conv's zero padding
+      int trow[4];
+      bool tin[4], tval[4];
+#pragma unroll
+      for (int fi = 0; fi < 4; ++fi) {
+        const int t = t0 - 16 + fi * 16 + lr;
+        trow[fi] = fi * 16 + lr - 1;
+        tin[fi] = trow[fi] >= 0 && trow[fi] < TROWS;
+        tval[fi] = t >= 0 && t < Tv;
+      }
+      {
+        f32x4 v[2], gt[2], vh[2], gth[2];
+        stream_k(a.pw1f, std::integral_constant<int, 8>{}, [&](const WF& cur, int u) {
+          if (!(u & 1)) {
+            mma_of(act, cur, false, v);
+            mma_of(acth, cur, false, vh);
+          } else {
+            mma_of(act, cur, false, gt);
+            mma_of(acth, cur, false, gth);
+            const int j = u >> 1;
+            const float4 bv = *(const float4*)(cpar + 768 + (2 * j) * 64 + ncol);
+            const float4 bg = *(const float4*)(cpar + 768 + (2 * j + 1) * 64 + ncol);
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+              const bool own = fi == 1 || fi == 2;
+              const int i2 = own ? fi - 1 : (fi == 0 ? 0 : 1);
+              const f32x4 vv = own ? v[i2] : vh[i2], gg = own ? gt[i2] : gth[i2];
+              bf16x4 pk = {(bf16)((vv[0] + bv.x) * sigmoidf_(gg[0] + bg.x)), (bf16)((vv[1] + bv.y) * sigmoidf_(gg[1] + bg.y)),
+                           (bf16)((vv[2] + bv.z) * sigmoidf_(gg[2] + bg.z)), (bf16)((vv[3] + bv.w) * sigmoidf_(gg[3] + bg.w))};
+              if (!tval[fi]) pk = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+              if (tin[fi]) *(bf16x4*)(tile + trow[fi] * TPITCH + (64 * j + ncol) * 2) = pk;
+            }
+          }
+        });
+      }
+      fstamp(51);
+      bar(BAR_TILE);  // the tile is complete (and the conv weights, requested before it by every wave, are in LDS)
     }
-    fstamp(3);
-    bar(BAR_TILE);  // (the conv-weight lines were requested before the tile: a wave that has its tile rows has them too)
-    fstamp(4);
     // Behind the tile barrier, IN the convolution: the parameter groups, the residual rows, pointwise_conv2's first units
     // and the L2 warm-up, in three pieces of <= 64 KiB dealt into the conv's row loop.  Requested in one go they
     // block the wave in their issue (the memory pipeline of a CU takes ~64 KiB before it makes the issuing wave
@@ -687,7 +864,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll
       for (int o = 0; o < 16; ++o) acc[o] = bc2;
       dma_lines(a.params, PAR_OFF, std::integral_constant<int, NG * (PAR_BYTES / 1024)>{});
-      load_x();
+      if constexpr (!FOLD) load_x();  // (folded: the own rows' residual is already in registers, updated by linear_out)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16 + KW - 1; ++r) {
@@ -708,13 +885,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           }
           __builtin_amdgcn_sched_barrier(0);  // ... nor sink below the rows that follow
         }
-        const unsigned u = *(const unsigned*)(tile + ((hh * 16 + r) * D + 2 * cp) * 2);
+        const unsigned u = *(const unsigned*)(tile + (hh * 16 + r) * TPITCH + 4 * cp);
         const f32x2 v = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 #pragma unroll
         for (int o = 0; o < 16; ++o)
           if (r - o >= 0 && r - o < KW) acc[o] = __builtin_elementwise_fma(wk2[r - o], v, acc[o]);
       }
-      touch();  // (its chunk loop must stay OUT of the row loop: with a loop inside, hipcc does not unroll the rows and the accumulators go to scratch)
+      if constexpr (!FOLD) touch();  // (its chunk loop must stay OUT of the row loop: with a loop inside, hipcc does not unroll the rows and the accumulators go to scratch; folded: done in the C part)
       const int ch = 2 * cp, kt = ch >> 6, kl = ch & 63;
 #pragma unroll
       for (int o = 0; o < 16; ++o) {
@@ -727,7 +904,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     fstamp(6);
     // this wave's parameter lines were requested before the 32 loads of x and pointwise_conv2: landed once at most 32 are
     // outstanding (the barrier then publishes them with the conv output)
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    if constexpr (FOLD) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // (no x loads behind the parameter lines)
+    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     bar(0);  // conv output + parameter groups visible
     load_act();
     stamp(7);
@@ -977,13 +1155,17 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
     if (a->Tpad % 64 != 0 || a->Tpad < em_cdiv(a->T, BM) * BM) return EM_ERR_BAD_ARG;
   }
   if (need_d) {
-    if (!a->glu || !a->pw2 || !a->ff_w1 || !a->ff_w2 || !a->dw_w || !a->dw_b) return EM_ERR_BAD_ARG;
+    if ((!a->glu && !(mode & EM_BLOCK_C)) || !a->pw2 || !a->ff_w1 || !a->ff_w2 || !a->dw_w || !a->dw_b) return EM_ERR_BAD_ARG;
     if (a->kernel != KW) return EM_ERR_UNSUPPORTED;
   }
   if (mode == EM_BLOCK_C && (!a->ctx || !a->glu || !a->wout || !a->pw1f)) return EM_ERR_BAD_ARG;
+  if ((mode & EM_BLOCK_C) && need_d) {  // the C part folded into the launch (round 4)
+    if (!a->ctx || !a->wout || !a->pw1f || !a->params_c) return EM_ERR_BAD_ARG;
+    if (need_a && (!a->x_out || a->x_out == a->x)) return EM_ERR_BAD_ARG;  // neighbours read x as their halo: no in-place update
+  }
   if ((mode & EM_BLOCK_FINAL) && (!a->enc_out || !a->enc_act)) return EM_ERR_BAD_ARG;
   if (mode & EM_BLOCK_CTC) {
-    if (mode != (EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC) || !a->ctc_w || !a->ctc_b || !a->ctc_ids) return EM_ERR_BAD_ARG;
+    if ((mode & ~EM_BLOCK_C) != (EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC) || !a->ctc_w || !a->ctc_b || !a->ctc_ids) return EM_ERR_BAD_ARG;
     if (a->ctc_units <= 0) return EM_ERR_BAD_ARG;
   }
   // algorithmic flops of the GEMM-shaped stages (the depthwise conv and LayerNorms are VALU work)
@@ -1002,6 +1184,11 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
     case EM_BLOCK_D | EM_BLOCK_FINAL: rc = launch_block<EM_BLOCK_D | EM_BLOCK_FINAL>(a, s); break;
     case EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC:
       rc = launch_block<EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC>(a, s);
+      break;
+    case EM_BLOCK_C | EM_BLOCK_D | EM_BLOCK_A: rc = launch_block<EM_BLOCK_C | EM_BLOCK_D | EM_BLOCK_A>(a, s); break;
+    case EM_BLOCK_C | EM_BLOCK_D | EM_BLOCK_FINAL: rc = launch_block<EM_BLOCK_C | EM_BLOCK_D | EM_BLOCK_FINAL>(a, s); break;
+    case EM_BLOCK_C | EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC:
+      rc = launch_block<EM_BLOCK_C | EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC>(a, s);
       break;
   }
   if (rec) em_prof_end(stream, flops, EM_PROF_BLOCK);

@@ -9,6 +9,7 @@
 //   EncoderLayer.forward (x12)        .../conformer/encoder_layer.py:79-179
 //   CTC.argmax + G1 collapse          espnet2/asr/ctc.py:207-215, bin/asr_inference.py:574-575
 #include <math.h>
+#include <stdlib.h>
 
 #include "em_common.h"
 #include "subsample.h"
@@ -161,22 +162,36 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     set_a(ly[0]);
     ba.params = ly[0].fp_a;
     EM_TRY(em_conformer_block_fused(EM_BLOCK_A, &ba, stream));
+    // Round 4: the C part runs inside the launch that consumes it (block<C|D|...>: two launches per Conformer block).
+    // The residual stream then ping-pongs between `x` and the idle `big` slot of the workspace, because a workgroup
+    // reads its neighbours' rows of x as the depthwise conv's halo.  ESPNET_AMD_NO_FOLD=1 keeps the three-launch
+    // sequence (developer A/B switch).
+    static const bool no_fold = getenv("ESPNET_AMD_NO_FOLD") != nullptr;
+    const int cbit = no_fold ? 0 : EM_BLOCK_C;
+    float* xa = x;
+    float* xb = (float*)big;
     for (int l = 0; l < L; ++l) {
       const EmConformerLayer& q = ly[l];
       EM_TRY(em_relpos_attention2_bf16(qh, kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
                                        q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
-      ba.wout = q.woutp; ba.pw1f = q.pw1f; ba.params = q.fp_c;
-      EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
+      ba.wout = q.woutp; ba.pw1f = q.pw1f;
+      if (no_fold) {
+        ba.params = q.fp_c;
+        EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
+      } else {
+        ba.params_c = q.fp_c; ba.x = xa; ba.x_out = xb;
+      }
       ba.pw2 = q.pw2p; ba.ff_w1 = q.ff_w1p; ba.ff_w2 = q.ff_w2p; ba.dw_w = q.dw_w; ba.dw_b = q.dw_b;
       ba.params = q.fp_da;
       if (l + 1 < L) {
         set_a(ly[l + 1]);
-        EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_A, &ba, stream));
+        EM_TRY(em_conformer_block_fused(cbit | EM_BLOCK_D | EM_BLOCK_A, &ba, stream));
+        if (!no_fold) { float* t = xa; xa = xb; xb = t; }
       } else if (plan & EM_ENC_PLAN_CTC_IDS) {
         ba.ctc_w = w->ctc_w; ba.ctc_b = w->ctc_b; ba.ctc_ids = w->ctc_ids; ba.ctc_units = w->ctc_units;
-        EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC, &ba, stream));
+        EM_TRY(em_conformer_block_fused(cbit | EM_BLOCK_D | EM_BLOCK_FINAL | EM_BLOCK_CTC, &ba, stream));
       } else {
-        EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_FINAL, &ba, stream));
+        EM_TRY(em_conformer_block_fused(cbit | EM_BLOCK_D | EM_BLOCK_FINAL, &ba, stream));
       }
     }
     return EM_OK;

@@ -475,7 +475,9 @@ int launch(const EmGemmArgs* p, hipStream_t s) {
   // developer A/B.
   static const int forced = [] { const char* e = getenv("ESPNET_AMD_GEMM_STAGES"); return e ? atoi(e) : 0; }();
   const long wgs = (long)nb * em_cdiv(p->M, small ? 64 : 128);
-  const bool deep = forced ? forced >= 4 : wgs <= 2 * 256 && p->K >= 2048;
+  // (round 4: K >= 4096, was 2048 - the large model's second FFN matrix, K = 2048 on 500 workgroups, runs 65.6 us with
+  // four stages and ~40 with two: the whole B = 64 encoder step 8.24 -> 7.64 ms, profiles/r04b_gemm_stages_large_b64.txt)
+  const bool deep = forced ? forced >= 4 : wgs <= 2 * 256 && p->K >= 4096;
   if (small) return deep ? launch_tile<T, EPI, AMODE, 64, 4>(p, s, g) : launch_tile<T, EPI, AMODE, 64, 2>(p, s, g);
   return deep ? launch_tile<T, EPI, AMODE, 128, 4>(p, s, g) : launch_tile<T, EPI, AMODE, 128, 2>(p, s, g);
 }

@@ -67,7 +67,8 @@ class EmBlockArgs(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "T", "Tpad", "d", "ff", "kernel")] + [("eps", C.c_float)] + \
                [(n, C.c_void_p) for n in ("x", "ctx", "glu", "qh", "kh", "vt", "enc_out", "enc_act", "tlens", "wout",
                                           "pw1f", "pw2", "ff_w1", "ff_w2", "dw_w", "dw_b", "ffm_w1", "ffm_w2", "wqkv",
-                                          "params", "ctc_w", "ctc_b", "ctc_ids")] + [("ctc_units", C.c_int32)]
+                                          "params", "ctc_w", "ctc_b", "ctc_ids")] + [("ctc_units", C.c_int32)] + \
+               [("x_out", C.c_void_p), ("params_c", C.c_void_p)]
 
 
 class EmConformerWeights(C.Structure):

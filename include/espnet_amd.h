@@ -325,6 +325,7 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
  *         EM_BLOCK_D | EM_BLOCK_A   : glu -> depthwise conv + BN + Swish -> pointwise_conv2 + residual -> norm_ff
  *                                     -> FFN + residual -> norm_final; next block: norm_ff_macaron -> macaron FFN
  *                                     + residual -> norm_mha -> q / k / v projections
+ *         EM_BLOCK_C | EM_BLOCK_D | EM_BLOCK_A (round 4): both of the above in ONE launch (see x_out / params_c below)
  *         EM_BLOCK_A                : the second half alone (first block, after the embedding)
  *         EM_BLOCK_D | EM_BLOCK_FINAL: the first half, then after_norm -> enc_out (f32) / enc_act (bf16)
  *   x     [B*T][256] f32 residual stream, updated in place (block<C> and the A part write it back)
@@ -375,6 +376,13 @@ typedef struct EmBlockArgs {
   const float* ctc_b;
   int32_t* ctc_ids;
   int32_t ctc_units;
+  /* EM_BLOCK_C | EM_BLOCK_D | ...: the C part FOLDED into the launch that consumes it (round 4).  The workgroup computes
+   * linear_out / norm_conv / pointwise_conv1 + GLU for its 32 frames AND the 16 either side (the depthwise conv's halo)
+   * and keeps the GLU rows in LDS: `glu` is not used, `ctx`, `wout`, `pw1f` are, `params_c` is the C part's parameter
+   * group, and the residual stream is read from `x` and written to `x_out` (a different buffer: another workgroup of the
+   * same launch reads this one's rows of `x` as its halo).  With EM_BLOCK_FINAL nothing is written to x_out.        */
+  float* x_out;
+  const float* params_c;
 } EmBlockArgs;
 int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
 

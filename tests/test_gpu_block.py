@@ -266,6 +266,59 @@ def test_block_da(lib, B, T, ff):
     assert_close(vt[:, :, :, :T].permute(0, 3, 1, 2).reshape(B * T, D), qkv_ref[:, 2 * D:], 3e-2, "block<D|A> v")
 
 
+@pytest.mark.parametrize("B,T,ff", SHAPES)
+@pytest.mark.parametrize("masked", [False, True])
+def test_block_cda_folded(lib, B, T, ff, masked):
+    """Round 4: block<C|D|A> - the C part computed inside the launch that consumes it, for the workgroup's 32 frames and
+    the depthwise conv's halo either side; the residual stream goes x -> x_out.  Same restatement as the three-launch
+    sequence (part_c -> part_d -> next layer's part_a), utterance boundaries and a masked tail (tlens) included."""
+    l0, l1 = Layer(800, ff), Layer(900, ff)
+    x0, ctx = rnd(B * T, D, seed=12), q(rnd(B * T, D, seed=13))
+    tl = [max(1, T - 7 * b - 3) for b in range(B)] if masked else None
+    xc, glu_ref = l0.part_c(x0, ctx)
+    x_ref, qkv_ref = l1.part_a(l0.part_d(xc, glu_ref, B, T, tl))
+    Tp = tpad(T)
+    xd, xo = dev(x0.clone()), torch.full((B * T, D), float("nan"), device="cuda")
+    qh, kh = (torch.zeros(B, H, Tp, 64, dtype=BF, device="cuda") for _ in range(2))
+    vt = torch.zeros(B, H, 64, Tp, dtype=BF, device="cuda")
+    a = block_args(B, T, ff, x=xd, x_out=xo, ctx=dev(ctx.to(BF)), qh=qh, kh=kh, vt=vt,
+                   wout=dev(pack_k_units(l0.wout).to(BF)), pw1f=dev(pack_k_units(l0.pw1[l0.perm()]).to(BF)),
+                   params_c=dev(l0.c_group()), pw2=dev(pack_k_units(l0.pw2).to(BF)),
+                   ff_w1=dev(pack_w1(l0.ff_w1).to(BF)), ff_w2=dev(pack_w2(l0.ff_w2).to(BF)), dw_w=dev(l0.dw_w), dw_b=dev(l0.dw_b),
+                   ffm_w1=dev(pack_w1(l1.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(l1.ffm_w2).to(BF)), wqkv=dev(pack_k_units(l1.wqkv).to(BF)),
+                   tlens=dev(torch.tensor(tl, dtype=torch.int32)) if masked else None,
+                   params=dev(torch.cat(l0.d_groups() + l1.a_groups())))
+    mode = L.EM_BLOCK_C | L.EM_BLOCK_D | L.EM_BLOCK_A
+    L.check(lib.em_conformer_block_fused(mode, a, L.current_stream_ptr()), "block<C|D|A>")
+    assert torch.equal(xd.cpu(), x0), "the folded kernel must not write its input residual"
+    assert_close(xo, x_ref, 8e-3, "block<C|D|A> x_out")
+    assert_close(split_heads(qh, B, T), qkv_ref[:, :D], 3e-2, "block<C|D|A> q")
+    assert_close(split_heads(kh, B, T), qkv_ref[:, D:2 * D], 3e-2, "block<C|D|A> k")
+    assert_close(vt[:, :, :, :T].permute(0, 3, 1, 2).reshape(B * T, D), qkv_ref[:, 2 * D:], 3e-2, "block<C|D|A> v")
+    # in place is refused: a neighbour workgroup reads these rows as its halo
+    a.x_out = a.x
+    assert lib.em_conformer_block_fused(mode, a, L.current_stream_ptr()) == L.EM_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("B,T,ff", [(2, 249, 1024), (3, 70, 256), (2, 31, 64)])
+def test_block_cd_final_folded(lib, B, T, ff):
+    ly = Layer(1000, ff)
+    x0, ctx = rnd(B * T, D, seed=14), q(rnd(B * T, D, seed=15))
+    ag, ab = 1 + 0.1 * rnd(D, seed=16), 0.1 * rnd(D, seed=17)
+    ref = ln(ly.part_d(*ly.part_c(x0, ctx), B, T), ag, ab)
+    out = torch.zeros(B * T, D, dtype=torch.float32, device="cuda")
+    act = torch.zeros(B * T, D, dtype=BF, device="cuda")
+    a = block_args(B, T, ff, x=dev(x0.clone()), ctx=dev(ctx.to(BF)), enc_out=out, enc_act=act,
+                   wout=dev(pack_k_units(ly.wout).to(BF)), pw1f=dev(pack_k_units(ly.pw1[ly.perm()]).to(BF)),
+                   params_c=dev(ly.c_group()), pw2=dev(pack_k_units(ly.pw2).to(BF)),
+                   ff_w1=dev(pack_w1(ly.ff_w1).to(BF)), ff_w2=dev(pack_w2(ly.ff_w2).to(BF)), dw_w=dev(ly.dw_w), dw_b=dev(ly.dw_b),
+                   params=dev(torch.cat(ly.d_groups() + [group(ag, ab), torch.zeros(G)])))
+    L.check(lib.em_conformer_block_fused(L.EM_BLOCK_C | L.EM_BLOCK_D | L.EM_BLOCK_FINAL, a, L.current_stream_ptr()),
+            "block<C|D|FINAL>")
+    assert_close(out, ref, 6e-3, "block<C|D|FINAL> enc_out")
+    assert_close(act, ref, 2e-2, "block<C|D|FINAL> enc_act")
+
+
 def test_block_fused_rejects_outside_its_shapes(lib):
     x = torch.zeros(64, D, device="cuda")
     par = torch.zeros(4 * G, device="cuda")

@@ -31,7 +31,7 @@ SEARCH_CASES = ["tiny_beam5", "tiny_beam3_attn_only", "tiny_beam4_early_eos", "t
 # token, per scorer.  Measured on MI355X (round 4, printed by every run): decoder 2.3e-4 and ctc 1.9e-3 on the peaked
 # fixture (logits of +-12 through heads with row norms up to 7), 1e-4 at the bench's own size
 # (tests/test_gpu_fullsize.py::test_beam10_b16_rows_bf16_vs_oracle); bounds ~2x the largest value seen.
-BF16_EPS = {"decoder": 2e-3, "ctc": 5e-3, "lm": 2e-2}
+BF16_EPS = {"decoder": 1e-3, "ctc": 4e-3, "lm": 1e-3}  # largest seen: 4.4e-4 (tiny_beam5_gru), 1.9e-3 (peaked), 2.5e-4
 
 
 def bf16_rescore_check(tag, g, sd, enc_row, hyps, ctc_weight, lm_conf=None, eps=None):

@@ -42,6 +42,17 @@ case "$what" in
     for st in 0 2 4; do
       echo -n "stages $st: "; ESPNET_AMD_GEMM_STAGES=$st timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180
     done ;;
+  fold)     # round 4: block<C|D|A> (the C part folded into the launch that consumes it) - unit tests, end-to-end bf16 tests, A/B, table
+    echo "== block tests"; timeout 600 python -m pytest tests/test_gpu_block.py -q -x 2>&1 | tail -4 | tee "$out/pytest_block.txt"
+    echo "== e2e fused"; timeout 600 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_fullsize.py -q -x -k "bfloat16 or peaked or midmargin or greedy_b32" 2>&1 | tail -4 | tee "$out/pytest_e2e.txt"
+    for v in 1 0 1 0; do
+      if [ $v = 1 ]; then export ESPNET_AMD_NO_FOLD=1; else unset ESPNET_AMD_NO_FOLD; fi
+      echo -n "no_fold=$v: "; timeout 200 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 600 --warmup 30 2>/dev/null < /dev/null | cut -c100-180
+    done
+    unset ESPNET_AMD_NO_FOLD
+    echo "== stamps"; EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "block<7>" | tail -2 | tee "$out/block_stamps.txt"
+    echo "== kernel stats"; stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10
+    echo "== large b64"; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180 ;;
   full|bench)
     if [ "$what" = full ]; then
       echo "== pytest -m gpu"; (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) 2>&1 | tee "$out/pytest_gpu.txt"
