@@ -15,6 +15,7 @@ arithmetic is csrc/{frontend,gemm,norm,attention,conv,encoder}.hip.
 """
 import ctypes as C
 import math
+import os
 import threading
 from typing import List, Optional, Tuple
 
@@ -600,6 +601,8 @@ class ConformerEncoder(torch.nn.Module):
         # not re-derive the kernel's shape conditions)
         self.last_ctc_ids = None
         enc_flags = (L.EM_ENC_ISOLATE_UTTS if isolate else 0) | (0 if _fused_enabled(self) else L.EM_ENC_NO_FUSED)
+        if getattr(self, "fold_c", None) if getattr(self, "fold_c", None) is not None else os.environ.get("ESPNET_AMD_FOLD") == "1":
+            enc_flags |= L.EM_ENC_FOLD_C  # block<C|D|...>: two launches per block (opt-in: measured no faster)
         if hasattr(pk["w"], "ctc_ids"):
             pk["w"].ctc_ids = None
             if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "ctc_units", 0) > 0:

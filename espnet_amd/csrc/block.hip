@@ -743,7 +743,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       }
       // this wave's two parameter lines were requested before the 80 loads above: landed once at most 63 are outstanding
       // (the counter's range; it asks for a few of the loads behind them as well)
+      fstamp(2);
       asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      fstamp(3);
       touch();
       bar(0);  // the C part's parameter group is in LDS
       fstamp(4);
@@ -777,7 +779,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         float mean[2], rstd[2], meanh[2], rstdh[2];
         ln_partials(xr, red0);
         ln_partials(xh, red0 + 256);
+        fstamp(11);
         bar(0);
+        fstamp(12);
         ln_finish(red0, mean, rstd);
         ln_finish(red0 + 256, meanh, rstdh);
 #pragma unroll
@@ -798,7 +802,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
             *(bf16x4*)(abuf64 + f * 8192 + (3 * mi) * 2048 + tile_wr) = ph;   // fragments 0, 3
           }
         }
+        fstamp(13);
         bar(0);
+        fstamp(14);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -847,6 +853,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       }
       fstamp(51);
       bar(BAR_TILE);  // the tile is complete (and the conv weights, requested before it by every wave, are in LDS)
+      fstamp(52);
     }
     // Behind the tile barrier, IN the convolution: the parameter groups, the residual rows, pointwise_conv2's first units
     // and the L2 warm-up, in three pieces of <= 64 KiB dealt into the conv's row loop.  Requested in one go they

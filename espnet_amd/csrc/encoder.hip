@@ -164,9 +164,13 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     EM_TRY(em_conformer_block_fused(EM_BLOCK_A, &ba, stream));
     // Round 4: the C part runs inside the launch that consumes it (block<C|D|...>: two launches per Conformer block).
     // The residual stream then ping-pongs between `x` and the idle `big` slot of the workspace, because a workgroup
-    // reads its neighbours' rows of x as the depthwise conv's halo.  ESPNET_AMD_NO_FOLD=1 keeps the three-launch
-    // sequence (developer A/B switch).
-    static const bool no_fold = getenv("ESPNET_AMD_NO_FOLD") != nullptr;
+    // reads its neighbours' rows of x as the depthwise conv's halo.
+    // Measured (profiles/r04c_*, r04d_*: one box, in-call A/B): correct (53 kernel tests, every bf16 golden) and NOT
+    // faster - block<C|D|A> 54.1 us against 40.2 + 12.4 for the two launches, step 1.086 vs 1.066 ms.  The halo doubles
+    // the C part's prologue (ctx + x of 64 frames: 15 K cycles to issue 300 KiB per CU against a memory system that
+    // serves every CU's cold burst at ~13 B/clk), which costs what the saved launch boundary gains.  So it is OPT-IN:
+    // flag EM_ENC_FOLD_C (the host layer sets it from ESPNET_AMD_FOLD=1 / `encoder.fold_c`).
+    const bool no_fold = !(flags & EM_ENC_FOLD_C);
     const int cbit = no_fold ? 0 : EM_BLOCK_C;
     float* xa = x;
     float* xb = (float*)big;

@@ -22,6 +22,7 @@ EM_DW_SWISH, EM_DW_LINEAR, EM_DW_GATE, EM_DW_SELFRES = range(4)
 EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flags (include/espnet_amd.h)
 EM_ENC_NO_FUSED = 2
 EM_ENC_POS_PROJECTED = 4
+EM_ENC_FOLD_C = 8
 EM_ENC_PLAN_FUSED, EM_ENC_PLAN_CTC_IDS = 1, 2
 EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC = 1, 2, 4, 8, 16
 EM_BLOCK_PARAM_GROUP = 1792

@@ -289,6 +289,8 @@ typedef struct EmConformerWeights {
 /* em_conformer_encode flags */
 #define EM_ENC_ISOLATE_UTTS 1 /* every utterance of a ragged batch encodes as if it were alone */
 #define EM_ENC_NO_FUSED 2     /* keep the one-operator-per-launch sequence even where the fused block kernels apply */
+#define EM_ENC_FOLD_C 8       /* fused path: the C part of a block inside the launch that consumes it (block<C|D|...>: two launches
+                               * per Conformer block instead of three; measured no faster at B = 32, DESIGN.md: opt-in) */
 #define EM_ENC_POS_PROJECTED 4 /* pos_emb is ALREADY linear_pos of every block: [2T-1 (legacy: T)][L*d] act, i.e. pos_emb x wpos_all^T
                                * (it depends on T and the weights only: a caller decoding many batches of one length projects once) */
 

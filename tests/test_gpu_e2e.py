@@ -103,7 +103,7 @@ def margin_report(tag, margins_at_mismatch):
     return float(m.max()) if m.size else 0.0
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "fold"])
 @pytest.mark.parametrize("name", ["small_ragged", "small_10s", "large_10s"])
 def test_encode_bfloat16_within_tolerance(name, fused):
     """bf16 MFMA mode (the timed mode), both launch sequences: the fused per-block kernels (csrc/block.hip; they
@@ -112,7 +112,8 @@ def test_encode_bfloat16_within_tolerance(name, fused):
     by less than BF16_MARGIN; bounds at ~2x the measured values."""
     g = load_golden(name)
     model = build(g, "bfloat16")
-    model.encoder.fused = fused
+    model.encoder.fused = bool(fused)
+    model.encoder.fold_c = fused == "fold"  # block<C|D|...> (round 4; ragged batch: utterance boundaries inside the halo)
     speech, lens = golden_speech(g)
     st = model.encode_device(speech.cuda(), lens.tolist())
     ke = int(g["enc_keep_every"])
@@ -138,7 +139,7 @@ def test_encode_bfloat16_within_tolerance(name, fused):
     assert dist <= 0.03 * max(ref_len, 1) + 1
 
 
-@pytest.mark.parametrize("dtype,fused", [("float32", False), ("bfloat16", True), ("bfloat16", False)])
+@pytest.mark.parametrize("dtype,fused", [("float32", False), ("bfloat16", True), ("bfloat16", False), ("bfloat16", "fold")])
 def test_peaked_posteriors_tokens_exact(dtype, fused):
     """`small_10s_peaked`: the small model with a CTC head fitted to the reference's encoder output (reference
     top-2 margins all > 1, tests/golden/make_golden.py::fit_peaked_ctc_head).  With posteriors like a trained
@@ -147,7 +148,8 @@ def test_peaked_posteriors_tokens_exact(dtype, fused):
     g = load_golden("small_10s_peaked")
     assert float(g["ctc_margin"].min()) > 1.0
     model = build(g, dtype)
-    model.encoder.fused = fused
+    model.encoder.fused = bool(fused)
+    model.encoder.fold_c = fused == "fold"  # block<C|D|...>: the two-launch sequence (EM_ENC_FOLD_C)
     speech, lens = golden_speech(g)
     st = model.encode_device(speech.cuda(), lens.tolist())
     ids, tokens, tlens = model.greedy_ctc_device(st)

@@ -46,13 +46,17 @@ case "$what" in
     echo "== block tests"; timeout 600 python -m pytest tests/test_gpu_block.py -q -x 2>&1 | tail -4 | tee "$out/pytest_block.txt"
     echo "== e2e fused"; timeout 600 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_fullsize.py -q -x -k "bfloat16 or peaked or midmargin or greedy_b32" 2>&1 | tail -4 | tee "$out/pytest_e2e.txt"
     for v in 1 0 1 0; do
-      if [ $v = 1 ]; then export ESPNET_AMD_NO_FOLD=1; else unset ESPNET_AMD_NO_FOLD; fi
+      if [ $v = 1 ]; then unset ESPNET_AMD_FOLD; else export ESPNET_AMD_FOLD=1; fi
       echo -n "no_fold=$v: "; timeout 200 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 600 --warmup 30 2>/dev/null < /dev/null | cut -c100-180
     done
-    unset ESPNET_AMD_NO_FOLD
-    echo "== stamps"; EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "block<7>" | tail -2 | tee "$out/block_stamps.txt"
+    unset ESPNET_AMD_FOLD
+    echo "== stamps"; ESPNET_AMD_FOLD=1 EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "block<7>" | tail -2 | tee "$out/block_stamps.txt"
     echo "== kernel stats"; stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10
     echo "== large b64"; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180 ;;
+  fold-stamps)  # sub-stage stamps of all four waves of one workgroup of block<7> (developer build lib_fine.so)
+    ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_fine.so ESPNET_AMD_FOLD=1 EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "block<7>" | tail -8 | tee "$out/block_stamps_fine.txt" ;;
+  two-streams)  # probe: the batch as two half batches on two streams
+    timeout 300 python tools/two_stream_probe.py 2>&1 | grep "ms per step" | tee "$out/two_stream_probe.txt" ;;
   full|bench)
     if [ "$what" = full ]; then
       echo "== pytest -m gpu"; (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) 2>&1 | tee "$out/pytest_gpu.txt"
