@@ -205,6 +205,21 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   // earlier fusions of this sequence -- LayerNorm in a whole-row GEMM epilogue and a row-block fused FFN --
   // measured slower than what follows and live on only as records (tools/experiments/gemm_ln_epilogue.hip.txt,
   // ffn_fused_rowblock.hip.txt).
+  // Round 4: wherever d_k = 64 and the dtype is bf16 (the large model, 8 heads) the attention runs in the LDS-resident
+  // kernel of the fused path (csrc/attention2.hip: 0.11 of the MFMA peak against 0.05 for relpos_attn_kernel, which takes
+  // 90 us per block at B = 64): its per-head operands are written by the projection GEMMs themselves - q | k through
+  // EM_EPI_QK_HEADS, V^T as the swapped product W_v . xn^T through EM_EPI_VT_HEADS - so there is no repacking pass.
+  // ESPNET_AMD_NO_ATTN2_LARGE=1: developer A/B switch.
+  static const bool no_attn2 = getenv("ESPNET_AMD_NO_ATTN2_LARGE") != nullptr;
+  const bool attn2 = dtype == EM_BF16 && !w->legacy_relpos && !(flags & EM_ENC_NO_FUSED) && !no_attn2 && d == 64 * h &&
+                     (size_t)B * d * s.Tpad * 4 < ((size_t)1 << 32) - 64;
+  void* qh = ws + s.qh;
+  void* vt = ws + s.vt;
+  if (attn2) {
+    // frames >= T of every (b, head) slab must be finite: keys / probabilities there are masked, not skipped
+    if (hipMemsetAsync(qh, 0, (s.vt - s.qh) + (size_t)B * d * s.Tpad * es, (hipStream_t)stream) != hipSuccess)
+      return EM_ERR_LAUNCH;
+  }
   EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr,
                       stream));
   for (int l = 0; l < L; ++l) {
@@ -214,9 +229,22 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
     // self-attention
     EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
-    EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
-                               q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
+    if (attn2) {
+      EmGemmArgs a = {};
+      a.A = xn; a.W = q.wqkv; a.C = qh; a.bias = q.bqkv;
+      a.M = M; a.N = 2 * d; a.K = d; a.lda = d; a.ldc = 64; a.scale = 1.f;
+      a.T1 = T; a.T2 = s.Tpad; a.F1 = h; a.d = d;
+      EM_TRY(em_gemm(dtype, EM_EPI_QK_HEADS, EM_A_PLAIN, &a, stream));
+      a.A = (const unsigned char*)q.wqkv + (size_t)2 * d * d * es; a.W = xn; a.C = vt; a.bias = q.bqkv + 2 * d;
+      a.M = d; a.N = M; a.ldc = s.Tpad;
+      EM_TRY(em_gemm(dtype, EM_EPI_VT_HEADS, EM_A_PLAIN, &a, stream));
+      EM_TRY(em_relpos_attention2_bf16(qh, ws + s.kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
+                                       q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
+    } else {
+      EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
+      EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
+                                 q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
+    }
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
     // convolution module
     EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));

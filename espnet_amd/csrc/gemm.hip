@@ -363,6 +363,66 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A,
   const int c4 = (lane & 15) * 4;  // 4 consecutive output columns handled by this lane
   const int ncol = wn0 + c4;
   if (ncol >= N) return;
+  if constexpr (EPI == EM_EPI_QK_HEADS) {
+    // q | k projections written PER HEAD for csrc/attention2.hip: column n = which * d + 64 * head + c, row m = (b, t) ->
+    // C[which][b][head][t][c] with [Tpad][64] per (b, head)  (g.T1 = T, g.T2 = Tpad, g.F1 = heads, g.d = d; N = 2 d).
+    // A lane's 4 columns stay inside one head (64 | head boundary): 8-byte stores through a buffer resource.
+    if constexpr (sizeof(T) == 2) {
+      const int Tn = g.T1, Tpad = g.T2, H = g.F1, dm = g.d;
+      const size_t per_head = (size_t)(M / Tn) * dm * Tpad;
+      const int which = ncol / dm, c = ncol - which * dm, head = c >> 6, cc = c & 63;
+      const float4 b4 = bias ? *(const float4*)(bias + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (int)(unsigned)(2 * per_head * 2), 0x00020000);
+      const int b0 = wm0 / Tn, r0 = wm0 - b0 * Tn;
+#pragma unroll
+      for (int q = 0; q < MI * 4; ++q) {
+        const int dm_ = (q >> 2) * 16 + (q & 3) * 4 + lg;
+        const int m = wm0 + dm_;
+        int rem = r0 + dm_, bb = b0;
+        while (rem >= Tn) {
+          rem -= Tn;
+          ++bb;
+        }
+        const bf16x4 pk = {(bf16)(vals[q].x + b4.x), (bf16)(vals[q].y + b4.y), (bf16)(vals[q].z + b4.z), (bf16)(vals[q].w + b4.w)};
+        const size_t el = (size_t)which * per_head + ((size_t)(bb * H + head) * Tpad + rem) * 64 + cc;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, m < M ? (unsigned)(el * 2) : 0xffffffffu, 0, 0);
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == EM_EPI_VT_HEADS) {
+    // V^T for csrc/attention2.hip from the SWAPPED product: A = W_v [d][K] (row m = channel), W = activations [B*T][K]
+    // (column n = (b, t)) -> C[b][m][t] with Tpad frames per row (= [B][heads][64][Tpad]); bias per ROW.  T is odd in
+    // general, so a lane's 4 frames are not 8-byte aligned and may straddle an utterance: 2-byte stores.
+    if constexpr (sizeof(T) == 2) {
+      const int Tn = g.T1, Tpad = g.T2, dm = g.d;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(Cv, 0, (int)(unsigned)((size_t)(N / Tn) * dm * Tpad * 2), 0x00020000);
+      size_t colbase[4];
+      bool colok[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = ncol + e;
+        colok[e] = n < N;
+        const int bb = (n < N ? n : N - 1) / Tn, t = (n < N ? n : N - 1) - bb * Tn;
+        colbase[e] = (size_t)bb * dm * Tpad + t;
+      }
+#pragma unroll
+      for (int q = 0; q < MI * 4; ++q) {
+        const int m = wm0 + (q >> 2) * 16 + (q & 3) * 4 + lg;
+        const float bm = (bias && m < M) ? bias[m] : 0.f;
+        const float vv[4] = {vals[q].x, vals[q].y, vals[q].z, vals[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16 hv = (bf16)(vv[e] + bm);
+          const unsigned off = (m < M && colok[e]) ? (unsigned)((colbase[e] + (size_t)m * Tpad) * 2) : 0xffffffffu;
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), rs, off, 0, 0);
+        }
+      }
+    }
+    return;
+  }
   if constexpr (EPI == EM_EPI_RESID_F32) {
     // Residual rows leave through a raw buffer resource: a row past M gets an out-of-range offset and the hardware
     // drops its store - no per-row branch.  (With `if (m < M)` around each store hipcc put an s_waitcnt vmcnt(0)
@@ -498,6 +558,16 @@ int dispatch(int epi, int amode, const EmGemmArgs* p, hipStream_t s) {
     case EM_EPI_GLU: return launch<T, EM_EPI_GLU, EM_A_PLAIN>(p, s);
     case EM_EPI_STORE_F32: return launch<T, EM_EPI_STORE_F32, EM_A_PLAIN>(p, s);
     case EM_EPI_ARGMAX_PART: return launch<T, EM_EPI_ARGMAX_PART, EM_A_PLAIN>(p, s);
+    case EM_EPI_QK_HEADS:
+      if (sizeof(T) != 2 || p->T1 <= 0 || p->T2 < p->T1 || p->F1 <= 0 || p->d != p->F1 * 64 || p->N != 2 * p->d ||
+          p->M % p->T1 != 0 || !p->bias || (size_t)(p->M / p->T1) * p->d * p->T2 * 4 >= ((size_t)1 << 32) - 64)
+        return EM_ERR_UNSUPPORTED;
+      return launch<T, EM_EPI_QK_HEADS, EM_A_PLAIN>(p, s);
+    case EM_EPI_VT_HEADS:
+      if (sizeof(T) != 2 || p->T1 <= 0 || p->T2 < p->T1 || p->d != p->M || p->N % p->T1 != 0 ||
+          (size_t)(p->N / p->T1) * p->d * p->T2 * 2 >= ((size_t)1 << 32) - 64)
+        return EM_ERR_UNSUPPORTED;
+      return launch<T, EM_EPI_VT_HEADS, EM_A_PLAIN>(p, s);
   }
   return EM_ERR_BAD_ARG;
 }

@@ -15,7 +15,8 @@ EM_OK = 0
 EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE, EM_ERR_IO = -1, -2, -3, -4, -5, -6
 EM_F32, EM_BF16 = 0, 1
 (EM_EPI_STORE, EM_EPI_SWISH, EM_EPI_RELU, EM_EPI_RESID_F32, EM_EPI_SCALE_F32, EM_EPI_GLU,
- EM_EPI_STORE_F32, _EM_EPI_UNUSED_7, _EM_EPI_UNUSED_8, EM_EPI_ARGMAX_PART, EM_EPI_GELU) = range(11)
+ EM_EPI_STORE_F32, _EM_EPI_UNUSED_7, _EM_EPI_UNUSED_8, EM_EPI_ARGMAX_PART, EM_EPI_GELU, EM_EPI_QK_HEADS,
+ EM_EPI_VT_HEADS) = range(13)
 EM_A_PLAIN, EM_A_CONV2 = 0, 1
 
 EM_DW_SWISH, EM_DW_LINEAR, EM_DW_GATE, EM_DW_SELFRES = range(4)

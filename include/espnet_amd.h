@@ -49,6 +49,15 @@ extern "C" {
  *   ldc = number of 64-column groups = 2 * ceil(N / 128); finish with em_argmax_partials.        */
 #define EM_EPI_ARGMAX_PART 9
 #define EM_EPI_GELU 10     /* C[act]  = gelu_erf(acc + bias)    (cgMLP channel_proj1, cgmlp.py:106) */
+/* Operands of the LDS-resident attention (em_relpos_attention2_bf16) written by the projection GEMM itself (bf16 only;
+ * T1 = T frames per utterance, T2 = Tpad, F1 = heads, d = heads * 64; M resp. N a multiple of T):
+ *   EM_EPI_QK_HEADS  A = activations [B*T][K], W = the q | k rows [2d][K], bias [2d]:
+ *                    C = q then k, each [B][heads][Tpad][64]   (column n = which * d + 64 * head + c, row m = (b, t))
+ *   EM_EPI_VT_HEADS  the SWAPPED product A = W_v [d][K], W = activations [B*T][K], bias PER ROW [d]:
+ *                    C = V^T [B][heads][64][Tpad]              (row m = channel, column n = (b, t))
+ * Frames t >= T of a (b, head) slab are not written.                                                              */
+#define EM_EPI_QK_HEADS 11
+#define EM_EPI_VT_HEADS 12
 
 /* A-operand addressing */
 #define EM_A_PLAIN 0 /* row m at A + m*lda */

@@ -454,3 +454,32 @@ def test_gemm_large_m_bf16_128x128_tile(lib, epi):
     L.check(lib.em_gemm(L.EM_BF16, code, L.EM_A_PLAIN, args, sptr()), "em_gemm large")
     assert_close(out, ref, 2e-4 if f32out else 2e-2, f"large-M gemm {epi}")
 
+
+
+@pytest.mark.parametrize("B,T,h", [(3, 249, 8), (2, 31, 4), (5, 64, 2)])
+def test_gemm_head_layout_epilogues(lib, B, T, h):
+    """Round 4: the per-head operands of the LDS-resident attention written by the projection GEMMs themselves -
+    EM_EPI_QK_HEADS (q | k as [B][heads][Tpad][64]) and EM_EPI_VT_HEADS (V^T [B][heads][64][Tpad] from the swapped product
+    W_v . x^T with a per-row bias); frames >= T of a slab are left untouched.  T odd, utterance boundaries inside a tile."""
+    d, K, Tpad = 64 * h, 64 * h, 256
+    M = B * T
+    x = q(rnd(M, K, seed=1), torch.bfloat16)
+    w = q(rnd(3 * d, K, seed=2, scale=K ** -0.5), torch.bfloat16)
+    bias = rnd(3 * d, seed=3)
+    xd, wd, bd = dev(x.to(torch.bfloat16)), dev(w.to(torch.bfloat16)), dev(bias)
+    qk = torch.full((2, B, h, Tpad, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    vt = torch.full((B, h, 64, Tpad), 7.0, dtype=torch.bfloat16, device="cuda")
+    a = L.EmGemmArgs(A=xd.data_ptr(), W=wd.data_ptr(), C=qk.data_ptr(), bias=bd.data_ptr(), M=M, N=2 * d, K=K, lda=K,
+                     ldc=64, scale=1.0, T1=T, T2=Tpad, F1=h, d=d)
+    L.check(lib.em_gemm(L.EM_BF16, L.EM_EPI_QK_HEADS, L.EM_A_PLAIN, a, sptr()), "em_gemm(QK_HEADS)")
+    a = L.EmGemmArgs(A=wd.data_ptr() + 2 * d * K * 2, W=xd.data_ptr(), C=vt.data_ptr(), bias=bd.data_ptr() + 2 * d * 4,
+                     M=d, N=M, K=K, lda=K, ldc=Tpad, scale=1.0, T1=T, T2=Tpad, F1=h, d=d)
+    L.check(lib.em_gemm(L.EM_BF16, L.EM_EPI_VT_HEADS, L.EM_A_PLAIN, a, sptr()), "em_gemm(VT_HEADS)")
+    ref = x @ w.t() + bias  # (M, 3d)
+    for which in range(2):
+        want = ref[:, which * d : (which + 1) * d].reshape(B, T, h, 64).permute(0, 2, 1, 3)
+        assert_close(qk[which, :, :, :T], want, 2e-2, f"head layout which={which}")
+        assert bool((qk[which, :, :, T:].float() == 7.0).all())
+    want_v = ref[:, 2 * d :].reshape(B, T, h, 64).permute(0, 2, 3, 1)
+    assert_close(vt[:, :, :, :T], want_v, 2e-2, "V^T head layout")
+    assert bool((vt[:, :, :, T:].float() == 7.0).all())

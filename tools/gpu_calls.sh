@@ -57,6 +57,15 @@ case "$what" in
     ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_fine.so ESPNET_AMD_FOLD=1 EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "block<7>" | tail -8 | tee "$out/block_stamps_fine.txt" ;;
   two-streams)  # probe: the batch as two half batches on two streams
     timeout 300 python tools/two_stream_probe.py 2>&1 | grep "ms per step" | tee "$out/two_stream_probe.txt" ;;
+  attn2-large)  # round 4: the large model's attention through attention2 (per-head operands from the projection GEMMs)
+    echo "== tests"; timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_e2e.py tests/test_gpu_search.py tests/test_gpu_ebranchformer.py -q -x \
+       -k "head_layout or large or gemm or ebf or bf_" 2>&1 | tail -4 | tee "$out/pytest.txt"
+    for v in 1 0 1 0; do
+      if [ $v = 1 ]; then export ESPNET_AMD_NO_ATTN2_LARGE=1; else unset ESPNET_AMD_NO_ATTN2_LARGE; fi
+      echo -n "no_attn2_large=$v: "; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180
+    done
+    unset ESPNET_AMD_NO_ATTN2_LARGE
+    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
   full|bench)
     if [ "$what" = full ]; then
       echo "== pytest -m gpu"; (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) 2>&1 | tee "$out/pytest_gpu.txt"
