@@ -152,7 +152,7 @@ def pack_conv1_frags(w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
     w1 = w1.detach().to(torch.float32).cpu().reshape(-1, 9)
     b1 = b1.detach().to(torch.float32).cpu()
     d = w1.shape[0]
-    assert d == 256, d
+    assert d % 32 == 0, d
 
     def hi(x):
         return x.to(torch.bfloat16).to(torch.float32)
@@ -161,7 +161,7 @@ def pack_conv1_frags(w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
     wl, bl = hi(w1 - wh), hi(b1 - bh)
     k = torch.zeros(d, 32)
     k[:, 0:9], k[:, 9:18], k[:, 18:27], k[:, 27], k[:, 28] = wh, wh, wl, bh, bl
-    return k.reshape(8, 2, 16, 4, 8).permute(0, 1, 3, 2, 4).contiguous().reshape(-1)
+    return k.reshape(d // 32, 2, 16, 4, 8).permute(0, 1, 3, 2, 4).contiguous().reshape(-1)
 
 
 def pack_conv2_frags(w2: torch.Tensor) -> torch.Tensor:
@@ -170,9 +170,12 @@ def pack_conv2_frags(w2: torch.Tensor) -> torch.Tensor:
     MFMA row lr of a wave's fragment j is an output channel chosen so that a lane's 16 results of a position
     (4 fragments x 4 rows) are 16 CONSECUTIVE channels - two 16-byte stores instead of four 8-byte ones."""
     n, k = w2.shape
-    assert n == 256 and k == 9 * 256, (n, k)
-    u = w2.detach().reshape(4, 4, 4, 4, 9, 8, 4, 8)  # [w][q = lr // 4][j][r = lr % 4][tap][cc][lg][e]
-    return u.permute(5, 4, 0, 2, 6, 1, 3, 7).contiguous().reshape(-1)
+    assert n % 256 == 0 and k == 9 * n, (n, k)  # (d = 512: one block of this layout per 256 output channels, 16 chunks each)
+    halves = []
+    for h0 in range(0, n, 256):
+        u = w2.detach()[h0 : h0 + 256].reshape(4, 4, 4, 4, 9, n // 32, 4, 8)  # [w][q = lr // 4][j][r = lr % 4][tap][cc][lg][e]
+        halves.append(u.permute(5, 4, 0, 2, 6, 1, 3, 7).contiguous().reshape(-1))
+    return torch.cat(halves)
 
 
 def rel_pos_table(T: int, d: int) -> torch.Tensor:
@@ -459,7 +462,7 @@ class ConformerEncoder(torch.nn.Module):
         k2 = e.conv[2].weight.size(-1)
         t["conv2_w"] = A(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, k2 * k2 * d))
         t["conv2_b"] = F(e.conv[2].bias)
-        if layer == "conv2d" and d == 256 and self.em_dtype == L.EM_BF16:
+        if layer == "conv2d" and d in (256, 512) and self.em_dtype == L.EM_BF16:
             # operands of the fused conv1 + conv2 kernel (csrc/subsample2.hip): the conv1 map is never materialised
             t["conv1_wf"] = A(pack_conv1_frags(e.conv[0].weight, e.conv[0].bias))
             t["conv2_wf"] = A(pack_conv2_frags(e.conv[2].weight.permute(0, 2, 3, 1).reshape(d, 9 * d)))

@@ -42,11 +42,11 @@
 
 namespace {
 
-constexpr int D = 256;
+constexpr int D = 256;           // OUTPUT channels of one launch; wider models run one launch per 256-channel half (round 4)
 constexpr int TT = 8;          // output time rows per workgroup
 constexpr int MF = 10;         // position fragments of conv2: TT * F2 <= 160
 constexpr int CC = 32;         // input channels per chunk = one MFMA k-step per tap
-constexpr int NCHUNK = D / CC; // 8
+// (chunks of 32 INPUT channels: a template argument of the kernel - 8 for d = 256, 16 for d = 512)
 constexpr int T1R = 2 * TT + 1;   // conv1 rows a tile reaches: 17
 constexpr int INR = 2 * T1R + 1;  // feature rows: 35
 constexpr int F1MAX = 40, F2MAX = 19, MELMAX = 2 * F1MAX + 2;
@@ -69,7 +69,6 @@ constexpr int MEAN_OFF = PATCH_OFF + 2 * PATCH_BYTES;  // f32 [MAXK][MELMAX]: pe
 constexpr int BIAS_OFF = MEAN_OFF + MAXK * MELMAX * 4;  // f32 [D]: conv2's bias (read in the epilogue without touching vmcnt)
 constexpr int SMEM_BYTES = BIAS_OFF + D * 4;
 static_assert(INR * MELMAX * 4 + 1024 <= PATCH_BYTES && SMEM_BYTES <= 160 * 1024, "LDS");
-static_assert(NCHUNK % 2 == 0, "the last chunk must read patch 1");
 template <bool V> struct Flag { static constexpr bool value = V; };
 constexpr int PF_PER_WAVE = (NPF + 3) / 4;  // 11
 static_assert(PF_PER_WAVE <= 17, "a conv1 fragment per group of a chunk at most, finished in the group after");
@@ -105,7 +104,8 @@ struct Sub2Args {
   const void* w1f;        // conv1 weights + bias as MFMA operands, [8 chunks][2 fragments][64 lanes][8] bf16
   const void* w2f;        // conv2 weights, fragment-major [chunk][tap][wave][frag][lane][8] bf16
   const float* b2;        // [256]
-  void* out;              // [B][T2][F2][256] bf16
+  void* out;              // [B][T2][F2][ldo] bf16, already offset to this launch's first output channel
+  int ldo;                // channels per output position (= d of the model)
   int B, T_f, n_mels, F1, T2, F2;
   long long* stamps;      // developer timing (EM_SUB2_STAMPS): cycle stamps of workgroup (3, 5), wave 0
 };
@@ -121,7 +121,9 @@ __device__ __forceinline__ void mfma_acc(f32x4& acc, const bf16x8& a, const bf16
 __device__ __forceinline__ bf16 hi_of(float x) { return (bf16)x; }
 __device__ __forceinline__ bf16 lo_of(float x) { return (bf16)(x - (float)(bf16)x); }
 
+template <int NCHUNK>
 __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
+  static_assert(NCHUNK % 2 == 0, "the last chunk must read patch 1");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* const s_in = (float*)(smem + IN_OFF);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
     const int t2l = m / F2, f2 = m - t2l * F2;
     pb[i] = (2 * t2l) * ROWP + (2 * f2) * PSTRIDE + lg * 16;
   }
-  const size_t out_bytes = (size_t)a.B * a.T2 * F2 * D * 2;
+  const size_t out_bytes = ((size_t)a.B * a.T2 * F2 * a.ldo - (a.ldo - D)) * 2;  // (from this launch's first channel to the end of the last position's 256)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)(unsigned)out_bytes, 0x00020000);
 
   for (;;) {
@@ -469,13 +471,13 @@ __global__ __launch_bounds__(256, 1) void sub2_kernel(const Sub2Args a) {
   // a scratch reload in front of every group of stores, each one a wait for all the stores before it)
   int mlim = (a.T2 - t2_0) * F2;
   mlim = mlim < M ? mlim : M;
-  const unsigned base0 = (unsigned)(((((size_t)b * a.T2 + t2_0) * F2 + lr) * D + wave * 64 + lg * 16) * 2);
+  const unsigned base0 = (unsigned)(((((size_t)b * a.T2 + t2_0) * F2 + lr) * a.ldo + wave * 64 + lg * 16) * 2);
   ++kt;
   const float* const s_mean_next = s_means + (next < ntiles ? kt : kt - 1) * MELMAX;
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const bool ok = i * 16 + lr < mlim;
-    const unsigned off = ok ? base0 + (unsigned)(i * 16 * D * 2) : 0xffffffffu;
+    const unsigned off = ok ? base0 + (unsigned)(i * 16 * a.ldo * 2) : 0xffffffffu;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // fragments 2 h, 2 h + 1: channels 8 h .. 8 h + 7 of the lane's sixteen
       typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -515,13 +517,16 @@ extern "C" int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial
   const int T1 = (T_f - 3) / 2 + 1, F1 = (n_mels - 3) / 2 + 1;
   const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
   if (n_mels % 4 != 0) return EM_ERR_UNSUPPORTED;  // 16-byte LDS-DMA pieces of whole rows
-  if (d != D || n_mels < 7 || n_mels > MELMAX || F1 > F1MAX || F2 > F2MAX || TT * F2 > 16 * MF) return EM_ERR_UNSUPPORTED;
-  if ((size_t)B * T2 * F2 * D * 2 >= ((size_t)1 << 32) - 64) return EM_ERR_UNSUPPORTED;  // one buffer resource
-  static EmLdsCap cap = {};
-  if (em_raise_lds_cap((const void*)sub2_kernel, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
+  if ((d != D && d != 2 * D) || n_mels < 7 || n_mels > MELMAX || F1 > F1MAX || F2 > F2MAX || TT * F2 > 16 * MF) return EM_ERR_UNSUPPORTED;
+  if ((size_t)B * T2 * F2 * d * 2 >= ((size_t)1 << 32) - 64) return EM_ERR_UNSUPPORTED;  // one buffer resource
+  const int nhalf = d / D;  // d = 512 (round 4): one launch per 256 output channels, 16 chunks of input channels each;
+                            // conv1 is recomputed by both (22 of a chunk's 382 MFMAs per wave)
+  static EmLdsCap cap8 = {}, cap16 = {};
+  if (nhalf == 1 && em_raise_lds_cap((const void*)sub2_kernel<8>, SMEM_BYTES, &cap8) != EM_OK) return EM_ERR_LAUNCH;
+  if (nhalf == 2 && em_raise_lds_cap((const void*)sub2_kernel<16>, SMEM_BYTES, &cap16) != EM_OK) return EM_ERR_LAUNCH;
   Sub2Args a;
   a.feats = feats; a.partial = mvn_partial; a.flens = flens;
-  a.w1f = conv1_wf; a.w2f = conv2_wf; a.b2 = conv2_b; a.out = c2;
+  a.w1f = conv1_wf; a.w2f = conv2_wf; a.b2 = conv2_b; a.out = c2; a.ldo = d;
   a.B = B; a.T_f = T_f; a.n_mels = n_mels; a.F1 = F1; a.T2 = T2; a.F2 = F2;
   static long long* stamps = nullptr;
   static const bool want_stamps = getenv("EM_SUB2_STAMPS") != nullptr;
@@ -541,7 +546,16 @@ extern "C" int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial
   const int ntiles = em_cdiv(T2, TT) * B;
   int grid = ntiles < ncu ? ntiles : ncu;
   if (em_cdiv(ntiles, grid) > MAXK) grid = em_cdiv(ntiles, MAXK);  // (very large batches: more than one workgroup per CU in sequence)
-  hipLaunchKernelGGL(sub2_kernel, dim3(grid), dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+  if (nhalf == 1) {
+    hipLaunchKernelGGL(sub2_kernel<8>, dim3(grid), dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+  } else {
+    for (int hf = 0; hf < 2; ++hf) {
+      a.w2f = (const unsigned char*)conv2_wf + (size_t)hf * 16 * 9 * 16384;
+      a.b2 = conv2_b + hf * D;
+      a.out = (unsigned char*)c2 + (size_t)hf * D * 2;
+      hipLaunchKernelGGL(sub2_kernel<16>, dim3(grid), dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+    }
+  }
   if (want_stamps) {
     long long h[32];
     if (hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -551,7 +565,7 @@ extern "C" int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial
       fflush(stdout);
     }
   }
-  if (rec) em_prof_end(stream, 2.0 * (double)B * T2 * F2 * D * 9.0 * D, EM_PROF_GEMM);
+  if (rec) em_prof_end(stream, 2.0 * (double)B * T2 * F2 * d * 9.0 * d, EM_PROF_GEMM);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

@@ -203,8 +203,9 @@ def test_utt_mvn_and_conv1(lib):
         assert_close(out, ref, tol, f"conv1 {prec}")
 
 
+@pytest.mark.parametrize("d", [256, 512])
 @pytest.mark.parametrize("T_f,D,with_mvn", [(61, 80, True), (133, 80, False), (47, 40, True), (7, 80, True)])
-def test_conv2d_sub12_fused(lib, T_f, D, with_mvn):
+def test_conv2d_sub12_fused(lib, T_f, D, with_mvn, d):
     """Conv2dSubsampling's two convolutions in one kernel (csrc/subsample2.hip; conv1 on the matrix cores with split-bf16
     operands, the conv1 map only in LDS) against torch's f32 convolutions.
 
@@ -216,7 +217,7 @@ def test_conv2d_sub12_fused(lib, T_f, D, with_mvn):
     profiles/r03k_sub12_accuracy.txt)."""
     from espnet_amd.asr.encoder.conformer_encoder import pack_conv1_frags, pack_conv2_frags
 
-    B, d = 3, 256
+    B = 3  # d = 512 (round 4): one launch per 256 output channels, 16 chunks of input channels
     flens = torch.tensor([T_f, max(7, T_f - 9), 7])
     feats = (rnd(B, T_f, D, seed=31) * 2 - 8).masked_fill(oc.make_pad_mask(flens, T_f)[:, :, None], 0.0)
     fl = dev(flens.to(torch.int32))

@@ -66,6 +66,14 @@ case "$what" in
     done
     unset ESPNET_AMD_NO_ATTN2_LARGE
     echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
+  sub2-large)  # round 4: the fused conv1 + conv2 kernel at d = 512 (two launches of 256 output channels)
+    echo "== tests"; timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_e2e.py -q -x -k "sub12 or large or conv2d" 2>&1 | tail -4 | tee "$out/pytest.txt"
+    for v in 1 0 1 0; do
+      if [ $v = 1 ]; then export ESPNET_AMD_NO_SUB12=1; else unset ESPNET_AMD_NO_SUB12; fi
+      echo -n "no_sub12=$v: "; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180
+    done
+    unset ESPNET_AMD_NO_SUB12
+    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
   full|bench)
     if [ "$what" = full ]; then
       echo "== pytest -m gpu"; (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) 2>&1 | tee "$out/pytest_gpu.txt"
