@@ -81,7 +81,14 @@ case "$what" in
     echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -4 | tee "$out/smoke.txt"
     echo "== default bench"; (time timeout 900 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5
     echo "== rocprofv3 kernel stats, greedy"
-    stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10 ;;
+    stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10
+    if [ "$what" = full ]; then
+      echo "== box state (TCC counters)"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tail -12 | tee "$out/box_state.txt"
+      echo "== rocprofv3 kernel stats, large B=64"
+      stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3
+      echo "== E-Branchformer"; timeout 300 python bench.py --model ebf --quick --no-traffic --no-cpu-baseline --steps 50 --warmup 5 2>/dev/null < /dev/null | tee "$out/bench_ebf.json" | cut -c1-200
+      echo "== search kernel stats"; stats "$out/search_stats" python "$R/bench.py" --workload beam --steps 1 --warmup 1 --no-cpu-baseline --no-traffic
+    fi ;;
   sub2)
     echo "== stamps"
     EM_SUB2_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 3 --warmup 2 2>&1 | grep "sub2 stamps" | head -2 | tee "$out/stamps.txt"
