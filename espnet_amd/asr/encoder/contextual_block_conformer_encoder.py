@@ -189,12 +189,56 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
                 pw2=A(cm.pointwise_conv2.weight.reshape(d, d)), pw2_b=F(cm.pointwise_conv2.bias),
                 ff_w1=A(l.feed_forward.w_1.weight), ff_b1=F(l.feed_forward.w_1.bias),
                 ff_w2=A(l.feed_forward.w_2.weight), ff_b2=F(l.feed_forward.w_2.bias))
+            if self._fusable():
+                lt.update(self._fused_layer(l, A, F))
             for k, v in lt.items():
                 setattr(layers[i], k, v.data_ptr())
         w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))
         pe = abs_pos_table(5000, d).to(dev)  # StreamPositionalEncoding.extend_pe (embedding.py:357-374)
         self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype, pe=pe, F2=F2)
         return self._packed
+
+    def _fusable(self) -> bool:
+        """Shapes the fused streaming layer covers (csrc/streaming.hip `cb_fusable`, csrc/block.hip with EM_BLOCK_RELU):
+        bf16, 256 wide, 4 heads, depthwise conv width 15, feed-forward width a multiple of 128 up to 4096 - the
+        aishell streaming recipe.  Everything else keeps the thirteen launches per layer."""
+        return (bool(getattr(self, "fused", True))  # (`enc.fused = False` + `invalidate()`: A/B and bisecting)
+                and self.em_dtype == L.EM_BF16 and self._output_size == 256 and self.heads == 4
+                and self.cnn_module_kernel == 15 and self.linear_units % 128 == 0 and self.linear_units <= 4096)
+
+    def _fused_layer(self, l, A, F):
+        """Operands of the row-block kernels for one contextual-block layer (include/espnet_amd.h, EmBlockArgs): weights
+        in fragment-major units (`pack_k_units` / `pack_w1` / `pack_w2` of the Conformer encoder), bias / LayerNorm
+        vectors as groups of EM_BLOCK_PARAM_GROUP floats in the order the kernels consume them.  The first FFN bias
+        does not fit a group at ff = 2048: the kernels read it from the row-major `ffm_b1` / `ff_b1` (EmBlockArgs.ffm_b1g /
+        ff_b1g) and its slot in the group stays zero."""
+        from espnet_amd.asr.encoder.conformer_encoder import pack_k_units, pack_w1, pack_w2
+
+        d, G = self._output_size, L.EM_BLOCK_PARAM_GROUP
+        sa, cm = l.self_attn, l.conv_module
+
+        def group(*vecs):
+            v = torch.cat([t.detach().to(torch.float32).reshape(-1).cpu() for t in vecs])
+            assert v.numel() <= G
+            return torch.nn.functional.pad(v, (0, G - v.numel()))
+
+        b1_slot = torch.zeros(1024)
+        perm = torch.cat([torch.cat([torch.arange(64 * j, 64 * j + 64), torch.arange(d + 64 * j, d + 64 * j + 64)])
+                          for j in range(d // 64)])
+        pw1 = cm.pointwise_conv1.weight.reshape(2 * d, d)
+        fp_a = torch.cat([group(l.norm_ff_macaron.weight, l.norm_ff_macaron.bias, b1_slot, l.feed_forward_macaron.w_2.bias),
+                          group(l.norm1.weight, l.norm1.bias, sa.linear_q.bias, sa.linear_k.bias, sa.linear_v.bias)])
+        fp_d = torch.cat([group(cm.pointwise_conv2.bias, l.norm2.weight, l.norm2.bias),
+                          group(b1_slot, l.feed_forward.w_2.bias, l.norm_final.weight, l.norm_final.bias),
+                          torch.zeros(G)])
+        return dict(
+            pw1f=A(pack_k_units(pw1[perm])), ffm_w2p=A(pack_w2(l.feed_forward_macaron.w_2.weight)),
+            ff_w2p=A(pack_w2(l.feed_forward.w_2.weight)), woutp=A(pack_k_units(sa.linear_out.weight)),
+            pw2p=A(pack_k_units(cm.pointwise_conv2.weight.reshape(d, d))),
+            ff_w1p=A(pack_w1(l.feed_forward.w_1.weight)), ffm_w1p=A(pack_w1(l.feed_forward_macaron.w_1.weight)),
+            wqkvp=A(pack_k_units(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0))),
+            fp_c=F(group(sa.linear_out.bias, l.norm_conv.weight, l.norm_conv.bias, cm.pointwise_conv1.bias[perm])),
+            fp_da=F(fp_d), fp_a=F(fp_a))
 
     def _ensure_packed(self, device):
         p = self._packed

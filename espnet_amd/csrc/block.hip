@@ -74,12 +74,13 @@ constexpr int XCH_OFF = WK_OFF + 32768;                      // 48 KiB more: wit
 constexpr int XSLOT = 8192;                                  // one (destination wave, source wave) slot: [4 fragments][2 halves][64 lanes] f32x4
 constexpr int SMEM_BYTES = XCH_OFF + 49152;                  // 159 KiB
 static_assert(ABUF_OFF % 1024 == 0 && TILE_OFF % 1024 == 0 && SMEM_BYTES <= 160 * 1024, "LDS layout");
-constexpr int KW = 31, HALF = 15, TROWS = BM + KW - 1;  // depthwise conv: 62-row input tile
+constexpr int KW_MAX = 31, TROWS_MAX = BM + KW_MAX - 1;  // depthwise conv: kernel width is a template argument (31: the
+                                                          // Conformer recipes, 15: the streaming recipe), 62-row input tile at most
 // Row pitch of the conv tile: 512 + 16 bytes.  The conv reads a row's 256 channels contiguously (any pitch will do);
 // the folded C part WRITES it from the GEMM layout - lane (lr, lg) 8 bytes of row lr - and with the dense pitch the 16
 // rows of a fragment fall on the same banks (16-way conflict); 132 words per row step them by 4 banks: conflict-free.
 constexpr int TPITCH = 528;
-static_assert(TROWS * TPITCH <= 32768, "conv tile");
+static_assert(TROWS_MAX * TPITCH <= 32768, "conv tile");
 // The folded C part borrows the FFN's exchange area (idle until the first FFN): its parameter group and LN(x) of its 64
 // rows as four [64][64] bf16 k-tiles.
 constexpr int CPAR_OFF = XCH_OFF;
@@ -111,14 +112,19 @@ constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;  // what
 
 #define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int MODE>
+// KWT: depthwise-conv kernel width (D part).  RELU: the feed-forward activation is ReLU (the contextual-block streaming
+// encoder, contextual_block_conformer_encoder.py:148-154) instead of Swish; the conv module's Swish is unaffected.
+template <int MODE, int KWT = 31, bool RELU = false>
 __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long long* __restrict__ stamps) {
+  constexpr int KW = KWT, HALF = KWT / 2, TROWS = BM + KWT - 1;
+  static_assert(KWT == 31 || KWT == 15, "depthwise conv width");
   constexpr int dbg = EM_BLOCK_DBG;
   using MM = Mma<bf16>;
   constexpr bool HAS_C = (MODE & EM_BLOCK_C) != 0, HAS_D = (MODE & EM_BLOCK_D) != 0;
   constexpr bool HAS_A = (MODE & EM_BLOCK_A) != 0, FINAL = (MODE & EM_BLOCK_FINAL) != 0;
   constexpr bool CTC = (MODE & EM_BLOCK_CTC) != 0;
   constexpr bool FOLD = HAS_C && HAS_D;  // the C part computed in this launch, for 64 frames (round 4)
+  static_assert(!FOLD || KWT == 31, "the folded C part is written for the 15-frame halo of k = 31");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const abuf = smem + ABUF_OFF;
   float* const red0 = (float*)(smem + RED_OFF);
@@ -477,8 +483,20 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     read_w2(w2, 0, 0, ring[2]);
     read_w2(w2, 0, 1, ring[3]);
   };
-  auto ffn = [&](const float* pb, int b1o, int b2o, float scale, const void* w1, const void* w2, bool repark) {
+  // b1g != NULL: the first bias comes from GLOBAL memory (ff > 1024 does not fit the 7 KiB parameter group: the streaming
+  // recipe's 2048), requested one pair ahead so that its latency is never in the chain
+  auto ffn = [&](const float* pb, int b1o, int b2o, float scale, const void* w1, const void* w2, bool repark,
+                 const float* b1g) {
     const int np = nch >> 1, lastc = nch - 1;
+    // (compile-time: only the streaming instantiations carry the global-bias path; in the Conformer kernels a run-time
+    // choice cost 30 registers)
+    constexpr bool B1G = RELU;
+    float4 nb0 = make_float4(0.f, 0.f, 0.f, 0.f), nb1 = nb0;
+    if constexpr (B1G) {
+      nb0 = *(const float4*)(b1g + ncol);
+      nb1 = *(const float4*)(b1g + 64 + ncol);
+    }
+    auto act_ = [](float v) { return RELU ? fmaxf(v, 0.f) : swishf_(v); };
     f32x4 acc2[16][2];
 #pragma unroll
     for (int f = 0; f < 16; ++f) acc2[f][0] = acc2[f][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -491,14 +509,23 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       for (int f = 0; f < 4; ++f) xpark[(mi * 4 + f) * NT] = xr[mi][f];
     // bias + Swish + bf16 of the two chunks' 16 hidden columns of this wave -> the B fragments of the pair
     auto swish_pack = [&](const f32x4 h[2][2], int p, bf16x8 hb[2]) {
-      const float4 b0 = *(const float4*)(pb + b1o + (2 * p) * 64 + ncol);
-      const float4 b1 = *(const float4*)(pb + b1o + (2 * p + 1) * 64 + ncol);
+      float4 b0, b1;
+      if constexpr (B1G) {
+        b0 = nb0;
+        b1 = nb1;
+        const int pn = p + 1 < np ? p + 1 : p;  // (unconditional: past the end the last pair's again)
+        nb0 = *(const float4*)(b1g + (2 * pn) * 64 + ncol);
+        nb1 = *(const float4*)(b1g + (2 * pn + 1) * 64 + ncol);
+      } else {
+        b0 = *(const float4*)(pb + b1o + (2 * p) * 64 + ncol);
+        b1 = *(const float4*)(pb + b1o + (2 * p + 1) * 64 + ncol);
+      }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        hb[mi] = (bf16x8){(bf16)swishf_(h[0][mi][0] + b0.x), (bf16)swishf_(h[0][mi][1] + b0.y),
-                          (bf16)swishf_(h[0][mi][2] + b0.z), (bf16)swishf_(h[0][mi][3] + b0.w),
-                          (bf16)swishf_(h[1][mi][0] + b1.x), (bf16)swishf_(h[1][mi][1] + b1.y),
-                          (bf16)swishf_(h[1][mi][2] + b1.z), (bf16)swishf_(h[1][mi][3] + b1.w)};
+        hb[mi] = (bf16x8){(bf16)act_(h[0][mi][0] + b0.x), (bf16)act_(h[0][mi][1] + b0.y),
+                          (bf16)act_(h[0][mi][2] + b0.z), (bf16)act_(h[0][mi][3] + b0.w),
+                          (bf16)act_(h[1][mi][0] + b1.x), (bf16)act_(h[1][mi][1] + b1.y),
+                          (bf16)act_(h[1][mi][2] + b1.z), (bf16)act_(h[1][mi][3] + b1.w)};
     };
     // 16 MFMAs of a W2 sub-unit: output fragments 8 half .. 8 half + 7, both frame halves
     auto mma_w2 = [&](const WF& w, int half, const bf16x8 hb[2]) {
@@ -878,13 +905,14 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         // (pinned: the opaque asm ties a zero offset of the request addresses to ALL accumulators of the running
         // convolution, so the requests can neither be hoisted above this row nor the rows before it sunk below them;
         // a sched_barrier alone does not do it: instruction selection places arithmetic freely around it)
-        if (r == 15 || r == 30) {
+        constexpr int PIN1 = KWT == 31 ? 15 : 10, PIN2 = KWT == 31 ? 30 : 20;  // (thirds of the row loop)
+        if (r == PIN1 || r == PIN2) {
           unsigned o = 0;
           asm volatile("" : "+s"(o), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
                        "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]),
                        "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
           const unsigned char* wp = (const unsigned char*)a.pw2 + o;
-          if (r == 15) {
+          if (r == PIN1) {
             read_unit(wp, 0, ring[0]);
             read_unit(wp, 1, ring[1]);
           } else {
@@ -922,7 +950,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     ffn_pre(a.ff_w1, a.ff_w2);
     ln_to_act(pb0, 256, 512, 0);                   // norm_ff
     stamp(15);
-    ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false);  // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
+    ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false, a.ff_b1g);  // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
     stamp(22);
     {
       float4 y[2][4];
@@ -1035,6 +1063,11 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       touch_done();
       return;
     }
+    if constexpr (!HAS_A && !FINAL) {  // the D part alone (streaming layers: the context hand-over sits between D and A)
+      store_x();
+      touch_done();
+      return;
+    }
   } else {
     load_x();
   }
@@ -1051,7 +1084,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     if (!HAS_D) touch();
     ln_to_act(pa0, 0, 256, 0);
     stamp(15);
-    ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2, true);  // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
+    ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2, true, a.ffm_b1g);  // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
     stamp(22);
     // (x is stored at the very END of the kernel, from its LDS parking place: its eight 16-byte stores per lane, issued
     // in front of the q / k / v weight requests, sat in the same in-order count the waits for those requests use and
@@ -1125,16 +1158,16 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   touch_done();
 }
 
-template <int MODE>
+template <int MODE, int KWT = 31, bool RELU = false>
 int launch_block(const EmBlockArgs* a, hipStream_t s) {
   static EmLdsCap cap = {};
-  if (em_raise_lds_cap((const void*)block_kernel<MODE>, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
+  if (em_raise_lds_cap((const void*)block_kernel<MODE, KWT, RELU>, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(a->T, BM), a->B);
   static long long* stamps = nullptr;
   static const bool want_stamps = getenv("EM_BLOCK_STAMPS") != nullptr;
   if (want_stamps && !stamps) hipMalloc((void**)&stamps, 256 * sizeof(long long));
   if (want_stamps) hipMemsetAsync(stamps, 0, 256 * sizeof(long long), s);
-  hipLaunchKernelGGL((block_kernel<MODE>), grid, dim3(NT), SMEM_BYTES, s, *a, stamps);
+  hipLaunchKernelGGL((block_kernel<MODE, KWT, RELU>), grid, dim3(NT), SMEM_BYTES, s, *a, stamps);
   if (want_stamps) {
     long long h[256];
     hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
@@ -1154,16 +1187,23 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
 }  // namespace
 extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* stream) {
   if (!a || !a->x || !a->params || a->B <= 0 || a->T <= 0) return EM_ERR_BAD_ARG;
-  if (a->d != D || a->ff <= 0 || a->ff % 64 != 0 || a->ff > 1024) return EM_ERR_UNSUPPORTED;
+  const bool relu = (mode & EM_BLOCK_RELU) != 0;  // streaming layers: ReLU feed-forward, conv width 15, ff up to 4096
+  mode &= ~EM_BLOCK_RELU;
+  if (a->d != D || a->ff <= 0 || a->ff % 64 != 0 || a->ff > 4096) return EM_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const bool need_a = (mode & EM_BLOCK_A) != 0, need_d = (mode & EM_BLOCK_D) != 0;
+  // the first FFN bias lives in the 7 KiB parameter group up to ff = 1024; wider FFNs hand it over in global memory
+  if (!relu && a->ff > 1024) return EM_ERR_UNSUPPORTED;
+  if (relu && ((need_a && !a->ffm_b1g) || (need_d && !a->ff_b1g))) return EM_ERR_BAD_ARG;  // (these instantiations always read it there)
+  if (relu && mode != EM_BLOCK_A && mode != EM_BLOCK_D) return EM_ERR_UNSUPPORTED;  // (the instantiations that exist)
+  if (!relu && mode == EM_BLOCK_D) return EM_ERR_UNSUPPORTED;
   if (need_a) {
     if (!a->ffm_w1 || !a->ffm_w2 || !a->wqkv || !a->qh || !a->kh || !a->vt) return EM_ERR_BAD_ARG;
     if (a->Tpad % 64 != 0 || a->Tpad < em_cdiv(a->T, BM) * BM) return EM_ERR_BAD_ARG;
   }
   if (need_d) {
     if ((!a->glu && !(mode & EM_BLOCK_C)) || !a->pw2 || !a->ff_w1 || !a->ff_w2 || !a->dw_w || !a->dw_b) return EM_ERR_BAD_ARG;
-    if (a->kernel != KW) return EM_ERR_UNSUPPORTED;
+    if (a->kernel != (relu ? 15 : 31)) return EM_ERR_UNSUPPORTED;
   }
   if (mode == EM_BLOCK_C && (!a->ctx || !a->glu || !a->wout || !a->pw1f)) return EM_ERR_BAD_ARG;
   if ((mode & EM_BLOCK_C) && need_d) {  // the C part folded into the launch (round 4)
@@ -1184,6 +1224,12 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   if (mode & EM_BLOCK_CTC) flops += 2.0 * M * D * 64.0 * a->ctc_units;
   const bool rec = em_prof_begin(stream);
   int rc = EM_ERR_BAD_ARG;
+  if (relu) {
+    if (mode == EM_BLOCK_A) rc = launch_block<EM_BLOCK_A, 31, true>(a, s);
+    else rc = launch_block<EM_BLOCK_D, 15, true>(a, s);
+    if (rec) em_prof_end(stream, flops, EM_PROF_BLOCK);
+    return rc;
+  }
   switch (mode) {
     case EM_BLOCK_C: rc = launch_block<EM_BLOCK_C>(a, s); break;
     case EM_BLOCK_A: rc = launch_block<EM_BLOCK_A>(a, s); break;

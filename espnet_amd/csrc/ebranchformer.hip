@@ -15,6 +15,7 @@
 // the 2d channels with the self residual fused -> merge_proj GEMM into the f32 residual stream ->
 // FFN -> norm_final (fused with the next layer's first LayerNorm).
 #include <math.h>
+#include <stdlib.h>
 
 #include "em_common.h"
 #include "subsample.h"
@@ -26,7 +27,8 @@ constexpr float LN_EPS = 1e-12f;
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws {
-  size_t c1, c2, c3, x, xn, xn2, big, gn, gated, cat, tmp, ctx, pall, mw, total;
+  size_t c1, c2, c3, x, xn, xn2, big, gn, gated, cat, tmp, ctx, pall, mw, qh, kh, vt, total;
+  int Tpad;
 };
 inline Ws layout(int dtype, const EmEBranchformerWeights* w, int B, int T_f) {
   const size_t es = dtype == EM_BF16 ? 2 : 4;
@@ -53,6 +55,12 @@ inline Ws layout(int dtype, const EmEBranchformerWeights* w, int B, int T_f) {
   s.ctx = o; o += align_up(M * d * es);
   s.pall = o; o += align_up((size_t)(2 * g.T_out - 1) * w->num_blocks * d * es);
   s.mw = o; o += align_up((size_t)B * 2 * sizeof(float));
+  // per-head operands of the LDS-resident attention (csrc/attention2.hip; bf16, d_k = 64): as in encoder.hip
+  s.Tpad = (g.T_out + 255) / 256 * 256;
+  const size_t per_head = (size_t)B * d * s.Tpad * es;
+  s.qh = o; o += align_up(per_head);
+  s.kh = o; o += align_up(per_head);
+  s.vt = o; o += align_up(per_head);
   s.total = o;
   return s;
 }
@@ -208,11 +216,20 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   const size_t es = dtype == EM_BF16 ? 2 : 4;
 
   // ---- Conv2dSubsampling{,6,8} (+MVN) -> Linear, * sqrt(d) (subsample.h); linear_pos of every block in one GEMM
-  EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream));
+  EM_TRY(em_sub::run(dtype, w, g, feats, mvn_partial, flens, B, c1, c2, c3, x, stream, w->conv1_wf, w->conv2_wf));
   EM_TRY(gemm(dtype, EM_EPI_STORE, pos_emb, w->wpos_all, pall, nullptr, w->legacy_relpos ? T : 2 * T - 1, L * d, d, d, L * d, 1.f,
               stream));
   const EmEBranchformerLayer* ly = w->layers;
   const bool ffn = w->use_ffn != 0;
+  // round 4: bf16 with d_k = 64 -> the LDS-resident attention, its operands written per head by the projection GEMMs
+  // (see encoder.hip; ESPNET_AMD_NO_ATTN2_LARGE=1: developer A/B switch)
+  static const bool no_attn2 = getenv("ESPNET_AMD_NO_ATTN2_LARGE") != nullptr;
+  const bool attn2 = dtype == EM_BF16 && !w->legacy_relpos && !no_attn2 && !(flags & EM_ENC_NO_FUSED) && d == 64 * h &&
+                     (size_t)B * d * s.Tpad * 4 < ((size_t)1 << 32) - 64;
+  void* qh = ws + s.qh;
+  void* vt = ws + s.vt;
+  if (attn2 && hipMemsetAsync(qh, 0, (s.vt - s.qh) + (size_t)B * d * s.Tpad * es, (hipStream_t)stream) != hipSuccess)
+    return EM_ERR_LAUNCH;
   if (ffn)
     EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr, stream));
   for (int l = 0; l < L; ++l) {
@@ -226,9 +243,22 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
     EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(em_layernorm(dtype, x, q.norm_mlp_g, q.norm_mlp_b, M, d, LN_EPS, xn2, nullptr, stream));
     // branch 1 (:141-152): rel-pos self-attention; linear_out lands in cat[:, :d]
-    EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
-    EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
-                               q.pos_v, olens, B, T, h, 64, ctx, stream));
+    if (attn2) {
+      EmGemmArgs a = {};
+      a.A = xn; a.W = q.wqkv; a.C = qh; a.bias = q.bqkv;
+      a.M = M; a.N = 2 * d; a.K = d; a.lda = d; a.ldc = 64; a.scale = 1.f;
+      a.T1 = T; a.T2 = s.Tpad; a.F1 = h; a.d = d;
+      EM_TRY(em_gemm(dtype, EM_EPI_QK_HEADS, EM_A_PLAIN, &a, stream));
+      a.A = (const unsigned char*)q.wqkv + (size_t)2 * d * d * es; a.W = xn; a.C = vt; a.bias = q.bqkv + 2 * d;
+      a.M = d; a.N = M; a.ldc = s.Tpad;
+      EM_TRY(em_gemm(dtype, EM_EPI_VT_HEADS, EM_A_PLAIN, &a, stream));
+      EM_TRY(em_relpos_attention2_bf16(qh, ws + s.kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
+                                       q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
+    } else {
+      EM_TRY(gemm(dtype, EM_EPI_STORE, xn, q.wqkv, big, q.bqkv, M, 3 * d, d, d, 3 * d, 1.f, stream));
+      EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
+                                 q.pos_v, olens, B, T, h, 64, ctx, stream));
+    }
     EM_TRY(gemm(dtype, EM_EPI_STORE, ctx, q.wout, cat, q.bout, M, d, d, d, 2 * d, 1.f, stream));
     // branch 2 (:154-163): cgMLP = Linear + GELU -> [r | g]; g <- LN(g); r * (dwconv(g) + b) -> Linear,
     // which lands in cat[:, d:]

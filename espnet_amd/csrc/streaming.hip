@@ -134,6 +134,67 @@ __global__ __launch_bounds__(256) void block_mha_kernel(const T* __restrict__ qk
   for (int c = 0; c < DKP; ++c) out[c] = from_f32<T>(acc[c] * inv);
 }
 
+// The same attention over the PER-HEAD operands the fused block kernels write (csrc/block.hip, EM_BLOCK_A): q / k
+// [n_blk][H][Tpad][64], V transposed [n_blk][H][64][Tpad], bf16; ctx [n_blk*L][H*64] bf16.  (round 4: the fused streaming layer)
+__global__ __launch_bounds__(256) void cb_mha_heads_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
+                                                          const bf16* __restrict__ vt, int L, int Tpad, int H,
+                                                          int mask_mode, bf16* __restrict__ ctx) {
+  constexpr int DK = 64, DKP = DK / 4;
+  extern __shared__ float sm[];
+  float* Ks = sm;                 // [L][DK]
+  float* Vs = Ks + L * DK;        // [L][DK]
+  float* S = Vs + L * DK;         // [64][L + 1] scaled scores
+  const int h = blockIdx.x, blk = blockIdx.y, tid = threadIdx.x;
+  const int r = tid >> 2, part = tid & 3;
+  const size_t bh = (size_t)blk * H + h;
+  const bf16* qb = qh + bh * Tpad * DK;
+  const bf16* kb = kh + bh * Tpad * DK;
+  const bf16* vb = vt + bh * DK * Tpad;
+  for (int e = tid; e < L * DK; e += 256) {
+    const int j = e / DK, c = e - j * DK;
+    Ks[e] = (float)kb[(size_t)j * DK + c];
+  }
+  for (int e = tid; e < L * DK; e += 256) {  // (V^T rows are contiguous in j: read along j, store transposed)
+    const int c = e / L, j = e - c * L;
+    Vs[j * DK + c] = (float)vb[(size_t)c * Tpad + j];
+  }
+  __syncthreads();
+  const int nkeys = mask_mode ? L - 1 : L;
+  const bool active = r < L;
+  const int rq = active ? r : L - 1;
+  float q[DKP];
+#pragma unroll
+  for (int c = 0; c < DKP; ++c) q[c] = (float)qb[(size_t)rq * DK + part * DKP + c];
+  const float scale = rsqrtf((float)DK);
+  float mx = -INFINITY;
+  for (int j = 0; j < nkeys; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DKP; ++c) s = fmaf(q[c], Ks[j * DK + part * DKP + c], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s *= scale;
+    mx = fmaxf(mx, s);
+    if (part == 0) S[r * (L + 1) + j] = s;
+  }
+  __syncthreads();
+  float acc[DKP];
+#pragma unroll
+  for (int c = 0; c < DKP; ++c) acc[c] = 0.f;
+  float sum = 0.f;
+  for (int j = 0; j < nkeys; ++j) {
+    const float p = expf(S[r * (L + 1) + j] - mx);
+    sum += p;
+#pragma unroll
+    for (int c = 0; c < DKP; ++c) acc[c] = fmaf(p, Vs[j * DK + part * DKP + c], acc[c]);
+  }
+  if (!active) return;
+  bf16* out = ctx + ((size_t)blk * L + r) * (H * DK) + h * DK + part * DKP;
+  const float inv = (mask_mode && r == 0) ? 0.f : 1.0f / sum;
+#pragma unroll
+  for (int c = 0; c < DKP; ++c) out[c] = (bf16)(acc[c] * inv);
+}
+
 // Context hand-over after a layer (layer :292-304), in place on x [n_blk][L][d] f32:
 //   x[0][0] = past_ctx (or x[0][L-1] for the first block of an utterance); x[b][0] = x[b-1][L-1];
 //   next_ctx = x[n_blk-1][L-1].
@@ -169,7 +230,8 @@ __global__ __launch_bounds__(256) void stream_pos_enc_kernel(const float* __rest
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct CbWs {
-  size_t xn, big, g, g2, ctx, total;
+  size_t xn, big, g, g2, ctx, qh, kh, vt, total;
+  int Tpad;
 };
 inline CbWs cb_layout(int dtype, const EmConformerWeights* w, int M) {
   const size_t es = dtype == EM_BF16 ? 2 : 4;
@@ -184,6 +246,34 @@ inline CbWs cb_layout(int dtype, const EmConformerWeights* w, int M) {
   s.ctx = o; o += align_up((size_t)M * d * es);
   s.total = o;
   return s;
+}
+// ... plus the per-head operands of the fused layer (bf16, d = 256: csrc/block.hip): q / k [n_blk][4][Tpad][64],
+// V^T [n_blk][4][64][Tpad] with Tpad = the 32-row workgroups' reach
+inline CbWs cb_layout_fused(int dtype, const EmConformerWeights* w, int n_blk, int L) {
+  CbWs s = cb_layout(dtype, w, n_blk * L);
+  s.Tpad = (L + 63) / 64 * 64;
+  const size_t per_head = (size_t)n_blk * w->d * s.Tpad * 2;
+  size_t o = s.total;
+  s.qh = o; o += align_up(per_head);
+  s.kh = o; o += align_up(per_head);
+  s.vt = o; o += align_up(per_head);
+  s.total = o;
+  return s;
+}
+// Which streaming layers take the fused launch sequence: bf16, 256 wide, 4 heads, conv width 15, ff <= 4096 in whole
+// chunk pairs, blocks of at most 64 slots, every layer packed for it by the host.
+inline bool cb_fusable(int dtype, const EmConformerWeights* w, int L) {
+  static const bool off = getenv("ESPNET_AMD_STREAM_NO_FUSED") != nullptr;  // developer A/B switch
+  if (off || dtype != EM_BF16 || w->d != 256 || w->heads != 4 || w->kernel != 15 || w->ff > 4096 || w->ff % 128 != 0 ||
+      L > 64 || !w->layers)
+    return false;
+  for (int l = 0; l < w->num_blocks; ++l) {
+    const EmConformerLayer& q = w->layers[l];
+    if (!q.fp_a || !q.fp_c || !q.fp_da || !q.ffm_w1p || !q.ffm_w2p || !q.wqkvp || !q.woutp || !q.pw1f || !q.pw2p ||
+        !q.ff_w1p || !q.ff_w2p || !q.ffm_b1 || !q.ff_b1)
+      return false;
+  }
+  return true;
 }
 
 inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const float* bias, int M,
@@ -284,7 +374,7 @@ extern "C" int em_cb_propagate_ctx_f32(float* x, const float* past_ctx, float* n
 extern "C" size_t em_cb_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t n_blk,
                                         int32_t L) {
   if (!w || n_blk <= 0 || L <= 0) return 0;
-  return cb_layout(dtype, w, n_blk * L).total;
+  return cb_fusable(dtype, w, L) ? cb_layout_fused(dtype, w, n_blk, L).total : cb_layout(dtype, w, n_blk * L).total;
 }
 
 // All layers of the block encoder on x [n_blk][L][d] f32 (in place).  past_ctx / next_ctx:
@@ -302,10 +392,45 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
   const int n_blk = n_streams * n_blk_s;
   const int d = w->d, h = w->heads, ff = w->ff, NL = w->num_blocks, M = n_blk * L;
   if (d % 64 != 0 || ff % 64 != 0 || (d / h != 64 && d / h != 32)) return EM_ERR_UNSUPPORTED;
-  const CbWs s = cb_layout(dtype, w, M);
+  const bool fused = cb_fusable(dtype, w, L);
+  const CbWs s = fused ? cb_layout_fused(dtype, w, n_blk, L) : cb_layout(dtype, w, M);
   if (workspace_bytes < s.total) return EM_ERR_WORKSPACE;
   unsigned char* ws = (unsigned char*)workspace;
   void *xn = ws + s.xn, *big = ws + s.big, *gl = ws + s.g, *g2 = ws + s.g2, *ctx = ws + s.ctx;
+  if (fused) {
+    // ---- round 4: the layer as FIVE launches instead of thirteen, on the row-block kernels of the Conformer path
+    // (csrc/block.hip; a block of L <= 64 slots = an "utterance" of two 32-row workgroups):
+    //   block<A | RELU>   norm_ff_macaron + macaron FFN (ReLU, ff up to 4096) + norm_mha + q / k / v per head
+    //   cb_mha_heads      plain multi-head attention over the block's slots (contextual mask)
+    //   block<C>          linear_out + residual, norm_conv, pointwise_conv1 + GLU
+    //   block<D | RELU>   depthwise conv (k = 15) + BN + Swish, pointwise_conv2 + residual, norm_ff, FFN, norm_final
+    //   propagate_ctx     the context hand-over between blocks (why D and the next layer's A stay separate launches)
+    // contextual_block_encoder_layer.py:197-310.  One stream, one block: 1.18 ms -> see profiles/r04*_stream*.
+    EmBlockArgs ba = {};
+    ba.B = n_blk; ba.T = L; ba.Tpad = s.Tpad; ba.d = d; ba.ff = ff; ba.kernel = w->kernel; ba.eps = LN_EPS;
+    ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = ws + s.qh; ba.kh = ws + s.kh; ba.vt = ws + s.vt;
+    const size_t mha_lds = ((size_t)2 * L * 64 + (size_t)64 * (L + 1)) * sizeof(float);
+    for (int l = 0; l < NL; ++l) {
+      const EmConformerLayer& q = w->layers[l];
+      ba.ffm_w1 = q.ffm_w1p; ba.ffm_w2 = q.ffm_w2p; ba.wqkv = q.wqkvp; ba.ffm_b1g = q.ffm_b1; ba.params = q.fp_a;
+      EM_TRY(em_conformer_block_fused(EM_BLOCK_A | EM_BLOCK_RELU, &ba, stream));
+      hipLaunchKernelGGL(cb_mha_heads_kernel, dim3(h, n_blk), dim3(256), mha_lds, (hipStream_t)stream,
+                         (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
+      EM_CHECK_LAUNCH();
+      ba.wout = q.woutp; ba.pw1f = q.pw1f; ba.params = q.fp_c;
+      EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
+      ba.pw2 = q.pw2p; ba.ff_w1 = q.ff_w1p; ba.ff_w2 = q.ff_w2p; ba.dw_w = q.dw_w; ba.dw_b = q.dw_b; ba.ff_b1g = q.ff_b1;
+      ba.params = q.fp_da;
+      EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_RELU, &ba, stream));
+      if (mask_mode) {
+        hipLaunchKernelGGL(cb_propagate_ctx_kernel, dim3(n_blk_s, n_streams), dim3(256), 0, (hipStream_t)stream, x,
+                           past_ctx ? past_ctx + (size_t)l * d : nullptr, next_ctx ? next_ctx + (size_t)l * d : nullptr,
+                           n_blk_s, L, d, NL * d);
+        EM_CHECK_LAUNCH();
+      }
+    }
+    return EM_OK;
+  }
   // A pre-norm LayerNorm rides in the prologue of the projection that consumes it (csrc/ln_gemm.hip) where that kernel
   // has the epilogue (plain / ReLU): three launches less per layer.  A step is ~200 dependent launches of ~5.6 us for
   // 42 rows - launch latency, nothing else - so the count is what matters (round 3: 1.30 -> see profiles/r03p).

@@ -25,7 +25,7 @@ EM_ENC_NO_FUSED = 2
 EM_ENC_POS_PROJECTED = 4
 EM_ENC_FOLD_C = 8
 EM_ENC_PLAN_FUSED, EM_ENC_PLAN_CTC_IDS = 1, 2
-EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC = 1, 2, 4, 8, 16
+EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC, EM_BLOCK_RELU = 1, 2, 4, 8, 16, 32
 EM_BLOCK_PARAM_GROUP = 1792
 EM_BLOCK_CTC_MAX_UNITS = 88  # vocabularies up to 5 632 labels take the fused CTC stage (the sizes the GPU tests cover); larger ones keep the arg-max GEMM
 EM_PROF_GEMM, EM_PROF_BLOCK, EM_PROF_ATTN = 0, 1, 2
@@ -70,7 +70,7 @@ class EmBlockArgs(C.Structure):
                [(n, C.c_void_p) for n in ("x", "ctx", "glu", "qh", "kh", "vt", "enc_out", "enc_act", "tlens", "wout",
                                           "pw1f", "pw2", "ff_w1", "ff_w2", "dw_w", "dw_b", "ffm_w1", "ffm_w2", "wqkv",
                                           "params", "ctc_w", "ctc_b", "ctc_ids")] + [("ctc_units", C.c_int32)] + \
-               [("x_out", C.c_void_p), ("params_c", C.c_void_p)]
+               [("x_out", C.c_void_p), ("params_c", C.c_void_p), ("ffm_b1g", C.c_void_p), ("ff_b1g", C.c_void_p)]
 
 
 class EmConformerWeights(C.Structure):
@@ -106,7 +106,8 @@ class EmEBranchformerWeights(C.Structure):
                                           "wpos_all", "after_norm_g", "after_norm_b")] + \
                [("layers", C.POINTER(EmEBranchformerLayer)), ("use_ffn", C.c_int32), ("merge_conv", C.c_int32),
                 ("subsample", C.c_int32), ("conv3_w", C.c_void_p), ("conv3_b", C.c_void_p),
-                ("legacy_relpos", C.c_int32), ("merge_method", C.c_int32)]
+                ("legacy_relpos", C.c_int32), ("merge_method", C.c_int32), ("conv1_wf", C.c_void_p),
+                ("conv2_wf", C.c_void_p)]
 
 
 class EmWavInfo(C.Structure):

@@ -352,6 +352,10 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
 #define EM_BLOCK_A 4
 #define EM_BLOCK_FINAL 8
 #define EM_BLOCK_CTC 16 /* with D | FINAL: + the CTC head's per-frame arg-max */
+#define EM_BLOCK_RELU 32 /* the contextual-block STREAMING layer (contextual_block_encoder_layer.py:197-310): ReLU feed-forward,
+                          * depthwise conv width 15, ff up to 4096 (ffm_b1g / ff_b1g).  With EM_BLOCK_A (macaron FFN, norm_mha,
+                          * q / k / v per head) or EM_BLOCK_D alone (conv module back, FFN, norm_final -> x: the context
+                          * hand-over between layers sits behind it); EM_BLOCK_C is the same kernel as without. */
 #define EM_BLOCK_PARAM_GROUP 1792
 typedef struct EmBlockArgs {
   int32_t B, T, Tpad, d, ff, kernel;
@@ -394,6 +398,10 @@ typedef struct EmBlockArgs {
    * same launch reads this one's rows of `x` as its halo).  With EM_BLOCK_FINAL nothing is written to x_out.        */
   float* x_out;
   const float* params_c;
+  /* ff > 1024: the first bias of the FFNs in global memory, [ff rounded up to 128] f32 (the 7 KiB parameter groups hold
+   * 1024 of it; their b1 slot is then unused).  NULL otherwise. */
+  const float* ffm_b1g;
+  const float* ff_b1g;
 } EmBlockArgs;
 int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
 
@@ -457,6 +465,8 @@ typedef struct EmEBranchformerWeights {
   const float* conv3_b;
   int32_t legacy_relpos; /* as EmConformerWeights.legacy_relpos */
   int32_t merge_method;  /* EM_MERGE_* (Branchformer; requires merge_conv = 0 unless EM_MERGE_CONCAT) */
+  const void* conv1_wf;  /* as EmConformerWeights: operands of the fused conv1 + conv2 kernel (bf16, d = 256 / 512), or NULL */
+  const void* conv2_wf;
 } EmEBranchformerWeights;
 
 /* ---- Branchformer learned_ave merge input (BranchformerEncoderLayer.forward, branchformer_encoder.py:212-270).

@@ -54,6 +54,32 @@ def test_streaming_encoder_bf16_within_tolerance():
     assert err.max() < 0.2 and err.mean() < 0.02, (err.max(), err.mean())
 
 
+def test_streaming_fused_layers_match_per_operator_sequence():
+    """Round 4: the contextual-block layer as five launches on the row-block kernels (csrc/block.hip with EM_BLOCK_RELU,
+    conv width 15, ff 2048; csrc/streaming.hip `cb_fusable`) against the thirteen-launch sequence of the same bf16
+    weights: same frames per call, outputs equal to bf16 round-off of differently ordered sums; both within the bf16
+    tolerance of the reference fixture; also the one-shot (many blocks at once) and short-utterance paths."""
+    g = load_stream_golden("stream_small_6s")
+    feats = stream_feats(int(g["utt_id"]), int(g["n_samples"]))
+    enc = build(g, "bfloat16")
+    assert enc._fusable()
+    ys_f, lens_f = run_chunks(enc, feats, int(g["chunk_frames"]))
+    one_f, _, _ = enc(feats[None].cuda(), torch.tensor([feats.size(0)]), None, is_final=True, infer_mode=True)
+    short_f, _, _ = enc(feats[None, :100].cuda(), torch.tensor([100]), None, is_final=True, infer_mode=True)
+    enc.fused = False
+    enc.invalidate()
+    ys_u, lens_u = run_chunks(enc, feats, int(g["chunk_frames"]))
+    one_u, _, _ = enc(feats[None].cuda(), torch.tensor([feats.size(0)]), None, is_final=True, infer_mode=True)
+    short_u, _, _ = enc(feats[None, :100].cuda(), torch.tensor([100]), None, is_final=True, infer_mode=True)
+    assert lens_f == lens_u == g["out_lens"].tolist()
+    for name, a, b in (("chunked", ys_f, ys_u), ("one-shot", one_f, one_u), ("short", short_f, short_u)):
+        d = (a.float() - b.float()).abs()
+        print(f"[stream fused vs per-operator, {name}] max {d.max().item():.3e} mean {d.mean().item():.3e}")
+        assert d.max().item() < 8e-2 and d.mean().item() < 8e-3, name
+    err = np.abs(ys_f.cpu()[:: int(g["keep_every"])].numpy() - g["ys"])
+    assert err.max() < 0.2 and err.mean() < 0.02, (err.max(), err.mean())
+
+
 def test_streaming_chunking_invariance():
     """Size-independent property: the frames a streaming run emits do not depend on how the audio
     is cut into calls once a block is complete -- chunked == one-shot (f32, same kernels)."""

@@ -74,6 +74,29 @@ case "$what" in
     done
     unset ESPNET_AMD_NO_SUB12
     echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
+  stream-fused)  # round 4: contextual-block layer on the row-block kernels (5 launches instead of 13) + E-Branchformer on sub2 / attention2
+    echo "== tests"; timeout 900 python -m pytest tests/test_gpu_streaming.py tests/test_gpu_online_search.py tests/test_gpu_ebranchformer.py tests/test_gpu_block.py -q -x -s 2>&1 | grep -E "^\[stream|passed|failed|Error|assert" | tail -12 | tee "$out/pytest.txt"
+    for v in 1 0; do
+      if [ $v = 1 ]; then export ESPNET_AMD_STREAM_NO_FUSED=1; else unset ESPNET_AMD_STREAM_NO_FUSED; fi
+      echo "stream_no_fused=$v: "; timeout 300 python bench.py --workload stream --no-cpu-baseline 2>/dev/null < /dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); c=d['config']
+print('  one stream:', d['value'], 'audio-s/s, call latency median', c.get('call_latency_ms_median'), 'p95', c.get('call_latency_ms_p95'))"
+    done
+    unset ESPNET_AMD_STREAM_NO_FUSED
+    echo "== stream leg of the default line (batch32)"; timeout 300 python - <<'PY' 2>/dev/null | tee "$out/stream_batch32.txt"
+import json, bench
+for v in (True, False):
+    import os
+    r = bench.run_stream_batch("bfloat16", 32, 3, 1)
+    print("batch32:", json.dumps({k: r[k] for k in r if k != "config"})[:300])
+    break
+PY
+    echo "== E-Branchformer"; for v in 1 0; do
+      if [ $v = 1 ]; then export ESPNET_AMD_NO_ATTN2_LARGE=1 ESPNET_AMD_NO_SUB12=1; else unset ESPNET_AMD_NO_ATTN2_LARGE ESPNET_AMD_NO_SUB12; fi
+      echo -n "old_path=$v: "; timeout 300 python bench.py --model ebf --quick --no-traffic --no-roofline --no-cpu-baseline --steps 50 --warmup 5 2>/dev/null < /dev/null | cut -c100-180
+    done
+    unset ESPNET_AMD_NO_ATTN2_LARGE ESPNET_AMD_NO_SUB12 ;;
   full|bench)
     if [ "$what" = full ]; then
       echo "== pytest -m gpu"; (time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) 2>&1 | tee "$out/pytest_gpu.txt"
