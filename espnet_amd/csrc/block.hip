@@ -1193,7 +1193,7 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   hipStream_t s = (hipStream_t)stream;
   const bool need_a = (mode & EM_BLOCK_A) != 0, need_d = (mode & EM_BLOCK_D) != 0;
   // the first FFN bias lives in the 7 KiB parameter group up to ff = 1024; wider FFNs hand it over in global memory
-  if (!relu && a->ff > 1024) return EM_ERR_UNSUPPORTED;
+  if (!relu && a->ff > 1024 && (need_a || need_d)) return EM_ERR_UNSUPPORTED;  // (the C part has no FFN)
   if (relu && ((need_a && !a->ffm_b1g) || (need_d && !a->ff_b1g))) return EM_ERR_BAD_ARG;  // (these instantiations always read it there)
   if (relu && mode != EM_BLOCK_A && mode != EM_BLOCK_D) return EM_ERR_UNSUPPORTED;  // (the instantiations that exist)
   if (!relu && mode == EM_BLOCK_D) return EM_ERR_UNSUPPORTED;

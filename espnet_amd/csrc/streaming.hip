@@ -262,9 +262,15 @@ inline CbWs cb_layout_fused(int dtype, const EmConformerWeights* w, int n_blk, i
 }
 // Which streaming layers take the fused launch sequence: bf16, 256 wide, 4 heads, conv width 15, ff <= 4096 in whole
 // chunk pairs, blocks of at most 64 slots, every layer packed for it by the host.
-inline bool cb_fusable(int dtype, const EmConformerWeights* w, int L) {
+// ... and at least FUSED_MIN_BLOCKS blocks in the call (a batch of streams, or a long one-shot input).  A workgroup of
+// the fused kernels ingests ALL of a layer's 5 MB of weights through one CU: with one block (one stream, one call) that
+// is two workgroups on an otherwise empty chip - 1.47 ms per call against 1.15 for the per-operator sequence, whose GEMMs
+// spread every weight matrix over a hundred CUs - while 32 blocks fill 64 CUs and the tick drops from 1.83 to 1.44 ms
+// (profiles/r04i_stream_fused_ab.txt).  ESPNET_AMD_STREAM_FUSED_MIN=n: developer A/B switch.
+inline bool cb_fusable(int dtype, const EmConformerWeights* w, int L, int n_blk) {
   static const bool off = getenv("ESPNET_AMD_STREAM_NO_FUSED") != nullptr;  // developer A/B switch
-  if (off || dtype != EM_BF16 || w->d != 256 || w->heads != 4 || w->kernel != 15 || w->ff > 4096 || w->ff % 128 != 0 ||
+  static const int min_blk = getenv("ESPNET_AMD_STREAM_FUSED_MIN") ? atoi(getenv("ESPNET_AMD_STREAM_FUSED_MIN")) : 8;
+  if (off || n_blk < min_blk || dtype != EM_BF16 || w->d != 256 || w->heads != 4 || w->kernel != 15 || w->ff > 4096 || w->ff % 128 != 0 ||
       L > 64 || !w->layers)
     return false;
   for (int l = 0; l < w->num_blocks; ++l) {
@@ -374,7 +380,7 @@ extern "C" int em_cb_propagate_ctx_f32(float* x, const float* past_ctx, float* n
 extern "C" size_t em_cb_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t n_blk,
                                         int32_t L) {
   if (!w || n_blk <= 0 || L <= 0) return 0;
-  return cb_fusable(dtype, w, L) ? cb_layout_fused(dtype, w, n_blk, L).total : cb_layout(dtype, w, n_blk * L).total;
+  return cb_fusable(dtype, w, L, n_blk) ? cb_layout_fused(dtype, w, n_blk, L).total : cb_layout(dtype, w, n_blk * L).total;
 }
 
 // All layers of the block encoder on x [n_blk][L][d] f32 (in place).  past_ctx / next_ctx:
@@ -392,7 +398,7 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
   const int n_blk = n_streams * n_blk_s;
   const int d = w->d, h = w->heads, ff = w->ff, NL = w->num_blocks, M = n_blk * L;
   if (d % 64 != 0 || ff % 64 != 0 || (d / h != 64 && d / h != 32)) return EM_ERR_UNSUPPORTED;
-  const bool fused = cb_fusable(dtype, w, L);
+  const bool fused = cb_fusable(dtype, w, L, n_blk);
   const CbWs s = fused ? cb_layout_fused(dtype, w, n_blk, L) : cb_layout(dtype, w, M);
   if (workspace_bytes < s.total) return EM_ERR_WORKSPACE;
   unsigned char* ws = (unsigned char*)workspace;

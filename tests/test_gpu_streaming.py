@@ -59,6 +59,10 @@ def test_streaming_fused_layers_match_per_operator_sequence():
     conv width 15, ff 2048; csrc/streaming.hip `cb_fusable`) against the thirteen-launch sequence of the same bf16
     weights: same frames per call, outputs equal to bf16 round-off of differently ordered sums; both within the bf16
     tolerance of the reference fixture; also the one-shot (many blocks at once) and short-utterance paths."""
+    import os
+
+    os.environ["ESPNET_AMD_STREAM_FUSED_MIN"] = "1"  # (read once by the library: by default calls of fewer than 8 blocks
+    # keep the per-operator sequence - one stream's single block is faster there; this test wants the fused kernels)
     g = load_stream_golden("stream_small_6s")
     feats = stream_feats(int(g["utt_id"]), int(g["n_samples"]))
     enc = build(g, "bfloat16")
