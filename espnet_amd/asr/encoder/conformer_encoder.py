@@ -145,6 +145,26 @@ def pack_w2(w: torch.Tensor) -> torch.Tensor:
     return u.reshape(ffp // 128, 4 * 16 * 64 * 8)
 
 
+def pack_ffn_rows_w1(w: torch.Tensor) -> torch.Tensor:
+    """First matrix of an FFN of the 512-wide model, [ff][512] -> the operand stream of csrc/ffn_rows.hip
+    (include/espnet_amd.h, EmFfnRowsArgs): [c][ks][wv][lg][lr][e] = W1[128 c + 16 wv + lr][32 ks + 8 lg + e]."""
+    ff, k = w.shape
+    assert k == 512 and ff % 128 == 0, (ff, k)
+    # [row = 128 c + 16 wv + lr][col = 32 ks + 8 lg + e] -> [c][ks][wv][lg][lr][e]
+    u = w.detach().reshape(ff // 128, 8, 16, 16, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous()
+    return u.reshape(ff, k)
+
+
+def pack_ffn_rows_w2(w: torch.Tensor) -> torch.Tensor:
+    """Second matrix, [512][ff] -> [c][s][cf][wv][lg][lr][e] = W2[64 wv + 16 cf + lr][128 c + 32 s + 16 (e >> 2) + 4 lg + (e & 3)]:
+    the contraction index in the order the kernel's waves hold the hidden activation."""
+    d, ff = w.shape
+    assert d == 512 and ff % 128 == 0, (d, ff)
+    # [o = 64 wv + 16 cf + lr][hidden = 128 c + 32 s + 16 eh + 4 lg + el] -> [c][s][cf][wv][lg][lr][eh][el]
+    u = w.detach().reshape(8, 4, 16, ff // 128, 4, 2, 4, 4).permute(3, 4, 1, 0, 6, 2, 5, 7).contiguous()
+    return u.reshape(ff // 128, 4 * 4 * 8 * 64 * 8)
+
+
 def pack_conv1_frags(w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
     """conv.0 weight [256][9] + bias [256] (f32) -> the MFMA operand of the fused conv1 + conv2 kernel (include/espnet_amd.h,
     em_conv2d_sub12_bf16): per channel 32 bf16 k-slots  hi(w) | hi(w) | lo(w) | hi(b), lo(b), 0, 0, 0  with hi(x) = bf16(x),
@@ -372,6 +392,15 @@ class ConformerEncoder(torch.nn.Module):
         if self._fusable():
             self._pack_fused(layers, A, F)
             self._pack_fused_ctc(w, A, F)
+        elif self.em_dtype == L.EM_BF16 and d == 512 and ff % 128 == 0 and ff >= 256 and _fused_enabled(self):
+            # the 512-wide model: each feed-forward module as one row-block launch (csrc/ffn_rows.hip)
+            for i, l in enumerate(self.encoders):
+                lt = dict(ffm_w1p=A(pack_ffn_rows_w1(l.feed_forward_macaron.w_1.weight)),
+                          ffm_w2p=A(pack_ffn_rows_w2(l.feed_forward_macaron.w_2.weight)),
+                          ff_w1p=A(pack_ffn_rows_w1(l.feed_forward.w_1.weight)),
+                          ff_w2p=A(pack_ffn_rows_w2(l.feed_forward.w_2.weight)))
+                for k, v in lt.items():
+                    setattr(layers[i], k, v.data_ptr())
         w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))
         self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype)
         self._pos_cache = {}

@@ -220,15 +220,34 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     if (hipMemsetAsync(qh, 0, (s.vt - s.qh) + (size_t)B * d * s.Tpad * es, (hipStream_t)stream) != hipSuccess)
       return EM_ERR_LAUNCH;
   }
+  // Round 4: at d = 512 (bf16) each feed-forward module - w_1 + Swish, w_2 + residual and the LayerNorm(s) behind it - is
+  // ONE row-block launch (csrc/ffn_rows.hip) when the host packed its operands: 19 -> 15 launches per block, the [M][ff]
+  // hidden activation and one f32 round trip of the residual stream gone.  ESPNET_AMD_NO_FFN_ROWS=1: developer A/B switch.
+  static const bool no_ffn_rows = getenv("ESPNET_AMD_NO_FFN_ROWS") != nullptr;
+  bool ffn_rows = dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) && !no_ffn_rows;
+  for (int l = 0; ffn_rows && l < L; ++l) ffn_rows = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
+  auto ffn_fused = [&](const void* w1p, const void* w2p, const float* b1, const float* b2, int ln_mode, const float* g1,
+                       const float* be1, const float* g2, const float* be2, void* xn_out, float* out_f32) {
+    EmFfnRowsArgs fa = {};
+    fa.xn_in = xn; fa.x = x; fa.w1p = w1p; fa.w2p = w2p; fa.b1 = b1; fa.b2 = b2;
+    fa.g1 = g1; fa.be1 = be1; fa.g2 = g2; fa.be2 = be2; fa.xn_out = xn_out; fa.out_f32 = out_f32;
+    fa.M = M; fa.d = d; fa.ff = ff; fa.ln_mode = ln_mode; fa.scale = 0.5f; fa.eps = LN_EPS;
+    return em_ffn_rows_fused(&fa, stream);
+  };
   EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr,
                       stream));
   for (int l = 0; l < L; ++l) {
     const EmConformerLayer& q = ly[l];
-    // macaron FFN: x += 0.5 * w2(swish(w1 LN(x)))
-    EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
-    // self-attention
-    EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
+    if (ffn_rows) {
+      // macaron FFN + residual + norm_mha
+      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr));
+    } else {
+      // macaron FFN: x += 0.5 * w2(swish(w1 LN(x)))
+      EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
+      // self-attention
+      EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
+    }
     if (attn2) {
       EmGemmArgs a = {};
       a.A = xn; a.W = q.wqkv; a.C = qh; a.bias = q.bqkv;
@@ -253,6 +272,15 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
     // FFN
     EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
+    if (ffn_rows) {  // FFN + residual + norm_final + the next consumer's LayerNorm
+      if (l + 1 < L)
+        EM_TRY(ffn_fused(q.ff_w1p, q.ff_w2p, q.ff_b1, q.ff_b2, 2, q.norm_final_g, q.norm_final_b, ly[l + 1].norm_ff_mac_g,
+                         ly[l + 1].norm_ff_mac_b, xn, nullptr));
+      else
+        EM_TRY(ffn_fused(q.ff_w1p, q.ff_w2p, q.ff_b1, q.ff_b2, 2, q.norm_final_g, q.norm_final_b, w->after_norm_g,
+                         w->after_norm_b, enc_act, enc_out));
+      continue;
+    }
     EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ff_w1, big, q.ff_b1, M, ff, d, d, ff, 1.f, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ff_w2, x, q.ff_b2, M, d, ff, ff, d, 0.5f, stream));
     // norm_final, fused with the next consumer's LayerNorm

@@ -1,0 +1,446 @@
+// Row-block fused feed-forward module for the 512-wide Conformer (bf16 MFMA): one launch computes
+//     x += scale * (W2 . swish(W1 . xn + b1) + b2);   xn' = LayerNorm(x)          (ln_mode 1)
+//     x  = LayerNorm_1(x + scale * (...));            xn' = LayerNorm_2(x)        (ln_mode 2)
+// for 64 consecutive rows per workgroup, i.e. the three launches  GEMM(Swish) -> GEMM(+residual) -> LayerNorm  of the
+// per-operator sequence (csrc/encoder.hip) with the [M][ff] hidden activation never written to memory and the f32
+// residual stream read and written once.
+//
+// Reference: PositionwiseFeedForward.forward (transformer/positionwise_feed_forward.py:30-32: w_2(act(w_1 x))) inside
+// EncoderLayer.forward (conformer/encoder_layer.py:111-121 macaron, :160-168 feed_forward with ff_scale 0.5, :170-171
+// norm_final), followed by the LayerNorm of the NEXT consumer (norm_mha :124; norm_ff_macaron of the next block :112;
+// ConformerEncoder's after_norm, conformer_encoder.py:410).  LayerNorm eps 1e-12 (transformer/layer_norm.py:23).
+//
+// Why this shape.  At B = 64 the large model has M = 15 936 rows = 249 workgroups of 64 rows: one per
+// CU.  A workgroup that owns 64 rows ingests every weight byte once per 64 rows, so the L2 -> CU weight stream (64 B/clk
+// per CU) and the matrix cores take the same time (per 128 hidden units: 256 KiB of weights = 4 096 cycles; 1 024 MFMAs
+// over four SIMDs = 4 096 cycles): the balance the 256-wide block kernels (32 rows, csrc/block.hip) cannot reach.
+//   * EIGHT waves, two per SIMD.  The first version had four (one per SIMD, 512 registers each) and measured 7.1 K cycles
+//     per chunk against the 4.1 K of its MFMAs: total = MFMA time + 4 cycles x (every other instruction) to within 3 %
+//     (developer builds without weight requests / LDS reads / both, profiles/r04m) - a wave alone on its SIMD does not
+//     hide its own loads, LDS reads, waits and Swish arithmetic behind its own MFMAs.  With two waves per SIMD one
+//     wave's non-MFMA instructions issue under the other's MFMAs.
+//   * GEMM 1 is split over the HIDDEN dimension (wave w: hidden columns 16 w .. 16 w + 15 of every 128-wide chunk, all 64
+//     rows), GEMM 2 over the OUTPUT columns (wave w: columns 64 w .. 64 w + 63, all 64 rows: 16 accumulator fragments =
+//     64 registers that live for the whole kernel);
+//   * LN(x) of the 64 rows (bf16, 64 KiB) is LDS-resident: loaded once by LDS-DMA, 16-byte chunks XOR-swizzled by the
+//     row so that the MFMA B-operand reads (one row per lane) are bank-conflict free;
+//   * weights go global memory -> MFMA A-operand registers, fragment-major (a wave-wide load = 1 KiB contiguous, the
+//     eight waves' current fragments = 8 consecutive KiB, i.e. every L2 channel) through a ring of 16 fragments per
+//     wave: a slot is refilled the moment its 4 MFMAs are issued, with the fragment the wave needs 16 fragments (~2 000
+//     cycles of the SIMD's MFMA time) later.  Requests are buffer loads (scalar chunk base in the resource, the fragment
+//     offset a scalar constant, lane offset in one VGPR): no address arithmetic in the loop.  No LDS staging, no
+//     barrier for the stream;
+//   * the hidden activation of a chunk (bias + Swish + bf16 in registers, already in B-operand layout because the host
+//     orders W2's contraction index to match) is exchanged between the waves through a double-buffered 16 KiB LDS
+//     tile: ONE barrier per chunk, placed half a GEMM-1 chunk after the tile was written;
+//   * software pipeline: [GEMM 1 of chunk c, barrier in its middle] [GEMM 2 of chunk c - 1 with the Swish of chunk c
+//     between its MFMAs];
+//   * epilogue: residual add, LayerNorm statistics (Chan's pairwise update: lane groups through register swaps, the eight
+//     waves through one LDS exchange), normalised rows out as bf16 for the next GEMM.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "em_common.h"
+
+#ifndef EM_FFN_DBG
+#define EM_FFN_DBG 0  // developer builds (tools/build_block_variants.sh ffn<d>; timing only, results wrong by design unless 8):
+#endif                // 1 no MFMAs, 2 no weight requests in the loop, 4 no LDS operand reads in the loop, 8 cycle stamps (EM_FFN_STAMPS=1)
+
+namespace {
+
+constexpr int D = 512;    // model width
+constexpr int RB = 64;    // rows per workgroup
+constexpr int NW = 8;     // waves
+constexpr int NT = 64 * NW;
+constexpr int CH = 128;   // hidden units per chunk
+constexpr int CHUNK_BYTES = CH * D * 2;       // of W1 and of W2 each: 16 fragments x 8 waves x 1 KiB
+constexpr int ACT_OFF = 0;                    // 64 KiB: LN(x) [64 rows][1 KiB], chunk q of row r at (q & ~15) | ((q ^ r) & 15)
+constexpr int H_OFF = ACT_OFF + RB * D * 2;   // 2 x 16 KiB: hidden activation tiles [buf][k-step s][row fragment][lane][16 B]
+constexpr int RED_OFF = H_OFF + 2 * 16384;    // 2 x 4 KiB: LayerNorm partials [set][wave][64 rows] (sum, M2)
+constexpr int SMEM_BYTES = RED_OFF + 8192;
+static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
+
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// LDS-DMA from inline asm (as csrc/attention2.hip): 16 bytes per lane from sbase + voff to LDS lds_dst + 16 lane
+__device__ __forceinline__ void glds16(const unsigned char* sbase, int voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float rsqrt_nr(float var) {
+  // v_rsq_f32 (1 ulp) + one Newton step: f32-accurate without the IEEE sqrt + division sequences (as csrc/block.hip)
+  const float y0 = __builtin_amdgcn_rsqf(var);
+  return y0 * (1.5f - 0.5f * var * y0 * y0);
+}
+
+template <int LNMODE>
+__global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, long long* __restrict__ stamps) {
+  using MM = Mma<bf16>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * RB, M = a.M;
+  const int nch = a.ff / CH;
+  // developer timing (-DEM_FFN_DBG=8, EM_FFN_STAMPS=1): cycle stamps of wave 0 of workgroup 5
+  constexpr int dbg = EM_FFN_DBG;
+  int nts = 0;
+  auto stamp = [&]() {
+    if constexpr ((dbg & 8) != 0) {
+      if (stamps && blockIdx.x == 5 && tid == 0 && nts < 64) stamps[nts] = (long long)__builtin_amdgcn_s_memtime();
+      ++nts;
+    }
+  };
+  stamp();
+
+  // ---- LN(x) of the 64 rows -> LDS (LDS-DMA, 1 KiB = one row per wave-instruction; lane l fills LDS chunk l of the row
+  // with global chunk (l & ~15) | ((l ^ row) & 15)).  Requested FIRST: GEMM 1 needs all of it and only the head of the ring.
+  // (from inline asm: an LDS-DMA hipcc knows about makes its wait-count pass put s_waitcnt vmcnt(0) in front of the first LDS
+  // read - i.e. wait for the ring AND the residual rows requested behind it - instead of the counted wait below)
+  {
+    const unsigned char* src = (const unsigned char*)a.xn_in;
+#pragma unroll
+    for (int i = 0; i < RB / NW; ++i) {
+      const int row = wave * (RB / NW) + i;
+      int m = m0 + row;
+      m = m < M ? m : M - 1;
+      const int g = (lane & ~15) | ((lane ^ row) & 15);
+      glds16(uniform_ptr(src + (size_t)m * (D * 2)), g * 16, ACT_OFF + row * 1024);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- weight stream: per chunk 16 fragments x [8 waves] x 1 KiB of W1 and as many of W2 (include/espnet_amd.h,
+  // EmFfnRowsArgs): fragment i of this wave at chunk + i * 8 KiB + wave * 1 KiB + lane * 16
+  bf16x8 ring[16];
+  const unsigned voff = wave * 1024 + lane * 16;
+  auto rsrc = [&](const void* base, int c) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)base + (size_t)c * CHUNK_BYTES), 0, CHUNK_BYTES, 0x00020000);
+  };
+  auto ld = [&](__amdgpu_buffer_rsrc_t rs, int i) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, i * 8192, 0));
+  };
+  {
+    const __amdgpu_buffer_rsrc_t r0 = rsrc(a.w1p, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ring[i] = ld(r0, i);
+  }
+  // this lane's first-bias values: hidden 128 c + 16 wave + 4 lg + r
+  const float* b1p = a.b1 + 16 * wave + 4 * lg;
+  float4 bia = *(const float4*)(b1p);
+
+  // B-operand read offsets of GEMM 1: row 16 rf + lr, k-step ks = 4 kq + kj: chunk 16 kq + ((4 kj + lg) ^ lr)
+  int aoff[4];
+  {
+    const int x0 = lg ^ lr;
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) aoff[kj] = ACT_OFF + lr * 1024 + (((kj * 4) ^ x0) << 4);
+  }
+  const int hrd = H_OFF + lane * 16;                                        // + buf * 16384 + s * 4096 + rf * 1024
+  const int hwr = H_OFF + (wave >> 1) * 4096 + lane * 16 + (wave & 1) * 8;  // + buf * 16384 + rf * 1024
+
+  f32x4 acc1[4];
+  // The residual rides in GEMM 2's accumulators: acc2 starts as x / scale + b2 and the epilogue multiplies by scale (exact
+  // for the ff_scale of 0.5: a power of two).  The rows are requested right behind the prologue barrier and travel under
+  // the first GEMM 1 (older than every refill: the in-order return costs nothing).  Measured alternatives (gpurun calls
+  // r04m - r04q, developer stamps): all rows in front of the last GEMM 2 (the first version) - every workgroup asks at once
+  // and waits ~5 K cycles with idle matrix cores, 83.6 us; all rows in the prologue beside LN(x) - LN(x) lands at 16 K
+  // instead of 7 K cycles, 88 us; one 16-row piece per iteration of the first four chunks - every GEMM 2 phase 4.4 K
+  // instead of 3.1 K cycles (requests with 64-byte segments between the weight requests), 87 us; this one 82.9 us.
+  // Lane (lr, lg) holds columns 64 wave + 16 cf + 4 lg + r of rows 16 rf + lr.
+  const int col0 = 64 * wave + 4 * lg;
+  const float scale = a.scale, inv_scale = 1.0f / a.scale;
+  f32x4 acc2[4][4];
+
+  // The instruction order below is pinned with sched_barrier(0) after every group of [4 MFMAs + 1 weight request]: left
+  // alone hipcc gathers the requests of a phase into one cluster at the phase's end, i.e. directly in front of
+  // their first use, and the ring's lookahead is gone.  The LDS operand reads are therefore pipelined by hand: a
+  // k-step's fragments are requested one k-step ahead, across the phase boundaries too (af0 / h0).
+  bf16x8 af0[4], h0[4];
+  auto read_act = [&](int ks, bf16x8 (&af)[4]) {
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) af[rf] = *(const bf16x8*)(smem + aoff[ks & 3] + rf * 16384 + (ks >> 2) * 256);
+  };
+  auto read_h = [&](int buf, int s, bf16x8 (&hf_)[4]) {
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) hf_[rf] = *(const bf16x8*)(smem + hrd + buf * 16384 + s * 4096 + rf * 1024);
+  };
+  auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // GEMM 1 of a chunk: H^T[hidden 16 wave + ..][row] over K = 512; every slot refilled from chunk `refill`.
+  // SYNC: the chunk barrier sits in the middle (k-step 8) and the first hidden fragments of tile `hbuf` are requested at the end.
+  auto gemm1 = [&](__amdgpu_buffer_rsrc_t refill, auto sync, int hbuf) {
+    constexpr bool SYNC = decltype(sync)::value;
+    bf16x8 cur[4], nxt[4];
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) cur[rf] = af0[rf];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 1 < 16 && !(dbg & 4)) read_act(ks + 1, nxt);
+      if (SYNC && ks == 8) barrier();
+      if (SYNC && ks == 15) read_h(hbuf, 0, h0);
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf) {
+        if constexpr ((dbg & 1) == 0)
+          acc1[rf] = MM::mma(ring[ks], cur[rf], ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc1[rf]);
+        else
+          acc1[rf][rf] = (float)ring[ks][rf] + (float)cur[rf][1];
+      }
+      if constexpr ((dbg & 2) == 0) ring[ks] = ld(refill, ks);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf)
+        if (!(dbg & 4)) cur[rf] = nxt[rf];
+    }
+  };
+  // bias + Swish of ONE hidden value (row fragment rf, hidden 16 wave + 4 lg + r); after the fourth: bf16 -> the wave's
+  // half of the B fragments of k-step (wave >> 1) in hidden tile `buf`
+  float hv[4];
+  auto swish_piece = [&](int rf, int r, int buf) {
+    const float bias = r == 0 ? bia.x : r == 1 ? bia.y : r == 2 ? bia.z : bia.w;
+    hv[r] = swishf_(acc1[rf][r] + bias);
+    if (r == 3) {
+      const bf16x4 hb = {(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]};
+      *(bf16x4*)(smem + hwr + buf * 16384 + rf * 1024) = hb;
+    }
+  };
+  // GEMM 2 of a chunk from hidden tile `buf` (its first fragments already in h0): out^T[col 64 wave + 16 cf + ..][row] +=
+  // W2 . H^T; `piece(s, cf)` runs beside every group of 4 MFMAs (the Swish of the NEXT chunk); ends by requesting the first
+  // activation fragments of the next GEMM 1
+  auto gemm2 = [&](int buf, __amdgpu_buffer_rsrc_t refill, auto do_refill, auto&& piece) {
+    bf16x8 cur[4], nxt[4];
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) cur[rf] = h0[rf];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if constexpr ((dbg & 4) == 0) {
+        if (s + 1 < 4) read_h(buf, s + 1, nxt);
+        else read_act(0, af0);
+      }
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) {
+        piece(s, cf);
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf) {
+          if constexpr ((dbg & 1) == 0) acc2[cf][rf] = MM::mma(ring[s * 4 + cf], cur[rf], acc2[cf][rf]);
+          else acc2[cf][rf][rf] += (float)ring[s * 4 + cf][rf] + (float)cur[rf][cf];
+        }
+        if constexpr (decltype(do_refill)::value && (dbg & 2) == 0) ring[s * 4 + cf] = ld(refill, s * 4 + cf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf)
+        if (!(dbg & 4)) cur[rf] = nxt[rf];
+    }
+  };
+
+  // LN(x) has landed (requested before the 16 ring fragments and the bias: loads return in order; the memory clobbers keep
+  // hipcc from moving any other request across either asm statement, so the count is exact)
+  asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  stamp();
+#pragma unroll
+  for (int rf = 0; rf < 4; ++rf) {
+    int m = m0 + rf * 16 + lr;
+    m = m < M ? m : M - 1;
+    const float* xr = a.x + (size_t)m * D + col0;
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) acc2[cf][rf] = *(const f32x4*)(xr + 16 * cf);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  read_act(0, af0);
+
+  gemm1(nch > 1 ? rsrc(a.w1p, 1) : rsrc(a.w2p, 0), std::false_type{}, 0);
+#pragma unroll
+  for (int rf = 0; rf < 4; ++rf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) swish_piece(rf, r, 0);
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf) {
+    const float4 b2 = *(const float4*)(a.b2 + col0 + 16 * cf);
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      acc2[cf][rf][0] = acc2[cf][rf][0] * inv_scale + b2.x;
+      acc2[cf][rf][1] = acc2[cf][rf][1] * inv_scale + b2.y;
+      acc2[cf][rf][2] = acc2[cf][rf][2] * inv_scale + b2.z;
+      acc2[cf][rf][3] = acc2[cf][rf][3] * inv_scale + b2.w;
+    }
+  }
+#pragma unroll 1
+  for (int c = 1; c < nch; ++c) {
+    // (requests are unconditional and their addresses always valid: hipcc counts its waits only over straight-line loads)
+    bia = *(const float4*)(b1p + c * CH);
+    // barrier inside: tile (c - 1) & 1 is complete; everybody is done reading tile c & 1 (chunk c - 2)
+    gemm1(rsrc(a.w2p, c - 1), std::true_type{}, (c - 1) & 1);
+    if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc1[3]));
+    stamp();
+    gemm2((c - 1) & 1, c + 1 < nch ? rsrc(a.w1p, c + 1) : rsrc(a.w2p, nch - 1), std::true_type{},
+          [&](int s, int cf) { swish_piece(s, cf, c & 1); });
+    stamp();
+  }
+  barrier();
+  read_h((nch - 1) & 1, 0, h0);
+  gemm2((nch - 1) & 1, rsrc(a.w2p, 0), std::false_type{}, [&](int, int) {});
+  if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc2[3][3]));
+  stamp();
+
+  // ---- epilogue: x' = scale * acc2
+  float4 xin[4][4];
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf)
+      xin[rf][cf] = make_float4(scale * acc2[cf][rf][0], scale * acc2[cf][rf][1], scale * acc2[cf][rf][2], scale * acc2[cf][rf][3]);
+  // LayerNorm over the 512 columns of every row, v -> v normalised (in place); `set` alternates the exchange buffer
+  auto layer_norm = [&](const float* __restrict__ g, const float* __restrict__ be, int set) {
+    float2* const red = (float2*)(smem + RED_OFF + set * 4096);
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      float s = 0.f;
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) s += (xin[rf][cf].x + xin[rf][cf].y) + (xin[rf][cf].z + xin[rf][cf].w);
+      const float mu = s * (1.0f / 16.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) {
+        const float dx = xin[rf][cf].x - mu, dy = xin[rf][cf].y - mu, dz = xin[rf][cf].z - mu, dw = xin[rf][cf].w - mu;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      // Chan's update for equal-sized groups: M2 = M2a + M2b + (sa - sb)^2 / (2 n)
+      {
+        const Pair2 ps = wave_xor16_pair(s), pq = wave_xor16_pair(q);
+        q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 32.0f);
+        s = ps.a + ps.b;
+      }
+      {
+        const Pair2 ps = wave_xor32_pair(s), pq = wave_xor32_pair(q);
+        q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 64.0f);
+        s = ps.a + ps.b;
+      }
+      if (lg == 0) red[wave * 64 + rf * 16 + lr] = make_float2(s, q);
+    }
+    barrier();
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      const int r = rf * 16 + lr;
+      float2 p[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) p[w] = red[w * 64 + r];
+      // pairwise over the waves (64 columns each), summed in wave order whatever the arrival order: deterministic
+#pragma unroll
+      for (int w = 0; w < 8; w += 2) {
+        p[w].y = p[w].y + p[w + 1].y + (p[w].x - p[w + 1].x) * (p[w].x - p[w + 1].x) * (1.0f / 128.0f);
+        p[w].x += p[w + 1].x;
+      }
+#pragma unroll
+      for (int w = 0; w < 8; w += 4) {
+        p[w].y = p[w].y + p[w + 2].y + (p[w].x - p[w + 2].x) * (p[w].x - p[w + 2].x) * (1.0f / 256.0f);
+        p[w].x += p[w + 2].x;
+      }
+      const float qq = p[0].y + p[4].y + (p[0].x - p[4].x) * (p[0].x - p[4].x) * (1.0f / 512.0f);
+      const float mean = (p[0].x + p[4].x) * (1.0f / D);
+      const float rstd = rsqrt_nr(qq * (1.0f / D) + a.eps);
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) {
+        const float4 g4 = *(const float4*)(g + col0 + 16 * cf);
+        const float4 b4 = *(const float4*)(be + col0 + 16 * cf);
+        xin[rf][cf].x = (xin[rf][cf].x - mean) * rstd * g4.x + b4.x;
+        xin[rf][cf].y = (xin[rf][cf].y - mean) * rstd * g4.y + b4.y;
+        xin[rf][cf].z = (xin[rf][cf].z - mean) * rstd * g4.z + b4.z;
+        xin[rf][cf].w = (xin[rf][cf].w - mean) * rstd * g4.w + b4.w;
+      }
+    }
+  };
+  auto store_f32 = [&](float* __restrict__ dst) {
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      const int m = m0 + rf * 16 + lr;
+      if (m < M) {
+        float* o = dst + (size_t)m * D + col0;
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) *(float4*)(o + 16 * cf) = xin[rf][cf];
+      }
+    }
+  };
+  if constexpr (LNMODE == 1) {
+    store_f32(a.x);
+    layer_norm(a.g1, a.be1, 0);
+  } else {
+    layer_norm(a.g1, a.be1, 0);
+    store_f32(a.x);
+    layer_norm(a.g2, a.be2, 1);
+    if (a.out_f32) store_f32(a.out_f32);
+  }
+  {
+    bf16* const out = (bf16*)a.xn_out;
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      const int m = m0 + rf * 16 + lr;
+      if (m < M) {
+        bf16* o = out + (size_t)m * D + col0;
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          const bf16x4 pk = {(bf16)xin[rf][cf].x, (bf16)xin[rf][cf].y, (bf16)xin[rf][cf].z, (bf16)xin[rf][cf].w};
+          *(bf16x4*)(o + 16 * cf) = pk;
+        }
+      }
+    }
+  }
+  stamp();
+}
+
+}  // namespace
+
+extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
+  if (!a || !a->xn_in || !a->x || !a->w1p || !a->w2p || !a->b1 || !a->b2 || !a->g1 || !a->be1 || !a->xn_out)
+    return EM_ERR_BAD_ARG;
+  if (a->M <= 0 || a->ff <= 0) return EM_ERR_BAD_ARG;
+  if (a->d != D || a->ff % CH != 0 || a->ff < 2 * CH) return EM_ERR_UNSUPPORTED;
+  if (a->ln_mode != 1 && a->ln_mode != 2) return EM_ERR_BAD_ARG;
+  if (a->ln_mode == 2 && (!a->g2 || !a->be2)) return EM_ERR_BAD_ARG;
+  static EmLdsCap cap1 = {}, cap2 = {};
+  const dim3 grid(em_cdiv(a->M, RB));
+  static long long* stamps = nullptr;
+  static const bool want_stamps = (EM_FFN_DBG & 8) && getenv("EM_FFN_STAMPS") != nullptr;
+  if (want_stamps && !stamps && hipMalloc((void**)&stamps, 64 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
+  if (want_stamps && hipMemsetAsync(stamps, 0, 64 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
+  long long* const st = want_stamps ? stamps : nullptr;
+  const bool rec = em_prof_begin(stream);
+  if (a->ln_mode == 1) {
+    if (em_raise_lds_cap((const void*)ffn_rows_kernel<1>, SMEM_BYTES, &cap1) != EM_OK) return EM_ERR_LAUNCH;
+    hipLaunchKernelGGL(ffn_rows_kernel<1>, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);
+  } else {
+    if (em_raise_lds_cap((const void*)ffn_rows_kernel<2>, SMEM_BYTES, &cap2) != EM_OK) return EM_ERR_LAUNCH;
+    hipLaunchKernelGGL(ffn_rows_kernel<2>, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);
+  }
+  if (want_stamps) {
+    long long hs[64];
+    if (hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess) {
+      printf("[ffn_rows<%d> stamps, cycles since entry]", a->ln_mode);
+      for (int i = 1; i < 64 && hs[i]; ++i) printf(" %lld", hs[i] - hs[0]);
+      printf("\n");
+      fflush(stdout);
+    }
+  }
+  if (rec) em_prof_end(stream, 4.0 * a->M * (double)D * a->ff, EM_PROF_GEMM);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}

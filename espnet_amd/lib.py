@@ -73,6 +73,13 @@ class EmBlockArgs(C.Structure):
                [("x_out", C.c_void_p), ("params_c", C.c_void_p), ("ffm_b1g", C.c_void_p), ("ff_b1g", C.c_void_p)]
 
 
+class EmFfnRowsArgs(C.Structure):
+    """include/espnet_amd.h EmFfnRowsArgs (csrc/ffn_rows.hip)."""
+    _fields_ = [(n, C.c_void_p) for n in ("xn_in", "x", "w1p", "w2p", "b1", "b2", "g1", "be1", "g2", "be2", "xn_out",
+                                          "out_f32")] + \
+               [(n, C.c_int32) for n in ("M", "d", "ff", "ln_mode")] + [("scale", C.c_float), ("eps", C.c_float)]
+
+
 class EmConformerWeights(C.Structure):
     _fields_ = [("d", C.c_int32), ("heads", C.c_int32), ("ff", C.c_int32),
                 ("num_blocks", C.c_int32), ("kernel", C.c_int32), ("n_mels", C.c_int32),
@@ -240,6 +247,7 @@ _SIGNATURES = {
     "em_profile_read": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "em_profile_read2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "em_conformer_block_fused": (C.c_int, [C.c_int, C.POINTER(EmBlockArgs), _vp]),
+    "em_ffn_rows_fused": (C.c_int, [C.POINTER(EmFfnRowsArgs), _vp]),
     "em_relpos_attention2_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
                                             _vp]),
     "em_cast_f32": (C.c_int, [C.c_int, _vp, _sz, _vp, _vp]),

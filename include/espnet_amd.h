@@ -261,6 +261,8 @@ typedef struct EmConformerLayer {
   const void* pw1f;      /* [2d][d]: pointwise_conv1 rows in 64-row granules [v0..63, g0..63, v64..127, ...], K units */
   const void *ffm_w2p, *ff_w2p; /* w_2 of the two FFNs, packed per pair of hidden chunks (EmBlockArgs) */
   const void *woutp, *pw2p, *ff_w1p, *ffm_w1p, *wqkvp; /* K units of wout, pw2, ff_w1, ffm_w1, wqkv */
+  /* d = 512 (bf16): ffm_w1p / ffm_w2p / ff_w1p / ff_w2p hold the operand streams of em_ffn_rows_fused instead (EmFfnRowsArgs
+   * w1p / w2p) and em_conformer_encode runs each feed-forward module as one row-block launch; the other fields stay NULL */
   const float* fp_c;     /* parameter groups of block<C> for this layer (EM_BLOCK_PARAM_GROUP floats each) */
   const float* fp_da;    /* groups of block<D|A> (D part of this layer, A part of the next) or block<D|FINAL> */
   const float* fp_a;     /* groups of block<A> (layer 0 only) */
@@ -404,6 +406,31 @@ typedef struct EmBlockArgs {
   const float* ff_b1g;
 } EmBlockArgs;
 int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
+
+/* ---- A9 + A10, row-block fused feed-forward module for the 512-wide Conformer (bf16; csrc/ffn_rows.hip):
+ *      PositionwiseFeedForward.forward (transformer/positionwise_feed_forward.py:30-32) with its residual
+ *      (conformer/encoder_layer.py:111-121, :160-168) and the LayerNorm(s) that follow it (:124 norm_mha; :170-171
+ *      norm_final + the next block's :112 norm_ff_macaron, or ConformerEncoder's after_norm), 64 rows per workgroup:
+ *        ln_mode 1:  x += scale * (W2 . swish(W1 . xn_in + b1) + b2);      xn_out = LN(x; g1, be1)
+ *        ln_mode 2:  x  = LN(x + scale * (...); g1, be1);                  xn_out = LN(x; g2, be2)  (+ out_f32)
+ *      The [M][ff] hidden activation is never written; x is read and written once.  xn_out may alias xn_in.
+ *   w1p: W1 [ff][512] in 128-row chunks of 16 x 8 MFMA operand fragments of 1 KiB (the eight waves' fragments adjacent):
+ *        [c][ks 16][w 8][lane = 16 lg + lr][e 8] = W1[128 c + 16 w + lr][32 ks + 8 lg + e]
+ *   w2p: W2 [512][ff], the contraction index ordered as the waves hold the hidden activation:
+ *        [c][s 4][cf 4][w 8][lane][e 8] = W2[64 w + 16 cf + lr][128 c + 32 s + 16 (e >> 2) + 4 lg + (e & 3)]
+ *        (host: pack_ffn_rows_w1 / pack_ffn_rows_w2, espnet_amd/asr/encoder/conformer_encoder.py)            */
+typedef struct EmFfnRowsArgs {
+  const void* xn_in; /* [M][512] bf16: the module's input, LN(x) */
+  float* x;          /* [M][512] f32 residual stream, updated in place */
+  const void *w1p, *w2p;
+  const float *b1, *b2; /* [ff], [512] */
+  const float *g1, *be1, *g2, *be2; /* LayerNorm weights / biases [512] (g2 / be2: ln_mode 2 only) */
+  void* xn_out;   /* [M][512] bf16 */
+  float* out_f32; /* optional (ln_mode 2): the second LayerNorm's result in f32 as well */
+  int32_t M, d, ff, ln_mode;
+  float scale, eps;
+} EmFfnRowsArgs;
+int em_ffn_rows_fused(const EmFfnRowsArgs* args, void* stream);
 
 /* ---- A7, LDS-resident form (bf16, d_k = 64): RelPositionMultiHeadedAttention.forward core
  *      (transformer/attention.py:416-459, rel_shift :391-408) over per-head operands.  One workgroup

@@ -14,6 +14,13 @@ mkdir -p espnet_amd/lib/dbg
 objs=$(ls espnet_amd/lib/*.o | grep -v "/block.o")
 for v in "$@"; do
   case "$v" in
+    ffn*)  # csrc/ffn_rows.hip -DEM_FFN_DBG=<d>: 1 no MFMAs, 2 no weight requests, 4 no LDS operand reads, 8 cycle stamps
+      o2=$(ls espnet_amd/lib/*.o | grep -v "/ffn_rows.o")
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -DEM_FFN_DBG=${v#ffn} \
+        -Iinclude -Iespnet_amd/csrc -c espnet_amd/csrc/ffn_rows.hip -o espnet_amd/lib/dbg/ffn_rows_$v.o 2>/dev/null
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o espnet_amd/lib/dbg/lib_$v.so $o2 espnet_amd/lib/dbg/ffn_rows_$v.o
+      rm -f espnet_amd/lib/dbg/ffn_rows_$v.o
+      echo "built espnet_amd/lib/dbg/lib_$v.so"; continue ;;
     nt) def="-DEM_BLOCK_NO_TOUCH=1" ;;
     fine*) def="-DEM_BLOCK_FINE=1 -DEM_BLOCK_VAR=${v#fine}"; [ "$v" = fine ] && def="-DEM_BLOCK_FINE=1" ;;
     v*) def="-DEM_BLOCK_VAR=${v#v}" ;;

@@ -74,6 +74,24 @@ case "$what" in
     done
     unset ESPNET_AMD_NO_SUB12
     echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
+  ffn-rows)  # round 4: the 512-wide model's feed-forward modules as row-block launches (csrc/ffn_rows.hip)
+    echo "== tests"; timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_e2e.py tests/test_gpu_search.py -q -x \
+       -k "ffn_rows or large" 2>&1 | tail -6 | tee "$out/pytest.txt"
+    for v in 1 0 1 0; do
+      if [ $v = 1 ]; then export ESPNET_AMD_NO_FFN_ROWS=1; else unset ESPNET_AMD_NO_FFN_ROWS; fi
+      echo -n "no_ffn_rows=$v: "; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180
+    done
+    unset ESPNET_AMD_NO_FFN_ROWS
+    echo "== stamps"; EM_FFN_STAMPS=1 timeout 120 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 1 --warmup 1 2>&1 < /dev/null | grep "ffn_rows<" | tail -4 | tee "$out/ffn_stamps.txt"
+    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
+  ffn-dbg)  # round 4: where ffn_rows_kernel's time goes: developer builds without MFMAs / weight requests / LDS operand reads, stamps
+    bash tools/build_block_variants.sh ffn2 ffn4 ffn6 ffn8 > /dev/null 2>&1
+    for v in "" 2 4 6; do
+      if [ -z "$v" ]; then unset ESPNET_AMD_LIB; else export ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_ffn$v.so; fi
+      echo "-- dbg=${v:-0}"; timeout 120 python tools/ffn_rows_bench.py 2>&1 | grep "ffn_rows mode"
+    done 2>&1 | tee "$out/ffn_dbg.txt"
+    echo "-- stamps"; ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_ffn8.so EM_FFN_STAMPS=1 timeout 120 python tools/ffn_rows_bench.py 2>&1 | grep "stamps" | head -4 | tee "$out/ffn_stamps.txt"
+    unset ESPNET_AMD_LIB ;;
   stream-fused)  # round 4: contextual-block layer on the row-block kernels (5 launches instead of 13) + E-Branchformer on sub2 / attention2
     echo "== tests"; timeout 900 python -m pytest tests/test_gpu_streaming.py tests/test_gpu_online_search.py tests/test_gpu_ebranchformer.py tests/test_gpu_block.py -q -x -s 2>&1 | grep -E "^\[stream|passed|failed|Error|assert" | tail -12 | tee "$out/pytest.txt"
     for v in 1 0; do
