@@ -225,6 +225,21 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   // hidden activation and one f32 round trip of the residual stream gone.  ESPNET_AMD_NO_FFN_ROWS=1: developer A/B switch.
   static const bool no_ffn_rows = getenv("ESPNET_AMD_NO_FFN_ROWS") != nullptr;
   bool ffn_rows = dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) && !no_ffn_rows;
+  if (ffn_rows) {
+    // A row-block launch takes ~80 us per ROUND of 64-row workgroups whatever the number of rows (one workgroup streams all
+    // 4 MiB of the module's weights through its CU), the three launches it replaces scale with M (90 us at M = 15 936, ~31 us at
+    // the beam search's M = 3 984, where only 63 CUs would work: profiles/r04r_search_kernel_stats.csv): taken only when its
+    // rounds fill at least three quarters of the chip.
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                 ? prop.multiProcessorCount : 256;
+    }
+    const long wgs = ((long)M + 63) / 64, rounds = (wgs + n_cu - 1) / n_cu;
+    ffn_rows = 4 * wgs >= 3 * rounds * n_cu;
+  }
   for (int l = 0; ffn_rows && l < L; ++l) ffn_rows = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
   auto ffn_fused = [&](const void* w1p, const void* w2p, const float* b1, const float* b2, int ln_mode, const float* g1,
                        const float* be1, const float* g2, const float* be2, void* xn_out, float* out_f32) {
