@@ -165,6 +165,14 @@ def pack_ffn_rows_w2(w: torch.Tensor) -> torch.Tensor:
     return u.reshape(ff // 128, 4 * 4 * 8 * 64 * 8)
 
 
+def pack_rows_proj(w: torch.Tensor) -> torch.Tensor:
+    """A [512][512] projection in front of a row-block feed-forward launch (EmFfnRowsArgs.pre_w):
+    [ks][cf][wv][lg][lr][e] = W[64 wv + 16 cf + lr][32 ks + 8 lg + e]."""
+    n, k = w.shape
+    assert n == 512 and k == 512, (n, k)
+    return w.detach().reshape(8, 4, 16, 16, 4, 8).permute(3, 1, 0, 4, 2, 5).contiguous().reshape(n, k)
+
+
 def pack_conv1_frags(w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
     """conv.0 weight [256][9] + bias [256] (f32) -> the MFMA operand of the fused conv1 + conv2 kernel (include/espnet_amd.h,
     em_conv2d_sub12_bf16): per channel 32 bf16 k-slots  hi(w) | hi(w) | lo(w) | hi(b), lo(b), 0, 0, 0  with hi(x) = bf16(x),
@@ -398,7 +406,8 @@ class ConformerEncoder(torch.nn.Module):
                 lt = dict(ffm_w1p=A(pack_ffn_rows_w1(l.feed_forward_macaron.w_1.weight)),
                           ffm_w2p=A(pack_ffn_rows_w2(l.feed_forward_macaron.w_2.weight)),
                           ff_w1p=A(pack_ffn_rows_w1(l.feed_forward.w_1.weight)),
-                          ff_w2p=A(pack_ffn_rows_w2(l.feed_forward.w_2.weight)))
+                          ff_w2p=A(pack_ffn_rows_w2(l.feed_forward.w_2.weight)),
+                          pw2p=A(pack_rows_proj(l.conv_module.pointwise_conv2.weight.reshape(d, d))))
                 for k, v in lt.items():
                     setattr(layers[i], k, v.data_ptr())
         w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))

@@ -241,9 +241,18 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     ffn_rows = 4 * wgs >= 3 * rounds * n_cu;
   }
   for (int l = 0; ffn_rows && l < L; ++l) ffn_rows = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
+  // ... and pointwise_conv2 + residual + norm_ff ride in the second module's launch when the host packed pw2 as well
+  bool pre_pw2 = ffn_rows;
+  for (int l = 0; pre_pw2 && l < L; ++l) pre_pw2 = ly[l].pw2p != nullptr;
+  const EmConformerLayer* pre_layer = nullptr;  // set for the call that carries the projection
+  const void* const conv_out = g2;              // the depthwise conv's output: the projection's input
   auto ffn_fused = [&](const void* w1p, const void* w2p, const float* b1, const float* b2, int ln_mode, const float* g1,
                        const float* be1, const float* g2, const float* be2, void* xn_out, float* out_f32) {
     EmFfnRowsArgs fa = {};
+    if (pre_layer) {
+      fa.pre_in = conv_out; fa.pre_w = pre_layer->pw2p; fa.pre_b = pre_layer->pw2_b;
+      fa.pre_g = pre_layer->norm_ff_g; fa.pre_be = pre_layer->norm_ff_b;
+    }
     fa.xn_in = xn; fa.x = x; fa.w1p = w1p; fa.w2p = w2p; fa.b1 = b1; fa.b2 = b2;
     fa.g1 = g1; fa.be1 = be1; fa.g2 = g2; fa.be2 = be2; fa.xn_out = xn_out; fa.out_f32 = out_f32;
     fa.M = M; fa.d = d; fa.ff = ff; fa.ln_mode = ln_mode; fa.scale = 0.5f; fa.eps = LN_EPS;
@@ -253,6 +262,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
                       stream));
   for (int l = 0; l < L; ++l) {
     const EmConformerLayer& q = ly[l];
+    pre_layer = nullptr;
     if (ffn_rows) {
       // macaron FFN + residual + norm_mha
       EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr));
@@ -284,9 +294,12 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
     EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, conv_lens, B, T, d, w->kernel, g2, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
-    // FFN
-    EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
+    if (!pre_pw2) {
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));
+      // FFN
+      EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
+    }
+    pre_layer = pre_pw2 ? &q : nullptr;
     if (ffn_rows) {  // FFN + residual + norm_final + the next consumer's LayerNorm
       if (l + 1 < L)
         EM_TRY(ffn_fused(q.ff_w1p, q.ff_w2p, q.ff_b1, q.ff_b2, 2, q.norm_final_g, q.norm_final_b, ly[l + 1].norm_ff_mac_g,

@@ -93,7 +93,11 @@ __device__ __forceinline__ float rsqrt_nr(float var) {
   return y0 * (1.5f - 0.5f * var * y0 * y0);
 }
 
-template <int LNMODE>
+// PRE: the launch starts with a projection of its own - x += W_pre . pre_in + b_pre (pointwise_conv2 of the conv module,
+// convolution.py:78-79 + the residual of encoder_layer.py:158) followed by LayerNorm(pre_g, pre_be) (norm_ff, :161) whose
+// result becomes the feed-forward module's input: the GEMM + residual launch and the LayerNorm launch in front of the
+// second feed-forward module of a block (19.1 + 9.8 us at B = 64) become 256 more MFMAs per wave in this one.
+template <int LNMODE, bool PRE>
 __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, long long* __restrict__ stamps) {
   using MM = Mma<bf16>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   // (from inline asm: an LDS-DMA hipcc knows about makes its wait-count pass put s_waitcnt vmcnt(0) in front of the first LDS
   // read - i.e. wait for the ring AND the residual rows requested behind it - instead of the counted wait below)
   {
-    const unsigned char* src = (const unsigned char*)a.xn_in;
+    const unsigned char* src = (const unsigned char*)(PRE ? a.pre_in : a.xn_in);
 #pragma unroll
     for (int i = 0; i < RB / NW; ++i) {
       const int row = wave * (RB / NW) + i;
@@ -139,8 +143,11 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   auto ld = [&](__amdgpu_buffer_rsrc_t rs, int i) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, i * 8192, 0));
   };
+  // (PRE: the projection's 64 fragments x [8 waves] x 1 KiB, [ks][cf][wave][lane][e] = W_pre[64 wave + 16 cf + lr][32 ks + 8 lg + e])
+  const __amdgpu_buffer_rsrc_t rs_pre =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(PRE ? a.pre_w : a.w1p), 0, 4 * CHUNK_BYTES, 0x00020000);
   {
-    const __amdgpu_buffer_rsrc_t r0 = rsrc(a.w1p, 0);
+    const __amdgpu_buffer_rsrc_t r0 = PRE ? rs_pre : rsrc(a.w1p, 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) ring[i] = ld(r0, i);
   }
@@ -268,6 +275,119 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   __builtin_amdgcn_sched_barrier(0);
   read_act(0, af0);
 
+  // LayerNorm statistics of the 64 rows over values v[cf][rf] (lane: columns 64 wave + 16 cf + 4 lg + r of rows 16 rf + lr):
+  // every lane reduces its 16 values to (sum, M2 about its own mean), the lane groups combine with Chan's update for
+  // equal-sized groups (M2 = M2a + M2b + (sa - sb)^2 / (2 n)) through register swaps, the eight waves through ONE LDS
+  // exchange, summed in wave order whatever the arrival order: deterministic.  `set` alternates the exchange buffer.
+  auto ln_stats = [&](const f32x4 (&v)[4][4], int set, float (&mean)[4], float (&rstd)[4]) {
+    float2* const red = (float2*)(smem + RED_OFF + set * 4096);
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      float s = 0.f;
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) s += (v[cf][rf][0] + v[cf][rf][1]) + (v[cf][rf][2] + v[cf][rf][3]);
+      const float mu = s * (1.0f / 16.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) {
+        const float dx = v[cf][rf][0] - mu, dy = v[cf][rf][1] - mu, dz = v[cf][rf][2] - mu, dw = v[cf][rf][3] - mu;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      {
+        const Pair2 ps = wave_xor16_pair(s), pq = wave_xor16_pair(q);
+        q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 32.0f);
+        s = ps.a + ps.b;
+      }
+      {
+        const Pair2 ps = wave_xor32_pair(s), pq = wave_xor32_pair(q);
+        q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 64.0f);
+        s = ps.a + ps.b;
+      }
+      if (lg == 0) red[wave * 64 + rf * 16 + lr] = make_float2(s, q);
+    }
+    barrier();
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      const int r = rf * 16 + lr;
+      float2 p[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) p[w] = red[w * 64 + r];
+#pragma unroll
+      for (int w = 0; w < 8; w += 2) {
+        p[w].y = p[w].y + p[w + 1].y + (p[w].x - p[w + 1].x) * (p[w].x - p[w + 1].x) * (1.0f / 128.0f);
+        p[w].x += p[w + 1].x;
+      }
+#pragma unroll
+      for (int w = 0; w < 8; w += 4) {
+        p[w].y = p[w].y + p[w + 2].y + (p[w].x - p[w + 2].x) * (p[w].x - p[w + 2].x) * (1.0f / 256.0f);
+        p[w].x += p[w + 2].x;
+      }
+      const float qq = p[0].y + p[4].y + (p[0].x - p[4].x) * (p[0].x - p[4].x) * (1.0f / 512.0f);
+      mean[rf] = (p[0].x + p[4].x) * (1.0f / D);
+      rstd[rf] = rsqrt_nr(qq * (1.0f / D) + a.eps);
+    }
+  };
+
+  if constexpr (PRE) {
+    // ---- the projection: accp^T[col 64 wave + 16 cf + ..][row] = W_pre . tile^T over K = 512, GEMM-2 style (the tile's
+    // fragments one k-step ahead, a slot refilled behind its 4 MFMAs: the projection's fragment 16 positions on, then
+    // the head of W1's first chunk)
+    f32x4 accp[4][4];
+    {
+      const __amdgpu_buffer_rsrc_t rw1 = rsrc(a.w1p, 0);
+      bf16x8 cur[4], nxt[4];
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf) cur[rf] = af0[rf];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks + 1 < 16) read_act(ks + 1, nxt);
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          const int pos = ks * 4 + cf;
+#pragma unroll
+          for (int rf = 0; rf < 4; ++rf)
+            accp[cf][rf] = MM::mma(ring[pos & 15], cur[rf], ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : accp[cf][rf]);
+          ring[pos & 15] = pos + 16 < 64 ? ld(rs_pre, pos + 16) : ld(rw1, pos + 16 - 64);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf) cur[rf] = nxt[rf];
+      }
+    }
+    // x' = x + (acc + b_pre): the residual stream for the rest of the launch
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) {
+      const float4 bp = *(const float4*)(a.pre_b + col0 + 16 * cf);
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf) {
+        acc2[cf][rf][0] += accp[cf][rf][0] + bp.x;
+        acc2[cf][rf][1] += accp[cf][rf][1] + bp.y;
+        acc2[cf][rf][2] += accp[cf][rf][2] + bp.z;
+        acc2[cf][rf][3] += accp[cf][rf][3] + bp.w;
+      }
+    }
+    // LayerNorm(x') -> bf16 -> the activation tile (its barrier also says that every wave is done reading the tile)
+    float mean[4], rstd[4];
+    ln_stats(acc2, 0, mean, rstd);
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) {
+      const float4 g4 = *(const float4*)(a.pre_g + col0 + 16 * cf);
+      const float4 b4 = *(const float4*)(a.pre_be + col0 + 16 * cf);
+      const int q = 8 * wave + 2 * cf + (lg >> 1);  // 16-byte chunk of the row that holds columns col0 + 16 cf ..
+      const int pos = (q & ~15) | ((q ^ lr) & 15);
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf) {
+        const bf16x4 pk = {(bf16)((acc2[cf][rf][0] - mean[rf]) * rstd[rf] * g4.x + b4.x),
+                           (bf16)((acc2[cf][rf][1] - mean[rf]) * rstd[rf] * g4.y + b4.y),
+                           (bf16)((acc2[cf][rf][2] - mean[rf]) * rstd[rf] * g4.z + b4.z),
+                           (bf16)((acc2[cf][rf][3] - mean[rf]) * rstd[rf] * g4.w + b4.w)};
+        *(bf16x4*)(smem + ACT_OFF + (rf * 16 + lr) * 1024 + pos * 16 + (lg & 1) * 8) = pk;
+      }
+    }
+    barrier();
+    read_act(0, af0);
+  }
+
   gemm1(nch > 1 ? rsrc(a.w1p, 1) : rsrc(a.w2p, 0), std::false_type{}, 0);
 #pragma unroll
   for (int rf = 0; rf < 4; ++rf)
@@ -302,70 +422,25 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc2[3][3]));
   stamp();
 
-  // ---- epilogue: x' = scale * acc2
-  float4 xin[4][4];
+  // ---- epilogue: x' = scale * acc2, then the LayerNorm(s) behind the module
+  f32x4 xin[4][4];
 #pragma unroll
   for (int cf = 0; cf < 4; ++cf)
 #pragma unroll
-    for (int rf = 0; rf < 4; ++rf)
-      xin[rf][cf] = make_float4(scale * acc2[cf][rf][0], scale * acc2[cf][rf][1], scale * acc2[cf][rf][2], scale * acc2[cf][rf][3]);
-  // LayerNorm over the 512 columns of every row, v -> v normalised (in place); `set` alternates the exchange buffer
-  auto layer_norm = [&](const float* __restrict__ g, const float* __restrict__ be, int set) {
-    float2* const red = (float2*)(smem + RED_OFF + set * 4096);
+    for (int rf = 0; rf < 4; ++rf) xin[cf][rf] = acc2[cf][rf] * scale;
+  auto layer_norm = [&](const float* __restrict__ g, const float* __restrict__ be, int set) {  // in place
+    float mean[4], rstd[4];
+    ln_stats(xin, set, mean, rstd);
 #pragma unroll
-    for (int rf = 0; rf < 4; ++rf) {
-      float s = 0.f;
+    for (int cf = 0; cf < 4; ++cf) {
+      const float4 g4 = *(const float4*)(g + col0 + 16 * cf);
+      const float4 b4 = *(const float4*)(be + col0 + 16 * cf);
 #pragma unroll
-      for (int cf = 0; cf < 4; ++cf) s += (xin[rf][cf].x + xin[rf][cf].y) + (xin[rf][cf].z + xin[rf][cf].w);
-      const float mu = s * (1.0f / 16.0f);
-      float q = 0.f;
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf) {
-        const float dx = xin[rf][cf].x - mu, dy = xin[rf][cf].y - mu, dz = xin[rf][cf].z - mu, dw = xin[rf][cf].w - mu;
-        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      // Chan's update for equal-sized groups: M2 = M2a + M2b + (sa - sb)^2 / (2 n)
-      {
-        const Pair2 ps = wave_xor16_pair(s), pq = wave_xor16_pair(q);
-        q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 32.0f);
-        s = ps.a + ps.b;
-      }
-      {
-        const Pair2 ps = wave_xor32_pair(s), pq = wave_xor32_pair(q);
-        q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 64.0f);
-        s = ps.a + ps.b;
-      }
-      if (lg == 0) red[wave * 64 + rf * 16 + lr] = make_float2(s, q);
-    }
-    barrier();
-#pragma unroll
-    for (int rf = 0; rf < 4; ++rf) {
-      const int r = rf * 16 + lr;
-      float2 p[8];
-#pragma unroll
-      for (int w = 0; w < 8; ++w) p[w] = red[w * 64 + r];
-      // pairwise over the waves (64 columns each), summed in wave order whatever the arrival order: deterministic
-#pragma unroll
-      for (int w = 0; w < 8; w += 2) {
-        p[w].y = p[w].y + p[w + 1].y + (p[w].x - p[w + 1].x) * (p[w].x - p[w + 1].x) * (1.0f / 128.0f);
-        p[w].x += p[w + 1].x;
-      }
-#pragma unroll
-      for (int w = 0; w < 8; w += 4) {
-        p[w].y = p[w].y + p[w + 2].y + (p[w].x - p[w + 2].x) * (p[w].x - p[w + 2].x) * (1.0f / 256.0f);
-        p[w].x += p[w + 2].x;
-      }
-      const float qq = p[0].y + p[4].y + (p[0].x - p[4].x) * (p[0].x - p[4].x) * (1.0f / 512.0f);
-      const float mean = (p[0].x + p[4].x) * (1.0f / D);
-      const float rstd = rsqrt_nr(qq * (1.0f / D) + a.eps);
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf) {
-        const float4 g4 = *(const float4*)(g + col0 + 16 * cf);
-        const float4 b4 = *(const float4*)(be + col0 + 16 * cf);
-        xin[rf][cf].x = (xin[rf][cf].x - mean) * rstd * g4.x + b4.x;
-        xin[rf][cf].y = (xin[rf][cf].y - mean) * rstd * g4.y + b4.y;
-        xin[rf][cf].z = (xin[rf][cf].z - mean) * rstd * g4.z + b4.z;
-        xin[rf][cf].w = (xin[rf][cf].w - mean) * rstd * g4.w + b4.w;
+      for (int rf = 0; rf < 4; ++rf) {
+        xin[cf][rf][0] = (xin[cf][rf][0] - mean[rf]) * rstd[rf] * g4.x + b4.x;
+        xin[cf][rf][1] = (xin[cf][rf][1] - mean[rf]) * rstd[rf] * g4.y + b4.y;
+        xin[cf][rf][2] = (xin[cf][rf][2] - mean[rf]) * rstd[rf] * g4.z + b4.z;
+        xin[cf][rf][3] = (xin[cf][rf][3] - mean[rf]) * rstd[rf] * g4.w + b4.w;
       }
     }
   };
@@ -376,17 +451,17 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
       if (m < M) {
         float* o = dst + (size_t)m * D + col0;
 #pragma unroll
-        for (int cf = 0; cf < 4; ++cf) *(float4*)(o + 16 * cf) = xin[rf][cf];
+        for (int cf = 0; cf < 4; ++cf) *(f32x4*)(o + 16 * cf) = xin[cf][rf];
       }
     }
   };
   if constexpr (LNMODE == 1) {
     store_f32(a.x);
-    layer_norm(a.g1, a.be1, 0);
+    layer_norm(a.g1, a.be1, 1);
   } else {
-    layer_norm(a.g1, a.be1, 0);
+    layer_norm(a.g1, a.be1, 1);
     store_f32(a.x);
-    layer_norm(a.g2, a.be2, 1);
+    layer_norm(a.g2, a.be2, 0);
     if (a.out_f32) store_f32(a.out_f32);
   }
   {
@@ -398,7 +473,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
         bf16* o = out + (size_t)m * D + col0;
 #pragma unroll
         for (int cf = 0; cf < 4; ++cf) {
-          const bf16x4 pk = {(bf16)xin[rf][cf].x, (bf16)xin[rf][cf].y, (bf16)xin[rf][cf].z, (bf16)xin[rf][cf].w};
+          const bf16x4 pk = {(bf16)xin[cf][rf][0], (bf16)xin[cf][rf][1], (bf16)xin[cf][rf][2], (bf16)xin[cf][rf][3]};
           *(bf16x4*)(o + 16 * cf) = pk;
         }
       }
@@ -410,37 +485,37 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
 }  // namespace
 
 extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
-  if (!a || !a->xn_in || !a->x || !a->w1p || !a->w2p || !a->b1 || !a->b2 || !a->g1 || !a->be1 || !a->xn_out)
-    return EM_ERR_BAD_ARG;
+  if (!a || !a->x || !a->w1p || !a->w2p || !a->b1 || !a->b2 || !a->g1 || !a->be1 || !a->xn_out) return EM_ERR_BAD_ARG;
+  const bool pre = a->pre_in != nullptr;
+  if (pre ? (!a->pre_w || !a->pre_b || !a->pre_g || !a->pre_be) : !a->xn_in) return EM_ERR_BAD_ARG;
   if (a->M <= 0 || a->ff <= 0) return EM_ERR_BAD_ARG;
   if (a->d != D || a->ff % CH != 0 || a->ff < 2 * CH) return EM_ERR_UNSUPPORTED;
   if (a->ln_mode != 1 && a->ln_mode != 2) return EM_ERR_BAD_ARG;
   if (a->ln_mode == 2 && (!a->g2 || !a->be2)) return EM_ERR_BAD_ARG;
-  static EmLdsCap cap1 = {}, cap2 = {};
   const dim3 grid(em_cdiv(a->M, RB));
   static long long* stamps = nullptr;
   static const bool want_stamps = (EM_FFN_DBG & 8) && getenv("EM_FFN_STAMPS") != nullptr;
   if (want_stamps && !stamps && hipMalloc((void**)&stamps, 64 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
   if (want_stamps && hipMemsetAsync(stamps, 0, 64 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   long long* const st = want_stamps ? stamps : nullptr;
+  typedef void (*kern_t)(const EmFfnRowsArgs, long long*);
+  static EmLdsCap caps[4] = {};
+  const int which = (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
+  const kern_t kern = which == 0 ? ffn_rows_kernel<1, false> : which == 1 ? ffn_rows_kernel<1, true>
+                    : which == 2 ? ffn_rows_kernel<2, false> : ffn_rows_kernel<2, true>;
+  if (em_raise_lds_cap((const void*)kern, SMEM_BYTES, &caps[which]) != EM_OK) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
-  if (a->ln_mode == 1) {
-    if (em_raise_lds_cap((const void*)ffn_rows_kernel<1>, SMEM_BYTES, &cap1) != EM_OK) return EM_ERR_LAUNCH;
-    hipLaunchKernelGGL(ffn_rows_kernel<1>, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);
-  } else {
-    if (em_raise_lds_cap((const void*)ffn_rows_kernel<2>, SMEM_BYTES, &cap2) != EM_OK) return EM_ERR_LAUNCH;
-    hipLaunchKernelGGL(ffn_rows_kernel<2>, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);
-  }
+  hipLaunchKernelGGL(kern, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);
   if (want_stamps) {
     long long hs[64];
     if (hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess) {
-      printf("[ffn_rows<%d> stamps, cycles since entry]", a->ln_mode);
+      printf("[ffn_rows<%d,%d> stamps, cycles since entry]", a->ln_mode, (int)pre);
       for (int i = 1; i < 64 && hs[i]; ++i) printf(" %lld", hs[i] - hs[0]);
       printf("\n");
       fflush(stdout);
     }
   }
-  if (rec) em_prof_end(stream, 4.0 * a->M * (double)D * a->ff, EM_PROF_GEMM);
+  if (rec) em_prof_end(stream, 4.0 * a->M * (double)D * a->ff + (pre ? 2.0 * a->M * (double)D * D : 0.0), EM_PROF_GEMM);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

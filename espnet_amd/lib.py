@@ -77,7 +77,8 @@ class EmFfnRowsArgs(C.Structure):
     """include/espnet_amd.h EmFfnRowsArgs (csrc/ffn_rows.hip)."""
     _fields_ = [(n, C.c_void_p) for n in ("xn_in", "x", "w1p", "w2p", "b1", "b2", "g1", "be1", "g2", "be2", "xn_out",
                                           "out_f32")] + \
-               [(n, C.c_int32) for n in ("M", "d", "ff", "ln_mode")] + [("scale", C.c_float), ("eps", C.c_float)]
+               [(n, C.c_int32) for n in ("M", "d", "ff", "ln_mode")] + [("scale", C.c_float), ("eps", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("pre_in", "pre_w", "pre_b", "pre_g", "pre_be")]
 
 
 class EmConformerWeights(C.Structure):

@@ -262,7 +262,8 @@ typedef struct EmConformerLayer {
   const void *ffm_w2p, *ff_w2p; /* w_2 of the two FFNs, packed per pair of hidden chunks (EmBlockArgs) */
   const void *woutp, *pw2p, *ff_w1p, *ffm_w1p, *wqkvp; /* K units of wout, pw2, ff_w1, ffm_w1, wqkv */
   /* d = 512 (bf16): ffm_w1p / ffm_w2p / ff_w1p / ff_w2p hold the operand streams of em_ffn_rows_fused instead (EmFfnRowsArgs
-   * w1p / w2p) and em_conformer_encode runs each feed-forward module as one row-block launch; the other fields stay NULL */
+   * w1p / w2p), pw2p the projection in front of the second one (EmFfnRowsArgs.pre_w), and em_conformer_encode runs each
+   * feed-forward module as one row-block launch; the other fields stay NULL */
   const float* fp_c;     /* parameter groups of block<C> for this layer (EM_BLOCK_PARAM_GROUP floats each) */
   const float* fp_da;    /* groups of block<D|A> (D part of this layer, A part of the next) or block<D|FINAL> */
   const float* fp_a;     /* groups of block<A> (layer 0 only) */
@@ -429,6 +430,15 @@ typedef struct EmFfnRowsArgs {
   float* out_f32; /* optional (ln_mode 2): the second LayerNorm's result in f32 as well */
   int32_t M, d, ff, ln_mode;
   float scale, eps;
+  /* optional projection in front of the module (pre_in != NULL; xn_in is then unused):
+   *   x += W_pre . pre_in + pre_b;   the module's input = LN(x; pre_g, pre_be)
+   * i.e. ConvolutionModule's pointwise_conv2 (conformer/convolution.py:78-79) with the residual of
+   * encoder_layer.py:158 and norm_ff (:161) inside the launch of the second feed-forward module.
+   *   pre_in [M][512] bf16;  pre_w: W_pre [512][512] as 64 x 8 operand fragments of 1 KiB,
+   *   [ks 16][cf 4][w 8][lane][e 8] = W_pre[64 w + 16 cf + lr][32 ks + 8 lg + e]  (host: pack_rows_proj)          */
+  const void* pre_in;
+  const void* pre_w;
+  const float *pre_b, *pre_g, *pre_be;
 } EmFfnRowsArgs;
 int em_ffn_rows_fused(const EmFfnRowsArgs* args, void* stream);
 

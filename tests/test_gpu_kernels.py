@@ -486,24 +486,34 @@ def test_gemm_head_layout_epilogues(lib, B, T, h):
     assert bool((vt[:, :, :, T:].float() == 7.0).all())
 
 
-@pytest.mark.parametrize("M,ff,ln_mode", [(200, 256, 1), (1000, 2048, 1), (1000, 2048, 2), (64, 1024, 2)])
-def test_ffn_rows_fused(lib, M, ff, ln_mode):
+@pytest.mark.parametrize("M,ff,ln_mode,pre", [(200, 256, 1, False), (1000, 2048, 1, False), (1000, 2048, 2, False),
+                                              (64, 1024, 2, False), (1000, 2048, 2, True), (333, 512, 1, True)])
+def test_ffn_rows_fused(lib, M, ff, ln_mode, pre):
     """Round 4: the 512-wide model's feed-forward module as ONE row-block launch (csrc/ffn_rows.hip: w_1 + Swish + w_2 +
     residual + the LayerNorm(s) that follow, positionwise_feed_forward.py:30-32 inside encoder_layer.py:111-121 / :160-171)
     against torch f32 on the same bf16-rounded operands (the hidden activation rounded to bf16 as the kernel rounds it).
-    Ragged M (the last workgroup overhangs), the minimal two chunks, both LayerNorm modes, rows past M untouched."""
-    from espnet_amd.asr.encoder.conformer_encoder import pack_ffn_rows_w1, pack_ffn_rows_w2
+    Ragged M (the last workgroup overhangs), the minimal two chunks, both LayerNorm modes, rows past M untouched.
+    pre: the launch starts with a projection of its own, x += W_pre . pre_in + b_pre, and LayerNorm(pre_g, pre_be) of the
+    result is the module's input (pointwise_conv2 + residual + norm_ff, convolution.py:78-79, encoder_layer.py:158-161)."""
+    from espnet_amd.asr.encoder.conformer_encoder import pack_ffn_rows_w1, pack_ffn_rows_w2, pack_rows_proj
 
     d = 512
     x = rnd(M, d, seed=51) * 2 + 0.3
     g0, b0 = 1 + 0.1 * rnd(d, seed=52), 0.1 * rnd(d, seed=53)
-    xn = q(F.layer_norm(x, (d,), g0, b0, 1e-12), torch.bfloat16)
     w1 = q(rnd(ff, d, seed=54, scale=d ** -0.5), torch.bfloat16)
     w2 = q(rnd(d, ff, seed=55, scale=ff ** -0.5), torch.bfloat16)
     b1, b2 = 0.1 * rnd(ff, seed=56), 0.1 * rnd(d, seed=57)
     g1, be1, g2, be2 = 1 + 0.1 * rnd(d, seed=58), 0.1 * rnd(d, seed=59), 1 + 0.1 * rnd(d, seed=60), 0.1 * rnd(d, seed=61)
+    if pre:
+        pin = q(rnd(M, d, seed=62), torch.bfloat16)
+        wp = q(rnd(d, d, seed=63, scale=d ** -0.5), torch.bfloat16)
+        bp = 0.1 * rnd(d, seed=64)
+        x0 = x + (pin @ wp.t() + bp)  # the residual stream the module sees
+    else:
+        x0 = x
+    xn = q(F.layer_norm(x0, (d,), g0, b0, 1e-12), torch.bfloat16)
     h = q(oc.swish(xn @ w1.t() + b1), torch.bfloat16)
-    x1 = x + 0.5 * (h @ w2.t() + b2)
+    x1 = x0 + 0.5 * (h @ w2.t() + b2)
     if ln_mode == 1:
         ref_x, ref_n = x1, F.layer_norm(x1, (d,), g1, be1, 1e-12)
     else:
@@ -514,13 +524,17 @@ def test_ffn_rows_fused(lib, M, ff, ln_mode):
     xnd = dev(torch.cat([xn, torch.full((pad, d), 7.0)]).to(torch.bfloat16))
     out_n = torch.full((M + pad, d), 7.0, dtype=torch.bfloat16, device="cuda")
     out_f = torch.full((M + pad, d), 7.0, device="cuda")
-    a = L.EmFfnRowsArgs(xn_in=xnd.data_ptr(), x=xd.data_ptr(),
+    a = L.EmFfnRowsArgs(xn_in=0 if pre else xnd.data_ptr(), x=xd.data_ptr(),
                         w1p=dev(pack_ffn_rows_w1(w1).to(torch.bfloat16)).data_ptr(),
                         w2p=dev(pack_ffn_rows_w2(w2).to(torch.bfloat16)).data_ptr(),
                         b1=dev(b1).data_ptr(), b2=dev(b2).data_ptr(), g1=dev(g1).data_ptr(), be1=dev(be1).data_ptr(),
                         g2=dev(g2).data_ptr(), be2=dev(be2).data_ptr(), xn_out=out_n.data_ptr(),
                         out_f32=out_f.data_ptr() if ln_mode == 2 else 0, M=M, d=d, ff=ff, ln_mode=ln_mode, scale=0.5,
                         eps=1e-12)
+    if pre:
+        pind = dev(torch.cat([pin, torch.full((pad, d), 7.0)]).to(torch.bfloat16))
+        a.pre_in, a.pre_w = pind.data_ptr(), dev(pack_rows_proj(wp).to(torch.bfloat16)).data_ptr()
+        a.pre_b, a.pre_g, a.pre_be = dev(bp).data_ptr(), dev(g0).data_ptr(), dev(b0).data_ptr()
     L.check(lib.em_ffn_rows_fused(a, sptr()), "em_ffn_rows_fused")
     torch.cuda.synchronize()
     assert_close(xd[:M], ref_x, 2e-3, f"ffn_rows x (mode {ln_mode})")  # f32 out; the bf16 rounding of H is in the reference
@@ -529,12 +543,12 @@ def test_ffn_rows_fused(lib, M, ff, ln_mode):
         assert_close(out_f[:M], ref_n, 2e-3, "ffn_rows f32 copy")
     assert bool((xd[M:] == 7.0).all()) and bool((out_n[M:].float() == 7.0).all()) and bool((out_f[M:] == 7.0).all())
     # in place over its own input (the encoder's use): same result
-    a.xn_out = xnd.data_ptr()
+    a.xn_out = pind.data_ptr() if pre else xnd.data_ptr()
     xd2 = dev(torch.cat([x, torch.full((pad, d), 7.0)]))
     a.x = xd2.data_ptr()
     L.check(lib.em_ffn_rows_fused(a, sptr()), "em_ffn_rows_fused (aliased)")
     torch.cuda.synchronize()
-    assert torch.equal(xnd[:M], out_n[:M]) and torch.equal(xd2[:M], xd[:M])
+    assert torch.equal((pind if pre else xnd)[:M], out_n[:M]) and torch.equal(xd2[:M], xd[:M])
     with pytest.raises(NotImplementedError):
         a.d = 256
         L.check(lib.em_ffn_rows_fused(a, sptr()), "em_ffn_rows_fused d=256")
