@@ -173,6 +173,18 @@ def pack_rows_proj(w: torch.Tensor) -> torch.Tensor:
     return w.detach().reshape(8, 4, 16, 16, 4, 8).permute(3, 1, 0, 4, 2, 5).contiguous().reshape(n, k)
 
 
+def glu_chunk_order(d: int = 512) -> torch.Tensor:
+    """Row order of pointwise_conv1 ([value rows 0 .. d) | gate rows d .. 2 d), F.glu(dim=1), convolution.py:66) for the
+    row-block GLU launch: chunk 2 j = the value rows of output columns 128 j .. 128 j + 127, chunk 2 j + 1 their gate rows."""
+    idx = torch.arange(2 * d).reshape(2, d // 128, 128)  # [value | gate][j][128]
+    return idx.permute(1, 0, 2).reshape(-1)
+
+
+def pack_rows_glu(w: torch.Tensor) -> torch.Tensor:
+    """pointwise_conv1 [2 * 512][512] -> the w1p layout of EmFfnRowsArgs in value / gate chunk pairs (EM_ROWS_GLU)."""
+    return pack_ffn_rows_w1(w.detach()[glu_chunk_order(w.shape[1])])
+
+
 def pack_conv1_frags(w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
     """conv.0 weight [256][9] + bias [256] (f32) -> the MFMA operand of the fused conv1 + conv2 kernel (include/espnet_amd.h,
     em_conv2d_sub12_bf16): per channel 32 bf16 k-slots  hi(w) | hi(w) | lo(w) | hi(b), lo(b), 0, 0, 0  with hi(x) = bf16(x),
@@ -407,7 +419,10 @@ class ConformerEncoder(torch.nn.Module):
                           ffm_w2p=A(pack_ffn_rows_w2(l.feed_forward_macaron.w_2.weight)),
                           ff_w1p=A(pack_ffn_rows_w1(l.feed_forward.w_1.weight)),
                           ff_w2p=A(pack_ffn_rows_w2(l.feed_forward.w_2.weight)),
-                          pw2p=A(pack_rows_proj(l.conv_module.pointwise_conv2.weight.reshape(d, d))))
+                          pw2p=A(pack_rows_proj(l.conv_module.pointwise_conv2.weight.reshape(d, d))),
+                          woutp=A(pack_rows_proj(l.self_attn.linear_out.weight)),
+                          pw1f=A(pack_rows_glu(l.conv_module.pointwise_conv1.weight.reshape(2 * d, d))),
+                          fp_c=F(l.conv_module.pointwise_conv1.bias[glu_chunk_order(d)]))
                 for k, v in lt.items():
                     setattr(layers[i], k, v.data_ptr())
         w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))

@@ -244,6 +244,10 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   // ... and pointwise_conv2 + residual + norm_ff ride in the second module's launch when the host packed pw2 as well
   bool pre_pw2 = ffn_rows;
   for (int l = 0; pre_pw2 && l < L; ++l) pre_pw2 = ly[l].pw2p != nullptr;
+  // ... and linear_out + residual + norm_conv + pointwise_conv1 + GLU are one launch (EM_ROWS_GLU) with woutp / pw1f / fp_c
+  // (= pointwise_conv1's bias in the chunk order) packed
+  bool rows_glu = ffn_rows;
+  for (int l = 0; rows_glu && l < L; ++l) rows_glu = ly[l].woutp && ly[l].pw1f && ly[l].fp_c;
   const EmConformerLayer* pre_layer = nullptr;  // set for the call that carries the projection
   const void* const conv_out = g2;              // the depthwise conv's output: the projection's input
   auto ffn_fused = [&](const void* w1p, const void* w2p, const float* b1, const float* b2, int ln_mode, const float* g1,
@@ -289,10 +293,19 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
       EM_TRY((w->legacy_relpos ? em_legacy_relpos_attention : em_relpos_attention)(dtype, big, (const unsigned char*)pall + (size_t)l * d * es, L * d,
                                  q.pos_u, q.pos_v, olens, B, T, h, 64, ctx, stream));
     }
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
-    // convolution module
-    EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
-    EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
+    if (rows_glu) {  // linear_out + residual + norm_conv + pointwise_conv1 + GLU: one row-block launch
+      EmFfnRowsArgs fa = {};
+      fa.x = x; fa.w1p = q.pw1f; fa.b1 = q.fp_c; fa.xn_out = gl;
+      fa.M = M; fa.d = d; fa.ff = 2 * d; fa.ln_mode = 1; fa.scale = 1.f; fa.eps = LN_EPS;
+      fa.pre_in = ctx; fa.pre_w = q.woutp; fa.pre_b = q.bout; fa.pre_g = q.norm_conv_g; fa.pre_be = q.norm_conv_b;
+      fa.main = EM_ROWS_GLU;
+      EM_TRY(em_ffn_rows_fused(&fa, stream));
+    } else {
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, ctx, q.wout, x, q.bout, M, d, d, d, d, 1.f, stream));
+      // convolution module
+      EM_TRY(em_layernorm(dtype, x, q.norm_conv_g, q.norm_conv_b, M, d, LN_EPS, xn, nullptr, stream));
+      EM_TRY(gemm(dtype, EM_EPI_GLU, xn, q.pw1, gl, q.pw1_b, M, 2 * d, d, d, d, 1.f, stream));
+    }
     EM_TRY(em_dwconv_bn_swish(dtype, gl, q.dw_w, q.dw_b, conv_lens, B, T, d, w->kernel, g2, stream));
     if (!pre_pw2) {
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, g2, q.pw2, x, q.pw2_b, M, d, d, d, d, 1.f, stream));

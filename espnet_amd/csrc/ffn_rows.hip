@@ -59,7 +59,8 @@ constexpr int CHUNK_BYTES = CH * D * 2;       // of W1 and of W2 each: 16 fragme
 constexpr int ACT_OFF = 0;                    // 64 KiB: LN(x) [64 rows][1 KiB], chunk q of row r at (q & ~15) | ((q ^ r) & 15)
 constexpr int H_OFF = ACT_OFF + RB * D * 2;   // 2 x 16 KiB: hidden activation tiles [buf][k-step s][row fragment][lane][16 B]
 constexpr int RED_OFF = H_OFF + 2 * 16384;    // 2 x 4 KiB: LayerNorm partials [set][wave][64 rows] (sum, M2)
-constexpr int SMEM_BYTES = RED_OFF + 8192;
+constexpr int PAR_OFF = RED_OFF + 8192;       // 8 x 2 KiB: pre_b, pre_g, pre_be, b2, g1, be1, g2, be2 (512 f32 each), by LDS-DMA in the prologue
+constexpr int SMEM_BYTES = PAR_OFF + 8 * 2048;
 static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
 
 typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -97,7 +98,13 @@ __device__ __forceinline__ float rsqrt_nr(float var) {
 // convolution.py:78-79 + the residual of encoder_layer.py:158) followed by LayerNorm(pre_g, pre_be) (norm_ff, :161) whose
 // result becomes the feed-forward module's input: the GEMM + residual launch and the LayerNorm launch in front of the
 // second feed-forward module of a block (19.1 + 9.8 us at B = 64) become 256 more MFMAs per wave in this one.
-template <int LNMODE, bool PRE>
+// MAIN = EM_ROWS_GLU: what follows the projection is not a feed-forward module but pointwise_conv1 + GLU of the conv module
+// (convolution.py:62-66): the launch is  x += linear_out . ctx + b  (attention.py:149-151 + the residual of
+// encoder_layer.py:147) -> norm_conv (:151) -> glu = value * sigmoid(gate), i.e. the GEMM + residual, LayerNorm and GLU GEMM
+// launches between the attention and the depthwise conv (19.1 + 9.8 + 29.7 us at B = 64).  Its matrix is walked in the
+// GEMM-1 form (wave w: 16 output columns of every 128-row chunk), chunks alternating value rows and their gate rows, so a
+// lane holds matching value / gate pairs; no hidden tile, no barrier in the loop.
+template <int LNMODE, bool PRE, int MAIN>
 __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, long long* __restrict__ stamps) {
   using MM = Mma<bf16>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -130,6 +137,20 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
       m = m < M ? m : M - 1;
       const int g = (lane & ~15) | ((lane ^ row) & 15);
       glds16(uniform_ptr(src + (size_t)m * (D * 2)), g * 16, ACT_OFF + row * 1024);
+    }
+  }
+  // ---- the bias / LayerNorm vectors -> LDS, wave w vector w.  Read from global memory where they are used, each LayerNorm
+  // exposed a dependent L2 round trip (and, behind a burst of stores, the stores' acknowledgement: loads and stores share
+  // vmcnt) - the hand-over between the projection and the GLU walk took 22 K cycles (stamps r04v).
+  {
+    const float* const vecs[8] = {a.pre_b, a.pre_g, a.pre_be, a.b2, a.g1, a.be1, a.g2, a.be2};
+    const float* v = vecs[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) v = wave == i ? vecs[i] : v;
+    if (v != nullptr) {  // (uniform)
+      const unsigned char* vb = uniform_ptr((const unsigned char*)v);
+      glds16(vb, lane * 16, PAR_OFF + wave * 2048);
+      glds16(vb, 1024 + lane * 16, PAR_OFF + wave * 2048 + 1024);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -175,6 +196,9 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   // instead of 3.1 K cycles (requests with 64-byte segments between the weight requests), 87 us; this one 82.9 us.
   // Lane (lr, lg) holds columns 64 wave + 16 cf + 4 lg + r of rows 16 rf + lr.
   const int col0 = 64 * wave + 4 * lg;
+  // bias / LayerNorm vector `which` (order of PAR_OFF) at this lane's columns 16 cf ..
+  auto par4 = [&](int which, int cf) { return *(const float4*)(smem + PAR_OFF + which * 2048 + (col0 + 16 * cf) * 4); };
+  auto parv = [&](int which, int cf) { return *(const f32x4*)(smem + PAR_OFF + which * 2048 + (col0 + 16 * cf) * 4); };
   const float scale = a.scale, inv_scale = 1.0f / a.scale;
   f32x4 acc2[4][4];
 
@@ -204,6 +228,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
       if (ks + 1 < 16 && !(dbg & 4)) read_act(ks + 1, nxt);
       if (SYNC && ks == 8) barrier();
       if (SYNC && ks == 15) read_h(hbuf, 0, h0);
+      if (MAIN == EM_ROWS_GLU && ks == 15) read_act(0, af0);  // (the next chunk's first fragments; af0 was copied to cur above)
 #pragma unroll
       for (int rf = 0; rf < 4; ++rf) {
         if constexpr ((dbg & 1) == 0)
@@ -264,14 +289,17 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   stamp();
+  auto load_x = [&](f32x4 (&v)[4][4]) {
 #pragma unroll
-  for (int rf = 0; rf < 4; ++rf) {
-    int m = m0 + rf * 16 + lr;
-    m = m < M ? m : M - 1;
-    const float* xr = a.x + (size_t)m * D + col0;
+    for (int rf = 0; rf < 4; ++rf) {
+      int m = m0 + rf * 16 + lr;
+      m = m < M ? m : M - 1;
+      const float* xr = a.x + (size_t)m * D + col0;
 #pragma unroll
-    for (int cf = 0; cf < 4; ++cf) acc2[cf][rf] = *(const f32x4*)(xr + 16 * cf);
-  }
+      for (int cf = 0; cf < 4; ++cf) v[cf][rf] = *(const f32x4*)(xr + 16 * cf);
+    }
+  };
+  load_x(acc2);
   __builtin_amdgcn_sched_barrier(0);
   read_act(0, af0);
 
@@ -283,16 +311,14 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     float2* const red = (float2*)(smem + RED_OFF + set * 4096);
 #pragma unroll
     for (int rf = 0; rf < 4; ++rf) {
-      float s = 0.f;
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf) s += (v[cf][rf][0] + v[cf][rf][1]) + (v[cf][rf][2] + v[cf][rf][3]);
+      // (whole-vector arithmetic: hipcc turns it into v_pk_*_f32, two values per instruction - written value by value one
+      // LayerNorm was ~850 VALU instructions per wave, 8 K cycles with the matrix cores idle: stamps r04w)
+      const f32x4 s4 = (v[0][rf] + v[1][rf]) + (v[2][rf] + v[3][rf]);
+      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
       const float mu = s * (1.0f / 16.0f);
-      float q = 0.f;
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf) {
-        const float dx = v[cf][rf][0] - mu, dy = v[cf][rf][1] - mu, dz = v[cf][rf][2] - mu, dw = v[cf][rf][3] - mu;
-        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
+      const f32x4 d0 = v[0][rf] - mu, d1 = v[1][rf] - mu, d2 = v[2][rf] - mu, d3 = v[3][rf] - mu;
+      const f32x4 q4 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
       {
         const Pair2 ps = wave_xor16_pair(s), pq = wave_xor16_pair(q);
         q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 32.0f);
@@ -332,7 +358,11 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     // ---- the projection: accp^T[col 64 wave + 16 cf + ..][row] = W_pre . tile^T over K = 512, GEMM-2 style (the tile's
     // fragments one k-step ahead, a slot refilled behind its 4 MFMAs: the projection's fragment 16 positions on, then
     // the head of W1's first chunk)
-    f32x4 accp[4][4];
+    // The accumulators START as the residual rows (requested behind the prologue barrier like the plain launch's): no
+    // registers of their own.  (Two versions with the rows in registers of their own - requested in front of the projection,
+    // or at its k-step 12 - pushed the kernel past 256 registers: hipcc spilled ring refills the moment they were loaded, each
+    // behind an s_waitcnt vmcnt(0), and the 256 MFMAs per wave took 20 K cycles: stamps r04u.)  The price: the first MFMAs
+    // wait for the rows, ~10 K cycles at the rate 249 workgroups get their 128 KiB each.
     {
       const __amdgpu_buffer_rsrc_t rw1 = rsrc(a.w1p, 0);
       bf16x8 cur[4], nxt[4];
@@ -345,8 +375,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
         for (int cf = 0; cf < 4; ++cf) {
           const int pos = ks * 4 + cf;
 #pragma unroll
-          for (int rf = 0; rf < 4; ++rf)
-            accp[cf][rf] = MM::mma(ring[pos & 15], cur[rf], ks == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : accp[cf][rf]);
+          for (int rf = 0; rf < 4; ++rf) acc2[cf][rf] = MM::mma(ring[pos & 15], cur[rf], acc2[cf][rf]);
           ring[pos & 15] = pos + 16 < 64 ? ld(rs_pre, pos + 16) : ld(rw1, pos + 16 - 64);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -354,16 +383,27 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
         for (int rf = 0; rf < 4; ++rf) cur[rf] = nxt[rf];
       }
     }
+    if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc2[3][3]));
+    stamp();
     // x' = x + (acc + b_pre): the residual stream for the rest of the launch
 #pragma unroll
     for (int cf = 0; cf < 4; ++cf) {
-      const float4 bp = *(const float4*)(a.pre_b + col0 + 16 * cf);
+      const f32x4 bp = parv(0, cf);
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf) acc2[cf][rf] += bp;
+    }
+    if constexpr (MAIN == EM_ROWS_GLU) {
+      // the residual stream leaves here: nothing else of this launch touches it, and the GLU walk needs the registers.
+      // (Stores count on vmcnt like the weight requests; issued here they drain under the LayerNorm, whose parameters come
+      // from LDS - behind the LayerNorm they delayed the first four chunks of the walk: stamps r04w.)
 #pragma unroll
       for (int rf = 0; rf < 4; ++rf) {
-        acc2[cf][rf][0] += accp[cf][rf][0] + bp.x;
-        acc2[cf][rf][1] += accp[cf][rf][1] + bp.y;
-        acc2[cf][rf][2] += accp[cf][rf][2] + bp.z;
-        acc2[cf][rf][3] += accp[cf][rf][3] + bp.w;
+        const int m = m0 + rf * 16 + lr;
+        if (m < M) {
+          float* o = a.x + (size_t)m * D + col0;
+#pragma unroll
+          for (int cf = 0; cf < 4; ++cf) *(f32x4*)(o + 16 * cf) = acc2[cf][rf];
+        }
       }
     }
     // LayerNorm(x') -> bf16 -> the activation tile (its barrier also says that every wave is done reading the tile)
@@ -371,21 +411,58 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     ln_stats(acc2, 0, mean, rstd);
 #pragma unroll
     for (int cf = 0; cf < 4; ++cf) {
-      const float4 g4 = *(const float4*)(a.pre_g + col0 + 16 * cf);
-      const float4 b4 = *(const float4*)(a.pre_be + col0 + 16 * cf);
+      const f32x4 g4 = parv(1, cf), b4 = parv(2, cf);
       const int q = 8 * wave + 2 * cf + (lg >> 1);  // 16-byte chunk of the row that holds columns col0 + 16 cf ..
       const int pos = (q & ~15) | ((q ^ lr) & 15);
 #pragma unroll
       for (int rf = 0; rf < 4; ++rf) {
-        const bf16x4 pk = {(bf16)((acc2[cf][rf][0] - mean[rf]) * rstd[rf] * g4.x + b4.x),
-                           (bf16)((acc2[cf][rf][1] - mean[rf]) * rstd[rf] * g4.y + b4.y),
-                           (bf16)((acc2[cf][rf][2] - mean[rf]) * rstd[rf] * g4.z + b4.z),
-                           (bf16)((acc2[cf][rf][3] - mean[rf]) * rstd[rf] * g4.w + b4.w)};
-        *(bf16x4*)(smem + ACT_OFF + (rf * 16 + lr) * 1024 + pos * 16 + (lg & 1) * 8) = pk;
+        const f32x4 y = (acc2[cf][rf] - mean[rf]) * (g4 * rstd[rf]) + b4;
+        *(bf16x4*)(smem + ACT_OFF + (rf * 16 + lr) * 1024 + pos * 16 + (lg & 1) * 8) = __builtin_convertvector(y, bf16x4);
       }
     }
     barrier();
     read_act(0, af0);
+    stamp();
+  }
+
+  if constexpr (MAIN == EM_ROWS_GLU) {
+    static_assert(PRE, "the GLU launch starts with the projection");
+    // chunk 2 j: value rows of output columns 128 j .., chunk 2 j + 1: their gate rows (host: pack_rows_glu); this lane:
+    // columns 128 j + 16 wave + 4 lg + r of rows 16 rf + lr.  Nothing is stored INSIDE the walk: stores count on vmcnt like
+    // the weight requests, and with every pair's outputs stored behind its gate chunk every chunk took 4.3 K cycles instead
+    // of 2.6 K (stamps r04u).  The four pairs' packed outputs wait in 32 registers.
+    bf16x4 outp[4][4];
+    f32x4 val[4];
+    float4 bv = bia;
+    constexpr int NPAIR = 4;  // 2 * 512 rows = 8 chunks
+#pragma unroll
+    for (int c = 0; c < 2 * NPAIR; ++c) {
+      const float4 bnext = *(const float4*)(b1p + (c + 1 < 2 * NPAIR ? c + 1 : c) * CH);
+      gemm1(rsrc(a.w1p, c + 1 < 2 * NPAIR ? c + 1 : c), std::false_type{}, 0);
+      if ((c & 1) == 0) {
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf) val[rf] = acc1[rf] + (f32x4){bv.x, bv.y, bv.z, bv.w};
+      } else {
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf)
+          outp[c >> 1][rf] = (bf16x4){(bf16)(val[rf][0] * sigmoidf_(acc1[rf][0] + bv.x)), (bf16)(val[rf][1] * sigmoidf_(acc1[rf][1] + bv.y)),
+                                      (bf16)(val[rf][2] * sigmoidf_(acc1[rf][2] + bv.z)), (bf16)(val[rf][3] * sigmoidf_(acc1[rf][3] + bv.w))};
+      }
+      bv = bnext;
+      if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc1[3]));
+      stamp();
+    }
+    bf16* const out = (bf16*)a.xn_out;
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      const int m = m0 + rf * 16 + lr;
+      if (m < M) {
+#pragma unroll
+        for (int j = 0; j < NPAIR; ++j) *(bf16x4*)(out + (size_t)m * D + j * CH + 16 * wave + 4 * lg) = outp[j][rf];
+      }
+    }
+    stamp();
+    return;
   }
 
   gemm1(nch > 1 ? rsrc(a.w1p, 1) : rsrc(a.w2p, 0), std::false_type{}, 0);
@@ -395,14 +472,9 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     for (int r = 0; r < 4; ++r) swish_piece(rf, r, 0);
 #pragma unroll
   for (int cf = 0; cf < 4; ++cf) {
-    const float4 b2 = *(const float4*)(a.b2 + col0 + 16 * cf);
+    const f32x4 b2 = parv(3, cf);
 #pragma unroll
-    for (int rf = 0; rf < 4; ++rf) {
-      acc2[cf][rf][0] = acc2[cf][rf][0] * inv_scale + b2.x;
-      acc2[cf][rf][1] = acc2[cf][rf][1] * inv_scale + b2.y;
-      acc2[cf][rf][2] = acc2[cf][rf][2] * inv_scale + b2.z;
-      acc2[cf][rf][3] = acc2[cf][rf][3] * inv_scale + b2.w;
-    }
+    for (int rf = 0; rf < 4; ++rf) acc2[cf][rf] = acc2[cf][rf] * inv_scale + b2;
   }
 #pragma unroll 1
   for (int c = 1; c < nch; ++c) {
@@ -428,20 +500,14 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   for (int cf = 0; cf < 4; ++cf)
 #pragma unroll
     for (int rf = 0; rf < 4; ++rf) xin[cf][rf] = acc2[cf][rf] * scale;
-  auto layer_norm = [&](const float* __restrict__ g, const float* __restrict__ be, int set) {  // in place
+  auto layer_norm = [&](int gi, int set) {  // in place; weight / bias = vectors gi, gi + 1 of PAR_OFF
     float mean[4], rstd[4];
     ln_stats(xin, set, mean, rstd);
 #pragma unroll
     for (int cf = 0; cf < 4; ++cf) {
-      const float4 g4 = *(const float4*)(g + col0 + 16 * cf);
-      const float4 b4 = *(const float4*)(be + col0 + 16 * cf);
+      const f32x4 g4 = parv(gi, cf), b4 = parv(gi + 1, cf);
 #pragma unroll
-      for (int rf = 0; rf < 4; ++rf) {
-        xin[cf][rf][0] = (xin[cf][rf][0] - mean[rf]) * rstd[rf] * g4.x + b4.x;
-        xin[cf][rf][1] = (xin[cf][rf][1] - mean[rf]) * rstd[rf] * g4.y + b4.y;
-        xin[cf][rf][2] = (xin[cf][rf][2] - mean[rf]) * rstd[rf] * g4.z + b4.z;
-        xin[cf][rf][3] = (xin[cf][rf][3] - mean[rf]) * rstd[rf] * g4.w + b4.w;
-      }
+      for (int rf = 0; rf < 4; ++rf) xin[cf][rf] = (xin[cf][rf] - mean[rf]) * (g4 * rstd[rf]) + b4;
     }
   };
   auto store_f32 = [&](float* __restrict__ dst) {
@@ -457,11 +523,11 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   };
   if constexpr (LNMODE == 1) {
     store_f32(a.x);
-    layer_norm(a.g1, a.be1, 1);
+    layer_norm(4, 1);
   } else {
-    layer_norm(a.g1, a.be1, 1);
+    layer_norm(4, 1);
     store_f32(a.x);
-    layer_norm(a.g2, a.be2, 0);
+    layer_norm(6, 0);
     if (a.out_f32) store_f32(a.out_f32);
   }
   {
@@ -473,8 +539,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
         bf16* o = out + (size_t)m * D + col0;
 #pragma unroll
         for (int cf = 0; cf < 4; ++cf) {
-          const bf16x4 pk = {(bf16)xin[cf][rf][0], (bf16)xin[cf][rf][1], (bf16)xin[cf][rf][2], (bf16)xin[cf][rf][3]};
-          *(bf16x4*)(o + 16 * cf) = pk;
+          *(bf16x4*)(o + 16 * cf) = __builtin_convertvector(xin[cf][rf], bf16x4);
         }
       }
     }
@@ -485,13 +550,18 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
 }  // namespace
 
 extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
-  if (!a || !a->x || !a->w1p || !a->w2p || !a->b1 || !a->b2 || !a->g1 || !a->be1 || !a->xn_out) return EM_ERR_BAD_ARG;
+  if (!a || !a->x || !a->w1p || !a->b1 || !a->xn_out) return EM_ERR_BAD_ARG;
+  if (a->main == EM_ROWS_FFN && (!a->w2p || !a->b2 || !a->g1 || !a->be1)) return EM_ERR_BAD_ARG;
   const bool pre = a->pre_in != nullptr;
   if (pre ? (!a->pre_w || !a->pre_b || !a->pre_g || !a->pre_be) : !a->xn_in) return EM_ERR_BAD_ARG;
   if (a->M <= 0 || a->ff <= 0) return EM_ERR_BAD_ARG;
   if (a->d != D || a->ff % CH != 0 || a->ff < 2 * CH) return EM_ERR_UNSUPPORTED;
-  if (a->ln_mode != 1 && a->ln_mode != 2) return EM_ERR_BAD_ARG;
-  if (a->ln_mode == 2 && (!a->g2 || !a->be2)) return EM_ERR_BAD_ARG;
+  const bool glu = a->main == EM_ROWS_GLU;
+  if (a->main != EM_ROWS_FFN && !glu) return EM_ERR_BAD_ARG;
+  if (glu && !pre) return EM_ERR_BAD_ARG;
+  if (glu && a->ff != 2 * D) return EM_ERR_UNSUPPORTED;
+  if (!glu && a->ln_mode != 1 && a->ln_mode != 2) return EM_ERR_BAD_ARG;
+  if (!glu && a->ln_mode == 2 && (!a->g2 || !a->be2)) return EM_ERR_BAD_ARG;
   const dim3 grid(em_cdiv(a->M, RB));
   static long long* stamps = nullptr;
   static const bool want_stamps = (EM_FFN_DBG & 8) && getenv("EM_FFN_STAMPS") != nullptr;
@@ -499,10 +569,13 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   if (want_stamps && hipMemsetAsync(stamps, 0, 64 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   long long* const st = want_stamps ? stamps : nullptr;
   typedef void (*kern_t)(const EmFfnRowsArgs, long long*);
-  static EmLdsCap caps[4] = {};
-  const int which = (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
-  const kern_t kern = which == 0 ? ffn_rows_kernel<1, false> : which == 1 ? ffn_rows_kernel<1, true>
-                    : which == 2 ? ffn_rows_kernel<2, false> : ffn_rows_kernel<2, true>;
+  static EmLdsCap caps[5] = {};
+  const int which = glu ? 4 : (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
+  const kern_t kern = which == 0   ? ffn_rows_kernel<1, false, EM_ROWS_FFN>
+                      : which == 1 ? ffn_rows_kernel<1, true, EM_ROWS_FFN>
+                      : which == 2 ? ffn_rows_kernel<2, false, EM_ROWS_FFN>
+                      : which == 3 ? ffn_rows_kernel<2, true, EM_ROWS_FFN>
+                                   : ffn_rows_kernel<1, true, EM_ROWS_GLU>;
   if (em_raise_lds_cap((const void*)kern, SMEM_BYTES, &caps[which]) != EM_OK) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
   hipLaunchKernelGGL(kern, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);
@@ -515,7 +588,7 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
       fflush(stdout);
     }
   }
-  if (rec) em_prof_end(stream, 4.0 * a->M * (double)D * a->ff + (pre ? 2.0 * a->M * (double)D * D : 0.0), EM_PROF_GEMM);
+  if (rec) em_prof_end(stream, (glu ? 2.0 : 4.0) * a->M * (double)D * a->ff + (pre ? 2.0 * a->M * (double)D * D : 0.0), EM_PROF_GEMM);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

@@ -73,12 +73,15 @@ class EmBlockArgs(C.Structure):
                [("x_out", C.c_void_p), ("params_c", C.c_void_p), ("ffm_b1g", C.c_void_p), ("ff_b1g", C.c_void_p)]
 
 
+EM_ROWS_FFN, EM_ROWS_GLU = 0, 1
+
+
 class EmFfnRowsArgs(C.Structure):
     """include/espnet_amd.h EmFfnRowsArgs (csrc/ffn_rows.hip)."""
     _fields_ = [(n, C.c_void_p) for n in ("xn_in", "x", "w1p", "w2p", "b1", "b2", "g1", "be1", "g2", "be2", "xn_out",
                                           "out_f32")] + \
                [(n, C.c_int32) for n in ("M", "d", "ff", "ln_mode")] + [("scale", C.c_float), ("eps", C.c_float)] + \
-               [(n, C.c_void_p) for n in ("pre_in", "pre_w", "pre_b", "pre_g", "pre_be")]
+               [(n, C.c_void_p) for n in ("pre_in", "pre_w", "pre_b", "pre_g", "pre_be")] + [("main", C.c_int32)]
 
 
 class EmConformerWeights(C.Structure):

@@ -262,8 +262,9 @@ typedef struct EmConformerLayer {
   const void *ffm_w2p, *ff_w2p; /* w_2 of the two FFNs, packed per pair of hidden chunks (EmBlockArgs) */
   const void *woutp, *pw2p, *ff_w1p, *ffm_w1p, *wqkvp; /* K units of wout, pw2, ff_w1, ffm_w1, wqkv */
   /* d = 512 (bf16): ffm_w1p / ffm_w2p / ff_w1p / ff_w2p hold the operand streams of em_ffn_rows_fused instead (EmFfnRowsArgs
-   * w1p / w2p), pw2p the projection in front of the second one (EmFfnRowsArgs.pre_w), and em_conformer_encode runs each
-   * feed-forward module as one row-block launch; the other fields stay NULL */
+   * w1p / w2p), pw2p the projection in front of the second one (EmFfnRowsArgs.pre_w), woutp / pw1f / fp_c the operands of the
+   * EM_ROWS_GLU launch (linear_out as pre_w, pointwise_conv1 in value / gate chunk pairs, its bias in that order), and
+   * em_conformer_encode runs the block in 10 launches (when its rows fill the chip); the other fields stay NULL */
   const float* fp_c;     /* parameter groups of block<C> for this layer (EM_BLOCK_PARAM_GROUP floats each) */
   const float* fp_da;    /* groups of block<D|A> (D part of this layer, A part of the next) or block<D|FINAL> */
   const float* fp_a;     /* groups of block<A> (layer 0 only) */
@@ -439,7 +440,16 @@ typedef struct EmFfnRowsArgs {
   const void* pre_in;
   const void* pre_w;
   const float *pre_b, *pre_g, *pre_be;
+  /* what follows the projection: EM_ROWS_FFN (0) the feed-forward module above;  EM_ROWS_GLU (needs pre_in): pointwise_conv1 +
+   * GLU of the conv module (conformer/convolution.py:62-66) on LN(x; pre_g, pre_be) - with linear_out as the projection the
+   * launch is attention output -> x += linear_out . ctx + b -> norm_conv -> glu (encoder_layer.py:147-151).  Then
+   *   w1p: pointwise_conv1 [2 * 512][512] in the w1p layout with chunk 2 j = the value rows of output columns 128 j ..
+   *        128 j + 127 and chunk 2 j + 1 their gate rows (host: pack_rows_glu), b1 its bias in that order, ff = 1024;
+   *   xn_out [M][512] bf16 = value * sigmoid(gate);  x is updated;  w2p, b2, g1 .. be2, out_f32, ln_mode, scale unused.   */
+  int32_t main;
 } EmFfnRowsArgs;
+#define EM_ROWS_FFN 0
+#define EM_ROWS_GLU 1
 int em_ffn_rows_fused(const EmFfnRowsArgs* args, void* stream);
 
 /* ---- A7, LDS-resident form (bf16, d_k = 64): RelPositionMultiHeadedAttention.forward core

@@ -552,3 +552,37 @@ def test_ffn_rows_fused(lib, M, ff, ln_mode, pre):
     with pytest.raises(NotImplementedError):
         a.d = 256
         L.check(lib.em_ffn_rows_fused(a, sptr()), "em_ffn_rows_fused d=256")
+
+
+@pytest.mark.parametrize("M", [1000, 77])
+def test_rows_glu_fused(lib, M):
+    """Round 4: attention output -> linear_out + residual -> norm_conv -> pointwise_conv1 + GLU as ONE row-block launch
+    (csrc/ffn_rows.hip, EM_ROWS_GLU; attention.py:149-151, encoder_layer.py:147-151, convolution.py:62-66) against torch f32 on
+    the same bf16-rounded operands (LN(x) rounded to bf16 as the kernel rounds it).  Ragged M, rows past M untouched."""
+    from espnet_amd.asr.encoder.conformer_encoder import glu_chunk_order, pack_rows_glu, pack_rows_proj
+
+    d = 512
+    x = rnd(M, d, seed=71) * 2 + 0.3
+    ctx = q(rnd(M, d, seed=72), torch.bfloat16)
+    wout = q(rnd(d, d, seed=73, scale=d ** -0.5), torch.bfloat16)
+    bout = 0.1 * rnd(d, seed=74)
+    g, be = 1 + 0.1 * rnd(d, seed=75), 0.1 * rnd(d, seed=76)
+    pw1 = q(rnd(2 * d, d, seed=77, scale=d ** -0.5), torch.bfloat16)
+    pb = 0.1 * rnd(2 * d, seed=78)
+    x1 = x + (ctx @ wout.t() + bout)
+    xn = q(F.layer_norm(x1, (d,), g, be, 1e-12), torch.bfloat16)
+    pw = xn @ pw1.t() + pb
+    ref = pw[:, :d] * torch.sigmoid(pw[:, d:])
+    pad = 70
+    xd = dev(torch.cat([x, torch.full((pad, d), 7.0)]))
+    cd = dev(torch.cat([ctx, torch.full((pad, d), 7.0)]).to(torch.bfloat16))
+    out = torch.full((M + pad, d), 7.0, dtype=torch.bfloat16, device="cuda")
+    a = L.EmFfnRowsArgs(x=xd.data_ptr(), w1p=dev(pack_rows_glu(pw1).to(torch.bfloat16)).data_ptr(),
+                        b1=dev(pb[glu_chunk_order(d)]).data_ptr(), xn_out=out.data_ptr(), M=M, d=d, ff=2 * d, ln_mode=1,
+                        scale=1.0, eps=1e-12, pre_in=cd.data_ptr(), pre_w=dev(pack_rows_proj(wout).to(torch.bfloat16)).data_ptr(),
+                        pre_b=dev(bout).data_ptr(), pre_g=dev(g).data_ptr(), pre_be=dev(be).data_ptr(), main=L.EM_ROWS_GLU)
+    L.check(lib.em_ffn_rows_fused(a, sptr()), "em_ffn_rows_fused(GLU)")
+    torch.cuda.synchronize()
+    assert_close(xd[:M], x1, 2e-3, "rows_glu x")
+    assert_close(out[:M], ref, 1e-2, "rows_glu out")
+    assert bool((xd[M:] == 7.0).all()) and bool((out[M:].float() == 7.0).all())
