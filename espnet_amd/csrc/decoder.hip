@@ -289,13 +289,26 @@ __global__ __launch_bounds__(1024) void dec_self_attn_kernel(const T* __restrict
 // per label step.  Now a wave requests the key tiles of a batch (UT tiles x KS fragments) AND its first UV fragments
 // of V^T - which do not depend on the softmax - in one burst before its first MFMA, the softmax reductions run on DPP,
 // and only the rows that exist (W of the 16) are normalised, dealt round-robin to the waves.
-template <typename T, int DK>
+//
+// Round 4, NVQ > 0: the pre-norm LayerNorm and the query projection (decoder_layer.py:119-121 norm2 -> src_attn's linear_q,
+// attention.py:94) run in THIS kernel's prologue - the label step's LayerNorm + q launch (ln_gemm, 4.7 us at the
+// single-round-trip floor, six per step) is gone.  A workgroup needs only ITS head's 64 query columns of its 16 rows:
+// the workgroup normalises the 16 rows (f32 residual stream x, K = 64 NVQ) into LDS exactly as ln_gemm_kernel does
+// (16 lanes per row, DPP statistics), wave w contracts them with rows h DK + 16 w .. + 15 of W_q (fragments straight
+// from global memory, requested first), the result (+ bias, rounded to the act dtype like the q tensor it replaces) goes
+// through a [16][DK] LDS tile into the A-operand fragments.  Same summation order as ln_gemm: the same q bit for bit.
+struct SrcLnQ {
+  const float *x, *g, *be, *bq;
+  const void* wq;
+  float eps;
+};
+template <typename T, int DK, int NVQ>
 __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__ qs,
                                                            const T* __restrict__ kmem, int ldk,
                                                            const T* __restrict__ vT,
                                                            const int* __restrict__ klens, int W,
                                                            int d, int Tn, int Tpad,
-                                                           T* __restrict__ ctx) {
+                                                           T* __restrict__ ctx, SrcLnQ lq) {
   using M = Mma<T>;
   constexpr int KS = DK / M::K;
   constexpr int UT = sizeof(T) == 2 ? 4 : 2;  // key tiles per wave and batch (UT * KS operand loads in flight)
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
   const bool pv_wave = wave < DK / 16;
 
   typename M::frag qf[KS];
-  {
+  if constexpr (NVQ == 0) {
     const int rr = lr < nrows ? lr : nrows - 1;
     const T* qrow = qs + (size_t)(row0 + rr) * d + h * DK;
 #pragma unroll
@@ -331,15 +344,80 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
   typename M::frag vf[UV];
 #pragma unroll
   for (int u = 0; u < UV; ++u) vf[u] = M::load(vb + (u < nkk ? u : nkk - 1) * M::K + lg * M::EPL);
-  for (int nt0 = 0; nt0 < ntile; nt0 += 4 * UT) {
-    typename M::frag kf[UT][KS];
+  typename M::frag kf[UT][KS];
+  auto load_k = [&](int nt0) {  // unconditional, from clamped rows (tiles past the end are computed and dropped)
 #pragma unroll
-    for (int u = 0; u < UT; ++u) {  // unconditional, from clamped rows (tiles past the end are computed and dropped)
+    for (int u = 0; u < UT; ++u) {
       const int key = (nt0 + wave + 4 * u) * 16 + lr;
       const int kc_ = key < Tn ? key : Tn - 1;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) kf[u][ks] = M::load(kb + (size_t)kc_ * ldk + ks * M::K + lg * M::EPL);
     }
+  };
+  if constexpr (NVQ > 0) load_k(0);  // the first key tiles do not depend on the queries: under the LayerNorm + projection
+  if constexpr (NVQ > 0) {
+    static_assert(DK == 64 && sizeof(T) == 2, "fused query projection: bf16, d_k = 64");
+    constexpr int K = 64 * NVQ, LDA = K + 8, LDQ = DK + 8, NST = K / M::K;
+    T* const sA = (T*)(smem_raw + (size_t)16 * LDS_S * 4 + 64 + (size_t)16 * LDS_P * sizeof(T));  // behind S, sums, P
+    T* const sQ = sA + 16 * LDA;
+    // W_q rows of this wave's 16 query columns: requested before anything of the LayerNorm
+    const T* wrow = (const T*)lq.wq + (size_t)(h * DK + wave * 16 + lr) * K + lg * M::EPL;
+    typename M::frag fw[NST];
+#pragma unroll
+    for (int u = 0; u < NST; ++u) fw[u] = M::load(wrow + (size_t)u * M::K);
+    const float bv = lq.bq[h * DK + wave * 16 + lr];
+    {
+      const int grp = lane >> 4, li = lane & 15;
+      const int rq = wave * 4 + grp;  // the row of the 16 this lane group normalises (rows past nrows: copies of the last)
+      const float4* xr = (const float4*)(lq.x + (size_t)(row0 + (rq < nrows ? rq : nrows - 1)) * K);
+      float4 v[NVQ], g4[NVQ], b4[NVQ];
+#pragma unroll
+      for (int j = 0; j < NVQ; ++j) v[j] = xr[j * 16 + li];
+#pragma unroll
+      for (int j = 0; j < NVQ; ++j) {
+        g4[j] = *(const float4*)(lq.g + (j * 16 + li) * 4);
+        b4[j] = *(const float4*)(lq.be + (j * 16 + li) * 4);
+      }
+      asm volatile("" ::: "memory");  // every request of the prologue is out before the first reduction (as ln_gemm.hip)
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NVQ; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+      s += dpp_f32<DPP_XOR1>(s); s += dpp_f32<DPP_XOR2>(s); s += dpp_f32<DPP_HALF_MIRROR>(s); s += dpp_f32<DPP_MIRROR>(s);
+      const float mean = s / (float)K;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NVQ; ++j) {
+        const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+      q += dpp_f32<DPP_XOR1>(q); q += dpp_f32<DPP_XOR2>(q); q += dpp_f32<DPP_HALF_MIRROR>(q); q += dpp_f32<DPP_MIRROR>(q);
+      const float rstd = 1.0f / sqrtf(q / (float)K + lq.eps);
+      T* dst = sA + (size_t)rq * LDA;
+#pragma unroll
+      for (int j = 0; j < NVQ; ++j) {
+        const int c0 = (j * 16 + li) * 4;
+        __attribute__((aligned(8))) T o[4];
+        o[0] = from_f32<T>((v[j].x - mean) * rstd * g4[j].x + b4[j].x);
+        o[1] = from_f32<T>((v[j].y - mean) * rstd * g4[j].y + b4[j].y);
+        o[2] = from_f32<T>((v[j].z - mean) * rstd * g4[j].z + b4[j].z);
+        o[3] = from_f32<T>((v[j].w - mean) * rstd * g4[j].w + b4[j].w);
+        *(uint2*)(dst + c0) = *(const uint2*)o;
+      }
+    }
+    __syncthreads();
+    f32x4 qa = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const T* a0p = sA + (size_t)lr * LDA + lg * M::EPL;
+#pragma unroll
+    for (int u = 0; u < NST; ++u) qa = M::mma(M::load(a0p + (size_t)u * M::K), fw[u], qa);
+    // C/D layout: col = lr (query column 16 wave + lr), row = lg * 4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sQ[(lg * 4 + r) * LDQ + wave * 16 + lr] = from_f32<T>(qa[r] + bv);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = M::load(sQ + lr * LDQ + ks * M::K + lg * M::EPL);
+  }
+  for (int nt0 = 0; nt0 < ntile; nt0 += 4 * UT) {
+    if (nt0 > 0 || NVQ == 0) load_k(nt0);  // (NVQ > 0: the first batch was requested in front of the query prologue)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
@@ -504,9 +582,31 @@ int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const 
 
 template <typename T>
 int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, const int* klens,
-                    int B, int W, int d, int heads, int Tn, int Tpad, void* ctx, hipStream_t s) {
+                    int B, int W, int d, int heads, int Tn, int Tpad, void* ctx, hipStream_t s, const SrcLnQ* lq = nullptr) {
   const int dk = d / heads;
-  const size_t lds = (size_t)16 * (Tpad + 4) * 4 + 64 + (size_t)16 * (Tpad + 16 / sizeof(T)) * sizeof(T);
+  size_t lds = (size_t)16 * (Tpad + 4) * 4 + 64 + (size_t)16 * (Tpad + 16 / sizeof(T)) * sizeof(T);
+  if (lq) {  // fused LayerNorm + query projection (bf16, d_k = 64, d = 256 or 512)
+    if constexpr (sizeof(T) == 2) {
+      if (dk != 64 || (d != 256 && d != 512)) return EM_ERR_UNSUPPORTED;
+      lds += (size_t)16 * (d + 8) * 2 + 16 * (64 + 8) * 2;
+      if (lds > 160 * 1024) return EM_ERR_UNSUPPORTED;
+      dim3 grid(heads, B, em_cdiv(W, 16));
+      static EmLdsCap capq4 = {}, capq8 = {};
+      if (d == 256) {
+        if (em_raise_lds_cap((const void*)dec_src_attn_kernel<T, 64, 4>, lds, &capq4) != EM_OK) return EM_ERR_LAUNCH;
+        hipLaunchKernelGGL((dec_src_attn_kernel<T, 64, 4>), grid, dim3(256), lds, s, (const T*)nullptr, (const T*)kmem, ldk,
+                           (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx, *lq);
+      } else {
+        if (em_raise_lds_cap((const void*)dec_src_attn_kernel<T, 64, 8>, lds, &capq8) != EM_OK) return EM_ERR_LAUNCH;
+        hipLaunchKernelGGL((dec_src_attn_kernel<T, 64, 8>), grid, dim3(256), lds, s, (const T*)nullptr, (const T*)kmem, ldk,
+                           (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx, *lq);
+      }
+      EM_CHECK_LAUNCH();
+      return EM_OK;
+    } else {
+      return EM_ERR_UNSUPPORTED;
+    }
+  }
   // the 16 score rows of a workgroup live in LDS: memories beyond ~1 690 frames (bf16; ~1 270 in f32) do
   // not fit the 160 KB of a CU -- say so instead of failing at launch
   if (lds > 160 * 1024) return EM_ERR_UNSUPPORTED;
@@ -515,13 +615,13 @@ int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, c
   //  which also keeps the launch legal inside a stream capture)
   static EmLdsCap cap64 = {}, cap32 = {};
   if (dk == 64) {
-    if (em_raise_lds_cap((const void*)dec_src_attn_kernel<T, 64>, lds, &cap64) != EM_OK) return EM_ERR_LAUNCH;
-    hipLaunchKernelGGL((dec_src_attn_kernel<T, 64>), grid, dim3(256), lds, s, (const T*)qs,
-                       (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx);
+    if (em_raise_lds_cap((const void*)dec_src_attn_kernel<T, 64, 0>, lds, &cap64) != EM_OK) return EM_ERR_LAUNCH;
+    hipLaunchKernelGGL((dec_src_attn_kernel<T, 64, 0>), grid, dim3(256), lds, s, (const T*)qs,
+                       (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx, SrcLnQ{});
   } else if (dk == 32) {
-    if (em_raise_lds_cap((const void*)dec_src_attn_kernel<T, 32>, lds, &cap32) != EM_OK) return EM_ERR_LAUNCH;
-    hipLaunchKernelGGL((dec_src_attn_kernel<T, 32>), grid, dim3(256), lds, s, (const T*)qs,
-                       (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx);
+    if (em_raise_lds_cap((const void*)dec_src_attn_kernel<T, 32, 0>, lds, &cap32) != EM_OK) return EM_ERR_LAUNCH;
+    hipLaunchKernelGGL((dec_src_attn_kernel<T, 32, 0>), grid, dim3(256), lds, s, (const T*)qs,
+                       (const T*)kmem, ldk, (const T*)vT, klens, W, d, Tn, Tpad, (T*)ctx, SrcLnQ{});
   } else {
     return EM_ERR_UNSUPPORTED;
   }
@@ -564,6 +664,17 @@ extern "C" int em_dec_src_attention(int dtype, const void* qs, const void* kmem,
   if (dtype == EM_BF16)
     return src_attn_launch<bf16>(qs, kmem, ldk, vT, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
+}
+
+extern "C" int em_dec_src_attention_lnq(int dtype, const float* x, const float* g, const float* be, float eps,
+                                        const void* wq, const float* bq, const void* kmem, int32_t ldk, const void* vT,
+                                        const int32_t* klens, int32_t B, int32_t W, int32_t d, int32_t heads, int32_t T,
+                                        int32_t Tpad, void* ctx, void* stream) {
+  if (!x || !g || !be || !wq || !bq || !kmem || !vT || !klens || !ctx) return EM_ERR_BAD_ARG;
+  if (B <= 0 || W <= 0 || T <= 0 || Tpad < T || Tpad % 32 != 0 || heads <= 0) return EM_ERR_BAD_ARG;
+  if (dtype != EM_BF16) return EM_ERR_UNSUPPORTED;  // (the f32 parity mode keeps ln_gemm + em_dec_src_attention)
+  const SrcLnQ lq = {x, g, be, bq, wq, eps};
+  return src_attn_launch<bf16>(nullptr, kmem, ldk, vT, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream, &lq);
 }
 
 extern "C" int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t T, int32_t d,

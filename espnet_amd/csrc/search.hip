@@ -1357,9 +1357,17 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
       EM_TRY(em_dec_self_attention(dtype, a.qkv, kc, vc, anc, anc, n, d, h, a.Lmax, i, nullptr, (a.W + 1) / 2,
                                    nullptr, a.ctx, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.self_wout, a.x, q.self_bout, n, d, d, d, d, 1.f, stream));
-    EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm2_g, q.norm2_b, q.src_wq, q.src_bq, a.qs, a.xn, n, d, d,
-                   stream));
-    EM_TRY(em_dec_src_attention(dtype, a.qs, kv, 2 * d, vT, a.xlens, a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
+    // round 4: norm2 + the source attention's query projection ride in the attention kernel's prologue (bf16, d_k = 64,
+    // d = 256 | 512: one launch less per layer; ESPNET_AMD_NO_SRC_LNQ=1: developer A/B switch)
+    static const bool no_lnq = getenv("ESPNET_AMD_NO_SRC_LNQ") != nullptr;
+    if (dtype == EM_BF16 && !no_lnq && d == 64 * h && (d == 256 || d == 512)) {
+      EM_TRY(em_dec_src_attention_lnq(dtype, a.x, q.norm2_g, q.norm2_b, LN_EPS, q.src_wq, q.src_bq, kv, 2 * d, vT, a.xlens,
+                                      a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
+    } else {
+      EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm2_g, q.norm2_b, q.src_wq, q.src_bq, a.qs, a.xn, n, d, d,
+                     stream));
+      EM_TRY(em_dec_src_attention(dtype, a.qs, kv, 2 * d, vT, a.xlens, a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
+    }
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.src_wout, a.x, q.src_bout, n, d, d, d, d, 1.f, stream));
     EM_TRY(ln_proj(dtype, EM_EPI_RELU, a.x, q.norm3_g, q.norm3_b, q.w1, q.b1, a.hbuf, a.xn, n, ff, d, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.hbuf, q.w2, a.x, q.b2, n, d, ff, ff, d, 1.f, stream));

@@ -262,6 +262,8 @@ _SIGNATURES = {
     "em_lm_input_norm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "em_dec_src_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                                        _i32, _i32, _vp, _vp]),
+    "em_dec_src_attention_lnq": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32,
+                                          _i32, _i32, _i32, _vp, _vp]),
     "em_dec_transpose_v": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "em_search_init": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),
                                  C.POINTER(EmSearchBuffers), _vp, _i32, _vp, _vp, _vp]),

@@ -577,6 +577,14 @@ int em_lm_input_norm_f32(float* x, const float* g, const float* b, const float* 
 int em_dec_src_attention(int dtype, const void* qs, const void* kmem, int32_t ldk, const void* vT,
                          const int32_t* klens, int32_t B, int32_t W, int32_t d, int32_t heads,
                          int32_t T, int32_t Tpad, void* ctx, void* stream);
+/*   ... with the pre-norm LayerNorm and the query projection in the kernel's prologue (bf16, d_k = 64, d = 256 | 512):
+ *   qs = (LN(x; g, be, eps) . wq^T + bq) rounded to bf16, x [B*W][d] f32, wq [d][d] act - DecoderLayer.forward's
+ *   norm2 + src_attn.linear_q (decoder_layer.py:119-121, attention.py:94) without a launch of their own; the same q bit
+ *   for bit as em_ln_gemm followed by em_dec_src_attention.  EM_ERR_UNSUPPORTED for other shapes / EM_F32.            */
+int em_dec_src_attention_lnq(int dtype, const float* x, const float* g, const float* be, float eps, const void* wq,
+                             const float* bq, const void* kmem, int32_t ldk, const void* vT, const int32_t* klens,
+                             int32_t B, int32_t W, int32_t d, int32_t heads, int32_t T, int32_t Tpad, void* ctx,
+                             void* stream);
 /*   vT[b][c][t] = kv[(b*T + t)*2d + d + c]                                                       */
 int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t T, int32_t d, int32_t Tpad,
                        void* vT, void* stream);

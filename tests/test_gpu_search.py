@@ -479,6 +479,42 @@ def test_dec_src_attention(lib, prec, heads, d, W):
         assert (ctx[b * W : (b + 1) * W].float().cpu() - ref).abs().max().item() < tol, b
 
 
+@pytest.mark.parametrize("heads,d,W", [(8, 512, 10), (4, 256, 20), (8, 512, 3)])
+def test_dec_src_attention_lnq_equals_two_launches(lib, heads, d, W):
+    """Round 4: norm2 + src_attn.linear_q (decoder_layer.py:119-121, attention.py:94) in the prologue of the source-attention
+    kernel (em_dec_src_attention_lnq, bf16): the context must equal em_ln_gemm followed by em_dec_src_attention BIT FOR BIT
+    (same LayerNorm arithmetic, same summation order, q rounded to bf16 at the same point), W not a multiple of 16."""
+    from espnet_amd import lib as L
+
+    torch.manual_seed(7)
+    B, T = 3, 75
+    Tpad = (T + 31) // 32 * 32
+    n = B * W
+    dt = torch.bfloat16
+    x = (torch.randn(n, d) * 2 + 0.3).cuda()
+    g, be = (1 + 0.1 * torch.randn(d)).cuda(), (0.1 * torch.randn(d)).cuda()
+    wq = (torch.randn(d, d) * d ** -0.5).to(dt).cuda()
+    bq = (0.1 * torch.randn(d)).cuda()
+    kv = torch.randn(B * T, 2 * d).to(dt).cuda()
+    vT = torch.zeros(B, d, Tpad, dtype=dt, device="cuda")
+    L.check(lib.em_dec_transpose_v(L.EM_BF16, L.ptr(kv), B, T, d, Tpad, L.ptr(vT), None), "transpose_v")
+    kl = torch.tensor([75, 40, 1], dtype=torch.int32).cuda()
+    qs = torch.empty(n, d, dtype=dt, device="cuda")
+    L.check(lib.em_ln_gemm(L.EM_BF16, L.EM_EPI_STORE, L.ptr(x), L.ptr(g), L.ptr(be), 1e-12, L.ptr(wq), L.ptr(bq), L.ptr(qs),
+                           n, d, d, d, None), "em_ln_gemm")
+    ref = torch.empty(n, d, dtype=dt, device="cuda")
+    L.check(lib.em_dec_src_attention(L.EM_BF16, L.ptr(qs), L.ptr(kv), 2 * d, L.ptr(vT), L.ptr(kl), B, W, d, heads, T, Tpad,
+                                     L.ptr(ref), None), "src_attn")
+    got = torch.full((n, d), 7.0, dtype=dt, device="cuda")
+    L.check(lib.em_dec_src_attention_lnq(L.EM_BF16, L.ptr(x), L.ptr(g), L.ptr(be), 1e-12, L.ptr(wq), L.ptr(bq), L.ptr(kv),
+                                         2 * d, L.ptr(vT), L.ptr(kl), B, W, d, heads, T, Tpad, L.ptr(got), None), "src_attn_lnq")
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    with pytest.raises(NotImplementedError):
+        L.check(lib.em_dec_src_attention_lnq(L.EM_F32, L.ptr(x), L.ptr(g), L.ptr(be), 1e-12, L.ptr(wq), L.ptr(bq), L.ptr(kv),
+                                             2 * d, L.ptr(vT), L.ptr(kl), B, W, d, heads, T, Tpad, L.ptr(got), None), "f32")
+
+
 @pytest.mark.parametrize("T", [1, 2, 3, 6])
 def test_search_very_short_memories_match_oracle(T):
     """Edge of the length logic: encoder memories of 1-6 frames (maxlen = T: the forced <eos> of
