@@ -673,13 +673,16 @@ def PROF_NAMES():
 
     return {L.EM_PROF_GEMM: "gemm_kernel<T,EPI,AMODE> (all instantiations)",
             L.EM_PROF_BLOCK: "block_kernel<MODE> (fused Conformer block, csrc/block.hip)",
-            L.EM_PROF_ATTN: "relpos_attn2_kernel (csrc/attention2.hip)"}
+            L.EM_PROF_ATTN: "relpos_attn2_kernel (csrc/attention2.hip)",
+            L.EM_PROF_ROWS: "ffn_rows_kernel<LNMODE,PRE,MAIN> (row-block feed-forward / projection / GLU launches of the 512-wide "
+                            "model, csrc/ffn_rows.hip)"}
 
 
 def PROF_MATCH():
     from espnet_amd import lib as L
 
-    return {L.EM_PROF_GEMM: "gemm_kernel", L.EM_PROF_BLOCK: "block_kernel", L.EM_PROF_ATTN: "relpos_attn2_kernel"}
+    return {L.EM_PROF_GEMM: "gemm_kernel", L.EM_PROF_BLOCK: "block_kernel", L.EM_PROF_ATTN: "relpos_attn2_kernel",
+            L.EM_PROF_ROWS: "ffn_rows_kernel"}
 
 
 def profile_families(step_fn, nprof):

@@ -588,7 +588,7 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
       fflush(stdout);
     }
   }
-  if (rec) em_prof_end(stream, (glu ? 2.0 : 4.0) * a->M * (double)D * a->ff + (pre ? 2.0 * a->M * (double)D * D : 0.0), EM_PROF_GEMM);
+  if (rec) em_prof_end(stream, (glu ? 2.0 : 4.0) * a->M * (double)D * a->ff + (pre ? 2.0 * a->M * (double)D * D : 0.0), EM_PROF_ROWS);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

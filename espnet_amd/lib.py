@@ -28,7 +28,7 @@ EM_ENC_PLAN_FUSED, EM_ENC_PLAN_CTC_IDS = 1, 2
 EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC, EM_BLOCK_RELU = 1, 2, 4, 8, 16, 32
 EM_BLOCK_PARAM_GROUP = 1792
 EM_BLOCK_CTC_MAX_UNITS = 88  # vocabularies up to 5 632 labels take the fused CTC stage (the sizes the GPU tests cover); larger ones keep the arg-max GEMM
-EM_PROF_GEMM, EM_PROF_BLOCK, EM_PROF_ATTN = 0, 1, 2
+EM_PROF_GEMM, EM_PROF_BLOCK, EM_PROF_ATTN, EM_PROF_ROWS = 0, 1, 2, 3
 DTYPES = {"float32": EM_F32, "fp32": EM_F32, "f32": EM_F32, "bfloat16": EM_BF16, "bf16": EM_BF16}
 
 

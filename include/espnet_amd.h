@@ -906,6 +906,7 @@ int em_profile_read(EmProfile* prof, float* ms, double* flops, int32_t max_n, in
 #define EM_PROF_GEMM 0
 #define EM_PROF_BLOCK 1
 #define EM_PROF_ATTN 2
+#define EM_PROF_ROWS 3 /* em_ffn_rows_fused: flops of its feed-forward / projection / GLU GEMMs */
 int em_profile_read2(EmProfile* prof, float* ms, double* flops, int32_t* tags, int32_t max_n, int32_t* count);
 
 /* f32 -> act dtype copy (lets reference-shaped f32 entry points feed the act-dtype GEMMs) */
