@@ -153,6 +153,24 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
       glds16(vb, 1024 + lane * 16, PAR_OFF + wave * 2048 + 1024);
     }
   }
+  // ---- the residual rows (lane (lr, lg): columns 64 wave + 16 cf + 4 lg + r of rows 16 rf + lr).  A launch that starts with
+  // a projection needs them at its first MFMA - the accumulators start as x - so it requests them HERE, in front of the ring's
+  // head, and the counted wait below covers them: requested behind the prologue barrier (as the plain launch does, whose
+  // first GEMM 1 does not need them) the waves got their rows up to 8 K cycles apart, ran the projection out of step and the
+  // LayerNorm barrier behind it waited for the last one (hand-over 11 K cycles, stamps r04x).
+  const int col0 = 64 * wave + 4 * lg;
+  f32x4 acc2[4][4];
+  auto load_x = [&](f32x4 (&v)[4][4]) {
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      int m = m0 + rf * 16 + lr;
+      m = m < M ? m : M - 1;
+      const float* xr = a.x + (size_t)m * D + col0;
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) v[cf][rf] = *(const f32x4*)(xr + 16 * cf);
+    }
+  };
+  if constexpr (PRE) load_x(acc2);
   __builtin_amdgcn_sched_barrier(0);
   // ---- weight stream: per chunk 16 fragments x [8 waves] x 1 KiB of W1 and as many of W2 (include/espnet_amd.h,
   // EmFfnRowsArgs): fragment i of this wave at chunk + i * 8 KiB + wave * 1 KiB + lane * 16
@@ -195,12 +213,10 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   // instead of 7 K cycles, 88 us; one 16-row piece per iteration of the first four chunks - every GEMM 2 phase 4.4 K
   // instead of 3.1 K cycles (requests with 64-byte segments between the weight requests), 87 us; this one 82.9 us.
   // Lane (lr, lg) holds columns 64 wave + 16 cf + 4 lg + r of rows 16 rf + lr.
-  const int col0 = 64 * wave + 4 * lg;
   // bias / LayerNorm vector `which` (order of PAR_OFF) at this lane's columns 16 cf ..
   auto par4 = [&](int which, int cf) { return *(const float4*)(smem + PAR_OFF + which * 2048 + (col0 + 16 * cf) * 4); };
   auto parv = [&](int which, int cf) { return *(const f32x4*)(smem + PAR_OFF + which * 2048 + (col0 + 16 * cf) * 4); };
   const float scale = a.scale, inv_scale = 1.0f / a.scale;
-  f32x4 acc2[4][4];
 
   // The instruction order below is pinned with sched_barrier(0) after every group of [4 MFMAs + 1 weight request]: left
   // alone hipcc gathers the requests of a phase into one cluster at the phase's end, i.e. directly in front of
@@ -284,22 +300,13 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     }
   };
 
-  // LN(x) has landed (requested before the 16 ring fragments and the bias: loads return in order; the memory clobbers keep
+  // LN(x) (and a projection launch's residual rows) have landed (requested before the 16 ring fragments and the bias: loads
+  // return in order; the memory clobbers keep
   // hipcc from moving any other request across either asm statement, so the count is exact)
   asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   stamp();
-  auto load_x = [&](f32x4 (&v)[4][4]) {
-#pragma unroll
-    for (int rf = 0; rf < 4; ++rf) {
-      int m = m0 + rf * 16 + lr;
-      m = m < M ? m : M - 1;
-      const float* xr = a.x + (size_t)m * D + col0;
-#pragma unroll
-      for (int cf = 0; cf < 4; ++cf) v[cf][rf] = *(const f32x4*)(xr + 16 * cf);
-    }
-  };
-  load_x(acc2);
+  if constexpr (!PRE) load_x(acc2);
   __builtin_amdgcn_sched_barrier(0);
   read_act(0, af0);
 
