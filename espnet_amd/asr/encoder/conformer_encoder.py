@@ -425,6 +425,7 @@ class ConformerEncoder(torch.nn.Module):
                           fp_c=F(l.conv_module.pointwise_conv1.bias[glu_chunk_order(d)]))
                 for k, v in lt.items():
                     setattr(layers[i], k, v.data_ptr())
+            self._pack_rows_ctc(w, A, F)
         w.layers = C.cast(layers, C.POINTER(L.EmConformerLayer))
         self._packed = dict(w=w, layers=layers, keep=keep, device=dev, dtype=self.em_dtype)
         self._pos_cache = {}
@@ -499,6 +500,21 @@ class ConformerEncoder(torch.nn.Module):
         bt = torch.full((units * 64,), -3.0e38, dtype=torch.float32)
         bt[:V] = ctc.ctc_lo.bias.detach().to(torch.float32).cpu()
         w.ctc_w, w.ctc_b, w.ctc_units = A(pack_k_units(wt)).data_ptr(), F(bt).data_ptr(), units
+        self._ctc_stamp = self._ctc_version(ctc)
+
+    def _pack_rows_ctc(self, w, A, F):
+        """512-wide model: the attached CTC head for the arg-max walk behind the last row-block launch (EmFfnRowsArgs.post_*):
+        weight zero-padded to whole 128-row chunks in the w1p layout, bias padded with -3e38."""
+        ctc = getattr(self, "fused_ctc", None)
+        if ctc is None or ctc.eprojs != self._output_size:
+            return
+        V = ctc.odim
+        chunks = (V + 127) // 128
+        wt = torch.zeros(chunks * 128, self._output_size, dtype=torch.float32)
+        wt[:V] = ctc.ctc_lo.weight.detach().to(torch.float32).cpu()
+        bt = torch.full((chunks * 128,), -3.0e38, dtype=torch.float32)
+        bt[:V] = ctc.ctc_lo.bias.detach().to(torch.float32).cpu()
+        w.ctc_w, w.ctc_b, w.ctc_units = A(pack_ffn_rows_w1(wt)).data_ptr(), F(bt).data_ptr(), chunks
         self._ctc_stamp = self._ctc_version(ctc)
 
     @staticmethod
@@ -664,7 +680,7 @@ class ConformerEncoder(torch.nn.Module):
             if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "ctc_units", 0) > 0:
                 ids = torch.empty(B, T, dtype=torch.int32, device=dev)
                 pk["w"].ctc_ids = ids.data_ptr()
-                plan = lib.em_conformer_encode_plan(self.em_dtype, C.byref(pk["w"]), enc_flags)
+                plan = lib.em_conformer_encode_plan_for(self.em_dtype, C.byref(pk["w"]), enc_flags, B, T_f)
                 if plan < 0:
                     L.check(plan, "em_conformer_encode_plan")
                 if plan & L.EM_ENC_PLAN_CTC_IDS:

@@ -65,9 +65,52 @@ inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const
 }
 
 
+// The 512-wide model's row-block launches (csrc/ffn_rows.hip).  Round 4: at d = 512 (bf16) the block's row-local operators
+// run as three launches of 64-row workgroups when the host packed their operands: [macaron FFN + residual + norm_mha],
+// [linear_out + residual + norm_conv + pointwise_conv1 + GLU], [pointwise_conv2 + residual + norm_ff + FFN + residual +
+// norm_final + the next LayerNorm] (+ the CTC head's arg-max behind the last one).  ESPNET_AMD_NO_FFN_ROWS=1: developer switch.
+struct RowsPlan {
+  bool ffn, pre_pw2, glu, ctc;
+};
+inline RowsPlan rows_plan(int dtype, const EmConformerWeights* w, int flags, long M) {
+  RowsPlan r = {false, false, false, false};
+  static const bool no_ffn_rows = getenv("ESPNET_AMD_NO_FFN_ROWS") != nullptr;
+  const int d = w->d, ff = w->ff, L = w->num_blocks;
+  const EmConformerLayer* ly = w->layers;
+  if (!(dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) && !no_ffn_rows && ly && L > 0 &&
+        M > 0))
+    return r;
+  // A row-block launch takes ~80 us per ROUND of 64-row workgroups whatever the number of rows (one workgroup streams all
+  // 4 MiB of the module's weights through its CU), the launches it replaces scale with M (90 us at M = 15 936, ~31 us at
+  // the beam search's M = 3 984, where only 63 CUs would work: profiles/r04r_search_kernel_stats.csv): taken only when its
+  // rounds fill at least three quarters of the chip.
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+               ? prop.multiProcessorCount : 256;
+  }
+  const long wgs = (M + 63) / 64, rounds = (wgs + n_cu - 1) / n_cu;
+  r.ffn = 4 * wgs >= 3 * rounds * n_cu;
+  for (int l = 0; r.ffn && l < L; ++l) r.ffn = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
+  // ... pointwise_conv2 + residual + norm_ff ride in the second module's launch when the host packed pw2 as well
+  r.pre_pw2 = r.ffn;
+  for (int l = 0; r.pre_pw2 && l < L; ++l) r.pre_pw2 = ly[l].pw2p != nullptr;
+  // ... linear_out + residual + norm_conv + pointwise_conv1 + GLU are one launch (EM_ROWS_GLU) with woutp / pw1f / fp_c
+  // (= pointwise_conv1's bias in the chunk order) packed
+  r.glu = r.ffn;
+  for (int l = 0; r.glu && l < L; ++l) r.glu = ly[l].woutp && ly[l].pw1f && ly[l].fp_c;
+  // ... and the CTC head's arg-max is a walk behind the last launch (ctc_w: ctc_lo.weight in 128-row chunks, w1p layout)
+  static const bool no_rows_ctc = getenv("ESPNET_AMD_NO_ROWS_CTC") != nullptr;  // developer A/B switch
+  r.ctc = r.ffn && !no_rows_ctc && w->ctc_ids && w->ctc_w && w->ctc_b && w->ctc_units > 0;
+  return r;
+}
+
 // Which launch sequence em_conformer_encode takes: the ONE place that decides (the host layer asks through
 // em_conformer_encode_plan instead of re-deriving the shape conditions).
-inline int encode_plan(int dtype, const EmConformerWeights* w, int flags) {
+inline int encode_plan(int dtype, const EmConformerWeights* w, int flags, long M = 0) {
+  if (rows_plan(dtype, w, flags, M).ctc) return EM_ENC_PLAN_CTC_IDS;
   const int d = w->d, h = w->heads, ff = w->ff, L = w->num_blocks;
   const EmConformerLayer* ly = w->layers;
   bool fused = dtype == EM_BF16 && d == 256 && h == 4 && ff <= 1024 && w->kernel == 31 && !w->legacy_relpos &&
@@ -97,6 +140,13 @@ extern "C" size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeigh
 extern "C" int em_conformer_encode_plan(int dtype, const EmConformerWeights* w, int32_t flags) {
   if (!w || (dtype != EM_F32 && dtype != EM_BF16)) return EM_ERR_BAD_ARG;
   return encode_plan(dtype, w, flags);
+}
+
+extern "C" int em_conformer_encode_plan_for(int dtype, const EmConformerWeights* w, int32_t flags, int32_t B, int32_t T_f) {
+  if (!w || (dtype != EM_F32 && dtype != EM_BF16) || B <= 0) return EM_ERR_BAD_ARG;
+  em_sub::Geo g;
+  if (T_f < em_sub::min_frames(w->subsample) || !em_sub::geo(w->subsample, T_f, w->n_mels, &g)) return EM_ERR_BAD_ARG;
+  return encode_plan(dtype, w, flags, (long)B * g.T_out);
 }
 
 extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* feats,
@@ -220,34 +270,8 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     if (hipMemsetAsync(qh, 0, (s.vt - s.qh) + (size_t)B * d * s.Tpad * es, (hipStream_t)stream) != hipSuccess)
       return EM_ERR_LAUNCH;
   }
-  // Round 4: at d = 512 (bf16) each feed-forward module - w_1 + Swish, w_2 + residual and the LayerNorm(s) behind it - is
-  // ONE row-block launch (csrc/ffn_rows.hip) when the host packed its operands: 19 -> 15 launches per block, the [M][ff]
-  // hidden activation and one f32 round trip of the residual stream gone.  ESPNET_AMD_NO_FFN_ROWS=1: developer A/B switch.
-  static const bool no_ffn_rows = getenv("ESPNET_AMD_NO_FFN_ROWS") != nullptr;
-  bool ffn_rows = dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) && !no_ffn_rows;
-  if (ffn_rows) {
-    // A row-block launch takes ~80 us per ROUND of 64-row workgroups whatever the number of rows (one workgroup streams all
-    // 4 MiB of the module's weights through its CU), the three launches it replaces scale with M (90 us at M = 15 936, ~31 us at
-    // the beam search's M = 3 984, where only 63 CUs would work: profiles/r04r_search_kernel_stats.csv): taken only when its
-    // rounds fill at least three quarters of the chip.
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                 ? prop.multiProcessorCount : 256;
-    }
-    const long wgs = ((long)M + 63) / 64, rounds = (wgs + n_cu - 1) / n_cu;
-    ffn_rows = 4 * wgs >= 3 * rounds * n_cu;
-  }
-  for (int l = 0; ffn_rows && l < L; ++l) ffn_rows = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
-  // ... and pointwise_conv2 + residual + norm_ff ride in the second module's launch when the host packed pw2 as well
-  bool pre_pw2 = ffn_rows;
-  for (int l = 0; pre_pw2 && l < L; ++l) pre_pw2 = ly[l].pw2p != nullptr;
-  // ... and linear_out + residual + norm_conv + pointwise_conv1 + GLU are one launch (EM_ROWS_GLU) with woutp / pw1f / fp_c
-  // (= pointwise_conv1's bias in the chunk order) packed
-  bool rows_glu = ffn_rows;
-  for (int l = 0; rows_glu && l < L; ++l) rows_glu = ly[l].woutp && ly[l].pw1f && ly[l].fp_c;
+  const RowsPlan rp = rows_plan(dtype, w, flags, M);
+  const bool ffn_rows = rp.ffn, pre_pw2 = rp.pre_pw2, rows_glu = rp.glu;
   const EmConformerLayer* pre_layer = nullptr;  // set for the call that carries the projection
   const void* const conv_out = g2;              // the depthwise conv's output: the projection's input
   auto ffn_fused = [&](const void* w1p, const void* w2p, const float* b1, const float* b2, int ln_mode, const float* g1,
@@ -260,6 +284,10 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     fa.xn_in = xn; fa.x = x; fa.w1p = w1p; fa.w2p = w2p; fa.b1 = b1; fa.b2 = b2;
     fa.g1 = g1; fa.be1 = be1; fa.g2 = g2; fa.be2 = be2; fa.xn_out = xn_out; fa.out_f32 = out_f32;
     fa.M = M; fa.d = d; fa.ff = ff; fa.ln_mode = ln_mode; fa.scale = 0.5f; fa.eps = LN_EPS;
+    if (out_f32 && rp.ctc) {  // the last launch of the stack: the CTC head's arg-max behind after_norm
+      fa.post_w = w->ctc_w; fa.post_b = w->ctc_b; fa.post_ids = w->ctc_ids; fa.post_chunks = w->ctc_units;
+      fa.post_vocab = w->ctc_units * 128;
+    }
     return em_ffn_rows_fused(&fa, stream);
   };
   EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr,

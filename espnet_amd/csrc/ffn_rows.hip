@@ -104,7 +104,8 @@ __device__ __forceinline__ float rsqrt_nr(float var) {
 // launches between the attention and the depthwise conv (19.1 + 9.8 + 29.7 us at B = 64).  Its matrix is walked in the
 // GEMM-1 form (wave w: 16 output columns of every 128-row chunk), chunks alternating value rows and their gate rows, so a
 // lane holds matching value / gate pairs; no hidden tile, no barrier in the loop.
-template <int LNMODE, bool PRE, int MAIN>
+// POST: the CTC head's arg-max walk behind the launch (the last launch of the stack), see the end of the kernel.
+template <int LNMODE, bool PRE, int MAIN, bool POST = false>
 __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, long long* __restrict__ stamps) {
   using MM = Mma<bf16>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -234,8 +235,9 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   // GEMM 1 of a chunk: H^T[hidden 16 wave + ..][row] over K = 512; every slot refilled from chunk `refill`.
   // SYNC: the chunk barrier sits in the middle (k-step 8) and the first hidden fragments of tile `hbuf` are requested at the end.
-  auto gemm1 = [&](__amdgpu_buffer_rsrc_t refill, auto sync, int hbuf) {
+  auto gemm1 = [&](__amdgpu_buffer_rsrc_t refill, auto sync, int hbuf, auto walk) {
     constexpr bool SYNC = decltype(sync)::value;
+    constexpr bool WALK = decltype(walk)::value || MAIN == EM_ROWS_GLU;  // chunk after chunk of GEMM 1: prefetch the next one's head
     bf16x8 cur[4], nxt[4];
 #pragma unroll
     for (int rf = 0; rf < 4; ++rf) cur[rf] = af0[rf];
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
       if (ks + 1 < 16 && !(dbg & 4)) read_act(ks + 1, nxt);
       if (SYNC && ks == 8) barrier();
       if (SYNC && ks == 15) read_h(hbuf, 0, h0);
-      if (MAIN == EM_ROWS_GLU && ks == 15) read_act(0, af0);  // (the next chunk's first fragments; af0 was copied to cur above)
+      if (WALK && ks == 15) read_act(0, af0);  // (the next chunk's first fragments; af0 was copied to cur above)
 #pragma unroll
       for (int rf = 0; rf < 4; ++rf) {
         if constexpr ((dbg & 1) == 0)
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
 #pragma unroll
     for (int c = 0; c < 2 * NPAIR; ++c) {
       const float4 bnext = *(const float4*)(b1p + (c + 1 < 2 * NPAIR ? c + 1 : c) * CH);
-      gemm1(rsrc(a.w1p, c + 1 < 2 * NPAIR ? c + 1 : c), std::false_type{}, 0);
+      gemm1(rsrc(a.w1p, c + 1 < 2 * NPAIR ? c + 1 : c), std::false_type{}, 0, std::true_type{});
       if ((c & 1) == 0) {
 #pragma unroll
         for (int rf = 0; rf < 4; ++rf) val[rf] = acc1[rf] + (f32x4){bv.x, bv.y, bv.z, bv.w};
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     return;
   }
 
-  gemm1(nch > 1 ? rsrc(a.w1p, 1) : rsrc(a.w2p, 0), std::false_type{}, 0);
+  gemm1(nch > 1 ? rsrc(a.w1p, 1) : rsrc(a.w2p, 0), std::false_type{}, 0, std::false_type{});
 #pragma unroll
   for (int rf = 0; rf < 4; ++rf)
 #pragma unroll
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     // (requests are unconditional and their addresses always valid: hipcc counts its waits only over straight-line loads)
     bia = *(const float4*)(b1p + c * CH);
     // barrier inside: tile (c - 1) & 1 is complete; everybody is done reading tile c & 1 (chunk c - 2)
-    gemm1(rsrc(a.w2p, c - 1), std::true_type{}, (c - 1) & 1);
+    gemm1(rsrc(a.w2p, c - 1), std::true_type{}, (c - 1) & 1, std::false_type{});
     if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc1[3]));
     stamp();
     gemm2((c - 1) & 1, c + 1 < nch ? rsrc(a.w1p, c + 1) : rsrc(a.w2p, nch - 1), std::true_type{},
@@ -497,7 +499,10 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   }
   barrier();
   read_h((nch - 1) & 1, 0, h0);
-  gemm2((nch - 1) & 1, rsrc(a.w2p, 0), std::false_type{}, [&](int, int) {});
+  if constexpr (POST)
+    gemm2((nch - 1) & 1, rsrc(a.post_w, 0), std::true_type{}, [&](int, int) {});  // (the ring leaves with the CTC matrix's head)
+  else
+    gemm2((nch - 1) & 1, rsrc(a.w2p, 0), std::false_type{}, [&](int, int) {});
   if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc2[3][3]));
   stamp();
 
@@ -552,6 +557,81 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     }
   }
   stamp();
+  if constexpr (POST) {
+    {
+      // ---- the CTC head's arg-max (asr/ctc.py:207-215: argmax over ctc_lo of the encoder output) as a walk behind the last
+      // launch of the stack: the 64 finished rows go back into the LDS tile (bf16: what the stand-alone GEMM reads from
+      // enc_act) and the [V rounded up to 128][512] matrix is walked in the GEMM-1 form, every lane keeping the running
+      // (maximum, label) of its rows over the labels 128 c + 16 wave + 4 lg + r it sees - ascending, strict >: the lowest
+      // label wins a tie, like torch.argmax.  The logits never exist; the stand-alone arg-max GEMM (201 us at B = 64: 5 000
+      // tiles of eight K-steps with a reduction epilogue each) and its partials pass are not launched.
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) {
+        const int q = 8 * wave + 2 * cf + (lg >> 1);
+        const int pos = (q & ~15) | ((q ^ lr) & 15);
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf)
+          *(bf16x4*)(smem + ACT_OFF + (rf * 16 + lr) * 1024 + pos * 16 + (lg & 1) * 8) = __builtin_convertvector(xin[cf][rf], bf16x4);
+      }
+      barrier();
+      read_act(0, af0);
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int bidx[4] = {0, 0, 0, 0};
+      const float* cbp = a.post_b + 16 * wave + 4 * lg;
+      const int nc = a.post_chunks;
+      float4 cb = *(const float4*)cbp;
+#pragma unroll 1
+      for (int c = 0; c < nc; ++c) {
+        const float4 cbn = *(const float4*)(cbp + (c + 1 < nc ? c + 1 : c) * CH);
+        gemm1(rsrc(a.post_w, c + 1 < nc ? c + 1 : c), std::false_type{}, 0, std::true_type{});
+        const int id0 = c * CH + 16 * wave + 4 * lg;
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf) {
+          const f32x4 v = acc1[rf] + (f32x4){cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (v[r] > best[rf]) {
+              best[rf] = v[r];
+              bidx[rf] = id0 + r;
+            }
+        }
+        cb = cbn;
+      }
+      // the four lane groups of a row (labels differ), then the eight waves through LDS; larger value, lower label on ties
+      float2* const red = (float2*)(smem + RED_OFF);
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf) {
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+          const auto pv = step == 0 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(best[rf]), __float_as_uint(best[rf]), false, false)
+                                    : __builtin_amdgcn_permlane32_swap(__float_as_uint(best[rf]), __float_as_uint(best[rf]), false, false);
+          const auto pi = step == 0 ? __builtin_amdgcn_permlane16_swap((unsigned)bidx[rf], (unsigned)bidx[rf], false, false)
+                                    : __builtin_amdgcn_permlane32_swap((unsigned)bidx[rf], (unsigned)bidx[rf], false, false);
+          const float va = __uint_as_float(pv[0]), vb = __uint_as_float(pv[1]);
+          const int ia = (int)pi[0], ib = (int)pi[1];
+          const bool take_b = vb > va || (vb == va && ib < ia);
+          best[rf] = take_b ? vb : va;
+          bidx[rf] = take_b ? ib : ia;
+        }
+        if (lg == 0) red[wave * 64 + rf * 16 + lr] = make_float2(best[rf], __int_as_float(bidx[rf]));
+      }
+      barrier();
+      if (tid < RB) {
+        float bv = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          const float2 p = red[w * 64 + tid];
+          const int pi = __float_as_int(p.y);
+          if (p.x > bv || (p.x == bv && pi < bi)) {
+            bv = p.x;
+            bi = pi;
+          }
+        }
+        if (m0 + tid < M) a.post_ids[m0 + tid] = bi;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -563,6 +643,8 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   if (pre ? (!a->pre_w || !a->pre_b || !a->pre_g || !a->pre_be) : !a->xn_in) return EM_ERR_BAD_ARG;
   if (a->M <= 0 || a->ff <= 0) return EM_ERR_BAD_ARG;
   if (a->d != D || a->ff % CH != 0 || a->ff < 2 * CH) return EM_ERR_UNSUPPORTED;
+  if (a->post_w && (a->main != EM_ROWS_FFN || a->ln_mode != 2 || !a->post_b || !a->post_ids || a->post_chunks <= 0))
+    return EM_ERR_BAD_ARG;
   const bool glu = a->main == EM_ROWS_GLU;
   if (a->main != EM_ROWS_FFN && !glu) return EM_ERR_BAD_ARG;
   if (glu && !pre) return EM_ERR_BAD_ARG;
@@ -576,13 +658,15 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   if (want_stamps && hipMemsetAsync(stamps, 0, 64 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   long long* const st = want_stamps ? stamps : nullptr;
   typedef void (*kern_t)(const EmFfnRowsArgs, long long*);
-  static EmLdsCap caps[5] = {};
-  const int which = glu ? 4 : (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
+  static EmLdsCap caps[7] = {};
+  const int which = glu ? 4 : a->post_w ? 5 + (pre ? 1 : 0) : (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
   const kern_t kern = which == 0   ? ffn_rows_kernel<1, false, EM_ROWS_FFN>
                       : which == 1 ? ffn_rows_kernel<1, true, EM_ROWS_FFN>
                       : which == 2 ? ffn_rows_kernel<2, false, EM_ROWS_FFN>
                       : which == 3 ? ffn_rows_kernel<2, true, EM_ROWS_FFN>
-                                   : ffn_rows_kernel<1, true, EM_ROWS_GLU>;
+                      : which == 4 ? ffn_rows_kernel<1, true, EM_ROWS_GLU>
+                      : which == 5 ? ffn_rows_kernel<2, false, EM_ROWS_FFN, true>
+                                   : ffn_rows_kernel<2, true, EM_ROWS_FFN, true>;
   if (em_raise_lds_cap((const void*)kern, SMEM_BYTES, &caps[which]) != EM_OK) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
   hipLaunchKernelGGL(kern, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);
@@ -595,7 +679,9 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
       fflush(stdout);
     }
   }
-  if (rec) em_prof_end(stream, (glu ? 2.0 : 4.0) * a->M * (double)D * a->ff + (pre ? 2.0 * a->M * (double)D * D : 0.0), EM_PROF_ROWS);
+  if (rec)
+    em_prof_end(stream, (glu ? 2.0 : 4.0) * a->M * (double)D * a->ff + (pre ? 2.0 * a->M * (double)D * D : 0.0) +
+                            (a->post_w ? 2.0 * a->M * (double)D * a->post_vocab : 0.0), EM_PROF_ROWS);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

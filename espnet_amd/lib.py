@@ -81,7 +81,8 @@ class EmFfnRowsArgs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("xn_in", "x", "w1p", "w2p", "b1", "b2", "g1", "be1", "g2", "be2", "xn_out",
                                           "out_f32")] + \
                [(n, C.c_int32) for n in ("M", "d", "ff", "ln_mode")] + [("scale", C.c_float), ("eps", C.c_float)] + \
-               [(n, C.c_void_p) for n in ("pre_in", "pre_w", "pre_b", "pre_g", "pre_be")] + [("main", C.c_int32)]
+               [(n, C.c_void_p) for n in ("pre_in", "pre_w", "pre_b", "pre_g", "pre_be")] + [("main", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("post_w", "post_b", "post_ids")] + [("post_chunks", C.c_int32), ("post_vocab", C.c_int32)]
 
 
 class EmConformerWeights(C.Structure):
@@ -286,6 +287,7 @@ _SIGNATURES = {
     "em_ctc_prefix_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                       _vp]),
     "em_conformer_encode_plan": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _i32]),
+    "em_conformer_encode_plan_for": (C.c_int, [C.c_int, C.POINTER(EmConformerWeights), _i32, _i32, _i32]),
     "em_ctc_prefix_extend": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "em_ctc_greedy": (C.c_int, [C.c_int, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32,
                                 _vp, _vp, _vp, _vp, _vp]),

@@ -312,6 +312,11 @@ typedef struct EmConformerWeights {
 #define EM_ENC_PLAN_FUSED 1   /* fused per-block kernels (csrc/block.hip) */
 #define EM_ENC_PLAN_CTC_IDS 2 /* ... and w->ctc_ids [B][T] WILL be written by the last block kernel */
 int em_conformer_encode_plan(int dtype, const EmConformerWeights* w, int32_t flags);
+/*   ... for a given batch (B utterances of T_f feature frames): the 512-wide model's row-block launches - and with them the
+ *   CTC arg-max behind the last one (ctc_w then = ctc_lo.weight zero-padded to ctc_units * 128 rows in the EmFfnRowsArgs.w1p
+ *   layout, ctc_b padded with -3e38) - are taken only when the batch's rows fill the chip, so EM_ENC_PLAN_CTC_IDS depends on
+ *   the shape there.  Equal to em_conformer_encode_plan for every other model.                                          */
+int em_conformer_encode_plan_for(int dtype, const EmConformerWeights* w, int32_t flags, int32_t B, int32_t T_f);
 
 /* bytes of scratch em_conformer_encode needs for (B, T_f) */
 size_t em_conformer_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t B, int32_t T_f);
@@ -447,6 +452,13 @@ typedef struct EmFfnRowsArgs {
    *        128 j + 127 and chunk 2 j + 1 their gate rows (host: pack_rows_glu), b1 its bias in that order, ff = 1024;
    *   xn_out [M][512] bf16 = value * sigmoid(gate);  x is updated;  w2p, b2, g1 .. be2, out_f32, ln_mode, scale unused.   */
   int32_t main;
+  /* optional walk behind a ln_mode 2 launch (post_w != NULL): the CTC head's per-row arg-max over the second LayerNorm's
+   * result (asr/ctc.py:207-215), post_ids [M] i32 out.  post_w: ctc_lo.weight zero-padded to post_chunks * 128 rows, in the
+   * w1p layout; post_b its bias padded with -3e38; post_vocab the real vocabulary size (flop accounting only).            */
+  const void* post_w;
+  const float* post_b;
+  int32_t* post_ids;
+  int32_t post_chunks, post_vocab;
 } EmFfnRowsArgs;
 #define EM_ROWS_FFN 0
 #define EM_ROWS_GLU 1

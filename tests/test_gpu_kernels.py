@@ -554,6 +554,61 @@ def test_ffn_rows_fused(lib, M, ff, ln_mode, pre):
         L.check(lib.em_ffn_rows_fused(a, sptr()), "em_ffn_rows_fused d=256")
 
 
+@pytest.mark.parametrize("M,V,pre", [(1000, 5000, True), (130, 300, False)])
+def test_ffn_rows_ctc_argmax_walk(lib, M, V, pre):
+    """Round 4: the CTC head's arg-max (asr/ctc.py:207-215) as a walk behind the last row-block launch of the 512-wide stack
+    (EmFfnRowsArgs.post_*): the ids must be arg-maxima of ctc_lo applied to the launch's OWN bf16 output (what the stand-alone
+    arg-max GEMM reads) - equal to torch.argmax except on near-ties (the summation order differs), where the chosen label's
+    logit is within 1e-3 of the maximum; rows past M untouched; V not a multiple of 128 (padded rows never win)."""
+    from espnet_amd.asr.encoder.conformer_encoder import pack_ffn_rows_w1, pack_ffn_rows_w2, pack_rows_proj
+
+    d, ff = 512, 1024
+    x = rnd(M, d, seed=81) * 2 + 0.3
+    g0, b0 = 1 + 0.1 * rnd(d, seed=82), 0.1 * rnd(d, seed=83)
+    w1 = q(rnd(ff, d, seed=84, scale=d ** -0.5), torch.bfloat16)
+    w2 = q(rnd(d, ff, seed=85, scale=ff ** -0.5), torch.bfloat16)
+    b1, b2 = 0.1 * rnd(ff, seed=86), 0.1 * rnd(d, seed=87)
+    g1, be1, g2, be2 = 1 + 0.1 * rnd(d, seed=88), 0.1 * rnd(d, seed=89), 1 + 0.1 * rnd(d, seed=90), 0.1 * rnd(d, seed=91)
+    wc = q(rnd(V, d, seed=92, scale=d ** -0.5), torch.bfloat16)
+    bc = 0.1 * rnd(V, seed=93)
+    chunks = (V + 127) // 128
+    wcp = torch.zeros(chunks * 128, d)
+    wcp[:V] = wc
+    bcp = torch.full((chunks * 128,), -3.0e38)
+    bcp[:V] = bc
+    pad = 70
+    xd = dev(torch.cat([x, torch.full((pad, d), 7.0)]))
+    out_n = torch.full((M + pad, d), 7.0, dtype=torch.bfloat16, device="cuda")
+    out_f = torch.full((M + pad, d), 7.0, device="cuda")
+    ids = torch.full((M + pad,), -7, dtype=torch.int32, device="cuda")
+    a = L.EmFfnRowsArgs(x=xd.data_ptr(), w1p=dev(pack_ffn_rows_w1(w1).to(torch.bfloat16)).data_ptr(),
+                        w2p=dev(pack_ffn_rows_w2(w2).to(torch.bfloat16)).data_ptr(), b1=dev(b1).data_ptr(), b2=dev(b2).data_ptr(),
+                        g1=dev(g1).data_ptr(), be1=dev(be1).data_ptr(), g2=dev(g2).data_ptr(), be2=dev(be2).data_ptr(),
+                        xn_out=out_n.data_ptr(), out_f32=out_f.data_ptr(), M=M, d=d, ff=ff, ln_mode=2, scale=0.5, eps=1e-12,
+                        post_w=dev(pack_ffn_rows_w1(wcp).to(torch.bfloat16)).data_ptr(), post_b=dev(bcp).data_ptr(),
+                        post_ids=ids.data_ptr(), post_chunks=chunks, post_vocab=V)
+    if pre:
+        pin = q(rnd(M, d, seed=94), torch.bfloat16)
+        wp = q(rnd(d, d, seed=95, scale=d ** -0.5), torch.bfloat16)
+        pind = dev(torch.cat([pin, torch.full((pad, d), 7.0)]).to(torch.bfloat16))
+        a.pre_in, a.pre_w = pind.data_ptr(), dev(pack_rows_proj(wp).to(torch.bfloat16)).data_ptr()
+        a.pre_b, a.pre_g, a.pre_be = dev(0.1 * rnd(d, seed=96)).data_ptr(), dev(g0).data_ptr(), dev(b0).data_ptr()
+    else:
+        xnd = dev(q(F.layer_norm(x, (d,), g0, b0, 1e-12), torch.bfloat16).to(torch.bfloat16))
+        a.xn_in = xnd.data_ptr()
+    L.check(lib.em_ffn_rows_fused(a, sptr()), "em_ffn_rows_fused(post)")
+    torch.cuda.synchronize()
+    logits = out_n[:M].float().cpu() @ wc.t() + bc  # from the launch's own bf16 output
+    got = ids[:M].cpu().long()
+    assert int(got.min()) >= 0 and int(got.max()) < V
+    ref = logits.argmax(-1)
+    chosen = logits.gather(1, got[:, None])[:, 0]
+    assert bool((chosen >= logits.max(-1).values - 1e-3).all()), (chosen - logits.max(-1).values).min().item()
+    print(f"[ctc walk] {int((got != ref).sum())} of {M} rows differ from torch.argmax (near-ties)")
+    assert int((got != ref).sum()) <= max(1, M // 200)
+    assert bool((ids[M:] == -7).all())
+
+
 @pytest.mark.parametrize("M", [1000, 77])
 def test_rows_glu_fused(lib, M):
     """Round 4: attention output -> linear_out + residual -> norm_conv -> pointwise_conv1 + GLU as ONE row-block launch
