@@ -160,6 +160,54 @@ def test_fragment_major_weight_units_follow_the_header():
         pack_k_units(torch.zeros(60, 256))
 
 
+def test_row_block_operand_streams_follow_the_header():
+    """pack_ffn_rows_w1 / _w2, pack_rows_proj, pack_rows_glu (the 512-wide model's row-block launches, csrc/ffn_rows.hip)
+    against the layouts include/espnet_amd.h states at EmFfnRowsArgs: wave w's fragment i of a 128-row chunk is the 1 KiB at
+    chunk + 8 KiB * i + 1 KiB * w, lane 16 lg + lr holding 8 consecutive k (W1, the projection) or its own hidden columns (W2)."""
+    from espnet_amd.asr.encoder.conformer_encoder import (glu_chunk_order, pack_ffn_rows_w1, pack_ffn_rows_w2,
+                                                          pack_rows_glu, pack_rows_proj)
+
+    ff = 256
+    w1 = torch.arange(ff * 512, dtype=torch.float32).reshape(ff, 512)
+    flat = pack_ffn_rows_w1(w1).reshape(-1)
+    for c in range(ff // 128):
+        for ks in (0, 7, 15):
+            for wv in (0, 3, 7):
+                for lane in (0, 5, 16, 37, 63):
+                    lg, lr = lane >> 4, lane & 15
+                    off = c * 65536 + ks * 4096 + wv * 512 + lane * 8  # elements: 128 KiB chunk = 65 536 bf16
+                    want = w1[128 * c + 16 * wv + lr, 32 * ks + 8 * lg: 32 * ks + 8 * lg + 8]
+                    assert torch.equal(flat[off:off + 8], want), (c, ks, wv, lane)
+    w2 = torch.arange(512 * ff, dtype=torch.float32).reshape(512, ff) + 1.0
+    flat = pack_ffn_rows_w2(w2).reshape(-1)
+    for c in range(ff // 128):
+        for s in range(4):
+            for cf in range(4):
+                for wv in (0, 2, 7):
+                    for lane in (0, 9, 31, 48, 63):
+                        lg, lr = lane >> 4, lane & 15
+                        off = c * 65536 + (s * 4 + cf) * 4096 + wv * 512 + lane * 8
+                        cols = [128 * c + 32 * s + 16 * (e >> 2) + 4 * lg + (e & 3) for e in range(8)]
+                        assert torch.equal(flat[off:off + 8], w2[64 * wv + 16 * cf + lr, cols]), (c, s, cf, wv, lane)
+    wp = torch.arange(512 * 512, dtype=torch.float32).reshape(512, 512)
+    flat = pack_rows_proj(wp).reshape(-1)
+    for ks in (0, 9, 15):
+        for cf in range(4):
+            for wv in (0, 5, 7):
+                for lane in (0, 21, 63):
+                    lg, lr = lane >> 4, lane & 15
+                    off = (ks * 4 + cf) * 4096 + wv * 512 + lane * 8
+                    assert torch.equal(flat[off:off + 8], wp[64 * wv + 16 * cf + lr, 32 * ks + 8 * lg: 32 * ks + 8 * lg + 8])
+    # GLU: chunk 2 j = the value rows of output columns 128 j .., chunk 2 j + 1 their gate rows (F.glu: value | gate halves)
+    order = glu_chunk_order(512)
+    assert order[:128].tolist() == list(range(128)) and order[128:256].tolist() == list(range(512, 640))
+    assert order[256:384].tolist() == list(range(128, 256)) and sorted(order.tolist()) == list(range(1024))
+    pw1 = torch.arange(1024 * 512, dtype=torch.float32).reshape(1024, 512)
+    assert torch.equal(pack_rows_glu(pw1), pack_ffn_rows_w1(pw1[order]))
+    for f, wt in ((pack_ffn_rows_w1, w1), (pack_ffn_rows_w2, w2), (pack_rows_proj, wp)):  # permutations
+        assert torch.equal(f(wt).reshape(-1).sort().values, wt.reshape(-1).sort().values)
+
+
 def test_rel_pos_table_matches_oracle():
     from espnet_amd.asr.encoder.conformer_encoder import rel_pos_table
     from oracle.conformer import rel_pos_emb
