@@ -487,7 +487,8 @@ def test_gemm_head_layout_epilogues(lib, B, T, h):
 
 
 @pytest.mark.parametrize("M,ff,ln_mode,pre", [(200, 256, 1, False), (1000, 2048, 1, False), (1000, 2048, 2, False),
-                                              (64, 1024, 2, False), (1000, 2048, 2, True), (333, 512, 1, True)])
+                                              (64, 1024, 2, False), (1000, 2048, 2, True), (333, 512, 1, True),
+                                              (17000, 256, 1, True)])  # (266 workgroups: a second round on 256 CUs)
 def test_ffn_rows_fused(lib, M, ff, ln_mode, pre):
     """Round 4: the 512-wide model's feed-forward module as ONE row-block launch (csrc/ffn_rows.hip: w_1 + Swish + w_2 +
     residual + the LayerNorm(s) that follow, positionwise_feed_forward.py:30-32 inside encoder_layer.py:111-121 / :160-171)
