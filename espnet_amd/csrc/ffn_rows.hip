@@ -1,4 +1,8 @@
-// Row-block fused feed-forward module for the 512-wide Conformer (bf16 MFMA): one launch computes
+// Row-block launches of the 512-wide Conformer (bf16 MFMA): the block's row-local operators as three launches of 64-row
+// workgroups (template flags, see the kernel):  [macaron FFN + residual + norm_mha]   [linear_out + residual + norm_conv +
+// pointwise_conv1 + GLU] (PRE, MAIN = EM_ROWS_GLU)   [pointwise_conv2 + residual + norm_ff + FFN + residual + norm_final +
+// the next LayerNorm] (PRE; POST: the CTC head's arg-max walked behind the stack's last launch).  The core is the
+// feed-forward module: one launch computes
 //     x += scale * (W2 . swish(W1 . xn + b1) + b2);   xn' = LayerNorm(x)          (ln_mode 1)
 //     x  = LayerNorm_1(x + scale * (...));            xn' = LayerNorm_2(x)        (ln_mode 2)
 // for 64 consecutive rows per workgroup, i.e. the three launches  GEMM(Swish) -> GEMM(+residual) -> LayerNorm  of the
