@@ -9,6 +9,8 @@
 #   sa-ab        decoder self-attention: waves per row x rows per workgroup (ESPNET_AMD_SA_SPLIT / _GROUP), label-step A/B
 #   attn-stamps  relpos_attn2 cycle stamps (EM_ATTN2_STAMPS)
 #   greedy-pmc   SQ counters (wave cycles, waits, MFMA busy, LDS bank conflicts) of the greedy step's main kernels
+#   ffn-rows     round 4: row-block launches of the 512-wide model - kernel + large e2e tests, in-call A/B (ESPNET_AMD_NO_FFN_ROWS), stamps, table
+#   ffn-dbg      ... where ffn_rows_kernel's time goes: developer builds (no weight requests / no LDS operand reads / both) and cycle stamps
 set -u
 what=${1:-bench}; tag=${2:-r03}; out=$PWD/gpurun_out/$tag; mkdir -p "$out"
 export TMPDIR=/tmp
