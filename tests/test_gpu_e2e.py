@@ -139,6 +139,44 @@ def test_encode_bfloat16_within_tolerance(name, fused):
     assert dist <= 0.03 * max(ref_len, 1) + 1
 
 
+def test_large_rows_path_at_b64_matches_reference():
+    """Round 4: the 512-wide model's row-block launches (csrc/ffn_rows.hip: three per block, the CTC arg-max walked behind the
+    last one) are taken only when a batch's rows fill the chip - none of the small-batch fixtures reaches them.  Here the
+    reference's `large_10s` utterance is encoded as a batch of 64 copies (M = 15 936 rows: the bench's shape): every row must
+    meet the reference's encoder output and per-frame CTC ids under the same bounds as the B = 1 test, all rows must be
+    bit-identical (a workgroup sees nothing but its own rows), and the per-operator sequence must agree to bf16 round-off."""
+    g = load_golden("large_10s")
+    model = build(g, "bfloat16")
+    speech, lens = golden_speech(g)
+    B = 64
+    wav = speech[:1].repeat(B, 1).cuda()
+    ln = [int(lens[0])] * B
+    model.encoder.fused = True
+    st = model.encode_device(wav, ln)
+    assert model.encoder.last_ctc_ids is not None, "the row-block path (with its CTC walk) was not taken at B = 64"
+    ke = int(g["enc_keep_every"])
+    enc = st.enc_out.float().cpu()
+    for k in (1, 31, 63):
+        assert torch.equal(enc[0], enc[k]), k
+    err = np.abs(enc[0].numpy()[::ke] - g["enc_out"][0])
+    print(f"[large_10s x 64, row-block path] bf16 encoder err max {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max() < 4e-2 and err.mean() < 6e-3
+    ids, tokens, tlens = model.greedy_ctc_device(st)
+    ids = ids.cpu().numpy()
+    assert (ids == ids[:1]).all()
+    T = int(g["enc_olens"][0])
+    diff = ids[0, :T] != g["ctc_ids"][0, :T]
+    worst = margin_report("large_10s x 64 row-block", g["ctc_margin"][0, :T][diff])
+    assert worst < BF16_MARGIN, f"a frame the reference decides by {worst:.3e} flipped in bf16"
+    assert diff.mean() < 0.03
+    model.encoder.fused = False  # the per-operator sequence on the same batch
+    st2 = model.encode_device(wav, ln)
+    assert model.encoder.last_ctc_ids is None
+    d = (st2.enc_out.float().cpu()[0] - enc[0]).abs()
+    print(f"[large_10s x 64] row-block vs per-operator bf16: max {d.max():.3e} mean {d.mean():.3e}")
+    assert d.max() < 0.08 and d.mean() < 6e-3
+
+
 @pytest.mark.parametrize("dtype,fused", [("float32", False), ("bfloat16", True), ("bfloat16", False), ("bfloat16", "fold")])
 def test_peaked_posteriors_tokens_exact(dtype, fused):
     """`small_10s_peaked`: the small model with a CTC head fitted to the reference's encoder output (reference
