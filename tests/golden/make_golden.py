@@ -31,6 +31,9 @@ HERE = Path(__file__).resolve().parent
 REPO = HERE.parent.parent
 sys.dont_write_bytecode = True
 sys.path[:0] = [str(HERE / "_shims"), "/root/reference", str(REPO)]
+# where the fixtures are written: tests/golden itself, or a scratch directory (tests/test_cpu_golden_regen.py re-runs cheap
+# cases into a tmpdir and compares them with the committed files bit for bit)
+OUT = Path(os.environ.get("GOLDEN_OUT") or HERE)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -348,7 +351,7 @@ def run_encode_case(name, conf, vocab, wseed, utt_ids, lengths, keep_every=1, wi
     for b, t in enumerate(toks):
         g1[b, : len(t)] = t
     out["g1_tokens"] = g1
-    np.savez_compressed(HERE / f"{name}.npz", **out)
+    np.savez_compressed(OUT / f"{name}.npz", **out)
     print(f"[{name}] done in {time.time()-t0:.1f}s feats{tuple(feats.shape)} enc{tuple(enc.shape)} "
           f"olens={olens.tolist()} g1_lens={out['g1_lens'].tolist()} "
           f"min margin={out['ctc_margin'].min():.2e}")
@@ -446,7 +449,7 @@ def run_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_weigh
         ref_seconds=np.array(t_dec),
     )
     out.update(extra)
-    np.savez_compressed(HERE / f"{name}.npz", **out)
+    np.savez_compressed(OUT / f"{name}.npz", **out)
     print(f"[{name}] done in {time.time()-t0:.1f}s (Speech2Text {t_dec:.1f}s) T={enc.shape[1]} "
           f"best len={len(results[0][3].yseq)} score={float(results[0][3].score):.4f} keys={keys}")
 
@@ -487,7 +490,7 @@ def run_cli_case(name, conf, vocab, wseed, utts, beam, ctc_weight, nbest):
         for f in sorted((td / "out").rglob("*")):
             if f.is_file():
                 files[str(f.relative_to(td / "out"))] = f.read_text()
-    np.savez_compressed(HERE / f"{name}.npz", config_yaml=np.array(cfg_text), vocab=np.array(vocab),
+    np.savez_compressed(OUT / f"{name}.npz", config_yaml=np.array(cfg_text), vocab=np.array(vocab),
                         wseed=np.array(wseed), utts=np.array(json.dumps(utts)), beam=np.array(beam),
                         ctc_weight=np.array(ctc_weight), nbest=np.array(nbest),
                         state_shapes=np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
@@ -550,7 +553,7 @@ def run_lm_search_case(name, conf, vocab, wseed, utt_id, n_samples, beam, ctc_we
                score_keys=np.array(json.dumps(keys)),
                scores=np.array([[float(h.scores[k]) for k in keys] for _, _, _, h in results]),
                token_int_best=np.array(results[0][2], dtype=np.int64))
-    np.savez_compressed(HERE / f"{name}.npz", **out)
+    np.savez_compressed(OUT / f"{name}.npz", **out)
     print(f"[{name}] done in {time.time()-t0:.1f}s T={enc.shape[1]} best len={len(results[0][3].yseq)} "
           f"score={float(results[0][3].score):.4f} keys={keys}")
 
@@ -601,7 +604,7 @@ def run_streaming_case(name, enc_conf, wseed, utt_id, n_samples, chunk_frames, k
                ys=ys[::keep_every].numpy().copy(), ys_oneshot=y1[::keep_every].numpy().copy(),
                keep_every=np.array(keep_every), ys_total=np.array(ys.size(0)),
                ys_oneshot_total=np.array(y1.size(0)))
-    np.savez_compressed(HERE / f"{name}.npz", **out)
+    np.savez_compressed(OUT / f"{name}.npz", **out)
     print(f"[{name}] done in {time.time()-t0:.1f}s feats{tuple(feats.shape)} out lens {lens} "
           f"total {ys.size(0)} oneshot {y1.size(0)}")
 
@@ -736,7 +739,7 @@ def run_stream_search_case(name, vocab, wseed, utt_id, n_samples, chunk_samples,
     logging.getLogger().removeHandler(h)
     enc_all = torch.cat(enc_chunks, 0) if enc_chunks else torch.zeros(0, 64)
     np.savez_compressed(
-        HERE / f"{name}.npz", config_yaml=np.array(cfg_text), vocab=np.array(vocab), wseed=np.array(wseed),
+        OUT / f"{name}.npz", config_yaml=np.array(cfg_text), vocab=np.array(vocab), wseed=np.array(wseed),
         utt_id=np.array(utt_id), n_samples=np.array(n_samples), chunk_samples=np.array(chunk_samples),
         beam=np.array(beam), ctc_weight=np.array(ctc_weight), nbest=np.array(nbest), penalty=np.array(penalty),
         tweaks=np.array(json.dumps(tweaks or [])),
@@ -793,7 +796,7 @@ def run_stream_frontend_case(name, utt_id, n_samples, chunk_samples, use_global_
                frontend_conf=np.array(json.dumps(fc)), use_global_mvn=np.array(use_global_mvn),
                melmat=model.frontend.logmel.melmat.numpy(), feat_lens=np.array(lens),
                feats=torch.cat(feats, 0).numpy(), **extra)
-    np.savez_compressed(HERE / f"{name}.npz", **out)
+    np.savez_compressed(OUT / f"{name}.npz", **out)
     print(f"[{name}] done in {time.time()-t0:.1f}s lens {lens}")
 
 
@@ -864,6 +867,10 @@ CASES = {
                                            with_blocks=True),
     # large model encoder, 10 s
     "large_10s": lambda: run_encode_case("large_10s", LARGE, 5000, 13, [6], [160000], keep_every=8),
+    # ... and with a ctc_lo FITTED to the reference's encoder output (peaked posteriors; 249 frames < 512 dimensions): the
+    # 512-wide model's row-block launches + the CTC arg-max walk behind them must return the reference's ids exactly
+    "large_10s_peaked": lambda: run_encode_case("large_10s_peaked", LARGE, 5000, 13, [6], [160000], keep_every=8,
+                                                peaked_seed=9),
     # G2: width-1 CTC prefix search (decode_ctc_bs1.yaml), short audio
     "small_g2_3s": lambda: run_search_case("small_g2_3s", SMALL, 5000, 11, 7, 48000, 1, 1.0, 1,
                                            keep_every=2),

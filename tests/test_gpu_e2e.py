@@ -177,6 +177,32 @@ def test_large_rows_path_at_b64_matches_reference():
     assert d.max() < 0.08 and d.mean() < 6e-3
 
 
+@pytest.mark.parametrize("B,fused", [(64, True), (64, False), (1, True)])
+def test_large_peaked_posteriors_ids_exact(B, fused):
+    """`large_10s_peaked` (round 5): the 512-wide model with a CTC head fitted to the reference's encoder output (reference
+    top-2 margins all > 4).  As a batch of 64 copies the encoder runs through the row-block launches (csrc/ffn_rows.hip)
+    with the CTC arg-max walked behind the last one: per-frame ids and G1 tokens must be the reference's EXACTLY
+    (asr/ctc.py:207-215, asr_inference.py:574-575), on every row; likewise through the per-operator sequence and at B = 1."""
+    g = load_golden("large_10s_peaked")
+    assert float(g["ctc_margin"].min()) > 1.0
+    model = build(g, "bfloat16")
+    model.encoder.fused = fused
+    speech, lens = golden_speech(g)
+    wav = speech[:1].repeat(B, 1).cuda()
+    st = model.encode_device(wav, [int(lens[0])] * B)
+    if B == 64 and fused:
+        assert model.encoder.last_ctc_ids is not None, "the row-block path (with its CTC walk) was not taken at B = 64"
+    ids, tokens, tlens = model.greedy_ctc_device(st)
+    n_fr = int(g["enc_olens"][0])
+    want_ids = g["ctc_ids"][0, :n_fr].tolist()
+    want = g["g1_tokens"][0, : int(g["g1_lens"][0])].tolist()
+    assert len(want) >= 20
+    for b in sorted({0, B // 2, B - 1}):
+        assert ids[b, :n_fr].cpu().tolist() == want_ids, b
+        assert tokens[b, : int(tlens[b])].cpu().tolist() == want, b
+    assert (ids.cpu() == ids[:1].cpu()).all()
+
+
 @pytest.mark.parametrize("dtype,fused", [("float32", False), ("bfloat16", True), ("bfloat16", False), ("bfloat16", "fold")])
 def test_peaked_posteriors_tokens_exact(dtype, fused):
     """`small_10s_peaked`: the small model with a CTC head fitted to the reference's encoder output (reference

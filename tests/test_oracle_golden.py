@@ -49,7 +49,7 @@ def test_stft_olens_formula():
     assert (feats[1, 8:] == 0).all()
 
 
-@pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "small_10s_peaked", "small_10s_midmargin", "large_10s",
+@pytest.mark.parametrize("name", ["tiny_blocks", "small_ragged", "small_10s", "small_10s_peaked", "small_10s_midmargin", "large_10s", "large_10s_peaked",
                                   "sub6_small_6s", "sub8_small_6s", "legacy_small_5s", "legacy_small_12s"])
 def test_frontend_and_encoder_match_reference(name):
     g = load_golden(name)
