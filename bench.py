@@ -204,12 +204,13 @@ def cpu_baseline_beam(model, beam, ctc_weight, budget_s=15.0):
                       f"(frontend + encoder + beam {beam} search, 249 steps), no warm-up"}
 
 
-def beam_vs_oracle(model, enc_row, hyps, beam, ctc_weight):
+def beam_vs_oracle(model, enc_row, hyps, beam, ctc_weight, noise_seeds=4, noise_sigma=2e-3):
     """Parity of the TIMED search mode on one utterance of the bench batch, with the oracle as the checker (part of the
     cpu_baseline leg: host cores, never the thing measured): every hypothesis the device returned re-scored
     teacher-forced under the oracle's f32 scorers over the encoder rows the device search consumed
-    (oracle.beam_search.rescore_batch), and the oracle's own f32 search over the same rows (tests/test_gpu_fullsize.py::
-    test_beam10_b16_rows_bf16_vs_oracle asserts the same quantities on three rows)."""
+    (oracle.beam_search.rescore_batch), the oracle's own f32 search over the same rows, and - `noise_seeds` > 0 - the
+    oracle search's OWN path noise at the device's per-entry error level (oracle.beam_search.path_noise_losses: the
+    yardstick tests/test_gpu_fullsize.py::test_beam10_b16_rows_bf16_vs_oracle holds `best_score_loss` against)."""
     from oracle import beam_search as ob
 
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
@@ -220,22 +221,37 @@ def beam_vs_oracle(model, enc_row, hyps, beam, ctc_weight):
     with torch.no_grad():
         ref = ob.rescore_batch(sd, e, ys, dec.heads, dec.num_blocks, ctc_weight, VOCAB - 1)
         orc = ob.beam_search(sd, e, dec.heads, dec.num_blocks, beam, ctc_weight, sos=VOCAB - 1, eos=VOCAB - 1)
+        losses = None
+        if noise_seeds > 0:
+            losses, _ = ob.path_noise_losses(sd, e, dec.heads, dec.num_blocks, beam, ctc_weight, VOCAB - 1, noise_sigma,
+                                             list(range(noise_seeds)), clean=orc)
     err = {k: max(abs(float(h.scores[k]) - r[k]) / max(1, r["n_scored"]) for h, r in zip(hyps, ref))
            for k in ("decoder", "ctc")}
     mine = {tuple(y) for y in ys}
-    best = max(r["score"] for r in ref)
-    return {"utterance": 0, "hypotheses_rescored": len(ys),
-            "max_abs_err_per_token": {k: round(v, 6) for k, v in err.items()},
-            "device_best_oracle_score": round(best, 4), "oracle_best_score": round(orc[0]["score"], 4),
-            "best_score_loss": round(orc[0]["score"] - best, 4),
-            "oracle_nbest_span": round(orc[0]["score"] - orc[-1]["score"], 4),
-            "oracle_hypotheses_in_device_nbest": sum(tuple(o["yseq"]) in mine for o in orc),
-            "oracle_hypotheses": len(orc), "checker_seconds": round(time.perf_counter() - t0, 1),
-            "what": "timed dtype against the oracle's f32 scorers on utterance 0 of the batch: per scored token and "
-                    "scorer |device - oracle| along the device's own token paths; best_score_loss = oracle best minus the "
-                    "oracle's score of the device's best (what reduced-precision pruning lost; random-init posteriors "
-                    "are flat: the oracle's own n-best span is beside it); exact n-best on peaked posteriors is asserted "
-                    "by tests/test_gpu_search.py::test_search_bf16_peaked_returns_reference_nbest_exactly"}
+    kb = max(range(len(ref)), key=lambda k: ref[k]["score"])
+    best = ref[kb]["score"]
+    out = {"utterance": 0, "hypotheses_rescored": len(ys),
+           "max_abs_err_per_token": {k: round(v, 6) for k, v in err.items()},
+           "device_best_oracle_score": round(best, 4), "oracle_best_score": round(orc[0]["score"], 4),
+           "best_score_loss": round(orc[0]["score"] - best, 4),
+           "token_edit_distance": ob.token_edit_distance(ys[kb][1:-1], orc[0]["yseq"][1:-1]),
+           "oracle_best_tokens": len(orc[0]["yseq"]) - 2,
+           "oracle_nbest_span": round(orc[0]["score"] - orc[-1]["score"], 4),
+           "oracle_hypotheses_in_device_nbest": sum(tuple(o["yseq"]) in mine for o in orc),
+           "oracle_hypotheses": len(orc)}
+    if losses is not None:
+        out["oracle_path_noise"] = {"sigma": noise_sigma, "seeds": noise_seeds, "best_score_losses": [round(x, 3) for x in losses],
+                                    "what": "the ORACLE's own search with N(0, sigma^2) on every log-probability, its best "
+                                            "re-scored without noise: what a perturbation of the device's size costs the "
+                                            "search itself (negative = the perturbed search ended better than the clean one)"}
+    out["checker_seconds"] = round(time.perf_counter() - t0, 1)
+    out["what"] = ("timed dtype against the oracle's f32 scorers on utterance 0 of the batch: per scored token and "
+                   "scorer |device - oracle| along the device's own token paths; best_score_loss = oracle best minus the "
+                   "oracle's score of the device's best (what reduced-precision pruning lost; random-init posteriors "
+                   "are flat: the oracle's own n-best span and path noise are beside it); token_edit_distance between "
+                   "the device's best and the oracle's best hypothesis; exact n-best on peaked posteriors is asserted "
+                   "by tests/test_gpu_search.py::test_search_bf16_peaked_returns_reference_nbest_exactly")
+    return out
 
 
 def run_stream(dtype, steps, warmup, chunk=10240, stream_beam=1, cpu_base=True):
@@ -489,7 +505,7 @@ def decoder_step_bytes(model, B, W, T, NC, steps, es):
     return w + mem + cache + logits + ctc
 
 
-def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True):
+def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, want_oracle=False):
     """configs[2] / configs[3]'s per-GPU batch: Conformer-large + 6-layer decoder, joint CTC/attention beam search."""
     from espnet_amd import distributed as D
     from espnet_amd.nets.batch_beam_search import build_beam_search
@@ -570,9 +586,11 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True):
         res["search"]["roofline"]["traffic_source"] = note
     if cpu_base:
         res["cpu_baseline"] = cpu_baseline_beam(model, beam, args.ctc_weight)
+    if (cpu_base or want_oracle) and world == 1:
         try:
             key = "bf16_vs_oracle" if args.dtype == "bfloat16" else "f32_vs_oracle"
-            res[key] = beam_vs_oracle(model, last["enc0"], last["nbest0"], beam, args.ctc_weight)
+            res[key] = beam_vs_oracle(model, last["enc0"], last["nbest0"], beam, args.ctc_weight,
+                                      noise_seeds=4 if cpu_base else 0)
         except Exception as e:  # noqa: BLE001 - a checker must not cost the line
             res["bf16_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"}
     return res
@@ -1098,7 +1116,8 @@ def main():
                 a2 = argparse.Namespace(**vars(args))
                 a2.model = "large"
                 r = run_beam(a2, dev, Bb, 10, steps, 1, cpu_base=cpu and not args.no_cpu_baseline,
-                             want_traffic=cpu)  # counters for the configs[2] leg only
+                             want_traffic=cpu,  # counters for the configs[2] leg only
+                             want_oracle=not args.no_cpu_baseline)  # ... the oracle check of utterance 0 for both
                 r.pop("model")
                 el_, tok_ = r.pop("elapsed"), r.pop("tokens")
                 torch.cuda.empty_cache()

@@ -26,6 +26,10 @@ from espnet_amd.nets_utils import (SUBSAMPLING_CONVS, SUBSAMPLING_MIN_FRAMES, co
                                    conv_out_size)
 
 _POS_PROJ_LOCK = threading.Lock()
+# the packed weights struct carries the per-call `ctc_ids` pointer: setting it and launching the encoder is one critical
+# section for host threads that encode concurrently; the ids a call produced are kept per THREAD
+_ENC_CALL_LOCK = threading.Lock()
+_TLS = threading.local()
 
 LN_EPS = 1e-12  # transformer/layer_norm.py:23
 
@@ -675,30 +679,43 @@ class ConformerEncoder(torch.nn.Module):
         enc_flags = (L.EM_ENC_ISOLATE_UTTS if isolate else 0) | (0 if _fused_enabled(self) else L.EM_ENC_NO_FUSED)
         if getattr(self, "fold_c", None) if getattr(self, "fold_c", None) is not None else os.environ.get("ESPNET_AMD_FOLD") == "1":
             enc_flags |= L.EM_ENC_FOLD_C  # block<C|D|...>: two launches per block (opt-in: measured no faster)
-        if hasattr(pk["w"], "ctc_ids"):
-            pk["w"].ctc_ids = None
-            if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "ctc_units", 0) > 0:
-                ids = torch.empty(B, T, dtype=torch.int32, device=dev)
-                pk["w"].ctc_ids = ids.data_ptr()
-                plan = lib.em_conformer_encode_plan_for(self.em_dtype, C.byref(pk["w"]), enc_flags, B, T_f)
-                if plan < 0:
-                    L.check(plan, "em_conformer_encode_plan")
-                if plan & L.EM_ENC_PLAN_CTC_IDS:
-                    self.last_ctc_ids = ids
-                else:
-                    pk["w"].ctc_ids = None
         pos = self._pos_emb(T, dev)
         if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "wpos_all", None):
             # linear_pos of every block depends on T and the weights only: projected once per length, handed over ready
             pos = self._pos_projected(T, dev, pk, pos)
             enc_flags |= L.EM_ENC_POS_PROJECTED
-        rc = getattr(lib, self._ENC_FN)(
-            self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
-            L.ptr(olens_dev), B, T_f, L.ptr(pos), L.ptr(ws),
-            ws.numel(), L.ptr(enc_out), L.ptr(enc_act),
-            enc_flags, L.current_stream_ptr())
+        with _ENC_CALL_LOCK:
+            if hasattr(pk["w"], "ctc_ids"):
+                pk["w"].ctc_ids = None
+                if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "ctc_units", 0) > 0:
+                    ids = torch.empty(B, T, dtype=torch.int32, device=dev)
+                    pk["w"].ctc_ids = ids.data_ptr()
+                    plan = lib.em_conformer_encode_plan_for(self.em_dtype, C.byref(pk["w"]), enc_flags, B, T_f)
+                    if plan < 0:
+                        L.check(plan, "em_conformer_encode_plan")
+                    if plan & L.EM_ENC_PLAN_CTC_IDS:
+                        self.last_ctc_ids = ids
+                    else:
+                        pk["w"].ctc_ids = None
+            rc = getattr(lib, self._ENC_FN)(
+                self.em_dtype, C.byref(pk["w"]), L.ptr(feats), L.ptr(mvn_partial), L.ptr(flens_dev),
+                L.ptr(olens_dev), B, T_f, L.ptr(pos), L.ptr(ws),
+                ws.numel(), L.ptr(enc_out), L.ptr(enc_act),
+                enc_flags, L.current_stream_ptr())
         L.check(rc, self._ENC_FN)
         return enc_out, enc_act, olens, olens_dev
+
+    @property
+    def last_ctc_ids(self):
+        """Per-frame CTC arg-max ids of the calling thread's last `forward_device` (None when the launch sequence taken
+        does not produce them)."""
+        return getattr(_TLS, "ids", {}).get(id(self))
+
+    @last_ctc_ids.setter
+    def last_ctc_ids(self, v):
+        if not hasattr(_TLS, "ids"):
+            _TLS.ids = {}
+        _TLS.ids[id(self)] = v
 
     def forward(self, xs_pad: torch.Tensor, ilens: torch.Tensor, prev_states: torch.Tensor = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:

@@ -389,7 +389,14 @@ def sharded_decode_rank(decode_claimed, keys, output_dir, nbest: int, max_len: i
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     shard_dir = Path(output_dir) / f"output.{rank + 1}"
-    claim = D.WindowClaimer(D.SharedCounter(D.work_store() if world > 1 else None, "asr_inference_windows"))
+    claim = D.WindowClaimer(D.SharedCounter(D.work_store() if world > 1 else None, D.call_key("asr_inference_windows")))
+    # rows of an earlier run into the same output_dir must not be taken for this rank's (the writer opens its files
+    # lazily: a rank that claims no window would never truncate them)
+    if shard_dir.is_dir():
+        import shutil
+
+        for sub in shard_dir.glob("*best_recog"):
+            shutil.rmtree(sub, ignore_errors=True)
     err, stats, rec = None, {}, None
     try:
         mine, stats = decode_claimed(claim, shard_dir)
@@ -460,7 +467,8 @@ def _inference_rank(kw: dict):
         ti, sc = shard_dir / "1best_recog" / "token_int", shard_dir / "1best_recog" / "score"
         rows = {ln.partition(" ")[0]: ln.partition(" ")[2] for ln in ti.read_text().splitlines()} if ti.exists() else {}
         srow = {ln.partition(" ")[0]: ln.partition(" ")[2] for ln in sc.read_text().splitlines()} if sc.exists() else {}
-        return {k: ([int(t) for t in v.split()], _first_float(srow.get(k, "0"))) for k, v in rows.items()}, st
+        mine = {k for w in claim.claimed for k in keys[w * window : (w + 1) * window]}  # only what THIS call decoded
+        return {k: ([int(t) for t in v.split()], _first_float(srow.get(k, "0"))) for k, v in rows.items() if k in mine}, st
 
     hyps, st = sharded_decode_rank(decode_claimed, keys, kw["output_dir"], nbest, 4096, torch.device("cuda"), window)
     return dict(st, utterances_total=len(hyps))

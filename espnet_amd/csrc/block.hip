@@ -238,10 +238,11 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         q = pq.a + pq.b + (ps.a - ps.b) * (ps.a - ps.b) * (1.0f / 64.0f);
         s = ps.a + ps.b;
       }
-      if (lg == 0) {
-        red[nf * 32 + mi * 16 + lr] = s;        // sum over this wave's 64 columns
-        red[128 + nf * 32 + mi * 16 + lr] = q;  // sum of squares about their mean
-      }
+      // (all four lane groups of a row hold the same totals - the pair updates are symmetric - and all of them store:
+      // no exec-masked branch, so the LayerNorm's first half is ONE scheduling region and the weight requests issued in
+      // front of it can be dealt between its VALU instructions, see ln_to_act)
+      red[nf * 32 + mi * 16 + lr] = s;        // sum over this wave's 64 columns
+      red[128 + nf * 32 + mi * 16 + lr] = q;  // sum of squares about their mean
     }
   };
   auto ln_finish = [&](const float* red, float mean[2], float rstd[2]) {
@@ -261,19 +262,37 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       rstd[mi] = y0 * (1.5f - 0.5f * var * y0 * y0);
     }
   };
-  auto ln_stats = [&](float mean[2], float rstd[2], int code) {
+  // `pre1()` / `pre2()` issue weight requests of the stage that FOLLOWS the LayerNorm (ring slots that are free by now):
+  // pre1 rides in the LayerNorm's first half (N1 wave-wide loads between the ~120 VALU instructions of the partial sums),
+  // pre2 in its second half (statistics, normalisation, bf16 tile).  Round 5: until then the requests were one cluster in
+  // front of the LayerNorm - 24 or 32 loads of 1 KiB per wave, four waves: 1 500 - 2 000 cycles in the ISSUE alone (a CU
+  // ingests 64 B/clk and the queue is short), during which the wave's LayerNorm arithmetic waited behind them although it
+  // needs none of them: every hand-over between two GEMMs cost stream time + LayerNorm time (4 - 6 K cycles, profiles/
+  // r03b_block_stamps_fine.txt) instead of the larger of the two.  sched_group_barrier pins the deal: left alone hipcc
+  // clusters the loads first.
+  auto no_pre = [] {};
+  auto ln_stats = [&](float mean[2], float rstd[2], int code, auto&& pre1, auto n1c) {
+    constexpr int N1 = decltype(n1c)::value;
     float* const red = red0 + (nln & 1) * 256;
     ++nln;
+    pre1();
     ln_partials(xr, red);
+    if constexpr (N1 > 0 && !(EM_BLOCK_VAR & 32)) {
+#pragma unroll
+      for (int i = 0; i < N1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // one weight request
+        __builtin_amdgcn_sched_group_barrier(0x002, N1 > 16 ? 4 : 7, 0);  // ... and its share of the partial sums
+      }
+    }
     fstamp(11);
     bar(code);
     fstamp(12);
     ln_finish(red, mean, rstd);
   };
   // y = LN(x; g, b) with g, b at float offsets go / bo of parameter buffer pb
-  auto ln_apply = [&](const float* pb, int go, int bo, float4 y[2][4], int code) {
+  auto ln_apply_pre = [&](const float* pb, int go, int bo, float4 y[2][4], int code, auto&& pre1, auto n1c) {
     float mean[2], rstd[2];
-    ln_stats(mean, rstd, code);
+    ln_stats(mean, rstd, code, pre1, n1c);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const float4 g4 = *(const float4*)(pb + go + 64 * f + ncol);
@@ -287,11 +306,17 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       }
     }
   };
+  auto ln_apply = [&](const float* pb, int go, int bo, float4 y[2][4], int code) {
+    ln_apply_pre(pb, go, bo, y, code, no_pre, std::integral_constant<int, 0>{});
+  };
   // LN(x) -> bf16 -> abuf -> activation fragments.  One more barrier, carrying `code` (the parameter reads of
   // this LayerNorm precede it).
-  auto ln_to_act = [&](const float* pb, int go, int bo, int code) {
+  auto ln_to_act_pre = [&](const float* pb, int go, int bo, int code, auto&& pre1, auto n1c, auto&& pre2, auto n2c) {
+    constexpr int N2 = decltype(n2c)::value;
     float4 y[2][4];
-    ln_apply(pb, go, bo, y, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    ln_apply_pre(pb, go, bo, y, 0, pre1, n1c);
+    pre2();
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -299,10 +324,20 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         bf16x4 pk = {(bf16)y[mi][f].x, (bf16)y[mi][f].y, (bf16)y[mi][f].z, (bf16)y[mi][f].w};
         *(bf16x4*)(abuf + f * 4096 + mi * 2048 + tile_wr) = pk;
       }
+    if constexpr (N2 > 0 && !(EM_BLOCK_VAR & 32)) {
+#pragma unroll
+      for (int i = 0; i < N2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, N2 > 8 ? 6 : 10, 0);
+      }
+    }
     fstamp(13);
     bar(code);
     fstamp(14);
     load_act();
+  };
+  auto ln_to_act = [&](const float* pb, int go, int bo, int code) {
+    ln_to_act_pre(pb, go, bo, code, no_pre, std::integral_constant<int, 0>{}, no_pre, std::integral_constant<int, 0>{});
   };
   // ---- units: weight fragments go global memory -> registers, THREE UNITS AHEAD of the MFMAs ------------
   // A unit is 32 contiguous KiB, fragment-major; this wave's eight fragments are eight 1 KiB lines at
@@ -669,8 +704,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
     proj_resid(pb0, 0, a.wout);
     fstamp(50);
-    k_pre(a.pw1f, 8);   // (x is stored at the end of the kernel, behind the last weight request: see the A part)
-    ln_to_act(pb0, 256, 512, 0);
+    // (x is stored at the end of the kernel, behind the last weight request: see the A part)
+    ln_to_act_pre(pb0, 256, 512, 0, [&] { read_unit(a.pw1f, 0, ring[0]); read_unit(a.pw1f, 1, ring[1]); }, std::integral_constant<int, 16>{},
+                  [&] { read_unit(a.pw1f, 2, ring[2]); }, std::integral_constant<int, 8>{});
     fstamp(15);
     // pointwise_conv1 + GLU (convolution.py:66-69): unit 2j = value rows 64j.., unit 2j+1 = their gates
     f32x4 v[2], gt[2];
@@ -947,14 +983,20 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]
     proj_resid(pb0, 0, a.pw2);                     // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
     stamp(10);
-    ffn_pre(a.ff_w1, a.ff_w2);
-    ln_to_act(pb0, 256, 512, 0);                   // norm_ff
+    ln_to_act_pre(pb0, 256, 512, 0,
+                  [&] { read_unit(a.ff_w1, 0, ring[0]); read_unit(a.ff_w1, 1, ring[1]); read_w2(a.ff_w2, 0, 0, ring[2]); }, std::integral_constant<int, 24>{},
+                  [&] { read_w2(a.ff_w2, 0, 1, ring[3]); }, std::integral_constant<int, 8>{});  // norm_ff
     stamp(15);
     ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false, a.ff_b1g);  // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
     stamp(22);
     {
       float4 y[2][4];
-      ln_apply(pb1, 1280, 1536, y, 0);             // norm_final (encoder_layer.py:170-171): the block's output
+      // norm_final (encoder_layer.py:170-171): the block's output; with an A part behind it the macaron module's first W1
+      // units are requested under it
+      if constexpr (HAS_A)
+        ln_apply_pre(pb1, 1280, 1536, y, 0, [&] { read_unit(a.ffm_w1, 0, ring[0]); read_unit(a.ffm_w1, 1, ring[1]); }, std::integral_constant<int, 16>{});
+      else
+        ln_apply(pb1, 1280, 1536, y, 0);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1080,9 +1122,15 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     stamp(30);
     const float* const pa0 = HAS_D ? pb2 : pb0;  // GA
     const float* const pa1 = HAS_D ? pb3 : pb1;  // GA + 1
-    ffn_pre(a.ffm_w1, a.ffm_w2);
-    if (!HAS_D) touch();
-    ln_to_act(pa0, 0, 256, 0);
+    if constexpr (HAS_D) {  // (W1's first units were requested under norm_final)
+      ln_to_act_pre(pa0, 0, 256, 0, [&] { read_w2(a.ffm_w2, 0, 0, ring[2]); read_w2(a.ffm_w2, 0, 1, ring[3]); }, std::integral_constant<int, 16>{},
+                    no_pre, std::integral_constant<int, 0>{});
+    } else {
+      touch();
+      ln_to_act_pre(pa0, 0, 256, 0,
+                    [&] { read_unit(a.ffm_w1, 0, ring[0]); read_unit(a.ffm_w1, 1, ring[1]); read_w2(a.ffm_w2, 0, 0, ring[2]); }, std::integral_constant<int, 24>{},
+                    [&] { read_w2(a.ffm_w2, 0, 1, ring[3]); }, std::integral_constant<int, 8>{});
+    }
     stamp(15);
     ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2, true, a.ffm_b1g);  // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
     stamp(22);
@@ -1091,8 +1139,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // their slow acknowledgement from L2 stalled the stream - norm_mha took 4 300 cycles to its first barrier against
     // 3 100 for the other LayerNorms.  The q / k / v stores themselves stay inside the stream: batched behind it they
     // cost MORE, a store-issue tail of 3 300 cycles that the stream otherwise hides; profiles/r03c_*)
-    k_pre(a.wqkv, 12);
-    ln_to_act(pa1, 0, 256, 0);                     // norm_mha (encoder_layer.py:123-127)
+    ln_to_act_pre(pa1, 0, 256, 0, [&] { read_unit(a.wqkv, 0, ring[0]); read_unit(a.wqkv, 1, ring[1]); }, std::integral_constant<int, 16>{},
+                  [&] { read_unit(a.wqkv, 2, ring[2]); }, std::integral_constant<int, 8>{});  // norm_mha (encoder_layer.py:123-127)
     stamp(15);
     // q / k / v projections (attention.py:91-97), written per head: Q, K as [B][H][Tpad][64], V transposed
     // as [B][H][64][Tpad] (computed with the MFMA operands swapped so a lane holds 4 consecutive frames).

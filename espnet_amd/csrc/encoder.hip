@@ -84,13 +84,15 @@ inline RowsPlan rows_plan(int dtype, const EmConformerWeights* w, int flags, lon
   // 4 MiB of the module's weights through its CU), the launches it replaces scale with M (90 us at M = 15 936, ~31 us at
   // the beam search's M = 3 984, where only 63 CUs would work: profiles/r04r_search_kernel_stats.csv): taken only when its
   // rounds fill at least three quarters of the chip.
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
+  // (per DEVICE, not per process: a process may decode on MI355X partitions with different CU counts)
+  static int n_cu_of[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (n_cu_of[dev] == 0) {
     hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-               ? prop.multiProcessorCount : 256;
+    n_cu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
+  const int n_cu = n_cu_of[dev];
   const long wgs = (M + 63) / 64, rounds = (wgs + n_cu - 1) / n_cu;
   r.ffn = 4 * wgs >= 3 * rounds * n_cu;
   for (int l = 0; r.ffn && l < L; ++l) r.ffn = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;

@@ -7,6 +7,8 @@
 //   espnet2/layers/log_mel.py:57-84    matmul(melmat) -> clamp(1e-10) -> log -> zero the padding
 //   espnet2/layers/utterance_mvn.py:45-88
 //   espnet2/legacy/nets/pytorch_backend/transformer/subsampling.py:400-403 (first Conv2d + ReLU)
+#include <stdlib.h>
+
 #include "em_common.h"
 
 __device__ const float2 EM_TW512[384] = {
@@ -166,6 +168,184 @@ __global__ __launch_bounds__(256) void frontend_logmel_kernel(
   }
 }
 
+
+// ---- round 5: the same arithmetic, organised around what round 4's counters said (39 % of LDS-active cycles in bank
+// conflicts, ~900 instructions per frame and wave, 0.07 of the HBM roofline).  A wave now walks FR frames instead of one,
+// so everything that does not depend on the frame lives in registers for the walk: the lane's 8 window values, its 9
+// stage twiddles + 5 untangling twiddles, and - a lane per mel filter - the filter's band of up to ML weights (the old
+// kernel fetched every tap of every filter from global memory inside a serial fma chain, per frame).  The Stockham
+// exchanges go through WAVE-PRIVATE LDS tiles without workgroup barriers (LDS operations of one wave execute in order;
+// the four waves never read each other's tiles), and the tiles are padded by 4 words per 32 (P(i) = i + 4 (i >> 5)):
+// the scattered stores of the p = 4 / p = 16 stages (lane 4 g + k -> 16 g + k + 4 q, lane 16 g + k -> 64 g + k + 16 q)
+// hit 8 resp. 16 of the 32 banks in the dense layout (8- / 4-way conflicts) and every bank exactly twice - the floor for
+// 64 lanes - in the padded one; stage 1 stores four consecutive points as one 16-byte write.  Results are bit-identical
+// to frontend_logmel_kernel (same operations in the same order; tests/test_gpu_kernels.py::test_frontend_v2_equals_v1).
+__device__ __forceinline__ int fpad(int i) { return i + ((i >> 5) << 2); }
+constexpr int FE_TILE = 288;  // 256 + 4 * 8 words
+constexpr int FE_POW = 320;   // 257 power bins + room for a band that runs past them (zero weights there, zeroed once)
+
+template <int ML, int FR>
+__global__ __launch_bounds__(256) void frontend_logmel_kernel2(
+    const float* __restrict__ wav, int N, int hop, const float* __restrict__ window,
+    const float* __restrict__ melw, const int* __restrict__ mel_lo, int mel_maxlen, int n_mels,
+    const int* __restrict__ flens, const int* __restrict__ wlens, int T_f,
+    float* __restrict__ feats) {
+  __shared__ __attribute__((aligned(16))) float s_re[4][2][FE_TILE];
+  __shared__ __attribute__((aligned(16))) float s_im[4][2][FE_TILE];
+  __shared__ float s_pow[4][FE_POW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const float* x = wav + (size_t)b * N;
+  const int Nb = wlens ? (wlens[b] < N ? wlens[b] : N) : N;
+  float(*re)[FE_TILE] = s_re[wave];
+  float(*im)[FE_TILE] = s_im[wave];
+  float* pw = s_pow[wave];
+  const int flen = flens[b];
+
+  // ---- frame-independent state of this lane
+  float2 win[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) win[m] = *(const float2*)(window + 2 * (lane + 64 * m));
+  float2 tw[3][3];
+  int jst[3];  // PADDED index of this lane's first output of stages p = 4, 16, 64
+#pragma unroll
+  for (int s = 1; s < 4; ++s) {
+    const int p = 1 << (2 * s);
+    const int k = lane & (p - 1);
+    jst[s - 1] = fpad(((lane - k) << 2) + k);
+    const int twstep = 2 * k * (64 / p);
+#pragma unroll
+    for (int m = 1; m < 4; ++m) tw[s - 1][m - 1] = EM_TW512[m * twstep];
+  }
+  // Padded addresses as ONE lane-dependent base + compile-time offsets (immediate offsets of the ds instructions):
+  //   fpad(lane + 64 m)          = rd0 + 72 m
+  //   fpad(j + q p), p = 4       = jst + 4 q               (16 (g & 1) + k + 4 q < 32: no carry into the pad)
+  //                  p = 16      = jst + 16 q + 4 (q >> 1)
+  //                  p = 64      = jst + 72 q
+  //   fpad(256 - lane - 64 m)    = kb0 - 72 m              (the mirrored bin of the untangling step; lane 0, m = 0: bin 0)
+  const int rd0 = fpad(lane);
+  const int kb0 = fpad(256 - lane);
+  const int st0 = fpad(4 * lane);
+  float2 twu[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) twu[m] = (lane + 64 * m < 384) ? EM_TW512[lane + 64 * m] : make_float2(0.f, 0.f);
+  // mel: lanes 0 .. 63 own filters 0 .. 63 (n_mels <= 64: filter `lane` if it exists); 64 < n_mels <= 80: the rest as four
+  // lanes per filter, a quarter of the band each
+  const int nfull = n_mels > 64 ? 64 : 0;
+  const int mA = lane < n_mels ? lane : n_mels - 1;
+  const int loA = mel_lo[mA];
+  // (taps past the widest band carry zero weights and read zeroed words behind the 257 bins: no per-tap predicate or index
+  // clamp in the frame loop; fma(p, 0, acc) = acc exactly)
+  float wA[ML];
+#pragma unroll
+  for (int s = 0; s < ML; ++s) wA[s] = (s < mel_maxlen && loA + s <= 256) ? melw[s * n_mels + mA] : 0.f;
+  const int rest = n_mels - nfull;
+  (void)rest;
+  const int qB = lane >> 4, mmB = nfull + (lane & 15);
+  const int mB = mmB < n_mels ? mmB : n_mels - 1;
+  const int per = (mel_maxlen + 3) >> 2;
+  const int s0B = qB * per, s1B = (s0B + per < mel_maxlen) ? s0B + per : mel_maxlen;
+  const int loB = mel_lo[mB] + s0B;
+  constexpr int MLB = (ML + 3) / 4;
+  float wB[MLB];
+#pragma unroll
+  for (int s = 0; s < MLB; ++s) wB[s] = (nfull && s0B + s < s1B && loB + s <= 256) ? melw[(s0B + s) * n_mels + mB] : 0.f;
+  for (int i = 257 + lane; i < FE_POW; i += 64) pw[i] = 0.f;
+  const float* const pwA = pw + loA;
+  const float* const pwB = pw + (loB < FE_POW - MLB ? loB : FE_POW - MLB);
+  for (int fi = 0; fi < FR; ++fi) {
+    const int t = (blockIdx.x * FR + fi) * 4 + wave;
+    if (t >= T_f) break;  // (wave-uniform)
+    // ---- load + window: z[n] = x[2n] + i x[2n+1], n = lane + 64 m
+    float2 u[4];
+    const int start = t * hop - 256;
+    if (start >= 0 && start + 512 <= Nb && !(start & 1)) {  // (wave-uniform) no reflection, 8-byte aligned
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float2 v = *(const float2*)(x + start + 2 * (lane + 64 * m));
+        u[m] = make_float2(v.x * win[m].x, v.y * win[m].y);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int n = lane + 64 * m;
+        int i0 = reflect_idx(start + 2 * n, Nb), i1 = reflect_idx(start + 2 * n + 1, Nb);
+        i0 = i0 < 0 ? 0 : (i0 < N ? i0 : N - 1);
+        i1 = i1 < 0 ? 0 : (i1 < N ? i1 : N - 1);
+        u[m] = make_float2(x[i0] * win[m].x, x[i1] * win[m].y);
+      }
+    }
+    // ---- stage p = 1 (no twiddles): out[4 lane + q], one 16-byte store per component
+    bfly4(u);
+    *(float4*)(re[0] + st0) = make_float4(u[0].x, u[1].x, u[2].x, u[3].x);
+    *(float4*)(im[0] + st0) = make_float4(u[0].y, u[1].y, u[2].y, u[3].y);
+    __builtin_amdgcn_wave_barrier();
+    // ---- stages p = 4, 16, 64
+    int cur = 0;
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+      const int p = 1 << (2 * s);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float2 v = make_float2(re[cur][rd0 + 72 * m], im[cur][rd0 + 72 * m]);
+        u[m] = (m == 0) ? v : cmul(v, tw[s - 1][m - 1]);
+      }
+      bfly4(u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int off = p == 4 ? 4 * q : (p == 16 ? 16 * q + 4 * (q >> 1) : 72 * q);
+        re[cur ^ 1][jst[s - 1] + off] = u[q].x;
+        im[cur ^ 1][jst[s - 1] + off] = u[q].y;
+      }
+      cur ^= 1;
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- real-FFT untangle + power: k = lane + 64 m (m < 4) and k = 256 on lane 0
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const int k = lane + 64 * m;
+      if (m == 4 && lane != 0) break;
+      // bins ka = k & 255 and kb = (256 - k) & 255, padded
+      const int pa = m < 4 ? rd0 + 72 * m : 0;
+      const int pb = m == 0 ? (lane == 0 ? 0 : kb0) : (m < 4 ? kb0 - 72 * m : 0);
+      const float2 zk = make_float2(re[cur][pa], im[cur][pa]);
+      const float2 zc = make_float2(re[cur][pb], -im[cur][pb]);
+      const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y));
+      const float2 dlt = make_float2(zk.x - zc.x, zk.y - zc.y);
+      const float2 o = make_float2(0.5f * dlt.y, -0.5f * dlt.x);
+      const float2 w = m < 4 ? twu[m] : EM_TW512[256];
+      const float2 xo = cmul(w, o);
+      const float xr = e.x + xo.x, xi = e.y + xo.y;
+      pw[k] = xr * xr + xi * xi;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- banded mel + log
+    const bool valid_frame = t < flen;
+    float* out = feats + ((size_t)b * T_f + t) * n_mels;
+    {
+      float acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < ML; ++s) acc = fmaf(pwA[s], wA[s], acc);
+      acc = fmaxf(acc, 1e-10f);
+      if (lane < n_mels) out[lane] = valid_frame ? logf(acc) : 0.f;
+    }
+    if (nfull) {
+      float acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < MLB; ++s) acc = fmaf(pwB[s], wB[s], acc);
+      {
+        const Pair2 p16 = wave_xor16_pair(acc);
+        acc = p16.a + p16.b;
+        const Pair2 p32 = wave_xor32_pair(acc);
+        acc = p32.a + p32.b;
+      }
+      acc = fmaxf(acc, 1e-10f);
+      if (qB == 0 && mmB < n_mels) out[mmB] = valid_frame ? logf(acc) : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();  // (the next frame's stage-1 stores come after this frame's reads of the tiles)
+  }
+}
+
 extern "C" int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, int32_t hop,
                                       const float* window, const float* mel_packed,
                                       const int32_t* mel_lo, int32_t mel_maxlen, int32_t n_mels,
@@ -174,6 +354,20 @@ extern "C" int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, in
   if (B <= 0 || T_f <= 0) return EM_ERR_BAD_ARG;
   if (N <= 256 || hop <= 0 || T_f != 1 + N / hop) return EM_ERR_BAD_ARG;
   if (mel_maxlen < 1 || mel_maxlen > 257 || n_mels < 1) return EM_ERR_BAD_ARG;
+  // ESPNET_AMD_FRONTEND_V1=1: developer A/B switch (one frame per wave, the kernel of rounds 1-4)
+  const bool v1 = getenv("ESPNET_AMD_FRONTEND_V1") != nullptr;  // (read per call: the equality test toggles it in-process)
+  constexpr int FR = 8;
+  if (!v1 && mel_maxlen <= 32 && n_mels <= 80) {
+    dim3 grid(em_cdiv(T_f, 4 * FR), B);
+    if (mel_maxlen <= 20)  // (80 mel filters over 257 bins: 18)
+      hipLaunchKernelGGL((frontend_logmel_kernel2<20, FR>), grid, dim3(256), 0, (hipStream_t)stream, wav, N, hop, window,
+                         mel_packed, mel_lo, mel_maxlen, n_mels, flens, wlens, T_f, feats);
+    else
+      hipLaunchKernelGGL((frontend_logmel_kernel2<32, FR>), grid, dim3(256), 0, (hipStream_t)stream, wav, N, hop, window,
+                         mel_packed, mel_lo, mel_maxlen, n_mels, flens, wlens, T_f, feats);
+    EM_CHECK_LAUNCH();
+    return EM_OK;
+  }
   dim3 grid(em_cdiv(T_f, 4), B);
   hipLaunchKernelGGL(frontend_logmel_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, N, hop,
                      window, mel_packed, mel_lo, mel_maxlen, n_mels, flens, wlens, T_f, feats);

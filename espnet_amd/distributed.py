@@ -162,6 +162,18 @@ class SharedCounter:
         return int(self.store.add(self.key, n)) - n
 
 
+_CALL_SEQ = {}
+
+
+def call_key(name: str) -> str:
+    """A counter key for ONE call of a collective entry point: `name` + how many times this process has asked for it.
+    Every rank makes the same calls in the same order, so the keys agree without communication, and a second decode
+    inside the same process group (torchrun decoding several test sets in one process) starts from a fresh counter
+    instead of the previous call's final value."""
+    _CALL_SEQ[name] = _CALL_SEQ.get(name, 0) + 1
+    return f"{name}_{_CALL_SEQ[name]}"
+
+
 class WindowClaimer:
     """`claim(w)` for units visited in increasing order w = 0, 1, 2, ... (every rank walks the same list): True for the
     units this rank owns.  A rank asks the shared counter for its next unit only when it reaches the previous one, so
@@ -239,7 +251,7 @@ def decode_dynamic(decode_unit, n_units: int, unit_items, max_len: int, device, 
     collective.  Returns (hypotheses in global utterance order, units this rank decoded)."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    counter = counter or SharedCounter(work_store() if world > 1 else None, "decode_dynamic")
+    counter = counter or SharedCounter(work_store() if world > 1 else None, call_key("decode_dynamic"))
     err, recs, mine = None, [], []
     try:
         while True:
@@ -326,7 +338,8 @@ class RecordRing:
                 self.events[half].synchronize()
             a = self.pinned[half].numpy()[:, steps - 1]  # the macro-batch's last step, all ranks: (world, rec)
             B, w = self.B, self.width
-            self.last = (a[:, : B * w].reshape(self.world * B, w), a[:, B * w : B * w + B].reshape(-1),
+            # (copies: at world == 1 the slices are views of the pinned half, which the ring overwrites two macro-batches on)
+            self.last = (a[:, : B * w].reshape(self.world * B, w).copy(), a[:, B * w : B * w + B].reshape(-1).copy(),
                          a[:, B * w + B :].copy().view(np.float32).reshape(-1))
         self.delivered += steps
 

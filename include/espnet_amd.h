@@ -454,7 +454,7 @@ typedef struct EmFfnRowsArgs {
   int32_t main;
   /* optional walk behind a ln_mode 2 launch (post_w != NULL): the CTC head's per-row arg-max over the second LayerNorm's
    * result (asr/ctc.py:207-215), post_ids [M] i32 out.  post_w: ctc_lo.weight zero-padded to post_chunks * 128 rows, in the
-   * w1p layout; post_b its bias padded with -3e38; post_vocab the real vocabulary size (flop accounting only).            */
+   * w1p layout; post_b its bias padded with -3e38; post_vocab the vocabulary rounded up to whole 128-label chunks, i.e. what the walk computes (flop accounting only).            */
   const void* post_w;
   const float* post_b;
   int32_t* post_ids;

@@ -232,16 +232,68 @@ def test_beam10_b16_rows_match_oracle():
 # size.  Per scored token and scorer (measured on MI355X, round 4: decoder 1.1e-4, ctc 7e-5 - the errors of 249 tokens
 # largely cancel; `beam.bf16_vs_oracle` of the bench line reports them live).
 BF16_BEAM_EPS = {"decoder": 1e-3, "ctc": 1e-3}
-# What reduced-precision pruning may lose: oracle best minus the oracle's score of the device's best, joint score in
-# nats.  Measured on rows 0 / 7 / 15: -0.74 (the device's hypothesis is BETTER than the oracle search's best), +0.04,
-# +2.45 of scores around -1738: on flat random-init posteriors the oracle's own 10-best span 0.14-0.25 and the ten
-# running hypotheses are decided by margins of 1e-3, so a 1e-4-per-token perturbation sends the beam down another
-# path whose end point is a few nats better or worse - beam search is a heuristic, and this is its path noise, not a
-# scoring error ((a) bounds that, and the peaked fixture pins the n-best where the posteriors decide).  A second,
-# equally valid rounding of the same encoder (its feed-forward modules on the row-block kernel, profiles/r04r_pytest_gpu.txt)
-# gave -1.89 / +0.37 / +5.03 on the same rows: the realisations of that noise differ by more than the first bound of
-# 2 x 2.45 allowed.  Bound = 2 x the spread seen over both realisations (-1.9 .. +5.0), symmetric.
-BF16_BEAM_BEST_LOSS = 10.0
+# What reduced-precision pruning may lose - (b): oracle best minus the oracle's score of the device's best, joint score in
+# nats.  Round 5: held against a MEASURED noise model instead of a +-10 nat constant.  On flat random-init
+# posteriors the oracle's own 10-best span 0.14-0.3 and the running hypotheses are decided by margins of 1e-3, so any
+# per-step perturbation of that size sends the beam down another path whose end point is a few nats better or worse -
+# beam search is a heuristic; its best is not the optimum (in the build container, utterance 0, oracle search with
+# N(0, s^2) on every log-probability, 8 seeds, losses re-scored without noise: s = 2.5e-4: all 0; s = 1e-3: -2.55 .. 0;
+# s = 4e-3: -2.33 .. +0.60 - the perturbed search usually ends BETTER than the clean one).  The device's per-entry
+# log-probability error is measured by tests/test_gpu_scorer_interface.py::test_decoder_batch_score_bf16_at_640_rows
+# (RMS ~ 1-2e-3 over the entries a pre-beam can reach), so the yardstick is the oracle's own path noise at
+# PATH_NOISE_SIGMA = 2e-3: oracle.beam_search.path_noise_losses over PATH_NOISE_SEEDS seeds on the SAME rows.  The device's
+# loss must lie within [min - pad, max + pad] of those losses, pad = their spread (at least PATH_NOISE_FLOOR): a search
+# that loses more than the oracle's own perturbed runs do - a mis-scored candidate, a wrong prune - falls outside.
+PATH_NOISE_SIGMA = 2e-3
+PATH_NOISE_SEEDS = 6
+PATH_NOISE_FLOOR = 0.5
+
+
+def _bf16_rows_vs_oracle(tag, model, st, nbest, rows, noise_rows, W=10, ctc_weight=0.3):
+    """(a) / (b) / (c) of the bf16 beam tests for some rows of a batch; returns the worst per-token errors."""
+    from oracle import beam_search as ob
+    from tests.helpers import oracle_rescore_batch
+
+    sd = _oracle_sd(model)
+    dec_m = model.decoder
+    eos = model.eos
+    worst = {"decoder": 0.0, "ctc": 0.0}
+    for b in rows:
+        e = st.enc_act[b, : int(st.olens[b])].float().cpu()  # exactly the (bf16) rows the device search consumed
+        ys = [h.yseq.tolist() for h in nbest[b]]
+        ref = oracle_rescore_batch(sd, e, ys, dec_m.heads, dec_m.num_blocks, ctc_weight, eos)
+        for h, r in zip(nbest[b], ref):
+            for k in worst:
+                err = abs(float(h.scores[k]) - r[k]) / r["n_scored"]
+                worst[k] = max(worst[k], err)
+                assert err <= BF16_BEAM_EPS[k], (tag, b, k, err)
+        if b in noise_rows:
+            losses, orc = ob.path_noise_losses(sd, e, dec_m.heads, dec_m.num_blocks, W, ctc_weight, eos, PATH_NOISE_SIGMA,
+                                               list(range(PATH_NOISE_SEEDS)))
+        else:
+            with torch.no_grad():
+                orc = ob.beam_search(sd, e, dec_m.heads, dec_m.num_blocks, W, ctc_weight, sos=eos, eos=eos)
+            losses = None
+        k_best = max(range(len(ref)), key=lambda k: ref[k]["score"])
+        mine_best = ref[k_best]["score"]
+        loss = orc[0]["score"] - mine_best
+        survive = sum(tuple(o["yseq"]) in {tuple(y) for y in ys} for o in orc)
+        span = orc[0]["score"] - orc[-1]["score"]
+        ted = ob.token_edit_distance(ys[k_best][1:-1], orc[0]["yseq"][1:-1])
+        msg = (f"[{tag} bf16 row {b}] device best (oracle-scored) {mine_best:.4f} vs oracle best {orc[0]['score']:.4f}: loss "
+               f"{loss:+.3f} (oracle 10-best span {span:.3f}); token edit distance device best <-> oracle best {ted} of "
+               f"{len(orc[0]['yseq']) - 2}; {survive} of {len(orc)} oracle hypotheses in the device n-best")
+        if losses is not None:
+            lo, hi = min(losses), max(losses)
+            pad = max(hi - lo, PATH_NOISE_FLOOR)
+            msg += (f"; oracle path noise at sigma {PATH_NOISE_SIGMA:g} over {len(losses)} seeds: "
+                    f"{[round(x, 2) for x in losses]} -> allowed [{lo - pad:+.2f}, {hi + pad:+.2f}]")
+            print(msg)
+            assert lo - pad <= loss <= hi + pad, (tag, b, loss, losses)
+        else:
+            print(msg)
+    print(f"[{tag} bf16] worst per-token error vs oracle: decoder {worst['decoder']:.2e}, ctc {worst['ctc']:.2e}")
+    return worst
 
 
 def test_beam10_b16_rows_bf16_vs_oracle():
@@ -249,43 +301,37 @@ def test_beam10_b16_rows_bf16_vs_oracle():
     (a) every hypothesis the device returns is re-scored teacher-forced by the oracle's scorers over the encoder rows
         the device search itself was given (so only the search's arithmetic is in question): |device - oracle| <=
         BF16_BEAM_EPS per scored token, per scorer;
-    (b) the oracle's score of the device's best hypothesis is within BF16_BEAM_BEST_LOSS of the best hypothesis of the
-        oracle's own f32 search over the same rows (what bf16 pruning can lose);
-    (c) how many of the oracle's 10 hypotheses survive in the device n-best is printed (random-init posteriors are
-        flat - the oracle's own top-2 differ by 1e-3 - so this is reported, not asserted; the peaked fixture of
-        tests/test_gpu_search.py asserts the n-best itself).
+    (b) the oracle's score of the device's best hypothesis, minus the best of the oracle's own f32 search over the same
+        rows, lies inside the oracle search's OWN path noise at the device's error level (path_noise_losses, see above);
+    (c) printed, not asserted: how many of the oracle's 10 hypotheses survive in the device n-best and the token edit
+        distance between the two best hypotheses (random-init posteriors are flat - the oracle's own top-2 differ by
+        1e-3; the peaked fixture of tests/test_gpu_search.py asserts the n-best itself).
     Matches batch_beam_search.py:253-357, ctc_prefix_score.py:71-191 through oracle/beam_search.py."""
     from espnet_amd.nets.batch_beam_search import build_beam_search
-    from oracle import beam_search as ob
-    from tests.helpers import oracle_rescore_batch
 
     B, N, W = 16, bench.N_SAMPLES, 10
-    rows = [0, 7, 15]
     wav = bench.synth_batch(0, B)
     model = _model("large", "bfloat16")
-    sd = _oracle_sd(model)
-    dec_m = model.decoder
     bs = build_beam_search(model, beam_size=W, ctc_weight=0.3, penalty=0.0, token_list=model.token_list)
     st = model.encode_device(wav.cuda(), [N] * B)
     nbest = bs.search_batch(st.enc_act, st.olens)
-    eos = model.eos
-    worst = {"decoder": 0.0, "ctc": 0.0}
-    for b in rows:
-        e = st.enc_act[b].float().cpu()  # exactly the (bf16) rows the device search consumed
-        ys = [h.yseq.tolist() for h in nbest[b]]
-        ref = oracle_rescore_batch(sd, e, ys, dec_m.heads, dec_m.num_blocks, 0.3, eos)
-        for h, r in zip(nbest[b], ref):
-            for k in worst:
-                err = abs(float(h.scores[k]) - r[k]) / r["n_scored"]
-                worst[k] = max(worst[k], err)
-                assert err <= BF16_BEAM_EPS[k], (b, k, err)
-        with torch.no_grad():
-            orc = ob.beam_search(sd, e, dec_m.heads, dec_m.num_blocks, W, 0.3, sos=eos, eos=eos)
-        mine_best = max(r["score"] for r in ref)
-        survive = sum(tuple(o["yseq"]) in {tuple(y) for y in ys} for o in orc)
-        span = orc[0]["score"] - orc[-1]["score"]
-        print(f"[configs[2] bf16 row {b}] device best (oracle-scored) {mine_best:.4f} vs oracle best {orc[0]['score']:.4f} "
-              f"(oracle 10-best span {span:.3f}); {survive} of {len(orc)} oracle hypotheses in the device n-best")
-        assert mine_best >= orc[0]["score"] - BF16_BEAM_BEST_LOSS, (b, mine_best, orc[0]["score"])
-        assert mine_best <= orc[0]["score"] + BF16_BEAM_BEST_LOSS  # (and a "better" end point is path noise of the same size)
-    print(f"[configs[2] bf16] worst per-token error vs oracle: decoder {worst['decoder']:.2e}, ctc {worst['ctc']:.2e}")
+    _bf16_rows_vs_oracle("configs[2]", model, st, nbest, rows=[0, 7, 15], noise_rows=[0, 7, 15], W=W)
+
+
+def test_beam10_b64_rows_bf16_vs_oracle():
+    """configs[3]'s per-GPU shape (64 utterances x beam 10 = 640 rows, bf16): the encoder runs through
+    the row-block launches (M = 15 936 fills the chip) and the label step through the kernel variants only this shape
+    reaches - decoder self-attention with one wave per row (heads x rows > 2048, csrc/decoder.hip), LayerNorm + tiled
+    GEMM pairs instead of the fused ln_gemm (grid > 256 workgroups, csrc/search.hip ln_proj), mid_gemm / source attention /
+    pre-beam / tail at 640 rows.  Rows 0 / 31 / 63 under the same (a) / (b) / (c) as the 160-row test."""
+    from espnet_amd.nets.batch_beam_search import build_beam_search
+
+    B, N, W = 64, bench.N_SAMPLES, 10
+    wav = bench.synth_batch(0, B)
+    model = _model("large", "bfloat16")
+    bs = build_beam_search(model, beam_size=W, ctc_weight=0.3, penalty=0.0, token_list=model.token_list)
+    st = model.encode_device(wav.cuda(), [N] * B)
+    assert model.encoder.last_ctc_ids is not None or not model.encoder.fused, "B = 64 did not take the row-block path"
+    nbest = bs.search_batch(st.enc_act, st.olens)
+    assert len(nbest) == B and all(len(h) == W for h in nbest)
+    _bf16_rows_vs_oracle("configs[3] per GPU", model, st, nbest, rows=[0, 31, 63], noise_rows=[31, 63], W=W)

@@ -180,6 +180,43 @@ def test_frontend_logmel(lib, win_length, hop):
     assert err < 2e-4, err
 
 
+@pytest.mark.parametrize("n_mels,hop,isolate", [(80, 160, False), (80, 128, True), (40, 160, False), (23, 160, True), (80, 97, False)])
+def test_frontend_v2_equals_v1(lib, n_mels, hop, isolate):
+    """Round 5: the frontend kernel that walks eight frames per wave (window, twiddles and the mel bands in registers,
+    wave-private padded LDS tiles) must give the bits of the one-frame-per-wave kernel of rounds 1-4
+    (ESPNET_AMD_FRONTEND_V1=1): same operations in the same order.  Ragged lengths (reflection at the utterance's own end
+    with `isolate`), mel banks with other band widths, an odd hop (the unaligned load path)."""
+    import os
+
+    from oracle.mel import slaney_mel_filterbank
+    from oracle.weights import synth_waveform
+
+    melmat = torch.from_numpy(slaney_mel_filterbank(16000, 512, n_mels, 0, 8000).T.copy())
+    lens = [16000, 12345, 5000, 700]
+    speech = torch.zeros(len(lens), 16000)
+    for i, n in enumerate(lens):
+        speech[i, :n] = synth_waveform(40 + i, n)
+    from espnet_amd.asr.frontend.default import DefaultFrontend
+
+    fe = DefaultFrontend(fs=16000, n_fft=512, win_length=400, hop_length=hop, n_mels=n_mels)
+    fe.logmel.melmat.copy_(melmat)
+    fe.cuda()
+    sp = dev(speech)
+    flens = dev(torch.tensor(fe.feature_lengths(lens), dtype=torch.int32))
+    wlens = dev(torch.tensor(lens, dtype=torch.int32)) if isolate else None
+    outs = []
+    for v1 in (False, True):
+        if v1:
+            os.environ["ESPNET_AMD_FRONTEND_V1"] = "1"
+        try:
+            outs.append(fe.forward_device(sp, flens, wlens).clone())
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("ESPNET_AMD_FRONTEND_V1", None)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
 def test_utt_mvn_and_conv1(lib):
     B, T_f, D, d = 3, 61, 80, 64
     feats = rnd(B, T_f, D, seed=11) * 2 - 8

@@ -115,6 +115,50 @@ def test_decoder_batch_score_and_forward_match_oracle_steps():
     assert (got - torch.stack(rows, 1)).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("n", [160, 640])
+def test_decoder_batch_score_bf16_at_640_rows(n):
+    """The decoder step in the TIMED dtype at the row counts of configs[2] (160) and configs[3] per GPU (640; VERDICT r04
+    item 1a): at 640 rows `em_decoder_step` runs the self-attention with one wave per row (heads x rows > 2048) and the
+    LayerNorm + tiled GEMM pairs instead of the fused ln_gemm (grid > 256 workgroups) - variants no 160-row test reaches.
+    Large decoder (6 x 512d, 8 heads, V = 5 000), n hypotheses with different 4-token prefixes over one 74-frame memory,
+    against the oracle's f32 K/V-cached step: bound on the log-probabilities, and the error statistics over the entries a
+    pre-beam can reach (the 15 best of every row) are printed - the device's per-entry noise level that
+    tests/test_gpu_fullsize.py's path-noise model (PATH_NOISE_SIGMA) stands on."""
+    from oracle import beam_search as ob
+
+    g = load_golden("large_beam10_3s")
+    sd = golden_state_dict(g)
+    enc, olens = oracle_enc(g, sd)
+    scorers, _, V, _ = build_scorers(g, sd, dtype="bfloat16")
+    dec = scorers["decoder"]
+    dc = g["config"]["decoder_conf"]
+    e = enc[0, : int(olens[0])].to(torch.bfloat16).float()  # the rows the bf16 step consumes
+    Lc = 4
+    gen = torch.Generator().manual_seed(11)
+    ys = torch.randint(1, V - 1, (n, Lc), generator=gen)
+    ys[:, 0] = V - 1
+    orc = ob.DecoderOracle(sd, e, dc["attention_heads"], dc["num_blocks"], Lc + 2)
+    cache = [(k.expand(n, -1, -1), v.expand(n, -1, -1)) for k, v in orc.init_cache()]
+    xs = e.cuda().expand(n, *e.shape)
+    states = [None] * n
+    worst, sq, cnt = 0.0, 0.0, 0
+    for pos in range(Lc):
+        with torch.no_grad():
+            want, cache = orc.step(ys[:, pos], pos, cache)
+        got, states = dec.batch_score(ys[:, : pos + 1].cuda(), states, xs)
+        diff = got.cpu() - want
+        top = want.topk(15, dim=-1).indices
+        dt = diff.gather(1, top)
+        worst = max(worst, dt.abs().max().item())
+        sq, cnt = sq + float((dt ** 2).sum()), cnt + dt.numel()
+        assert diff.abs().max().item() < 8e-2, (pos, diff.abs().max().item())
+        assert diff.abs().mean().item() < 8e-3, (pos, diff.abs().mean().item())
+    rms = (sq / cnt) ** 0.5
+    print(f"[decoder step bf16, {n} rows] log-prob error vs the f32 oracle over the 15 best entries of every row: "
+          f"RMS {rms:.2e}, max {worst:.2e}")
+    assert rms < 4e-3
+
+
 def test_ctc_prefix_scorer_matches_oracle_steps():
     """Unit level: batch_score_partial / select_state against oracle CtcPrefixScorer.score, with and without a
     candidate list, incl. a repeated last label and the <eos> / blank columns."""

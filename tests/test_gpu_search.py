@@ -413,13 +413,15 @@ def _act(prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-@pytest.mark.parametrize("heads,d", [(4, 256), (2, 64)])
-def test_dec_self_attention(lib, prec, heads, d):
+@pytest.mark.parametrize("heads,d,n", [(4, 256, 7), (2, 64, 7), (8, 512, 640), (8, 512, 160)])
+def test_dec_self_attention(lib, prec, heads, d, n):
+    """n = 640 (configs[3]'s per-GPU rows, heads x n > 2048): the launch with ONE wave per row (csrc/decoder.hip
+    self_attn_launch, SA_SPLIT = 1), which only that shape reaches; n = 160: two waves per row."""
     from espnet_amd import lib as L
 
     em, dt, tol = _act(prec)
     torch.manual_seed(1)
-    n, Lmax, pos = 7, 40, 21
+    Lmax, pos = (40, 21) if n < 100 else (160, 133)  # (long prefixes: three 64-position batches per row)
     dk = d // heads
     qkv = torch.randn(n, 3 * d).to(dt).cuda()
     kc = torch.randn(Lmax, n, d).to(dt).cuda()
@@ -431,13 +433,16 @@ def test_dec_self_attention(lib, prec, heads, d):
                                       d, heads, Lmax, pos, None, 3, None, L.ptr(ctx), None), "self_attn")
     torch.cuda.synchronize()
     q, k_new, v_new = qkv.float().split(d, dim=1)
-    ref = torch.empty(n, d)
-    for r in range(n):
-        ks = torch.stack([kc0[j, anc[r, j]].float() for j in range(pos)] + [k_new[r]]).cpu()
-        vs = torch.stack([vc0[j, anc[r, j]].float() for j in range(pos)] + [v_new[r]]).cpu()
-        qh = q[r].cpu().view(heads, 1, dk)
-        sc = torch.matmul(qh, ks.view(pos + 1, heads, dk).transpose(0, 1).transpose(1, 2)) / math.sqrt(dk)
-        ref[r] = torch.matmul(torch.softmax(sc, -1), vs.view(pos + 1, heads, dk).transpose(0, 1)).reshape(d)
+    # row r attends to cache rows kc[j, anc[r, j]], j < pos, and its own new K / V
+    idx = anc[:, :pos].long().t()                                        # (pos, n)
+    jj = torch.arange(pos, device="cuda")[:, None].expand(pos, n)
+    ks = torch.cat([kc0[jj, idx].float(), k_new[None]], 0).cpu()         # (pos + 1, n, d)
+    vs = torch.cat([vc0[jj, idx].float(), v_new[None]], 0).cpu()
+    qh = q.cpu().view(n, heads, 1, dk)
+    kh = ks.view(pos + 1, n, heads, dk).permute(1, 2, 3, 0)              # (n, h, dk, pos + 1)
+    vh = vs.view(pos + 1, n, heads, dk).permute(1, 2, 0, 3)              # (n, h, pos + 1, dk)
+    sc = torch.matmul(qh, kh) / math.sqrt(dk)
+    ref = torch.matmul(torch.softmax(sc, -1), vh).reshape(n, d)
     assert (ctx.float().cpu() - ref).abs().max().item() < tol
     # the new K/V were appended at `pos`, nothing else touched
     assert torch.equal(kc[pos].float().cpu(), k_new.to(dt).float().cpu())
@@ -546,3 +551,34 @@ def test_search_very_short_memories_match_oracle(T):
     both[0, :T], both[1] = enc, long
     hb = bs.search_batch(both.cuda(), [T, 40])[0]
     assert [h.yseq.tolist() for h in hb] == [h.yseq.tolist() for h in hyps]
+
+
+@pytest.mark.parametrize("T", [1600, 1480])
+def test_search_bf16_long_memory_falls_back_to_two_launch_source_attention(T):
+    """norm2 + the query projection inside the source-attention kernel (`em_dec_src_attention_lnq`) needs more
+    LDS than the plain kernel, so memories beyond Tpad 1 472 (d = 512) fit only the two-launch form - `decoder_step` must
+    take it instead of failing with EM_ERR_UNSUPPORTED (the usable memory length stays ~1 690 frames).
+    A 512-wide decoder over a T-frame memory (T = 1 600: only the two-launch form fits; 1 480: just past the switch), five
+    label steps (maxlenratio -5), two utterances of different length: every device hypothesis re-scored teacher-forced
+    under the oracle's scorers."""
+    g = load_golden("large_beam10_3s")
+    sd = golden_state_dict(g)
+    d = g["config"]["encoder_conf"]["output_size"]
+    torch.manual_seed(200 + T)
+    enc = (torch.randn(2, T, d) * 0.7).to(torch.bfloat16).float()
+    olens = [T, T - 37]
+    bs = build_search(g, sd, "bfloat16")
+    hyps = bs.search_batch(enc.cuda(), olens, maxlenratio=-5.0)
+    assert len(hyps) == 2 and all(len(h) > 0 for h in hyps)
+    from tests.helpers import oracle_rescore_batch
+
+    dc = g["config"]["decoder_conf"]
+    V = int(g["vocab"])
+    for b in range(2):
+        e = enc[b, : olens[b]]
+        ys = [h.yseq.tolist() for h in hyps[b]]
+        ref = oracle_rescore_batch(sd, e, ys, dc["attention_heads"], dc["num_blocks"], float(g["ctc_weight"]), V - 1, maxlen=5)
+        for h, r in zip(hyps[b], ref):
+            for k in ("decoder", "ctc"):
+                err = abs(float(h.scores[k]) - r[k]) / max(r["n_scored"], 1)
+                assert err <= BF16_EPS[k], (T, b, k, err)
