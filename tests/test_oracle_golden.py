@@ -323,3 +323,32 @@ def test_ebranchformer_encoder_matches_reference(name):
     ids = oc.ctc_argmax(sd, enc).numpy()
     diff = ids != g["ctc_ids"]
     assert (g["ctc_margin"][diff] < 1e-4).all() and diff.mean() < 0.01
+
+
+def test_lockstep_noisy_searches_equal_separate_ones():
+    """`beam_search(noise_seeds=[...])` - several perturbed searches of one utterance run in lock step (the path-noise
+    model of tests/test_gpu_fullsize.py and bench.py) - returns, group by group, exactly what separate calls with
+    noise_seed = s return: same hypotheses, same scores, groups ending at different steps."""
+    from oracle import beam_search as ob
+    from oracle import conformer as oc
+
+    g = load_golden("tiny_beam5")
+    sd = golden_state_dict(g)
+    hp = hparams(g)
+    speech, lens = golden_speech(g)
+    with torch.no_grad():
+        enc, olens = oc.encode(sd, speech, lens, hp["heads"], hp["num_blocks"], hp["n_fft"], hp["win_length"], hp["hop"])
+    e = enc[0, : int(olens[0])]
+    dc = g["config"]["decoder_conf"]
+    V = int(g["vocab"])
+    seeds = [0, 1, 2, 5]
+    with torch.no_grad():
+        multi = ob.beam_search(sd, e, dc["attention_heads"], dc["num_blocks"], 5, 0.3, sos=V - 1, eos=V - 1, noise=0.05,
+                               noise_seeds=seeds)
+        for s, m in zip(seeds, multi):
+            one = ob.beam_search(sd, e, dc["attention_heads"], dc["num_blocks"], 5, 0.3, sos=V - 1, eos=V - 1, noise=0.05,
+                                 noise_seed=s)
+            assert [x["yseq"] for x in one] == [x["yseq"] for x in m]
+            assert [x["score"] for x in one] == [x["score"] for x in m]
+        losses, clean = ob.path_noise_losses(sd, e, dc["attention_heads"], dc["num_blocks"], 5, 0.3, V - 1, 0.05, seeds)
+    assert len(losses) == len(seeds) and all(abs(x) < 50 for x in losses)

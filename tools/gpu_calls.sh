@@ -25,14 +25,12 @@ stats() {  # <dir> <cmd...>: rocprofv3 --kernel-trace --stats of a command, summ
 beam_line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['search']['ms_per_search_step'])"; }
 quick() { timeout 300 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps ${1:-600} --warmup 30 2>/dev/null < /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s', d['ms_per_step'], 'ms/step')"; }
 case "$what" in
-  r05a)     # round 5, first call: the new parity tests (prints = the measured numbers), LayerNorm hand-over with the weight
-            # requests dealt into it (A/B against lib_v32 = requests in one cluster), frontend v2 (A/B against ESPNET_AMD_FRONTEND_V1),
-            # fine stamps, kernel table, launch order of one step (where do the ~7 copyBuffer launches per step come from?)
+  r05a|r05b)  # round 5: kernel tests of the changed kernels, LayerNorm hand-over with the weight requests dealt into it (A/B against
+            # lib_v32 = requests in one cluster), frontend v2 (A/B against ESPNET_AMD_FRONTEND_V1), fine stamps, kernel table, launch
+            # order of one step (where do the ~7 copyBuffer launches per step come from?), then the new parity tests, each
+            # file under its own limit (r05a lost 25 GPU-minutes to oracle legs on an unbounded thread count)
     echo "== kernel tests of the changed kernels"
-    (timeout 900 python -m pytest -q -x tests/test_gpu_block.py tests/test_gpu_kernels.py -k "block or frontend or mvn" 2>&1 | tail -4) | tee "$out/pytest_kernels.txt"
-    echo "== new parity tests"
-    (time timeout 1500 python -m pytest -q -s tests/test_gpu_fullsize.py tests/test_gpu_scorer_interface.py tests/test_gpu_search.py tests/test_gpu_e2e.py \
-       -k "bf16_vs_oracle or 640_rows or dec_self_attention or long_memory or large_peaked or peaked_posteriors or lnq or bfloat16_within or large_rows" > "$out/pytest_parity_full.txt" 2>&1; grep -E "^\[|passed|failed|Error|assert " "$out/pytest_parity_full.txt" | cut -c1-400 | tail -60) 2>&1 | tee "$out/pytest_parity.txt"
+    (timeout 300 python -m pytest -q -x tests/test_gpu_block.py tests/test_gpu_kernels.py -k "block or frontend or mvn" 2>&1 | tail -4) | tee "$out/pytest_kernels.txt"
     echo "== A/B: LayerNorm hand-over (v32 = weight requests in one cluster in front of the LayerNorm)"
     for v in new v32 new v32; do
       if [ $v = new ]; then unset ESPNET_AMD_LIB; else export ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_$v.so; fi
@@ -48,7 +46,7 @@ case "$what" in
     echo "== fine stamps"; ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_fine.so EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep -E "block<(1|6)>" | tail -8 | cut -c1-900 | tee "$out/block_stamps_fine.txt"
     echo "== kernel stats + launch order of one step"
     d="$out/prof_greedy"
-    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$d" -o s --output-format csv -- python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 > "$d.log" 2>&1 < /dev/null)
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$d" -o s --output-format csv -- python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 > "$d.log" 2>&1 < /dev/null)
     f=$(find "$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f" | cut -c1-150
     t=$(find "$d" -name "*kernel_trace.csv" | head -1)
     [ -n "$t" ] && python - "$t" <<'PY' | tee "$out/launch_order.txt"
@@ -56,7 +54,6 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# the last frontend launch starts the last step
 idx = [i for i, n in enumerate(names) if "frontend_logmel" in n]
 lo, hi = idx[-2], idx[-1]
 t0 = int(rows[lo]["Start_Timestamp"])
@@ -64,7 +61,17 @@ for r in rows[lo:hi]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     print(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:7.1f}  {r['Kernel_Name'][:90]}")
 PY
-    find "$d" -name "*_kernel_trace.csv" -delete 2>/dev/null ;;
+    find "$d" -name "*_kernel_trace.csv" -delete 2>/dev/null
+    echo "== new parity tests"
+    for sel in "tests/test_gpu_e2e.py -k large_peaked_or_peaked_posteriors_or_bfloat16_within_or_large_rows" \
+               "tests/test_gpu_scorer_interface.py -k 640_rows" \
+               "tests/test_gpu_search.py -k dec_self_attention_or_long_memory_or_lnq" \
+               "tests/test_gpu_fullsize.py -k b16_rows_bf16_vs_oracle" \
+               "tests/test_gpu_fullsize.py -k b64_rows_bf16_vs_oracle"; do
+      sel=${sel//_or_/ or }
+      f=${sel%% *}; k=${sel#* -k }
+      (time timeout 420 python -m pytest -q -s "$f" -k "$k" > "$out/pytest_one.txt" 2>&1; grep -E "^\[|passed|failed|Error|assert " "$out/pytest_one.txt" | cut -c1-420 | tail -24) 2>&1 | tee -a "$out/pytest_parity.txt"
+    done ;;
   parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
     echo "== new parity tests"
