@@ -553,14 +553,20 @@ def test_search_very_short_memories_match_oracle(T):
     assert [h.yseq.tolist() for h in hb] == [h.yseq.tolist() for h in hyps]
 
 
-@pytest.mark.parametrize("T", [1600, 1480])
+# per scored token over FIVE label steps of an unscaled random memory (no cancellation over 249 tokens as in the bench-size
+# tests): measured on MI355X 1.17e-3 (T = 1 600) / 1.14e-3 (T = 1 480) through the two-launch source attention and the same
+# through the fused kernel at T = 1 472 (the control of this test: both forms must sit under ONE bound)
+LONG_MEMORY_EPS = 3e-3
+
+
+@pytest.mark.parametrize("T", [1600, 1480, 1472])
 def test_search_bf16_long_memory_falls_back_to_two_launch_source_attention(T):
     """norm2 + the query projection inside the source-attention kernel (`em_dec_src_attention_lnq`) needs more
     LDS than the plain kernel, so memories beyond Tpad 1 472 (d = 512) fit only the two-launch form - `decoder_step` must
     take it instead of failing with EM_ERR_UNSUPPORTED (the usable memory length stays ~1 690 frames).
-    A 512-wide decoder over a T-frame memory (T = 1 600: only the two-launch form fits; 1 480: just past the switch), five
-    label steps (maxlenratio -5), two utterances of different length: every device hypothesis re-scored teacher-forced
-    under the oracle's scorers."""
+    A 512-wide decoder over a T-frame memory (T = 1 600: only the two-launch form fits; 1 480: just past the switch; 1 472:
+    the fused kernel's largest memory, the control), five label steps (maxlenratio -5), two utterances of different
+    length: every device hypothesis re-scored teacher-forced under the oracle's scorers."""
     g = load_golden("large_beam10_3s")
     sd = golden_state_dict(g)
     d = g["config"]["encoder_conf"]["output_size"]
@@ -574,11 +580,13 @@ def test_search_bf16_long_memory_falls_back_to_two_launch_source_attention(T):
 
     dc = g["config"]["decoder_conf"]
     V = int(g["vocab"])
+    worst = {"decoder": 0.0, "ctc": 0.0}
     for b in range(2):
         e = enc[b, : olens[b]]
         ys = [h.yseq.tolist() for h in hyps[b]]
         ref = oracle_rescore_batch(sd, e, ys, dc["attention_heads"], dc["num_blocks"], float(g["ctc_weight"]), V - 1, maxlen=5)
         for h, r in zip(hyps[b], ref):
-            for k in ("decoder", "ctc"):
-                err = abs(float(h.scores[k]) - r[k]) / max(r["n_scored"], 1)
-                assert err <= BF16_EPS[k], (T, b, k, err)
+            for k in worst:
+                worst[k] = max(worst[k], abs(float(h.scores[k]) - r[k]) / max(r["n_scored"], 1))
+    print(f"[long memory T = {T}] bf16 vs oracle per scored token over 5 steps: decoder {worst['decoder']:.2e}, ctc {worst['ctc']:.2e}")
+    assert worst["decoder"] <= LONG_MEMORY_EPS and worst["ctc"] <= LONG_MEMORY_EPS, (T, worst)
