@@ -112,6 +112,15 @@ constexpr int BAR_UNIT = 1, BAR_PARAMS = 2, BAR_TILE = 4, BAR_LAST = 8;  // what
 
 #define EM_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// wave-uniform values handed to inline asm through "s" constraints: made scalar HERE (folds away when the value already
+// lives in SGPRs; a developer build with extra stamp code once kept `wave`-derived addresses in VGPRs and the asm did not assemble)
+__device__ __forceinline__ const unsigned char* em_uniform_ptr(const unsigned char* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
+}
+
 // KWT: depthwise-conv kernel width (D part).  RELU: the feed-forward activation is ReLU (the contextual-block streaming
 // encoder, contextual_block_conformer_encoder.py:148-154) instead of Swish; the conv module's Swish is unaffected.
 template <int MODE, int KWT = 31, bool RELU = false>
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // 11-14 LayerNorm (partials written, first barrier, applied + tiles written, second barrier), 15 LayerNorm done /
   // activations loaded, 20 FFN h0 done, 21 FFN loop done, 22 FFN residual done, 30 norm_final done, 31 x stored,
   // 40 q k v done, 50 linear_out done, 51 pointwise_conv1 + GLU done
-  auto stamp = [&](int code) {
+  auto stamp = [&](int code) __attribute__((always_inline)) {
     if constexpr (EM_BLOCK_FINE) {
       if (stamps && blockIdx.x == 3 && blockIdx.y == 5 && lane == 0 && nts < 64)
         stamps[wave * 64 + nts] = ((long long)code << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffll);
@@ -168,13 +177,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     }
     ++nts;
   };
-  auto fstamp = [&](int code) {  // sub-stage stamps: fine builds only
+  auto fstamp = [&](int code) __attribute__((always_inline)) {  // sub-stage stamps: fine builds only
     if constexpr (EM_BLOCK_FINE) stamp(code);
   };
   stamp(1);
   int nbar = 0;  // barriers passed
   // every barrier goes through here: retire own LDS operations, synchronise
-  auto bar = [&](int code) {  // `code` documents what the barrier is for
+  auto bar = [&](int code) __attribute__((always_inline)) {  // `code` documents what the barrier is for
     (void)code;
     ++nbar;
     EM_LGKM0();
@@ -184,14 +193,14 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // ---- row state ------------------------------------------------------------------------------
   float4 xr[2][4];     // residual x[frame mi][64 f + ncol .. + 3], f32
   bf16x8 act[2][8];    // activation fragments of the running GEMM: frame mi*16 + lr, k = 32 ks + 8 lg ..
-  auto load_x = [&]() {
+  auto load_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int f = 0; f < 4; ++f) xr[mi][f] = *(const float4*)(a.x + mrow[mi] * D + 64 * f + ncol);
   };
   float* const xdst = FOLD ? a.x_out : a.x;  // (folded: neighbours read this workgroup's rows of x as their halo)
-  auto store_x = [&]() {
+  auto store_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
       if (row_ok[mi]) {
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         for (int f = 0; f < 4; ++f) *(float4*)(xdst + mrow[mi] * D + 64 * f + ncol) = xr[mi][f];
       }
   };
-  auto load_act = [&]() {  // from abuf, after a barrier
+  auto load_act = [&]() __attribute__((always_inline)) {  // from abuf, after a barrier
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       red[128 + nf * 32 + mi * 16 + lr] = q;  // sum of squares about their mean
     }
   };
-  auto ln_finish = [&](const float* red, float mean[2], float rstd[2]) {
+  auto ln_finish = [&](const float* red, float mean[2], float rstd[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int m = mi * 16 + lr;
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // r03b_block_stamps_fine.txt) instead of the larger of the two.  sched_group_barrier pins the deal: left alone hipcc
   // clusters the loads first.
   auto no_pre = [] {};
-  auto ln_stats = [&](float mean[2], float rstd[2], int code, auto&& pre1, auto n1c) {
+  auto ln_stats = [&](float mean[2], float rstd[2], int code, auto&& pre1, auto n1c) __attribute__((always_inline)) {
     constexpr int N1 = decltype(n1c)::value;
     float* const red = red0 + (nln & 1) * 256;
     ++nln;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     ln_finish(red, mean, rstd);
   };
   // y = LN(x; g, b) with g, b at float offsets go / bo of parameter buffer pb
-  auto ln_apply_pre = [&](const float* pb, int go, int bo, float4 y[2][4], int code, auto&& pre1, auto n1c) {
+  auto ln_apply_pre = [&](const float* pb, int go, int bo, float4 y[2][4], int code, auto&& pre1, auto n1c) __attribute__((always_inline)) {
     float mean[2], rstd[2];
     ln_stats(mean, rstd, code, pre1, n1c);
 #pragma unroll
@@ -306,12 +315,12 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       }
     }
   };
-  auto ln_apply = [&](const float* pb, int go, int bo, float4 y[2][4], int code) {
+  auto ln_apply = [&](const float* pb, int go, int bo, float4 y[2][4], int code) __attribute__((always_inline)) {
     ln_apply_pre(pb, go, bo, y, code, no_pre, std::integral_constant<int, 0>{});
   };
   // LN(x) -> bf16 -> abuf -> activation fragments.  One more barrier, carrying `code` (the parameter reads of
   // this LayerNorm precede it).
-  auto ln_to_act_pre = [&](const float* pb, int go, int bo, int code, auto&& pre1, auto n1c, auto&& pre2, auto n2c) {
+  auto ln_to_act_pre = [&](const float* pb, int go, int bo, int code, auto&& pre1, auto n1c, auto&& pre2, auto n2c) __attribute__((always_inline)) {
     constexpr int N2 = decltype(n2c)::value;
     float4 y[2][4];
     __builtin_amdgcn_sched_barrier(0);
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     fstamp(14);
     load_act();
   };
-  auto ln_to_act = [&](const float* pb, int go, int bo, int code) {
+  auto ln_to_act = [&](const float* pb, int go, int bo, int code) __attribute__((always_inline)) {
     ln_to_act_pre(pb, go, bo, code, no_pre, std::integral_constant<int, 0>{}, no_pre, std::integral_constant<int, 0>{});
   };
   // ---- units: weight fragments go global memory -> registers, THREE UNITS AHEAD of the MFMAs ------------
@@ -350,20 +359,20 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   };
   WF ring[4];
   const unsigned voff = nf * 8192 + lane * 16;
-  auto read_unit = [&](const void* base, int u, WF& w) {
+  auto read_unit = [&](const void* base, int u, WF& w) __attribute__((always_inline)) {
     GU8 su = (GU8)base + (size_t)u * UNIT + voff;
 #pragma unroll
     for (int q = 0; q < 8; ++q) w.v[q] = *(GFRAG)(su + q * 1024);
   };
   // request the first units of a stage's K stream into ring[0 ..]: called as early as the ring is free (before
   // the LayerNorm / convolution that precedes the stage)
-  auto k_pre = [&](const void* base, int n) {
+  auto k_pre = [&](const void* base, int n) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) read_unit(base, j < n ? j : n - 1, ring[j]);
   };
   // N K units of `base` (compile-time count: fully unrolled, the body sees constants), the first min(3, N) already
   // requested by k_pre: body(fragments, u) per unit
-  auto stream_k = [&](const void* base, auto count, auto&& body) {
+  auto stream_k = [&](const void* base, auto count, auto&& body) __attribute__((always_inline)) {
     constexpr int N = decltype(count)::value;
 #pragma unroll
     for (int u = 0; u < N; ++u) {
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // profiles/r02u_static_vs_xcc_share.txt, but the returning atomic sat in front of every other request of the
   // prologue.)  Called as soon as the prologue's own requests are out.
   constexpr int MAXT = 16;  // chunks per wave at most: small grids warm what they can
-  auto touch = [&]() {
+  auto touch = [&]() __attribute__((always_inline)) {
 #ifdef EM_BLOCK_NO_TOUCH
     return;
 #endif
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     for (int i = 0; i < MAXT && worker + i * nworker < total; ++i) {
       int j = worker + i * nworker;                         // chunk of the launch's weight list (wave-uniform)
       const unsigned char* p = nullptr;
-      auto take = [&](const void* base, int n) {
+      auto take = [&](const void* base, int n) __attribute__((always_inline)) {
         if (p == nullptr) {
           if (j < n) p = (const unsigned char*)base + (size_t)j * 8192;
           else j -= n;
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           : "memory");
     }
   };
-  auto touch_done = [&]() {};
+  auto touch_done = [&]() __attribute__((always_inline)) {};
 
   // ---- prologue staging: parameter groups (and the depthwise conv's weights) go global memory -> LDS by LDS-DMA,
   // 1 KiB per wave-instruction, lines dealt round-robin to the four waves.  No registers, no wait at the point of
@@ -450,15 +459,15 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // (n1k is a compile-time count and every wave issues ceil(n1k / 4) requests, the surplus ones repeating the last line:
   // no loop, no branch.  Behind a LOOP around the asm hipcc put an s_waitcnt vmcnt(0) at the loop exit, i.e. a full
   // round trip for the lines just requested.)
-  auto dma_lines = [&](const void* g, unsigned lds_off, auto n1k_c) {
+  auto dma_lines = [&](const void* g, unsigned lds_off, auto n1k_c) __attribute__((always_inline)) {
     constexpr int n1k = decltype(n1k_c)::value;
     const unsigned voff16 = lane * 16;
 #pragma unroll
     for (int i = 0; i < (n1k + 3) / 4; ++i) {
       int j = wave + 4 * i;
       j = j < n1k ? j : n1k - 1;
-      const unsigned char* p = (const unsigned char*)g + (size_t)j * 1024;
-      const unsigned dst = lds_off + j * 1024;
+      const unsigned char* p = em_uniform_ptr((const unsigned char*)g + (size_t)j * 1024);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_off + j * 1024);
       unsigned keep;
       asm volatile(
           "s_mov_b32 %0, m0\n\t"
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     out[0] = c[0][0] + c[0][1];
     out[1] = c[1][0] + c[1][1];
   };
-  auto mma_k = [&](const WF& w, bool swap, f32x4 out[2]) { mma_of(act, w, swap, out); };
+  auto mma_k = [&](const WF& w, bool swap, f32x4 out[2]) __attribute__((always_inline)) { mma_of(act, w, swap, out); };
   // ---- FFN: x += scale * (W2 . swish(W1 . act + b1) + b2); b1 at pb + b1o, b2 at pb + b2o -------------------------
   // Round 3: the hidden activation never leaves the wave that computed it.  Wave w owns the 16 hidden columns
   // 16 w .. 16 w + 15 of every 64-wide chunk c (the K unit c of W1: 16 MFMAs over K = 256, as before).  In the
@@ -507,12 +516,12 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   // The weight stream is unchanged in bytes: per pair and wave 2 x 8 KiB of W1 (ring[0], ring[1]) and 2 x 8 KiB of
   // W2 (ring[2], ring[3]); a ring slot is refilled as soon as its 16 MFMAs are issued, i.e. requested one whole
   // iteration (64 MFMAs) ahead of its use.  The host pads odd chunk counts with a zero chunk (nch is even here).
-  auto read_w2 = [&](const void* w2, int p, int half, WF& w) {
+  auto read_w2 = [&](const void* w2, int p, int half, WF& w) __attribute__((always_inline)) {
     GU8 su = (GU8)w2 + (size_t)p * (2 * UNIT) + nf * 16384 + half * 8192 + lane * 16;
 #pragma unroll
     for (int q = 0; q < 8; ++q) w.v[q] = *(GFRAG)(su + q * 1024);
   };
-  auto ffn_pre = [&](const void* w1, const void* w2) {
+  auto ffn_pre = [&](const void* w1, const void* w2) __attribute__((always_inline)) {
     read_unit(w1, 0, ring[0]);
     read_unit(w1, 1, ring[1]);
     read_w2(w2, 0, 0, ring[2]);
@@ -520,9 +529,19 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   };
   // b1g != NULL: the first bias comes from GLOBAL memory (ff > 1024 does not fit the 7 KiB parameter group: the streaming
   // recipe's 2048), requested one pair ahead so that its latency is never in the chain
+  // `nbase` (may be null): W1-style units 0, 1 of the stage behind this module - what the two requests that run past the
+  // last chunk ask for (they used to repeat the last unit: issued unconditionally so that hipcc can count its waits, waited
+  // for by nobody); `after()`: the requests for ring[2], ring[3], issued behind the module's last MFMAs.
   auto ffn = [&](const float* pb, int b1o, int b2o, float scale, const void* w1, const void* w2, bool repark,
-                 const float* b1g) {
+                 const float* b1g, const void* nbase, auto&& after) __attribute__((always_inline)) {
     const int np = nch >> 1, lastc = nch - 1;
+    // chunk c of W1, or - past the end - unit c - nch of the next stage
+    auto read_w1 = [&](int c, WF& w) __attribute__((always_inline)) {
+      const bool past = c >= nch;
+      const void* b = (past && nbase) ? nbase : w1;
+      const int u = past ? (nbase ? c - nch : lastc) : c;
+      read_unit(b, u, w);
+    };
     // (compile-time: only the streaming instantiations carry the global-bias path; in the Conformer kernels a run-time
     // choice cost 30 registers)
     constexpr bool B1G = RELU;
@@ -543,7 +562,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll
       for (int f = 0; f < 4; ++f) xpark[(mi * 4 + f) * NT] = xr[mi][f];
     // bias + Swish + bf16 of the two chunks' 16 hidden columns of this wave -> the B fragments of the pair
-    auto swish_pack = [&](const f32x4 h[2][2], int p, bf16x8 hb[2]) {
+    auto swish_pack = [&](const f32x4 h[2][2], int p, bf16x8 hb[2]) __attribute__((always_inline)) {
       float4 b0, b1;
       if constexpr (B1G) {
         b0 = nb0;
@@ -563,7 +582,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
                           (bf16)act_(h[1][mi][2] + b1.z), (bf16)act_(h[1][mi][3] + b1.w)};
     };
     // 16 MFMAs of a W2 sub-unit: output fragments 8 half .. 8 half + 7, both frame halves
-    auto mma_w2 = [&](const WF& w, int half, const bf16x8 hb[2]) {
+    auto mma_w2 = [&](const WF& w, int half, const bf16x8 hb[2]) __attribute__((always_inline)) {
       if constexpr (dbg & 1) return;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -574,9 +593,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     f32x4 h[2][2];
     bf16x8 hb[2];
     mma_k(ring[0], false, h[0]);
-    read_unit(w1, 2 < nch ? 2 : lastc, ring[0]);
+    read_w1(2, ring[0]);
     mma_k(ring[1], false, h[1]);
-    read_unit(w1, 3 < nch ? 3 : lastc, ring[1]);
+    read_w1(3, ring[1]);
     swish_pack(h, 0, hb);
     // every wave holds its activation fragments and has read the conv weights: ABUF / WK may receive partial sums
     // from a wave that finishes early (the only barrier of the FFN besides the reduction's)
@@ -588,9 +607,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll 1
     for (int p = 0; p + 1 < np; ++p) {
       mma_k(ring[0], false, h[0]);                             // chunk 2p + 2
-      read_unit(w1, 2 * p + 4 < nch ? 2 * p + 4 : lastc, ring[0]);
+      read_w1(2 * p + 4, ring[0]);
       mma_k(ring[1], false, h[1]);                             // chunk 2p + 3
-      read_unit(w1, 2 * p + 5 < nch ? 2 * p + 5 : lastc, ring[1]);
+      read_w1(2 * p + 5, ring[1]);
       mma_w2(ring[2], 0, hb);                                  // pair p
       read_w2(w2, p + 1, 0, ring[2]);
       mma_w2(ring[3], 1, hb);
@@ -599,11 +618,12 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     }
     mma_w2(ring[2], 0, hb);                                    // the last pair
     mma_w2(ring[3], 1, hb);
+    after();
     fstamp(21);
     // ---- the four partial sums meet: wave w keeps the output fragments f = 4 f4 + w (its columns of the residual
     // layout) and hands the other twelve to their owners through 8 KiB slots (destination, source); summed in wave
     // order 0, 1, 2, 3 whatever the arrival order: deterministic
-    auto reduce_as = [&](auto nfc) {
+    auto reduce_as = [&](auto nfc) __attribute__((always_inline)) {
       constexpr int NF = decltype(nfc)::value;
 #pragma unroll
       for (int dst = 0; dst < 4; ++dst) {
@@ -647,8 +667,15 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     }
   };
   // x += (W . act + bias): four K units (N = 256), requested by k_pre(w, 4)
-  auto proj_resid = [&](const float* pb, int bo, const void* w) {
+  // `next(j)`, j = 0 .. 3: the request that fills ring[j] for the stage BEHIND this one.  Round 5: the stream does not stop
+  // at a stage boundary - a ring slot is handed to the next stage the moment its unit has been consumed (slot j once unit
+  // j is through, i.e. in front of unit j + 1; slot 3 behind the last unit), so the next stage's first units travel under
+  // this stage's last MFMAs and the LayerNorm between the two instead of being requested - 24 to 32 wave-wide loads, 1.5 -
+  // 2 K cycles of issue at a CU's 64 B/clk - at the head of that LayerNorm (profiles/r05b_block_stamps_fine.txt).
+  auto no_next = [](int) {};
+  auto proj_resid = [&](const float* pb, int bo, const void* w, auto&& next) __attribute__((always_inline)) {
     stream_k(w, std::integral_constant<int, 4>{}, [&](const WF& cur, int f) {
+      if (f > 0) next(f - 1);
       f32x4 c[2];
       mma_k(cur, false, c);
       const float4 b4 = *(const float4*)(pb + bo + 64 * f + ncol);
@@ -660,6 +687,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         xr[mi][f].w += c[mi][3] + b4.w;
       }
     });
+    next(3);
   };
 
   // every parameter group of the launch goes to LDS once (C: 1 group, A: 2, D|FINAL: 3, D|A: 4; 7 KiB each), and with a
@@ -702,11 +730,12 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     bar(0);  // the parameter groups are in LDS
     fstamp(4);
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
-    proj_resid(pb0, 0, a.wout);
+    proj_resid(pb0, 0, a.wout, [&](int j) {
+      if (j < 3) read_unit(a.pw1f, j, ring[j]);
+    });
     fstamp(50);
     // (x is stored at the end of the kernel, behind the last weight request: see the A part)
-    ln_to_act_pre(pb0, 256, 512, 0, [&] { read_unit(a.pw1f, 0, ring[0]); read_unit(a.pw1f, 1, ring[1]); }, std::integral_constant<int, 16>{},
-                  [&] { read_unit(a.pw1f, 2, ring[2]); }, std::integral_constant<int, 8>{});
+    ln_to_act(pb0, 256, 512, 0);
     fstamp(15);
     // pointwise_conv1 + GLU (convolution.py:66-69): unit 2j = value rows 64j.., unit 2j+1 = their gates
     f32x4 v[2], gt[2];
@@ -933,34 +962,114 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       f32x2 acc[16];
 #pragma unroll
       for (int o = 0; o < 16; ++o) acc[o] = bc2;
-      dma_lines(a.params, PAR_OFF, std::integral_constant<int, NG * (PAR_BYTES / 1024)>{});
-      if constexpr (!FOLD) load_x();  // (folded: the own rows' residual is already in registers, updated by linear_out)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < 16 + KW - 1; ++r) {
-        // (pinned: the opaque asm ties a zero offset of the request addresses to ALL accumulators of the running
-        // convolution, so the requests can neither be hoisted above this row nor the rows before it sunk below them;
-        // a sched_barrier alone does not do it: instruction selection places arithmetic freely around it)
-        constexpr int PIN1 = KWT == 31 ? 15 : 10, PIN2 = KWT == 31 ? 30 : 20;  // (thirds of the row loop)
-        if (r == PIN1 || r == PIN2) {
-          unsigned o = 0;
-          asm volatile("" : "+s"(o), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+      if constexpr (EM_BLOCK_VAR & 64) {  // (developer A/B: the requests in three clusters, as until round 4)
+        dma_lines(a.params, PAR_OFF, std::integral_constant<int, NG * (PAR_BYTES / 1024)>{});
+        if constexpr (!FOLD) load_x();  // (folded: the own rows' residual is already in registers, updated by linear_out)
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int r = 0; r < 16 + KW - 1; ++r) {
+          // (pinned: the opaque asm ties a zero offset of the request addresses to ALL accumulators of the running
+          // convolution, so the requests can neither be hoisted above this row nor the rows before it sunk below them;
+          // a sched_barrier alone does not do it: instruction selection places arithmetic freely around it)
+          constexpr int PIN1 = KWT == 31 ? 15 : 10, PIN2 = KWT == 31 ? 30 : 20;  // (thirds of the row loop)
+          if (r == PIN1 || r == PIN2) {
+            unsigned o = 0;
+            asm volatile("" : "+s"(o), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+                         "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]),
+                         "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+            const unsigned char* wp = (const unsigned char*)a.pw2 + o;
+            if (r == PIN1) {
+              read_unit(wp, 0, ring[0]);
+              read_unit(wp, 1, ring[1]);
+            } else {
+              read_unit(wp, 2, ring[2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // ... nor sink below the rows that follow
+          }
+          const unsigned u = *(const unsigned*)(tile + (hh * 16 + r) * TPITCH + 4 * cp);
+          const f32x2 v = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+  #pragma unroll
+          for (int o = 0; o < 16; ++o)
+            if (r - o >= 0 && r - o < KW) acc[o] = __builtin_elementwise_fma(wk2[r - o], v, acc[o]);
+        }
+      } else {
+        // Round 5: ONE request per row of the convolution instead of three clusters.  A cluster of 15 - 16 wave-wide
+        // requests (four waves: 60 KiB) stops the issuing wave for as long as the CU's memory pipeline takes to accept it
+        // - ~1 K cycles at 64 B/clk - and with one wave per SIMD nothing else issues meanwhile: the conv measured 9.3 K
+        // cycles against ~4.8 K of arithmetic + LDS waits (profiles/r05b_block_stamps_fine.txt: stamps 3 -> 5).  A row is
+        // ~72 cycles of packed FMAs; four waves asking for 1 KiB each per row stay under the 64 B/clk the pipeline drains.
+        // The order is: this wave's parameter lines (LDS-DMA), the residual rows, pointwise_conv2's first three units -
+        // the waits below count on the parameter lines being the oldest.  Every request sits between two pins: an opaque
+        // asm that redefines a zero offset in a VGPR (`vz`, part of every request's address) together with ALL
+        // accumulators - a request can neither be hoisted above the pin in front of it (its address depends on it) nor
+        // sunk below the one behind it (which overwrites the register it reads), and the pins are ordered with the rows
+        // through the accumulators.  No sched_barrier: the tile reads and the arithmetic of neighbouring rows interleave
+        // freely.
+        constexpr int NLINES = NG * (PAR_BYTES / 1024), NPW = (NLINES + 3) / 4;  // parameter lines of this wave
+        constexpr int NXL = FOLD ? 0 : 8, NREQ = NPW + NXL + 24, NROW = 16 + KW - 1, RPR = (NREQ + NROW - 1) / NROW;
+        unsigned vz = 0;
+        auto pin = [&]() __attribute__((always_inline)) {
+          asm volatile("" : "+v"(vz), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
                        "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]),
                        "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
-          const unsigned char* wp = (const unsigned char*)a.pw2 + o;
-          if (r == PIN1) {
-            read_unit(wp, 0, ring[0]);
-            read_unit(wp, 1, ring[1]);
+        };
+        auto request = [&](auto sc) __attribute__((always_inline)) {
+          constexpr int S = decltype(sc)::value;
+          if constexpr (S < NPW) {  // parameter line wave + 4 S (past the end: the last line again)
+            int j = wave + 4 * S;
+            j = j < NLINES ? j : NLINES - 1;
+            const unsigned char* pl = em_uniform_ptr((const unsigned char*)a.params + (size_t)j * 1024);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(PAR_OFF + j * 1024);
+            const unsigned vo = lane * 16 + vz;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %2\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(vo), "s"(pl), "s"(dst)
+                : "memory");
+          } else if constexpr (S < NPW + NXL) {
+            constexpr int i = S - NPW, mi = i >> 2, f = i & 3;
+            xr[mi][f] = *(const float4*)((const unsigned char*)(a.x + mrow[mi] * D + 64 * f + ncol) + vz);
           } else {
-            read_unit(wp, 2, ring[2]);
+            constexpr int i = S - NPW - NXL, u = i >> 3, q = i & 7;
+            GU8 su = (GU8)a.pw2 + (size_t)u * UNIT + (voff + vz);
+            ring[u].v[q] = *(GFRAG)(su + q * 1024);
           }
-          __builtin_amdgcn_sched_barrier(0);  // ... nor sink below the rows that follow
-        }
-        const unsigned u = *(const unsigned*)(tile + (hh * 16 + r) * TPITCH + 4 * cp);
-        const f32x2 v = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+        };
+        auto requests_of_row = [&](auto rc) __attribute__((always_inline)) {
+          constexpr int R = decltype(rc)::value;
+          if constexpr (R * RPR < NREQ) {
+            pin();
+            request(std::integral_constant<int, R * RPR>{});
+            if constexpr (RPR > 1 && R * RPR + 1 < NREQ) request(std::integral_constant<int, R * RPR + 1>{});
+          }
+        };
+        // (the tile words are read PF rows ahead, by hand: memory operations do not cross the pins - an asm with side
+        // effects orders them - so left to hipcc every row's LDS read sat right in front of its first use)
+        constexpr int PF = 3;
+        unsigned uw[NROW + PF];
+        auto tile_word = [&](int r) __attribute__((always_inline)) { return *(const unsigned*)(tile + (hh * 16 + r) * TPITCH + 4 * cp); };
 #pragma unroll
-        for (int o = 0; o < 16; ++o)
-          if (r - o >= 0 && r - o < KW) acc[o] = __builtin_elementwise_fma(wk2[r - o], v, acc[o]);
+        for (int r = 0; r < PF; ++r) uw[r] = tile_word(r);
+        auto rows = [&](auto self, auto rc) __attribute__((always_inline)) -> void {
+          constexpr int r = decltype(rc)::value;
+          if constexpr (r < NROW) {
+            requests_of_row(rc);
+            if constexpr (r + PF < NROW) uw[r + PF] = tile_word(r + PF);
+            const unsigned u = uw[r];
+            const f32x2 v = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+#pragma unroll
+            for (int o = 0; o < 16; ++o)
+              if (r - o >= 0 && r - o < KW) acc[o] = __builtin_elementwise_fma(wk2[r - o], v, acc[o]);
+            self(self, std::integral_constant<int, r + 1>{});
+          }
+        };
+        rows(rows, std::integral_constant<int, 0>{});
+        pin();  // (closes the last interval)
       }
       if constexpr (!FOLD) touch();  // (its chunk loop must stay OUT of the row loop: with a loop inside, hipcc does not unroll the rows and the accumulators go to scratch; folded: done in the C part)
       const int ch = 2 * cp, kt = ch >> 6, kl = ch & 63;
@@ -981,22 +1090,28 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     load_act();
     stamp(7);
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]
-    proj_resid(pb0, 0, a.pw2);                     // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158)
+    // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158); the ring goes over to the feed-forward module
+    proj_resid(pb0, 0, a.pw2, [&](int j) {
+      if (j == 0) read_unit(a.ff_w1, 0, ring[0]);
+      else if (j == 1) read_unit(a.ff_w1, 1, ring[1]);
+      else if (j == 2) read_w2(a.ff_w2, 0, 0, ring[2]);
+      else read_w2(a.ff_w2, 0, 1, ring[3]);
+    });
     stamp(10);
-    ln_to_act_pre(pb0, 256, 512, 0,
-                  [&] { read_unit(a.ff_w1, 0, ring[0]); read_unit(a.ff_w1, 1, ring[1]); read_w2(a.ff_w2, 0, 0, ring[2]); }, std::integral_constant<int, 24>{},
-                  [&] { read_w2(a.ff_w2, 0, 1, ring[3]); }, std::integral_constant<int, 8>{});  // norm_ff
+    ln_to_act(pb0, 256, 512, 0);                   // norm_ff
     stamp(15);
-    ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false, a.ff_b1g);  // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168)
+    // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168); with an A part behind it the ring goes over to the macaron module
+    if constexpr (HAS_A)
+      ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false, a.ff_b1g, a.ffm_w1, [&] {
+        read_w2(a.ffm_w2, 0, 0, ring[2]);
+        read_w2(a.ffm_w2, 0, 1, ring[3]);
+      });
+    else
+      ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false, a.ff_b1g, nullptr, [] {});
     stamp(22);
     {
       float4 y[2][4];
-      // norm_final (encoder_layer.py:170-171): the block's output; with an A part behind it the macaron module's first W1
-      // units are requested under it
-      if constexpr (HAS_A)
-        ln_apply_pre(pb1, 1280, 1536, y, 0, [&] { read_unit(a.ffm_w1, 0, ring[0]); read_unit(a.ffm_w1, 1, ring[1]); }, std::integral_constant<int, 16>{});
-      else
-        ln_apply(pb1, 1280, 1536, y, 0);
+      ln_apply(pb1, 1280, 1536, y, 0);             // norm_final (encoder_layer.py:170-171): the block's output
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1040,7 +1155,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       // the bias of unit u + 1 is requested while unit u computes: a global load issued next to its use would
       // put its L2 latency into every one of the 79 intervals
       float4 bnext = *(const float4*)(a.ctc_b + ncol);
-      auto ctc_unit = [&](const WF& w, int u) {
+      auto ctc_unit = [&](const WF& w, int u) __attribute__((always_inline)) {
         const float4 bb = bnext;
         bnext = *(const float4*)(a.ctc_b + (u + 1 < NU ? u + 1 : u) * 64 + ncol);
         f32x4 c[2];
@@ -1122,9 +1237,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     stamp(30);
     const float* const pa0 = HAS_D ? pb2 : pb0;  // GA
     const float* const pa1 = HAS_D ? pb3 : pb1;  // GA + 1
-    if constexpr (HAS_D) {  // (W1's first units were requested under norm_final)
-      ln_to_act_pre(pa0, 0, 256, 0, [&] { read_w2(a.ffm_w2, 0, 0, ring[2]); read_w2(a.ffm_w2, 0, 1, ring[3]); }, std::integral_constant<int, 16>{},
-                    no_pre, std::integral_constant<int, 0>{});
+    if constexpr (HAS_D) {  // (the macaron module's first units were requested by the feed-forward module in front of it)
+      ln_to_act(pa0, 0, 256, 0);
     } else {
       touch();
       ln_to_act_pre(pa0, 0, 256, 0,
@@ -1132,15 +1246,15 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
                     [&] { read_w2(a.ffm_w2, 0, 1, ring[3]); }, std::integral_constant<int, 8>{});
     }
     stamp(15);
-    ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2, true, a.ffm_b1g);  // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121)
+    // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121); the ring goes over to the q / k / v projections
+    ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2, true, a.ffm_b1g, a.wqkv, [&] { read_unit(a.wqkv, 2, ring[2]); });
     stamp(22);
     // (x is stored at the very END of the kernel, from its LDS parking place: its eight 16-byte stores per lane, issued
     // in front of the q / k / v weight requests, sat in the same in-order count the waits for those requests use and
     // their slow acknowledgement from L2 stalled the stream - norm_mha took 4 300 cycles to its first barrier against
     // 3 100 for the other LayerNorms.  The q / k / v stores themselves stay inside the stream: batched behind it they
     // cost MORE, a store-issue tail of 3 300 cycles that the stream otherwise hides; profiles/r03c_*)
-    ln_to_act_pre(pa1, 0, 256, 0, [&] { read_unit(a.wqkv, 0, ring[0]); read_unit(a.wqkv, 1, ring[1]); }, std::integral_constant<int, 16>{},
-                  [&] { read_unit(a.wqkv, 2, ring[2]); }, std::integral_constant<int, 8>{});  // norm_mha (encoder_layer.py:123-127)
+    ln_to_act(pa1, 0, 256, 0);                     // norm_mha (encoder_layer.py:123-127)
     stamp(15);
     // q / k / v projections (attention.py:91-97), written per head: Q, K as [B][H][Tpad][64], V transposed
     // as [B][H][64][Tpad] (computed with the MFMA operands swapped so a lane holds 4 consecutive frames).

@@ -72,6 +72,24 @@ PY
       f=${sel%% *}; k=${sel#* -k }
       (time timeout 420 python -m pytest -q -s "$f" -k "$k" > "$out/pytest_one.txt" 2>&1; grep -E "^\[|passed|failed|Error|assert " "$out/pytest_one.txt" | cut -c1-420 | tail -24) 2>&1 | tee -a "$out/pytest_parity.txt"
     done ;;
+  r05c)     # round 5: the weight stream carried across stage boundaries + one request per row of the depthwise conv
+            # (A/B: lib_prev = block.hip of the commit before, lib_v64 = new stream, conv requests in three clusters)
+    echo "== tests of the changed kernels (block kernels, streaming layers on them, end-to-end bf16 goldens)"
+    (timeout 600 python -m pytest -q -x tests/test_gpu_block.py tests/test_gpu_streaming.py tests/test_gpu_e2e.py -k "block or fused or stream or bfloat16_within or peaked or midmargin or per_operator" 2>&1 | tail -4) | tee "$out/pytest_kernels.txt"
+    echo "== A/B"
+    for v in new prev v64 new prev v64; do
+      if [ $v = new ]; then unset ESPNET_AMD_LIB; else export ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_$v.so; fi
+      echo -n "block $v: "; quick 600
+    done 2>&1 | tee "$out/ab_block.txt"
+    unset ESPNET_AMD_LIB
+    echo "== fine stamps"; ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_fine.so EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep -E "block<(1|6)>" | tail -8 | cut -c1-900 | tee "$out/block_stamps_fine.txt"
+    echo "== kernel stats"; stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 50 --warmup 5
+    echo "== stream batch32"; timeout 300 python - <<'PY' 2>/dev/null | tee "$out/stream_batch32.txt"
+import json, bench
+r = bench.run_stream_batch("bfloat16", 32, 3, 1)
+print("batch32:", json.dumps({k: r[k] for k in r if k != "config"})[:300])
+PY
+    ;;
   parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
     echo "== new parity tests"
