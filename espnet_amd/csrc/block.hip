@@ -962,7 +962,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       f32x2 acc[16];
 #pragma unroll
       for (int o = 0; o < 16; ++o) acc[o] = bc2;
-      if constexpr (EM_BLOCK_VAR & 64) {  // (developer A/B: the requests in three clusters, as until round 4)
+      if constexpr (!(EM_BLOCK_VAR & 64)) {  // the requests in three clusters (-DEM_BLOCK_VAR=64: one per row, below - measured no faster)
         dma_lines(a.params, PAR_OFF, std::integral_constant<int, NG * (PAR_BYTES / 1024)>{});
         if constexpr (!FOLD) load_x();  // (folded: the own rows' residual is already in registers, updated by linear_out)
         __builtin_amdgcn_sched_barrier(0);
@@ -993,7 +993,10 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
             if (r - o >= 0 && r - o < KW) acc[o] = __builtin_elementwise_fma(wk2[r - o], v, acc[o]);
         }
       } else {
-        // Round 5: ONE request per row of the convolution instead of three clusters.  A cluster of 15 - 16 wave-wide
+        // Round 5 experiment (built, verified, NOT faster: profiles/r05c_block_ab.txt - the conv phase drops from 9.3 K to
+        // 8.4 K cycles, but pointwise_conv2's units, now requested as late as row 38, arrive late and its four units take
+        // 5.3 K cycles instead of 1.9 K; the launch as a whole 1.026 - 1.029 against 1.021 - 1.025 ms per step):
+        // ONE request per row of the convolution instead of three clusters.  A cluster of 15 - 16 wave-wide
         // requests (four waves: 60 KiB) stops the issuing wave for as long as the CU's memory pipeline takes to accept it
         // - ~1 K cycles at 64 B/clk - and with one wave per SIMD nothing else issues meanwhile: the conv measured 9.3 K
         // cycles against ~4.8 K of arithmetic + LDS waits (profiles/r05b_block_stamps_fine.txt: stamps 3 -> 5).  A row is
