@@ -22,6 +22,15 @@
 // match with two 8-byte LDS loads.)  rel_shift is index arithmetic: the dense window
 // D[c][i] = p[c] . (q_i + v) over the 80 position rows a (16 query, 64 key) tile can reach is written to
 // a per-wave scratch and read back skewed, BD^T[j][i] = D[15 - i + j][i].
+//
+// Round 5, measured and NOT kept (git: the commit "attention: two 16-query fragments per wave ..."; profiles/r05e_attention_two_
+// fragments_ab.txt): two query fragments per wave with the key tiles dealt to the two halves of the workgroup - every K / V^T
+// operand fragment read from LDS feeding two MFMAs, the two fragments' position windows sharing 96 rows, the halves'
+// online-softmax states merged once at the end - cuts the LDS operand traffic by a third and is SLOWER: 12.15 against
+// 11.19 us (T = 249, 4 heads, B = 32), 42.5 against 40.1 us (8 heads, B = 64), same call, same box.  The tile loop is not
+// bound by LDS bandwidth; what it waits for is the dependent chain of a tile (operand reads -> MFMAs -> scratch round trip
+// -> row maximum -> exponentials -> P . V) with two waves per SIMD to cover it, and half as many, twice as fat waves cover
+// it worse.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -306,278 +315,6 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
 }
 
 
-// ---- round 5: the same computation with TWO 16-query fragments per wave and the key tiles dealt to the two halves of the
-// workgroup.  Round 4's counters and stamps put relpos_attn2_kernel at ~3.6 K cycles per 64-key tile with the matrix cores
-// busy a quarter of that; the operand traffic explains it: every wave reads the tile's whole K (8 KiB), 80 position rows
-// (10 KiB) and V^T (8 KiB) from LDS for its 16 queries and moves 10 KiB of rel-shift scratch - 36 KiB per wave and tile,
-// 288 KiB per tile for the eight waves = 2.3 K cycles of the LDS's 128 B/clk.  Here wave (qg, kh) owns the 32 queries
-// 32 qg .. 32 qg + 31 of the workgroup's 128 and the key tiles kt = kh (mod 2): an A-operand fragment of K / V^T read from
-// LDS feeds two MFMAs (one per query fragment), and the two fragments' position windows - 80 rows each, 16 apart - are 96
-// rows, six fragment reads for ten MFMAs.  LDS traffic per (32 queries, 64 keys): 8 + 12 + 8 KiB of operands + 20 KiB of
-// scratch against 2 x 36 KiB: -33 %.  Each half keeps its own online-softmax state over its tiles; the halves meet once,
-// at the end, through LDS (m = max(m0, m1), O = O0 e^(m0 - m) + O1 e^(m1 - m), likewise the denominators).
-__global__ __launch_bounds__(512) void relpos_attn3_kernel(
-    const bf16* __restrict__ qh, const bf16* __restrict__ kh_, const bf16* __restrict__ vt,
-    const bf16* __restrict__ p, int ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v,
-    const int* __restrict__ klens, int T, int Tpad, int H, bf16* __restrict__ ctx) {
-  using MM = Mma<bf16>;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qg = wave & 3, khalf = wave >> 2;
-  const int lr = lane & 15, lg = lane >> 4, swz = lr & 7;
-  const int hh = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * QB, iw0 = i0 + 32 * qg;
-  const int klen = klens[b] < T ? klens[b] : T;
-  const size_t bh = (size_t)b * H + hh;
-
-  const unsigned char* k_base = uniform_ptr((const unsigned char*)(kh_ + bh * Tpad * 64));
-  const unsigned char* v_base = uniform_ptr((const unsigned char*)(vt + bh * 64 * Tpad));
-  const unsigned char* p_base = uniform_ptr((const unsigned char*)(p + hh * 64));
-  // staging of one 64-key tile by all eight waves: exactly relpos_attn2_kernel's
-  auto stage_tile = [&](int js, int t) {
-    const int r8 = lane >> 3, c8 = lane & 7;
-    {
-      int row = js + 64 * t + 8 * wave + r8;
-      row = row < Tpad ? row : Tpad - 1;
-      glds16(k_base, row * 128 + ((c8 ^ r8) << 4), SK_OFF + (8 * t + wave) * 1024);
-    }
-    const int cbase = T - 1 - (i0 + QB - 1) + js;
-    auto prow = [&](int pj) {
-      int c = cbase + 8 * pj + r8;
-      c = c < 0 ? 0 : (c > 2 * T - 2 ? 2 * T - 2 : c);
-      glds16(p_base, c * (ldp * 2) + ((c8 ^ r8) << 4), SP_OFF + pj * 1024);
-    };
-    if (t == 0) {
-      prow(3 * wave);
-      prow(3 * wave + 1);
-      prow(3 * wave + 2);
-    } else {
-      prow(24 + 8 * (t - 1) + wave);
-    }
-    {
-      const int row = 8 * wave + r8;
-      int col = js + 64 * t;
-      col = col < Tpad ? col : Tpad - 64;
-      glds16(v_base, (row * Tpad + col) * 2 + ((c8 ^ ((row >> 1) & 7)) << 4), SV_OFF + t * 8192 + wave * 1024);
-    }
-  };
-
-  // ---- query fragments of the wave's two 16-query groups + the two position biases (inline asm: see relpos_attn2_kernel)
-  typedef __attribute__((ext_vector_type(4))) float f4;
-  f4 qraw[2][2], ur[4], vr[4];
-  {
-    const bf16* qrow0 = qh + (bh * Tpad + iw0 + lr) * 64 + lg * 8;
-    const bf16* qrow1 = qrow0 + 16 * 64;
-    const float* pu = pos_u + hh * 64 + lg * 8;
-    const float* pv = pos_v + hh * 64 + lg * 8;
-    asm volatile(
-        "global_load_dwordx4 %0, %12, off\n\t"
-        "global_load_dwordx4 %1, %12, off offset:64\n\t"
-        "global_load_dwordx4 %2, %13, off\n\t"
-        "global_load_dwordx4 %3, %13, off offset:64\n\t"
-        "global_load_dwordx4 %4, %14, off\n\t"
-        "global_load_dwordx4 %5, %14, off offset:16\n\t"
-        "global_load_dwordx4 %6, %14, off offset:128\n\t"
-        "global_load_dwordx4 %7, %14, off offset:144\n\t"
-        "global_load_dwordx4 %8, %15, off\n\t"
-        "global_load_dwordx4 %9, %15, off offset:16\n\t"
-        "global_load_dwordx4 %10, %15, off offset:128\n\t"
-        "global_load_dwordx4 %11, %15, off offset:144"
-        : "=&v"(qraw[0][0]), "=&v"(qraw[0][1]), "=&v"(qraw[1][0]), "=&v"(qraw[1][1]), "=&v"(ur[0]), "=&v"(ur[1]),
-          "=&v"(ur[2]), "=&v"(ur[3]), "=&v"(vr[0]), "=&v"(vr[1]), "=&v"(vr[2]), "=&v"(vr[3])
-        : "v"(qrow0), "v"(qrow1), "v"(pu), "v"(pv)
-        : "memory");
-  }
-  stage_tile(0, 0);
-  if (64 < klen) stage_tile(0, 1);
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(ur[0]), "+v"(ur[1]),
-                 "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]), "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
-               :
-               : "memory");
-  bf16x8 qu[2][2], qv[2][2];
-#pragma unroll
-  for (int qf = 0; qf < 2; ++qf)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 raw = __builtin_bit_cast(bf16x8, qraw[qf][ks]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float q = (float)raw[e];
-        qu[qf][ks][e] = (bf16)((q + ur[2 * ks + (e >> 2)][e & 3]) * 0.125f);  // 1 / sqrt(64) folded in: exact
-        qv[qf][ks][e] = (bf16)((q + vr[2 * ks + (e >> 2)][e & 3]) * 0.125f);
-      }
-    }
-
-  f32x4 acc_o[2][4], acc_l[2];
-  float row_m[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-  for (int qf = 0; qf < 2; ++qf) {
-    acc_l[qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int f = 0; f < 4; ++f) acc_o[qf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
-  constexpr float LOG2E = 1.4426950408889634f;
-  float* const bd = (float*)(smem + SBD_OFF) + wave * 16 * LDB;
-
-  for (int js = 0; js < klen; js += KSUP) {
-    if (js > 0) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave is done with the previous super-tile
-      stage_tile(js, 0);
-      if (js + 64 < klen) stage_tile(js, 1);
-    }
-#pragma unroll
-    for (int tp = 0; tp < KSUP / 128; ++tp) {
-      if (js + 128 * tp >= klen) break;  // (uniform)
-      // the pair's two tiles have landed (this wave's pieces, then - barrier - everybody's); the next pair travels meanwhile
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (tp + 1 < KSUP / 128) {
-        if (js + 128 * (tp + 1) < klen) stage_tile(js, 2 * tp + 2);
-        if (js + 128 * (tp + 1) + 64 < klen) stage_tile(js, 2 * tp + 3);
-      }
-      const int kt = 2 * tp + khalf, jl = kt * 64, j0 = js + jl;
-      if (j0 < klen) {  // (uniform per wave; no barrier inside)
-        // ---- S^T (64 keys x 16 queries) x 2 and the dense position windows: rows 96 - 32 qg + jl + 16 pf + lr, pf = 0 .. 5;
-        // query fragment 0 reads pf 1 .. 5, fragment 1 (16 queries later: window 16 rows earlier) pf 0 .. 4
-        f32x4 sc[2][4], dd[2][5];
-#pragma unroll
-        for (int qf = 0; qf < 2; ++qf) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n) sc[qf][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int n = 0; n < 5; ++n) dd[qf][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        const unsigned char* sk = smem + SK_OFF + (jl + lr) * 128;
-        const unsigned char* sp = smem + SP_OFF + (96 - 32 * qg + jl + lr) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int coff = ((ks * 4 + lg) ^ swz) << 4;
-#pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            const bf16x8 kf = *(const bf16x8*)(sk + n * 2048 + coff);
-            sc[0][n] = MM::mma(kf, qu[0][ks], sc[0][n]);
-            sc[1][n] = MM::mma(kf, qu[1][ks], sc[1][n]);
-          }
-#pragma unroll
-          for (int pf = 0; pf < 6; ++pf) {
-            const bf16x8 pfr = *(const bf16x8*)(sp + pf * 2048 + coff);
-            if (pf >= 1) dd[0][pf - 1] = MM::mma(pfr, qv[0][ks], dd[0][pf - 1]);
-            if (pf <= 4) dd[1][pf] = MM::mma(pfr, qv[1][ks], dd[1][pf]);
-          }
-        }
-        bf16x8 pb[2][2];
-#pragma unroll
-        for (int qf = 0; qf < 2; ++qf) {
-          // ---- rel_shift: D[c][i] -> scratch[i][c], read back at c = 15 - i + j (the wave's scratch serves its two
-          // fragments one after the other: LDS operations of one wave execute in order)
-#pragma unroll
-          for (int n = 0; n < 5; ++n)
-            *(float4*)(bd + lr * LDB + 16 * n + 4 * lg) = make_float4(dd[qf][n][0], dd[qf][n][1], dd[qf][n][2], dd[qf][n][3]);
-          const float* bdr = bd + lr * LDB + 15 - lr + 4 * lg;
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[qf][n][r] += bdr[16 * n + r];
-          if (j0 + 64 > klen) {  // (uniform: only the tile that holds the utterance's end masks anything)
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sc[qf][n][r] = (j0 + 16 * n + 4 * lg + r < klen) ? sc[qf][n][r] : -INFINITY;
-          }
-          float tm = -INFINITY;
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tm = fmaxf(tm, sc[qf][n][r]);
-          tm = wave_xor16_max(tm);
-          tm = wave_xor32_max(tm);
-          const float mn = fmaxf(row_m[qf], tm);
-          const float alpha = __expf(row_m[qf] - mn);
-          row_m[qf] = mn;
-          const float mnl = mn * LOG2E;
-          unsigned pbu[2][4];
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qf][n][2 * h], LOG2E, -mnl));
-              const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qf][n][2 * h + 1], LOG2E, -mnl));
-              typedef __attribute__((ext_vector_type(2))) float f32x2;
-              typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-              pbu[n >> 1][(n & 1) * 2 + h] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
-            }
-#pragma unroll
-          for (int jp = 0; jp < 2; ++jp) {
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-            pb[qf][jp] = __builtin_bit_cast(bf16x8, (u32x4){pbu[jp][0], pbu[jp][1], pbu[jp][2], pbu[jp][3]});
-          }
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            acc_o[qf][f][0] *= alpha; acc_o[qf][f][1] *= alpha; acc_o[qf][f][2] *= alpha; acc_o[qf][f][3] *= alpha;
-          }
-          acc_l[qf][0] *= alpha;
-        }
-        // ---- O^T += V^T . P^T for both fragments from one read of the V^T operands
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          acc_l[0] = MM::mma(ones, pb[0][jp], acc_l[0]);
-          acc_l[1] = MM::mma(ones, pb[1][jp], acc_l[1]);
-          const int c0 = 4 * jp + (lg >> 1);
-          const int sw = (lr >> 1) & 7;
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            const unsigned char* sv = smem + SV_OFF + kt * 8192 + (16 * f + lr) * 128 + (lg & 1) * 8;
-            const bf16x4 a0 = *(const bf16x4*)(sv + ((c0 ^ sw) << 4));
-            const bf16x4 a1 = *(const bf16x4*)(sv + (((c0 + 2) ^ sw) << 4));
-            const bf16x8 vf = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            acc_o[0][f] = MM::mma(vf, pb[0][jp], acc_o[0][f]);
-            acc_o[1][f] = MM::mma(vf, pb[1][jp], acc_o[1][f]);
-          }
-        }
-      }
-    }
-  }
-  // ---- the two key halves meet: half 1 hands (O, l, m) of its 32 queries to half 0 through the K / V^T area
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // nobody reads operands any more (and every request into this LDS has landed)
-  float* const mg = (float*)(smem + SK_OFF) + qg * (9 * 256);  // [8 x (fragment, f)][64 lanes] f32x4, then [64 lanes] (m0, l0, m1, l1)
-  if (khalf == 1) {
-#pragma unroll
-    for (int qf = 0; qf < 2; ++qf)
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-        *(float4*)(mg + ((qf * 4 + f) * 64 + lane) * 4) = make_float4(acc_o[qf][f][0], acc_o[qf][f][1], acc_o[qf][f][2], acc_o[qf][f][3]);
-    *(float4*)(mg + (8 * 64 + lane) * 4) = make_float4(row_m[0], acc_l[0][0], row_m[1], acc_l[1][0]);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (khalf == 0) {
-    const float4 st = *(const float4*)(mg + (8 * 64 + lane) * 4);
-    const float m1[2] = {st.x, st.z}, l1[2] = {st.y, st.w};
-#pragma unroll
-    for (int qf = 0; qf < 2; ++qf) {
-      const int i = iw0 + 16 * qf + lr;
-      const float m = fmaxf(row_m[qf], m1[qf]);  // (half 0 always has tile 0: finite)
-      const float a0 = __expf(row_m[qf] - m), a1 = __expf(m1[qf] - m);
-      const float row_l = acc_l[qf][0] * a0 + l1[qf] * a1;
-      const float inv = row_l > 0.f ? 1.0f / row_l : 0.f;
-      if (i < T) {
-        bf16* o = ctx + ((size_t)b * T + i) * (H * 64) + hh * 64 + 4 * lg;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          const float4 o1 = *(const float4*)(mg + ((qf * 4 + f) * 64 + lane) * 4);
-          bf16x4 pk = {(bf16)((acc_o[qf][f][0] * a0 + o1.x * a1) * inv), (bf16)((acc_o[qf][f][1] * a0 + o1.y * a1) * inv),
-                       (bf16)((acc_o[qf][f][2] * a0 + o1.z * a1) * inv), (bf16)((acc_o[qf][f][3] * a0 + o1.w * a1) * inv)};
-          *(bf16x4*)(o + 16 * f) = pk;
-        }
-      }
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int em_relpos_attention2_bf16(const void* qh, const void* kh, const void* vt, const void* p,
@@ -595,17 +332,6 @@ extern "C" int em_relpos_attention2_bf16(const void* qh, const void* kh, const v
   if (want_stamps && !stamps && hipMalloc((void**)&stamps, 32 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
   if (want_stamps && hipMemsetAsync(stamps, 0, 32 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
-  // ESPNET_AMD_ATTN2_V1=1: developer A/B switch - the kernel of rounds 2-4 (16 queries per wave, every wave all key tiles)
-  static const bool v1 = getenv("ESPNET_AMD_ATTN2_V1") != nullptr;
-  static EmLdsCap cap3 = {};
-  if (!v1 && !want_stamps) {
-    if (em_raise_lds_cap((const void*)relpos_attn3_kernel, SMEM_BYTES, &cap3) != EM_OK) return EM_ERR_LAUNCH;
-    hipLaunchKernelGGL(relpos_attn3_kernel, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
-                       (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h, (bf16*)ctx);
-    if (rec) em_prof_end(stream, 6.0 * B * h * (double)T * T * 64, EM_PROF_ATTN);
-    EM_CHECK_LAUNCH();
-    return EM_OK;
-  }
   hipLaunchKernelGGL(relpos_attn2_kernel, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
                      (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h,
                      (bf16*)ctx, want_stamps ? stamps : nullptr);

@@ -90,23 +90,6 @@ r = bench.run_stream_batch("bfloat16", 32, 3, 1)
 print("batch32:", json.dumps({k: r[k] for k in r if k != "config"})[:300])
 PY
     ;;
-  r05d)     # round 5: attention with two query fragments per wave, key tiles dealt to the workgroup's halves (A/B: ESPNET_AMD_ATTN2_V1=1)
-    echo "== tests"
-    (timeout 600 python -m pytest -q -x tests/test_gpu_block.py tests/test_gpu_e2e.py tests/test_gpu_ebranchformer.py tests/test_gpu_fullsize.py -k "attention2 or bfloat16_within or peaked or midmargin or large_rows or ebf or greedy_b32" 2>&1 | tail -4) | tee "$out/pytest_kernels.txt"
-    echo "== A/B small"
-    for v in 0 1 0 1; do
-      if [ $v = 1 ]; then export ESPNET_AMD_ATTN2_V1=1; else unset ESPNET_AMD_ATTN2_V1; fi
-      echo -n "attn2_v1=$v: "; quick 600
-    done 2>&1 | tee "$out/ab_small.txt"
-    echo "== A/B large B=64"
-    for v in 0 1 0 1; do
-      if [ $v = 1 ]; then export ESPNET_AMD_ATTN2_V1=1; else unset ESPNET_AMD_ATTN2_V1; fi
-      echo -n "attn2_v1=$v: "; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s', d['ms_per_step'], 'ms/step')"
-    done 2>&1 | tee "$out/ab_large.txt"
-    unset ESPNET_AMD_ATTN2_V1
-    echo "== kernel stats small"; stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 50 --warmup 5
-    echo "== kernel stats large"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3
-    ;;
   parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
     echo "== new parity tests"
