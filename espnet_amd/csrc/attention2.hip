@@ -68,6 +68,7 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
   return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
 }
 
+template <bool PIPE>
 __global__ __launch_bounds__(512) void relpos_attn2_kernel(
     const bf16* __restrict__ qh, const bf16* __restrict__ kh, const bf16* __restrict__ vt,
     const bf16* __restrict__ p, int ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v,
@@ -154,11 +155,21 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
         : "memory");
   }
   stage_tile(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]),
-                 "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
-               :
-               : "memory");
+  const bool tile1 = 64 < klen;  // (uniform)
+  if (tile1) stage_tile(0, 1);   // staging runs two tiles ahead, see the key loop
+  // the queries, the biases and this wave's pieces of tile 0 have landed (tile 1's three requests are newer)
+  if (tile1)
+    asm volatile("s_waitcnt vmcnt(3)"
+                 : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]),
+                   "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
+                 :
+                 : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]),
+                   "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
+                 :
+                 : "memory");
   stamp();
   bf16x8 qu[2], qv[2];
 #pragma unroll
@@ -185,113 +196,142 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
   constexpr float LOG2E = 1.4426950408889634f;
   float* const bd = (float*)(smem + SBD_OFF) + wave * 16 * LDB;
 
+  // Round 5: the S^T / window MFMAs of tile kt + 1 are ISSUED in front of tile kt's rel-shift, softmax and P . V (two sets of
+  // score / window accumulators): round 4's stamps put a tile at 3.6 - 4.5 K cycles of which the matrix cores work ~0.9 K -
+  // the rest is the dependent chain operand reads -> MFMAs -> scratch round trip -> row maximum -> exponentials -> P . V,
+  // with two waves per SIMD to cover it (profiles/r05f_attn2_stamps.txt).  With the next tile's products in flight the chain
+  // of the current tile runs under them.  ESPNET_AMD_ATTN2_NOPIPE=1 (developer A/B) keeps the old order.
+  f32x4 scb[2][4], ddb[2][5];
+  auto s_phase = [&](int kt, f32x4 (&sc)[4], f32x4 (&dd)[5]) __attribute__((always_inline)) {
+    const int jl = kt * 64;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) sc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 5; ++n) dd[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* sk = smem + SK_OFF + (jl + lr) * 128;
+    const unsigned char* sp = smem + SP_OFF + (112 - 16 * wave + jl + lr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + lg) ^ swz) << 4;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) sc[n] = MM::mma(*(const bf16x8*)(sk + n * 2048 + coff), qu[ks], sc[n]);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) dd[n] = MM::mma(*(const bf16x8*)(sp + n * 2048 + coff), qv[ks], dd[n]);
+    }
+  };
+  auto rest_phase = [&](int kt, int j0, f32x4 (&sc)[4], f32x4 (&dd)[5]) __attribute__((always_inline)) {
+    if (stamps) asm volatile("s_nop 0" : "+v"(sc[3]), "+v"(dd[4]));  // (developer timing: the MFMAs have finished)
+    stamp();
+    // ---- rel_shift: D[c][i] -> scratch[i][c], read back at c = 15 - i + j
+#pragma unroll
+    for (int n = 0; n < 5; ++n)
+      *(float4*)(bd + lr * LDB + 16 * n + 4 * lg) = make_float4(dd[n][0], dd[n][1], dd[n][2], dd[n][3]);
+    float tm = -INFINITY;
+    const float* bdr = bd + lr * LDB + 15 - lr + 4 * lg;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[n][r] += bdr[16 * n + r];
+    if (j0 + 64 > klen) {  // (uniform: only the tile that holds the utterance's end masks anything)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[n][r] = (j0 + 16 * n + 4 * lg + r < klen) ? sc[n][r] : -INFINITY;
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tm = fmaxf(tm, sc[n][r]);
+    // ---- online softmax; this lane's query is iw0 + lr, its keys the 16 (n, r) of lane group lg
+    if (stamps) asm volatile("s_nop 0" : "+v"(tm));
+    stamp();
+    tm = wave_xor16_max(tm);  // the four lane groups of a query: two register swaps (gfx950), no LDS round trip
+    tm = wave_xor32_max(tm);
+    const float mn = fmaxf(row_m, tm);
+    const float alpha = __expf(row_m - mn);
+    row_m = mn;
+    const float mnl = mn * LOG2E;
+    unsigned pbu[2][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 (masked: 2^-inf = 0); two values per conversion
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[n][2 * h], LOG2E, -mnl));
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[n][2 * h + 1], LOG2E, -mnl));
+        // (as a vector conversion: one v_cvt_pk_bf16_f32, and hipcc places the wait state a v_exp_f32 result needs
+        // before a VALU read - from inline asm it does not, and the conversion read stale registers)
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        pbu[n >> 1][(n & 1) * 2 + h] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
+      }
+    bf16x8 pb[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      pb[jp] = __builtin_bit_cast(bf16x8, (u32x4){pbu[jp][0], pbu[jp][1], pbu[jp][2], pbu[jp][3]});
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      acc_o[f][0] *= alpha; acc_o[f][1] *= alpha; acc_o[f][2] *= alpha; acc_o[f][3] *= alpha;
+    }
+    acc_l[0] *= alpha;  // (the other three rows of the ones fragment carry the same sum; only this one is read)
+    if (stamps) asm volatile("s_nop 0" : "+v"(acc_o[3]));
+    stamp();
+    // ---- O^T += V^T . P^T   (V^T tile kt: [64 dk][128 B], chunk c holds keys 8 c .. 8 c + 7 of the tile)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      acc_l = MM::mma(ones, pb[jp], acc_l);
+      const int c0 = 4 * jp + (lg >> 1);
+      const int sw = (lr >> 1) & 7;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const unsigned char* sv = smem + SV_OFF + kt * 8192 + (16 * f + lr) * 128 + (lg & 1) * 8;
+        const bf16x4 a0 = *(const bf16x4*)(sv + ((c0 ^ sw) << 4));
+        const bf16x4 a1 = *(const bf16x4*)(sv + (((c0 + 2) ^ sw) << 4));
+        const bf16x8 vf = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        acc_o[f] = MM::mma(vf, pb[jp], acc_o[f]);
+      }
+    }
+  };
+  // Staging runs TWO tiles ahead (round 5; one ahead until then): tile kt + 2's pieces are requested in front of tile kt's
+  // chain and the wait in front of tile kt + 1's products counts them out (`vmcnt(3)`: a later tile is three requests per
+  // wave - K, position rows, V^T - and requests complete in order).
+  auto exists = [&](int js, int t) { return t < KSUP / 64 && js + 64 * t < klen; };
+  auto wait_but_newest_tile = [&](bool newer) __attribute__((always_inline)) {
+    if (newer) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   for (int js = 0; js < klen; js += KSUP) {
     if (js > 0) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave is done with the previous super-tile
       stage_tile(js, 0);
+      if (exists(js, 1)) stage_tile(js, 1);
     }
+    // tile 0 of the super-tile has landed: this wave's own pieces, then everybody's (barrier).  (Requested all at once up
+    // front, the tiles' pieces of different waves interleave in the memory pipeline and the first tile is complete only when
+    // most of the 112 KiB are: 12.8 -> 12.2 us; tile by tile: see profiles/r03m.)
+    wait_but_newest_tile(exists(js, 1));
+    __builtin_amdgcn_s_barrier();
+    stamp();
+    if (exists(js, 2)) stage_tile(js, 2);
+    s_phase(0, scb[0], ddb[0]);
 #pragma unroll
     for (int kt = 0; kt < KSUP / 64; ++kt) {
-      const int jl = kt * 64, j0 = js + jl;
+      const int j0 = js + kt * 64;
       if (j0 >= klen) break;
-      // this tile's pieces have landed: this wave's own (everything it has requested so far), then everybody's
-      // (barrier); the NEXT tile's pieces are requested now and travel while this tile is computed.  (Requested all
-      // at once up front, the tiles' pieces of different waves interleave in the memory pipeline and the first tile
-      // is complete only when most of the 112 KiB are: 12.8 -> 12.2 us; tile by tile: see profiles/r03m.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      stamp();
-      if (kt + 1 < KSUP / 64 && j0 + 64 < klen) stage_tile(js, kt + 1);
-      // ---- S^T (64 keys x 16 queries) and the dense position window D (80 rows x 16 queries)
-      f32x4 sc[4], dd[5];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) sc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int n = 0; n < 5; ++n) dd[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const unsigned char* sk = smem + SK_OFF + (jl + lr) * 128;
-      const unsigned char* sp = smem + SP_OFF + (112 - 16 * wave + jl + lr) * 128;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int coff = ((ks * 4 + lg) ^ swz) << 4;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) sc[n] = MM::mma(*(const bf16x8*)(sk + n * 2048 + coff), qu[ks], sc[n]);
-#pragma unroll
-        for (int n = 0; n < 5; ++n) dd[n] = MM::mma(*(const bf16x8*)(sp + n * 2048 + coff), qv[ks], dd[n]);
+      if (exists(js, kt + 1)) {  // (uniform) the next tile: landed -> its products are issued
+        wait_but_newest_tile(exists(js, kt + 2));
+        __builtin_amdgcn_s_barrier();
+        stamp();
+        if (exists(js, kt + 3)) stage_tile(js, kt + 3);
+        if constexpr (PIPE) s_phase(kt + 1, scb[(kt + 1) & 1], ddb[(kt + 1) & 1]);
       }
-      if (stamps) asm volatile("s_nop 0" : "+v"(sc[3]), "+v"(dd[4]));  // (developer timing: the MFMAs have finished)
-      stamp();
-      // ---- rel_shift: D[c][i] -> scratch[i][c], read back at c = 15 - i + j
-#pragma unroll
-      for (int n = 0; n < 5; ++n)
-        *(float4*)(bd + lr * LDB + 16 * n + 4 * lg) = make_float4(dd[n][0], dd[n][1], dd[n][2], dd[n][3]);
-      float tm = -INFINITY;
-      const float* bdr = bd + lr * LDB + 15 - lr + 4 * lg;
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sc[n][r] += bdr[16 * n + r];
-      if (j0 + 64 > klen) {  // (uniform: only the tile that holds the utterance's end masks anything)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sc[n][r] = (j0 + 16 * n + 4 * lg + r < klen) ? sc[n][r] : -INFINITY;
+      if constexpr (!PIPE) {
+        if (kt > 0) s_phase(kt, scb[kt & 1], ddb[kt & 1]);
       }
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tm = fmaxf(tm, sc[n][r]);
-      // ---- online softmax; this lane's query is iw0 + lr, its keys the 16 (n, r) of lane group lg
-      if (stamps) asm volatile("s_nop 0" : "+v"(tm));
-      stamp();
-      tm = wave_xor16_max(tm);  // the four lane groups of a query: two register swaps (gfx950), no LDS round trip
-      tm = wave_xor32_max(tm);
-      const float mn = fmaxf(row_m, tm);
-      const float alpha = __expf(row_m - mn);
-      row_m = mn;
-      const float mnl = mn * LOG2E;
-      unsigned pbu[2][4];
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 (masked: 2^-inf = 0); two values per conversion
-          const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[n][2 * h], LOG2E, -mnl));
-          const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[n][2 * h + 1], LOG2E, -mnl));
-          // (as a vector conversion: one v_cvt_pk_bf16_f32, and hipcc places the wait state a v_exp_f32 result needs
-          // before a VALU read - from inline asm it does not, and the conversion read stale registers)
-          typedef __attribute__((ext_vector_type(2))) float f32x2;
-          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-          pbu[n >> 1][(n & 1) * 2 + h] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
-        }
-      bf16x8 pb[2];
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-        pb[jp] = __builtin_bit_cast(bf16x8, (u32x4){pbu[jp][0], pbu[jp][1], pbu[jp][2], pbu[jp][3]});
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        acc_o[f][0] *= alpha; acc_o[f][1] *= alpha; acc_o[f][2] *= alpha; acc_o[f][3] *= alpha;
-      }
-      acc_l[0] *= alpha;  // (the other three rows of the ones fragment carry the same sum; only this one is read)
-      if (stamps) asm volatile("s_nop 0" : "+v"(acc_o[3]));
-      stamp();
-      // ---- O^T += V^T . P^T   (V^T tile kt: [64 dk][128 B], chunk c holds keys 8 c .. 8 c + 7 of the tile)
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        acc_l = MM::mma(ones, pb[jp], acc_l);
-        const int c0 = 4 * jp + (lg >> 1);
-        const int sw = (lr >> 1) & 7;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          const unsigned char* sv = smem + SV_OFF + kt * 8192 + (16 * f + lr) * 128 + (lg & 1) * 8;
-          const bf16x4 a0 = *(const bf16x4*)(sv + ((c0 ^ sw) << 4));
-          const bf16x4 a1 = *(const bf16x4*)(sv + (((c0 + 2) ^ sw) << 4));
-          const bf16x8 vf = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-          acc_o[f] = MM::mma(vf, pb[jp], acc_o[f]);
-        }
-      }
+      rest_phase(kt, j0, scb[kt & 1], ddb[kt & 1]);
     }
   }
   // (a workgroup that stopped early - klen short of the staged keys - still has requests in flight into ITS LDS)
@@ -324,17 +364,24 @@ extern "C" int em_relpos_attention2_bf16(const void* qh, const void* kh, const v
   if (!qh || !kh || !vt || !p || !pos_u || !pos_v || !klens || !ctx) return EM_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || h <= 0) return EM_ERR_BAD_ARG;
   if (Tpad % KSUP != 0 || Tpad < T || ldp % 8 != 0) return EM_ERR_UNSUPPORTED;
-  static EmLdsCap cap = {};
-  if (em_raise_lds_cap((const void*)relpos_attn2_kernel, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
+  static EmLdsCap cap = {}, cap_np = {};
+  if (em_raise_lds_cap((const void*)relpos_attn2_kernel<true>, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
+  if (em_raise_lds_cap((const void*)relpos_attn2_kernel<false>, SMEM_BYTES, &cap_np) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(T, QB), h, B);
   static long long* stamps = nullptr;
   static const bool want_stamps = getenv("EM_ATTN2_STAMPS") != nullptr;
   if (want_stamps && !stamps && hipMalloc((void**)&stamps, 32 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
   if (want_stamps && hipMemsetAsync(stamps, 0, 32 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
-  hipLaunchKernelGGL(relpos_attn2_kernel, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
-                     (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h,
-                     (bf16*)ctx, want_stamps ? stamps : nullptr);
+  static const bool nopipe = getenv("ESPNET_AMD_ATTN2_NOPIPE") != nullptr;
+  if (nopipe)
+    hipLaunchKernelGGL(relpos_attn2_kernel<false>, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
+                       (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h,
+                       (bf16*)ctx, want_stamps ? stamps : nullptr);
+  else
+    hipLaunchKernelGGL(relpos_attn2_kernel<true>, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
+                       (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h,
+                       (bf16*)ctx, want_stamps ? stamps : nullptr);
   if (want_stamps) {
     long long hs[32];
     if (hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess) {

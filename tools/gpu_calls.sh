@@ -90,6 +90,23 @@ r = bench.run_stream_batch("bfloat16", 32, 3, 1)
 print("batch32:", json.dumps({k: r[k] for k in r if k != "config"})[:300])
 PY
     ;;
+  attn-stamps5)  # relpos_attn2 cycle stamps of one wave (EM_ATTN2_STAMPS), small model
+    EM_ATTN2_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "attn2 stamps" | tail -6 | tee "$out/attn2_stamps.txt" ;;
+  r05g)     # attention: next tile's score / window MFMAs issued in front of the current tile's softmax chain (A/B: ESPNET_AMD_ATTN2_NOPIPE=1)
+    echo "== tests"
+    (timeout 600 python -m pytest -q -x tests/test_gpu_block.py tests/test_gpu_e2e.py tests/test_gpu_ebranchformer.py -k "attention2 or bfloat16_within or peaked or midmargin or large_rows or ebf" 2>&1 | tail -3) | tee "$out/pytest_kernels.txt"
+    for v in 0 1; do
+      if [ $v = 1 ]; then export ESPNET_AMD_ATTN2_NOPIPE=1; else unset ESPNET_AMD_ATTN2_NOPIPE; fi
+      echo "== nopipe=$v small"; stats "$out/prof_small_$v" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 50 --warmup 5 | grep -E "relpos" | sed 's/.*)",/  /'
+      echo "== nopipe=$v large"; stats "$out/prof_large_$v" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 | grep -E "relpos" | sed 's/.*)",/  /'
+    done 2>&1 | tee "$out/ab_attn_kernel_tables.txt"
+    for f in small_0 small_1 large_0 large_1; do echo -n "$f: "; grep -h "relpos_attn" "$out"/prof_$f/*kernel_stats.csv | sed 's/.*)",//'; done | tee -a "$out/ab_attn_kernel_tables.txt"
+    unset ESPNET_AMD_ATTN2_NOPIPE
+    for v in 0 1 0 1; do
+      if [ $v = 1 ]; then export ESPNET_AMD_ATTN2_NOPIPE=1; else unset ESPNET_AMD_ATTN2_NOPIPE; fi
+      echo -n "nopipe=$v: "; quick 600
+    done 2>&1 | tee "$out/ab_small.txt"
+    unset ESPNET_AMD_ATTN2_NOPIPE ;;
   parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
     echo "== new parity tests"
