@@ -68,7 +68,6 @@ __device__ __forceinline__ const unsigned char* uniform_ptr(const unsigned char*
   return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
 }
 
-template <bool PIPE>
 __global__ __launch_bounds__(512) void relpos_attn2_kernel(
     const bf16* __restrict__ qh, const bf16* __restrict__ kh, const bf16* __restrict__ vt,
     const bf16* __restrict__ p, int ldp, const float* __restrict__ pos_u, const float* __restrict__ pos_v,
@@ -155,21 +154,16 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
         : "memory");
   }
   stage_tile(0, 0);
-  const bool tile1 = 64 < klen;  // (uniform)
-  if (tile1) stage_tile(0, 1);   // staging runs two tiles ahead, see the key loop
-  // the queries, the biases and this wave's pieces of tile 0 have landed (tile 1's three requests are newer)
-  if (tile1)
-    asm volatile("s_waitcnt vmcnt(3)"
-                 : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]),
-                   "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
-                 :
-                 : "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]),
-                   "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
-                 :
-                 : "memory");
+  // the queries and the biases have landed (tile 0's five requests are newer).  ONE statement, no branch around it: the
+  // "+v" ties keep the values in the registers the loads write - with the wait in two branches (a first version of the
+  // two-tiles-ahead staging) hipcc merged the branches through register copies placed IN FRONT of the waits, i.e. copies of
+  // registers whose loads were still in flight (NaNs in test_relpos_attention2[49]).
+  asm volatile("s_waitcnt vmcnt(5)"
+               : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]),
+                 "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
+               :
+               : "memory");
+  if (64 < klen) stage_tile(0, 1);  // staging runs two tiles ahead, see the key loop (tile 0 is waited for there)
   stamp();
   bf16x8 qu[2], qv[2];
 #pragma unroll
@@ -196,11 +190,9 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
   constexpr float LOG2E = 1.4426950408889634f;
   float* const bd = (float*)(smem + SBD_OFF) + wave * 16 * LDB;
 
-  // Round 5: the S^T / window MFMAs of tile kt + 1 are ISSUED in front of tile kt's rel-shift, softmax and P . V (two sets of
-  // score / window accumulators): round 4's stamps put a tile at 3.6 - 4.5 K cycles of which the matrix cores work ~0.9 K -
-  // the rest is the dependent chain operand reads -> MFMAs -> scratch round trip -> row maximum -> exponentials -> P . V,
-  // with two waves per SIMD to cover it (profiles/r05f_attn2_stamps.txt).  With the next tile's products in flight the chain
-  // of the current tile runs under them.  ESPNET_AMD_ATTN2_NOPIPE=1 (developer A/B) keeps the old order.
+  // (Round 5, measured and not kept: the S^T / window MFMAs of tile kt + 1 issued in front of tile kt's rel-shift, softmax and
+  // P . V - two sets of score / window accumulators, 172 registers - is as fast as this order once the staging runs two tiles
+  // ahead: 11.15 against 11.12 us, 40.2 against 39.8 us; profiles/r05g_attention_pipelined_ab.txt.)
   f32x4 scb[2][4], ddb[2][5];
   auto s_phase = [&](int kt, f32x4 (&sc)[4], f32x4 (&dd)[5]) __attribute__((always_inline)) {
     const int jl = kt * 64;
@@ -326,11 +318,8 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
         __builtin_amdgcn_s_barrier();
         stamp();
         if (exists(js, kt + 3)) stage_tile(js, kt + 3);
-        if constexpr (PIPE) s_phase(kt + 1, scb[(kt + 1) & 1], ddb[(kt + 1) & 1]);
       }
-      if constexpr (!PIPE) {
-        if (kt > 0) s_phase(kt, scb[kt & 1], ddb[kt & 1]);
-      }
+      if (kt > 0) s_phase(kt, scb[kt & 1], ddb[kt & 1]);
       rest_phase(kt, j0, scb[kt & 1], ddb[kt & 1]);
     }
   }
@@ -364,24 +353,17 @@ extern "C" int em_relpos_attention2_bf16(const void* qh, const void* kh, const v
   if (!qh || !kh || !vt || !p || !pos_u || !pos_v || !klens || !ctx) return EM_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || h <= 0) return EM_ERR_BAD_ARG;
   if (Tpad % KSUP != 0 || Tpad < T || ldp % 8 != 0) return EM_ERR_UNSUPPORTED;
-  static EmLdsCap cap = {}, cap_np = {};
-  if (em_raise_lds_cap((const void*)relpos_attn2_kernel<true>, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
-  if (em_raise_lds_cap((const void*)relpos_attn2_kernel<false>, SMEM_BYTES, &cap_np) != EM_OK) return EM_ERR_LAUNCH;
+  static EmLdsCap cap = {};
+  if (em_raise_lds_cap((const void*)relpos_attn2_kernel, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(T, QB), h, B);
   static long long* stamps = nullptr;
   static const bool want_stamps = getenv("EM_ATTN2_STAMPS") != nullptr;
   if (want_stamps && !stamps && hipMalloc((void**)&stamps, 32 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
   if (want_stamps && hipMemsetAsync(stamps, 0, 32 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
-  static const bool nopipe = getenv("ESPNET_AMD_ATTN2_NOPIPE") != nullptr;
-  if (nopipe)
-    hipLaunchKernelGGL(relpos_attn2_kernel<false>, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
-                       (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h,
-                       (bf16*)ctx, want_stamps ? stamps : nullptr);
-  else
-    hipLaunchKernelGGL(relpos_attn2_kernel<true>, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
-                       (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h,
-                       (bf16*)ctx, want_stamps ? stamps : nullptr);
+  hipLaunchKernelGGL(relpos_attn2_kernel, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, (const bf16*)qh,
+                     (const bf16*)kh, (const bf16*)vt, (const bf16*)p, ldp, pos_u, pos_v, klens, T, Tpad, h,
+                     (bf16*)ctx, want_stamps ? stamps : nullptr);
   if (want_stamps) {
     long long hs[32];
     if (hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost) == hipSuccess) {

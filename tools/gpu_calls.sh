@@ -92,6 +92,8 @@ PY
     ;;
   attn-stamps5)  # relpos_attn2 cycle stamps of one wave (EM_ATTN2_STAMPS), small model
     EM_ATTN2_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "attn2 stamps" | tail -6 | tee "$out/attn2_stamps.txt" ;;
+  attn-stamps5)  # relpos_attn2 cycle stamps of one wave (EM_ATTN2_STAMPS), small model
+    EM_ATTN2_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "attn2 stamps" | tail -6 | tee "$out/attn2_stamps.txt" ;;
   r05g)     # attention: next tile's score / window MFMAs issued in front of the current tile's softmax chain (A/B: ESPNET_AMD_ATTN2_NOPIPE=1)
     echo "== tests"
     (timeout 600 python -m pytest -q -x tests/test_gpu_block.py tests/test_gpu_e2e.py tests/test_gpu_ebranchformer.py -k "attention2 or bfloat16_within or peaked or midmargin or large_rows or ebf" 2>&1 | tail -3) | tee "$out/pytest_kernels.txt"
