@@ -732,38 +732,36 @@ def profile_families(step_fn, nprof):
     return fam
 
 
-def event_bracket_us(dev, dtype):
-    """What the HIP-event bracket adds to a launch's measured duration: one encoder-sized projection GEMM
-    (M = 7 968, N = K = 256) launched 200 times back to back between two events (its cost inside an unbracketed
-    pipeline, boundary included) against the mean of its bracketed durations.  The family figures of `roofline` are
-    reported net of it (the bracketed sum exceeded the wall step)."""
+def event_bracket_us(step_fn, fam, nprof, passes=5):
+    """What the HIP-event bracket adds to a launch's measured duration, calibrated ON THE STEP ITSELF (round 5; until then
+    on a stand-alone GEMM, and the net family sums still exceeded the wall step by 0.3 - 4 %: a bracket costs a kernel
+    more or less depending on what runs either side of it): the wall time of `passes` passes of `step_fn` with the
+    profiler attached minus the same passes without it, per bracketed launch.  By construction the net family sums then
+    cannot exceed the unbracketed wall time of the pass."""
     from espnet_amd import lib as L
 
     lib = L.load()
-    act = torch.bfloat16 if dtype == "bfloat16" else torch.float32
-    em = L.EM_BF16 if dtype == "bfloat16" else L.EM_F32
-    M, N, K = 7968, 256, 256
-    A = torch.randn(M, K, device=dev).to(act)
-    W = torch.randn(N, K, device=dev).to(act)
-    Cm = torch.empty(M, N, dtype=act, device=dev)
-    args = L.EmGemmArgs(A=A.data_ptr(), W=W.data_ptr(), C=Cm.data_ptr(), bias=None, M=M, N=N, K=K, lda=K, ldc=N, scale=1.0)
+    prof = lib.em_profile_create(32768)
 
-    def launch():
-        L.check(lib.em_gemm(em, L.EM_EPI_STORE, L.EM_A_PLAIN, C.byref(args), L.current_stream_ptr()), "em_gemm")
+    def wall(attach):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            if attach:
+                lib.em_profile_attach(prof)
+            step_fn()
+            if attach:
+                lib.em_profile_attach(None)  # (records pile up in the profile's 32 768 slots: a few hundred here)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / passes
 
-    n = 200
-    for _ in range(20):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
-    plain_us = e0.elapsed_time(e1) / n * 1e3
-    fam = profile_families(lambda: [launch() for _ in range(n)], 1)
-    brk_us = fam[L.EM_PROF_GEMM][0] / fam[L.EM_PROF_GEMM][2] * 1e3
-    return max(0.0, brk_us - plain_us)
+    with torch.no_grad():
+        wall(False)
+        plain = min(wall(False), wall(False))
+        brk = min(wall(True), wall(True))
+    lib.em_profile_destroy(prof)
+    launches = sum(f[2] for f in fam.values()) / nprof
+    return max(0.0, (brk - plain) / max(1.0, launches) * 1e6)
 
 
 def roofline_object(fam, nprof, bracket_us, peak, wall_s_per_step, traffic, traffic_note):
@@ -784,7 +782,7 @@ def roofline_object(fam, nprof, bracket_us, peak, wall_s_per_step, traffic, traf
         "avg_launch_us_with_event_bracket": round(d_gross * 1e3 / d_n, 2),
         "event_bracket_us": round(bracket_us, 2),
         "timing": "HIP events around every launch on the launch stream, net of the bracket's own cost "
-                  "(event_bracket_us, calibrated in the same process on a back-to-back GEMM); the gross figure is "
+                  "(event_bracket_us: wall time of the same passes with and without the brackets, per launch); the gross figure is "
                   "beside it",
         "algorithmic_gflop_per_launch": round(d_fl / d_n / 1e9, 3),
         "algorithmic_gflop_per_step": round(d_fl / nprof / 1e9, 2),
@@ -966,7 +964,7 @@ def main():
     if rank == 0 and not args.no_roofline and step_plain is not None:
         nprof = max(1, min(args.steps, 5))
         fam = profile_families(step_plain, nprof)
-        bracket_us = event_bracket_us(dev, args.dtype)
+        bracket_us = event_bracket_us(step_plain, fam, nprof)
         dom = max(fam, key=lambda t: fam[t][0])
         traffic, traffic_note = (None, "skipped")
         if world == 1 and not inner and not args.no_traffic and not args.quick:
@@ -1076,40 +1074,56 @@ def main():
                     "steps": k, "dtype": "f32", "what": "the exact-f32 parity mode (the mode the element-wise oracle "
                                                         "tests run in) on the same batch"}
 
-        def large_leg():
-            """The Conformer-large ENCODER alone (the model of configs[2] / [3]; greedy CTC so that the step is the
-            encoder): B = 64, the per-GPU batch of configs[3].  SURVEY 8(d): 68.56 algorithmic GFLOP per utterance."""
-            torch.manual_seed(0)
-            m = ASRTask.build_model(model_config("large", args.dtype)).to(dev).eval()
-            Bl = 64
-            w = synth_batch(0, Bl).to(dev)
-            ls = [N_SAMPLES] * Bl
-            sk = sink_factory(Bl, T)
+        def encoder_leg(name, Bl, survey_gflop_per_utt, what, want_pmc=False):
+            """An encoder alone (greedy CTC so that the step is the encoder) with the roofline of its MFMA kernel families:
+            Conformer-large (the model of configs[2] / [3]) at B = 64, the per-GPU batch of configs[3] - SURVEY 8(d): 68.56
+            algorithmic GFLOP per utterance; E-Branchformer at B = 32 - flops from the launches' own
+            accounting (no survey figure)."""
+            def fn():
+                torch.manual_seed(0)
+                m = ASRTask.build_model(model_config(name, args.dtype)).to(dev).eval()
+                w = synth_batch(0, Bl).to(dev)
+                ls = [N_SAMPLES] * Bl
+                sk = sink_factory(Bl, T)
 
-            def sp(out=None):
-                return m.greedy_ctc_device(m.encode_device(w, ls), out=out)
+                def sp(out=None):
+                    return m.greedy_ctc_device(m.encode_device(w, ls), out=out)
 
-            def st():
-                tok_v, len_v, _ = sk.slot()
-                sp(out=(tok_v, len_v))
-                sk.commit()
+                def st():
+                    tok_v, len_v, _ = sk.slot()
+                    sp(out=(tok_v, len_v))
+                    sk.commit()
 
-            k = 30
-            t = timed_loop(st, k, 3, barrier, sk.drain)
-            fam = profile_families(sp, 3)
-            brk = event_bracket_us(dev, args.dtype)
-            peak = MFMA_PEAK_TFLOPS[args.dtype]
-            r = roofline_object(fam, 3, brk, peak, t / k, None, "not collected for this leg")
-            survey_gflop = 68.56 * Bl
-            del m
-            torch.cuda.empty_cache()
-            return {"value": round(Bl * AUDIO_SEC * k / t, 1), "unit": "audio-s/s", "ms_per_step": round(t / k * 1e3, 3),
-                    "steps": k, "warmup": 3, "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
-                    "config": {"workload": f"Conformer-large (12x512d, 8 heads, ff 2048) encoder + greedy CTC, {Bl} x 10 s "
-                                           f"utterances per step, V={VOCAB}"},
-                    "whole_step_frac_of_mfma_peak": round(survey_gflop * 1e9 / (t / k) / 1e12 / peak, 4),
-                    "algorithmic_gflop_per_step_survey": round(survey_gflop, 1),
-                    "roofline": r}
+                k = 30
+                t = timed_loop(st, k, 3, barrier, sk.drain)
+                fam = profile_families(sp, 3)
+                brk = event_bracket_us(sp, fam, 3)
+                peak = MFMA_PEAK_TFLOPS[args.dtype]
+                del m
+                torch.cuda.empty_cache()
+                traffic, note = None, "not collected for this leg"
+                if want_pmc and world == 1 and not inner and not args.no_traffic:
+                    # HBM bytes per launch of the leg's dominant family (VERDICT r04 3e: the row-block launches had none)
+                    dom = max(fam, key=lambda tg: fam[tg][0])
+                    a2 = argparse.Namespace(**vars(args))
+                    a2.model, a2.batch = name, Bl
+                    try:
+                        traffic, note = collect_traffic(PROF_MATCH()[dom], a2)
+                    except Exception as e:  # noqa: BLE001 - a measurement helper must not cost the line
+                        traffic, note = None, f"{type(e).__name__}: {e}"
+                r = roofline_object(fam, 3, brk, peak, t / k, traffic, note)
+                res = {"value": round(Bl * AUDIO_SEC * k / t, 1), "unit": "audio-s/s", "ms_per_step": round(t / k * 1e3, 3),
+                       "steps": k, "warmup": 3, "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
+                       "config": {"workload": f"{what} encoder + greedy CTC, {Bl} x 10 s utterances per step, V={VOCAB}"}}
+                if survey_gflop_per_utt:
+                    g = survey_gflop_per_utt * Bl
+                    res["whole_step_frac_of_mfma_peak"] = round(g * 1e9 / (t / k) / 1e12 / peak, 4)
+                    res["algorithmic_gflop_per_step_survey"] = round(g, 1)
+                else:  # (the MFMA launches' own flop accounting over the wall time of the step)
+                    res["whole_step_frac_of_mfma_peak"] = r["whole_step"]["frac_of_mfma_peak_over_wall_time"]
+                res["roofline"] = r
+                return res
+            return fn
 
         def beam_leg(Bb, steps, cpu):
             def fn():
@@ -1148,7 +1162,8 @@ def main():
         guarded("f32_mode", f32_leg)
         del model
         torch.cuda.empty_cache()
-        guarded("encoder_large_b64", large_leg)
+        guarded("encoder_large_b64", encoder_leg("large", 64, 68.56, "Conformer-large (12x512d, 8 heads, ff 2048)", want_pmc=True))
+        guarded("encoder_ebranchformer_b32", encoder_leg("ebf", 32, None, "E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31)"))
         guarded("beam", beam_leg(16, 3, True))
         guarded("beam_cfg3_per_gpu", beam_leg(64, 2, False))
         guarded("stream", stream_leg)
