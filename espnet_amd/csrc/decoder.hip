@@ -558,6 +558,10 @@ int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const 
   // give back - 0.704 -> 0.769 ms per label step, profiles/r03af - and the rows themselves fill the chip)
   const int SA_SPLIT = fsplit > 0 ? (fsplit > 8 ? 8 : fsplit) : (heads * n <= 2048 ? 2 : 1);  // (two: 0.369 -> 0.358 ms per label step; four 0.363, eight 0.392 - every wave has its fixed cost; profiles/r03x)
   group = group < 1 ? 1 : (group > 16 / SA_SPLIT ? 16 / SA_SPLIT : group);  // 16 waves per workgroup
+  // (round 5: at most four rows - four waves, one per SIMD - per workgroup when every row is one wave: configs[3]'s per-GPU
+  // step, 640 rows, ran its half-beam groups of five at 0.715 ms per label step and runs groups of four at 0.651;
+  // groups of 1 / 2 / 3: 0.658 / 0.667 / 0.671; profiles/r05l_label_step_dispatch_sweep.txt)
+  if (SA_SPLIT == 1 && group > 4) group = 4;
   while (group > 1 && (size_t)(group * Lmax + SA_MERGE_FLOATS) * sizeof(int) > 64 * 1024) --group;  // default LDS limit
   // Rows of a beam on one CU share their ancestors' cache rows in its L1, but three quarters of the chip idle with
   // 160 rows x 4 heads in 64 workgroups: fewer rows per workgroup until the grid covers the CUs (the L2 still serves

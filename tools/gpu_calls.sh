@@ -109,6 +109,16 @@ PY
       echo -n "nopipe=$v: "; quick 600
     done 2>&1 | tee "$out/ab_small.txt"
     unset ESPNET_AMD_ATTN2_NOPIPE ;;
+  search640)  # label step at configs[3]'s per-GPU shape (64 x beam 10 = 640 rows): kernel table
+    stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic | cut -c1-200
+    f=$(find "$out/search640_stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" | cut -c1-220 > "$out/search640_kernel_stats_head.txt" ;;
+  sweep640)  # label step at 640 rows under the dispatch switches that were tuned at 160 rows
+    B64=${B64:-64}
+    bl() { timeout 200 python bench.py --workload beam --batch $B64 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic 2>/dev/null < /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s,', d['search']['ms_per_search_step'], 'ms per label step')"; }
+    export B64
+    for e in "" "ESPNET_AMD_SA_GROUP=1" "ESPNET_AMD_SA_GROUP=2" "ESPNET_AMD_SA_GROUP=3" "ESPNET_AMD_SA_GROUP=4" "ESPNET_AMD_MID_TILE=24" "ESPNET_AMD_MID_TILE=21" "ESPNET_AMD_MID_TILE=12" "ESPNET_AMD_SA_GROUP=4 ESPNET_AMD_MID_TILE=24" "ESPNET_AMD_SA_GROUP=2 ESPNET_AMD_MID_TILE=24" ""; do
+      echo -n "[B=$B64 $e] "; env $e bash -c "$(declare -f bl); bl"
+    done 2>&1 | tee "$out/sweep640.txt" ;;
   parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
     echo "== new parity tests"
