@@ -547,6 +547,310 @@ __global__ __launch_bounds__(256) void lm_input_norm_kernel(float* __restrict__ 
   }
 }
 
+// ---- round 5: self-attention over the UNION of a beam's ancestors, on the matrix cores ---------------------------------
+// The W hypotheses of an utterance are paths in one token tree: at position j they sit on a handful of distinct cache rows
+// (their common prefix on ONE), yet dec_self_attn_kernel above gathers every row's own copy of the prefix - W x pos K and V
+// rows per utterance, layer and step, 164 MB per layer at configs[3]'s per-GPU shape (640 rows, 8 heads, position ~125) -
+// and at 640 rows it is the label step's largest kernel (6 x 32 us of 0.72 ms, profiles/r05j_search640_kernel_stats.csv).
+// Here one workgroup owns (utterance, head): phase 1 finds, per position, the distinct cache rows under the beam (`first
+// [u][j]`: the lowest beam row that shares row u's ancestor at j; a key is kept where first[u][j] == u) and compacts them
+// into a key list by a block-wide prefix sum; the beam's own new tokens follow as W keys each visible to its own row.
+// Phase 2 walks the list in 64-key tiles (a wave per tile): the keys' K rows are gathered ONCE (buffer loads; lanes past
+// the list read nothing), S^T[key][row] = K . Q^T runs on MFMA for all W rows together, a score counts where
+// first[row][j(key)] == u(key), the online softmax is per lane as in relpos_attn2_kernel (scores transposed: the
+// probabilities are already the B operand of O^T = V^T . P^T), and V^T comes out of the tile by 2-byte reads.  The waves'
+// partial (m, l, O) meet once through LDS.  Reference: MultiHeadedAttention.forward over the cached prefix
+// (transformer/attention.py:121-151 via decoder_layer.py:96-117 with cache), identical for every hypothesis that shares
+// a prefix - which is what is exploited.  bf16, d_k = 64, W <= 16, Lmax <= 512 and a key list that fits 64 KiB of LDS (configs[2] / [3]: W = 10, Lmax = 258); other
+// shapes keep the per-row kernel.
+constexpr int TREE_LMAX = 512;  // positions (two per thread of phase 1 at most)
+// dynamic LDS: [tile 4 x 8 KiB][kj u16 NK][ks u16 NK][ku u8 NK][first u8 16 x LP][wsum 4 + nk], NK = W Lmax rounded up to 64,
+// LP = Lmax rounded up to 64; the launcher refuses shapes beyond 64 KiB (configs[2] / [3]: W = 10, Lmax = 258: 50 KiB)
+__host__ __device__ inline int tree_nk(int W, int Lmax) { return (W * Lmax + 63) & ~63; }
+__host__ __device__ inline int tree_lp(int Lmax) { return (Lmax + 63) & ~63; }
+__host__ __device__ inline size_t tree_lds_bytes(int W, int Lmax) {
+  return 32768 + (size_t)tree_nk(W, Lmax) * 5 + 16 * (size_t)tree_lp(Lmax) + 32;
+}
+
+template <int WT>  // beam width bound (the key-list pass is a triangle of WT (WT - 1) / 2 comparisons per position)
+__global__ __launch_bounds__(256) void dec_self_attn_tree_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc,
+                                                                  bf16* __restrict__ vc, const int* __restrict__ anc,
+                                                                  const int* __restrict__ anc_odd, int n, int d, int Lmax,
+                                                                  int pos, const int* __restrict__ pos_dev, int W,
+                                                                  bf16* __restrict__ ctx) {
+  using MM = Mma<bf16>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tree_lds[];
+  if (pos_dev) {
+    pos = *pos_dev;
+    if (pos >= Lmax) return;
+    if (pos & 1) anc = anc_odd;
+  }
+  const int NK = tree_nk(W, Lmax), LP = tree_lp(Lmax);
+  unsigned short* const s_kj = (unsigned short*)(tree_lds + 32768);  // key -> position
+  unsigned short* const s_ks = s_kj + NK;                             // key -> cache row (position pos: the beam row's own index)
+  unsigned char* const s_ku = (unsigned char*)(s_ks + NK);            // key -> beam row that owns it (first occurrence)
+  unsigned char* const s_first = s_ku + NK;                           // [16][LP]
+  int* const s_ws = (int*)(s_first + 16 * LP);                        // wsum[4], nk
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.x, r0 = blockIdx.y * W;
+
+  // ---- the new token's K / V go into the cache (read back by later steps only)
+  if (tid < W * 16) {
+    const int u = tid >> 4, which = (tid >> 3) & 1, ch = tid & 7;
+    const uint4 v = *(const uint4*)(qkv + (size_t)(r0 + u) * 3 * d + (1 + which) * d + h * 64 + ch * 8);
+    *(uint4*)((which ? vc : kc) + ((size_t)pos * n + r0 + u) * d + h * 64 + ch * 8) = v;
+  }
+  // ---- phase 1: positions tid and tid + 256 of the prefix
+  {
+    int a[2][WT];
+    unsigned own[2] = {0u, 0u};  // bit u: row u owns a key at this position
+    int cnt = 0;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int j = tid + 256 * pp;
+      if (j < pos) {
+#pragma unroll
+        for (int u = 0; u < WT; ++u) a[pp][u] = u < W ? anc[(size_t)(r0 + u) * Lmax + j] : -1 - u;
+#pragma unroll
+        for (int u = 0; u < WT; ++u) {
+          int f = u;
+#pragma unroll
+          for (int v = WT - 1; v >= 0; --v)
+            if (v < u && a[pp][v] == a[pp][u]) f = v;
+          s_first[u * LP + j] = (unsigned char)f;
+          if (f == u && u < W) {
+            own[pp] |= 1u << u;
+            ++cnt;
+          }
+        }
+      }
+      if (j == pos) {  // the beam's own new tokens: W keys, each visible to its own row
+#pragma unroll
+        for (int u = 0; u < WT; ++u) s_first[u * LP + j] = (unsigned char)u;
+      }
+    }
+    // block-wide exclusive prefix sum of cnt
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_ws[wave] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (w < wave) base += s_ws[w];
+    int k = base + inc - cnt;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int u = 0; u < WT; ++u)
+        if (own[pp] & (1u << u)) {
+          s_kj[k] = (unsigned short)(tid + 256 * pp);
+          s_ks[k] = (unsigned short)a[pp][u];
+          s_ku[k] = (unsigned char)u;
+          ++k;
+        }
+    if (tid == 0) {
+      const int nkc0 = s_ws[0] + s_ws[1] + s_ws[2] + s_ws[3];
+      s_ws[4] = nkc0 + W;
+      for (int u = 0; u < W; ++u) {
+        s_kj[nkc0 + u] = (unsigned short)pos;
+        s_ks[nkc0 + u] = (unsigned short)u;  // (index into the beam's rows of qkv)
+        s_ku[nkc0 + u] = (unsigned char)u;
+      }
+    }
+    __syncthreads();
+  }
+  const int nk = s_ws[4], nkc = nk - W;
+
+  // ---- query fragments (B operand: column = beam row lr, k-slice lg), 1 / sqrt(64) folded in (exact)
+  bf16x8 qf[2];
+  {
+    const int u = lr < W ? lr : W - 1;
+    const bf16* qrow = qkv + (size_t)(r0 + u) * 3 * d + h * 64 + lg * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 raw = *(const bf16x8*)(qrow + ks * 32);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16)((float)raw[e] * 0.125f);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, (int)((size_t)Lmax * n * d * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, (int)((size_t)Lmax * n * d * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (size_t)r0 * 3 * d), 0, W * 3 * d * 2, 0x00020000);
+  unsigned char* const tile = tree_lds + wave * 8192;
+  f32x4 acc_o[4], acc_l = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < 4; ++f) acc_o[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float row_m = -INFINITY;
+  const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+  constexpr float LOG2E = 1.4426950408889634f;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const int ntile = (nk + 63) >> 6;
+  for (int t = wave; t < ntile; t += 4) {
+    // ---- gather: key 64 t + 8 i + (lane >> 3), 16-byte chunk lane & 7 of its K and V rows
+    u32x4 kr[8], vr[8];
+    const int ch = lane & 7;
+    const bool has_new = 64 * t + 64 > nkc;  // (uniform) the tile holds keys of the current position: their rows come from qkv
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 64 * t + 8 * i + (lane >> 3);
+      const int kk = k < nk ? k : nk - 1;
+      const int j = s_kj[kk], sl = s_ks[kk];
+      const bool in_cache = k < nkc;
+      const unsigned off = in_cache ? (unsigned)((((size_t)j * n + sl) * d + h * 64 + ch * 8) * 2) : 0xffffffffu;
+      kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0);
+      vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0);
+      if (has_new) {
+        const bool is_new = k >= nkc && k < nk;
+        const unsigned qo = is_new ? (unsigned)(((size_t)sl * 3 * d + d + h * 64 + ch * 8) * 2) : 0xffffffffu;
+        const unsigned qo2 = is_new ? qo + (unsigned)(d * 2) : 0xffffffffu;
+        kr[i] |= __builtin_amdgcn_raw_buffer_load_b128(rq, qo, 0, 0);
+        vr[i] |= __builtin_amdgcn_raw_buffer_load_b128(rq, qo2, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int key = 8 * i + (lane >> 3);
+      *(u32x4*)(tile + key * 128 + ((ch ^ (key & 7)) << 4)) = kr[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- S^T (64 keys x 16 rows)
+    f32x4 sc[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) sc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const int row = 16 * nf + lr;
+        const bf16x8 kf = *(const bf16x8*)(tile + row * 128 + (((ks * 4 + lg) ^ (row & 7)) << 4));
+        sc[nf] = MM::mma(kf, qf[ks], sc[nf]);
+      }
+    // ---- which of this lane's 16 keys (16 nf + 4 lg + r) its row lr sees
+    float tm = -INFINITY;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int k0 = 64 * t + 16 * nf + 4 * lg;
+      const uint2 jj = *(const uint2*)(s_kj + k0);
+      const unsigned uu = *(const unsigned*)(s_ku + k0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int j = (int)(((r & 2) ? jj.y : jj.x) >> ((r & 1) * 16)) & 0xffff;
+        j = j < LP ? j : LP - 1;  // (slots past the list hold whatever: keep the look-up inside the table)
+        const int u = (int)(uu >> (8 * r)) & 0xff;
+        const bool ok = (k0 + r < nk) & (lr < W) & ((int)s_first[lr * LP + j] == u);
+        sc[nf][r] = ok ? sc[nf][r] : -INFINITY;
+        tm = fmaxf(tm, sc[nf][r]);
+      }
+    }
+    tm = wave_xor16_max(tm);
+    tm = wave_xor32_max(tm);
+    const float mn = fmaxf(row_m, tm);
+    // (a row beyond the beam, or a tile without a key of this row: everything is -inf; keep the state untouched)
+    const bool any = mn > -INFINITY;
+    const float alpha = any ? __expf(row_m - mn) : 1.f;
+    const float mnl = any ? mn * LOG2E : 0.f;
+    row_m = mn;
+    unsigned pbu[2][4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[nf][2 * hh], LOG2E, -mnl));
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[nf][2 * hh + 1], LOG2E, -mnl));
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        pbu[nf >> 1][(nf & 1) * 2 + hh] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
+      }
+    bf16x8 pb[2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) pb[jp] = __builtin_bit_cast(bf16x8, (u32x4){pbu[jp][0], pbu[jp][1], pbu[jp][2], pbu[jp][3]});
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      acc_o[f][0] *= alpha; acc_o[f][1] *= alpha; acc_o[f][2] *= alpha; acc_o[f][3] *= alpha;
+    }
+    acc_l[0] *= alpha;
+    // ---- V rows over the K rows (this wave's reads of them are done: LDS operations of a wave execute in order)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int key = 8 * i + (lane >> 3);
+      *(u32x4*)(tile + key * 128 + ((ch ^ (key & 7)) << 4)) = vr[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- O^T += V^T . P^T: the A operand of (dk fragment f, 32-key step jp) is V[key][16 f + lr] for the lane group's key
+    // slots 32 jp + 4 lg + e and 32 jp + 16 + 4 lg + e, e < 4 (the order the probabilities sit in pb)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      acc_l = MM::mma(ones, pb[jp], acc_l);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int dk = 16 * f + lr;
+        unsigned w4[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const int ka = 32 * jp + 16 * (e2 >> 1) + 4 * lg + 2 * (e2 & 1);
+          const unsigned lo = *(const unsigned short*)(tile + ka * 128 + ((((dk >> 3) ^ (ka & 7))) << 4) + (dk & 7) * 2);
+          const unsigned hi = *(const unsigned short*)(tile + (ka + 1) * 128 + ((((dk >> 3) ^ ((ka + 1) & 7))) << 4) + (dk & 7) * 2);
+          w4[e2] = lo | (hi << 16);
+        }
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, (u32x4){w4[0], w4[1], w4[2], w4[3]});
+        acc_o[f] = MM::mma(vf, pb[jp], acc_o[f]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- the waves' partial states meet in wave 0 (lane (lr, lg): row lr, channels 16 f + 4 lg + r)
+  __syncthreads();
+  float* const mg = (float*)tree_lds;  // [3 waves][18][64 lanes]: the tiles are free by now
+  if (wave > 0) {
+    float* o = mg + (wave - 1) * 18 * 64 + lane;
+    o[0] = row_m;
+    o[64] = acc_l[0];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(2 + f * 4 + r) * 64] = acc_o[f][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float M = row_m;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) M = fmaxf(M, mg[w * 18 * 64 + lane]);
+    const float a0 = row_m > -INFINITY ? __expf(row_m - M) : 0.f;
+    float l = acc_l[0] * a0;
+    float o[16];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[f * 4 + r] = acc_o[f][r] * a0;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float* src = mg + w * 18 * 64 + lane;
+      const float mw = src[0];
+      const float aw = mw > -INFINITY ? __expf(mw - M) : 0.f;
+      l += src[64] * aw;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[q] += src[(2 + q) * 64] * aw;
+    }
+    if (lr < W) {
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      bf16* dst = ctx + (size_t)(r0 + lr) * d + h * 64 + 4 * lg;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const bf16x4 pk = {(bf16)(o[f * 4] * inv), (bf16)(o[f * 4 + 1] * inv), (bf16)(o[f * 4 + 2] * inv), (bf16)(o[f * 4 + 3] * inv)};
+        *(bf16x4*)(dst + 16 * f) = pk;
+      }
+    }
+  }
+}
+
 template <typename T>
 int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n,
                      int d, int heads, int Lmax, int pos, const int* pos_dev, int group,
@@ -635,6 +939,36 @@ int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, c
 
 }  // namespace
 
+// the beam-tree form of em_dec_self_attention for the offline search's decoder step (bf16, d_k = 64, rows = B x W with
+// W <= 16 consecutive rows per utterance, Lmax <= 256, no token mask); EM_ERR_UNSUPPORTED otherwise (the caller keeps the
+// per-row kernel).  ESPNET_AMD_NO_SA_TREE=1: developer A/B switch.
+int em_dec_self_attention_tree_bf16(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n, int d,
+                                    int heads, int Lmax, int pos, const int* pos_dev, int W, void* ctx, void* stream) {
+  static const bool off = getenv("ESPNET_AMD_NO_SA_TREE") != nullptr;
+  if (off || heads <= 0 || d != 64 * heads || W < 1 || W > 16 || n % W != 0 || n > 65535 || Lmax > TREE_LMAX || pos < 0 ||
+      pos >= Lmax)
+    return EM_ERR_UNSUPPORTED;
+  // one workgroup per (utterance, head) walks the whole prefix: worth it once the per-row kernel's n x heads waves are several
+  // rounds of the chip - configs[3] per GPU (640 rows): 0.620 -> 0.593 ms per label step; configs[2] (160 rows): 0.352 ->
+  // 0.367, the per-row kernel stays (profiles/r05n_tree_self_attention_ab.txt).  ESPNET_AMD_SA_TREE_MIN_ROWS: developer switch.
+  const char* const mr = getenv("ESPNET_AMD_SA_TREE_MIN_ROWS");  // (read per call: the kernel tests lower it in-process)
+  const int min_rows = mr ? atoi(mr) : 320;
+  if (n < min_rows) return EM_ERR_UNSUPPORTED;
+  if ((size_t)Lmax * n * d * 2 >= ((size_t)1 << 31)) return EM_ERR_UNSUPPORTED;  // (buffer offsets are 32-bit)
+  const size_t lds = tree_lds_bytes(W, Lmax);
+  if (lds > 64 * 1024) return EM_ERR_UNSUPPORTED;  // (the default dynamic-LDS limit: no attribute call, legal inside a stream capture)
+  dim3 grid(heads, n / W);
+#define EM_TREE_LAUNCH(WT)                                                                                                  \
+  hipLaunchKernelGGL(dec_self_attn_tree_kernel<WT>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv, (bf16*)kc, \
+                     (bf16*)vc, anc, anc_odd, n, d, Lmax, pos, pos_dev, W, (bf16*)ctx)
+  if (W <= 5) EM_TREE_LAUNCH(5);
+  else if (W <= 10) EM_TREE_LAUNCH(10);
+  else EM_TREE_LAUNCH(16);
+#undef EM_TREE_LAUNCH
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+
 extern "C" int em_dec_embed_f32(const float* embed, const float* pe, const int32_t* tok_row,
                                 int32_t n, int32_t V, int32_t d, int32_t pos,
                                 const int32_t* pos_dev, int32_t pe_len, float* x, void* stream) {
@@ -656,6 +990,19 @@ extern "C" int em_dec_self_attention(int dtype, const void* qkv, void* kc, void*
   if (dtype == EM_BF16)
     return self_attn_launch<bf16>(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, group, tok_tab, ctx, (hipStream_t)stream);
   return EM_ERR_BAD_ARG;
+}
+
+extern "C" int em_dec_self_attention_beam(int dtype, const void* qkv, void* kc, void* vc, const int32_t* anc,
+                                          const int32_t* anc_odd, int32_t n, int32_t d, int32_t heads, int32_t Lmax,
+                                          int32_t pos, const int32_t* pos_dev, int32_t W, void* ctx, void* stream) {
+  if (n <= 0 || heads <= 0 || W <= 0 || n % W != 0 || pos < 0 || pos >= Lmax || Lmax > SA_MAXL) return EM_ERR_BAD_ARG;
+  int rc = EM_ERR_UNSUPPORTED;
+  if (dtype == EM_BF16 && W > 1)
+    rc = em_dec_self_attention_tree_bf16(qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, W, ctx, stream);
+  if (rc == EM_ERR_UNSUPPORTED)
+    rc = em_dec_self_attention(dtype, qkv, kc, vc, anc, anc_odd, n, d, heads, Lmax, pos, pos_dev, (W + 1) / 2, nullptr, ctx,
+                               stream);
+  return rc;
 }
 
 extern "C" int em_dec_src_attention(int dtype, const void* qs, const void* kmem, int32_t ldk,

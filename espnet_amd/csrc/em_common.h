@@ -183,3 +183,8 @@ static inline int em_raise_lds_cap(const void* fn, size_t bytes, EmLdsCap* cap) 
 // per-launch timing of the MFMA kernel families (csrc/gemm.hip; bench.py's roofline leg)
 bool em_prof_begin(void* stream);
 void em_prof_end(void* stream, double flops, int tag);
+
+// csrc/decoder.hip: self-attention over the union of a beam's ancestors (bf16, d_k = 64, W <= 16 consecutive rows per
+// utterance, Lmax <= 256); EM_ERR_UNSUPPORTED for other shapes (the caller keeps em_dec_self_attention)
+int em_dec_self_attention_tree_bf16(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n, int d,
+                                    int heads, int Lmax, int pos, const int* pos_dev, int W, void* ctx, void* stream);

@@ -1350,12 +1350,11 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
     // every pre-norm LayerNorm rides in the prologue of the projection that consumes it (ln_gemm.hip)
     EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm1_g, q.norm1_b, q.self_wqkv, q.self_bqkv, a.qkv, a.xn, n,
                    3 * d, d, stream));
+    // round 5: over the union of the beam's ancestors where the shape allows (bf16, d_k = 64, beams of <= 16, Lmax <= 256)
     if (a.pos_dev)
-      EM_TRY(em_dec_self_attention(dtype, a.qkv, kc, vc, a.anc_a, a.anc_b, n, d, h, a.Lmax, 0, a.pos_dev,
-                                   (a.W + 1) / 2, nullptr, a.ctx, stream));
+      EM_TRY(em_dec_self_attention_beam(dtype, a.qkv, kc, vc, a.anc_a, a.anc_b, n, d, h, a.Lmax, 0, a.pos_dev, a.W, a.ctx, stream));
     else
-      EM_TRY(em_dec_self_attention(dtype, a.qkv, kc, vc, anc, anc, n, d, h, a.Lmax, i, nullptr, (a.W + 1) / 2,
-                                   nullptr, a.ctx, stream));
+      EM_TRY(em_dec_self_attention_beam(dtype, a.qkv, kc, vc, anc, anc, n, d, h, a.Lmax, i, nullptr, a.W, a.ctx, stream));
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.self_wout, a.x, q.self_bout, n, d, d, d, d, 1.f, stream));
     // round 4: norm2 + the source attention's query projection ride in the attention kernel's prologue (bf16, d_k = 64,
     // d = 256 | 512: one launch less per layer; ESPNET_AMD_NO_SRC_LNQ=1: developer A/B switch)

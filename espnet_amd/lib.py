@@ -259,6 +259,8 @@ _SIGNATURES = {
     "em_dec_embed_f32": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "em_dec_self_attention": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                         _i32, _vp, _i32, _vp, _vp, _vp]),
+    "em_dec_self_attention_beam": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                             _i32, _vp, _i32, _vp, _vp]),
     "em_lm_embed": (C.c_int, [C.c_int, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "em_lm_input_norm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "em_dec_src_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,

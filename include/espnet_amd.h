@@ -577,6 +577,15 @@ int em_dec_self_attention(int dtype, const void* qkv, void* kc, void* vc, const 
                           const int32_t* anc_odd, int32_t n, int32_t d, int32_t heads, int32_t Lmax,
                           int32_t pos, const int32_t* pos_dev, int32_t group, const int32_t* tok_tab,
                           void* ctx, void* stream);
+/*   The same attention for rows that are B x W beams (W consecutive rows per utterance, no token mask): where the shape
+ *   allows (EM_BF16, d / heads = 64, W <= 16, Lmax <= 512 with a key list within 64 KiB of LDS, n <= 65 535) the keys are the UNION of the beam's ancestors -
+ *   every distinct cache row under the W hypotheses is gathered once and scored for all of them on the matrix cores, a
+ *   hypothesis seeing the keys on its own path (csrc/decoder.hip dec_self_attn_tree_kernel); other shapes run
+ *   em_dec_self_attention with group = (W + 1) / 2.  Same arguments otherwise; the result differs from the per-row
+ *   kernel by bf16 round-off of the probabilities (MultiHeadedAttention over the cached prefix, attention.py:121-151). */
+int em_dec_self_attention_beam(int dtype, const void* qkv, void* kc, void* vc, const int32_t* anc,
+                               const int32_t* anc_odd, int32_t n, int32_t d, int32_t heads, int32_t Lmax,
+                               int32_t pos, const int32_t* pos_dev, int32_t W, void* ctx, void* stream);
 /*   TransformerLM input (espnet2/lm/transformer_lm.py:35, transformer/encoder.py:132-139):
  *   e[r] = embed[tok_row[r]] in the act dtype;  then (after the input Linear) in place on x f32:
  *   torch LayerNorm(eps 1e-5) -> ReLU -> optional x*sqrt(d) + pe[pos].  pos_dev as above.       */

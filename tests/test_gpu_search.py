@@ -450,6 +450,76 @@ def test_dec_self_attention(lib, prec, heads, d, n):
     assert torch.equal(kc[:pos], kc0[:pos])
 
 
+@pytest.mark.parametrize("tree", ["beam_tree", "random", "all_shared"])
+@pytest.mark.parametrize("heads,d,B,W,pos,Lmax", [(8, 512, 64, 10, 133, 251), (8, 512, 16, 10, 0, 251), (4, 256, 3, 16, 255, 256),
+                                                  (8, 512, 5, 7, 64, 100), (8, 512, 2, 10, 63, 251), (4, 256, 4, 3, 1, 40),
+                                                  (8, 512, 16, 10, 257, 258), (4, 256, 2, 10, 390, 400)])
+def test_dec_self_attention_beam(lib, tree, heads, d, B, W, pos, Lmax):
+    """Round 5: `em_dec_self_attention_beam` - the decoder self-attention over the UNION of a beam's ancestors on MFMA
+    (csrc/decoder.hip dec_self_attn_tree_kernel) - against plain torch fp32 attention of every row over its own path
+    (attention.py:121-151 over the cached prefix).  Ancestor tables: a real token tree (beams that coalesce a few steps
+    back: few distinct cache rows per position), independent random slots (every row its own ancestors: the key list at its
+    longest), one shared path.  Shapes: configs[3]'s per-GPU rows at a mid position, position 0, the largest table
+    (W = 16, Lmax = 256, last position: 4 096 keys), odd beam widths, a prefix of exactly one tile, the search's own
+    Lmax = 258 at its last position and Lmax = 400 (two prefix positions per thread in the key-list pass)."""
+    import os
+
+    from espnet_amd import lib as L
+
+    os.environ["ESPNET_AMD_SA_TREE_MIN_ROWS"] = "0"  # (the library takes the tree form from 320 rows: here at every size)
+    torch.manual_seed(3)
+    n, dk = B * W, d // heads
+    dt = torch.bfloat16
+    qkv = torch.randn(n, 3 * d).to(dt).cuda()
+    kc = torch.randn(Lmax, n, d).to(dt).cuda()
+    vc = torch.randn(Lmax, n, d).to(dt).cuda()
+    base = (torch.arange(n) // W * W)[:, None]
+    if tree == "random":
+        anc = base + torch.randint(0, W, (n, Lmax))
+    elif tree == "all_shared":
+        anc = base + torch.randint(0, W, (B, 1, Lmax)).expand(B, W, Lmax).reshape(n, Lmax)
+    else:  # walk a beam forward: at every step each row continues one of the beam's rows (its parent), as the search does
+        anc = torch.zeros(n, Lmax, dtype=torch.long)
+        g = torch.Generator().manual_seed(5)
+        for j in range(Lmax):
+            parent = torch.randint(0, W, (B, W), generator=g)
+            parent = torch.minimum(parent, torch.randint(0, W, (B, W), generator=g))  # (bias to low rows: beams coalesce)
+            prev = anc.view(B, W, Lmax)
+            new = torch.gather(prev, 1, parent[:, :, None].expand(B, W, Lmax)).clone()
+            new[:, :, j] = torch.arange(W)[None, :] + (torch.arange(B) * W)[:, None]
+            anc = new.view(n, Lmax)
+    anc = anc.to(torch.int32).cuda()
+    ctx = torch.zeros(n, d, dtype=dt, device="cuda")
+    kc0, vc0 = kc.clone(), vc.clone()
+    try:
+        L.check(lib.em_dec_self_attention_beam(L.EM_BF16, L.ptr(qkv), L.ptr(kc), L.ptr(vc), L.ptr(anc), L.ptr(anc), n, d, heads,
+                                               Lmax, pos, None, W, L.ptr(ctx), None), "self_attn_beam")
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("ESPNET_AMD_SA_TREE_MIN_ROWS", None)
+    q, k_new, v_new = qkv.float().split(d, dim=1)
+    idx = anc[:, :pos].long().t()
+    jj = torch.arange(pos, device="cuda")[:, None].expand(pos, n)
+    ks = torch.cat([kc0[jj, idx].float(), k_new[None]], 0).cpu()
+    vs = torch.cat([vc0[jj, idx].float(), v_new[None]], 0).cpu()
+    qh = q.cpu().view(n, heads, 1, dk)
+    kh = ks.view(pos + 1, n, heads, dk).permute(1, 2, 3, 0)
+    vh = vs.view(pos + 1, n, heads, dk).permute(1, 2, 0, 3)
+    sc = torch.matmul(qh, kh) / math.sqrt(dk)
+    ref = torch.matmul(torch.softmax(sc, -1), vh).reshape(n, d)
+    err = (ctx.float().cpu() - ref).abs().max().item()
+    assert err < 3e-2, err
+    # the new K / V were appended at `pos`, nothing else touched
+    assert torch.equal(kc[pos], k_new.to(dt)) and torch.equal(vc[pos], v_new.to(dt))
+    assert torch.equal(kc[:pos], kc0[:pos]) and torch.equal(kc[pos + 1 :], kc0[pos + 1 :])
+    # ... and the per-row kernel agrees to bf16 round-off of the probabilities
+    ctx2 = torch.zeros(n, d, dtype=dt, device="cuda")
+    L.check(lib.em_dec_self_attention(L.EM_BF16, L.ptr(qkv), L.ptr(kc), L.ptr(vc), L.ptr(anc), L.ptr(anc), n, d, heads, Lmax,
+                                      pos, None, (W + 1) // 2, None, L.ptr(ctx2), None), "self_attn")
+    torch.cuda.synchronize()
+    assert (ctx.float() - ctx2.float()).abs().max().item() < 3e-2
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 @pytest.mark.parametrize("heads,d,W", [(8, 512, 10), (2, 64, 5), (4, 256, 20)])
 def test_dec_src_attention(lib, prec, heads, d, W):

@@ -119,6 +119,16 @@ PY
     for e in "" "ESPNET_AMD_SA_GROUP=1" "ESPNET_AMD_SA_GROUP=2" "ESPNET_AMD_SA_GROUP=3" "ESPNET_AMD_SA_GROUP=4" "ESPNET_AMD_MID_TILE=24" "ESPNET_AMD_MID_TILE=21" "ESPNET_AMD_MID_TILE=12" "ESPNET_AMD_SA_GROUP=4 ESPNET_AMD_MID_TILE=24" "ESPNET_AMD_SA_GROUP=2 ESPNET_AMD_MID_TILE=24" ""; do
       echo -n "[B=$B64 $e] "; env $e bash -c "$(declare -f bl); bl"
     done 2>&1 | tee "$out/sweep640.txt" ;;
+  tree-sa)  # round 5: decoder self-attention over the union of a beam's ancestors (A/B: ESPNET_AMD_NO_SA_TREE=1)
+    echo "== kernel test"; (timeout 300 python -m pytest -q -x tests/test_gpu_search.py -k "self_attention" 2>&1 | tail -5) | tee "$out/pytest_kernel.txt"
+    echo "== search tests"; (timeout 600 python -m pytest -q -x tests/test_gpu_search.py tests/test_gpu_online_search.py -k "bf16 or peaked or batched or structure or very_short" 2>&1 | tail -4) | tee "$out/pytest_search.txt"
+    bl() { timeout 200 python bench.py --workload beam --batch $1 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic 2>/dev/null < /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s,', d['search']['ms_per_search_step'], 'ms per label step')"; }
+    for b in 64 16; do for v in 0 1 0 1; do
+      if [ $v = 1 ]; then export ESPNET_AMD_NO_SA_TREE=1; else unset ESPNET_AMD_NO_SA_TREE; fi
+      echo -n "[B=$b no_tree=$v] "; bl $b
+    done; done 2>&1 | tee "$out/ab_tree.txt"
+    unset ESPNET_AMD_NO_SA_TREE
+    stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic | cut -c1-200 | head -8 ;;
   parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
     echo "== new parity tests"
