@@ -236,6 +236,8 @@ PY
       stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3
       echo "== E-Branchformer"; timeout 300 python bench.py --model ebf --quick --no-traffic --no-cpu-baseline --steps 50 --warmup 5 2>/dev/null < /dev/null | tee "$out/bench_ebf.json" | cut -c1-200
       echo "== search kernel stats"; stats "$out/search_stats" python "$R/bench.py" --workload beam --steps 1 --warmup 1 --no-cpu-baseline --no-traffic
+      echo "== search kernel stats, 640 rows (configs[3] per GPU)"; stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic
+      echo "== configs[3] per GPU with HBM traffic of the label step"; timeout 600 python bench.py --workload beam --batch 64 --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null < /dev/null | tee "$out/bench_beam_b64.json" | cut -c1-300
     fi ;;
   sub2)
     echo "== stamps"
