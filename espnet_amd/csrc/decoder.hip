@@ -562,7 +562,9 @@ __global__ __launch_bounds__(256) void lm_input_norm_kernel(float* __restrict__ 
 // partial (m, l, O) meet once through LDS.  Reference: MultiHeadedAttention.forward over the cached prefix
 // (transformer/attention.py:121-151 via decoder_layer.py:96-117 with cache), identical for every hypothesis that shares
 // a prefix - which is what is exploited.  bf16, d_k = 64, W <= 16, Lmax <= 512 and a key list that fits 64 KiB of LDS (configs[2] / [3]: W = 10, Lmax = 258); other
-// shapes keep the per-row kernel.
+// shapes keep the per-row kernel.  (Four waves and <= 64 KiB of LDS on purpose: two to three workgroups share a CU and the
+// launch's B x heads workgroups - 512 at configs[3]'s per-GPU shape - are all resident at once.  With eight waves, a tile each,
+// and 82 KiB the workgroups run in two rounds: 23.4 against 15.5 us per launch, profiles/r05n_tree_self_attention_ab.txt.)
 constexpr int TREE_LMAX = 512;  // positions (two per thread of phase 1 at most)
 // dynamic LDS: [tile 4 x 8 KiB][kj u16 NK][ks u16 NK][ku u8 NK][first u8 16 x LP][wsum 4 + nk], NK = W Lmax rounded up to 64,
 // LP = Lmax rounded up to 64; the launcher refuses shapes beyond 64 KiB (configs[2] / [3]: W = 10, Lmax = 258: 50 KiB)
