@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void frontend_logmel_kernel2(
     // ---- load + window: z[n] = x[2n] + i x[2n+1], n = lane + 64 m
     float2 u[4];
     const int start = t * hop - 256;
-    if (start >= 0 && start + 512 <= Nb && !(start & 1)) {  // (wave-uniform) no reflection, 8-byte aligned
+    if (start >= 0 && start + 512 <= Nb && !(((size_t)b * N + start) & 1)) {  // (wave-uniform) no reflection, 8-byte aligned
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const float2 v = *(const float2*)(x + start + 2 * (lane + 64 * m));
