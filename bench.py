@@ -798,7 +798,8 @@ def rocprof_family_ms(args, model, batch):
         ns = sum(float(x["TotalDurationNs"]) for x in rows if sub in x["Name"])
         if ns > 0:
             out[sub] = round(ns / steps * 1e-6, 4)
-    return out, f"rocprofv3 --kernel-trace --stats over {steps} steps of the same loop (nested run)"
+    return out, (f"rocprofv3 --kernel-trace --stats over {steps} steps of the same loop (nested run; under the tracer the loop "
+                 f"itself runs 1-3 % slower than the timed one, so this sum can still sit that much above ms_per_step)")
 
 
 def roofline_object(fam, nprof, bracket_us, peak, wall_s_per_step, traffic, traffic_note, rocprof=None, rocprof_note=None):
