@@ -16,12 +16,15 @@ N(0, 0.1^2) waveforms.
 
 One JSON line on rank 0 carries the throughput and, at N = 1: `roofline` (the dominant MFMA kernel family
 measured live with HIP events around every launch, HBM traffic from two `rocprofv3 --pmc` passes of this
-same script), `cpu_baseline` (the oracle port on this box's host cores + the reference figure it stands in
+same script and - `rocprofv3_*` fields - the un-bracketed kernel table of a nested `rocprofv3 --kernel-trace
+--stats` run of the same loop), `cpu_baseline` (the oracle port on this box's host cores + the reference figure it stands in
 for), `pcie_inclusive` (waveforms arriving in pinned host memory, H2D overlapped with compute),
 `f32_mode`, `bf16_vs_f32` (id mismatch rate of the timed mode on the bench batch), `frontend` (GB/s vs
-HBM peak), `encoder_large_b64` (the Conformer-large encoder at configs[3]'s per-GPU batch with its MFMA families),
-`beam` (configs[2] with the roofline of the search and `bf16_vs_oracle`), `beam_cfg3_per_gpu` (configs[3]'s per-GPU
-batch on one GPU) and `stream` (configs[4] + the 40 ms-per-call stress case).  `--quick` keeps only the
+HBM peak), `encoder_large_b64` (the Conformer-large encoder at configs[3]'s per-GPU batch with its MFMA families and the HBM
+traffic of its dominant one), `encoder_ebranchformer_b32` (the E-Branchformer encoder with its roofline),
+`beam` (configs[2] with the roofline of the search and `bf16_vs_oracle`: per-token error, best-score loss beside the
+oracle search's own path noise, token edit distance), `beam_cfg3_per_gpu` (configs[3]'s per-GPU batch on one GPU,
+with `bf16_vs_oracle`) and `stream` (configs[4] + the 40 ms-per-call stress case).  `--quick` keeps only the
 main line, `roofline` and `cpu_baseline`.
 """
 import argparse

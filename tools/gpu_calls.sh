@@ -11,6 +11,11 @@
 #   greedy-pmc   SQ counters (wave cycles, waits, MFMA busy, LDS bank conflicts) of the greedy step's main kernels
 #   ffn-rows     round 4: row-block launches of the 512-wide model - kernel + large e2e tests, in-call A/B (ESPNET_AMD_NO_FFN_ROWS), stamps, table
 #   ffn-dbg      ... where ffn_rows_kernel's time goes: developer builds (no weight requests / no LDS operand reads / both) and cycle stamps
+#   r05a|r05b    round 5: new parity tests (each file under its own limit), block / frontend A/B, fine stamps, launch order of one step
+#   r05c         round 5: block.hip stream across stage boundaries + per-row conv requests against lib_prev / lib_v64
+#   attn-stamps5 relpos_attn2 cycle stamps, small model
+#   search640, sweep640   label step at configs[3]'s per-GPU shape: kernel table; sweep of the dispatch switches (B64=16 for 160 rows)
+#   tree-sa      round 5: decoder self-attention over the union of a beam's ancestors: tests, in-call A/B, 640-row kernel table
 set -u
 what=${1:-bench}; tag=${2:-r03}; out=$PWD/gpurun_out/$tag; mkdir -p "$out"
 export TMPDIR=/tmp
