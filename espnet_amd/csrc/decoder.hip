@@ -951,10 +951,11 @@ int em_dec_self_attention_tree_bf16(const void* qkv, void* kc, void* vc, const i
       pos >= Lmax)
     return EM_ERR_UNSUPPORTED;
   // one workgroup per (utterance, head) walks the whole prefix: worth it once the per-row kernel's n x heads waves are several
-  // rounds of the chip - configs[3] per GPU (640 rows): 0.620 -> 0.593 ms per label step; configs[2] (160 rows): 0.352 ->
-  // 0.367, the per-row kernel stays (profiles/r05n_tree_self_attention_ab.txt).  ESPNET_AMD_SA_TREE_MIN_ROWS: developer switch.
+  // rounds of the chip - configs[3] per GPU (640 rows): 0.620 -> 0.593 ms per label step; 480 / 320 / 240 rows: 0.578 -> 0.557,
+  // 0.499 -> 0.492, 0.417 -> 0.410; configs[2] (160 rows): 0.352 -> 0.367, the per-row kernel stays (profiles/
+  // r05n_tree_self_attention_ab.txt, r05l_label_step_dispatch_sweep.txt).  ESPNET_AMD_SA_TREE_MIN_ROWS: developer switch.
   const char* const mr = getenv("ESPNET_AMD_SA_TREE_MIN_ROWS");  // (read per call: the kernel tests lower it in-process)
-  const int min_rows = mr ? atoi(mr) : 320;
+  const int min_rows = mr ? atoi(mr) : 200;
   if (n < min_rows) return EM_ERR_UNSUPPORTED;
   if ((size_t)Lmax * n * d * 2 >= ((size_t)1 << 31)) return EM_ERR_UNSUPPORTED;  // (buffer offsets are 32-bit)
   const size_t lds = tree_lds_bytes(W, Lmax);

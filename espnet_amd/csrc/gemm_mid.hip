@@ -192,8 +192,11 @@ int launch_mid(const EmGemmArgs* p, hipStream_t s) {
   // Round 5: 32 x 64 tiles once even 32 x 32 ones give every CU more than a workgroup - configs[3]'s per-GPU step (640 rows x
   // 512 columns: 320 tiles of 32 x 32) runs 0.684 against 0.715 ms per label step with them, the 160-row step 0.40 against
   // 0.35 (profiles/r05l_label_step_dispatch_sweep.txt), hence by tile count and not for all.
+  // (the residual projections of the label step, N = 512, at 240 / 320 / 480 / 640 rows - 128 / 160 / 240 / 320 tiles of 32 x 32 -
+  // run fastest with 16 x 32 / 32 x 32 / 32 x 32 / 32 x 64 tiles: 0.410, 0.464 against 0.492, 0.540 against 0.559, 0.684 against
+  // 0.715 ms per label step; same file)
   const long t32 = (long)em_cdiv(p->M, 32) * em_cdiv(p->N, 32);
-  const int tile = force ? force : (t32 < 256 ? 12 : (t32 < 288 ? 22 : 24));
+  const int tile = force ? force : (t32 < 144 ? 12 : (t32 < 288 ? 22 : 24));
   switch (tile) {
     case 11: return launch_mid_tile<T, EPI, 1, 1>(p, s);
     case 12: return launch_mid_tile<T, EPI, 1, 2>(p, s);
