@@ -466,7 +466,7 @@ def test_dec_self_attention_beam(lib, tree, heads, d, B, W, pos, Lmax):
 
     from espnet_amd import lib as L
 
-    os.environ["ESPNET_AMD_SA_TREE_MIN_ROWS"] = "0"  # (the library takes the tree form from 320 rows: here at every size)
+    os.environ["ESPNET_AMD_SA_TREE_MIN_ROWS"] = "0"  # (the library takes the tree form from 200 rows: here at every size)
     torch.manual_seed(3)
     n, dk = B * W, d // heads
     dt = torch.bfloat16
