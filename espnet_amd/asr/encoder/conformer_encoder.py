@@ -17,6 +17,7 @@ import ctypes as C
 import math
 import os
 import threading
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
@@ -709,13 +710,14 @@ class ConformerEncoder(torch.nn.Module):
     def last_ctc_ids(self):
         """Per-frame CTC arg-max ids of the calling thread's last `forward_device` (None when the launch sequence taken
         does not produce them)."""
-        return getattr(_TLS, "ids", {}).get(id(self))
+        ids = getattr(_TLS, "ids", None)
+        return ids.get(self) if ids is not None else None
 
     @last_ctc_ids.setter
     def last_ctc_ids(self, v):
         if not hasattr(_TLS, "ids"):
-            _TLS.ids = {}
-        _TLS.ids[id(self)] = v
+            _TLS.ids = weakref.WeakKeyDictionary()  # (keyed by the encoder itself: an entry dies with it, ids are never reused)
+        _TLS.ids[self] = v
 
     def forward(self, xs_pad: torch.Tensor, ilens: torch.Tensor, prev_states: torch.Tensor = None
                 ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:

@@ -942,7 +942,7 @@ int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, c
 }  // namespace
 
 // the beam-tree form of em_dec_self_attention for the offline search's decoder step (bf16, d_k = 64, rows = B x W with
-// W <= 16 consecutive rows per utterance, Lmax <= 256, no token mask); EM_ERR_UNSUPPORTED otherwise (the caller keeps the
+// W <= 16 consecutive rows per utterance, Lmax <= 512, no token mask); EM_ERR_UNSUPPORTED otherwise (the caller keeps the
 // per-row kernel).  ESPNET_AMD_NO_SA_TREE=1: developer A/B switch.
 int em_dec_self_attention_tree_bf16(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n, int d,
                                     int heads, int Lmax, int pos, const int* pos_dev, int W, void* ctx, void* stream) {

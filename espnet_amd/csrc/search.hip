@@ -1350,7 +1350,7 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
     // every pre-norm LayerNorm rides in the prologue of the projection that consumes it (ln_gemm.hip)
     EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm1_g, q.norm1_b, q.self_wqkv, q.self_bqkv, a.qkv, a.xn, n,
                    3 * d, d, stream));
-    // round 5: over the union of the beam's ancestors where the shape allows (bf16, d_k = 64, beams of <= 16, Lmax <= 256)
+    // round 5: over the union of the beam's ancestors where the shape allows (bf16, d_k = 64, beams of <= 16, Lmax <= 512)
     if (a.pos_dev)
       EM_TRY(em_dec_self_attention_beam(dtype, a.qkv, kc, vc, a.anc_a, a.anc_b, n, d, h, a.Lmax, 0, a.pos_dev, a.W, a.ctx, stream));
     else
