@@ -448,6 +448,17 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     }
   };
   auto touch_done = [&]() __attribute__((always_inline)) {};
+  // Round 5, launches that do not fill the chip (a tick of a batch of streams: 64 workgroups; one stream: 2): the launcher
+  // adds HELPER workgroups (rows of the grid past a.B) on the idle CUs.  A helper takes its share of the warm-up and leaves.
+  // Without them the few workgroups of an XCD touch the launch's whole list themselves - 10 to 16 wave-wide requests per wave,
+  // 640 to 1 024 lines, queued IN FRONT of the wave's own first units in the same in-order return stream - and everything not
+  // yet touched when a stream reaches it is a MALL-latency miss.  (The DMA lands in this workgroup's LDS: wait for it before
+  // the allocation is released to whoever comes next on this CU.)
+  if ((int)blockIdx.y >= a.B) {
+    touch();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
   // ---- prologue staging: parameter groups (and the depthwise conv's weights) go global memory -> LDS by LDS-DMA,
   // 1 KiB per wave-instruction, lines dealt round-robin to the four waves.  No registers, no wait at the point of
@@ -1327,7 +1338,25 @@ template <int MODE, int KWT = 31, bool RELU = false>
 int launch_block(const EmBlockArgs* a, hipStream_t s) {
   static EmLdsCap cap = {};
   if (em_raise_lds_cap((const void*)block_kernel<MODE, KWT, RELU>, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
-  dim3 grid(em_cdiv(a->T, BM), a->B);
+  // helper workgroups for launches smaller than the chip (see the kernel: L2 warm-up shares); ESPNET_AMD_BLOCK_NO_HELPERS:
+  // developer A/B switch
+  static const bool no_helpers = getenv("ESPNET_AMD_BLOCK_NO_HELPERS") != nullptr;
+  static int ncu_of[64];  // compute units per device (asked once: no runtime call on later launches, legal under stream capture)
+  const int gx = em_cdiv(a->T, BM);
+  int helper_rows = 0;
+  if (!no_helpers) {
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (ncu_of[dev] == 0) {
+        hipDeviceProp_t prop;
+        ncu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+      }
+      ncu = ncu_of[dev];
+    }
+    const long nwg = (long)gx * a->B;
+    if (nwg < ncu) helper_rows = (int)((ncu - nwg) / gx);
+  }
+  dim3 grid(gx, a->B + helper_rows);
   static long long* stamps = nullptr;
   static const bool want_stamps = getenv("EM_BLOCK_STAMPS") != nullptr;
   if (want_stamps && !stamps) hipMalloc((void**)&stamps, 256 * sizeof(long long));

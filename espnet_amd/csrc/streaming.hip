@@ -195,6 +195,122 @@ __global__ __launch_bounds__(256) void cb_mha_heads_kernel(const bf16* __restric
   for (int c = 0; c < DKP; ++c) out[c] = (bf16)(acc[c] * inv);
 }
 
+// Round 5: the same attention on the matrix cores, without LDS and without a barrier.  One wave per (block, head, 16 query
+// slots): Q and K rows are MFMA operands as they lie in memory ([slot][64] bf16, a lane reads 16 bytes of its row); the
+// scores are computed transposed, S^T[key][query] = K . Q^T, so a lane holds 16 keys of ONE query - the softmax statistics
+// are per lane plus two register swaps - and the probabilities, rounded to bf16, are already the B operand of
+// O^T = V^T . P^T, whose A operand is V^T as block<A> wrote it ([64][Tpad]: two 8-byte reads per fragment, the keys of the
+// lane's accumulator slots).  1 / sqrt(64) is folded into the query operands (a power of two: exact); the denominator is the
+// sum of the ROUNDED probabilities (a fragment of ones as a fifth A operand), as in relpos_attn2_kernel.  Slots past the
+// block (rows of the 64-slot operand tiles that no workgroup of block<A> wrote, or that it filled with copies of the last
+// slot) never count: their scores are replaced, not scaled, and their V columns are zeroed before the product.
+// The first version (above: f32 LDS copies of K and V, four threads per query, 2 x 41 dependent LDS round trips) took
+// 21.8 us per launch at 32 blocks, a fifth of the streaming layer (profiles/r04zs_stream_batch32_kernel_stats.csv).
+// Reference: MultiHeadedAttention.forward (transformer/attention.py:121-151) under the contextual mask
+// (contextual_block_conformer_encoder.py:539-544).  L <= 64 <= Tpad.
+__global__ __launch_bounds__(256) void cb_mha_heads_mfma_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
+                                                               const bf16* __restrict__ vt, int L, int Tpad, int H,
+                                                               int mask_mode, bf16* __restrict__ ctx) {
+  using MM = Mma<bf16>;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const int h = blockIdx.x, blk = blockIdx.y, lane = threadIdx.x & 63;
+  const int qt = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's 16 query slots
+  if (16 * qt >= L) return;
+  const int lr = lane & 15, lg = lane >> 4;
+  const size_t bh = (size_t)blk * H + h;
+  const bf16* const qb = qh + bh * Tpad * 64;
+  const bf16* const kb = kh + bh * Tpad * 64;
+  const bf16* const vb = vt + bh * 64 * Tpad;
+  const int nkeys = mask_mode ? L - 1 : L;
+  // ---- every operand requested up front: one round trip
+  bf16x8 qraw[2], kf[4][2];
+  uint2 vraw[4][2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qraw[ks] = *(const bf16x8*)(qb + (size_t)(16 * qt + lr) * 64 + ks * 32 + lg * 8);
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) kf[nf][ks] = *(const bf16x8*)(kb + (size_t)(16 * nf + lr) * 64 + ks * 32 + lg * 8);
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+        vraw[f][jp][hf] = *(const uint2*)(vb + (size_t)(16 * f + lr) * Tpad + 32 * jp + 16 * hf + 4 * lg);
+  // ---- S^T (64 keys x 16 queries): A = K rows (key 16 nf + lr, k-slice lg), B = Q^T (query lr, k-slice lg)
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16)((float)qraw[ks][e] * 0.125f);
+  f32x4 sc[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) sc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) sc[nf] = MM::mma(kf[nf][ks], qf[ks], sc[nf]);
+  // ---- this lane: keys 16 nf + 4 lg + r of query lr
+  float tm = -INFINITY;
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[nf][r] = (16 * nf + 4 * lg + r) < nkeys ? sc[nf][r] : -INFINITY;
+      tm = fmaxf(tm, sc[nf][r]);
+    }
+  tm = wave_xor16_max(tm);  // the four lane groups of a query
+  tm = wave_xor32_max(tm);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float mnl = tm * LOG2E;
+  unsigned pbu[2][4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[nf][2 * hh], LOG2E, -mnl));
+      const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[nf][2 * hh + 1], LOG2E, -mnl));
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      pbu[nf >> 1][(nf & 1) * 2 + hh] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
+    }
+  // ---- O^T += V^T . P^T: contraction slot e of the 32-key step jp is key 32 jp + 16 (e >> 2) + 4 lg + (e & 3) on both sides
+  const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+  f32x4 acc_o[4], acc_l = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < 4; ++f) acc_o[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    const bf16x8 pb = __builtin_bit_cast(bf16x8, (u32x4){pbu[jp][0], pbu[jp][1], pbu[jp][2], pbu[jp][3]});
+    acc_l = MM::mma(ones, pb, acc_l);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      unsigned w[4];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int nv = nkeys - (32 * jp + 16 * hf + 4 * lg);  // how many of the piece's four keys exist
+        w[2 * hf] = vraw[f][jp][hf].x & (nv >= 2 ? 0xffffffffu : (nv == 1 ? 0xffffu : 0u));
+        w[2 * hf + 1] = vraw[f][jp][hf].y & (nv >= 4 ? 0xffffffffu : (nv == 3 ? 0xffffu : 0u));
+      }
+      acc_o[f] = MM::mma(__builtin_bit_cast(bf16x8, (u32x4){w[0], w[1], w[2], w[3]}), pb, acc_o[f]);
+    }
+  }
+  // ---- lane (lr, lg): query 16 qt + lr, channels 16 f + 4 lg .. + 3
+  const int q = 16 * qt + lr;
+  if (q < L) {
+    const bool none = mask_mode && q == 0;  // (the context slot of the contextual mask attends to nothing: zeros, selected - not scaled)
+    const float inv = 1.0f / acc_l[0];
+    bf16* const dst = ctx + ((size_t)blk * L + q) * (H * 64) + h * 64 + 4 * lg;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const bf16x4 pk = {(bf16)(none ? 0.f : acc_o[f][0] * inv), (bf16)(none ? 0.f : acc_o[f][1] * inv),
+                         (bf16)(none ? 0.f : acc_o[f][2] * inv), (bf16)(none ? 0.f : acc_o[f][3] * inv)};
+      *(bf16x4*)(dst + 16 * f) = pk;
+    }
+  }
+}
+
 // Context hand-over after a layer (layer :292-304), in place on x [n_blk][L][d] f32:
 //   x[0][0] = past_ctx (or x[0][L-1] for the first block of an utterance); x[b][0] = x[b-1][L-1];
 //   next_ctx = x[n_blk-1][L-1].
@@ -416,12 +532,17 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
     ba.B = n_blk; ba.T = L; ba.Tpad = s.Tpad; ba.d = d; ba.ff = ff; ba.kernel = w->kernel; ba.eps = LN_EPS;
     ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = ws + s.qh; ba.kh = ws + s.kh; ba.vt = ws + s.vt;
     const size_t mha_lds = ((size_t)2 * L * 64 + (size_t)64 * (L + 1)) * sizeof(float);
+    static const bool mha_v1 = getenv("ESPNET_AMD_STREAM_MHA_V1") != nullptr;  // developer A/B switch: the LDS / VALU attention kernel of round 4
     for (int l = 0; l < NL; ++l) {
       const EmConformerLayer& q = w->layers[l];
       ba.ffm_w1 = q.ffm_w1p; ba.ffm_w2 = q.ffm_w2p; ba.wqkv = q.wqkvp; ba.ffm_b1g = q.ffm_b1; ba.params = q.fp_a;
       EM_TRY(em_conformer_block_fused(EM_BLOCK_A | EM_BLOCK_RELU, &ba, stream));
-      hipLaunchKernelGGL(cb_mha_heads_kernel, dim3(h, n_blk), dim3(256), mha_lds, (hipStream_t)stream,
-                         (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
+      if (mha_v1)
+        hipLaunchKernelGGL(cb_mha_heads_kernel, dim3(h, n_blk), dim3(256), mha_lds, (hipStream_t)stream,
+                           (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
+      else
+        hipLaunchKernelGGL(cb_mha_heads_mfma_kernel, dim3(h, n_blk), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
       EM_CHECK_LAUNCH();
       ba.wout = q.woutp; ba.pw1f = q.pw1f; ba.params = q.fp_c;
       EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));

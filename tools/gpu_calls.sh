@@ -16,6 +16,7 @@
 #   attn-stamps5 relpos_attn2 cycle stamps, small model
 #   search640, sweep640   label step at configs[3]'s per-GPU shape: kernel table; sweep of the dispatch switches (B64=16 for 160 rows)
 #   tree-sa      round 5: decoder self-attention over the union of a beam's ancestors: tests, in-call A/B, 640-row kernel table
+#   stream-ab    round 5: helper workgroups on a partly filled chip + block attention on MFMA: streaming A/B, suite, smoke, bench, 32-stream table
 set -u
 what=${1:-bench}; tag=${2:-r03}; out=$PWD/gpurun_out/$tag; mkdir -p "$out"
 export TMPDIR=/tmp
@@ -286,5 +287,39 @@ PY
     python tools/pmc_summary.py "$out/pmc" --match sub2_kernel relpos_attn2 block_kernel frontend_logmel gemm_kernel --source "bench.py --quick --steps 10 --warmup 3" > "$out/pmc_sq.json" 2>"$out/pmc_sq.err"
     find "$out/pmc" -name "*counter_collection.csv" -delete 2>/dev/null
     head -c 3000 "$out/pmc_sq.json" ;;
+  stream-ab)  # round 5: helper workgroups of the row-block launches on a partly filled chip + the contextual-block attention on MFMA:
+              # in-call A/B of the switches on the streaming workloads, then the whole suite, the streaming files again with the
+              # fused layers taken from ONE block, smoke and the default bench line
+    echo "== A/B streaming (one stream: audio-s/s, ms per call; 32 streams: audio-s/s, ms per tick)"
+    for cfg in "new" "ESPNET_AMD_BLOCK_NO_HELPERS=1" "ESPNET_AMD_STREAM_MHA_V1=1" "ESPNET_AMD_STREAM_FUSED_MIN=1" "ESPNET_AMD_STREAM_FUSED_MIN=1 ESPNET_AMD_BLOCK_NO_HELPERS=1"; do
+      echo -n "$cfg: "
+      if [ "$cfg" = new ]; then timeout 200 python tools/stream_ab.py both 2>/dev/null < /dev/null
+      else
+        case "$cfg" in *FUSED_MIN*) w=one ;; *) w=both ;; esac
+        env $cfg timeout 200 python tools/stream_ab.py $w 2>/dev/null < /dev/null
+      fi
+    done 2>&1 | tee "$out/stream_ab.txt"
+    echo "== pytest -m gpu"; (time timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -8) 2>&1 | tee "$out/pytest_gpu.txt"
+    echo "== streaming files with the fused layers from one block"
+    (ESPNET_AMD_STREAM_FUSED_MIN=1 timeout 300 python -m pytest tests/test_gpu_streaming.py tests/test_gpu_online_search.py -q 2>&1 | tail -6) | tee "$out/pytest_stream_fused_min1.txt"
+    echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -4 | tee "$out/smoke.txt"
+    echo "== default bench"; (time timeout 600 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5
+    echo "== kernel table of the 32-stream tick"
+    stats "$out/stream32_stats" python "$R/tools/stream_ab.py" batch ;;
+  stream-ab2)  # the 128-stream tick (no helper workgroups there: 256 workgroups) with either attention kernel, twice each; the greedy
+               # step at batches that leave CUs idle, with and without helper workgroups
+    for cfg in "new" "ESPNET_AMD_STREAM_MHA_V1=1" "new" "ESPNET_AMD_STREAM_MHA_V1=1"; do
+      echo -n "$cfg: "
+      if [ "$cfg" = new ]; then timeout 200 python tools/stream_ab.py batch128 2>/dev/null < /dev/null
+      else env $cfg timeout 200 python tools/stream_ab.py batch128 2>/dev/null < /dev/null; fi
+    done 2>&1 | tee "$out/stream128_ab.txt"
+    for b in 4 8 16; do
+      for h in 0 1 0 1; do
+        if [ $h = 1 ]; then export ESPNET_AMD_BLOCK_NO_HELPERS=1; else unset ESPNET_AMD_BLOCK_NO_HELPERS; fi
+        echo -n "batch $b no_helpers=$h: "
+        timeout 200 python bench.py --quick --batch $b --no-traffic --no-roofline --no-cpu-baseline --steps 400 --warmup 30 2>/dev/null < /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s', d['ms_per_step'], 'ms/step')"
+      done
+    done 2>&1 | tee "$out/helpers_small_batches.txt"
+    unset ESPNET_AMD_BLOCK_NO_HELPERS ;;
   *) echo "unknown call: $what"; exit 2 ;;
 esac
