@@ -1,6 +1,8 @@
 """CTC head on the MI355X.  Mirrors espnet2/asr/ctc.py:9-215 for inference (`ctc_lo`,
 `softmax`/`log_softmax`/`argmax`); state-dict keys `ctc_lo.{weight,bias}`.  The loss is training
 only and out of scope."""
+import os
+
 import torch
 
 from espnet_amd import lib as L
@@ -72,11 +74,26 @@ class CTC(torch.nn.Module):
 
     def argmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
         """asr/ctc.py:207-215.  Returns (B, T) int64 like the reference."""
-        logits = self.logits_device(self._to_act(hs_pad))
-        B, T, V = logits.shape
-        ids = torch.empty(B, T, dtype=torch.int32, device=logits.device)
-        L.check(L.load().em_argmax_rows_f32(L.ptr(logits), B * T, V, L.ptr(ids),
-                                            L.current_stream_ptr()), "em_argmax_rows_f32")
+        act = self._to_act(hs_pad)
+        B, T, d = act.shape
+        V, dev, st = self.odim, act.device, L.current_stream_ptr()
+        ids = torch.empty(B, T, dtype=torch.int32, device=dev)
+        if d % 64 != 0 or os.environ.get("ESPNET_AMD_CTC_ARGMAX_LOGITS"):
+            # the (B, T, V) f32 logits written and read back (rounds 1-4; developer A/B switch; widths the arg-max
+            # epilogue's GEMM does not take)
+            logits = self.logits_device(act)
+            L.check(L.load().em_argmax_rows_f32(L.ptr(logits), B * T, V, L.ptr(ids), st), "em_argmax_rows_f32")
+            return ids.to(torch.int64)
+        # round 5: arg-max in the epilogue of the ctc_lo GEMM, as em_ctc_greedy has it - the logits never exist (10 MB per
+        # tick of a 32-stream batch, 26.5 + 26.1 us of its 1.25 ms: profiles/r05x_stream_batch32_kernel_stats.csv); only
+        # (value, column) pairs per 64 columns are written and reduced.  Same values compared, ties to the lowest column.
+        p = self._pack(dev)
+        G = 2 * ((V + 127) // 128)
+        part = torch.empty(B * T * G * 2, dtype=torch.float32, device=dev)
+        a = L.EmGemmArgs(A=act.data_ptr(), W=p["w"].data_ptr(), C=part.data_ptr(), bias=p["b"].data_ptr(), M=B * T, N=V,
+                         K=d, lda=d, ldc=G, scale=1.0)
+        L.check(L.load().em_gemm(self.em_dtype, L.EM_EPI_ARGMAX_PART, L.EM_A_PLAIN, a, st), "em_gemm(ctc_lo, arg-max)")
+        L.check(L.load().em_argmax_partials(L.ptr(part), B * T, G, L.ptr(ids), st), "em_argmax_partials")
         return ids.to(torch.int64)
 
     @staticmethod

@@ -114,6 +114,7 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
         self.after_norm = LayerNorm(output_size)
         self._packed = None
         self._ws = {}
+        self._flen_cache = {}  # (streams, frames, device) -> per-stream frame counts on the device (_embed_device_batch)
 
     def output_size(self) -> int:
         return self._output_size
@@ -402,7 +403,11 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
         T1, F1 = (t - 3) // 2 + 1, (nm - 3) // 2 + 1
         T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
         dev, act, st = xs.device, self.act_dtype, L.current_stream_ptr()
-        flen = torch.full((S,), t, dtype=torch.int32, device=dev)
+        flen = self._flen_cache.get((S, t, dev))  # (a batch's ticks repeat their shapes: filled once, not per tick)
+        if flen is None:
+            if len(self._flen_cache) > 64:
+                self._flen_cache.clear()
+            flen = self._flen_cache[(S, t, dev)] = torch.full((S,), t, dtype=torch.int32, device=dev)
         c1 = torch.empty(S * T1 * F1 * d, dtype=act, device=dev)
         L.check(lib.em_conv2d_sub1(self.em_dtype, L.ptr(xs), None, L.ptr(flen), S, t, nm, w.conv1_w,
                                    w.conv1_b, d, L.ptr(c1), st), "em_conv2d_sub1")
@@ -509,7 +514,8 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
             y_len = x.size(1) if n_proc == 0 else x.size(1) - offset
         else:
             y_len = block_num * hs + (offset if n_proc == 0 else 0)
-        ys = torch.zeros(S, y_len, d, dtype=torch.float32, device=dev)
+        # (not final: the head piece and the blocks' hops below tile [0, y_len) exactly - nothing to clear)
+        ys = (torch.zeros if is_final else torch.empty)(S, y_len, d, dtype=torch.float32, device=dev)
         if n_proc == 0:
             ys[:, :offset] = ys_chunk[:, 0, :offset]
         for i in range(block_num):  # :565-576 (slicing only)

@@ -107,6 +107,7 @@ class Speech2TextStreaming:
         self.win_length = fconf["win_length"] if fconf.get("win_length") is not None else self.n_fft
         self.use_hipgraph = use_hipgraph
         self._runner = None
+        self._flens_cache = {}  # (streams, samples, device) -> frame counts on the device (apply_frontend_batch)
         self.reset()
 
     def reset(self):
@@ -207,8 +208,15 @@ class Speech2TextStreaming:
         wav = to_process.contiguous()
         S, n = wav.shape
         m = self.asr_model
-        flens = m.frontend.feature_lengths([n] * S)
-        flens_dev = torch.tensor(flens, dtype=torch.int32).to(wav.device)
+        # (the frame counts of a tick are the same tick after tick: their device copy is made once per (S, n), not with a
+        # pageable host -> device copy in front of every tick's launches)
+        key = (S, n, wav.device)
+        flens_dev = self._flens_cache.get(key)
+        if flens_dev is None:
+            if len(self._flens_cache) > 64:
+                self._flens_cache.clear()
+            flens = m.frontend.feature_lengths([n] * S)
+            flens_dev = self._flens_cache[key] = torch.tensor(flens, dtype=torch.int32).to(wav.device)
         feats = m.frontend.forward_device(wav, flens_dev)
         if m.normalize is not None:
             feats = m.normalize.forward_device(feats, flens_dev)

@@ -321,5 +321,17 @@ PY
       done
     done 2>&1 | tee "$out/helpers_small_batches.txt"
     unset ESPNET_AMD_BLOCK_NO_HELPERS ;;
+  stream-ab3)  # CTC.argmax through the arg-max epilogue of the ctc_lo GEMM (no logits), per-tick constants cached
+    (timeout 300 python -m pytest tests/test_gpu_streaming.py tests/test_gpu_online_search.py tests/test_gpu_ebranchformer.py -q 2>&1 | tail -4) | tee "$out/pytest_stream.txt"
+    (timeout 200 python -m pytest tests/test_gpu_e2e.py -q -k "api or ctc" 2>&1 | tail -3) | tee -a "$out/pytest_stream.txt"
+    for cfg in "new" "ESPNET_AMD_CTC_ARGMAX_LOGITS=1" "new" "ESPNET_AMD_CTC_ARGMAX_LOGITS=1"; do
+      echo -n "$cfg: "
+      if [ "$cfg" = new ]; then timeout 200 python tools/stream_ab.py both 2>/dev/null < /dev/null
+      else env $cfg timeout 200 python tools/stream_ab.py both 2>/dev/null < /dev/null; fi
+    done 2>&1 | tee "$out/stream_ab3.txt" ;;
+  final)  # the suite, smoke, the default bench line
+    echo "== pytest -m gpu"; (time timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -8) 2>&1 | tee "$out/pytest_gpu.txt"
+    echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -4 | tee "$out/smoke.txt"
+    echo "== default bench"; (time timeout 600 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5 ;;
   *) echo "unknown call: $what"; exit 2 ;;
 esac
