@@ -72,8 +72,9 @@ class CTC(torch.nn.Module):
                 "em_log_softmax_rows_f32")
         return logits
 
-    def argmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
-        """asr/ctc.py:207-215.  Returns (B, T) int64 like the reference."""
+    def argmax(self, hs_pad: torch.Tensor, as_int32: bool = False) -> torch.Tensor:
+        """asr/ctc.py:207-215.  Returns (B, T) int64 like the reference (`as_int32`: the kernel's own int32 ids, for
+        callers that read them back to the host anyway - one conversion launch less per streaming tick)."""
         act = self._to_act(hs_pad)
         B, T, d = act.shape
         V, dev, st = self.odim, act.device, L.current_stream_ptr()
@@ -83,7 +84,7 @@ class CTC(torch.nn.Module):
             # epilogue's GEMM does not take)
             logits = self.logits_device(act)
             L.check(L.load().em_argmax_rows_f32(L.ptr(logits), B * T, V, L.ptr(ids), st), "em_argmax_rows_f32")
-            return ids.to(torch.int64)
+            return ids if as_int32 else ids.to(torch.int64)
         # round 5: arg-max in the epilogue of the ctc_lo GEMM, as em_ctc_greedy has it - the logits never exist (10 MB per
         # tick of a 32-stream batch, 26.5 + 26.1 us of its 1.25 ms: profiles/r05x_stream_batch32_kernel_stats.csv); only
         # (value, column) pairs per 64 columns are written and reduced.  Same values compared, ties to the lowest column.
@@ -94,7 +95,7 @@ class CTC(torch.nn.Module):
                          K=d, lda=d, ldc=G, scale=1.0)
         L.check(L.load().em_gemm(self.em_dtype, L.EM_EPI_ARGMAX_PART, L.EM_A_PLAIN, a, st), "em_gemm(ctc_lo, arg-max)")
         L.check(L.load().em_argmax_partials(L.ptr(part), B * T, G, L.ptr(ids), st), "em_argmax_partials")
-        return ids.to(torch.int64)
+        return ids if as_int32 else ids.to(torch.int64)
 
     @staticmethod
     def _token_outputs(B, T, dev, out):

@@ -247,9 +247,9 @@ class Speech2TextStreaming:
         feats, bst["frontend"] = self.apply_frontend_batch(speech, bst["frontend"], is_final=is_final)
         m = self.asr_model
         if feats is not None:
-            enc, y_len, bst["encoder"] = m.encoder.forward_infer_batch(feats.contiguous(), bst["encoder"], is_final)
+            enc, y_len, bst["encoder"] = m.encoder.forward_infer_batch(feats, bst["encoder"], is_final)  # (a view: the encoder's own cat / contiguous() copies it once)
             if y_len > 0:
-                ids = m.ctc.argmax(enc).cpu().tolist()  # ONE device -> host read per tick for all streams
+                ids = m.ctc.argmax(enc, as_int32=True).cpu().tolist()  # ONE device -> host read per tick for all streams
                 drop = (m.blank_id, m.sos, m.eos)
                 for s_ in range(S):
                     last, out = bst["last"][s_], bst["ids"][s_]
@@ -282,7 +282,7 @@ class Speech2TextStreaming:
     def _extend_partial(self, enc: torch.Tensor):
         """Incremental G1: argmax of the new frames, collapsing repeats across the chunk seam."""
         m = self.asr_model
-        ids = m.ctc.argmax(enc.unsqueeze(0))[0].tolist()
+        ids = m.ctc.argmax(enc.unsqueeze(0), as_int32=True)[0].tolist()
         for t in ids:
             if t != self._last_id and t not in (m.blank_id, m.sos, m.eos):
                 self._partial_ids.append(t)
@@ -400,7 +400,7 @@ class StreamPool:
                     en["n_processed_blocks"] = en["n_processed_blocks"][0]
                 enc, y_len, en_next = m.encoder.forward_infer_batch(feats.contiguous(), en, is_final)
                 if y_len > 0:
-                    ids = m.ctc.argmax(enc).cpu().tolist()  # one device -> host read per group and tick
+                    ids = m.ctc.argmax(enc, as_int32=True).cpu().tolist()  # one device -> host read per group and tick
             else:
                 en_next = None if sts[0]["encoder"] is None else self._stack([st["encoder"] for st in sts])
             for i, (sid, _) in enumerate(members):

@@ -1236,11 +1236,30 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     }
     if constexpr (!HAS_A && !FINAL) {  // the D part alone (streaming layers: the context hand-over sits between D and A)
       store_x();
+      // (one block per stream and call: the block's last slot is this call's context vector of the layer - written
+      // here instead of by a hand-over launch, EmBlockArgs.last_dst)
+      if (a.last_dst) {
+        float* const dst = a.last_dst + (size_t)b * a.row_stride;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          if (t0 + mi * 16 + lr == T - 1) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) *(float4*)(dst + 64 * f + ncol) = xr[mi][f];
+          }
+      }
       touch_done();
       return;
     }
   } else {
-    load_x();
+    // (A alone.  One block per stream and call of the streaming layers: slot 0 is the previous call's context vector of the
+    // layer in front, read from where that call left it - EmBlockArgs.row0_src - instead of a hand-over launch copying it
+    // into x first; a select on the address, no branch around the loads)
+    const bool ctx_slot = a.row0_src != nullptr && t0 == 0 && lr == 0;
+    const float* const s0 = ctx_slot ? a.row0_src + (size_t)b * a.row_stride : a.x + mrow[0] * D;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) xr[0][f] = *(const float4*)(s0 + 64 * f + ncol);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) xr[1][f] = *(const float4*)(a.x + mrow[1] * D + 64 * f + ncol);
   }
 
   if (HAS_A) {

@@ -533,10 +533,21 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
     ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = ws + s.qh; ba.kh = ws + s.kh; ba.vt = ws + s.vt;
     const size_t mha_lds = ((size_t)2 * L * 64 + (size_t)64 * (L + 1)) * sizeof(float);
     static const bool mha_v1 = getenv("ESPNET_AMD_STREAM_MHA_V1") != nullptr;  // developer A/B switch: the LDS / VALU attention kernel of round 4
+    // One block per stream (the steady-state tick): the hand-over after layer l is "slot 0 := the previous call's context
+    // vector of layer l; this call's := the last slot" - block<A> of layer l + 1 reads its slot 0 from past_ctx and
+    // block<D> of layer l writes its last slot to next_ctx as well: twelve launches less per call (4.9 us each, 59 of a
+    // 32-stream tick's 1 170 us; profiles/r05x_stream_batch32_kernel_stats.csv).  What x[.][0] holds after the LAST layer
+    // is never read (slot 0 is not an output frame).  ESPNET_AMD_STREAM_NO_CTX_FOLD: developer A/B switch (read per call:
+    // tests/test_gpu_streaming.py compares the two bit for bit).
+    const bool fold_ctx = mask_mode && n_blk_s == 1 && past_ctx && next_ctx && getenv("ESPNET_AMD_STREAM_NO_CTX_FOLD") == nullptr;
+    ba.row_stride = NL * d;
     for (int l = 0; l < NL; ++l) {
       const EmConformerLayer& q = w->layers[l];
       ba.ffm_w1 = q.ffm_w1p; ba.ffm_w2 = q.ffm_w2p; ba.wqkv = q.wqkvp; ba.ffm_b1g = q.ffm_b1; ba.params = q.fp_a;
+      ba.row0_src = (fold_ctx && l > 0) ? past_ctx + (size_t)(l - 1) * d : nullptr;
+      ba.last_dst = nullptr;
       EM_TRY(em_conformer_block_fused(EM_BLOCK_A | EM_BLOCK_RELU, &ba, stream));
+      ba.row0_src = nullptr;
       if (mha_v1)
         hipLaunchKernelGGL(cb_mha_heads_kernel, dim3(h, n_blk), dim3(256), mha_lds, (hipStream_t)stream,
                            (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
@@ -548,8 +559,10 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
       EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
       ba.pw2 = q.pw2p; ba.ff_w1 = q.ff_w1p; ba.ff_w2 = q.ff_w2p; ba.dw_w = q.dw_w; ba.dw_b = q.dw_b; ba.ff_b1g = q.ff_b1;
       ba.params = q.fp_da;
+      ba.last_dst = fold_ctx ? next_ctx + (size_t)l * d : nullptr;
       EM_TRY(em_conformer_block_fused(EM_BLOCK_D | EM_BLOCK_RELU, &ba, stream));
-      if (mask_mode) {
+      ba.last_dst = nullptr;
+      if (mask_mode && !fold_ctx) {
         hipLaunchKernelGGL(cb_propagate_ctx_kernel, dim3(n_blk_s, n_streams), dim3(256), 0, (hipStream_t)stream, x,
                            past_ctx ? past_ctx + (size_t)l * d : nullptr, next_ctx ? next_ctx + (size_t)l * d : nullptr,
                            n_blk_s, L, d, NL * d);

@@ -70,7 +70,8 @@ class EmBlockArgs(C.Structure):
                [(n, C.c_void_p) for n in ("x", "ctx", "glu", "qh", "kh", "vt", "enc_out", "enc_act", "tlens", "wout",
                                           "pw1f", "pw2", "ff_w1", "ff_w2", "dw_w", "dw_b", "ffm_w1", "ffm_w2", "wqkv",
                                           "params", "ctc_w", "ctc_b", "ctc_ids")] + [("ctc_units", C.c_int32)] + \
-               [("x_out", C.c_void_p), ("params_c", C.c_void_p), ("ffm_b1g", C.c_void_p), ("ff_b1g", C.c_void_p)]
+               [("x_out", C.c_void_p), ("params_c", C.c_void_p), ("ffm_b1g", C.c_void_p), ("ff_b1g", C.c_void_p),
+                ("row0_src", C.c_void_p), ("last_dst", C.c_void_p), ("row_stride", C.c_int32)]
 
 
 EM_ROWS_FFN, EM_ROWS_GLU = 0, 1

@@ -411,6 +411,14 @@ typedef struct EmBlockArgs {
    * 1024 of it; their b1 slot is then unused).  NULL otherwise. */
   const float* ffm_b1g;
   const float* ff_b1g;
+  /* Contextual-block streaming layers with ONE block per stream and call (round 5): the context hand-over between layers
+   * (contextual_block_encoder_layer.py:292-304) without a launch of its own.  EM_BLOCK_A alone: slot 0 of block b is
+   * read from row0_src + b * row_stride instead of x (the previous call's context vector of the layer in front);
+   * EM_BLOCK_D alone: slot T - 1 of block b is ALSO written to last_dst + b * row_stride (this call's context vector of
+   * the layer).  [256] f32 rows, row_stride in floats.  NULL: off. */
+  const float* row0_src;
+  float* last_dst;
+  int32_t row_stride;
 } EmBlockArgs;
 int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
 

@@ -276,6 +276,43 @@ def test_batch_of_streams(name, dtype, atol):
     assert (got[0] - got[1]).abs().max().item() > 0.1
 
 
+def test_batch_tick_context_hand_over_in_the_block_launches_equals_its_own_launch():
+    """Round 5: with one block per stream and call, the fused streaming layer takes the context hand-over between layers
+    (contextual_block_encoder_layer.py:292-304) into the launches either side of it - block<A> reads slot 0 from the
+    previous call's context vectors, block<D> writes the last slot to this call's (csrc/streaming.hip `fold_ctx`,
+    EmBlockArgs.row0_src / last_dst) - instead of a launch per layer that copies them.  Only WHERE rows are read and
+    written changes: eight lock-step streams (8 blocks per call: the fused layers), chunk by chunk, bit for bit against
+    the hand-over launches (ESPNET_AMD_STREAM_NO_CTX_FOLD, read per call); stream 0 against the reference fixture."""
+    import os
+
+    g = load_stream_golden("stream_small_6s")
+    n, cf = int(g["n_samples"]), int(g["chunk_frames"])
+    feats = torch.stack([stream_feats(int(g["utt_id"]) + s, n) for s in range(8)])
+    enc = build(g, "bfloat16")
+    assert enc._fusable()
+
+    def run():
+        outs, state, pos, T = [], None, 0, feats.size(1)
+        while pos < T:
+            nxt = min(T, pos + cf)
+            y, y_len, state = enc.forward_infer_batch(feats[:, pos:nxt].cuda(), state, is_final=(nxt == T))
+            outs.append(y)
+            pos = nxt
+        return torch.cat(outs, 1).cpu()
+
+    os.environ.pop("ESPNET_AMD_STREAM_NO_CTX_FOLD", None)
+    folded = run()
+    os.environ["ESPNET_AMD_STREAM_NO_CTX_FOLD"] = "1"
+    try:
+        launched = run()
+    finally:
+        os.environ.pop("ESPNET_AMD_STREAM_NO_CTX_FOLD", None)
+    assert folded.shape == launched.shape and torch.equal(folded, launched)
+    assert (folded[0] - folded[1]).abs().max().item() > 0.1  # (different utterances)
+    err = np.abs(folded[0][:: int(g["keep_every"])].numpy() - g["ys"])
+    assert err.max() < 0.2 and err.mean() < 0.02, (err.max(), err.mean())
+
+
 def test_batch_call_equals_single_streams(tmp_path):
     """Speech2TextStreaming.batch_call (S lock-step streams, one launch sequence per tick: batched HIP frontend ->
     forward_infer_batch -> incremental greedy CTC) returns for every stream the tokens `__call__` returns for it alone

@@ -329,6 +329,14 @@ PY
       if [ "$cfg" = new ]; then timeout 200 python tools/stream_ab.py both 2>/dev/null < /dev/null
       else env $cfg timeout 200 python tools/stream_ab.py both 2>/dev/null < /dev/null; fi
     done 2>&1 | tee "$out/stream_ab3.txt" ;;
+  stream-ab4)  # the context hand-over folded into block<A> / block<D> (one block per stream and call)
+    (timeout 300 python -m pytest tests/test_gpu_streaming.py tests/test_gpu_block.py tests/test_gpu_online_search.py -q 2>&1 | tail -4) | tee "$out/pytest_stream.txt"
+    (ESPNET_AMD_STREAM_FUSED_MIN=1 timeout 300 python -m pytest tests/test_gpu_streaming.py tests/test_gpu_online_search.py -q 2>&1 | tail -4) | tee -a "$out/pytest_stream.txt"
+    for cfg in "new" "ESPNET_AMD_STREAM_NO_CTX_FOLD=1" "new" "ESPNET_AMD_STREAM_NO_CTX_FOLD=1"; do
+      echo -n "$cfg: "
+      if [ "$cfg" = new ]; then timeout 200 python tools/stream_ab.py batch 2>/dev/null < /dev/null
+      else env $cfg timeout 200 python tools/stream_ab.py batch 2>/dev/null < /dev/null; fi
+    done 2>&1 | tee "$out/stream_ab4.txt" ;;
   final)  # the suite, smoke, the default bench line
     echo "== pytest -m gpu"; (time timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -8) 2>&1 | tee "$out/pytest_gpu.txt"
     echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -4 | tee "$out/smoke.txt"
