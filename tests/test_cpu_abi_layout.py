@@ -57,3 +57,47 @@ def test_header_structs_all_have_a_mirror():
     declared = set(re.findall(r"typedef struct (Em\w+) \{", text))
     mirrored = {n for n, _ in _mirrors()}
     assert declared == mirrored, (declared - mirrored, mirrored - declared)
+
+
+def test_bound_signatures_match_the_header_prototypes():
+    """Every prototype of the header against the ctypes signature the host layer binds it with (espnet_amd.lib._SIGNATURES):
+    same number of parameters, each of the same kind (pointer / 32-bit int / float / double / 64-bit size), same kind of
+    result.  ctypes would pass a float where the library reads an int without a word."""
+    import re
+
+    text = (REPO / "include" / "espnet_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = re.findall(r"([A-Za-z_][\w \*]*?)\b(em_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text)
+    scalar = {"float": "f32", "double": "f64", "int32_t": "i32", "int": "i32", "size_t": "u64", "int64_t": "i64",
+              "long long": "i64", "uint32_t": "u32", "unsigned": "u32", "uint64_t": "u64", "void": None}
+
+    def kind_c(p):
+        p = p.strip()
+        if p in ("void", ""):
+            return None
+        if "*" in p or "[" in p:
+            return "ptr"
+        t = re.sub(r"\b(const|volatile)\b", "", p).split()
+        return scalar[" ".join(t[:-1]) if len(t) > 1 else t[0]]
+
+    def kind_ct(a):
+        if a is None:
+            return None
+        if a in (C.c_void_p, C.c_char_p) or (hasattr(a, "_type_") and not isinstance(a._type_, str)):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_int: "i32", C.c_float: "f32", C.c_double: "f64", C.c_size_t: "u64",
+                C.c_int64: "i64", C.c_uint32: "u32", C.c_uint64: "u64"}[a]
+
+    assert {n for _, n, _ in protos} == set(L._SIGNATURES)
+    bad = []
+    for ret, name, args in protos:
+        res, cargs = L._SIGNATURES[name]
+        want = [k for k in (kind_c(a) for a in args.split(",")) if k]
+        got = [kind_ct(a) for a in cargs]
+        if want != got:
+            bad.append((name, want, got))
+        r = ret.strip()
+        if ("ptr" if "*" in r else scalar[r]) != kind_ct(res):
+            bad.append((name, "result", r, res))
+    assert not bad, bad
