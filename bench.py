@@ -390,7 +390,7 @@ def main_stream(args):
                      cpu_base=not args.no_cpu_baseline)
     if args.stream_beam <= 1 and args.stream_chunk == 10240:
         res["batch32"] = run_stream_batch(args.dtype, 32, max(1, args.steps), 1)
-        res["batch128"] = run_stream_batch(args.dtype, 128, max(1, min(args.steps, 2)), 1)
+        res["batch128"] = run_stream_batch(args.dtype, 128, max(1, min(args.steps, 4)), 1)
     res = {"metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances", **res, "n_gpus": 1,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     print(json.dumps(res), flush=True)
@@ -1223,10 +1223,11 @@ def main():
             r["stress_40ms_calls"] = {"value": s["value"], "ms_per_step": s["ms_per_step"], **{
                 k: s["config"][k] for k in ("chunk_ms", "calls_per_utt", "call_latency_ms_median",
                                             "call_latency_ms_p95", "realtime_factor_of_one_stream")}}
-            r["batch32"] = run_stream_batch(args.dtype, 32, 3, 1)
-            # a tick's launches run on (streams x 42 rows) / 32 workgroups - 42 of 256 CUs at 32 streams - and are flat until
-            # the chip is full: the same tick with four times the streams
-            r["batch128"] = run_stream_batch(args.dtype, 128, 2, 1)
+            r["batch32"] = run_stream_batch(args.dtype, 32, 4, 1)
+            # a tick's row-block launches are two 32-row workgroups per stream - 64 of 256 CUs at 32 streams - and nearly flat
+            # until the chip is full: the same tick with four times the streams.  (Four steps, not two:
+            # one stalled tick in a two-step run read 34 800 where three runs around it read 52 800 - 53 200, profiles/r05x, r05y)
+            r["batch128"] = run_stream_batch(args.dtype, 128, 4, 1)
             return r
 
         guarded("frontend", frontend_leg)
