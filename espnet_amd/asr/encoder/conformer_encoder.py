@@ -680,6 +680,8 @@ class ConformerEncoder(torch.nn.Module):
         enc_flags = (L.EM_ENC_ISOLATE_UTTS if isolate else 0) | (0 if _fused_enabled(self) else L.EM_ENC_NO_FUSED)
         if getattr(self, "fold_c", None) if getattr(self, "fold_c", None) is not None else os.environ.get("ESPNET_AMD_FOLD") == "1":
             enc_flags |= L.EM_ENC_FOLD_C  # block<C|D|...>: two launches per block (opt-in: measured no faster)
+        if getattr(self, "split_att", None) if getattr(self, "split_att", None) is not None else os.environ.get("ESPNET_AMD_SPLIT_ATT") == "1":
+            enc_flags |= L.EM_ENC_SPLIT_ATT  # attention and block<C> as two launches (rounds 2-5) instead of block<ATT|C>: A/B switch
         pos = self._pos_emb(T, dev)
         if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "wpos_all", None):
             # linear_pos of every block depends on T and the weights only: projected once per length, handed over ready

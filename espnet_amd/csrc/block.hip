@@ -133,6 +133,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   constexpr bool HAS_A = (MODE & EM_BLOCK_A) != 0, FINAL = (MODE & EM_BLOCK_FINAL) != 0;
   constexpr bool CTC = (MODE & EM_BLOCK_CTC) != 0;
   constexpr bool FOLD = HAS_C && HAS_D;  // the C part computed in this launch, for 64 frames (round 4)
+  constexpr bool ATT = (MODE & EM_BLOCK_ATT) != 0;  // the attention of the workgroup's 32 queries in front of the C part (round 6)
+  static_assert(!ATT || (HAS_C && !HAS_D && !HAS_A && !FINAL), "block<ATT|C> is the only instantiation with the attention phase");
   static_assert(!FOLD || KWT == 31, "the folded C part is written for the 15-frame halo of k = 31");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const abuf = smem + ABUF_OFF;
@@ -143,7 +145,19 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nf = wave & 3;  // this wave's 16-column slice of every 64-column group
   const int lr = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.y, t0 = blockIdx.x * BM, T = a.T;
+  int b = blockIdx.y, t0 = blockIdx.x * BM;
+  const int T = a.T;
+  if constexpr (ATT) {
+    // The eight 32-query workgroups of an utterance read the same K / V^T (4 x 64 KiB) and the same position rows: they should
+    // share an L2.  Consecutive linear workgroup ids go round-robin over the 8 XCDs (see touch() below: driver behaviour, used
+    // for speed only), so inside a group of 8 utterances the id is dealt as (utterance = id % 8, query block = id / 8): every
+    // XCD then serves whole utterances.  A last group of fewer than 8 utterances keeps the plain order.
+    const int gx = gridDim.x, lid = blockIdx.y * gx + blockIdx.x, grp = lid / (8 * gx);
+    if ((int)blockIdx.y < a.B && grp * 8 + 8 <= a.B) {
+      b = grp * 8 + (lid & 7);
+      t0 = ((lid - grp * 8 * gx) >> 3) * BM;
+    }
+  }
 
   // this lane's two frames: mi * 16 + lr
   bool row_ok[2];
@@ -722,6 +736,233 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   const float* const pb3 = par + 3 * PAR_FLOATS;
 
   if (HAS_C && !HAS_D) {
+    if constexpr (ATT) {
+      // ---- Round 6: the relative-position self-attention of the workgroup's 32 queries, IN this launch
+      // (RelPositionMultiHeadedAttention.forward, attention.py:416-459; rel_shift :391-408; forward_attention :121-151):
+      //     AC[i][j] = (q_i + u) . k_j     BD[i][j] = (q_i + v) . p[T-1-i+j]     ctx_i = softmax_j((AC + BD) / 8) . v_j
+      // A wave per head, both 16-query fragments of the workgroup in that wave.  NO staging through LDS and no barrier: the
+      // K rows, the position rows and the V^T rows of a 64-key tile are MFMA A operands exactly as they lie in memory (a lane
+      // reads 16 bytes of "its" row), requested one tile ahead of the tile being computed, and every operand fragment feeds the
+      // MFMAs of BOTH query fragments.  As in csrc/attention2.hip the scores are computed transposed, S^T[key][query], so the
+      // softmax statistics are per-lane scalars and the bf16 probabilities are already the B operand of O^T = V^T . P^T; the
+      // key rows of a K fragment are chosen (row lr of fragment n = key 32 (n >> 1) + 8 (lr >> 2) + 4 (n & 1) + (lr & 3)) so that
+      // the eight contraction slots of a lane in P . V are eight CONSECUTIVE keys: V^T fragments are one 16-byte load per lane.
+      // rel_shift: the dense window D[c][i] = p[c] . (q_i + v) over the 96 position rows the (32 query, 64 key) rectangle
+      // can reach is computed per query fragment (80 rows each), written to a per-wave scratch and read back skewed.
+      // Why this unit of work: relpos_attn2_kernel (utterance, head, 128 queries) and block<C> were two launches
+      // of 11.3 + 12.3 us at B = 32, each a third cold prologue, with the context making a round trip through HBM between them
+      // and five barriers per key tile in the first; here the context goes from the accumulators to the LDS tile linear_out
+      // reads, the C part's weights are warmed into L2 while the attention runs, and the launch + prologue are paid once.
+      typedef __attribute__((ext_vector_type(4))) float f4;
+      typedef const __attribute__((address_space(1))) f4* GF4;
+      constexpr int LDB = 84;
+      const int hh = wave;  // head
+      int klen;
+      {
+        int kl;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kl) : "s"(a.klens + b) : "memory");
+        klen = kl < T ? kl : T;
+        klen = klen > 0 ? klen : 1;
+      }
+      const int Tp = a.Tpad;
+      const size_t bh = (size_t)b * 4 + hh;
+      GU8 qb = (GU8)a.qh + (bh * Tp + t0) * 128;
+      // K, V^T and the position rows arrive FRAGMENT-MAJOR (EmBlockArgs.kv_frag: the A part of the launch in front wrote K
+      // and V^T that way; em_relpos_pack_pos_bf16 the position windows): every operand fragment is 1 KiB contiguous, lane l
+      // reads bytes [16 l, 16 l + 16).  A first version read them "as they lie" row-major - lane (lr, lg) 16 bytes of row lr:
+      // 16 rows per wave-wide load, no two neighbouring lanes in the same line - and ran at the ~13 B/clk per CU of
+      // uncoalesced requests: 27.6 us per launch against 23.6 for the two launches it replaces (profiles/r06a_*).
+      GU8 kb = (GU8)a.kh + bh * Tp * 128 + lane * 16;
+      GU8 vb = (GU8)a.vt + bh * 64 * (size_t)Tp * 2 + lane * 16;
+      const int npg = a.ldp;  // position fragments per head
+      GU8 ppb = (GU8)a.pos + (size_t)hh * npg * 2048 + lane * 16;
+      const int g_q = 2 * (int)gridDim.x - (t0 >> 4);  // first position fragment of this query block at key tile 0
+      struct KP {
+        bf16x8 k[4][2], p[6][2];
+      };
+      struct VV {
+        bf16x8 v[4][2];
+      };
+      const int ntile = (klen + 63) >> 6;
+      // every request is unconditional (a tile past the end repeats the last one), so that hipcc counts its waits exactly
+      auto load_tile = [&](int jt, KP& kp, VV& vv) __attribute__((always_inline)) {
+        jt = jt < ntile ? jt : ntile - 1;
+        GU8 rk = kb + (size_t)jt * 8192;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) kp.k[n][ks] = *(GFRAG)(rk + n * 2048 + ks * 1024);
+        GU8 rp = ppb + (size_t)(g_q + 4 * jt) * 2048;
+#pragma unroll
+        for (int pn = 0; pn < 6; ++pn)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) kp.p[pn][ks] = *(GFRAG)(rp + pn * 2048 + ks * 1024);
+        GU8 rv = vb + (size_t)jt * 8192;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) vv.v[f][jp] = *(GFRAG)(rv + f * 2048 + jp * 1024);
+      };
+      // the queries (B operand: column = query 16 mi + lr, k-slice lg) and the two position biases
+      bf16x8 qraw[2][2];
+      f4 ur[2][2], vr[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qraw[mi][ks] = *(GFRAG)(qb + (16 * mi + lr) * 128 + (ks * 4 + lg) * 16);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          ur[ks][h2] = *(GF4)(a.pos_u + hh * 64 + ks * 32 + lg * 8 + h2 * 4);
+          vr[ks][h2] = *(GF4)(a.pos_v + hh * 64 + ks * 32 + lg * 8 + h2 * 4);
+        }
+      KP kpA, kpB;
+      VV vvA, vvB;
+      load_tile(0, kpA, vvA);
+      touch();  // the C part's weights into this XCD's L2 while the attention runs
+      bf16x8 qu[2][2], qv[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float qf = (float)qraw[mi][ks][e];
+            // 1 / sqrt(64) goes into the operands (a power of two: (AC + BD) / 8 comes out bit for bit the same)
+            qu[mi][ks][e] = (bf16)((qf + ur[ks][e >> 2][e & 3]) * 0.125f);
+            qv[mi][ks][e] = (bf16)((qf + vr[ks][e >> 2][e & 3]) * 0.125f);
+          }
+      f32x4 acc_o[2][4], acc_l[2];
+      float row_m[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc_l[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc_o[mi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      // (the softmax denominator rides on the matrix core: a fifth "V^T fragment" of ones, as in attention2.hip)
+      const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+      constexpr float LOG2E = 1.4426950408889634f;
+      float* const bdw = (float*)(smem + XCH_OFF) + wave * (2 * 16 * LDB);
+      auto tile = [&](int jt, const KP& kp, const VV& vv) __attribute__((always_inline)) {
+        const int j0 = jt * 64;  // (a tile past the end - odd tile counts - is masked as a whole)
+        f32x4 sc[2][4], dd[2][5];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) sc[mi][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int n = 0; n < 5; ++n) dd[mi][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) sc[mi][n] = MM::mma(kp.k[n][ks], qu[mi][ks], sc[mi][n]);
+          // window row cw = 31 - 16 mi - li + jl: queries 0 .. 15 reach position fragments 1 .. 5, queries 16 .. 31 fragments 0 .. 4
+#pragma unroll
+          for (int pn = 0; pn < 6; ++pn) {
+            if (pn >= 1) dd[0][pn - 1] = MM::mma(kp.p[pn][ks], qv[0][ks], dd[0][pn - 1]);
+            if (pn <= 4) dd[1][pn] = MM::mma(kp.p[pn][ks], qv[1][ks], dd[1][pn]);
+          }
+        }
+        // rel_shift: D[c][i] -> scratch[i][c], read back at c = 15 - i + (key of the tile)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int n = 0; n < 5; ++n)
+            *(float4*)(bdw + (mi * 16 + lr) * LDB + 16 * n + 4 * lg) = make_float4(dd[mi][n][0], dd[mi][n][1], dd[mi][n][2], dd[mi][n][3]);
+        bf16x8 pb[2][2];
+        float alpha[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const float* bdr = bdw + (mi * 16 + lr) * LDB + 15 - lr + 8 * lg;
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[mi][n][r] += bdr[32 * (n >> 1) + 4 * (n & 1) + r];
+          if (j0 + 64 > klen) {  // (uniform: only the tile that holds the utterance's end masks anything)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                sc[mi][n][r] = (j0 + 32 * (n >> 1) + 8 * lg + 4 * (n & 1) + r < klen) ? sc[mi][n][r] : -INFINITY;
+          }
+          float tm = -INFINITY;
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tm = fmaxf(tm, sc[mi][n][r]);
+          tm = wave_xor16_max(tm);  // the four lane groups of a query
+          tm = wave_xor32_max(tm);
+          const float mn = fmaxf(row_m[mi], tm);
+          alpha[mi] = __expf(row_m[mi] - mn);
+          row_m[mi] = mn;
+          const float mnl = mn * LOG2E;
+          unsigned pbu[2][4];
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[mi][n][2 * h], LOG2E, -mnl));
+              const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[mi][n][2 * h + 1], LOG2E, -mnl));
+              pbu[n >> 1][(n & 1) * 2 + h] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
+            }
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            pb[mi][jp] = __builtin_bit_cast(bf16x8, (u32x4){pbu[jp][0], pbu[jp][1], pbu[jp][2], pbu[jp][3]});
+          }
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            acc_o[mi][f][0] *= alpha[mi]; acc_o[mi][f][1] *= alpha[mi]; acc_o[mi][f][2] *= alpha[mi]; acc_o[mi][f][3] *= alpha[mi];
+          }
+          acc_l[mi][0] *= alpha[mi];  // (the other three rows of the ones fragment carry the same sum; only this one is read)
+        }
+        // O^T += V^T . P^T
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            acc_l[mi] = MM::mma(ones, pb[mi][jp], acc_l[mi]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc_o[mi][f] = MM::mma(vv.v[f][jp], pb[mi][jp], acc_o[mi][f]);
+          }
+      };
+      stamp(60);
+      const int npair = (ntile + 1) >> 1;
+#pragma unroll 1
+      for (int it = 0; it < npair; ++it) {
+        load_tile(2 * it + 1, kpB, vvB);
+        tile(2 * it, kpA, vvA);
+        load_tile(2 * it + 2, kpA, vvA);
+        tile(2 * it + 1, kpB, vvB);
+      }
+      stamp(61);
+      // the residual rows and linear_out's first units travel while the context is normalised and handed over
+      load_x();
+      read_unit(a.wout, 0, ring[0]);
+      read_unit(a.wout, 1, ring[1]);
+      read_unit(a.wout, 2, ring[2]);
+      // ctx[frame 16 mi + lr][64 hh + 16 f + 4 lg + r] -> bf16 -> k-tile hh of the LDS tile linear_out's activation fragments
+      // are read from (the same rounding point as the ctx buffer of the two-launch form)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float row_l = acc_l[mi][0];
+        const float inv = row_l > 0.f ? 1.0f / row_l : 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const bf16x4 pk = {(bf16)(acc_o[mi][f][0] * inv), (bf16)(acc_o[mi][f][1] * inv), (bf16)(acc_o[mi][f][2] * inv),
+                             (bf16)(acc_o[mi][f][3] * inv)};
+          *(bf16x4*)(abuf + hh * 4096 + mi * 2048 + lr * 128 + (((2 * f + (lg >> 1)) ^ swz) << 4) + (lg & 1) * 8) = pk;
+        }
+      }
+      bar(0);  // the context tile is complete; the parameter lines (requested before everything else) are in LDS
+      load_act();
+      stamp(4);
+    } else {
     // linear_out over the attention context: activation fragments straight from global memory
     // (attention.py:151 linear_out; encoder_layer.py:142-147 residual)
 #pragma unroll
@@ -740,6 +981,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     touch();
     bar(0);  // the parameter groups are in LDS
     fstamp(4);
+    }
     // G0: [bout 256][norm_conv g 256][b 256][pw1 bias, fused order 512]
     proj_resid(pb0, 0, a.wout, [&](int j) {
       if (j < 3) read_unit(a.pw1f, j, ring[j]);
@@ -771,7 +1013,8 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       }
     });
     store_x();
-    fstamp(51);
+    if constexpr (ATT) stamp(51);
+    else fstamp(51);
     touch_done();
     return;
   }
@@ -1332,11 +1575,25 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         o[2 + e] = r[1];
       }
       const int odd = lg & 1;  // this lane now holds half mi = odd of lane groups (lg & ~1) and (lg | 1)
-      if (which < 2) {
+      // a.kv_frag (round 6, for block<ATT|C>): K and V^T go out FRAGMENT-MAJOR per 64-key tile, the order in which the
+      // attention's MFMAs take them (EmBlockArgs.kv_frag in the header) - the same 16-byte pieces at other addresses
+      if (which == 0 || (which == 1 && !a.kv_frag)) {
         bf16* const dst = (bf16*)(which ? a.kh : a.qh) + (bh * a.Tpad + t0 + odd * 16 + lr) * 64 + nf * 16 + (lg & ~1) * 4;
         *(u32x4*)dst = o;
-      } else {
+      } else if (which == 1) {
+        const int j = t0 + odd * 16 + lr, jl = j & 63;                                  // key, columns 16 nf + 4 (lg & ~1) .. + 7
+        const int n = 2 * (jl >> 5) + ((jl >> 2) & 1), lrk = 4 * ((jl >> 3) & 3) + (jl & 3);  // fragment and row of key jl of a tile
+        const int lgk = (nf & 1) * 2 + (lg >> 1);                                        // k-slice of the 32-deep step nf >> 1
+        unsigned char* const dst = (unsigned char*)a.kh + bh * a.Tpad * 128 + (size_t)(j >> 6) * 8192 + n * 2048 + (nf >> 1) * 1024 +
+                                   (16 * lgk + lrk) * 16;
+        *(u32x4*)dst = o;
+      } else if (!a.kv_frag) {
         bf16* const dst = (bf16*)a.vt + (bh * 64 + nf * 16 + lr) * a.Tpad + t0 + odd * 16 + (lg & ~1) * 4;
+        *(u32x4*)dst = o;
+      } else {
+        const int j = t0 + odd * 16 + (lg & ~1) * 4, jl = j & 63;                        // eight consecutive keys of row 16 nf + lr
+        unsigned char* const dst = (unsigned char*)a.vt + bh * 64 * (size_t)a.Tpad * 2 + (size_t)(j >> 6) * 8192 + nf * 2048 +
+                                   (jl >> 5) * 1024 + (16 * ((jl & 31) >> 3) + lr) * 16;
         *(u32x4*)dst = o;
       }
     });
@@ -1397,7 +1654,28 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
   return EM_OK;
 }
 
+// Position rows of the relative-position attention, fragment-major for block<ATT|C>: fragment g of head h holds the rows
+// c = 16 g + T - 32 gx - 32 + lr (gx = ceil(T / 32); clamped to [0, 2T - 2]: only masked entries see a clamped row), so that the
+// six fragments a (query block t0, key tile j0) rectangle reaches are g = 2 gx - t0 / 16 + j0 / 16 .. + 5 - 12 KiB contiguous.
+__global__ void relpos_pack_pos_kernel(const bf16* __restrict__ pall, int ldp, int T, int gx, int npg, bf16* __restrict__ out) {
+  const int g = blockIdx.x, h = blockIdx.y, l = blockIdx.z, tid = threadIdx.x;  // 128 threads: (ks, lane)
+  const int ks = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+  int c = 16 * g + T - 32 * gx - 32 + lr;
+  c = c < 0 ? 0 : (c > 2 * T - 2 ? 2 * T - 2 : c);
+  const uint4 v = *(const uint4*)(pall + (size_t)c * ldp + l * D + h * 64 + ks * 32 + lg * 8);
+  *(uint4*)(out + ((((size_t)l * 4 + h) * npg + g) * 2 + ks) * 512 + lane * 8) = v;
+}
+
 }  // namespace
+extern "C" int em_relpos_pos_fragments(int32_t T) { return T > 0 ? 2 * em_cdiv(T, BM) + 4 * em_cdiv(T, 64) + 2 : 0; }
+extern "C" int em_relpos_pack_pos_bf16(const void* pall, int32_t ldp, int32_t T, int32_t L, void* out, void* stream) {
+  if (!pall || !out || T <= 0 || L <= 0 || ldp < L * D || ldp % 8 != 0) return EM_ERR_BAD_ARG;
+  const int npg = em_relpos_pos_fragments(T);
+  hipLaunchKernelGGL(relpos_pack_pos_kernel, dim3(npg, 4, L), dim3(128), 0, (hipStream_t)stream, (const bf16*)pall, ldp, T,
+                     em_cdiv(T, BM), npg, (bf16*)out);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
 extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* stream) {
   if (!a || !a->x || !a->params || a->B <= 0 || a->T <= 0) return EM_ERR_BAD_ARG;
   const bool relu = (mode & EM_BLOCK_RELU) != 0;  // streaming layers: ReLU feed-forward, conv width 15, ff up to 4096
@@ -1419,6 +1697,11 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
     if (a->kernel != (relu ? 15 : 31)) return EM_ERR_UNSUPPORTED;
   }
   if (mode == EM_BLOCK_C && (!a->ctx || !a->glu || !a->wout || !a->pw1f)) return EM_ERR_BAD_ARG;
+  if (mode & EM_BLOCK_ATT) {  // attention + the C part in one launch (round 6)
+    if (relu || mode != (EM_BLOCK_ATT | EM_BLOCK_C)) return EM_ERR_UNSUPPORTED;
+    if (!a->glu || !a->wout || !a->pw1f || !a->qh || !a->kh || !a->vt || !a->pos || !a->pos_u || !a->pos_v || !a->klens) return EM_ERR_BAD_ARG;
+    if (a->Tpad % 64 != 0 || a->Tpad < em_cdiv(a->T, BM) * BM || a->ldp != em_relpos_pos_fragments(a->T)) return EM_ERR_BAD_ARG;
+  }
   if ((mode & EM_BLOCK_C) && need_d) {  // the C part folded into the launch (round 4)
     if (!a->ctx || !a->wout || !a->pw1f || !a->params_c) return EM_ERR_BAD_ARG;
     if (need_a && (!a->x_out || a->x_out == a->x)) return EM_ERR_BAD_ARG;  // neighbours read x as their halo: no in-place update
@@ -1432,6 +1715,7 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   const double M = (double)a->B * a->T;
   double flops = 0.0;
   if (mode & EM_BLOCK_C) flops += 2.0 * M * D * (D + 2 * D);
+  if (mode & EM_BLOCK_ATT) flops += 6.0 * a->B * 4 * (double)a->T * a->T * 64;
   if (mode & EM_BLOCK_D) flops += 2.0 * M * D * (D + 2.0 * a->ff);
   if (mode & EM_BLOCK_A) flops += 2.0 * M * D * (2.0 * a->ff + 3 * D);
   if (mode & EM_BLOCK_CTC) flops += 2.0 * M * D * 64.0 * a->ctc_units;
@@ -1445,6 +1729,7 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   }
   switch (mode) {
     case EM_BLOCK_C: rc = launch_block<EM_BLOCK_C>(a, s); break;
+    case EM_BLOCK_ATT | EM_BLOCK_C: rc = launch_block<EM_BLOCK_ATT | EM_BLOCK_C>(a, s); break;
     case EM_BLOCK_A: rc = launch_block<EM_BLOCK_A>(a, s); break;
     case EM_BLOCK_D | EM_BLOCK_A: rc = launch_block<EM_BLOCK_D | EM_BLOCK_A>(a, s); break;
     case EM_BLOCK_D | EM_BLOCK_FINAL: rc = launch_block<EM_BLOCK_D | EM_BLOCK_FINAL>(a, s); break;

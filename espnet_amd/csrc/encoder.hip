@@ -21,7 +21,7 @@ constexpr float LN_EPS = 1e-12f;  // transformer/layer_norm.py:23
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws {
-  size_t c1, c2, c3, x, xn, big, g, g2, ctx, pall, qh, kh, vt, total;
+  size_t c1, c2, c3, x, xn, big, g, g2, ctx, pall, qh, kh, vt, ppk, total;
   int Tpad;
 };
 inline int fused_tpad(int T) { return (T + 255) / 256 * 256; }
@@ -51,6 +51,8 @@ inline Ws layout(int dtype, const EmConformerWeights* w, int B, int T_f) {
   s.qh = o; o += align_up(per_head);
   s.kh = o; o += align_up(per_head);
   s.vt = o; o += align_up(per_head);
+  // block<ATT|C> (round 6): the position rows of every block, fragment-major (em_relpos_pack_pos_bf16)
+  s.ppk = o; o += align_up((size_t)w->num_blocks * 4 * em_relpos_pos_fragments(g.T_out) * 2048);
   s.total = o;
   return s;
 }
@@ -211,6 +213,15 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = qh; ba.kh = kh; ba.vt = vt;
     ba.enc_out = enc_out; ba.enc_act = enc_act; ba.tlens = conv_lens;
     auto set_a = [&](const EmConformerLayer& q) { ba.ffm_w1 = q.ffm_w1p; ba.ffm_w2 = q.ffm_w2p; ba.wqkv = q.wqkvp; };
+    // Round 6: attention + the C part of a block as ONE launch, block<ATT|C> (EM_ENC_SPLIT_ATT / EM_ENC_FOLD_C: the forms of
+    // rounds 2-5).  Its K / V^T / position operands are fragment-major: packed position rows here, kv_frag for the A parts.
+    const bool att_c = !(flags & EM_ENC_FOLD_C) && !(flags & EM_ENC_SPLIT_ATT);
+    void* ppk = ws + s.ppk;
+    const int npg = em_relpos_pos_fragments(T);
+    if (att_c) {
+      EM_TRY(em_relpos_pack_pos_bf16(pall, L * d, T, L, ppk, stream));
+      ba.kv_frag = 1;  // the A parts write K and V^T in the order the attention's MFMAs take them
+    }
     set_a(ly[0]);
     ba.params = ly[0].fp_a;
     EM_TRY(em_conformer_block_fused(EM_BLOCK_A, &ba, stream));
@@ -228,10 +239,19 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     float* xb = (float*)big;
     for (int l = 0; l < L; ++l) {
       const EmConformerLayer& q = ly[l];
-      EM_TRY(em_relpos_attention2_bf16(qh, kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
-                                       q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
       ba.wout = q.woutp; ba.pw1f = q.pw1f;
-      if (no_fold) {
+      if (att_c) {
+        // Round 6: attention + the C part as ONE launch per (utterance, 32 queries) - block<ATT|C>, csrc/block.hip; the
+        // context never exists in memory.  EM_ENC_SPLIT_ATT: the two launches of rounds 2-5 (developer A/B switch).
+        ba.pos = (const unsigned char*)ppk + (size_t)l * 4 * npg * 2048; ba.ldp = npg; ba.pos_u = q.pos_u; ba.pos_v = q.pos_v;
+        ba.klens = olens; ba.params = q.fp_c;
+        EM_TRY(em_conformer_block_fused(EM_BLOCK_ATT | EM_BLOCK_C, &ba, stream));
+      } else {
+        EM_TRY(em_relpos_attention2_bf16(qh, kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
+                                         q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
+      }
+      if (att_c) {
+      } else if (no_fold) {
         ba.params = q.fp_c;
         EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
       } else {

@@ -24,8 +24,9 @@ EM_ENC_ISOLATE_UTTS = 1  # em_conformer_encode flags (include/espnet_amd.h)
 EM_ENC_NO_FUSED = 2
 EM_ENC_POS_PROJECTED = 4
 EM_ENC_FOLD_C = 8
+EM_ENC_SPLIT_ATT = 16
 EM_ENC_PLAN_FUSED, EM_ENC_PLAN_CTC_IDS = 1, 2
-EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC, EM_BLOCK_RELU = 1, 2, 4, 8, 16, 32
+EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC, EM_BLOCK_RELU, EM_BLOCK_ATT = 1, 2, 4, 8, 16, 32, 64
 EM_BLOCK_PARAM_GROUP = 1792
 EM_BLOCK_CTC_MAX_UNITS = 88  # vocabularies up to 5 632 labels take the fused CTC stage (the sizes the GPU tests cover); larger ones keep the arg-max GEMM
 EM_PROF_GEMM, EM_PROF_BLOCK, EM_PROF_ATTN, EM_PROF_ROWS = 0, 1, 2, 3
@@ -71,7 +72,8 @@ class EmBlockArgs(C.Structure):
                                           "pw1f", "pw2", "ff_w1", "ff_w2", "dw_w", "dw_b", "ffm_w1", "ffm_w2", "wqkv",
                                           "params", "ctc_w", "ctc_b", "ctc_ids")] + [("ctc_units", C.c_int32)] + \
                [("x_out", C.c_void_p), ("params_c", C.c_void_p), ("ffm_b1g", C.c_void_p), ("ff_b1g", C.c_void_p),
-                ("row0_src", C.c_void_p), ("last_dst", C.c_void_p), ("row_stride", C.c_int32)]
+                ("row0_src", C.c_void_p), ("last_dst", C.c_void_p), ("row_stride", C.c_int32), ("ldp", C.c_int32),
+                ("pos", C.c_void_p), ("pos_u", C.c_void_p), ("pos_v", C.c_void_p), ("klens", C.c_void_p), ("kv_frag", C.c_int32)]
 
 
 EM_ROWS_FFN, EM_ROWS_GLU = 0, 1
@@ -253,6 +255,8 @@ _SIGNATURES = {
     "em_profile_read": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "em_profile_read2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "em_conformer_block_fused": (C.c_int, [C.c_int, C.POINTER(EmBlockArgs), _vp]),
+    "em_relpos_pos_fragments": (C.c_int, [C.c_int32]),
+    "em_relpos_pack_pos_bf16": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "em_ffn_rows_fused": (C.c_int, [C.POINTER(EmFfnRowsArgs), _vp]),
     "em_relpos_attention2_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp,
                                             _vp]),

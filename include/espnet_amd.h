@@ -304,6 +304,8 @@ typedef struct EmConformerWeights {
 #define EM_ENC_NO_FUSED 2     /* keep the one-operator-per-launch sequence even where the fused block kernels apply */
 #define EM_ENC_FOLD_C 8       /* fused path: the C part of a block inside the launch that consumes it (block<C|D|...>: two launches
                                * per Conformer block instead of three; measured no faster at B = 32, DESIGN.md: opt-in) */
+#define EM_ENC_SPLIT_ATT 16    /* fused path: attention and the C part of a block as TWO launches (em_relpos_attention2_bf16 + block<C>,
+                               * rounds 2-5) instead of the one launch block<ATT|C> of round 6: developer A/B switch */
 #define EM_ENC_POS_PROJECTED 4 /* pos_emb is ALREADY linear_pos of every block: [2T-1 (legacy: T)][L*d] act, i.e. pos_emb x wpos_all^T
                                * (it depends on T and the weights only: a caller decoding many batches of one length projects once) */
 
@@ -348,6 +350,7 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
  *         EM_BLOCK_C | EM_BLOCK_D | EM_BLOCK_A (round 4): both of the above in ONE launch (see x_out / params_c below)
  *         EM_BLOCK_A                : the second half alone (first block, after the embedding)
  *         EM_BLOCK_D | EM_BLOCK_FINAL: the first half, then after_norm -> enc_out (f32) / enc_act (bf16)
+ *         EM_BLOCK_ATT | EM_BLOCK_C (round 6): relative-position attention + the C part in one launch (see EM_BLOCK_ATT)
  *   x     [B*T][256] f32 residual stream, updated in place (block<C> and the A part write it back)
  *   q / k [B][H][Tpad][64] bf16, vt [B][H][64][Tpad] bf16 (V transposed): inputs of em_relpos_attention2;
  *         Tpad % 64 == 0, Tpad >= 32 * ceil(T / 32); frames >= T of the last block hold finite padding
@@ -365,6 +368,12 @@ int em_conformer_encode(int dtype, const EmConformerWeights* w, const float* fea
                           * depthwise conv width 15, ff up to 4096 (ffm_b1g / ff_b1g).  With EM_BLOCK_A (macaron FFN, norm_mha,
                           * q / k / v per head) or EM_BLOCK_D alone (conv module back, FFN, norm_final -> x: the context
                           * hand-over between layers sits behind it); EM_BLOCK_C is the same kernel as without. */
+#define EM_BLOCK_ATT 64  /* round 6, with EM_BLOCK_C only: the relative-position self-attention of the workgroup's 32 queries
+                          * (RelPositionMultiHeadedAttention.forward, attention.py:391-459: all four heads, a wave per head)
+                          * runs IN FRONT of the C part, inside the same launch: one launch per (utterance, 32 queries) replaces
+                          * em_relpos_attention2_bf16 + block<C>, the context `ctx` never exists in memory.  Inputs qh / kh / vt
+                          * as A wrote them, plus pos / ldp / pos_u / pos_v / klens below (em_relpos_attention2_bf16's
+                          * arguments of the same names).  Any T; d = 256, 4 heads of 64. */
 #define EM_BLOCK_PARAM_GROUP 1792
 typedef struct EmBlockArgs {
   int32_t B, T, Tpad, d, ff, kernel;
@@ -419,8 +428,29 @@ typedef struct EmBlockArgs {
   const float* row0_src;
   float* last_dst;
   int32_t row_stride;
+  /* EM_BLOCK_ATT | EM_BLOCK_C (round 6): the attention's operands besides qh / kh / vt (inputs here, as the A part of
+   * the launch in front wrote them; rows >= T of qh / kh may hold anything, columns >= T of vt must be finite):
+   * pos / ldp: the position rows p[T - 1 - i + j] fragment-major (see kv_frag below), pos_u / pos_v [4][64] f32, klens [B]
+   * valid keys per utterance (clamped to T). */
+  int32_t ldp;
+  const void* pos;
+  const float *pos_u, *pos_v;
+  const int32_t* klens;
+  /* kv_frag != 0: K and V^T FRAGMENT-MAJOR per 64-key tile - what EM_BLOCK_A writes and what EM_BLOCK_ATT reads (0: the
+   * row-major layouts above, em_relpos_attention2_bf16's).  Same buffer sizes; per (utterance, head) and tile jt, 8 KiB:
+   *   K   tile[n][ks][lane = 16 lg + lr][e] = k[key 64 jt + 32 (n >> 1) + 8 (lr >> 2) + 4 (n & 1) + (lr & 3)][32 ks + 8 lg + e]
+   *   V^T tile[f][jp][lane][e]              = v[key 64 jt + 32 jp + 8 lg + e][16 f + lr]        n, f < 4; ks, jp < 2; e < 8
+   * (a lane's eight contraction slots of P . V are eight consecutive keys; every MFMA operand is one contiguous KiB).
+   * With EM_BLOCK_ATT, `pos` is em_relpos_pack_pos_bf16's table of THIS block ([4 heads][ldp fragments][2][64][8] bf16)
+   * and ldp = em_relpos_pos_fragments(T). */
+  int32_t kv_frag;
 } EmBlockArgs;
 int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
+/* Position rows for EM_BLOCK_ATT: pall [2T-1][ldp] bf16 holds linear_pos of L blocks side by side (block l at columns
+ * 256 l ..); out [L][4][em_relpos_pos_fragments(T)][2][64][8] bf16: fragment g of a head = rows 16 g + T - 32 ceil(T/32) - 32 + lr
+ * (clamped to the table), lane 16 lg + lr holding columns 32 ks + 8 lg .. + 7 of its row.  Depends on T and the weights only. */
+int em_relpos_pos_fragments(int32_t T);
+int em_relpos_pack_pos_bf16(const void* pall, int32_t ldp, int32_t T, int32_t L, void* out, void* stream);
 
 /* ---- A9 + A10, row-block fused feed-forward module for the 512-wide Conformer (bf16; csrc/ffn_rows.hip):
  *      PositionwiseFeedForward.forward (transformer/positionwise_feed_forward.py:30-32) with its residual

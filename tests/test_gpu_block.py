@@ -188,11 +188,69 @@ def split_heads(buf, B, T):
     return buf[:, :, :T].permute(0, 2, 1, 3).reshape(B * T, D)
 
 
+def _k_frag_index(Tp):
+    """key index of K'[jt][n][ks][lane][e] (EmBlockArgs.kv_frag): [Tp/64, 4, 1, 64, 1] broadcastable."""
+    jt = torch.arange(Tp // 64).reshape(-1, 1, 1, 1, 1)
+    n = torch.arange(4).reshape(1, -1, 1, 1, 1)
+    lane = torch.arange(64).reshape(1, 1, 1, -1, 1)
+    lr = lane % 16
+    return 64 * jt + 32 * (n // 2) + 8 * (lr // 4) + 4 * (n % 2) + (lr % 4)
+
+
+def k_to_frag(kh):
+    """[B][H][Tp][64] row-major -> the fragment-major K of EmBlockArgs.kv_frag (same shape, other order)."""
+    B, Hh, Tp, _ = kh.shape
+    key = _k_frag_index(Tp).expand(Tp // 64, 4, 2, 64, 8)
+    ks = torch.arange(2).reshape(1, 1, -1, 1, 1)
+    lg = (torch.arange(64) // 16).reshape(1, 1, 1, -1, 1)
+    col = (32 * ks + 8 * lg + torch.arange(8).reshape(1, 1, 1, 1, -1)).expand(Tp // 64, 4, 2, 64, 8)
+    return kh[:, :, key, col].reshape(B, Hh, Tp, 64)
+
+
+def k_from_frag(kf):
+    B, Hh, Tp, _ = kf.shape
+    key = _k_frag_index(Tp).expand(Tp // 64, 4, 2, 64, 8)
+    ks = torch.arange(2).reshape(1, 1, -1, 1, 1)
+    lg = (torch.arange(64) // 16).reshape(1, 1, 1, -1, 1)
+    col = (32 * ks + 8 * lg + torch.arange(8).reshape(1, 1, 1, 1, -1)).expand(Tp // 64, 4, 2, 64, 8)
+    out = torch.zeros_like(kf)
+    out[:, :, key, col] = kf.reshape(B, Hh, Tp // 64, 4, 2, 64, 8)
+    return out
+
+
+def _vt_frag_index(Tp):
+    jt = torch.arange(Tp // 64).reshape(-1, 1, 1, 1, 1)
+    f = torch.arange(4).reshape(1, -1, 1, 1, 1)
+    jp = torch.arange(2).reshape(1, 1, -1, 1, 1)
+    lane = torch.arange(64).reshape(1, 1, 1, -1, 1)
+    e = torch.arange(8).reshape(1, 1, 1, 1, -1)
+    row = (16 * f + lane % 16).expand(Tp // 64, 4, 2, 64, 8)
+    key = (64 * jt + 32 * jp + 8 * (lane // 16) + e).expand(Tp // 64, 4, 2, 64, 8)
+    return row, key
+
+
+def vt_to_frag(vt):
+    """[B][H][64][Tp] (V transposed, row-major) -> the fragment-major V^T of EmBlockArgs.kv_frag."""
+    B, Hh, _, Tp = vt.shape
+    row, key = _vt_frag_index(Tp)
+    return vt[:, :, row, key].reshape(B, Hh, 64, Tp)
+
+
+def vt_from_frag(vf):
+    B, Hh, _, Tp = vf.shape
+    row, key = _vt_frag_index(Tp)
+    out = torch.zeros_like(vf)
+    out[:, :, row, key] = vf.reshape(B, Hh, Tp // 64, 4, 2, 64, 8)
+    return out
+
+
 SHAPES = [(2, 249, 1024), (3, 70, 256), (1, 32, 1024), (2, 31, 64), (1, 40, 192), (2, 100, 576)]  # ff / 64 even, 1, odd
 
 
 @pytest.mark.parametrize("B,T,ff", SHAPES)
-def test_block_a(lib, B, T, ff):
+@pytest.mark.parametrize("kv_frag", [0, 1])
+def test_block_a(lib, B, T, ff, kv_frag):
+    """kv_frag = 1 (round 6): K and V^T written fragment-major for block<ATT|C>; unpacked here and held to the same reference."""
     ly = Layer(100, ff)
     x0 = rnd(B * T, D, seed=1)
     x_ref, qkv_ref = ly.part_a(x0)
@@ -202,7 +260,10 @@ def test_block_a(lib, B, T, ff):
     vt = torch.zeros(B, H, 64, Tp, dtype=BF, device="cuda")
     a = block_args(B, T, ff, x=xd, qh=qh, kh=kh, vt=vt, ffm_w1=dev(pack_w1(ly.ffm_w1).to(BF)), ffm_w2=dev(pack_w2(ly.ffm_w2).to(BF)),
                    wqkv=dev(pack_k_units(ly.wqkv).to(BF)), params=dev(torch.cat(ly.a_groups())))
+    a.kv_frag = kv_frag
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_A, a, L.current_stream_ptr()), "block<A>")
+    if kv_frag:
+        kh, vt = k_from_frag(kh.cpu()), vt_from_frag(vt.cpu())
     assert_close(xd, x_ref, 4e-3, "block<A> x")
     assert_close(split_heads(qh, B, T), qkv_ref[:, :D], 2e-2, "block<A> q")
     assert_close(split_heads(kh, B, T), qkv_ref[:, D:2 * D], 2e-2, "block<A> k")
@@ -223,6 +284,128 @@ def test_block_c(lib, B, T, ff):
     L.check(lib.em_conformer_block_fused(L.EM_BLOCK_C, a, L.current_stream_ptr()), "block<C>")
     assert_close(xd, x_ref, 4e-3, "block<C> x")
     assert_close(glu, glu_ref, 2e-2, "block<C> glu")
+
+
+def _attention_inputs(B, T, klens, seed):
+    """Per-head operands of the attention as block<A> writes them, and the torch restatement of the context."""
+    dk = 64
+    qq = q(rnd(B, T, H, dk, seed=seed))
+    kk = q(rnd(B, T, H, dk, seed=seed + 1))
+    vv = q(rnd(B, T, H, dk, seed=seed + 2))
+    Lb = 3  # linear_pos of several blocks side by side (ldp = Lb * d); the middle one is this block's
+    pall = q(rnd(2 * T - 1, Lb * D, seed=seed + 3))
+    p = pall[:, D:2 * D]
+    u, v = rnd(H, dk, seed=seed + 4, scale=0.3), rnd(H, dk, seed=seed + 5, scale=0.3)
+    q_u = q((qq + u) * 0.125).transpose(1, 2)  # (1 / sqrt(d_k) rides in the operands: a power of two, exact)
+    q_v = q((qq + v) * 0.125).transpose(1, 2)
+    pp = p.reshape(1, 2 * T - 1, H, dk).transpose(1, 2)
+    scores = q_u @ kk.transpose(1, 2).transpose(-2, -1) + oc.rel_shift(q_v @ pp.transpose(-2, -1))
+    mask = oc.make_pad_mask(torch.tensor(klens), T)[:, None, None, :]
+    attn = torch.softmax(scores.masked_fill(mask, torch.finfo(torch.float32).min), -1).masked_fill(mask, 0.0)
+    ctx = (attn @ vv.transpose(1, 2)).transpose(1, 2).reshape(B * T, D)
+    Tp = tpad(T)
+    qh = torch.full((B, H, Tp, dk), float("nan"), dtype=BF)  # rows >= T: never read into a stored output
+    kh = torch.full((B, H, Tp, dk), float("nan"), dtype=BF)  # keys >= klen: masked by select, never by arithmetic
+    vt = torch.zeros(B, H, dk, Tp, dtype=BF)                 # V^T padding must be finite (0 * x)
+    qh[:, :, :T] = qq.transpose(1, 2).to(BF)
+    kh[:, :, :T] = kk.transpose(1, 2).to(BF)
+    vt[:, :, :, :T] = vv.permute(0, 2, 3, 1).to(BF)
+    return dict(qh=qh, kh=kh, vt=vt, pall=pall, u=u, v=v, ctx=ctx, Lb=Lb)
+
+
+def packed_pos(lib, palld, T, Lb):
+    """em_relpos_pack_pos_bf16 of a [2T-1][Lb * 256] table, checked against its definition (include/espnet_amd.h)."""
+    npg = lib.em_relpos_pos_fragments(T)
+    assert npg == 2 * ((T + 31) // 32) + 4 * ((T + 63) // 64) + 2
+    out = torch.full((Lb, 4, npg, 2, 64, 8), float("nan"), dtype=BF, device="cuda")
+    L.check(lib.em_relpos_pack_pos_bf16(L.ptr(palld), Lb * D, T, Lb, L.ptr(out), L.current_stream_ptr()), "pack_pos")
+    gx = (T + 31) // 32
+    g = torch.arange(npg).reshape(-1, 1, 1, 1)
+    lane = torch.arange(64).reshape(1, 1, -1, 1)
+    row = (16 * g + T - 32 * gx - 32 + lane % 16).clamp(0, 2 * T - 2).expand(npg, 2, 64, 8)
+    col = (32 * torch.arange(2).reshape(1, -1, 1, 1) + 8 * (lane // 16) + torch.arange(8).reshape(1, 1, 1, -1)).expand(npg, 2, 64, 8)
+    p = palld.cpu()
+    for l in range(Lb):
+        for h in range(4):
+            assert torch.equal(out[l, h].cpu(), p[row, l * D + h * 64 + col]), (l, h)
+    _KEEP.append(out)
+    return out, npg
+
+
+ATT_SHAPES = [(2, 249, [249, 130]), (3, 70, [70, 1, 33]), (1, 32, [32]), (2, 31, [31, 7]), (1, 128, [128]), (2, 256, [256, 255]),
+              (1, 300, [257]), (2, 700, [700, 513]), (9, 40, [40, 39, 38, 37, 3, 2, 1, 40, 17]), (16, 65, list(range(50, 66)))]
+
+
+@pytest.mark.parametrize("B,T,klens", ATT_SHAPES)
+def test_block_att_c(lib, B, T, klens):
+    """Round 6, block<ATT|C>: relative-position attention of a workgroup's 32 queries + linear_out + residual + norm_conv +
+    pointwise_conv1 + GLU in ONE launch, against the torch restatement of attention.py:416-459 followed by part_c, and
+    against the two-launch form (em_relpos_attention2_bf16 + block<C>) on the same operands.  Shapes: key counts that end
+    inside / on a 64-key tile, odd and even tile counts, more than 256 keys, utterances of one frame, batches that do and
+    do not fill groups of 8 utterances (the workgroup -> (utterance, query block) map differs)."""
+    ly = Layer(1100, 256)
+    at = _attention_inputs(B, T, klens, 40)
+    x0 = rnd(B * T, D, seed=2)
+    x_ref, glu_ref = ly.part_c(x0, q(at["ctx"]))
+    Tp = tpad(T)
+    palld = dev(at["pall"].to(BF))
+    qh, kh, vt = dev(at["qh"]), dev(at["kh"]), dev(at["vt"])
+    khf, vtf = dev(k_to_frag(at["kh"])), dev(vt_to_frag(at["vt"]))  # the layouts the A part writes with kv_frag = 1
+    ppk, npg = packed_pos(lib, palld, T, at["Lb"])
+    u, v, kl = dev(at["u"]), dev(at["v"]), dev(torch.tensor(klens, dtype=torch.int32))
+    wout, pw1f, par = dev(pack_k_units(ly.wout).to(BF)), dev(pack_k_units(ly.pw1[ly.perm()]).to(BF)), dev(ly.c_group())
+    xd = dev(x0.clone())
+    glu = torch.zeros(B * T, D, dtype=BF, device="cuda")
+    a = block_args(B, T, 256, x=xd, glu=glu, qh=qh, kh=khf, vt=vtf, wout=wout, pw1f=pw1f, params=par, pos_u=u, pos_v=v, klens=kl)
+    a.pos, a.ldp, a.kv_frag = ppk.data_ptr() + 4 * npg * 2048, npg, 1  # (the middle block of the table)
+    L.check(lib.em_conformer_block_fused(L.EM_BLOCK_ATT | L.EM_BLOCK_C, a, L.current_stream_ptr()), "block<ATT|C>")
+    # rows of an utterance past its key count attend over the valid keys like any other row (the reference masks keys only)
+    assert_close(xd, x_ref, 4e-3, "block<ATT|C> x")
+    assert_close(glu, glu_ref, 2e-2, "block<ATT|C> glu")
+    # the two-launch form on the same operands: same rounding points, so the two agree far inside the tolerance above
+    ctx2 = torch.zeros(B * T, D, dtype=BF, device="cuda")
+    L.check(lib.em_relpos_attention2_bf16(L.ptr(qh), L.ptr(kh), L.ptr(vt), palld.data_ptr() + D * 2, at["Lb"] * D, L.ptr(u),
+                                          L.ptr(v), L.ptr(kl), B, T, Tp, H, L.ptr(ctx2), L.current_stream_ptr()), "attention2")
+    x2 = dev(x0.clone())
+    glu2 = torch.zeros(B * T, D, dtype=BF, device="cuda")
+    a2 = block_args(B, T, 256, x=x2, ctx=ctx2, glu=glu2, wout=wout, pw1f=pw1f, params=par)
+    L.check(lib.em_conformer_block_fused(L.EM_BLOCK_C, a2, L.current_stream_ptr()), "block<C>")
+    assert_close(xd, x2, 1e-3, "block<ATT|C> vs attention2 + block<C>: x")
+    assert_close(glu, glu2, 1.6e-2, "block<ATT|C> vs attention2 + block<C>: glu")  # (a bf16 ulp where a rounding falls the other way)
+    # missing operands are refused
+    a.klens = None
+    assert lib.em_conformer_block_fused(L.EM_BLOCK_ATT | L.EM_BLOCK_C, a, L.current_stream_ptr()) == L.EM_ERR_BAD_ARG
+
+
+def test_block_att_c_repeatable_at_bench_shape(lib):
+    """block<ATT|C> at B = 32 x T = 249 twenty times back to back: bit-identical outputs (operands are requested a tile ahead on
+    counted waits; a read that raced its request would show up as run-to-run differences)."""
+    B, T = 32, 249
+    ly = Layer(1200, 256)
+    at = _attention_inputs(B, T, [T - (b % 5) * 11 for b in range(B)], 60)
+    x0 = rnd(B * T, D, seed=3)
+    palld = dev(at["pall"].to(BF))
+    x0d, xd = dev(x0), dev(x0.clone())
+    glu = torch.zeros(B * T, D, dtype=BF, device="cuda")
+    ppk, npg = packed_pos(lib, palld, T, at["Lb"])
+    a = block_args(B, T, 256, x=xd, glu=glu, qh=dev(at["qh"]), kh=dev(k_to_frag(at["kh"])), vt=dev(vt_to_frag(at["vt"])),
+                   wout=dev(pack_k_units(ly.wout).to(BF)),
+                   pw1f=dev(pack_k_units(ly.pw1[ly.perm()]).to(BF)), params=dev(ly.c_group()), pos_u=dev(at["u"]), pos_v=dev(at["v"]),
+                   klens=dev(torch.tensor([T - (b % 5) * 11 for b in range(B)], dtype=torch.int32)))
+    a.pos, a.ldp, a.kv_frag = ppk.data_ptr() + 4 * npg * 2048, npg, 1
+    first = None
+    for it in range(20):
+        xd.copy_(x0d)
+        L.check(lib.em_conformer_block_fused(L.EM_BLOCK_ATT | L.EM_BLOCK_C, a, L.current_stream_ptr()), "block<ATT|C>")
+        got = (xd.clone(), glu.clone())
+        if first is None:
+            first = got
+            x_ref, glu_ref = ly.part_c(x0, q(at["ctx"]))
+            assert_close(xd, x_ref, 4e-3, "block<ATT|C> x at B=32")
+            assert_close(glu, glu_ref, 2e-2, "block<ATT|C> glu at B=32")
+        else:
+            for g0, g1 in zip(first, got):
+                assert torch.equal(g0, g1), f"run {it} differs from run 0"
 
 
 @pytest.mark.parametrize("B,T,ff", SHAPES)

@@ -31,6 +31,23 @@ stats() {  # <dir> <cmd...>: rocprofv3 --kernel-trace --stats of a command, summ
 beam_line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['search']['ms_per_search_step'])"; }
 quick() { timeout 300 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps ${1:-600} --warmup 30 2>/dev/null < /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s', d['ms_per_step'], 'ms/step')"; }
 case "$what" in
+  r06a)  # round 6: block<ATT|C> (attention + the C part in one launch): kernel tests, e2e parity of the small model, in-call A/B
+         # against the two-launch form (ESPNET_AMD_SPLIT_ATT=1), kernel table
+    echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tail -4 | tee "$out/box_state.txt"
+    echo "== kernel tests"
+    (timeout 600 python -m pytest -q -x tests/test_gpu_block.py 2>&1 | tail -6) | tee "$out/pytest_block.txt"
+    echo "== e2e parity (small model paths)"
+    (timeout 900 python -m pytest -q -x tests/test_gpu_e2e.py tests/test_gpu_fullsize.py -k "not beam" 2>&1 | tail -6) | tee "$out/pytest_e2e.txt"
+    echo "== A/B: split=1 is attention2 + block<C> (rounds 2-5), split=0 is block<ATT|C>"
+    for v in 0 1 0 1; do
+      if [ $v = 1 ]; then export ESPNET_AMD_SPLIT_ATT=1; else unset ESPNET_AMD_SPLIT_ATT; fi
+      echo -n "split_att=$v: "; quick 600
+    done 2>&1 | tee "$out/ab_att_c.txt"
+    unset ESPNET_AMD_SPLIT_ATT
+    echo "== stamps"; EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep -E "block<65>" | tail -3 | cut -c1-600 | tee "$out/block_stamps.txt"
+    echo "== kernel table"
+    stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10 | cut -c1-200
+    f=$(find "$out/prof_greedy" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/bench_small_b32_kernel_stats.csv" ;;
   r05a|r05b)  # round 5: kernel tests of the changed kernels, LayerNorm hand-over with the weight requests dealt into it (A/B against
             # lib_v32 = requests in one cluster), frontend v2 (A/B against ESPNET_AMD_FRONTEND_V1), fine stamps, kernel table, launch
             # order of one step (where do the ~7 copyBuffer launches per step come from?), then the new parity tests, each
