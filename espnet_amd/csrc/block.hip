@@ -121,6 +121,15 @@ __device__ __forceinline__ const unsigned char* em_uniform_ptr(const unsigned ch
   return (const unsigned char*)(((unsigned long long)hi << 32) | lo);
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): loop indices that must be constant EXPRESSIONS (asm "n" operands)
+template <int N, typename F>
+__device__ __forceinline__ void em_static_for(F&& f) {
+  if constexpr (N > 0) {
+    em_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 // KWT: depthwise-conv kernel width (D part).  RELU: the feed-forward activation is ReLU (the contextual-block streaming
 // encoder, contextual_block_conformer_encoder.py:148-154) instead of Swish; the conv module's Swish is unaffected.
 template <int MODE, int KWT = 31, bool RELU = false>
@@ -757,13 +766,27 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       typedef const __attribute__((address_space(1))) f4* GF4;
       constexpr int LDB = 84;
       const int hh = wave;  // head
-      int klen;
-      {
-        int kl;
-        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kl) : "s"(a.klens + b) : "memory");
-        klen = kl < T ? kl : T;
-        klen = klen > 0 ? klen : 1;
-      }
+      int klen_raw;
+      asm volatile("s_load_dword %0, %1, 0x0" : "=s"(klen_raw) : "s"(a.klens + b) : "memory");  // (waited for below)
+      // the residual rows go to their LDS parking place (lane-major, where an FFN parks them) by LDS-DMA, first of all: cold
+      // HBM lines that are needed only behind the attention
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const float* xp = a.x + mrow[mi] * D + 64 * f + ncol;
+          const unsigned dst = __builtin_amdgcn_readfirstlane(TILE_OFF + ((mi * 4 + f) * NT + wave * 64) * 16);
+          unsigned keep;
+          asm volatile(
+              "s_mov_b32 %0, m0\n\t"
+              "s_mov_b32 m0, %2\n\t"
+              "s_nop 0\n\t"
+              "global_load_lds_dwordx4 %1, off\n\t"
+              "s_mov_b32 m0, %0"
+              : "=&s"(keep)
+              : "v"(xp), "s"(dst)
+              : "memory");
+        }
       const int Tp = a.Tpad;
       const size_t bh = (size_t)b * 4 + hh;
       GU8 qb = (GU8)a.qh + (bh * Tp + t0) * 128;
@@ -775,33 +798,35 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       GU8 kb = (GU8)a.kh + bh * Tp * 128 + lane * 16;
       GU8 vb = (GU8)a.vt + bh * 64 * (size_t)Tp * 2 + lane * 16;
       const int npg = a.ldp;  // position fragments per head
-      GU8 ppb = (GU8)a.pos + (size_t)hh * npg * 2048 + lane * 16;
       const int g_q = 2 * (int)gridDim.x - (t0 >> 4);  // first position fragment of this query block at key tile 0
+      GU8 ppb = (GU8)a.pos + ((size_t)hh * npg + g_q) * 2048 + lane * 16;
       struct KP {
-        bf16x8 k[4][2], p[6][2];
+        bf16x8 k[8], p[12];  // k[2 n + ks], p[2 pn + ks]
       };
       struct VV {
-        bf16x8 v[4][2];
+        bf16x8 v[8];         // v[2 f + jp]
       };
-      const int ntile = (klen + 63) >> 6;
-      // every request is unconditional (a tile past the end repeats the last one), so that hipcc counts its waits exactly
-      auto load_tile = [&](int jt, KP& kp, VV& vv) __attribute__((always_inline)) {
-        jt = jt < ntile ? jt : ntile - 1;
+      // ONE set of operand registers (K + position rows 80, V^T 32), refilled the moment its MFMAs are issued: K and the
+      // position rows of tile t + 1 are requested behind the score MFMAs of tile t and travel under its rel-shift, softmax
+      // and P . V; V^T of tile t + 1 is requested behind P . V of tile t and travels under the scores and softmax of t + 1.
+      // (Second version.  The first kept two whole tiles in flight - 224 operand registers next to the ~190 the two
+      // query fragments' softmax needs: at the 256-VGPR line hipcc turned every skewed scratch read of the rel-shift
+      // into "read, wait, add" through the same two registers, 16 dependent LDS round trips per fragment and tile:
+      // 4.1 K cycles per tile for 0.9 K of MFMA, profiles/r06b_block_stamps.txt.  Requests written as inline asm with AGPR
+      // destinations and hand-counted waits tied to their registers cost ~200 accumulator-register copies per tile.)
+      // Every request is unconditional (a tile past the end repeats the last one), so that hipcc counts its waits exactly.
+      auto load_kp = [&](int jt, KP& kp) __attribute__((always_inline)) {
         GU8 rk = kb + (size_t)jt * 8192;
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int i = 0; i < 8; ++i) kp.k[i] = *(GFRAG)(rk + i * 1024);
+        GU8 rp = ppb + (size_t)jt * 8192;
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) kp.k[n][ks] = *(GFRAG)(rk + n * 2048 + ks * 1024);
-        GU8 rp = ppb + (size_t)(g_q + 4 * jt) * 2048;
-#pragma unroll
-        for (int pn = 0; pn < 6; ++pn)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) kp.p[pn][ks] = *(GFRAG)(rp + pn * 2048 + ks * 1024);
+        for (int i = 0; i < 12; ++i) kp.p[i] = *(GFRAG)(rp + i * 1024);
+      };
+      auto load_v = [&](int jt, VV& vv) __attribute__((always_inline)) {
         GU8 rv = vb + (size_t)jt * 8192;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int jp = 0; jp < 2; ++jp) vv.v[f][jp] = *(GFRAG)(rv + f * 2048 + jp * 1024);
+        for (int i = 0; i < 8; ++i) vv.v[i] = *(GFRAG)(rv + i * 1024);
       };
       // the queries (B operand: column = query 16 mi + lr, k-slice lg) and the two position biases
       bf16x8 qraw[2][2];
@@ -817,10 +842,18 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           ur[ks][h2] = *(GF4)(a.pos_u + hh * 64 + ks * 32 + lg * 8 + h2 * 4);
           vr[ks][h2] = *(GF4)(a.pos_v + hh * 64 + ks * 32 + lg * 8 + h2 * 4);
         }
-      KP kpA, kpB;
-      VV vvA, vvB;
-      load_tile(0, kpA, vvA);
+      KP kp;
+      VV vv;
+      load_kp(0, kp);
+      load_v(0, vv);
       touch();  // the C part's weights into this XCD's L2 while the attention runs
+      int klen;
+      {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(klen_raw) : : "memory");
+        klen = klen_raw < T ? klen_raw : T;
+        klen = klen > 0 ? klen : 1;
+      }
+      const int ntile = (klen + 63) >> 6, nfull = klen >> 6;
       bf16x8 qu[2][2], qv[2][2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -845,8 +878,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
       constexpr float LOG2E = 1.4426950408889634f;
       float* const bdw = (float*)(smem + XCH_OFF) + wave * (2 * 16 * LDB);
-      auto tile = [&](int jt, const KP& kp, const VV& vv) __attribute__((always_inline)) {
-        const int j0 = jt * 64;  // (a tile past the end - odd tile counts - is masked as a whole)
+      // one 64-key tile; MASK: the tile holds the utterance's end (or lies past it: odd tile counts) - two instantiations,
+      // chosen by a uniform branch AROUND the tile, so that each is one scheduling region
+      const int last = ((klen + 63) >> 6) - 1;
+      auto tile = [&](int jt, auto maskc) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(maskc)::value;
+        const int j0 = jt * 64;
+        const int jn = jt < last ? jt + 1 : last;  // the tile whose operands are requested from inside this one
         f32x4 sc[2][4], dd[2][5];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -857,17 +895,20 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) sc[mi][n] = MM::mma(kp.k[n][ks], qu[mi][ks], sc[mi][n]);
           // window row cw = 31 - 16 mi - li + jl: queries 0 .. 15 reach position fragments 1 .. 5, queries 16 .. 31 fragments 0 .. 4
 #pragma unroll
           for (int pn = 0; pn < 6; ++pn) {
-            if (pn >= 1) dd[0][pn - 1] = MM::mma(kp.p[pn][ks], qv[0][ks], dd[0][pn - 1]);
-            if (pn <= 4) dd[1][pn] = MM::mma(kp.p[pn][ks], qv[1][ks], dd[1][pn]);
+            if (pn >= 1) dd[0][pn - 1] = MM::mma(kp.p[2 * pn + ks], qv[0][ks], dd[0][pn - 1]);
+            if (pn <= 4) dd[1][pn] = MM::mma(kp.p[2 * pn + ks], qv[1][ks], dd[1][pn]);
           }
         }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) sc[mi][n] = MM::mma(kp.k[2 * n + ks], qu[mi][ks], sc[mi][n]);
+        load_kp(jn, kp);  // (the registers are free: their MFMAs have been issued)
         // rel_shift: D[c][i] -> scratch[i][c], read back at c = 15 - i + (key of the tile)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -883,12 +924,12 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc[mi][n][r] += bdr[32 * (n >> 1) + 4 * (n & 1) + r];
-          if (j0 + 64 > klen) {  // (uniform: only the tile that holds the utterance's end masks anything)
+          if constexpr (MASK) {
+            const int kl = klen - j0 - 8 * lg;  // this lane's keys of the tile are 32 (n >> 1) + 4 (n & 1) + r < kl
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                sc[mi][n][r] = (j0 + 32 * (n >> 1) + 8 * lg + 4 * (n & 1) + r < klen) ? sc[mi][n][r] : -INFINITY;
+              for (int r = 0; r < 4; ++r) sc[mi][n][r] = (32 * (n >> 1) + 4 * (n & 1) + r < kl) ? sc[mi][n][r] : -INFINITY;
           }
           float tm = -INFINITY;
 #pragma unroll
@@ -928,24 +969,29 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           for (int mi = 0; mi < 2; ++mi) {
             acc_l[mi] = MM::mma(ones, pb[mi][jp], acc_l[mi]);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc_o[mi][f] = MM::mma(vv.v[f][jp], pb[mi][jp], acc_o[mi][f]);
+            for (int f = 0; f < 4; ++f) acc_o[mi][f] = MM::mma(vv.v[2 * f + jp], pb[mi][jp], acc_o[mi][f]);
           }
+        load_v(jn, vv);
       };
       stamp(60);
-      const int npair = (ntile + 1) >> 1;
 #pragma unroll 1
-      for (int it = 0; it < npair; ++it) {
-        load_tile(2 * it + 1, kpB, vvB);
-        tile(2 * it, kpA, vvA);
-        load_tile(2 * it + 2, kpA, vvA);
-        tile(2 * it + 1, kpB, vvB);
+      for (int jt = 0; jt < ntile; ++jt) {
+        if (jt < nfull) tile(jt, std::false_type{});
+        else tile(jt, std::true_type{});
       }
       stamp(61);
-      // the residual rows and linear_out's first units travel while the context is normalised and handed over
-      load_x();
+      // linear_out's first units travel while the context is normalised and handed over; the residual rows come out of
+      // their parking place
       read_unit(a.wout, 0, ring[0]);
       read_unit(a.wout, 1, ring[1]);
       read_unit(a.wout, 2, ring[2]);
+      {
+        const float4* const xp = (const float4*)(smem + TILE_OFF) + tid;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) xr[mi][f] = xp[(mi * 4 + f) * NT];
+      }
       // ctx[frame 16 mi + lr][64 hh + 16 f + 4 lg + r] -> bf16 -> k-tile hh of the LDS tile linear_out's activation fragments
       // are read from (the same rounding point as the ctx buffer of the two-launch form)
 #pragma unroll
