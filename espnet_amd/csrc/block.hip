@@ -768,25 +768,29 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       const int hh = wave;  // head
       int klen_raw;
       asm volatile("s_load_dword %0, %1, 0x0" : "=s"(klen_raw) : "s"(a.klens + b) : "memory");  // (waited for below)
-      // the residual rows go to their LDS parking place (lane-major, where an FFN parks them) by LDS-DMA, first of all: cold
-      // HBM lines that are needed only behind the attention
+      // The residual rows go to their LDS parking place (lane-major, where an FFN parks them) by LDS-DMA - requested from
+      // inside the LAST key tile, behind its score MFMAs: cold HBM lines (8 MB over the chip) that are needed only behind the
+      // attention.  Requested at kernel entry (second version) they were part of the burst every workgroup opens with - 15 MB
+      // that have to cross the fabric before the first MFMA: the prologue took 7.5 K cycles (profiles/r06c_block_stamps.txt).
+      auto park_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          const float* xp = a.x + mrow[mi] * D + 64 * f + ncol;
-          const unsigned dst = __builtin_amdgcn_readfirstlane(TILE_OFF + ((mi * 4 + f) * NT + wave * 64) * 16);
-          unsigned keep;
-          asm volatile(
-              "s_mov_b32 %0, m0\n\t"
-              "s_mov_b32 m0, %2\n\t"
-              "s_nop 0\n\t"
-              "global_load_lds_dwordx4 %1, off\n\t"
-              "s_mov_b32 m0, %0"
-              : "=&s"(keep)
-              : "v"(xp), "s"(dst)
-              : "memory");
-        }
+          for (int f = 0; f < 4; ++f) {
+            const float* xp = a.x + mrow[mi] * D + 64 * f + ncol;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(TILE_OFF + ((mi * 4 + f) * NT + wave * 64) * 16);
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(xp), "s"(dst)
+                : "memory");
+          }
+      };
       const int Tp = a.Tpad;
       const size_t bh = (size_t)b * 4 + hh;
       GU8 qb = (GU8)a.qh + (bh * Tp + t0) * 128;
@@ -795,11 +799,13 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       // reads bytes [16 l, 16 l + 16).  A first version read them "as they lie" row-major - lane (lr, lg) 16 bytes of row lr:
       // 16 rows per wave-wide load, no two neighbouring lanes in the same line - and ran at the ~13 B/clk per CU of
       // uncoalesced requests: 27.6 us per launch against 23.6 for the two launches it replaces (profiles/r06a_*).
-      GU8 kb = (GU8)a.kh + bh * Tp * 128 + lane * 16;
-      GU8 vb = (GU8)a.vt + bh * 64 * (size_t)Tp * 2 + lane * 16;
+      // (wave-uniform bases in scalar registers + ONE 32-bit lane offset)
+      const unsigned lo16 = lane * 16;
+      GU8 kb = (GU8)em_uniform_ptr((const unsigned char*)a.kh + bh * Tp * 128);
+      GU8 vb = (GU8)em_uniform_ptr((const unsigned char*)a.vt + bh * 64 * (size_t)Tp * 2);
       const int npg = a.ldp;  // position fragments per head
       const int g_q = 2 * (int)gridDim.x - (t0 >> 4);  // first position fragment of this query block at key tile 0
-      GU8 ppb = (GU8)a.pos + ((size_t)hh * npg + g_q) * 2048 + lane * 16;
+      GU8 ppb = (GU8)em_uniform_ptr((const unsigned char*)a.pos + ((size_t)hh * npg + g_q) * 2048);
       struct KP {
         bf16x8 k[8], p[12];  // k[2 n + ks], p[2 pn + ks]
       };
@@ -818,15 +824,15 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       auto load_kp = [&](int jt, KP& kp) __attribute__((always_inline)) {
         GU8 rk = kb + (size_t)jt * 8192;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kp.k[i] = *(GFRAG)(rk + i * 1024);
+        for (int i = 0; i < 8; ++i) kp.k[i] = *(GFRAG)(rk + i * 1024 + lo16);
         GU8 rp = ppb + (size_t)jt * 8192;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) kp.p[i] = *(GFRAG)(rp + i * 1024);
+        for (int i = 0; i < 12; ++i) kp.p[i] = *(GFRAG)(rp + i * 1024 + lo16);
       };
       auto load_v = [&](int jt, VV& vv) __attribute__((always_inline)) {
         GU8 rv = vb + (size_t)jt * 8192;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) vv.v[i] = *(GFRAG)(rv + i * 1024);
+        for (int i = 0; i < 8; ++i) vv.v[i] = *(GFRAG)(rv + i * 1024 + lo16);
       };
       // the queries (B operand: column = query 16 mi + lr, k-slice lg) and the two position biases
       bf16x8 qraw[2][2];
@@ -909,6 +915,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) sc[mi][n] = MM::mma(kp.k[2 * n + ks], qu[mi][ks], sc[mi][n]);
         load_kp(jn, kp);  // (the registers are free: their MFMAs have been issued)
+        if (jt == last) park_x();
         // rel_shift: D[c][i] -> scratch[i][c], read back at c = 15 - i + (key of the tile)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -985,6 +992,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       read_unit(a.wout, 0, ring[0]);
       read_unit(a.wout, 1, ring[1]);
       read_unit(a.wout, 2, ring[2]);
+      // the residual rows' DMA (requested inside the last tile, not known to hipcc's counting) has landed once at most the 24
+      // requests just made are outstanding
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       {
         const float4* const xp = (const float4*)(smem + TILE_OFF) + tid;
 #pragma unroll
