@@ -573,11 +573,22 @@ class ConformerEncoder(torch.nn.Module):
             pos = pos.contiguous()
             rows, d = pos.shape
             n = self.num_blocks * d
-            out = torch.empty(rows, n, dtype=self.act_dtype, device=device)
+            # the fused 256-wide bf16 path also wants the rows fragment-major (block<ATT|C>): packed here, once per length,
+            # behind the table (EM_ENC_POS_PACKED)
+            packed = (self.em_dtype == L.EM_BF16 and d == 256 and rows == 2 * T - 1 and not getattr(pk["w"], "legacy_relpos", 0))
+            es = 2 if self.em_dtype == L.EM_BF16 else 4
+            tbytes = (rows * n * es + 255) // 256 * 256
+            npg = L.load().em_relpos_pos_fragments(T) if packed else 0
+            flat = torch.empty(tbytes + self.num_blocks * 4 * npg * 2048, dtype=torch.uint8, device=device)
+            out = flat[:rows * n * es].view(self.act_dtype).view(rows, n)
+            out._em_flat, out._em_packed = flat, packed  # (keeps the block alive; read back in forward_device)
             args = L.EmGemmArgs(A=pos.data_ptr(), W=pk["w"].wpos_all, C=out.data_ptr(), bias=None, M=rows, N=n, K=d,
                                 lda=d, ldc=n, scale=1.0)
             L.check(L.load().em_gemm(self.em_dtype, L.EM_EPI_STORE, L.EM_A_PLAIN, C.byref(args),
                                      L.current_stream_ptr()), "em_gemm(linear_pos)")
+            if packed:
+                L.check(L.load().em_relpos_pack_pos_bf16(out.data_ptr(), n, T, self.num_blocks, flat.data_ptr() + tbytes,
+                                                         L.current_stream_ptr()), "em_relpos_pack_pos_bf16")
             ev = torch.cuda.Event()
             ev.record(cur)
             with lock:
@@ -686,7 +697,7 @@ class ConformerEncoder(torch.nn.Module):
         if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "wpos_all", None):
             # linear_pos of every block depends on T and the weights only: projected once per length, handed over ready
             pos = self._pos_projected(T, dev, pk, pos)
-            enc_flags |= L.EM_ENC_POS_PROJECTED
+            enc_flags |= L.EM_ENC_POS_PROJECTED | (L.EM_ENC_POS_PACKED if getattr(pos, "_em_packed", False) else 0)
         with _ENC_CALL_LOCK:
             if hasattr(pk["w"], "ctc_ids"):
                 pk["w"].ctc_ids = None

@@ -219,7 +219,10 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     void* ppk = ws + s.ppk;
     const int npg = em_relpos_pos_fragments(T);
     if (att_c) {
-      EM_TRY(em_relpos_pack_pos_bf16(pall, L * d, T, L, ppk, stream));
+      if ((flags & EM_ENC_POS_PROJECTED) && (flags & EM_ENC_POS_PACKED))  // the caller packed them once for this length
+        ppk = (unsigned char*)const_cast<void*>(pos_emb) + align_up((size_t)(2 * T - 1) * L * d * es);
+      else
+        EM_TRY(em_relpos_pack_pos_bf16(pall, L * d, T, L, ppk, stream));
       ba.kv_frag = 1;  // the A parts write K and V^T in the order the attention's MFMAs take them
     }
     set_a(ly[0]);
@@ -251,6 +254,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
                                          q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
       }
       if (att_c) {
+        // (done above)
       } else if (no_fold) {
         ba.params = q.fp_c;
         EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));

@@ -25,6 +25,7 @@ EM_ENC_NO_FUSED = 2
 EM_ENC_POS_PROJECTED = 4
 EM_ENC_FOLD_C = 8
 EM_ENC_SPLIT_ATT = 16
+EM_ENC_POS_PACKED = 32
 EM_ENC_PLAN_FUSED, EM_ENC_PLAN_CTC_IDS = 1, 2
 EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC, EM_BLOCK_RELU, EM_BLOCK_ATT = 1, 2, 4, 8, 16, 32, 64
 EM_BLOCK_PARAM_GROUP = 1792

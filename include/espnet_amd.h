@@ -306,6 +306,9 @@ typedef struct EmConformerWeights {
                                * per Conformer block instead of three; measured no faster at B = 32, DESIGN.md: opt-in) */
 #define EM_ENC_SPLIT_ATT 16    /* fused path: attention and the C part of a block as TWO launches (em_relpos_attention2_bf16 + block<C>,
                                * rounds 2-5) instead of the one launch block<ATT|C> of round 6: developer A/B switch */
+#define EM_ENC_POS_PACKED 32   /* with EM_ENC_POS_PROJECTED (bf16, d = 256): behind the projected table, at the next multiple of 256
+                               * bytes, pos_emb ALSO holds em_relpos_pack_pos_bf16's output for (T, the num_blocks blocks) - what
+                               * block<ATT|C> reads; without the flag the encoder packs it per call (~5 us at T = 249) */
 #define EM_ENC_POS_PROJECTED 4 /* pos_emb is ALREADY linear_pos of every block: [2T-1 (legacy: T)][L*d] act, i.e. pos_emb x wpos_all^T
                                * (it depends on T and the weights only: a caller decoding many batches of one length projects once) */
 
