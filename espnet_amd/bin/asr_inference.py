@@ -389,7 +389,9 @@ def sharded_decode_rank(decode_claimed, keys, output_dir, nbest: int, max_len: i
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     shard_dir = Path(output_dir) / f"output.{rank + 1}"
-    claim = D.WindowClaimer(D.SharedCounter(D.work_store() if world > 1 else None, D.call_key("asr_inference_windows")))
+    work = D.work_store() if world > 1 else None
+    win_key = D.call_key("asr_inference_windows", work, world)
+    claim = D.WindowClaimer(D.SharedCounter(work, win_key))
     # rows of an earlier run into the same output_dir must not be taken for this rank's (the writer opens its files
     # lazily: a rank that claims no window would never truncate them)
     if shard_dir.is_dir():
@@ -417,6 +419,7 @@ def sharded_decode_rank(decode_claimed, keys, output_dir, nbest: int, max_len: i
     if failed:
         raise RuntimeError(f"rank {rank}: another rank failed before the hypothesis collation; nothing was gathered")
     hyps = D.unpack_indexed_records(D.gather_variable_records(rec), len(keys))
+    D.release_key(work, win_key, rank)  # (behind the collation: every rank is past its last claim)
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:

@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 
 namespace {
 
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
   // "+v" ties keep the values in the registers the loads write - with the wait in two branches (a first version of the
   // two-tiles-ahead staging) hipcc merged the branches through register copies placed IN FRONT of the waits, i.e. copies of
   // registers whose loads were still in flight (NaNs in test_relpos_attention2[49]).
+  // (5 = tile 0's requests of this wave: K, three position pieces, V^T - see stage_tile)
   asm volatile("s_waitcnt vmcnt(5)"
                : "+v"(qraw[0]), "+v"(qraw[1]), "+v"(ur[0]), "+v"(ur[1]), "+v"(ur[2]), "+v"(ur[3]), "+v"(vr[0]),
                  "+v"(vr[1]), "+v"(vr[2]), "+v"(vr[3])
@@ -290,8 +292,13 @@ __global__ __launch_bounds__(512) void relpos_attn2_kernel(
   // chain and the wait in front of tile kt + 1's products counts them out (`vmcnt(3)`: a later tile is three requests per
   // wave - K, position rows, V^T - and requests complete in order).
   auto exists = [&](int js, int t) { return t < KSUP / 64 && js + 64 * t < klen; };
+  // (The counts are exact only while nothing else of this wave is in the memory pipeline between a tile's requests and
+  // its wait: stores count in vmcnt on gfx9, so the developer stamps - one store each - would let a wait pass before its
+  // tile has landed.  With stamps on, wait for everything: timing of a diagnostic build, never a race.  ADVICE r05;
+  // tools/isa_waits.py checks the product build for stray VMEM instructions between the staging asm and the waits.)
+  constexpr int TILE_REQS = 3;  // K rows, position rows, V^T rows: one request per wave each for a tile after the first
   auto wait_but_newest_tile = [&](bool newer) __attribute__((always_inline)) {
-    if (newer) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (newer && !stamps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TILE_REQS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   for (int js = 0; js < klen; js += KSUP) {
@@ -357,7 +364,7 @@ extern "C" int em_relpos_attention2_bf16(const void* qh, const void* kh, const v
   if (em_raise_lds_cap((const void*)relpos_attn2_kernel, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
   dim3 grid(em_cdiv(T, QB), h, B);
   static long long* stamps = nullptr;
-  static const bool want_stamps = getenv("EM_ATTN2_STAMPS") != nullptr;
+  const bool want_stamps = em_sw().attn2_stamps;
   if (want_stamps && !stamps && hipMalloc((void**)&stamps, 32 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
   if (want_stamps && hipMemsetAsync(stamps, 0, 32 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);

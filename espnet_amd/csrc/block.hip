@@ -53,6 +53,7 @@
 #include <type_traits>
 
 #include "em_common.h"
+#include "switches.h"
 
 namespace {
 
@@ -914,14 +915,16 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) sc[mi][n] = MM::mma(kp.k[2 * n + ks], qu[mi][ks], sc[mi][n]);
-        load_kp(jn, kp);  // (the registers are free: their MFMAs have been issued)
+        if constexpr (!(EM_BLOCK_VAR & 512)) load_kp(jn, kp);  // (the registers are free: their MFMAs have been issued)
         if (jt == last) park_x();
         // rel_shift: D[c][i] -> scratch[i][c], read back at c = 15 - i + (key of the tile)
+        if constexpr (!(EM_BLOCK_VAR & 256)) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int n = 0; n < 5; ++n)
             *(float4*)(bdw + (mi * 16 + lr) * LDB + 16 * n + 4 * lg) = make_float4(dd[mi][n][0], dd[mi][n][1], dd[mi][n][2], dd[mi][n][3]);
+        }
         bf16x8 pb[2][2];
         float alpha[2];
 #pragma unroll
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll
           for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[mi][n][r] += bdr[32 * (n >> 1) + 4 * (n & 1) + r];
+            for (int r = 0; r < 4; ++r) sc[mi][n][r] += (EM_BLOCK_VAR & 256) ? dd[mi][n][r] : bdr[32 * (n >> 1) + 4 * (n & 1) + r];
           if constexpr (MASK) {
             const int kl = klen - j0 - 8 * lg;  // this lane's keys of the tile are 32 (n >> 1) + 4 (n & 1) + r < kl
 #pragma unroll
@@ -954,8 +957,11 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
           for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[mi][n][2 * h], LOG2E, -mnl));
-              const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[mi][n][2 * h + 1], LOG2E, -mnl));
+              // (developer timing builds, wrong results: EM_BLOCK_VAR & 128 no exponentials, & 256 no rel-shift scratch round
+              // trip, & 512 the operand requests of tile 0 only)
+              const float a0 = __builtin_fmaf(sc[mi][n][2 * h], LOG2E, -mnl), a1 = __builtin_fmaf(sc[mi][n][2 * h + 1], LOG2E, -mnl);
+              const float e0 = (EM_BLOCK_VAR & 128) ? a0 : __builtin_amdgcn_exp2f(a0);
+              const float e1 = (EM_BLOCK_VAR & 128) ? a1 : __builtin_amdgcn_exp2f(a1);
               pbu[n >> 1][(n & 1) * 2 + h] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
             }
 #pragma unroll
@@ -978,7 +984,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc_o[mi][f] = MM::mma(vv.v[2 * f + jp], pb[mi][jp], acc_o[mi][f]);
           }
-        load_v(jn, vv);
+        if constexpr (!(EM_BLOCK_VAR & 512)) load_v(jn, vv);
       };
       stamp(60);
 #pragma unroll 1
@@ -1672,7 +1678,7 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
   if (em_raise_lds_cap((const void*)block_kernel<MODE, KWT, RELU>, SMEM_BYTES, &cap) != EM_OK) return EM_ERR_LAUNCH;
   // helper workgroups for launches smaller than the chip (see the kernel: L2 warm-up shares); ESPNET_AMD_BLOCK_NO_HELPERS:
   // developer A/B switch
-  static const bool no_helpers = getenv("ESPNET_AMD_BLOCK_NO_HELPERS") != nullptr;
+  const bool no_helpers = em_sw().block_no_helpers;
   static int ncu_of[64];  // compute units per device (asked once: no runtime call on later launches, legal under stream capture)
   const int gx = em_cdiv(a->T, BM);
   int helper_rows = 0;
@@ -1690,7 +1696,7 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
   }
   dim3 grid(gx, a->B + helper_rows);
   static long long* stamps = nullptr;
-  static const bool want_stamps = getenv("EM_BLOCK_STAMPS") != nullptr;
+  const bool want_stamps = em_sw().block_stamps;
   if (want_stamps && !stamps) hipMalloc((void**)&stamps, 256 * sizeof(long long));
   if (want_stamps) hipMemsetAsync(stamps, 0, 256 * sizeof(long long), s);
   hipLaunchKernelGGL((block_kernel<MODE, KWT, RELU>), grid, dim3(NT), SMEM_BYTES, s, *a, stamps);

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 
 namespace {
 
@@ -859,7 +860,7 @@ int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const 
                      const int* tok_tab, void* ctx, hipStream_t s) {
   const int dk = d / heads;
   // waves per row: batches of 64 positions run in parallel instead of in sequence once a prefix is longer than that
-  static const int fsplit = [] { const char* e = getenv("ESPNET_AMD_SA_SPLIT"); return e ? atoi(e) : 0; }();
+  const int fsplit = em_sw().sa_split;
   // (only while the launch is small: at 640 rows x 8 heads the second wave per row costs more than the shorter chains
   // give back - 0.704 -> 0.769 ms per label step, profiles/r03af - and the rows themselves fill the chip)
   const int SA_SPLIT = fsplit > 0 ? (fsplit > 8 ? 8 : fsplit) : (heads * n <= 2048 ? 2 : 1);  // (two: 0.369 -> 0.358 ms per label step; four 0.363, eight 0.392 - every wave has its fixed cost; profiles/r03x)
@@ -872,7 +873,7 @@ int self_attn_launch(const void* qkv, void* kc, void* vc, const int* anc, const 
   // Rows of a beam on one CU share their ancestors' cache rows in its L1, but three quarters of the chip idle with
   // 160 rows x 4 heads in 64 workgroups: fewer rows per workgroup until the grid covers the CUs (the L2 still serves
   // the shared rows once).  ESPNET_AMD_SA_GROUP: developer A/B.
-  static const int forced = [] { const char* e = getenv("ESPNET_AMD_SA_GROUP"); return e ? atoi(e) : 0; }();
+  const int forced = em_sw().sa_group;
   if (forced > 0) group = forced < group ? forced : group;
   else while (group > 1 && heads * em_cdiv(n, group) < 512) --group;
   if ((size_t)(group * Lmax + SA_MERGE_FLOATS) * sizeof(int) > 64 * 1024) return EM_ERR_UNSUPPORTED;
@@ -946,7 +947,7 @@ int src_attn_launch(const void* qs, const void* kmem, int ldk, const void* vT, c
 // per-row kernel).  ESPNET_AMD_NO_SA_TREE=1: developer A/B switch.
 int em_dec_self_attention_tree_bf16(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n, int d,
                                     int heads, int Lmax, int pos, const int* pos_dev, int W, void* ctx, void* stream) {
-  static const bool off = getenv("ESPNET_AMD_NO_SA_TREE") != nullptr;
+  const bool off = em_sw().no_sa_tree;
   if (off || heads <= 0 || d != 64 * heads || W < 1 || W > 16 || n % W != 0 || n > 65535 || Lmax > TREE_LMAX || pos < 0 ||
       pos >= Lmax)
     return EM_ERR_UNSUPPORTED;
@@ -954,8 +955,7 @@ int em_dec_self_attention_tree_bf16(const void* qkv, void* kc, void* vc, const i
   // rounds of the chip - configs[3] per GPU (640 rows): 0.620 -> 0.593 ms per label step; 480 / 320 / 240 rows: 0.578 -> 0.557,
   // 0.499 -> 0.492, 0.417 -> 0.410; configs[2] (160 rows): 0.352 -> 0.367, the per-row kernel stays (profiles/
   // r05n_tree_self_attention_ab.txt, r05l_label_step_dispatch_sweep.txt).  ESPNET_AMD_SA_TREE_MIN_ROWS: developer switch.
-  const char* const mr = getenv("ESPNET_AMD_SA_TREE_MIN_ROWS");  // (read per call: the kernel tests lower it in-process)
-  const int min_rows = mr ? atoi(mr) : 200;
+  const int min_rows = em_sw().sa_tree_min_rows;  // (the kernel tests lower it in-process: em_dev_switches_reload)
   if (n < min_rows) return EM_ERR_UNSUPPORTED;
   if ((size_t)Lmax * n * d * 2 >= ((size_t)1 << 31)) return EM_ERR_UNSUPPORTED;  // (buffer offsets are 32-bit)
   const size_t lds = tree_lds_bytes(W, Lmax);

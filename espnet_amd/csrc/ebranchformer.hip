@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 #include "subsample.h"
 
 namespace {
@@ -223,7 +224,7 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   const bool ffn = w->use_ffn != 0;
   // round 4: bf16 with d_k = 64 -> the LDS-resident attention, its operands written per head by the projection GEMMs
   // (see encoder.hip; ESPNET_AMD_NO_ATTN2_LARGE=1: developer A/B switch)
-  static const bool no_attn2 = getenv("ESPNET_AMD_NO_ATTN2_LARGE") != nullptr;
+  const bool no_attn2 = em_sw().no_attn2_large;
   const bool attn2 = dtype == EM_BF16 && !w->legacy_relpos && !no_attn2 && !(flags & EM_ENC_NO_FUSED) && d == 64 * h &&
                      (size_t)B * d * s.Tpad * 4 < ((size_t)1 << 32) - 64;
   void* qh = ws + s.qh;

@@ -185,6 +185,7 @@ bool em_prof_begin(void* stream);
 void em_prof_end(void* stream, double flops, int tag);
 
 // csrc/decoder.hip: self-attention over the union of a beam's ancestors (bf16, d_k = 64, W <= 16 consecutive rows per
-// utterance, Lmax <= 256); EM_ERR_UNSUPPORTED for other shapes (the caller keeps em_dec_self_attention)
+// utterance, Lmax <= 512 with the key list inside 64 KiB of LDS); EM_ERR_UNSUPPORTED for other shapes (the caller keeps
+// em_dec_self_attention)
 int em_dec_self_attention_tree_bf16(const void* qkv, void* kc, void* vc, const int* anc, const int* anc_odd, int n, int d,
                                     int heads, int Lmax, int pos, const int* pos_dev, int W, void* ctx, void* stream);

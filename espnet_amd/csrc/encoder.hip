@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 #include "subsample.h"
 
 namespace {
@@ -76,7 +77,7 @@ struct RowsPlan {
 };
 inline RowsPlan rows_plan(int dtype, const EmConformerWeights* w, int flags, long M) {
   RowsPlan r = {false, false, false, false};
-  static const bool no_ffn_rows = getenv("ESPNET_AMD_NO_FFN_ROWS") != nullptr;
+  const bool no_ffn_rows = em_sw().no_ffn_rows;
   const int d = w->d, ff = w->ff, L = w->num_blocks;
   const EmConformerLayer* ly = w->layers;
   if (!(dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) && !no_ffn_rows && ly && L > 0 &&
@@ -106,7 +107,7 @@ inline RowsPlan rows_plan(int dtype, const EmConformerWeights* w, int flags, lon
   r.glu = r.ffn;
   for (int l = 0; r.glu && l < L; ++l) r.glu = ly[l].woutp && ly[l].pw1f && ly[l].fp_c;
   // ... and the CTC head's arg-max is a walk behind the last launch (ctc_w: ctc_lo.weight in 128-row chunks, w1p layout)
-  static const bool no_rows_ctc = getenv("ESPNET_AMD_NO_ROWS_CTC") != nullptr;  // developer A/B switch
+  const bool no_rows_ctc = em_sw().no_rows_ctc;  // developer A/B switch
   r.ctc = r.ffn && !no_rows_ctc && w->ctc_ids && w->ctc_w && w->ctc_b && w->ctc_units > 0;
   return r;
 }
@@ -286,7 +287,7 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   // 90 us per block at B = 64): its per-head operands are written by the projection GEMMs themselves - q | k through
   // EM_EPI_QK_HEADS, V^T as the swapped product W_v . xn^T through EM_EPI_VT_HEADS - so there is no repacking pass.
   // ESPNET_AMD_NO_ATTN2_LARGE=1: developer A/B switch.
-  static const bool no_attn2 = getenv("ESPNET_AMD_NO_ATTN2_LARGE") != nullptr;
+  const bool no_attn2 = em_sw().no_attn2_large;
   const bool attn2 = dtype == EM_BF16 && !w->legacy_relpos && !(flags & EM_ENC_NO_FUSED) && !no_attn2 && d == 64 * h &&
                      (size_t)B * d * s.Tpad * 4 < ((size_t)1 << 32) - 64;
   void* qh = ws + s.qh;

@@ -47,6 +47,7 @@
 #include <type_traits>
 
 #include "em_common.h"
+#include "switches.h"
 
 #ifndef EM_FFN_DBG
 #define EM_FFN_DBG 0  // developer builds (tools/build_block_variants.sh ffn<d>; timing only, results wrong by design unless 8):
@@ -657,7 +658,7 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   if (!glu && a->ln_mode == 2 && (!a->g2 || !a->be2)) return EM_ERR_BAD_ARG;
   const dim3 grid(em_cdiv(a->M, RB));
   static long long* stamps = nullptr;
-  static const bool want_stamps = (EM_FFN_DBG & 8) && getenv("EM_FFN_STAMPS") != nullptr;
+  const bool want_stamps = (EM_FFN_DBG & 8) && em_sw().ffn_stamps;
   if (want_stamps && !stamps && hipMalloc((void**)&stamps, 64 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
   if (want_stamps && hipMemsetAsync(stamps, 0, 64 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   long long* const st = want_stamps ? stamps : nullptr;

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 
 __device__ const float2 EM_TW512[384] = {
 #include "twiddle512.inc"
@@ -355,7 +356,7 @@ extern "C" int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, in
   if (N <= 256 || hop <= 0 || T_f != 1 + N / hop) return EM_ERR_BAD_ARG;
   if (mel_maxlen < 1 || mel_maxlen > 257 || n_mels < 1) return EM_ERR_BAD_ARG;
   // ESPNET_AMD_FRONTEND_V1=1: developer A/B switch (one frame per wave, the kernel of rounds 1-4)
-  const bool v1 = getenv("ESPNET_AMD_FRONTEND_V1") != nullptr;  // (read per call: the equality test toggles it in-process)
+  const bool v1 = em_sw().frontend_v1;  // (the equality test toggles it in-process: em_dev_switches_reload)
   constexpr int FR = 8;
   if (!v1 && mel_maxlen <= 32 && n_mels <= 80) {
     dim3 grid(em_cdiv(T_f, 4 * FR), B);

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "em_common.h"
+#include "switches.h"
 
 struct EmProfile {
   int capacity, count;
@@ -533,7 +534,7 @@ int launch(const EmGemmArgs* p, hipStream_t s) {
   // projections) and larger grids keep two stages and two or three co-resident workgroups per CU, which cover each
   // other's waits and cost no three-tile prologue: four stages are 25-50 % slower there.  ESPNET_AMD_GEMM_STAGES = 2 | 4:
   // developer A/B.
-  static const int forced = [] { const char* e = getenv("ESPNET_AMD_GEMM_STAGES"); return e ? atoi(e) : 0; }();
+  const int forced = em_sw().gemm_stages;
   const long wgs = (long)nb * em_cdiv(p->M, small ? 64 : 128);
   // (round 4: K >= 4096, was 2048 - the large model's second FFN matrix, K = 2048 on 500 workgroups, runs 65.6 us with
   // four stages and ~40 with two: the whole B = 64 encoder step 8.24 -> 7.64 ms, profiles/r04b_gemm_stages_large_b64.txt)
@@ -611,7 +612,7 @@ extern "C" int em_gemm(int dtype, int epilogue, int a_mode, const EmGemmArgs* p,
   }
   const bool rec = em_prof_begin(stream);
   int rc = EM_ERR_UNSUPPORTED;
-  static const bool no_mid = getenv("ESPNET_AMD_NO_MID_GEMM") != nullptr;  // developer A/B switch (tools/gemm_bench.py)
+  const bool no_mid = em_sw().no_mid_gemm;  // developer A/B switch (tools/gemm_bench.py)
   // very few rows (streaming encoder step, single-utterance beam): latency-bound weight streaming
   if (a_mode == EM_A_PLAIN && p->M <= 48) rc = em_gemm_skinny(dtype, epilogue, p, stream);
   // a few hundred rows x a few hundred columns (the residual projections of a beam-search label step): the tiled grid

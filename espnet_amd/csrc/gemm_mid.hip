@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 
 namespace {
 
@@ -185,10 +186,7 @@ int launch_mid(const EmGemmArgs* p, hipStream_t s) {
   // 16 x 32 tiles while 32 x 32 ones would not even give every CU a workgroup: at 160 x 512 the label step runs 0.383
   // against 0.399 ms with them (profiles/r03h: more workgroups beat fewer operand bytes; 16 x 16 and 32 x 16 do not
   // help further, 16 x 64 and 32 x 64 lose).  Developer A/B switch: ESPNET_AMD_MID_TILE = "11" | "12" | "21" | "22" | "14" | "24".
-  static const int force = [] {
-    const char* e = getenv("ESPNET_AMD_MID_TILE");
-    return e ? atoi(e) : 0;
-  }();
+  const int force = em_sw().mid_tile;
   // Round 5: 32 x 64 tiles once even 32 x 32 ones give every CU more than a workgroup - configs[3]'s per-GPU step (640 rows x
   // 512 columns: 320 tiles of 32 x 32) runs 0.684 against 0.715 ms per label step with them, the 160-row step 0.40 against
   // 0.35 (profiles/r05l_label_step_dispatch_sweep.txt), hence by tile count and not for all.

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 
 namespace {
 
@@ -184,10 +185,7 @@ template <typename T, int EPI, int NV, bool EXACT>
 int launch_ln_gemm_nv(const float* x, const float* g, const float* b, float eps, const void* W, const float* bias,
                       void* C, int M, int N, int K, int ldc, hipStream_t s) {
   // 16-row workgroups where 32-row ones would leave most of the chip idle (developer switch: ESPNET_AMD_LNG_RT = 1 | 2)
-  static const int force = [] {
-    const char* e = getenv("ESPNET_AMD_LNG_RT");
-    return e ? atoi(e) : 0;
-  }();
+  const int force = em_sw().lng_rt;
   const bool rt1 = force ? force == 1 : (long)em_cdiv(N, LG_BN) * em_cdiv(M, 32) < 144;  // (160 rows: the q / k / v and source-q projections 6.0 -> 4.8 us, the 2048-wide FFN projection 6.6 -> 7.3 us with 16-row workgroups: profiles/r03h, r03j)
   if (rt1) return launch_ln_gemm_rt<T, EPI, NV, EXACT, 1>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);
   return launch_ln_gemm_rt<T, EPI, NV, EXACT, 2>(x, g, b, eps, W, bias, C, M, N, K, ldc, s);

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 
 namespace {
 
@@ -1098,7 +1099,7 @@ inline int ln_proj(int dtype, int epi, const float* x, const float* g, const flo
                    const float* bias, void* C, void* xn_scratch, int n, int N, int K, void* stream) {
   const long wgs = (long)em_cdiv(N, 64) * em_cdiv(n, 32);
   // n <= 48 (one stream): LayerNorm + the skinny GEMM is 6.6 us, the fused kernel 7.5
-  static const int wide = getenv("ESPNET_AMD_LNG_WIDE") ? atoi(getenv("ESPNET_AMD_LNG_WIDE")) : 256;  // developer A/B switch
+  const int wide = em_sw().lng_wide;  // developer A/B switch
   if (n > 48 && wgs <= wide && K % 64 == 0 && K <= 1024)
     return em_ln_gemm(dtype, epi, x, g, be, LN_EPS, W, bias, C, n, N, K, N, stream);
   EM_TRY(em_layernorm(dtype, x, g, be, n, K, LN_EPS, xn_scratch, nullptr, stream));
@@ -1358,7 +1359,7 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.self_wout, a.x, q.self_bout, n, d, d, d, d, 1.f, stream));
     // round 4: norm2 + the source attention's query projection ride in the attention kernel's prologue (bf16, d_k = 64,
     // d = 256 | 512: one launch less per layer; ESPNET_AMD_NO_SRC_LNQ=1: developer A/B switch)
-    static const bool no_lnq = getenv("ESPNET_AMD_NO_SRC_LNQ") != nullptr;
+    const bool no_lnq = em_sw().no_src_lnq;
     // (the fused kernel adds its LN(x) rows and query tile to the score / probability tiles of the plain kernel: long
     // memories - Tpad > 1 472 at d = 512, > 1 568 at d = 256 - fit only the two-launch form)
     const size_t lnq_lds = (size_t)16 * (a.Tpad + 4) * 4 + 64 + (size_t)16 * (a.Tpad + 8) * 2 + (size_t)16 * (d + 8) * 2 + 16 * (64 + 8) * 2;
@@ -1558,7 +1559,7 @@ extern "C" int em_search_steps(int dtype, const EmSearchParams* p, const EmDecod
   // selection + the winners' CTC state + the new rows in one launch where a beam's chains fit the LDS side by side
   const int lt_cap = ldt(*p);
   const size_t tail_lds = p->w_ctc != 0.f ? (size_t)p->W * 5 * lt_cap * sizeof(float) : 0;
-  static const bool no_tail = getenv("ESPNET_AMD_NO_TAIL_FUSION") != nullptr;  // developer A/B switch
+  const bool no_tail = em_sw().no_tail_fusion;  // developer A/B switch
   const bool fused_tail = !no_tail && p->W <= 16 && p->W * p->NC <= 64 * SEL_KM && tail_lds <= 144 * 1024;
   static EmLdsCap cap = {};
   if (fused_tail && tail_lds > 64 * 1024 && em_raise_lds_cap((const void*)tail_kernel, tail_lds, &cap) != EM_OK) return EM_ERR_LAUNCH;

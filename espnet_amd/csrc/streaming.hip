@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 
 namespace {
 
@@ -384,8 +385,8 @@ inline CbWs cb_layout_fused(int dtype, const EmConformerWeights* w, int n_blk, i
 // spread every weight matrix over a hundred CUs - while 32 blocks fill 64 CUs and the tick drops from 1.83 to 1.44 ms
 // (profiles/r04i_stream_fused_ab.txt).  ESPNET_AMD_STREAM_FUSED_MIN=n: developer A/B switch.
 inline bool cb_fusable(int dtype, const EmConformerWeights* w, int L, int n_blk) {
-  static const bool off = getenv("ESPNET_AMD_STREAM_NO_FUSED") != nullptr;  // developer A/B switch
-  static const int min_blk = getenv("ESPNET_AMD_STREAM_FUSED_MIN") ? atoi(getenv("ESPNET_AMD_STREAM_FUSED_MIN")) : 8;
+  const bool off = em_sw().stream_no_fused;  // developer A/B switch
+  const int min_blk = em_sw().stream_fused_min;
   if (off || n_blk < min_blk || dtype != EM_BF16 || w->d != 256 || w->heads != 4 || w->kernel != 15 || w->ff > 4096 || w->ff % 128 != 0 ||
       L > 64 || !w->layers)
     return false;
@@ -532,14 +533,16 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
     ba.B = n_blk; ba.T = L; ba.Tpad = s.Tpad; ba.d = d; ba.ff = ff; ba.kernel = w->kernel; ba.eps = LN_EPS;
     ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = ws + s.qh; ba.kh = ws + s.kh; ba.vt = ws + s.vt;
     const size_t mha_lds = ((size_t)2 * L * 64 + (size_t)64 * (L + 1)) * sizeof(float);
-    static const bool mha_v1 = getenv("ESPNET_AMD_STREAM_MHA_V1") != nullptr;  // developer A/B switch: the LDS / VALU attention kernel of round 4
+    const bool mha_v1 = em_sw().stream_mha_v1;  // developer A/B switch: the LDS / VALU attention kernel of round 4
     // One block per stream (the steady-state tick): the hand-over after layer l is "slot 0 := the previous call's context
     // vector of layer l; this call's := the last slot" - block<A> of layer l + 1 reads its slot 0 from past_ctx and
     // block<D> of layer l writes its last slot to next_ctx as well: twelve launches less per call (4.9 us each, 59 of a
     // 32-stream tick's 1 170 us; profiles/r05x_stream_batch32_kernel_stats.csv).  What x[.][0] holds after the LAST layer
     // is never read (slot 0 is not an output frame).  ESPNET_AMD_STREAM_NO_CTX_FOLD: developer A/B switch (read per call:
     // tests/test_gpu_streaming.py compares the two bit for bit).
-    const bool fold_ctx = mask_mode && n_blk_s == 1 && past_ctx && next_ctx && getenv("ESPNET_AMD_STREAM_NO_CTX_FOLD") == nullptr;
+    // (past_ctx == next_ctx: layer l + 1 would read THIS call's vector where it wants the previous call's - the hand-over launch reads
+    // before it writes and is safe in place, so an aliased call keeps it)
+    const bool fold_ctx = mask_mode && n_blk_s == 1 && past_ctx && next_ctx && past_ctx != next_ctx && !em_sw().stream_no_ctx_fold;
     ba.row_stride = NL * d;
     for (int l = 0; l < NL; ++l) {
       const EmConformerLayer& q = w->layers[l];
@@ -574,7 +577,7 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
   // A pre-norm LayerNorm rides in the prologue of the projection that consumes it (csrc/ln_gemm.hip) where that kernel
   // has the epilogue (plain / ReLU): three launches less per layer.  A step is ~200 dependent launches of ~5.6 us for
   // 42 rows - launch latency, nothing else - so the count is what matters (round 3: 1.30 -> see profiles/r03p).
-  static const bool no_lng = getenv("ESPNET_AMD_STREAM_NO_LN_GEMM") != nullptr;  // developer A/B switch
+  const bool no_lng = em_sw().stream_no_ln_gemm;  // developer A/B switch
   const bool lng = !no_lng && d % 64 == 0 && d <= 1024;
   auto ln_proj = [&](int epi, const float* g, const float* be, const void* W, const float* bias, void* C, int N) {
     if (lng) return em_ln_gemm(dtype, epi, x, g, be, LN_EPS, W, bias, C, M, N, d, N, stream);

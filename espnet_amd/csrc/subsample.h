@@ -8,6 +8,7 @@
 // channel-last map of the previous one; the Linear is a GEMM with the x * sqrt(d) of the positional
 // encoding (embedding.py:328) in its epilogue.
 #pragma once
+#include "switches.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -64,7 +65,7 @@ inline int run(int dtype, const W* w, const Geo& g, const float* feats, const fl
                const void* conv1_wf = nullptr, const void* conv2_wf = nullptr) {
   const int d = w->d;
   int rc = EM_ERR_UNSUPPORTED;
-  static const bool no_fused = getenv("ESPNET_AMD_NO_SUB12") != nullptr;  // developer A/B switch
+  const bool no_fused = em_sw().no_sub12;  // developer A/B switch
   const bool try_fused = dtype == EM_BF16 && conv1_wf && conv2_wf && mode_of(w->subsample) == 4 && !no_fused;
   if (try_fused)
     rc = em_conv2d_sub12_bf16(feats, mvn_partial, flens, B, g.T[0], g.F[0], conv1_wf, conv2_wf, w->conv2_b, d, c2, stream);

@@ -39,6 +39,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include "switches.h"
 
 namespace {
 
@@ -529,7 +530,7 @@ extern "C" int em_conv2d_sub12_bf16(const float* feats, const float* mvn_partial
   a.w1f = conv1_wf; a.w2f = conv2_wf; a.b2 = conv2_b; a.out = c2; a.ldo = d;
   a.B = B; a.T_f = T_f; a.n_mels = n_mels; a.F1 = F1; a.T2 = T2; a.F2 = F2;
   static long long* stamps = nullptr;
-  static const bool want_stamps = getenv("EM_SUB2_STAMPS") != nullptr;
+  const bool want_stamps = em_sw().sub2_stamps;
   if (want_stamps && !stamps && hipMalloc((void**)&stamps, 32 * sizeof(long long)) != hipSuccess) return EM_ERR_LAUNCH;
   if (want_stamps && hipMemsetAsync(stamps, 0, 32 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   a.stamps = want_stamps ? stamps : nullptr;

@@ -165,13 +165,43 @@ class SharedCounter:
 _CALL_SEQ = {}
 
 
-def call_key(name: str) -> str:
-    """A counter key for ONE call of a collective entry point: `name` + how many times this process has asked for it.
-    Every rank makes the same calls in the same order, so the keys agree without communication, and a second decode
-    inside the same process group (torchrun decoding several test sets in one process) starts from a fresh counter
-    instead of the previous call's final value."""
+def call_key(name: str, store=None, world: int = 1, timeout_s: float = 300.0) -> str:
+    """A counter key for ONE call of a collective entry point: `name` + how many times this process has asked for it, so a
+    second decode inside the same process group starts from a fresh counter instead of the previous call's final value
+    (ADVICE r04).  The keys agree without communication ONLY if every rank makes the same calls in the same order; a rank
+    that skipped or repeated a call (an exception before its decode, a retry on one rank) would silently work on a counter
+    of its own and decode every window again.  So with a store the ranks MEET on the key: each adds itself to
+    `<key>/arrive`; more arrivals than ranks, or fewer within `timeout_s`, is an error on the ranks that see it, not a
+    duplicated transcript.  `release_key` deletes the key's entries when the call is over."""
     _CALL_SEQ[name] = _CALL_SEQ.get(name, 0) + 1
-    return f"{name}_{_CALL_SEQ[name]}"
+    key = f"{name}_{_CALL_SEQ[name]}"
+    if store is not None and world > 1:
+        import time
+
+        n = int(store.add(key + "/arrive", 1))
+        if n > world:
+            raise RuntimeError(f"{key}: {n} arrivals for {world} ranks - the ranks' call sequences have diverged")
+        t0 = time.monotonic()
+        while n < world:
+            if time.monotonic() - t0 > timeout_s:
+                raise RuntimeError(f"{key}: only {n} of {world} ranks arrived within {timeout_s:.0f} s - the ranks' call "
+                                   f"sequences have diverged (or a rank died before this call)")
+            time.sleep(0.002)
+            n = int(store.add(key + "/arrive", 0))
+        if n > world:
+            raise RuntimeError(f"{key}: {n} arrivals for {world} ranks - the ranks' call sequences have diverged")
+    return key
+
+
+def release_key(store, key: str, rank: int = 0):
+    """Forget a finished call's counter (rank 0, after the call's closing collective: nobody reads it any more)."""
+    if store is None or rank != 0:
+        return
+    for k in (key, key + "/arrive"):
+        try:
+            store.delete_key(k)
+        except Exception:  # noqa: BLE001  (a store without delete_key: the keys stay, as before)
+            pass
 
 
 class WindowClaimer:
@@ -251,7 +281,11 @@ def decode_dynamic(decode_unit, n_units: int, unit_items, max_len: int, device, 
     collective.  Returns (hypotheses in global utterance order, units this rank decoded)."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    counter = counter or SharedCounter(work_store() if world > 1 else None, call_key("decode_dynamic"))
+    own_key = None
+    if counter is None:
+        st = work_store() if world > 1 else None
+        own_key = call_key("decode_dynamic", st, world)
+        counter = SharedCounter(st, own_key)
     err, recs, mine = None, [], []
     try:
         while True:
@@ -274,7 +308,10 @@ def decode_dynamic(decode_unit, n_units: int, unit_items, max_len: int, device, 
     if failed:
         raise RuntimeError(f"rank {rank}: another rank failed before the hypothesis collation; nothing was gathered")
     rec = torch.cat(recs, dim=0) if recs else torch.empty((0, max_len + 3), dtype=torch.int32, device=device)
-    return unpack_indexed_records(gather_variable_records(rec, group), unit_items), mine
+    out = unpack_indexed_records(gather_variable_records(rec, group), unit_items), mine
+    if own_key is not None:
+        release_key(counter.store, own_key, rank)  # (behind the closing collective: every rank is past its last claim)
+    return out
 
 
 class RecordRing:

@@ -256,6 +256,7 @@ _SIGNATURES = {
     "em_profile_read": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "em_profile_read2": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "em_conformer_block_fused": (C.c_int, [C.c_int, C.POINTER(EmBlockArgs), _vp]),
+    "em_dev_switches_reload": (None, []),
     "em_relpos_pos_fragments": (C.c_int, [C.c_int32]),
     "em_relpos_pack_pos_bf16": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "em_ffn_rows_fused": (C.c_int, [C.POINTER(EmFfnRowsArgs), _vp]),

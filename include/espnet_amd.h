@@ -79,6 +79,11 @@ typedef struct EmGemmArgs {
 /* ---- library ------------------------------------------------------------------------------- */
 int em_version(void);
 const char* em_error_string(int code);
+/* Developer switches (ESPNET_AMD_* / EM_*_STAMPS environment variables, DESIGN.md: A/B timing and diagnostics between DEVICE code
+ * paths, never a CPU path) are read from the environment ONCE, at the first launch that consults one, into a struct the
+ * launchers share (csrc/switches.h): no getenv() on a call path.  A process that changes such a variable afterwards - the
+ * tests that compare two kernels in one process do - calls this to have them read again. */
+void em_dev_switches_reload(void);
 
 /* ---- A1+A2: Stft.forward (espnet2/layers/stft.py:48-120) + power (asr/frontend/default.py:110)
  *      + LogMel.forward (espnet2/layers/log_mel.py:57-84), fused.  n_fft is fixed at 512.
@@ -928,7 +933,9 @@ int em_cb_propagate_ctx_f32(float* x, const float* past_ctx, float* next_ctx, in
                             int32_t L, int32_t d, void* stream);
 size_t em_cb_workspace_bytes(int dtype, const EmConformerWeights* w, int32_t n_blk, int32_t L);
 /*   All layers on x [n_blk][L][d] f32 in place.  EmConformerLayer is reused (norm_mha = norm1,
- *   norm_ff = norm2, pos_u/pos_v unused; ReLU feed-forward).  past_ctx / next_ctx [num_blocks][d].  */
+ *   norm_ff = norm2, pos_u/pos_v unused; ReLU feed-forward).  past_ctx / next_ctx [num_blocks][d]: give them DIFFERENT
+ *   buffers - with one block per stream the hand-over rides in the block launches (layer l + 1 reads past_ctx[l] after layer
+ *   l wrote next_ctx[l]); a call with past_ctx == next_ctx is still correct, it falls back to the hand-over launch.  */
 int em_cb_encode_blocks(int dtype, const EmConformerWeights* w, float* x, int32_t n_blk, int32_t L,
                         int32_t mask_mode, const float* past_ctx, float* next_ctx, void* workspace,
                         size_t workspace_bytes, void* stream);

@@ -390,3 +390,44 @@ def test_bench_gpus_n_without_launcher_becomes_the_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _diverging_worker(rank, world, port, q):
+    """Rank 1 makes one call of the collective entry point more than rank 0 before the call both make: its call sequence
+    is one ahead, and without the meeting on the key it would silently work on a counter of its own."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from espnet_amd import distributed as D
+
+    st = D.work_store()
+    try:
+        k1 = D.call_key("decode_x", st, world)               # both ranks: agree
+        if rank == 1:
+            D._CALL_SEQ["decode_x"] += 1                     # (the skipped / repeated call, without its wait)
+        try:
+            D.call_key("decode_x", st, world, timeout_s=2.0)
+            q.put((rank, k1, "no error"))
+        except RuntimeError as e:
+            q.put((rank, k1, str(e)))
+        D.release_key(st, k1, rank)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_diverged_call_sequences_raise_instead_of_duplicating_work():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_diverging_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: (k, msg) for r, k, msg in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] == "decode_x_1"            # the call both made met on one key
+    for r in range(world):                                   # the diverged one is an error on every rank that waits for it
+        assert "diverged" in got[r][1], got

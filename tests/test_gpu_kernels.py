@@ -209,11 +209,13 @@ def test_frontend_v2_equals_v1(lib, n_mels, hop, isolate):
     for v1 in (False, True):
         if v1:
             os.environ["ESPNET_AMD_FRONTEND_V1"] = "1"
+        L.load().em_dev_switches_reload()  # (the library reads its developer switches once; this test flips one in-process)
         try:
             outs.append(fe.forward_device(sp, flens, wlens).clone())
             torch.cuda.synchronize()
         finally:
             os.environ.pop("ESPNET_AMD_FRONTEND_V1", None)
+            L.load().em_dev_switches_reload()
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
 

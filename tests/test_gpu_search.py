@@ -467,6 +467,7 @@ def test_dec_self_attention_beam(lib, tree, heads, d, B, W, pos, Lmax):
     from espnet_amd import lib as L
 
     os.environ["ESPNET_AMD_SA_TREE_MIN_ROWS"] = "0"  # (the library takes the tree form from 200 rows: here at every size)
+    L.load().em_dev_switches_reload()
     torch.manual_seed(3)
     n, dk = B * W, d // heads
     dt = torch.bfloat16
@@ -497,6 +498,7 @@ def test_dec_self_attention_beam(lib, tree, heads, d, B, W, pos, Lmax):
         torch.cuda.synchronize()
     finally:
         os.environ.pop("ESPNET_AMD_SA_TREE_MIN_ROWS", None)
+        L.load().em_dev_switches_reload()
     q, k_new, v_new = qkv.float().split(d, dim=1)
     idx = anc[:, :pos].long().t()
     jj = torch.arange(pos, device="cuda")[:, None].expand(pos, n)

@@ -61,8 +61,11 @@ def test_streaming_fused_layers_match_per_operator_sequence():
     tolerance of the reference fixture; also the one-shot (many blocks at once) and short-utterance paths."""
     import os
 
+    from espnet_amd import lib as _L
+
     os.environ["ESPNET_AMD_STREAM_FUSED_MIN"] = "1"  # (read once by the library: by default calls of fewer than 8 blocks
     # keep the per-operator sequence - one stream's single block is faster there; this test wants the fused kernels)
+    _L.load().em_dev_switches_reload()
     g = load_stream_golden("stream_small_6s")
     feats = stream_feats(int(g["utt_id"]), int(g["n_samples"]))
     enc = build(g, "bfloat16")
@@ -300,13 +303,18 @@ def test_batch_tick_context_hand_over_in_the_block_launches_equals_its_own_launc
             pos = nxt
         return torch.cat(outs, 1).cpu()
 
+    from espnet_amd import lib as _L
+
     os.environ.pop("ESPNET_AMD_STREAM_NO_CTX_FOLD", None)
+    _L.load().em_dev_switches_reload()
     folded = run()
     os.environ["ESPNET_AMD_STREAM_NO_CTX_FOLD"] = "1"
+    _L.load().em_dev_switches_reload()
     try:
         launched = run()
     finally:
         os.environ.pop("ESPNET_AMD_STREAM_NO_CTX_FOLD", None)
+        _L.load().em_dev_switches_reload()
     assert folded.shape == launched.shape and torch.equal(folded, launched)
     assert (folded[0] - folded[1]).abs().max().item() > 0.1  # (different utterances)
     err = np.abs(folded[0][:: int(g["keep_every"])].numpy() - g["ys"])
