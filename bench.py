@@ -478,19 +478,96 @@ def pick_copy_stream(dev, host, dst, candidates=6):
     return best[1], {"extra_ms_per_candidate": report, "compute_ms": round(tc * 1e3, 3)}
 
 
-class HostFeeder:
-    """Waveforms arriving in pinned host memory (the boundary's real input): batch k+1 is copied host -> device
-    on a copy stream into the second device buffer while batch k computes."""
+class StepPipeline:
+    """`depth` batches in flight on as many HIP streams (round 6).  Every kernel of the greedy step takes the whole chip, so
+    two steps never run side by side - but between two DEPENDENT launches of one stream the chip idles for the boundary
+    (1.5 - 1.9 us, ~27 per step: drain, signal, dispatch), and the other stream's next launch fills it: 0.905 against 0.983 ms
+    per batch with two streams, tools/two_stream_probe.py / profiles/r06k_two_stream_probe.txt.  Utterance batches are
+    independent (that is the data-parallel story of the whole path); the encoder keeps one workspace per stream.
+    The streams are chosen so that they really sit on different hardware queues (two single-thread spin kernels must run
+    side by side): see pick_copy_stream for why that is not a given."""
 
-    def __init__(self, wav_host, dev):
+    def __init__(self, dev, depth):
+        self.dev, self.depth, self.i = dev, depth, 0
+        self.streams, self.probe = self._pick(dev, depth)
+        self.done = [None] * depth
+        self.flush_ev = {}
+
+    @staticmethod
+    def _pick(dev, depth, candidates=8, spin=400000):
+        def wall(sts):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for st in sts:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(spin)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        cand = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+        one = min(wall([cand[0]]) for _ in range(3))
+        chosen = [cand[0]]
+        for st in cand[1:]:
+            if len(chosen) == depth:
+                break
+            if min(wall(chosen + [st]) for _ in range(2)) < 1.35 * one:  # runs beside every stream chosen so far
+                chosen.append(st)
+        note = {"streams_side_by_side": len(chosen), "asked": depth}
+        while len(chosen) < depth:  # (no such stream found: still correct, just no overlap)
+            chosen.append(cand[len(chosen)])
+        return chosen, note
+
+    def fork(self, half=None):
+        """Before the first step of a macro-batch: every stream waits for the flush that last read the ring half it is about to
+        write (recorded by `flushed(half)` a whole macro-batch ago - no stall), or, without one, for whatever the caller's stream
+        has enqueued so far."""
+        ev = self.flush_ev.get(half) if half is not None else None
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record()
+        for st in self.streams:
+            st.wait_event(ev)
+
+    def flushed(self, half):
+        """The caller's stream has just enqueued the flush (all-gather + D2H) of ring half `half`."""
+        ev = self.flush_ev.get(half)
+        if ev is None:
+            ev = self.flush_ev[half] = torch.cuda.Event()
+        ev.record()
+
+    def run(self, fn):
+        k = self.i % self.depth
+        with torch.cuda.stream(self.streams[k]):
+            fn()
+            if self.done[k] is None:
+                self.done[k] = torch.cuda.Event()
+            self.done[k].record()
+        self.i += 1
+
+    def join(self):
+        """The caller's stream waits for every step enqueued so far."""
+        cur = torch.cuda.current_stream()
+        for ev in self.done:
+            if ev is not None:
+                cur.wait_event(ev)
+
+
+class HostFeeder:
+    """Waveforms arriving in pinned host memory (the boundary's real input): with `nbuf` device buffers the copy of batch
+    k + nbuf - 1 is issued on a copy stream when batch k is released, i.e. it runs under the compute of the nbuf - 1 batches in
+    front of it (nbuf = batches in flight + 1)."""
+
+    def __init__(self, wav_host, dev, nbuf=2):
         self.host = wav_host.pin_memory()
-        self.bufs = [torch.empty_like(wav_host, device=dev) for _ in range(2)]
+        self.n = nbuf
+        self.bufs = [torch.empty_like(wav_host, device=dev) for _ in range(nbuf)]
         self.copy_stream, self.stream_probe = pick_copy_stream(dev, self.host, self.bufs[0])
-        self.copied = [torch.cuda.Event(), torch.cuda.Event()]
-        self.consumed = [None, None]
-        self._consumed_ev = [torch.cuda.Event(), torch.cuda.Event()]  # (re-recorded every step: no event creation in the loop)
+        self.copied = [torch.cuda.Event() for _ in range(nbuf)]
+        self.consumed = [None] * nbuf
+        self._consumed_ev = [torch.cuda.Event() for _ in range(nbuf)]  # (re-recorded every step: no event creation in the loop)
         self.k = 0
-        self._prefetch(0)
+        for slot in range(nbuf - 1):
+            self._prefetch(slot)
 
     def _prefetch(self, slot):
         with torch.cuda.stream(self.copy_stream):
@@ -500,17 +577,17 @@ class HostFeeder:
             self.copied[slot].record(self.copy_stream)
 
     def acquire(self):
-        slot = self.k & 1
+        slot = self.k % self.n
         torch.cuda.current_stream().wait_event(self.copied[slot])
         return self.bufs[slot]
 
     def release(self):
-        slot = self.k & 1
+        slot = self.k % self.n
         ev = self._consumed_ev[slot]
         ev.record()
         self.consumed[slot] = ev
         self.k += 1
-        self._prefetch(self.k & 1)
+        self._prefetch((self.k + self.n - 2) % self.n)
 
 
 def _edit_distance(a, b):
@@ -928,6 +1005,8 @@ def main():
     ap.add_argument("--h2d", action="store_true",
                     help="main loop with the waveforms arriving in pinned host memory (H2D overlapped with "
                          "compute); the default run reports this as the `pcie_inclusive` sub-object instead")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="greedy workload: batches in flight on as many HIP streams (1 = one stream, steps back to back)")
     ap.add_argument("--quick", action="store_true", help="main line + roofline + cpu_baseline only")
     ap.add_argument("--dist-debug-one-gpu", action="store_true",
                     help="developer check of the multi-rank control flow on a ONE-GPU box: every rank uses "
@@ -1017,16 +1096,37 @@ def main():
             st = model.encode_device(wav if src is None else src, lens)
             return model.greedy_ctc_device(st, out=out)
 
+        pipe = StepPipeline(dev, args.in_flight) if args.in_flight > 1 and feeder is None else None
+
         def step():
             tok_v, len_v, _ = sink.slot()
             if feeder is not None:
                 step_plain(feeder.acquire(), out=(tok_v, len_v))
                 feeder.release()
+            elif pipe is not None:
+                # (a macro-batch of the record ring = RING_STEPS steps dealt round-robin to the streams; the ring half is
+                # flushed - all-gather + D2H on the main stream - behind all of them, and rewritten only behind its flush)
+                half = (sink.k // RING_STEPS) & 1
+                if sink.k % RING_STEPS == 0:
+                    pipe.fork(half)
+                pipe.run(lambda: step_plain(out=(tok_v, len_v)))
+                if (sink.k + 1) % RING_STEPS == 0:
+                    pipe.join()
+                    sink.commit()
+                    pipe.flushed(half)
+                    return
             else:
                 step_plain(out=(tok_v, len_v))
             sink.commit()
 
-        elapsed = timed_loop(step, args.steps, args.warmup, barrier, sink.drain)
+        def finish():
+            if pipe is not None:
+                pipe.join()
+            sink.drain()
+            if pipe is not None:
+                pipe.flush_ev.clear()  # (drain delivered everything to the host: the next macro-batch forks from this stream)
+
+        elapsed = timed_loop(step, args.steps, args.warmup, barrier, finish)
         n_tok = int(sink.last[1].sum()) if sink.last is not None else 0
         assert rank != 0 or sink.delivered == args.steps + args.warmup, (sink.delivered, args.steps, args.warmup)
     el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.dist_debug_one_gpu else dev)
@@ -1067,6 +1167,13 @@ def main():
                                        "the `pcie_inclusive` sub-object of this line)"),
                        "tokens_last_step": n_tok},
         }
+        if args.workload == "greedy":
+            out["config"]["batches_in_flight"] = (
+                {"n": pipe.depth, **pipe.probe,
+                 "what": "steps dealt round-robin to this many HIP streams: every kernel takes the whole chip, so steps do not run "
+                         "side by side, but one stream's launch fills the boundary between two dependent launches of the "
+                         "other (~27 per step); ms_per_step = timed region / steps, i.e. per batch; `one_stream` below is the "
+                         "same loop with --in-flight 1"} if pipe is not None else {"n": 1})
         out.update(extras)
     # ---- roofline of the MFMA kernel families: HIP events around every launch (on the launch stream)
     if rank == 0 and not args.no_roofline and step_plain is not None:
@@ -1120,24 +1227,57 @@ def main():
                     "kernel": "frontend_logmel (STFT + power + log-mel, csrc/frontend.hip), HIP events on the launch "
                               "stream over 50 launches"}
 
-        def pcie_leg():
-            fd = HostFeeder(wav_host, dev)
-            sk = sink_factory(B, T)
-
+        def pipelined_loop(sk, pp, body, k, warm):
+            """`k` timed steps of `body(tok_v, len_v)` collated through ring `sk`, dealt to the streams of `pp` (None: this stream)."""
             def st():
                 tok_v, len_v, _ = sk.slot()
-                step_plain(fd.acquire(), out=(tok_v, len_v))
-                fd.release()
+                if pp is None:
+                    body(tok_v, len_v)
+                else:
+                    half = (sk.k // RING_STEPS) & 1
+                    if sk.k % RING_STEPS == 0:
+                        pp.fork(half)
+                    pp.run(lambda: body(tok_v, len_v))
+                    if (sk.k + 1) % RING_STEPS == 0:
+                        pp.join()
+                        sk.commit()
+                        pp.flushed(half)
+                        return
                 sk.commit()
 
+            def fin():
+                if pp is not None:
+                    pp.join()
+                sk.drain()
+                if pp is not None:
+                    pp.flush_ev.clear()
+
+            return timed_loop(st, k, warm, barrier, fin)
+
+        def one_stream_leg():
+            k = min(args.steps, 600)
+            t = pipelined_loop(sink_factory(B, T), None, lambda a, b: step_plain(out=(a, b)), k, 20)
+            return {"value": round(B * AUDIO_SEC * k / t, 1), "unit": "audio-s/s", "ms_per_step": round(t / k * 1e3, 3), "steps": k,
+                    "what": "the loop of `value` with ONE batch in flight (steps back to back on one stream: the form of rounds 1-5)"}
+
+        def pcie_leg():
+            depth = pipe.depth if pipe is not None else 1
+            fd = HostFeeder(wav_host, dev, nbuf=depth + 1)
+            pp = StepPipeline(dev, depth) if depth > 1 else None
+
+            def body(tok_v, len_v):
+                step_plain(fd.acquire(), out=(tok_v, len_v))
+                fd.release()
+
             k = min(args.steps, 300)
-            t = timed_loop(st, k, 10, barrier, sk.drain)
+            t = pipelined_loop(sink_factory(B, T), pp, body, k, 10)
             return {"value": round(B * AUDIO_SEC * k / t, 1), "unit": "audio-s/s", "ms_per_step": round(t / k * 1e3, 3),
                     "vs_resident": round((B * AUDIO_SEC * k / t) / value, 4),
                     "copy_stream_probe": fd.stream_probe,
                     "steps": k, "what": "the same step with the waveforms arriving in pinned host memory: H2D of "
-                                        f"{B * N_SAMPLES * 4 / 1e6:.1f} MB per step on a copy stream, double buffered, "
-                                        "overlapped with the previous step's compute; D2H of the hypotheses as in `value`"}
+                                        f"{B * N_SAMPLES * 4 / 1e6:.1f} MB per step on a copy stream into one of (batches in flight + 1) buffers, "
+                                        "overlapped with the previous steps' compute, batches in flight as in `value`; D2H of the "
+                                        "hypotheses as in `value`"}
 
         ids_bf16 = {}
 
@@ -1281,6 +1421,8 @@ def main():
 
         guarded("frontend", frontend_leg)
         guarded("pcie_inclusive", pcie_leg)
+        if pipe is not None:
+            guarded("one_stream", one_stream_leg)
         guarded("bf16_vs_f32", parity_leg)
         guarded("f32_mode", f32_leg)
         del model

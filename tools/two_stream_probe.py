@@ -32,8 +32,17 @@ def main():
             with torch.cuda.stream(s):
                 model.greedy_ctc_device(model.encode_device(w, hl))
 
+    # round 6: two FULL batches in flight on two streams (each stream has its own workspace in the encoder): what one stream
+    # leaves idle at a kernel boundary (1.5 - 1.9 us between dependent launches, ~27 per step) the other stream's launch can
+    # fill.  Counts per batch: one call = two batches.
+    def two_full():
+        for s in streams:
+            with torch.cuda.stream(s):
+                model.greedy_ctc_device(model.encode_device(wav, lens))
+
     with torch.no_grad():
-        for name, fn in (("one stream x 32", one), ("two streams x 16", two), ("one stream x 32", one), ("two streams x 16", two)):
+        for name, fn, per in (("one stream x 32", one, 1), ("two streams x 16", two, 1), ("two streams x 32 (two batches in flight)", two_full, 2),
+                              ("one stream x 32", one, 1), ("two streams x 32 (two batches in flight)", two_full, 2)):
             for _ in range(30):
                 fn()
             torch.cuda.synchronize()
@@ -41,7 +50,7 @@ def main():
             for _ in range(steps):
                 fn()
             torch.cuda.synchronize()
-            print(f"{name}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step of {B} utterances", flush=True)
+            print(f"{name}: {(time.perf_counter() - t0) / steps / per * 1e3:.3f} ms per batch of {B} utterances", flush=True)
 
 
 if __name__ == "__main__":
