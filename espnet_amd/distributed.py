@@ -314,6 +314,61 @@ def decode_dynamic(decode_unit, n_units: int, unit_items, max_len: int, device, 
     return out
 
 
+def decode_dynamic_lanes(start, poll, n_lanes: int, n_units: int, unit_items, max_len: int, device, group=None,
+                         counter=None):
+    """`decode_dynamic` with several work units IN FLIGHT per rank (round 6: one joint search per HIP stream,
+    espnet_amd.nets.batch_beam_search.SearchLanes).  `start(lane, u)` enqueues unit u on lane `lane` and returns at once;
+    `poll(lane)` returns None while the lane is busy, else (global utterance indices, token-id lists, scores) of the unit it
+    finished.  Units are claimed from the shared counter one at a time, whenever a lane falls free; collation and failure
+    protocol as in `decode_dynamic`.  Returns (hypotheses in global utterance order, units this rank decoded)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    own_key = None
+    if counter is None:
+        st = work_store() if world > 1 else None
+        own_key = call_key("decode_dynamic", st, world)
+        counter = SharedCounter(st, own_key)
+    err, recs, mine = None, [], []
+    try:
+        unit_of, exhausted = [None] * n_lanes, False
+        while True:
+            for k in range(n_lanes):  # fill the free lanes
+                if unit_of[k] is None and not exhausted:
+                    u = counter.next(1)
+                    if u >= n_units:
+                        exhausted = True
+                    else:
+                        start(k, u)
+                        unit_of[k] = u
+            busy = [k for k in range(n_lanes) if unit_of[k] is not None]
+            if not busy:
+                break
+            for k in busy:
+                r = poll(k)
+                if r is not None:
+                    idx, toks, scores = r
+                    recs.append(pack_indexed_records(idx, toks, scores, max_len, device))
+                    mine.append(unit_of[k])
+                    unit_of[k] = None
+    except Exception as e:  # re-raised below, after the peers have been told
+        err = e
+    if world > 1:
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        failed = int(flag.item()) != 0
+    else:
+        failed = err is not None
+    if err is not None:
+        raise err
+    if failed:
+        raise RuntimeError(f"rank {rank}: another rank failed before the hypothesis collation; nothing was gathered")
+    rec = torch.cat(recs, dim=0) if recs else torch.empty((0, max_len + 3), dtype=torch.int32, device=device)
+    out = unpack_indexed_records(gather_variable_records(rec, group), unit_items), mine
+    if own_key is not None:
+        release_key(counter.store, own_key, rank)
+    return out
+
+
 class RecordRing:
     """Per-step collation for a loop that decodes one fixed-shape batch per step (bench.py): a device ring of M steps'
     records `[ids (B x width) | counts (B) | score bits (B)]` that the decode kernels write IN PLACE (`slot()` hands out

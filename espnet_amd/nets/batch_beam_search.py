@@ -336,6 +336,74 @@ class BatchBeamSearch(BeamSearch):
     __call__ = forward
 
 
+class SearchLanes:
+    """Several joint searches IN FLIGHT, one per HIP stream (round 6).  A label step of the batched search is ~47 small
+    launches whose grids cover a fraction of the chip (160 hypothesis rows at configs[2]) and whose time is launch latency and
+    dependent round trips, not bandwidth: a second, independent search on another stream runs in the gaps of the first.
+    Each lane owns a `BatchBeamSearch` (its own buffer set and hipGraphs - two searches must not share them) over the SAME
+    scorers (weights are read-only), and is driven through the search generator (`_search_run`): the host enqueues a chunk of
+    steps on a lane, moves on to the next lane, and comes back to look at the lane's `done` flags.  The host-side readout of a
+    finished search (D2H + back-trace) overlaps the other lanes' steps as well.
+
+        lanes = SearchLanes([build_beam_search(model, ...) for _ in range(2)], device)
+        lanes.start(k, enc_act, olens, tag)      # on lane k's stream: enqueue the first chunk
+        tag, nbest = lanes.poll(k)               # None while lane k is still searching
+    `lanes.stream(k)` is the stream to run the lane's encoder call on."""
+
+    def __init__(self, searches, device):
+        import torch as _t
+
+        self.searches = list(searches)
+        self.streams = [_t.cuda.Stream(device=device) for _ in self.searches]
+        self.state = [None] * len(self.searches)
+
+    def __len__(self):
+        return len(self.searches)
+
+    def stream(self, k):
+        return self.streams[k]
+
+    def busy(self, k) -> bool:
+        return self.state[k] is not None
+
+    @torch.no_grad()
+    def start(self, k, enc_act, olens, tag=None, maxlenratio: float = 0.0, minlenratio: float = 0.0):
+        assert self.state[k] is None, "lane is busy"
+        with torch.cuda.stream(self.streams[k]):
+            gen = self.searches[k]._search_run(enc_act, olens, maxlenratio, minlenratio)
+            try:
+                req = gen.send(None)
+                self.state[k] = dict(gen=gen, req=req, out=None, tag=tag, args=(enc_act, olens, maxlenratio, minlenratio))
+            except StopIteration as e:  # (a search shorter than one chunk of steps)
+                self.state[k] = dict(gen=None, req=None, out=e.value, tag=tag, args=(enc_act, olens, maxlenratio, minlenratio))
+
+    @torch.no_grad()
+    def poll(self, k):
+        """Look at lane k's `done` flags (waits for the chunk in flight on ITS stream only) and enqueue its next chunk;
+        (tag, n-best lists) once the search has ended, else None."""
+        st = self.state[k]
+        assert st is not None, "lane is idle"
+        with torch.cuda.stream(self.streams[k]):
+            if st["out"] is None:
+                msg = bool(st["req"].all().item())
+                try:
+                    st["req"] = st["gen"].send(msg)
+                    return None
+                except StopIteration as e:
+                    st["out"] = e.value
+            out = st["out"]
+            enc_act, olens, maxr, minr = st["args"]
+            empty = [b for b, h in enumerate(out) if len(h) == 0]
+            if empty and minr >= 0.1:  # the reference's back-off for an utterance that ended no hypothesis (search_batch)
+                idx = torch.tensor(empty, device=enc_act.device)
+                again = self.searches[k].search_batch(enc_act.index_select(0, idx), [olens[b] for b in empty], maxr,
+                                                      max(0.0, minr - 0.1))
+                for b, h in zip(empty, again):
+                    out[b] = h
+        self.state[k] = None
+        return st["tag"], out
+
+
 def build_beam_search(asr_model, beam_size: int, ctc_weight: float, penalty: float,
                       lm_weight: float = 0.0, token_list=None, normalize_length: bool = False, lm=None):
     """Scorer / weight set-up of Speech2Text (espnet2/bin/asr_inference.py:168-176, 310-316,

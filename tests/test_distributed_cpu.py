@@ -431,3 +431,56 @@ def test_diverged_call_sequences_raise_instead_of_duplicating_work():
     assert got[0][0] == got[1][0] == "decode_x_1"            # the call both made met on one key
     for r in range(world):                                   # the diverged one is an error on every rank that waits for it
         assert "diverged" in got[r][1], got
+
+
+def _lanes_worker(rank, world, port, n_units, q):
+    """decode_dynamic_lanes over gloo: three lanes per rank, a unit needs a few polls before it is done (rank 1 twice as many)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from espnet_amd import distributed as D
+
+    B = 2
+    lanes = {}
+    try:
+        def start(k, u):
+            assert k not in lanes
+            lanes[k] = [u, (2 + u % 3) * (1 + rank)]
+
+        def poll(k):
+            import time
+
+            time.sleep(0.004 * (1 + rank))  # (a poll waits for the lane's stream: rank 1's take twice as long)
+            lanes[k][1] -= 1
+            if lanes[k][1] > 0:
+                return None
+            u = lanes.pop(k)[0]
+            toks, scores = fake_decode(u * B, u * B + B)
+            return list(range(u * B, u * B + B)), toks, scores
+
+        dist.barrier()  # (both ranks start claiming together)
+        hyps, mine = D.decode_dynamic_lanes(start, poll, 3, n_units, n_units * B, 8, "cpu")
+        q.put((rank, hyps, mine))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dynamic_dispatch_with_lanes_two_ranks():
+    world, n_units, B = 2, 24, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lanes_worker, args=(r, world, port, n_units, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: (h, m) for r, h, m in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_t, want_s = fake_decode(0, n_units * B)
+    for r in range(world):  # every rank holds the full result in global utterance order
+        assert [t for t, _ in got[r][0]] == want_t
+        assert [s for _, s in got[r][0]] == pytest.approx(want_s)
+    assert sorted(got[0][1] + got[1][1]) == list(range(n_units))  # every unit decoded exactly once
+    assert len(got[0][1]) > len(got[1][1]) > 0  # the rank whose units take a quarter of the time took more of them

@@ -262,6 +262,52 @@ def test_search_batched_equals_single():
             assert abs(float(hs.score) - float(hb.score)) < 1e-3
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_search_lanes_equal_searches_run_alone(dtype):
+    """Round 6, SearchLanes: several joint searches in flight on as many HIP streams (each lane its own buffer set and
+    hipGraph over the SAME scorers) return, bit for bit, what each search returns run alone - five different ragged
+    batches dealt over two lanes and over three, more batches than lanes (a lane is reused), searches of different lengths
+    in flight together (the short one finishes while the long one is mid-way)."""
+    from espnet_amd.nets.batch_beam_search import SearchLanes
+
+    g = load_golden("tiny_beam4_early_eos")
+    sd = golden_state_dict(g)
+    d = g["config"]["encoder_conf"]["output_size"]
+    torch.manual_seed(11)
+    batches = []
+    for lens in ([49, 31, 40], [12], [64, 64], [7, 55, 23, 41], [30, 9]):
+        enc = torch.randn(len(lens), max(lens), d) * 0.5
+        for b, n in enumerate(lens):
+            enc[b, n:] = 0.0
+        batches.append((enc.to(torch.bfloat16 if dtype == "bfloat16" else torch.float32).cuda(), lens))
+    alone_bs = build_search(g, sd, dtype)
+    alone = [alone_bs.search_batch(e, l) for e, l in batches]
+    for n_lanes in (2, 3):
+        lanes = SearchLanes([build_search(g, sd, dtype) for _ in range(n_lanes)], torch.device("cuda"))
+        todo, got, unit_of = list(range(len(batches))), {}, [None] * n_lanes
+        while todo or any(u is not None for u in unit_of):
+            for k in range(n_lanes):
+                if unit_of[k] is None and todo:
+                    u = todo.pop(0)
+                    lanes.start(k, batches[u][0], batches[u][1], tag=u)
+                    unit_of[k] = u
+            for k in range(n_lanes):
+                if unit_of[k] is not None:
+                    r = lanes.poll(k)
+                    if r is not None:
+                        assert r[0] == unit_of[k]
+                        got[r[0]] = r[1]
+                        unit_of[k] = None
+        for u, want in enumerate(alone):
+            assert len(got[u]) == len(want)
+            for hw, hg in zip(want, got[u]):
+                assert len(hw) == len(hg) > 0
+                for a, b in zip(hw, hg):
+                    assert a.yseq.tolist() == b.yseq.tolist()
+                    assert float(a.score) == float(b.score)
+                    assert {k: float(v) for k, v in a.scores.items()} == {k: float(v) for k, v in b.scores.items()}
+
+
 def test_search_structure_invariants():
     """Size-independent properties on a full-size run: every hypothesis starts with <sos>, ends
     with <eos>, has no <eos> inside (unless forced at maxlen), length <= maxlen + 2, and
