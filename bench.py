@@ -185,8 +185,8 @@ def cpu_baseline_beam(model, beam, ctc_weight, budget_s=15.0):
     cores = max(1, min(32, avail))
     torch.set_num_threads(cores)
     times = []
-    t_start = time.perf_counter()
-    i = 0
+    i = -1  # (utterance -1 is the warm-up: thread pool, allocator, first-touch of the weights; not timed)
+    t_start = None
     with torch.no_grad():
         while True:
             wav = synth_batch(9000 + i, 1)
@@ -195,16 +195,19 @@ def cpu_baseline_beam(model, beam, ctc_weight, budget_s=15.0):
                               fe.win_length, 160)
             ob.beam_search(sd, e[0, : int(ol[0])], dec.heads, dec.num_blocks, beam, ctc_weight,
                            sos=VOCAB - 1, eos=VOCAB - 1)
-            times.append(time.perf_counter() - t0)
+            if i >= 0:
+                times.append(time.perf_counter() - t0)
+            else:
+                t_start = time.perf_counter()
             i += 1
-            if time.perf_counter() - t_start > budget_s or len(times) >= 20:
+            if len(times) >= 3 and (time.perf_counter() - t_start > budget_s or len(times) >= 20):
                 break
     med = sorted(times)[len(times) // 2]
     return {"value": round(AUDIO_SEC / med, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
             "cpu_model": _cpu_model(), "reference_measured": REFERENCE_MEASURED["beam"],
             "sample": f"oracle CPU-fp32 port (K/V-cached restatement of Speech2Text beam search), "
                       f"{len(times)} utterances of 10 s, batch 1, median {med:.2f} s/utt "
-                      f"(frontend + encoder + beam {beam} search, 249 steps), no warm-up"}
+                      f"(frontend + encoder + beam {beam} search, 249 steps), one untimed warm-up utterance"}
 
 
 def beam_vs_oracle(model, enc_row, hyps, beam, ctc_weight, noise_seeds=4, noise_sigma=2e-3):
@@ -753,7 +756,7 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, wan
         try:
             key = "bf16_vs_oracle" if args.dtype == "bfloat16" else "f32_vs_oracle"
             res[key] = beam_vs_oracle(model, last["enc0"], last["nbest0"], beam, args.ctc_weight,
-                                      noise_seeds=4 if cpu_base else 0)
+                                      noise_seeds=4 if args.dtype == "bfloat16" else 0)
         except Exception as e:  # noqa: BLE001 - a checker must not cost the line
             res["bf16_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"}
     return res
@@ -773,7 +776,7 @@ def collect_traffic(kernel_substr, args):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", td, "-o", "t", "--output-format", "csv", "--",
-                   sys.executable, str(REPO / "bench.py"), "--quick", "--no-roofline", "--no-cpu-baseline",
+                   sys.executable, str(REPO / "bench.py"), "--quick", "--no-roofline", "--no-cpu-baseline", "--in-flight", "1",
                    "--steps", "3", "--warmup", "2", "--dtype", args.dtype, "--batch", str(args.batch),
                    "--model", args.model]
             env = dict(os.environ, TMPDIR="/tmp", ESPNET_AMD_BENCH_INNER="1")
@@ -820,7 +823,7 @@ def collect_search_traffic(args, B, beam):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", td, "-o", "t", "--output-format", "csv", "--",
-                   sys.executable, str(REPO / "bench.py"), "--workload", "beam", "--no-cpu-baseline", "--steps", "1",
+                   sys.executable, str(REPO / "bench.py"), "--workload", "beam", "--no-cpu-baseline", "--in-flight", "1", "--steps", "1",
                    "--warmup", "0", "--dtype", args.dtype, "--batch", str(B), "--beam", str(beam),
                    "--ctc-weight", str(args.ctc_weight)]
             env = dict(os.environ, TMPDIR="/tmp", ESPNET_AMD_BENCH_INNER="1")
@@ -943,6 +946,7 @@ def rocprof_family_ms(args, model, batch):
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         cmd = [exe, "--kernel-trace", "--stats", "-d", td, "-o", "s", "--output-format", "csv", "--",
                sys.executable, str(REPO / "bench.py"), "--quick", "--no-roofline", "--no-cpu-baseline", "--no-traffic",
+               "--in-flight", "1",  # (one batch in flight: kernels of two streams that overlap in time inflate each other's durations)
                "--steps", "20", "--warmup", "3", "--dtype", args.dtype, "--batch", str(batch), "--model", model]
         env = dict(os.environ, TMPDIR="/tmp", ESPNET_AMD_BENCH_INNER="1")
         try:
@@ -965,7 +969,31 @@ def rocprof_family_ms(args, model, batch):
                  f"itself runs 1-3 % slower than the timed one, so this sum can still sit that much above ms_per_step)")
 
 
-def roofline_object(fam, nprof, bracket_us, peak, wall_s_per_step, traffic, traffic_note, rocprof=None, rocprof_note=None):
+def block_family_algorithmic_bytes(B, T, ff, d=256, L=12, vocab_units=79):
+    """Algorithmic HBM bytes of ONE greedy step's block_kernel launches (256-wide fused path): every operand a
+    launch must read or write once - the f32 residual rows in and out, q (row-major) and K / V^T (Tpad keys per head) bf16,
+    the GLU rows bf16, the position fragments, the launch's weights once - nothing counted twice for the halo or per
+    workgroup.  Returns (bytes per step, launches per step)."""
+    M = B * T
+    Tpad = (T + 255) // 256 * 256
+    x = M * d * 4
+    qkv = 3 * B * Tpad * d * 2
+    glu = M * d * 2
+    w_ffn = 2 * d * ff * 2
+    w_a = w_ffn + 3 * d * d * 2                      # macaron FFN + q | k | v
+    w_c = d * d * 2 + 2 * d * d * 2                  # linear_out + pointwise_conv1
+    w_d = d * d * 2 + w_ffn + 31 * d * 4             # pointwise_conv2 + FFN + depthwise taps
+    npg = 2 * ((T + 31) // 32) + 4 * ((T + 63) // 64) + 2
+    pos = 4 * npg * 2048
+    a = 2 * x + qkv + w_a
+    attc = qkv + pos + 2 * x + glu + w_c
+    da = glu + 2 * x + qkv + w_d + w_a
+    fin = glu + x + M * d * 4 + M * d * 2 + M * 4 + w_d + vocab_units * 64 * d * 2
+    return a + L * attc + (L - 1) * da + fin, 2 * L + 1
+
+
+def roofline_object(fam, nprof, bracket_us, peak, wall_s_per_step, traffic, traffic_note, rocprof=None, rocprof_note=None,
+                    algorithmic_bytes_per_launch=None):
     names = PROF_NAMES()
     net = {t: max(f[0] - f[2] * bracket_us * 1e-3, 1e-9) for t, f in fam.items()}  # ms, net of the event brackets
     tot_ms = sum(net.values())
@@ -978,6 +1006,9 @@ def roofline_object(fam, nprof, bracket_us, peak, wall_s_per_step, traffic, traf
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": None if traffic is None else round(traffic),
         "traffic_source": traffic_note,
+        "algorithmic_bytes_per_launch": None if algorithmic_bytes_per_launch is None else round(algorithmic_bytes_per_launch),
+        "traffic_over_algorithmic": (None if traffic is None or not algorithmic_bytes_per_launch
+                                     else round(traffic / algorithmic_bytes_per_launch, 3)),
         "kernel": names[dom], "launches_per_step": d_n // nprof,
         "avg_launch_us": round(d_ms * 1e3 / d_n, 2),
         "avg_launch_us_with_event_bracket": round(d_gross * 1e3 / d_n, 2),
@@ -1018,6 +1049,55 @@ def roofline_object(fam, nprof, bracket_us, peak, wall_s_per_step, traffic, traf
     elif rocprof_note:
         obj["rocprofv3_source"] = rocprof_note
     return obj
+
+
+# what the probes of box_state() read on the boxes of this round that ran the step at its nominal speed (profiles/r06*)
+BOX_NOMINAL = {"gemm_4096_tflops": 600.0, "copy_gbs": 2500.0, "block_family_avg_launch_us": 36.0}
+
+
+def box_state(dev, roofline):
+    """Is this box in the pool's slow state?  (HISTORY.md C: the same build at 1.0 and at 1.4 - 1.6 ms per step; the weight-
+    streaming kernels run ~1.5x slower there, ALU-bound kernels unchanged.)  Three cheap probes, recorded with the line so that
+    a slow lease is labelled instead of being read as a regression: a 4096^3 bf16 GEMM of the library (MFMA + L2), a 1 GiB
+    device-to-device copy (HBM), and the fused block kernels' own mean launch time from the roofline leg."""
+    from espnet_amd import lib as L
+
+    lib = L.load()
+    n = 4096
+    A = torch.randn(n, n, device=dev).to(torch.bfloat16)
+    W = torch.randn(n, n, device=dev).to(torch.bfloat16)
+    Cm = torch.empty(n, n, dtype=torch.bfloat16, device=dev)
+    ga = L.EmGemmArgs(A=A.data_ptr(), W=W.data_ptr(), C=Cm.data_ptr(), bias=None, M=n, N=n, K=n, lda=n, ldc=n, scale=1.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def gemm():
+        L.check(lib.em_gemm(L.EM_BF16, L.EM_EPI_STORE, L.EM_A_PLAIN, C.byref(ga), L.current_stream_ptr()), "em_gemm")
+
+    for _ in range(3):
+        gemm()
+    e0.record()
+    for _ in range(20):
+        gemm()
+    e1.record()
+    torch.cuda.synchronize()
+    tfl = 2.0 * n ** 3 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 2.0 * src.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst, A, W, Cm
+    blk = roofline.get("avg_launch_us") if "block_kernel" in roofline.get("kernel", "") else None
+    slow = tfl < 0.75 * BOX_NOMINAL["gemm_4096_tflops"] or gbs < 0.75 * BOX_NOMINAL["copy_gbs"] or (
+        blk is not None and blk > 1.25 * BOX_NOMINAL["block_family_avg_launch_us"])
+    return {"state": "slow" if slow else "nominal", "gemm_4096_tflops": round(tfl, 1), "copy_gbs": round(gbs, 1),
+            "block_family_avg_launch_us": blk, "nominal": BOX_NOMINAL,
+            "what": "probes of the pool's slow state (a probe 25 % off its nominal value labels the run `slow`: read the "
+                    "headline as a property of the lease, not of the code)"}
 
 
 def main():
@@ -1229,8 +1309,13 @@ def main():
                 rp, rp_note = rocprof_family_ms(args, args.model, args.batch)
             except Exception as e:  # noqa: BLE001
                 rp, rp_note = None, f"{type(e).__name__}: {e}"
+        alg = None
+        if args.model == "small" and PROF_MATCH()[dom] == "block_kernel":
+            ab, nl = block_family_algorithmic_bytes(B, T, CONFIGS["small"]["ff"])
+            alg = ab / nl
         out["roofline"] = roofline_object(fam, nprof, bracket_us, MFMA_PEAK_TFLOPS[args.dtype], elapsed / args.steps,
-                                          traffic, traffic_note, rp, rp_note)
+                                          traffic, traffic_note, rp, rp_note, algorithmic_bytes_per_launch=alg)
+        out["box_state"] = box_state(dev, out["roofline"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "greedy":
         out["cpu_baseline"] = cpu_baseline(model)
 
@@ -1381,13 +1466,9 @@ def main():
                 def sp(out=None):
                     return m.greedy_ctc_device(m.encode_device(w, ls), out=out)
 
-                def st():
-                    tok_v, len_v, _ = sk.slot()
-                    sp(out=(tok_v, len_v))
-                    sk.commit()
-
-                k = 30
-                t = timed_loop(st, k, 3, barrier, sk.drain)
+                k = 32
+                pp = StepPipeline(dev, pipe.depth) if pipe is not None else None  # (batches in flight as in `value`)
+                t = pipelined_loop(sk, pp, lambda a_, b_: sp(out=(a_, b_)), k, 4)
                 fam = profile_families(sp, 3)
                 brk = event_bracket_us(dev, args.dtype)
                 peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -1411,8 +1492,9 @@ def main():
                         rp, rp_note = None, f"{type(e).__name__}: {e}"
                 r = roofline_object(fam, 3, brk, peak, t / k, traffic, note, rp, rp_note)
                 res = {"value": round(Bl * AUDIO_SEC * k / t, 1), "unit": "audio-s/s", "ms_per_step": round(t / k * 1e3, 3),
-                       "steps": k, "warmup": 3, "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
-                       "config": {"workload": f"{what} encoder + greedy CTC, {Bl} x 10 s utterances per step, V={VOCAB}"}}
+                       "steps": k, "warmup": 4, "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
+                       "config": {"workload": f"{what} encoder + greedy CTC, {Bl} x 10 s utterances per step, V={VOCAB}",
+                                  "batches_in_flight": pp.depth if pp is not None else 1}}
                 if survey_gflop_per_utt:
                     g = survey_gflop_per_utt * Bl
                     res["whole_step_frac_of_mfma_peak"] = round(g * 1e9 / (t / k) / 1e12 / peak, 4)
@@ -1433,6 +1515,21 @@ def main():
                 r.pop("model")
                 el_, tok_ = r.pop("elapsed"), r.pop("tokens")
                 torch.cuda.empty_cache()
+                if cpu and not args.no_cpu_baseline:
+                    # the exact-f32 parity mode of the same search on the same batch: the mode in which every oracle
+                    # hypothesis is in the device n-best
+                    try:
+                        a3 = argparse.Namespace(**vars(a2))
+                        a3.dtype, a3.in_flight = "float32", 1
+                        r3 = run_beam(a3, dev, Bb, 10, 1, 1, cpu_base=False, want_traffic=False, want_oracle=True)
+                        r3.pop("model")
+                        e3 = r3.pop("elapsed")
+                        r["f32_mode"] = {"value": round(Bb * AUDIO_SEC / e3, 1), "unit": "audio-s/s", "ms_per_step": round(e3 * 1e3, 2),
+                                         "ms_per_search_step": r3["search"]["ms_per_search_step"],
+                                         "f32_vs_oracle": r3.get("f32_vs_oracle")}
+                        torch.cuda.empty_cache()
+                    except Exception as e:  # noqa: BLE001
+                        r["f32_mode"] = {"error": f"{type(e).__name__}: {e}"}
                 return {"value": round(Bb * AUDIO_SEC * steps / el_, 1), "unit": "audio-s/s",
                         "ms_per_step": round(el_ / steps * 1e3, 2), "steps": steps, "warmup": 1,
                         "dtype": "bf16" if args.dtype == "bfloat16" else "f32",
@@ -1464,7 +1561,7 @@ def main():
         del model
         torch.cuda.empty_cache()
         guarded("encoder_large_b64", encoder_leg("large", 64, 68.56, "Conformer-large (12x512d, 8 heads, ff 2048)", want_pmc=True))
-        guarded("encoder_ebranchformer_b32", encoder_leg("ebf", 32, None, "E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31)"))
+        guarded("encoder_ebranchformer_b32", encoder_leg("ebf", 32, None, "E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31)", want_pmc=True))
         guarded("beam", beam_leg(16, 6, True))
         guarded("beam_cfg3_per_gpu", beam_leg(64, 4, False))
         guarded("stream", stream_leg)
