@@ -134,8 +134,22 @@ class Speech2Text:
         enqueue the next batch first and format this one while the GPU runs.  The beam search polls the
         device between step chunks and therefore completes inside this call."""
         if not self.ctc_greedy:
-            res = self.batch_decode(speech, speech_lengths)
-            return _Done(res)
+            # Round 6: two joint searches in flight (espnet_amd.nets.batch_beam_search.SearchLanes) - this batch is encoded
+            # and its search started on a free lane's stream, the handle's `.result()` drives the lanes until it has ended.
+            # A caller that submits batch n + 1 before it asks for batch n (the decode CLI does) keeps both lanes busy.
+            lanes = self.__dict__.get("_lanes")
+            if lanes is None:
+                from espnet_amd.nets.batch_beam_search import SearchLanes
+
+                lanes = self._lanes = SearchLanes([self.beam_search, self.beam_search.clone()], self.device)
+            k = lanes.free_lane()
+            if k is None:  # (both lanes carry searches nobody has asked for yet: finish this one on the calling stream)
+                return _Done(self.batch_decode(speech, speech_lengths))
+            with torch.cuda.stream(lanes.stream(k)):
+                speech = speech.to(self.device, torch.float32, non_blocking=True)
+                st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths], isolate=True)
+            lanes.start(k, st.enc_act, st.olens, tag=(st, speech), maxlenratio=self.maxlenratio, minlenratio=self.minlenratio)
+            return _PendingBeam(self, lanes, k)
         speech = speech.to(self.device, torch.float32, non_blocking=True)
         st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths], isolate=True)
         tokens, tlens = self.decode_greedy_device(st)
@@ -194,6 +208,19 @@ class _Done:
         self._res = res
 
     def result(self):
+        return self._res
+
+
+class _PendingBeam:
+    """A batch whose joint search is in flight on lane `k` of the Speech2Text's `SearchLanes`."""
+
+    def __init__(self, s2t, lanes, k):
+        self.s2t, self.lanes, self.k, self._res = s2t, lanes, k, None
+
+    def result(self):
+        if self._res is None:
+            _tag, hyps = self.lanes.wait(self.k)
+            self._res = [self.s2t._format(h[: self.s2t.nbest]) for h in hyps]
         return self._res
 
 

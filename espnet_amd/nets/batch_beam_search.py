@@ -79,6 +79,15 @@ class BeamSearch:
 
 
 class BatchBeamSearch(BeamSearch):
+    def clone(self):
+        """Another search object over the SAME scorers and weights with its own buffer sets and hipGraphs: what a second
+        search in flight needs (`SearchLanes`)."""
+        import copy
+
+        c = copy.copy(self)
+        c._bufs, c._graphs = {}, {}
+        return c
+
     # ------------------------------------------------------------------ buffers
     def _alloc(self, dev, act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl, lm=None, online=False):
         key = (str(dev), act, B, W, V, T, Tpad, NC, Lmax, cap, d, ff, nl,
@@ -356,6 +365,7 @@ class SearchLanes:
         self.searches = list(searches)
         self.streams = [_t.cuda.Stream(device=device) for _ in self.searches]
         self.state = [None] * len(self.searches)
+        self.ready = {}  # results finished while another lane was being waited for (`wait`)
 
     def __len__(self):
         return len(self.searches)
@@ -402,6 +412,24 @@ class SearchLanes:
                     out[b] = h
         self.state[k] = None
         return st["tag"], out
+
+    def free_lane(self):
+        """Index of an idle lane, or None."""
+        for k, st in enumerate(self.state):
+            if st is None and k not in self.ready:
+                return k
+        return None
+
+    def wait(self, k):
+        """(tag, n-best lists) of lane k's search.  While waiting, the OTHER busy lanes are polled as well - a lane that is not
+        polled stops after the chunk of steps it has enqueued - and what they finish is kept for their own `wait`."""
+        while k not in self.ready:
+            for j in range(len(self.state)):
+                if self.state[j] is not None and j not in self.ready:
+                    r = self.poll(j)
+                    if r is not None:
+                        self.ready[j] = r
+        return self.ready.pop(k)
 
 
 def build_beam_search(asr_model, beam_size: int, ctc_weight: float, penalty: float,
