@@ -19,7 +19,7 @@ EmSwitches read_switches() {
   s.no_sa_tree = on("ESPNET_AMD_NO_SA_TREE"); s.sa_tree_min_rows = num("ESPNET_AMD_SA_TREE_MIN_ROWS", 200);
   s.no_attn2_large = on("ESPNET_AMD_NO_ATTN2_LARGE"); s.no_ffn_rows = on("ESPNET_AMD_NO_FFN_ROWS");
   s.no_rows_ctc = on("ESPNET_AMD_NO_ROWS_CTC"); s.frontend_v1 = on("ESPNET_AMD_FRONTEND_V1");
-  s.gemm_stages = num("ESPNET_AMD_GEMM_STAGES", 0); s.no_mid_gemm = on("ESPNET_AMD_NO_MID_GEMM");
+  s.gemm_stages = num("ESPNET_AMD_GEMM_STAGES", 0); s.gemm_bm = num("ESPNET_AMD_GEMM_BM", 0); s.no_mid_gemm = on("ESPNET_AMD_NO_MID_GEMM");
   s.mid_tile = num("ESPNET_AMD_MID_TILE", 0); s.lng_rt = num("ESPNET_AMD_LNG_RT", 0); s.lng_wide = num("ESPNET_AMD_LNG_WIDE", 256);
   s.no_src_lnq = on("ESPNET_AMD_NO_SRC_LNQ"); s.no_tail_fusion = on("ESPNET_AMD_NO_TAIL_FUSION");
   s.stream_no_fused = on("ESPNET_AMD_STREAM_NO_FUSED"); s.stream_mha_v1 = on("ESPNET_AMD_STREAM_MHA_V1");

@@ -527,7 +527,8 @@ int launch(const EmGemmArgs* p, hipStream_t s) {
   ConvGeom g{p->T1, p->F1, p->T2, p->F2, p->d, p->conv_k > 0 ? p->conv_k : 3, p->conv_s > 0 ? p->conv_s : 2};
   const int nb = em_cdiv(p->N, 128);
   // fewer than ~1.5 workgroups per CU at BM=128 -> halve the M tile to fill the 256 CUs
-  const bool small = (long)nb * em_cdiv(p->M, 128) < 384;
+  const int force_bm = em_sw().gemm_bm;
+  const bool small = force_bm ? force_bm == 64 : (long)nb * em_cdiv(p->M, 128) < 384;
   // Stages of the LDS ring.  A long K walked by at most ~two workgroups per CU has nothing else to hide a tile's memory
   // latency behind: four stages (96 / 128 KiB of LDS, one workgroup per CU) - the embedding Linear, K = 19 d: 46.0 ->
   // 40.7 us at d = 256, 82.8 -> 72.3 at d = 512 (profiles/r03t_gemm_bench.txt).  Short K (the d x d and d x 4 d

@@ -13,7 +13,7 @@ struct EmSwitches {
   int sa_tree_min_rows;                                              // ESPNET_AMD_SA_TREE_MIN_ROWS (default 200)
   bool no_attn2_large, no_ffn_rows, no_rows_ctc;                     // ESPNET_AMD_NO_ATTN2_LARGE / _NO_FFN_ROWS / _NO_ROWS_CTC
   bool frontend_v1;                                                  // ESPNET_AMD_FRONTEND_V1
-  int gemm_stages;                                                   // ESPNET_AMD_GEMM_STAGES (0: automatic)
+  int gemm_stages, gemm_bm;                                          // ESPNET_AMD_GEMM_STAGES / _GEMM_BM (0: automatic; 64 | 128: the M tile)
   bool no_mid_gemm;                                                  // ESPNET_AMD_NO_MID_GEMM
   int mid_tile, lng_rt, lng_wide;                                    // ESPNET_AMD_MID_TILE / _LNG_RT (0: automatic) / _LNG_WIDE (256)
   bool no_src_lnq, no_tail_fusion;                                   // ESPNET_AMD_NO_SRC_LNQ / _NO_TAIL_FUSION
