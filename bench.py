@@ -645,6 +645,8 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, wan
     model = ASRTask.build_model(model_config("large", args.dtype)).to(dev).eval()
     bs = build_beam_search(model, beam_size=beam, ctc_weight=args.ctc_weight, penalty=0.0,
                            token_list=model.token_list)
+    if os.environ.get("BENCH_STEP_CHUNK"):  # developer probe: label steps enqueued between two polls of the `done` flags
+        bs.step_chunk = int(os.environ["BENCH_STEP_CHUNK"])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     wav = synth_batch(rank * B, B).to(dev)
@@ -685,8 +687,7 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, wan
         # host-side readout of a finished search overlaps the other lane's steps.
         from espnet_amd.nets.batch_beam_search import SearchLanes
 
-        lanes = SearchLanes([bs] + [build_beam_search(model, beam_size=beam, ctc_weight=args.ctc_weight, penalty=0.0,
-                                                      token_list=model.token_list) for _ in range(depth - 1)], dev)
+        lanes = SearchLanes([bs] + [bs.clone() for _ in range(depth - 1)], dev)
 
         def lane_start(k, u):
             with torch.cuda.stream(lanes.stream(k)):
