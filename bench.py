@@ -435,50 +435,44 @@ def cpu_baseline_stream(model, enc_conf, budget_s=8.0):
                       f"forward_infer, no decoding), {len(times)} utterances of 10 s, median {med:.2f} s/utt"}
 
 
-def pick_copy_stream(dev, host, dst, candidates=6):
-    """A copy stream that really runs beside the compute stream.  HIP deals its streams onto a handful of hardware queues, and a
-    copy stream that lands on the compute stream's queue is executed IN that queue's order: the copy of batch k + 1, submitted
-    behind the kernels of step k, then starts when step k has finished and step k + 1 waits for it - the whole copy (0.42 ms for
-    20.5 MB) lands in the step.  Which queue a new stream gets is not in the API; profiles/r06g_h2d_probe.txt shows the same
-    feeder at 1.04 and at 1.39 ms per step in one process, depending on the streams created before it.  So: try a few streams,
-    time a copy beside ~1 ms of kernels on the compute stream, keep the stream with the least serialisation."""
-    work = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+def pick_copy_stream(dev, host, bufs, candidates=6, beside=None, trial_steps=24):
+    """A copy stream that really runs beside the compute stream(s).  HIP deals its streams onto a handful of hardware queues, and
+    a copy stream that shares a queue with a stream the steps (or the record ring's flush) run on is executed IN that queue's
+    order: the copy of a later batch then starts when the steps submitted before it have finished, and the whole copy (0.42 ms
+    for 20.5 MB) lands in the step.  Which queue a new stream gets is not in the API; profiles/r06g_h2d_probe.txt shows the same
+    feeder at 1.04 and at 1.39 ms per step in one process, depending on the streams created before it.  So every candidate
+    runs a short trial of the feeder's OWN event pattern (acquire -> ~0.5 ms of kernels on the step's stream -> release ->
+    prefetch, steps dealt to the streams of `beside` as the timed loop deals them) and the stream with the shortest trial
+    stays.  (Round 6, first form: a copy timed beside free-running kernels - it did not see the bad pairings of the pipelined
+    loop, where the copy stream must avoid three other queues.)"""
+    beside = list(beside) if beside else [torch.cuda.current_stream()]
+    work = [torch.empty(48 << 20, dtype=torch.float32, device=dev) for _ in beside]
 
-    def compute():
-        for _ in range(6):
-            work.mul_(1.0)
-
-    def timed(fn):
+    def trial(st):
+        fd = HostFeeder.__new__(HostFeeder)
+        fd._init(host, bufs, st)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        fn()
+        for k in range(trial_steps):
+            x = beside[k % len(beside)]
+            with torch.cuda.stream(x):
+                fd.acquire()
+                for _ in range(4):
+                    work[k % len(beside)].mul_(1.0)
+                fd.release()
         torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        return (time.perf_counter() - t0) / trial_steps
 
-    compute()
-    tc = min(timed(compute) for _ in range(3))
     best, report = None, []
     for _ in range(candidates):
         st = torch.cuda.Stream(device=dev)
-
-        def both():
-            compute()
-            with torch.cuda.stream(st):
-                dst.copy_(host, non_blocking=True)
-
-        def copy_only():
-            with torch.cuda.stream(st):
-                dst.copy_(host, non_blocking=True)
-
-        copy_only()
-        tx = min(timed(copy_only) for _ in range(2))
-        t = min(timed(both) for _ in range(3))
-        extra = t - max(tc, tx)
-        report.append(round(extra * 1e3, 3))
-        if best is None or extra < best[0]:
-            best = (extra, st)
+        trial(st)
+        t = min(trial(st) for _ in range(2))
+        report.append(round(t * 1e3, 3))
+        if best is None or t < best[0]:
+            best = (t, st)
     del work
-    return best[1], {"extra_ms_per_candidate": report, "compute_ms": round(tc * 1e3, 3)}
+    return best[1], {"trial_ms_per_step_per_candidate": report}
 
 
 class StepPipeline:
@@ -560,16 +554,19 @@ class HostFeeder:
     k + nbuf - 1 is issued on a copy stream when batch k is released, i.e. it runs under the compute of the nbuf - 1 batches in
     front of it (nbuf = batches in flight + 1)."""
 
-    def __init__(self, wav_host, dev, nbuf=2):
-        self.host = wav_host.pin_memory()
-        self.n = nbuf
-        self.bufs = [torch.empty_like(wav_host, device=dev) for _ in range(nbuf)]
-        self.copy_stream, self.stream_probe = pick_copy_stream(dev, self.host, self.bufs[0])
-        self.copied = [torch.cuda.Event() for _ in range(nbuf)]
-        self.consumed = [None] * nbuf
-        self._consumed_ev = [torch.cuda.Event() for _ in range(nbuf)]  # (re-recorded every step: no event creation in the loop)
+    def __init__(self, wav_host, dev, nbuf=2, beside=None):
+        host = wav_host.pin_memory()
+        bufs = [torch.empty_like(wav_host, device=dev) for _ in range(nbuf)]
+        st, self.stream_probe = pick_copy_stream(dev, host, bufs, beside=beside)
+        self._init(host, bufs, st)
+
+    def _init(self, host, bufs, copy_stream):
+        self.host, self.bufs, self.n, self.copy_stream = host, bufs, len(bufs), copy_stream
+        self.copied = [torch.cuda.Event() for _ in bufs]
+        self.consumed = [None] * self.n
+        self._consumed_ev = [torch.cuda.Event() for _ in bufs]  # (re-recorded every step: no event creation in the loop)
         self.k = 0
-        for slot in range(nbuf - 1):
+        for slot in range(self.n - 1):
             self._prefetch(slot)
 
     def _prefetch(self, slot):
@@ -1207,33 +1204,37 @@ def main():
         lens = [N_SAMPLES] * B
         T = model.encoder.output_frames(1 + N_SAMPLES // 160)
         sink = sink_factory(B, T)
-        feeder = HostFeeder(wav_host, dev) if args.h2d else None
+        pipe = StepPipeline(dev, args.in_flight) if args.in_flight > 1 else None
+        feeder = (HostFeeder(wav_host, dev, nbuf=(pipe.depth if pipe is not None else 1) + 1,
+                             beside=pipe.streams if pipe is not None else None) if args.h2d else None)
 
         def step_plain(src=None, out=None):
             st = model.encode_device(wav if src is None else src, lens)
             return model.greedy_ctc_device(st, out=out)
 
-        pipe = StepPipeline(dev, args.in_flight) if args.in_flight > 1 and feeder is None else None
-
-        def step():
-            tok_v, len_v, _ = sink.slot()
+        def body(tok_v, len_v):
             if feeder is not None:
                 step_plain(feeder.acquire(), out=(tok_v, len_v))
                 feeder.release()
-            elif pipe is not None:
+            else:
+                step_plain(out=(tok_v, len_v))
+
+        def step():
+            tok_v, len_v, _ = sink.slot()
+            if pipe is not None:
                 # (a macro-batch of the record ring = RING_STEPS steps dealt round-robin to the streams; the ring half is
                 # flushed - all-gather + D2H on the main stream - behind all of them, and rewritten only behind its flush)
                 half = (sink.k // RING_STEPS) & 1
                 if sink.k % RING_STEPS == 0:
                     pipe.fork(half)
-                pipe.run(lambda: step_plain(out=(tok_v, len_v)))
+                pipe.run(lambda: body(tok_v, len_v))
                 if (sink.k + 1) % RING_STEPS == 0:
                     pipe.join()
                     sink.commit()
                     pipe.flushed(half)
                     return
             else:
-                step_plain(out=(tok_v, len_v))
+                body(tok_v, len_v)
             sink.commit()
 
         def finish():
@@ -1384,8 +1385,9 @@ def main():
 
         def pcie_leg():
             depth = pipe.depth if pipe is not None else 1
-            fd = HostFeeder(wav_host, dev, nbuf=depth + 1)
             pp = StepPipeline(dev, depth) if depth > 1 else None
+            # (the copy stream must run beside EVERY stream the steps run on: probed against them, not against this stream)
+            fd = HostFeeder(wav_host, dev, nbuf=depth + 1, beside=pp.streams if pp is not None else None)
 
             def body(tok_v, len_v):
                 step_plain(fd.acquire(), out=(tok_v, len_v))

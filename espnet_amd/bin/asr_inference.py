@@ -150,16 +150,26 @@ class Speech2Text:
                 st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths], isolate=True)
             lanes.start(k, st.enc_act, st.olens, tag=(st, speech), maxlenratio=self.maxlenratio, minlenratio=self.minlenratio)
             return _PendingBeam(self, lanes, k)
-        speech = speech.to(self.device, torch.float32, non_blocking=True)
-        st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths], isolate=True)
-        tokens, tlens = self.decode_greedy_device(st)
-        tok_h = torch.empty(tokens.shape, dtype=tokens.dtype).pin_memory()
-        len_h = torch.empty(tlens.shape, dtype=tlens.dtype).pin_memory()
-        tok_h.copy_(tokens, non_blocking=True)
-        len_h.copy_(tlens, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        return _PendingGreedy(self, tok_h, len_h, ev, (tokens, tlens, st))
+        # (round 6: consecutive batches go to alternating HIP streams - every kernel of the greedy step takes the whole chip,
+        # but one stream's launch fills the boundary between two dependent launches of the other: DESIGN.md 4g)
+        pair = self.__dict__.get("_greedy_streams")
+        if pair is None:
+            pair = self._greedy_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            self._greedy_turn = 0
+        stream = pair[self._greedy_turn & 1]
+        self._greedy_turn += 1
+        stream.wait_stream(torch.cuda.current_stream())  # (whatever produced `speech` on the caller's stream)
+        with torch.cuda.stream(stream):
+            speech = speech.to(self.device, torch.float32, non_blocking=True)
+            st = self.asr_model.encode_device(speech, [int(n) for n in speech_lengths], isolate=True)
+            tokens, tlens = self.decode_greedy_device(st)
+            tok_h = torch.empty(tokens.shape, dtype=tokens.dtype).pin_memory()
+            len_h = torch.empty(tlens.shape, dtype=tlens.dtype).pin_memory()
+            tok_h.copy_(tokens, non_blocking=True)
+            len_h.copy_(tlens, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return _PendingGreedy(self, tok_h, len_h, ev, (tokens, tlens, st, speech))
 
     def decode_greedy_device(self, st):
         """Device-resident G1 result: (tokens (B,T) i32 padded with -1, token_lens (B,) i32)."""

@@ -46,7 +46,7 @@ case "$what" in
     unset ESPNET_AMD_SPLIT_ATT
     echo "== stamps"; EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep -E "block<65>" | tail -3 | cut -c1-600 | tee "$out/block_stamps.txt"
     echo "== kernel table"
-    stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10 | cut -c1-200
+    stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 100 --warmup 10 | cut -c1-200
     f=$(find "$out/prof_greedy" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/bench_small_b32_kernel_stats.csv" ;;
   r05a|r05b)  # round 5: kernel tests of the changed kernels, LayerNorm hand-over with the weight requests dealt into it (A/B against
             # lib_v32 = requests in one cluster), frontend v2 (A/B against ESPNET_AMD_FRONTEND_V1), fine stamps, kernel table, launch
@@ -123,7 +123,7 @@ PY
     for v in 0 1; do
       if [ $v = 1 ]; then export ESPNET_AMD_ATTN2_NOPIPE=1; else unset ESPNET_AMD_ATTN2_NOPIPE; fi
       echo "== nopipe=$v small"; stats "$out/prof_small_$v" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 50 --warmup 5 | grep -E "relpos" | sed 's/.*)",/  /'
-      echo "== nopipe=$v large"; stats "$out/prof_large_$v" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 | grep -E "relpos" | sed 's/.*)",/  /'
+      echo "== nopipe=$v large"; stats "$out/prof_large_$v" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 20 --warmup 3 | grep -E "relpos" | sed 's/.*)",/  /'
     done 2>&1 | tee "$out/ab_attn_kernel_tables.txt"
     for f in small_0 small_1 large_0 large_1; do echo -n "$f: "; grep -h "relpos_attn" "$out"/prof_$f/*kernel_stats.csv | sed 's/.*)",//'; done | tee -a "$out/ab_attn_kernel_tables.txt"
     unset ESPNET_AMD_ATTN2_NOPIPE
@@ -133,7 +133,7 @@ PY
     done 2>&1 | tee "$out/ab_small.txt"
     unset ESPNET_AMD_ATTN2_NOPIPE ;;
   search640)  # label step at configs[3]'s per-GPU shape (64 x beam 10 = 640 rows): kernel table
-    stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic | cut -c1-200
+    stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic | cut -c1-200
     f=$(find "$out/search640_stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" | cut -c1-220 > "$out/search640_kernel_stats_head.txt" ;;
   sweep640)  # label step at 640 rows under the dispatch switches that were tuned at 160 rows
     B64=${B64:-64}
@@ -151,14 +151,14 @@ PY
       echo -n "[B=$b no_tree=$v] "; bl $b
     done; done 2>&1 | tee "$out/ab_tree.txt"
     unset ESPNET_AMD_NO_SA_TREE
-    stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic | cut -c1-200 | head -8 ;;
+    stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic | cut -c1-200 | head -8 ;;
   parity)   # round 4: the new bf16 parity tests (prints = the measured epsilons), box state, the large encoder's kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tee "$out/box_state.txt"
     echo "== new parity tests"
     (time timeout 900 python -m pytest -q -s tests/test_gpu_search.py tests/test_gpu_online_search.py tests/test_gpu_fullsize.py tests/test_gpu_e2e.py \
        -k "peaked or bf16 or midmargin or structure or lm_scorer_bf16 or restarts" > "$out/pytest_parity_full.txt" 2>&1; grep -E "^\[|passed|failed|Error|assert " "$out/pytest_parity_full.txt" | cut -c1-260 | tail -60) 2>&1 | tee "$out/pytest_parity.txt"
     echo "== large encoder B=64: kernel stats"
-    stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3
+    stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 20 --warmup 3
     echo "== default bench"; (time timeout 900 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5 ;;
   r04b)     # stream pool, RecordRing / dynamic dispatch on the GPU (two ranks on one GPU through gloo), parity prints, GEMM stage A/B
     echo "== stream pool + new parity"
@@ -181,7 +181,7 @@ PY
     done
     unset ESPNET_AMD_FOLD
     echo "== stamps"; ESPNET_AMD_FOLD=1 EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "block<7>" | tail -2 | tee "$out/block_stamps.txt"
-    echo "== kernel stats"; stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10
+    echo "== kernel stats"; stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 100 --warmup 10
     echo "== large b64"; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180 ;;
   fold-stamps)  # sub-stage stamps of all four waves of one workgroup of block<7> (developer build lib_fine.so)
     ESPNET_AMD_LIB=$R/espnet_amd/lib/dbg/lib_fine.so ESPNET_AMD_FOLD=1 EM_BLOCK_STAMPS=1 timeout 120 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps 2 --warmup 1 2>&1 < /dev/null | grep "block<7>" | tail -8 | tee "$out/block_stamps_fine.txt" ;;
@@ -195,7 +195,7 @@ PY
       echo -n "no_attn2_large=$v: "; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180
     done
     unset ESPNET_AMD_NO_ATTN2_LARGE
-    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
+    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 20 --warmup 3 ;;
   sub2-large)  # round 4: the fused conv1 + conv2 kernel at d = 512 (two launches of 256 output channels)
     echo "== tests"; timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_e2e.py -q -x -k "sub12 or large or conv2d" 2>&1 | tail -4 | tee "$out/pytest.txt"
     for v in 1 0 1 0; do
@@ -203,7 +203,7 @@ PY
       echo -n "no_sub12=$v: "; timeout 200 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 30 --warmup 3 2>/dev/null < /dev/null | cut -c100-180
     done
     unset ESPNET_AMD_NO_SUB12
-    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
+    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 20 --warmup 3 ;;
   ffn-rows)  # round 4: the 512-wide model's feed-forward modules as row-block launches (csrc/ffn_rows.hip)
     echo "== tests"; timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_e2e.py tests/test_gpu_search.py -q -x \
        -k "ffn_rows or large" 2>&1 | tail -6 | tee "$out/pytest.txt"
@@ -213,7 +213,7 @@ PY
     done
     unset ESPNET_AMD_NO_FFN_ROWS
     echo "== stamps"; EM_FFN_STAMPS=1 timeout 120 python bench.py --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 1 --warmup 1 2>&1 < /dev/null | grep "ffn_rows<" | tail -4 | tee "$out/ffn_stamps.txt"
-    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3 ;;
+    echo "== kernel stats"; stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 20 --warmup 3 ;;
   ffn-dbg)  # round 4: where ffn_rows_kernel's time goes: developer builds without MFMAs / weight requests / LDS operand reads, stamps
     bash tools/build_block_variants.sh ffn2 ffn4 ffn6 ffn8 > /dev/null 2>&1
     for v in "" 2 4 6; do
@@ -252,14 +252,14 @@ PY
     echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -4 | tee "$out/smoke.txt"
     echo "== default bench"; (time timeout 900 python bench.py 2>"$out/bench_default.err" < /dev/null | tee "$out/bench_default.json" | cut -c1-300) 2>&1 | tail -5
     echo "== rocprofv3 kernel stats, greedy"
-    stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 100 --warmup 10
+    stats "$out/prof_greedy" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 100 --warmup 10
     if [ "$what" = full ]; then
       echo "== box state (TCC counters)"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tail -12 | tee "$out/box_state.txt"
       echo "== rocprofv3 kernel stats, large B=64"
-      stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --steps 20 --warmup 3
+      stats "$out/prof_large" python "$R/bench.py" --model large --batch 64 --quick --no-traffic --no-roofline --no-cpu-baseline --in-flight 1 --steps 20 --warmup 3
       echo "== E-Branchformer"; timeout 300 python bench.py --model ebf --quick --no-traffic --no-cpu-baseline --steps 50 --warmup 5 2>/dev/null < /dev/null | tee "$out/bench_ebf.json" | cut -c1-200
-      echo "== search kernel stats"; stats "$out/search_stats" python "$R/bench.py" --workload beam --steps 1 --warmup 1 --no-cpu-baseline --no-traffic
-      echo "== search kernel stats, 640 rows (configs[3] per GPU)"; stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic
+      echo "== search kernel stats"; stats "$out/search_stats" python "$R/bench.py" --workload beam --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic
+      echo "== search kernel stats, 640 rows (configs[3] per GPU)"; stats "$out/search640_stats" python "$R/bench.py" --workload beam --batch 64 --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic
       echo "== configs[3] per GPU with HBM traffic of the label step"; timeout 600 python bench.py --workload beam --batch 64 --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null < /dev/null | tee "$out/bench_beam_b64.json" | cut -c1-300
     fi ;;
   sub2)
@@ -269,7 +269,7 @@ PY
     echo "== kernel stats"; stats "$out/stats" python "$R/bench.py" --quick --no-traffic --no-roofline --no-cpu-baseline --steps 50 --warmup 5
     echo "== bench"; timeout 200 python bench.py --quick --no-traffic --no-cpu-baseline --steps 600 --warmup 30 2>/dev/null < /dev/null | tee "$out/bench_quick.json" | cut -c1-260 ;;
   search-stats)
-    stats "$out/search_stats" python "$R/bench.py" --workload beam --steps 1 --warmup 1 --no-cpu-baseline --no-traffic ;;
+    stats "$out/search_stats" python "$R/bench.py" --workload beam --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic ;;
   search-pmc)
     cmd="python $R/bench.py --workload beam --steps 1 --warmup 1 --no-cpu-baseline"
     cd /tmp
