@@ -103,7 +103,7 @@ def margin_report(tag, margins_at_mismatch):
     return float(m.max()) if m.size else 0.0
 
 
-@pytest.mark.parametrize("fused", [True, False, "fold"])
+@pytest.mark.parametrize("fused", [True, False, "fold", "split"])
 @pytest.mark.parametrize("name", ["small_ragged", "small_10s", "large_10s"])
 def test_encode_bfloat16_within_tolerance(name, fused):
     """bf16 MFMA mode (the timed mode), both launch sequences: the fused per-block kernels (csrc/block.hip; they
@@ -114,6 +114,7 @@ def test_encode_bfloat16_within_tolerance(name, fused):
     model = build(g, "bfloat16")
     model.encoder.fused = bool(fused)
     model.encoder.fold_c = fused == "fold"  # block<C|D|...> (round 4; ragged batch: utterance boundaries inside the halo)
+    model.encoder.split_att = fused == "split"  # attention + block<C> as two launches (rounds 2-5); default (round 6): block<ATT|C>
     speech, lens = golden_speech(g)
     st = model.encode_device(speech.cuda(), lens.tolist())
     ke = int(g["enc_keep_every"])
@@ -203,7 +204,8 @@ def test_large_peaked_posteriors_ids_exact(B, fused):
     assert (ids.cpu() == ids[:1].cpu()).all()
 
 
-@pytest.mark.parametrize("dtype,fused", [("float32", False), ("bfloat16", True), ("bfloat16", False), ("bfloat16", "fold")])
+@pytest.mark.parametrize("dtype,fused", [("float32", False), ("bfloat16", True), ("bfloat16", False), ("bfloat16", "fold"),
+                                         ("bfloat16", "split")])
 def test_peaked_posteriors_tokens_exact(dtype, fused):
     """`small_10s_peaked`: the small model with a CTC head fitted to the reference's encoder output (reference
     top-2 margins all > 1, tests/golden/make_golden.py::fit_peaked_ctc_head).  With posteriors like a trained
@@ -214,6 +216,7 @@ def test_peaked_posteriors_tokens_exact(dtype, fused):
     model = build(g, dtype)
     model.encoder.fused = bool(fused)
     model.encoder.fold_c = fused == "fold"  # block<C|D|...>: the two-launch sequence (EM_ENC_FOLD_C)
+    model.encoder.split_att = fused == "split"  # relpos_attn2 + block<C> (EM_ENC_SPLIT_ATT) instead of block<ATT|C>
     speech, lens = golden_speech(g)
     st = model.encode_device(speech.cuda(), lens.tolist())
     ids, tokens, tlens = model.greedy_ctc_device(st)
@@ -244,6 +247,26 @@ def test_fused_blocks_match_per_operator_sequence_bf16():
             d = (a - b).abs()
             print(f"[{name}] fused vs per-operator bf16: max {d.max():.3e} mean {d.mean():.3e}")
             assert d.max() < 0.08 and d.mean() < 6e-3
+
+
+def test_position_rows_packed_by_the_host_or_by_the_call_are_the_same():
+    """block<ATT|C> reads the position rows fragment-major.  `ConformerEncoder._pos_projected` packs them once per length behind
+    the projected table (EM_ENC_POS_PACKED); a caller that hands over the projected table alone - or the raw table - has
+    `em_conformer_encode` pack them per call: same launch sequence, bit-identical encoder outputs and CTC ids, ragged batch."""
+    g = load_golden("small_ragged")
+    model = build(g, "bfloat16")
+    speech, lens = golden_speech(g)
+    enc = model.encoder
+    st = model.encode_device(speech.cuda(), lens.tolist())
+    ref_out, ref_ids = st.enc_out.clone(), model.greedy_ctc_device(st)[0].clone()
+    orig = enc._pos_projected
+    try:
+        enc._pos_projected = lambda T, dev, pk, pos: orig(T, dev, pk, pos).clone()  # (a clone carries no `_em_packed` mark)
+        st2 = model.encode_device(speech.cuda(), lens.tolist())
+        assert torch.equal(st2.enc_out, ref_out)
+        assert torch.equal(model.greedy_ctc_device(st2)[0], ref_ids)
+    finally:
+        enc._pos_projected = orig
 
 
 def test_reference_api_encode_and_ctc():
