@@ -9,7 +9,10 @@ A "step" = one pass of the hot path over one batch of synthetic utterances alrea
 HBM: HIP STFT/log-mel frontend -> HIP Conformer encoder (fused block kernels) -> greedy CTC (G1)
 decode -> the hypotheses of ALL ranks collated by `espnet_amd.distributed.RecordRing` (fixed-shape records
 written in place into a device ring; ONE RCCL all-gather when N > 1 and ONE pinned, asynchronous device->host
-copy per 16 steps, delivered while the next steps run, all K delivered inside the timed region).  Workload =
+copy per 16 steps, delivered while the next steps run, all K delivered inside the timed region).  Round 6: `--in-flight 2`
+(default) deals the K steps to two HIP streams - utterance batches are independent, every kernel takes the whole chip, and one
+stream's launch fills the boundary between two dependent launches of the other (`StepPipeline`; `one_stream` in the line is the
+same loop with one batch in flight); `ms_per_step` = timed region / K, i.e. per batch.  Workload =
 BASELINE.json configs[1]: Conformer-small (12 x 256d, 4 heads, ff 1024), batch 32 x 10 s @ 16 kHz per
 GPU (weak scaling: per-GPU batch fixed).  Random-init weights (torch.manual_seed(0)), synthetic
 N(0, 0.1^2) waveforms.
@@ -24,8 +27,9 @@ HBM peak), `encoder_large_b64` (the Conformer-large encoder at configs[3]'s per-
 traffic of its dominant one), `encoder_ebranchformer_b32` (the E-Branchformer encoder with its roofline),
 `beam` (configs[2] with the roofline of the search and `bf16_vs_oracle`: per-token error, best-score loss beside the
 oracle search's own path noise, token edit distance), `beam_cfg3_per_gpu` (configs[3]'s per-GPU batch on one GPU,
-with `bf16_vs_oracle`) and `stream` (configs[4] + the 40 ms-per-call stress case).  `--quick` keeps only the
-main line, `roofline` and `cpu_baseline`.
+with `bf16_vs_oracle`; both beam legs with two joint searches in flight, `SearchLanes`) and `stream` (configs[4] + the 40 ms-per-call
+stress case); `box_state` (three probes of the pool's slow state: a slow lease is labelled, not read as a regression).  `--quick`
+keeps only the main line, `roofline` and `cpu_baseline`.
 """
 import argparse
 import csv
