@@ -506,12 +506,13 @@ class StepPipeline:
             return time.perf_counter() - t0
 
         cand = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
-        one = min(wall([cand[0]]) for _ in range(3))
-        chosen = [cand[0]]
-        for st in cand[1:]:
+        main = torch.cuda.current_stream()  # (the record ring is flushed there, behind the step streams: keep its queue apart too)
+        one = min(wall([main]) for _ in range(3))
+        chosen = []
+        for st in cand:
             if len(chosen) == depth:
                 break
-            if min(wall(chosen + [st]) for _ in range(2)) < 1.35 * one:  # runs beside every stream chosen so far
+            if min(wall([main] + chosen + [st]) for _ in range(2)) < 1.35 * one:  # runs beside every stream chosen so far
                 chosen.append(st)
         note = {"streams_side_by_side": len(chosen), "asked": depth}
         while len(chosen) < depth:  # (no such stream found: still correct, just no overlap)
