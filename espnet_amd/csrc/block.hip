@@ -1474,11 +1474,10 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       // the bias of unit u + 1 is requested while unit u computes: a global load issued next to its use would
       // put its L2 latency into every one of the 79 intervals
       float4 bnext = *(const float4*)(a.ctc_b + ncol);
-      auto ctc_unit = [&](const WF& w, int u) __attribute__((always_inline)) {
-        const float4 bb = bnext;
-        bnext = *(const float4*)(a.ctc_b + (u + 1 < NU ? u + 1 : u) * 64 + ncol);
-        f32x4 c[2];
-        mma_k(w, false, c);
+      // Software-pipelined by one unit (round 6): the 16 MFMAs of unit u are issued FIRST, the arg-max update of unit u - 1
+      // (bias, compare, select: ~40 VALU instructions that need nothing of unit u) runs while they execute.  As one dependent
+      // body per unit - MFMAs, wait for them, update - the walk took ~760 cycles per unit for 256 of MFMA.
+      auto ctc_update = [&](const f32x4 (&c)[2], const float4 bb, int u) __attribute__((always_inline)) {
         const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -1491,15 +1490,29 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
             }
           }
       };
+      f32x4 cprev[2] = {(f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}, (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}};
+      float4 bprev = make_float4(0.f, 0.f, 0.f, 0.f);
+      int uprev = 0;  // (the first update sees -inf everywhere: nothing is taken)
 #pragma unroll 1
       for (int u0 = 0; u0 < NU; u0 += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int u = u0 + j;
           read_unit(a.ctc_w, u + 3 < NU ? u + 3 : NU - 1, ring[(j + 3) & 3]);  // unconditional: see ffn()
-          if (u < NU) ctc_unit(ring[j], u);
+          if (u < NU) {
+            const float4 bb = bnext;
+            bnext = *(const float4*)(a.ctc_b + (u + 1 < NU ? u + 1 : u) * 64 + ncol);
+            f32x4 c[2];
+            mma_k(ring[j], false, c);
+            ctc_update(cprev, bprev, uprev);
+            cprev[0] = c[0];
+            cprev[1] = c[1];
+            bprev = bb;
+            uprev = u;
+          }
         }
       }
+      ctc_update(cprev, bprev, uprev);
       float* const cred = red0 + (nln & 1) * 256;  // [4 waves][32 frames] value, then label
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
