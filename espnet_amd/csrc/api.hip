@@ -24,7 +24,8 @@ EmSwitches read_switches() {
   s.no_src_lnq = on("ESPNET_AMD_NO_SRC_LNQ"); s.no_tail_fusion = on("ESPNET_AMD_NO_TAIL_FUSION");
   s.stream_no_fused = on("ESPNET_AMD_STREAM_NO_FUSED"); s.stream_mha_v1 = on("ESPNET_AMD_STREAM_MHA_V1");
   s.stream_no_ctx_fold = on("ESPNET_AMD_STREAM_NO_CTX_FOLD"); s.stream_no_ln_gemm = on("ESPNET_AMD_STREAM_NO_LN_GEMM");
-  s.stream_fused_min = num("ESPNET_AMD_STREAM_FUSED_MIN", 8); s.no_sub12 = on("ESPNET_AMD_NO_SUB12");
+  s.stream_fused_min = num("ESPNET_AMD_STREAM_FUSED_MIN", 1); s.no_sub12 = on("ESPNET_AMD_NO_SUB12");
+  s.stream_ffn_split = num("ESPNET_AMD_STREAM_FFN_SPLIT", 0);
   return s;
 }
 std::atomic<const EmSwitches*> g_sw{nullptr};

@@ -134,7 +134,27 @@ __device__ __forceinline__ void em_static_for(F&& f) {
 // KWT: depthwise-conv kernel width (D part).  RELU: the feed-forward activation is ReLU (the contextual-block streaming
 // encoder, contextual_block_conformer_encoder.py:148-154) instead of Swish; the conv module's Swish is unaffected.
 template <int MODE, int KWT = 31, bool RELU = false>
-__global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long long* __restrict__ stamps) {
+__global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a_in, long long* __restrict__ stamps) {
+  // Round 6, streaming (RELU) instantiations with a.ffn_split = S > 1: the FFN's hidden dimension is dealt to S workgroups
+  // per 32-row block (grid z): each streams 1 / S of w_1 / w_2 and leaves its partial sum in memory; the LAST of them to
+  // arrive (a ticket: nobody ever waits) adds the S partial sums in split order and carries the rows on.  A tick of a few
+  // streams runs every launch on a few of the chip's 256 CUs, each streaming the whole 2 MiB of an FFN through ONE CU.
+  const EmBlockArgs& a = a_in;
+  const void *ffm_w1 = a_in.ffm_w1, *ffm_w2 = a_in.ffm_w2, *ff_w1 = a_in.ff_w1, *ff_w2 = a_in.ff_w2;
+  const float *ffm_b1g = a_in.ffm_b1g, *ff_b1g = a_in.ff_b1g;
+  int nsplit = 1;
+  if constexpr (RELU) {
+    nsplit = a_in.ffn_split > 1 ? a_in.ffn_split : 1;
+    if (nsplit > 1) {
+      const int nch_all = ((a_in.ff >> 6) + 1) & ~1, nch_s = nch_all / nsplit, sidx = blockIdx.z;
+      const size_t wo = (size_t)sidx * nch_s * UNIT;  // (w_1: nch_s units; w_2: nch_s / 2 pairs of 2 units: the same bytes)
+      if (ffm_w1) { ffm_w1 = (const unsigned char*)ffm_w1 + wo; ffm_w2 = (const unsigned char*)ffm_w2 + wo; }
+      if (ff_w1) { ff_w1 = (const unsigned char*)ff_w1 + wo; ff_w2 = (const unsigned char*)ff_w2 + wo; }
+      if (ffm_b1g) ffm_b1g += sidx * nch_s * 64;
+      if (ff_b1g) ff_b1g += sidx * nch_s * 64;
+    }
+  }
+  bool ffn_exit = false;  // (RELU, split: this workgroup was not the last to arrive at an FFN's meeting point)
   constexpr int KW = KWT, HALF = KWT / 2, TROWS = BM + KWT - 1;
   static_assert(KWT == 31 || KWT == 15, "depthwise conv width");
   constexpr int dbg = EM_BLOCK_DBG;
@@ -182,7 +202,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
   const int swz = lr & 7;
   // byte offset of (frame lr, columns ncol .. ncol + 3) inside a [32][64] bf16 k-tile of abuf (+ 2048 for frame 16 + lr)
   const int tile_wr = lr * 128 + (((2 * nf + (lg >> 1)) ^ swz) << 4) + (lg & 1) * 8;
-  const int nch = ((a.ff >> 6) + 1) & ~1;  // 64-wide chunks of the FFN hidden dimension, rounded up to whole PAIRS (the host pads with a zero chunk)
+  // 64-wide chunks of the FFN hidden dimension, rounded up to whole PAIRS (the host pads with a zero chunk); with a split
+  // FFN (streaming instantiations) this workgroup's share of them
+  const int nch = (((a.ff >> 6) + 1) & ~1) / nsplit;
   // developer profiling (EM_BLOCK_STAMPS / EM_BLOCK_DBG, tools/block_bench.py): stage-level cycle stamps of thread 0
   // of workgroup (0, 0); dbg 1 = no MFMA / epilogue work, dbg 2 = no DMA
   int nts = 0;
@@ -196,13 +218,16 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       if (stamps && blockIdx.x == 3 && blockIdx.y == 5 && lane == 0 && nts < 64)
         stamps[wave * 64 + nts] = ((long long)code << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffll);
     } else {
-      if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nts < 64)
-        stamps[nts] = ((long long)code << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffll);
+      if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z < 4 && tid == 0 && nts < 64)  // (split FFN: a row per share)
+        stamps[blockIdx.z * 64 + nts] = ((long long)code << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffll);
     }
     ++nts;
   };
   auto fstamp = [&](int code) __attribute__((always_inline)) {  // sub-stage stamps: fine builds only
     if constexpr (EM_BLOCK_FINE) stamp(code);
+  };
+  auto rstamp = [&](int code) __attribute__((always_inline)) {  // ... and the streaming instantiations (FFN h0 / loop / meeting point: 20, 21, 23, 24)
+    if constexpr (EM_BLOCK_FINE || RELU) stamp(code);
   };
   stamp(1);
   int nbar = 0;  // barriers passed
@@ -446,12 +471,12 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       }
       if (HAS_D) {
         take(a.pw2, 16);
-        take(a.ff_w1, nch * 4);
-        take(a.ff_w2, nch * 4);
+        take(ff_w1, nch * 4);
+        take(ff_w2, nch * 4);
       }
       if (HAS_A) {
-        take(a.ffm_w1, nch * 4);
-        take(a.ffm_w2, nch * 4);
+        take(ffm_w1, nch * 4);
+        take(ffm_w2, nch * 4);
         take(a.wqkv, 48);
       }
       if (CTC) take(a.ctc_w, a.ctc_units * 4);
@@ -635,7 +660,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // every wave holds its activation fragments and has read the conv weights: ABUF / WK may receive partial sums
     // from a wave that finishes early (the only barrier of the FFN besides the reduction's)
     bar(0);
-    fstamp(20);
+    rstamp(20);
     // The requests are UNCONDITIONAL (past the end they repeat the last unit, which nobody waits for): a load under
     // a branch makes hipcc's wait-count pass assume it may not have been issued, and every wait for an older load
     // degrades to "wait for everything" - the whole point of the ring.
@@ -654,10 +679,11 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     mma_w2(ring[2], 0, hb);                                    // the last pair
     mma_w2(ring[3], 1, hb);
     after();
-    fstamp(21);
+    rstamp(21);
     // ---- the four partial sums meet: wave w keeps the output fragments f = 4 f4 + w (its columns of the residual
     // layout) and hands the other twelve to their owners through 8 KiB slots (destination, source); summed in wave
     // order 0, 1, 2, 3 whatever the arrival order: deterministic
+    float4 psum[2][4];  // (split FFN, streaming instantiations: this share's partial sum)
     auto reduce_as = [&](auto nfc) __attribute__((always_inline)) {
       constexpr int NF = decltype(nfc)::value;
 #pragma unroll
@@ -685,6 +711,12 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
             sum = first ? v : sum + v;
             first = false;
           }
+          if constexpr (RELU) {
+            if (nsplit > 1) {  // (split FFN: the partial sum of THIS workgroup's share; finished below, behind the meeting point)
+              psum[mi][f4] = make_float4(sum[0], sum[1], sum[2], sum[3]);
+              continue;
+            }
+          }
           xr[mi][f4] = xpark[(mi * 4 + f4) * NT];
           xr[mi][f4].x += scale * (sum[0] + b4.x);
           xr[mi][f4].y += scale * (sum[1] + b4.y);
@@ -699,6 +731,110 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
       case 1: reduce_as(std::integral_constant<int, 1>{}); break;
       case 2: reduce_as(std::integral_constant<int, 2>{}); break;
       default: reduce_as(std::integral_constant<int, 3>{}); break;
+    }
+    if constexpr (RELU) {
+      if (nsplit > 1) {
+        // ---- the S shares of this row block meet.  Publish: plain stores of the partial sum (lane-major, as the residual is
+        // parked), barrier, ONE lane releases at agent scope and takes a ticket; the workgroup that draws the last ticket
+        // acquires, resets the ticket for the next launch and sums the S partial sums in split order (whatever the arrival
+        // order: deterministic); the others are done.  Nobody waits for anybody: no deadlock whatever the residency.
+        // (MI355X_MICROARCH.md, "valid forms": plain stores -> __syncthreads -> lane-0 release fence -> drained -> relaxed
+        // agent atomic; consumer: one agent acquire -> __syncthreads -> plain loads.)
+        const int wg = b * (int)gridDim.x + (int)blockIdx.x;
+        float4* const part = (float4*)a.ffn_part + ((size_t)wg * nsplit) * 8 * NT;
+        float4* const mine = part + (size_t)blockIdx.z * 8 * NT + tid;
+        constexpr bool SEAM_PLAIN = (EM_BLOCK_VAR & 1024) != 0, SEAM_FENCED = (EM_BLOCK_VAR & (1024 | 2048)) != 0;
+        auto put = [&](float4* p, const float4& v) __attribute__((always_inline)) {
+          if constexpr (SEAM_PLAIN) {
+            *p = v;
+          } else {  // agent-scope relaxed stores (sc1: written through this XCD's L2)
+            __hip_atomic_store((unsigned long long*)p, ((const unsigned long long*)&v)[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((unsigned long long*)p + 1, ((const unsigned long long*)&v)[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        };
+        auto get = [&](const float4* p) __attribute__((always_inline)) -> float4 {
+          if constexpr (SEAM_PLAIN) {
+            return *p;
+          } else {  // agent-scope relaxed loads (sc1: past whatever this XCD's L2 holds of an earlier launch's partial sums)
+            unsigned long long w[2];
+            w[0] = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w[1] = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float4 v;
+            __builtin_memcpy(&v, w, 16);
+            return v;
+          }
+        };
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int f4 = 0; f4 < 4; ++f4) put(mine + (mi * 4 + f4) * NT, psum[mi][f4]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (acknowledged: at the memory side for the sc1 stores)
+        bar(0);
+        int* const flag = (int*)(red0 + 480);  // (a word of the LayerNorm exchange area nobody uses at this point)
+        if (tid == 0) {
+          if constexpr (SEAM_FENCED) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          const int t = __hip_atomic_fetch_add(a.ffn_ticket + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (t == nsplit - 1) {
+            __hip_atomic_store(a.ffn_ticket + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every share has arrived
+            if constexpr (SEAM_FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          *flag = t;
+        }
+        bar(0);
+        if (*flag != nsplit - 1) {
+          ffn_exit = true;
+          return;
+        }
+        rstamp(23);
+        // (every partial sum of a row half requested before the first is added: one trip to memory per half instead of S - the
+        // shares were written by other XCDs, nothing of them is in this one's L2; profiles/r06u_stream_stamps.txt)
+        auto sum_shares = [&](auto SC) __attribute__((always_inline)) {
+          constexpr int SU = decltype(SC)::value;  // shares read per batch (0: any S, one at a time)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            float4 tot[4];
+#pragma unroll
+            for (int f4 = 0; f4 < 4; ++f4) tot[f4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (SU > 0) {
+              float4 v[SU][4];
+#pragma unroll
+              for (int sp = 0; sp < SU; ++sp)
+#pragma unroll
+                for (int f4 = 0; f4 < 4; ++f4) v[sp][f4] = get(part + ((size_t)sp * 8 + (mi * 4 + f4)) * NT + tid);
+#pragma unroll
+              for (int sp = 0; sp < SU; ++sp)
+#pragma unroll
+                for (int f4 = 0; f4 < 4; ++f4) {
+                  tot[f4].x += v[sp][f4].x; tot[f4].y += v[sp][f4].y; tot[f4].z += v[sp][f4].z; tot[f4].w += v[sp][f4].w;
+                }
+            } else {
+              for (int sp = 0; sp < nsplit; ++sp)
+#pragma unroll
+                for (int f4 = 0; f4 < 4; ++f4) {
+                  const float4 v = get(part + ((size_t)sp * 8 + (mi * 4 + f4)) * NT + tid);
+                  tot[f4].x += v.x; tot[f4].y += v.y; tot[f4].z += v.z; tot[f4].w += v.w;
+                }
+            }
+#pragma unroll
+            for (int f4 = 0; f4 < 4; ++f4) {
+              const float4 b4 = *(const float4*)(pb + b2o + 64 * f4 + ncol);
+              xr[mi][f4] = xpark[(mi * 4 + f4) * NT];
+              xr[mi][f4].x += scale * (tot[f4].x + b4.x);
+              xr[mi][f4].y += scale * (tot[f4].y + b4.y);
+              xr[mi][f4].z += scale * (tot[f4].z + b4.z);
+              xr[mi][f4].w += scale * (tot[f4].w + b4.w);
+              if (repark) xpark[(mi * 4 + f4) * NT] = xr[mi][f4];
+            }
+          }
+        };
+        if (nsplit == 2) sum_shares(std::integral_constant<int, 2>{});
+        else if (nsplit == 4) sum_shares(std::integral_constant<int, 4>{});
+        else sum_shares(std::integral_constant<int, 0>{});
+        rstamp(24);
+      }
     }
   };
   // x += (W . act + bias): four K units (N = 256), requested by k_pre(w, 4)
@@ -1411,22 +1547,25 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     // G0: [pw2 bias 256][norm_ff g 256][b 256]; G1: [ff b1 1024][ff b2 256][norm_final g 256][b 256]
     // pointwise_conv2 + residual (convolution.py:77, encoder_layer.py:149-158); the ring goes over to the feed-forward module
     proj_resid(pb0, 0, a.pw2, [&](int j) {
-      if (j == 0) read_unit(a.ff_w1, 0, ring[0]);
-      else if (j == 1) read_unit(a.ff_w1, 1, ring[1]);
-      else if (j == 2) read_w2(a.ff_w2, 0, 0, ring[2]);
-      else read_w2(a.ff_w2, 0, 1, ring[3]);
+      if (j == 0) read_unit(ff_w1, 0, ring[0]);
+      else if (j == 1) read_unit(ff_w1, 1, ring[1]);
+      else if (j == 2) read_w2(ff_w2, 0, 0, ring[2]);
+      else read_w2(ff_w2, 0, 1, ring[3]);
     });
     stamp(10);
     ln_to_act(pb0, 256, 512, 0);                   // norm_ff
     stamp(15);
     // x += 0.5 * FFN(norm_ff(x))   (encoder_layer.py:160-168); with an A part behind it the ring goes over to the macaron module
     if constexpr (HAS_A)
-      ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false, a.ff_b1g, a.ffm_w1, [&] {
-        read_w2(a.ffm_w2, 0, 0, ring[2]);
-        read_w2(a.ffm_w2, 0, 1, ring[3]);
+      ffn(pb1, 0, 1024, 0.5f, ff_w1, ff_w2, false, ff_b1g, ffm_w1, [&] {
+        read_w2(ffm_w2, 0, 0, ring[2]);
+        read_w2(ffm_w2, 0, 1, ring[3]);
       });
     else
-      ffn(pb1, 0, 1024, 0.5f, a.ff_w1, a.ff_w2, false, a.ff_b1g, nullptr, [] {});
+      ffn(pb1, 0, 1024, 0.5f, ff_w1, ff_w2, false, ff_b1g, nullptr, [] {});
+    if constexpr (RELU) {
+      if (ffn_exit) return;  // (split FFN: another share of this row block carries the rows on)
+    }
     stamp(22);
     {
       float4 y[2][4];
@@ -1593,12 +1732,15 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a, long 
     } else {
       touch();
       ln_to_act_pre(pa0, 0, 256, 0,
-                    [&] { read_unit(a.ffm_w1, 0, ring[0]); read_unit(a.ffm_w1, 1, ring[1]); read_w2(a.ffm_w2, 0, 0, ring[2]); }, std::integral_constant<int, 24>{},
-                    [&] { read_w2(a.ffm_w2, 0, 1, ring[3]); }, std::integral_constant<int, 8>{});
+                    [&] { read_unit(ffm_w1, 0, ring[0]); read_unit(ffm_w1, 1, ring[1]); read_w2(ffm_w2, 0, 0, ring[2]); }, std::integral_constant<int, 24>{},
+                    [&] { read_w2(ffm_w2, 0, 1, ring[3]); }, std::integral_constant<int, 8>{});
     }
     stamp(15);
     // x += 0.5 * FFN_macaron(norm_ff_macaron(x))  (encoder_layer.py:108-121); the ring goes over to the q / k / v projections
-    ffn(pa0, 512, 1536, 0.5f, a.ffm_w1, a.ffm_w2, true, a.ffm_b1g, a.wqkv, [&] { read_unit(a.wqkv, 2, ring[2]); });
+    ffn(pa0, 512, 1536, 0.5f, ffm_w1, ffm_w2, true, ffm_b1g, a.wqkv, [&] { read_unit(a.wqkv, 2, ring[2]); });
+    if constexpr (RELU) {
+      if (ffn_exit) return;
+    }
     stamp(22);
     // (x is stored at the very END of the kernel, from its LDS parking place: its eight 16-byte stores per lane, issued
     // in front of the q / k / v weight requests, sat in the same in-order count the waits for those requests use and
@@ -1704,10 +1846,10 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
       }
       ncu = ncu_of[dev];
     }
-    const long nwg = (long)gx * a->B;
-    if (nwg < ncu) helper_rows = (int)((ncu - nwg) / gx);
+    const long nwg = (long)gx * a->B * (RELU && a->ffn_split > 1 ? a->ffn_split : 1);
+    if (nwg < ncu) helper_rows = (int)((ncu - nwg) / ((long)gx * (RELU && a->ffn_split > 1 ? a->ffn_split : 1)));
   }
-  dim3 grid(gx, a->B + helper_rows);
+  dim3 grid(gx, a->B + helper_rows, RELU && a->ffn_split > 1 ? a->ffn_split : 1);
   static long long* stamps = nullptr;
   const bool want_stamps = em_sw().block_stamps;
   if (want_stamps && !stamps) hipMalloc((void**)&stamps, 256 * sizeof(long long));
@@ -1717,7 +1859,7 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
     long long h[256];
     hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
     const long long M56 = 0xffffffffffffffll;
-    for (int wv = 0; wv < (EM_BLOCK_FINE ? 4 : 1); ++wv) {
+    for (int wv = 0; wv < (EM_BLOCK_FINE ? 4 : grid.z > 1 ? (int)(grid.z < 4 ? grid.z : 4) : 1); ++wv) {  // (waves, or the shares of a split FFN)
       printf("[block<%d> wave %d stamps code:cycles since entry]", MODE, wv);
       for (int i = 0; i < 64 && h[wv * 64 + i]; ++i)
         printf(" %d:%lld", (int)(h[wv * 64 + i] >> 56), (h[wv * 64 + i] & M56) - (h[wv * 64] & M56));
@@ -1762,6 +1904,10 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   if (!relu && a->ff > 1024 && (need_a || need_d)) return EM_ERR_UNSUPPORTED;  // (the C part has no FFN)
   if (relu && ((need_a && !a->ffm_b1g) || (need_d && !a->ff_b1g))) return EM_ERR_BAD_ARG;  // (these instantiations always read it there)
   if (relu && mode != EM_BLOCK_A && mode != EM_BLOCK_D) return EM_ERR_UNSUPPORTED;  // (the instantiations that exist)
+  if (a->ffn_split > 1 && (need_a || need_d)) {  // split FFN (streaming instantiations): whole pairs of 64-wide chunks per share; a launch without an FFN ignores it
+    const int nch_all = ((a->ff >> 6) + 1) & ~1;
+    if (!relu || a->ffn_split > 16 || nch_all % (2 * a->ffn_split) != 0 || !a->ffn_part || !a->ffn_ticket) return EM_ERR_BAD_ARG;
+  }
   if (!relu && mode == EM_BLOCK_D) return EM_ERR_UNSUPPORTED;
   if (need_a) {
     if (!a->ffm_w1 || !a->ffm_w2 || !a->wqkv || !a->qh || !a->kh || !a->vt) return EM_ERR_BAD_ARG;

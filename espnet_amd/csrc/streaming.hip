@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void stream_pos_enc_kernel(const float* __rest
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct CbWs {
-  size_t xn, big, g, g2, ctx, qh, kh, vt, total;
+  size_t xn, big, g, g2, ctx, qh, kh, vt, part, ticket, total;
   int Tpad;
 };
 inline CbWs cb_layout(int dtype, const EmConformerWeights* w, int M) {
@@ -366,6 +366,25 @@ inline CbWs cb_layout(int dtype, const EmConformerWeights* w, int M) {
 }
 // ... plus the per-head operands of the fused layer (bf16, d = 256: csrc/block.hip): q / k [n_blk][4][Tpad][64],
 // V^T [n_blk][4][64][Tpad] with Tpad = the 32-row workgroups' reach
+// Shares of an FFN's hidden dimension per 32-row block in the fused streaming layers (EmBlockArgs.ffn_split, round 6).  A tick
+// of a few streams runs every launch on a few of the chip's 256 CUs, each pushing the whole 2 MiB of an FFN through ONE CU's
+// MFMA pipes (~8 us of a ~20 us launch); S workgroups per row block take 1 / S of it each and meet once (a store, a ticket,
+// the last one sums: 3 - 5 us, growing with S).  Measured per call of 12 layers (profiles/r06t_stream_split_sweep.txt):
+//   streams (row blocks)   1 (2)   8 (16)   16 (32)   32 (64)   64 (128)
+//   S = 1                  926     941      941       945       946   us
+//   S = 2                  788     807      846       874      1029
+//   S = 4                  720     772      840       996      1430
+//   S = 8                  742     826     1030      1429      2184
+// so: 4 up to 32 row blocks, 2 up to 64, 1 beyond; whole pairs of 64-wide chunks per share.
+// ESPNET_AMD_STREAM_FFN_SPLIT=n: developer switch (1 = off, n = forced).
+inline int cb_ffn_split(const EmConformerWeights* w, int row_blocks) {
+  const int forced = em_sw().stream_ffn_split;
+  const int pairs = (((w->ff >> 6) + 1) & ~1) / 2;
+  int S = forced > 0 ? forced : row_blocks <= 32 ? 4 : row_blocks <= 64 ? 2 : 1;
+  if (S > 16) S = 16;
+  while (S > 1 && pairs % S != 0) --S;
+  return S;
+}
 inline CbWs cb_layout_fused(int dtype, const EmConformerWeights* w, int n_blk, int L) {
   CbWs s = cb_layout(dtype, w, n_blk * L);
   s.Tpad = (L + 63) / 64 * 64;
@@ -374,16 +393,21 @@ inline CbWs cb_layout_fused(int dtype, const EmConformerWeights* w, int n_blk, i
   s.qh = o; o += align_up(per_head);
   s.kh = o; o += align_up(per_head);
   s.vt = o; o += align_up(per_head);
+  // split FFN of the row-block launches (round 6, EmBlockArgs.ffn_split): partial sums [row blocks][S][8192] f32 + tickets
+  const int nrb = n_blk * ((L + 31) / 32), S = cb_ffn_split(w, nrb);
+  s.part = o; o += S > 1 ? align_up((size_t)nrb * S * 8192 * 4) : 0;
+  s.ticket = o; o += S > 1 ? align_up((size_t)nrb * 4) : 0;
   s.total = o;
   return s;
 }
 // Which streaming layers take the fused launch sequence: bf16, 256 wide, 4 heads, conv width 15, ff <= 4096 in whole
 // chunk pairs, blocks of at most 64 slots, every layer packed for it by the host.
-// ... and at least FUSED_MIN_BLOCKS blocks in the call (a batch of streams, or a long one-shot input).  A workgroup of
-// the fused kernels ingests ALL of a layer's 5 MB of weights through one CU: with one block (one stream, one call) that
-// is two workgroups on an otherwise empty chip - 1.47 ms per call against 1.15 for the per-operator sequence, whose GEMMs
-// spread every weight matrix over a hundred CUs - while 32 blocks fill 64 CUs and the tick drops from 1.83 to 1.44 ms
-// (profiles/r04i_stream_fused_ab.txt).  ESPNET_AMD_STREAM_FUSED_MIN=n: developer A/B switch.
+// Rounds 4 and 5 also asked for at least 8 blocks in the call: a workgroup of the fused kernels pushes ALL of a layer's 5 MB of
+// weights through one CU, and with one block (one stream, one call) that was two workgroups on an otherwise empty chip - 1.47 ms
+// per call against 1.15 for the per-operator sequence, whose GEMMs spread every weight matrix over a hundred CUs
+// (profiles/r04i_stream_fused_ab.txt; equal in round 5 with the helper workgroups).  Round 6: with each FFN dealt to four
+// workgroups per row block (cb_ffn_split) the fused layers win from one block on - 720 us against 870 per call
+// (profiles/r06t_stream_split_sweep.txt) - and the floor is gone.  ESPNET_AMD_STREAM_FUSED_MIN=n: developer A/B switch.
 inline bool cb_fusable(int dtype, const EmConformerWeights* w, int L, int n_blk) {
   const bool off = em_sw().stream_no_fused;  // developer A/B switch
   const int min_blk = em_sw().stream_fused_min;
@@ -544,6 +568,13 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
     // before it writes and is safe in place, so an aliased call keeps it)
     const bool fold_ctx = mask_mode && n_blk_s == 1 && past_ctx && next_ctx && past_ctx != next_ctx && !em_sw().stream_no_ctx_fold;
     ba.row_stride = NL * d;
+    // Round 6: a tick that leaves CUs idle deals each FFN's hidden dimension to S workgroups per row block (cb_ffn_split;
+    // csrc/block.hip, "the S shares of this row block meet").  The tickets start at zero and every launch leaves them there.
+    const int ffn_s = cb_ffn_split(w, n_blk * ((L + 31) / 32));
+    if (ffn_s > 1) {
+      ba.ffn_split = ffn_s; ba.ffn_part = (float*)(ws + s.part); ba.ffn_ticket = (int32_t*)(ws + s.ticket);
+      if (hipMemsetAsync(ba.ffn_ticket, 0, (size_t)n_blk * ((L + 31) / 32) * 4, (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
+    }
     for (int l = 0; l < NL; ++l) {
       const EmConformerLayer& q = w->layers[l];
       ba.ffm_w1 = q.ffm_w1p; ba.ffm_w2 = q.ffm_w2p; ba.wqkv = q.wqkvp; ba.ffm_b1g = q.ffm_b1; ba.params = q.fp_a;

@@ -452,6 +452,14 @@ typedef struct EmBlockArgs {
    * With EM_BLOCK_ATT, `pos` is em_relpos_pack_pos_bf16's table of THIS block ([4 heads][ldp fragments][2][64][8] bf16)
    * and ldp = em_relpos_pos_fragments(T). */
   int32_t kv_frag;
+  /* EM_BLOCK_RELU (streaming layers), ffn_split = S > 1 (round 6): the FFN's hidden dimension is dealt to S workgroups per
+   * 32-row block; each leaves its partial sum in ffn_part and takes a ticket from ffn_ticket, the last to arrive adds the
+   * partial sums in split order and carries the rows through the rest of the launch (nobody waits).  ff / 64 rounded up to
+   * an even number must be a multiple of 2 S.  ffn_part: [B * ceil(T / 32)][S][8192] f32 scratch; ffn_ticket: [B * ceil(T / 32)]
+   * i32, ZERO before the first launch (every launch leaves it zero).  S <= 1: off. */
+  int32_t ffn_split;
+  float* ffn_part;
+  int32_t* ffn_ticket;
 } EmBlockArgs;
 int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
 /* Position rows for EM_BLOCK_ATT: pall [2T-1][ldp] bf16 holds linear_pos of L blocks side by side (block l at columns

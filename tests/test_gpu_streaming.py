@@ -63,8 +63,7 @@ def test_streaming_fused_layers_match_per_operator_sequence():
 
     from espnet_amd import lib as _L
 
-    os.environ["ESPNET_AMD_STREAM_FUSED_MIN"] = "1"  # (read once by the library: by default calls of fewer than 8 blocks
-    # keep the per-operator sequence - one stream's single block is faster there; this test wants the fused kernels)
+    os.environ.pop("ESPNET_AMD_STREAM_FUSED_MIN", None)  # (rounds 4 - 5: calls of fewer than 8 blocks kept the per-operator sequence)
     _L.load().em_dev_switches_reload()
     g = load_stream_golden("stream_small_6s")
     feats = stream_feats(int(g["utt_id"]), int(g["n_samples"]))
@@ -319,6 +318,54 @@ def test_batch_tick_context_hand_over_in_the_block_launches_equals_its_own_launc
     assert (folded[0] - folded[1]).abs().max().item() > 0.1  # (different utterances)
     err = np.abs(folded[0][:: int(g["keep_every"])].numpy() - g["ys"])
     assert err.max() < 0.2 and err.mean() < 0.02, (err.max(), err.mean())
+
+
+@pytest.mark.parametrize("n_streams", [1, 8, 24])
+def test_split_ffn_of_the_block_launches(n_streams):
+    """Round 6: a tick that leaves CUs idle deals each FFN's hidden dimension to S workgroups per 32-row block (grid z of
+    block<A | RELU> / block<D | RELU>, EmBlockArgs.ffn_split; csrc/streaming.hip `cb_ffn_split`: 4 shares up to 32 row blocks,
+    2 up to 64): each leaves the partial sum of its share in the workspace and the LAST to arrive adds them in split order.
+    Only the order of an f32 sum changes (contextual_block_encoder_layer.py:218-222, 280-284 are the FFNs): against the
+    unsplit launches (ESPNET_AMD_STREAM_FFN_SPLIT=1) within bf16 round-off of the layers behind it, the same bits on a second
+    run whatever the arrival order, also at 8 and 16 shares (2 chunks of 64 each: the shortest stream the ring runs), and
+    stream 0 within the bf16 tolerance of the reference fixture."""
+    import os
+
+    from espnet_amd import lib as _L
+
+    g = load_stream_golden("stream_small_6s")
+    n, cf = int(g["n_samples"]), int(g["chunk_frames"])
+    feats = torch.stack([stream_feats(int(g["utt_id"]) + s, n) for s in range(n_streams)])
+    enc = build(g, "bfloat16")
+    assert enc._fusable()
+
+    def run(split):
+        if split is None:
+            os.environ.pop("ESPNET_AMD_STREAM_FFN_SPLIT", None)
+        else:
+            os.environ["ESPNET_AMD_STREAM_FFN_SPLIT"] = str(split)
+        _L.load().em_dev_switches_reload()
+        outs, state, pos, T = [], None, 0, feats.size(1)
+        while pos < T:
+            nxt = min(T, pos + cf)
+            y, y_len, state = enc.forward_infer_batch(feats[:, pos:nxt].cuda(), state, is_final=(nxt == T))
+            outs.append(y)
+            pos = nxt
+        return torch.cat(outs, 1).cpu()
+
+    try:
+        whole = run(1)
+        for split in (None, 8, 16):
+            a, b = run(split), run(split)
+            assert torch.equal(a, b), f"split {split}: not repeatable"
+            d = (a - whole).abs()
+            print(f"[split FFN {split or 'automatic'}, {n_streams} streams] max {d.max().item():.3e} mean {d.mean().item():.3e}")
+            assert d.max().item() < 8e-2 and d.mean().item() < 4e-3, split
+            err = np.abs(a[0][:: int(g["keep_every"])].numpy() - g["ys"])
+            assert err.max() < 0.2 and err.mean() < 0.02, (split, err.max(), err.mean())
+    finally:
+        os.environ.pop("ESPNET_AMD_STREAM_FFN_SPLIT", None)
+        _L.load().em_dev_switches_reload()
 
 
 def test_batch_call_equals_single_streams(tmp_path):

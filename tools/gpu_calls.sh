@@ -31,6 +31,24 @@ stats() {  # <dir> <cmd...>: rocprofv3 --kernel-trace --stats of a command, summ
 beam_line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['search']['ms_per_search_step'])"; }
 quick() { timeout 300 python bench.py --quick --no-traffic --no-roofline --no-cpu-baseline --steps ${1:-600} --warmup 30 2>/dev/null < /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s', d['ms_per_step'], 'ms/step')"; }
 case "$what" in
+  r06t)  # round 6: split FFN of the streaming row-block launches (EmBlockArgs.ffn_split): streaming + block tests, the sweep
+         # over streams x shares, in-call A/B (ESPNET_AMD_STREAM_FFN_SPLIT=1 + _FUSED_MIN=8 is round 5's form), 1 / 32 / 128 streams
+    echo "== tests"
+    (timeout 900 python -m pytest -q -x tests/test_gpu_streaming.py tests/test_gpu_online_search.py tests/test_gpu_block.py 2>&1 | tail -6) | tee "$out/pytest.txt"
+    echo "== sweep"
+    timeout 600 python tools/experiments/stream_split_sweep.py 2>&1 | grep streams | tee "$out/split_sweep.txt"
+    echo "== A/B"
+    for v in new r05 new r05; do
+      if [ $v = r05 ]; then export ESPNET_AMD_STREAM_FFN_SPLIT=1 ESPNET_AMD_STREAM_FUSED_MIN=8; else unset ESPNET_AMD_STREAM_FFN_SPLIT ESPNET_AMD_STREAM_FUSED_MIN; fi
+      echo -n "$v: "
+      timeout 600 python bench.py --workload stream --no-cpu-baseline --steps 6 --warmup 2 2>/dev/null < /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'audio-s/s one stream, call median', d['config']['call_latency_ms_median'], 'ms; batch32', d.get('batch32',{}).get('value'), 'tick', d.get('batch32',{}).get('tick_latency_ms_median'), 'batch128', d.get('batch128',{}).get('value'))"
+    done 2>&1 | tee "$out/ab_ffn_split.txt"
+    unset ESPNET_AMD_STREAM_FFN_SPLIT ESPNET_AMD_STREAM_FUSED_MIN ;;
+  r06u)  # round 6: kernel tables of the streaming call with the split FFN: one stream (hipGraph step) and the 32-stream tick
+    echo "== one stream"; stats "$out/stream1_stats" python "$R/tools/stream_ab.py" one
+    f=$(find "$out/stream1_stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/stream_one_kernel_stats.csv"
+    echo "== 32 streams"; stats "$out/stream32_stats" python "$R/tools/stream_ab.py" batch
+    f=$(find "$out/stream32_stats" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/stream_batch32_kernel_stats.csv" ;;
   r06a)  # round 6: block<ATT|C> (attention + the C part in one launch): kernel tests, e2e parity of the small model, in-call A/B
          # against the two-launch form (ESPNET_AMD_SPLIT_ATT=1), kernel table
     echo "== box state"; BOX_STATE_OUT="$out/box_state" bash tools/box_state.sh 2>&1 | tail -4 | tee "$out/box_state.txt"
