@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a_in, lo
   const void *ffm_w1 = a_in.ffm_w1, *ffm_w2 = a_in.ffm_w2, *ff_w1 = a_in.ff_w1, *ff_w2 = a_in.ff_w2;
   const float *ffm_b1g = a_in.ffm_b1g, *ff_b1g = a_in.ff_b1g;
   int nsplit = 1;
-  if constexpr (RELU) {
+  if constexpr (RELU && (MODE & (EM_BLOCK_A | EM_BLOCK_D)) != 0) {  // (the launches with an FFN)
     nsplit = a_in.ffn_split > 1 ? a_in.ffn_split : 1;
     if (nsplit > 1) {
       const int nch_all = ((a_in.ff >> 6) + 1) & ~1, nch_s = nch_all / nsplit, sidx = blockIdx.z;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a_in, lo
   // 40 q k v done, 50 linear_out done, 51 pointwise_conv1 + GLU done
   auto stamp = [&](int code) __attribute__((always_inline)) {
     if constexpr (EM_BLOCK_FINE) {
-      if (stamps && blockIdx.x == 3 && blockIdx.y == 5 && lane == 0 && nts < 64)
+      if (stamps && blockIdx.x == (gridDim.x > 3 ? 3 : 0) && blockIdx.y == (a.B > 5 ? 5 : 0) && blockIdx.z == 0 && lane == 0 && nts < 64)
         stamps[wave * 64 + nts] = ((long long)code << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffll);
     } else {
       if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z < 4 && tid == 0 && nts < 64)  // (split FFN: a row per share)
@@ -743,9 +743,14 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a_in, lo
         const int wg = b * (int)gridDim.x + (int)blockIdx.x;
         float4* const part = (float4*)a.ffn_part + ((size_t)wg * nsplit) * 8 * NT;
         float4* const mine = part + (size_t)blockIdx.z * 8 * NT + tid;
-        constexpr bool SEAM_PLAIN = (EM_BLOCK_VAR & 1024) != 0, SEAM_FENCED = (EM_BLOCK_VAR & (1024 | 2048)) != 0;
+        // Developer builds (profiles/r06u_stream_seam_ab*.txt): EM_BLOCK_VAR & 8192 = agent-scope (sc1) stores and no release
+        // fence, & 4096 = agent-scope loads and no acquire fence.  One stream: 661 us per call as built, 679 - 697 with either;
+        // 32 streams: 823 against 802 - 807 with the sc1 stores (the release fence writes back what the XCD's OTHER
+        // workgroups have dirtied).  The fenced form is the documented one and stays.
+        constexpr bool SEAM_ST_PLAIN = (EM_BLOCK_VAR & 8192) == 0, SEAM_LD_PLAIN = (EM_BLOCK_VAR & 4096) == 0;
+        constexpr bool SEAM_REL = SEAM_ST_PLAIN, SEAM_ACQ = SEAM_LD_PLAIN;
         auto put = [&](float4* p, const float4& v) __attribute__((always_inline)) {
-          if constexpr (SEAM_PLAIN) {
+          if constexpr (SEAM_ST_PLAIN) {
             *p = v;
           } else {  // agent-scope relaxed stores (sc1: written through this XCD's L2)
             __hip_atomic_store((unsigned long long*)p, ((const unsigned long long*)&v)[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a_in, lo
           }
         };
         auto get = [&](const float4* p) __attribute__((always_inline)) -> float4 {
-          if constexpr (SEAM_PLAIN) {
+          if constexpr (SEAM_LD_PLAIN) {
             return *p;
           } else {  // agent-scope relaxed loads (sc1: past whatever this XCD's L2 holds of an earlier launch's partial sums)
             unsigned long long w[2];
@@ -772,14 +777,14 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a_in, lo
         bar(0);
         int* const flag = (int*)(red0 + 480);  // (a word of the LayerNorm exchange area nobody uses at this point)
         if (tid == 0) {
-          if constexpr (SEAM_FENCED) {
+          if constexpr (SEAM_REL) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
           const int t = __hip_atomic_fetch_add(a.ffn_ticket + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (t == nsplit - 1) {
             __hip_atomic_store(a.ffn_ticket + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every share has arrived
-            if constexpr (SEAM_FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if constexpr (SEAM_ACQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           }
           *flag = t;
         }
@@ -882,7 +887,119 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a_in, lo
   const float* const pb3 = par + 3 * PAR_FLOATS;
 
   if (HAS_C && !HAS_D) {
-    if constexpr (ATT) {
+    if constexpr (ATT && RELU) {
+      // ---- Round 6, streaming layers: the plain multi-head attention over a block's slots (contextual_block_encoder_layer.py:
+      // 236-262; attention.py:100-151) IN this launch - what csrc/streaming.hip `cb_mha_heads_mfma_kernel` did in a launch of
+      // its own between block<A> and block<C>: 5 us of which 4 were a launch's cold start, with the context making a round
+      // trip through memory.  A wave per head, both 16-query fragments of the workgroup in that wave; every operand of the
+      // (<= 64 keys) tile requested up front together with linear_out's first units and the residual rows: one round trip.
+      // Same arithmetic, same rounding points as that kernel (scores transposed S^T[key][query], scaled q in bf16, softmax
+      // statistics per lane, bf16 probabilities as the B operand of O^T = V^T . P^T, the row sum from a ones fragment, the
+      // context rounded to bf16): bit for bit the two-launch form (tests/test_gpu_streaming.py).
+      // q / k row-major [B][H][Tpad][64], V^T [B][H][64][Tpad] (kv_frag = 0), T <= 64; att_mask: the contextual mask - the
+      // last slot is no key, slot 0 (the context vector) attends to nothing and its context is zero.
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const int hh = wave;
+      const int Tp = a.Tpad;
+      const size_t bh = (size_t)b * 4 + hh;
+      const bf16* const qb = (const bf16*)a.qh + bh * Tp * 64;
+      const bf16* const kb = (const bf16*)a.kh + bh * Tp * 64;
+      const bf16* const vb = (const bf16*)a.vt + bh * 64 * Tp;
+      const int nkeys = a.att_mask ? T - 1 : T;
+      bf16x8 qraw[2][2], kf[4][2];
+      uint2 vraw[4][2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qraw[mi][ks] = *(const bf16x8*)(qb + (size_t)(t0 + 16 * mi + lr) * 64 + ks * 32 + lg * 8);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[n][ks] = *(const bf16x8*)(kb + (size_t)(16 * n + lr) * 64 + ks * 32 + lg * 8);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+            vraw[f][jp][hf] = *(const uint2*)(vb + (size_t)(16 * f + lr) * Tp + 32 * jp + 16 * hf + 4 * lg);
+      read_unit(a.wout, 0, ring[0]);
+      load_x();
+      read_unit(a.wout, 1, ring[1]);
+      read_unit(a.wout, 2, ring[2]);
+      constexpr float LOG2E = 1.4426950408889634f;
+      const bf16x8 ones = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16)((float)qraw[mi][ks][e] * 0.125f);
+        f32x4 sc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) sc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) sc[n] = MM::mma(kf[n][ks], qf[ks], sc[n]);
+        float tm = -INFINITY;  // this lane: keys 16 n + 4 lg + r of query lr
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sc[n][r] = (16 * n + 4 * lg + r) < nkeys ? sc[n][r] : -INFINITY;
+            tm = fmaxf(tm, sc[n][r]);
+          }
+        tm = wave_xor16_max(tm);
+        tm = wave_xor32_max(tm);
+        const float mnl = tm * LOG2E;
+        unsigned pbu[2][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[n][2 * h2], LOG2E, -mnl));
+            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[n][2 * h2 + 1], LOG2E, -mnl));
+            pbu[n >> 1][(n & 1) * 2 + h2] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
+          }
+        f32x4 acc_o[4], acc_l = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc_o[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const bf16x8 pbf = __builtin_bit_cast(bf16x8, (u32x4){pbu[jp][0], pbu[jp][1], pbu[jp][2], pbu[jp][3]});
+          acc_l = MM::mma(ones, pbf, acc_l);
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            unsigned w[4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const int nv = nkeys - (32 * jp + 16 * hf + 4 * lg);  // how many of the piece's four keys exist
+              w[2 * hf] = vraw[f][jp][hf].x & (nv >= 2 ? 0xffffffffu : (nv == 1 ? 0xffffu : 0u));
+              w[2 * hf + 1] = vraw[f][jp][hf].y & (nv >= 4 ? 0xffffffffu : (nv == 3 ? 0xffffu : 0u));
+            }
+            acc_o[f] = MM::mma(__builtin_bit_cast(bf16x8, (u32x4){w[0], w[1], w[2], w[3]}), pbf, acc_o[f]);
+          }
+        }
+        // ctx[frame 16 mi + lr][64 hh + 16 f + 4 lg + r] -> bf16 -> k-tile hh of the LDS tile linear_out's activation fragments
+        // are read from
+        const bool none = a.att_mask && t0 + 16 * mi + lr == 0;
+        const float inv = 1.0f / acc_l[0];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const bf16x4 pk = {(bf16)(none ? 0.f : acc_o[f][0] * inv), (bf16)(none ? 0.f : acc_o[f][1] * inv),
+                             (bf16)(none ? 0.f : acc_o[f][2] * inv), (bf16)(none ? 0.f : acc_o[f][3] * inv)};
+          *(bf16x4*)(abuf + hh * 4096 + mi * 2048 + lr * 128 + (((2 * f + (lg >> 1)) ^ swz) << 4) + (lg & 1) * 8) = pk;
+        }
+      }
+      // this wave's parameter lines were requested before everything above
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      touch();
+      bar(0);  // the context tile is complete; the parameter groups are in LDS
+      load_act();
+      stamp(4);
+    } else if constexpr (ATT) {
       // ---- Round 6: the relative-position self-attention of the workgroup's 32 queries, IN this launch
       // (RelPositionMultiHeadedAttention.forward, attention.py:416-459; rel_shift :391-408; forward_attention :121-151):
       //     AC[i][j] = (q_i + u) . k_j     BD[i][j] = (q_i + v) . p[T-1-i+j]     ctx_i = softmax_j((AC + BD) / 8) . v_j
@@ -1175,7 +1292,9 @@ __global__ __launch_bounds__(NT, 1) void block_kernel(const EmBlockArgs a_in, lo
     read_unit(a.wout, 1, ring[1]);
     read_unit(a.wout, 2, ring[2]);
     // this wave's parameter lines were requested before the 48 loads above: in LDS once at most 48 are outstanding
+    fstamp(2);
     asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    fstamp(3);
     touch();
     bar(0);  // the parameter groups are in LDS
     fstamp(4);
@@ -1836,6 +1955,8 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
   const bool no_helpers = em_sw().block_no_helpers;
   static int ncu_of[64];  // compute units per device (asked once: no runtime call on later launches, legal under stream capture)
   const int gx = em_cdiv(a->T, BM);
+  // grid z: the shares of a split FFN (streaming launches with an FFN; EmBlockArgs.ffn_split)
+  const int zs = (RELU && (MODE & (EM_BLOCK_A | EM_BLOCK_D)) != 0 && a->ffn_split > 1) ? a->ffn_split : 1;
   int helper_rows = 0;
   if (!no_helpers) {
     int dev = 0, ncu = 256;
@@ -1846,10 +1967,10 @@ int launch_block(const EmBlockArgs* a, hipStream_t s) {
       }
       ncu = ncu_of[dev];
     }
-    const long nwg = (long)gx * a->B * (RELU && a->ffn_split > 1 ? a->ffn_split : 1);
-    if (nwg < ncu) helper_rows = (int)((ncu - nwg) / ((long)gx * (RELU && a->ffn_split > 1 ? a->ffn_split : 1)));
+    const long nwg = (long)gx * a->B * zs;
+    if (nwg < ncu) helper_rows = (int)((ncu - nwg) / ((long)gx * zs));
   }
-  dim3 grid(gx, a->B + helper_rows, RELU && a->ffn_split > 1 ? a->ffn_split : 1);
+  dim3 grid(gx, a->B + helper_rows, zs);
   static long long* stamps = nullptr;
   const bool want_stamps = em_sw().block_stamps;
   if (want_stamps && !stamps) hipMalloc((void**)&stamps, 256 * sizeof(long long));
@@ -1903,7 +2024,7 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   // the first FFN bias lives in the 7 KiB parameter group up to ff = 1024; wider FFNs hand it over in global memory
   if (!relu && a->ff > 1024 && (need_a || need_d)) return EM_ERR_UNSUPPORTED;  // (the C part has no FFN)
   if (relu && ((need_a && !a->ffm_b1g) || (need_d && !a->ff_b1g))) return EM_ERR_BAD_ARG;  // (these instantiations always read it there)
-  if (relu && mode != EM_BLOCK_A && mode != EM_BLOCK_D) return EM_ERR_UNSUPPORTED;  // (the instantiations that exist)
+  if (relu && mode != EM_BLOCK_A && mode != EM_BLOCK_D && mode != (EM_BLOCK_ATT | EM_BLOCK_C)) return EM_ERR_UNSUPPORTED;  // (the instantiations that exist)
   if (a->ffn_split > 1 && (need_a || need_d)) {  // split FFN (streaming instantiations): whole pairs of 64-wide chunks per share; a launch without an FFN ignores it
     const int nch_all = ((a->ff >> 6) + 1) & ~1;
     if (!relu || a->ffn_split > 16 || nch_all % (2 * a->ffn_split) != 0 || !a->ffn_part || !a->ffn_ticket) return EM_ERR_BAD_ARG;
@@ -1919,9 +2040,14 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   }
   if (mode == EM_BLOCK_C && (!a->ctx || !a->glu || !a->wout || !a->pw1f)) return EM_ERR_BAD_ARG;
   if (mode & EM_BLOCK_ATT) {  // attention + the C part in one launch (round 6)
-    if (relu || mode != (EM_BLOCK_ATT | EM_BLOCK_C)) return EM_ERR_UNSUPPORTED;
-    if (!a->glu || !a->wout || !a->pw1f || !a->qh || !a->kh || !a->vt || !a->pos || !a->pos_u || !a->pos_v || !a->klens) return EM_ERR_BAD_ARG;
-    if (a->Tpad % 64 != 0 || a->Tpad < em_cdiv(a->T, BM) * BM || a->ldp != em_relpos_pos_fragments(a->T)) return EM_ERR_BAD_ARG;
+    if (mode != (EM_BLOCK_ATT | EM_BLOCK_C)) return EM_ERR_UNSUPPORTED;
+    if (!a->glu || !a->wout || !a->pw1f || !a->qh || !a->kh || !a->vt) return EM_ERR_BAD_ARG;
+    if (a->Tpad % 64 != 0 || a->Tpad < em_cdiv(a->T, BM) * BM) return EM_ERR_BAD_ARG;
+    if (relu) {  // streaming layers: plain attention over the block's <= 64 slots, q / k / v row-major
+      if (a->T > 64 || a->kv_frag) return EM_ERR_UNSUPPORTED;
+    } else if (!a->pos || !a->pos_u || !a->pos_v || !a->klens || a->ldp != em_relpos_pos_fragments(a->T)) {
+      return EM_ERR_BAD_ARG;
+    }
   }
   if ((mode & EM_BLOCK_C) && need_d) {  // the C part folded into the launch (round 4)
     if (!a->ctx || !a->wout || !a->pw1f || !a->params_c) return EM_ERR_BAD_ARG;
@@ -1944,6 +2070,7 @@ extern "C" int em_conformer_block_fused(int mode, const EmBlockArgs* a, void* st
   int rc = EM_ERR_BAD_ARG;
   if (relu) {
     if (mode == EM_BLOCK_A) rc = launch_block<EM_BLOCK_A, 31, true>(a, s);
+    else if (mode == (EM_BLOCK_ATT | EM_BLOCK_C)) rc = launch_block<EM_BLOCK_ATT | EM_BLOCK_C, 31, true>(a, s);
     else rc = launch_block<EM_BLOCK_D, 15, true>(a, s);
     if (rec) em_prof_end(stream, flops, EM_PROF_BLOCK);
     return rc;

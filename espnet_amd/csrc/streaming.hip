@@ -558,6 +558,10 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
     ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = ws + s.qh; ba.kh = ws + s.kh; ba.vt = ws + s.vt;
     const size_t mha_lds = ((size_t)2 * L * 64 + (size_t)64 * (L + 1)) * sizeof(float);
     const bool mha_v1 = em_sw().stream_mha_v1;  // developer A/B switch: the LDS / VALU attention kernel of round 4
+    // round 6: the block attention in front of block<C>, in its launch (csrc/block.hip, EM_BLOCK_ATT | EM_BLOCK_C | EM_BLOCK_RELU).
+    // ESPNET_AMD_STREAM_SPLIT_ATT: developer A/B switch - the attention launch of rounds 4 - 5 (bit for bit the same rows)
+    const bool att_c = !mha_v1 && !em_sw().stream_split_att;
+    ba.att_mask = mask_mode;
     // One block per stream (the steady-state tick): the hand-over after layer l is "slot 0 := the previous call's context
     // vector of layer l; this call's := the last slot" - block<A> of layer l + 1 reads its slot 0 from past_ctx and
     // block<D> of layer l writes its last slot to next_ctx as well: twelve launches less per call (4.9 us each, 59 of a
@@ -582,15 +586,19 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
       ba.last_dst = nullptr;
       EM_TRY(em_conformer_block_fused(EM_BLOCK_A | EM_BLOCK_RELU, &ba, stream));
       ba.row0_src = nullptr;
-      if (mha_v1)
-        hipLaunchKernelGGL(cb_mha_heads_kernel, dim3(h, n_blk), dim3(256), mha_lds, (hipStream_t)stream,
-                           (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
-      else
-        hipLaunchKernelGGL(cb_mha_heads_mfma_kernel, dim3(h, n_blk), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
-      EM_CHECK_LAUNCH();
       ba.wout = q.woutp; ba.pw1f = q.pw1f; ba.params = q.fp_c;
-      EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
+      if (att_c) {  // round 6: the attention in front of the C part, one launch
+        EM_TRY(em_conformer_block_fused(EM_BLOCK_ATT | EM_BLOCK_C | EM_BLOCK_RELU, &ba, stream));
+      } else {
+        if (mha_v1)
+          hipLaunchKernelGGL(cb_mha_heads_kernel, dim3(h, n_blk), dim3(256), mha_lds, (hipStream_t)stream,
+                             (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
+        else
+          hipLaunchKernelGGL(cb_mha_heads_mfma_kernel, dim3(h, n_blk), dim3(256), 0, (hipStream_t)stream,
+                             (const bf16*)ba.qh, (const bf16*)ba.kh, (const bf16*)ba.vt, L, s.Tpad, h, mask_mode, (bf16*)ctx);
+        EM_CHECK_LAUNCH();
+        EM_TRY(em_conformer_block_fused(EM_BLOCK_C, &ba, stream));
+      }
       ba.pw2 = q.pw2p; ba.ff_w1 = q.ff_w1p; ba.ff_w2 = q.ff_w2p; ba.dw_w = q.dw_w; ba.dw_b = q.dw_b; ba.ff_b1g = q.ff_b1;
       ba.params = q.fp_da;
       ba.last_dst = fold_ctx ? next_ctx + (size_t)l * d : nullptr;

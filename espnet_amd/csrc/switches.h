@@ -19,6 +19,7 @@ struct EmSwitches {
   bool no_src_lnq, no_tail_fusion;                                   // ESPNET_AMD_NO_SRC_LNQ / _NO_TAIL_FUSION
   bool stream_no_fused, stream_mha_v1, stream_no_ctx_fold, stream_no_ln_gemm;  // ESPNET_AMD_STREAM_*
   int stream_fused_min;                                              // ESPNET_AMD_STREAM_FUSED_MIN (default 1; 8 in rounds 4 - 5)
+  bool stream_split_att;                                             // ESPNET_AMD_STREAM_SPLIT_ATT
   int stream_ffn_split;                                              // ESPNET_AMD_STREAM_FFN_SPLIT (0: automatic; 1: off; n: forced)
   bool no_sub12;                                                     // ESPNET_AMD_NO_SUB12
 };

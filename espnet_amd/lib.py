@@ -75,7 +75,7 @@ class EmBlockArgs(C.Structure):
                [("x_out", C.c_void_p), ("params_c", C.c_void_p), ("ffm_b1g", C.c_void_p), ("ff_b1g", C.c_void_p),
                 ("row0_src", C.c_void_p), ("last_dst", C.c_void_p), ("row_stride", C.c_int32), ("ldp", C.c_int32),
                 ("pos", C.c_void_p), ("pos_u", C.c_void_p), ("pos_v", C.c_void_p), ("klens", C.c_void_p), ("kv_frag", C.c_int32),
-                ("ffn_split", C.c_int32), ("ffn_part", C.c_void_p), ("ffn_ticket", C.c_void_p)]
+                ("ffn_split", C.c_int32), ("ffn_part", C.c_void_p), ("ffn_ticket", C.c_void_p), ("att_mask", C.c_int32)]
 
 
 EM_ROWS_FFN, EM_ROWS_GLU = 0, 1

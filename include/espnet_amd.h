@@ -460,6 +460,12 @@ typedef struct EmBlockArgs {
   int32_t ffn_split;
   float* ffn_part;
   int32_t* ffn_ticket;
+  /* EM_BLOCK_ATT | EM_BLOCK_C | EM_BLOCK_RELU (streaming layers, round 6): PLAIN multi-head attention over the block's T <= 64
+   * slots in front of the C part (q / k [B][4][Tpad][64], V^T [B][4][64][Tpad] row-major as EM_BLOCK_A | EM_BLOCK_RELU
+   * writes them; no pos / klens) - bit for bit em_cb_encode_blocks' attention launch + EM_BLOCK_C.  att_mask != 0: the
+   * contextual mask (contextual_block_conformer_encoder.py:352-360): the last slot is no key; slot 0 attends to nothing and
+   * its context is zero. */
+  int32_t att_mask;
 } EmBlockArgs;
 int em_conformer_block_fused(int mode, const EmBlockArgs* args, void* stream);
 /* Position rows for EM_BLOCK_ATT: pall [2T-1][ldp] bf16 holds linear_pos of L blocks side by side (block l at columns

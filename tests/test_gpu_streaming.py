@@ -368,6 +368,52 @@ def test_split_ffn_of_the_block_launches(n_streams):
         _L.load().em_dev_switches_reload()
 
 
+@pytest.mark.parametrize("n_streams", [1, 8])
+def test_block_attention_in_the_c_launch_equals_its_own_launch(n_streams):
+    """Round 6: the plain multi-head attention over a block's slots (contextual_block_encoder_layer.py:236-262) runs in front
+    of the C part IN its launch (csrc/block.hip, EM_BLOCK_ATT | EM_BLOCK_C | EM_BLOCK_RELU) instead of a launch of its own
+    (csrc/streaming.hip cb_mha_heads_mfma_kernel, kept behind ESPNET_AMD_STREAM_SPLIT_ATT): the same MFMAs on the same
+    operands, the context rounded to bf16 at the same point - bit for bit, chunk by chunk (contextual mask, 42 slots), one-shot
+    (many blocks per call) and on the short-utterance path (no mask, a block of as many slots as there are frames)."""
+    import os
+
+    from espnet_amd import lib as _L
+
+    g = load_stream_golden("stream_small_6s")
+    n, cf = int(g["n_samples"]), int(g["chunk_frames"])
+    feats = torch.stack([stream_feats(int(g["utt_id"]) + s, n) for s in range(n_streams)])
+    enc = build(g, "bfloat16")
+    assert enc._fusable()
+
+    def run(split):
+        if split:
+            os.environ["ESPNET_AMD_STREAM_SPLIT_ATT"] = "1"
+        else:
+            os.environ.pop("ESPNET_AMD_STREAM_SPLIT_ATT", None)
+        _L.load().em_dev_switches_reload()
+        outs, state, pos, T = [], None, 0, feats.size(1)
+        while pos < T:
+            nxt = min(T, pos + cf)
+            y, y_len, state = enc.forward_infer_batch(feats[:, pos:nxt].cuda(), state, is_final=(nxt == T))
+            outs.append(y)
+            pos = nxt
+        one, _, _ = enc(feats[:1].cuda(), torch.tensor([feats.size(1)]), None, is_final=True, infer_mode=True)
+        shorts = [enc(feats[:1, :k].cuda(), torch.tensor([k]), None, is_final=True, infer_mode=True)[0].cpu() for k in (100, 131, 163)]
+        return torch.cat(outs, 1).cpu(), one.cpu(), shorts
+
+    try:
+        fused, one_f, short_f = run(False)
+        split, one_s, short_s = run(True)
+    finally:
+        os.environ.pop("ESPNET_AMD_STREAM_SPLIT_ATT", None)
+        _L.load().em_dev_switches_reload()
+    assert torch.equal(fused, split) and torch.equal(one_f, one_s)
+    for a, b in zip(short_f, short_s):
+        assert a.shape == b.shape and a.numel() > 0 and torch.equal(a, b)
+    err = np.abs(fused[0][:: int(g["keep_every"])].numpy() - g["ys"])
+    assert err.max() < 0.2 and err.mean() < 0.02, (err.max(), err.mean())
+
+
 def test_batch_call_equals_single_streams(tmp_path):
     """Speech2TextStreaming.batch_call (S lock-step streams, one launch sequence per tick: batched HIP frontend ->
     forward_infer_batch -> incremental greedy CTC) returns for every stream the tokens `__call__` returns for it alone

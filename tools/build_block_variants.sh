@@ -22,6 +22,7 @@ for v in "$@"; do
       rm -f espnet_amd/lib/dbg/ffn_rows_$v.o
       echo "built espnet_amd/lib/dbg/lib_$v.so"; continue ;;
     nt) def="-DEM_BLOCK_NO_TOUCH=1" ;;
+    finent) def="-DEM_BLOCK_FINE=1 -DEM_BLOCK_NO_TOUCH=1" ;;
     fine*) def="-DEM_BLOCK_FINE=1 -DEM_BLOCK_VAR=${v#fine}"; [ "$v" = fine ] && def="-DEM_BLOCK_FINE=1" ;;
     v*) def="-DEM_BLOCK_VAR=${v#v}" ;;
     *) def="-DEM_BLOCK_DBG=$v" ;;
