@@ -331,7 +331,7 @@ def run_stream(dtype, steps, warmup, chunk=10240, stream_beam=1, cpu_base=True):
     return res
 
 
-def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240):
+def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240, groups=1):
     """configs[4] as a SERVER runs it: n_streams live connections fed 640 ms chunks in lock step, one launch sequence
     per tick for all of them (Speech2TextStreaming.batch_call: batched HIP frontend -> forward_infer_batch -> greedy
     CTC, one device -> host read per tick).  A step = n_streams utterances of 10 s."""
@@ -360,12 +360,24 @@ def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240):
     # 1.3 MB copies of 32 streams stall ~90 ms every few ticks inside the HIP runtime (profiles/r03q_stream_batch_ticks.txt)
     ticks = [wav[:, lo:hi].contiguous().pin_memory() for lo, hi in bounds]
 
+    # groups > 1: that many independent sets of n_streams lock-step streams, each on a HIP stream of its own, a tick of each in
+    # flight (Speech2TextStreaming.batch_call_async): while the host reads group g's ids and prepares its next tick, the other
+    # groups' launches keep the device busy.  A "tick latency" is then submit -> ids on the host of one group's tick.
+    G = groups
+    sts = StepPipeline._pick(torch.device("cuda", torch.cuda.current_device()), G)[0] if G > 1 else [None]
+
     def step():
-        lat = []
+        lat, pend, t_sub, out = [], [None] * G, [0.0] * G, None
         for k in range(len(bounds)):
-            t0 = time.perf_counter()
-            out = s2t.batch_call(ticks[k], is_final=(k == len(bounds) - 1))  # ends with a host read of the new ids
-            lat.append(time.perf_counter() - t0)
+            for g in range(G):
+                if pend[g] is not None:
+                    out = pend[g].result()  # ends with a host read of the new ids
+                    lat.append(time.perf_counter() - t_sub[g])
+                t_sub[g] = time.perf_counter()
+                pend[g] = s2t.batch_call_async(ticks[k], is_final=(k == len(bounds) - 1), group=g, stream=sts[g])
+        for g in range(G):
+            out = pend[g].result()
+            lat.append(time.perf_counter() - t_sub[g])
         return out, lat
 
     for _ in range(warmup):
@@ -375,19 +387,22 @@ def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240):
     lats = []
     for _ in range(steps):
         out, lat = step()
-        lats += lat[2:-1]
+        lats += lat[2 * G : -G]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lats.sort()
-    return {"value": round(n_streams * AUDIO_SEC * steps / elapsed, 1), "unit": "audio-s/s", "streams": n_streams,
+    n_streams_all = n_streams * G
+    return {"value": round(n_streams_all * AUDIO_SEC * steps / elapsed, 1), "unit": "audio-s/s", "streams": n_streams_all,
+            "groups_in_flight": G, "streams_per_tick": n_streams,
             "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "tick_latency_ms_median": round(lats[len(lats) // 2] * 1e3, 3),
             "tick_latency_ms_p95": round(lats[int(len(lats) * 0.95)] * 1e3, 3),
             "chunk_ms": chunk / 16.0, "ticks_per_utt": len(bounds),
             "realtime_multiple": int(n_streams * (chunk / 16.0) / (lats[len(lats) // 2] * 1e3)),  # audio ms per wall ms of a tick
             "tokens_stream0": len(out[0]) if out else 0,
-            "what": f"{n_streams} lock-step streams, 640 ms chunks, one launch sequence per tick for all of them "
-                    f"(eager launches, waveform chunks from pinned host memory, greedy CTC ids read back once per tick)"}
+            "what": f"{n_streams} lock-step streams per tick, 640 ms chunks, one launch sequence per tick for all of them "
+                    f"(eager launches, waveform chunks from pinned host memory, greedy CTC ids read back once per tick)"
+                    + (f"; {G} such groups, a tick of each in flight on its own HIP stream" if G > 1 else "")}
 
 
 def main_stream(args):
@@ -398,6 +413,8 @@ def main_stream(args):
     if args.stream_beam <= 1 and args.stream_chunk == 10240:
         res["batch32"] = run_stream_batch(args.dtype, 32, max(1, args.steps), 1)
         res["batch128"] = run_stream_batch(args.dtype, 128, max(1, min(args.steps, 4)), 1)
+        res["batch32_two_groups"] = run_stream_batch(args.dtype, 32, max(1, args.steps), 1, groups=2)
+        res["batch128_two_groups"] = run_stream_batch(args.dtype, 128, max(1, min(args.steps, 4)), 1, groups=2)
     res = {"metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances", **res, "n_gpus": 1,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     print(json.dumps(res), flush=True)
@@ -1558,6 +1575,11 @@ def main():
             # until the chip is full: the same tick with four times the streams.  (Four steps, not two:
             # one stalled tick in a two-step run read 34 800 where three runs around it read 52 800 - 53 200, profiles/r05x, r05y)
             r["batch128"] = run_stream_batch(args.dtype, 128, 4, 1)
+            # ... and with a tick of a SECOND group of streams in flight on another HIP stream (batch_call_async): the host's
+            # turn-around between a tick's read and the next tick's first launch, and the ~25 small launches either side of the
+            # layers, under the other group's launches
+            r["batch32_two_groups"] = run_stream_batch(args.dtype, 32, 4, 1, groups=2)
+            r["batch128_two_groups"] = run_stream_batch(args.dtype, 128, 4, 1, groups=2)
             return r
 
         guarded("frontend", frontend_leg)

@@ -408,6 +408,7 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
             if len(self._flen_cache) > 64:
                 self._flen_cache.clear()
             flen = self._flen_cache[(S, t, dev)] = torch.full((S,), t, dtype=torch.int32, device=dev)
+            torch.cuda.current_stream().synchronize()  # (filled before another stream's tick may read it)
         c1 = torch.empty(S * T1 * F1 * d, dtype=act, device=dev)
         L.check(lib.em_conv2d_sub1(self.em_dtype, L.ptr(xs), None, L.ptr(flen), S, t, nm, w.conv1_w,
                                    w.conv1_b, d, L.ptr(c1), st), "em_conv2d_sub1")

@@ -16,6 +16,7 @@ Decoding (`search=`):
   * "offline": greedy partials, and the offline joint CTC/attention beam search over the accumulated
     encoder output at `is_final`.
 """
+import contextlib
 import logging
 import math
 from pathlib import Path
@@ -113,7 +114,7 @@ class Speech2TextStreaming:
     def reset(self):
         self.frontend_states = None
         self.encoder_states = None
-        self._batch = None
+        self._batches = {}  # group -> state of one set of lock-step streams (batch_call / batch_call_async)
         self._enc_chunks = []
         self._last_id = -1
         self._partial_ids: List[int] = []
@@ -217,6 +218,7 @@ class Speech2TextStreaming:
                 self._flens_cache.clear()
             flens = m.frontend.feature_lengths([n] * S)
             flens_dev = self._flens_cache[key] = torch.tensor(flens, dtype=torch.int32).to(wav.device)
+            torch.cuda.current_stream().synchronize()  # (other streams' ticks read it too: batch_call_async)
         feats = m.frontend.forward_device(wav, flens_dev)
         if m.normalize is not None:
             feats = m.normalize.forward_device(feats, flens_dev)
@@ -236,32 +238,43 @@ class Speech2TextStreaming:
         collapsed across chunk seams, blank / <sos/eos> dropped).  Stream s sees exactly what `__call__` gives it alone
         (tests/test_gpu_streaming.py::test_batch_call_equals_single_streams); one launch sequence serves all S streams
         (ContextualBlockConformerEncoder.forward_infer_batch).  The object holds the batch's state until is_final."""
+        return self.batch_call_async(speech, is_final).result()
+
+    @torch.no_grad()
+    def batch_call_async(self, speech: torch.Tensor, is_final: bool = False, group=0, stream=None) -> "PendingTick":
+        """`batch_call` without the wait: the tick's launches are queued (on `stream`, a torch.cuda.Stream; default: the current
+        one), the new token ids travel to pinned host memory behind them, and the returned PendingTick's `result()` waits for
+        them and gives what `batch_call` gives.  `group`: a key for the state of one set of lock-step streams - several
+        groups (each on a stream of its own) may have a tick in flight at the same time: a tick ends with a host read, and
+        between that read and the next tick's first launch the device would idle (94 us of a 1.06 ms tick of 32 streams,
+        profiles/r06w_stream_tick_order.txt), as it mostly does under the ~25 small launches either side of the layers.
+        A group's results must be taken in order (a later tick's `result()` takes the earlier ones first)."""
         if self.search == "online":
             raise NotImplementedError("batch_call decodes greedily; the block-synchronous beam search is per stream")
         if isinstance(speech, np.ndarray):
             speech = torch.tensor(speech)
         S = speech.size(0)
-        if self._batch is None:
-            self._batch = dict(frontend=None, encoder=None, last=[-1] * S, ids=[[] for _ in range(S)])
-        bst = self._batch
-        feats, bst["frontend"] = self.apply_frontend_batch(speech, bst["frontend"], is_final=is_final)
+        bst = self._batches.get(group)
+        if bst is None:
+            bst = self._batches[group] = dict(frontend=None, encoder=None, last=[-1] * S, ids=[[] for _ in range(S)], pending=None)
         m = self.asr_model
-        if feats is not None:
-            enc, y_len, bst["encoder"] = m.encoder.forward_infer_batch(feats, bst["encoder"], is_final)  # (a view: the encoder's own cat / contiguous() copies it once)
-            if y_len > 0:
-                ids = m.ctc.argmax(enc, as_int32=True).cpu().tolist()  # ONE device -> host read per tick for all streams
-                drop = (m.blank_id, m.sos, m.eos)
-                for s_ in range(S):
-                    last, out = bst["last"][s_], bst["ids"][s_]
-                    for t in ids[s_]:
-                        if t != last and t not in drop:
-                            out.append(t)
-                        last = t
-                    bst["last"][s_] = last
-        res = [list(v) for v in bst["ids"]]
+        ids_host, event = None, None
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            feats, bst["frontend"] = self.apply_frontend_batch(speech, bst["frontend"], is_final=is_final)
+            if feats is not None:
+                enc, y_len, bst["encoder"] = m.encoder.forward_infer_batch(feats, bst["encoder"], is_final)  # (a view: the encoder's own cat / contiguous() copies it once)
+                if y_len > 0:
+                    ids = m.ctc.argmax(enc, as_int32=True)
+                    ids_host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
+                    ids_host.copy_(ids, non_blocking=True)  # ONE device -> host read per tick for all streams
+                    event = torch.cuda.Event()
+                    event.record()
+        tick = PendingTick(self, bst, ids_host, event, bst["pending"])
+        bst["pending"] = tick
         if is_final:
-            self._batch = None
-        return res
+            del self._batches[group]
+        return tick
 
     def stream_pool(self) -> "StreamPool":
         """A pool of independent streams served by batched launches (streams may join, pause, finish at any tick)."""
@@ -307,6 +320,40 @@ class Speech2TextStreaming:
             text = self.tokenizer.tokens2text(token) if self.tokenizer is not None else None
             results.append((text, token, token_int, hyp))
         return results
+
+
+class PendingTick:
+    """A tick of `Speech2TextStreaming.batch_call_async` whose launches are queued: `result()` waits for its token ids and
+    returns, per stream, the ids decoded so far."""
+
+    def __init__(self, s2t, bst, ids_host, event, prev):
+        self._s2t, self._bst, self._ids_host, self._event, self._prev = s2t, bst, ids_host, event, prev
+        self._res = None
+
+    def done(self) -> bool:
+        return self._res is not None or self._event is None or self._event.query()
+
+    def result(self) -> List[List[int]]:
+        if self._res is None:
+            if self._prev is not None:
+                self._prev.result()  # (the seam state - last id per stream - is carried in tick order)
+                self._prev = None
+            bst, m = self._bst, self._s2t.asr_model
+            if self._ids_host is not None:
+                self._event.synchronize()
+                drop = (m.blank_id, m.sos, m.eos)
+                for s_, row in enumerate(self._ids_host.tolist()):
+                    last, out = bst["last"][s_], bst["ids"][s_]
+                    for t in row:
+                        if t != last and t not in drop:
+                            out.append(t)
+                        last = t
+                    bst["last"][s_] = last
+                self._ids_host = None
+            self._res = [list(v) for v in bst["ids"]]
+            if bst["pending"] is self:
+                bst["pending"] = None
+        return self._res
 
 
 class StreamPool:

@@ -455,6 +455,23 @@ def test_batch_call_equals_single_streams(tmp_path):
     for s in range(S):
         assert got[s] == singles[s], (s, got[s][:10], singles[s][:10])
     assert got[0] != got[1]
+    # round 6: two groups of streams, a tick of each in flight on its own HIP stream (batch_call_async; the second group is the
+    # first one's streams in another order): per tick what batch_call gives, results taken one tick late
+    perm = [2, 0, 1]
+    sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+    per_tick = [[], []]
+    pend = [None, None]
+    for pos in range(0, N, CH):
+        nxt = min(N, pos + CH)
+        for gi, w in enumerate((wavs, wavs[perm])):
+            if pend[gi] is not None:
+                per_tick[gi].append(pend[gi].result())
+            pend[gi] = s2t.batch_call_async(w[:, pos:nxt].contiguous().pin_memory(), is_final=(nxt == N), group=gi, stream=sts[gi])
+    for gi in range(2):
+        per_tick[gi].append(pend[gi].result())
+    assert per_tick[0][-1] == got and per_tick[1][-1] == [got[j] for j in perm]
+    assert all(len(a[0]) <= len(b[0]) for a, b in zip(per_tick[0], per_tick[0][1:]))  # (ids only ever grow)
+    assert not s2t._batches
 
 
 def test_stream_pool_ragged(tmp_path):

@@ -1,6 +1,6 @@
 """One line per run: the streaming workloads of bench.py (configs[4]: one stream through the hipGraph-captured step; 32
 lock-step streams per tick) without the CPU baseline, for in-call A/B of the developer switches
-(ESPNET_AMD_BLOCK_NO_HELPERS, ESPNET_AMD_STREAM_MHA_V1, ESPNET_AMD_STREAM_FUSED_MIN).  Usage: python tools/stream_ab.py [one|batch|both|batch128]"""
+(ESPNET_AMD_BLOCK_NO_HELPERS, ESPNET_AMD_STREAM_MHA_V1, ESPNET_AMD_STREAM_FUSED_MIN).  Usage: python tools/stream_ab.py [one|batch|groups|both|batch128]"""
 import json
 import sys
 from pathlib import Path
@@ -19,6 +19,10 @@ if what in ("one", "both"):
 if what in ("batch", "both"):
     r = bench.run_stream_batch("bfloat16", 32, 3, 1)
     out["batch32"] = {"audio_s_per_s": r["value"], "tick_ms": r["tick_latency_ms_median"]}
+if what in ("groups", "both"):
+    for n in (32, 128):
+        r = bench.run_stream_batch("bfloat16", n, 3, 1, groups=2)
+        out[f"batch{n}_two_groups"] = {"audio_s_per_s": r["value"], "tick_ms": r["tick_latency_ms_median"]}
 if what == "batch128":
     r = bench.run_stream_batch("bfloat16", 128, 3, 1)
     out["batch128"] = {"audio_s_per_s": r["value"], "tick_ms": r["tick_latency_ms_median"], "tick_ms_p95": r["tick_latency_ms_p95"],
