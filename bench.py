@@ -415,6 +415,7 @@ def main_stream(args):
         res["batch128"] = run_stream_batch(args.dtype, 128, max(1, min(args.steps, 4)), 1)
         res["batch32_two_groups"] = run_stream_batch(args.dtype, 32, max(1, args.steps), 1, groups=2)
         res["batch128_two_groups"] = run_stream_batch(args.dtype, 128, max(1, min(args.steps, 4)), 1, groups=2)
+        res["batch64_three_groups"] = run_stream_batch(args.dtype, 64, max(1, min(args.steps, 4)), 1, groups=3)
     res = {"metric": "audio-seconds/sec (RTF^-1), Conformer-ASR, 10 s utterances", **res, "n_gpus": 1,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     print(json.dumps(res), flush=True)
@@ -1580,6 +1581,7 @@ def main():
             # layers, under the other group's launches
             r["batch32_two_groups"] = run_stream_batch(args.dtype, 32, 4, 1, groups=2)
             r["batch128_two_groups"] = run_stream_batch(args.dtype, 128, 4, 1, groups=2)
+            r["batch64_three_groups"] = run_stream_batch(args.dtype, 64, 4, 1, groups=3)
             return r
 
         guarded("frontend", frontend_leg)

@@ -1,6 +1,6 @@
-# launch order of one steady-state tick of 32 lock-step streams (rocprofv3 kernel trace of tools/stream_ab.py batch)
+# launch order of one steady-state tick of 32 lock-step streams (rocprofv3 kernel trace of tools/stream_ab.py batch), or - second argument "one" - of one call of one stream through the hipGraph step
 export TMPDIR=/tmp; R=$PWD; d=$R/gpurun_out/${1:-r06w}/tick_trace; mkdir -p $d
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace -d "$d" -o s --output-format csv -- python "$R/tools/stream_ab.py" batch > "$d.log" 2>&1 < /dev/null)
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace -d "$d" -o s --output-format csv -- python "$R/tools/stream_ab.py" ${2:-batch} > "$d.log" 2>&1 < /dev/null)
 t=$(find "$d" -name "*kernel_trace.csv" | head -1)
 python - "$t" <<'PY'
 import csv, sys
