@@ -331,7 +331,7 @@ def run_stream(dtype, steps, warmup, chunk=10240, stream_beam=1, cpu_base=True):
     return res
 
 
-def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240, groups=1):
+def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240, groups=1, graph=False):
     """configs[4] as a SERVER runs it: n_streams live connections fed 640 ms chunks in lock step, one launch sequence
     per tick for all of them (Speech2TextStreaming.batch_call: batched HIP frontend -> forward_infer_batch -> greedy
     CTC, one device -> host read per tick).  A step = n_streams utterances of 10 s."""
@@ -353,7 +353,8 @@ def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240, groups=1):
     with tempfile.TemporaryDirectory() as td:
         (Path(td) / "config.yaml").write_text(yaml.safe_dump(cfg))
         s2t = Speech2TextStreaming(str(Path(td) / "config.yaml"), None, device="cuda", dtype=dtype, beam_size=1,
-                                   ctc_weight=0.3, use_hipgraph=False)
+                                   ctc_weight=0.3, use_hipgraph=graph)  # (graph: the steady-state tick of a group as one hipGraph, BatchTickGraph - measured no faster
+                                   # than the eager launches, 1.03 - 1.04 against 1.015 ms per tick of 32 streams: profiles/r06y_stream_tick_graph.txt)
     wav = synth_batch(0, n_streams)  # (S, N) host
     bounds = [(p, min(N_SAMPLES, p + chunk)) for p in range(0, N_SAMPLES, chunk)]
     # a tick's audio arrives in pinned host memory (what a server's receive buffers are): from pageable memory the
@@ -394,6 +395,7 @@ def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240, groups=1):
     n_streams_all = n_streams * G
     return {"value": round(n_streams_all * AUDIO_SEC * steps / elapsed, 1), "unit": "audio-s/s", "streams": n_streams_all,
             "groups_in_flight": G, "streams_per_tick": n_streams,
+            "hipgraph_replays": sum(tg.n_replays for tg in s2t._tick_graphs.values()),
             "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
             "tick_latency_ms_median": round(lats[len(lats) // 2] * 1e3, 3),
             "tick_latency_ms_p95": round(lats[int(len(lats) * 0.95)] * 1e3, 3),
@@ -401,7 +403,7 @@ def run_stream_batch(dtype, n_streams, steps, warmup, chunk=10240, groups=1):
             "realtime_multiple": int(n_streams * (chunk / 16.0) / (lats[len(lats) // 2] * 1e3)),  # audio ms per wall ms of a tick
             "tokens_stream0": len(out[0]) if out else 0,
             "what": f"{n_streams} lock-step streams per tick, 640 ms chunks, one launch sequence per tick for all of them "
-                    f"(eager launches, waveform chunks from pinned host memory, greedy CTC ids read back once per tick)"
+                    f"({'the steady-state tick as one hipGraph' if graph else 'eager launches'}, waveform chunks from pinned host memory, greedy CTC ids read back once per tick)"
                     + (f"; {G} such groups, a tick of each in flight on its own HIP stream" if G > 1 else "")}
 
 
@@ -413,6 +415,7 @@ def main_stream(args):
     if args.stream_beam <= 1 and args.stream_chunk == 10240:
         res["batch32"] = run_stream_batch(args.dtype, 32, max(1, args.steps), 1)
         res["batch128"] = run_stream_batch(args.dtype, 128, max(1, min(args.steps, 4)), 1)
+        res["batch32_hipgraph"] = run_stream_batch(args.dtype, 32, max(1, args.steps), 1, graph=True)
         res["batch32_two_groups"] = run_stream_batch(args.dtype, 32, max(1, args.steps), 1, groups=2)
         res["batch128_two_groups"] = run_stream_batch(args.dtype, 128, max(1, min(args.steps, 4)), 1, groups=2)
         res["batch64_three_groups"] = run_stream_batch(args.dtype, 64, max(1, min(args.steps, 4)), 1, groups=3)
@@ -1579,6 +1582,7 @@ def main():
             # ... and with a tick of a SECOND group of streams in flight on another HIP stream (batch_call_async): the host's
             # turn-around between a tick's read and the next tick's first launch, and the ~25 small launches either side of the
             # layers, under the other group's launches
+            r["batch32_hipgraph"] = run_stream_batch(args.dtype, 32, 4, 1, graph=True)  # (the tick as one captured unit: no faster)
             r["batch32_two_groups"] = run_stream_batch(args.dtype, 32, 4, 1, groups=2)
             r["batch128_two_groups"] = run_stream_batch(args.dtype, 128, 4, 1, groups=2)
             r["batch64_three_groups"] = run_stream_batch(args.dtype, 64, 4, 1, groups=3)

@@ -495,7 +495,12 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
         Lb = bs + 2
         chunks = torch.empty(S, block_num, Lb, d, dtype=torch.float32, device=dev)
         addin = torch.empty(S, d, dtype=torch.float32, device=dev)
-        if n_rows is None:
+        rows_static = st.get("n_processed_blocks_dev")  # (S,) int32 on the device: set by a captured tick only (BatchTickGraph)
+        if rows_static is not None:
+            L.check(lib.em_cb_build_blocks_rows_f32(L.ptr(x), L.ptr(pk["pe"]), L.ptr(prev_addin), L.ptr(rows_static), S,
+                                                    block_num, x.size(1), bs, hs, d, L.ptr(chunks), L.ptr(addin), stream),
+                    "em_cb_build_blocks_rows_f32")
+        elif n_rows is None:
             L.check(lib.em_cb_build_blocks_batch_f32(L.ptr(x), L.ptr(pk["pe"]), L.ptr(prev_addin), n_proc, S, block_num,
                                                      x.size(1), bs, hs, d, L.ptr(chunks), L.ptr(addin), stream),
                     "em_cb_build_blocks_batch_f32")

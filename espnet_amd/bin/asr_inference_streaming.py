@@ -109,6 +109,7 @@ class Speech2TextStreaming:
         self.use_hipgraph = use_hipgraph
         self._runner = None
         self._flens_cache = {}  # (streams, samples, device) -> frame counts on the device (apply_frontend_batch)
+        self._tick_graphs = {}  # (group, chunk shape) -> BatchTickGraph of finished utterances (batch_call_async)
         self.reset()
 
     def reset(self):
@@ -256,23 +257,43 @@ class Speech2TextStreaming:
         S = speech.size(0)
         bst = self._batches.get(group)
         if bst is None:
-            bst = self._batches[group] = dict(frontend=None, encoder=None, last=[-1] * S, ids=[[] for _ in range(S)], pending=None)
+            bst = self._batches[group] = dict(frontend=None, encoder=None, last=[-1] * S, ids=[[] for _ in range(S)], pending=None,
+                                              graph=self._tick_graphs.get((group, tuple(speech.shape))))
         m = self.asr_model
         ids_host, event = None, None
         ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
         with ctx:
-            feats, bst["frontend"] = self.apply_frontend_batch(speech, bst["frontend"], is_final=is_final)
-            if feats is not None:
-                enc, y_len, bst["encoder"] = m.encoder.forward_infer_batch(feats, bst["encoder"], is_final)  # (a view: the encoder's own cat / contiguous() copies it once)
-                if y_len > 0:
-                    ids = m.ctc.argmax(enc, as_int32=True)
-                    ids_host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
-                    ids_host.copy_(ids, non_blocking=True)  # ONE device -> host read per tick for all streams
-                    event = torch.cuda.Event()
-                    event.record()
+            ids = None
+            tg = bst.get("graph")
+            sig = BatchTickGraph.signature(speech, bst) if (self.use_hipgraph and not is_final) else None
+            if tg is not None and tg.graph is not None and sig is not None and sig == tg.sig:
+                ids = tg.replay(speech, bst)  # steady state: one graph launch
+            else:
+                if tg is not None:
+                    tg.leave(bst)
+                speech_dev = speech.to(self.device, dtype=torch.float32, non_blocking=True)
+                feats, bst["frontend"] = self.apply_frontend_batch(speech_dev, bst["frontend"], is_final=is_final)
+                if feats is not None:
+                    enc, y_len, bst["encoder"] = m.encoder.forward_infer_batch(feats, bst["encoder"], is_final)  # (a view: the encoder's own cat / contiguous() copies it once)
+                    if y_len > 0:
+                        ids = m.ctc.argmax(enc, as_int32=True)
+                # a second tick of the same shape in a row: the ticks from here on are this one again - capture it
+                if sig is not None and (tg is None or tg.graph is None) and BatchTickGraph.signature(speech, bst) == sig:
+                    if tg is None:
+                        tg = bst["graph"] = BatchTickGraph(self)
+                    tg.sig = sig
+                    tg.capture(speech_dev, bst)
+            if ids is not None:
+                ids_host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
+                ids_host.copy_(ids, non_blocking=True)  # ONE device -> host read per tick for all streams
+                event = torch.cuda.Event()
+                event.record()
         tick = PendingTick(self, bst, ids_host, event, bst["pending"])
         bst["pending"] = tick
         if is_final:
+            tg = bst.get("graph")
+            if tg is not None and tg.graph is not None:  # (the captured tick outlives the utterances: the group's next ones replay it)
+                self._tick_graphs[(group, tg.sig[0])] = tg
             del self._batches[group]
         return tick
 
@@ -320,6 +341,88 @@ class Speech2TextStreaming:
             text = self.tokenizer.tokens2text(token) if self.tokenizer is not None else None
             results.append((text, token, token_int, hyp))
         return results
+
+
+class BatchTickGraph:
+    """hipGraph replay of the steady-state tick of one group of lock-step streams (`batch_call` / `batch_call_async` with
+    `use_hipgraph`): fed equal chunks, the carried buffers (waveform tail, feature tail, subsampled tail, context vectors)
+    keep their shapes after a few ticks and every tick is the same ~70 launches - frontend, subsampling, block building, 36
+    layer launches, CTC arg-max - except for the positional-encoding offset, which the captured tick reads from device memory
+    (`n_processed_blocks_dev`, em_cb_build_blocks_rows_f32).  The first ticks run eagerly; once two consecutive ticks have the same
+    signature the next one is captured over static input / state buffers and replayed from then on: one graph launch per tick
+    instead of a launch sequence the HOST cannot issue as fast as the device runs its first fifteen kernels (140 us of a 1.04 ms
+    tick, profiles/r06y_stream_tick_order.txt).  The final tick and any tick of another shape leave graph mode (the state is
+    copied back out) and run eagerly."""
+
+    _KEYS = ("prev_addin", "buffer_before_downsampling", "buffer_after_downsampling", "past_encoder_ctx")
+
+    def __init__(self, s2t):
+        self.s2t, self.graph, self.sig, self.in_graph, self.n_replays = s2t, None, None, False, 0
+
+    @classmethod
+    def signature(cls, speech, bst):
+        fe, en = bst["frontend"], bst["encoder"]
+        if fe is None or en is None or any(en.get(k) is None for k in cls._KEYS) or not isinstance(en["n_processed_blocks"], int) \
+                or en["n_processed_blocks"] <= 0:
+            return None
+        return (tuple(speech.shape), tuple(fe["waveform_buffer"].shape)) + tuple(tuple(en[k].shape) for k in cls._KEYS)
+
+    def _body(self):
+        s2t, m = self.s2t, self.s2t.asr_model
+        feats, nfe = s2t.apply_frontend_batch(self.s_in, self.s_fe, is_final=False)
+        enc, y_len, nen = m.encoder.forward_infer_batch(feats, dict(self.s_en), False)
+        return m.ctc.argmax(enc, as_int32=True), y_len, nfe, nen
+
+    def capture(self, speech_dev, bst):
+        """`bst`: the state BEHIND an eager tick of this shape (what the next tick starts from)."""
+        fe, en = bst["frontend"], bst["encoder"]
+        self.s_in = speech_dev.clone()
+        self.s_fe = {"waveform_buffer": fe["waveform_buffer"].clone()}
+        self.s_en = {k: en[k].clone() for k in self._KEYS}
+        self.s_en["n_processed_blocks"] = 1  # (> 0: steady state; the real counts live on the device)
+        self.s_en["n_processed_blocks_dev"] = torch.full((speech_dev.size(0),), en["n_processed_blocks"], dtype=torch.int32,
+                                                         device=speech_dev.device)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=speech_dev.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up on a side stream (allocator, workspaces, shape caches); the static state is not written
+            self._body()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ids, y_len, nfe, nen = self._body()
+            self.s_fe["waveform_buffer"].copy_(nfe["waveform_buffer"])  # the state carried forward inside the graph
+            for k in self._KEYS:
+                self.s_en[k].copy_(nen[k])
+            self.blocks_per_tick = nen["n_processed_blocks"] - 1
+            self.s_en["n_processed_blocks_dev"].add_(self.blocks_per_tick)
+        assert y_len > 0
+        self.graph, self.s_ids, self.in_graph = g, ids, False
+
+    def replay(self, speech, bst):
+        """One tick from the static state; returns the (static) ids tensor.  `bst` keeps only the host-side block count while in
+        graph mode."""
+        if not self.in_graph:  # enter graph mode: this group's state into the static buffers
+            fe, en = bst["frontend"], bst["encoder"]
+            self.s_fe["waveform_buffer"].copy_(fe["waveform_buffer"])
+            for k in self._KEYS:
+                self.s_en[k].copy_(en[k])
+            self.s_en["n_processed_blocks_dev"].fill_(en["n_processed_blocks"])
+            self.in_graph = True
+        self.s_in.copy_(speech, non_blocking=True)
+        self.graph.replay()
+        self.n_replays += 1
+        bst["encoder"]["n_processed_blocks"] += self.blocks_per_tick
+        return self.s_ids
+
+    def leave(self, bst):
+        """Back to eager ticks: the state out of the static buffers."""
+        if self.in_graph:
+            bst["frontend"] = {"waveform_buffer": self.s_fe["waveform_buffer"].clone()}
+            for k in self._KEYS:
+                bst["encoder"][k] = self.s_en[k].clone()
+            self.in_graph = False
 
 
 class PendingTick:

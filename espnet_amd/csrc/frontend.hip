@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "em_common.h"
+#include <type_traits>
 #include "switches.h"
 
 __device__ const float2 EM_TW512[384] = {
@@ -357,15 +358,28 @@ extern "C" int em_frontend_logmel_f32(const float* wav, int32_t B, int32_t N, in
   if (mel_maxlen < 1 || mel_maxlen > 257 || n_mels < 1) return EM_ERR_BAD_ARG;
   // ESPNET_AMD_FRONTEND_V1=1: developer A/B switch (one frame per wave, the kernel of rounds 1-4)
   const bool v1 = em_sw().frontend_v1;  // (the equality test toggles it in-process: em_dev_switches_reload)
-  constexpr int FR = 8;
   if (!v1 && mel_maxlen <= 32 && n_mels <= 80) {
-    dim3 grid(em_cdiv(T_f, 4 * FR), B);
-    if (mel_maxlen <= 20)  // (80 mel filters over 257 bins: 18)
-      hipLaunchKernelGGL((frontend_logmel_kernel2<20, FR>), grid, dim3(256), 0, (hipStream_t)stream, wav, N, hop, window,
+    // a wave walks FR frames with its frame-independent state in registers: 8 for a batch of utterances; 2 where that would
+    // leave the chip mostly idle (a streaming chunk is 67 frames: 3 workgroups per stream, 18 - 21 us of a serial walk -
+    // round 6).  Frames are independent: the same bits either way.
+    auto launch = [&](auto ml_c, auto fr_c) {
+      constexpr int ML = decltype(ml_c)::value, FR = decltype(fr_c)::value;
+      dim3 grid(em_cdiv(T_f, 4 * FR), B);
+      hipLaunchKernelGGL((frontend_logmel_kernel2<ML, FR>), grid, dim3(256), 0, (hipStream_t)stream, wav, N, hop, window,
                          mel_packed, mel_lo, mel_maxlen, n_mels, flens, wlens, T_f, feats);
-    else
-      hipLaunchKernelGGL((frontend_logmel_kernel2<32, FR>), grid, dim3(256), 0, (hipStream_t)stream, wav, N, hop, window,
-                         mel_packed, mel_lo, mel_maxlen, n_mels, flens, wlens, T_f, feats);
+    };
+    const bool few = (long)em_cdiv(T_f, 32) * B < 256;
+    using I2 = std::integral_constant<int, 2>;
+    using I8 = std::integral_constant<int, 8>;
+    using I20 = std::integral_constant<int, 20>;  // (80 mel filters over 257 bins: 18)
+    using I32 = std::integral_constant<int, 32>;
+    if (mel_maxlen <= 20) {
+      if (few) launch(I20{}, I2{});
+      else launch(I20{}, I8{});
+    } else {
+      if (few) launch(I32{}, I2{});
+      else launch(I32{}, I8{});
+    }
     EM_CHECK_LAUNCH();
     return EM_OK;
   }

@@ -28,7 +28,7 @@ namespace {
 //   slot L-1 = addin_i   = mean(frames of block i) * sqrt(d) + pe[i + n_proc]
 //   slot 0   = addin_{i-1} (i > 0), else prev_addin carried from the previous call, else addin_0
 //   slot 1+j = xs[cur + j] * sqrt(d) + pe[cur + hop * n_proc + j]; unused slots are zero
-__global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __restrict__ xs,
+__global__ __launch_bounds__(256) void cb_build_blocks_kernel_v1(const float* __restrict__ xs,
                                                               const float* __restrict__ pe,
                                                               const float* __restrict__ prev_addin,
                                                               int n_proc_host,
@@ -74,6 +74,75 @@ __global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __res
     }
     xb[c] = first;
     if (i == gridDim.x - 1) addin_out[c] = addin;
+  }
+}
+
+// Round 6: the same block, rows dealt to four thread groups (a thread: four columns of every fourth row) instead of a thread
+// per column walking all 40 rows - 13.4 us of a serial walk per tick for 1.4 MB (profiles/r06w_stream_tick_order.txt).  The
+// block's mean is the sum of the four groups' sums in a fixed order ((g0 + g1) + (g2 + g3)): deterministic, the same for one
+// stream and for a batch; against the serial sum of the first version it differs by f32 round-off only.  d % 4 == 0, d <= 1024.
+__global__ __launch_bounds__(256) void cb_build_blocks_kernel(const float* __restrict__ xs,
+                                                              const float* __restrict__ pe,
+                                                              const float* __restrict__ prev_addin,
+                                                              int n_proc_host,
+                                                              const int* __restrict__ n_proc_dev, int np_stride,
+                                                              int total, int bs, int hs,
+                                                              int d, float xscale,
+                                                              float* __restrict__ x,
+                                                              float* __restrict__ addin_out) {
+  __shared__ float4 part[2][4][256];
+  const int i = blockIdx.x, L = bs + 2, nq = d >> 2;
+  const int sidx = blockIdx.y;
+  xs += (size_t)sidx * total * d;
+  if (prev_addin) prev_addin += (size_t)sidx * d;
+  x += (size_t)sidx * gridDim.x * L * d;
+  addin_out += (size_t)sidx * d;
+  const int n_proc = n_proc_dev ? n_proc_dev[(size_t)sidx * np_stride] : n_proc_host;
+  float* xb = x + (size_t)i * L * d;
+  const int cur = i * hs;
+  const int clen = (total - cur) < bs ? (total - cur) : bs;
+  const int pcur = (i - 1) * hs;
+  const int plen = i > 0 ? ((total - pcur) < bs ? (total - pcur) : bs) : 0;
+  const int g = threadIdx.x >> 6, q0 = threadIdx.x & 63;
+  auto add4 = [](float4 a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; return a; };
+  for (int q = q0; q < nq; q += 64) {
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), ps = sum;
+    for (int j = g; j < bs; j += 4) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < clen) {
+        const float4 v = *(const float4*)(xs + (size_t)(cur + j) * d + 4 * q);
+        const float4 p = *(const float4*)(pe + (size_t)(cur + hs * n_proc + j) * d + 4 * q);
+        sum = add4(sum, v);
+        o = make_float4(v.x * xscale + p.x, v.y * xscale + p.y, v.z * xscale + p.z, v.w * xscale + p.w);
+      }
+      *(float4*)(xb + (size_t)(1 + j) * d + 4 * q) = o;
+    }
+    for (int j = g; j < plen; j += 4) ps = add4(ps, *(const float4*)(xs + (size_t)(pcur + j) * d + 4 * q));
+    part[0][g][q] = sum;
+    part[1][g][q] = ps;
+  }
+  __syncthreads();
+  if (g == 0) {
+    for (int q = q0; q < nq; q += 64) {
+      const float4 s4 = add4(add4(part[0][0][q], part[0][1][q]), add4(part[0][2][q], part[0][3][q]));
+      const float4 pa = *(const float4*)(pe + (size_t)(i + n_proc) * d + 4 * q);
+      const float fc = (float)clen;
+      const float4 addin = make_float4((s4.x / fc) * xscale + pa.x, (s4.y / fc) * xscale + pa.y, (s4.z / fc) * xscale + pa.z,
+                                       (s4.w / fc) * xscale + pa.w);
+      *(float4*)(xb + (size_t)(L - 1) * d + 4 * q) = addin;
+      float4 first;
+      if (i > 0) {  // the previous block's context: recomputed here, no inter-workgroup dependency
+        const float4 p4 = add4(add4(part[1][0][q], part[1][1][q]), add4(part[1][2][q], part[1][3][q]));
+        const float4 pp = *(const float4*)(pe + (size_t)(i - 1 + n_proc) * d + 4 * q);
+        const float fp = (float)plen;
+        first = make_float4((p4.x / fp) * xscale + pp.x, (p4.y / fp) * xscale + pp.y, (p4.z / fp) * xscale + pp.z,
+                            (p4.w / fp) * xscale + pp.w);
+      } else {
+        first = prev_addin ? *(const float4*)(prev_addin + 4 * q) : addin;
+      }
+      *(float4*)(xb + 4 * q) = first;
+      if (i == (int)gridDim.x - 1) *(float4*)(addin_out + 4 * q) = addin;
+    }
   }
 }
 
@@ -449,7 +518,11 @@ extern "C" int em_cb_build_blocks_f32(const float* xs, const float* pe, const fl
   if (!xs || !pe || !x || !addin_out || n_blk <= 0 || total <= 0 || bs <= 0 || hs <= 0 || d <= 0)
     return EM_ERR_BAD_ARG;
   if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
-  hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk), dim3(256), 0, (hipStream_t)stream, xs, pe,
+  if (d % 4 == 0 && d <= 1024)
+    hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk), dim3(256), 0, (hipStream_t)stream, xs, pe,
+                     prev_addin, n_proc, n_proc_dev, 0, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+  else
+    hipLaunchKernelGGL(cb_build_blocks_kernel_v1, dim3(n_blk), dim3(256), 0, (hipStream_t)stream, xs, pe,
                      prev_addin, n_proc, n_proc_dev, 0, total, bs, hs, d, sqrtf((float)d), x, addin_out);
   EM_CHECK_LAUNCH();
   return EM_OK;
@@ -461,7 +534,11 @@ extern "C" int em_cb_build_blocks_batch_f32(const float* xs, const float* pe, co
   if (!xs || !pe || !x || !addin_out || n_streams <= 0 || n_blk <= 0 || total <= 0 || bs <= 0 || hs <= 0 || d <= 0)
     return EM_ERR_BAD_ARG;
   if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
-  hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
+  if (d % 4 == 0 && d <= 1024)
+    hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
+                     prev_addin, n_proc, (const int*)nullptr, 0, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+  else
+    hipLaunchKernelGGL(cb_build_blocks_kernel_v1, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
                      prev_addin, n_proc, (const int*)nullptr, 0, total, bs, hs, d, sqrtf((float)d), x, addin_out);
   EM_CHECK_LAUNCH();
   return EM_OK;
@@ -474,7 +551,11 @@ extern "C" int em_cb_build_blocks_rows_f32(const float* xs, const float* pe, con
       hs <= 0 || d <= 0)
     return EM_ERR_BAD_ARG;
   if ((n_blk - 1) * hs >= total) return EM_ERR_BAD_ARG;  // every block holds at least one frame
-  hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
+  if (d % 4 == 0 && d <= 1024)
+    hipLaunchKernelGGL(cb_build_blocks_kernel, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
+                     prev_addin, 0, n_proc_rows, 1, total, bs, hs, d, sqrtf((float)d), x, addin_out);
+  else
+    hipLaunchKernelGGL(cb_build_blocks_kernel_v1, dim3(n_blk, n_streams), dim3(256), 0, (hipStream_t)stream, xs, pe,
                      prev_addin, 0, n_proc_rows, 1, total, bs, hs, d, sqrtf((float)d), x, addin_out);
   EM_CHECK_LAUNCH();
   return EM_OK;

@@ -472,6 +472,19 @@ def test_batch_call_equals_single_streams(tmp_path):
     assert per_tick[0][-1] == got and per_tick[1][-1] == [got[j] for j in perm]
     assert all(len(a[0]) <= len(b[0]) for a, b in zip(per_tick[0], per_tick[0][1:]))  # (ids only ever grow)
     assert not s2t._batches
+    # ... and with the steady-state tick of a group replayed as one hipGraph (BatchTickGraph: eager until two ticks in a row have
+    # the same shapes, the next one captured, the rest replayed; the final - shorter - tick eager again): the same ids, tick by
+    # tick, for two utterances in a row (the second one replays the first one's graph)
+    s2t.use_hipgraph = True
+    for rep in range(2):
+        ticks = []
+        for pos in range(0, N, CH):
+            nxt = min(N, pos + CH)
+            ticks.append(s2t.batch_call(wavs[:, pos:nxt].contiguous().pin_memory(), is_final=(nxt == N)))
+        assert ticks == per_tick[0], rep
+    tgs = list(s2t._tick_graphs.values())
+    assert len(tgs) == 1 and tgs[0].n_replays >= 6, [t.n_replays for t in tgs]
+    s2t.use_hipgraph = False
 
 
 def test_stream_pool_ragged(tmp_path):

@@ -19,6 +19,9 @@ if what in ("one", "both"):
 if what in ("batch", "both"):
     r = bench.run_stream_batch("bfloat16", 32, 3, 1)
     out["batch32"] = {"audio_s_per_s": r["value"], "tick_ms": r["tick_latency_ms_median"]}
+if what in ("graph", "both"):
+    r = bench.run_stream_batch("bfloat16", 32, 3, 1, graph=True)
+    out["batch32_hipgraph"] = {"audio_s_per_s": r["value"], "tick_ms": r["tick_latency_ms_median"], "replays": r["hipgraph_replays"]}
 if what in ("groups", "both"):
     for n in (32, 128):
         r = bench.run_stream_batch("bfloat16", n, 3, 1, groups=2)
