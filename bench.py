@@ -27,7 +27,7 @@ HBM peak), `encoder_large_b64` (the Conformer-large encoder at configs[3]'s per-
 traffic of its dominant one), `encoder_ebranchformer_b32` (the E-Branchformer encoder with its roofline),
 `beam` (configs[2] with the roofline of the search and `bf16_vs_oracle`: per-token error, best-score loss beside the
 oracle search's own path noise, token edit distance), `beam_cfg3_per_gpu` (configs[3]'s per-GPU batch on one GPU,
-with `bf16_vs_oracle`; both beam legs with two joint searches in flight, `SearchLanes`) and `stream` (configs[4] + the 40 ms-per-call
+with `bf16_vs_oracle`; both beam legs with four joint searches in flight, a host thread each: `SearchLanes`) and `stream` (configs[4] + the 40 ms-per-call
 stress case); `box_state` (three probes of the pool's slow state: a slow lease is labelled, not read as a regression).  `--quick`
 keeps only the main line, `roofline` and `cpu_baseline`.
 """
@@ -668,6 +668,8 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, wan
     model = ASRTask.build_model(model_config("large", args.dtype)).to(dev).eval()
     bs = build_beam_search(model, beam_size=beam, ctc_weight=args.ctc_weight, penalty=0.0,
                            token_list=model.token_list)
+    if os.environ.get("BENCH_SEARCH_EAGER"):  # developer probe: label steps as eager launches from em_search_steps, no hipGraph
+        bs.use_hipgraph = False
     if os.environ.get("BENCH_STEP_CHUNK"):  # developer probe: label steps enqueued between two polls of the `done` flags
         bs.step_chunk = int(os.environ["BENCH_STEP_CHUNK"])
     rank = int(os.environ.get("RANK", "0"))
@@ -710,7 +712,11 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, wan
         # host-side readout of a finished search overlaps the other lane's steps.
         from espnet_amd.nets.batch_beam_search import SearchLanes
 
-        lanes = SearchLanes([bs] + [bs.clone() for _ in range(depth - 1)], dev)
+        # (lane streams that really sit on different hardware queues; BENCH_LANE_STREAMS=plain: whatever torch hands out, round 6's first form)
+        lane_streams = None if os.environ.get("BENCH_LANE_STREAMS") == "plain" else StepPipeline._pick(dev, depth)[0]
+        # (BENCH_LANE_THREADS=1 / args.lane_threads: a host thread per lane - the lanes' launches in parallel, see SearchLanes)
+        lane_threads = bool(getattr(args, "lane_threads", False)) or os.environ.get("BENCH_LANE_THREADS") == "1"
+        lanes = SearchLanes([bs] + [bs.clone() for _ in range(depth - 1)], dev, streams=lane_streams, threaded=lane_threads)
 
         def lane_start(k, u):
             with torch.cuda.stream(lanes.stream(k)):
@@ -744,6 +750,8 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, wan
                                                 counter=counter)
         barrier()
         elapsed = time.perf_counter() - t0
+        if lanes is not None:
+            lanes.close()
         step(instrument=True)
     n_tok = sum(len(t) for t, _ in hyps[-B:])
     es = 2 if args.dtype == "bfloat16" else 4
@@ -754,7 +762,7 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, wan
            "search": {"ms_per_search_step": round(t_search[0] / max(1, n_steps) * 1e3, 4),
                       "search_steps_per_utt_batch": n_steps, "steps_per_s": round(n_steps / t_search[0], 1),
                       "rows": B * beam,
-                      "batches_in_flight": depth,
+                      "batches_in_flight": depth, "host_threads": depth if (lanes is not None and lane_threads) else 1,
                       "what": "ms_per_search_step: ONE search alone on the chip (latency of a label step); `value` of this "
                               "object's parent: `batches_in_flight` searches on as many HIP streams",
                       "roofline": {"bound": "hbm", "achieved": round(per_step * n_steps / t_search[0] / 1e9, 1),
@@ -1145,8 +1153,12 @@ def main():
     ap.add_argument("--h2d", action="store_true",
                     help="main loop with the waveforms arriving in pinned host memory (H2D overlapped with "
                          "compute); the default run reports this as the `pcie_inclusive` sub-object instead")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="greedy workload: batches in flight on as many HIP streams (1 = one stream, steps back to back)")
+    ap.add_argument("--in-flight", type=int, default=None,
+                    help="batches in flight on as many HIP streams: greedy workload default 2 (1 = one stream, steps back to "
+                         "back), beam workload default 4 joint searches (a host thread each)")
+    ap.add_argument("--no-lane-threads", action="store_true",
+                    help="beam workload: ONE host thread drives every search in flight (round 6's first form; saturates at two lanes) "
+                         "instead of a host thread per lane (SearchLanes(threaded=True))")
     ap.add_argument("--quick", action="store_true", help="main line + roofline + cpu_baseline only")
     ap.add_argument("--dist-debug-one-gpu", action="store_true",
                     help="developer check of the multi-rank control flow on a ONE-GPU box: every rank uses "
@@ -1165,7 +1177,10 @@ def main():
     if args.batch is None:
         args.batch = 32 if args.workload == "greedy" else 16
     if args.workload == "beam" and args.steps == 2000 and args.warmup == 50:
-        args.steps, args.warmup = 6, 1  # a beam step is ~100x a greedy one
+        args.steps, args.warmup = 12, 1  # a beam step is ~100x a greedy one
+    if args.in_flight is None:
+        args.in_flight = 4 if args.workload == "beam" else 2
+    args.lane_threads = not args.no_lane_threads
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become the launcher (the contract's own command line,
@@ -1538,6 +1553,7 @@ def main():
             def fn():
                 a2 = argparse.Namespace(**vars(args))
                 a2.model = "large"
+                a2.in_flight, a2.lane_threads = 4, True  # four joint searches in flight, a host thread per lane
                 r = run_beam(a2, dev, Bb, 10, steps, 1, cpu_base=cpu and not args.no_cpu_baseline,
                              want_traffic=cpu,  # counters for the configs[2] leg only
                              want_oracle=not args.no_cpu_baseline)  # ... the oracle check of utterance 0 for both
@@ -1598,8 +1614,8 @@ def main():
         torch.cuda.empty_cache()
         guarded("encoder_large_b64", encoder_leg("large", 64, 68.56, "Conformer-large (12x512d, 8 heads, ff 2048)", want_pmc=True))
         guarded("encoder_ebranchformer_b32", encoder_leg("ebf", 32, None, "E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31)", want_pmc=True))
-        guarded("beam", beam_leg(16, 6, True))
-        guarded("beam_cfg3_per_gpu", beam_leg(64, 4, False))
+        guarded("beam", beam_leg(16, 12, True))
+        guarded("beam_cfg3_per_gpu", beam_leg(64, 8, False))
         guarded("stream", stream_leg)
     if rank == 0:
         print(json.dumps(out), flush=True)

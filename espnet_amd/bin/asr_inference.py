@@ -134,16 +134,21 @@ class Speech2Text:
         enqueue the next batch first and format this one while the GPU runs.  The beam search polls the
         device between step chunks and therefore completes inside this call."""
         if not self.ctc_greedy:
-            # Round 6: two joint searches in flight (espnet_amd.nets.batch_beam_search.SearchLanes) - this batch is encoded
+            # Round 6: several joint searches in flight (espnet_amd.nets.batch_beam_search.SearchLanes) - this batch is encoded
             # and its search started on a free lane's stream, the handle's `.result()` drives the lanes until it has ended.
-            # A caller that submits batch n + 1 before it asks for batch n (the decode CLI does) keeps both lanes busy.
+            # A caller that submits batch n + 1 before it asks for batch n (the decode CLI does) keeps the lanes busy.
             lanes = self.__dict__.get("_lanes")
             if lanes is None:
                 from espnet_amd.nets.batch_beam_search import SearchLanes
 
-                lanes = self._lanes = SearchLanes([self.beam_search, self.beam_search.clone()], self.device)
+                # (four lanes, a host thread each: with ONE host thread two lanes already saturate the host's launch rate -
+                # 2 / 3 / 4 lanes 60.4 / 60.3 / 60.9 ms per batch of 16 - with a thread per lane 4 lanes reach 48.0;
+                # profiles/r06z_beam_lanes_threads_ab.txt.  `search_lanes` / `lane_threads` attributes: set before the first call)
+                n_lanes = max(1, int(getattr(self, "search_lanes", 4)))
+                lanes = self._lanes = SearchLanes([self.beam_search] + [self.beam_search.clone() for _ in range(n_lanes - 1)],
+                                                  self.device, threaded=bool(getattr(self, "lane_threads", True)))
             k = lanes.free_lane()
-            if k is None:  # (both lanes carry searches nobody has asked for yet: finish this one on the calling stream)
+            if k is None:  # (every lane carries a search nobody has asked for yet: finish this one on the calling stream)
                 return _Done(self.batch_decode(speech, speech_lengths))
             with torch.cuda.stream(lanes.stream(k)):
                 speech = speech.to(self.device, torch.float32, non_blocking=True)

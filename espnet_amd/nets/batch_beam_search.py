@@ -70,12 +70,17 @@ class BeamSearch:
         self._graphs = {}
         self.max_live_shapes = 3  # buffer sets (and their captured graphs) kept for recurring batch shapes
         self.step_chunk = 16  # steps enqueued between two polls of the `done` flags
-        self.use_hipgraph = True  # replay a captured hipGraph of `step_chunk` search steps
+        # use_hipgraph: replay a captured hipGraph of `step_chunk` search steps instead of em_search_steps' eager launches.  On by
+        # default through round 5; round 6 measured the eager launches (issued from C, ~2.5 us each) no slower - one search alone
+        # 0.343 against 0.352 ms per label step, four searches in flight 46.1 against 47.5 - 49.3 ms per batch of 16
+        # (profiles/r06z_beam_eager_ab.txt) - and a capture cannot run while another host thread launches (SearchLanes'
+        # threaded lanes: hipErrorStreamCaptureInvalidated).  Off by default; ESPNET_AMD_SEARCH_GRAPH=1 turns it on.
+        self.use_hipgraph = False
         # (Round 2 also cut the batch into sub-batch searches on concurrent HIP streams: 0.646 -> 0.740 (2 lanes) ->
         # 1.332 ms (4) per label step, profiles/r02_experiments_not_kept.txt - the launches of the lanes do not
         # overlap.  Removed in round 3; the search is one generator over the whole batch.)
-        if os.environ.get("ESPNET_AMD_SEARCH_GRAPH") == "0":
-            self.use_hipgraph = False
+        if os.environ.get("ESPNET_AMD_SEARCH_GRAPH") == "1":
+            self.use_hipgraph = True
 
 
 class BatchBeamSearch(BeamSearch):
@@ -359,13 +364,59 @@ class SearchLanes:
         tag, nbest = lanes.poll(k)               # None while lane k is still searching
     `lanes.stream(k)` is the stream to run the lane's encoder call on."""
 
-    def __init__(self, searches, device):
+    def __init__(self, searches, device, streams=None, threaded=False):
+        """`streams`: one HIP stream per lane (default: new ones).  HIP deals streams onto a handful of hardware queues and two
+        streams on the same queue serialise - a caller that wants the lanes side by side probes for streams that are
+        (bench.py `StepPipeline._pick`)."""
         import torch as _t
 
         self.searches = list(searches)
-        self.streams = [_t.cuda.Stream(device=device) for _ in self.searches]
+        self.streams = list(streams) if streams is not None else [_t.cuda.Stream(device=device) for _ in self.searches]
+        assert len(self.streams) == len(self.searches)
+        # threaded: a HOST THREAD per lane runs the lane's whole search (search_batch) on the lane's stream.  With one host
+        # thread the lanes saturate at two: 249 label steps x 47 launches x ~2.5 us of hipLaunchKernel per search is the host's
+        # launch rate, not the device (profiles/r06z_beam_lanes_ab.txt: 2 / 3 / 4 lanes 60.4 / 60.3 / 60.9 ms per batch).  ctypes
+        # releases the GIL inside em_search_steps and torch inside its waits, so the lanes' launches proceed in parallel
+        # (profiles/r06z_beam_threads_probe.txt: 2 / 3 / 6 threads 61.7 / 54.3 / 49.7 ms per batch of 16).
+        self.threaded = bool(threaded)
+        if self.threaded:
+            for bs_ in self.searches:  # (a graph capture while another lane's thread launches is invalid: eager label steps)
+                bs_.use_hipgraph = False
+            import queue
+            import threading
+
+            self._jobs = [queue.SimpleQueue() for _ in self.searches]
+            self._res = [None] * len(self.searches)
+            self._done = threading.Event()
+            self._threads = [threading.Thread(target=self._worker, args=(k,), daemon=True) for k in range(len(self.searches))]
+            for t in self._threads:
+                t.start()
         self.state = [None] * len(self.searches)
         self.ready = {}  # results finished while another lane was being waited for (`wait`)
+
+    def _worker(self, k):
+        while True:
+            job = self._jobs[k].get()
+            if job is None:
+                return
+            tag, args = job
+            try:
+                with torch.no_grad(), torch.cuda.stream(self.streams[k]):
+                    out = self.searches[k].search_batch(*args)
+                    torch.cuda.current_stream().synchronize()
+                self._res[k] = (tag, out, None)
+            except BaseException as e:  # handed to the thread that polls
+                self._res[k] = (tag, None, e)
+            self._done.set()
+
+    def close(self):
+        """Threaded lanes: end the worker threads (idle lanes only)."""
+        if self.threaded:
+            for q in self._jobs:
+                q.put(None)
+            for t in self._threads:
+                t.join()
+            self.threaded = False
 
     def __len__(self):
         return len(self.searches)
@@ -379,6 +430,11 @@ class SearchLanes:
     @torch.no_grad()
     def start(self, k, enc_act, olens, tag=None, maxlenratio: float = 0.0, minlenratio: float = 0.0):
         assert self.state[k] is None, "lane is busy"
+        if self.threaded:  # (enc_act was produced on this lane's stream or is complete: the worker's launches follow it there)
+            self.state[k] = dict(tag=tag)
+            self._res[k] = None
+            self._jobs[k].put((tag, (enc_act, olens, maxlenratio, minlenratio)))
+            return
         with torch.cuda.stream(self.streams[k]):
             gen = self.searches[k]._search_run(enc_act, olens, maxlenratio, minlenratio)
             try:
@@ -393,6 +449,18 @@ class SearchLanes:
         (tag, n-best lists) once the search has ended, else None."""
         st = self.state[k]
         assert st is not None, "lane is idle"
+        if self.threaded:
+            r = self._res[k]
+            if r is None:  # (no spinning on the GIL the workers need: sleep until some lane reports, a millisecond at most)
+                self._done.wait(0.001)
+                self._done.clear()
+                r = self._res[k]
+                if r is None:
+                    return None
+            self._res[k], self.state[k] = None, None
+            if r[2] is not None:
+                raise r[2]
+            return r[0], r[1]
         with torch.cuda.stream(self.streams[k]):
             if st["out"] is None:
                 msg = bool(st["req"].all().item())

@@ -267,7 +267,7 @@ def test_search_lanes_equal_searches_run_alone(dtype):
     """Round 6, SearchLanes: several joint searches in flight on as many HIP streams (each lane its own buffer set and
     hipGraph over the SAME scorers) return, bit for bit, what each search returns run alone - five different ragged
     batches dealt over two lanes and over three, more batches than lanes (a lane is reused), searches of different lengths
-    in flight together (the short one finishes while the long one is mid-way)."""
+    in flight together (the short one finishes while the long one is mid-way); the same with a host thread per lane (two and four)."""
     from espnet_amd.nets.batch_beam_search import SearchLanes
 
     g = load_golden("tiny_beam4_early_eos")
@@ -282,8 +282,10 @@ def test_search_lanes_equal_searches_run_alone(dtype):
         batches.append((enc.to(torch.bfloat16 if dtype == "bfloat16" else torch.float32).cuda(), lens))
     alone_bs = build_search(g, sd, dtype)
     alone = [alone_bs.search_batch(e, l) for e, l in batches]
-    for n_lanes in (2, 3):
-        lanes = SearchLanes([build_search(g, sd, dtype) for _ in range(n_lanes)], torch.device("cuda"))
+    torch.cuda.synchronize()
+    # (threaded: a host thread per lane runs the lane's search - the lanes' launches are then issued in parallel)
+    for n_lanes, threaded in ((2, False), (3, False), (2, True), (4, True)):
+        lanes = SearchLanes([build_search(g, sd, dtype) for _ in range(n_lanes)], torch.device("cuda"), threaded=threaded)
         todo, got, unit_of = list(range(len(batches))), {}, [None] * n_lanes
         while todo or any(u is not None for u in unit_of):
             for k in range(n_lanes):
@@ -306,6 +308,7 @@ def test_search_lanes_equal_searches_run_alone(dtype):
                     assert a.yseq.tolist() == b.yseq.tolist()
                     assert float(a.score) == float(b.score)
                     assert {k: float(v) for k, v in a.scores.items()} == {k: float(v) for k, v in b.scores.items()}
+        lanes.close()
 
 
 def test_search_structure_invariants():
