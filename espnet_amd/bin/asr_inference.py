@@ -351,17 +351,21 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
                         w["text"][key] = text
                 written += 1
 
-        inflight = None  # one batch stays enqueued on the GPU while the previous one is formatted and written
+        # batches stay enqueued on the GPU while earlier ones are formatted and written: one for greedy CTC (two batches in
+        # flight on alternating streams), three for the joint search (four searches in flight, a host thread each)
+        import collections
+
+        depth = 1 if getattr(speech2text, "ctc_greedy", False) else max(1, int(getattr(speech2text, "search_lanes", 4)) - 1)
+        inflight = collections.deque()
         for keys, batch in loader:
             assert all(isinstance(s, str) for s in keys), keys
             assert len(keys) == batch["speech"].size(0)
             n_samples += int(batch["speech_lengths"].sum())
-            nxt = (keys, submit(keys, batch))
-            if inflight is not None:
-                drain(*inflight)
-            inflight = nxt
-        if inflight is not None:
-            drain(*inflight)
+            inflight.append((keys, submit(keys, batch)))
+            while len(inflight) > depth:
+                drain(*inflight.popleft())
+        while inflight:
+            drain(*inflight.popleft())
         assert not pending, sorted(pending)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
