@@ -307,6 +307,22 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
         return self.forward_infer(xs_pad, ilens, prev_states, is_final)
 
     @torch.no_grad()
+    def _empty_out(self, dev):
+        e = self.__dict__.get("_empty_cache")
+        if e is None or e[0].device != dev:
+            e = self._empty_cache = (torch.zeros(1, 0, self._output_size, device=dev), torch.zeros(1, device=dev))
+        return e
+
+    def _olen_out(self, dev, n):
+        c = self.__dict__.setdefault("_olen_cache", {})
+        t = c.get((dev, n))
+        if t is None:
+            if len(c) > 256:
+                c.clear()
+            t = c[(dev, n)] = torch.full((1,), float(n), device=dev)
+            torch.cuda.current_stream().synchronize()  # (filled before any stream may read it)
+        return t
+
     def forward_infer(self, xs_pad: torch.Tensor, ilens: torch.Tensor, prev_states=None,
                       is_final: bool = True) -> Tuple[torch.Tensor, torch.Tensor, Optional[dict]]:
         """contextual_block_conformer_encoder.py:386-600.  xs_pad (1, t, idim) f32 ON THE GPU."""
@@ -324,7 +340,7 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
         xs = xs_pad[0].to(torch.float32)
         if st["buffer_before_downsampling"] is not None:
             xs = torch.cat([st["buffer_before_downsampling"], xs], dim=0)
-        empty = (xs.new_zeros(1, 0, d), xs.new_zeros(1))
+        empty = self._empty_out(dev)  # (cached: two fills per call otherwise)
         if is_final:
             buf_before = None
         else:
@@ -360,7 +376,7 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
             L.check(lib.em_stream_pos_enc_f32(L.ptr(x), L.ptr(pk["pe"]), 0, total, d, L.ptr(xc), stream),
                     "em_stream_pos_enc_f32")
             self._encode_blocks(xc, 0, None, None)
-            return self._after_norm(xc[0]).unsqueeze(0), xs.new_zeros(1), None
+            return self._after_norm(xc[0]).unsqueeze(0), self._olen_out(dev, 0), None
         chunks = torch.empty(block_num, bs + 2, d, dtype=torch.float32, device=dev)
         addin = torch.empty(d, dtype=torch.float32, device=dev)
         n_proc_dev = st.get("n_processed_blocks_dev")  # set by StreamingStepGraph only
@@ -376,7 +392,8 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
             y_len = x.size(0) if n_proc == 0 else x.size(0) - offset
         else:
             y_len = block_num * hs + (offset if n_proc == 0 else 0)
-        ys = torch.zeros(y_len, d, dtype=torch.float32, device=dev)
+        # (not final: the head piece and the blocks' hops below tile [0, y_len) exactly - nothing to clear)
+        ys = (torch.zeros if is_final else torch.empty)(y_len, d, dtype=torch.float32, device=dev)
         if n_proc == 0:
             ys[:offset] = ys_chunk[0, :offset]
         for i in range(block_num):  # :565-576 (slicing only)
@@ -384,7 +401,7 @@ class ContextualBlockConformerEncoder(torch.nn.Module):
             clen = min(bs - offset, y_len - cur) if (i == block_num - 1 and is_final) else hs
             ys[cur : cur + clen] = ys_chunk[i, offset : offset + clen]
         ys = self._after_norm(ys).unsqueeze(0)
-        olen = xs.new_full((1,), float(y_len))  # device fill (capturable), as the reference returns it
+        olen = self._olen_out(dev, y_len)  # (f32 (1,) on the device as the reference returns it; cached per value: read-only)
         if is_final:
             return ys, olen, None
         return ys, olen, dict(prev_addin=addin, buffer_before_downsampling=buf_before,
