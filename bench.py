@@ -1615,7 +1615,7 @@ def main():
         guarded("encoder_large_b64", encoder_leg("large", 64, 68.56, "Conformer-large (12x512d, 8 heads, ff 2048)", want_pmc=True))
         guarded("encoder_ebranchformer_b32", encoder_leg("ebf", 32, None, "E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31)", want_pmc=True))
         guarded("beam", beam_leg(16, 12, True))
-        guarded("beam_cfg3_per_gpu", beam_leg(64, 8, False))
+        guarded("beam_cfg3_per_gpu", beam_leg(64, 12, False))
         guarded("stream", stream_leg)
     if rank == 0:
         print(json.dumps(out), flush=True)
