@@ -27,6 +27,16 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("embed large", 3984, 512, 9728, L.EM_EPI_SCALE_F32),
     ("qkv large", 3984, 1536, 512, L.EM_EPI_STORE),
     ("out large", 3984, 512, 512, L.EM_EPI_RESID_F32),
+    # E-Branchformer (17 x 512d, ff 2048, cgMLP 3072), B = 32: 7 968 rows
+    ("ebf ffn_w1", 7968, 2048, 512, L.EM_EPI_SWISH),
+    ("ebf ffn_w2", 7968, 512, 2048, L.EM_EPI_RESID_F32),
+    ("ebf cgmlp_p1", 7968, 3072, 512, L.EM_EPI_GELU),
+    ("ebf cgmlp_p2", 7968, 512, 1536, L.EM_EPI_STORE),
+    ("ebf qkv", 7968, 1536, 512, L.EM_EPI_STORE),
+    ("ebf merge", 7968, 512, 1024, L.EM_EPI_RESID_F32),
+    # Conformer-large, B = 64: 15 936 rows
+    ("large64 ffn_w1", 15936, 2048, 512, L.EM_EPI_SWISH),
+    ("large64 qkv", 15936, 1536, 512, L.EM_EPI_STORE),
 ]
 
 
