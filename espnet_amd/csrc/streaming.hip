@@ -627,13 +627,15 @@ static int cb_encode_blocks_impl(int dtype, const EmConformerWeights* w, float* 
   void *xn = ws + s.xn, *big = ws + s.big, *gl = ws + s.g, *g2 = ws + s.g2, *ctx = ws + s.ctx;
   if (fused) {
     // ---- round 4: the layer as FIVE launches instead of thirteen, on the row-block kernels of the Conformer path
-    // (csrc/block.hip; a block of L <= 64 slots = an "utterance" of two 32-row workgroups):
-    //   block<A | RELU>   norm_ff_macaron + macaron FFN (ReLU, ff up to 4096) + norm_mha + q / k / v per head
-    //   cb_mha_heads      plain multi-head attention over the block's slots (contextual mask)
-    //   block<C>          linear_out + residual, norm_conv, pointwise_conv1 + GLU
-    //   block<D | RELU>   depthwise conv (k = 15) + BN + Swish, pointwise_conv2 + residual, norm_ff, FFN, norm_final
-    //   propagate_ctx     the context hand-over between blocks (why D and the next layer's A stay separate launches)
-    // contextual_block_encoder_layer.py:197-310.  One stream, one block: 1.18 ms -> see profiles/r04*_stream*.
+    // (csrc/block.hip; a block of L <= 64 slots = an "utterance" of two 32-row workgroups); round 6: THREE -
+    //   block<A | RELU>        norm_ff_macaron + macaron FFN (ReLU, ff up to 4096) + norm_mha + q / k / v per head
+    //   block<ATT | C | RELU>  plain multi-head attention over the block's slots (contextual mask) in front of
+    //                          linear_out + residual, norm_conv, pointwise_conv1 + GLU   (rounds 4 - 5: cb_mha_heads + block<C>)
+    //   block<D | RELU>        depthwise conv (k = 15) + BN + Swish, pointwise_conv2 + residual, norm_ff, FFN, norm_final
+    //   (propagate_ctx: the context hand-over between blocks, why D and the next layer's A stay separate launches; with one
+    //   block per stream and call it is folded into A and D: fold_ctx below)
+    // On a chip the launch does not fill, the FFNs of A and D are dealt to 2 - 4 workgroups per row block (cb_ffn_split).
+    // contextual_block_encoder_layer.py:197-310.  One stream, one block: 1.18 ms (round 4) -> 0.64 ms per call of 12 layers.
     EmBlockArgs ba = {};
     ba.B = n_blk; ba.T = L; ba.Tpad = s.Tpad; ba.d = d; ba.ff = ff; ba.kernel = w->kernel; ba.eps = LN_EPS;
     ba.x = x; ba.ctx = ctx; ba.glu = gl; ba.qh = ws + s.qh; ba.kh = ws + s.kh; ba.vt = ws + s.vt;
