@@ -109,6 +109,7 @@ class Speech2TextStreaming:
         self.use_hipgraph = use_hipgraph
         self._runner = None
         self._flens_cache = {}  # (streams, samples, device) -> frame counts on the device (apply_frontend_batch)
+        self._pin_ring = {}  # chunk length -> two pinned staging rows + a turn counter (apply_frontend)
         self._tick_graphs = {}  # (group, chunk shape) -> BatchTickGraph of finished utterances (batch_call_async)
         self.reset()
 
@@ -142,11 +143,31 @@ class Speech2TextStreaming:
             speech_to_process = speech.narrow(0, 0, n_frames * self.hop_length)
             keep = (edge * 2 - 1) * self.hop_length + n_residual
             waveform_buffer = speech.narrow(0, speech.size(0) - keep, keep).clone()
-        wav = speech_to_process.unsqueeze(0).to(torch.float32).to(self.device)
-        n = wav.size(1)
+        # (the chunk through one of two pinned staging rows and an asynchronous copy, the frame count from a per-length cache:
+        # a pageable host -> device copy is synchronous, and there were two of them in front of every call's first launch)
+        n = speech_to_process.size(0)
+        if speech_to_process.is_cuda:
+            wav = speech_to_process.unsqueeze(0).to(torch.float32)
+        else:
+            pins = self.__dict__.setdefault("_pin_ring", {})  # (objects assembled without __init__ in the tests)
+            ring = pins.get(n)
+            if ring is None:
+                if len(pins) > 16:
+                    pins.clear()
+                ring = pins[n] = [torch.empty(1, n, dtype=torch.float32).pin_memory() for _ in range(2)] + [0]
+            buf = ring[ring[2] & 1]
+            ring[2] += 1
+            buf[0].copy_(speech_to_process)
+            wav = buf.to(self.device, non_blocking=True)
         m = self.asr_model
-        flens = m.frontend.feature_lengths([n])
-        flens_dev = torch.tensor(flens, dtype=torch.int32).to(wav.device)
+        key = (1, n, wav.device)
+        fcache = self.__dict__.setdefault("_flens_cache", {})
+        flens_dev = fcache.get(key)
+        if flens_dev is None:
+            if len(fcache) > 64:
+                fcache.clear()
+            flens_dev = fcache[key] = torch.tensor(m.frontend.feature_lengths([n]), dtype=torch.int32).to(wav.device)
+            torch.cuda.current_stream().synchronize()
         feats = m.frontend.forward_device(wav, flens_dev)  # espnet_model.py:450-467
         if m.normalize is not None:
             feats = m.normalize.forward_device(feats, flens_dev)
