@@ -146,8 +146,8 @@ class Speech2TextStreaming:
         # (the chunk through one of two pinned staging rows and an asynchronous copy, the frame count from a per-length cache:
         # a pageable host -> device copy is synchronous, and there were two of them in front of every call's first launch)
         n = speech_to_process.size(0)
-        if speech_to_process.is_cuda:
-            wav = speech_to_process.unsqueeze(0).to(torch.float32)
+        if speech_to_process.is_cuda or torch.device(self.device).type != "cuda":
+            wav = speech_to_process.unsqueeze(0).to(torch.float32).to(self.device)
         else:
             pins = self.__dict__.setdefault("_pin_ring", {})  # (objects assembled without __init__ in the tests)
             ring = pins.get(n)
@@ -167,7 +167,8 @@ class Speech2TextStreaming:
             if len(fcache) > 64:
                 fcache.clear()
             flens_dev = fcache[key] = torch.tensor(m.frontend.feature_lengths([n]), dtype=torch.int32).to(wav.device)
-            torch.cuda.current_stream().synchronize()
+            if wav.is_cuda:
+                torch.cuda.current_stream().synchronize()
         feats = m.frontend.forward_device(wav, flens_dev)  # espnet_model.py:450-467
         if m.normalize is not None:
             feats = m.normalize.forward_device(feats, flens_dev)
