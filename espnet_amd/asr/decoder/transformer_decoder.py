@@ -138,6 +138,10 @@ class TransformerDecoder(torch.nn.Module, BatchScorerInterface):
                 src_bkv=F(torch.cat([ca.linear_k.bias, ca.linear_v.bias], 0)),
                 src_wout=A(ca.linear_out.weight), src_bout=F(ca.linear_out.bias),
                 w1=A(ff.w_1.weight), b1=F(ff.w_1.bias), w2=A(ff.w_2.weight), b2=F(ff.w_2.bias))
+            if act == torch.bfloat16 and self.d % 32 == 0 and self.linear_units % 32 == 0:
+                # fragment-major copies for the one-launch feed-forward of the label step (csrc/dec_ffn.hip)
+                lt["w1_frag"] = A(L.pack_frag16(ff.w_1.weight.detach()))
+                lt["w2_frag"] = A(L.pack_frag16(ff.w_2.weight.detach()))
             for k, v in lt.items():
                 setattr(layers[i], k, v.data_ptr())
         w.layers = C.cast(layers, C.POINTER(L.EmDecoderLayer))

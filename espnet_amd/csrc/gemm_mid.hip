@@ -56,7 +56,11 @@ struct Frag16<float> {
 
 constexpr int NW = 8;  // waves per workgroup = K slices
 
-template <typename T, int EPI, int BMT, int BNT, int U>  // U: steps of a slice requested together
+// FRAG (round 6, bf16): both operands FRAGMENT-MAJOR - a [R][K] matrix as [R / 16][K / 32][lane][8 elements], the 16 rows x 32 k
+// of one MFMA operand 1 KiB contiguous (espnet_amd.lib.pack_frag16; csrc/dec_ffn.hip writes its hidden activation that way) -
+// so a wave-wide operand load is ONE contiguous KiB instead of 16 rows x 64 bytes: the K = 2048 projection of the decoder's
+// feed-forward at 640 rows, 384 KiB of operands per workgroup, was 14.4 us from row-major operands.
+template <typename T, int EPI, int BMT, int BNT, int U, bool FRAG = false>  // U: steps of a slice requested together
 __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                            void* __restrict__ Cv, const float* __restrict__ bias,
                                                            int M, int N, int K, int lda, int ldc, float scale) {
@@ -75,16 +79,29 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
   const T* wrow[BNT];
 #pragma unroll
   for (int i = 0; i < BMT; ++i) {
-    int m = m0 + i * 16 + lr;
-    m = m < M ? m : M - 1;
-    arow[i] = A + (size_t)m * lda + lg * F::EPL;
+    if constexpr (FRAG) {  // (M, N multiples of 16: whole fragments; a tile past the edge repeats the last fragment)
+      int rf = (m0 >> 4) + i;
+      rf = rf < (M >> 4) ? rf : (M >> 4) - 1;
+      arow[i] = A + ((size_t)rf * nsteps * 64 + lane) * F::EPL;
+    } else {
+      int m = m0 + i * 16 + lr;
+      m = m < M ? m : M - 1;
+      arow[i] = A + (size_t)m * lda + lg * F::EPL;
+    }
   }
 #pragma unroll
   for (int j = 0; j < BNT; ++j) {
-    int n = n0 + j * 16 + lr;
-    n = n < N ? n : N - 1;
-    wrow[j] = W + (size_t)n * K + lg * F::EPL;
+    if constexpr (FRAG) {
+      int cf = (n0 >> 4) + j;
+      cf = cf < (N >> 4) ? cf : (N >> 4) - 1;
+      wrow[j] = W + ((size_t)cf * nsteps * 64 + lane) * F::EPL;
+    } else {
+      int n = n0 + j * 16 + lr;
+      n = n < N ? n : N - 1;
+      wrow[j] = W + (size_t)n * K + lg * F::EPL;
+    }
   }
+  constexpr int SSTRIDE = FRAG ? 64 * F::EPL : F::KS;  // elements between consecutive k-steps of an operand
   f32x4 acc[BMT][BNT];
 #pragma unroll
   for (int i = 0; i < BMT; ++i)
@@ -124,9 +141,9 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
     for (int u = 0; u < U; ++u) {
       const int s = s0 + u < s_hi ? s0 + u : s_hi - 1;
 #pragma unroll
-      for (int j = 0; j < BNT; ++j) fw[u][j].load(wrow[j] + (size_t)s * F::KS);
+      for (int j = 0; j < BNT; ++j) fw[u][j].load(wrow[j] + (size_t)s * SSTRIDE);
 #pragma unroll
-      for (int i = 0; i < BMT; ++i) fa[u][i].load(arow[i] + (size_t)s * F::KS);
+      for (int i = 0; i < BMT; ++i) fa[u][i].load(arow[i] + (size_t)s * SSTRIDE);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -165,13 +182,13 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
   }
 }
 
-template <typename T, int EPI, int BMT, int BNT>
+template <typename T, int EPI, int BMT, int BNT, bool FRAG = false>
 int launch_mid_tile(const EmGemmArgs* p, hipStream_t s) {
   static_assert(BMT * BNT <= NW, "one finishing wave per fragment");
   dim3 grid(em_cdiv(p->N, 16 * BNT), em_cdiv(p->M, 16 * BMT));
   const int per = em_cdiv(p->K / Frag16<T>::KS, NW);  // steps per wave: K = 512 bf16 -> 2, K = 2048 -> 8
 #define EM_MID_LAUNCH(UU)                                                                                              \
-  hipLaunchKernelGGL((mid_gemm_kernel<T, EPI, BMT, BNT, UU>), grid, dim3(64 * NW), 0, s, (const T*)p->A, (const T*)p->W, \
+  hipLaunchKernelGGL((mid_gemm_kernel<T, EPI, BMT, BNT, UU, FRAG>), grid, dim3(64 * NW), 0, s, (const T*)p->A, (const T*)p->W, \
                      p->C, p->bias, p->M, p->N, p->K, p->lda, p->ldc, p->scale)
   if (per <= 2) EM_MID_LAUNCH(2);
   else if (per <= 4) EM_MID_LAUNCH(4);
@@ -219,6 +236,23 @@ int dispatch_mid(int epi, const EmGemmArgs* p, hipStream_t s) {
 }
 
 }  // namespace
+
+// bf16, both operands fragment-major (A [M][K], W [N][K]; M, N multiples of 16, K of 32), C row-major f32: the decoder
+// feed-forward's second projection (csrc/dec_ffn.hip).  Tiles by workgroup count as launch_mid above.
+int em_gemm_mid_frag(int epilogue, const EmGemmArgs* p, void* stream) {
+  if (epilogue != EM_EPI_RESID_F32 || p->M % 16 != 0 || p->N % 16 != 0 || p->K % 32 != 0) return EM_ERR_UNSUPPORTED;
+  if ((size_t)p->M * p->ldc * 4 >= 0xffffffc0ull) return EM_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int force = em_sw().mid_tile;
+  const long t32 = (long)em_cdiv(p->M, 32) * em_cdiv(p->N, 32);
+  const int tile = force ? force : (t32 < 144 ? 12 : (t32 < 288 ? 22 : 24));
+  switch (tile) {
+    case 12: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 1, 2, true>(p, s);
+    case 24: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 2, 4, true>(p, s);
+    case 14: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 1, 4, true>(p, s);
+    default: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 2, 2, true>(p, s);
+  }
+}
 
 // Called by em_gemm (gemm.hip) for EM_A_PLAIN launches whose tiled grid would leave most of the chip idle; returns
 // EM_ERR_UNSUPPORTED for what it does not implement (the tiled kernel then takes the launch).

@@ -1337,6 +1337,7 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   const int d = dw->d, ff = dw->ff, h = dw->heads;
   const int* anc = (i & 1) ? a.anc_b : a.anc_a;
+  const int ffn_frag = (dtype == EM_BF16 && n >= 96) ? em_dec_ffn_split(n, d, ff) : 0;  // (fewer rows: ln_gemm + mid_gemm at the latency floor)
   if (a.pos_dev)
     EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, a.tok, n, V, d, 0, a.pos_dev, a.Lmax, a.x, stream));
   else
@@ -1372,8 +1373,14 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
       EM_TRY(em_dec_src_attention(dtype, a.qs, kv, 2 * d, vT, a.xlens, a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
     }
     EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.src_wout, a.x, q.src_bout, n, d, d, d, d, 1.f, stream));
-    EM_TRY(ln_proj(dtype, EM_EPI_RELU, a.x, q.norm3_g, q.norm3_b, q.w1, q.b1, a.hbuf, a.xn, n, ff, d, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.hbuf, q.w2, a.x, q.b2, n, d, ff, ff, d, 1.f, stream));
+    // round 6: norm3 + feed_forward + residual on fragment-major operands (csrc/dec_ffn.hip: LayerNorm in the first
+    // projection's prologue, 1 KiB operand loads in both; bf16, d = 256 | 512, rows in whole fragments of 16)
+    if (ffn_frag > 0 && q.w1_frag && q.w2_frag) {
+      EM_TRY(em_dec_ffn(dtype, a.x, q.norm3_g, q.norm3_b, LN_EPS, q.w1_frag, q.b1, q.w2_frag, q.b2, n, d, ff, a.hbuf, stream));
+    } else {
+      EM_TRY(ln_proj(dtype, EM_EPI_RELU, a.x, q.norm3_g, q.norm3_b, q.w1, q.b1, a.hbuf, a.xn, n, ff, d, stream));
+      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.hbuf, q.w2, a.x, q.b2, n, d, ff, ff, d, 1.f, stream));
+    }
   }
   return ln_proj(dtype, EM_EPI_STORE_F32, a.x, dw->after_norm_g, dw->after_norm_b, dw->out_w, dw->out_b,
                  a.logits, a.xn, n, V, d, stream);

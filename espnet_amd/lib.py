@@ -134,7 +134,15 @@ class EmWavInfo(C.Structure):
 
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",
                    "self_bqkv", "self_wout", "self_bout", "src_wq", "src_bq", "src_wkv", "src_bkv",
-                   "src_wout", "src_bout", "w1", "b1", "w2", "b2"]
+                   "src_wout", "src_bout", "w1", "b1", "w2", "b2", "w1_frag", "w2_frag"]
+
+
+def pack_frag16(w):
+    """[R][K] -> fragment-major [R/16][K/32][lane = 16 * (k % 32 // 8) + r % 16][k % 8] (csrc/dec_ffn.hip: the 16 rows x
+    32 k of one MFMA operand contiguous, so that a wave-wide 16-byte-per-lane load reads 1 KiB in one piece)."""
+    R, K = w.shape
+    assert R % 16 == 0 and K % 32 == 0, (R, K)
+    return w.reshape(R // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
 class EmDecoderLayer(C.Structure):
@@ -230,6 +238,8 @@ _SIGNATURES = {
     "em_wav_probe": (C.c_int, [C.POINTER(C.c_char_p), _i32, C.POINTER(EmWavInfo), _i32]),
     "em_wav_load_rows": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(EmWavInfo), _i32, _vp, C.c_int64, _i32]),
     "em_branch_learned_ave": (C.c_int, [C.c_int, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "em_dec_ffn": (C.c_int, [C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "em_dec_ffn_split": (C.c_int, [_i32, _i32, _i32]),
     "em_ln_gemm": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "em_dwconv": (C.c_int, [C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp,
                             _i32, _vp]),

@@ -666,6 +666,19 @@ int em_dec_src_attention_lnq(int dtype, const float* x, const float* g, const fl
                              const float* bq, const void* kmem, int32_t ldk, const void* vT, const int32_t* klens,
                              int32_t B, int32_t W, int32_t d, int32_t heads, int32_t T, int32_t Tpad, void* ctx,
                              void* stream);
+/*   The feed-forward sublayer of a decoder label step on fragment-major operands (bf16; csrc/dec_ffn.hip, two launches):
+ *     x[n][d] f32  +=  w2 . relu(w1 . LN(x; ln_g, ln_b, eps) + b1) + b2
+ *   = DecoderLayer.forward's norm3 -> feed_forward -> residual (decoder_layer.py:150-158, pre-norm),
+ *   PositionwiseFeedForward.forward (positionwise_feed_forward.py:30-32).  w1f [ff][d] and w2f [d][ff] are bf16 and
+ *   FRAGMENT-MAJOR: a [R][K] matrix as [R/16][K/32][lane = 16 * (k % 32 / 8) + r % 16][k % 8], the 16 rows x 32 k of one
+ *   MFMA operand 1 KiB contiguous (host: espnet_amd.lib.pack_frag16; EmDecoderLayer.w1_frag / w2_frag).  hbuf: n * ff
+ *   bf16 of scratch (the hidden activation, written fragment-major).  d = 256 | 512, ff % 128 == 0, n % 16 == 0;
+ *   EM_ERR_UNSUPPORTED otherwise and for EM_F32 (em_dec_ffn_split tells beforehand).                                   */
+int em_dec_ffn(int dtype, float* x, const float* ln_g, const float* ln_b, float eps, const void* w1f, const float* b1,
+               const void* w2f, const float* b2, int32_t n, int32_t d, int32_t ff, void* hbuf, void* stream);
+/*   hidden units per workgroup of em_dec_ffn's first launch for (n, d, ff); 0 = shape not covered (keep em_ln_gemm +
+ *   em_gemm on the row-major matrices)                                                                               */
+int em_dec_ffn_split(int32_t n, int32_t d, int32_t ff);
 /*   vT[b][c][t] = kv[(b*T + t)*2d + d + c]                                                       */
 int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t T, int32_t d, int32_t Tpad,
                        void* vT, void* stream);
@@ -686,6 +699,7 @@ typedef struct EmDecoderLayer {
   const float* b1;
   const void* w2; /* [d][ff] act */
   const float* b2;
+  const void *w1_frag, *w2_frag; /* bf16 fragment-major copies of w1 / w2 for em_dec_ffn, or NULL (round 6) */
 } EmDecoderLayer;
 
 typedef struct EmDecoderWeights {

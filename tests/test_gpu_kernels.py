@@ -474,6 +474,65 @@ def test_ln_gemm_small_m(lib, prec, M, N, K):
         assert_close(out, r, tol, f"ln_gemm {prec} epi {epi}")
 
 
+@pytest.mark.parametrize("n,d,ff,hs", [(640, 512, 2048, 0), (160, 512, 2048, 0), (160, 512, 2048, 256), (320, 512, 2048, 512),
+                                       (144, 256, 2048, 0), (640, 256, 2048, 512), (96, 256, 1024, 128), (32, 512, 2048, 128),
+                                       (16, 512, 2048, 0)])
+def test_dec_ffn_fragment_major(lib, n, d, ff, hs):
+    """em_dec_ffn (norm3 + feed_forward + residual of a decoder label step on fragment-major operands: LayerNorm in the
+    prologue of the first projection, which writes the hidden activation fragment-major; mid_gemm on 1 KiB operand loads):
+    against torch fp32 on bf16-rounded operands with the hidden activation rounded to bf16, against the three-launch form on
+    the row-major matrices (em_layernorm + em_gemm x 2: the same LayerNorm bits, another summation order), bit-repeatable;
+    hs forces the hidden units per workgroup of the first launch (developer switch)."""
+    import os
+    x = rnd(n, d, seed=71) * 2 + 0.3
+    g, be = 1 + 0.1 * rnd(d, seed=72), 0.1 * rnd(d, seed=73)
+    w1 = q(rnd(ff, d, seed=74, scale=d ** -0.5), torch.bfloat16)
+    w2 = q(rnd(d, ff, seed=75, scale=ff ** -0.5), torch.bfloat16)
+    b1, b2 = 0.1 * rnd(ff, seed=76), 0.1 * rnd(d, seed=77)
+    xn = q(F.layer_norm(x, (d,), g, be, 1e-12), torch.bfloat16)
+    hid = q(torch.relu(F.linear(xn, w1, b1)), torch.bfloat16)
+    ref = x + F.linear(hid, w2, b2)
+    gd, bd, w1d, w2d, b1d, b2d = dev(g), dev(be), dev(w1.to(torch.bfloat16)), dev(w2.to(torch.bfloat16)), dev(b1), dev(b2)
+    w1f, w2f = dev(L.pack_frag16(w1.to(torch.bfloat16))), dev(L.pack_frag16(w2.to(torch.bfloat16)))
+    if hs:
+        os.environ["ESPNET_AMD_DEC_FFN_SPLIT"] = str(hs)
+        lib.em_dev_switches_reload()
+    try:
+        assert lib.em_dec_ffn_split(n, d, ff) == (hs or {640: 512, 160: 128, 144: 128, 16: 128}[n])
+        outs = []
+        for _ in range(3):
+            xd = dev(x.clone())
+            hb = torch.full((n, ff), float("nan"), dtype=torch.bfloat16, device="cuda")
+            L.check(lib.em_dec_ffn(L.EM_BF16, L.ptr(xd), L.ptr(gd), L.ptr(bd), 1e-12, L.ptr(w1f), L.ptr(b1d), L.ptr(w2f),
+                                   L.ptr(b2d), n, d, ff, L.ptr(hb), sptr()), "em_dec_ffn")
+            torch.cuda.synchronize()
+            outs.append(xd.clone())
+            # the hidden activation, read back out of its fragment-major layout: exactly relu(W1 LN(x) + b1) in bf16 up to
+            # the summation order
+            hrow = hb.view(n // 16, ff // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(n, ff)
+            assert_close(hrow, hid, 2e-2, "dec_ffn hidden")
+    finally:
+        if hs:
+            del os.environ["ESPNET_AMD_DEC_FFN_SPLIT"]
+            lib.em_dev_switches_reload()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert_close(outs[0], ref, 2e-3, "dec_ffn vs torch")
+    # the three-launch form on the same inputs
+    x3 = dev(x.clone())
+    hb3 = torch.zeros(n, ff, dtype=torch.bfloat16, device="cuda")
+    xs = torch.zeros(n, d, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.em_layernorm(L.EM_BF16, L.ptr(x3), L.ptr(gd), L.ptr(bd), n, d, 1e-12, L.ptr(xs), None, sptr()))
+    a1 = L.EmGemmArgs(A=xs.data_ptr(), W=w1d.data_ptr(), C=hb3.data_ptr(), bias=b1d.data_ptr(), M=n, N=ff, K=d, lda=d, ldc=ff, scale=1.0)
+    L.check(lib.em_gemm(L.EM_BF16, L.EM_EPI_RELU, L.EM_A_PLAIN, a1, sptr()))
+    a2 = L.EmGemmArgs(A=hb3.data_ptr(), W=w2d.data_ptr(), C=x3.data_ptr(), bias=b2d.data_ptr(), M=n, N=d, K=ff, lda=ff, ldc=d, scale=1.0)
+    L.check(lib.em_gemm(L.EM_BF16, L.EM_EPI_RESID_F32, L.EM_A_PLAIN, a2, sptr()))
+    assert_close(outs[0], x3, 2e-3, "dec_ffn vs three launches")
+    # shapes outside the kernels are refused, never computed on another path
+    assert lib.em_dec_ffn(L.EM_F32, L.ptr(x3), L.ptr(gd), L.ptr(bd), 1e-12, L.ptr(w1f), L.ptr(b1d), L.ptr(w2f), L.ptr(b2d),
+                          n, d, ff, L.ptr(hb3), sptr()) == L.EM_ERR_UNSUPPORTED
+    assert lib.em_dec_ffn_split(n + 3, d, ff) == 0 and lib.em_dec_ffn_split(n, 384, ff) == 0
+
+
 @pytest.mark.parametrize("epi", ["STORE", "SWISH", "RELU", "GELU", "RESID_F32", "SCALE_F32", "STORE_F32"])
 def test_gemm_large_m_bf16_128x128_tile(lib, epi):
     """Shapes big enough for the 128x128 tile (>= 384 workgroups; the other GEMM tests run the 64-row tile):
