@@ -121,6 +121,8 @@ class TransformerDecoder(torch.nn.Module, BatchScorerInterface):
         top = dict(embed=F(self.embed[0].weight), pe=F(abs_pos_table(pe_len, self.d)),
                    after_norm_g=F(self.after_norm.weight), after_norm_b=F(self.after_norm.bias),
                    out_w=A(self.output_layer.weight), out_b=F(self.output_layer.bias))
+        if act == torch.bfloat16 and self.d % 32 == 0:
+            top["out_w_frag"] = A(L.pack_frag16(self.output_layer.weight.detach(), pad_rows=512))
         for k, v in top.items():
             setattr(w, k, v.data_ptr())
         layers = (L.EmDecoderLayer * self.num_blocks)()
@@ -142,6 +144,10 @@ class TransformerDecoder(torch.nn.Module, BatchScorerInterface):
                 # fragment-major copies for the one-launch feed-forward of the label step (csrc/dec_ffn.hip)
                 lt["w1_frag"] = A(L.pack_frag16(ff.w_1.weight.detach()))
                 lt["w2_frag"] = A(L.pack_frag16(ff.w_2.weight.detach()))
+                lt["self_wqkv_frag"] = A(L.pack_frag16(torch.cat([sa.linear_q.weight, sa.linear_k.weight,
+                                                                  sa.linear_v.weight], 0).detach(), pad_rows=512))
+                lt["self_wout_frag"] = A(L.pack_frag16(sa.linear_out.weight.detach()))
+                lt["src_wout_frag"] = A(L.pack_frag16(ca.linear_out.weight.detach()))
             for k, v in lt.items():
                 setattr(layers[i], k, v.data_ptr())
         w.layers = C.cast(layers, C.POINTER(L.EmDecoderLayer))

@@ -37,12 +37,15 @@ __device__ __forceinline__ float ffn_row16_allsum(float v) {  // (ln_gemm.hip's 
   return v;
 }
 
-// DT: model dimension (256 | 512); HS: hidden units of one workgroup (128 | 256 | 512)
-template <int DT, int HS>
-__global__ __launch_bounds__(256) void dec_ffn_hidden_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                             const float* __restrict__ be, float eps,
-                                                             const bf16* __restrict__ W1, const float* __restrict__ b1, int n,
-                                                             int ff, bf16* __restrict__ H) {
+// out[n][N] = epilogue(LN(x[n][DT]; g, be) . W1^T + b1), W1 fragment-major with rows padded to a multiple of HS.
+// DT: model dimension (256 | 512); HS: output columns of one workgroup (128 | 256 | 512); OUT: EM_LNF_RELU_FRAG - ReLU, bf16,
+// written FRAGMENT-MAJOR (the feed-forward's hidden activation; `ff` = its width); EM_LNF_STORE - bf16 rows [n][ff];
+// EM_LNF_STORE_F32 - f32 rows [n][ff] (the vocabulary logits).  Row-major outputs mask rows >= n and columns >= ff.
+template <int DT, int HS, int OUT>
+__global__ __launch_bounds__(256) void ln_frag_gemm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           const float* __restrict__ be, float eps,
+                                                           const bf16* __restrict__ W1, const float* __restrict__ b1, int n,
+                                                           int ff, void* __restrict__ Hv) {
   constexpr int XP = DT + 8;  // LDS row pitch (elements): 16-byte aligned rows, a 4-bank step per row
   constexpr int NV = DT / 64;              // float4 chunks per lane of a row's LayerNorm (16 lanes per row)
   // per wave NF1 fragments of 16 hidden units x NK1 k-steps, in batches of GB1 fragments = 16 loads
@@ -68,7 +71,10 @@ __global__ __launch_bounds__(256) void dec_ffn_hidden_kernel(const float* __rest
   load1(w[0], 0);
   float4 bias1[NF1];
 #pragma unroll
-  for (int f = 0; f < NF1; ++f) bias1[f] = *(const float4*)(b1 + h0 + (wave * NF1 + f) * 16 + lg * 4);
+  for (int f = 0; f < NF1; ++f) {  // (columns past the matrix' real width - zero weight rows of the padded packing - have no bias)
+    const int c0 = h0 + (wave * NF1 + f) * 16 + lg * 4;
+    bias1[f] = (OUT == EM_LNF_RELU_FRAG || c0 + 3 < ff) ? *(const float4*)(b1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- LayerNorm of the 16 rows into LDS (16 lanes per row; rows past n repeat row n - 1 and are never stored)
@@ -136,44 +142,102 @@ __global__ __launch_bounds__(256) void dec_ffn_hidden_kernel(const float* __rest
         // lane (lr, lg): row lr, hidden units 16 f + 4 lg .. + 3 of this share
         const int f = bt * GB1 + gi;
         const float4 bb = bias1[f];
-        bf16x4 o;
-        o[0] = (bf16)fmaxf(acc[0] + bb.x, 0.f);
-        o[1] = (bf16)fmaxf(acc[1] + bb.y, 0.f);
-        o[2] = (bf16)fmaxf(acc[2] + bb.z, 0.f);
-        o[3] = (bf16)fmaxf(acc[3] + bb.w, 0.f);
-        // H fragment-major: hidden fragment fg is the (fg & 1) half of k-step fg >> 1 of row fragment rb; this lane's four
-        // values are elements (lg & 1) * 4 .. + 3 of operand lane ((fg & 1) * 2 + (lg >> 1)) * 16 + lr
-        const int fg = (h0 >> 4) + wave * NF1 + f;
-        *(bf16x4*)(H + (((size_t)rb * (ff >> 5) + (fg >> 1)) * 64 + ((fg & 1) * 2 + (lg >> 1)) * 16 + lr) * 8 + (lg & 1) * 4) = o;
+        if constexpr (OUT == EM_LNF_RELU_FRAG) {
+          bf16x4 o;
+          o[0] = (bf16)fmaxf(acc[0] + bb.x, 0.f);
+          o[1] = (bf16)fmaxf(acc[1] + bb.y, 0.f);
+          o[2] = (bf16)fmaxf(acc[2] + bb.z, 0.f);
+          o[3] = (bf16)fmaxf(acc[3] + bb.w, 0.f);
+          // H fragment-major: hidden fragment fg is the (fg & 1) half of k-step fg >> 1 of row fragment rb; this lane's four
+          // values are elements (lg & 1) * 4 .. + 3 of operand lane ((fg & 1) * 2 + (lg >> 1)) * 16 + lr
+          const int fg = (h0 >> 4) + wave * NF1 + f;
+          *(bf16x4*)((bf16*)Hv + (((size_t)rb * (ff >> 5) + (fg >> 1)) * 64 + ((fg & 1) * 2 + (lg >> 1)) * 16 + lr) * 8 + (lg & 1) * 4) = o;
+        } else {
+          const int c0 = h0 + (wave * NF1 + f) * 16 + lg * 4;
+          if (r0 + lr < n && c0 + 3 < ff) {
+            const size_t o0 = (size_t)(r0 + lr) * ff + c0;
+            if constexpr (OUT == EM_LNF_STORE) {
+              bf16x4 o;
+              o[0] = (bf16)(acc[0] + bb.x);
+              o[1] = (bf16)(acc[1] + bb.y);
+              o[2] = (bf16)(acc[2] + bb.z);
+              o[3] = (bf16)(acc[3] + bb.w);
+              *(bf16x4*)((bf16*)Hv + o0) = o;
+            } else {
+              *(float4*)((float*)Hv + o0) = make_float4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+            }
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-template <int DT, int HS>
-int launch_dec_ffn_hidden(const float* x, const float* g, const float* be, float eps, const void* w1, const float* b1, int n,
-                          int ff, void* hbuf, hipStream_t s) {
-  hipLaunchKernelGGL((dec_ffn_hidden_kernel<DT, HS>), dim3(ff / HS, em_cdiv(n, FR)), dim3(256), 0, s, x, g, be, eps,
-                     (const bf16*)w1, b1, n, ff, (bf16*)hbuf);
+template <int DT, int HS, int OUT>
+int launch_lnf(const float* x, const float* g, const float* be, float eps, const void* w1, const float* b1, int n, int N,
+               void* out, hipStream_t s) {
+  hipLaunchKernelGGL((ln_frag_gemm_kernel<DT, HS, OUT>), dim3(em_cdiv(N, HS), em_cdiv(n, FR)), dim3(256), 0, s, x, g, be, eps,
+                     (const bf16*)w1, b1, n, N, out);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
 
+template <int OUT>
+int dispatch_lnf(const float* x, const float* g, const float* be, float eps, const void* wf, const float* bias, int n, int N,
+                 int d, int hs, void* out, hipStream_t st) {
+#define EM_LNF_CASE(DD, HH) \
+  if (d == DD && hs == HH) return launch_lnf<DD, HH, OUT>(x, g, be, eps, wf, bias, n, N, out, st)
+  EM_LNF_CASE(512, 512);
+  EM_LNF_CASE(512, 256);
+  EM_LNF_CASE(512, 128);
+  EM_LNF_CASE(256, 512);
+  EM_LNF_CASE(256, 256);
+  EM_LNF_CASE(256, 128);
+#undef EM_LNF_CASE
+  return EM_ERR_UNSUPPORTED;
+}
+
+// output columns per workgroup: ~160 workgroups per launch (fewer columns for fewer rows), 128 at least
+int lnf_columns(int n, int N) {
+  const int forced = em_sw().dec_ffn_split;  // ESPNET_AMD_DEC_FFN_SPLIT: 0 automatic, 1 off, 128 | 256 | 512 forced
+  if (forced == 128 || forced == 256 || forced == 512) return forced;
+  const int rbs = em_cdiv(n, FR);
+  int hs = 512;
+  while (hs > 128 && rbs * em_cdiv(N, hs) < 160) hs >>= 1;
+  return hs;
+}
+
 }  // namespace
 
-// Hidden units per workgroup of the first launch for (n, d, ff); 0 = the shape is not covered (the caller keeps LayerNorm +
-// two row-major projections).  Covered: d = 256 | 512, ff a multiple of 128, n a multiple of 16 (H is written in whole row
-// fragments; the search's n = B x beam rows are).
+// C[n][N] = epilogue(LN(x[n][d]; g, be, eps) . W^T + bias) with W FRAGMENT-MAJOR, its N rows zero-padded to a multiple of
+// 512 (espnet_amd.lib.pack_frag16(w, pad_rows=512)): the LayerNorm + projection launches of a label step with 1 KiB operand loads.
+// out_mode EM_LNF_RELU_FRAG (ReLU, bf16, fragment-major: n % 16 == 0, N % 128 == 0) | EM_LNF_STORE (bf16 rows) |
+// EM_LNF_STORE_F32 (f32 rows); N % 4 == 0; d = 256 | 512; bf16 only.
+extern "C" int em_ln_gemm_frag(int out_mode, const float* x, const float* ln_g, const float* ln_b, float eps, const void* wf,
+                               const float* bias, void* out, int32_t n, int32_t N, int32_t d, void* stream) {
+  if (!x || !ln_g || !ln_b || !wf || !bias || !out || n <= 0 || N <= 0) return EM_ERR_BAD_ARG;
+  if ((d != 256 && d != 512) || N % 4 != 0) return EM_ERR_UNSUPPORTED;
+  if (em_sw().dec_ffn_split == 1) return EM_ERR_UNSUPPORTED;
+  const int hs = lnf_columns(n, N);
+  hipStream_t st = (hipStream_t)stream;
+  switch (out_mode) {
+    case EM_LNF_RELU_FRAG:
+      if (n % FR != 0 || N % hs != 0) return EM_ERR_UNSUPPORTED;
+      return dispatch_lnf<EM_LNF_RELU_FRAG>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, out, st);
+    case EM_LNF_STORE: return dispatch_lnf<EM_LNF_STORE>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, out, st);
+    case EM_LNF_STORE_F32: return dispatch_lnf<EM_LNF_STORE_F32>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, out, st);
+  }
+  return EM_ERR_BAD_ARG;
+}
+
+// Output columns per workgroup of the feed-forward's first launch for (n, d, ff); 0 = the shape is not covered (the caller
+// keeps LayerNorm + two row-major projections).  Covered: d = 256 | 512, ff a multiple of 128, n a multiple of 16 (H is
+// written in whole row fragments; the search's n = B x beam rows are).
 extern "C" int em_dec_ffn_split(int32_t n, int32_t d, int32_t ff) {
   if (n <= 0 || n % FR != 0 || (d != 256 && d != 512) || ff <= 0 || ff % 128 != 0) return 0;
-  const int forced = em_sw().dec_ffn_split;  // ESPNET_AMD_DEC_FFN_SPLIT: 0 automatic, 1 off, 128 | 256 | 512 forced
-  if (forced == 1) return 0;
-  if (forced > 1) return ((forced == 128 || forced == 256 || forced == 512) && ff % forced == 0) ? forced : 0;
-  // ~160 workgroups per launch: fewer hidden units per workgroup for fewer rows (640 rows: 512, 320: 256, 160: 128)
-  const int rbs = n / FR;
-  int hs = 512;
-  while (hs > 128 && (ff % hs != 0 || rbs * (ff / hs) < 160)) hs >>= 1;
+  if (em_sw().dec_ffn_split == 1) return 0;
+  const int hs = lnf_columns(n, ff);
   return ff % hs == 0 ? hs : 0;
 }
 
@@ -182,22 +246,11 @@ extern "C" int em_dec_ffn(int dtype, float* x, const float* ln_g, const float* l
                           void* stream) {
   if (dtype != EM_BF16) return EM_ERR_UNSUPPORTED;
   if (!x || !ln_g || !ln_b || !w1f || !b1 || !w2f || !b2 || !hbuf || n <= 0) return EM_ERR_BAD_ARG;
-  const int hs = em_dec_ffn_split(n, d, ff);
-  if (hs == 0) return EM_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
-  int rc = EM_ERR_UNSUPPORTED;
-#define EM_DEC_FFN_CASE(DD, HH) \
-  if (d == DD && hs == HH) rc = launch_dec_ffn_hidden<DD, HH>(x, ln_g, ln_b, eps, w1f, b1, n, ff, hbuf, st)
-  EM_DEC_FFN_CASE(512, 512);
-  EM_DEC_FFN_CASE(512, 256);
-  EM_DEC_FFN_CASE(512, 128);
-  EM_DEC_FFN_CASE(256, 512);
-  EM_DEC_FFN_CASE(256, 256);
-  EM_DEC_FFN_CASE(256, 128);
-#undef EM_DEC_FFN_CASE
+  if (em_dec_ffn_split(n, d, ff) == 0) return EM_ERR_UNSUPPORTED;
+  const int rc = em_ln_gemm_frag(EM_LNF_RELU_FRAG, x, ln_g, ln_b, eps, w1f, b1, hbuf, n, ff, d, stream);
   if (rc != EM_OK) return rc;
   EmGemmArgs a = {};
   a.A = hbuf; a.W = w2f; a.C = x; a.bias = b2;
   a.M = n; a.N = d; a.K = ff; a.lda = ff; a.ldc = d; a.scale = 1.f;
-  return em_gemm_mid_frag(EM_EPI_RESID_F32, &a, stream);
+  return em_gemm_mid_frag(EM_EPI_RESID_F32, 1, &a, stream);
 }

@@ -184,8 +184,8 @@ static inline int em_raise_lds_cap(const void* fn, size_t bytes, EmLdsCap* cap) 
 bool em_prof_begin(void* stream);
 void em_prof_end(void* stream, double flops, int tag);
 
-// csrc/gemm_mid.hip: mid_gemm on fragment-major bf16 operands (EM_EPI_RESID_F32; csrc/dec_ffn.hip's second launch)
-int em_gemm_mid_frag(int epilogue, const EmGemmArgs* p, void* stream);
+// csrc/gemm_mid.hip: mid_gemm on fragment-major bf16 operands (EM_EPI_RESID_F32; frag 1: A and W, 2: W only)
+int em_gemm_mid_frag(int epilogue, int frag, const EmGemmArgs* p, void* stream);
 
 // csrc/decoder.hip: self-attention over the union of a beam's ancestors (bf16, d_k = 64, W <= 16 consecutive rows per
 // utterance, Lmax <= 512 with the key list inside 64 KiB of LDS); EM_ERR_UNSUPPORTED for other shapes (the caller keeps

@@ -60,7 +60,7 @@ constexpr int NW = 8;  // waves per workgroup = K slices
 // of one MFMA operand 1 KiB contiguous (espnet_amd.lib.pack_frag16; csrc/dec_ffn.hip writes its hidden activation that way) -
 // so a wave-wide operand load is ONE contiguous KiB instead of 16 rows x 64 bytes: the K = 2048 projection of the decoder's
 // feed-forward at 640 rows, 384 KiB of operands per workgroup, was 14.4 us from row-major operands.
-template <typename T, int EPI, int BMT, int BNT, int U, bool FRAG = false>  // U: steps of a slice requested together
+template <typename T, int EPI, int BMT, int BNT, int U, int FRAG = 0>  // U: steps of a slice requested together; FRAG: 1 both operands fragment-major, 2 W only
 __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                            void* __restrict__ Cv, const float* __restrict__ bias,
                                                            int M, int N, int K, int lda, int ldc, float scale) {
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
   const T* wrow[BNT];
 #pragma unroll
   for (int i = 0; i < BMT; ++i) {
-    if constexpr (FRAG) {  // (M, N multiples of 16: whole fragments; a tile past the edge repeats the last fragment)
+    if constexpr (FRAG == 1) {  // (M, N multiples of 16: whole fragments; a tile past the edge repeats the last fragment)
       int rf = (m0 >> 4) + i;
       rf = rf < (M >> 4) ? rf : (M >> 4) - 1;
       arow[i] = A + ((size_t)rf * nsteps * 64 + lane) * F::EPL;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
   }
 #pragma unroll
   for (int j = 0; j < BNT; ++j) {
-    if constexpr (FRAG) {
+    if constexpr (FRAG != 0) {
       int cf = (n0 >> 4) + j;
       cf = cf < (N >> 4) ? cf : (N >> 4) - 1;
       wrow[j] = W + ((size_t)cf * nsteps * 64 + lane) * F::EPL;
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
       wrow[j] = W + (size_t)n * K + lg * F::EPL;
     }
   }
-  constexpr int SSTRIDE = FRAG ? 64 * F::EPL : F::KS;  // elements between consecutive k-steps of an operand
+  constexpr int ASTRIDE = FRAG == 1 ? 64 * F::EPL : F::KS;  // elements between consecutive k-steps of an operand
+  constexpr int WSTRIDE = FRAG != 0 ? 64 * F::EPL : F::KS;
   f32x4 acc[BMT][BNT];
 #pragma unroll
   for (int i = 0; i < BMT; ++i)
@@ -141,9 +142,9 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
     for (int u = 0; u < U; ++u) {
       const int s = s0 + u < s_hi ? s0 + u : s_hi - 1;
 #pragma unroll
-      for (int j = 0; j < BNT; ++j) fw[u][j].load(wrow[j] + (size_t)s * SSTRIDE);
+      for (int j = 0; j < BNT; ++j) fw[u][j].load(wrow[j] + (size_t)s * WSTRIDE);
 #pragma unroll
-      for (int i = 0; i < BMT; ++i) fa[u][i].load(arow[i] + (size_t)s * SSTRIDE);
+      for (int i = 0; i < BMT; ++i) fa[u][i].load(arow[i] + (size_t)s * ASTRIDE);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64 * NW) void mid_gemm_kernel(const T* __restrict__
   }
 }
 
-template <typename T, int EPI, int BMT, int BNT, bool FRAG = false>
+template <typename T, int EPI, int BMT, int BNT, int FRAG = 0>
 int launch_mid_tile(const EmGemmArgs* p, hipStream_t s) {
   static_assert(BMT * BNT <= NW, "one finishing wave per fragment");
   dim3 grid(em_cdiv(p->N, 16 * BNT), em_cdiv(p->M, 16 * BMT));
@@ -237,21 +238,28 @@ int dispatch_mid(int epi, const EmGemmArgs* p, hipStream_t s) {
 
 }  // namespace
 
-// bf16, both operands fragment-major (A [M][K], W [N][K]; M, N multiples of 16, K of 32), C row-major f32: the decoder
-// feed-forward's second projection (csrc/dec_ffn.hip).  Tiles by workgroup count as launch_mid above.
-int em_gemm_mid_frag(int epilogue, const EmGemmArgs* p, void* stream) {
-  if (epilogue != EM_EPI_RESID_F32 || p->M % 16 != 0 || p->N % 16 != 0 || p->K % 32 != 0) return EM_ERR_UNSUPPORTED;
-  if ((size_t)p->M * p->ldc * 4 >= 0xffffffc0ull) return EM_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
+// bf16 on fragment-major operands, C row-major f32 += (EM_EPI_RESID_F32): frag 1 = A [M][K] and W [N][K] both fragment-major
+// (M, N multiples of 16, K of 32: the decoder feed-forward's second projection, csrc/dec_ffn.hip), frag 2 = W only (A row-major
+// with leading dimension lda: the attention out-projections of a label step, whose `ctx` the attention kernels write as rows).
+// Tiles by workgroup count as launch_mid above.
+template <int FRAG>
+int launch_mid_frag(const EmGemmArgs* p, hipStream_t s) {
   const int force = em_sw().mid_tile;
   const long t32 = (long)em_cdiv(p->M, 32) * em_cdiv(p->N, 32);
   const int tile = force ? force : (t32 < 144 ? 12 : (t32 < 288 ? 22 : 24));
   switch (tile) {
-    case 12: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 1, 2, true>(p, s);
-    case 24: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 2, 4, true>(p, s);
-    case 14: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 1, 4, true>(p, s);
-    default: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 2, 2, true>(p, s);
+    case 12: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 1, 2, FRAG>(p, s);
+    case 24: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 2, 4, FRAG>(p, s);
+    case 14: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 1, 4, FRAG>(p, s);
+    default: return launch_mid_tile<bf16, EM_EPI_RESID_F32, 2, 2, FRAG>(p, s);
   }
+}
+int em_gemm_mid_frag(int epilogue, int frag, const EmGemmArgs* p, void* stream) {
+  if (epilogue != EM_EPI_RESID_F32 || p->N % 16 != 0 || p->K % 32 != 0) return EM_ERR_UNSUPPORTED;
+  if ((size_t)p->M * p->ldc * 4 >= 0xffffffc0ull) return EM_ERR_UNSUPPORTED;
+  if (frag == 1) return p->M % 16 == 0 ? launch_mid_frag<1>(p, (hipStream_t)stream) : EM_ERR_UNSUPPORTED;
+  if (frag == 2) return p->lda % 8 == 0 ? launch_mid_frag<2>(p, (hipStream_t)stream) : EM_ERR_UNSUPPORTED;
+  return EM_ERR_BAD_ARG;
 }
 
 // Called by em_gemm (gemm.hip) for EM_A_PLAIN launches whose tiled grid would leave most of the chip idle; returns

@@ -1337,7 +1337,21 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   const int d = dw->d, ff = dw->ff, h = dw->heads;
   const int* anc = (i & 1) ? a.anc_b : a.anc_a;
-  const int ffn_frag = (dtype == EM_BF16 && n >= 96) ? em_dec_ffn_split(n, d, ff) : 0;  // (fewer rows: ln_gemm + mid_gemm at the latency floor)
+  // round 6: the step's projections on FRAGMENT-MAJOR copies of the weights where the host packed them (EmDecoderLayer.*_frag:
+  // 1 KiB operand loads instead of 16 rows x 64 bytes; csrc/dec_ffn.hip, mid_gemm<FRAG>); bf16, d = 256 | 512, from 96 rows
+  // (fewer rows: ln_gemm + mid_gemm sit at the latency floor).  ESPNET_AMD_DEC_FFN_SPLIT=1: developer A/B switch (off).
+  const bool frag = dtype == EM_BF16 && n >= 96 && (d == 256 || d == 512) && em_sw().dec_ffn_split != 1;
+  const int ffn_frag = frag ? em_dec_ffn_split(n, d, ff) : 0;
+  auto resid_proj = [&](const void* ctx, const void* w, const void* wfrag, const float* bias) -> int {
+    if (frag && wfrag) {
+      EmGemmArgs g = {};
+      g.A = ctx; g.W = wfrag; g.C = a.x; g.bias = bias;
+      g.M = n; g.N = d; g.K = d; g.lda = d; g.ldc = d; g.scale = 1.f;
+      const int rc = em_gemm_mid_frag(EM_EPI_RESID_F32, 2, &g, stream);
+      if (rc != EM_ERR_UNSUPPORTED) return rc;
+    }
+    return gemm(dtype, EM_EPI_RESID_F32, ctx, w, a.x, bias, n, d, d, d, d, 1.f, stream);
+  };
   if (a.pos_dev)
     EM_TRY(em_dec_embed_f32(dw->embed, dw->pe, a.tok, n, V, d, 0, a.pos_dev, a.Lmax, a.x, stream));
   else
@@ -1350,14 +1364,17 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
     const unsigned char* kv = (const unsigned char*)a.mem_kv + (size_t)l * a.B * a.T * 2 * d * es;
     const unsigned char* vT = (const unsigned char*)a.mem_vT + (size_t)l * a.B * d * a.Tpad * es;
     // every pre-norm LayerNorm rides in the prologue of the projection that consumes it (ln_gemm.hip)
-    EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm1_g, q.norm1_b, q.self_wqkv, q.self_bqkv, a.qkv, a.xn, n,
-                   3 * d, d, stream));
+    if (frag && q.self_wqkv_frag)
+      EM_TRY(em_ln_gemm_frag(EM_LNF_STORE, a.x, q.norm1_g, q.norm1_b, LN_EPS, q.self_wqkv_frag, q.self_bqkv, a.qkv, n, 3 * d, d, stream));
+    else
+      EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm1_g, q.norm1_b, q.self_wqkv, q.self_bqkv, a.qkv, a.xn, n,
+                     3 * d, d, stream));
     // round 5: over the union of the beam's ancestors where the shape allows (bf16, d_k = 64, beams of <= 16, Lmax <= 512)
     if (a.pos_dev)
       EM_TRY(em_dec_self_attention_beam(dtype, a.qkv, kc, vc, a.anc_a, a.anc_b, n, d, h, a.Lmax, 0, a.pos_dev, a.W, a.ctx, stream));
     else
       EM_TRY(em_dec_self_attention_beam(dtype, a.qkv, kc, vc, anc, anc, n, d, h, a.Lmax, i, nullptr, a.W, a.ctx, stream));
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.self_wout, a.x, q.self_bout, n, d, d, d, d, 1.f, stream));
+    EM_TRY(resid_proj(a.ctx, q.self_wout, q.self_wout_frag, q.self_bout));
     // round 4: norm2 + the source attention's query projection ride in the attention kernel's prologue (bf16, d_k = 64,
     // d = 256 | 512: one launch less per layer; ESPNET_AMD_NO_SRC_LNQ=1: developer A/B switch)
     const bool no_lnq = em_sw().no_src_lnq;
@@ -1372,7 +1389,7 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
                      stream));
       EM_TRY(em_dec_src_attention(dtype, a.qs, kv, 2 * d, vT, a.xlens, a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
     }
-    EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.ctx, q.src_wout, a.x, q.src_bout, n, d, d, d, d, 1.f, stream));
+    EM_TRY(resid_proj(a.ctx, q.src_wout, q.src_wout_frag, q.src_bout));
     // round 6: norm3 + feed_forward + residual on fragment-major operands (csrc/dec_ffn.hip: LayerNorm in the first
     // projection's prologue, 1 KiB operand loads in both; bf16, d = 256 | 512, rows in whole fragments of 16)
     if (ffn_frag > 0 && q.w1_frag && q.w2_frag) {
@@ -1382,6 +1399,11 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, a.hbuf, q.w2, a.x, q.b2, n, d, ff, ff, d, 1.f, stream));
     }
   }
+  // (the vocabulary projection: up to 320 rows - at 640 rows x 5 000 labels it is a GEMM proper, and 16-row workgroups that
+  // each stream their 512 labels' weights lose to the tiled kernel's 64-row tiles: 20.3 against 11.3 + 5.0 us, profiles/r06ad)
+  if (frag && n <= 320 && dw->out_w_frag && V % 4 == 0)
+    return em_ln_gemm_frag(EM_LNF_STORE_F32, a.x, dw->after_norm_g, dw->after_norm_b, LN_EPS, dw->out_w_frag, dw->out_b, a.logits,
+                           n, V, d, stream);
   return ln_proj(dtype, EM_EPI_STORE_F32, a.x, dw->after_norm_g, dw->after_norm_b, dw->out_w, dw->out_b,
                  a.logits, a.xn, n, V, d, stream);
 }

@@ -12,6 +12,7 @@ from pathlib import Path
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libespnet_amd.so"
 
 EM_OK = 0
+EM_LNF_RELU_FRAG, EM_LNF_STORE, EM_LNF_STORE_F32 = 0, 1, 2
 EM_ERR_UNSUPPORTED, EM_ERR_BAD_ARG, EM_ERR_TOO_SHORT, EM_ERR_LAUNCH, EM_ERR_WORKSPACE, EM_ERR_IO = -1, -2, -3, -4, -5, -6
 EM_F32, EM_BF16 = 0, 1
 (EM_EPI_STORE, EM_EPI_SWISH, EM_EPI_RELU, EM_EPI_RESID_F32, EM_EPI_SCALE_F32, EM_EPI_GLU,
@@ -134,15 +135,22 @@ class EmWavInfo(C.Structure):
 
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",
                    "self_bqkv", "self_wout", "self_bout", "src_wq", "src_bq", "src_wkv", "src_bkv",
-                   "src_wout", "src_bout", "w1", "b1", "w2", "b2", "w1_frag", "w2_frag"]
+                   "src_wout", "src_bout", "w1", "b1", "w2", "b2", "w1_frag", "w2_frag", "self_wqkv_frag",
+                   "self_wout_frag", "src_wout_frag"]
 
 
-def pack_frag16(w):
+def pack_frag16(w, pad_rows=16):
     """[R][K] -> fragment-major [R/16][K/32][lane = 16 * (k % 32 // 8) + r % 16][k % 8] (csrc/dec_ffn.hip: the 16 rows x
-    32 k of one MFMA operand contiguous, so that a wave-wide 16-byte-per-lane load reads 1 KiB in one piece)."""
+    32 k of one MFMA operand contiguous, so that a wave-wide 16-byte-per-lane load reads 1 KiB in one piece).  Rows are
+    zero-padded to a multiple of `pad_rows` (em_ln_gemm_frag wants 512: whole workgroup column slices)."""
+    import torch
+
     R, K = w.shape
-    assert R % 16 == 0 and K % 32 == 0, (R, K)
-    return w.reshape(R // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+    assert pad_rows % 16 == 0 and K % 32 == 0, (R, K, pad_rows)
+    Rp = (R + pad_rows - 1) // pad_rows * pad_rows
+    if Rp != R:
+        w = torch.cat([w, w.new_zeros(Rp - R, K)], 0)
+    return w.reshape(Rp // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
 class EmDecoderLayer(C.Structure):
@@ -154,7 +162,7 @@ class EmDecoderWeights(C.Structure):
                 ("num_blocks", C.c_int32), ("vocab", C.c_int32), ("pe_len", C.c_int32),
                 ("embed", C.c_void_p), ("pe", C.c_void_p), ("after_norm_g", C.c_void_p),
                 ("after_norm_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
-                ("layers", C.POINTER(EmDecoderLayer))]
+                ("layers", C.POINTER(EmDecoderLayer)), ("out_w_frag", C.c_void_p)]
 
 
 class EmDecoderStepArgs(C.Structure):
@@ -240,6 +248,7 @@ _SIGNATURES = {
     "em_branch_learned_ave": (C.c_int, [C.c_int, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "em_dec_ffn": (C.c_int, [C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "em_dec_ffn_split": (C.c_int, [_i32, _i32, _i32]),
+    "em_ln_gemm_frag": (C.c_int, [C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "em_ln_gemm": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "em_dwconv": (C.c_int, [C.c_int, C.c_int, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp,
                             _i32, _vp]),

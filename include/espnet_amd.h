@@ -679,6 +679,17 @@ int em_dec_ffn(int dtype, float* x, const float* ln_g, const float* ln_b, float 
 /*   hidden units per workgroup of em_dec_ffn's first launch for (n, d, ff); 0 = shape not covered (keep em_ln_gemm +
  *   em_gemm on the row-major matrices)                                                                               */
 int em_dec_ffn_split(int32_t n, int32_t d, int32_t ff);
+/*   LayerNorm + projection of a label step on a FRAGMENT-MAJOR weight (bf16; csrc/dec_ffn.hip):
+ *     out[n][N] = epilogue(LN(x[n][d]; ln_g, ln_b, eps) . wf^T + bias),   x f32, wf [N][d] fragment-major with its rows
+ *   ZERO-PADDED to a multiple of 512 (espnet_amd.lib.pack_frag16(w, pad_rows=512)), bias [N] f32;
+ *   out_mode EM_LNF_RELU_FRAG: ReLU, bf16, written fragment-major (n % 16 == 0, N % 128 == 0: em_dec_ffn's hidden activation);
+ *            EM_LNF_STORE: bf16 rows [n][N];  EM_LNF_STORE_F32: f32 rows [n][N] (the vocabulary logits).
+ *   d = 256 | 512, N % 4 == 0; EM_ERR_UNSUPPORTED otherwise (callers keep em_ln_gemm / em_layernorm + em_gemm).          */
+#define EM_LNF_RELU_FRAG 0
+#define EM_LNF_STORE 1
+#define EM_LNF_STORE_F32 2
+int em_ln_gemm_frag(int out_mode, const float* x, const float* ln_g, const float* ln_b, float eps, const void* wf,
+                    const float* bias, void* out, int32_t n, int32_t N, int32_t d, void* stream);
 /*   vT[b][c][t] = kv[(b*T + t)*2d + d + c]                                                       */
 int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t T, int32_t d, int32_t Tpad,
                        void* vT, void* stream);
@@ -699,7 +710,10 @@ typedef struct EmDecoderLayer {
   const float* b1;
   const void* w2; /* [d][ff] act */
   const float* b2;
-  const void *w1_frag, *w2_frag; /* bf16 fragment-major copies of w1 / w2 for em_dec_ffn, or NULL (round 6) */
+  /* round 6: bf16 fragment-major copies (espnet_amd.lib.pack_frag16) for the label step's projections on 1 KiB operand
+   * loads, or NULL (then the row-major matrix above is used): w1 / w2 (em_dec_ffn), self_wqkv (em_ln_gemm_frag, rows
+   * padded to a multiple of 512), self_wout / src_wout (mid_gemm with a fragment-major W)                            */
+  const void *w1_frag, *w2_frag, *self_wqkv_frag, *self_wout_frag, *src_wout_frag;
 } EmDecoderLayer;
 
 typedef struct EmDecoderWeights {
@@ -710,6 +724,7 @@ typedef struct EmDecoderWeights {
   const void* out_w; /* [V][d] act: decoder.output_layer */
   const float* out_b;
   const EmDecoderLayer* layers; /* [num_blocks], host array */
+  const void* out_w_frag; /* round 6: out_w fragment-major, rows zero-padded to a multiple of 512 (em_ln_gemm_frag), or NULL */
 } EmDecoderWeights;
 
 /* ---- A12 + A13: label-synchronous joint CTC/attention beam search, batched over utterances

@@ -533,6 +533,35 @@ def test_dec_ffn_fragment_major(lib, n, d, ff, hs):
     assert lib.em_dec_ffn_split(n + 3, d, ff) == 0 and lib.em_dec_ffn_split(n, 384, ff) == 0
 
 
+@pytest.mark.parametrize("n,N,d", [(640, 1536, 512), (160, 1536, 512), (160, 5000, 512), (640, 5000, 512), (150, 768, 256),
+                                   (97, 5000, 256), (3, 260, 512)])
+def test_ln_gemm_frag_rows(lib, n, N, d):
+    """em_ln_gemm_frag with row-major outputs (the label step's norm1 + q|k|v projection and after_norm + output_layer on a
+    fragment-major weight whose rows are zero-padded to 512): against torch fp32 on the bf16-rounded LayerNorm output and
+    against em_ln_gemm on the row-major matrix (the same LayerNorm bits); ragged n and N, nothing written past either."""
+    x = rnd(n, d, seed=81) * 2 + 0.3
+    g, be = 1 + 0.1 * rnd(d, seed=82), 0.1 * rnd(d, seed=83)
+    w = q(rnd(N, d, seed=84, scale=d ** -0.5), torch.bfloat16)
+    bias = 0.1 * rnd(N, seed=85)
+    xn = q(F.layer_norm(x, (d,), g, be, 1e-12), torch.bfloat16)
+    ref = F.linear(xn, w, bias)
+    xd, gd, bd, wd, biasd = dev(x), dev(g), dev(be), dev(w.to(torch.bfloat16)), dev(bias)
+    wf = dev(L.pack_frag16(w.to(torch.bfloat16), pad_rows=512))
+    for mode, odt, epi, tol in ((L.EM_LNF_STORE, torch.bfloat16, L.EM_EPI_STORE, 2e-2), (L.EM_LNF_STORE_F32, torch.float32, L.EM_EPI_STORE_F32, 2e-3)):
+        out = torch.full((n + 1, N), 5.0, dtype=odt, device="cuda")
+        L.check(lib.em_ln_gemm_frag(mode, L.ptr(xd), L.ptr(gd), L.ptr(bd), 1e-12, L.ptr(wf), L.ptr(biasd), L.ptr(out), n, N, d,
+                                    sptr()), "em_ln_gemm_frag")
+        torch.cuda.synchronize()
+        assert (out[n] == 5.0).all()
+        assert_close(out[:n], ref, tol, f"ln_gemm_frag mode {mode}")
+        old = torch.zeros(n, N, dtype=odt, device="cuda")
+        L.check(lib.em_ln_gemm(L.EM_BF16, epi, L.ptr(xd), L.ptr(gd), L.ptr(bd), 1e-12, L.ptr(wd), L.ptr(biasd), L.ptr(old),
+                               n, N, d, N, sptr()), "em_ln_gemm")
+        assert_close(out[:n], old, tol, f"ln_gemm_frag vs ln_gemm mode {mode}")
+    assert lib.em_ln_gemm_frag(L.EM_LNF_STORE, L.ptr(xd), L.ptr(gd), L.ptr(bd), 1e-12, L.ptr(wf), L.ptr(biasd), L.ptr(out), n, N + 2,
+                               d, sptr()) == L.EM_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("epi", ["STORE", "SWISH", "RELU", "GELU", "RESID_F32", "SCALE_F32", "STORE_F32"])
 def test_gemm_large_m_bf16_128x128_tile(lib, epi):
     """Shapes big enough for the 128x128 tile (>= 384 workgroups; the other GEMM tests run the 64-row tile):
