@@ -1246,6 +1246,9 @@ def main():
         T = model.encoder.output_frames(1 + N_SAMPLES // 160)
         sink = sink_factory(B, T)
         pipe = StepPipeline(dev, args.in_flight) if args.in_flight > 1 else None
+        # (the library takes the 512-wide models' row-block launches from a smaller share of the chip when it is told that
+        # other batches are in flight: EM_ENC_IN_FLIGHT)
+        model.encoder.batches_in_flight = pipe.depth if pipe is not None else 1
         feeder = (HostFeeder(wav_host, dev, nbuf=(pipe.depth if pipe is not None else 1) + 1,
                              beside=pipe.streams if pipe is not None else None) if args.h2d else None)
 
@@ -1512,6 +1515,7 @@ def main():
 
                 k = 32
                 pp = StepPipeline(dev, pipe.depth) if pipe is not None else None  # (batches in flight as in `value`)
+                m.encoder.batches_in_flight = pp.depth if pp is not None else 1
                 t = pipelined_loop(sk, pp, lambda a_, b_: sp(out=(a_, b_)), k, 4)
                 fam = profile_families(sp, 3)
                 brk = event_bracket_us(dev, args.dtype)

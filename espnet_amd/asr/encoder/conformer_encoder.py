@@ -693,6 +693,9 @@ class ConformerEncoder(torch.nn.Module):
             enc_flags |= L.EM_ENC_FOLD_C  # block<C|D|...>: two launches per block (opt-in: measured no faster)
         if getattr(self, "split_att", None) if getattr(self, "split_att", None) is not None else os.environ.get("ESPNET_AMD_SPLIT_ATT") == "1":
             enc_flags |= L.EM_ENC_SPLIT_ATT  # attention and block<C> as two launches (rounds 2-5) instead of block<ATT|C>: A/B switch
+        # batches the caller keeps in flight on other HIP streams (bench.py's StepPipeline, the decode CLI's lanes set the
+        # attribute): the library takes the 512-wide models' row-block launches from a smaller share of the chip then
+        enc_flags |= L.EM_ENC_IN_FLIGHT(max(1, min(15, int(getattr(self, "batches_in_flight", 1) or 1))))
         pos = self._pos_emb(T, dev)
         if self._ENC_FN == "em_conformer_encode" and getattr(pk["w"], "wpos_all", None):
             # linear_pos of every block depends on T and the weights only: projected once per length, handed over ready

@@ -22,7 +22,8 @@ import torch
 from espnet_amd import lib as L
 from espnet_amd.asr.encoder.conformer_encoder import (ConformerEncoder, LayerNorm, _Conv2dSubsampling,
                                                       _PositionwiseFeedForward,
-                                                      _RelPositionMultiHeadedAttention)
+                                                      _RelPositionMultiHeadedAttention, pack_ffn_rows_w1,
+                                                      pack_ffn_rows_w2)
 
 
 class _CSGU(torch.nn.Module):
@@ -203,6 +204,12 @@ class EBranchformerEncoder(ConformerEncoder):
                     ffm_w2=A(l.feed_forward_macaron.w_2.weight), ffm_b2=F(l.feed_forward_macaron.w_2.bias),
                     ff_w1=A(l.feed_forward.w_1.weight), ff_b1=F(l.feed_forward.w_1.bias),
                     ff_w2=A(l.feed_forward.w_2.weight), ff_b2=F(l.feed_forward.w_2.bias))
+            if has_ffn and d == 512 and ff % 128 == 0 and ff >= 256 and act == torch.bfloat16:
+                # operand streams of the row-block feed-forward launches (csrc/ffn_rows.hip), as the 512-wide Conformer's
+                lt.update(ffm_w1p=A(pack_ffn_rows_w1(l.feed_forward_macaron.w_1.weight)),
+                          ffm_w2p=A(pack_ffn_rows_w2(l.feed_forward_macaron.w_2.weight)),
+                          ff_w1p=A(pack_ffn_rows_w1(l.feed_forward.w_1.weight)),
+                          ff_w2p=A(pack_ffn_rows_w2(l.feed_forward.w_2.weight)))
             if has_mconv:
                 lt.update(merge_conv_w=F(l.depthwise_conv_fusion.weight.reshape(2 * d, -1).t()),
                           merge_conv_b=F(l.depthwise_conv_fusion.bias))

@@ -231,17 +231,38 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   void* vt = ws + s.vt;
   if (attn2 && hipMemsetAsync(qh, 0, (s.vt - s.qh) + (size_t)B * d * s.Tpad * es, (hipStream_t)stream) != hipSuccess)
     return EM_ERR_LAUNCH;
+  // Round 6: the two feed-forward modules as row-block launches of csrc/ffn_rows.hip (bf16, d = 512, the host packed their
+  // operand streams): [macaron FFN + residual + norm_mha] and [FFN + residual + norm_final + the next LayerNorm] - three
+  // launches each until now (two tiled GEMMs through the [M][ff] hidden activation + a LayerNorm) - when a round of
+  // 64-row workgroups fills its share of the chip (em_rows_fill_ok: B = 32 x 10 s is 125 workgroups - taken with two batches
+  // in flight, EM_ENC_IN_FLIGHT).  ESPNET_AMD_NO_FFN_ROWS=1: developer switch.
+  bool ffn_rows = ffn && dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) &&
+                  !em_sw().no_ffn_rows && em_rows_fill_ok(M, flags);
+  for (int l = 0; ffn_rows && l < L; ++l) ffn_rows = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
+  auto ffn_fused = [&](const void* w1p, const void* w2p, const float* b1, const float* b2, int ln_mode, const float* g1,
+                       const float* be1, const float* g2, const float* be2, void* xn_out, float* out_f32) {
+    EmFfnRowsArgs fa = {};
+    fa.xn_in = xn; fa.x = x; fa.w1p = w1p; fa.w2p = w2p; fa.b1 = b1; fa.b2 = b2;
+    fa.g1 = g1; fa.be1 = be1; fa.g2 = g2; fa.be2 = be2; fa.xn_out = xn_out; fa.out_f32 = out_f32;
+    fa.M = M; fa.d = d; fa.ff = ff; fa.ln_mode = ln_mode; fa.scale = 0.5f; fa.eps = LN_EPS;
+    return em_ffn_rows_fused(&fa, stream);
+  };
   if (ffn)
     EM_TRY(em_layernorm(dtype, x, ly[0].norm_ff_mac_g, ly[0].norm_ff_mac_b, M, d, LN_EPS, xn, nullptr, stream));
   for (int l = 0; l < L; ++l) {
     const EmEBranchformerLayer& q = ly[l];
-    if (ffn) {
-      // macaron FFN (:132-135): x += 0.5 * w2(swish(w1 LN(x)))
-      EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
-      EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
+    if (ffn_rows) {
+      // macaron FFN + residual + norm_mha (the attention branch's LayerNorm) in one launch
+      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr));
+    } else {
+      if (ffn) {
+        // macaron FFN (:132-135): x += 0.5 * w2(swish(w1 LN(x)))
+        EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
+        EM_TRY(gemm(dtype, EM_EPI_RESID_F32, big, q.ffm_w2, x, q.ffm_b2, M, d, ff, ff, d, 0.5f, stream));
+      }
+      // the two branches read the same x (:138-139)
+      EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
     }
-    // the two branches read the same x (:138-139)
-    EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
     EM_TRY(em_layernorm(dtype, x, q.norm_mlp_g, q.norm_mlp_b, M, d, LN_EPS, xn2, nullptr, stream));
     // branch 1 (:141-152): rel-pos self-attention; linear_out lands in cat[:, :d]
     if (attn2) {
@@ -288,6 +309,17 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
         merged = tmp;
       }
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, merged, q.merge_w, x, q.merge_b, M, d, 2 * d, 2 * d, d, 1.f, stream));
+    }
+    if (ffn_rows) {
+      // FFN (:172-176) + residual + norm_final (:178) + the next consumer's LayerNorm in one launch
+      EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
+      if (l + 1 < L)
+        EM_TRY(ffn_fused(q.ff_w1p, q.ff_w2p, q.ff_b1, q.ff_b2, 2, q.norm_final_g, q.norm_final_b, ly[l + 1].norm_ff_mac_g,
+                         ly[l + 1].norm_ff_mac_b, xn, nullptr));
+      else
+        EM_TRY(ffn_fused(q.ff_w1p, q.ff_w2p, q.ff_b1, q.ff_b2, 2, q.norm_final_g, q.norm_final_b, w->after_norm_g, w->after_norm_b,
+                         enc_act, enc_out));
+      continue;
     }
     if (ffn) {
       // FFN (:172-176)

@@ -184,6 +184,10 @@ static inline int em_raise_lds_cap(const void* fn, size_t bytes, EmLdsCap* cap) 
 bool em_prof_begin(void* stream);
 void em_prof_end(void* stream, double flops, int tag);
 
+// csrc/encoder.hip: do the rounds of M / 64 row-block workgroups (csrc/ffn_rows.hip) fill enough of this device's CUs?  `flags`:
+// the encoder call's flags (EM_ENC_IN_FLIGHT: launches of other streams run beside a half-filled one)
+bool em_rows_fill_ok(long M, int flags);
+
 // csrc/gemm_mid.hip: mid_gemm on fragment-major bf16 operands (EM_EPI_RESID_F32; frag 1: A and W, 2: W only)
 int em_gemm_mid_frag(int epilogue, int frag, const EmGemmArgs* p, void* stream);
 

@@ -68,6 +68,35 @@ inline int gemm(int dtype, int epi, const void* A, const void* W, void* C, const
 }
 
 
+}  // namespace
+
+// A row-block launch takes ~80 us per ROUND of 64-row workgroups whatever the number of rows (one workgroup streams all
+// 4 MiB of the module's weights through its CU), the launches it replaces scale with M (90 us at M = 15 936, ~31 us at
+// the beam search's M = 3 984, where only 63 CUs would work: profiles/r04r_search_kernel_stats.csv): taken only when its
+// rounds fill at least 72 % of the chip - or 72 % / n when the caller keeps n batches in flight (EM_ENC_IN_FLIGHT): a launch
+// that fills half the chip runs side by side with the other stream's (round 6, profiles/r06ae_rows_fill_ab.txt: Conformer-
+// large at B = 32, 125 workgroups: 3.84 against 3.72 ms per batch alone, 2.63 against 3.28 with two in flight; B = 16 with
+// three in flight 1.52 against 1.71).  ESPNET_AMD_FFN_ROWS_MIN_FILL: developer switch (percent).
+// (per DEVICE, not per process: a process may decode on MI355X partitions with different CU counts)
+bool em_rows_fill_ok(long M, int flags) {
+  static int n_cu_of[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (n_cu_of[dev] == 0) {
+    hipDeviceProp_t prop;
+    n_cu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const int n_cu = n_cu_of[dev];
+  int n = (flags >> 8) & 15;
+  n = n < 1 ? 1 : n;
+  const int forced = em_sw().ffn_rows_min_fill;
+  const long fill = forced > 0 ? forced : 72 / n;
+  const long wgs = (M + 63) / 64, rounds = (wgs + n_cu - 1) / n_cu;
+  return M > 0 && 100 * wgs >= fill * rounds * n_cu;
+}
+
+namespace {
+
 // The 512-wide model's row-block launches (csrc/ffn_rows.hip).  Round 4: at d = 512 (bf16) the block's row-local operators
 // run as three launches of 64-row workgroups when the host packed their operands: [macaron FFN + residual + norm_mha],
 // [linear_out + residual + norm_conv + pointwise_conv1 + GLU], [pointwise_conv2 + residual + norm_ff + FFN + residual +
@@ -83,21 +112,7 @@ inline RowsPlan rows_plan(int dtype, const EmConformerWeights* w, int flags, lon
   if (!(dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) && !no_ffn_rows && ly && L > 0 &&
         M > 0))
     return r;
-  // A row-block launch takes ~80 us per ROUND of 64-row workgroups whatever the number of rows (one workgroup streams all
-  // 4 MiB of the module's weights through its CU), the launches it replaces scale with M (90 us at M = 15 936, ~31 us at
-  // the beam search's M = 3 984, where only 63 CUs would work: profiles/r04r_search_kernel_stats.csv): taken only when its
-  // rounds fill at least three quarters of the chip.
-  // (per DEVICE, not per process: a process may decode on MI355X partitions with different CU counts)
-  static int n_cu_of[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (n_cu_of[dev] == 0) {
-    hipDeviceProp_t prop;
-    n_cu_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  const int n_cu = n_cu_of[dev];
-  const long wgs = (M + 63) / 64, rounds = (wgs + n_cu - 1) / n_cu;
-  r.ffn = 4 * wgs >= 3 * rounds * n_cu;
+  r.ffn = em_rows_fill_ok(M, flags);
   for (int l = 0; r.ffn && l < L; ++l) r.ffn = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
   // ... pointwise_conv2 + residual + norm_ff ride in the second module's launch when the host packed pw2 as well
   r.pre_pw2 = r.ffn;

@@ -27,6 +27,12 @@ EM_ENC_POS_PROJECTED = 4
 EM_ENC_FOLD_C = 8
 EM_ENC_SPLIT_ATT = 16
 EM_ENC_POS_PACKED = 32
+
+
+def EM_ENC_IN_FLIGHT(n):
+    return (int(n) & 15) << 8
+
+
 EM_ENC_PLAN_FUSED, EM_ENC_PLAN_CTC_IDS = 1, 2
 EM_BLOCK_C, EM_BLOCK_D, EM_BLOCK_A, EM_BLOCK_FINAL, EM_BLOCK_CTC, EM_BLOCK_RELU, EM_BLOCK_ATT = 1, 2, 4, 8, 16, 32, 64
 EM_BLOCK_PARAM_GROUP = 1792
@@ -109,7 +115,7 @@ _EBF_LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b",
                    "ffm_b1", "ffm_b2", "ff_b1", "ff_b2", "wqkv", "bqkv", "pos_u", "pos_v", "wout", "bout",
                    "proj1_w", "proj1_b", "csgu_norm_g", "csgu_norm_b", "csgu_conv_w", "csgu_conv_b", "proj2_w",
                    "proj2_b", "merge_conv_w", "merge_conv_b", "merge_w", "merge_b", "pool_w", "pool_b", "wproj_w",
-                   "wproj_b"]
+                   "wproj_b", "ffm_w1p", "ffm_w2p", "ff_w1p", "ff_w2p"]
 EM_MERGE_CONCAT, EM_MERGE_LEARNED_AVE = 0, 1
 
 

@@ -316,6 +316,11 @@ typedef struct EmConformerWeights {
                                * block<ATT|C> reads; without the flag the encoder packs it per call (~5 us at T = 249) */
 #define EM_ENC_POS_PROJECTED 4 /* pos_emb is ALREADY linear_pos of every block: [2T-1 (legacy: T)][L*d] act, i.e. pos_emb x wpos_all^T
                                * (it depends on T and the weights only: a caller decoding many batches of one length projects once) */
+#define EM_ENC_IN_FLIGHT(n) (((n) & 15) << 8) /* the caller keeps n batches in flight on n HIP streams (0 / 1: this call has the
+                               * chip to itself).  The 512-wide models' row-block launches (64-row workgroups, csrc/ffn_rows.hip) are
+                               * taken when a round of them fills 72 % / n of the CUs: a launch that fills half the chip loses to the
+                               * per-operator sequence alone and wins when another stream's launch runs beside it (Conformer-large,
+                               * B = 32: 3.72 vs 3.84 ms alone, 3.28 vs 2.63 ms with two in flight; profiles/r06ae_rows_fill_ab.txt) */
 
 /* Which launch sequence em_conformer_encode will take for these weights and flags (>= 0; negative = status):
  * the single source of that decision, so that the host layer never re-derives the shape conditions.           */
@@ -559,6 +564,11 @@ typedef struct EmEBranchformerLayer {
   /* Branchformer merge_method="learned_ave" (branchformer_encoder.py:102-112); NULL otherwise */
   const float *pool_w, *pool_b;   /* pooling_proj1 | pooling_proj2: [2][d], [2] */
   const float *wproj_w, *wproj_b; /* weight_proj1 | weight_proj2:   [2][d], [2] */
+  /* round 6 (bf16, d = 512, ff % 128 == 0): the operand streams of em_ffn_rows_fused for the two feed-forward modules
+   * (EmFfnRowsArgs w1p / w2p; host: pack_ffn_rows_w1 / _w2) - with all four set, each module (+ residual + the LayerNorm
+   * that follows: norm_mha after the macaron one; norm_final + the next block's norm_ff_macaron / after_norm after the
+   * other) is ONE row-block launch when its rounds fill the chip (EM_ENC_IN_FLIGHT); NULL: two GEMMs + LayerNorm */
+  const void *ffm_w1p, *ffm_w2p, *ff_w1p, *ff_w2p;
 } EmEBranchformerLayer;
 
 #define EM_MERGE_CONCAT 0      /* x += merge_proj([x1 | x2]); also fixed_ave, whose host packing is

@@ -218,3 +218,67 @@ def test_cgmlp_kernels_against_torch(prec):
     L.check(lib.em_dwconv(dt, L.EM_DW_SELFRES, catd.data_ptr(), 2 * d, mwd.data_ptr(), mbd.data_ptr(), None, B, T,
                           2 * d, 7, None, 0, outm.data_ptr(), 2 * d, sp), "dw selfres")
     assert (outm.float().cpu() - ref_m).abs().max().item() < tol * 8
+
+
+def test_ebranchformer_512_row_block_ffn_matches_per_operator_and_oracle():
+    """Round 6: at d = 512 (bf16) the two feed-forward modules of an E-Branchformer block run as row-block launches of
+    csrc/ffn_rows.hip ([macaron FFN + residual + norm_mha], [FFN + residual + norm_final + the next LayerNorm / after_norm])
+    when a round of 64-row workgroups fills its share of the chip.  No reference fixture has d = 512: a seeded 3-block model
+    (512d, 8 heads, linear_units 1024, cgMLP 3072, merge kernel 31) is encoded (a) through the row-block launches (fill rule
+    lowered by the developer switch), (b) through the per-operator sequence (ESPNET_AMD_NO_FFN_ROWS), (c) by the f32 CPU oracle
+    (oracle/ebranchformer.py, which restates e_branchformer_encoder.py:110-183): (a) against (b) to bf16 round-off, both
+    against (c) under the bound of the other bf16 encoder tests; rows of equal utterances bit-identical."""
+    import os
+
+    from espnet_amd import lib as L
+    from espnet_amd.tasks.asr import ASRTask
+
+    torch.manual_seed(5)
+    vocab = 40
+    conf = dict(output_size=512, attention_heads=8, linear_units=1024, num_blocks=3, input_layer="conv2d", rel_pos_type="latest",
+                pos_enc_layer_type="rel_pos", attention_layer_type="rel_selfattn", cgmlp_linear_units=3072, cgmlp_conv_kernel=31,
+                use_linear_after_conv=False, gate_activation="identity", use_ffn=True, macaron_ffn=True,
+                ffn_activation_type="swish", merge_conv_kernel=31)
+    cfg = dict(token_list=["<blank>", "<unk>"] + [f"t{i}" for i in range(vocab - 3)] + ["<sos/eos>"], frontend="default",
+               frontend_conf=dict(n_fft=512, hop_length=160), normalize="utterance_mvn", normalize_conf={},
+               encoder="e_branchformer", encoder_conf=conf, decoder="transformer",
+               decoder_conf=dict(attention_heads=8, linear_units=256, num_blocks=1), model_conf=dict(ctc_weight=0.3),
+               compute_dtype="bfloat16")
+    model = ASRTask.build_model(cfg).cuda().eval()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    n = 16000 * 3
+    g = torch.Generator().manual_seed(9)
+    one = 0.1 * torch.randn(1, n, generator=g)
+    B = 6
+    wav = one.repeat(B, 1).cuda()
+    lens = [n] * B
+    lib = L.load()
+
+    def run(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        lib.em_dev_switches_reload()
+        try:
+            model.encoder._packed = None  # (pack again: nothing is cached across the switch)
+            st = model.encode_device(wav, lens)
+            return st.enc_out.float().cpu(), st.olens
+        finally:
+            for k in env:
+                del os.environ[k]
+            lib.em_dev_switches_reload()
+
+    rows, olens = run({"ESPNET_AMD_FFN_ROWS_MIN_FILL": "1"})
+    plain, _ = run({"ESPNET_AMD_NO_FFN_ROWS": "1"})
+    T = int(olens[0])
+    for k in (1, B - 1):
+        assert torch.equal(rows[0], rows[k]), k
+    d = (rows[0, :T] - plain[0, :T]).abs()
+    print(f"[ebf 512, row-block vs per-operator] max {d.max():.3e} mean {d.mean():.3e}")
+    assert d.max() < 0.08 and d.mean() < 6e-3 and d.max() > 0.0  # (> 0: the two paths really are different launches)
+    with torch.no_grad():
+        ref, ol = oe.encode(sd, one, torch.tensor([n]), 8, 3, 512, 512, 160)
+    assert int(ol[0]) == T
+    for name, enc in (("row-block", rows), ("per-operator", plain)):
+        rel = (enc[0, :T] - ref[0]).norm() / ref[0].norm()
+        print(f"[ebf 512, {name} vs oracle] relative error {float(rel):.3e}")
+        assert rel < 3e-2, (name, float(rel))
