@@ -668,6 +668,8 @@ def run_beam(args, dev, B, beam, steps, warmup, cpu_base, want_traffic=True, wan
     model = ASRTask.build_model(model_config("large", args.dtype)).to(dev).eval()
     bs = build_beam_search(model, beam_size=beam, ctc_weight=args.ctc_weight, penalty=0.0,
                            token_list=model.token_list)
+    if os.environ.get("BENCH_ENC_IN_FLIGHT"):  # developer probe: what the encoder call is told about batches in flight (EM_ENC_IN_FLIGHT)
+        model.encoder.batches_in_flight = int(os.environ["BENCH_ENC_IN_FLIGHT"])
     if os.environ.get("BENCH_SEARCH_EAGER"):  # developer probe: label steps as eager launches from em_search_steps, no hipGraph
         bs.use_hipgraph = False
     if os.environ.get("BENCH_STEP_CHUNK"):  # developer probe: label steps enqueued between two polls of the `done` flags
@@ -1514,7 +1516,9 @@ def main():
                     return m.greedy_ctc_device(m.encode_device(w, ls), out=out)
 
                 k = 32
-                pp = StepPipeline(dev, pipe.depth) if pipe is not None else None  # (batches in flight as in `value`)
+                # (batches in flight as in `value`; the E-Branchformer leg at B = 32 - 125 row-block workgroups per launch, half the
+                # chip - with three: 4.62 against 4.89 ms per batch with two, profiles/r06ae_rows_fill_ab.txt)
+                pp = StepPipeline(dev, max(pipe.depth, 3) if name == "ebf" else pipe.depth) if pipe is not None else None
                 m.encoder.batches_in_flight = pp.depth if pp is not None else 1
                 t = pipelined_loop(sk, pp, lambda a_, b_: sp(out=(a_, b_)), k, 4)
                 fam = profile_families(sp, 3)
