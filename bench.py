@@ -1369,7 +1369,11 @@ def main():
 
     # ---- the other rows of the measurement contract, as sub-objects of the one line (N = 1 only) -------------
     if rank == 0 and world == 1 and args.workload == "greedy" and not args.quick and not inner:
+        only = [x for x in os.environ.get("BENCH_ONLY_LEGS", "").split(",") if x]  # developer probe: run these sub-legs only
+
         def guarded(name, fn):
+            if only and name not in only:
+                return
             try:
                 out[name] = fn()
             except Exception as e:  # a sub-measurement must never cost the headline line
@@ -1612,6 +1616,16 @@ def main():
             r["batch64_three_groups"] = run_stream_batch(args.dtype, 64, 4, 1, groups=3)
             return r
 
+        # Order (round 6): the two beam legs first.  Inside this one process the late legs measured slower than the same
+        # leg alone (`BENCH_ONLY_LEGS=beam_cfg3_per_gpu`: 0.515 ms per label step and 7 250 - 7 550 audio-s/s; at the end of the
+        # full line 0.58 and 5 600 - 6 400, three runs) while nothing but the process' history differed (H2D feeders, pinned
+        # buffers, the encoder legs' models and PMC sub-processes in front of them).  The cause is not identified: the number
+        # of streams the process has created is NOT it (tools/null_stream_probe.py: 4.6 against 4.7 us per launch after all of
+        # torch's pool exists, profiles/r06ak_null_stream_probe.txt).  A label step is ~40 launches of ~10 us and feels every
+        # microsecond of launch cost; the other legs measure the same in either order (profiles/r06ai vs r06ak).
+        # `python bench.py --workload beam --batch 16 | 64` is each leg in a process of its own.
+        guarded("beam", beam_leg(16, 12, True))
+        guarded("beam_cfg3_per_gpu", beam_leg(64, 12, False))
         guarded("frontend", frontend_leg)
         guarded("pcie_inclusive", pcie_leg)
         if pipe is not None:
@@ -1622,8 +1636,6 @@ def main():
         torch.cuda.empty_cache()
         guarded("encoder_large_b64", encoder_leg("large", 64, 68.56, "Conformer-large (12x512d, 8 heads, ff 2048)", want_pmc=True))
         guarded("encoder_ebranchformer_b32", encoder_leg("ebf", 32, None, "E-Branchformer (17x512d, 8 heads, cgMLP 3072, merge k31)", want_pmc=True))
-        guarded("beam", beam_leg(16, 12, True))
-        guarded("beam_cfg3_per_gpu", beam_leg(64, 12, False))
         guarded("stream", stream_leg)
     if rank == 0:
         print(json.dumps(out), flush=True)
