@@ -983,6 +983,8 @@ def rocprof_family_ms(args, model, batch):
                "--in-flight", "1",  # (one batch in flight: kernels of two streams that overlap in time inflate each other's durations)
                "--steps", "20", "--warmup", "3", "--dtype", args.dtype, "--batch", str(batch), "--model", model]
         env = dict(os.environ, TMPDIR="/tmp", ESPNET_AMD_BENCH_INNER="1")
+        if getattr(args, "enc_in_flight", None):  # (the SAME launch sequence as the timed loop: its row-block choice depends on it)
+            env["BENCH_ENC_IN_FLIGHT"] = str(args.enc_in_flight)
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=200)
         except subprocess.TimeoutExpired:
@@ -1250,7 +1252,7 @@ def main():
         pipe = StepPipeline(dev, args.in_flight) if args.in_flight > 1 else None
         # (the library takes the 512-wide models' row-block launches from a smaller share of the chip when it is told that
         # other batches are in flight: EM_ENC_IN_FLIGHT)
-        model.encoder.batches_in_flight = pipe.depth if pipe is not None else 1
+        model.encoder.batches_in_flight = int(os.environ.get("BENCH_ENC_IN_FLIGHT") or (pipe.depth if pipe is not None else 1))
         feeder = (HostFeeder(wav_host, dev, nbuf=(pipe.depth if pipe is not None else 1) + 1,
                              beside=pipe.streams if pipe is not None else None) if args.h2d else None)
 
@@ -1543,7 +1545,9 @@ def main():
                 rp, rp_note = None, None
                 if want_pmc and world == 1 and not inner and not args.no_traffic:
                     try:
-                        rp, rp_note = rocprof_family_ms(args, name, Bl)
+                        a4 = argparse.Namespace(**vars(args))
+                        a4.enc_in_flight = pp.depth if pp is not None else 1
+                        rp, rp_note = rocprof_family_ms(a4, name, Bl)
                     except Exception as e:  # noqa: BLE001
                         rp, rp_note = None, f"{type(e).__name__}: {e}"
                 r = roofline_object(fam, 3, brk, peak, t / k, traffic, note, rp, rp_note)
