@@ -1569,7 +1569,10 @@ def main():
             def fn():
                 a2 = argparse.Namespace(**vars(args))
                 a2.model = "large"
-                a2.in_flight, a2.lane_threads = 4, True  # four joint searches in flight, a host thread per lane
+                # joint searches in flight, a host thread per lane: four at configs[3]'s per-GPU batch (6 / 8: no more), eight at
+                # configs[2]'s 160 rows, whose launches leave most of the chip idle (4 / 6 / 8 lanes: 4 033 / 4 083 / 4 705
+                # audio-s/s, profiles/r06al_beam_lanes_sweep.txt)
+                a2.in_flight, a2.lane_threads = (8 if Bb <= 16 else 4), True
                 r = run_beam(a2, dev, Bb, 10, steps, 1, cpu_base=cpu and not args.no_cpu_baseline,
                              want_traffic=cpu,  # counters for the configs[2] leg only
                              want_oracle=not args.no_cpu_baseline)  # ... the oracle check of utterance 0 for both
@@ -1628,7 +1631,7 @@ def main():
         # torch's pool exists, profiles/r06ak_null_stream_probe.txt).  A label step is ~40 launches of ~10 us and feels every
         # microsecond of launch cost; the other legs measure the same in either order (profiles/r06ai vs r06ak).
         # `python bench.py --workload beam --batch 16 | 64` is each leg in a process of its own.
-        guarded("beam", beam_leg(16, 12, True))
+        guarded("beam", beam_leg(16, 24, True))
         guarded("beam_cfg3_per_gpu", beam_leg(64, 12, False))
         guarded("frontend", frontend_leg)
         guarded("pcie_inclusive", pcie_leg)

@@ -428,6 +428,9 @@ class ConformerEncoder(torch.nn.Module):
                           woutp=A(pack_rows_proj(l.self_attn.linear_out.weight)),
                           pw1f=A(pack_rows_glu(l.conv_module.pointwise_conv1.weight.reshape(2 * d, d))),
                           fp_c=F(l.conv_module.pointwise_conv1.bias[glu_chunk_order(d)]))
+                if self.heads * 64 == d:  # round 6: q | k | v walked behind the macaron launch (EmFfnRowsArgs.post_q)
+                    sa = l.self_attn
+                    lt["wqkvp"] = A(pack_ffn_rows_w1(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0)))
                 for k, v in lt.items():
                     setattr(layers[i], k, v.data_ptr())
             self._pack_rows_ctc(w, A, F)

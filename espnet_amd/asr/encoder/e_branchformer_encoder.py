@@ -209,7 +209,8 @@ class EBranchformerEncoder(ConformerEncoder):
                 lt.update(ffm_w1p=A(pack_ffn_rows_w1(l.feed_forward_macaron.w_1.weight)),
                           ffm_w2p=A(pack_ffn_rows_w2(l.feed_forward_macaron.w_2.weight)),
                           ff_w1p=A(pack_ffn_rows_w1(l.feed_forward.w_1.weight)),
-                          ff_w2p=A(pack_ffn_rows_w2(l.feed_forward.w_2.weight)))
+                          ff_w2p=A(pack_ffn_rows_w2(l.feed_forward.w_2.weight)),
+                          wqkvp=A(pack_ffn_rows_w1(torch.cat([sa.linear_q.weight, sa.linear_k.weight, sa.linear_v.weight], 0))))
             if has_mconv:
                 lt.update(merge_conv_w=F(l.depthwise_conv_fusion.weight.reshape(2 * d, -1).t()),
                           merge_conv_b=F(l.depthwise_conv_fusion.bias))

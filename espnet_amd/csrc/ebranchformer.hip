@@ -239,9 +239,17 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   bool ffn_rows = ffn && dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) &&
                   !em_sw().no_ffn_rows && em_rows_fill_ok(M, flags);
   for (int l = 0; ffn_rows && l < L; ++l) ffn_rows = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
+  // ... and q | k | v walked behind the macaron launch (EmFfnRowsArgs.post_q; ESPNET_AMD_NO_ROWS_QKV=1: developer switch)
+  bool rows_qkv = ffn_rows && attn2 && h == 8 && !em_sw().no_rows_qkv;
+  for (int l = 0; rows_qkv && l < L; ++l) rows_qkv = ly[l].wqkvp != nullptr;
   auto ffn_fused = [&](const void* w1p, const void* w2p, const float* b1, const float* b2, int ln_mode, const float* g1,
-                       const float* be1, const float* g2, const float* be2, void* xn_out, float* out_f32) {
+                       const float* be1, const float* g2, const float* be2, void* xn_out, float* out_f32,
+                       const EmEBranchformerLayer* qkv_of = nullptr) {
     EmFfnRowsArgs fa = {};
+    if (qkv_of) {
+      fa.post_w = qkv_of->wqkvp; fa.post_b = qkv_of->bqkv; fa.post_chunks = 12;
+      fa.post_q = qh; fa.post_k = ws + s.kh; fa.post_vt = vt; fa.post_T = T; fa.post_Tpad = s.Tpad;
+    }
     fa.xn_in = xn; fa.x = x; fa.w1p = w1p; fa.w2p = w2p; fa.b1 = b1; fa.b2 = b2;
     fa.g1 = g1; fa.be1 = be1; fa.g2 = g2; fa.be2 = be2; fa.xn_out = xn_out; fa.out_f32 = out_f32;
     fa.M = M; fa.d = d; fa.ff = ff; fa.ln_mode = ln_mode; fa.scale = 0.5f; fa.eps = LN_EPS;
@@ -253,7 +261,8 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
     const EmEBranchformerLayer& q = ly[l];
     if (ffn_rows) {
       // macaron FFN + residual + norm_mha (the attention branch's LayerNorm) in one launch
-      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr));
+      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr,
+                       rows_qkv ? &q : nullptr));
     } else {
       if (ffn) {
         // macaron FFN (:132-135): x += 0.5 * w2(swish(w1 LN(x)))
@@ -266,14 +275,16 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
     EM_TRY(em_layernorm(dtype, x, q.norm_mlp_g, q.norm_mlp_b, M, d, LN_EPS, xn2, nullptr, stream));
     // branch 1 (:141-152): rel-pos self-attention; linear_out lands in cat[:, :d]
     if (attn2) {
-      EmGemmArgs a = {};
-      a.A = xn; a.W = q.wqkv; a.C = qh; a.bias = q.bqkv;
-      a.M = M; a.N = 2 * d; a.K = d; a.lda = d; a.ldc = 64; a.scale = 1.f;
-      a.T1 = T; a.T2 = s.Tpad; a.F1 = h; a.d = d;
-      EM_TRY(em_gemm(dtype, EM_EPI_QK_HEADS, EM_A_PLAIN, &a, stream));
-      a.A = (const unsigned char*)q.wqkv + (size_t)2 * d * d * es; a.W = xn; a.C = vt; a.bias = q.bqkv + 2 * d;
-      a.M = d; a.N = M; a.ldc = s.Tpad;
-      EM_TRY(em_gemm(dtype, EM_EPI_VT_HEADS, EM_A_PLAIN, &a, stream));
+      if (!rows_qkv) {
+        EmGemmArgs a = {};
+        a.A = xn; a.W = q.wqkv; a.C = qh; a.bias = q.bqkv;
+        a.M = M; a.N = 2 * d; a.K = d; a.lda = d; a.ldc = 64; a.scale = 1.f;
+        a.T1 = T; a.T2 = s.Tpad; a.F1 = h; a.d = d;
+        EM_TRY(em_gemm(dtype, EM_EPI_QK_HEADS, EM_A_PLAIN, &a, stream));
+        a.A = (const unsigned char*)q.wqkv + (size_t)2 * d * d * es; a.W = xn; a.C = vt; a.bias = q.bqkv + 2 * d;
+        a.M = d; a.N = M; a.ldc = s.Tpad;
+        EM_TRY(em_gemm(dtype, EM_EPI_VT_HEADS, EM_A_PLAIN, &a, stream));
+      }
       EM_TRY(em_relpos_attention2_bf16(qh, ws + s.kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
                                        q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
     } else {

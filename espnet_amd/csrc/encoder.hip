@@ -316,9 +316,18 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
   const bool ffn_rows = rp.ffn, pre_pw2 = rp.pre_pw2, rows_glu = rp.glu;
   const EmConformerLayer* pre_layer = nullptr;  // set for the call that carries the projection
   const void* const conv_out = g2;              // the depthwise conv's output: the projection's input
+  // round 6: q | k | v walked behind the macaron launch (EmFfnRowsArgs.post_q): no projection GEMMs, LN(x) never stored.
+  // ESPNET_AMD_NO_ROWS_QKV=1: developer A/B switch.
+  bool rows_qkv = ffn_rows && attn2 && d == 512 && h == 8 && !em_sw().no_rows_qkv;
+  for (int l = 0; rows_qkv && l < L; ++l) rows_qkv = ly[l].wqkvp != nullptr;
   auto ffn_fused = [&](const void* w1p, const void* w2p, const float* b1, const float* b2, int ln_mode, const float* g1,
-                       const float* be1, const float* g2, const float* be2, void* xn_out, float* out_f32) {
+                       const float* be1, const float* g2, const float* be2, void* xn_out, float* out_f32,
+                       const EmConformerLayer* qkv_of = nullptr) {
     EmFfnRowsArgs fa = {};
+    if (qkv_of) {
+      fa.post_w = qkv_of->wqkvp; fa.post_b = qkv_of->bqkv; fa.post_chunks = 12;
+      fa.post_q = qh; fa.post_k = ws + s.kh; fa.post_vt = vt; fa.post_T = T; fa.post_Tpad = s.Tpad;
+    }
     if (pre_layer) {
       fa.pre_in = conv_out; fa.pre_w = pre_layer->pw2p; fa.pre_b = pre_layer->pw2_b;
       fa.pre_g = pre_layer->norm_ff_g; fa.pre_be = pre_layer->norm_ff_b;
@@ -339,7 +348,8 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     pre_layer = nullptr;
     if (ffn_rows) {
       // macaron FFN + residual + norm_mha
-      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr));
+      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr,
+                       rows_qkv ? &q : nullptr));
     } else {
       // macaron FFN: x += 0.5 * w2(swish(w1 LN(x)))
       EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));
@@ -348,14 +358,16 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
       EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
     }
     if (attn2) {
-      EmGemmArgs a = {};
-      a.A = xn; a.W = q.wqkv; a.C = qh; a.bias = q.bqkv;
-      a.M = M; a.N = 2 * d; a.K = d; a.lda = d; a.ldc = 64; a.scale = 1.f;
-      a.T1 = T; a.T2 = s.Tpad; a.F1 = h; a.d = d;
-      EM_TRY(em_gemm(dtype, EM_EPI_QK_HEADS, EM_A_PLAIN, &a, stream));
-      a.A = (const unsigned char*)q.wqkv + (size_t)2 * d * d * es; a.W = xn; a.C = vt; a.bias = q.bqkv + 2 * d;
-      a.M = d; a.N = M; a.ldc = s.Tpad;
-      EM_TRY(em_gemm(dtype, EM_EPI_VT_HEADS, EM_A_PLAIN, &a, stream));
+      if (!rows_qkv) {
+        EmGemmArgs a = {};
+        a.A = xn; a.W = q.wqkv; a.C = qh; a.bias = q.bqkv;
+        a.M = M; a.N = 2 * d; a.K = d; a.lda = d; a.ldc = 64; a.scale = 1.f;
+        a.T1 = T; a.T2 = s.Tpad; a.F1 = h; a.d = d;
+        EM_TRY(em_gemm(dtype, EM_EPI_QK_HEADS, EM_A_PLAIN, &a, stream));
+        a.A = (const unsigned char*)q.wqkv + (size_t)2 * d * d * es; a.W = xn; a.C = vt; a.bias = q.bqkv + 2 * d;
+        a.M = d; a.N = M; a.ldc = s.Tpad;
+        EM_TRY(em_gemm(dtype, EM_EPI_VT_HEADS, EM_A_PLAIN, &a, stream));
+      }
       EM_TRY(em_relpos_attention2_bf16(qh, ws + s.kh, vt, (const unsigned char*)pall + (size_t)l * d * es, L * d, q.pos_u,
                                        q.pos_v, olens, B, T, s.Tpad, h, ctx, stream));
     } else {

@@ -109,8 +109,10 @@ __device__ __forceinline__ float rsqrt_nr(float var) {
 // launches between the attention and the depthwise conv (19.1 + 9.8 + 29.7 us at B = 64).  Its matrix is walked in the
 // GEMM-1 form (wave w: 16 output columns of every 128-row chunk), chunks alternating value rows and their gate rows, so a
 // lane holds matching value / gate pairs; no hidden tile, no barrier in the loop.
-// POST: the CTC head's arg-max walk behind the launch (the last launch of the stack), see the end of the kernel.
-template <int LNMODE, bool PRE, int MAIN, bool POST = false>
+// POST 1: the CTC head's arg-max walk behind the launch (the last launch of the stack), see the end of the kernel.
+// POST 2 (round 6): the attention's q | k | v projections walked behind a ln_mode 1 launch (macaron FFN + residual + norm_mha):
+// their per-head operands (csrc/attention2.hip) written straight from the walk, LN(x) itself never stored.
+template <int LNMODE, bool PRE, int MAIN, int POST = 0>
 __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, long long* __restrict__ stamps) {
   using MM = Mma<bf16>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -504,8 +506,8 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   }
   barrier();
   read_h((nch - 1) & 1, 0, h0);
-  if constexpr (POST)
-    gemm2((nch - 1) & 1, rsrc(a.post_w, 0), std::true_type{}, [&](int, int) {});  // (the ring leaves with the CTC matrix's head)
+  if constexpr (POST != 0)
+    gemm2((nch - 1) & 1, rsrc(a.post_w, 0), std::true_type{}, [&](int, int) {});  // (the ring leaves with the walked matrix's head)
   else
     gemm2((nch - 1) & 1, rsrc(a.w2p, 0), std::false_type{}, [&](int, int) {});
   if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc2[3][3]));
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     layer_norm(6, 0);
     if (a.out_f32) store_f32(a.out_f32);
   }
-  {
+  if constexpr (POST != 2) {
     bf16* const out = (bf16*)a.xn_out;
 #pragma unroll
     for (int rf = 0; rf < 4; ++rf) {
@@ -562,7 +564,65 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     }
   }
   stamp();
-  if constexpr (POST) {
+  if constexpr (POST == 2) {
+    // ---- q | k | v of the attention that follows (RelPositionMultiHeadedAttention.forward_qkv, transformer/attention.py:77-98)
+    // as a walk behind norm_mha: the 64 normalised rows go back into the LDS tile (bf16: what the projection GEMMs read from
+    // `xn`), [linear_q | linear_k | linear_v] (1 536 x 512, twelve chunks of 128 rows in the w1p layout) is walked in the GEMM-1
+    // form and every chunk's results leave in the layouts csrc/attention2.hip reads: q, k [B][heads][Tpad][64] (a lane's four
+    // columns are four consecutive dims of one head: 8-byte stores), V^T [B][512][Tpad] (2-byte stores: T is odd in general).
+    // Replaces two tiled-GEMM launches per block (26.0 + 21.4 us at B = 64) and the store + reload of LN(x).
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) {
+      const int q = 8 * wave + 2 * cf + (lg >> 1);
+      const int pos = (q & ~15) | ((q ^ lr) & 15);
+#pragma unroll
+      for (int rf = 0; rf < 4; ++rf)
+        *(bf16x4*)(smem + ACT_OFF + (rf * 16 + lr) * 1024 + pos * 16 + (lg & 1) * 8) = __builtin_convertvector(xin[cf][rf], bf16x4);
+    }
+    barrier();
+    read_act(0, af0);
+    const int Tn = a.post_T, Tp = a.post_Tpad;
+    size_t qk_off[4], vt_off[4];  // element offsets of this lane's four rows: (b * 8 heads * Tpad + t) * 64, b * 512 * Tpad + t
+    bool rok[4];
+#pragma unroll
+    for (int rf = 0; rf < 4; ++rf) {
+      const int m = m0 + rf * 16 + lr;
+      rok[rf] = m < M;
+      const int mm = rok[rf] ? m : M - 1;
+      const int bb = mm / Tn, tt = mm - bb * Tn;
+      qk_off[rf] = ((size_t)bb * (D / 64) * Tp + tt) * 64;
+      vt_off[rf] = (size_t)bb * D * Tp + tt;
+    }
+    const float* cbp = a.post_b + 16 * wave + 4 * lg;
+    const int nc = a.post_chunks;  // 12
+    float4 cb = *(const float4*)cbp;
+#pragma unroll 1
+    for (int c = 0; c < nc; ++c) {
+      const float4 cbn = *(const float4*)(cbp + (c + 1 < nc ? c + 1 : c) * CH);
+      gemm1(rsrc(a.post_w, c + 1 < nc ? c + 1 : c), std::false_type{}, 0, std::true_type{});
+      const int j0 = (c & 3) * CH + 16 * wave + 4 * lg;  // this lane's first column inside q, k or v (a chunk never straddles two)
+      if (c < 8) {
+        bf16* const base = (bf16*)(c < 4 ? a.post_q : a.post_k) + (size_t)(j0 >> 6) * Tp * 64 + (j0 & 63);
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf) {
+          const f32x4 v = acc1[rf] + (f32x4){cb.x, cb.y, cb.z, cb.w};
+          if (rok[rf]) *(bf16x4*)(base + qk_off[rf]) = __builtin_convertvector(v, bf16x4);
+        }
+      } else {
+        bf16* const base = (bf16*)a.post_vt + (size_t)j0 * Tp;
+#pragma unroll
+        for (int rf = 0; rf < 4; ++rf) {
+          const f32x4 v = acc1[rf] + (f32x4){cb.x, cb.y, cb.z, cb.w};
+          if (rok[rf]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[vt_off[rf] + (size_t)r * Tp] = (bf16)v[r];
+          }
+        }
+      }
+      cb = cbn;
+    }
+  }
+  if constexpr (POST == 1) {
     {
       // ---- the CTC head's arg-max (asr/ctc.py:207-215: argmax over ctc_lo of the encoder output) as a walk behind the last
       // launch of the stack: the 64 finished rows go back into the LDS tile (bf16: what the stand-alone GEMM reads from
@@ -642,14 +702,20 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
 }  // namespace
 
 extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
-  if (!a || !a->x || !a->w1p || !a->b1 || !a->xn_out) return EM_ERR_BAD_ARG;
+  const bool post_qkv = a && a->post_q != nullptr;
+  if (!a || !a->x || !a->w1p || !a->b1 || (!a->xn_out && !post_qkv)) return EM_ERR_BAD_ARG;
   if (a->main == EM_ROWS_FFN && (!a->w2p || !a->b2 || !a->g1 || !a->be1)) return EM_ERR_BAD_ARG;
   const bool pre = a->pre_in != nullptr;
   if (pre ? (!a->pre_w || !a->pre_b || !a->pre_g || !a->pre_be) : !a->xn_in) return EM_ERR_BAD_ARG;
   if (a->M <= 0 || a->ff <= 0) return EM_ERR_BAD_ARG;
   if (a->d != D || a->ff % CH != 0 || a->ff < 2 * CH) return EM_ERR_UNSUPPORTED;
-  if (a->post_w && (a->main != EM_ROWS_FFN || a->ln_mode != 2 || !a->post_b || !a->post_ids || a->post_chunks <= 0))
+  if (post_qkv) {  // q | k | v walked behind a ln_mode 1 launch without a projection in front
+    if (a->main != EM_ROWS_FFN || a->ln_mode != 1 || pre || !a->post_w || !a->post_b || !a->post_k || !a->post_vt ||
+        a->post_chunks != 3 * D / CH || a->post_T <= 0 || a->post_Tpad < a->post_T || a->M % a->post_T != 0)
+      return EM_ERR_BAD_ARG;
+  } else if (a->post_w && (a->main != EM_ROWS_FFN || a->ln_mode != 2 || !a->post_b || !a->post_ids || a->post_chunks <= 0)) {
     return EM_ERR_BAD_ARG;
+  }
   const bool glu = a->main == EM_ROWS_GLU;
   if (a->main != EM_ROWS_FFN && !glu) return EM_ERR_BAD_ARG;
   if (glu && !pre) return EM_ERR_BAD_ARG;
@@ -663,15 +729,16 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   if (want_stamps && hipMemsetAsync(stamps, 0, 64 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   long long* const st = want_stamps ? stamps : nullptr;
   typedef void (*kern_t)(const EmFfnRowsArgs, long long*);
-  static EmLdsCap caps[7] = {};
-  const int which = glu ? 4 : a->post_w ? 5 + (pre ? 1 : 0) : (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
+  static EmLdsCap caps[8] = {};
+  const int which = post_qkv ? 7 : glu ? 4 : a->post_w ? 5 + (pre ? 1 : 0) : (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
   const kern_t kern = which == 0   ? ffn_rows_kernel<1, false, EM_ROWS_FFN>
                       : which == 1 ? ffn_rows_kernel<1, true, EM_ROWS_FFN>
                       : which == 2 ? ffn_rows_kernel<2, false, EM_ROWS_FFN>
                       : which == 3 ? ffn_rows_kernel<2, true, EM_ROWS_FFN>
                       : which == 4 ? ffn_rows_kernel<1, true, EM_ROWS_GLU>
-                      : which == 5 ? ffn_rows_kernel<2, false, EM_ROWS_FFN, true>
-                                   : ffn_rows_kernel<2, true, EM_ROWS_FFN, true>;
+                      : which == 5 ? ffn_rows_kernel<2, false, EM_ROWS_FFN, 1>
+                      : which == 6 ? ffn_rows_kernel<2, true, EM_ROWS_FFN, 1>
+                                   : ffn_rows_kernel<1, false, EM_ROWS_FFN, 2>;
   if (em_raise_lds_cap((const void*)kern, SMEM_BYTES, &caps[which]) != EM_OK) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
   hipLaunchKernelGGL(kern, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);
@@ -686,7 +753,7 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   }
   if (rec)
     em_prof_end(stream, (glu ? 2.0 : 4.0) * a->M * (double)D * a->ff + (pre ? 2.0 * a->M * (double)D * D : 0.0) +
-                            (a->post_w ? 2.0 * a->M * (double)D * a->post_vocab : 0.0), EM_PROF_ROWS);
+                            (a->post_w ? 2.0 * a->M * (double)D * (post_qkv ? 3 * D : a->post_vocab) : 0.0), EM_PROF_ROWS);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }

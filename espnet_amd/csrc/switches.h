@@ -11,6 +11,7 @@ struct EmSwitches {
   int sa_split, sa_group;                                            // ESPNET_AMD_SA_SPLIT / _SA_GROUP (0: automatic)
   bool no_sa_tree;                                                   // ESPNET_AMD_NO_SA_TREE
   int sa_tree_min_rows;                                              // ESPNET_AMD_SA_TREE_MIN_ROWS (default 200)
+  bool no_rows_qkv;                                                  // ESPNET_AMD_NO_ROWS_QKV (512-wide: q | k | v as two GEMM launches instead of the walk behind the macaron launch)
   bool no_attn2_large, no_ffn_rows, no_rows_ctc;                     // ESPNET_AMD_NO_ATTN2_LARGE / _NO_FFN_ROWS / _NO_ROWS_CTC
   bool frontend_v1;                                                  // ESPNET_AMD_FRONTEND_V1
   int gemm_stages, gemm_bm;                                          // ESPNET_AMD_GEMM_STAGES / _GEMM_BM (0: automatic; 64 | 128: the M tile)

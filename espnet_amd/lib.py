@@ -94,7 +94,8 @@ class EmFfnRowsArgs(C.Structure):
                                           "out_f32")] + \
                [(n, C.c_int32) for n in ("M", "d", "ff", "ln_mode")] + [("scale", C.c_float), ("eps", C.c_float)] + \
                [(n, C.c_void_p) for n in ("pre_in", "pre_w", "pre_b", "pre_g", "pre_be")] + [("main", C.c_int32)] + \
-               [(n, C.c_void_p) for n in ("post_w", "post_b", "post_ids")] + [("post_chunks", C.c_int32), ("post_vocab", C.c_int32)]
+               [(n, C.c_void_p) for n in ("post_w", "post_b", "post_ids")] + [("post_chunks", C.c_int32), ("post_vocab", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("post_q", "post_k", "post_vt")] + [("post_T", C.c_int32), ("post_Tpad", C.c_int32)]
 
 
 class EmConformerWeights(C.Structure):
@@ -115,7 +116,7 @@ _EBF_LAYER_PTRS = ["norm_ff_mac_g", "norm_ff_mac_b", "norm_mha_g", "norm_mha_b",
                    "ffm_b1", "ffm_b2", "ff_b1", "ff_b2", "wqkv", "bqkv", "pos_u", "pos_v", "wout", "bout",
                    "proj1_w", "proj1_b", "csgu_norm_g", "csgu_norm_b", "csgu_conv_w", "csgu_conv_b", "proj2_w",
                    "proj2_b", "merge_conv_w", "merge_conv_b", "merge_w", "merge_b", "pool_w", "pool_b", "wproj_w",
-                   "wproj_b", "ffm_w1p", "ffm_w2p", "ff_w1p", "ff_w2p"]
+                   "wproj_b", "ffm_w1p", "ffm_w2p", "ff_w1p", "ff_w2p", "wqkvp"]
 EM_MERGE_CONCAT, EM_MERGE_LEARNED_AVE = 0, 1
 
 

@@ -266,7 +266,8 @@ typedef struct EmConformerLayer {
   const void* pw1f;      /* [2d][d]: pointwise_conv1 rows in 64-row granules [v0..63, g0..63, v64..127, ...], K units */
   const void *ffm_w2p, *ff_w2p; /* w_2 of the two FFNs, packed per pair of hidden chunks (EmBlockArgs) */
   const void *woutp, *pw2p, *ff_w1p, *ffm_w1p, *wqkvp; /* K units of wout, pw2, ff_w1, ffm_w1, wqkv */
-  /* d = 512 (bf16): ffm_w1p / ffm_w2p / ff_w1p / ff_w2p hold the operand streams of em_ffn_rows_fused instead (EmFfnRowsArgs
+  /* d = 512 (bf16): wqkvp = [linear_q | linear_k | linear_v] in the w1p layout (round 6: walked behind the macaron launch,
+   * EmFfnRowsArgs.post_q; NULL: two projection GEMMs); ffm_w1p / ffm_w2p / ff_w1p / ff_w2p hold the operand streams of em_ffn_rows_fused instead (EmFfnRowsArgs
    * w1p / w2p), pw2p the projection in front of the second one (EmFfnRowsArgs.pre_w), woutp / pw1f / fp_c the operands of the
    * EM_ROWS_GLU launch (linear_out as pre_w, pointwise_conv1 in value / gate chunk pairs, its bias in that order), and
    * em_conformer_encode runs the block in 10 launches (when its rows fill the chip); the other fields stay NULL */
@@ -524,6 +525,13 @@ typedef struct EmFfnRowsArgs {
   const float* post_b;
   int32_t* post_ids;
   int32_t post_chunks, post_vocab;
+  /* round 6, optional walk behind a ln_mode 1 launch WITHOUT a projection in front (post_q != NULL): the q | k | v projections
+   * of the attention that follows norm_mha (transformer/attention.py:77-98), written per head as csrc/attention2.hip reads
+   * them - post_q, post_k [B][8][post_Tpad][64] bf16, post_vt [B][512][post_Tpad] bf16 (V transposed; frames >= post_T are the
+   * caller's padding) - with M = B * post_T rows.  post_w: [linear_q | linear_k | linear_v] (1 536 x 512) in the w1p layout
+   * (post_chunks = 12), post_b their biases [1 536].  xn_out may then be NULL: LN(x) is not stored.                          */
+  void *post_q, *post_k, *post_vt;
+  int32_t post_T, post_Tpad;
 } EmFfnRowsArgs;
 #define EM_ROWS_FFN 0
 #define EM_ROWS_GLU 1
@@ -569,6 +577,7 @@ typedef struct EmEBranchformerLayer {
    * that follows: norm_mha after the macaron one; norm_final + the next block's norm_ff_macaron / after_norm after the
    * other) is ONE row-block launch when its rounds fill the chip (EM_ENC_IN_FLIGHT); NULL: two GEMMs + LayerNorm */
   const void *ffm_w1p, *ffm_w2p, *ff_w1p, *ff_w2p;
+  const void* wqkvp; /* [linear_q | linear_k | linear_v] in the w1p layout: walked behind the macaron launch (EmFfnRowsArgs.post_q), or NULL */
 } EmEBranchformerLayer;
 
 #define EM_MERGE_CONCAT 0      /* x += merge_proj([x1 | x2]); also fixed_ave, whose host packing is

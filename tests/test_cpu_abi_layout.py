@@ -101,3 +101,36 @@ def test_bound_signatures_match_the_header_prototypes():
         if ("ptr" if "*" in r else scalar[r]) != kind_ct(res):
             bad.append((name, "result", r, res))
     assert not bad, bad
+
+
+def test_fragment_major_packing_and_flag_macros(tmp_path):
+    """Round 6: `pack_frag16` is the layout include/espnet_amd.h states for em_dec_ffn / em_ln_gemm_frag -
+    [R/16][K/32][lane = 16 * (k % 32 / 8) + r % 16][k % 8], rows zero-padded to `pad_rows` - and the Python mirrors of the
+    round's macros (EM_ENC_IN_FLIGHT, EM_LNF_*) are the header's values as gcc evaluates them."""
+    import subprocess
+
+    import torch
+
+    from espnet_amd import lib as L
+
+    R, K = 40, 96
+    w = torch.arange(R * K, dtype=torch.float32).reshape(R, K)
+    f = L.pack_frag16(w, pad_rows=32).reshape(-1)
+    Rp = 64
+    assert f.numel() == Rp * K
+    for r, k in ((0, 0), (5, 7), (15, 31), (16, 32), (39, 95), (23, 40)):
+        lane = 16 * ((k % 32) // 8) + r % 16
+        idx = (((r // 16) * (K // 32) + k // 32) * 64 + lane) * 8 + k % 8
+        assert f[idx].item() == w[r, k].item(), (r, k)
+    back = f.reshape(Rp // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(Rp, K)
+    assert torch.equal(back[:R], w) and (back[R:] == 0).all()
+    src = tmp_path / "m.c"
+    src.write_text('#include <stdio.h>\n#include "espnet_amd.h"\nint main(void) { printf("%d %d %d %d %d\\n", EM_ENC_IN_FLIGHT(3), '
+                   'EM_ENC_IN_FLIGHT(17), EM_LNF_RELU_FRAG, EM_LNF_STORE, EM_LNF_STORE_F32); return 0; }\n')
+    exe = tmp_path / "m"
+    inc = str(__import__("pathlib").Path(L.__file__).resolve().parents[1] / "include")
+    subprocess.run(["gcc", "-I", inc, str(src), "-o", str(exe)], check=True)
+    vals = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert vals == [L.EM_ENC_IN_FLIGHT(3), L.EM_ENC_IN_FLIGHT(17), L.EM_LNF_RELU_FRAG, L.EM_LNF_STORE, L.EM_LNF_STORE_F32]
+    for bit in (L.EM_ENC_ISOLATE_UTTS, L.EM_ENC_NO_FUSED, L.EM_ENC_POS_PROJECTED, L.EM_ENC_POS_PACKED):
+        assert L.EM_ENC_IN_FLIGHT(15) & bit == 0  # (the count's bits are its own)
