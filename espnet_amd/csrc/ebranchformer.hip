@@ -261,8 +261,13 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
     const EmEBranchformerLayer& q = ly[l];
     if (ffn_rows) {
       // macaron FFN + residual + norm_mha (the attention branch's LayerNorm) in one launch
-      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr,
-                       rows_qkv ? &q : nullptr));
+      // (with the q | k | v walk norm_mha's result never leaves the launch, and norm_mlp - the cgMLP branch's LayerNorm of the
+      // same rows - leaves in its place: one set of statistics, two affine maps, no LayerNorm launch)
+      if (rows_qkv)
+        EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, q.norm_mlp_g, q.norm_mlp_b, xn2,
+                         nullptr, &q));
+      else
+        EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr));
     } else {
       if (ffn) {
         // macaron FFN (:132-135): x += 0.5 * w2(swish(w1 LN(x)))
@@ -272,7 +277,7 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
       // the two branches read the same x (:138-139)
       EM_TRY(em_layernorm(dtype, x, q.norm_mha_g, q.norm_mha_b, M, d, LN_EPS, xn, nullptr, stream));
     }
-    EM_TRY(em_layernorm(dtype, x, q.norm_mlp_g, q.norm_mlp_b, M, d, LN_EPS, xn2, nullptr, stream));
+    if (!(ffn_rows && rows_qkv)) EM_TRY(em_layernorm(dtype, x, q.norm_mlp_g, q.norm_mlp_b, M, d, LN_EPS, xn2, nullptr, stream));
     // branch 1 (:141-152): rel-pos self-attention; linear_out lands in cat[:, :d]
     if (attn2) {
       if (!rows_qkv) {

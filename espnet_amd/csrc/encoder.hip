@@ -348,8 +348,8 @@ extern "C" int em_conformer_encode(int dtype, const EmConformerWeights* w, const
     pre_layer = nullptr;
     if (ffn_rows) {
       // macaron FFN + residual + norm_mha
-      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr, xn, nullptr,
-                       rows_qkv ? &q : nullptr));
+      EM_TRY(ffn_fused(q.ffm_w1p, q.ffm_w2p, q.ffm_b1, q.ffm_b2, 1, q.norm_mha_g, q.norm_mha_b, nullptr, nullptr,
+                       rows_qkv ? nullptr : xn, nullptr, rows_qkv ? &q : nullptr));  // (with the walk LN(x) is not stored)
     } else {
       // macaron FFN: x += 0.5 * w2(swish(w1 LN(x)))
       EM_TRY(gemm(dtype, EM_EPI_SWISH, xn, q.ffm_w1, big, q.ffm_b1, M, ff, d, d, ff, 1.f, stream));

@@ -542,7 +542,33 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   };
   if constexpr (LNMODE == 1) {
     store_f32(a.x);
-    layer_norm(4, 1);
+    if constexpr (POST == 2) {
+      if (a.xn_out != nullptr) {  // (uniform) a SIBLING LayerNorm of the same rows leaves as xn_out (vectors g2 / be2): E-Branchformer's
+        float mean[4], rstd[4];   // norm_mlp beside norm_mha (e_branchformer_encoder.py:138-139) - one set of statistics, two affine maps
+        ln_stats(xin, 1, mean, rstd);
+        bf16* const out = (bf16*)a.xn_out;
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          const f32x4 g4 = parv(6, cf), b4 = parv(7, cf);
+#pragma unroll
+          for (int rf = 0; rf < 4; ++rf) {
+            const int m = m0 + rf * 16 + lr;
+            const f32x4 y = (xin[cf][rf] - mean[rf]) * (g4 * rstd[rf]) + b4;
+            if (m < M) *(bf16x4*)(out + (size_t)m * D + col0 + 16 * cf) = __builtin_convertvector(y, bf16x4);
+          }
+        }
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          const f32x4 g4 = parv(4, cf), b4 = parv(5, cf);
+#pragma unroll
+          for (int rf = 0; rf < 4; ++rf) xin[cf][rf] = (xin[cf][rf] - mean[rf]) * (g4 * rstd[rf]) + b4;
+        }
+      } else {
+        layer_norm(4, 1);
+      }
+    } else {
+      layer_norm(4, 1);
+    }
   } else {
     layer_norm(4, 1);
     store_f32(a.x);
@@ -710,6 +736,7 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   if (a->M <= 0 || a->ff <= 0) return EM_ERR_BAD_ARG;
   if (a->d != D || a->ff % CH != 0 || a->ff < 2 * CH) return EM_ERR_UNSUPPORTED;
   if (post_qkv) {  // q | k | v walked behind a ln_mode 1 launch without a projection in front
+    if (a->xn_out && (!a->g2 || !a->be2)) return EM_ERR_BAD_ARG;  // (xn_out then = LayerNorm(x; g2, be2), a sibling of norm_mha)
     if (a->main != EM_ROWS_FFN || a->ln_mode != 1 || pre || !a->post_w || !a->post_b || !a->post_k || !a->post_vt ||
         a->post_chunks != 3 * D / CH || a->post_T <= 0 || a->post_Tpad < a->post_T || a->M % a->post_T != 0)
       return EM_ERR_BAD_ARG;

@@ -529,7 +529,8 @@ typedef struct EmFfnRowsArgs {
    * of the attention that follows norm_mha (transformer/attention.py:77-98), written per head as csrc/attention2.hip reads
    * them - post_q, post_k [B][8][post_Tpad][64] bf16, post_vt [B][512][post_Tpad] bf16 (V transposed; frames >= post_T are the
    * caller's padding) - with M = B * post_T rows.  post_w: [linear_q | linear_k | linear_v] (1 536 x 512) in the w1p layout
-   * (post_chunks = 12), post_b their biases [1 536].  xn_out may then be NULL: LN(x) is not stored.                          */
+   * (post_chunks = 12), post_b their biases [1 536].  LN(x; g1, be1) is not stored; xn_out, when not NULL, receives a SIBLING
+   * LayerNorm of the same rows, LN(x; g2, be2) (E-Branchformer's norm_mlp beside norm_mha, e_branchformer_encoder.py:138-139).   */
   void *post_q, *post_k, *post_vt;
   int32_t post_T, post_Tpad;
 } EmFfnRowsArgs;
