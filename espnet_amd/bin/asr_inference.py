@@ -144,7 +144,11 @@ class Speech2Text:
                 # (four lanes, a host thread each: with ONE host thread two lanes already saturate the host's launch rate -
                 # 2 / 3 / 4 lanes 60.4 / 60.3 / 60.9 ms per batch of 16 - with a thread per lane 4 lanes reach 48.0;
                 # profiles/r06z_beam_lanes_threads_ab.txt.  `search_lanes` / `lane_threads` attributes: set before the first call)
-                n_lanes = max(1, int(getattr(self, "search_lanes", 4)))
+                # (round 6, late: eight lanes while a search's launches leave most of the chip idle - up to ~200 rows = batch x beam:
+                # 4 / 6 / 8 lanes 4 033 / 4 083 / 4 705 audio-s/s at 16 x beam 10; at 64 x beam 10 four lanes are as good as eight,
+                # profiles/r06al_beam_lanes_sweep.txt)
+                rows = int(speech.shape[0]) * int(getattr(self.beam_search, "beam_size", 10))
+                n_lanes = max(1, int(getattr(self, "search_lanes", None) or (8 if rows <= 200 else 4)))
                 lanes = self._lanes = SearchLanes([self.beam_search] + [self.beam_search.clone() for _ in range(n_lanes - 1)],
                                                   self.device, threaded=bool(getattr(self, "lane_threads", True)))
             k = lanes.free_lane()
@@ -355,7 +359,8 @@ def inference(output_dir: str, maxlenratio: float = 0.0, minlenratio: float = 0.
         # flight on alternating streams), three for the joint search (four searches in flight, a host thread each)
         import collections
 
-        depth = 1 if getattr(speech2text, "ctc_greedy", False) else max(1, int(getattr(speech2text, "search_lanes", 4)) - 1)
+        lanes = getattr(speech2text, "search_lanes", None) or (8 if int(batch_size) * int(beam_size) <= 200 else 4)  # (as batch_decode_async)
+        depth = 1 if getattr(speech2text, "ctc_greedy", False) else max(1, int(lanes) - 1)
         inflight = collections.deque()
         for keys, batch in loader:
             assert all(isinstance(s, str) for s in keys), keys

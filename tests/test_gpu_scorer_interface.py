@@ -115,7 +115,7 @@ def test_decoder_batch_score_and_forward_match_oracle_steps():
     assert (got - torch.stack(rows, 1)).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("n", [160, 640])
+@pytest.mark.parametrize("n", [160, 640, 100, 330])
 def test_decoder_batch_score_bf16_at_640_rows(n):
     """The decoder step in the TIMED dtype at the row counts of configs[2] (160) and configs[3] per GPU (640; VERDICT r04
     item 1a): at 640 rows `em_decoder_step` runs the self-attention with one wave per row (heads x rows > 2048) and the
@@ -123,7 +123,10 @@ def test_decoder_batch_score_bf16_at_640_rows(n):
     Large decoder (6 x 512d, 8 heads, V = 5 000), n hypotheses with different 4-token prefixes over one 74-frame memory,
     against the oracle's f32 K/V-cached step: bound on the log-probabilities, and the error statistics over the entries a
     pre-beam can reach (the 15 best of every row) are printed - the device's per-entry noise level that
-    tests/test_gpu_fullsize.py's path-noise model (PATH_NOISE_SIGMA) stands on."""
+    tests/test_gpu_fullsize.py's path-noise model (PATH_NOISE_SIGMA) stands on.  Round 6: from 96 rows the step's projections
+    run on fragment-major weights (csrc/dec_ffn.hip, mid_gemm<FRAG>); n = 100 and 330 are row counts that are NOT whole
+    16-row fragments (the feed-forward keeps its row-major launches there, q | k | v / out-projections / - up to 320 rows -
+    the logits take the fragment-major ones with masked edge rows)."""
     from oracle import beam_search as ob
 
     g = load_golden("large_beam10_3s")
