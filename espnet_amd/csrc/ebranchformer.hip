@@ -239,6 +239,7 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
   bool ffn_rows = ffn && dtype == EM_BF16 && d == 512 && ff % 128 == 0 && ff >= 256 && !(flags & EM_ENC_NO_FUSED) &&
                   !em_sw().no_ffn_rows && em_rows_fill_ok(M, flags);
   for (int l = 0; ffn_rows && l < L; ++l) ffn_rows = ly[l].ffm_w1p && ly[l].ffm_w2p && ly[l].ff_w1p && ly[l].ff_w2p;
+  const EmEBranchformerLayer* ln_in = nullptr;  // set for the launch that computes norm_ff itself (reset after it)
   // ... and q | k | v walked behind the macaron launch (EmFfnRowsArgs.post_q; ESPNET_AMD_NO_ROWS_QKV=1: developer switch)
   bool rows_qkv = ffn_rows && attn2 && h == 8 && !em_sw().no_rows_qkv;
   for (int l = 0; rows_qkv && l < L; ++l) rows_qkv = ly[l].wqkvp != nullptr;
@@ -250,7 +251,10 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
       fa.post_w = qkv_of->wqkvp; fa.post_b = qkv_of->bqkv; fa.post_chunks = 12;
       fa.post_q = qh; fa.post_k = ws + s.kh; fa.post_vt = vt; fa.post_T = T; fa.post_Tpad = s.Tpad;
     }
-    fa.xn_in = xn; fa.x = x; fa.w1p = w1p; fa.w2p = w2p; fa.b1 = b1; fa.b2 = b2;
+    if (ln_in) {  // the module's input = LayerNorm(x; norm_ff) computed in the launch
+      fa.pre_g = ln_in->norm_ff_g; fa.pre_be = ln_in->norm_ff_b;
+    }
+    fa.xn_in = ln_in ? nullptr : xn; fa.x = x; fa.w1p = w1p; fa.w2p = w2p; fa.b1 = b1; fa.b2 = b2;
     fa.g1 = g1; fa.be1 = be1; fa.g2 = g2; fa.be2 = be2; fa.xn_out = xn_out; fa.out_f32 = out_f32;
     fa.M = M; fa.d = d; fa.ff = ff; fa.ln_mode = ln_mode; fa.scale = 0.5f; fa.eps = LN_EPS;
     return em_ffn_rows_fused(&fa, stream);
@@ -327,14 +331,17 @@ extern "C" int em_ebranchformer_encode(int dtype, const EmEBranchformerWeights* 
       EM_TRY(gemm(dtype, EM_EPI_RESID_F32, merged, q.merge_w, x, q.merge_b, M, d, 2 * d, 2 * d, d, 1.f, stream));
     }
     if (ffn_rows) {
-      // FFN (:172-176) + residual + norm_final (:178) + the next consumer's LayerNorm in one launch
-      EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
+      // norm_ff + FFN (:172-176) + residual + norm_final (:178) + the next consumer's LayerNorm in one launch (norm_ff in its
+      // prologue, EmFfnRowsArgs.pre_g / pre_be without a projection; ESPNET_AMD_NO_ROWS_QKV=1 also keeps the LayerNorm launch)
+      ln_in = !em_sw().no_rows_qkv ? &q : nullptr;
+      if (!ln_in) EM_TRY(em_layernorm(dtype, x, q.norm_ff_g, q.norm_ff_b, M, d, LN_EPS, xn, nullptr, stream));
       if (l + 1 < L)
         EM_TRY(ffn_fused(q.ff_w1p, q.ff_w2p, q.ff_b1, q.ff_b2, 2, q.norm_final_g, q.norm_final_b, ly[l + 1].norm_ff_mac_g,
                          ly[l + 1].norm_ff_mac_b, xn, nullptr));
       else
         EM_TRY(ffn_fused(q.ff_w1p, q.ff_w2p, q.ff_b1, q.ff_b2, 2, q.norm_final_g, q.norm_final_b, w->after_norm_g, w->after_norm_b,
                          enc_act, enc_out));
+      ln_in = nullptr;
       continue;
     }
     if (ffn) {

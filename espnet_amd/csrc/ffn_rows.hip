@@ -112,7 +112,7 @@ __device__ __forceinline__ float rsqrt_nr(float var) {
 // POST 1: the CTC head's arg-max walk behind the launch (the last launch of the stack), see the end of the kernel.
 // POST 2 (round 6): the attention's q | k | v projections walked behind a ln_mode 1 launch (macaron FFN + residual + norm_mha):
 // their per-head operands (csrc/attention2.hip) written straight from the walk, LN(x) itself never stored.
-template <int LNMODE, bool PRE, int MAIN, int POST = 0>
+template <int LNMODE, int PRE, int MAIN, int POST = 0>
 __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, long long* __restrict__ stamps) {
   using MM = Mma<bf16>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -136,7 +136,10 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   // with global chunk (l & ~15) | ((l ^ row) & 15)).  Requested FIRST: GEMM 1 needs all of it and only the head of the ring.
   // (from inline asm: an LDS-DMA hipcc knows about makes its wait-count pass put s_waitcnt vmcnt(0) in front of the first LDS
   // read - i.e. wait for the ring AND the residual rows requested behind it - instead of the counted wait below)
-  {
+  // (PRE == 2, round 6: no projection and no tile to fetch - the module's input is LayerNorm(x; pre_g, pre_be) of the residual
+  // rows themselves, computed where a projection launch computes it: the LayerNorm launch in front of E-Branchformer's second
+  // feed-forward module, e_branchformer_encoder.py:172-174, is gone)
+  if constexpr (PRE != 2) {
     const unsigned char* src = (const unsigned char*)(PRE ? a.pre_in : a.xn_in);
 #pragma unroll
     for (int i = 0; i < RB / NW; ++i) {
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
       for (int cf = 0; cf < 4; ++cf) v[cf][rf] = *(const f32x4*)(xr + 16 * cf);
     }
   };
-  if constexpr (PRE) load_x(acc2);
+  if constexpr (PRE != 0) load_x(acc2);
   __builtin_amdgcn_sched_barrier(0);
   // ---- weight stream: per chunk 16 fragments x [8 waves] x 1 KiB of W1 and as many of W2 (include/espnet_amd.h,
   // EmFfnRowsArgs): fragment i of this wave at chunk + i * 8 KiB + wave * 1 KiB + lane * 16
@@ -192,9 +195,9 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   };
   // (PRE: the projection's 64 fragments x [8 waves] x 1 KiB, [ks][cf][wave][lane][e] = W_pre[64 wave + 16 cf + lr][32 ks + 8 lg + e])
   const __amdgpu_buffer_rsrc_t rs_pre =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(PRE ? a.pre_w : a.w1p), 0, 4 * CHUNK_BYTES, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(PRE == 1 ? a.pre_w : a.w1p), 0, 4 * CHUNK_BYTES, 0x00020000);
   {
-    const __amdgpu_buffer_rsrc_t r0 = PRE ? rs_pre : rsrc(a.w1p, 0);
+    const __amdgpu_buffer_rsrc_t r0 = PRE == 1 ? rs_pre : rsrc(a.w1p, 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) ring[i] = ld(r0, i);
   }
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   stamp();
-  if constexpr (!PRE) load_x(acc2);
+  if constexpr (PRE == 0) load_x(acc2);
   __builtin_amdgcn_sched_barrier(0);
   read_act(0, af0);
 
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     }
   };
 
-  if constexpr (PRE) {
+  if constexpr (PRE != 0) {
     // ---- the projection: accp^T[col 64 wave + 16 cf + ..][row] = W_pre . tile^T over K = 512, GEMM-2 style (the tile's
     // fragments one k-step ahead, a slot refilled behind its 4 MFMAs: the projection's fragment 16 positions on, then
     // the head of W1's first chunk)
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     // or at its k-step 12 - pushed the kernel past 256 registers: hipcc spilled ring refills the moment they were loaded, each
     // behind an s_waitcnt vmcnt(0), and the 256 MFMAs per wave took 20 K cycles: stamps r04u.)  The price: the first MFMAs
     // wait for the rows, ~10 K cycles at the rate 249 workgroups get their 128 KiB each.
-    {
+    if constexpr (PRE == 1) {
       const __amdgpu_buffer_rsrc_t rw1 = rsrc(a.w1p, 0);
       bf16x8 cur[4], nxt[4];
 #pragma unroll
@@ -402,11 +405,13 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
     if constexpr ((dbg & 8) != 0) asm volatile("s_nop 0" : "+v"(acc2[3][3]));
     stamp();
     // x' = x + (acc + b_pre): the residual stream for the rest of the launch
+    if constexpr (PRE == 1) {
 #pragma unroll
-    for (int cf = 0; cf < 4; ++cf) {
-      const f32x4 bp = parv(0, cf);
+      for (int cf = 0; cf < 4; ++cf) {
+        const f32x4 bp = parv(0, cf);
 #pragma unroll
-      for (int rf = 0; rf < 4; ++rf) acc2[cf][rf] += bp;
+        for (int rf = 0; rf < 4; ++rf) acc2[cf][rf] += bp;
+      }
     }
     if constexpr (MAIN == EM_ROWS_GLU) {
       // the residual stream leaves here: nothing else of this launch touches it, and the GLU walk needs the registers.
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(NT, 1) void ffn_rows_kernel(const EmFfnRowsArgs a, 
   }
 
   if constexpr (MAIN == EM_ROWS_GLU) {
-    static_assert(PRE, "the GLU launch starts with the projection");
+    static_assert(PRE == 1, "the GLU launch starts with the projection");
     // chunk 2 j: value rows of output columns 128 j .., chunk 2 j + 1: their gate rows (host: pack_rows_glu); this lane:
     // columns 128 j + 16 wave + 4 lg + r of rows 16 rf + lr.  Nothing is stored INSIDE the walk: stores count on vmcnt like
     // the weight requests, and with every pair's outputs stored behind its gate chunk every chunk took 4.3 K cycles instead
@@ -732,7 +737,10 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   if (!a || !a->x || !a->w1p || !a->b1 || (!a->xn_out && !post_qkv)) return EM_ERR_BAD_ARG;
   if (a->main == EM_ROWS_FFN && (!a->w2p || !a->b2 || !a->g1 || !a->be1)) return EM_ERR_BAD_ARG;
   const bool pre = a->pre_in != nullptr;
-  if (pre ? (!a->pre_w || !a->pre_b || !a->pre_g || !a->pre_be) : !a->xn_in) return EM_ERR_BAD_ARG;
+  // (round 6: no projection, no xn_in, but pre_g / pre_be - the module's input is LayerNorm(x; pre_g, pre_be), computed in the launch)
+  const bool lnin = !pre && !a->xn_in && a->pre_g && a->pre_be;
+  if (pre ? (!a->pre_w || !a->pre_b || !a->pre_g || !a->pre_be) : (!a->xn_in && !lnin)) return EM_ERR_BAD_ARG;
+  if (lnin && (a->main != EM_ROWS_FFN || a->ln_mode != 2 || a->post_w)) return EM_ERR_UNSUPPORTED;
   if (a->M <= 0 || a->ff <= 0) return EM_ERR_BAD_ARG;
   if (a->d != D || a->ff % CH != 0 || a->ff < 2 * CH) return EM_ERR_UNSUPPORTED;
   if (post_qkv) {  // q | k | v walked behind a ln_mode 1 launch without a projection in front
@@ -756,16 +764,17 @@ extern "C" int em_ffn_rows_fused(const EmFfnRowsArgs* a, void* stream) {
   if (want_stamps && hipMemsetAsync(stamps, 0, 64 * sizeof(long long), (hipStream_t)stream) != hipSuccess) return EM_ERR_LAUNCH;
   long long* const st = want_stamps ? stamps : nullptr;
   typedef void (*kern_t)(const EmFfnRowsArgs, long long*);
-  static EmLdsCap caps[8] = {};
-  const int which = post_qkv ? 7 : glu ? 4 : a->post_w ? 5 + (pre ? 1 : 0) : (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
-  const kern_t kern = which == 0   ? ffn_rows_kernel<1, false, EM_ROWS_FFN>
-                      : which == 1 ? ffn_rows_kernel<1, true, EM_ROWS_FFN>
-                      : which == 2 ? ffn_rows_kernel<2, false, EM_ROWS_FFN>
-                      : which == 3 ? ffn_rows_kernel<2, true, EM_ROWS_FFN>
-                      : which == 4 ? ffn_rows_kernel<1, true, EM_ROWS_GLU>
-                      : which == 5 ? ffn_rows_kernel<2, false, EM_ROWS_FFN, 1>
-                      : which == 6 ? ffn_rows_kernel<2, true, EM_ROWS_FFN, 1>
-                                   : ffn_rows_kernel<1, false, EM_ROWS_FFN, 2>;
+  static EmLdsCap caps[9] = {};
+  const int which = lnin ? 8 : post_qkv ? 7 : glu ? 4 : a->post_w ? 5 + (pre ? 1 : 0) : (a->ln_mode - 1) * 2 + (pre ? 1 : 0);
+  const kern_t kern = which == 0   ? ffn_rows_kernel<1, 0, EM_ROWS_FFN>
+                      : which == 1 ? ffn_rows_kernel<1, 1, EM_ROWS_FFN>
+                      : which == 2 ? ffn_rows_kernel<2, 0, EM_ROWS_FFN>
+                      : which == 3 ? ffn_rows_kernel<2, 1, EM_ROWS_FFN>
+                      : which == 4 ? ffn_rows_kernel<1, 1, EM_ROWS_GLU>
+                      : which == 5 ? ffn_rows_kernel<2, 0, EM_ROWS_FFN, 1>
+                      : which == 6 ? ffn_rows_kernel<2, 1, EM_ROWS_FFN, 1>
+                      : which == 7 ? ffn_rows_kernel<1, 0, EM_ROWS_FFN, 2>
+                                   : ffn_rows_kernel<2, 2, EM_ROWS_FFN>;
   if (em_raise_lds_cap((const void*)kern, SMEM_BYTES, &caps[which]) != EM_OK) return EM_ERR_LAUNCH;
   const bool rec = em_prof_begin(stream);
   hipLaunchKernelGGL(kern, grid, dim3(NT), SMEM_BYTES, (hipStream_t)stream, *a, st);

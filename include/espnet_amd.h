@@ -508,6 +508,9 @@ typedef struct EmFfnRowsArgs {
    * encoder_layer.py:158 and norm_ff (:161) inside the launch of the second feed-forward module.
    *   pre_in [M][512] bf16;  pre_w: W_pre [512][512] as 64 x 8 operand fragments of 1 KiB,
    *   [ks 16][cf 4][w 8][lane][e 8] = W_pre[64 w + 16 cf + lr][32 ks + 8 lg + e]  (host: pack_rows_proj)          */
+  /* round 6: with pre_in, pre_w AND xn_in all NULL but pre_g / pre_be set (ln_mode 2, no walk) there is no projection and the
+   * module's input is LayerNorm(x; pre_g, pre_be) of the residual rows, computed in the launch (E-Branchformer's norm_ff in
+   * front of its second feed-forward module, e_branchformer_encoder.py:172-174): no LayerNorm launch in front.                 */
   const void* pre_in;
   const void* pre_w;
   const float *pre_b, *pre_g, *pre_be;
