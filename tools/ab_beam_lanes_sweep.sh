@@ -1,5 +1,5 @@
 set -u
-out=gpurun_out/r06al; mkdir -p $out
+out=gpurun_out/${1:-r06al}; mkdir -p $out
 pr() { python -c "
 import sys, json
 j=json.loads(sys.stdin.read()); s=j.get('search') or {}
