@@ -26,7 +26,7 @@ EmSwitches read_switches() {
   s.stream_no_ctx_fold = on("ESPNET_AMD_STREAM_NO_CTX_FOLD"); s.stream_no_ln_gemm = on("ESPNET_AMD_STREAM_NO_LN_GEMM");
   s.stream_fused_min = num("ESPNET_AMD_STREAM_FUSED_MIN", 1); s.no_sub12 = on("ESPNET_AMD_NO_SUB12");
   s.stream_ffn_split = num("ESPNET_AMD_STREAM_FFN_SPLIT", 0); s.stream_split_att = on("ESPNET_AMD_STREAM_SPLIT_ATT");
-  s.dec_ffn_split = num("ESPNET_AMD_DEC_FFN_SPLIT", 0); s.no_rows_qkv = on("ESPNET_AMD_NO_ROWS_QKV"); s.ffn_rows_min_fill = num("ESPNET_AMD_FFN_ROWS_MIN_FILL", 0);
+  s.dec_ffn_split = num("ESPNET_AMD_DEC_FFN_SPLIT", 0); s.dec_ffn_rows = num("ESPNET_AMD_DEC_FFN_ROWS", 0); s.no_rows_qkv = on("ESPNET_AMD_NO_ROWS_QKV"); s.ffn_rows_min_fill = num("ESPNET_AMD_FFN_ROWS_MIN_FILL", 0);
   return s;
 }
 std::atomic<const EmSwitches*> g_sw{nullptr};

@@ -41,7 +41,9 @@ __device__ __forceinline__ float ffn_row16_allsum(float v) {  // (ln_gemm.hip's 
 // DT: model dimension (256 | 512); HS: output columns of one workgroup (128 | 256 | 512); OUT: EM_LNF_RELU_FRAG - ReLU, bf16,
 // written FRAGMENT-MAJOR (the feed-forward's hidden activation; `ff` = its width); EM_LNF_STORE - bf16 rows [n][ff];
 // EM_LNF_STORE_F32 - f32 rows [n][ff] (the vocabulary logits).  Row-major outputs mask rows >= n and columns >= ff.
-template <int DT, int HS, int OUT>
+// FRN: 16-row fragments per workgroup (1 | 2).  Two from 320 rows on: a weight fragment then feeds two MFMAs and the launch streams
+// half the weight bytes per row (640 rows: the feed-forward's first projection 9.8 us with 16-row workgroups).
+template <int DT, int HS, int OUT, int FRN>
 __global__ __launch_bounds__(256) void ln_frag_gemm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                            const float* __restrict__ be, float eps,
                                                            const bf16* __restrict__ W1, const float* __restrict__ b1, int n,
@@ -51,11 +53,12 @@ __global__ __launch_bounds__(256) void ln_frag_gemm_kernel(const float* __restri
   // per wave NF1 fragments of 16 hidden units x NK1 k-steps, in batches of GB1 fragments = 16 loads
   constexpr int NK1 = DT / 32, NF1 = HS / 64, GB1 = (LOADS / NK1) < 1 ? 1 : (LOADS / NK1), NB1 = NF1 / GB1;
   static_assert(GB1 * NK1 == LOADS && NB1 >= 1 && NB1 * GB1 == NF1, "batches of 16 loads");
-  __shared__ __attribute__((aligned(16))) bf16 sX[FR * XP];
+  constexpr int FRT = FR * FRN;  // rows per workgroup
+  __shared__ __attribute__((aligned(16))) bf16 sX[FRT * XP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int sp = blockIdx.x, rb = blockIdx.y, r0 = rb * FR;
+  const int sp = blockIdx.x, rb = blockIdx.y, r0 = rb * FRT;
   const int h0 = sp * HS;
 
   // W1 fragment-major: the wave's stream is NF1 x NK1 consecutive KiB
@@ -79,50 +82,58 @@ __global__ __launch_bounds__(256) void ln_frag_gemm_kernel(const float* __restri
 
   // ---- LayerNorm of the 16 rows into LDS (16 lanes per row; rows past n repeat row n - 1 and are never stored)
   {
-    const int row = tid >> 4, li = tid & 15;
-    int m = r0 + row;
-    m = m < n ? m : n - 1;
-    const float4* xr = (const float4*)(x + (size_t)m * DT);
-    float4 v[NV], g4[NV], b4[NV];
+    const int li = tid & 15;
+    float4 v[FRN][NV], g4[NV], b4[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = xr[j * 16 + li];
+    for (int ps = 0; ps < FRN; ++ps) {
+      int m = r0 + ps * FR + (tid >> 4);
+      m = m < n ? m : n - 1;
+      const float4* xr = (const float4*)(x + (size_t)m * DT);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[ps][j] = xr[j * 16 + li];
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       g4[j] = *(const float4*)(g + (j * 16 + li) * 4);
       b4[j] = *(const float4*)(be + (j * 16 + li) * 4);
     }
     asm volatile("" ::: "memory");  // every request above is out before the first reduction
-    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    s = ffn_row16_allsum(s);
-    const float mean = s / (float)DT;
-    float q = 0.f;
+    for (int ps = 0; ps < FRN; ++ps) {
+      float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
-      q += (a * a + b * b) + (c * c + d * d);
-    }
-    q = ffn_row16_allsum(q);
-    const float rstd = 1.0f / sqrtf(q / (float)DT + eps);
-    bf16* dst = sX + row * XP;
+      for (int j = 0; j < NV; ++j) s += (v[ps][j].x + v[ps][j].y) + (v[ps][j].z + v[ps][j].w);
+      s = ffn_row16_allsum(s);
+      const float mean = s / (float)DT;
+      float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      bf16x4 o;
-      o[0] = (bf16)((v[j].x - mean) * rstd * g4[j].x + b4[j].x);
-      o[1] = (bf16)((v[j].y - mean) * rstd * g4[j].y + b4[j].y);
-      o[2] = (bf16)((v[j].z - mean) * rstd * g4[j].z + b4[j].z);
-      o[3] = (bf16)((v[j].w - mean) * rstd * g4[j].w + b4[j].w);
-      *(bf16x4*)(dst + (j * 16 + li) * 4) = o;
+      for (int j = 0; j < NV; ++j) {
+        const float a = v[ps][j].x - mean, b = v[ps][j].y - mean, c = v[ps][j].z - mean, d = v[ps][j].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+      q = ffn_row16_allsum(q);
+      const float rstd = 1.0f / sqrtf(q / (float)DT + eps);
+      bf16* dst = sX + (ps * FR + (tid >> 4)) * XP;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        bf16x4 o;
+        o[0] = (bf16)((v[ps][j].x - mean) * rstd * g4[j].x + b4[j].x);
+        o[1] = (bf16)((v[ps][j].y - mean) * rstd * g4[j].y + b4[j].y);
+        o[2] = (bf16)((v[ps][j].z - mean) * rstd * g4[j].z + b4[j].z);
+        o[3] = (bf16)((v[ps][j].w - mean) * rstd * g4[j].w + b4[j].w);
+        *(bf16x4*)(dst + (j * 16 + li) * 4) = o;
+      }
     }
   }
   __syncthreads();
 
   // ---- H[row][hidden] = relu(W1 . LN(x) + b1), this wave's NF1 fragments of 16 hidden units
   {
-    bf16x8 xb[NK1];  // B operand: column = row lr, k-slice lg
+    bf16x8 xb[FRN][NK1];  // B operands: column = row mi * 16 + lr, k-slice lg
 #pragma unroll
-    for (int ks = 0; ks < NK1; ++ks) xb[ks] = *(const bf16x8*)(sX + lr * XP + ks * 32 + lg * 8);
+    for (int mi = 0; mi < FRN; ++mi)
+#pragma unroll
+      for (int ks = 0; ks < NK1; ++ks) xb[mi][ks] = *(const bf16x8*)(sX + (mi * FR + lr) * XP + ks * 32 + lg * 8);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int bt = 0; bt < NB1; ++bt) {
@@ -132,39 +143,50 @@ __global__ __launch_bounds__(256) void ln_frag_gemm_kernel(const float* __restri
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int gi = 0; gi < GB1; ++gi) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};  // two chains: even / odd k-steps
+        f32x4 acc[FRN], acc1[FRN];  // two chains per row fragment: even / odd k-steps
 #pragma unroll
-        for (int ks = 0; ks < NK1; ks += 2) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[bt & 1][gi * NK1 + ks], xb[ks], acc, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[bt & 1][gi * NK1 + ks + 1], xb[ks + 1], acc1, 0, 0, 0);
-        }
-        acc += acc1;
-        // lane (lr, lg): row lr, hidden units 16 f + 4 lg .. + 3 of this share
+        for (int mi = 0; mi < FRN; ++mi) acc[mi] = acc1[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NK1; ks += 2)
+#pragma unroll
+          for (int mi = 0; mi < FRN; ++mi) {
+            acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[bt & 1][gi * NK1 + ks], xb[mi][ks], acc[mi], 0, 0, 0);
+            acc1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[bt & 1][gi * NK1 + ks + 1], xb[mi][ks + 1], acc1[mi], 0, 0, 0);
+          }
+        // lane (lr, lg): row mi * 16 + lr, output columns 16 f + 4 lg .. + 3 of this workgroup's slice
         const int f = bt * GB1 + gi;
         const float4 bb = bias1[f];
-        if constexpr (OUT == EM_LNF_RELU_FRAG) {
-          bf16x4 o;
-          o[0] = (bf16)fmaxf(acc[0] + bb.x, 0.f);
-          o[1] = (bf16)fmaxf(acc[1] + bb.y, 0.f);
-          o[2] = (bf16)fmaxf(acc[2] + bb.z, 0.f);
-          o[3] = (bf16)fmaxf(acc[3] + bb.w, 0.f);
-          // H fragment-major: hidden fragment fg is the (fg & 1) half of k-step fg >> 1 of row fragment rb; this lane's four
-          // values are elements (lg & 1) * 4 .. + 3 of operand lane ((fg & 1) * 2 + (lg >> 1)) * 16 + lr
-          const int fg = (h0 >> 4) + wave * NF1 + f;
-          *(bf16x4*)((bf16*)Hv + (((size_t)rb * (ff >> 5) + (fg >> 1)) * 64 + ((fg & 1) * 2 + (lg >> 1)) * 16 + lr) * 8 + (lg & 1) * 4) = o;
-        } else {
-          const int c0 = h0 + (wave * NF1 + f) * 16 + lg * 4;
-          if (r0 + lr < n && c0 + 3 < ff) {
-            const size_t o0 = (size_t)(r0 + lr) * ff + c0;
-            if constexpr (OUT == EM_LNF_STORE) {
-              bf16x4 o;
-              o[0] = (bf16)(acc[0] + bb.x);
-              o[1] = (bf16)(acc[1] + bb.y);
-              o[2] = (bf16)(acc[2] + bb.z);
-              o[3] = (bf16)(acc[3] + bb.w);
-              *(bf16x4*)((bf16*)Hv + o0) = o;
-            } else {
-              *(float4*)((float*)Hv + o0) = make_float4(acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+#pragma unroll
+        for (int mi = 0; mi < FRN; ++mi) {
+          const f32x4 a = acc[mi] + acc1[mi];
+          const int row = r0 + mi * FR + lr;
+          if constexpr (OUT == EM_LNF_RELU_FRAG) {
+            bf16x4 o;
+            o[0] = (bf16)fmaxf(a[0] + bb.x, 0.f);
+            o[1] = (bf16)fmaxf(a[1] + bb.y, 0.f);
+            o[2] = (bf16)fmaxf(a[2] + bb.z, 0.f);
+            o[3] = (bf16)fmaxf(a[3] + bb.w, 0.f);
+            // H fragment-major: hidden fragment fg is the (fg & 1) half of k-step fg >> 1 of row fragment rb * FRN + mi; this
+            // lane's four values are elements (lg & 1) * 4 .. + 3 of operand lane ((fg & 1) * 2 + (lg >> 1)) * 16 + lr.
+            // (a row fragment wholly past n - the second one of the last workgroup when n / 16 is odd - is not in H)
+            const int fg = (h0 >> 4) + wave * NF1 + f;
+            if (r0 + mi * FR < n)
+              *(bf16x4*)((bf16*)Hv + (((size_t)(rb * FRN + mi) * (ff >> 5) + (fg >> 1)) * 64 + ((fg & 1) * 2 + (lg >> 1)) * 16 + lr) * 8 +
+                         (lg & 1) * 4) = o;
+          } else {
+            const int c0 = h0 + (wave * NF1 + f) * 16 + lg * 4;
+            if (row < n && c0 + 3 < ff) {
+              const size_t o0 = (size_t)row * ff + c0;
+              if constexpr (OUT == EM_LNF_STORE) {
+                bf16x4 o;
+                o[0] = (bf16)(a[0] + bb.x);
+                o[1] = (bf16)(a[1] + bb.y);
+                o[2] = (bf16)(a[2] + bb.z);
+                o[3] = (bf16)(a[3] + bb.w);
+                *(bf16x4*)((bf16*)Hv + o0) = o;
+              } else {
+                *(float4*)((float*)Hv + o0) = make_float4(a[0] + bb.x, a[1] + bb.y, a[2] + bb.z, a[3] + bb.w);
+              }
             }
           }
         }
@@ -174,20 +196,22 @@ __global__ __launch_bounds__(256) void ln_frag_gemm_kernel(const float* __restri
   }
 }
 
-template <int DT, int HS, int OUT>
+template <int DT, int HS, int OUT, int FRN>
 int launch_lnf(const float* x, const float* g, const float* be, float eps, const void* w1, const float* b1, int n, int N,
                void* out, hipStream_t s) {
-  hipLaunchKernelGGL((ln_frag_gemm_kernel<DT, HS, OUT>), dim3(em_cdiv(N, HS), em_cdiv(n, FR)), dim3(256), 0, s, x, g, be, eps,
-                     (const bf16*)w1, b1, n, N, out);
+  hipLaunchKernelGGL((ln_frag_gemm_kernel<DT, HS, OUT, FRN>), dim3(em_cdiv(N, HS), em_cdiv(n, FR * FRN)), dim3(256), 0, s, x, g, be,
+                     eps, (const bf16*)w1, b1, n, N, out);
   EM_CHECK_LAUNCH();
   return EM_OK;
 }
 
 template <int OUT>
 int dispatch_lnf(const float* x, const float* g, const float* be, float eps, const void* wf, const float* bias, int n, int N,
-                 int d, int hs, void* out, hipStream_t st) {
-#define EM_LNF_CASE(DD, HH) \
-  if (d == DD && hs == HH) return launch_lnf<DD, HH, OUT>(x, g, be, eps, wf, bias, n, N, out, st)
+                 int d, int hs, int frn, void* out, hipStream_t st) {
+#define EM_LNF_CASE(DD, HH)                                                                          \
+  if (d == DD && hs == HH)                                                                           \
+  return frn == 2 ? launch_lnf<DD, HH, OUT, 2>(x, g, be, eps, wf, bias, n, N, out, st)               \
+                  : launch_lnf<DD, HH, OUT, 1>(x, g, be, eps, wf, bias, n, N, out, st)
   EM_LNF_CASE(512, 512);
   EM_LNF_CASE(512, 256);
   EM_LNF_CASE(512, 128);
@@ -198,11 +222,17 @@ int dispatch_lnf(const float* x, const float* g, const float* be, float eps, con
   return EM_ERR_UNSUPPORTED;
 }
 
+// rows per workgroup (16 | 32: two row fragments from 320 rows on; ESPNET_AMD_DEC_FFN_ROWS=16 | 32: developer switch)
+int lnf_row_frags(int n) {
+  const int forced = em_sw().dec_ffn_rows;
+  if (forced == 16 || forced == 32) return forced / 16;
+  return n >= 320 ? 2 : 1;
+}
 // output columns per workgroup: ~160 workgroups per launch (fewer columns for fewer rows), 128 at least
 int lnf_columns(int n, int N) {
   const int forced = em_sw().dec_ffn_split;  // ESPNET_AMD_DEC_FFN_SPLIT: 0 automatic, 1 off, 128 | 256 | 512 forced
   if (forced == 128 || forced == 256 || forced == 512) return forced;
-  const int rbs = em_cdiv(n, FR);
+  const int rbs = em_cdiv(n, FR * lnf_row_frags(n));
   int hs = 512;
   while (hs > 128 && rbs * em_cdiv(N, hs) < 160) hs >>= 1;
   return hs;
@@ -219,14 +249,14 @@ extern "C" int em_ln_gemm_frag(int out_mode, const float* x, const float* ln_g, 
   if (!x || !ln_g || !ln_b || !wf || !bias || !out || n <= 0 || N <= 0) return EM_ERR_BAD_ARG;
   if ((d != 256 && d != 512) || N % 4 != 0) return EM_ERR_UNSUPPORTED;
   if (em_sw().dec_ffn_split == 1) return EM_ERR_UNSUPPORTED;
-  const int hs = lnf_columns(n, N);
+  const int hs = lnf_columns(n, N), frn = lnf_row_frags(n);
   hipStream_t st = (hipStream_t)stream;
   switch (out_mode) {
     case EM_LNF_RELU_FRAG:
       if (n % FR != 0 || N % hs != 0) return EM_ERR_UNSUPPORTED;
-      return dispatch_lnf<EM_LNF_RELU_FRAG>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, out, st);
-    case EM_LNF_STORE: return dispatch_lnf<EM_LNF_STORE>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, out, st);
-    case EM_LNF_STORE_F32: return dispatch_lnf<EM_LNF_STORE_F32>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, out, st);
+      return dispatch_lnf<EM_LNF_RELU_FRAG>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, frn, out, st);
+    case EM_LNF_STORE: return dispatch_lnf<EM_LNF_STORE>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, frn, out, st);
+    case EM_LNF_STORE_F32: return dispatch_lnf<EM_LNF_STORE_F32>(x, ln_g, ln_b, eps, wf, bias, n, N, d, hs, frn, out, st);
   }
   return EM_ERR_BAD_ARG;
 }

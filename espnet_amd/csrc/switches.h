@@ -24,6 +24,7 @@ struct EmSwitches {
   int stream_ffn_split;                                              // ESPNET_AMD_STREAM_FFN_SPLIT (0: automatic; 1: off; n: forced)
   bool no_sub12;                                                     // ESPNET_AMD_NO_SUB12
   int ffn_rows_min_fill;                                             // ESPNET_AMD_FFN_ROWS_MIN_FILL (percent of the CUs a round of 64-row workgroups must fill; 0 = automatic: 72 / batches in flight)
+  int dec_ffn_rows;                                                  // ESPNET_AMD_DEC_FFN_ROWS (16 | 32 rows per workgroup of ln_frag_gemm_kernel; 0: automatic, 32 from 320 rows)
   int dec_ffn_split;                                                 // ESPNET_AMD_DEC_FFN_SPLIT (0: automatic; 1: off - LayerNorm + two projections; n: forced)
 };
 

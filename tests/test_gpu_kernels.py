@@ -476,13 +476,14 @@ def test_ln_gemm_small_m(lib, prec, M, N, K):
 
 @pytest.mark.parametrize("n,d,ff,hs", [(640, 512, 2048, 0), (160, 512, 2048, 0), (160, 512, 2048, 256), (320, 512, 2048, 512),
                                        (144, 256, 2048, 0), (640, 256, 2048, 512), (96, 256, 1024, 128), (32, 512, 2048, 128),
-                                       (16, 512, 2048, 0)])
+                                       (16, 512, 2048, 0), (336, 512, 2048, 0), (336, 256, 1024, 256)])
 def test_dec_ffn_fragment_major(lib, n, d, ff, hs):
     """em_dec_ffn (norm3 + feed_forward + residual of a decoder label step on fragment-major operands: LayerNorm in the
     prologue of the first projection, which writes the hidden activation fragment-major; mid_gemm on 1 KiB operand loads):
     against torch fp32 on bf16-rounded operands with the hidden activation rounded to bf16, against the three-launch form on
     the row-major matrices (em_layernorm + em_gemm x 2: the same LayerNorm bits, another summation order), bit-repeatable;
-    hs forces the hidden units per workgroup of the first launch (developer switch)."""
+    hs forces the hidden units per workgroup of the first launch (developer switch).  From 320 rows a workgroup owns TWO row
+    fragments (n = 336: 21 fragments - the last workgroup's second one is past the end and must not be written)."""
     import os
     x = rnd(n, d, seed=71) * 2 + 0.3
     g, be = 1 + 0.1 * rnd(d, seed=72), 0.1 * rnd(d, seed=73)
@@ -498,7 +499,7 @@ def test_dec_ffn_fragment_major(lib, n, d, ff, hs):
         os.environ["ESPNET_AMD_DEC_FFN_SPLIT"] = str(hs)
         lib.em_dev_switches_reload()
     try:
-        assert lib.em_dec_ffn_split(n, d, ff) == (hs or {640: 512, 160: 128, 144: 128, 16: 128}[n])
+        assert lib.em_dec_ffn_split(n, d, ff) == (hs or {640: 256, 160: 128, 144: 128, 16: 128, 336: 128}[n])  # (from 320 rows 32-row workgroups: 640 rows = 20 row blocks)
         outs = []
         for _ in range(3):
             xd = dev(x.clone())
@@ -534,7 +535,7 @@ def test_dec_ffn_fragment_major(lib, n, d, ff, hs):
 
 
 @pytest.mark.parametrize("n,N,d", [(640, 1536, 512), (160, 1536, 512), (160, 5000, 512), (640, 5000, 512), (150, 768, 256),
-                                   (97, 5000, 256), (3, 260, 512)])
+                                   (97, 5000, 256), (3, 260, 512), (333, 1536, 512), (321, 5000, 256)])
 def test_ln_gemm_frag_rows(lib, n, N, d):
     """em_ln_gemm_frag with row-major outputs (the label step's norm1 + q|k|v projection and after_norm + output_layer on a
     fragment-major weight whose rows are zero-padded to 512): against torch fp32 on the bf16-rounded LayerNorm output and
