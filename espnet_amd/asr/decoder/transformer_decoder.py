@@ -148,6 +148,7 @@ class TransformerDecoder(torch.nn.Module, BatchScorerInterface):
                                                                   sa.linear_v.weight], 0).detach(), pad_rows=512))
                 lt["self_wout_frag"] = A(L.pack_frag16(sa.linear_out.weight.detach()))
                 lt["src_wout_frag"] = A(L.pack_frag16(ca.linear_out.weight.detach()))
+                lt["src_wq_frag"] = A(L.pack_frag16(ca.linear_q.weight.detach()))
             for k, v in lt.items():
                 setattr(layers[i], k, v.data_ptr())
         w.layers = C.cast(layers, C.POINTER(L.EmDecoderLayer))

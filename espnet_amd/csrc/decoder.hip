@@ -302,6 +302,7 @@ struct SrcLnQ {
   const float *x, *g, *be, *bq;
   const void* wq;
   float eps;
+  int wq_frag;  // round 6: wq is FRAGMENT-MAJOR (espnet_amd.lib.pack_frag16): the wave's 16 x K operand rows are K / 32 contiguous KiB
 };
 template <typename T, int DK, int NVQ>
 __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__ qs,
@@ -362,10 +363,13 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
     T* const sA = (T*)(smem_raw + (size_t)16 * LDS_S * 4 + 64 + (size_t)16 * LDS_P * sizeof(T));  // behind S, sums, P
     T* const sQ = sA + 16 * LDA;
     // W_q rows of this wave's 16 query columns: requested before anything of the LayerNorm
-    const T* wrow = (const T*)lq.wq + (size_t)(h * DK + wave * 16 + lr) * K + lg * M::EPL;
+    // (row-major: 16 rows x 64 bytes per wave-wide load; fragment-major: one contiguous KiB - the same values either way)
+    const T* wrow = lq.wq_frag ? (const T*)lq.wq + ((size_t)(h * (DK / 16) + wave) * NST * 64 + lane) * M::EPL
+                               : (const T*)lq.wq + (size_t)(h * DK + wave * 16 + lr) * K + lg * M::EPL;
+    const size_t wstep = lq.wq_frag ? (size_t)64 * M::EPL : (size_t)M::K;
     typename M::frag fw[NST];
 #pragma unroll
-    for (int u = 0; u < NST; ++u) fw[u] = M::load(wrow + (size_t)u * M::K);
+    for (int u = 0; u < NST; ++u) fw[u] = M::load(wrow + (size_t)u * wstep);
     const float bv = lq.bq[h * DK + wave * 16 + lr];
     {
       const int grp = lane >> 4, li = lane & 15;
@@ -1027,7 +1031,20 @@ extern "C" int em_dec_src_attention_lnq(int dtype, const float* x, const float* 
   if (!x || !g || !be || !wq || !bq || !kmem || !vT || !klens || !ctx) return EM_ERR_BAD_ARG;
   if (B <= 0 || W <= 0 || T <= 0 || Tpad < T || Tpad % 32 != 0 || heads <= 0) return EM_ERR_BAD_ARG;
   if (dtype != EM_BF16) return EM_ERR_UNSUPPORTED;  // (the f32 parity mode keeps ln_gemm + em_dec_src_attention)
-  const SrcLnQ lq = {x, g, be, bq, wq, eps};
+  const SrcLnQ lq = {x, g, be, bq, wq, eps, 0};
+  return src_attn_launch<bf16>(nullptr, kmem, ldk, vT, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream, &lq);
+}
+
+// ... with wq FRAGMENT-MAJOR (round 6; EmDecoderLayer.src_wq_frag): the same arithmetic in the same order - bit for bit the
+// context of em_dec_src_attention_lnq - with the query projection's operand rows read as contiguous KiB.
+extern "C" int em_dec_src_attention_lnq_frag(int dtype, const float* x, const float* g, const float* be, float eps,
+                                             const void* wq_frag, const float* bq, const void* kmem, int32_t ldk, const void* vT,
+                                             const int32_t* klens, int32_t B, int32_t W, int32_t d, int32_t heads, int32_t T,
+                                             int32_t Tpad, void* ctx, void* stream) {
+  if (!x || !g || !be || !wq_frag || !bq || !kmem || !vT || !klens || !ctx) return EM_ERR_BAD_ARG;
+  if (B <= 0 || W <= 0 || T <= 0 || Tpad < T || Tpad % 32 != 0 || heads <= 0) return EM_ERR_BAD_ARG;
+  if (dtype != EM_BF16) return EM_ERR_UNSUPPORTED;
+  const SrcLnQ lq = {x, g, be, bq, wq_frag, eps, 1};
   return src_attn_launch<bf16>(nullptr, kmem, ldk, vT, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream, &lq);
 }
 

@@ -1382,8 +1382,12 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
     // memories - Tpad > 1 472 at d = 512, > 1 568 at d = 256 - fit only the two-launch form)
     const size_t lnq_lds = (size_t)16 * (a.Tpad + 4) * 4 + 64 + (size_t)16 * (a.Tpad + 8) * 2 + (size_t)16 * (d + 8) * 2 + 16 * (64 + 8) * 2;
     if (dtype == EM_BF16 && !no_lnq && d == 64 * h && (d == 256 || d == 512) && lnq_lds <= 160 * 1024) {
-      EM_TRY(em_dec_src_attention_lnq(dtype, a.x, q.norm2_g, q.norm2_b, LN_EPS, q.src_wq, q.src_bq, kv, 2 * d, vT, a.xlens,
-                                      a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
+      if (frag && q.src_wq_frag)
+        EM_TRY(em_dec_src_attention_lnq_frag(dtype, a.x, q.norm2_g, q.norm2_b, LN_EPS, q.src_wq_frag, q.src_bq, kv, 2 * d, vT, a.xlens,
+                                             a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
+      else
+        EM_TRY(em_dec_src_attention_lnq(dtype, a.x, q.norm2_g, q.norm2_b, LN_EPS, q.src_wq, q.src_bq, kv, 2 * d, vT, a.xlens,
+                                        a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
     } else {
       EM_TRY(ln_proj(dtype, EM_EPI_STORE, a.x, q.norm2_g, q.norm2_b, q.src_wq, q.src_bq, a.qs, a.xn, n, d, d,
                      stream));

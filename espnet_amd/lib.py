@@ -143,7 +143,7 @@ class EmWavInfo(C.Structure):
 _DEC_LAYER_PTRS = ["norm1_g", "norm1_b", "norm2_g", "norm2_b", "norm3_g", "norm3_b", "self_wqkv",
                    "self_bqkv", "self_wout", "self_bout", "src_wq", "src_bq", "src_wkv", "src_bkv",
                    "src_wout", "src_bout", "w1", "b1", "w2", "b2", "w1_frag", "w2_frag", "self_wqkv_frag",
-                   "self_wout_frag", "src_wout_frag"]
+                   "self_wout_frag", "src_wout_frag", "src_wq_frag"]
 
 
 def pack_frag16(w, pad_rows=16):
@@ -300,6 +300,8 @@ _SIGNATURES = {
     "em_dec_src_attention": (C.c_int, [C.c_int, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                                        _i32, _i32, _vp, _vp]),
     "em_dec_src_attention_lnq": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32,
+                                          _i32, _i32, _i32, _vp, _vp]),
+    "em_dec_src_attention_lnq_frag": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32,
                                           _i32, _i32, _i32, _vp, _vp]),
     "em_dec_transpose_v": (C.c_int, [C.c_int, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "em_search_init": (C.c_int, [C.c_int, C.POINTER(EmSearchParams), C.POINTER(EmDecoderWeights),

@@ -713,6 +713,11 @@ int em_dec_ffn_split(int32_t n, int32_t d, int32_t ff);
 #define EM_LNF_STORE_F32 2
 int em_ln_gemm_frag(int out_mode, const float* x, const float* ln_g, const float* ln_b, float eps, const void* wf,
                     const float* bias, void* out, int32_t n, int32_t N, int32_t d, void* stream);
+/*   ... the same with wq FRAGMENT-MAJOR (espnet_amd.lib.pack_frag16; EmDecoderLayer.src_wq_frag): bit for bit the same context */
+int em_dec_src_attention_lnq_frag(int dtype, const float* x, const float* g, const float* be, float eps, const void* wq_frag,
+                                  const float* bq, const void* kmem, int32_t ldk, const void* vT, const int32_t* klens,
+                                  int32_t B, int32_t W, int32_t d, int32_t heads, int32_t T, int32_t Tpad, void* ctx,
+                                  void* stream);
 /*   vT[b][c][t] = kv[(b*T + t)*2d + d + c]                                                       */
 int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t T, int32_t d, int32_t Tpad,
                        void* vT, void* stream);
@@ -737,6 +742,7 @@ typedef struct EmDecoderLayer {
    * loads, or NULL (then the row-major matrix above is used): w1 / w2 (em_dec_ffn), self_wqkv (em_ln_gemm_frag, rows
    * padded to a multiple of 512), self_wout / src_wout (mid_gemm with a fragment-major W)                            */
   const void *w1_frag, *w2_frag, *self_wqkv_frag, *self_wout_frag, *src_wout_frag;
+  const void* src_wq_frag; /* src_wq fragment-major (em_dec_src_attention_lnq_frag), or NULL */
 } EmDecoderLayer;
 
 typedef struct EmDecoderWeights {

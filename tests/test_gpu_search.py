@@ -636,6 +636,13 @@ def test_dec_src_attention_lnq_equals_two_launches(lib, heads, d, W):
                                          2 * d, L.ptr(vT), L.ptr(kl), B, W, d, heads, T, Tpad, L.ptr(got), None), "src_attn_lnq")
     torch.cuda.synchronize()
     assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    # round 6: the same launch reading linear_q from its FRAGMENT-MAJOR copy (em_dec_src_attention_lnq_frag): the same bits
+    got2 = torch.full((n, d), 7.0, dtype=dt, device="cuda")
+    wqf = L.pack_frag16(wq)
+    L.check(lib.em_dec_src_attention_lnq_frag(L.EM_BF16, L.ptr(x), L.ptr(g), L.ptr(be), 1e-12, L.ptr(wqf), L.ptr(bq), L.ptr(kv),
+                                              2 * d, L.ptr(vT), L.ptr(kl), B, W, d, heads, T, Tpad, L.ptr(got2), None), "src_attn_lnq_frag")
+    torch.cuda.synchronize()
+    assert torch.equal(got2, ref), (got2.float() - ref.float()).abs().max().item()
     with pytest.raises(NotImplementedError):
         L.check(lib.em_dec_src_attention_lnq(L.EM_F32, L.ptr(x), L.ptr(g), L.ptr(be), 1e-12, L.ptr(wq), L.ptr(bq), L.ptr(kv),
                                              2 * d, L.ptr(vT), L.ptr(kl), B, W, d, heads, T, Tpad, L.ptr(got), None), "f32")
