@@ -303,6 +303,10 @@ struct SrcLnQ {
   const void* wq;
   float eps;
   int wq_frag;  // round 6: wq is FRAGMENT-MAJOR (espnet_amd.lib.pack_frag16): the wave's 16 x K operand rows are K / 32 contiguous KiB
+  // round 6: the memory's K and V^T FRAGMENT-MAJOR (dec_pack_mem_frag_kernel below; both or neither): every operand load of the
+  // kernel is then one contiguous KiB.  kf [B][heads][Tpad / 16][DK / 32][lane][8], vf [B][heads][DK / 16][Tpad / 32][lane][8],
+  // zero for keys >= T.
+  const void *kf, *vf;
 };
 template <typename T, int DK, int NVQ>
 __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__ qs,
@@ -340,20 +344,27 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = M::load(qrow + ks * M::K + lg * M::EPL);
   }
-  const T* kb = kmem + (size_t)b * Tn * ldk + h * DK;
-  const T* vb = vT + ((size_t)b * d + h * DK + (pv_wave ? wave : 0) * 16 + lr) * Tpad;
+  const bool mfrag = lq.kf != nullptr;  // (uniform) fragment-major memory: one contiguous KiB per operand load
+  const int H = gridDim.x;
+  const T* kb = mfrag ? (const T*)lq.kf + ((size_t)(b * H + h) * ntile * KS * 64 + lane) * M::EPL : kmem + (size_t)b * Tn * ldk + h * DK;
+  const T* vb = mfrag ? (const T*)lq.vf + (((size_t)(b * H + h) * (DK / 16) + (pv_wave ? wave : 0)) * nkk * 64 + lane) * M::EPL
+                      : vT + ((size_t)b * d + h * DK + (pv_wave ? wave : 0) * 16 + lr) * Tpad + lg * M::EPL;
+  const size_t vstep = mfrag ? (size_t)64 * M::EPL : (size_t)M::K;  // elements between consecutive 32-key fragments of V^T
   // the first batch of V^T fragments: requested before the scores exist
   typename M::frag vf[UV];
 #pragma unroll
-  for (int u = 0; u < UV; ++u) vf[u] = M::load(vb + (u < nkk ? u : nkk - 1) * M::K + lg * M::EPL);
+  for (int u = 0; u < UV; ++u) vf[u] = M::load(vb + (size_t)(u < nkk ? u : nkk - 1) * vstep);
   typename M::frag kf[UT][KS];
-  auto load_k = [&](int nt0) {  // unconditional, from clamped rows (tiles past the end are computed and dropped)
+  auto load_k = [&](int nt0) {  // unconditional, from clamped rows / tiles (tiles past the end are computed and dropped)
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
-      const int key = (nt0 + wave + 4 * u) * 16 + lr;
+      const int nt = nt0 + wave + 4 * u;
+      const int key = nt * 16 + lr;
       const int kc_ = key < Tn ? key : Tn - 1;
+      const int tl = nt < ntile ? nt : ntile - 1;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[u][ks] = M::load(kb + (size_t)kc_ * ldk + ks * M::K + lg * M::EPL);
+      for (int ks = 0; ks < KS; ++ks)
+        kf[u][ks] = M::load(mfrag ? kb + (size_t)(tl * KS + ks) * 64 * M::EPL : kb + (size_t)kc_ * ldk + ks * M::K + lg * M::EPL);
     }
   };
   if constexpr (NVQ > 0) load_k(0);  // the first key tiles do not depend on the queries: under the LayerNorm + projection
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
     for (int kk0 = 0; kk0 < nkk; kk0 += UV) {
       if (kk0 > 0) {
 #pragma unroll
-        for (int u = 0; u < UV; ++u) vf[u] = M::load(vb + (kk0 + u < nkk ? kk0 + u : nkk - 1) * M::K + lg * M::EPL);
+        for (int u = 0; u < UV; ++u) vf[u] = M::load(vb + (size_t)(kk0 + u < nkk ? kk0 + u : nkk - 1) * vstep);
       }
 #pragma unroll
       for (int u = 0; u < UV; ++u) {
@@ -480,6 +491,48 @@ __global__ __launch_bounds__(256) void dec_src_attn_kernel(const T* __restrict__
       if (rr < nrows)
         ctx[(size_t)(row0 + rr) * d + h * DK + wave * 16 + lr] = from_f32<T>(acc[r] / sums[rr]);
     }
+  }
+}
+
+// Round 6: the source-attention memory FRAGMENT-MAJOR (one thread per 16-byte chunk of either output).
+//   kf[b][h][tile][ks][lane = lg * 16 + lr][e] = K[b * T + 16 tile + lr][h DK + 32 ks + 8 lg + e]      (K = kv columns 0 .. d - 1)
+//   vf[b][h][df][kk][lane = lg * 16 + lr][e]   = V[b * T + 32 kk + 8 lg + e][h DK + 16 df + lr]        (V = kv columns d .. 2 d - 1)
+// zero for keys >= T.  Tpad % 32 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void dec_pack_mem_frag_kernel(const T* __restrict__ kv, int B, int Tn, int Tpad, int d, int H,
+                                                                T* __restrict__ kf, T* __restrict__ vf) {
+  const int DK = d / H;
+  const size_t nchunk = (size_t)B * d * Tpad / 8;  // 16-byte chunks of one output
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= 2 * nchunk) return;
+  const bool is_v = id >= nchunk;
+  size_t c = is_v ? id - nchunk : id;
+  const int lane = (int)(c & 63), lr = lane & 15, lg = lane >> 4;
+  c >>= 6;
+  typedef __attribute__((ext_vector_type(8))) T vec8;
+  vec8 out;
+  if (!is_v) {
+    const int KS = DK / 32, ntile = Tpad / 16;
+    const int ks = (int)(c % KS); c /= KS;
+    const int tile = (int)(c % ntile); c /= ntile;
+    const int h = (int)(c % H), b = (int)(c / H);
+    const int key = tile * 16 + lr;
+    const T* src = kv + ((size_t)b * Tn + (key < Tn ? key : 0)) * 2 * d + h * DK + ks * 32 + lg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = key < Tn ? src[e] : (T)0.f;
+    *(vec8*)(kf + id * 8) = out;
+  } else {
+    const int nkk = Tpad / 32, DF = DK / 16;
+    const int kk = (int)(c % nkk); c /= nkk;
+    const int df = (int)(c % DF); c /= DF;
+    const int h = (int)(c % H), b = (int)(c / H);
+    const int col = d + h * DK + df * 16 + lr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = kk * 32 + lg * 8 + e;
+      out[e] = key < Tn ? kv[((size_t)b * Tn + key) * 2 * d + col] : (T)0.f;
+    }
+    *(vec8*)(vf + (id - nchunk) * 8) = out;
   }
 }
 
@@ -1031,7 +1084,7 @@ extern "C" int em_dec_src_attention_lnq(int dtype, const float* x, const float* 
   if (!x || !g || !be || !wq || !bq || !kmem || !vT || !klens || !ctx) return EM_ERR_BAD_ARG;
   if (B <= 0 || W <= 0 || T <= 0 || Tpad < T || Tpad % 32 != 0 || heads <= 0) return EM_ERR_BAD_ARG;
   if (dtype != EM_BF16) return EM_ERR_UNSUPPORTED;  // (the f32 parity mode keeps ln_gemm + em_dec_src_attention)
-  const SrcLnQ lq = {x, g, be, bq, wq, eps, 0};
+  const SrcLnQ lq = {x, g, be, bq, wq, eps, 0, nullptr, nullptr};
   return src_attn_launch<bf16>(nullptr, kmem, ldk, vT, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream, &lq);
 }
 
@@ -1044,8 +1097,29 @@ extern "C" int em_dec_src_attention_lnq_frag(int dtype, const float* x, const fl
   if (!x || !g || !be || !wq_frag || !bq || !kmem || !vT || !klens || !ctx) return EM_ERR_BAD_ARG;
   if (B <= 0 || W <= 0 || T <= 0 || Tpad < T || Tpad % 32 != 0 || heads <= 0) return EM_ERR_BAD_ARG;
   if (dtype != EM_BF16) return EM_ERR_UNSUPPORTED;
-  const SrcLnQ lq = {x, g, be, bq, wq_frag, eps, 1};
+  const SrcLnQ lq = {x, g, be, bq, wq_frag, eps, 1, nullptr, nullptr};
   return src_attn_launch<bf16>(nullptr, kmem, ldk, vT, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream, &lq);
+}
+
+// csrc/search.hip (em_common.h): the memory of one decoder layer fragment-major, and the source attention of a label step on
+// it (bf16, d_k = 64, d = 256 | 512; wq fragment-major as well).  The same arithmetic in the same order as
+// em_dec_src_attention_lnq: bit for bit its context.
+int em_dec_pack_memory_frag_bf16(const void* kv, int B, int T, int Tpad, int d, int heads, void* kf, void* vf, void* stream) {
+  if (!kv || !kf || !vf || B <= 0 || T <= 0 || Tpad < T || Tpad % 32 != 0 || heads <= 0 || d % heads != 0 || (d / heads) % 32 != 0)
+    return EM_ERR_BAD_ARG;
+  const size_t nchunk = (size_t)B * d * Tpad / 8;
+  hipLaunchKernelGGL(dec_pack_mem_frag_kernel<bf16>, dim3((unsigned)((2 * nchunk + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)kv, B, T, Tpad, d, heads, (bf16*)kf, (bf16*)vf);
+  EM_CHECK_LAUNCH();
+  return EM_OK;
+}
+int em_dec_src_attention_lnq_memfrag_bf16(const float* x, const float* g, const float* be, float eps, const void* wq_frag,
+                                          const float* bq, const void* kf, const void* vf, const int32_t* klens, int B, int W, int d,
+                                          int heads, int T, int Tpad, void* ctx, void* stream) {
+  if (!x || !g || !be || !wq_frag || !bq || !kf || !vf || !klens || !ctx) return EM_ERR_BAD_ARG;
+  if (B <= 0 || W <= 0 || T <= 0 || Tpad < T || Tpad % 32 != 0 || heads <= 0) return EM_ERR_BAD_ARG;
+  const SrcLnQ lq = {x, g, be, bq, wq_frag, eps, 1, kf, vf};
+  return src_attn_launch<bf16>(nullptr, nullptr, 0, nullptr, klens, B, W, d, heads, T, Tpad, ctx, (hipStream_t)stream, &lq);
 }
 
 extern "C" int em_dec_transpose_v(int dtype, const void* kv, int32_t B, int32_t T, int32_t d,

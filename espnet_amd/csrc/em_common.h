@@ -188,6 +188,14 @@ void em_prof_end(void* stream, double flops, int tag);
 // the encoder call's flags (EM_ENC_IN_FLIGHT: launches of other streams run beside a half-filled one)
 bool em_rows_fill_ok(long M, int flags);
 
+// csrc/decoder.hip (round 6): the source-attention memory of one decoder layer fragment-major (kv [B*T][2d] = K | V rows ->
+// kf [B][heads][Tpad/16][dk/32][64][8], vf [B][heads][dk/16][Tpad/32][64][8], zero for keys >= T), and the label step's source
+// attention (norm2 + query projection in its prologue, wq fragment-major) reading it: bit for bit em_dec_src_attention_lnq
+int em_dec_pack_memory_frag_bf16(const void* kv, int B, int T, int Tpad, int d, int heads, void* kf, void* vf, void* stream);
+int em_dec_src_attention_lnq_memfrag_bf16(const float* x, const float* g, const float* be, float eps, const void* wq_frag,
+                                          const float* bq, const void* kf, const void* vf, const int32_t* klens, int B, int W, int d,
+                                          int heads, int T, int Tpad, void* ctx, void* stream);
+
 // csrc/gemm_mid.hip: mid_gemm on fragment-major bf16 operands (EM_EPI_RESID_F32; frag 1: A and W, 2: W only)
 int em_gemm_mid_frag(int epilogue, int frag, const EmGemmArgs* p, void* stream);
 

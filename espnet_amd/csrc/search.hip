@@ -1274,6 +1274,12 @@ int project_memory(int dtype, const EmSearchParams* p, const EmDecoderWeights* d
     EM_TRY(gemm(dtype, EM_EPI_STORE, enc_act, dw->layers[l].src_wkv, kv, dw->layers[l].src_bkv,
                 p->B * p->T, 2 * d, d, d, 2 * d, 1.f, stream));
     EM_TRY(em_dec_transpose_v(dtype, kv, p->B, p->T, d, p->Tpad, vT, stream));
+    // round 6: ... and fragment-major where the caller provides the buffers (bf16, d_k = 64; the label step's source attention)
+    if (dtype == EM_BF16 && b->mem_kf && b->mem_vf && d == 64 * dw->heads) {
+      const size_t per = (size_t)p->B * d * p->Tpad * es;
+      EM_TRY(em_dec_pack_memory_frag_bf16(kv, p->B, p->T, p->Tpad, d, dw->heads, (unsigned char*)b->mem_kf + l * per,
+                                          (unsigned char*)b->mem_vf + l * per, stream));
+    }
   }
   return EM_OK;
 }
@@ -1330,6 +1336,7 @@ struct DecStep {
   float* x;
   void *xn, *qkv, *qs, *ctx, *hbuf;
   float* logits;
+  const void *mem_kf = nullptr, *mem_vf = nullptr;  // the memory fragment-major (EmSearchBuffers.mem_kf / mem_vf), or NULL
 };
 
 int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* stream) {
@@ -1382,7 +1389,12 @@ int decoder_step(int dtype, const EmDecoderWeights* dw, const DecStep& a, void* 
     // memories - Tpad > 1 472 at d = 512, > 1 568 at d = 256 - fit only the two-launch form)
     const size_t lnq_lds = (size_t)16 * (a.Tpad + 4) * 4 + 64 + (size_t)16 * (a.Tpad + 8) * 2 + (size_t)16 * (d + 8) * 2 + 16 * (64 + 8) * 2;
     if (dtype == EM_BF16 && !no_lnq && d == 64 * h && (d == 256 || d == 512) && lnq_lds <= 160 * 1024) {
-      if (frag && q.src_wq_frag)
+      if (frag && q.src_wq_frag && a.mem_kf && a.mem_vf) {
+        const size_t per = (size_t)a.B * d * a.Tpad * es;
+        EM_TRY(em_dec_src_attention_lnq_memfrag_bf16(a.x, q.norm2_g, q.norm2_b, LN_EPS, q.src_wq_frag, q.src_bq,
+                                                     (const unsigned char*)a.mem_kf + l * per, (const unsigned char*)a.mem_vf + l * per,
+                                                     a.xlens, a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
+      } else if (frag && q.src_wq_frag)
         EM_TRY(em_dec_src_attention_lnq_frag(dtype, a.x, q.norm2_g, q.norm2_b, LN_EPS, q.src_wq_frag, q.src_bq, kv, 2 * d, vT, a.xlens,
                                              a.B, a.W, d, h, a.T, a.Tpad, a.ctx, stream));
       else
@@ -1424,7 +1436,7 @@ int search_core(int dtype, const EmSearchParams* p, const EmDecoderWeights* dw, 
   const size_t es = dtype == EM_BF16 ? 2 : 4;
   if (p->w_dec != 0.f) {
     DecStep a{p->B, p->W, p->T, p->Tpad, p->Lmax, i, b->step, b->tok, b->anc_a, b->anc_b, b->xlens, b->self_k,
-              b->self_v, b->mem_kv, b->mem_vT, b->x, b->xn, b->qkv, b->qs, b->ctx, b->hbuf, b->dec_logp};
+              b->self_v, b->mem_kv, b->mem_vT, b->x, b->xn, b->qkv, b->qs, b->ctx, b->hbuf, b->dec_logp, b->mem_kf, b->mem_vf};
     EM_TRY(decoder_step(dtype, dw, a, stream));
   }
   if (p->w_lm != 0.f) EM_TRY(lm_step(dtype, p, b, i, stream));

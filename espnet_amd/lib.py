@@ -215,7 +215,7 @@ SEARCH_BUFFERS = ["xlens", "maxlens", "minlens", "ctc_lpT", "tok", "parent", "an
                   "ctx", "hbuf", "dec_logp", "self_k", "self_v", "mem_kv", "mem_vT",
                   "lm", "lm_e", "lm_xn", "lm_qkv", "lm_ctx", "lm_h", "lm_x", "lm_logp", "lm_k", "lm_v",
                   "run_slm", "end_slm", "rnn_hs", "rnn_cs", "rnn_hin", "rnn_gates",
-                  "online_best", "online_psi", "online_snap"]
+                  "online_best", "online_psi", "online_snap", "mem_kf", "mem_vf"]
 
 
 class EmSearchBuffers(C.Structure):

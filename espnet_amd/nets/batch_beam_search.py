@@ -27,7 +27,7 @@ logger = logging.getLogger(__name__)
 
 _I32 = {"xlens", "maxlens", "minlens", "tok", "parent", "anc_a", "anc_b", "alive", "cand_tok",
         "sel_idx", "end_count", "end_pos", "end_slot", "end_forced", "done", "step"}
-_ACT = {"xn", "qkv", "qs", "ctx", "hbuf", "self_k", "self_v", "mem_kv", "mem_vT", "lm_e", "lm_xn",
+_ACT = {"xn", "qkv", "qs", "ctx", "hbuf", "self_k", "self_v", "mem_kv", "mem_vT", "mem_kf", "mem_vf", "lm_e", "lm_xn",
         "lm_qkv", "lm_ctx", "lm_h", "lm_k", "lm_v", "rnn_hs", "rnn_hin"}
 _ZERO = {"mem_vT", "rnn_hs", "rnn_cs", "rnn_hin"}  # pad columns / tails that must read as zero
 
@@ -120,6 +120,11 @@ class BatchBeamSearch(BeamSearch):
             shapes.update(x=(n, d), xn=(n, d), qkv=(n, 3 * d), qs=(n, d), ctx=(n, d), hbuf=(n, ff),
                           dec_logp=(n, V), self_k=(nl, Lmax, n, d), self_v=(nl, Lmax, n, d),
                           mem_kv=(nl, B * T, 2 * d), mem_vT=(nl, B, d, Tpad))
+            if (act == torch.bfloat16 and not online and d % 64 == 0 and n >= 96
+                    and os.environ.get("ESPNET_AMD_NO_MEM_FRAG") != "1"):
+                # round 6: the memory's K / V^T fragment-major as well (EmSearchBuffers.mem_kf / mem_vf): 1 KiB operand loads in the
+                # source attention of a label step.  ESPNET_AMD_NO_MEM_FRAG=1: developer A/B switch (read at allocation).
+                shapes.update(mem_kf=(nl, B, d, Tpad), mem_vf=(nl, B, d, Tpad))
         if lm is not None:
             shapes.update(lm.search_buffers(n, V, Lmax, B, cap))
         if online:  # em_search_online_* (batch_beam_search_online.py)

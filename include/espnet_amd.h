@@ -873,6 +873,11 @@ typedef struct EmSearchBuffers {
   float *online_best;                       /* [n][8] valid, parent slot, token, total, dec, ctc, len, lm */
   float *online_psi;                        /* [n] log psi of the selected candidates (next s_prev) */
   float *online_snap;                       /* [n][8] per-row scalars of prev_hyps */
+  /* round 6 (bf16, d_k = 64; both or neither; NULL: the source attention reads mem_kv / mem_vT): the memory's K and V^T
+   * FRAGMENT-MAJOR - the 16 x 32 operand tiles of the source attention's MFMAs contiguous - written by em_search_init beside
+   * mem_kv / mem_vT: mem_kf act [layers][B][heads][Tpad/16][2][64][8], mem_vf act [layers][B][heads][4][Tpad/32][64][8]
+   * (B * d * Tpad elements per layer each), zero for frames >= T                                                              */
+  void *mem_kf, *mem_vf;
 } EmSearchBuffers;
 
 /*   Projects the encoder memory (enc_act [B][T][d_model] act) to per-layer K | V and V^T, computes

@@ -262,6 +262,36 @@ def test_search_batched_equals_single():
             assert abs(float(hs.score) - float(hb.score)) < 1e-3
 
 
+def test_search_fragment_major_memory_is_bit_identical(monkeypatch):
+    """Round 6: from 96 rows the label step's source attention reads the memory's K / V^T from FRAGMENT-MAJOR copies
+    (EmSearchBuffers.mem_kf / mem_vf, written by em_search_init; dec_pack_mem_frag_kernel) and linear_q from its fragment-major
+    copy - the same arithmetic in the same order as the row-major launch.  A ragged batch of 12 memories x beam 10 (120 rows,
+    lengths that are not multiples of 16 or 32, one of a single frame) must return the SAME hypotheses with the SAME scores,
+    bit for bit, with the buffers (default) and without them (ESPNET_AMD_NO_MEM_FRAG=1, read when the buffers are allocated)."""
+    g = load_golden("large_beam10_3s")
+    sd = golden_state_dict(g)
+    d = g["config"]["encoder_conf"]["output_size"]
+    torch.manual_seed(23)
+    lens = [74, 33, 17, 64, 1, 50, 47, 32, 15, 70, 9, 41]
+    enc = torch.randn(len(lens), max(lens), d) * 0.5
+    for b, n in enumerate(lens):
+        enc[b, n:] = 0.0
+    enc = enc.to(torch.bfloat16).cuda()
+    with_frag = build_search(g, sd, "bfloat16")
+    a = with_frag.search_batch(enc, lens)
+    assert any("mem_kf" in t for t in with_frag._bufs.values()), "the fragment-major memory was not allocated"
+    monkeypatch.setenv("ESPNET_AMD_NO_MEM_FRAG", "1")
+    without = build_search(g, sd, "bfloat16")
+    b_ = without.search_batch(enc, lens)
+    assert not any("mem_kf" in t for t in without._bufs.values())
+    for ha, hb in zip(a, b_):
+        assert len(ha) == len(hb) > 0
+        for x, y in zip(ha, hb):
+            assert x.yseq.tolist() == y.yseq.tolist()
+            assert float(x.score) == float(y.score)
+            assert {k: float(v) for k, v in x.scores.items()} == {k: float(v) for k, v in y.scores.items()}
+
+
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 def test_search_lanes_equal_searches_run_alone(dtype):
     """Round 6, SearchLanes: several joint searches in flight on as many HIP streams (each lane its own buffer set and
