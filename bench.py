@@ -27,7 +27,7 @@ HBM peak), `encoder_large_b64` (the Conformer-large encoder at configs[3]'s per-
 traffic of its dominant one), `encoder_ebranchformer_b32` (the E-Branchformer encoder with its roofline),
 `beam` (configs[2] with the roofline of the search and `bf16_vs_oracle`: per-token error, best-score loss beside the
 oracle search's own path noise, token edit distance), `beam_cfg3_per_gpu` (configs[3]'s per-GPU batch on one GPU,
-with `bf16_vs_oracle`; both beam legs with four joint searches in flight, a host thread each: `SearchLanes`) and `stream` (configs[4] + the 40 ms-per-call
+with `bf16_vs_oracle`; the beam legs with eight (configs[2]) and four (configs[3] per GPU) joint searches in flight, a host thread each: `SearchLanes`) and `stream` (configs[4] + the 40 ms-per-call
 stress case); `box_state` (three probes of the pool's slow state: a slow lease is labelled, not read as a regression).  `--quick`
 keeps only the main line, `roofline` and `cpu_baseline`.
 """
