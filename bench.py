@@ -526,7 +526,7 @@ class StepPipeline:
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
-        cand = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+        cand = [torch.cuda.Stream(device=dev) for _ in range(max(candidates, depth))]
         main = torch.cuda.current_stream()  # (the record ring is flushed there, behind the step streams: keep its queue apart too)
         one = min(wall([main]) for _ in range(3))
         chosen = []
